@@ -1,0 +1,155 @@
+/*
+ * necat_hip.h - C ABI of libnecat_hip.so, the MI355X (gfx950) implementation of NECAT's all-vs-all
+ * overlap stage (oc2pmov: k-mer index -> seeding / DDF vote / chain DP -> block-wise banded Myers
+ * extension -> candidate / M4 records).
+ *
+ * NECAT has no in-process plugin interface for this stage: the drop-in boundary is the
+ * oc2pmov process (argv + volume files in, one record file out), which necat_amd/csrc/oc2pmov_main.cpp
+ * reproduces on top of this ABI.  The entry points below mirror, at batch granularity, the three calls
+ * the reference's worker (pm_one_volume/pm_worker.c) makes into libontcns, so that a maintainer could
+ * also bind them directly:
+ *
+ *   necat_index_build      <- build_lookup_table      lookup_table/lookup_table.h:23-27, lookup_table.c:149
+ *   necat_find_candidates  <- find_candidates (+ the per-read sort/truncate of pm_search_one_volume)
+ *                                                     word_finder/word_finder.h:33-45, pm_worker.c:100-140,163-171
+ *   necat_extend           <- extend_candidates/onc_align
+ *                                                     pm_worker.c:29-83, gapped_align/oc_aligner.h:45-55
+ *   necat_volume_upload    <- pdb_load                common/packed_db.c:386 (the 2-bit pac + SequenceInfo)
+ *
+ * Conventions: plain C types only; every function returns 0 on success and a negative code on failure
+ * (necat_last_error() gives the text); output arrays are malloc'ed by the library and released with
+ * necat_free(); handles are opaque; one host thread per context.  There is no CPU fallback: every entry
+ * point fails with NECAT_ERR_DEVICE if no gfx950 device is usable.
+ */
+#ifndef NECAT_HIP_H
+#define NECAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NECAT_OK            0
+#define NECAT_ERR_ARG      (-1)
+#define NECAT_ERR_DEVICE   (-2)   /* no usable GPU / HIP runtime error */
+#define NECAT_ERR_MEMORY   (-3)
+#define NECAT_ERR_CAPACITY (-4)   /* an internal device buffer overflowed (reported, never silent) */
+#define NECAT_ERR_INTERNAL (-5)
+
+typedef struct necat_ctx necat_ctx;
+typedef struct necat_volume necat_volume;
+typedef struct necat_index necat_index;
+
+/* common/map_options.h:10-25 (same fields, same meaning) */
+typedef struct {
+    int    kmer_size;           /* -k */
+    int    scan_window;         /* -z */
+    int    kmer_cnt_cutoff;     /* -q */
+    int    block_size;          /* -b */
+    int    block_score_cutoff;  /* -s */
+    int    num_candidates;      /* -n */
+    int    align_size_cutoff;   /* -a */
+    double ddfs_cutoff;         /* -d (parsed, ignored by the reference: word_finder.c:10) */
+    double error;               /* -e */
+    int    num_output;          /* -m (unused by oc2pmov) */
+    int    num_threads;         /* -t */
+    int    job;                 /* -j 0 = candidates, 1 = align */
+    int    binary_output;       /* -u */
+    int    use_hdr_as_id;       /* -i */
+} necat_map_options;
+
+/* common/gapped_candidate.h:9-19 (GappedCandidate; idx fields are 64-bit unsigned there) */
+typedef struct {
+    int32_t  qid, sid, qdir, sdir, score;
+    int32_t  _pad;
+    uint64_t qbeg, qend, qsize;
+    uint64_t sbeg, send, ssize;
+    uint64_t qoff, soff;
+} necat_candidate;
+
+/* common/m4_record.h:10-25 (M4Record, 96 bytes, identical field order) */
+typedef struct {
+    int32_t  qid, qdir;
+    uint64_t qoff, qend, qext, qsize;
+    int32_t  sid, sdir;
+    uint64_t soff, send, sext, ssize;
+    double   ident_perc;
+    int32_t  vscore;
+    int32_t  _pad;
+} necat_m4;
+
+/* wall-clock (ms, HIP events) of the last call of each stage + work counters of the extension */
+typedef struct {
+    double   index_ms, seed_ms, extend_ms;
+    double   myers_ms;          /* sum over launches of the block Myers DP kernel */
+    double   traceback_ms;
+    uint64_t myers_launches;
+    uint64_t myers_blocks;      /* block alignments (Edlib_align equivalents) */
+    uint64_t myers_word_updates;/* 64-row word updates actually computed (SHW + NW) */
+    uint64_t myers_cells_bases; /* sum over blocks of query+target fragment bases */
+    uint64_t rounds;
+} necat_timings;
+
+void        necat_default_options(necat_map_options* o);            /* map_options.c:12-28 */
+int         necat_ctx_create(int device_id, necat_ctx** out);
+void        necat_ctx_destroy(necat_ctx* ctx);
+const char* necat_last_error(const necat_ctx* ctx);
+int         necat_device_name(const necat_ctx* ctx, char* buf, size_t n);
+
+/* pac: NECAT 2-bit bases (first base of a byte in its top two bits, ontcns_aux.h:118-119);
+ * seq_offset/seq_size: SequenceInfo.offset/.size (packed_db.h:12-18). Host buffers are not retained. */
+int  necat_volume_upload(necat_ctx* ctx, const uint8_t* pac, uint64_t nbases,
+                         const uint64_t* seq_offset, const uint64_t* seq_size, uint64_t nseq,
+                         necat_volume** out);
+void necat_volume_free(necat_ctx* ctx, necat_volume* v);
+
+/* Final LookupTable contents (lookup_table.h:6-21): kmer_stats[h] = cnt<<34 | start for k-mers with
+ * 1..max_occ occurrences (0 otherwise); offset_list = base offsets grouped by hash, ascending inside
+ * one hash. */
+int  necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, int max_occ,
+                       necat_index** out);
+int  necat_index_size(const necat_index* ix, uint64_t* table_entries, uint64_t* n_offsets);
+/* copy the index to host buffers (either may be NULL); used by parity tests */
+int  necat_index_download(necat_ctx* ctx, const necat_index* ix, uint64_t* kmer_stats, uint64_t* offset_list);
+void necat_index_free(necat_ctx* ctx, necat_index* ix);
+
+/* All reads of `reads` (both strands) against `ref`.  Output: per read, its candidates in exactly the
+ * order pm_search_one_volume would hand them on (job 0: discovery order FWD then REV, sorted by
+ * GappedCandidate_PmScoreGT and cut to num_candidates only when more than num_candidates; job 1:
+ * always sorted and cut), reads in ascending id; ids are GLOBAL (+= read_start_id / ref_start_id,
+ * pm_worker.c:165-166).  `pairwise` as in find_candidates (self-volume: only subjects before the
+ * query, word_finder.c:121-127). */
+int  necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref,
+                           const necat_volume* reads, int read_start_id, int ref_start_id,
+                           int pairwise, const necat_map_options* opt,
+                           necat_candidate** out, uint64_t* n_out);
+
+/* onc_align on every candidate (ids global, as produced above; block size kOcaBlockSize = 512,
+ * edlib_ex_aux.h:23), then the per-read containment filter of extend_candidates in candidate order
+ * (pm_worker.c:44, map_aux.c:4).  Output records carry global ids; REV query coordinates are flipped
+ * to forward-strand numbering (pm_worker.c:73-78). */
+int  necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* reads,
+                  int read_start_id, int ref_start_id,
+                  const necat_candidate* cands, uint64_t n, const necat_map_options* opt,
+                  int tail_match_len, necat_m4** out, uint64_t* n_out);
+
+/* Test / profiling hook for the dominant kernel: n independent Edlib_align calls
+ * (edlib_ex.c:733) on byte-coded (0..3) sequences.  seqs = concatenated fragments, q_off/t_off =
+ * start of each fragment in `seqs`.  Outputs per block: edit distance (-1 = fail), qend, tend, and
+ * the alignment as one op per column (0 match, 1 ins(query base vs gap), 2 del, 3 mismatch) in
+ * forward order, ops_off[i]..ops_off[i+1]. */
+int  necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_len,
+                             const uint64_t* q_off, const int32_t* q_len,
+                             const uint64_t* t_off, const int32_t* t_len, uint64_t n, double error,
+                             int32_t* dist, int32_t* qend, int32_t* tend,
+                             uint8_t** ops, uint64_t** ops_off);
+
+int  necat_get_timings(const necat_ctx* ctx, necat_timings* t);
+void necat_free(void* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NECAT_HIP_H */

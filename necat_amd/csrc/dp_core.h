@@ -1,0 +1,337 @@
+// dp_core.h - block-wise banded Myers bit-vector alignment (the Edlib_align equivalent,
+// gapped_align/edlib_ex.c:733): per-lane cores of the DP kernel (SHW distance pass + banded NW
+// pass that stores the P/M/score band for the traceback) and of the traceback kernel.
+//
+// One GPU lane owns one block alignment.  The column state (P, M, score of each 64-row word) lives
+// in registers: the word loop is fully unrolled over NW so every register index is static, the
+// per-lane band [fblk, lblk] becomes a predicate, and words no lane of the wave needs are skipped
+// with one wave-uniform ballot.  Query symbols are kept as two complemented bit-planes per word
+// (Eq is rebuilt with 3 logic ops instead of a 4 x NW peq table).  Band growth / shrink rules,
+// the k updates and the end-column choice follow the reference line by line, so distances, end
+// columns and tracebacks are bit-identical.
+#pragma once
+#include "dev_common.h"
+
+namespace necat {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NECAT_ANY(cond) (__ballot(cond) != 0ULL)
+#else
+#define NECAT_ANY(cond) (cond)
+#endif
+
+constexpr u64 kHighBit = 1ULL << 63;
+
+// edlib_ex.c:71-106 calculateBlock (Myers' Advance_Block)
+NECAT_HD int advance_block(u64 Pv, u64 Mv, u64 Eq, int hin, u64& PvOut, u64& MvOut)
+{
+    const u64 hinIsNeg = (u64)(hin >> 2) & 1ULL;
+    const u64 Xv = Eq | Mv;
+    Eq |= hinIsNeg;
+    const u64 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+    u64 Ph = Mv | ~(Xh | Pv);
+    u64 Mh = Pv & Xh;
+    int hout = (int)(Ph >> 63) - (int)(Mh >> 63);
+    Ph <<= 1; Mh <<= 1;
+    Mh |= hinIsNeg;
+    Ph |= (u64)((hin + 1) >> 1);
+    PvOut = Mh | ~(Xv | Ph);
+    MvOut = Ph & Xv;
+    return hout;
+}
+
+template <int NW>
+struct MyersRegs {
+    u64 P[NW], M[NW];
+    int S[NW];
+    u64 nlo[NW], nhi[NW];   // complemented query bit-planes (bit r = row 64*b + r)
+};
+
+struct MyersResult {
+    int dist;       // edit distance, -1 = no alignment within k
+    int endc;       // end_locations[0] (edlib_ex.c:770)
+    int err;        // non-zero: internal disagreement between the two passes
+    u32 words;      // word updates performed (SHW + NW), for the roofline report
+};
+
+// Functor contracts:
+//   Tgt::code(c)                      -> 2-bit target code of column c
+//   Mat::store(c, b, P, M, S)         -> band word of column c (NW pass)
+//   Mat::band(c, fblk, lblk)          -> first/last band word of column c
+template <int NW, bool FULL, class Tgt, class Mat>
+NECAT_HD MyersResult myers_block(MyersRegs<NW>& R, int qn, int tn, double error, Tgt& tgt, Mat& mat)
+{
+    MyersResult res; res.dist = -1; res.endc = -1; res.err = 0; res.words = 0;
+    const int nblk = FULL ? NW : (qn + 63) / 64;
+    const int W = FULL ? 0 : nblk * 64 - qn;
+    const u64 padmask = (FULL || W == 0) ? 0ULL : (~0ULL << ((64 - W) & 63));    // build_peq pad bits (edlib_ex.c:46)
+    int k = (int)((double)(qn < tn ? qn : tn) * error * 1.1);             // edlib_ex.c:751
+
+#define NECAT_EQ(b, ma, mb) (((R.nlo[b] ^ (ma)) & (R.nhi[b] ^ (mb))) | ((!FULL && (b) == nblk - 1) ? padmask : 0ULL))
+
+    // ------------------------------------------------------------------ SHW pass (edlib_ex.c:108-223)
+    int fblk = 0, lblk;
+    { int X = (k + 1 + 63) / 64; lblk = (X < nblk ? X : nblk) - 1; }
+#pragma unroll
+    for (int b = 0; b < NW; ++b) { R.S[b] = (b + 1) * 64; R.P[b] = ~0ULL; R.M[b] = 0ULL; }
+    int best = -1, end0 = -1;
+    bool alive = true;
+    for (int c = 0; c < tn && alive; ++c) {
+        const int tc = tgt.code(c);
+        const u64 ma = (tc & 1) ? ~0ULL : 0ULL, mb = (tc & 2) ? ~0ULL : 0ULL;
+        int hout = 1, lastS = 0, firstS = 0;
+        const int lblk0 = lblk;
+        bool grew = false;
+        res.words += (u32)(lblk - fblk + 1);
+#pragma unroll
+        for (int b = 0; b < NW; ++b) {
+            const bool act = (b >= fblk) & (b <= lblk0);
+            const bool edge = (b == lblk0 + 1) & (b < nblk);
+            if (NECAT_ANY(act | edge)) {
+                const u64 eq = NECAT_EQ(b, ma, mb);
+                if (act) {
+                    hout = advance_block(R.P[b], R.M[b], eq, hout, R.P[b], R.M[b]);
+                    R.S[b] += hout; lastS = R.S[b];
+                    if (b == fblk) firstS = R.S[b];
+                } else if (edge) {
+                    if (lastS - hout <= k && ((eq & 1ULL) || hout < 0)) {      // edlib_ex.c:150
+                        u64 p, m;
+                        const int nh = advance_block(~0ULL, 0ULL, eq, hout, p, m);
+                        R.P[b] = p; R.M[b] = m;
+                        R.S[b] = lastS - hout + 64 + nh;
+                        lastS = R.S[b]; lblk = b; grew = true; ++res.words;
+                    }
+                }
+            }
+        }
+        if (NECAT_ANY(!grew && lastS >= k + 64)) {
+            if (!grew) {
+#pragma unroll
+                for (int b = NW - 1; b >= 0; --b)
+                    if (b == lblk && lblk >= fblk && R.S[b] >= k + 64) --lblk;
+            }
+        }
+        if (NECAT_ANY(firstS >= k + 64)) {
+#pragma unroll
+            for (int b = 0; b < NW; ++b)
+                if (b == fblk && fblk <= lblk && R.S[b] >= k + 64) ++fblk;
+        }
+        if (lblk < fblk) { alive = false; break; }
+        if (lblk == nblk - 1) {
+            const int cs = lastS;
+            if (cs <= k && (best == -1 || cs <= best)) {
+                if (cs != best) { best = cs; k = best; end0 = c - W; }
+            }
+        }
+    }
+    if (alive && !FULL && W > 0 && lblk == nblk - 1) {
+        // edlib_ex.c:205-219: the last W true columns sit inside the last word
+        u64 P = 0, M = 0; int S = 0;
+#pragma unroll
+        for (int b = 0; b < NW; ++b) if (b == nblk - 1) { P = R.P[b]; M = R.M[b]; S = R.S[b]; }
+        int score = S;
+        for (int i = 0; i < W; ++i) {
+            // scores[i + 1]: after consuming bit (63 - i)
+            if (P & (kHighBit >> i)) --score;
+            if (M & (kHighBit >> i)) ++score;
+            if (score <= k && (best == -1 || score <= best)) {
+                if (score != best) { k = best = score; end0 = tn - W + i; }
+            }
+        }
+    }
+    if (best == -1) return res;
+
+    // ------------------------------------------------------------------ NW pass (edlib_ex.c:226-370)
+    const int d = best;
+    const int tn2 = end0 + 1;
+    k = d;
+    { int ad = tn2 - qn; if (ad < 0) ad = -ad; if (k < ad) { res.err = 1; return res; } }
+    { int mx = qn > tn2 ? qn : tn2; if (k > mx) k = mx; }
+    fblk = 0;
+    { int X = (k + qn - tn2) / 2; int Y = k < X ? k : X; int Z = (Y + 1 + 63) / 64; lblk = (nblk < Z ? nblk : Z) - 1; }
+#pragma unroll
+    for (int b = 0; b < NW; ++b) { R.S[b] = (b + 1) * 64; R.P[b] = ~0ULL; R.M[b] = 0ULL; }
+    alive = true;
+    for (int c = 0; c < tn2; ++c) {
+        const int tc = tgt.code(c);
+        const u64 ma = (tc & 1) ? ~0ULL : 0ULL, mb = (tc & 2) ? ~0ULL : 0ULL;
+        int hout = 1, lastS = 0, firstS = 0;
+        const int lblk0 = lblk;
+        bool kdone = false;
+        res.words += (u32)(lblk - fblk + 1);
+#pragma unroll
+        for (int b = 0; b < NW; ++b) {
+            const bool act = (b >= fblk) & (b <= lblk0);
+            const bool edge = (b == lblk0 + 1) & (b < nblk);
+            if (NECAT_ANY(act | edge)) {
+                const u64 eq = NECAT_EQ(b, ma, mb);
+                if (act) {
+                    hout = advance_block(R.P[b], R.M[b], eq, hout, R.P[b], R.M[b]);
+                    R.S[b] += hout; lastS = R.S[b];
+                    if (b == fblk) firstS = R.S[b];
+                } else if (edge) {
+                    // k update of edlib_ex.c:297-302 (lblk0 < nblk - 1 here, so no W term)
+                    { int X1 = tn2 - c - 1, X2 = qn - ((1 + lblk0) * 64 - 1) - 1; int Z = (X1 > X2 ? X1 : X2) + lastS; if (Z < k) k = Z; }
+                    kdone = true;
+                    const bool r = (lblk0 + 1) * 64 - 1 > k - lastS + 2 * 64 - 2 - tn2 + c + qn;   // edlib_ex.c:305
+                    if (!r) {
+                        u64 p, m;
+                        const int nh = advance_block(~0ULL, 0ULL, eq, hout, p, m);
+                        R.P[b] = p; R.M[b] = m;
+                        R.S[b] = lastS - hout + 64 + nh;
+                        lastS = R.S[b]; lblk = b; hout = nh; ++res.words;
+                    }
+                }
+            }
+        }
+        if (!kdone) {
+            int X1 = tn2 - c - 1, X2 = qn - ((1 + lblk0) * 64 - 1) - 1;
+            int Z = (X1 > X2 ? X1 : X2) + ((lblk0 == nblk - 1) ? W : 0) + lastS;
+            if (Z < k) k = Z;
+        }
+        {
+            const bool need = lastS >= k + 64 || ((lblk + 1) * 64 - 1 > k - lastS + 2 * 64 - 2 - tn2 + c + qn + 1);
+            if (NECAT_ANY(need)) {
+#pragma unroll
+                for (int b = NW - 1; b >= 0; --b)
+                    if (b == lblk && lblk >= fblk &&
+                        (R.S[b] >= k + 64 || ((b + 1) * 64 - 1 > k - R.S[b] + 2 * 64 - 2 - tn2 + c + qn + 1))) --lblk;
+            }
+        }
+        {
+            const bool need = firstS >= k + 64 || ((fblk + 1) * 64 - 1 < firstS - k - tn2 + qn + c);
+            if (NECAT_ANY(need)) {
+#pragma unroll
+                for (int b = 0; b < NW; ++b)
+                    if (b == fblk && fblk <= lblk &&
+                        (R.S[b] >= k + 64 || ((b + 1) * 64 - 1 < R.S[b] - k - tn2 + qn + c))) ++fblk;
+            }
+        }
+        if (lblk < fblk) { alive = false; break; }
+#pragma unroll
+        for (int b = 0; b < NW; ++b) {
+            const bool in = (b >= fblk) & (b <= lblk);
+            if (NECAT_ANY(in)) { if (in) mat.store(c, b, R.P[b], R.M[b], R.S[b]); }
+        }
+        mat.band(c, fblk, lblk);
+    }
+    int d2 = -1;
+    if (alive && lblk == nblk - 1) {
+        u64 P = 0, M = 0; int S = 0;
+#pragma unroll
+        for (int b = 0; b < NW; ++b) if (b == nblk - 1) { P = R.P[b]; M = R.M[b]; S = R.S[b]; }
+        int cs = S;
+        if (W > 0) cs = S - popc64(P >> ((64 - W) & 63)) + popc64(M >> ((64 - W) & 63));   // calc_block_cell_scores()[W]
+        if (cs <= k) d2 = cs;
+    }
+    if (d2 != d) { res.err = 2; return res; }     // edlib_ex.c:779-780 asserts the same
+    res.dist = d; res.endc = end0;
+#undef NECAT_EQ
+    return res;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Traceback (edlib_ex.c:383-621, obtainAlignmentTraceback): move priority up > left > diagonal.
+//   Mat::P(c,b) / M(c,b) / S(c,b) / first(c) / last(c)   read the stored band
+//   Ops::push(op)                                         receives ops in END -> START order
+// Op codes: 0 match, 1 insert (consumes a query base), 2 delete (consumes a target base),
+// 3 mismatch (edlib_ex.c:10-13).
+// ---------------------------------------------------------------------------------------------
+template <class Mat, class Ops>
+NECAT_HD void traceback_block(int qn, int tn, int bestScore, Mat& mat, Ops& ops)
+{
+    const int nblk = (qn + 63) / 64, W = nblk * 64 - qn;
+    int c = tn - 1, b = nblk - 1;
+    int cur = bestScore, lS = -1, uS = -1, ulS = -1;
+    u64 curP = mat.P(c, b), curM = mat.M(c, b);
+    bool left = c > 0 && b >= mat.first(c - 1) && b <= mat.last(c - 1);
+    u64 lP = 0, lM = 0;
+    if (left) { lP = mat.P(c - 1, b); lM = mat.M(c - 1, b); }
+    curP <<= W; curM <<= W;
+    int pos = 64 - W - 1;
+    for (;;) {
+        if (c == 0) { left = true; lS = b * 64 + pos + 1; ulS = lS - 1; }
+        if (lS == -1 && left) {
+            lS = mat.S(c - 1, b);
+            const int n = 64 - pos - 1;          // the reference walks n bits from the top
+            if (n > 0) {
+                lS += popc64(lM >> (64 - n)) - popc64(lP >> (64 - n));
+                lP <<= n; lM <<= n;
+            }
+        }
+        if (ulS == -1) {
+            if (lS != -1) {
+                ulS = lS;
+                if (lP & kHighBit) ulS--;
+                if (lM & kHighBit) ulS++;
+            } else if (c > 0 && b - 1 >= mat.first(c - 1) && b - 1 <= mat.last(c - 1)) {
+                ulS = mat.S(c - 1, b - 1);
+            }
+        }
+        if (uS == -1) {
+            uS = cur;
+            if (curP & kHighBit) uS--;
+            if (curM & kHighBit) uS++;
+            curP <<= 1; curM <<= 1;
+        }
+        if (uS != -1 && uS + 1 == cur) {
+            cur = uS; lS = ulS; uS = ulS = -1;
+            if (pos == 0) {
+                if (b == 0) {
+                    ops.push(1);
+                    for (int i = 0; i < c + 1; ++i) ops.push(2);
+                    break;
+                } else {
+                    pos = 63; b--;
+                    curP = mat.P(c, b); curM = mat.M(c, b);
+                    if (c > 0 && b >= mat.first(c - 1) && b <= mat.last(c - 1)) { left = true; lP = mat.P(c - 1, b); lM = mat.M(c - 1, b); }
+                    else left = false;
+                }
+            } else { pos--; lP <<= 1; lM <<= 1; }
+            ops.push(1);
+        } else if (lS != -1 && lS + 1 == cur) {
+            cur = lS; uS = ulS; lS = ulS = -1;
+            c--;
+            if (c == -1) {
+                ops.push(2);
+                const int numUp = b * 64 + pos + 1;
+                for (int i = 0; i < numUp; ++i) ops.push(1);
+                break;
+            }
+            curP = lP; curM = lM;
+            if (c > 0 && b >= mat.first(c - 1) && b <= mat.last(c - 1)) { left = true; lP = mat.P(c - 1, b); lM = mat.M(c - 1, b); }
+            else if (c == 0) { left = true; lS = b * 64 + pos + 1; ulS = lS - 1; }
+            else left = false;
+            ops.push(2);
+        } else if (ulS != -1) {
+            const int mv = ulS == cur ? 0 : 3;
+            cur = ulS; uS = lS = ulS = -1;
+            c--;
+            if (c == -1) {
+                ops.push(mv);
+                const int numUp = b * 64 + pos;
+                for (int i = 0; i < numUp; ++i) ops.push(1);
+                break;
+            }
+            if (pos == 0) {
+                if (b == 0) {
+                    ops.push(mv);
+                    for (int i = 0; i < c + 1; ++i) ops.push(2);
+                    break;
+                }
+                pos = 63; b--;
+                curP = mat.P(c, b); curM = mat.M(c, b);
+            } else {
+                pos--;
+                curP = lP; curM = lM;
+                curP <<= 1; curM <<= 1;
+            }
+            if (c > 0 && b >= mat.first(c - 1) && b <= mat.last(c - 1)) { left = true; lP = mat.P(c - 1, b); lM = mat.M(c - 1, b); }
+            else if (c == 0) { left = true; lS = b * 64 + pos + 1; ulS = lS - 1; }
+            else left = false;
+            ops.push(mv);
+        } else break;
+    }
+}
+
+}  // namespace necat

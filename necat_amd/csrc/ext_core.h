@@ -1,0 +1,185 @@
+// ext_core.h - the block-stitching driver of onc_align (gapped_align/oc_aligner.c:303) restated as a
+// per-candidate state machine that advances one 512-bp block per round:
+//
+//   plan  (ext_plan)         = get_next_sequence_block (oc_aligner.c:111-155) + the glue between the
+//                              left and the right extension (oc_aligner.c:340-417)
+//   DP + traceback           = Edlib_align (dp_core.h)
+//   finish (ext_finish_block)= the tail trimming of oca_extend (oc_aligner.c:216-262)
+//
+// The reference materialises gapped strings and re-scans them; a candidate here only carries running
+// column / base / match counters of its alignment stream (what M4 needs: coordinates + identity), so
+// no strings ever leave the GPU.
+#pragma once
+#include "dev_common.h"
+
+namespace necat {
+
+struct ExtTask {
+    // constants
+    i32 cand;            // candidate index
+    i32 qdir;
+    i64 q_g0, s_g0;      // global base offsets of the query read (reads volume) / subject read (ref volume)
+    i32 qlen, slen;
+    // anchor + progress
+    i32 QS, TS;          // current anchor (moved by the left extension, oc_aligner.c:356-357, :398-399)
+    i32 phase;           // 0 = left extension, 1 = right extension, 2 = done
+    i32 ext_done;        // current extension finished (a block set `done`)
+    i32 ext_q, ext_t;    // sizes of the current extension (query_size/target_size of oca_extend)
+    i32 qidx, tidx;
+    // current block
+    i32 qblk, tblk, last;
+    // alignment-stream statistics of the current extension, in stream order
+    i32 m_run, found;                        // running match count / first run of 8 seen
+    i32 pre_cols, pre_q, pre_t, pre_mat;     // totals at the column closing that first run
+    i32 tot_cols, tot_q, tot_t, tot_mat;
+    // kept part of the left extension
+    i32 l_cols, l_q, l_t, l_mat;
+    // final result (oc_aligner.c:419-450)
+    i32 r_qoff, r_qend, r_toff, r_tend, r_cols, r_mat;
+    i32 _pad;
+};
+
+NECAT_HD void ext_reset_stream(ExtTask& t)
+{
+    t.m_run = 0; t.found = 0;
+    t.pre_cols = t.pre_q = t.pre_t = t.pre_mat = 0;
+    t.tot_cols = t.tot_q = t.tot_t = t.tot_mat = 0;
+    t.qidx = t.tidx = 0; t.ext_done = 0;
+}
+
+NECAT_HD void ext_init(ExtTask& t, i32 cand, i32 qdir, i64 q_g0, i32 qlen, i64 s_g0, i32 slen, i32 qoff, i32 soff)
+{
+    t.cand = cand; t.qdir = qdir; t.q_g0 = q_g0; t.s_g0 = s_g0; t.qlen = qlen; t.slen = slen;
+    t.QS = qoff; t.TS = soff; t.phase = 0;
+    t.ext_q = qoff; t.ext_t = soff;           // left: oca_extend(query + QS - 1, QS, target + TS - 1, TS, ...)
+    ext_reset_stream(t);
+    t.qblk = t.tblk = t.last = 0;
+    t.l_cols = t.l_q = t.l_t = t.l_mat = 0;
+    t.r_qoff = t.r_qend = t.r_toff = t.r_tend = t.r_cols = t.r_mat = 0;
+    t._pad = 0;
+}
+
+// one alignment column in stream order
+NECAT_HD void ext_stream_col(ExtTask& t, bool is_match, bool has_q, bool has_t)
+{
+    t.tot_cols += 1; t.tot_q += has_q; t.tot_t += has_t; t.tot_mat += is_match;
+    if (!t.found) {
+        t.m_run = is_match ? t.m_run + 1 : 0;
+        if (t.m_run == kOcaMatCnt) {
+            t.found = 1;
+            t.pre_cols = t.tot_cols; t.pre_q = t.tot_q; t.pre_t = t.tot_t; t.pre_mat = t.tot_mat;
+        }
+    }
+}
+
+// Decide the next block of the task, or finish it.  Returns true when a block (t.qblk x t.tblk) is
+// scheduled; false when the task is done (results in t.r_*).
+NECAT_HD bool ext_plan(ExtTask& t)
+{
+    for (;;) {
+        if (t.phase == 2) return false;
+        if (!t.ext_done) {
+            // get_next_sequence_block (oc_aligner.c:111-155)
+            const int qleft = t.ext_q - t.qidx, tleft = t.ext_t - t.tidx;
+            int qblk, tblk, last;
+            if (qleft < kOcaBlockSize + 100 || tleft < kOcaBlockSize + 100) {
+                qblk = (int)((double)tleft * 1.3); if (qleft < qblk) qblk = qleft;
+                tblk = (int)((double)qleft * 1.3); if (tleft < tblk) tblk = tleft;
+                last = 1;
+            } else { qblk = kOcaBlockSize; tblk = kOcaBlockSize; last = 0; }
+            if (qblk != 0 && tblk != 0) { t.qblk = qblk; t.tblk = tblk; t.last = last; return true; }
+        }
+        // the current extension is over
+        if (t.phase == 0) {
+            // oc_aligner.c:340-367: keep the left alignment only beyond its first run of 8 matches
+            if (t.found) {
+                t.QS -= t.pre_q; t.TS -= t.pre_t;
+                t.l_cols = t.tot_cols - t.pre_cols; t.l_q = t.tot_q - t.pre_q;
+                t.l_t = t.tot_t - t.pre_t; t.l_mat = t.tot_mat - t.pre_mat;
+            }
+            t.phase = 1;
+            t.ext_q = t.qlen - t.QS; t.ext_t = t.slen - t.TS;   // oca_extend(query + QS, query_size - QS, ...)
+            ext_reset_stream(t);
+        } else {
+            int f_cols = 0, f_q = 0, f_t = 0, f_mat = 0;
+            if (t.l_cols == 0) {
+                // oc_aligner.c:386-416: no left part -> start the right alignment at its first run of 8
+                if (t.found) {
+                    t.QS += t.pre_q - kOcaMatCnt; t.TS += t.pre_t - kOcaMatCnt;
+                    f_cols = t.tot_cols - (t.pre_cols - kOcaMatCnt);
+                    f_q = t.tot_q - (t.pre_q - kOcaMatCnt);
+                    f_t = t.tot_t - (t.pre_t - kOcaMatCnt);
+                    f_mat = t.tot_mat - (t.pre_mat - kOcaMatCnt);
+                }
+            } else { f_cols = t.tot_cols; f_q = t.tot_q; f_t = t.tot_t; f_mat = t.tot_mat; }
+            t.r_qoff = t.QS - t.l_q; t.r_qend = t.QS + f_q;
+            t.r_toff = t.TS - t.l_t; t.r_tend = t.TS + f_t;
+            t.r_cols = t.l_cols + f_cols; t.r_mat = t.l_mat + f_mat;
+            t.phase = 2;
+            return false;
+        }
+    }
+}
+
+// Fragment geometry of the scheduled block: element i of the query fragment is base
+// (q_base + q_dir * i) of the reads volume (complemented when q_comp), same for the target.
+struct FragGeom { i64 q_base; int q_dir, q_comp; i64 t_base; int t_dir; };
+
+NECAT_HD FragGeom ext_frag_geom(const ExtTask& t)
+{
+    FragGeom g;
+    // strand position p of the query: left  p = QS - 1 - qidx - i ; right p = QS + qidx + i
+    // FWD read: g = q_g0 + p ; REV read: g = q_g0 + qlen - 1 - p with complement (packed_db.c:268-274)
+    const bool right = t.phase == 1;
+    const i64 p0 = right ? (i64)t.QS + t.qidx : (i64)t.QS - 1 - t.qidx;
+    if (t.qdir == 0) { g.q_base = t.q_g0 + p0; g.q_dir = right ? +1 : -1; g.q_comp = 0; }
+    else { g.q_base = t.q_g0 + t.qlen - 1 - p0; g.q_dir = right ? -1 : +1; g.q_comp = 1; }
+    const i64 s0 = right ? (i64)t.TS + t.tidx : (i64)t.TS - 1 - t.tidx;
+    g.t_base = t.s_g0 + s0; g.t_dir = right ? +1 : -1;
+    return g;
+}
+
+// Tail trimming + stream update after the block's alignment (oc_aligner.c:216-262).
+//   dist < 0  : Edlib_align failed (empty alignment)
+//   rops(j)   : op j of the alignment in END -> START order, n_ops of them
+//   same(i)   : query fragment element i == target fragment element i (exact-prefix fallback)
+template <class ROps, class Same>
+NECAT_HD void ext_finish_block(ExtTask& t, int dist, int endc, int n_ops, int tail_match_len, ROps& rops, Same& same)
+{
+    const int qn = t.qblk, tn = t.tblk;
+    const int qfae = dist >= 0 ? qn : 0, tfae = dist >= 0 ? endc + 1 : 0;   // the alignment is global in the query
+    int done = t.last;
+    if (qn - qfae > 30 && tn - tfae > 30) done = 1;
+    const int M = done ? tail_match_len : kOcaMatCnt;
+    const int n = dist >= 0 ? n_ops : 0;
+    int acnt = 0, qcnt = 0, tcnt = 0, m = 0, j = 0;
+    while (j < n) {
+        const int op = rops(j);
+        if (op != 2) ++qcnt;
+        if (op != 1) ++tcnt;
+        if (op == 0) ++m; else m = 0;
+        ++acnt;
+        if (m == M) break;
+        ++j;
+    }
+    const int kfirst = n - 1 - j;       // forward index where the scan stopped (k in the reference)
+    if (m != M || kfirst < 1) {
+        // exact-match prefix of the raw fragments, then stop (oc_aligner.c:243-254)
+        const int lim = qn < tn ? qn : tn;
+        for (int i = 0; i < lim; ++i) {
+            if (!same(i)) break;
+            ext_stream_col(t, true, true, true);
+        }
+        done = 1;
+    } else {
+        t.qidx += qfae - qcnt; t.tidx += tfae - tcnt;
+        const int lo = done ? acnt - M : acnt;    // on the final block the M matching columns are kept (:258)
+        for (int jj = n - 1; jj >= lo; --jj) {
+            const int op = rops(jj);
+            ext_stream_col(t, op == 0, op != 2, op != 1);
+        }
+    }
+    t.ext_done = done;
+}
+
+}  // namespace necat

@@ -1,0 +1,283 @@
+// ext_kernels.h - __global__ shells of the extension stage (onc_align for 10^5..10^6 candidates at once).
+//
+// Every candidate is a small state machine (ext_core.h) that needs one block alignment per round;
+// a round is four launches over the still-active candidates:
+//
+//   k_ext_plan      decide each candidate's next block (or finish it); full 512 x 512 blocks go to
+//                   list A, the variable-size last blocks of an extension (<= 794 x 794) to list B
+//   k_ext_frag      gather the two fragments of every block from the 2-bit volumes: query as two
+//                   complemented bit-planes per 64 rows, target 2-bit packed; written lane-interleaved
+//                   so the DP kernel's loads are fully coalesced
+//   k_myers<NW>     THE hot kernel: one lane = one block alignment, SHW pass + banded NW pass
+//                   (dp_core.h); 64 alignments of similar shape advance in lock-step per wave; the NW
+//                   band (P,M as one 16-byte pair + i16 score) is stored [column][word][lane], i.e.
+//                   every store instruction writes one contiguous 1 KiB line per wave
+//   k_traceback     walk the stored band back (up > left > diagonal), trim the block tail at the last
+//                   run of 8 matches and fold the kept columns into the candidate's running counters
+//
+// Groups of 64 work items share one slab of the matrix pool; list A slabs (512 cols x 8 words) come
+// first, list B slabs (794 x 13) after them.
+#pragma once
+#include "dp_core.h"
+#include "ext_core.h"
+
+namespace necat {
+
+constexpr int kColsA = 512, kWordsA = 8, kTWordsA = 16, kOpsA = 1024;
+constexpr int kColsB = kMaxFragLen, kWordsB = kMaxWords, kTWordsB = kMaxTWords, kOpsB = 1600;
+constexpr int kFragWordsA = 2 * kWordsA + kTWordsA;   // 32 u64 per item
+constexpr int kFragWordsB = 2 * kWordsB + kTWordsB;   // 51 u64 per item
+
+// bytes of one 64-item slab
+constexpr size_t kPmBytesA = (size_t)kColsA * kWordsA * 64 * 16, kScBytesA = (size_t)kColsA * kWordsA * 64 * 2, kBandBytesA = (size_t)kColsA * 64 * 2;
+constexpr size_t kPmBytesB = (size_t)kColsB * kWordsB * 64 * 16, kScBytesB = (size_t)kColsB * kWordsB * 64 * 2, kBandBytesB = (size_t)kColsB * 64 * 2;
+constexpr size_t kSlabA = kPmBytesA + kScBytesA + kBandBytesA;
+constexpr size_t kSlabB = kPmBytesB + kScBytesB + kBandBytesB;
+
+struct BlockItem {       // one scheduled block alignment
+    FragGeom g;
+    i32 task;            // owning ExtTask (-1 for the stand-alone batch API)
+    i16 qn, tn;
+};
+
+struct BlockResult { i32 dist, endc, err; u32 words; };
+
+struct ExtLists {
+    u32* count;          // [0] = nA, [1] = nB  (this round)
+    BlockItem* itemsA; BlockItem* itemsB;
+};
+
+__global__ void __launch_bounds__(256)
+k_ext_init(const necat_candidate* __restrict__ cands, u32 n, u32 cand_base, int read_start_id, int ref_start_id,
+           const u64* __restrict__ reads_off, const u64* __restrict__ ref_off, ExtTask* __restrict__ tasks, u32* __restrict__ active)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const necat_candidate c = cands[i];
+    const int lq = c.qid - read_start_id, ls = c.sid - ref_start_id;
+    ExtTask t;
+    ext_init(t, (i32)(cand_base + i), c.qdir, (i64)reads_off[lq], (i32)c.qsize, (i64)ref_off[ls], (i32)c.ssize, (i32)c.qoff, (i32)c.soff);
+    tasks[i] = t;
+    active[i] = i;
+}
+
+__global__ void __launch_bounds__(256)
+k_ext_plan(ExtTask* __restrict__ tasks, const u32* __restrict__ active, u32 n_active, ExtLists L, u32* __restrict__ next_active_unused)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_active) return;
+    const u32 ti = active[i];
+    ExtTask t = tasks[ti];
+    const bool go = ext_plan(t);
+    tasks[ti] = t;
+    if (!go) return;
+    BlockItem it;
+    it.g = ext_frag_geom(t); it.task = (i32)ti; it.qn = (i16)t.qblk; it.tn = (i16)t.tblk;
+    if (!t.last && t.qblk == kOcaBlockSize && t.tblk == kOcaBlockSize) L.itemsA[atomicAdd(&L.count[0], 1u)] = it;
+    else L.itemsB[atomicAdd(&L.count[1], 1u)] = it;
+}
+
+// next round's active list = this round's items (A then B)
+__global__ void __launch_bounds__(256)
+k_ext_collect(const BlockItem* __restrict__ itemsA, u32 nA, const BlockItem* __restrict__ itemsB, u32 nB, u32* __restrict__ active)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nA) active[i] = (u32)itemsA[i].task;
+    else if (i < nA + nB) active[i] = (u32)itemsB[i - nA].task;
+}
+
+// frag layout per 64-item group g: word w of lane l at frag[(g * FW + w) * 64 + l];
+// words [0,NW) = ~lo planes, [NW,2NW) = ~hi planes, [2NW, 2NW+TW) = target 2-bit words
+template <int NW, int TW>
+__global__ void __launch_bounds__(256)
+k_ext_frag(DevVolume reads, DevVolume ref, const BlockItem* __restrict__ items, u32 n, u64* __restrict__ frag)
+{
+    constexpr int FW = 2 * NW + TW, CH = NW + TW;
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 grp = gid / (64 * CH);
+    const u32 r = (u32)(gid % (64 * CH));
+    const int ch = (int)(r >> 6), lane = (int)(r & 63);
+    const u64 item = grp * 64 + lane;
+    if (item >= n) return;
+    const BlockItem it = items[item];
+    u64* dst = frag + grp * FW * 64 + lane;
+    if (ch < NW) {
+        if (ch * 64 < it.qn) {
+            u64 lo, hi;
+            load64_planes(reads.bases, it.g.q_base, it.g.q_dir, it.g.q_comp, ch * 64, &lo, &hi);
+            dst[(u64)ch * 64] = ~lo; dst[(u64)(NW + ch) * 64] = ~hi;
+        }
+    } else {
+        const int tw = ch - NW;
+        if (tw * 32 < it.tn)
+            dst[(u64)(2 * NW + tw) * 64] = load32_dir(ref.bases, it.g.t_base + (i64)it.g.t_dir * (tw * 32), it.g.t_dir, 0);
+    }
+}
+
+template <int NW>
+struct TgtReader {
+    const u64* w; u64 cur;
+    NECAT_D int code(int c)
+    {
+        if ((c & 31) == 0) cur = w[(u64)(c >> 5) * 64];
+        return (int)((cur >> ((c & 31) * 2)) & 3);
+    }
+};
+
+template <int NW>
+struct MatWriter {
+    ulonglong2* pm; i16* sc; u16* bnd;   // already offset to this lane
+    NECAT_D void store(int c, int b, u64 P, u64 M, int S)
+    {
+        const size_t idx = ((size_t)c * NW + b) * 64;
+        pm[idx] = make_ulonglong2(P, M); sc[idx] = (i16)S;
+    }
+    NECAT_D void band(int c, int f, int l) { bnd[(size_t)c * 64] = (u16)(f | (l << 8)); }
+};
+
+template <int NW>
+struct MatReader {
+    const ulonglong2* pm; const i16* sc; const u16* bnd;
+    NECAT_D u64 P(int c, int b) const { return pm[((size_t)c * NW + b) * 64].x; }
+    NECAT_D u64 M(int c, int b) const { return pm[((size_t)c * NW + b) * 64].y; }
+    NECAT_D int S(int c, int b) const { return sc[((size_t)c * NW + b) * 64]; }
+    NECAT_D int first(int c) const { return bnd[(size_t)c * 64] & 0xff; }
+    NECAT_D int last(int c) const { return bnd[(size_t)c * 64] >> 8; }
+};
+
+template <int NW, int COLS>
+NECAT_D void slab_pointers(char* slab, int lane, ulonglong2*& pm, i16*& sc, u16*& band)
+{
+    pm = reinterpret_cast<ulonglong2*>(slab) + lane;
+    sc = reinterpret_cast<i16*>(slab + (size_t)COLS * NW * 64 * 16) + lane;
+    band = reinterpret_cast<u16*>(slab + (size_t)COLS * NW * 64 * 18) + lane;
+}
+
+// The hot kernel.  One wave = 64 block alignments in lock-step.  No LDS: the whole column state is
+// register resident (dp_core.h) and the only memory traffic is the coalesced band store.
+template <int NW, int TW, int COLS, bool FULL>
+__global__ void __launch_bounds__(64)
+k_myers(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
+        double error, BlockResult* __restrict__ results)
+{
+    constexpr int FW = 2 * NW + TW;
+    const u32 grp = blockIdx.x;
+    const int lane = threadIdx.x;
+    const u64 item = (u64)grp * 64 + lane;
+    if (item >= n) return;
+    const int qn = FULL ? kOcaBlockSize : items[item].qn;
+    const int tn = FULL ? kOcaBlockSize : items[item].tn;
+    const u64* fr = frag + (u64)grp * FW * 64 + lane;
+    MyersRegs<NW> R;
+    const int nblk = (qn + 63) >> 6;
+#pragma unroll
+    for (int b = 0; b < NW; ++b) {
+        const bool have = FULL || b < nblk;
+        R.nlo[b] = have ? fr[(u64)b * 64] : 0ULL;
+        R.nhi[b] = have ? fr[(u64)(NW + b) * 64] : 0ULL;
+    }
+    TgtReader<NW> tg; tg.w = fr + (u64)2 * NW * 64; tg.cur = 0;
+    MatWriter<NW> mw;
+    slab_pointers<NW, COLS>(slabs + (size_t)grp * slab_bytes, lane, mw.pm, mw.sc, mw.bnd);
+    const MyersResult r = myers_block<NW, FULL>(R, qn, tn, error, tg, mw);
+    BlockResult br; br.dist = r.dist; br.endc = r.endc; br.err = r.err; br.words = r.words;
+    results[item] = br;
+}
+
+struct OpsWriter {
+    u8* ops; int n; int cap; int overflow;
+    NECAT_D void push(int op) { if (n < cap) ops[(size_t)n * 64] = (u8)op; else overflow = 1; ++n; }
+};
+struct OpsReader {
+    const u8* ops;
+    NECAT_D int operator()(int j) const { return ops[(size_t)j * 64]; }
+};
+template <int NW>
+struct SameReader {   // query fragment element i == target fragment element i ?
+    const u64* fr;
+    NECAT_D bool operator()(int i) const
+    {
+        const u64 nlo = fr[(u64)(i >> 6) * 64], nhi = fr[(u64)(NW + (i >> 6)) * 64];
+        const int q = (int)((~nlo >> (i & 63)) & 1) | ((int)((~nhi >> (i & 63)) & 1) << 1);
+        const u64 tw = fr[(u64)(2 * NW + (i >> 5)) * 64];
+        return q == (int)((tw >> ((i & 31) * 2)) & 3);
+    }
+};
+
+// EXPORT = false: fold the block into its ExtTask.  EXPORT = true (batch API): keep the ops.
+template <int NW, int TW, int COLS, int MAXOPS, bool EXPORT>
+__global__ void __launch_bounds__(64)
+k_traceback(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag, const char* __restrict__ slabs, size_t slab_bytes,
+            const BlockResult* __restrict__ results, u8* __restrict__ ops_pool, ExtTask* __restrict__ tasks, int tail_match_len,
+            i32* __restrict__ n_ops_out, int* __restrict__ err_flag)
+{
+    constexpr int FW = 2 * NW + TW;
+    const u32 grp = blockIdx.x;
+    const int lane = threadIdx.x;
+    const u64 item = (u64)grp * 64 + lane;
+    if (item >= n) return;
+    const BlockItem it = items[item];
+    const BlockResult br = results[item];
+    if (br.err) atomicExch(err_flag, 10 + br.err);
+    OpsWriter ow; ow.ops = ops_pool + (size_t)grp * MAXOPS * 64 + lane; ow.n = 0; ow.cap = MAXOPS; ow.overflow = 0;
+    if (br.dist >= 0) {
+        MatReader<NW> mr;
+        ulonglong2* pm; i16* sc; u16* band;
+        slab_pointers<NW, COLS>(const_cast<char*>(slabs) + (size_t)grp * slab_bytes, lane, pm, sc, band);
+        mr.pm = pm; mr.sc = sc; mr.bnd = band;
+        traceback_block(it.qn, br.endc + 1, br.dist, mr, ow);
+        if (ow.overflow) atomicExch(err_flag, 20);
+    }
+    if (EXPORT) { n_ops_out[item] = ow.n; return; }
+    OpsReader rd; rd.ops = ow.ops;
+    SameReader<NW> same; same.fr = frag + (u64)grp * FW * 64 + lane;
+    ExtTask t = tasks[it.task];
+    ext_finish_block(t, br.dist, br.endc, ow.n, tail_match_len, rd, same);
+    tasks[it.task] = t;
+}
+
+// ---- final records: pm_worker.c:56-80 (M4 fields), oc_aligner.c:419-450 (coordinates, identity) ----
+__global__ void __launch_bounds__(256)
+k_ext_result(const ExtTask* __restrict__ tasks, u32 n, const necat_candidate* __restrict__ cands, u32 cand_base,
+             int min_align, necat_m4* __restrict__ m4, u8* __restrict__ ok)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ExtTask t = tasks[i];
+    const necat_candidate c = cands[i];
+    necat_m4 m;
+    m.qid = c.qid; m.qdir = c.qdir; m.qoff = (u64)t.r_qoff; m.qend = (u64)t.r_qend; m.qext = c.qoff; m.qsize = c.qsize;
+    m.sid = c.sid; m.sdir = 0; m.soff = (u64)t.r_toff; m.send = (u64)t.r_tend; m.sext = c.soff; m.ssize = c.ssize;
+    m.ident_perc = t.r_cols ? 100.0 * (double)t.r_mat / (double)t.r_cols : 0.0;
+    m.vscore = c.score; m._pad = 0;
+    if (m.qdir == 1) { const u64 qo = m.qsize - m.qend, qe = m.qsize - m.qoff; m.qoff = qo; m.qend = qe; }
+    m4[cand_base + i] = m;
+    ok[cand_base + i] = t.r_cols >= min_align ? 1 : 0;
+}
+
+// extend_candidates' containment rule (pm_worker.c:44, map_aux.c:4-20), one lane per query read:
+// a candidate whose anchor lies inside an already ACCEPTED record of the same (qdir, sid) is dropped.
+// Aligning every candidate first and filtering afterwards is equivalent because acceptance of a
+// candidate depends only on its own alignment.
+__global__ void __launch_bounds__(64)
+k_m4_filter(const necat_candidate* __restrict__ cands, const u64* __restrict__ group_off, u32 n_groups,
+            const necat_m4* __restrict__ m4, u8* __restrict__ ok, necat_m4* __restrict__ out, u32* __restrict__ out_count)
+{
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const u64 lo = group_off[g], hi = group_off[g + 1];
+    for (u64 i = lo; i < hi; ++i) {
+        const necat_candidate c = cands[i];
+        bool contained = false;
+        for (u64 j = lo; j < i && !contained; ++j) {
+            if (ok[j] != 2) continue;
+            const necat_m4& m = m4[j];
+            contained = c.qdir == m.qdir && c.sid == m.sid && c.qoff >= m.qoff && c.qoff <= m.qend &&
+                        c.soff >= m.soff && c.soff <= m.send;
+        }
+        if (!contained && ok[i] == 1) { ok[i] = 2; out[atomicAdd(out_count, 1u)] = m4[i]; }
+        else ok[i] = 0;
+    }
+}
+
+}  // namespace necat

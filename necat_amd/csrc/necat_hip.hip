@@ -1,0 +1,661 @@
+// necat_hip.hip - libnecat_hip.so: C ABI (include/necat_hip.h) + host orchestration of the gfx950
+// kernels.  Written for MI355X only (wave64, 256 CUs, 288 GB HBM3E): buffers are sized for HBM
+// residency of whole volumes, work lists and the traceback band of 10^5 concurrent alignments.
+#include <algorithm>
+#include <numeric>
+
+#include "runtime.h"
+#include "index_kernels.h"
+#include "seed_kernels.h"
+#include "ext_kernels.h"
+
+using namespace necat;
+
+namespace {
+
+inline unsigned grid_for(uint64_t n, unsigned block, unsigned cap = 1u << 20)
+{
+    uint64_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+DevVolume dev_view(const necat_volume* v)
+{
+    DevVolume d; d.bases = v->bases; d.seq_off = v->seq_off; d.nbases = v->nbases; d.nseq = v->nseq;
+    return d;
+}
+
+double ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0; return ms; }
+
+}  // namespace
+
+extern "C" {
+
+void necat_default_options(necat_map_options* o)
+{   // map_options.c:12-28 (sDefaultPairwiseMapingOptions)
+    o->kmer_size = 15; o->scan_window = 10; o->kmer_cnt_cutoff = 500; o->block_size = 2000;
+    o->block_score_cutoff = 3; o->num_candidates = 500; o->align_size_cutoff = 500;
+    o->ddfs_cutoff = 0.25; o->error = 0.5; o->num_output = 500; o->num_threads = 1;
+    o->job = 1; o->binary_output = 0; o->use_hdr_as_id = 1;
+}
+
+int necat_ctx_create(int device_id, necat_ctx** out)
+{
+    if (!out) return NECAT_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NECAT_ERR_DEVICE;
+    if (device_id < 0 || device_id >= ndev) return NECAT_ERR_ARG;
+    if (hipSetDevice(device_id) != hipSuccess) return NECAT_ERR_DEVICE;
+    necat_ctx* ctx = new necat_ctx();
+    ctx->device = device_id;
+    memset(&ctx->tm, 0, sizeof ctx->tm);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+        snprintf(ctx->devname, sizeof ctx->devname, "%s (%s), %d CUs", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+        ctx->num_cu = prop.multiProcessorCount;
+    }
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
+    for (int i = 0; i < 8; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
+    *out = ctx;
+    return NECAT_OK;
+}
+
+void necat_ctx_destroy(necat_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& b : ctx->scratch) if (b.p) (void)hipFree(b.p);
+    for (int i = 0; i < 8; ++i) (void)hipEventDestroy(ctx->ev[i]);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* necat_last_error(const necat_ctx* ctx) { return ctx ? ctx->err : "no context"; }
+
+int necat_device_name(const necat_ctx* ctx, char* buf, size_t n)
+{
+    if (!ctx || !buf || !n) return NECAT_ERR_ARG;
+    snprintf(buf, n, "%s", ctx->devname);
+    return NECAT_OK;
+}
+
+int necat_get_timings(const necat_ctx* ctx, necat_timings* t)
+{
+    if (!ctx || !t) return NECAT_ERR_ARG;
+    *t = ctx->tm;
+    return NECAT_OK;
+}
+
+void necat_free(void* p) { free(p); }
+
+// ------------------------------------------------------------------------------------------ volumes
+
+int necat_volume_upload(necat_ctx* ctx, const uint8_t* pac, uint64_t nbases, const uint64_t* seq_offset,
+                        const uint64_t* seq_size, uint64_t nseq, necat_volume** out)
+{
+    if (!ctx || !out || (nbases && !pac) || (nseq && (!seq_offset || !seq_size))) return NECAT_ERR_ARG;
+    *out = nullptr;
+    NECAT_HIP(ctx, hipSetDevice(ctx->device));
+    // the overlap stage requires the reads of a volume to tile it in order (packed_db.c:229-253)
+    uint64_t run = 0;
+    for (uint64_t i = 0; i < nseq; ++i) {
+        if (seq_offset[i] != run) return set_err(ctx, NECAT_ERR_ARG, "sequence %lu does not start where sequence %lu ends", (unsigned long)i, (unsigned long)(i - 1));
+        run += seq_size[i];
+    }
+    if (run != nbases) return set_err(ctx, NECAT_ERR_ARG, "sequence sizes sum to %lu, volume holds %lu bases", (unsigned long)run, (unsigned long)nbases);
+    if (nbases >= (1ULL << 34) / 2) return set_err(ctx, NECAT_ERR_ARG, "volume too large for 34-bit offsets");
+    necat_volume* v = new necat_volume();
+    v->nbases = nbases; v->nseq = nseq;
+    const uint64_t nwords = (nbases + 31) / 32;
+    const uint64_t pac_bytes = (nbases + 3) / 4;
+    NECAT_HIP(ctx, hipMalloc((void**)&v->bases_alloc, (nwords + 2 * kGuardWords) * 8));
+    NECAT_HIP(ctx, hipMemsetAsync(v->bases_alloc, 0, (nwords + 2 * kGuardWords) * 8, ctx->stream));
+    v->bases = v->bases_alloc + kGuardWords;
+    if (nwords) {
+        uint64_t* staging = nullptr;
+        NECAT_HIP(ctx, hipMalloc((void**)&staging, nwords * 8));
+        NECAT_HIP(ctx, hipMemsetAsync(staging, 0, nwords * 8, ctx->stream));
+        NECAT_HIP(ctx, hipMemcpyAsync(staging, pac, pac_bytes, hipMemcpyHostToDevice, ctx->stream));
+        hipLaunchKernelGGL(k_repack, dim3(grid_for(nwords, 256, 65536)), dim3(256), 0, ctx->stream, staging, nwords, v->bases);
+        NECAT_CHECK_LAUNCH(ctx, "k_repack");
+        NECAT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        NECAT_HIP(ctx, hipFree(staging));
+    }
+    v->h_seq_off.resize(nseq + 1);
+    for (uint64_t i = 0; i < nseq; ++i) v->h_seq_off[i] = seq_offset[i];
+    v->h_seq_off[nseq] = nbases;
+    NECAT_HIP(ctx, hipMalloc((void**)&v->seq_off, (nseq + 1) * 8));
+    NECAT_HIP(ctx, hipMemcpyAsync(v->seq_off, v->h_seq_off.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    NECAT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = v;
+    return NECAT_OK;
+}
+
+void necat_volume_free(necat_ctx* ctx, necat_volume* v)
+{
+    if (!v) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (v->bases_alloc) (void)hipFree(v->bases_alloc);
+    if (v->seq_off) (void)hipFree(v->seq_off);
+    delete v;
+}
+
+// ------------------------------------------------------------------------------------------ index
+
+int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, int max_occ, necat_index** out)
+{
+    if (!ctx || !ref || !out) return NECAT_ERR_ARG;
+    *out = nullptr;
+    if (kmer_size < 1 || kmer_size > 15) return set_err(ctx, NECAT_ERR_ARG, "kmer_size %d outside 1..15 (HashBits = 30, lookup_table.h:13)", kmer_size);
+    if (max_occ < 0) return set_err(ctx, NECAT_ERR_ARG, "negative kmer_cnt_cutoff");
+    NECAT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const uint64_t T = 1ULL << (2 * kmer_size);
+    const uint64_t ntiles = (T + kScanTile - 1) / kScanTile;
+    DevVolume vol = dev_view(ref);
+    necat_index* ix = new necat_index();
+    ix->k = kmer_size; ix->table_entries = T;
+    int rc;
+    if ((rc = buf_ensure(ctx, ctx->scratch[SC_CNT32], T * 4)) || (rc = buf_ensure(ctx, ctx->scratch[SC_PARTIAL], (ntiles + 1) * 8))) { delete ix; return rc; }
+    u32* cnt32 = (u32*)ctx->scratch[SC_CNT32].p;
+    u64* partial = (u64*)ctx->scratch[SC_PARTIAL].p;
+    NECAT_HIP(ctx, hipMalloc((void**)&ix->kmer_stats, T * 8));
+    NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
+    NECAT_HIP(ctx, hipMemsetAsync(cnt32, 0, T * 4, s));
+    const uint64_t nchunks = (ref->nbases + kPosPerThread - 1) / kPosPerThread;
+    const unsigned pass_grid = grid_for(nchunks, 256, 1u << 16);
+    hipLaunchKernelGGL(k_kmer_pass<0>, dim3(pass_grid), dim3(256), 0, s, vol, kmer_size, cnt32, (const u64*)nullptr, (u64*)nullptr);
+    NECAT_CHECK_LAUNCH(ctx, "k_kmer_pass<count>");
+    hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)ntiles), dim3(256), 0, s, cnt32, T, (u32)max_occ, partial);
+    NECAT_CHECK_LAUNCH(ctx, "k_tile_sums");
+    hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partial, ntiles);
+    NECAT_CHECK_LAUNCH(ctx, "k_scan_partials");
+    hipLaunchKernelGGL(k_write_stats, dim3((unsigned)ntiles), dim3(256), 0, s, cnt32, T, (u32)max_occ, partial, ix->kmer_stats);
+    NECAT_CHECK_LAUNCH(ctx, "k_write_stats");
+    uint64_t n_off = 0;
+    NECAT_HIP(ctx, hipMemcpyAsync(&n_off, partial + ntiles, 8, hipMemcpyDeviceToHost, s));
+    NECAT_HIP(ctx, hipStreamSynchronize(s));
+    ix->n_offsets = n_off;
+    NECAT_HIP(ctx, hipMalloc((void**)&ix->offset_list, (n_off + 1) * 8));
+    if (n_off) {
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_TMPLIST], n_off * 8))) { necat_index_free(ctx, ix); return rc; }
+        u64* tmp = (u64*)ctx->scratch[SC_TMPLIST].p;
+        hipLaunchKernelGGL(k_kmer_pass<1>, dim3(pass_grid), dim3(256), 0, s, vol, kmer_size, cnt32, (const u64*)ix->kmer_stats, tmp);
+        NECAT_CHECK_LAUNCH(ctx, "k_kmer_pass<scatter>");
+        hipLaunchKernelGGL(k_rank_buckets, dim3(grid_for(n_off, 256, 1u << 16)), dim3(256), 0, s, vol, kmer_size, (const u64*)ix->kmer_stats, (const u64*)tmp, n_off, ix->offset_list);
+        NECAT_CHECK_LAUNCH(ctx, "k_rank_buckets");
+    }
+    NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s));
+    NECAT_HIP(ctx, hipStreamSynchronize(s));
+    ctx->tm.index_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
+    *out = ix;
+    return NECAT_OK;
+}
+
+int necat_index_size(const necat_index* ix, uint64_t* table_entries, uint64_t* n_offsets)
+{
+    if (!ix) return NECAT_ERR_ARG;
+    if (table_entries) *table_entries = ix->table_entries;
+    if (n_offsets) *n_offsets = ix->n_offsets;
+    return NECAT_OK;
+}
+
+int necat_index_download(necat_ctx* ctx, const necat_index* ix, uint64_t* kmer_stats, uint64_t* offset_list)
+{
+    if (!ctx || !ix) return NECAT_ERR_ARG;
+    NECAT_HIP(ctx, hipSetDevice(ctx->device));
+    if (kmer_stats) NECAT_HIP(ctx, hipMemcpy(kmer_stats, ix->kmer_stats, ix->table_entries * 8, hipMemcpyDeviceToHost));
+    if (offset_list && ix->n_offsets) NECAT_HIP(ctx, hipMemcpy(offset_list, ix->offset_list, ix->n_offsets * 8, hipMemcpyDeviceToHost));
+    return NECAT_OK;
+}
+
+void necat_index_free(necat_ctx* ctx, necat_index* ix)
+{
+    if (!ix) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    if (ix->kmer_stats) (void)hipFree(ix->kmer_stats);
+    if (ix->offset_list) (void)hipFree(ix->offset_list);
+    delete ix;
+}
+
+// ------------------------------------------------------------------------------------------ seeding
+
+int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, const necat_volume* reads,
+                          int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt,
+                          necat_candidate** out, uint64_t* n_out)
+{
+    if (!ctx || !ix || !ref || !reads || !opt || !out || !n_out) return NECAT_ERR_ARG;
+    *out = nullptr; *n_out = 0;
+    if (opt->kmer_size != ix->k) return set_err(ctx, NECAT_ERR_ARG, "index was built for k=%d, options say %d", ix->k, opt->kmer_size);
+    if (opt->scan_window < 1 || opt->block_size < 1 || opt->block_size > 32767)
+        return set_err(ctx, NECAT_ERR_ARG, "scan_window/block_size out of range (block offsets are 16-bit, word_finder_aux.h:21)");
+    NECAT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const u32 nreads = (u32)reads->nseq;
+    std::vector<necat_candidate> all;
+    if (nreads == 0) return NECAT_OK;
+    DevVolume dref = dev_view(ref), drd = dev_view(reads);
+    NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
+    int rc;
+    // ---- pass 1: hit counts per read-strand
+    if ((rc = buf_ensure(ctx, ctx->scratch[SC_MISC], (size_t)nreads * 8 + 64))) return rc;
+    u32* d_hits = (u32*)ctx->scratch[SC_MISC].p;
+    hipLaunchKernelGGL(k_seed_hits, dim3(grid_for((u64)nreads * 64, 256)), dim3(256), 0, s, drd, (const u64*)ix->kmer_stats,
+                       opt->kmer_size, opt->scan_window, 0u, nreads, d_hits);
+    NECAT_CHECK_LAUNCH(ctx, "k_seed_hits");
+    std::vector<u32> hits((size_t)nreads * 2);
+    NECAT_HIP(ctx, hipMemcpyAsync(hits.data(), d_hits, (size_t)nreads * 8, hipMemcpyDeviceToHost, s));
+    NECAT_HIP(ctx, hipStreamSynchronize(s));
+    // ---- plan: reads in descending work order, chunks bounded by a scratch budget
+    std::vector<u32> order(nreads);
+    std::iota(order.begin(), order.end(), 0u);
+    auto work = [&](u32 r) { return (u64)std::max(hits[2 * (size_t)r], hits[2 * (size_t)r + 1]); };
+    std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return work(a) > work(b); });
+    const u64 budget_hits = 48ULL << 20;     // ~48 M pool blocks (~13 GB of SBlocks) per chunk
+    std::vector<i32> ncand_of_read(nreads, 0);
+    std::vector<std::vector<necat_candidate>> chunk_out;
+    std::vector<std::vector<u32>> chunk_reads;
+    SeedParams P;
+    P.k = opt->kmer_size; P.z = opt->scan_window; P.block_size = opt->block_size; P.s_cutoff = opt->block_score_cutoff;
+    P.align_cutoff = opt->align_size_cutoff; P.num_candidates = opt->num_candidates; P.job = opt->job; P.pairwise = pairwise;
+    P.read_start_id = read_start_id; P.ref_start_id = ref_start_id;
+    int* d_err = nullptr;
+    NECAT_HIP(ctx, hipMalloc((void**)&d_err, 4));
+    NECAT_HIP(ctx, hipMemsetAsync(d_err, 0, 4, s));
+    // final per-read offsets need all counts: collect per chunk, assemble at the end
+    std::vector<necat_candidate*> host_parts;
+    std::vector<u64> read_final_off(nreads + 1, 0);
+    struct ChunkRec { u32 lo, hi; std::vector<i32> ncand; std::vector<SeedMeta> meta; };
+    u32 pos = 0;
+    std::vector<necat_candidate> result;
+    std::vector<std::pair<u32, std::vector<necat_candidate>>> per_chunk;
+    std::vector<i32> ncands_by_order(nreads, 0);
+    std::vector<std::vector<DevCand>> unused;
+    // storage of every chunk's compacted candidates in ORDER-index space
+    std::vector<necat_candidate> packed_all;
+    std::vector<u64> packed_off(nreads + 1, 0);
+    while (pos < nreads) {
+        u64 acc = 0; u32 hi = pos;
+        while (hi < nreads && (hi == pos || acc + work(order[hi]) + 1 <= budget_hits)) { acc += work(order[hi]) + 1; ++hi; }
+        const u32 n = hi - pos;
+        std::vector<SeedMeta> meta(n);
+        u64 ht_tot = 0, pool_tot = 0, chain_tot = 0, out_tot = 0;
+        for (u32 i = 0; i < n; ++i) {
+            const u32 r = order[pos + i];
+            const u64 H = std::max<u64>(1, work(r));
+            u64 cap = 4; while (cap < 2 * H) cap <<= 1;
+            SeedMeta& m = meta[i];
+            m.ht_off = ht_tot; m.ht_mask = (u32)(cap - 1); ht_tot += cap;
+            m.pool_off = pool_tot; m.pool_cap = (u32)H; pool_tot += H;
+            m.chain_off = chain_tot; m.cs_cap = (u32)(H + 1); chain_tot += H + 1;
+            const u64 oc = (u64)hits[2 * (size_t)r] + hits[2 * (size_t)r + 1] + 1;
+            m.out_off = out_tot; m.out_cap = (u32)oc; out_tot += oc;
+        }
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_SEED_META], n * sizeof(SeedMeta) + n * 4 + n * 4 + n * 8 + 64)) ||
+            (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_HT], ht_tot * 8)) ||
+            (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_POOL], pool_tot * sizeof(SBlock))) ||
+            (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_CHAIN], chain_tot * (8 + 16 + 8 + sizeof(DevCand)))) ||
+            (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_OUT], out_tot * sizeof(DevCand)))) { (void)hipFree(d_err); return rc; }
+        char* mb = (char*)ctx->scratch[SC_SEED_META].p;
+        SeedMeta* d_meta = (SeedMeta*)mb; mb += n * sizeof(SeedMeta);
+        u64* d_final = (u64*)mb; mb += (size_t)n * 8;
+        u32* d_order = (u32*)mb; mb += (size_t)n * 4;
+        i32* d_ncand = (i32*)mb;
+        SeedArenas A;
+        A.ht_key = (i32*)ctx->scratch[SC_SEED_HT].p; A.ht_val = A.ht_key + ht_tot;
+        A.pool = (SBlock*)ctx->scratch[SC_SEED_POOL].p;
+        char* cb = (char*)ctx->scratch[SC_SEED_CHAIN].p;
+        A.cs = (u64*)cb; cb += chain_tot * 8;
+        A.u = (u64*)cb; cb += chain_tot * 8;
+        A.lcan = (DevCand*)cb; cb += chain_tot * sizeof(DevCand);
+        A.f = (i32*)cb; cb += chain_tot * 4; A.p = (i32*)cb; cb += chain_tot * 4; A.t = (i32*)cb; cb += chain_tot * 4; A.v = (i32*)cb;
+        A.out = (DevCand*)ctx->scratch[SC_SEED_OUT].p;
+        NECAT_HIP(ctx, hipMemcpyAsync(d_meta, meta.data(), n * sizeof(SeedMeta), hipMemcpyHostToDevice, s));
+        NECAT_HIP(ctx, hipMemcpyAsync(d_order, order.data() + pos, (size_t)n * 4, hipMemcpyHostToDevice, s));
+        NECAT_HIP(ctx, hipMemsetAsync(A.ht_key, 0xFF, ht_tot * 4, s));
+        hipLaunchKernelGGL(k_seed_reads, dim3(grid_for(n, 64)), dim3(64), 0, s, dref, drd, (const u64*)ix->kmer_stats, (const u64*)ix->offset_list,
+                           P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A, d_ncand, d_err);
+        NECAT_CHECK_LAUNCH(ctx, "k_seed_reads");
+        std::vector<i32> nc(n);
+        NECAT_HIP(ctx, hipMemcpyAsync(nc.data(), d_ncand, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+        int herr = 0;
+        NECAT_HIP(ctx, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, s));
+        NECAT_HIP(ctx, hipStreamSynchronize(s));
+        if (herr) { (void)hipFree(d_err); return set_err(ctx, NECAT_ERR_CAPACITY, "seeding scratch overflow (code %d)", herr); }
+        std::vector<u64> foff(n + 1, 0);
+        for (u32 i = 0; i < n; ++i) foff[i + 1] = foff[i] + (u64)nc[i];
+        const u64 tot = foff[n];
+        const size_t base = packed_all.size();
+        packed_all.resize(base + tot);
+        if (tot) {
+            if ((rc = buf_ensure(ctx, ctx->scratch[SC_SEED_FINAL], tot * sizeof(necat_candidate)))) { (void)hipFree(d_err); return rc; }
+            necat_candidate* d_dst = (necat_candidate*)ctx->scratch[SC_SEED_FINAL].p;
+            NECAT_HIP(ctx, hipMemcpyAsync(d_final, foff.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_pack_cands, dim3(grid_for((u64)n * 64, 256)), dim3(256), 0, s, (const DevCand*)A.out, (const SeedMeta*)d_meta,
+                               (const i32*)d_ncand, (const u64*)d_final, n, read_start_id, ref_start_id, d_dst);
+            NECAT_CHECK_LAUNCH(ctx, "k_pack_cands");
+            NECAT_HIP(ctx, hipMemcpyAsync(packed_all.data() + base, d_dst, tot * sizeof(necat_candidate), hipMemcpyDeviceToHost, s));
+            NECAT_HIP(ctx, hipStreamSynchronize(s));
+        }
+        for (u32 i = 0; i < n; ++i) { ncands_by_order[pos + i] = nc[i]; packed_off[pos + i] = base + foff[i]; }
+        pos = hi;
+    }
+    (void)hipFree(d_err);
+    NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s));
+    NECAT_HIP(ctx, hipStreamSynchronize(s));
+    ctx->tm.seed_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
+    // ---- assemble in ascending read id
+    std::vector<u32> inv(nreads);
+    for (u32 i = 0; i < nreads; ++i) inv[order[i]] = i;
+    u64 total = packed_all.size();
+    necat_candidate* res = (necat_candidate*)malloc(std::max<u64>(1, total) * sizeof(necat_candidate));
+    if (!res) return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed");
+    u64 w = 0;
+    for (u32 r = 0; r < nreads; ++r) {
+        const u32 i = inv[r];
+        const i32 c = ncands_by_order[i];
+        if (c) memcpy(res + w, packed_all.data() + packed_off[i], (size_t)c * sizeof(necat_candidate));
+        w += (u64)c;
+    }
+    *out = res; *n_out = total;
+    return NECAT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ extension
+
+namespace {
+
+struct ExtBuffers {
+    ExtTask* tasks; u32* active; u32* count; BlockItem* itemsA; BlockItem* itemsB;
+    u64* fragA; u64* fragB; char* slabs; u8* opsA; u8* opsB; BlockResult* resA; BlockResult* resB;
+};
+
+// run rounds until every task of the batch is done
+int run_rounds(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, ExtBuffers& B, u32 n_tasks, double error,
+               int tail_match_len, int* d_err)
+{
+    hipStream_t s = ctx->stream;
+    u32 n_active = n_tasks;
+    ExtLists L; L.count = B.count; L.itemsA = B.itemsA; L.itemsB = B.itemsB;
+    hipEvent_t e0 = ctx->ev[4], e1 = ctx->ev[5], e2 = ctx->ev[6];
+    while (n_active) {
+        NECAT_HIP(ctx, hipMemsetAsync(B.count, 0, 8, s));
+        hipLaunchKernelGGL(k_ext_plan, dim3(grid_for(n_active, 256)), dim3(256), 0, s, B.tasks, (const u32*)B.active, n_active, L, (u32*)nullptr);
+        NECAT_CHECK_LAUNCH(ctx, "k_ext_plan");
+        u32 cnt[2] = {0, 0};
+        NECAT_HIP(ctx, hipMemcpyAsync(cnt, B.count, 8, hipMemcpyDeviceToHost, s));
+        NECAT_HIP(ctx, hipStreamSynchronize(s));
+        const u32 nA = cnt[0], nB = cnt[1];
+        if (nA + nB == 0) break;
+        const u32 gA = (nA + 63) / 64, gB = (nB + 63) / 64;
+        char* slabsB = B.slabs + (size_t)gA * kSlabA;
+        if (nA) {
+            hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)gA * 64 * (kWordsA + kTWordsA), 256)), dim3(256), 0, s,
+                               drd, dref, (const BlockItem*)B.itemsA, nA, B.fragA);
+            NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<A>");
+        }
+        if (nB) {
+            hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, s,
+                               drd, dref, (const BlockItem*)B.itemsB, nB, B.fragB);
+            NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
+        }
+        NECAT_HIP(ctx, hipEventRecord(e0, s));
+        if (nA) {
+            hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(gA), dim3(64), 0, s, (const BlockItem*)B.itemsA, nA,
+                               (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA);
+            NECAT_CHECK_LAUNCH(ctx, "k_myers<A>");
+        }
+        if (nB) {
+            hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, s, (const BlockItem*)B.itemsB, nB,
+                               (const u64*)B.fragB, slabsB, kSlabB, error, B.resB);
+            NECAT_CHECK_LAUNCH(ctx, "k_myers<B>");
+        }
+        NECAT_HIP(ctx, hipEventRecord(e1, s));
+        if (nA) {
+            hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false>), dim3(gA), dim3(64), 0, s, (const BlockItem*)B.itemsA, nA,
+                               (const u64*)B.fragA, (const char*)B.slabs, kSlabA, (const BlockResult*)B.resA, B.opsA, B.tasks, tail_match_len,
+                               (i32*)nullptr, d_err);
+            NECAT_CHECK_LAUNCH(ctx, "k_traceback<A>");
+        }
+        if (nB) {
+            hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false>), dim3(gB), dim3(64), 0, s, (const BlockItem*)B.itemsB, nB,
+                               (const u64*)B.fragB, (const char*)slabsB, kSlabB, (const BlockResult*)B.resB, B.opsB, B.tasks, tail_match_len,
+                               (i32*)nullptr, d_err);
+            NECAT_CHECK_LAUNCH(ctx, "k_traceback<B>");
+        }
+        NECAT_HIP(ctx, hipEventRecord(e2, s));
+        hipLaunchKernelGGL(k_ext_collect, dim3(grid_for(nA + nB, 256)), dim3(256), 0, s, (const BlockItem*)B.itemsA, nA, (const BlockItem*)B.itemsB, nB, B.active);
+        NECAT_CHECK_LAUNCH(ctx, "k_ext_collect");
+        NECAT_HIP(ctx, hipStreamSynchronize(s));
+        ctx->tm.myers_ms += ev_ms(e0, e1);
+        ctx->tm.traceback_ms += ev_ms(e1, e2);
+        ctx->tm.myers_launches += (nA ? 1 : 0) + (nB ? 1 : 0);
+        ctx->tm.myers_blocks += nA + nB;
+        ctx->tm.rounds += 1;
+        n_active = nA + nB;
+    }
+    return NECAT_OK;
+}
+
+}  // namespace
+
+int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* reads, int read_start_id, int ref_start_id,
+                 const necat_candidate* cands, uint64_t n, const necat_map_options* opt, int tail_match_len,
+                 necat_m4** out, uint64_t* n_out)
+{
+    if (!ctx || !ref || !reads || !opt || !out || !n_out || (n && !cands)) return NECAT_ERR_ARG;
+    *out = nullptr; *n_out = 0;
+    if (n == 0) return NECAT_OK;
+    if (n >= (1ULL << 31)) return set_err(ctx, NECAT_ERR_ARG, "too many candidates in one call");
+    for (uint64_t i = 0; i < n; ++i) {
+        const necat_candidate& c = cands[i];
+        const int64_t lq = (int64_t)c.qid - read_start_id, ls = (int64_t)c.sid - ref_start_id;
+        if (lq < 0 || (uint64_t)lq >= reads->nseq || ls < 0 || (uint64_t)ls >= ref->nseq)
+            return set_err(ctx, NECAT_ERR_ARG, "candidate %lu refers to a read outside the volumes", (unsigned long)i);
+        if (c.qsize != reads->h_seq_off[lq + 1] - reads->h_seq_off[lq] || c.ssize != ref->h_seq_off[ls + 1] - ref->h_seq_off[ls] ||
+            c.qoff > c.qsize || c.soff > c.ssize)
+            return set_err(ctx, NECAT_ERR_ARG, "candidate %lu has inconsistent sizes/anchor", (unsigned long)i);
+    }
+    NECAT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    DevVolume dref = dev_view(ref), drd = dev_view(reads);
+    ctx->tm.myers_ms = ctx->tm.traceback_ms = 0; ctx->tm.myers_launches = ctx->tm.myers_blocks = ctx->tm.rounds = 0;
+    ctx->tm.myers_word_updates = ctx->tm.myers_cells_bases = 0;
+    NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
+    const u32 batch = (u32)std::min<uint64_t>(n, 131072);
+    const u32 groups = (batch + 63) / 64 + 1;
+    int rc;
+    // candidate-wide arrays
+    necat_candidate* d_cands = nullptr; necat_m4* d_m4 = nullptr; necat_m4* d_out = nullptr; u8* d_ok = nullptr; u32* d_outcnt = nullptr; int* d_err = nullptr;
+    u64* d_goff = nullptr;
+    NECAT_HIP(ctx, hipMalloc((void**)&d_cands, n * sizeof(necat_candidate)));
+    NECAT_HIP(ctx, hipMalloc((void**)&d_m4, n * sizeof(necat_m4)));
+    NECAT_HIP(ctx, hipMalloc((void**)&d_out, n * sizeof(necat_m4)));
+    NECAT_HIP(ctx, hipMalloc((void**)&d_ok, n));
+    NECAT_HIP(ctx, hipMalloc((void**)&d_outcnt, 8));
+    NECAT_HIP(ctx, hipMalloc((void**)&d_err, 4));
+    NECAT_HIP(ctx, hipMemcpyAsync(d_cands, cands, n * sizeof(necat_candidate), hipMemcpyHostToDevice, s));
+    NECAT_HIP(ctx, hipMemsetAsync(d_outcnt, 0, 8, s));
+    NECAT_HIP(ctx, hipMemsetAsync(d_err, 0, 4, s));
+    auto cleanup = [&]() { (void)hipFree(d_cands); (void)hipFree(d_m4); (void)hipFree(d_out); (void)hipFree(d_ok); (void)hipFree(d_outcnt); (void)hipFree(d_err); if (d_goff) (void)hipFree(d_goff); };
+    if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_TASKS], (size_t)batch * (sizeof(ExtTask) + 4) + 64)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], (size_t)batch * 2 * sizeof(BlockItem) + 64)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_FRAG], (size_t)groups * 64 * (kFragWordsA + kFragWordsB) * 8)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_MAT], (size_t)groups * kSlabB + kSlabA)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_OPS], (size_t)groups * 64 * (kOpsA + kOpsB))) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_RES], (size_t)groups * 64 * 2 * sizeof(BlockResult)))) { cleanup(); return rc; }
+    ExtBuffers B;
+    {
+        char* p = (char*)ctx->scratch[SC_EXT_TASKS].p;
+        B.tasks = (ExtTask*)p; p += (size_t)batch * sizeof(ExtTask);
+        B.active = (u32*)p;
+        B.count = d_outcnt + 0;   // placeholder, replaced below
+        char* q = (char*)ctx->scratch[SC_EXT_LISTS].p;
+        B.itemsA = (BlockItem*)q; B.itemsB = B.itemsA + batch;
+        B.fragA = (u64*)ctx->scratch[SC_EXT_FRAG].p; B.fragB = B.fragA + (size_t)groups * 64 * kFragWordsA;
+        B.slabs = (char*)ctx->scratch[SC_EXT_MAT].p;
+        B.opsA = (u8*)ctx->scratch[SC_EXT_OPS].p; B.opsB = B.opsA + (size_t)groups * 64 * kOpsA;
+        B.resA = (BlockResult*)ctx->scratch[SC_EXT_RES].p; B.resB = B.resA + (size_t)groups * 64;
+    }
+    u32* d_count = nullptr;
+    NECAT_HIP(ctx, hipMalloc((void**)&d_count, 8));
+    B.count = d_count;
+    for (uint64_t base = 0; base < n; base += batch) {
+        const u32 nb = (u32)std::min<uint64_t>(batch, n - base);
+        hipLaunchKernelGGL(k_ext_init, dim3(grid_for(nb, 256)), dim3(256), 0, s, (const necat_candidate*)(d_cands + base), nb, (u32)base,
+                           read_start_id, ref_start_id, (const u64*)reads->seq_off, (const u64*)ref->seq_off, B.tasks, B.active);
+        NECAT_CHECK_LAUNCH(ctx, "k_ext_init");
+        if ((rc = run_rounds(ctx, dref, drd, B, nb, opt->error, tail_match_len, d_err))) { (void)hipFree(d_count); cleanup(); return rc; }
+        hipLaunchKernelGGL(k_ext_result, dim3(grid_for(nb, 256)), dim3(256), 0, s, (const ExtTask*)B.tasks, nb, (const necat_candidate*)(d_cands + base),
+                           (u32)base, opt->align_size_cutoff, d_m4 - 0, d_ok);
+        NECAT_CHECK_LAUNCH(ctx, "k_ext_result");
+    }
+    (void)hipFree(d_count);
+    // groups of equal qid (candidates arrive grouped per read: pm_worker.c:100-140)
+    std::vector<u64> goff;
+    goff.push_back(0);
+    for (uint64_t i = 1; i < n; ++i) if (cands[i].qid != cands[i - 1].qid) goff.push_back(i);
+    goff.push_back(n);
+    const u32 ng = (u32)goff.size() - 1;
+    NECAT_HIP(ctx, hipMalloc((void**)&d_goff, goff.size() * 8));
+    NECAT_HIP(ctx, hipMemcpyAsync(d_goff, goff.data(), goff.size() * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_m4_filter, dim3(grid_for(ng, 64)), dim3(64), 0, s, (const necat_candidate*)d_cands, (const u64*)d_goff, ng,
+                       (const necat_m4*)d_m4, d_ok, d_out, d_outcnt);
+    NECAT_CHECK_LAUNCH(ctx, "k_m4_filter");
+    u32 nout = 0; int herr = 0;
+    NECAT_HIP(ctx, hipMemcpyAsync(&nout, d_outcnt, 4, hipMemcpyDeviceToHost, s));
+    NECAT_HIP(ctx, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, s));
+    NECAT_HIP(ctx, hipStreamSynchronize(s));
+    if (herr) { cleanup(); return set_err(ctx, NECAT_ERR_INTERNAL, "extension kernels reported error code %d", herr); }
+    necat_m4* res = (necat_m4*)malloc(std::max<size_t>(1, nout) * sizeof(necat_m4));
+    if (!res) { cleanup(); return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
+    if (nout) NECAT_HIP(ctx, hipMemcpyAsync(res, d_out, (size_t)nout * sizeof(necat_m4), hipMemcpyDeviceToHost, s));
+    NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s));
+    NECAT_HIP(ctx, hipStreamSynchronize(s));
+    ctx->tm.extend_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
+    cleanup();
+    *out = res; *n_out = nout;
+    return NECAT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ batch Edlib_align (test / profiling hook)
+
+int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_len, const uint64_t* q_off, const int32_t* q_len,
+                            const uint64_t* t_off, const int32_t* t_len, uint64_t n, double error,
+                            int32_t* dist, int32_t* qend, int32_t* tend, uint8_t** ops, uint64_t** ops_off)
+{
+    if (!ctx || !seqs || !q_off || !q_len || !t_off || !t_len || !dist || !qend || !tend) return NECAT_ERR_ARG;
+    if (ops) *ops = nullptr;
+    if (ops_off) *ops_off = nullptr;
+    if (n == 0) return NECAT_OK;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (q_len[i] < 1 || t_len[i] < 1 || q_len[i] > kMaxFragLen || t_len[i] > kMaxFragLen ||
+            q_off[i] + q_len[i] > seqs_len || t_off[i] + t_len[i] > seqs_len)
+            return set_err(ctx, NECAT_ERR_ARG, "block %lu: fragment lengths must be 1..%d and inside seqs", (unsigned long)i, kMaxFragLen);
+    }
+    NECAT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    // pack to NECAT pac and upload as a one-read pseudo volume
+    std::vector<uint8_t> pac((seqs_len + 3) / 4 + 8, 0);
+    for (uint64_t i = 0; i < seqs_len; ++i) pac[i >> 2] |= (uint8_t)((seqs[i] & 3) << ((~i & 3) << 1));
+    uint64_t off0 = 0, size0 = seqs_len;
+    necat_volume* vol = nullptr;
+    int rc = necat_volume_upload(ctx, pac.data(), seqs_len, &off0, &size0, 1, &vol);
+    if (rc) return rc;
+    DevVolume dv = dev_view(vol);
+    // split into the two kernel shapes
+    std::vector<BlockItem> itA, itB; std::vector<u64> idA, idB;
+    for (uint64_t i = 0; i < n; ++i) {
+        BlockItem it; it.g.q_base = (i64)q_off[i]; it.g.q_dir = 1; it.g.q_comp = 0; it.g.t_base = (i64)t_off[i]; it.g.t_dir = 1;
+        it.task = -1; it.qn = (i16)q_len[i]; it.tn = (i16)t_len[i];
+        if (q_len[i] == kOcaBlockSize && t_len[i] == kOcaBlockSize) { itA.push_back(it); idA.push_back(i); } else { itB.push_back(it); idB.push_back(i); }
+    }
+    ctx->tm.myers_ms = 0; ctx->tm.traceback_ms = 0; ctx->tm.myers_launches = 0; ctx->tm.myers_blocks = n; ctx->tm.myers_word_updates = 0;
+    ctx->tm.myers_cells_bases = 0;
+    std::vector<std::vector<uint8_t>> fwd_ops(n);
+    int* d_err = nullptr;
+    NECAT_HIP(ctx, hipMalloc((void**)&d_err, 4));
+    NECAT_HIP(ctx, hipMemsetAsync(d_err, 0, 4, s));
+    const u32 chunk = 65536;
+    auto run_shape = [&](std::vector<BlockItem>& items, std::vector<u64>& ids, bool full) -> int {
+        for (size_t base = 0; base < items.size(); base += chunk) {
+            const u32 m = (u32)std::min<size_t>(chunk, items.size() - base);
+            const u32 g = (m + 63) / 64;
+            const size_t slab = full ? kSlabA : kSlabB;
+            const int fw = full ? kFragWordsA : kFragWordsB, maxops = full ? kOpsA : kOpsB;
+            int rc2;
+            if ((rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], (size_t)m * sizeof(BlockItem))) ||
+                (rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_FRAG], (size_t)g * 64 * fw * 8)) ||
+                (rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_MAT], (size_t)g * slab)) ||
+                (rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_OPS], (size_t)g * 64 * maxops)) ||
+                (rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_RES], (size_t)g * 64 * (sizeof(BlockResult) + 4)))) return rc2;
+            BlockItem* d_items = (BlockItem*)ctx->scratch[SC_EXT_LISTS].p;
+            u64* d_frag = (u64*)ctx->scratch[SC_EXT_FRAG].p;
+            char* d_slabs = (char*)ctx->scratch[SC_EXT_MAT].p;
+            u8* d_ops = (u8*)ctx->scratch[SC_EXT_OPS].p;
+            BlockResult* d_res = (BlockResult*)ctx->scratch[SC_EXT_RES].p;
+            i32* d_nops = (i32*)(d_res + (size_t)g * 64);
+            NECAT_HIP(ctx, hipMemcpyAsync(d_items, items.data() + base, (size_t)m * sizeof(BlockItem), hipMemcpyHostToDevice, s));
+            if (full) hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)g * 64 * (kWordsA + kTWordsA), 256)), dim3(256), 0, s, dv, dv, (const BlockItem*)d_items, m, d_frag);
+            else hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)g * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, s, dv, dv, (const BlockItem*)d_items, m, d_frag);
+            NECAT_CHECK_LAUNCH(ctx, "k_ext_frag");
+            NECAT_HIP(ctx, hipEventRecord(ctx->ev[4], s));
+            if (full) hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res);
+            else hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res);
+            NECAT_CHECK_LAUNCH(ctx, "k_myers");
+            NECAT_HIP(ctx, hipEventRecord(ctx->ev[5], s));
+            if (full) hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, (const char*)d_slabs, slab,
+                                         (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err);
+            else hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, (const char*)d_slabs, slab,
+                                    (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err);
+            NECAT_CHECK_LAUNCH(ctx, "k_traceback");
+            NECAT_HIP(ctx, hipEventRecord(ctx->ev[6], s));
+            std::vector<BlockResult> hres(m); std::vector<i32> hn(m); std::vector<u8> hops((size_t)g * 64 * maxops);
+            NECAT_HIP(ctx, hipMemcpyAsync(hres.data(), d_res, (size_t)m * sizeof(BlockResult), hipMemcpyDeviceToHost, s));
+            NECAT_HIP(ctx, hipMemcpyAsync(hn.data(), d_nops, (size_t)m * 4, hipMemcpyDeviceToHost, s));
+            NECAT_HIP(ctx, hipMemcpyAsync(hops.data(), d_ops, hops.size(), hipMemcpyDeviceToHost, s));
+            NECAT_HIP(ctx, hipStreamSynchronize(s));
+            ctx->tm.myers_ms += ev_ms(ctx->ev[4], ctx->ev[5]); ctx->tm.traceback_ms += ev_ms(ctx->ev[5], ctx->ev[6]); ctx->tm.myers_launches += 1;
+            for (u32 j = 0; j < m; ++j) {
+                const u64 id = ids[base + j];
+                dist[id] = hres[j].dist;
+                ctx->tm.myers_word_updates += hres[j].words;
+                ctx->tm.myers_cells_bases += (u64)q_len[id] + (u64)t_len[id];
+                if (hres[j].dist >= 0) {
+                    const int no = hn[j];
+                    std::vector<uint8_t>& f = fwd_ops[id];
+                    f.resize((size_t)no);
+                    const u8* src = hops.data() + (size_t)(j / 64) * maxops * 64 + (j % 64);
+                    int qe = 0, te = 0;
+                    for (int x = 0; x < no; ++x) { const u8 op = src[(size_t)(no - 1 - x) * 64]; f[x] = op; qe += op != 2; te += op != 1; }
+                    qend[id] = qe; tend[id] = te;
+                } else { qend[id] = 0; tend[id] = 0; }
+            }
+        }
+        return NECAT_OK;
+    };
+    rc = run_shape(itA, idA, true);
+    if (!rc) rc = run_shape(itB, idB, false);
+    int herr = 0;
+    if (!rc) { hipError_t e = hipMemcpy(&herr, d_err, 4, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = set_err(ctx, NECAT_ERR_DEVICE, "memcpy failed"); }
+    (void)hipFree(d_err);
+    necat_volume_free(ctx, vol);
+    if (rc) return rc;
+    if (herr) return set_err(ctx, NECAT_ERR_INTERNAL, "edlib kernels reported error code %d", herr);
+    if (ops && ops_off) {
+        uint64_t* off = (uint64_t*)malloc((n + 1) * 8);
+        uint64_t tot = 0;
+        for (uint64_t i = 0; i < n; ++i) { off[i] = tot; tot += fwd_ops[i].size(); }
+        off[n] = tot;
+        uint8_t* o = (uint8_t*)malloc(tot ? tot : 1);
+        for (uint64_t i = 0; i < n; ++i) if (!fwd_ops[i].empty()) memcpy(o + off[i], fwd_ops[i].data(), fwd_ops[i].size());
+        *ops = o; *ops_off = off;
+    }
+    return NECAT_OK;
+}
+
+}  // extern "C"

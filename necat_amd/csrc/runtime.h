@@ -1,0 +1,96 @@
+// runtime.h - host-side plumbing of libnecat_hip.so: context, error capture, grow-only device
+// buffers, HIP event timers.  No torch types, no CPU fallback: every failure is reported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/necat_hip.h"
+#include "dev_common.h"
+
+namespace necat {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct StageTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+};
+
+}  // namespace necat
+
+struct necat_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    char err[1024] = {0};
+    necat_timings tm;
+    hipEvent_t ev[8];
+    std::vector<void*> owned;          // scratch buffers released at destroy
+    necat::DevBuf scratch[16];         // grow-only arenas, indexed by purpose
+    char devname[256] = {0};
+    int num_cu = 0;
+};
+
+struct necat_volume {
+    uint64_t nbases = 0, nseq = 0;
+    uint64_t* bases_alloc = nullptr;   // guarded allocation
+    uint64_t* bases = nullptr;         // bases_alloc + guard
+    uint64_t* seq_off = nullptr;       // [nseq + 1]
+    std::vector<uint64_t> h_seq_off;   // host copy (offsets are tiny; used for planning)
+};
+
+struct necat_index {
+    int k = 0;
+    uint64_t table_entries = 0, n_offsets = 0;
+    uint64_t* kmer_stats = nullptr;
+    uint64_t* offset_list = nullptr;
+};
+
+namespace necat {
+
+inline int set_err(necat_ctx* ctx, int code, const char* fmt, ...)
+{
+    if (ctx) {
+        va_list ap; va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof ctx->err, fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define NECAT_HIP(ctx, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) \
+    return necat::set_err(ctx, NECAT_ERR_DEVICE, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); } while (0)
+
+#define NECAT_CHECK_LAUNCH(ctx, name) do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) \
+    return necat::set_err(ctx, NECAT_ERR_DEVICE, "launch of %s failed: %s", name, hipGetErrorString(e__)); } while (0)
+
+constexpr int kGuardWords = 4;   // 128 bases of slack on both sides of a volume's bases
+
+inline int buf_ensure(necat_ctx* ctx, DevBuf& b, size_t bytes)
+{
+    if (bytes <= b.cap) return NECAT_OK;
+    if (b.p) { hipError_t e = hipFree(b.p); (void)e; b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr; b.cap = 0;
+        return set_err(ctx, NECAT_ERR_MEMORY, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+    return NECAT_OK;
+}
+
+enum ScratchId {
+    SC_CNT32 = 0, SC_PARTIAL, SC_TMPLIST, SC_MISC,
+    SC_SEED_META, SC_SEED_HT, SC_SEED_POOL, SC_SEED_CHAIN, SC_SEED_OUT, SC_SEED_FINAL,
+    SC_EXT_TASKS, SC_EXT_LISTS, SC_EXT_FRAG, SC_EXT_MAT, SC_EXT_OPS, SC_EXT_RES
+};
+
+}  // namespace necat

@@ -1,0 +1,475 @@
+// seed_core.h - per-read candidate search (k-mer sampling -> block buckets -> DDF vote -> co-linear
+// gather -> chain DP -> candidate), the work one GPU lane does for one query read.
+//
+// Behaviour follows word_finder/word_finder.c:364 (find_candidates) and chain_dp.c:37 bit for bit;
+// the data structures do not: the reference keeps a DENSE ScoringBlock table of ref_bases/b entries
+// per worker (252 MB per thread for a 2 Gbp volume, word_finder.c:15-38), impossible for 10^5
+// concurrent lanes, so each lane owns a sparse open-addressing table block_id -> pool slot sized from
+// its own hit count, with the pool order doubling as the reference's first-touch list (blk_idx_list).
+#pragma once
+#include "dev_common.h"
+
+namespace necat {
+
+struct DevCand {          // GappedCandidate (gapped_candidate.h:9-19) with 32-bit coordinates
+    i32 qid, sid, qdir, score;
+    i32 qbeg, qend, qsize;
+    i32 sbeg, send, ssize;
+    i32 qoff, soff;
+};
+
+struct SBlock {           // ScoringBlock (word_finder_aux.h:19-25) + its blk_idx_list entry
+    short score;
+    short blk_offset[kBlkSeeds];
+    i32 kmer_id[kBlkSeeds];
+    i32 last_kmer_id;
+    i32 block_id;
+    i32 stale;            // blk_idx_list[].score (word_finder.c:103)
+    i32 slot;             // hash slot, for O(1) reset
+    i32 _pad;
+};
+
+struct SeedParams {
+    int k, z, block_size, s_cutoff, align_cutoff, num_candidates, job, pairwise;
+    int read_start_id, ref_start_id;
+};
+
+struct SeedScratch {      // all per-lane, sized from the lane's hit bound H (see seed.hip)
+    i32* ht_key;          // [ht_mask+1], -1 = empty
+    i32* ht_val;
+    u32 ht_mask;
+    SBlock* pool;         // [H]
+    u32 pool_cap;
+    u64* cs;              // chain seeds as soff<<32|qoff  [H+1]
+    i32 *f, *p, *t, *v;   // [H+1] each
+    u64* u;               // [H+1]
+    DevCand* lcan;        // [H+1]
+    u32 cs_cap;
+    DevCand* out;         // candidates of this read (both strands)
+    u32 out_cap;
+};
+
+constexpr int kSeedErrCapacity = -1;
+
+NECAT_HD u32 ht_hash(i32 key, u32 mask) { return ((u32)key * 2654435761u) & mask; }
+
+NECAT_HD SBlock* sb_find(const SeedScratch& S, i32 block_id)
+{
+    if (block_id < 0) return nullptr;
+    u32 h = ht_hash(block_id, S.ht_mask);
+    for (;;) {
+        i32 kx = S.ht_key[h];
+        if (kx == block_id) return S.pool + S.ht_val[h];
+        if (kx == -1) return nullptr;
+        h = (h + 1) & S.ht_mask;
+    }
+}
+NECAT_HD int sb_score(const SeedScratch& S, i32 block_id)
+{
+    SBlock* b = sb_find(S, block_id);
+    return b ? b->score : 0;
+}
+
+template <typename T>
+NECAT_HD void heap_sort_u64(T* a, int n)   // ascending
+{
+    for (int start = n / 2 - 1; start >= 0; --start) {
+        int root = start; T x = a[root];
+        for (;;) { int c = 2 * root + 1; if (c >= n) break; if (c + 1 < n && a[c] < a[c + 1]) ++c; if (!(x < a[c])) break; a[root] = a[c]; root = c; }
+        a[root] = x;
+    }
+    for (int end = n - 1; end > 0; --end) {
+        T x = a[end]; a[end] = a[0];
+        int root = 0;
+        for (;;) { int c = 2 * root + 1; if (c >= end) break; if (c + 1 < end && a[c] < a[c + 1]) ++c; if (!(x < a[c])) break; a[root] = a[c]; root = c; }
+        a[root] = x;
+    }
+}
+
+// GappedCandidate_PmScoreGT (pm_worker.c:16-24): true if a sorts before b
+NECAT_HD bool cand_pm_before(const DevCand& a, const DevCand& b)
+{
+    if (a.score != b.score) return a.score > b.score;
+    if (a.qdir != b.qdir) return a.qdir < b.qdir;
+    if (a.sid != b.sid) return a.sid < b.sid;
+    if (a.qoff != b.qoff) return a.qoff < b.qoff;
+    if (a.soff != b.soff) return a.soff < b.soff;
+    return false;
+}
+// GappedCandidate_cdpScoreGT (chain_dp.c:26-32)
+NECAT_HD bool cand_cdp_before(const DevCand& a, const DevCand& b)
+{
+    if (a.score != b.score) return a.score > b.score;
+    if (a.qoff != b.qoff) return a.qoff < b.qoff;
+    if (a.soff != b.soff) return a.soff < b.soff;
+    return false;
+}
+
+template <bool PM>
+NECAT_HD void sort_cands(DevCand* a, int n)   // heap sort with the comparator above (total orders)
+{
+    auto before = [](const DevCand& x, const DevCand& y) { return PM ? cand_pm_before(x, y) : cand_cdp_before(x, y); };
+    for (int start = n / 2 - 1; start >= 0; --start) {
+        int root = start; DevCand x = a[root];
+        for (;;) { int c = 2 * root + 1; if (c >= n) break; if (c + 1 < n && before(a[c], a[c + 1])) ++c; if (!before(x, a[c])) break; a[root] = a[c]; root = c; }
+        a[root] = x;
+    }
+    for (int end = n - 1; end > 0; --end) {
+        DevCand x = a[end]; a[end] = a[0];
+        int root = 0;
+        for (;;) { int c = 2 * root + 1; if (c >= end) break; if (c + 1 < end && before(a[c], a[c + 1])) ++c; if (!before(x, a[c])) break; a[root] = a[c]; root = c; }
+        a[root] = x;
+    }
+}
+
+NECAT_HD int ilog2_u32(u32 v)   // chain_dp.c:18-23, v > 0
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return 31 - __clz((int)v);
+#else
+    return 31 - __builtin_clz(v);
+#endif
+}
+
+// word_finder.c:141-168: quotient in float, "- 1.0" and the compare in double
+NECAT_HD bool ddf_ok(int dloc, int dseed, float scan_window)
+{
+    float q = (float)dloc / ((float)dseed * scan_window);
+    double d = (double)q - 1.0;
+    if (d < 0) d = -d;
+    return d < 0.25;
+}
+
+NECAT_HD int scoring_seeds(const int* t_loc, const int* t_seedn, int* t_score, int* loc, int k, int* rep_loc,
+                           float scan_window, int read_size)
+{
+    int i, j, maxval = 0, maxi = 0, rep = 0, lasti = 0, tempi;
+    for (i = 0; i < k; i++) t_score[i] = 0;
+    for (i = 0; i < k - 1; i++)
+        for (j = i + 1, tempi = t_seedn[i]; j < k; j++)
+            if (tempi != t_seedn[j] && t_seedn[j] - t_seedn[i] > 0 && t_loc[j] - t_loc[i] > 0 &&
+                t_loc[j] - t_loc[i] < read_size && ddf_ok(t_loc[j] - t_loc[i], t_seedn[j] - t_seedn[i], scan_window)) {
+                t_score[i]++; t_score[j]++; tempi = t_seedn[j];
+            }
+    for (i = 0; i < k; i++) {
+        if (maxval < t_score[i]) { maxval = t_score[i]; maxi = i; rep = 0; }
+        else if (maxval == t_score[i]) { rep++; lasti = i; }
+    }
+    for (i = 0; i < 4; i++) loc[i] = 0;
+    if (maxval >= 5 && rep == maxval) {
+        loc[0] = t_loc[maxi]; loc[1] = t_seedn[maxi]; *rep_loc = maxi; loc[2] = t_loc[lasti]; loc[3] = t_seedn[lasti];
+        return 1;
+    } else if (maxval >= 5 && rep != maxval) {
+        for (j = 0; j < maxi; j++)
+            if (t_seedn[maxi] - t_seedn[j] > 0 && t_loc[maxi] - t_loc[j] > 0 && t_loc[maxi] - t_loc[j] < read_size &&
+                ddf_ok(t_loc[maxi] - t_loc[j], t_seedn[maxi] - t_seedn[j], scan_window)) {
+                if (loc[0] == 0) { loc[0] = t_loc[j]; loc[1] = t_seedn[j]; *rep_loc = j; }
+                else { loc[2] = t_loc[j]; loc[3] = t_seedn[j]; }
+            }
+        j = maxi;
+        if (loc[0] == 0) { loc[0] = t_loc[j]; loc[1] = t_seedn[j]; *rep_loc = j; }
+        else { loc[2] = t_loc[j]; loc[3] = t_seedn[j]; }
+        for (j = maxi + 1; j < k; j++)
+            if (t_seedn[j] - t_seedn[maxi] > 0 && t_loc[j] - t_loc[maxi] > 0 && t_loc[j] - t_loc[maxi] <= read_size &&
+                ddf_ok(t_loc[j] - t_loc[maxi], t_seedn[j] - t_seedn[maxi], scan_window)) {
+                if (loc[0] == 0) { loc[0] = t_loc[j]; loc[1] = t_seedn[j]; *rep_loc = j; }
+                else { loc[2] = t_loc[j]; loc[3] = t_seedn[j]; }
+            }
+        return 1;
+    }
+    return 0;
+}
+
+// chain_dp.c:37-159.  Seeds are S.cs[0..n) sorted ascending by (soff, qoff); chains land in S.lcan.
+NECAT_HD int chain_dp(SeedScratch& S, int n_seeds, int kmer_size, int min_cnt, DevCand proto)
+{
+    const int max_dist = 5000, bw = 500, max_skip = 25, min_sc = 30;   // chain_dp.c:174-178
+    const u64* cs = S.cs;
+    i32 *f = S.f, *p = S.p, *t = S.t, *v = S.v;
+    for (int i = 0; i < n_seeds; ++i) { f[i] = 0; p[i] = -1; t[i] = 0; v[i] = 0; }
+    int i, j, k, st = 0;
+    for (i = 0; i < n_seeds; ++i) {
+        const i64 ri = (i64)(cs[i] >> 32), qi = (i64)(cs[i] & 0xffffffffu);
+        int max_j = -1, max_f = kmer_size, n_skip = 0;
+        while (st < i && ri - (i64)(cs[st] >> 32) > max_dist) ++st;
+        for (j = i - 1; j >= st; --j) {
+            const i64 rj = (i64)(cs[j] >> 32), qj = (i64)(cs[j] & 0xffffffffu);
+            if (ri <= rj || qi <= qj || qi - qj > max_dist) continue;
+            i64 dr = ri - rj, dq = qi - qj;
+            i64 dd = dr > dq ? dr - dq : dq - dr;
+            if (dd > bw) continue;
+            i64 min_d = dq < dr ? dq : dr;
+            int sc = (int)(min_d < kmer_size ? min_d : kmer_size);
+            int log_dd = dd ? ilog2_u32((u32)dd) : 0;
+            sc -= (int)((double)dd * 0.01 * (double)kmer_size) + (log_dd >> 1);
+            sc += f[j];
+            if (sc > max_f) {
+                max_f = sc; max_j = j;
+                if (n_skip > 0) --n_skip;
+            } else if (t[j] == i) {
+                if (++n_skip > max_skip) break;
+            }
+            if (p[j] >= 0) t[p[j]] = i;
+        }
+        f[i] = max_f; p[i] = max_j;
+        v[i] = (max_j >= 0 && v[max_j] > max_f) ? v[max_j] : max_f;
+    }
+    for (i = 0; i < n_seeds; ++i) t[i] = 0;
+    for (i = 0; i < n_seeds; ++i) if (p[i] >= 0) t[p[i]] = 1;
+    int n_u = 0;
+    for (i = 0; i < n_seeds; ++i) {
+        if (t[i] == 0 && v[i] >= min_sc) {
+            j = i;
+            while (j >= 0 && f[j] < v[j]) j = p[j];
+            if (j < 0) j = i;
+            // IntPair_ChainDpGT (chain_dp.c:8): first desc, second asc  -> ascending u64 key
+            S.u[n_u++] = ((u64)(u32)(0x7fffffff - f[j]) << 32) | (u32)j;
+        }
+    }
+    if (n_u == 0) return 0;
+    heap_sort_u64(S.u, n_u);
+    for (i = 0; i < n_seeds; ++i) t[i] = 0;
+    int n_v = 0, ncan = 0;
+    for (i = n_v = k = 0; i < n_u; ++i) {
+        int n_v0 = n_v, k0 = k;
+        const int first = 0x7fffffff - (int)(u32)(S.u[i] >> 32);
+        j = (int)(u32)(S.u[i] & 0xffffffffu);
+        DevCand can = proto;
+        can.qend = (i32)(cs[j] & 0xffffffffu) + kmer_size;
+        can.send = (i32)(cs[j] >> 32) + kmer_size;
+        can.qoff = can.qend; can.soff = can.send;
+        int last_j = j;
+        do { last_j = j; n_v++; t[j] = 1; j = p[j]; } while (j >= 0 && t[j] == 0);
+        bool emit = false;
+        if (j < 0) {
+            if (n_v - n_v0 >= min_cnt) { can.score = first; emit = true; }
+        } else if (first - f[j] >= min_sc) {
+            if (n_v - n_v0 >= min_cnt) { can.score = first - f[j]; emit = true; }
+        }
+        if (emit) {
+            can.qbeg = (i32)(cs[last_j] & 0xffffffffu); can.sbeg = (i32)(cs[last_j] >> 32);
+            S.lcan[ncan++] = can; ++k;
+        }
+        if (k0 == k) n_v = n_v0;
+    }
+    if (ncan > 1) sort_cands<false>(S.lcan, ncan);
+    return ncan;
+}
+
+// word_finder.c:171-182 (only touched blocks exist in the sparse table; zeroing an untouched block
+// is a no-op in the reference as well)
+NECAT_HD void clear_block_scores(const SeedScratch& S, const DevCand& can, u64 subject_start, int block_size)
+{
+    i64 sblk = (i64)(((u64)can.sbeg + subject_start) / (u64)block_size);
+    i64 eblk = (i64)(((u64)can.send + subject_start) / (u64)block_size);
+    for (i64 i = sblk; i <= eblk; ++i) { SBlock* b = sb_find(S, (i32)i); if (b) b->score = 0; }
+}
+
+// word_finder.c:184-360.  Returns 1 if a candidate was appended, 0 if not, <0 on capacity error.
+NECAT_HD int find_candidate_for_one_block(SeedScratch& S, SBlock* cur, const DevVolume& ref, const SeedParams& P,
+                                          int qid, int qdir, int qsize, int* n_out)
+{
+    int kmer_id_list[kBlkSeeds * 2], blk_offset_list[kBlkSeeds * 2], score_list[kBlkSeeds * 2];
+    const int block_id = cur->block_id;
+    const int bs = P.block_size, z = P.z;
+    int n_seeds = 0, A = 0;
+    u64 blk_start = (u64)bs * (u64)block_id;
+    SBlock* prev = sb_find(S, block_id - 1);
+    if (prev && prev->score) {
+        for (int i = 0; i < prev->score; ++i) { kmer_id_list[n_seeds] = prev->kmer_id[i]; blk_offset_list[n_seeds] = prev->blk_offset[i]; ++n_seeds; }
+        A = bs;
+        blk_start = (u64)bs * (u64)(block_id - 1);
+    }
+    for (int i = 0; i < cur->score; ++i) { kmer_id_list[n_seeds] = cur->kmer_id[i]; blk_offset_list[n_seeds] = cur->blk_offset[i] + A; ++n_seeds; }
+
+    int max_score_id = -1, sc4[4];
+    if (!scoring_seeds(blk_offset_list, kmer_id_list, score_list, sc4, n_seeds, &max_score_id, (float)z, qsize)) return 0;
+    if (score_list[max_score_id] < 2 * P.s_cutoff) return 0;
+
+    u64 seed_toff = (u64)sc4[0] + blk_start;
+    const i64 seed_qoff = (i64)(sc4[1] - 1) * z;
+    const int seed_bid = (int)(seed_toff / (u64)bs);
+    const u64 seed_tid = seq_of_offset(ref.seq_off, ref.nseq, seed_toff);
+    const u64 seed_tstart = ref.seq_off[seed_tid];
+    const u64 seed_tend = ref.seq_off[seed_tid + 1];
+    const i64 seed_tsize = (i64)(seed_tend - seed_tstart);
+    seed_toff -= seed_tstart;
+    const i64 stoff = (i64)seed_toff;
+    i64 L = stoff < seed_qoff ? stoff : seed_qoff;
+    int bid_start = seed_bid - (int)(L / bs) - 1;
+    if (bid_start < 0) bid_start = 0;
+    const i64 tr = seed_tsize - stoff, qr = (i64)qsize - seed_qoff;
+    L = tr < qr ? tr : qr;
+    const int bid_end = seed_bid + (int)((L + bs - 1) / bs);
+
+    int ncs = 0, seed_score = 0;
+    for (int i = bid_start; i <= seed_bid; ++i) {
+        SBlock* sb = sb_find(S, i);
+        if (!sb || !sb->score) continue;
+        const u64 bstart = (u64)i * (u64)bs;
+        int relevant = 0;
+        for (int k = 0; k < sb->score; ++k) {
+            u64 toff = bstart + (u64)(i64)sb->blk_offset[k];
+            const i64 qoff = (i64)(sb->kmer_id[k] - 1) * z;
+            if (toff < seed_tstart) continue;
+            toff -= seed_tstart;
+            if ((i64)toff < stoff && qoff < seed_qoff) {
+                double s = 1.0 * (double)(u64)(stoff - (i64)toff) / (double)(u64)(seed_qoff - qoff) - 1.0;
+                if (s < 0) s = -s;
+                if (!(s < 0.25)) continue;
+                ++relevant;
+                if ((u32)ncs >= S.cs_cap) return kSeedErrCapacity;
+                S.cs[ncs++] = (toff << 32) | (u64)(u32)qoff;
+            }
+        }
+        if (i != seed_bid && 1.0 * relevant / sb->score >= 0.4) sb->score = 0;
+        seed_score += relevant;
+    }
+    if ((u32)ncs >= S.cs_cap) return kSeedErrCapacity;
+    S.cs[ncs++] = ((u64)stoff << 32) | (u64)(u32)seed_qoff;
+    for (int i = seed_bid; i <= bid_end; ++i) {
+        SBlock* sb = sb_find(S, i);
+        if (!sb || !sb->score) continue;
+        const u64 bstart = (u64)i * (u64)bs;
+        int relevant = 0;
+        for (int k = 0; k < sb->score; ++k) {
+            u64 toff = bstart + (u64)(i64)sb->blk_offset[k];
+            const i64 qoff = (i64)(sb->kmer_id[k] - 1) * z;
+            if (toff >= seed_tend) continue;
+            toff -= seed_tstart;
+            if ((i64)toff > stoff && qoff > seed_qoff) {
+                double s = 1.0 * (double)(u64)((i64)toff - stoff) / (double)(u64)(qoff - seed_qoff) - 1.0;
+                if (s < 0) s = -s;
+                if (!(s < 0.25)) continue;
+                ++relevant;
+                if ((u32)ncs >= S.cs_cap) return kSeedErrCapacity;
+                S.cs[ncs++] = (toff << 32) | (u64)(u32)qoff;
+            }
+        }
+        if (i != seed_bid && 1.0 * relevant / sb->score >= 0.4) sb->score = 0;
+        seed_score += relevant;
+    }
+
+    heap_sort_u64(S.cs, ncs);   // ChainSeedLT: (soff, qoff) ascending
+    DevCand proto;
+    proto.qid = qid; proto.sid = (i32)seed_tid; proto.qdir = qdir; proto.score = 0;
+    proto.qbeg = proto.qend = 0; proto.qsize = qsize; proto.sbeg = proto.send = 0; proto.ssize = (i32)seed_tsize;
+    proto.qoff = proto.soff = 0;
+    const int ncan = chain_dp(S, ncs, P.k, P.s_cutoff, proto);
+    if (!ncan) return 0;
+
+    auto contains = [&](const DevCand& c) {
+        return seed_qoff >= c.qbeg && seed_qoff < c.qend && stoff >= c.sbeg && stoff < c.send;
+    };
+    DevCand can = S.lcan[0];
+    bool emit = contains(can);
+    if (!emit) {
+        int max_i = ncan, max_cov = 0;
+        for (int i = 0; i < ncan; ++i) {
+            can = S.lcan[i];
+            if (contains(can)) { int cov = can.qend - can.qbeg; if (cov > max_cov) { max_cov = cov; max_i = i; } }
+        }
+        // word_finder.c:335-343 emits `can` as the loop left it (the LAST chain), not lcanv[max_i]
+        if (max_i < ncan) emit = true;
+        else {
+            can = S.lcan[0];
+            if (can.qend - can.qbeg >= 5000) emit = true;
+        }
+    }
+    if (!emit) return 0;
+    can.score = seed_score; can.qoff = (i32)seed_qoff; can.soff = (i32)stoff;
+    clear_block_scores(S, can, seed_tstart, bs);
+    const bool ok = (can.send - can.sbeg >= P.align_cutoff) || (can.qend - can.qbeg >= P.align_cutoff);
+    if (ok) {
+        if ((u32)*n_out >= S.out_cap) return kSeedErrCapacity;
+        S.out[(*n_out)++] = can;
+    }
+    return ok ? 1 : 0;
+}
+
+// One strand of one read: word_finder.c:364-412 (find_candidates) incl. collect_seeds :107-139.
+// Candidates are appended to S.out with LOCAL ids.  Returns 0 or kSeedErrCapacity.
+NECAT_HD int seed_one_strand(const DevVolume& ref, const u64* kmer_stats, const u64* offset_list,
+                             const DevVolume& reads, int read_id, int qdir, const SeedParams& P,
+                             SeedScratch& S, int* n_out)
+{
+    const u64 q_goff = reads.seq_off[read_id];
+    const int L = (int)(reads.seq_off[read_id + 1] - q_goff);
+    u64 soff_max = ~0ULL;
+    if (P.pairwise) {
+        const int gid = read_id + P.read_start_id;
+        if (gid >= P.ref_start_id && gid < P.ref_start_id + (int)ref.nseq) soff_max = ref.seq_off[read_id];
+    }
+    int nblk = 0;
+    const int k = P.k, z = P.z, bs = P.block_size;
+    int kmer_i = 0;
+    for (int i = 0; i <= L - k; i += z, ++kmer_i) {
+        // extract_hash_values (word_finder.c:66-83): first base most significant
+        const u64 x = qdir == 0 ? load32_dir(reads.bases, (i64)q_goff + i, +1, 0)
+                                : load32_dir(reads.bases, (i64)q_goff + L - 1 - i, -1, 1);
+        const u64 hash = rev2(x) >> (64 - 2 * k);
+        const u64 st = kmer_stats[hash];                    // extract_kmer_list (lookup_table.c:176)
+        const u64 cnt = st >> kOffsetBits;
+        const u64* list = offset_list + (st & kOffsetMask);
+        for (u64 kk = 0; kk < cnt; ++kk) {
+            const u64 off = list[kk];
+            if (off >= soff_max) continue;
+            // fill_one_seed (word_finder.c:85-104)
+            const i32 blk_id = (i32)(off / (u64)bs);
+            const short blk_off = (short)(off % (u64)bs);
+            u32 h = ht_hash(blk_id, S.ht_mask);
+            SBlock* sb = nullptr;
+            for (;;) {
+                const i32 kx = S.ht_key[h];
+                if (kx == blk_id) { sb = S.pool + S.ht_val[h]; break; }
+                if (kx == -1) break;
+                h = (h + 1) & S.ht_mask;
+            }
+            if (!sb) {
+                if ((u32)nblk >= S.pool_cap) return kSeedErrCapacity;
+                sb = S.pool + nblk;
+                S.ht_key[h] = blk_id; S.ht_val[h] = nblk;
+                sb->score = 0; sb->last_kmer_id = -1; sb->block_id = blk_id; sb->stale = 0; sb->slot = (i32)h;
+                ++nblk;
+            }
+            if (sb->last_kmer_id >= kmer_i + 1) continue;
+            if (sb->score >= kBlkSeeds) continue;
+            const int sid = sb->score;
+            ++sb->score;
+            sb->blk_offset[sid] = blk_off;
+            sb->kmer_id[sid] = kmer_i + 1;
+            sb->last_kmer_id = kmer_i + 1;
+            sb->stale = sb->score + sb_score(S, blk_id - 1);
+        }
+    }
+    int rc = 0;
+    for (int i = 0; i < nblk; ++i) {
+        SBlock* sb = S.pool + i;
+        if (sb->score >= P.s_cutoff && sb->stale >= 2 * P.s_cutoff) {
+            int r = find_candidate_for_one_block(S, sb, ref, P, read_id, qdir, L, n_out);
+            if (r < 0) { rc = r; break; }
+        }
+    }
+    for (int i = 0; i < nblk; ++i) S.ht_key[S.pool[i].slot] = -1;   // clear_WordFindData (word_finder.c:40-52)
+    return rc;
+}
+
+// Both strands of one read + the per-read post-processing of pm_search_one_volume
+// (pm_worker.c:133-140 for job 1, :163-171 for job 0).  Returns the number of candidates left in
+// S.out (local ids), or <0 on capacity error.
+NECAT_HD int seed_one_read(const DevVolume& ref, const u64* kmer_stats, const u64* offset_list,
+                           const DevVolume& reads, int read_id, const SeedParams& P, SeedScratch& S)
+{
+    int n = 0;
+    int rc = seed_one_strand(ref, kmer_stats, offset_list, reads, read_id, 0, P, S, &n);
+    if (rc < 0) return rc;
+    rc = seed_one_strand(ref, kmer_stats, offset_list, reads, read_id, 1, P, S, &n);
+    if (rc < 0) return rc;
+    if (P.job == 1 || n > P.num_candidates) {
+        if (n > 1) sort_cands<true>(S.out, n);
+        if (n > P.num_candidates) n = P.num_candidates;
+    }
+    return n;
+}
+
+}  // namespace necat

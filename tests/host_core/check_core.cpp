@@ -1,0 +1,175 @@
+// check_core.cpp - TEST ONLY.  Compiles the product's per-lane kernel cores (necat_amd/csrc/*_core.h)
+// with g++ and replays them lane by lane on the CPU against the oracle, so kernel logic can be
+// validated on a machine without a GPU.  Nothing here is part of the product path.
+//
+// usage: check_core <wrk_dir> <vid> k z q b s n a e [max_reads]
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+
+#include "../../necat_amd/csrc/seed_core.h"
+#include "../../necat_amd/csrc/dp_core.h"
+#include "../../necat_amd/csrc/ext_core.h"
+extern "C" {
+#include "../../oracle/necat_oracle.h"
+}
+using namespace necat;
+
+struct HostVol { std::vector<u64> words; std::vector<u64> off; DevVolume dv; };
+
+static void make_vol(const ora_volume& v, HostVol& h)
+{
+    const int G = 4;
+    u64 nw = (v.nbases + 31) / 32;
+    h.words.assign(nw + 2 * G, 0);
+    for (u64 i = 0; i < v.nbases; ++i) {
+        u64 c = (v.pac[i >> 2] >> ((~i & 3) << 1)) & 3;
+        h.words[G + (i >> 5)] |= c << ((i & 31) * 2);
+    }
+    h.off.resize(v.nseq + 1);
+    for (u64 i = 0; i < v.nseq; ++i) h.off[i] = v.offset[i];
+    h.off[v.nseq] = v.nbases;
+    h.dv.bases = h.words.data() + G; h.dv.seq_off = h.off.data(); h.dv.nbases = v.nbases; h.dv.nseq = v.nseq;
+}
+
+// ---- host functors for the DP core (lane stride 1)
+struct HTgt { const u64* w; int code(int c) { return (int)((w[c >> 5] >> ((c & 31) * 2)) & 3); } };
+struct HMat {
+    std::vector<u64> P, M; std::vector<int> S, F, L; int nw;
+    void init(int cols, int nw_) { nw = nw_; P.assign((size_t)cols * nw, 0); M.assign((size_t)cols * nw, 0); S.assign((size_t)cols * nw, 0); F.assign(cols, 0); L.assign(cols, 0); }
+    void store(int c, int b, u64 p, u64 m, int s) { P[(size_t)c * nw + b] = p; M[(size_t)c * nw + b] = m; S[(size_t)c * nw + b] = s; }
+    void band(int c, int f, int l) { F[c] = f; L[c] = l; }
+    u64 Pr(int c, int b) const { return P[(size_t)c * nw + b]; }
+};
+struct HMatR {
+    const HMat* m;
+    u64 P(int c, int b) const { return m->P[(size_t)c * m->nw + b]; }
+    u64 M(int c, int b) const { return m->M[(size_t)c * m->nw + b]; }
+    int S(int c, int b) const { return m->S[(size_t)c * m->nw + b]; }
+    int first(int c) const { return m->F[c]; }
+    int last(int c) const { return m->L[c]; }
+};
+struct HOps { std::vector<int> v; void push(int op) { v.push_back(op); } };
+
+template <int NW, bool FULL>
+static MyersResult run_block(const DevVolume& reads, const DevVolume& ref, const FragGeom& g, int qn, int tn, double error, HMat& mat, u64* tw, MyersRegs<NW>& R)
+{
+    for (int b = 0; b < NW; ++b) {
+        u64 lo = 0, hi = 0;
+        if (b * 64 < qn) load64_planes(reads.bases, g.q_base, g.q_dir, g.q_comp, b * 64, &lo, &hi);
+        R.nlo[b] = ~lo; R.nhi[b] = ~hi;
+    }
+    for (int w = 0; w * 32 < tn; ++w) tw[w] = load32_dir(ref.bases, g.t_base + (i64)g.t_dir * (w * 32), g.t_dir, 0);
+    HTgt tg; tg.w = tw;
+    mat.init(tn, NW);
+    return myers_block<NW, FULL>(R, qn, tn, error, tg, mat);
+}
+
+struct HRops { const std::vector<int>* v; int operator()(int j) const { return (*v)[j]; } };
+template <int NW> struct HSame {
+    const MyersRegs<NW>* R; const u64* tw;
+    bool operator()(int i) const {
+        int q = (int)((~R->nlo[i >> 6] >> (i & 63)) & 1) | ((int)((~R->nhi[i >> 6] >> (i & 63)) & 1) << 1);
+        return q == (int)((tw[i >> 5] >> ((i & 31) * 2)) & 3);
+    }
+};
+
+int main(int argc, char** argv)
+{
+    if (argc < 11) { fprintf(stderr, "usage: %s wrk_dir vid k z q b s n a e [max_reads] [job]\n", argv[0]); return 2; }
+    const char* wrk = argv[1]; int vid = atoi(argv[2]);
+    ora_options opt; ora_options_default(&opt);
+    opt.kmer_size = atoi(argv[3]); opt.scan_window = atoi(argv[4]); opt.kmer_cnt_cutoff = atoi(argv[5]); opt.block_size = atoi(argv[6]);
+    opt.block_score_cutoff = atoi(argv[7]); opt.num_candidates = atoi(argv[8]); opt.align_size_cutoff = atoi(argv[9]); opt.error = atof(argv[10]);
+    int max_reads = argc > 11 ? atoi(argv[11]) : 1 << 30;
+    opt.job = argc > 12 ? atoi(argv[12]) : 1;
+    ora_volumes_info vi;
+    if (ora_volumes_info_load(wrk, &vi)) return 2;
+    ora_volume ref;
+    if (ora_volume_load(vi.names[vid], &ref)) return 2;
+    ora_index* ix = ora_index_build(&ref, opt.kmer_size, opt.kmer_cnt_cutoff);
+    HostVol href; make_vol(ref, href);
+    long bad_seed = 0, bad_ext = 0, n_cand = 0, n_blocks = 0, n_m4 = 0;
+    for (int v = vid; v < vi.num_volumes; ++v) {
+        ora_volume rd_own; const ora_volume* rd = &ref; HostVol hrd_own; const HostVol* hrd = &href;
+        if (v != vid) { if (ora_volume_load(vi.names[v], &rd_own)) return 2; rd = &rd_own; make_vol(rd_own, hrd_own); hrd = &hrd_own; }
+        ora_wfd* w = ora_wfd_new(ref.nbases, opt.block_size, opt.kmer_size, opt.block_score_cutoff);
+        ora_aligner* al = ora_aligner_new(opt.error);
+        ora_can_vec oc = {0, 0, 0};
+        std::vector<uint8_t> fwd, rev, subj;
+        SeedParams P; P.k = opt.kmer_size; P.z = opt.scan_window; P.block_size = opt.block_size; P.s_cutoff = opt.block_score_cutoff;
+        P.align_cutoff = opt.align_size_cutoff; P.num_candidates = opt.num_candidates; P.job = opt.job; P.pairwise = 1;
+        P.read_start_id = vi.read_start_id[v]; P.ref_start_id = vi.read_start_id[vid];
+        const int H = 1 << 20;
+        std::vector<i32> htk(4 * H, -1), htv(4 * H, 0); std::vector<SBlock> pool(H); std::vector<u64> cs(H + 1), uu(H + 1);
+        std::vector<i32> f(H + 1), p(H + 1), t(H + 1), vv(H + 1); std::vector<DevCand> lcan(H + 1), outc(H);
+        SeedScratch S; S.ht_key = htk.data(); S.ht_val = htv.data(); S.ht_mask = 4 * H - 1; S.pool = pool.data(); S.pool_cap = H;
+        S.cs = cs.data(); S.f = f.data(); S.p = p.data(); S.t = t.data(); S.v = vv.data(); S.u = uu.data(); S.lcan = lcan.data(); S.cs_cap = H + 1;
+        S.out = outc.data(); S.out_cap = H;
+        static MyersRegs<8> R8; static MyersRegs<13> R13; HMat mat; u64 tw[32];
+        int nreads = (int)std::min<u64>(rd->nseq, (u64)max_reads);
+        for (int r = 0; r < nreads; ++r) {
+            size_t L = rd->size[r];
+            fwd.resize(L + 1); rev.resize(L + 1);
+            oc.n = 0;
+            ora_volume_extract(rd, r, 0, fwd.data());
+            ora_find_candidates(fwd.data(), (int)L, r, 0, P.read_start_id, P.ref_start_id, 1, &ref, ix, &opt, w, &oc);
+            ora_volume_extract(rd, r, 1, rev.data());
+            ora_find_candidates(rev.data(), (int)L, r, 1, P.read_start_id, P.ref_start_id, 1, &ref, ix, &opt, w, &oc);
+            // oracle per-read post-processing (pm_worker.c:133-140 / :163-171)
+            std::vector<ora_candidate> ocv(oc.a, oc.a + oc.n);
+            auto before = [](const ora_candidate& a, const ora_candidate& b) {
+                if (a.score != b.score) return a.score > b.score; if (a.qdir != b.qdir) return a.qdir < b.qdir;
+                if (a.sid != b.sid) return a.sid < b.sid; if (a.qoff != b.qoff) return a.qoff < b.qoff; return a.soff < b.soff; };
+            if (opt.job == 1 || (int)ocv.size() > opt.num_candidates) { std::sort(ocv.begin(), ocv.end(), before); if ((int)ocv.size() > opt.num_candidates) ocv.resize(opt.num_candidates); }
+            int n = seed_one_read(href.dv, ix->kmer_stats, ix->offset_list, hrd->dv, r, P, S);
+            bool same = n == (int)ocv.size();
+            for (int i = 0; same && i < n; ++i) {
+                const DevCand& a = outc[i]; const ora_candidate& b = ocv[i];
+                same = a.qid == b.qid && a.sid == b.sid && a.qdir == b.qdir && a.score == b.score && a.qbeg == b.qbeg && a.qend == b.qend &&
+                       a.qsize == b.qsize && a.sbeg == b.sbeg && a.send == b.send && a.ssize == b.ssize && a.qoff == b.qoff && a.soff == b.soff;
+            }
+            if (!same) { if (bad_seed < 5) fprintf(stderr, "SEED MISMATCH read %d: core %d vs oracle %zu\n", r, n, ocv.size()); ++bad_seed; }
+            n_cand += n;
+            if (opt.job != 1) continue;
+            // extension of every candidate with both implementations
+            for (size_t ci = 0; ci < ocv.size(); ++ci) {
+                const ora_candidate& c = ocv[ci];
+                subj.resize((size_t)c.ssize + 1);
+                ora_volume_extract(&ref, (uint64_t)c.sid, 0, subj.data());
+                ora_align_result ar;
+                int ok = ora_onc_align(al, c.qdir == 0 ? fwd.data() : rev.data(), (int)c.qoff, (int)c.qsize, subj.data(), (int)c.soff, (int)c.ssize, 512, opt.align_size_cutoff, 1, &ar);
+                ExtTask tk;
+                ext_init(tk, 0, c.qdir, (i64)rd->offset[c.qid], (i32)c.qsize, (i64)ref.offset[c.sid], (i32)c.ssize, (i32)c.qoff, (i32)c.soff);
+                while (ext_plan(tk)) {
+                    FragGeom g = ext_frag_geom(tk);
+                    MyersResult mr; HOps ops; ++n_blocks;
+                    if (!tk.last && tk.qblk == 512 && tk.tblk == 512) {
+                        mr = run_block<8, true>(hrd->dv, href.dv, g, tk.qblk, tk.tblk, opt.error, mat, tw, R8);
+                        if (mr.dist >= 0) { HMatR m{&mat}; traceback_block(tk.qblk, mr.endc + 1, mr.dist, m, ops); }
+                        HRops ro{&ops.v}; HSame<8> sm{&R8, tw};
+                        ext_finish_block(tk, mr.dist, mr.endc, (int)ops.v.size(), 1, ro, sm);
+                    } else {
+                        mr = run_block<13, false>(hrd->dv, href.dv, g, tk.qblk, tk.tblk, opt.error, mat, tw, R13);
+                        if (mr.dist >= 0) { HMatR m{&mat}; traceback_block(tk.qblk, mr.endc + 1, mr.dist, m, ops); }
+                        HRops ro{&ops.v}; HSame<13> sm{&R13, tw};
+                        ext_finish_block(tk, mr.dist, mr.endc, (int)ops.v.size(), 1, ro, sm);
+                    }
+                    if (mr.err) { fprintf(stderr, "DP internal error %d\n", mr.err); ++bad_ext; }
+                }
+                double ident = tk.r_cols ? 100.0 * (double)tk.r_mat / (double)tk.r_cols : 0.0;
+                int ok2 = tk.r_cols >= opt.align_size_cutoff;
+                bool se = ok == ok2 && tk.r_qoff == ar.qoff && tk.r_qend == ar.qend && tk.r_toff == ar.toff && tk.r_tend == ar.tend && tk.r_cols == ar.align_size && ident == ar.ident_perc;
+                if (!se) { if (bad_ext < 5) fprintf(stderr, "EXT MISMATCH read %d cand %zu: core (%d %d %d %d cols %d id %.4f) oracle (%d %d %d %d cols %d id %.4f)\n", r, ci,
+                           tk.r_qoff, tk.r_qend, tk.r_toff, tk.r_tend, tk.r_cols, ident, ar.qoff, ar.qend, ar.toff, ar.tend, ar.align_size, ar.ident_perc); ++bad_ext; }
+                n_m4 += ok2;
+            }
+        }
+        ora_wfd_free(w); ora_aligner_free(al); free(oc.a);
+        if (v != vid) ora_volume_free(&rd_own);
+    }
+    printf("check_core: candidates=%ld blocks=%ld m4=%ld seed_mismatch=%ld ext_mismatch=%ld\n", n_cand, n_blocks, n_m4, bad_seed, bad_ext);
+    return (bad_seed || bad_ext) ? 1 : 0;
+}
