@@ -1,0 +1,90 @@
+"""Build helpers: compile the gfx950 library, the oc2pmov/oc2pm host programs and the test oracle.
+
+Everything is built IN-TREE (the .so / binaries travel to the GPU box with the source snapshot):
+  necat_amd/csrc/libnecat_hip.so   hipcc --offload-arch=gfx950   (the product)
+  necat_amd/csrc/oc2pmov, oc2pm    host programs on top of the C ABI
+  oracle/liboracle.so, oc2pmov_oracle, _ref/*   test infrastructure (oracle/Makefile)
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libnecat_hip.so")
+OC2PMOV = os.path.join(CSRC, "oc2pmov")
+OC2PM = os.path.join(CSRC, "oc2pm")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+
+HIP_SOURCES = ["necat_hip.hip"]
+HIP_DEPS = ["necat_hip.hip", "runtime.h", "dev_common.h", "index_kernels.h", "seed_core.h", "seed_kernels.h",
+            "dp_core.h", "ext_core.h", "ext_kernels.h", os.path.join(ROOT, "include", "necat_hip.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the gfx950 library cannot be built (there is no CPU fallback)")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    for d in deps:
+        p = d if os.path.isabs(d) else os.path.join(CSRC, d)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def _run(cmd, cwd=None):
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout)
+        raise RuntimeError("build step failed: %s" % " ".join(cmd))
+    return r.stdout
+
+
+def build_hip(force: bool = False) -> str:
+    if force or _stale(LIB, HIP_DEPS):
+        _run([_hipcc()] + HIPCC_FLAGS + ["-shared", "-o", LIB] + HIP_SOURCES, cwd=CSRC)
+    return LIB
+
+
+def build_cli(force: bool = False):
+    build_hip()
+    if force or _stale(OC2PMOV, ["oc2pmov_main.cpp", "host_io.h", LIB]):
+        _run([_hipcc(), "-O2", "-std=c++17", "-o", OC2PMOV, "oc2pmov_main.cpp", "-L" + CSRC, "-lnecat_hip",
+              "-Wl,-rpath,$ORIGIN", "-lpthread"], cwd=CSRC)
+    if force or _stale(OC2PM, ["oc2pm_main.cpp", "host_io.h"]):
+        _run([shutil.which("g++") or "g++", "-O2", "-std=c++17", "-o", OC2PM, "oc2pm_main.cpp"], cwd=CSRC)
+    return OC2PMOV, OC2PM
+
+
+def build_oracle(force: bool = False) -> str:
+    """liboracle.so (+ oracle/_ref when /root/reference is present).  Building the checker is not
+    using it: only tests/, smoke() and bench.py's cpu_baseline leg load these."""
+    args = ["make", "-s", "-C", ORACLE_DIR, "all"]
+    if force:
+        _run(["make", "-s", "-C", ORACLE_DIR, "clean"])
+    _run(args)
+    return ORACLE_LIB
+
+
+def build_all(force: bool = False):
+    build_hip(force)
+    build_cli(force)
+    build_oracle(False)
+
+
+if __name__ == "__main__":
+    build_all("--force" in sys.argv)
+    print("built:", LIB)

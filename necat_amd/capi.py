@@ -1,0 +1,335 @@
+"""ctypes binding of libnecat_hip.so (include/necat_hip.h) + a Python mirror of pm_main.
+
+The product is the C ABI and the oc2pmov program on top of it; this module only lets tests and
+bench.py drive the same entry points.  No computation happens in Python, and there is no CPU
+fallback: if the library or a GPU is missing every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import build as _build
+from .synth import read_volume
+
+
+class MapOptions(C.Structure):
+    """common/map_options.h:10-25"""
+    _fields_ = [("kmer_size", C.c_int), ("scan_window", C.c_int), ("kmer_cnt_cutoff", C.c_int),
+                ("block_size", C.c_int), ("block_score_cutoff", C.c_int), ("num_candidates", C.c_int),
+                ("align_size_cutoff", C.c_int), ("ddfs_cutoff", C.c_double), ("error", C.c_double),
+                ("num_output", C.c_int), ("num_threads", C.c_int), ("job", C.c_int),
+                ("binary_output", C.c_int), ("use_hdr_as_id", C.c_int)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("index_ms", C.c_double), ("seed_ms", C.c_double), ("extend_ms", C.c_double),
+                ("myers_ms", C.c_double), ("traceback_ms", C.c_double), ("myers_launches", C.c_uint64),
+                ("myers_blocks", C.c_uint64), ("myers_word_updates", C.c_uint64),
+                ("myers_cells_bases", C.c_uint64), ("rounds", C.c_uint64)]
+
+
+CANDIDATE_DTYPE = np.dtype([("qid", "<i4"), ("sid", "<i4"), ("qdir", "<i4"), ("sdir", "<i4"), ("score", "<i4"),
+                            ("_pad", "<i4"), ("qbeg", "<u8"), ("qend", "<u8"), ("qsize", "<u8"),
+                            ("sbeg", "<u8"), ("send", "<u8"), ("ssize", "<u8"), ("qoff", "<u8"), ("soff", "<u8")])
+M4_DTYPE = np.dtype([("qid", "<i4"), ("qdir", "<i4"), ("qoff", "<u8"), ("qend", "<u8"), ("qext", "<u8"),
+                     ("qsize", "<u8"), ("sid", "<i4"), ("sdir", "<i4"), ("soff", "<u8"), ("send", "<u8"),
+                     ("sext", "<u8"), ("ssize", "<u8"), ("ident_perc", "<f8"), ("vscore", "<i4"), ("_pad", "<i4")])
+assert CANDIDATE_DTYPE.itemsize == 88 and M4_DTYPE.itemsize == 96
+
+EXPORTED_SYMBOLS = [
+    "necat_default_options", "necat_ctx_create", "necat_ctx_destroy", "necat_last_error", "necat_device_name",
+    "necat_volume_upload", "necat_volume_free", "necat_index_build", "necat_index_size", "necat_index_download",
+    "necat_index_free", "necat_find_candidates", "necat_extend", "necat_edlib_align_batch", "necat_get_timings",
+    "necat_free",
+]
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen the in-tree library; never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = path or _build.LIB
+    if not os.path.exists(p):
+        raise RuntimeError("libnecat_hip.so is not built (%s): run `python -m necat_amd.build`" % p)
+    lib = C.CDLL(p)
+    vp, u64p, i32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)
+    lib.necat_default_options.argtypes = [C.POINTER(MapOptions)]
+    lib.necat_default_options.restype = None
+    lib.necat_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.necat_ctx_destroy.argtypes = [vp]
+    lib.necat_ctx_destroy.restype = None
+    lib.necat_last_error.argtypes = [vp]
+    lib.necat_last_error.restype = C.c_char_p
+    lib.necat_device_name.argtypes = [vp, C.c_char_p, C.c_size_t]
+    lib.necat_volume_upload.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.POINTER(vp)]
+    lib.necat_volume_free.argtypes = [vp, vp]
+    lib.necat_volume_free.restype = None
+    lib.necat_index_build.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.necat_index_size.argtypes = [vp, u64p, u64p]
+    lib.necat_index_download.argtypes = [vp, vp, vp, vp]
+    lib.necat_index_free.argtypes = [vp, vp]
+    lib.necat_index_free.restype = None
+    lib.necat_find_candidates.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(MapOptions),
+                                          C.POINTER(vp), u64p]
+    lib.necat_extend.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_uint64, C.POINTER(MapOptions), C.c_int,
+                                 C.POINTER(vp), u64p]
+    lib.necat_edlib_align_batch.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, C.c_double,
+                                            vp, vp, vp, C.POINTER(vp), C.POINTER(vp)]
+    lib.necat_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    lib.necat_free.argtypes = [vp]
+    lib.necat_free.restype = None
+    for name in EXPORTED_SYMBOLS:
+        getattr(lib, name)
+    _lib = lib
+    return lib
+
+
+def default_options(**kw) -> MapOptions:
+    o = MapOptions()
+    load_library().necat_default_options(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+class NecatError(RuntimeError):
+    pass
+
+
+class Context:
+    """necat_ctx + RAII wrappers of volumes and indexes."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        rc = self.lib.necat_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise NecatError("necat_ctx_create(device=%d) failed with %d: no usable gfx950 GPU "
+                             "(this library has no CPU fallback)" % (device, rc))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.necat_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise NecatError("%s failed (%d): %s" % (what, rc, self.lib.necat_last_error(self.h).decode()))
+
+    def device_name(self) -> str:
+        b = C.create_string_buffer(256)
+        self.lib.necat_device_name(self.h, b, 256)
+        return b.value.decode()
+
+    def timings(self) -> Timings:
+        t = Timings()
+        self.lib.necat_get_timings(self.h, C.byref(t))
+        return t
+
+    # ---- volumes
+    def upload_volume(self, pac: np.ndarray, nbases: int, offsets: np.ndarray, sizes: np.ndarray) -> "Volume":
+        pac = np.ascontiguousarray(pac, dtype=np.uint8)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        sz = np.ascontiguousarray(sizes, dtype=np.uint64)
+        h = C.c_void_p()
+        self._check(self.lib.necat_volume_upload(self.h, pac.ctypes.data, nbases, off.ctypes.data, sz.ctypes.data,
+                                                 off.shape[0], C.byref(h)), "necat_volume_upload")
+        return Volume(self, h, nbases, off.astype(np.int64), sz.astype(np.int64))
+
+    def load_volume(self, path: str) -> "Volume":
+        pac, off, sz, names = read_volume(path)
+        v = self.upload_volume(pac, int(sz.sum()), off, sz)
+        v.names = names
+        return v
+
+    def build_index(self, ref: "Volume", k: int, max_occ: int) -> "Index":
+        h = C.c_void_p()
+        self._check(self.lib.necat_index_build(self.h, ref.h, k, max_occ, C.byref(h)), "necat_index_build")
+        return Index(self, h, k)
+
+    def find_candidates(self, ix: "Index", ref: "Volume", reads: "Volume", read_start_id: int, ref_start_id: int,
+                        opt: MapOptions, pairwise: bool = True) -> np.ndarray:
+        p = C.c_void_p()
+        n = C.c_uint64()
+        self._check(self.lib.necat_find_candidates(self.h, ix.h, ref.h, reads.h, read_start_id, ref_start_id,
+                                                   1 if pairwise else 0, C.byref(opt), C.byref(p), C.byref(n)),
+                    "necat_find_candidates")
+        return self._take(p, n.value, CANDIDATE_DTYPE)
+
+    def extend(self, ref: "Volume", reads: "Volume", read_start_id: int, ref_start_id: int, cands: np.ndarray,
+               opt: MapOptions, tail_match_len: int = 1) -> np.ndarray:
+        cands = np.ascontiguousarray(cands, dtype=CANDIDATE_DTYPE)
+        p = C.c_void_p()
+        n = C.c_uint64()
+        self._check(self.lib.necat_extend(self.h, ref.h, reads.h, read_start_id, ref_start_id, cands.ctypes.data,
+                                          cands.shape[0], C.byref(opt), tail_match_len, C.byref(p), C.byref(n)),
+                    "necat_extend")
+        return self._take(p, n.value, M4_DTYPE)
+
+    def edlib_align_batch(self, seqs: np.ndarray, q_off, q_len, t_off, t_len, error: float = 0.5, want_ops: bool = True):
+        seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
+        q_off = np.ascontiguousarray(q_off, dtype=np.uint64)
+        t_off = np.ascontiguousarray(t_off, dtype=np.uint64)
+        q_len = np.ascontiguousarray(q_len, dtype=np.int32)
+        t_len = np.ascontiguousarray(t_len, dtype=np.int32)
+        n = q_off.shape[0]
+        dist = np.zeros(n, dtype=np.int32)
+        qend = np.zeros(n, dtype=np.int32)
+        tend = np.zeros(n, dtype=np.int32)
+        ops = C.c_void_p()
+        ops_off = C.c_void_p()
+        self._check(self.lib.necat_edlib_align_batch(self.h, seqs.ctypes.data, seqs.shape[0], q_off.ctypes.data,
+                                                     q_len.ctypes.data, t_off.ctypes.data, t_len.ctypes.data, n, error,
+                                                     dist.ctypes.data, qend.ctypes.data, tend.ctypes.data,
+                                                     C.byref(ops) if want_ops else None,
+                                                     C.byref(ops_off) if want_ops else None), "necat_edlib_align_batch")
+        o = oo = None
+        if want_ops and n:
+            oo = self._take(ops_off, n + 1, np.dtype("<u8"))
+            o = self._take(ops, int(oo[-1]), np.dtype("u1"))
+        return dist, qend, tend, o, oo
+
+    def _take(self, p: C.c_void_p, n: int, dtype: np.dtype) -> np.ndarray:
+        if not p.value:
+            return np.zeros(0, dtype=dtype)
+        if n:
+            buf = (C.c_char * (n * dtype.itemsize)).from_address(p.value)
+            arr = np.frombuffer(buf, dtype=dtype, count=n).copy()
+        else:
+            arr = np.zeros(0, dtype=dtype)
+        self.lib.necat_free(p)
+        return arr
+
+
+class Volume:
+    def __init__(self, ctx: Context, h, nbases: int, offsets: np.ndarray, sizes: np.ndarray):
+        self.ctx, self.h, self.nbases, self.offsets, self.sizes = ctx, h, nbases, offsets, sizes
+        self.names: List[str] = []
+
+    @property
+    def nseq(self) -> int:
+        return int(self.sizes.shape[0])
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.necat_volume_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Index:
+    def __init__(self, ctx: Context, h, k: int):
+        self.ctx, self.h, self.k = ctx, h, k
+
+    def sizes(self) -> Tuple[int, int]:
+        a, b = C.c_uint64(), C.c_uint64()
+        self.ctx.lib.necat_index_size(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def download(self, want_stats: bool = True) -> Tuple[Optional[np.ndarray], np.ndarray]:
+        T, n = self.sizes()
+        stats = np.empty(T, dtype=np.uint64) if want_stats else None
+        offs = np.empty(n, dtype=np.uint64)
+        self.ctx._check(self.ctx.lib.necat_index_download(self.ctx.h, self.h, stats.ctypes.data if want_stats else None,
+                                                          offs.ctypes.data if n else None), "necat_index_download")
+        return stats, offs
+
+    def free(self):
+        if self.h and self.ctx.h:
+            self.ctx.lib.necat_index_free(self.ctx.h, self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+# --------------------------------------------------------------------------------------------------
+# Python mirror of pm_main (pm_one_volume/pm_worker.c:338-400) for tests / bench: volume `vid`
+# against every volume >= vid, records returned instead of written.
+# --------------------------------------------------------------------------------------------------
+
+def load_volumes_info(wrk_dir: str):
+    """common/makedb_aux.c:78-118"""
+    base = wrk_dir if wrk_dir.endswith("/") else wrk_dir + "/"
+    with open(base + "reads_info.txt") as f:
+        nv, nr = [int(x) for x in f.read().split()[:2]]
+    vols = []
+    with open(base + "volume_names.txt") as f:
+        for _ in range(nv):
+            parts = f.readline().split()
+            vols.append((parts[0], int(parts[1]), int(parts[2])))
+    return nv, nr, vols
+
+
+def pack_candidates(c: np.ndarray) -> np.ndarray:
+    """pack_candidate (common/gapped_candidate.c:13-30): 7 x u32 records."""
+    out = np.zeros((c.shape[0], 7), dtype=np.uint32)
+    item0 = np.minimum(c["score"], 1000000).astype(np.uint32)
+    item0 |= (c["sdir"] == 1).astype(np.uint32) << 31
+    item0 |= (c["qdir"] == 1).astype(np.uint32) << 30
+    item0 |= (c["qoff"] == c["qbeg"]).astype(np.uint32) << 29
+    out[:, 0] = item0
+    out[:, 1] = c["sid"].astype(np.uint32)
+    out[:, 2] = c["sbeg"].astype(np.uint32)
+    out[:, 3] = c["send"].astype(np.uint32)
+    out[:, 4] = c["qid"].astype(np.uint32)
+    out[:, 5] = c["qbeg"].astype(np.uint32)
+    out[:, 6] = c["qend"].astype(np.uint32)
+    return out
+
+
+def m4_text_lines(m: np.ndarray) -> List[bytes]:
+    """DUMP_ASM_M4 (common/m4_record.h:72-97), numeric ids."""
+    return [b"%d\t%d\t%.2f\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n" %
+            (r["qid"], r["sid"], r["ident_perc"], r["vscore"], r["qdir"], r["qoff"], r["qend"], r["qsize"],
+             r["sdir"], r["soff"], r["send"], r["ssize"]) for r in m]
+
+
+def candidate_text_lines(c: np.ndarray) -> List[bytes]:
+    """DUMP_GAPPED_CANDIDATE (common/gapped_candidate.h:26-42)."""
+    return [b"%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n" %
+            (r["qid"], r["sid"], r["score"], r["qdir"], r["qbeg"], r["qend"], r["qoff"], r["qsize"], r["sdir"],
+             r["sbeg"], r["send"], r["soff"], r["ssize"]) for r in c]
+
+
+def pm_main(ctx: Context, opt: MapOptions, vid: int, wrk_dir: str):
+    """Returns (candidates, m4) over all volume pairs (vid, i >= vid); m4 is None for job 0."""
+    nv, _, vols = load_volumes_info(wrk_dir)
+    ref = ctx.load_volume(vols[vid][0])
+    ix = ctx.build_index(ref, opt.kmer_size, opt.kmer_cnt_cutoff)
+    cands, m4s = [], []
+    for i in range(vid, nv):
+        reads = ref if i == vid else ctx.load_volume(vols[i][0])
+        c = ctx.find_candidates(ix, ref, reads, vols[i][1], vols[vid][1], opt, True)
+        cands.append(c)
+        if opt.job == 1:
+            m4s.append(ctx.extend(ref, reads, vols[i][1], vols[vid][1], c, opt, 1))
+        if reads is not ref:
+            reads.free()
+    ix.free()
+    ref.free()
+    return np.concatenate(cands), (np.concatenate(m4s) if opt.job == 1 else None)

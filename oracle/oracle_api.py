@@ -1,0 +1,154 @@
+"""ctypes access to the oracle (oracle/liboracle.so) and to the reference build (oracle/_ref).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg - never by necat_amd/ (the product)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "liboracle.so")
+ORACLE_BIN = os.path.join(HERE, "oc2pmov_oracle")
+REF_PMOV = os.path.join(HERE, "_ref", "oc2pmov")
+REF_MKDB = os.path.join(HERE, "_ref", "oc2mkdb")
+REF_LIB = os.path.join(HERE, "_ref", "libnecat_ref.so")
+
+
+class OraOptions(C.Structure):
+    _fields_ = [("kmer_size", C.c_int), ("scan_window", C.c_int), ("kmer_cnt_cutoff", C.c_int),
+                ("block_size", C.c_int), ("block_score_cutoff", C.c_int), ("num_candidates", C.c_int),
+                ("align_size_cutoff", C.c_int), ("ddfs_cutoff", C.c_double), ("error", C.c_double),
+                ("num_output", C.c_int), ("num_threads", C.c_int), ("job", C.c_int),
+                ("binary_output", C.c_int), ("use_hdr_as_id", C.c_int)]
+
+
+class OraStats(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("aligned_qbases", C.c_uint64), ("t_index", C.c_double), ("t_map", C.c_double)]
+
+
+class OraVolume(C.Structure):
+    _fields_ = [("pac", C.c_void_p), ("nbases", C.c_uint64), ("nseq", C.c_uint64), ("offset", C.c_void_p),
+                ("size", C.c_void_p), ("hdr_offset", C.c_void_p), ("hdr", C.c_void_p), ("hdr_bytes", C.c_uint64)]
+
+
+class OraIndex(C.Structure):
+    _fields_ = [("kmer_stats", C.POINTER(C.c_uint64)), ("offset_list", C.POINTER(C.c_uint64)),
+                ("n_offsets", C.c_uint64), ("k", C.c_int)]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            subprocess.check_call(["make", "-s", "-C", HERE, "oracle"])
+        l = C.CDLL(LIB)
+        l.ora_options_default.argtypes = [C.POINTER(OraOptions)]
+        l.ora_pm_main.argtypes = [C.POINTER(OraOptions), C.c_int, C.c_char_p, C.c_char_p, C.POINTER(OraStats)]
+        l.ora_volume_load.argtypes = [C.c_char_p, C.POINTER(OraVolume)]
+        l.ora_volume_free.argtypes = [C.POINTER(OraVolume)]
+        l.ora_index_build.argtypes = [C.POINTER(OraVolume), C.c_int, C.c_int]
+        l.ora_index_build.restype = C.POINTER(OraIndex)
+        l.ora_index_free.argtypes = [C.POINTER(OraIndex)]
+        l.ora_aligner_new.argtypes = [C.c_double]
+        l.ora_aligner_new.restype = C.c_void_p
+        l.ora_aligner_free.argtypes = [C.c_void_p]
+        l.ora_edlib_align.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p,
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        _lib = l
+    return _lib
+
+
+def options(**kw) -> OraOptions:
+    o = OraOptions()
+    lib().ora_options_default(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def pm_main(opt: OraOptions, vid: int, wrk_dir: str, output: str) -> OraStats:
+    st = OraStats()
+    rc = lib().ora_pm_main(C.byref(opt), vid, wrk_dir.encode(), output.encode(), C.byref(st))
+    if rc != 0:
+        raise RuntimeError("oracle pm_main failed (%d)" % rc)
+    return st
+
+
+def build_index(volume_path: str, k: int, max_occ: int):
+    """Returns (kmer_stats copy, offset_list copy)."""
+    v = OraVolume()
+    if lib().ora_volume_load(volume_path.encode(), C.byref(v)) != 0:
+        raise RuntimeError("oracle cannot load " + volume_path)
+    ix = lib().ora_index_build(C.byref(v), k, max_occ)
+    T = 1 << (2 * k)
+    stats = np.ctypeslib.as_array(ix.contents.kmer_stats, shape=(T,)).copy()
+    n = int(ix.contents.n_offsets)
+    offs = np.ctypeslib.as_array(ix.contents.offset_list, shape=(max(n, 1),))[:n].copy()
+    lib().ora_index_free(ix)
+    lib().ora_volume_free(C.byref(v))
+    return stats, offs
+
+
+_OPS = {"M": 0, "I": 1, "D": 2, "X": 3}
+
+
+def edlib_align(query: np.ndarray, target: np.ndarray, error: float = 0.5):
+    """Edlib_align on byte-coded sequences: (ok, dist, qend, tend, ops[uint8]) with the op codes of
+    include/necat_hip.h (0 match, 1 ins, 2 del, 3 mismatch)."""
+    l = lib()
+    a = l.ora_aligner_new(error)
+    q = np.ascontiguousarray(query, dtype=np.uint8)
+    t = np.ascontiguousarray(target, dtype=np.uint8)
+    qa = C.create_string_buffer(8192)
+    ta = C.create_string_buffer(8192)
+    qe, te, d = C.c_int(), C.c_int(), C.c_int()
+    ok = l.ora_edlib_align(a, q.ctypes.data, q.shape[0], t.ctypes.data, t.shape[0], qa, ta, C.byref(qe), C.byref(te), C.byref(d))
+    l.ora_aligner_free(a)
+    ops = []
+    if ok:
+        for x, y in zip(qa.value, ta.value):
+            if x == 45:
+                ops.append(2)
+            elif y == 45:
+                ops.append(1)
+            else:
+                ops.append(0 if x == y else 3)
+    return bool(ok), d.value, qe.value, te.value, np.asarray(ops, dtype=np.uint8)
+
+
+def have_ref() -> bool:
+    return os.path.exists(REF_PMOV)
+
+
+def opt_argv(o) -> List[str]:
+    """MapOptions2String (common/map_options.c:70-87)"""
+    return ["-k", str(o.kmer_size), "-z", str(o.scan_window), "-q", str(o.kmer_cnt_cutoff), "-b", str(o.block_size),
+            "-s", str(o.block_score_cutoff), "-n", str(o.num_candidates), "-a", str(o.align_size_cutoff),
+            "-d", "%f" % o.ddfs_cutoff, "-e", "%f" % o.error, "-m", str(o.num_output), "-t", str(o.num_threads),
+            "-j", str(o.job), "-u", str(o.binary_output), "-i", str(o.use_hdr_as_id)]
+
+
+def run_ref(o, vid: int, wrk_dir: str, output: str, binary: Optional[str] = None) -> float:
+    """Run the compiled reference oc2pmov; returns the 'pairwise mapping' seconds summed from its log."""
+    out = subprocess.run([binary or REF_PMOV] + opt_argv(o) + [wrk_dir, str(vid), output], check=True,
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+    t = 0.0
+    for line in out.splitlines():
+        if "'pairwise mapping" in line and "takes" in line:
+            t += float(line.split("takes")[1].split("secs")[0])
+    return t
+
+
+def sorted_records(path: str, binary_size: int = 0) -> List[bytes]:
+    b = open(path, "rb").read()
+    if binary_size:
+        return sorted(b[i:i + binary_size] for i in range(0, len(b), binary_size))
+    return sorted(b.splitlines(keepends=True))

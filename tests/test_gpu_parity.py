@@ -1,0 +1,204 @@
+"""GPU parity tests: every stage of the HIP path, called through the C ABI, against the oracle on the
+same seeded inputs (bit-exact: integer / index work; ident_perc is an exactly reproducible IEEE
+quotient, compared with ==)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import util
+from oracle import oracle_api as ora
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small(tmp_path_factory):
+    d, rs, nv = util.make_dataset(tmp_path_factory.mktemp("small"), genome=150_000, coverage=18.0, seed=5)
+    return d, rs
+
+
+@pytest.fixture(scope="module")
+def multi(tmp_path_factory):
+    d, rs, nv = util.make_dataset(tmp_path_factory.mktemp("multi"), genome=200_000, coverage=20.0, seed=11, err=0.10,
+                                  repeat_frac=0.05, vol_size=1_500_000)
+    assert nv >= 3
+    return d, rs, nv
+
+
+def test_index_matches_oracle(ctx, small):
+    d, rs = small
+    vol = ctx.load_volume(os.path.join(d, "vol0"))
+    for k, q in ((11, 50), (13, 500)):
+        ix = ctx.build_index(vol, k, q)
+        stats, offs = ix.download()
+        ostats, ooffs = ora.build_index(os.path.join(d, "vol0"), k, q)
+        assert np.array_equal(stats, ostats)
+        assert np.array_equal(offs, ooffs)
+        ix.free()
+    vol.free()
+
+
+def _oracle_records(opt_kw, d, vid, tmp_path, job, binary):
+    o = ora.options(**dict(opt_kw, job=job, binary_output=binary))
+    out = os.path.join(str(tmp_path), "o_%d_%d_%d.out" % (vid, job, binary))
+    st = ora.pm_main(o, vid, d, out)
+    return out, st
+
+
+@pytest.mark.parametrize("preset", ["FAST", "SENSITIVE"])
+def test_candidates_match_oracle(ctx, small, tmp_path, preset):
+    from necat_amd import capi
+    d, rs = small
+    kw = getattr(util, preset)
+    out, st = _oracle_records(kw, d, 0, tmp_path, 0, 1)
+    opt = capi.default_options(**dict(kw, job=0, binary_output=1))
+    cands, _ = capi.pm_main(ctx, opt, 0, d)
+    mine = sorted(bytes(r) for r in capi.pack_candidates(cands).astype("<u4"))
+    assert len(mine) == st.n_records
+    assert mine == ora.sorted_records(out, 28)
+    assert len(mine) > 500
+
+
+def test_m4_matches_oracle(ctx, small, tmp_path):
+    from necat_amd import capi
+    d, rs = small
+    out, st = _oracle_records(util.FAST, d, 0, tmp_path, 1, 1)
+    opt = capi.default_options(**dict(util.FAST, job=1))
+    _, m4 = capi.pm_main(ctx, opt, 0, d)
+    ref = np.frombuffer(open(out, "rb").read(), dtype=capi.M4_DTYPE)
+    assert m4.shape[0] == ref.shape[0] == st.n_records
+    assert util.m4_key_rows(m4) == util.m4_key_rows(ref)
+    assert int((m4["qend"] - m4["qoff"]).sum()) == st.aligned_qbases
+
+
+def test_multi_volume_all_pairs(ctx, multi, tmp_path):
+    from necat_amd import capi
+    d, rs, nv = multi
+    kw = dict(util.SENSITIVE, kmer_size=12, kmer_cnt_cutoff=200)
+    for vid in range(nv):
+        out, st = _oracle_records(kw, d, vid, tmp_path, 1, 1)
+        opt = capi.default_options(**dict(kw, job=1))
+        _, m4 = capi.pm_main(ctx, opt, vid, d)
+        ref = np.frombuffer(open(out, "rb").read(), dtype=capi.M4_DTYPE)
+        assert util.m4_key_rows(m4) == util.m4_key_rows(ref), "volume %d" % vid
+
+
+def test_truncation_to_num_candidates(ctx, small, tmp_path):
+    """-n smaller than the per-read candidate count exercises the sort + cut of pm_worker.c:168-171."""
+    from necat_amd import capi
+    d, rs = small
+    kw = dict(util.FAST, num_candidates=3)
+    for job in (0, 1):
+        out, st = _oracle_records(kw, d, 0, tmp_path, job, 1)
+        opt = capi.default_options(**dict(kw, job=job))
+        c, m4 = capi.pm_main(ctx, opt, 0, d)
+        if job == 0:
+            assert sorted(bytes(r) for r in capi.pack_candidates(c).astype("<u4")) == ora.sorted_records(out, 28)
+        else:
+            ref = np.frombuffer(open(out, "rb").read(), dtype=capi.M4_DTYPE)
+            assert util.m4_key_rows(m4) == util.m4_key_rows(ref)
+
+
+def _random_pairs(rng, n, qlo, qhi, err):
+    seqs, qo, ql, to, tl = [], [], [], [], []
+    pos = 0
+    from necat_amd.synth import _mutate
+    for _ in range(n):
+        L = int(rng.integers(qlo, qhi + 1))
+        t = rng.integers(0, 4, L, dtype=np.uint8)
+        q = _mutate(t, err, rng)[:794]
+        if q.shape[0] == 0:
+            q = t[:1].copy()
+        extra = rng.integers(0, 4, int(rng.integers(0, 60)), dtype=np.uint8)
+        t = np.concatenate([t, extra])[:794]
+        seqs += [q, t]
+        qo.append(pos); ql.append(q.shape[0]); pos += q.shape[0]
+        to.append(pos); tl.append(t.shape[0]); pos += t.shape[0]
+    return np.concatenate(seqs), qo, ql, to, tl
+
+
+def test_edlib_blocks_match_oracle(ctx):
+    """The dominant kernel in isolation: distance, end column and the full edit path, including
+    ragged sizes (1..794), failures (too divergent) and exact 512 x 512 blocks (the FULL kernel)."""
+    rng = np.random.default_rng(2024)
+    seqs, qo, ql, to, tl = _random_pairs(rng, 300, 1, 794, 0.15)
+    # query much longer than the target: distance >= |q| - |t| > k = 0.55 * min(|q|, |t|) -> Edlib_align fails
+    s2, qo2, ql2, to2, tl2 = [], [], [], [], []
+    p2 = 0
+    for _ in range(40):
+        q = rng.integers(0, 4, int(rng.integers(500, 794)), dtype=np.uint8)
+        t = rng.integers(0, 4, int(rng.integers(50, 250)), dtype=np.uint8)
+        s2 += [q, t]
+        qo2.append(p2); ql2.append(q.shape[0]); p2 += q.shape[0]
+        to2.append(p2); tl2.append(t.shape[0]); p2 += t.shape[0]
+    s2 = np.concatenate(s2)
+    base = seqs.shape[0]
+    # exact 512 x 512 blocks cut from longer pairs
+    full_q, full_t = [], []
+    from necat_amd.synth import _mutate
+    for _ in range(200):
+        t = rng.integers(0, 4, 700, dtype=np.uint8)
+        q = _mutate(t, 0.13, rng)
+        if q.shape[0] >= 512:
+            full_q.append(q[:512]); full_t.append(t[:512])
+    allseq = [seqs, s2] + [x for p in zip(full_q, full_t) for x in p]
+    qo += [o + base for o in qo2]; to += [o + base for o in to2]; ql += ql2; tl += tl2
+    pos = base + s2.shape[0]
+    for _ in full_q:
+        qo.append(pos); ql.append(512); pos += 512
+        to.append(pos); tl.append(512); pos += 512
+    allseq = np.concatenate(allseq)
+    dist, qend, tend, ops, ops_off = ctx.edlib_align_batch(allseq, qo, ql, to, tl, 0.5)
+    nfail = 0
+    for i in range(len(qo)):
+        q = allseq[qo[i]:qo[i] + ql[i]]
+        t = allseq[to[i]:to[i] + tl[i]]
+        ok, d, qe, te, oops = ora.edlib_align(q, t, 0.5)
+        if not ok:
+            assert dist[i] == -1, i
+            nfail += 1
+            continue
+        assert (dist[i], qend[i], tend[i]) == (d, qe, te), i
+        assert np.array_equal(ops[ops_off[i]:ops_off[i + 1]], oops), i
+    assert nfail >= 40 and nfail < len(qo) // 2
+    tm = ctx.timings()
+    assert tm.myers_word_updates > 0
+
+
+def test_empty_and_tiny_inputs(ctx, tmp_path):
+    """Edge cases: reads shorter than k, a volume with a single read, no candidates at all."""
+    from necat_amd import capi, synth
+    rng = np.random.default_rng(1)
+    reads = [rng.integers(0, 4, n, dtype=np.uint8) for n in (5, 3000, 12, 4000)]
+    sizes = np.array([r.shape[0] for r in reads], dtype=np.int64)
+    rs = synth.ReadSet(np.concatenate(reads), np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64), sizes,
+                       ["a", "b", "c", "d"])
+    d = os.path.join(str(tmp_path), "tiny")
+    synth.write_volume_dir(d, rs)
+    opt = capi.default_options(**dict(util.FAST, job=1))
+    c, m4 = capi.pm_main(ctx, opt, 0, d)
+    assert c.shape[0] == 0 and m4.shape[0] == 0
+    # identical reads: every later read overlaps every earlier one end to end
+    base = rng.integers(0, 4, 5000, dtype=np.uint8)
+    rs2 = synth.ReadSet(np.concatenate([base] * 3), np.array([0, 5000, 10000]), np.array([5000] * 3), ["x", "y", "z"])
+    d2 = os.path.join(str(tmp_path), "same")
+    synth.write_volume_dir(d2, rs2)
+    o = ora.options(**dict(util.FAST, job=1, binary_output=1))
+    out = os.path.join(str(tmp_path), "same.out")
+    ora.pm_main(o, 0, d2, out)
+    ref = np.frombuffer(open(out, "rb").read(), dtype=capi.M4_DTYPE)
+    c, m4 = capi.pm_main(ctx, opt, 0, d2)
+    assert util.m4_key_rows(m4) == util.m4_key_rows(ref)
+    assert m4.shape[0] == 3 and np.all(m4["ident_perc"] == 100.0)
+
+
+def test_bad_arguments_fail_loudly(ctx):
+    from necat_amd import capi
+    pac = np.zeros(10, dtype=np.uint8)
+    with pytest.raises(capi.NecatError):
+        ctx.upload_volume(pac, 40, np.array([0, 30]), np.array([20, 20]))     # gap between reads
+    vol = ctx.upload_volume(pac, 40, np.array([0, 20]), np.array([20, 20]))
+    with pytest.raises(capi.NecatError):
+        ctx.build_index(vol, 16, 500)                                          # HashBits = 30
+    vol.free()
