@@ -1,0 +1,209 @@
+#!/usr/bin/env python
+"""bench.py - overlaps/sec of the all-vs-all overlap stage (oc2pmov path) on MI355X.
+
+One "step" = one full pass of the hot path over one reference volume that is already resident in
+HBM: k-mer index build -> candidate search (both strands of every read) -> block-wise banded Myers
+extension -> M4 records back on the host.  Workload at N=1 = BASELINE.json configs[1]:
+E. coli-size (4.6 Mb) 40x synthetic ONT reads, OVLP_FAST_OPTIONS with -j 1 (M4 output).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns one independent
+reference volume of the same size (seed + rank) - the unit necat.pl itself distributes
+(necat.pl:190-202) - so there is no data-path collective and scaling is weak; the barrier and the
+max-over-ranks time follow the driver's contract.
+
+Prints ONE JSON line (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz (32-bit integer lane-ops)
+OPS_PER_WORD_UPDATE = 45       # 32-bit VALU ops of one 64-row Myers word update
+
+FAST = dict(kmer_size=15, scan_window=20, kmer_cnt_cutoff=500, block_size=2000, block_score_cutoff=3,
+            num_candidates=500, align_size_cutoff=1000, ddfs_cutoff=0.25, error=0.5, num_output=500,
+            use_hdr_as_id=0)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--genome", type=int, default=4_600_000)
+    ap.add_argument("--coverage", type=float, default=40.0)
+    ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--kmer", type=int, default=15)
+    ap.add_argument("--scan-window", type=int, default=20)
+    ap.add_argument("--job", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-genome", type=int, default=460_000, help="genome size of the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def dist_setup(args):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist_.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        dist = dist_
+    return rank, world, local, dist
+
+
+def barrier_sync(dist, local):
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize(local)
+    except ImportError:
+        pass
+    if dist is not None:
+        dist.barrier()
+
+
+def cpu_baseline(args, opt_kw):
+    """The reference's own oc2pmov (oracle/_ref, built from /root/reference) - or, when absent, the
+    oracle port - timed on this host's cores on a bounded sample of the same workload."""
+    from necat_amd import synth
+    from oracle import oracle_api as ora
+    cores = os.cpu_count() or 1
+    tmp = tempfile.mkdtemp(prefix="necat_cpu_")
+    rs = synth.simulate_reads(args.cpu_genome, args.coverage, seed=args.seed)
+    d = os.path.join(tmp, "vols")
+    synth.write_volume_dir(d, rs)
+    o = ora.options(**dict(opt_kw, job=args.job, binary_output=0, num_threads=cores))
+    out = os.path.join(tmp, "out.txt")
+    kind = "reference" if ora.have_ref() else "port"
+    t0 = time.time()
+    if kind == "reference":
+        t_map = ora.run_ref(o, 0, d, out)
+        wall = time.time() - t0
+    else:
+        st = ora.pm_main(o, 0, d, out)
+        wall = time.time() - t0
+        t_map = st.t_map
+    nrec = sum(1 for _ in open(out, "rb"))
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    return {"value": round(nrec / max(t_map, 1e-9), 1), "unit": "overlaps/s", "cores": cores, "kind": kind,
+            "sample": "%.2f Mb genome x %.0fx (%d reads, %d bp), same options; mapping phase %.2f s "
+                      "(index build excluded, as in the reference's own 'pairwise mapping' timer); whole process %.1f s"
+                      % (args.cpu_genome / 1e6, args.coverage, rs.nreads, rs.nbases, t_map, wall),
+            "overlaps": nrec, "mapping_s": round(t_map, 3), "whole_process_s": round(wall, 2)}
+
+
+def main():
+    args = parse()
+    rank, world, local, dist = dist_setup(args)
+    from necat_amd import build, capi, synth
+    build.build_hip()
+    opt_kw = dict(FAST, kmer_size=args.kmer, scan_window=args.scan_window)
+    opt = capi.default_options(**dict(opt_kw, job=args.job, num_threads=1))
+    # ---- synthetic volume of this rank, made resident in HBM before the clock starts
+    rs = synth.simulate_reads(args.genome, args.coverage, seed=args.seed + 1000 * rank)
+    pac = synth.pack_2bit(rs.codes)
+    ctx = capi.Context(local)
+    vol = ctx.upload_volume(pac, rs.nbases, rs.offsets, rs.sizes)
+
+    def step():
+        ix = ctx.build_index(vol, opt.kmer_size, opt.kmer_cnt_cutoff)
+        t_index = ctx.timings().index_ms
+        cands = ctx.find_candidates(ix, vol, vol, 0, 0, opt, True)
+        m4 = ctx.extend(vol, vol, 0, 0, cands, opt, 1) if args.job == 1 else None
+        tm = ctx.timings()
+        ix.free()
+        return cands, m4, t_index, tm
+
+    for _ in range(args.warmup):
+        step()
+    barrier_sync(dist, local)
+    t0 = time.perf_counter()
+    agg = dict(index_ms=0.0, seed_ms=0.0, extend_ms=0.0, myers_ms=0.0, traceback_ms=0.0, launches=0, blocks=0, words=0, bases=0, rounds=0)
+    n_over = 0
+    gbp = 0.0
+    for _ in range(args.steps):
+        cands, m4, t_index, tm = step()
+        n_over += (m4.shape[0] if m4 is not None else cands.shape[0])
+        if m4 is not None:
+            gbp += float((m4["qend"] - m4["qoff"]).sum()) / 1e9
+        agg["index_ms"] += t_index; agg["seed_ms"] += tm.seed_ms; agg["extend_ms"] += tm.extend_ms
+        agg["myers_ms"] += tm.myers_ms; agg["traceback_ms"] += tm.traceback_ms; agg["launches"] += tm.myers_launches
+        agg["blocks"] += tm.myers_blocks; agg["words"] += tm.myers_word_updates; agg["bases"] += tm.myers_cells_bases
+        agg["rounds"] += tm.rounds
+    barrier_sync(dist, local)
+    elapsed = time.perf_counter() - t0
+    tot_over, tot_gbp = n_over, gbp
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed, float(n_over), gbp], dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0]); tot_over = float(t[1]); tot_gbp = float(t[2])
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    K = max(1, args.steps)
+    # ---- roofline of the dominant kernel (k_myers): algorithmic HBM bytes per launch / launch time.
+    # A block alignment must read its two 2-bit fragments and write one 16-byte result (SURVEY.md §8d
+    # "extension" row restated per block); everything else it touches is its own scratch.
+    alg_bytes = agg["bases"] / 4.0 + 16.0 * agg["blocks"]
+    launches = max(1, agg["launches"])
+    avg_launch_ms = agg["myers_ms"] / launches
+    achieved = (alg_bytes / launches) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    word_rate = agg["words"] / (agg["myers_ms"] * 1e-3) if agg["myers_ms"] > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_myers", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                "launches": int(agg["launches"]), "avg_launch_ms": round(avg_launch_ms, 4),
+                "algorithmic_bytes_per_launch": round(alg_bytes / launches, 1),
+                "word_updates_per_s": round(word_rate, 1),
+                "valu_frac": round(word_rate * OPS_PER_WORD_UPDATE / VALU_LANE_OPS_PER_S, 4),
+                "note": "integer DP: HBM fraction is small by construction (SURVEY.md 8d); valu_frac = word updates x %d "
+                        "lane-ops / (256 CU x 128 lanes x 2.4 GHz)" % OPS_PER_WORD_UPDATE}
+    out = {
+        "metric": "overlaps/sec (all-vs-all, index build + seeding + banded Myers extension -> M4)",
+        "value": round(tot_over / elapsed, 1), "unit": "overlaps/s",
+        "gbp_aligned_per_s": round(tot_gbp / elapsed, 4),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / K, 2),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "E. coli-size %.1f Mb genome, %.0fx synthetic ONT reads (12%% errors), %d reads / %d bp per GPU, "
+                               "OVLP_FAST_OPTIONS (-k %d -z %d -q 500 -b 2000 -s 3 -n 500 -a 1000 -e 0.5) with -j %d; one reference volume per GPU"
+                               % (args.genome / 1e6, args.coverage, rs.nreads, rs.nbases, args.kmer, args.scan_window, args.job),
+                   "overlaps_per_step_per_gpu": n_over // K, "parallelism": "volume-per-gpu x%d" % world},
+        "phases_ms_per_step": {"index": round(agg["index_ms"] / K, 2), "seed": round(agg["seed_ms"] / K, 2),
+                               "extend": round(agg["extend_ms"] / K, 2), "myers_kernel": round(agg["myers_ms"] / K, 2),
+                               "traceback_kernel": round(agg["traceback_ms"] / K, 2), "rounds": agg["rounds"] // K},
+        "device": ctx.device_name(),
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(args, opt_kw)
+        except Exception as e:  # the baseline is a reported extra; never fail the GPU measurement on it
+            out["cpu_baseline"] = {"value": None, "unit": "overlaps/s", "cores": os.cpu_count(), "kind": "unavailable", "sample": str(e)}
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -158,7 +158,7 @@ NECAT_D void slab_pointers(char* slab, int lane, ulonglong2*& pm, i16*& sc, u16*
 template <int NW, int TW, int COLS, bool FULL>
 __global__ void __launch_bounds__(64)
 k_myers(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
-        double error, BlockResult* __restrict__ results)
+        double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats)
 {
     constexpr int FW = 2 * NW + TW;
     const u32 grp = blockIdx.x;
@@ -182,6 +182,12 @@ k_myers(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag
     const MyersResult r = myers_block<NW, FULL>(R, qn, tn, error, tg, mw);
     BlockResult br; br.dist = r.dist; br.endc = r.endc; br.err = r.err; br.words = r.words;
     results[item] = br;
+    // work counters for the roofline report: one atomic per wave
+    u32 w = r.words, bases = (u32)(qn + tn);
+    if ((u64)n - (u64)grp * 64 >= 64) {      // full wave: every lane is alive, shuffles are safe
+        for (int o = 32; o > 0; o >>= 1) { w += __shfl_down(w, o); bases += __shfl_down(bases, o); }
+        if (lane == 0) { atomicAdd(&stats[0], (unsigned long long)w); atomicAdd(&stats[1], (unsigned long long)bases); }
+    } else { atomicAdd(&stats[0], (unsigned long long)w); atomicAdd(&stats[1], (unsigned long long)bases); }
 }
 
 struct OpsWriter {

@@ -371,7 +371,7 @@ namespace {
 
 struct ExtBuffers {
     ExtTask* tasks; u32* active; u32* count; BlockItem* itemsA; BlockItem* itemsB;
-    u64* fragA; u64* fragB; char* slabs; u8* opsA; u8* opsB; BlockResult* resA; BlockResult* resB;
+    u64* fragA; u64* fragB; char* slabs; u8* opsA; u8* opsB; BlockResult* resA; BlockResult* resB; unsigned long long* stats;
 };
 
 // run rounds until every task of the batch is done
@@ -406,12 +406,12 @@ int run_rounds(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, ExtB
         NECAT_HIP(ctx, hipEventRecord(e0, s));
         if (nA) {
             hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(gA), dim3(64), 0, s, (const BlockItem*)B.itemsA, nA,
-                               (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA);
+                               (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA, B.stats);
             NECAT_CHECK_LAUNCH(ctx, "k_myers<A>");
         }
         if (nB) {
             hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, s, (const BlockItem*)B.itemsB, nB,
-                               (const u64*)B.fragB, slabsB, kSlabB, error, B.resB);
+                               (const u64*)B.fragB, slabsB, kSlabB, error, B.resB, B.stats);
             NECAT_CHECK_LAUNCH(ctx, "k_myers<B>");
         }
         NECAT_HIP(ctx, hipEventRecord(e1, s));
@@ -502,8 +502,10 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
         B.resA = (BlockResult*)ctx->scratch[SC_EXT_RES].p; B.resB = B.resA + (size_t)groups * 64;
     }
     u32* d_count = nullptr;
-    NECAT_HIP(ctx, hipMalloc((void**)&d_count, 8));
+    NECAT_HIP(ctx, hipMalloc((void**)&d_count, 8 + 16));
     B.count = d_count;
+    B.stats = (unsigned long long*)(d_count + 2);
+    NECAT_HIP(ctx, hipMemsetAsync(B.stats, 0, 16, s));
     for (uint64_t base = 0; base < n; base += batch) {
         const u32 nb = (u32)std::min<uint64_t>(batch, n - base);
         hipLaunchKernelGGL(k_ext_init, dim3(grid_for(nb, 256)), dim3(256), 0, s, (const necat_candidate*)(d_cands + base), nb, (u32)base,
@@ -513,6 +515,12 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
         hipLaunchKernelGGL(k_ext_result, dim3(grid_for(nb, 256)), dim3(256), 0, s, (const ExtTask*)B.tasks, nb, (const necat_candidate*)(d_cands + base),
                            (u32)base, opt->align_size_cutoff, d_m4 - 0, d_ok);
         NECAT_CHECK_LAUNCH(ctx, "k_ext_result");
+    }
+    {
+        unsigned long long hs[2] = {0, 0};
+        NECAT_HIP(ctx, hipMemcpyAsync(hs, B.stats, 16, hipMemcpyDeviceToHost, s));
+        NECAT_HIP(ctx, hipStreamSynchronize(s));
+        ctx->tm.myers_word_updates = hs[0]; ctx->tm.myers_cells_bases = hs[1];
     }
     (void)hipFree(d_count);
     // groups of equal qid (candidates arrive grouped per read: pm_worker.c:100-140)
@@ -578,8 +586,9 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
     ctx->tm.myers_cells_bases = 0;
     std::vector<std::vector<uint8_t>> fwd_ops(n);
     int* d_err = nullptr;
-    NECAT_HIP(ctx, hipMalloc((void**)&d_err, 4));
-    NECAT_HIP(ctx, hipMemsetAsync(d_err, 0, 4, s));
+    NECAT_HIP(ctx, hipMalloc((void**)&d_err, 4 + 4 + 16));
+    NECAT_HIP(ctx, hipMemsetAsync(d_err, 0, 24, s));
+    unsigned long long* d_stats = (unsigned long long*)(d_err + 2);
     const u32 chunk = 65536;
     auto run_shape = [&](std::vector<BlockItem>& items, std::vector<u64>& ids, bool full) -> int {
         for (size_t base = 0; base < items.size(); base += chunk) {
@@ -604,8 +613,8 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
             else hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)g * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, s, dv, dv, (const BlockItem*)d_items, m, d_frag);
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[4], s));
-            if (full) hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res);
-            else hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res);
+            if (full) hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats);
+            else hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats);
             NECAT_CHECK_LAUNCH(ctx, "k_myers");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[5], s));
             if (full) hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, (const char*)d_slabs, slab,
@@ -625,6 +634,7 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
                 dist[id] = hres[j].dist;
                 ctx->tm.myers_word_updates += hres[j].words;
                 ctx->tm.myers_cells_bases += (u64)q_len[id] + (u64)t_len[id];
+                (void)d_stats;
                 if (hres[j].dist >= 0) {
                     const int no = hn[j];
                     std::vector<uint8_t>& f = fwd_ops[id];

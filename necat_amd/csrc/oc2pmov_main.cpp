@@ -1,0 +1,114 @@
+// oc2pmov - drop-in replacement of NECAT's oc2pmov (pm_one_volume/main.c, pm_worker.c:338 pm_main):
+//   oc2pmov [options] wrk-dir volume-id output
+// Same argv, same volume inputs, same candidate / M4 record files; the work runs on one MI355X
+// through libnecat_hip.so (device from NECAT_GPU, default 0).  There is no CPU fallback: without a
+// usable GPU the program exits 1, like every other fatal error of the reference (OC_ERROR).
+#include "host_io.h"
+
+using namespace necat_host;
+
+static int fail(const char* what, const char* detail)
+{
+    fprintf(stderr, "[oc2pmov] ERROR: %s: %s\n", what, detail);
+    return 1;
+}
+
+int main(int argc, char** argv)
+{
+    necat_map_options opt;
+    necat_default_options(&opt);
+    if (argc < 4) {     // pm_one_volume/main.c:30-33
+        fprintf(stderr, "USAGE:\n%s [options] wrk-dir volume-id output\n\nOPTIONS AND DESCRIPTIONS:\n", argv[0]);
+        describe_options(stderr, &opt);
+        return 1;
+    }
+    if (!parse_options(argc - 3, argv, &opt)) {
+        fprintf(stderr, "USAGE:\n%s [options] wrk-dir volume-id output\n\nOPTIONS AND DESCRIPTIONS:\n", argv[0]);
+        necat_map_options d; necat_default_options(&d);
+        describe_options(stderr, &d);
+        return 1;
+    }
+    const char* wrk_dir = argv[argc - 3];
+    const int vid = atoi(argv[argc - 2]);
+    const char* output = argv[argc - 1];
+
+    std::string err;
+    VolumesInfo vi;
+    if (!load_volumes_info(wrk_dir, &vi, &err)) return fail("volume directory", err.c_str());
+    if (vid < 0 || vid >= vi.num_volumes) return fail("volume id", "out of range");
+    const char* dev_env = getenv("NECAT_GPU");
+    necat_ctx* ctx = nullptr;
+    int rc = necat_ctx_create(dev_env ? atoi(dev_env) : 0, &ctx);
+    if (rc) return fail("GPU", "no usable gfx950 device (libnecat_hip has no CPU fallback)");
+
+    HostVolume href;
+    if (!load_volume(vi.names[vid].c_str(), &href, &err)) return fail("volume", err.c_str());
+    necat_volume* ref = nullptr;
+    if ((rc = necat_volume_upload(ctx, href.pac.data(), href.nbases, href.offset.data(), href.size.data(), href.offset.size(), &ref)))
+        return fail("necat_volume_upload", necat_last_error(ctx));
+    log_line("", "build_lookup_table");
+    double t0 = now_sec();
+    necat_index* ix = nullptr;
+    if ((rc = necat_index_build(ctx, ref, opt.kmer_size, opt.kmer_cnt_cutoff, &ix))) return fail("necat_index_build", necat_last_error(ctx));
+    log_line("[%s] INFO: '%s' takes %.2lf secs.\n", "build_lookup_table", now_sec() - t0);
+
+    // write to a temporary name first: a failed run never leaves a complete-looking pm_result_i
+    const std::string tmp_out = std::string(output) + ".part";
+    FILE* out = fopen(tmp_out.c_str(), "w");
+    if (!out) return fail("output", "cannot open for writing");
+    const int ref_start = vi.read_start_id[vid];
+    uint64_t n_records = 0;
+    for (int i = vid; i < vi.num_volumes; ++i) {     // pm_worker.c:372-390
+        char job[256];
+        snprintf(job, sizeof job, "pairwise mapping v%d vs v%d", i, vid);
+        log_line("", job);
+        t0 = now_sec();
+        HostVolume hreads_own; const HostVolume* hreads = &href;
+        necat_volume* reads = ref;
+        if (i != vid) {
+            if (!load_volume(vi.names[i].c_str(), &hreads_own, &err)) return fail("volume", err.c_str());
+            hreads = &hreads_own;
+            if ((rc = necat_volume_upload(ctx, hreads_own.pac.data(), hreads_own.nbases, hreads_own.offset.data(), hreads_own.size.data(),
+                                          hreads_own.offset.size(), &reads))) return fail("necat_volume_upload", necat_last_error(ctx));
+        }
+        const int read_start = vi.read_start_id[i];
+        necat_candidate* cands = nullptr; uint64_t ncand = 0;
+        if ((rc = necat_find_candidates(ctx, ix, ref, reads, read_start, ref_start, 1, &opt, &cands, &ncand)))
+            return fail("necat_find_candidates", necat_last_error(ctx));
+        if (opt.job == 1) {
+            necat_m4* m4 = nullptr; uint64_t nm4 = 0;
+            if ((rc = necat_extend(ctx, ref, reads, read_start, ref_start, cands, ncand, &opt, 1 /* ONC_TAIL_MATCH_LEN_SHORT */, &m4, &nm4)))
+                return fail("necat_extend", necat_last_error(ctx));
+            for (uint64_t k = 0; k < nm4; ++k) {
+                const necat_m4& m = m4[k];
+                if (opt.binary_output) fwrite(&m, sizeof m, 1, out);
+                else if (opt.use_hdr_as_id)      // DUMP_ASM_M4_HDR_ID (m4_record.h:99-124)
+                    fprintf(out, "%s\t%s\t%.2f\t%d\t%d\t%lu\t%lu\t%lu\t%d\t%lu\t%lu\t%lu\n", hreads->name((uint64_t)(m.qid - read_start)),
+                            href.name((uint64_t)(m.sid - ref_start)), m.ident_perc, m.vscore, m.qdir, m.qoff, m.qend, m.qsize, m.sdir, m.soff, m.send, m.ssize);
+                else                              // DUMP_ASM_M4 (m4_record.h:72-97)
+                    fprintf(out, "%d\t%d\t%.2f\t%d\t%d\t%lu\t%lu\t%lu\t%d\t%lu\t%lu\t%lu\n", m.qid, m.sid, m.ident_perc, m.vscore, m.qdir,
+                            m.qoff, m.qend, m.qsize, m.sdir, m.soff, m.send, m.ssize);
+            }
+            n_records += nm4;
+            necat_free(m4);
+        } else {
+            for (uint64_t k = 0; k < ncand; ++k) {
+                const necat_candidate& c = cands[k];
+                if (opt.binary_output) { uint32_t item[7]; pack_candidate(&c, item); fwrite(item, 28, 1, out); }
+                else                              // DUMP_GAPPED_CANDIDATE (gapped_candidate.h:26-42)
+                    fprintf(out, "%d\t%d\t%d\t%d\t%lu\t%lu\t%lu\t%lu\t%d\t%lu\t%lu\t%lu\t%lu\n", c.qid, c.sid, c.score, c.qdir, c.qbeg, c.qend, c.qoff,
+                            c.qsize, c.sdir, c.sbeg, c.send, c.soff, c.ssize);
+            }
+            n_records += ncand;
+        }
+        necat_free(cands);
+        if (reads != ref) necat_volume_free(ctx, reads);
+        log_line("[%s] INFO: '%s' takes %.2lf secs.\n", job, now_sec() - t0);
+    }
+    if (fclose(out) != 0) return fail("output", "write failed");
+    if (rename(tmp_out.c_str(), output) != 0) return fail("output", "rename failed");
+    necat_index_free(ctx, ix);
+    necat_volume_free(ctx, ref);
+    necat_ctx_destroy(ctx);
+    return 0;
+}
