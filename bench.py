@@ -150,14 +150,8 @@ def main():
         agg["rounds"] += tm.rounds
     barrier_sync(dist, local)
     elapsed = time.perf_counter() - t0
-    tot_over, tot_gbp = n_over, gbp
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed, float(n_over), gbp], dtype=torch.float64, device="cuda")
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        elapsed = float(tmax[0]); tot_over = float(t[1]); tot_gbp = float(t[2])
+    from necat_amd import shard
+    elapsed, tot_over, tot_gbp = shard.reduce_step_stats(dist, elapsed, float(n_over), gbp, device="cuda" if dist is not None else None)
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()

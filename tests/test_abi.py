@@ -1,0 +1,78 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/necat_hip.h declares; without a GPU every entry point fails loudly (no CPU fallback); the
+oc2pmov / oc2pm programs keep the reference's argv contract."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from tests import util
+
+try:
+    import torch
+    HAVE_GPU = torch.cuda.is_available()
+except Exception:      # pragma: no cover
+    HAVE_GPU = False
+
+
+def test_library_exports_every_declared_symbol(built):
+    from necat_amd import capi
+    hdr = open(os.path.join(util.ROOT, "include", "necat_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(necat_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 14
+    lib = ctypes.CDLL(built.LIB)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(capi.EXPORTED_SYMBOLS) == declared
+
+
+def test_struct_layouts_match_reference_records(built):
+    from necat_amd import capi
+    assert capi.M4_DTYPE.itemsize == 96          # m4_record.h:10-25
+    assert capi.CANDIDATE_DTYPE.itemsize == 88   # gapped_candidate.h:9-19
+    o = capi.default_options()
+    assert (o.kmer_size, o.scan_window, o.kmer_cnt_cutoff, o.block_size, o.block_score_cutoff) == (15, 10, 500, 2000, 3)
+    assert (o.num_candidates, o.align_size_cutoff, o.job, o.binary_output, o.use_hdr_as_id) == (500, 500, 1, 0, 1)
+
+
+@pytest.mark.skipif(HAVE_GPU, reason="a GPU is present")
+def test_no_silent_cpu_fallback(built):
+    from necat_amd import capi
+    with pytest.raises(capi.NecatError):
+        capi.Context(0)
+
+
+def test_pack_candidates_matches_oracle_layout(built):
+    """host-side record packing (gapped_candidate.c:13-30) against the golden binary records."""
+    import json
+    import numpy as np
+    from necat_amd import capi
+    man = json.load(open(os.path.join(util.GOLDEN, "manifest.json")))
+    txt = open(os.path.join(util.GOLDEN, man["a_fast_can_txt"]["file"])).read().split("\n")
+    rows = [tuple(int(x) for x in ln.split()) for ln in txt if ln]
+    c = np.zeros(len(rows), dtype=capi.CANDIDATE_DTYPE)
+    for i, r in enumerate(rows):   # qid sid score qdir qbeg qend qoff qsize sdir sbeg send soff ssize
+        c[i] = (r[0], r[1], r[3], r[8], r[2], 0, r[4], r[5], r[7], r[9], r[10], r[12], r[6], r[11])
+    packed = sorted(bytes(x) for x in capi.pack_candidates(c).astype("<u4"))
+    gold = open(os.path.join(util.GOLDEN, man["a_fast_can_bin"]["file"]), "rb").read()
+    assert b"".join(packed) == gold
+
+
+def test_cli_usage_and_errors(built, tmp_path):
+    pmov, pm = built.build_cli()
+    r = subprocess.run([pmov], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "USAGE" in r.stderr and "wrk-dir volume-id output" in r.stderr   # main.c:30-33
+    r = subprocess.run([pmov, "-x", "1", "a", "0", "b"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1
+    r = subprocess.run([pm], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "USAGE" in r.stderr
+    # missing volume directory -> exit 1 and no output file
+    out = os.path.join(str(tmp_path), "o")
+    r = subprocess.run([pmov, "-k", "13", os.path.join(str(tmp_path), "nope"), "0", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and not os.path.exists(out)
+    if not HAVE_GPU:
+        d = util.install_golden_volumes("vols_a", tmp_path)
+        r = subprocess.run([pmov, "-k", "13", d, "0", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 1 and "no usable gfx950" in r.stderr and not os.path.exists(out)

@@ -1,0 +1,66 @@
+"""CPU tests: the oracle (oracle/necat_oracle.c) against the golden vectors generated from the
+compiled reference (tests/golden/make_golden.py), and - when oracle/_ref is present - against the
+reference itself on fresh seeded data."""
+import hashlib
+import json
+import os
+
+import pytest
+
+from tests import util
+from oracle import oracle_api as ora
+
+MANIFEST = json.load(open(os.path.join(util.GOLDEN, "manifest.json")))
+
+
+@pytest.mark.parametrize("name", sorted(MANIFEST))
+def test_oracle_reproduces_golden(name, tmp_path, built):
+    m = MANIFEST[name]
+    d = util.install_golden_volumes(m["dataset"], tmp_path)
+    o = ora.options(**m["options"])
+    out = os.path.join(str(tmp_path), "o.out")
+    st = ora.pm_main(o, m["vid"], d, out)
+    recs = ora.sorted_records(out, 28 if o.binary_output else 0)
+    gold = open(os.path.join(util.GOLDEN, m["file"]), "rb").read()
+    assert st.n_records == m["records"] == len(recs)
+    assert hashlib.md5(gold).hexdigest() == m["md5"]
+    assert b"".join(recs) == gold
+
+
+@pytest.mark.skipif(not ora.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("job,binary", [(0, 1), (1, 0)])
+def test_oracle_matches_reference_on_fresh_data(job, binary, tmp_path, built):
+    d, rs, nv = util.make_dataset(tmp_path, genome=120_000, coverage=15.0, seed=77, err=0.13, vol_size=900_000)
+    assert nv >= 2
+    kw = dict(util.SENSITIVE, kmer_size=12, job=job, binary_output=binary)
+    for vid in range(nv):
+        o = ora.options(**kw)
+        a = os.path.join(str(tmp_path), "ref.out")
+        b = os.path.join(str(tmp_path), "ora.out")
+        ora.run_ref(o, vid, d, a)
+        ora.pm_main(o, vid, d, b)
+        ra, rb = ora.sorted_records(a, 28 if binary else 0), ora.sorted_records(b, 28 if binary else 0)
+        assert len(ra) > 0 and ra == rb
+
+
+@pytest.mark.skipif(not ora.have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+def test_volume_writer_matches_oc2mkdb(tmp_path, built):
+    """necat_amd.synth.write_volume_dir against the reference's oc2mkdb (struct padding ignored)."""
+    import subprocess
+    import numpy as np
+    from necat_amd import synth
+    rs = synth.simulate_reads(30_000, 8.0, seed=5)
+    d = os.path.join(str(tmp_path), "mine")
+    synth.write_volume_dir(d, rs)
+    fa = os.path.join(str(tmp_path), "r.fa")
+    synth.write_fasta(fa, rs)
+    lst = os.path.join(str(tmp_path), "list.txt")
+    open(lst, "w").write(fa + "\n")
+    refd = os.path.join(str(tmp_path), "ref")
+    subprocess.run([ora.REF_MKDB, refd, lst], check=True, stdout=subprocess.DEVNULL)
+    a = synth.read_volume(os.path.join(d, "vol0"))
+    b = synth.read_volume(os.path.join(refd, "vol0"))
+    for x, y in zip(a[:3], b[:3]):
+        assert np.array_equal(x, y)
+    assert a[3] == b[3]
+    assert open(os.path.join(d, "reads_info.txt")).read() == open(os.path.join(refd, "reads_info.txt")).read()
