@@ -232,27 +232,44 @@ NECAT_HD MyersResult myers_block(MyersRegs<NW>& R, int qn, int tn, double error,
 
 // ---------------------------------------------------------------------------------------------
 // Traceback (edlib_ex.c:383-621, obtainAlignmentTraceback): move priority up > left > diagonal.
-//   Mat::P(c,b) / M(c,b) / S(c,b) / first(c) / last(c)   read the stored band
-//   Ops::push(op)                                         receives ops in END -> START order
+//   Mat::cur(c, b, P, M)   band word (c, b)
+//   Mat::left(c, b)        LeftView of column c (= current column - 1) at word b: whether word b /
+//                          word b-1 are inside that column's band, and their P, M, score.  One call per
+//                          column change lets the reader prefetch the columns ahead (the walk is a chain
+//                          of dependent loads otherwise).
+//   Ops::push(op)          receives ops in END -> START order
 // Op codes: 0 match, 1 insert (consumes a query base), 2 delete (consumes a target base),
 // 3 mismatch (edlib_ex.c:10-13).
 // ---------------------------------------------------------------------------------------------
+struct LeftView {
+    u64 P, M;
+    int S, Sup;
+    bool in, up_in;
+};
+
 template <class Mat, class Ops>
 NECAT_HD void traceback_block(int qn, int tn, int bestScore, Mat& mat, Ops& ops)
 {
+    // The state (cur, lS, uS, ulS, curP/M, lP/M, left) and its update rules are those of
+    // edlib_ex.c:400-600; the three move bodies are folded so that the band is read at ONE place per
+    // iteration (64 lanes walk 64 different paths: every extra call site is executed by the whole wave).
     const int nblk = (qn + 63) / 64, W = nblk * 64 - qn;
     int c = tn - 1, b = nblk - 1;
     int cur = bestScore, lS = -1, uS = -1, ulS = -1;
-    u64 curP = mat.P(c, b), curM = mat.M(c, b);
-    bool left = c > 0 && b >= mat.first(c - 1) && b <= mat.last(c - 1);
+    u64 curP, curM;
+    mat.cur(c, b, curP, curM);
+    LeftView V; V.P = V.M = 0; V.S = V.Sup = 0; V.in = V.up_in = false;
+    if (c > 0) V = mat.left(c - 1, b);
+    bool left = c > 0 && V.in;
     u64 lP = 0, lM = 0;
-    if (left) { lP = mat.P(c - 1, b); lM = mat.M(c - 1, b); }
+    if (left) { lP = V.P; lM = V.M; }
     curP <<= W; curM <<= W;
     int pos = 64 - W - 1;
+    int term = 0, term_op = 0;       // how the walk ended (boundary cases push runs of ops)
     for (;;) {
         if (c == 0) { left = true; lS = b * 64 + pos + 1; ulS = lS - 1; }
         if (lS == -1 && left) {
-            lS = mat.S(c - 1, b);
+            lS = V.S;
             const int n = 64 - pos - 1;          // the reference walks n bits from the top
             if (n > 0) {
                 lS += popc64(lM >> (64 - n)) - popc64(lP >> (64 - n));
@@ -264,8 +281,8 @@ NECAT_HD void traceback_block(int qn, int tn, int bestScore, Mat& mat, Ops& ops)
                 ulS = lS;
                 if (lP & kHighBit) ulS--;
                 if (lM & kHighBit) ulS++;
-            } else if (c > 0 && b - 1 >= mat.first(c - 1) && b - 1 <= mat.last(c - 1)) {
-                ulS = mat.S(c - 1, b - 1);
+            } else if (c > 0 && V.up_in) {
+                ulS = V.Sup;
             }
         }
         if (uS == -1) {
@@ -274,63 +291,61 @@ NECAT_HD void traceback_block(int qn, int tn, int bestScore, Mat& mat, Ops& ops)
             if (curM & kHighBit) uS++;
             curP <<= 1; curM <<= 1;
         }
-        if (uS != -1 && uS + 1 == cur) {
+        int op;
+        bool reload_cur = false, reload_left = false, edge_ok = true;
+        if (uS != -1 && uS + 1 == cur) {                 // up: consumes a query base
+            op = 1;
             cur = uS; lS = ulS; uS = ulS = -1;
             if (pos == 0) {
-                if (b == 0) {
-                    ops.push(1);
-                    for (int i = 0; i < c + 1; ++i) ops.push(2);
-                    break;
-                } else {
-                    pos = 63; b--;
-                    curP = mat.P(c, b); curM = mat.M(c, b);
-                    if (c > 0 && b >= mat.first(c - 1) && b <= mat.last(c - 1)) { left = true; lP = mat.P(c - 1, b); lM = mat.M(c - 1, b); }
-                    else left = false;
-                }
+                if (b == 0) { term = 1; break; }
+                pos = 63; b--;
+                reload_cur = true; reload_left = true; edge_ok = false;
             } else { pos--; lP <<= 1; lM <<= 1; }
-            ops.push(1);
-        } else if (lS != -1 && lS + 1 == cur) {
+        } else if (lS != -1 && lS + 1 == cur) {          // left: consumes a target base
+            op = 2;
             cur = lS; uS = ulS; lS = ulS = -1;
             c--;
-            if (c == -1) {
-                ops.push(2);
-                const int numUp = b * 64 + pos + 1;
-                for (int i = 0; i < numUp; ++i) ops.push(1);
-                break;
-            }
+            if (c == -1) { term = 2; break; }
             curP = lP; curM = lM;
-            if (c > 0 && b >= mat.first(c - 1) && b <= mat.last(c - 1)) { left = true; lP = mat.P(c - 1, b); lM = mat.M(c - 1, b); }
-            else if (c == 0) { left = true; lS = b * 64 + pos + 1; ulS = lS - 1; }
-            else left = false;
-            ops.push(2);
-        } else if (ulS != -1) {
-            const int mv = ulS == cur ? 0 : 3;
+            reload_left = true;
+        } else if (ulS != -1) {                          // diagonal
+            op = ulS == cur ? 0 : 3;
             cur = ulS; uS = lS = ulS = -1;
             c--;
-            if (c == -1) {
-                ops.push(mv);
-                const int numUp = b * 64 + pos;
-                for (int i = 0; i < numUp; ++i) ops.push(1);
-                break;
-            }
+            if (c == -1) { term = 3; term_op = op; break; }
             if (pos == 0) {
-                if (b == 0) {
-                    ops.push(mv);
-                    for (int i = 0; i < c + 1; ++i) ops.push(2);
-                    break;
-                }
+                if (b == 0) { term = 4; term_op = op; break; }
                 pos = 63; b--;
-                curP = mat.P(c, b); curM = mat.M(c, b);
+                reload_cur = true;
             } else {
                 pos--;
-                curP = lP; curM = lM;
-                curP <<= 1; curM <<= 1;
+                curP = lP << 1; curM = lM << 1;
             }
-            if (c > 0 && b >= mat.first(c - 1) && b <= mat.last(c - 1)) { left = true; lP = mat.P(c - 1, b); lM = mat.M(c - 1, b); }
-            else if (c == 0) { left = true; lS = b * 64 + pos + 1; ulS = lS - 1; }
-            else left = false;
-            ops.push(mv);
+            reload_left = true;
         } else break;
+        if (reload_cur) mat.cur(c, b, curP, curM);
+        if (reload_left) {
+            if (c > 0) V = mat.left(c - 1, b);
+            if (c > 0 && V.in) { left = true; lP = V.P; lM = V.M; }
+            else if (c == 0 && edge_ok) { left = true; lS = b * 64 + pos + 1; ulS = lS - 1; }
+            else left = false;
+        }
+        ops.push(op);
+    }
+    if (term == 1) {                 // up move out of the first row
+        ops.push(1);
+        for (int i = 0; i < c + 1; ++i) ops.push(2);
+    } else if (term == 2) {          // left move out of the first column
+        ops.push(2);
+        const int numUp = b * 64 + pos + 1;
+        for (int i = 0; i < numUp; ++i) ops.push(1);
+    } else if (term == 3) {          // diagonal move out of the first column
+        ops.push(term_op);
+        const int numUp = b * 64 + pos;
+        for (int i = 0; i < numUp; ++i) ops.push(1);
+    } else if (term == 4) {          // diagonal move out of the first row
+        ops.push(term_op);
+        for (int i = 0; i < c + 1; ++i) ops.push(2);
     }
 }
 

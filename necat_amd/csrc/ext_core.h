@@ -139,31 +139,54 @@ NECAT_HD FragGeom ext_frag_geom(const ExtTask& t)
     return g;
 }
 
+// Running statistics of one block's alignment, gathered while the traceback emits ops END -> START:
+// totals of the whole alignment, and the totals of its tail up to (and including) the first run of
+// M consecutive matches met from the end (oc_aligner.c:224-241).  With these the kept part of the
+// block is known in closed form and the op list never has to be read back.
+struct TailScan {
+    int M;                       // run length looked for (8, or tail_match_len on a final block)
+    int n, nq, nt, nmat;         // whole alignment: columns, query bases, target bases, matches
+    int m;                       // current run of matches (frozen once hit)
+    int hit;                     // the run was found
+    int acnt, qcnt, tcnt, mcnt;  // columns / bases / matches scanned when the run completed
+};
+
+NECAT_HD void tail_init(TailScan& s, int M) { s.M = M; s.n = s.nq = s.nt = s.nmat = 0; s.m = 0; s.hit = 0; s.acnt = s.qcnt = s.tcnt = s.mcnt = 0; }
+
+NECAT_HD void tail_push(TailScan& s, int op)
+{
+    const int hq = op != 2, ht = op != 1, mt = op == 0;
+    s.n += 1; s.nq += hq; s.nt += ht; s.nmat += mt;
+    if (!s.hit) {
+        s.m = mt ? s.m + 1 : 0;
+        if (s.m == s.M) { s.hit = 1; s.acnt = s.n; s.qcnt = s.nq; s.tcnt = s.nt; s.mcnt = s.nmat; }
+    }
+}
+
+// Whether this block ends its extension, known before the traceback: Edlib_align aligns the whole
+// query fragment (qfae = qn) and the target up to its end column (tfae = endc + 1), so the
+// "> 30 unaligned bases on both sides" test of oc_aligner.c:221 can only fire on a failed block.
+NECAT_HD int ext_block_done(const ExtTask& t, int dist, int endc)
+{
+    const int qfae = dist >= 0 ? t.qblk : 0, tfae = dist >= 0 ? endc + 1 : 0;
+    int done = t.last;
+    if (t.qblk - qfae > 30 && t.tblk - tfae > 30) done = 1;
+    return done;
+}
+
 // Tail trimming + stream update after the block's alignment (oc_aligner.c:216-262).
 //   dist < 0  : Edlib_align failed (empty alignment)
-//   rops(j)   : op j of the alignment in END -> START order, n_ops of them
+//   ts        : statistics gathered during the traceback with M = ext_block_done ? tail_match_len : 8
+//   rops(j)   : op j of the alignment in END -> START order (only read while the stream has not yet
+//               seen its first run of 8 matches, i.e. on the first block(s) of an extension)
 //   same(i)   : query fragment element i == target fragment element i (exact-prefix fallback)
 template <class ROps, class Same>
-NECAT_HD void ext_finish_block(ExtTask& t, int dist, int endc, int n_ops, int tail_match_len, ROps& rops, Same& same)
+NECAT_HD void ext_finish_block(ExtTask& t, int dist, int endc, int done, const TailScan& ts, ROps& rops, Same& same)
 {
     const int qn = t.qblk, tn = t.tblk;
-    const int qfae = dist >= 0 ? qn : 0, tfae = dist >= 0 ? endc + 1 : 0;   // the alignment is global in the query
-    int done = t.last;
-    if (qn - qfae > 30 && tn - tfae > 30) done = 1;
-    const int M = done ? tail_match_len : kOcaMatCnt;
-    const int n = dist >= 0 ? n_ops : 0;
-    int acnt = 0, qcnt = 0, tcnt = 0, m = 0, j = 0;
-    while (j < n) {
-        const int op = rops(j);
-        if (op != 2) ++qcnt;
-        if (op != 1) ++tcnt;
-        if (op == 0) ++m; else m = 0;
-        ++acnt;
-        if (m == M) break;
-        ++j;
-    }
-    const int kfirst = n - 1 - j;       // forward index where the scan stopped (k in the reference)
-    if (m != M || kfirst < 1) {
+    const int n = dist >= 0 ? ts.n : 0;
+    const int kfirst = n - ts.acnt;       // forward index where the tail scan stopped (k in the reference)
+    if (dist < 0 || !ts.hit || kfirst < 1) {
         // exact-match prefix of the raw fragments, then stop (oc_aligner.c:243-254)
         const int lim = qn < tn ? qn : tn;
         for (int i = 0; i < lim; ++i) {
@@ -172,12 +195,22 @@ NECAT_HD void ext_finish_block(ExtTask& t, int dist, int endc, int n_ops, int ta
         }
         done = 1;
     } else {
-        t.qidx += qfae - qcnt; t.tidx += tfae - tcnt;
-        const int lo = done ? acnt - M : acnt;    // on the final block the M matching columns are kept (:258)
-        for (int jj = n - 1; jj >= lo; --jj) {
+        const int M = ts.M;
+        t.qidx += ts.nq - ts.qcnt; t.tidx += ts.nt - ts.tcnt;      // qfae - qcnt, tfae - tcnt
+        // kept columns: forward [0, kfirst) plus, on a final block, the M matching columns (:258)
+        int keep_cols = n - ts.acnt, keep_q = ts.nq - ts.qcnt, keep_t = ts.nt - ts.tcnt, keep_mat = ts.nmat - ts.mcnt;
+        if (done) { keep_cols += M; keep_q += M; keep_t += M; keep_mat += M; }
+        const int lo = done ? ts.acnt - M : ts.acnt;
+        int jj = n - 1;
+        // until the stream has its first run of 8 matches the columns must be replayed in order
+        const int c0 = t.tot_cols, q0 = t.tot_q, t0 = t.tot_t, m0 = t.tot_mat;
+        while (!t.found && jj >= lo) {
             const int op = rops(jj);
             ext_stream_col(t, op == 0, op != 2, op != 1);
+            --jj;
         }
+        // the rest only adds to the totals
+        t.tot_cols = c0 + keep_cols; t.tot_q = q0 + keep_q; t.tot_t = t0 + keep_t; t.tot_mat = m0 + keep_mat;
     }
     t.ext_done = done;
 }

@@ -135,14 +135,37 @@ struct MatWriter {
     NECAT_D void band(int c, int f, int l) { bnd[(size_t)c * 64] = (u16)(f | (l << 8)); }
 };
 
+// Band reader of the traceback.  The walk moves one column at a time at a (mostly) fixed word b and
+// every column needs P/M, the score of word b, the score of word b-1 and the band limits of the column
+// to its left - a chain of dependent loads.  The reader issues the loads of column c-1 while column c
+// is being consumed, so the walk pays max(compute, latency) per column instead of their sum.
 template <int NW>
 struct MatReader {
-    const ulonglong2* pm; const i16* sc; const u16* bnd;
-    NECAT_D u64 P(int c, int b) const { return pm[((size_t)c * NW + b) * 64].x; }
-    NECAT_D u64 M(int c, int b) const { return pm[((size_t)c * NW + b) * 64].y; }
-    NECAT_D int S(int c, int b) const { return sc[((size_t)c * NW + b) * 64]; }
-    NECAT_D int first(int c) const { return bnd[(size_t)c * 64] & 0xff; }
-    NECAT_D int last(int c) const { return bnd[(size_t)c * 64] >> 8; }
+    const ulonglong2* pm; const i16* sc; const u16* bnd;     // lane-offset slab pointers
+    int nc, nb;                                              // coordinates of the prefetched view
+    ulonglong2 np; i16 ns, nu; u16 nbd;
+    NECAT_D void init() { nc = -100; nb = -100; }
+    NECAT_D void fetch(int c, int b, ulonglong2& p, i16& s, i16& u, u16& bd) const
+    {
+        if (c >= 0) {
+            const u32 idx = ((u32)c * NW + (u32)b) * 64u;
+            p = pm[idx]; s = sc[idx]; u = b > 0 ? sc[idx - 64] : (i16)0; bd = bnd[(u32)c * 64u];
+        }
+    }
+    NECAT_D void cur(int c, int b, u64& P, u64& M) const { const ulonglong2 v = pm[((u32)c * NW + (u32)b) * 64u]; P = v.x; M = v.y; }
+    NECAT_D LeftView left(int c, int b)
+    {
+        ulonglong2 p; i16 s, u; u16 bd;
+        if (c == nc && b == nb) { p = np; s = ns; u = nu; bd = nbd; }
+        else fetch(c, b, p, s, u, bd);
+        nc = c - 1; nb = b;
+        fetch(nc, nb, np, ns, nu, nbd);
+        const int f = bd & 0xff, l = bd >> 8;
+        LeftView v;
+        v.in = b >= f && b <= l; v.up_in = b - 1 >= f && b - 1 <= l;
+        v.P = p.x; v.M = p.y; v.S = s; v.Sup = u;
+        return v;
+    }
 };
 
 template <int NW, int COLS>
@@ -190,9 +213,136 @@ k_myers(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag
     } else { atomicAdd(&stats[0], (unsigned long long)w); atomicAdd(&stats[1], (unsigned long long)bases); }
 }
 
+// Cooperative variant for rounds with few blocks (the latency-bound tail: a candidate's blocks form a
+// dependent chain, so once only the longest overlaps are left the chip is empty and only the latency
+// of ONE block alignment matters).  G lanes share a block, lane b owns 64-row word b, and column c of
+// word b is computed at step c + b (anti-diagonal wavefront); the carry between vertically adjacent
+// words travels by DPP row_shr:1, no LDS.  The band heuristics are dropped: every word of every
+// column is computed and stored ("band" = all words).  Distance, end column and traceback are
+// unchanged by that - banding only prunes cells that cannot lie on an alignment of cost <= k
+// (Ukkonen), every cell the traceback visits or compares against is exact in both, and any cell
+// whose value differs is > k - which tests/test_gpu_parity.py::test_coop_equals_banded checks.
+NECAT_D int dpp_from_lane_below(int v)   // lane i receives v of lane i-1 (within a row of 16); row lane 0 gets 1
+{
+    return __builtin_amdgcn_update_dpp(1, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+}
+
+template <int NW, int TW, int COLS, int G>
+__global__ void __launch_bounds__(64)
+k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
+             double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats)
+{
+    constexpr int FW = 2 * NW + TW, BPW = 64 / G;
+    const int lane = threadIdx.x, sub = lane / G, b = lane % G;
+    const u64 item = (u64)blockIdx.x * BPW + sub;
+    const bool valid = item < n;
+    const u64 grp = item >> 6;
+    const int il = (int)(item & 63);
+    int qn = 0, tn = 0;
+    if (valid) { qn = items[item].qn; tn = items[item].tn; }
+    const int nblk = (qn + 63) >> 6, W = nblk * 64 - qn;
+    const bool have = valid && b < nblk;
+    const bool is_last = have && b == nblk - 1;
+    const u64* fr = frag + grp * FW * 64 + il;
+    u64 nlo = 0, nhi = 0;
+    if (have) { nlo = fr[(u64)b * 64]; nhi = fr[(u64)(NW + b) * 64]; }
+    const u64 pad = (is_last && W > 0) ? (~0ULL << ((64 - W) & 63)) : 0ULL;
+    // target words of the wave's blocks staged in LDS: a lane needs a new 32-column word every 32
+    // steps, at a step that differs per lane; served from global memory that read would sit in the same
+    // vmcnt queue as the NW band stores and stall every step on them
+    __shared__ u64 t_lds[BPW][TW];
+    if (valid) for (int w = b; w < TW; w += G) t_lds[sub][w] = (w * 32 < tn) ? fr[(u64)(2 * NW + w) * 64] : 0ULL;
+    __syncthreads();
+    const u64* tw = t_lds[sub];
+    ulonglong2* pm; i16* sc; u16* bnd;
+    slab_pointers<NW, COLS>(slabs + (size_t)grp * slab_bytes, il, pm, sc, bnd);
+
+    // wave-uniform trip count of the SHW wavefront
+    int steps = valid ? tn + nblk - 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
+
+    // ------------------------------------------------------------------ SHW (edlib_ex.c:108-223, band = everything)
+    int k = (int)((double)(qn < tn ? qn : tn) * error * 1.1);
+    u64 P = ~0ULL, M = 0ULL;
+    int S = (b + 1) * 64, best = -1, end0 = -1, hout = 1;
+    u64 tcur = 0;
+    for (int s = 0; s < steps; ++s) {
+        const int c = s - b;
+        int hin = dpp_from_lane_below(hout);
+        if (b == 0) hin = 1;
+        if (have && c >= 0 && c < tn) {
+            if ((c & 31) == 0) tcur = tw[c >> 5];
+            const int tc = (int)((tcur >> ((c & 31) * 2)) & 3);
+            const u64 ma = (tc & 1) ? ~0ULL : 0ULL, mb = (tc & 2) ? ~0ULL : 0ULL;
+            const u64 eq = ((nlo ^ ma) & (nhi ^ mb)) | pad;
+            hout = advance_block(P, M, eq, hin, P, M);
+            S += hout;
+            if (is_last && S <= k && (best == -1 || S <= best)) {
+                if (S != best) { best = S; k = best; end0 = c - W; }
+            }
+        }
+    }
+    if (is_last && W > 0) {          // edlib_ex.c:205-219
+        int score = S;
+        for (int i = 0; i < W; ++i) {
+            if (P & (kHighBit >> i)) --score;
+            if (M & (kHighBit >> i)) ++score;
+            if (score <= k && (best == -1 || score <= best)) {
+                if (score != best) { k = best = score; end0 = tn - W + i; }
+            }
+        }
+    }
+    // the owner of the last word broadcasts (best, end0) to its group
+    const int owner = sub * G + (nblk > 0 ? nblk - 1 : 0);
+    best = __shfl(best, owner); end0 = __shfl(end0, owner);
+    if (!valid) best = -1;
+
+    // ------------------------------------------------------------------ NW on target[0..end0] with k = best (edlib_ex.c:226-370)
+    const int tn2 = end0 + 1;
+    int err = 0;
+    if (best >= 0) { int ad = tn2 - qn; if (ad < 0) ad = -ad; if (best < ad) err = 1; }
+    const bool go = have && best >= 0 && !err;
+    steps = go ? tn2 + nblk - 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
+    P = ~0ULL; M = 0ULL; S = (b + 1) * 64; hout = 1;
+    const u16 full_band = (u16)(0 | ((nblk - 1) << 8));
+    for (int s = 0; s < steps; ++s) {
+        const int c = s - b;
+        int hin = dpp_from_lane_below(hout);
+        if (b == 0) hin = 1;
+        if (go && c >= 0 && c < tn2) {
+            if ((c & 31) == 0) tcur = tw[c >> 5];
+            const int tc = (int)((tcur >> ((c & 31) * 2)) & 3);
+            const u64 ma = (tc & 1) ? ~0ULL : 0ULL, mb = (tc & 2) ? ~0ULL : 0ULL;
+            const u64 eq = ((nlo ^ ma) & (nhi ^ mb)) | pad;
+            hout = advance_block(P, M, eq, hin, P, M);
+            S += hout;
+            const size_t idx = ((size_t)c * NW + b) * 64;
+            pm[idx] = make_ulonglong2(P, M); sc[idx] = (i16)S;
+            if (b == 0) bnd[(size_t)c * 64] = full_band;
+        }
+    }
+    if (is_last) {
+        if (best >= 0 && !err) {
+            int cs = S;
+            if (W > 0) cs = S - popc64(P >> ((64 - W) & 63)) + popc64(M >> ((64 - W) & 63));
+            if (cs != best) err = 2;
+        }
+        BlockResult br; br.dist = err ? -1 : best; br.endc = end0; br.err = err;
+        br.words = (u32)(nblk * (tn + (best >= 0 ? tn2 : 0)));
+        results[item] = br;
+        atomicAdd(&stats[0], (unsigned long long)br.words); atomicAdd(&stats[1], (unsigned long long)(qn + tn));
+    }
+}
+
 struct OpsWriter {
-    u8* ops; int n; int cap; int overflow;
-    NECAT_D void push(int op) { if (n < cap) ops[(size_t)n * 64] = (u8)op; else overflow = 1; ++n; }
+    u8* ops; int cap; int overflow; bool store;
+    TailScan ts;
+    NECAT_D void push(int op)
+    {
+        if (store) { if (ts.n < cap) ops[(size_t)ts.n * 64] = (u8)op; else overflow = 1; }
+        tail_push(ts, op);
+    }
 };
 struct OpsReader {
     const u8* ops;
@@ -225,20 +375,27 @@ k_traceback(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ 
     const BlockItem it = items[item];
     const BlockResult br = results[item];
     if (br.err) atomicExch(err_flag, 10 + br.err);
-    OpsWriter ow; ow.ops = ops_pool + (size_t)grp * MAXOPS * 64 + lane; ow.n = 0; ow.cap = MAXOPS; ow.overflow = 0;
+    OpsWriter ow; ow.ops = ops_pool + (size_t)grp * MAXOPS * 64 + lane; ow.cap = MAXOPS; ow.overflow = 0; ow.store = true;
+    ExtTask t;
+    int done = 0;
+    if (!EXPORT) {
+        t = tasks[it.task];
+        done = ext_block_done(t, br.dist, br.endc);
+        ow.store = !t.found;       // the op list is only replayed until the stream's first run of 8 matches
+    }
+    tail_init(ow.ts, (EXPORT || !done) ? kOcaMatCnt : tail_match_len);
     if (br.dist >= 0) {
         MatReader<NW> mr;
         ulonglong2* pm; i16* sc; u16* band;
         slab_pointers<NW, COLS>(const_cast<char*>(slabs) + (size_t)grp * slab_bytes, lane, pm, sc, band);
-        mr.pm = pm; mr.sc = sc; mr.bnd = band;
+        mr.pm = pm; mr.sc = sc; mr.bnd = band; mr.init();
         traceback_block(it.qn, br.endc + 1, br.dist, mr, ow);
         if (ow.overflow) atomicExch(err_flag, 20);
     }
-    if (EXPORT) { n_ops_out[item] = ow.n; return; }
+    if (EXPORT) { n_ops_out[item] = ow.ts.n; return; }
     OpsReader rd; rd.ops = ow.ops;
     SameReader<NW> same; same.fr = frag + (u64)grp * FW * 64 + lane;
-    ExtTask t = tasks[it.task];
-    ext_finish_block(t, br.dist, br.endc, ow.n, tail_match_len, rd, same);
+    ext_finish_block(t, br.dist, br.endc, done, ow.ts, rd, same);
     tasks[it.task] = t;
 }
 

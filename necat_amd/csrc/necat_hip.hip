@@ -27,6 +27,11 @@ DevVolume dev_view(const necat_volume* v)
     return d;
 }
 
+// rounds with at most this many blocks of a shape use the cooperative (latency-optimised) DP kernel;
+// NECAT_COOP_THRESHOLD overrides it (0 = never, huge = always) for tests and A/B measurements
+u32 g_coop_threshold = 49152;
+int g_trace = 0;
+
 double ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0; return ms; }
 
 }  // namespace
@@ -51,14 +56,17 @@ int necat_ctx_create(int device_id, necat_ctx** out)
     if (hipSetDevice(device_id) != hipSuccess) return NECAT_ERR_DEVICE;
     necat_ctx* ctx = new necat_ctx();
     ctx->device = device_id;
+    if (const char* e = getenv("NECAT_COOP_THRESHOLD")) g_coop_threshold = (u32)strtoul(e, nullptr, 10);
+    if (const char* e = getenv("NECAT_TRACE")) g_trace = atoi(e);
     memset(&ctx->tm, 0, sizeof ctx->tm);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
         snprintf(ctx->devname, sizeof ctx->devname, "%s (%s), %d CUs", prop.name, prop.gcnArchName, prop.multiProcessorCount);
         ctx->num_cu = prop.multiProcessorCount;
     }
-    if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
-    for (int i = 0; i < 8; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
+    if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream_a) != hipSuccess ||
+        hipStreamCreate(&ctx->stream_b) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
+    for (int i = 0; i < 12; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
     *out = ctx;
     return NECAT_OK;
 }
@@ -69,8 +77,8 @@ void necat_ctx_destroy(necat_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& b : ctx->scratch) if (b.p) (void)hipFree(b.p);
-    for (int i = 0; i < 8; ++i) (void)hipEventDestroy(ctx->ev[i]);
-    (void)hipStreamDestroy(ctx->stream);
+    for (int i = 0; i < 12; ++i) (void)hipEventDestroy(ctx->ev[i]);
+    (void)hipStreamDestroy(ctx->stream); (void)hipStreamDestroy(ctx->stream_a); (void)hipStreamDestroy(ctx->stream_b);
     delete ctx;
 }
 
@@ -378,10 +386,10 @@ struct ExtBuffers {
 int run_rounds(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, ExtBuffers& B, u32 n_tasks, double error,
                int tail_match_len, int* d_err)
 {
-    hipStream_t s = ctx->stream;
+    hipStream_t s = ctx->stream, sa = ctx->stream_a, sb = ctx->stream_b;
     u32 n_active = n_tasks;
     ExtLists L; L.count = B.count; L.itemsA = B.itemsA; L.itemsB = B.itemsB;
-    hipEvent_t e0 = ctx->ev[4], e1 = ctx->ev[5], e2 = ctx->ev[6];
+    hipEvent_t a0 = ctx->ev[4], a1 = ctx->ev[5], a2 = ctx->ev[6], b0 = ctx->ev[7], b1 = ctx->ev[8], b2 = ctx->ev[9];
     while (n_active) {
         NECAT_HIP(ctx, hipMemsetAsync(B.count, 0, 8, s));
         hipLaunchKernelGGL(k_ext_plan, dim3(grid_for(n_active, 256)), dim3(256), 0, s, B.tasks, (const u32*)B.active, n_active, L, (u32*)nullptr);
@@ -393,46 +401,53 @@ int run_rounds(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, ExtB
         if (nA + nB == 0) break;
         const u32 gA = (nA + 63) / 64, gB = (nB + 63) / 64;
         char* slabsB = B.slabs + (size_t)gA * kSlabA;
+        // the two shapes of the round are independent: list A on stream_a, list B on stream_b
         if (nA) {
-            hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)gA * 64 * (kWordsA + kTWordsA), 256)), dim3(256), 0, s,
+            hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)gA * 64 * (kWordsA + kTWordsA), 256)), dim3(256), 0, sa,
                                drd, dref, (const BlockItem*)B.itemsA, nA, B.fragA);
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<A>");
-        }
-        if (nB) {
-            hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, s,
-                               drd, dref, (const BlockItem*)B.itemsB, nB, B.fragB);
-            NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
-        }
-        NECAT_HIP(ctx, hipEventRecord(e0, s));
-        if (nA) {
-            hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(gA), dim3(64), 0, s, (const BlockItem*)B.itemsA, nA,
-                               (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA, B.stats);
+            NECAT_HIP(ctx, hipEventRecord(a0, sa));
+            if (nA <= g_coop_threshold)
+                hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((nA + 7) / 8), dim3(64), 0, sa, (const BlockItem*)B.itemsA, nA,
+                                   (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA, B.stats);
+            else
+                hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(gA), dim3(64), 0, sa, (const BlockItem*)B.itemsA, nA,
+                                   (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA, B.stats);
             NECAT_CHECK_LAUNCH(ctx, "k_myers<A>");
-        }
-        if (nB) {
-            hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, s, (const BlockItem*)B.itemsB, nB,
-                               (const u64*)B.fragB, slabsB, kSlabB, error, B.resB, B.stats);
-            NECAT_CHECK_LAUNCH(ctx, "k_myers<B>");
-        }
-        NECAT_HIP(ctx, hipEventRecord(e1, s));
-        if (nA) {
-            hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false>), dim3(gA), dim3(64), 0, s, (const BlockItem*)B.itemsA, nA,
+            NECAT_HIP(ctx, hipEventRecord(a1, sa));
+            hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false>), dim3(gA), dim3(64), 0, sa, (const BlockItem*)B.itemsA, nA,
                                (const u64*)B.fragA, (const char*)B.slabs, kSlabA, (const BlockResult*)B.resA, B.opsA, B.tasks, tail_match_len,
                                (i32*)nullptr, d_err);
             NECAT_CHECK_LAUNCH(ctx, "k_traceback<A>");
+            NECAT_HIP(ctx, hipEventRecord(a2, sa));
         }
         if (nB) {
-            hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false>), dim3(gB), dim3(64), 0, s, (const BlockItem*)B.itemsB, nB,
+            hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, sb,
+                               drd, dref, (const BlockItem*)B.itemsB, nB, B.fragB);
+            NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
+            NECAT_HIP(ctx, hipEventRecord(b0, sb));
+            if (nB <= g_coop_threshold)
+                hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, sb, (const BlockItem*)B.itemsB, nB,
+                                   (const u64*)B.fragB, slabsB, kSlabB, error, B.resB, B.stats);
+            else
+                hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, sb, (const BlockItem*)B.itemsB, nB,
+                                   (const u64*)B.fragB, slabsB, kSlabB, error, B.resB, B.stats);
+            NECAT_CHECK_LAUNCH(ctx, "k_myers<B>");
+            NECAT_HIP(ctx, hipEventRecord(b1, sb));
+            hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false>), dim3(gB), dim3(64), 0, sb, (const BlockItem*)B.itemsB, nB,
                                (const u64*)B.fragB, (const char*)slabsB, kSlabB, (const BlockResult*)B.resB, B.opsB, B.tasks, tail_match_len,
                                (i32*)nullptr, d_err);
             NECAT_CHECK_LAUNCH(ctx, "k_traceback<B>");
+            NECAT_HIP(ctx, hipEventRecord(b2, sb));
         }
-        NECAT_HIP(ctx, hipEventRecord(e2, s));
+        if (nA) NECAT_HIP(ctx, hipStreamSynchronize(sa));
+        if (nB) NECAT_HIP(ctx, hipStreamSynchronize(sb));
         hipLaunchKernelGGL(k_ext_collect, dim3(grid_for(nA + nB, 256)), dim3(256), 0, s, (const BlockItem*)B.itemsA, nA, (const BlockItem*)B.itemsB, nB, B.active);
         NECAT_CHECK_LAUNCH(ctx, "k_ext_collect");
-        NECAT_HIP(ctx, hipStreamSynchronize(s));
-        ctx->tm.myers_ms += ev_ms(e0, e1);
-        ctx->tm.traceback_ms += ev_ms(e1, e2);
+        const double mA = nA ? ev_ms(a0, a1) : 0, tA = nA ? ev_ms(a1, a2) : 0, mB = nB ? ev_ms(b0, b1) : 0, tB = nB ? ev_ms(b1, b2) : 0;
+        ctx->tm.myers_ms += mA + mB;
+        ctx->tm.traceback_ms += tA + tB;
+        if (g_trace) fprintf(stderr, "[necat] round %3lu: nA=%7u nB=%7u myers %.3f + %.3f ms traceback %.3f + %.3f ms\n", (unsigned long)ctx->tm.rounds, nA, nB, mA, mB, tA, tB);
         ctx->tm.myers_launches += (nA ? 1 : 0) + (nB ? 1 : 0);
         ctx->tm.myers_blocks += nA + nB;
         ctx->tm.rounds += 1;
@@ -466,7 +481,7 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
     ctx->tm.myers_ms = ctx->tm.traceback_ms = 0; ctx->tm.myers_launches = ctx->tm.myers_blocks = ctx->tm.rounds = 0;
     ctx->tm.myers_word_updates = ctx->tm.myers_cells_bases = 0;
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
-    const u32 batch = (u32)std::min<uint64_t>(n, 131072);
+    const u32 batch = (u32)std::min<uint64_t>(n, 524288);      // slab pool <= ~100 GB of the 288 GB HBM
     const u32 groups = (batch + 63) / 64 + 1;
     int rc;
     // candidate-wide arrays
@@ -613,7 +628,10 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
             else hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)g * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, s, dv, dv, (const BlockItem*)d_items, m, d_frag);
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[4], s));
-            if (full) hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats);
+            const bool coop = m <= g_coop_threshold;
+            if (full && coop) hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats);
+            else if (full) hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats);
+            else if (coop) hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((m + 3) / 4), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats);
             else hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats);
             NECAT_CHECK_LAUNCH(ctx, "k_myers");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[5], s));

@@ -29,9 +29,10 @@ struct StageTimer {
 struct necat_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream_a = nullptr, stream_b = nullptr;   // the two block shapes of a round run concurrently
     char err[1024] = {0};
     necat_timings tm;
-    hipEvent_t ev[8];
+    hipEvent_t ev[12];
     std::vector<void*> owned;          // scratch buffers released at destroy
     necat::DevBuf scratch[16];         // grow-only arenas, indexed by purpose
     char devname[256] = {0};

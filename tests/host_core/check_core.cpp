@@ -45,13 +45,15 @@ struct HMat {
 };
 struct HMatR {
     const HMat* m;
-    u64 P(int c, int b) const { return m->P[(size_t)c * m->nw + b]; }
-    u64 M(int c, int b) const { return m->M[(size_t)c * m->nw + b]; }
-    int S(int c, int b) const { return m->S[(size_t)c * m->nw + b]; }
-    int first(int c) const { return m->F[c]; }
-    int last(int c) const { return m->L[c]; }
+    void cur(int c, int b, u64& P, u64& M) const { P = m->P[(size_t)c * m->nw + b]; M = m->M[(size_t)c * m->nw + b]; }
+    LeftView left(int c, int b) const {
+        LeftView v; v.in = b >= m->F[c] && b <= m->L[c]; v.up_in = b - 1 >= m->F[c] && b - 1 <= m->L[c];
+        v.P = v.in ? m->P[(size_t)c * m->nw + b] : 0; v.M = v.in ? m->M[(size_t)c * m->nw + b] : 0;
+        v.S = v.in ? m->S[(size_t)c * m->nw + b] : 0; v.Sup = v.up_in ? m->S[(size_t)c * m->nw + b - 1] : 0;
+        return v;
+    }
 };
-struct HOps { std::vector<int> v; void push(int op) { v.push_back(op); } };
+struct HOps { std::vector<int> v; TailScan ts; void push(int op) { v.push_back(op); tail_push(ts, op); } };
 
 template <int NW, bool FULL>
 static MyersResult run_block(const DevVolume& reads, const DevVolume& ref, const FragGeom& g, int qn, int tn, double error, HMat& mat, u64* tw, MyersRegs<NW>& R)
@@ -148,14 +150,18 @@ int main(int argc, char** argv)
                     MyersResult mr; HOps ops; ++n_blocks;
                     if (!tk.last && tk.qblk == 512 && tk.tblk == 512) {
                         mr = run_block<8, true>(hrd->dv, href.dv, g, tk.qblk, tk.tblk, opt.error, mat, tw, R8);
+                        const int done = ext_block_done(tk, mr.dist, mr.endc);
+                        tail_init(ops.ts, done ? 1 : kOcaMatCnt);
                         if (mr.dist >= 0) { HMatR m{&mat}; traceback_block(tk.qblk, mr.endc + 1, mr.dist, m, ops); }
                         HRops ro{&ops.v}; HSame<8> sm{&R8, tw};
-                        ext_finish_block(tk, mr.dist, mr.endc, (int)ops.v.size(), 1, ro, sm);
+                        ext_finish_block(tk, mr.dist, mr.endc, done, ops.ts, ro, sm);
                     } else {
                         mr = run_block<13, false>(hrd->dv, href.dv, g, tk.qblk, tk.tblk, opt.error, mat, tw, R13);
+                        const int done = ext_block_done(tk, mr.dist, mr.endc);
+                        tail_init(ops.ts, done ? 1 : kOcaMatCnt);
                         if (mr.dist >= 0) { HMatR m{&mat}; traceback_block(tk.qblk, mr.endc + 1, mr.dist, m, ops); }
                         HRops ro{&ops.v}; HSame<13> sm{&R13, tw};
-                        ext_finish_block(tk, mr.dist, mr.endc, (int)ops.v.size(), 1, ro, sm);
+                        ext_finish_block(tk, mr.dist, mr.endc, done, ops.ts, ro, sm);
                     }
                     if (mr.err) { fprintf(stderr, "DP internal error %d\n", mr.err); ++bad_ext; }
                 }

@@ -202,3 +202,44 @@ def test_bad_arguments_fail_loudly(ctx):
     with pytest.raises(capi.NecatError):
         ctx.build_index(vol, 16, 500)                                          # HashBits = 30
     vol.free()
+
+
+def _fresh_ctx(threshold):
+    from necat_amd import capi
+    os.environ["NECAT_COOP_THRESHOLD"] = str(threshold)
+    try:
+        return capi.Context(0)
+    finally:
+        os.environ.pop("NECAT_COOP_THRESHOLD", None)
+
+
+def test_coop_equals_banded(small, tmp_path):
+    """The cooperative (unbanded, 8/16 lanes per block) and the lane-per-block (reference banding) DP
+    kernels must give identical distances, end columns and edit paths, and identical M4 records."""
+    from necat_amd import capi
+    rng = np.random.default_rng(77)
+    seqs, qo, ql, to, tl = _random_pairs(rng, 600, 1, 794, 0.14)
+    from necat_amd.synth import _mutate
+    parts = [seqs]
+    pos = seqs.shape[0]
+    for _ in range(300):
+        t = rng.integers(0, 4, 700, dtype=np.uint8)
+        q = _mutate(t, float(rng.uniform(0.02, 0.3)), rng)
+        if q.shape[0] >= 512:
+            parts += [q[:512], t[:512]]
+            qo.append(pos); ql.append(512); pos += 512
+            to.append(pos); tl.append(512); pos += 512
+    allseq = np.concatenate(parts)
+    outs = []
+    for thr in (0, 1 << 30):
+        c = _fresh_ctx(thr)
+        outs.append(c.edlib_align_batch(allseq, qo, ql, to, tl, 0.5))
+        d, rs = small
+        opt = capi.default_options(**dict(util.FAST, job=1))
+        outs[-1] = outs[-1] + (util.m4_key_rows(capi.pm_main(c, opt, 0, d)[1]),)
+        c.close()
+    a, b = outs
+    for x, y in zip(a[:5], b[:5]):
+        assert np.array_equal(x, y)
+    assert a[5] == b[5] and len(a[5]) > 500
+    assert int((a[0] >= 0).sum()) > 500
