@@ -271,6 +271,7 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
     P.k = opt->kmer_size; P.z = opt->scan_window; P.block_size = opt->block_size; P.s_cutoff = opt->block_score_cutoff;
     P.align_cutoff = opt->align_size_cutoff; P.num_candidates = opt->num_candidates; P.job = opt->job; P.pairwise = pairwise;
     P.read_start_id = read_start_id; P.ref_start_id = ref_start_id;
+    P.debug_phase = getenv("NECAT_SEED_DEBUG") ? atoi(getenv("NECAT_SEED_DEBUG")) : 0;
     int* d_err = nullptr;
     NECAT_HIP(ctx, hipMalloc((void**)&d_err, 4));
     NECAT_HIP(ctx, hipMemsetAsync(d_err, 0, 4, s));

@@ -32,6 +32,7 @@ struct SBlock {           // ScoringBlock (word_finder_aux.h:19-25) + its blk_id
 struct SeedParams {
     int k, z, block_size, s_cutoff, align_cutoff, num_candidates, job, pairwise;
     int read_start_id, ref_start_id;
+    int debug_phase;      // 0 = normal; 1 = stop after seed collection (profiling only)
 };
 
 struct SeedScratch {      // all per-lane, sized from the lane's hit bound H (see seed.hip)
@@ -443,7 +444,7 @@ NECAT_HD int seed_one_strand(const DevVolume& ref, const u64* kmer_stats, const 
         }
     }
     int rc = 0;
-    for (int i = 0; i < nblk; ++i) {
+    for (int i = 0; i < (P.debug_phase == 1 ? 0 : nblk); ++i) {
         SBlock* sb = S.pool + i;
         if (sb->score >= P.s_cutoff && sb->stale >= 2 * P.s_cutoff) {
             int r = find_candidate_for_one_block(S, sb, ref, P, read_id, qdir, L, n_out);

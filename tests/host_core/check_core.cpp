@@ -103,7 +103,7 @@ int main(int argc, char** argv)
         std::vector<uint8_t> fwd, rev, subj;
         SeedParams P; P.k = opt.kmer_size; P.z = opt.scan_window; P.block_size = opt.block_size; P.s_cutoff = opt.block_score_cutoff;
         P.align_cutoff = opt.align_size_cutoff; P.num_candidates = opt.num_candidates; P.job = opt.job; P.pairwise = 1;
-        P.read_start_id = vi.read_start_id[v]; P.ref_start_id = vi.read_start_id[vid];
+        P.read_start_id = vi.read_start_id[v]; P.ref_start_id = vi.read_start_id[vid]; P.debug_phase = 0;
         const int H = 1 << 20;
         std::vector<i32> htk(4 * H, -1), htv(4 * H, 0); std::vector<SBlock> pool(H); std::vector<u64> cs(H + 1), uu(H + 1);
         std::vector<i32> f(H + 1), p(H + 1), t(H + 1), vv(H + 1); std::vector<DevCand> lcan(H + 1), outc(H);
