@@ -47,43 +47,41 @@ struct ExtLists {
     BlockItem* itemsA; BlockItem* itemsB;
 };
 
+// Append the scheduled block of task `ti` to list A (full 512 x 512 blocks) or list B (the
+// variable-size last block of an extension); one atomic per wave and list (ballot-aggregated).
+NECAT_D void ext_append_block(const ExtTask& t, u32 ti, bool go, const ExtLists& L)
+{
+    const bool isA = go && !t.last && t.qblk == kOcaBlockSize && t.tblk == kOcaBlockSize;
+    const bool isB = go && !isA;
+    const int lane = (int)(threadIdx.x & 63);
+    const u64 below = (1ULL << lane) - 1ULL;
+    const u64 mA = __ballot(isA), mB = __ballot(isB);
+    u32 baseA = 0, baseB = 0;
+    if (mA) { const int leader = ctz64(mA); if (lane == leader) baseA = atomicAdd(&L.count[0], (u32)popc64(mA)); baseA = __shfl(baseA, leader); }
+    if (mB) { const int leader = ctz64(mB); if (lane == leader) baseB = atomicAdd(&L.count[1], (u32)popc64(mB)); baseB = __shfl(baseB, leader); }
+    if (go) {
+        BlockItem it;
+        it.g = ext_frag_geom(t); it.task = (i32)ti; it.qn = (i16)t.qblk; it.tn = (i16)t.tblk;
+        if (isA) L.itemsA[baseA + (u32)popc64(mA & below)] = it;
+        else L.itemsB[baseB + (u32)popc64(mB & below)] = it;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_ext_init(const necat_candidate* __restrict__ cands, u32 n, u32 cand_base, int read_start_id, int ref_start_id,
-           const u64* __restrict__ reads_off, const u64* __restrict__ ref_off, ExtTask* __restrict__ tasks, u32* __restrict__ active)
+           const u64* __restrict__ reads_off, const u64* __restrict__ ref_off, ExtTask* __restrict__ tasks, ExtLists L)
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const necat_candidate c = cands[i];
-    const int lq = c.qid - read_start_id, ls = c.sid - ref_start_id;
     ExtTask t;
-    ext_init(t, (i32)(cand_base + i), c.qdir, (i64)reads_off[lq], (i32)c.qsize, (i64)ref_off[ls], (i32)c.ssize, (i32)c.qoff, (i32)c.soff);
-    tasks[i] = t;
-    active[i] = i;
-}
-
-__global__ void __launch_bounds__(256)
-k_ext_plan(ExtTask* __restrict__ tasks, const u32* __restrict__ active, u32 n_active, ExtLists L, u32* __restrict__ next_active_unused)
-{
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_active) return;
-    const u32 ti = active[i];
-    ExtTask t = tasks[ti];
-    const bool go = ext_plan(t);
-    tasks[ti] = t;
-    if (!go) return;
-    BlockItem it;
-    it.g = ext_frag_geom(t); it.task = (i32)ti; it.qn = (i16)t.qblk; it.tn = (i16)t.tblk;
-    if (!t.last && t.qblk == kOcaBlockSize && t.tblk == kOcaBlockSize) L.itemsA[atomicAdd(&L.count[0], 1u)] = it;
-    else L.itemsB[atomicAdd(&L.count[1], 1u)] = it;
-}
-
-// next round's active list = this round's items (A then B)
-__global__ void __launch_bounds__(256)
-k_ext_collect(const BlockItem* __restrict__ itemsA, u32 nA, const BlockItem* __restrict__ itemsB, u32 nB, u32* __restrict__ active)
-{
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nA) active[i] = (u32)itemsA[i].task;
-    else if (i < nA + nB) active[i] = (u32)itemsB[i - nA].task;
+    bool go = false;
+    if (i < n) {
+        const necat_candidate c = cands[i];
+        const int lq = c.qid - read_start_id, ls = c.sid - ref_start_id;
+        ext_init(t, (i32)(cand_base + i), c.qdir, (i64)reads_off[lq], (i32)c.qsize, (i64)ref_off[ls], (i32)c.ssize, (i32)c.qoff, (i32)c.soff);
+        go = ext_plan(t);          // first block (or an immediately finished candidate)
+        tasks[i] = t;
+    }
+    ext_append_block(t, i, go, L);
 }
 
 // frag layout per 64-item group g: word w of lane l at frag[(g * FW + w) * 64 + l];
@@ -365,7 +363,7 @@ template <int NW, int TW, int COLS, int MAXOPS, bool EXPORT>
 __global__ void __launch_bounds__(64)
 k_traceback(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag, const char* __restrict__ slabs, size_t slab_bytes,
             const BlockResult* __restrict__ results, u8* __restrict__ ops_pool, ExtTask* __restrict__ tasks, int tail_match_len,
-            i32* __restrict__ n_ops_out, int* __restrict__ err_flag)
+            i32* __restrict__ n_ops_out, int* __restrict__ err_flag, ExtLists next)
 {
     constexpr int FW = 2 * NW + TW;
     const u32 grp = blockIdx.x;
@@ -396,7 +394,9 @@ k_traceback(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ 
     OpsReader rd; rd.ops = ow.ops;
     SameReader<NW> same; same.fr = frag + (u64)grp * FW * 64 + lane;
     ext_finish_block(t, br.dist, br.endc, done, ow.ts, rd, same);
+    const bool go = ext_plan(t);       // schedule the candidate's next block for the next round (or finish it)
     tasks[it.task] = t;
+    ext_append_block(t, (u32)it.task, go, next);
 }
 
 // ---- final records: pm_worker.c:56-80 (M4 fields), oc_aligner.c:419-450 (coordinates, identity) ----

@@ -379,7 +379,7 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
 namespace {
 
 struct ExtBuffers {
-    ExtTask* tasks; u32* active; u32* count; BlockItem* itemsA; BlockItem* itemsB;
+    ExtTask* tasks; u32* count; BlockItem* itemsA[2]; BlockItem* itemsB[2];   // count[2][2]: per list parity (nA, nB)
     u64* fragA; u64* fragB; char* slabs; u8* opsA; u8* opsB; BlockResult* resA; BlockResult* resB; unsigned long long* stats;
 };
 
@@ -388,63 +388,61 @@ int run_rounds(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, ExtB
                int tail_match_len, int* d_err)
 {
     hipStream_t s = ctx->stream, sa = ctx->stream_a, sb = ctx->stream_b;
-    u32 n_active = n_tasks;
-    ExtLists L; L.count = B.count; L.itemsA = B.itemsA; L.itemsB = B.itemsB;
+    (void)n_tasks;
     hipEvent_t a0 = ctx->ev[4], a1 = ctx->ev[5], a2 = ctx->ev[6], b0 = ctx->ev[7], b1 = ctx->ev[8], b2 = ctx->ev[9];
-    while (n_active) {
-        NECAT_HIP(ctx, hipMemsetAsync(B.count, 0, 8, s));
-        hipLaunchKernelGGL(k_ext_plan, dim3(grid_for(n_active, 256)), dim3(256), 0, s, B.tasks, (const u32*)B.active, n_active, L, (u32*)nullptr);
-        NECAT_CHECK_LAUNCH(ctx, "k_ext_plan");
+    // lists of parity p were filled by k_ext_init (round 0) or by the previous round's tracebacks
+    for (int p = 0;; p ^= 1) {
         u32 cnt[2] = {0, 0};
-        NECAT_HIP(ctx, hipMemcpyAsync(cnt, B.count, 8, hipMemcpyDeviceToHost, s));
+        NECAT_HIP(ctx, hipMemcpyAsync(cnt, B.count + 2 * p, 8, hipMemcpyDeviceToHost, s));
+        NECAT_HIP(ctx, hipMemsetAsync(B.count + 2 * (p ^ 1), 0, 8, s));
         NECAT_HIP(ctx, hipStreamSynchronize(s));
         const u32 nA = cnt[0], nB = cnt[1];
         if (nA + nB == 0) break;
         const u32 gA = (nA + 63) / 64, gB = (nB + 63) / 64;
         char* slabsB = B.slabs + (size_t)gA * kSlabA;
+        const BlockItem* itA = B.itemsA[p]; const BlockItem* itB = B.itemsB[p];
+        ExtLists next; next.count = B.count + 2 * (p ^ 1); next.itemsA = B.itemsA[p ^ 1]; next.itemsB = B.itemsB[p ^ 1];
         // the two shapes of the round are independent: list A on stream_a, list B on stream_b
         if (nA) {
             hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)gA * 64 * (kWordsA + kTWordsA), 256)), dim3(256), 0, sa,
-                               drd, dref, (const BlockItem*)B.itemsA, nA, B.fragA);
+                               drd, dref, itA, nA, B.fragA);
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<A>");
             NECAT_HIP(ctx, hipEventRecord(a0, sa));
             if (nA <= g_coop_threshold)
-                hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((nA + 7) / 8), dim3(64), 0, sa, (const BlockItem*)B.itemsA, nA,
+                hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((nA + 7) / 8), dim3(64), 0, sa, itA, nA,
                                    (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA, B.stats);
             else
-                hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(gA), dim3(64), 0, sa, (const BlockItem*)B.itemsA, nA,
+                hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(gA), dim3(64), 0, sa, itA, nA,
                                    (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA, B.stats);
             NECAT_CHECK_LAUNCH(ctx, "k_myers<A>");
             NECAT_HIP(ctx, hipEventRecord(a1, sa));
-            hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false>), dim3(gA), dim3(64), 0, sa, (const BlockItem*)B.itemsA, nA,
+            hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false>), dim3(gA), dim3(64), 0, sa, itA, nA,
                                (const u64*)B.fragA, (const char*)B.slabs, kSlabA, (const BlockResult*)B.resA, B.opsA, B.tasks, tail_match_len,
-                               (i32*)nullptr, d_err);
+                               (i32*)nullptr, d_err, next);
             NECAT_CHECK_LAUNCH(ctx, "k_traceback<A>");
             NECAT_HIP(ctx, hipEventRecord(a2, sa));
         }
         if (nB) {
             hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, sb,
-                               drd, dref, (const BlockItem*)B.itemsB, nB, B.fragB);
+                               drd, dref, itB, nB, B.fragB);
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
             NECAT_HIP(ctx, hipEventRecord(b0, sb));
             if (nB <= g_coop_threshold)
-                hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, sb, (const BlockItem*)B.itemsB, nB,
+                hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB,
                                    (const u64*)B.fragB, slabsB, kSlabB, error, B.resB, B.stats);
             else
-                hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, sb, (const BlockItem*)B.itemsB, nB,
+                hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB,
                                    (const u64*)B.fragB, slabsB, kSlabB, error, B.resB, B.stats);
             NECAT_CHECK_LAUNCH(ctx, "k_myers<B>");
             NECAT_HIP(ctx, hipEventRecord(b1, sb));
-            hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false>), dim3(gB), dim3(64), 0, sb, (const BlockItem*)B.itemsB, nB,
+            hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB,
                                (const u64*)B.fragB, (const char*)slabsB, kSlabB, (const BlockResult*)B.resB, B.opsB, B.tasks, tail_match_len,
-                               (i32*)nullptr, d_err);
+                               (i32*)nullptr, d_err, next);
             NECAT_CHECK_LAUNCH(ctx, "k_traceback<B>");
             NECAT_HIP(ctx, hipEventRecord(b2, sb));
         }
         if (nA) NECAT_HIP(ctx, hipStreamSynchronize(sa));
         if (nB) NECAT_HIP(ctx, hipStreamSynchronize(sb));
-        hipLaunchKernelGGL(k_ext_collect, dim3(grid_for(nA + nB, 256)), dim3(256), 0, s, (const BlockItem*)B.itemsA, nA, (const BlockItem*)B.itemsB, nB, B.active);
-        NECAT_CHECK_LAUNCH(ctx, "k_ext_collect");
         const double mA = nA ? ev_ms(a0, a1) : 0, tA = nA ? ev_ms(a1, a2) : 0, mB = nB ? ev_ms(b0, b1) : 0, tB = nB ? ev_ms(b1, b2) : 0;
         ctx->tm.myers_ms += mA + mB;
         ctx->tm.traceback_ms += tA + tB;
@@ -452,7 +450,6 @@ int run_rounds(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, ExtB
         ctx->tm.myers_launches += (nA ? 1 : 0) + (nB ? 1 : 0);
         ctx->tm.myers_blocks += nA + nB;
         ctx->tm.rounds += 1;
-        n_active = nA + nB;
     }
     return NECAT_OK;
 }
@@ -498,8 +495,8 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
     NECAT_HIP(ctx, hipMemsetAsync(d_outcnt, 0, 8, s));
     NECAT_HIP(ctx, hipMemsetAsync(d_err, 0, 4, s));
     auto cleanup = [&]() { (void)hipFree(d_cands); (void)hipFree(d_m4); (void)hipFree(d_out); (void)hipFree(d_ok); (void)hipFree(d_outcnt); (void)hipFree(d_err); if (d_goff) (void)hipFree(d_goff); };
-    if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_TASKS], (size_t)batch * (sizeof(ExtTask) + 4) + 64)) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], (size_t)batch * 2 * sizeof(BlockItem) + 64)) ||
+    if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_TASKS], (size_t)batch * sizeof(ExtTask) + 64)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], (size_t)batch * 4 * sizeof(BlockItem) + 64)) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_FRAG], (size_t)groups * 64 * (kFragWordsA + kFragWordsB) * 8)) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_MAT], (size_t)groups * kSlabB + kSlabA)) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_OPS], (size_t)groups * 64 * (kOpsA + kOpsB))) ||
@@ -507,25 +504,26 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
     ExtBuffers B;
     {
         char* p = (char*)ctx->scratch[SC_EXT_TASKS].p;
-        B.tasks = (ExtTask*)p; p += (size_t)batch * sizeof(ExtTask);
-        B.active = (u32*)p;
-        B.count = d_outcnt + 0;   // placeholder, replaced below
-        char* q = (char*)ctx->scratch[SC_EXT_LISTS].p;
-        B.itemsA = (BlockItem*)q; B.itemsB = B.itemsA + batch;
+        B.tasks = (ExtTask*)p;
+        B.count = nullptr;        // set below
+        BlockItem* q = (BlockItem*)ctx->scratch[SC_EXT_LISTS].p;
+        B.itemsA[0] = q; B.itemsB[0] = q + batch; B.itemsA[1] = q + 2 * (size_t)batch; B.itemsB[1] = q + 3 * (size_t)batch;
         B.fragA = (u64*)ctx->scratch[SC_EXT_FRAG].p; B.fragB = B.fragA + (size_t)groups * 64 * kFragWordsA;
         B.slabs = (char*)ctx->scratch[SC_EXT_MAT].p;
         B.opsA = (u8*)ctx->scratch[SC_EXT_OPS].p; B.opsB = B.opsA + (size_t)groups * 64 * kOpsA;
         B.resA = (BlockResult*)ctx->scratch[SC_EXT_RES].p; B.resB = B.resA + (size_t)groups * 64;
     }
     u32* d_count = nullptr;
-    NECAT_HIP(ctx, hipMalloc((void**)&d_count, 8 + 16));
+    NECAT_HIP(ctx, hipMalloc((void**)&d_count, 16 + 16));
     B.count = d_count;
-    B.stats = (unsigned long long*)(d_count + 2);
-    NECAT_HIP(ctx, hipMemsetAsync(B.stats, 0, 16, s));
+    B.stats = (unsigned long long*)(d_count + 4);
+    NECAT_HIP(ctx, hipMemsetAsync(d_count, 0, 32, s));
     for (uint64_t base = 0; base < n; base += batch) {
         const u32 nb = (u32)std::min<uint64_t>(batch, n - base);
+        NECAT_HIP(ctx, hipMemsetAsync(B.count, 0, 16, s));
+        ExtLists L0; L0.count = B.count; L0.itemsA = B.itemsA[0]; L0.itemsB = B.itemsB[0];
         hipLaunchKernelGGL(k_ext_init, dim3(grid_for(nb, 256)), dim3(256), 0, s, (const necat_candidate*)(d_cands + base), nb, (u32)base,
-                           read_start_id, ref_start_id, (const u64*)reads->seq_off, (const u64*)ref->seq_off, B.tasks, B.active);
+                           read_start_id, ref_start_id, (const u64*)reads->seq_off, (const u64*)ref->seq_off, B.tasks, L0);
         NECAT_CHECK_LAUNCH(ctx, "k_ext_init");
         if ((rc = run_rounds(ctx, dref, drd, B, nb, opt->error, tail_match_len, d_err))) { (void)hipFree(d_count); cleanup(); return rc; }
         hipLaunchKernelGGL(k_ext_result, dim3(grid_for(nb, 256)), dim3(256), 0, s, (const ExtTask*)B.tasks, nb, (const necat_candidate*)(d_cands + base),
@@ -637,9 +635,9 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
             NECAT_CHECK_LAUNCH(ctx, "k_myers");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[5], s));
             if (full) hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, (const char*)d_slabs, slab,
-                                         (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err);
+                                         (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists());
             else hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, (const char*)d_slabs, slab,
-                                    (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err);
+                                    (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists());
             NECAT_CHECK_LAUNCH(ctx, "k_traceback");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[6], s));
             std::vector<BlockResult> hres(m); std::vector<i32> hn(m); std::vector<u8> hops((size_t)g * 64 * maxops);
