@@ -244,7 +244,6 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
     NECAT_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const u32 nreads = (u32)reads->nseq;
-    std::vector<necat_candidate> all;
     if (nreads == 0) return NECAT_OK;
     DevVolume dref = dev_view(ref), drd = dev_view(reads);
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
@@ -264,9 +263,6 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
     auto work = [&](u32 r) { return (u64)std::max(hits[2 * (size_t)r], hits[2 * (size_t)r + 1]); };
     std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return work(a) > work(b); });
     const u64 budget_hits = 48ULL << 20;     // ~48 M pool blocks (~13 GB of SBlocks) per chunk
-    std::vector<i32> ncand_of_read(nreads, 0);
-    std::vector<std::vector<necat_candidate>> chunk_out;
-    std::vector<std::vector<u32>> chunk_reads;
     SeedParams P;
     P.k = opt->kmer_size; P.z = opt->scan_window; P.block_size = opt->block_size; P.s_cutoff = opt->block_score_cutoff;
     P.align_cutoff = opt->align_size_cutoff; P.num_candidates = opt->num_candidates; P.job = opt->job; P.pairwise = pairwise;
@@ -275,36 +271,34 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
     int* d_err = nullptr;
     NECAT_HIP(ctx, hipMalloc((void**)&d_err, 4));
     NECAT_HIP(ctx, hipMemsetAsync(d_err, 0, 4, s));
-    // final per-read offsets need all counts: collect per chunk, assemble at the end
-    std::vector<necat_candidate*> host_parts;
-    std::vector<u64> read_final_off(nreads + 1, 0);
-    struct ChunkRec { u32 lo, hi; std::vector<i32> ncand; std::vector<SeedMeta> meta; };
     u32 pos = 0;
-    std::vector<necat_candidate> result;
-    std::vector<std::pair<u32, std::vector<necat_candidate>>> per_chunk;
     std::vector<i32> ncands_by_order(nreads, 0);
-    std::vector<std::vector<DevCand>> unused;
     // storage of every chunk's compacted candidates in ORDER-index space
     std::vector<necat_candidate> packed_all;
     std::vector<u64> packed_off(nreads + 1, 0);
     while (pos < nreads) {
         u64 acc = 0; u32 hi = pos;
-        while (hi < nreads && (hi == pos || acc + work(order[hi]) + 1 <= budget_hits)) { acc += work(order[hi]) + 1; ++hi; }
+        auto both = [&](u32 r) { return (u64)hits[2 * (size_t)r] + hits[2 * (size_t)r + 1] + 2; };
+        while (hi < nreads && (hi == pos || acc + both(order[hi]) <= budget_hits)) { acc += both(order[hi]); ++hi; }
         const u32 n = hi - pos;
         std::vector<SeedMeta> meta(n);
         u64 ht_tot = 0, pool_tot = 0, chain_tot = 0, out_tot = 0;
         for (u32 i = 0; i < n; ++i) {
             const u32 r = order[pos + i];
-            const u64 H = std::max<u64>(1, work(r));
-            u64 cap = 4; while (cap < 2 * H) cap <<= 1;
             SeedMeta& m = meta[i];
-            m.ht_off = ht_tot; m.ht_mask = (u32)(cap - 1); ht_tot += cap;
-            m.pool_off = pool_tot; m.pool_cap = (u32)H; pool_tot += H;
-            m.chain_off = chain_tot; m.cs_cap = (u32)(H + 1); chain_tot += H + 1;
+            u64 Hmax = 1;
+            for (int st = 0; st < 2; ++st) {
+                const u64 H = std::max<u64>(1, hits[2 * (size_t)r + st]);
+                u64 cap = 4; while (cap < 2 * H) cap <<= 1;
+                m.ht_off[st] = ht_tot; m.ht_mask[st] = (u32)(cap - 1); ht_tot += cap;
+                m.pool_off[st] = pool_tot; m.pool_cap[st] = (u32)H; pool_tot += H;
+                Hmax = std::max(Hmax, H);
+            }
+            m.chain_off = chain_tot; m.cs_cap = (u32)(Hmax + 1); chain_tot += Hmax + 1;
             const u64 oc = (u64)hits[2 * (size_t)r] + hits[2 * (size_t)r + 1] + 1;
             m.out_off = out_tot; m.out_cap = (u32)oc; out_tot += oc;
         }
-        if ((rc = buf_ensure(ctx, ctx->scratch[SC_SEED_META], n * sizeof(SeedMeta) + n * 4 + n * 4 + n * 8 + 64)) ||
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_SEED_META], n * sizeof(SeedMeta) + (size_t)n * (8 + 4 + 4 + 8) + 64)) ||
             (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_HT], ht_tot * 8)) ||
             (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_POOL], pool_tot * sizeof(SBlock))) ||
             (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_CHAIN], chain_tot * (8 + 16 + 8 + sizeof(DevCand)))) ||
@@ -312,6 +306,7 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
         char* mb = (char*)ctx->scratch[SC_SEED_META].p;
         SeedMeta* d_meta = (SeedMeta*)mb; mb += n * sizeof(SeedMeta);
         u64* d_final = (u64*)mb; mb += (size_t)n * 8;
+        i32* d_nblk = (i32*)mb; mb += (size_t)n * 8;
         u32* d_order = (u32*)mb; mb += (size_t)n * 4;
         i32* d_ncand = (i32*)mb;
         SeedArenas A;
@@ -326,9 +321,12 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
         NECAT_HIP(ctx, hipMemcpyAsync(d_meta, meta.data(), n * sizeof(SeedMeta), hipMemcpyHostToDevice, s));
         NECAT_HIP(ctx, hipMemcpyAsync(d_order, order.data() + pos, (size_t)n * 4, hipMemcpyHostToDevice, s));
         NECAT_HIP(ctx, hipMemsetAsync(A.ht_key, 0xFF, ht_tot * 4, s));
-        hipLaunchKernelGGL(k_seed_reads, dim3(grid_for(n, 64)), dim3(64), 0, s, dref, drd, (const u64*)ix->kmer_stats, (const u64*)ix->offset_list,
-                           P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A, d_ncand, d_err);
-        NECAT_CHECK_LAUNCH(ctx, "k_seed_reads");
+        hipLaunchKernelGGL(k_seed_collect, dim3(grid_for((u64)2 * n, 64)), dim3(64), 0, s, dref, drd, (const u64*)ix->kmer_stats, (const u64*)ix->offset_list,
+                           P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A, d_nblk, d_err);
+        NECAT_CHECK_LAUNCH(ctx, "k_seed_collect");
+        hipLaunchKernelGGL(k_seed_eval, dim3(n), dim3(64), 0, s, dref, drd, P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A,
+                           (const i32*)d_nblk, d_ncand, d_err);
+        NECAT_CHECK_LAUNCH(ctx, "k_seed_eval");
         std::vector<i32> nc(n);
         NECAT_HIP(ctx, hipMemcpyAsync(nc.data(), d_ncand, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         int herr = 0;

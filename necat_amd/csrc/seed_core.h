@@ -141,17 +141,28 @@ NECAT_HD bool ddf_ok(int dloc, int dseed, float scan_window)
     return d < 0.25;
 }
 
-NECAT_HD int scoring_seeds(const int* t_loc, const int* t_seedn, int* t_score, int* loc, int k, int* rep_loc,
-                           float scan_window, int read_size)
+// word_finder.c:141-168 is split in two so that the O(n^2) vote can be spread over the lanes of a
+// wave (seed_kernels.h) while the order-dependent selection stays scalar:
+//   scoring_vote_row : the votes seed i collects from / gives to the seeds j > i ("one vote per
+//                      distinct later kmer_id" rule carried by tempi)
+//   scoring_pick     : max vote, repeat count and the anchor choice (incl. the loc[0]==0 quirk)
+template <class AddJ>
+NECAT_HD int scoring_vote_row(const int* t_loc, const int* t_seedn, int i, int k, float scan_window, int read_size, AddJ& add_j)
 {
-    int i, j, maxval = 0, maxi = 0, rep = 0, lasti = 0, tempi;
-    for (i = 0; i < k; i++) t_score[i] = 0;
-    for (i = 0; i < k - 1; i++)
-        for (j = i + 1, tempi = t_seedn[i]; j < k; j++)
-            if (tempi != t_seedn[j] && t_seedn[j] - t_seedn[i] > 0 && t_loc[j] - t_loc[i] > 0 &&
-                t_loc[j] - t_loc[i] < read_size && ddf_ok(t_loc[j] - t_loc[i], t_seedn[j] - t_seedn[i], scan_window)) {
-                t_score[i]++; t_score[j]++; tempi = t_seedn[j];
-            }
+    int own = 0;
+    int tempi = t_seedn[i];
+    for (int j = i + 1; j < k; j++)
+        if (tempi != t_seedn[j] && t_seedn[j] - t_seedn[i] > 0 && t_loc[j] - t_loc[i] > 0 &&
+            t_loc[j] - t_loc[i] < read_size && ddf_ok(t_loc[j] - t_loc[i], t_seedn[j] - t_seedn[i], scan_window)) {
+            ++own; add_j(j); tempi = t_seedn[j];
+        }
+    return own;
+}
+
+NECAT_HD int scoring_pick(const int* t_loc, const int* t_seedn, const int* t_score, int* loc, int k, int* rep_loc,
+                          float scan_window, int read_size)
+{
+    int i, j, maxval = 0, maxi = 0, rep = 0, lasti = 0;
     for (i = 0; i < k; i++) {
         if (maxval < t_score[i]) { maxval = t_score[i]; maxi = i; rep = 0; }
         else if (maxval == t_score[i]) { rep++; lasti = i; }
@@ -179,6 +190,17 @@ NECAT_HD int scoring_seeds(const int* t_loc, const int* t_seedn, int* t_score, i
         return 1;
     }
     return 0;
+}
+
+struct ScoreAdder { int* t_score; NECAT_HD void operator()(int j) { t_score[j]++; } };
+
+NECAT_HD int scoring_seeds(const int* t_loc, const int* t_seedn, int* t_score, int* loc, int k, int* rep_loc,
+                           float scan_window, int read_size)
+{
+    for (int i = 0; i < k; i++) t_score[i] = 0;
+    ScoreAdder add; add.t_score = t_score;
+    for (int i = 0; i < k - 1; i++) t_score[i] += scoring_vote_row(t_loc, t_seedn, i, k, scan_window, read_size, add);
+    return scoring_pick(t_loc, t_seedn, t_score, loc, k, rep_loc, scan_window, read_size);
 }
 
 // chain_dp.c:37-159.  Seeds are S.cs[0..n) sorted ascending by (soff, qoff); chains land in S.lcan.
@@ -266,99 +288,93 @@ NECAT_HD void clear_block_scores(const SeedScratch& S, const DevCand& can, u64 s
     for (i64 i = sblk; i <= eblk; ++i) { SBlock* b = sb_find(S, (i32)i); if (b) b->score = 0; }
 }
 
-// word_finder.c:184-360.  Returns 1 if a candidate was appended, 0 if not, <0 on capacity error.
-NECAT_HD int find_candidate_for_one_block(SeedScratch& S, SBlock* cur, const DevVolume& ref, const SeedParams& P,
-                                          int qid, int qdir, int qsize, int* n_out)
+// ---- find_candidate_for_one_block (word_finder.c:184-360) in stages, so that the wave kernel can
+// ---- run the data-parallel ones (vote, gather) on all lanes and the rest on one lane.
+
+// stage A: seeds of block b-1 (if it has any) followed by those of block b, offsets of b shifted by the
+// block size (word_finder.c:197-222)
+NECAT_HD int block_seed_lists(const SeedScratch& S, const SBlock* cur, int bs, int* kmer_id_list, int* blk_offset_list, u64* blk_start)
 {
-    int kmer_id_list[kBlkSeeds * 2], blk_offset_list[kBlkSeeds * 2], score_list[kBlkSeeds * 2];
     const int block_id = cur->block_id;
-    const int bs = P.block_size, z = P.z;
     int n_seeds = 0, A = 0;
-    u64 blk_start = (u64)bs * (u64)block_id;
-    SBlock* prev = sb_find(S, block_id - 1);
+    *blk_start = (u64)bs * (u64)block_id;
+    const SBlock* prev = sb_find(S, block_id - 1);
     if (prev && prev->score) {
         for (int i = 0; i < prev->score; ++i) { kmer_id_list[n_seeds] = prev->kmer_id[i]; blk_offset_list[n_seeds] = prev->blk_offset[i]; ++n_seeds; }
         A = bs;
-        blk_start = (u64)bs * (u64)(block_id - 1);
+        *blk_start = (u64)bs * (u64)(block_id - 1);
     }
     for (int i = 0; i < cur->score; ++i) { kmer_id_list[n_seeds] = cur->kmer_id[i]; blk_offset_list[n_seeds] = cur->blk_offset[i] + A; ++n_seeds; }
+    return n_seeds;
+}
 
-    int max_score_id = -1, sc4[4];
-    if (!scoring_seeds(blk_offset_list, kmer_id_list, score_list, sc4, n_seeds, &max_score_id, (float)z, qsize)) return 0;
-    if (score_list[max_score_id] < 2 * P.s_cutoff) return 0;
+struct AnchorGeom {       // word_finder.c:230-246
+    u64 seed_tid, seed_tstart, seed_tend;
+    i64 seed_tsize, stoff, seed_qoff;
+    int seed_bid, bid_start, bid_end;
+};
 
-    u64 seed_toff = (u64)sc4[0] + blk_start;
-    const i64 seed_qoff = (i64)(sc4[1] - 1) * z;
-    const int seed_bid = (int)(seed_toff / (u64)bs);
-    const u64 seed_tid = seq_of_offset(ref.seq_off, ref.nseq, seed_toff);
-    const u64 seed_tstart = ref.seq_off[seed_tid];
-    const u64 seed_tend = ref.seq_off[seed_tid + 1];
-    const i64 seed_tsize = (i64)(seed_tend - seed_tstart);
-    seed_toff -= seed_tstart;
-    const i64 stoff = (i64)seed_toff;
-    i64 L = stoff < seed_qoff ? stoff : seed_qoff;
-    int bid_start = seed_bid - (int)(L / bs) - 1;
-    if (bid_start < 0) bid_start = 0;
-    const i64 tr = seed_tsize - stoff, qr = (i64)qsize - seed_qoff;
+NECAT_HD AnchorGeom anchor_geometry(const DevVolume& ref, int loc0, int seedn0, u64 blk_start, int bs, int z, int qsize)
+{
+    AnchorGeom g;
+    u64 seed_toff = (u64)loc0 + blk_start;
+    g.seed_qoff = (i64)(seedn0 - 1) * z;
+    g.seed_bid = (int)(seed_toff / (u64)bs);
+    g.seed_tid = seq_of_offset(ref.seq_off, ref.nseq, seed_toff);
+    g.seed_tstart = ref.seq_off[g.seed_tid];
+    g.seed_tend = ref.seq_off[g.seed_tid + 1];
+    g.seed_tsize = (i64)(g.seed_tend - g.seed_tstart);
+    seed_toff -= g.seed_tstart;
+    g.stoff = (i64)seed_toff;
+    i64 L = g.stoff < g.seed_qoff ? g.stoff : g.seed_qoff;
+    g.bid_start = g.seed_bid - (int)(L / bs) - 1;
+    if (g.bid_start < 0) g.bid_start = 0;
+    const i64 tr = g.seed_tsize - g.stoff, qr = (i64)qsize - g.seed_qoff;
     L = tr < qr ? tr : qr;
-    const int bid_end = seed_bid + (int)((L + bs - 1) / bs);
+    g.bid_end = g.seed_bid + (int)((L + bs - 1) / bs);
+    return g;
+}
 
-    int ncs = 0, seed_score = 0;
-    for (int i = bid_start; i <= seed_bid; ++i) {
-        SBlock* sb = sb_find(S, i);
-        if (!sb || !sb->score) continue;
-        const u64 bstart = (u64)i * (u64)bs;
-        int relevant = 0;
-        for (int k = 0; k < sb->score; ++k) {
-            u64 toff = bstart + (u64)(i64)sb->blk_offset[k];
-            const i64 qoff = (i64)(sb->kmer_id[k] - 1) * z;
-            if (toff < seed_tstart) continue;
-            toff -= seed_tstart;
-            if ((i64)toff < stoff && qoff < seed_qoff) {
-                double s = 1.0 * (double)(u64)(stoff - (i64)toff) / (double)(u64)(seed_qoff - qoff) - 1.0;
-                if (s < 0) s = -s;
-                if (!(s < 0.25)) continue;
-                ++relevant;
-                if ((u32)ncs >= S.cs_cap) return kSeedErrCapacity;
-                S.cs[ncs++] = (toff << 32) | (u64)(u32)qoff;
-            }
-        }
-        if (i != seed_bid && 1.0 * relevant / sb->score >= 0.4) sb->score = 0;
-        seed_score += relevant;
+// stage D, one seed: is seed k of block i co-linear with the anchor (left: word_finder.c:249-275,
+// right: :281-307)?  On success *key receives the chain-seed key soff<<32|qoff.
+NECAT_HD bool gather_test(const AnchorGeom& g, const SBlock* sb, int k, int block_i, int bs, int z, bool right, u64* key)
+{
+    u64 toff = (u64)block_i * (u64)bs + (u64)(i64)sb->blk_offset[k];
+    const i64 qoff = (i64)(sb->kmer_id[k] - 1) * z;
+    if (!right) {
+        if (toff < g.seed_tstart) return false;
+        toff -= g.seed_tstart;
+        if (!((i64)toff < g.stoff && qoff < g.seed_qoff)) return false;
+        double s = 1.0 * (double)(u64)(g.stoff - (i64)toff) / (double)(u64)(g.seed_qoff - qoff) - 1.0;
+        if (s < 0) s = -s;
+        if (!(s < 0.25)) return false;
+    } else {
+        if (toff >= g.seed_tend) return false;
+        toff -= g.seed_tstart;
+        if (!((i64)toff > g.stoff && qoff > g.seed_qoff)) return false;
+        double s = 1.0 * (double)(u64)((i64)toff - g.stoff) / (double)(u64)(qoff - g.seed_qoff) - 1.0;
+        if (s < 0) s = -s;
+        if (!(s < 0.25)) return false;
     }
-    if ((u32)ncs >= S.cs_cap) return kSeedErrCapacity;
-    S.cs[ncs++] = ((u64)stoff << 32) | (u64)(u32)seed_qoff;
-    for (int i = seed_bid; i <= bid_end; ++i) {
-        SBlock* sb = sb_find(S, i);
-        if (!sb || !sb->score) continue;
-        const u64 bstart = (u64)i * (u64)bs;
-        int relevant = 0;
-        for (int k = 0; k < sb->score; ++k) {
-            u64 toff = bstart + (u64)(i64)sb->blk_offset[k];
-            const i64 qoff = (i64)(sb->kmer_id[k] - 1) * z;
-            if (toff >= seed_tend) continue;
-            toff -= seed_tstart;
-            if ((i64)toff > stoff && qoff > seed_qoff) {
-                double s = 1.0 * (double)(u64)((i64)toff - stoff) / (double)(u64)(qoff - seed_qoff) - 1.0;
-                if (s < 0) s = -s;
-                if (!(s < 0.25)) continue;
-                ++relevant;
-                if ((u32)ncs >= S.cs_cap) return kSeedErrCapacity;
-                S.cs[ncs++] = (toff << 32) | (u64)(u32)qoff;
-            }
-        }
-        if (i != seed_bid && 1.0 * relevant / sb->score >= 0.4) sb->score = 0;
-        seed_score += relevant;
-    }
+    *key = (toff << 32) | (u64)(u32)qoff;
+    return true;
+}
 
+// the 40 % rule of word_finder.c:273 / :305
+NECAT_HD bool gather_zeroes_block(int relevant, int score) { return 1.0 * relevant / score >= 0.4; }
+
+// stage E: sort the chain seeds, chain them, choose and emit the candidate (word_finder.c:309-358)
+NECAT_HD int finish_candidate(SeedScratch& S, int ncs, int seed_score, const AnchorGeom& g, const SeedParams& P,
+                              int qid, int qdir, int qsize, int* n_out)
+{
     heap_sort_u64(S.cs, ncs);   // ChainSeedLT: (soff, qoff) ascending
     DevCand proto;
-    proto.qid = qid; proto.sid = (i32)seed_tid; proto.qdir = qdir; proto.score = 0;
-    proto.qbeg = proto.qend = 0; proto.qsize = qsize; proto.sbeg = proto.send = 0; proto.ssize = (i32)seed_tsize;
+    proto.qid = qid; proto.sid = (i32)g.seed_tid; proto.qdir = qdir; proto.score = 0;
+    proto.qbeg = proto.qend = 0; proto.qsize = qsize; proto.sbeg = proto.send = 0; proto.ssize = (i32)g.seed_tsize;
     proto.qoff = proto.soff = 0;
     const int ncan = chain_dp(S, ncs, P.k, P.s_cutoff, proto);
     if (!ncan) return 0;
-
+    const i64 seed_qoff = g.seed_qoff, stoff = g.stoff;
     auto contains = [&](const DevCand& c) {
         return seed_qoff >= c.qbeg && seed_qoff < c.qend && stoff >= c.sbeg && stoff < c.send;
     };
@@ -379,7 +395,7 @@ NECAT_HD int find_candidate_for_one_block(SeedScratch& S, SBlock* cur, const Dev
     }
     if (!emit) return 0;
     can.score = seed_score; can.qoff = (i32)seed_qoff; can.soff = (i32)stoff;
-    clear_block_scores(S, can, seed_tstart, bs);
+    clear_block_scores(S, can, g.seed_tstart, P.block_size);
     const bool ok = (can.send - can.sbeg >= P.align_cutoff) || (can.qend - can.qbeg >= P.align_cutoff);
     if (ok) {
         if ((u32)*n_out >= S.out_cap) return kSeedErrCapacity;
@@ -388,11 +404,49 @@ NECAT_HD int find_candidate_for_one_block(SeedScratch& S, SBlock* cur, const Dev
     return ok ? 1 : 0;
 }
 
-// One strand of one read: word_finder.c:364-412 (find_candidates) incl. collect_seeds :107-139.
-// Candidates are appended to S.out with LOCAL ids.  Returns 0 or kSeedErrCapacity.
-NECAT_HD int seed_one_strand(const DevVolume& ref, const u64* kmer_stats, const u64* offset_list,
-                             const DevVolume& reads, int read_id, int qdir, const SeedParams& P,
-                             SeedScratch& S, int* n_out)
+// word_finder.c:184-360, scalar composition of the stages.  Returns 1 if a candidate was appended,
+// 0 if not, <0 on capacity error.
+NECAT_HD int find_candidate_for_one_block(SeedScratch& S, SBlock* cur, const DevVolume& ref, const SeedParams& P,
+                                          int qid, int qdir, int qsize, int* n_out)
+{
+    int kmer_id_list[kBlkSeeds * 2], blk_offset_list[kBlkSeeds * 2], score_list[kBlkSeeds * 2];
+    const int bs = P.block_size, z = P.z;
+    u64 blk_start;
+    const int n_seeds = block_seed_lists(S, cur, bs, kmer_id_list, blk_offset_list, &blk_start);
+    int max_score_id = -1, sc4[4];
+    if (!scoring_seeds(blk_offset_list, kmer_id_list, score_list, sc4, n_seeds, &max_score_id, (float)z, qsize)) return 0;
+    if (score_list[max_score_id] < 2 * P.s_cutoff) return 0;
+    const AnchorGeom g = anchor_geometry(ref, sc4[0], sc4[1], blk_start, bs, z, qsize);
+    int ncs = 0, seed_score = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int lo = pass == 0 ? g.bid_start : g.seed_bid, hi = pass == 0 ? g.seed_bid : g.bid_end;
+        for (int i = lo; i <= hi; ++i) {
+            SBlock* sb = sb_find(S, i);
+            if (!sb || !sb->score) continue;
+            int relevant = 0;
+            for (int k = 0; k < sb->score; ++k) {
+                u64 key;
+                if (!gather_test(g, sb, k, i, bs, z, pass == 1, &key)) continue;
+                ++relevant;
+                if ((u32)ncs >= S.cs_cap) return kSeedErrCapacity;
+                S.cs[ncs++] = key;
+            }
+            if (i != g.seed_bid && gather_zeroes_block(relevant, sb->score)) sb->score = 0;
+            seed_score += relevant;
+        }
+        if (pass == 0) {
+            if ((u32)ncs >= S.cs_cap) return kSeedErrCapacity;
+            S.cs[ncs++] = ((u64)g.stoff << 32) | (u64)(u32)g.seed_qoff;
+        }
+    }
+    return finish_candidate(S, ncs, seed_score, g, P, qid, qdir, qsize, n_out);
+}
+
+// collect_seeds (word_finder.c:107-139) incl. extract_hash_values (:66-83) and fill_one_seed (:85-104)
+// for one strand of one read.  Returns the number of touched blocks (pool entries, in first-touch
+// order) or kSeedErrCapacity.
+NECAT_HD int seed_collect_strand(const DevVolume& ref, const u64* kmer_stats, const u64* offset_list,
+                                 const DevVolume& reads, int read_id, int qdir, const SeedParams& P, SeedScratch& S)
 {
     const u64 q_goff = reads.seq_off[read_id];
     const int L = (int)(reads.seq_off[read_id + 1] - q_goff);
@@ -443,6 +497,24 @@ NECAT_HD int seed_one_strand(const DevVolume& ref, const u64* kmer_stats, const 
             sb->stale = sb->score + sb_score(S, blk_id - 1);
         }
     }
+    return nblk;
+}
+
+// clear_WordFindData (word_finder.c:40-52): only touched blocks are reset
+NECAT_HD void seed_reset_table(SeedScratch& S, int nblk)
+{
+    for (int i = 0; i < nblk; ++i) S.ht_key[S.pool[i].slot] = -1;
+}
+
+// One strand of one read: word_finder.c:364-412 (find_candidates).  Candidates are appended to S.out
+// with LOCAL ids.  Returns 0 or kSeedErrCapacity.
+NECAT_HD int seed_one_strand(const DevVolume& ref, const u64* kmer_stats, const u64* offset_list,
+                             const DevVolume& reads, int read_id, int qdir, const SeedParams& P,
+                             SeedScratch& S, int* n_out)
+{
+    const int L = (int)(reads.seq_off[read_id + 1] - reads.seq_off[read_id]);
+    const int nblk = seed_collect_strand(ref, kmer_stats, offset_list, reads, read_id, qdir, P, S);
+    if (nblk < 0) return nblk;
     int rc = 0;
     for (int i = 0; i < (P.debug_phase == 1 ? 0 : nblk); ++i) {
         SBlock* sb = S.pool + i;
@@ -451,13 +523,22 @@ NECAT_HD int seed_one_strand(const DevVolume& ref, const u64* kmer_stats, const 
             if (r < 0) { rc = r; break; }
         }
     }
-    for (int i = 0; i < nblk; ++i) S.ht_key[S.pool[i].slot] = -1;   // clear_WordFindData (word_finder.c:40-52)
+    seed_reset_table(S, nblk);
     return rc;
 }
 
-// Both strands of one read + the per-read post-processing of pm_search_one_volume
-// (pm_worker.c:133-140 for job 1, :163-171 for job 0).  Returns the number of candidates left in
-// S.out (local ids), or <0 on capacity error.
+// per-read post-processing of pm_search_one_volume (pm_worker.c:133-140 for job 1, :163-171 for job 0)
+NECAT_HD int seed_finish_read(const SeedParams& P, SeedScratch& S, int n)
+{
+    if (P.job == 1 || n > P.num_candidates) {
+        if (n > 1) sort_cands<true>(S.out, n);
+        if (n > P.num_candidates) n = P.num_candidates;
+    }
+    return n;
+}
+
+// Both strands of one read, scalar.  Returns the number of candidates left in S.out (local ids), or
+// <0 on capacity error.
 NECAT_HD int seed_one_read(const DevVolume& ref, const u64* kmer_stats, const u64* offset_list,
                            const DevVolume& reads, int read_id, const SeedParams& P, SeedScratch& S)
 {
@@ -466,11 +547,7 @@ NECAT_HD int seed_one_read(const DevVolume& ref, const u64* kmer_stats, const u6
     if (rc < 0) return rc;
     rc = seed_one_strand(ref, kmer_stats, offset_list, reads, read_id, 1, P, S, &n);
     if (rc < 0) return rc;
-    if (P.job == 1 || n > P.num_candidates) {
-        if (n > 1) sort_cands<true>(S.out, n);
-        if (n > P.num_candidates) n = P.num_candidates;
-    }
-    return n;
+    return seed_finish_read(P, S, n);
 }
 
 }  // namespace necat

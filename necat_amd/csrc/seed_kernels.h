@@ -12,12 +12,12 @@
 
 namespace necat {
 
-struct SeedMeta {
-    u64 ht_off;      // entries
-    u64 pool_off;    // SBlocks
-    u64 chain_off;   // entries of (H+1)
-    u64 out_off;     // DevCands
-    u32 ht_mask, pool_cap, cs_cap, out_cap;
+struct SeedMeta {           // per processed read; strand 0 = FWD, 1 = REV
+    u64 ht_off[2];          // entries
+    u64 pool_off[2];        // SBlocks
+    u64 chain_off;          // entries of (max(H0,H1)+1)
+    u64 out_off;            // DevCands
+    u32 ht_mask[2], pool_cap[2], cs_cap, out_cap;
 };
 
 __global__ void __launch_bounds__(256)
@@ -48,24 +48,129 @@ struct SeedArenas {
     DevCand* out;
 };
 
-__global__ void __launch_bounds__(64)
-k_seed_reads(DevVolume ref, DevVolume reads, const u64* __restrict__ kmer_stats, const u64* __restrict__ offset_list,
-             SeedParams P, const u32* __restrict__ order, const SeedMeta* __restrict__ meta, u32 n,
-             SeedArenas A, i32* __restrict__ n_cands, int* __restrict__ err_flag)
+NECAT_D SeedScratch seed_scratch(const SeedArenas& A, const SeedMeta& m, int strand)
 {
-    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u32 r = order[i];
-    const SeedMeta m = meta[i];
     SeedScratch S;
-    S.ht_key = A.ht_key + m.ht_off; S.ht_val = A.ht_val + m.ht_off; S.ht_mask = m.ht_mask;
-    S.pool = A.pool + m.pool_off; S.pool_cap = m.pool_cap;
+    S.ht_key = A.ht_key + m.ht_off[strand]; S.ht_val = A.ht_val + m.ht_off[strand]; S.ht_mask = m.ht_mask[strand];
+    S.pool = A.pool + m.pool_off[strand]; S.pool_cap = m.pool_cap[strand];
     S.cs = A.cs + m.chain_off; S.f = A.f + m.chain_off; S.p = A.p + m.chain_off; S.t = A.t + m.chain_off;
     S.v = A.v + m.chain_off; S.u = A.u + m.chain_off; S.lcan = A.lcan + m.chain_off; S.cs_cap = m.cs_cap;
     S.out = A.out + m.out_off; S.out_cap = m.out_cap;
-    const int nc = seed_one_read(ref, kmer_stats, offset_list, reads, (int)r, P, S);
-    if (nc < 0) { atomicExch(err_flag, 1); n_cands[i] = 0; return; }
-    n_cands[i] = nc;
+    return S;
+}
+
+// Seed collection: one lane per (read, strand); every lane runs the same loop nest (sampled k-mers x
+// their occurrence lists), so lanes diverge only in trip counts.
+__global__ void __launch_bounds__(64)
+k_seed_collect(DevVolume ref, DevVolume reads, const u64* __restrict__ kmer_stats, const u64* __restrict__ offset_list,
+               SeedParams P, const u32* __restrict__ order, const SeedMeta* __restrict__ meta, u32 n,
+               SeedArenas A, i32* __restrict__ nblk_out, int* __restrict__ err_flag)
+{
+    const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n) return;
+    const u32 i = t >> 1;
+    const int strand = (int)(t & 1);
+    SeedScratch S = seed_scratch(A, meta[i], strand);
+    const int nb = seed_collect_strand(ref, kmer_stats, offset_list, reads, (int)order[i], strand, P, S);
+    if (nb < 0) atomicExch(err_flag, 1);
+    nblk_out[t] = nb < 0 ? 0 : nb;
+}
+
+struct LdsAdder { int* s; NECAT_D void operator()(int j) { atomicAdd(&s[j], 1); } };
+
+// Block evaluation: one WAVE per read.  The touched blocks are still visited strictly in first-touch
+// order (accepted candidates zero the scores later blocks read), but inside one evaluation the O(n^2)
+// DDF vote and the co-linear gather run on all 64 lanes; the order-dependent rest (anchor choice,
+// chain DP, candidate choice) runs on lane 0.  __syncthreads() (the block is a single wave) separates
+// the lane-0 phases from the cooperative ones - it also stops the compiler from forwarding values
+// across lanes' stores.
+__global__ void __launch_bounds__(64)
+k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict__ order, const SeedMeta* __restrict__ meta, u32 n,
+            SeedArenas A, const i32* __restrict__ nblk_in, i32* __restrict__ n_cands, int* __restrict__ err_flag)
+{
+    __shared__ int s_loc[kBlkSeeds * 2], s_seedn[kBlkSeeds * 2], s_score[kBlkSeeds * 2];
+    __shared__ int s_ctl[4];
+    __shared__ u64 s_blk_start;
+    __shared__ AnchorGeom s_g;
+    const u32 i = blockIdx.x;
+    if (i >= n) return;
+    const int lane = threadIdx.x;
+    const u64 below = (1ULL << lane) - 1ULL;
+    const int r = (int)order[i];
+    const SeedMeta m = meta[i];
+    const int L = (int)(reads.seq_off[r + 1] - reads.seq_off[r]);
+    const int bs = P.block_size, z = P.z, cut = P.s_cutoff;
+    int n_out = 0;            // meaningful on lane 0
+    bool failed = false;
+    for (int strand = 0; strand < 2 && !failed; ++strand) {
+        SeedScratch S = seed_scratch(A, m, strand);
+        const int nblk = P.debug_phase == 1 ? 0 : nblk_in[2 * (u64)i + strand];
+        for (int bi = 0; bi < nblk; ++bi) {
+            __syncthreads();
+            SBlock* sb = S.pool + bi;
+            if (!(sb->score >= cut && sb->stale >= 2 * cut)) continue;         // wave-uniform
+            // A: seed lists (lane 0)
+            if (lane == 0) { u64 bst; s_ctl[0] = block_seed_lists(S, sb, bs, s_seedn, s_loc, &bst); s_blk_start = bst; }
+            for (int x = lane; x < kBlkSeeds * 2; x += 64) s_score[x] = 0;
+            __syncthreads();
+            const int ns = s_ctl[0];
+            // B: DDF vote, one row per lane
+            for (int ii = lane; ii < ns - 1; ii += 64) {
+                LdsAdder add; add.s = s_score;
+                const int own = scoring_vote_row(s_loc, s_seedn, ii, ns, (float)z, L, add);
+                if (own) atomicAdd(&s_score[ii], own);
+            }
+            __syncthreads();
+            // C: anchor (lane 0)
+            if (lane == 0) {
+                int msid = -1, sc4[4];
+                int ok = scoring_pick(s_loc, s_seedn, s_score, sc4, ns, &msid, (float)z, L);
+                if (ok && s_score[msid] < 2 * cut) ok = 0;
+                if (ok) s_g = anchor_geometry(ref, sc4[0], sc4[1], s_blk_start, bs, z, L);
+                s_ctl[1] = ok;
+            }
+            __syncthreads();
+            if (!s_ctl[1]) continue;
+            const AnchorGeom g = s_g;
+            // D: co-linear gather, one seed per lane (a block holds <= 40 seeds)
+            int ncs = 0, seed_score = 0;
+            bool overflow = false;
+            for (int pass = 0; pass < 2; ++pass) {
+                const int lo = pass == 0 ? g.bid_start : g.seed_bid, hi = pass == 0 ? g.seed_bid : g.bid_end;
+                for (int b = lo; b <= hi; ++b) {
+                    SBlock* sbi = sb_find(S, b);
+                    if (!sbi) continue;
+                    const int nsc = sbi->score;
+                    if (!nsc) continue;
+                    u64 key = 0;
+                    const bool acc = lane < nsc && gather_test(g, sbi, lane, b, bs, z, pass == 1, &key);
+                    const u64 mask = __ballot(acc);
+                    const int rel = popc64(mask);
+                    if ((u32)(ncs + rel) >= S.cs_cap) { overflow = true; break; }
+                    if (acc) S.cs[ncs + popc64(mask & below)] = key;
+                    ncs += rel; seed_score += rel;
+                    if (lane == 0 && b != g.seed_bid && gather_zeroes_block(rel, nsc)) sbi->score = 0;
+                }
+                if (overflow) break;
+                if (pass == 0) { if (lane == 0) S.cs[ncs] = ((u64)g.stoff << 32) | (u64)(u32)g.seed_qoff; ++ncs; }
+            }
+            __syncthreads();
+            // E: chain + choose + emit (lane 0)
+            if (lane == 0) {
+                int rc = overflow ? kSeedErrCapacity : finish_candidate(S, ncs, seed_score, g, P, r, strand, L, &n_out);
+                s_ctl[2] = rc < 0 ? 1 : 0;
+            }
+            __syncthreads();
+            if (s_ctl[2]) { failed = true; break; }
+        }
+    }
+    if (lane == 0) {
+        if (failed) { atomicExch(err_flag, 1); n_cands[i] = 0; }
+        else {
+            SeedScratch S = seed_scratch(A, m, 0);
+            n_cands[i] = seed_finish_read(P, S, n_out);
+        }
+    }
 }
 
 // dst[final_off[i] + j] = candidate j of the i-th processed read, ids made global
