@@ -56,8 +56,10 @@ struct MyersResult {
 
 // Functor contracts:
 //   Tgt::code(c)                      -> 2-bit target code of column c
-//   Mat::store(c, b, P, M, S)         -> band word of column c (NW pass)
-//   Mat::band(c, fblk, lblk)          -> first/last band word of column c
+//   Mat::store(c, b, P, M, S, Sup, fblk, lblk) -> band word b of column c (NW pass) as ONE self-contained
+//                                        record: its P/M/score, the score of word b-1 of the same column
+//                                        and the column's band limits - everything the traceback needs
+//                                        when it steps into (c, b) comes back with a single 32-byte load
 template <int NW, bool FULL, class Tgt, class Mat>
 NECAT_HD MyersResult myers_block(MyersRegs<NW>& R, int qn, int tn, double error, Tgt& tgt, Mat& mat)
 {
@@ -211,9 +213,8 @@ NECAT_HD MyersResult myers_block(MyersRegs<NW>& R, int qn, int tn, double error,
 #pragma unroll
         for (int b = 0; b < NW; ++b) {
             const bool in = (b >= fblk) & (b <= lblk);
-            if (NECAT_ANY(in)) { if (in) mat.store(c, b, R.P[b], R.M[b], R.S[b]); }
+            if (NECAT_ANY(in)) { if (in) mat.store(c, b, R.P[b], R.M[b], R.S[b], b > 0 ? R.S[b > 0 ? b - 1 : 0] : 0, fblk, lblk); }
         }
-        mat.band(c, fblk, lblk);
     }
     int d2 = -1;
     if (alive && lblk == nblk - 1) {

@@ -28,11 +28,16 @@ constexpr int kColsB = kMaxFragLen, kWordsB = kMaxWords, kTWordsB = kMaxTWords, 
 constexpr int kFragWordsA = 2 * kWordsA + kTWordsA;   // 32 u64 per item
 constexpr int kFragWordsB = 2 * kWordsB + kTWordsB;   // 51 u64 per item
 
+// One band record per (column, word, lane): P, M, score of the word, score of the word above it in
+// the same column, band limits of the column.  32 bytes, so the traceback - 64 lanes walking 64
+// different paths, every access its own DRAM sector - fetches ONE sector per step instead of four
+// (separate P/M, score, upper score and band arrays made k_traceback HBM-sector bound: measured
+// 5.7 us per step at 200 k concurrent blocks).
+struct __attribute__((aligned(32))) BandRec { u64 P, M; i16 S, Sup; u8 first, last; u8 _pad[10]; };
+static_assert(sizeof(BandRec) == 32, "BandRec must be 32 bytes");
 // bytes of one 64-item slab
-constexpr size_t kPmBytesA = (size_t)kColsA * kWordsA * 64 * 16, kScBytesA = (size_t)kColsA * kWordsA * 64 * 2, kBandBytesA = (size_t)kColsA * 64 * 2;
-constexpr size_t kPmBytesB = (size_t)kColsB * kWordsB * 64 * 16, kScBytesB = (size_t)kColsB * kWordsB * 64 * 2, kBandBytesB = (size_t)kColsB * 64 * 2;
-constexpr size_t kSlabA = kPmBytesA + kScBytesA + kBandBytesA;
-constexpr size_t kSlabB = kPmBytesB + kScBytesB + kBandBytesB;
+constexpr size_t kSlabA = (size_t)kColsA * kWordsA * 64 * sizeof(BandRec);
+constexpr size_t kSlabB = (size_t)kColsB * kWordsB * 64 * sizeof(BandRec);
 
 struct BlockItem {       // one scheduled block alignment
     FragGeom g;
@@ -122,64 +127,78 @@ struct TgtReader {
     }
 };
 
+// Record words: a = (P, M); t.x = S | Sup<<16 | first<<32 | last<<40; t.y = validity tag.
+// A slot (column, word, lane) is written only while that word is inside the column's band, so a read
+// of an out-of-band word returns whatever an earlier round left there: every record carries
+// tag = epoch<<10 | column (epoch = launch counter; the pool is zeroed once at allocation) and a
+// record counts only if its tag is the expected one.
+NECAT_D ulonglong2 rec_tail(int S, int Sup, int f, int l, u32 tag)
+{
+    return make_ulonglong2((u64)(u16)(i16)S | ((u64)(u16)(i16)Sup << 16) | ((u64)(u32)f << 32) | ((u64)(u32)l << 40), (u64)tag);
+}
+NECAT_D u32 rec_tag(u32 epoch, int c) { return (epoch << 10) | (u32)c; }
+
 template <int NW>
 struct MatWriter {
-    ulonglong2* pm; i16* sc; u16* bnd;   // already offset to this lane
-    NECAT_D void store(int c, int b, u64 P, u64 M, int S)
+    ulonglong2* rec;   // slab + lane (16-byte units: record r of this lane at rec[r * 128 + {0,1}])
+    u32 epoch;
+    NECAT_D void store(int c, int b, u64 P, u64 M, int S, int Sup, int f, int l)
     {
-        const size_t idx = ((size_t)c * NW + b) * 64;
-        pm[idx] = make_ulonglong2(P, M); sc[idx] = (i16)S;
+        ulonglong2* p = rec + ((size_t)c * NW + b) * 128;
+        p[0] = make_ulonglong2(P, M);
+        p[1] = rec_tail(S, Sup, f, l, rec_tag(epoch, c));
     }
-    NECAT_D void band(int c, int f, int l) { bnd[(size_t)c * 64] = (u16)(f | (l << 8)); }
 };
 
-// Band reader of the traceback.  The walk moves one column at a time at a (mostly) fixed word b and
-// every column needs P/M, the score of word b, the score of word b-1 and the band limits of the column
-// to its left - a chain of dependent loads.  The reader issues the loads of column c-1 while column c
-// is being consumed, so the walk pays max(compute, latency) per column instead of their sum.
+// Band reader of the traceback.  The walk moves one column at a time at a (mostly) fixed word b - a
+// chain of dependent loads.  The reader issues the load of column c-1 while column c is consumed, so
+// the walk pays max(compute, latency) per column instead of their sum.
 template <int NW>
 struct MatReader {
-    const ulonglong2* pm; const i16* sc; const u16* bnd;     // lane-offset slab pointers
-    int nc, nb;                                              // coordinates of the prefetched view
-    ulonglong2 np; i16 ns, nu; u16 nbd;
+    const ulonglong2* rec;     // slab + lane
+    u32 epoch;
+    int nc, nb;                // coordinates of the prefetched record
+    ulonglong2 na, nt;
     NECAT_D void init() { nc = -100; nb = -100; }
-    NECAT_D void fetch(int c, int b, ulonglong2& p, i16& s, i16& u, u16& bd) const
+    NECAT_D void fetch(int c, int b, ulonglong2& a, ulonglong2& t) const
     {
-        if (c >= 0) {
-            const u32 idx = ((u32)c * NW + (u32)b) * 64u;
-            p = pm[idx]; s = sc[idx]; u = b > 0 ? sc[idx - 64] : (i16)0; bd = bnd[(u32)c * 64u];
-        }
+        if (c >= 0) { const ulonglong2* p = rec + ((size_t)c * NW + b) * 128; a = p[0]; t = p[1]; }
     }
-    NECAT_D void cur(int c, int b, u64& P, u64& M) const { const ulonglong2 v = pm[((u32)c * NW + (u32)b) * 64u]; P = v.x; M = v.y; }
+    NECAT_D void cur(int c, int b, u64& P, u64& M) const { const ulonglong2 v = rec[((size_t)c * NW + b) * 128]; P = v.x; M = v.y; }
     NECAT_D LeftView left(int c, int b)
     {
-        ulonglong2 p; i16 s, u; u16 bd;
-        if (c == nc && b == nb) { p = np; s = ns; u = nu; bd = nbd; }
-        else fetch(c, b, p, s, u, bd);
+        ulonglong2 a, t;
+        if (c == nc && b == nb) { a = na; t = nt; } else fetch(c, b, a, t);
         nc = c - 1; nb = b;
-        fetch(nc, nb, np, ns, nu, nbd);
-        const int f = bd & 0xff, l = bd >> 8;
+        fetch(nc, nb, na, nt);
         LeftView v;
-        v.in = b >= f && b <= l; v.up_in = b - 1 >= f && b - 1 <= l;
-        v.P = p.x; v.M = p.y; v.S = s; v.Sup = u;
+        const u32 want = rec_tag(epoch, c);
+        v.in = (u32)t.y == want;
+        v.P = a.x; v.M = a.y; v.S = (i16)(t.x & 0xffff);
+        if (v.in) {
+            const int f = (int)((t.x >> 32) & 0xff);
+            v.up_in = b - 1 >= f; v.Sup = (i16)((t.x >> 16) & 0xffff);
+        } else {
+            // word b is outside column c's band: the upper word decides the diagonal fallback
+            // (edlib_ex.c:447-451); rare, one extra load
+            v.up_in = false; v.Sup = 0;
+            if (b > 0) {
+                const ulonglong2 u = rec[((size_t)c * NW + (b - 1)) * 128 + 1];
+                if ((u32)u.y == want) { v.up_in = true; v.Sup = (i16)(u.x & 0xffff); }
+            }
+        }
         return v;
     }
 };
 
-template <int NW, int COLS>
-NECAT_D void slab_pointers(char* slab, int lane, ulonglong2*& pm, i16*& sc, u16*& band)
-{
-    pm = reinterpret_cast<ulonglong2*>(slab) + lane;
-    sc = reinterpret_cast<i16*>(slab + (size_t)COLS * NW * 64 * 16) + lane;
-    band = reinterpret_cast<u16*>(slab + (size_t)COLS * NW * 64 * 18) + lane;
-}
+NECAT_D ulonglong2* slab_records(char* slab, int lane) { return reinterpret_cast<ulonglong2*>(slab) + (size_t)lane * 2; }
 
 // The hot kernel.  One wave = 64 block alignments in lock-step.  No LDS: the whole column state is
 // register resident (dp_core.h) and the only memory traffic is the coalesced band store.
 template <int NW, int TW, int COLS, bool FULL>
 __global__ void __launch_bounds__(64)
 k_myers(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
-        double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats)
+        double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, u32 epoch)
 {
     constexpr int FW = 2 * NW + TW;
     const u32 grp = blockIdx.x;
@@ -199,7 +218,7 @@ k_myers(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag
     }
     TgtReader<NW> tg; tg.w = fr + (u64)2 * NW * 64; tg.cur = 0;
     MatWriter<NW> mw;
-    slab_pointers<NW, COLS>(slabs + (size_t)grp * slab_bytes, lane, mw.pm, mw.sc, mw.bnd);
+    mw.rec = slab_records(slabs + (size_t)grp * slab_bytes, lane); mw.epoch = epoch;
     const MyersResult r = myers_block<NW, FULL>(R, qn, tn, error, tg, mw);
     BlockResult br; br.dist = r.dist; br.endc = r.endc; br.err = r.err; br.words = r.words;
     results[item] = br;
@@ -228,7 +247,7 @@ NECAT_D int dpp_from_lane_below(int v)   // lane i receives v of lane i-1 (withi
 template <int NW, int TW, int COLS, int G>
 __global__ void __launch_bounds__(64)
 k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
-             double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats)
+             double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, u32 epoch)
 {
     constexpr int FW = 2 * NW + TW, BPW = 64 / G;
     const int lane = threadIdx.x, sub = lane / G, b = lane % G;
@@ -252,8 +271,7 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
     if (valid) for (int w = b; w < TW; w += G) t_lds[sub][w] = (w * 32 < tn) ? fr[(u64)(2 * NW + w) * 64] : 0ULL;
     __syncthreads();
     const u64* tw = t_lds[sub];
-    ulonglong2* pm; i16* sc; u16* bnd;
-    slab_pointers<NW, COLS>(slabs + (size_t)grp * slab_bytes, il, pm, sc, bnd);
+    ulonglong2* rec = slab_records(slabs + (size_t)grp * slab_bytes, il);
 
     // wave-uniform trip count of the SHW wavefront
     int steps = valid ? tn + nblk - 1 : 0;
@@ -303,10 +321,10 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
     steps = go ? tn2 + nblk - 1 : 0;
     for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
     P = ~0ULL; M = 0ULL; S = (b + 1) * 64; hout = 1;
-    const u16 full_band = (u16)(0 | ((nblk - 1) << 8));
     for (int s = 0; s < steps; ++s) {
         const int c = s - b;
         int hin = dpp_from_lane_below(hout);
+        const int Sup = dpp_from_lane_below(S);     // score of word b-1 at column c (computed one step ago)
         if (b == 0) hin = 1;
         if (go && c >= 0 && c < tn2) {
             if ((c & 31) == 0) tcur = tw[c >> 5];
@@ -315,9 +333,9 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
             const u64 eq = ((nlo ^ ma) & (nhi ^ mb)) | pad;
             hout = advance_block(P, M, eq, hin, P, M);
             S += hout;
-            const size_t idx = ((size_t)c * NW + b) * 64;
-            pm[idx] = make_ulonglong2(P, M); sc[idx] = (i16)S;
-            if (b == 0) bnd[(size_t)c * 64] = full_band;
+            ulonglong2* p = rec + ((size_t)c * NW + b) * 128;
+            p[0] = make_ulonglong2(P, M);
+            p[1] = rec_tail(S, Sup, 0, nblk - 1, rec_tag(epoch, c));
         }
     }
     if (is_last) {
@@ -363,7 +381,7 @@ template <int NW, int TW, int COLS, int MAXOPS, bool EXPORT>
 __global__ void __launch_bounds__(64)
 k_traceback(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag, const char* __restrict__ slabs, size_t slab_bytes,
             const BlockResult* __restrict__ results, u8* __restrict__ ops_pool, ExtTask* __restrict__ tasks, int tail_match_len,
-            i32* __restrict__ n_ops_out, int* __restrict__ err_flag, ExtLists next)
+            i32* __restrict__ n_ops_out, int* __restrict__ err_flag, ExtLists next, u32 epoch)
 {
     constexpr int FW = 2 * NW + TW;
     const u32 grp = blockIdx.x;
@@ -384,9 +402,7 @@ k_traceback(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ 
     tail_init(ow.ts, (EXPORT || !done) ? kOcaMatCnt : tail_match_len);
     if (br.dist >= 0) {
         MatReader<NW> mr;
-        ulonglong2* pm; i16* sc; u16* band;
-        slab_pointers<NW, COLS>(const_cast<char*>(slabs) + (size_t)grp * slab_bytes, lane, pm, sc, band);
-        mr.pm = pm; mr.sc = sc; mr.bnd = band; mr.init();
+        mr.rec = slab_records(const_cast<char*>(slabs) + (size_t)grp * slab_bytes, lane); mr.epoch = epoch; mr.init();
         traceback_block(it.qn, br.endc + 1, br.dist, mr, ow);
         if (ow.overflow) atomicExch(err_flag, 20);
     }

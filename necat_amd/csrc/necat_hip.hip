@@ -13,6 +13,16 @@ using namespace necat;
 
 namespace {
 
+// (re)allocate a band-record pool; a fresh allocation is zeroed once so that no stale tag can match
+int ensure_zeroed(necat_ctx* ctx, DevBuf& b, size_t bytes, hipStream_t s)
+{
+    const void* before = b.p; const size_t cap0 = b.cap;
+    int rc = buf_ensure(ctx, b, bytes);
+    if (rc) return rc;
+    if (b.p != before || b.cap != cap0) { hipError_t e = hipMemsetAsync(b.p, 0, b.cap, s); if (e != hipSuccess) return set_err(ctx, NECAT_ERR_DEVICE, "memset failed"); }
+    return NECAT_OK;
+}
+
 inline unsigned grid_for(uint64_t n, unsigned block, unsigned cap = 1u << 20)
 {
     uint64_t g = (n + block - 1) / block;
@@ -399,6 +409,7 @@ int run_rounds(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, ExtB
         const u32 gA = (nA + 63) / 64, gB = (nB + 63) / 64;
         char* slabsB = B.slabs + (size_t)gA * kSlabA;
         const BlockItem* itA = B.itemsA[p]; const BlockItem* itB = B.itemsB[p];
+        const u32 epoch = ++ctx->epoch & 0x3fffffu;
         ExtLists next; next.count = B.count + 2 * (p ^ 1); next.itemsA = B.itemsA[p ^ 1]; next.itemsB = B.itemsB[p ^ 1];
         // the two shapes of the round are independent: list A on stream_a, list B on stream_b
         if (nA) {
@@ -408,15 +419,15 @@ int run_rounds(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, ExtB
             NECAT_HIP(ctx, hipEventRecord(a0, sa));
             if (nA <= g_coop_threshold)
                 hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((nA + 7) / 8), dim3(64), 0, sa, itA, nA,
-                                   (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA, B.stats);
+                                   (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA, B.stats, epoch);
             else
                 hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(gA), dim3(64), 0, sa, itA, nA,
-                                   (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA, B.stats);
+                                   (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA, B.stats, epoch);
             NECAT_CHECK_LAUNCH(ctx, "k_myers<A>");
             NECAT_HIP(ctx, hipEventRecord(a1, sa));
             hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false>), dim3(gA), dim3(64), 0, sa, itA, nA,
                                (const u64*)B.fragA, (const char*)B.slabs, kSlabA, (const BlockResult*)B.resA, B.opsA, B.tasks, tail_match_len,
-                               (i32*)nullptr, d_err, next);
+                               (i32*)nullptr, d_err, next, epoch);
             NECAT_CHECK_LAUNCH(ctx, "k_traceback<A>");
             NECAT_HIP(ctx, hipEventRecord(a2, sa));
         }
@@ -427,15 +438,15 @@ int run_rounds(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, ExtB
             NECAT_HIP(ctx, hipEventRecord(b0, sb));
             if (nB <= g_coop_threshold)
                 hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB,
-                                   (const u64*)B.fragB, slabsB, kSlabB, error, B.resB, B.stats);
+                                   (const u64*)B.fragB, slabsB, kSlabB, error, B.resB, B.stats, epoch);
             else
                 hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB,
-                                   (const u64*)B.fragB, slabsB, kSlabB, error, B.resB, B.stats);
+                                   (const u64*)B.fragB, slabsB, kSlabB, error, B.resB, B.stats, epoch);
             NECAT_CHECK_LAUNCH(ctx, "k_myers<B>");
             NECAT_HIP(ctx, hipEventRecord(b1, sb));
             hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB,
                                (const u64*)B.fragB, (const char*)slabsB, kSlabB, (const BlockResult*)B.resB, B.opsB, B.tasks, tail_match_len,
-                               (i32*)nullptr, d_err, next);
+                               (i32*)nullptr, d_err, next, epoch);
             NECAT_CHECK_LAUNCH(ctx, "k_traceback<B>");
             NECAT_HIP(ctx, hipEventRecord(b2, sb));
         }
@@ -477,7 +488,7 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
     ctx->tm.myers_ms = ctx->tm.traceback_ms = 0; ctx->tm.myers_launches = ctx->tm.myers_blocks = ctx->tm.rounds = 0;
     ctx->tm.myers_word_updates = ctx->tm.myers_cells_bases = 0;
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
-    const u32 batch = (u32)std::min<uint64_t>(n, 524288);      // slab pool <= ~100 GB of the 288 GB HBM
+    const u32 batch = (u32)std::min<uint64_t>(n, 393216);      // slab pool <= ~130 GB of the 288 GB HBM
     const u32 groups = (batch + 63) / 64 + 1;
     int rc;
     // candidate-wide arrays
@@ -496,7 +507,7 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
     if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_TASKS], (size_t)batch * sizeof(ExtTask) + 64)) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], (size_t)batch * 4 * sizeof(BlockItem) + 64)) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_FRAG], (size_t)groups * 64 * (kFragWordsA + kFragWordsB) * 8)) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_MAT], (size_t)groups * kSlabB + kSlabA)) ||
+        (rc = ensure_zeroed(ctx, ctx->scratch[SC_EXT_MAT], (size_t)groups * kSlabB + kSlabA, s)) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_OPS], (size_t)groups * 64 * (kOpsA + kOpsB))) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_RES], (size_t)groups * 64 * 2 * sizeof(BlockResult)))) { cleanup(); return rc; }
     ExtBuffers B;
@@ -611,7 +622,7 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
             int rc2;
             if ((rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], (size_t)m * sizeof(BlockItem))) ||
                 (rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_FRAG], (size_t)g * 64 * fw * 8)) ||
-                (rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_MAT], (size_t)g * slab)) ||
+                (rc2 = ensure_zeroed(ctx, ctx->scratch[SC_EXT_MAT], (size_t)g * slab, s)) ||
                 (rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_OPS], (size_t)g * 64 * maxops)) ||
                 (rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_RES], (size_t)g * 64 * (sizeof(BlockResult) + 4)))) return rc2;
             BlockItem* d_items = (BlockItem*)ctx->scratch[SC_EXT_LISTS].p;
@@ -626,16 +637,17 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[4], s));
             const bool coop = m <= g_coop_threshold;
-            if (full && coop) hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats);
-            else if (full) hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats);
-            else if (coop) hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((m + 3) / 4), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats);
-            else hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats);
+            const u32 epoch = ++ctx->epoch & 0x3fffffu;
+            if (full && coop) hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch);
+            else if (full) hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch);
+            else if (coop) hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((m + 3) / 4), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch);
+            else hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch);
             NECAT_CHECK_LAUNCH(ctx, "k_myers");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[5], s));
             if (full) hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, (const char*)d_slabs, slab,
-                                         (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists());
+                                         (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), epoch);
             else hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, (const char*)d_slabs, slab,
-                                    (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists());
+                                    (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), epoch);
             NECAT_CHECK_LAUNCH(ctx, "k_traceback");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[6], s));
             std::vector<BlockResult> hres(m); std::vector<i32> hn(m); std::vector<u8> hops((size_t)g * 64 * maxops);

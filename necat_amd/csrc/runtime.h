@@ -37,6 +37,7 @@ struct necat_ctx {
     necat::DevBuf scratch[16];         // grow-only arenas, indexed by purpose
     char devname[256] = {0};
     int num_cu = 0;
+    uint32_t epoch = 0;                // launch counter stamped into the traceback band records
 };
 
 struct necat_volume {
