@@ -22,21 +22,31 @@ namespace necat {
 
 constexpr u64 kHighBit = 1ULL << 63;
 
-// edlib_ex.c:71-106 calculateBlock (Myers' Advance_Block)
+// edlib_ex.c:71-106 calculateBlock (Myers' Advance_Block), written on 32-bit halves: gfx950 has no
+// full-rate 64-bit integer add / shift (v_lshl_add_u64, v_lshlrev_b64 issue at a fraction of the
+// 32-bit rate and were ~1/3 of this function's time); add-with-carry and funnel shifts are full rate.
 NECAT_HD int advance_block(u64 Pv, u64 Mv, u64 Eq, int hin, u64& PvOut, u64& MvOut)
 {
-    const u64 hinIsNeg = (u64)(hin >> 2) & 1ULL;
-    const u64 Xv = Eq | Mv;
-    Eq |= hinIsNeg;
-    const u64 Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-    u64 Ph = Mv | ~(Xh | Pv);
-    u64 Mh = Pv & Xh;
-    int hout = (int)(Ph >> 63) - (int)(Mh >> 63);
-    Ph <<= 1; Mh <<= 1;
-    Mh |= hinIsNeg;
-    Ph |= (u64)((hin + 1) >> 1);
-    PvOut = Mh | ~(Xv | Ph);
-    MvOut = Ph & Xv;
+    const u32 pl = (u32)Pv, ph = (u32)(Pv >> 32), ml = (u32)Mv, mh = (u32)(Mv >> 32);
+    u32 el = (u32)Eq;
+    const u32 eh = (u32)(Eq >> 32);
+    const u32 neg = (u32)hin >> 31;                 // 1 iff hin == -1  (hinIsNeg)
+    const u32 pos = (u32)(hin + 1) >> 1;            // 1 iff hin == +1
+    const u32 xvl = el | ml, xvh = eh | mh;         // Xv = Eq | Mv  (before the hin fix-up of Eq)
+    el |= neg;
+    const u32 al = el & pl, ah = eh & ph;
+    const u32 sl = al + pl;                         // ((Eq & Pv) + Pv)
+    const u32 sh = ah + ph + (u32)(sl < al);
+    const u32 xhl = (sl ^ pl) | el, xhh = (sh ^ ph) | eh;
+    u32 Phl = ml | ~(xhl | pl), Phh = mh | ~(xhh | ph);
+    u32 Mhl = pl & xhl, Mhh = ph & xhh;
+    const int hout = (int)(Phh >> 31) - (int)(Mhh >> 31);
+    Phh = (Phh << 1) | (Phl >> 31); Phl = (Phl << 1) | pos;
+    Mhh = (Mhh << 1) | (Mhl >> 31); Mhl = (Mhl << 1) | neg;
+    const u32 ol = Mhl | ~(xvl | Phl), oh = Mhh | ~(xvh | Phh);
+    const u32 nl = Phl & xvl, nh = Phh & xvh;
+    PvOut = ((u64)oh << 32) | ol;
+    MvOut = ((u64)nh << 32) | nl;
     return hout;
 }
 

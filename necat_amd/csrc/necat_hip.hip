@@ -41,6 +41,7 @@ DevVolume dev_view(const necat_volume* v)
 // NECAT_COOP_THRESHOLD overrides it (0 = never, huge = always) for tests and A/B measurements
 u32 g_coop_threshold = 49152;
 int g_trace = 0;
+int g_dbg = 0;     // NECAT_DBG: profiling-only variants of the DP kernel (1 = no band stores, 2 = no NW pass)
 
 double ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0; return ms; }
 
@@ -68,6 +69,7 @@ int necat_ctx_create(int device_id, necat_ctx** out)
     ctx->device = device_id;
     if (const char* e = getenv("NECAT_COOP_THRESHOLD")) g_coop_threshold = (u32)strtoul(e, nullptr, 10);
     if (const char* e = getenv("NECAT_TRACE")) g_trace = atoi(e);
+    if (const char* e = getenv("NECAT_DBG")) g_dbg = atoi(e);
     memset(&ctx->tm, 0, sizeof ctx->tm);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
@@ -612,7 +614,7 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
     NECAT_HIP(ctx, hipMalloc((void**)&d_err, 4 + 4 + 16));
     NECAT_HIP(ctx, hipMemsetAsync(d_err, 0, 24, s));
     unsigned long long* d_stats = (unsigned long long*)(d_err + 2);
-    const u32 chunk = 65536;
+    const u32 chunk = getenv("NECAT_BATCH_CHUNK") ? (u32)strtoul(getenv("NECAT_BATCH_CHUNK"), nullptr, 10) : 65536u;
     auto run_shape = [&](std::vector<BlockItem>& items, std::vector<u64>& ids, bool full) -> int {
         for (size_t base = 0; base < items.size(); base += chunk) {
             const u32 m = (u32)std::min<size_t>(chunk, items.size() - base);
@@ -639,7 +641,7 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
             const bool coop = m <= g_coop_threshold;
             const u32 epoch = ++ctx->epoch & 0x3fffffu;
             if (full && coop) hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch);
-            else if (full) hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch);
+            else if (full) hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | ((u32)g_dbg << 28));
             else if (coop) hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((m + 3) / 4), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch);
             else hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch);
             NECAT_CHECK_LAUNCH(ctx, "k_myers");
