@@ -2,6 +2,7 @@
 // kernels.  Written for MI355X only (wave64, 256 CUs, 288 GB HBM3E): buffers are sized for HBM
 // residency of whole volumes, work lists and the traceback band of 10^5 concurrent alignments.
 #include <algorithm>
+#include <time.h>
 #include <numeric>
 
 #include "runtime.h"
@@ -42,6 +43,8 @@ DevVolume dev_view(const necat_volume* v)
 u32 g_coop_threshold = 49152;
 int g_trace = 0;
 int g_dbg = 0;     // NECAT_DBG: profiling-only variants of the DP kernel (1 = no band stores, 2 = no NW pass)
+
+double wall_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 
 double ev_ms(hipEvent_t a, hipEvent_t b) { float ms = 0; if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0; return ms; }
 
@@ -89,6 +92,7 @@ void necat_ctx_destroy(necat_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& b : ctx->scratch) if (b.p) (void)hipFree(b.p);
+    for (auto& b : ctx->idx_cache) if (b.p) (void)hipFree(b.p);
     for (int i = 0; i < 12; ++i) (void)hipEventDestroy(ctx->ev[i]);
     (void)hipStreamDestroy(ctx->stream); (void)hipStreamDestroy(ctx->stream_a); (void)hipStreamDestroy(ctx->stream_b);
     delete ctx;
@@ -168,6 +172,7 @@ void necat_volume_free(necat_ctx* ctx, necat_volume* v)
 
 int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, int max_occ, necat_index** out)
 {
+    const double w0 = wall_ms();
     if (!ctx || !ref || !out) return NECAT_ERR_ARG;
     *out = nullptr;
     if (kmer_size < 1 || kmer_size > 15) return set_err(ctx, NECAT_ERR_ARG, "kmer_size %d outside 1..15 (HashBits = 30, lookup_table.h:13)", kmer_size);
@@ -183,7 +188,8 @@ int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, in
     if ((rc = buf_ensure(ctx, ctx->scratch[SC_CNT32], T * 4)) || (rc = buf_ensure(ctx, ctx->scratch[SC_PARTIAL], (ntiles + 1) * 8))) { delete ix; return rc; }
     u32* cnt32 = (u32*)ctx->scratch[SC_CNT32].p;
     u64* partial = (u64*)ctx->scratch[SC_PARTIAL].p;
-    NECAT_HIP(ctx, hipMalloc((void**)&ix->kmer_stats, T * 8));
+    if (ctx->idx_cache[0].p && ctx->idx_cache[0].cap >= T * 8) { ix->kmer_stats = (uint64_t*)ctx->idx_cache[0].p; ix->stats_cap = ctx->idx_cache[0].cap; ctx->idx_cache[0] = DevBuf(); }
+    else { NECAT_HIP(ctx, hipMalloc((void**)&ix->kmer_stats, T * 8)); ix->stats_cap = T * 8; }
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
     NECAT_HIP(ctx, hipMemsetAsync(cnt32, 0, T * 4, s));
     const uint64_t nchunks = (ref->nbases + kPosPerThread - 1) / kPosPerThread;
@@ -200,7 +206,8 @@ int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, in
     NECAT_HIP(ctx, hipMemcpyAsync(&n_off, partial + ntiles, 8, hipMemcpyDeviceToHost, s));
     NECAT_HIP(ctx, hipStreamSynchronize(s));
     ix->n_offsets = n_off;
-    NECAT_HIP(ctx, hipMalloc((void**)&ix->offset_list, (n_off + 1) * 8));
+    if (ctx->idx_cache[1].p && ctx->idx_cache[1].cap >= (n_off + 1) * 8) { ix->offset_list = (uint64_t*)ctx->idx_cache[1].p; ix->offs_cap = ctx->idx_cache[1].cap; ctx->idx_cache[1] = DevBuf(); }
+    else { NECAT_HIP(ctx, hipMalloc((void**)&ix->offset_list, (n_off + 1) * 8 + (n_off >> 4))); ix->offs_cap = (n_off + 1) * 8 + (n_off >> 4); }
     if (n_off) {
         if ((rc = buf_ensure(ctx, ctx->scratch[SC_TMPLIST], n_off * 8))) { necat_index_free(ctx, ix); return rc; }
         u64* tmp = (u64*)ctx->scratch[SC_TMPLIST].p;
@@ -212,6 +219,7 @@ int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, in
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s));
     NECAT_HIP(ctx, hipStreamSynchronize(s));
     ctx->tm.index_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
+    if (g_trace) fprintf(stderr, "[necat] index: events %.2f ms, host wall %.2f ms\n", ctx->tm.index_ms, wall_ms() - w0);
     *out = ix;
     return NECAT_OK;
 }
@@ -237,8 +245,14 @@ void necat_index_free(necat_ctx* ctx, necat_index* ix)
 {
     if (!ix) return;
     if (ctx) (void)hipSetDevice(ctx->device);
-    if (ix->kmer_stats) (void)hipFree(ix->kmer_stats);
-    if (ix->offset_list) (void)hipFree(ix->offset_list);
+    auto give = [&](void* p, size_t cap, DevBuf& slot) {
+        if (!p) return;
+        if (ctx && cap > slot.cap) { if (slot.p) (void)hipFree(slot.p); slot.p = p; slot.cap = cap; }
+        else (void)hipFree(p);
+    };
+    DevBuf none;
+    give(ix->kmer_stats, ix->stats_cap, ctx ? ctx->idx_cache[0] : none);
+    give(ix->offset_list, ix->offs_cap, ctx ? ctx->idx_cache[1] : none);
     delete ix;
 }
 
@@ -494,18 +508,20 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
     const u32 groups = (batch + 63) / 64 + 1;
     int rc;
     // candidate-wide arrays
-    necat_candidate* d_cands = nullptr; necat_m4* d_m4 = nullptr; necat_m4* d_out = nullptr; u8* d_ok = nullptr; u32* d_outcnt = nullptr; int* d_err = nullptr;
-    u64* d_goff = nullptr;
-    NECAT_HIP(ctx, hipMalloc((void**)&d_cands, n * sizeof(necat_candidate)));
-    NECAT_HIP(ctx, hipMalloc((void**)&d_m4, n * sizeof(necat_m4)));
-    NECAT_HIP(ctx, hipMalloc((void**)&d_out, n * sizeof(necat_m4)));
-    NECAT_HIP(ctx, hipMalloc((void**)&d_ok, n));
-    NECAT_HIP(ctx, hipMalloc((void**)&d_outcnt, 8));
-    NECAT_HIP(ctx, hipMalloc((void**)&d_err, 4));
+    const uint64_t n_groups_max = n;
+    const size_t cand_bytes = n * sizeof(necat_candidate) + 2 * n * sizeof(necat_m4) + ((n + 63) & ~63ULL) + (n_groups_max + 1) * 8 + 256;
+    if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_CAND], cand_bytes))) return rc;
+    char* cb = (char*)ctx->scratch[SC_EXT_CAND].p;
+    necat_candidate* d_cands = (necat_candidate*)cb; cb += n * sizeof(necat_candidate);
+    necat_m4* d_m4 = (necat_m4*)cb; cb += n * sizeof(necat_m4);
+    necat_m4* d_out = (necat_m4*)cb; cb += n * sizeof(necat_m4);
+    u64* d_goff = (u64*)cb; cb += (n_groups_max + 1) * 8;
+    u32* d_outcnt = (u32*)cb; cb += 64;           // [0..1] output counter, [2..5] list counts, [6..9] stats
+    int* d_err = (int*)cb; cb += 64;
+    u8* d_ok = (u8*)cb;
     NECAT_HIP(ctx, hipMemcpyAsync(d_cands, cands, n * sizeof(necat_candidate), hipMemcpyHostToDevice, s));
-    NECAT_HIP(ctx, hipMemsetAsync(d_outcnt, 0, 8, s));
-    NECAT_HIP(ctx, hipMemsetAsync(d_err, 0, 4, s));
-    auto cleanup = [&]() { (void)hipFree(d_cands); (void)hipFree(d_m4); (void)hipFree(d_out); (void)hipFree(d_ok); (void)hipFree(d_outcnt); (void)hipFree(d_err); if (d_goff) (void)hipFree(d_goff); };
+    NECAT_HIP(ctx, hipMemsetAsync(d_outcnt, 0, 128, s));
+    auto cleanup = [&]() {};
     if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_TASKS], (size_t)batch * sizeof(ExtTask) + 64)) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], (size_t)batch * 4 * sizeof(BlockItem) + 64)) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_FRAG], (size_t)groups * 64 * (kFragWordsA + kFragWordsB) * 8)) ||
@@ -524,11 +540,9 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
         B.opsA = (u8*)ctx->scratch[SC_EXT_OPS].p; B.opsB = B.opsA + (size_t)groups * 64 * kOpsA;
         B.resA = (BlockResult*)ctx->scratch[SC_EXT_RES].p; B.resB = B.resA + (size_t)groups * 64;
     }
-    u32* d_count = nullptr;
-    NECAT_HIP(ctx, hipMalloc((void**)&d_count, 16 + 16));
+    u32* d_count = d_outcnt + 2;
     B.count = d_count;
-    B.stats = (unsigned long long*)(d_count + 4);
-    NECAT_HIP(ctx, hipMemsetAsync(d_count, 0, 32, s));
+    B.stats = (unsigned long long*)(d_outcnt + 6);
     for (uint64_t base = 0; base < n; base += batch) {
         const u32 nb = (u32)std::min<uint64_t>(batch, n - base);
         NECAT_HIP(ctx, hipMemsetAsync(B.count, 0, 16, s));
@@ -536,7 +550,7 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
         hipLaunchKernelGGL(k_ext_init, dim3(grid_for(nb, 256)), dim3(256), 0, s, (const necat_candidate*)(d_cands + base), nb, (u32)base,
                            read_start_id, ref_start_id, (const u64*)reads->seq_off, (const u64*)ref->seq_off, B.tasks, L0);
         NECAT_CHECK_LAUNCH(ctx, "k_ext_init");
-        if ((rc = run_rounds(ctx, dref, drd, B, nb, opt->error, tail_match_len, d_err))) { (void)hipFree(d_count); cleanup(); return rc; }
+        if ((rc = run_rounds(ctx, dref, drd, B, nb, opt->error, tail_match_len, d_err))) { cleanup(); return rc; }
         hipLaunchKernelGGL(k_ext_result, dim3(grid_for(nb, 256)), dim3(256), 0, s, (const ExtTask*)B.tasks, nb, (const necat_candidate*)(d_cands + base),
                            (u32)base, opt->align_size_cutoff, d_m4 - 0, d_ok);
         NECAT_CHECK_LAUNCH(ctx, "k_ext_result");
@@ -547,14 +561,12 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
         NECAT_HIP(ctx, hipStreamSynchronize(s));
         ctx->tm.myers_word_updates = hs[0]; ctx->tm.myers_cells_bases = hs[1];
     }
-    (void)hipFree(d_count);
     // groups of equal qid (candidates arrive grouped per read: pm_worker.c:100-140)
     std::vector<u64> goff;
     goff.push_back(0);
     for (uint64_t i = 1; i < n; ++i) if (cands[i].qid != cands[i - 1].qid) goff.push_back(i);
     goff.push_back(n);
     const u32 ng = (u32)goff.size() - 1;
-    NECAT_HIP(ctx, hipMalloc((void**)&d_goff, goff.size() * 8));
     NECAT_HIP(ctx, hipMemcpyAsync(d_goff, goff.data(), goff.size() * 8, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_m4_filter, dim3(grid_for(ng, 64)), dim3(64), 0, s, (const necat_candidate*)d_cands, (const u64*)d_goff, ng,
                        (const necat_m4*)d_m4, d_ok, d_out, d_outcnt);

@@ -34,10 +34,11 @@ struct necat_ctx {
     necat_timings tm;
     hipEvent_t ev[12];
     std::vector<void*> owned;          // scratch buffers released at destroy
-    necat::DevBuf scratch[16];         // grow-only arenas, indexed by purpose
+    necat::DevBuf scratch[24];         // grow-only arenas, indexed by purpose
     char devname[256] = {0};
     int num_cu = 0;
-    uint32_t epoch = 0;                // launch counter stamped into the traceback band records
+    uint32_t epoch = 0;
+    necat::DevBuf idx_cache[2];        // released index arrays kept for the next build (8.6 GB hipMalloc/hipFree per step otherwise)                // launch counter stamped into the traceback band records
 };
 
 struct necat_volume {
@@ -53,6 +54,7 @@ struct necat_index {
     uint64_t table_entries = 0, n_offsets = 0;
     uint64_t* kmer_stats = nullptr;
     uint64_t* offset_list = nullptr;
+    size_t stats_cap = 0, offs_cap = 0;   // allocation sizes in bytes
 };
 
 namespace necat {
@@ -92,7 +94,7 @@ inline int buf_ensure(necat_ctx* ctx, DevBuf& b, size_t bytes)
 enum ScratchId {
     SC_CNT32 = 0, SC_PARTIAL, SC_TMPLIST, SC_MISC,
     SC_SEED_META, SC_SEED_HT, SC_SEED_POOL, SC_SEED_CHAIN, SC_SEED_OUT, SC_SEED_FINAL,
-    SC_EXT_TASKS, SC_EXT_LISTS, SC_EXT_FRAG, SC_EXT_MAT, SC_EXT_OPS, SC_EXT_RES
+    SC_EXT_TASKS, SC_EXT_LISTS, SC_EXT_FRAG, SC_EXT_MAT, SC_EXT_OPS, SC_EXT_RES, SC_EXT_CAND, SC_SMALL
 };
 
 }  // namespace necat
