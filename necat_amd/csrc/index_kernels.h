@@ -25,10 +25,12 @@ NECAT_D u64 kmer_hash_at(const u64* bases, i64 g, int k)
     return rev2(load32(bases, g)) >> (64 - 2 * k);
 }
 
-// MODE 0: count occurrences.  MODE 1: scatter offsets into bucket slots.
+// MODE 0: count occurrences.  MODE 1: scatter offsets into bucket slots; cnt32[h] then holds the
+// bucket's END cursor (start + count; 0 for k-mers dropped by the occurrence cutoff), so one atomic
+// both tests the k-mer and yields its slot - no second random read of kmer_stats.
 template <int MODE>
 __global__ void __launch_bounds__(256)
-k_kmer_pass(DevVolume vol, int k, u32* __restrict__ cnt32, const u64* __restrict__ kmer_stats, u64* __restrict__ tmp_list)
+k_kmer_pass(DevVolume vol, int k, u32* __restrict__ cnt32, u64 n_offsets, u64* __restrict__ tmp_list)
 {
     const u64 nthreads = (u64)gridDim.x * blockDim.x;
     const u64 nchunks = (vol.nbases + kPosPerThread - 1) / kPosPerThread;
@@ -46,11 +48,8 @@ k_kmer_pass(DevVolume vol, int k, u32* __restrict__ cnt32, const u64* __restrict
                 if (MODE == 0) {
                     atomicAdd(&cnt32[h], 1u);
                 } else {
-                    const u64 st = kmer_stats[h];
-                    if (st >> kOffsetBits) {
-                        const u32 old = atomicSub(&cnt32[h], 1u);
-                        tmp_list[(st & kOffsetMask) + old - 1] = p;
-                    }
+                    const u32 old = atomicSub(&cnt32[h], 1u);      // kept k-mer: start < old <= start + count
+                    if (old != 0u && (u64)old <= n_offsets) tmp_list[old - 1] = p;
                 }
             }
         }
@@ -93,33 +92,47 @@ k_scan_partials(u64* __restrict__ partial, u64 n)
 }
 
 // kmer_stats[h] = cnt<<34 | start (start = 0 for absent k-mers, as in the reference where only
-// present hashes get their start OR-ed in: lookup_table.c:94-113)
+// present hashes get their start OR-ed in: lookup_table.c:94-113); cnt32[h] becomes the scatter
+// pass's end cursor.  Pure streaming: 4 B in, 12 B out per table entry.
 __global__ void __launch_bounds__(256)
 k_write_stats(u32* __restrict__ cnt32, u64 n, u32 max_occ, const u64* __restrict__ partial, u64* __restrict__ kmer_stats)
 {
-    __shared__ u64 sh[256];
+    __shared__ u64 wave_tot[4];
     const u64 base = (u64)blockIdx.x * kScanTile + (u64)threadIdx.x * 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     u32 c[8]; u64 s = 0;
+    if (base + 8 <= n) {
+        const uint4 v0 = *reinterpret_cast<const uint4*>(cnt32 + base), v1 = *reinterpret_cast<const uint4*>(cnt32 + base + 4);
+        c[0] = v0.x; c[1] = v0.y; c[2] = v0.z; c[3] = v0.w; c[4] = v1.x; c[5] = v1.y; c[6] = v1.z; c[7] = v1.w;
+    } else {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { const u64 idx = base + i; c[i] = idx < n ? filtered_count(cnt32[idx], max_occ) : 0u; s += c[i]; }
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 256 thread sums
-    for (int off = 1; off < 256; off <<= 1) {
-        u64 v = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
-        __syncthreads();
-        sh[threadIdx.x] += v;
-        __syncthreads();
+        for (int i = 0; i < 8; ++i) c[i] = base + i < n ? cnt32[base + i] : 0u;
     }
-    u64 run = partial[blockIdx.x] + sh[threadIdx.x] - s;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { c[i] = filtered_count(c[i], max_occ); s += c[i]; }
+    u64 incl = s;                                  // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u64 v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    u64 run = partial[blockIdx.x] + incl - s;
+    for (int w = 0; w < wave; ++w) run += wave_tot[w];
+    u64 st[8]; u32 cur[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const u64 idx = base + i;
-        if (idx < n) {
-            kmer_stats[idx] = ((u64)c[i] << kOffsetBits) | (c[i] ? run : 0ULL);
-            cnt32[idx] = c[i];       // becomes the bucket cursor of the scatter pass
-            run += c[i];
-        }
+        st[i] = ((u64)c[i] << kOffsetBits) | (c[i] ? run : 0ULL);
+        run += c[i];
+        cur[i] = c[i] ? (u32)run : 0u;             // end cursor = start + count
+    }
+    if (base + 8 <= n) {
+        ulonglong2* o = reinterpret_cast<ulonglong2*>(kmer_stats + base);
+        o[0] = make_ulonglong2(st[0], st[1]); o[1] = make_ulonglong2(st[2], st[3]);
+        o[2] = make_ulonglong2(st[4], st[5]); o[3] = make_ulonglong2(st[6], st[7]);
+        uint4* q = reinterpret_cast<uint4*>(cnt32 + base);
+        q[0] = make_uint4(cur[0], cur[1], cur[2], cur[3]); q[1] = make_uint4(cur[4], cur[5], cur[6], cur[7]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (base + i < n) { kmer_stats[base + i] = st[i]; cnt32[base + i] = cur[i]; }
     }
 }
 

@@ -131,7 +131,7 @@ int necat_volume_upload(necat_ctx* ctx, const uint8_t* pac, uint64_t nbases, con
         run += seq_size[i];
     }
     if (run != nbases) return set_err(ctx, NECAT_ERR_ARG, "sequence sizes sum to %lu, volume holds %lu bases", (unsigned long)run, (unsigned long)nbases);
-    if (nbases >= (1ULL << 34) / 2) return set_err(ctx, NECAT_ERR_ARG, "volume too large for 34-bit offsets");
+    if (nbases >= (1ULL << 32)) return set_err(ctx, NECAT_ERR_ARG, "volume too large (>= 2^32 bases; oc2mkdb cuts volumes at 2e9, makedb/main.c:8)");
     necat_volume* v = new necat_volume();
     v->nbases = nbases; v->nseq = nseq;
     const uint64_t nwords = (nbases + 31) / 32;
@@ -194,7 +194,7 @@ int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, in
     NECAT_HIP(ctx, hipMemsetAsync(cnt32, 0, T * 4, s));
     const uint64_t nchunks = (ref->nbases + kPosPerThread - 1) / kPosPerThread;
     const unsigned pass_grid = grid_for(nchunks, 256, 1u << 16);
-    hipLaunchKernelGGL(k_kmer_pass<0>, dim3(pass_grid), dim3(256), 0, s, vol, kmer_size, cnt32, (const u64*)nullptr, (u64*)nullptr);
+    hipLaunchKernelGGL(k_kmer_pass<0>, dim3(pass_grid), dim3(256), 0, s, vol, kmer_size, cnt32, (u64)0, (u64*)nullptr);
     NECAT_CHECK_LAUNCH(ctx, "k_kmer_pass<count>");
     hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)ntiles), dim3(256), 0, s, cnt32, T, (u32)max_occ, partial);
     NECAT_CHECK_LAUNCH(ctx, "k_tile_sums");
@@ -211,7 +211,7 @@ int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, in
     if (n_off) {
         if ((rc = buf_ensure(ctx, ctx->scratch[SC_TMPLIST], n_off * 8))) { necat_index_free(ctx, ix); return rc; }
         u64* tmp = (u64*)ctx->scratch[SC_TMPLIST].p;
-        hipLaunchKernelGGL(k_kmer_pass<1>, dim3(pass_grid), dim3(256), 0, s, vol, kmer_size, cnt32, (const u64*)ix->kmer_stats, tmp);
+        hipLaunchKernelGGL(k_kmer_pass<1>, dim3(pass_grid), dim3(256), 0, s, vol, kmer_size, cnt32, n_off, tmp);
         NECAT_CHECK_LAUNCH(ctx, "k_kmer_pass<scatter>");
         hipLaunchKernelGGL(k_rank_buckets, dim3(grid_for(n_off, 256, 1u << 16)), dim3(256), 0, s, vol, kmer_size, (const u64*)ix->kmer_stats, (const u64*)tmp, n_off, ix->offset_list);
         NECAT_CHECK_LAUNCH(ctx, "k_rank_buckets");
