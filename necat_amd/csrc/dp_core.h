@@ -126,6 +126,7 @@ NECAT_HD MyersResult myers_block(MyersRegs<NW>& R, int qn, int tn, double error,
         }
     }
     if (best == -1) return res;
+    if (mat.skip_nw()) { res.dist = best; res.endc = end0; return res; }     // profiling-only switch
 
     // ------------------------------------------------------------------ NW pass (edlib_ex.c:226-370)
     const int d = best;

@@ -143,6 +143,7 @@ struct MatWriter {
     ulonglong2* rec;   // slab + lane (16-byte units: record r of this lane at rec[r * 128 + {0,1}])
     u32 epoch;
     int dbg;
+    NECAT_D bool skip_nw() const { return dbg == 2; }
     NECAT_D void store(int c, int b, u64 P, u64 M, int S, int Sup, int f, int l)
     {
         if (dbg == 1) return;
@@ -200,10 +201,10 @@ NECAT_D ulonglong2* slab_records(char* slab, int lane) { return reinterpret_cast
 template <int NW, int TW, int COLS, bool FULL>
 __global__ void __launch_bounds__(64)
 k_myers(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
-        double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, u32 epoch)
+        double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, u32 epoch, u32 item_base)
 {
     constexpr int FW = 2 * NW + TW;
-    const u32 grp = blockIdx.x;
+    const u32 grp = blockIdx.x + (item_base >> 6);      // item_base is a multiple of 64; n = end of this launch's range
     const int lane = threadIdx.x;
     const u64 item = (u64)grp * 64 + lane;
     if (item >= n) return;
@@ -249,11 +250,11 @@ NECAT_D int dpp_from_lane_below(int v)   // lane i receives v of lane i-1 (withi
 template <int NW, int TW, int COLS, int G>
 __global__ void __launch_bounds__(64)
 k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
-             double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, u32 epoch)
+             double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, u32 epoch, u32 item_base)
 {
     constexpr int FW = 2 * NW + TW, BPW = 64 / G;
     const int lane = threadIdx.x, sub = lane / G, b = lane % G;
-    const u64 item = (u64)blockIdx.x * BPW + sub;
+    const u64 item = (u64)item_base + (u64)blockIdx.x * BPW + sub;
     const bool valid = item < n;
     const u64 grp = item >> 6;
     const int il = (int)(item & 63);

@@ -42,6 +42,7 @@ DevVolume dev_view(const necat_volume* v)
 // NECAT_COOP_THRESHOLD overrides it (0 = never, huge = always) for tests and A/B measurements
 u32 g_coop_threshold = 49152;
 int g_trace = 0;
+int g_coop_split = 0;   // NECAT_COOP_SPLIT: percent of a big list A given to the cooperative kernel, run concurrently
 int g_dbg = 0;     // NECAT_DBG: profiling-only variants of the DP kernel (1 = no band stores, 2 = no NW pass)
 
 double wall_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
@@ -73,6 +74,7 @@ int necat_ctx_create(int device_id, necat_ctx** out)
     if (const char* e = getenv("NECAT_COOP_THRESHOLD")) g_coop_threshold = (u32)strtoul(e, nullptr, 10);
     if (const char* e = getenv("NECAT_TRACE")) g_trace = atoi(e);
     if (const char* e = getenv("NECAT_DBG")) g_dbg = atoi(e);
+    if (const char* e = getenv("NECAT_COOP_SPLIT")) g_coop_split = atoi(e);
     memset(&ctx->tm, 0, sizeof ctx->tm);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
@@ -80,7 +82,7 @@ int necat_ctx_create(int device_id, necat_ctx** out)
         ctx->num_cu = prop.multiProcessorCount;
     }
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream_a) != hipSuccess ||
-        hipStreamCreate(&ctx->stream_b) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
+        hipStreamCreate(&ctx->stream_b) != hipSuccess || hipStreamCreate(&ctx->stream_c) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
     for (int i = 0; i < 12; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
     *out = ctx;
     return NECAT_OK;
@@ -94,7 +96,7 @@ void necat_ctx_destroy(necat_ctx* ctx)
     for (auto& b : ctx->scratch) if (b.p) (void)hipFree(b.p);
     for (auto& b : ctx->idx_cache) if (b.p) (void)hipFree(b.p);
     for (int i = 0; i < 12; ++i) (void)hipEventDestroy(ctx->ev[i]);
-    (void)hipStreamDestroy(ctx->stream); (void)hipStreamDestroy(ctx->stream_a); (void)hipStreamDestroy(ctx->stream_b);
+    (void)hipStreamDestroy(ctx->stream); (void)hipStreamDestroy(ctx->stream_a); (void)hipStreamDestroy(ctx->stream_b); (void)hipStreamDestroy(ctx->stream_c);
     delete ctx;
 }
 
@@ -435,10 +437,24 @@ int run_rounds(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, ExtB
             NECAT_HIP(ctx, hipEventRecord(a0, sa));
             if (nA <= g_coop_threshold)
                 hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((nA + 7) / 8), dim3(64), 0, sa, itA, nA,
-                                   (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA, B.stats, epoch);
-            else
-                hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(gA), dim3(64), 0, sa, itA, nA,
-                                   (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA, B.stats, epoch);
+                                   (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA, B.stats, epoch, 0u);
+            else {
+                // big list: the register-heavy lane-per-block kernel leaves issue slots idle (<= 4 waves/SIMD);
+                // an optional slice of the list runs through the light cooperative kernel at the same time
+                u32 n1 = nA;
+                if (g_coop_split > 0) n1 = (u32)((u64)nA * (100 - g_coop_split) / 100) & ~63u;
+                hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3((n1 + 63) / 64), dim3(64), 0, sa, itA, n1,
+                                   (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA, B.stats, epoch, 0u);
+                if (n1 < nA) {
+                    hipStream_t sc = ctx->stream_c;
+                    NECAT_HIP(ctx, hipEventRecord(ctx->ev[10], sa));        // after k_ext_frag<A> (and the lane-per-block launch)
+                    NECAT_HIP(ctx, hipStreamWaitEvent(sc, a0, 0));
+                    hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((nA - n1 + 7) / 8), dim3(64), 0, sc, itA, nA,
+                                       (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA, B.stats, epoch, n1);
+                    NECAT_HIP(ctx, hipEventRecord(ctx->ev[11], sc));
+                    NECAT_HIP(ctx, hipStreamWaitEvent(sa, ctx->ev[11], 0));
+                }
+            }
             NECAT_CHECK_LAUNCH(ctx, "k_myers<A>");
             NECAT_HIP(ctx, hipEventRecord(a1, sa));
             hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false>), dim3(gA), dim3(64), 0, sa, itA, nA,
@@ -454,10 +470,10 @@ int run_rounds(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, ExtB
             NECAT_HIP(ctx, hipEventRecord(b0, sb));
             if (nB <= g_coop_threshold)
                 hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB,
-                                   (const u64*)B.fragB, slabsB, kSlabB, error, B.resB, B.stats, epoch);
+                                   (const u64*)B.fragB, slabsB, kSlabB, error, B.resB, B.stats, epoch, 0u);
             else
                 hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB,
-                                   (const u64*)B.fragB, slabsB, kSlabB, error, B.resB, B.stats, epoch);
+                                   (const u64*)B.fragB, slabsB, kSlabB, error, B.resB, B.stats, epoch, 0u);
             NECAT_CHECK_LAUNCH(ctx, "k_myers<B>");
             NECAT_HIP(ctx, hipEventRecord(b1, sb));
             hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB,
@@ -652,10 +668,10 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[4], s));
             const bool coop = m <= g_coop_threshold;
             const u32 epoch = ++ctx->epoch & 0x3fffffu;
-            if (full && coop) hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch);
-            else if (full) hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | ((u32)g_dbg << 28));
-            else if (coop) hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((m + 3) / 4), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch);
-            else hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch);
+            if (full && coop) hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch, 0u);
+            else if (full) hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | ((u32)g_dbg << 28), 0u);
+            else if (coop) hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((m + 3) / 4), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch, 0u);
+            else hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch, 0u);
             NECAT_CHECK_LAUNCH(ctx, "k_myers");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[5], s));
             if (full) hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, (const char*)d_slabs, slab,

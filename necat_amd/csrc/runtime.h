@@ -30,6 +30,7 @@ struct necat_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream_a = nullptr, stream_b = nullptr;   // the two block shapes of a round run concurrently
+    hipStream_t stream_c = nullptr;                       // second DP kernel of a split list A
     char err[1024] = {0};
     necat_timings tm;
     hipEvent_t ev[12];

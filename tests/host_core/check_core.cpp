@@ -40,7 +40,7 @@ struct HMat {
     std::vector<u64> P, M; std::vector<int> S, F, L; int nw;
     void init(int cols, int nw_) { nw = nw_; P.assign((size_t)cols * nw, 0); M.assign((size_t)cols * nw, 0); S.assign((size_t)cols * nw, 0); F.assign(cols, 0); L.assign(cols, 0); }
     void store(int c, int b, u64 p, u64 m, int s, int sup, int f, int l) { P[(size_t)c * nw + b] = p; M[(size_t)c * nw + b] = m; S[(size_t)c * nw + b] = s; (void)sup; F[c] = f; L[c] = l; }
-    u64 Pr(int c, int b) const { return P[(size_t)c * nw + b]; }
+    bool skip_nw() const { return false; }
 };
 struct HMatR {
     const HMat* m;
