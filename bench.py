@@ -140,7 +140,8 @@ def main():
         step()
     barrier_sync(dist, local)
     t0 = time.perf_counter()
-    agg = dict(index_ms=0.0, seed_ms=0.0, extend_ms=0.0, myers_ms=0.0, traceback_ms=0.0, launches=0, blocks=0, words=0, bases=0, rounds=0)
+    agg = dict(index_ms=0.0, seed_ms=0.0, extend_ms=0.0, myers_ms=0.0, traceback_ms=0.0, launches=0, blocks=0, words=0, bases=0, rounds=0,
+               a_ms=0.0, a_launches=0, a_blocks=0)
     n_over = 0
     gbp = 0.0
     for _ in range(args.steps):
@@ -152,6 +153,7 @@ def main():
         agg["myers_ms"] += tm.myers_ms; agg["traceback_ms"] += tm.traceback_ms; agg["launches"] += tm.myers_launches
         agg["blocks"] += tm.myers_blocks; agg["words"] += tm.myers_word_updates; agg["bases"] += tm.myers_cells_bases
         agg["rounds"] += tm.rounds
+        agg["a_ms"] += tm.myersA_ms; agg["a_launches"] += tm.myersA_launches; agg["a_blocks"] += tm.myersA_blocks
     barrier_sync(dist, local)
     elapsed = time.perf_counter() - t0
     from necat_amd import shard
@@ -161,22 +163,34 @@ def main():
             dist.destroy_process_group()
         return
     K = max(1, args.steps)
-    # ---- roofline of the dominant kernel (k_myers): algorithmic HBM bytes per launch / launch time.
-    # A block alignment must read its two 2-bit fragments and write one 16-byte result (SURVEY.md §8d
-    # "extension" row restated per block); everything else it touches is its own scratch.
-    alg_bytes = agg["bases"] / 4.0 + 16.0 * agg["blocks"]
-    launches = max(1, agg["launches"])
-    avg_launch_ms = agg["myers_ms"] / launches
-    achieved = (alg_bytes / launches) / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    # ---- roofline of the dominant kernel: k_myers<8,16,512,true> (lane-per-block DP of full 512 x 512
+    # blocks; largest single entry of the rocprof summary, profiles/r01_kernel_stats.md).  Algorithmic
+    # HBM bytes of one block alignment = its two 2-bit fragments in (2 x 512 / 4 B) + one 16-byte result
+    # out (SURVEY.md 8d "extension" row restated per block); everything else the kernel moves is the
+    # traceback band it stores (reported as `traffic`, from the PMC passes kept in profiles/).
+    A_BYTES_PER_BLOCK = 2 * 512 / 4.0 + 16.0
+    a_launches = max(1, agg["a_launches"])
+    avg_launch_ms = agg["a_ms"] / a_launches
+    alg_per_launch = A_BYTES_PER_BLOCK * agg["a_blocks"] / a_launches
+    achieved = alg_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     word_rate = agg["words"] / (agg["myers_ms"] * 1e-3) if agg["myers_ms"] > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_myers", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                "launches": int(agg["launches"]), "avg_launch_ms": round(avg_launch_ms, 4),
-                "algorithmic_bytes_per_launch": round(alg_bytes / launches, 1),
-                "word_updates_per_s": round(word_rate, 1),
-                "valu_frac": round(word_rate * OPS_PER_WORD_UPDATE / VALU_LANE_OPS_PER_S, 4),
-                "note": "integer DP: HBM fraction is small by construction (SURVEY.md 8d); valu_frac = word updates x %d "
-                        "lane-ops / (256 CU x 128 lanes x 2.4 GHz)" % OPS_PER_WORD_UPDATE}
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        k = pmc["void necat::k_myers<8, 16, 512, true>"]
+        # FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section)
+        traffic = (2.0 * k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]) * 1024.0
+    except Exception:
+        pass
+    roofline = {"bound": "hbm", "kernel": "k_myers<8,16,512,true>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "launches": int(agg["a_launches"]), "avg_launch_ms": round(avg_launch_ms, 4),
+                "algorithmic_bytes_per_launch": round(alg_per_launch, 1),
+                "all_dp_kernels": {"launches": int(agg["launches"]), "ms": round(agg["myers_ms"], 2), "blocks": int(agg["blocks"]),
+                                   "word_updates_per_s": round(word_rate, 1),
+                                   "valu_frac": round(word_rate * OPS_PER_WORD_UPDATE / VALU_LANE_OPS_PER_S, 4)},
+                "note": "integer DP: the HBM fraction is small by construction (SURVEY.md 8d); traffic (PMC, profiles/r01_pmc_hbm_traffic.json) "
+                        "is dominated by the stored traceback band; valu_frac = word updates x %d lane-ops / (256 CU x 128 lanes x 2.4 GHz)" % OPS_PER_WORD_UPDATE}
     out = {
         "metric": "overlaps/sec (all-vs-all, index build + seeding + banded Myers extension -> M4)",
         "value": round(tot_over / elapsed, 1), "unit": "overlaps/s",

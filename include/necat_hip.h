@@ -90,6 +90,9 @@ typedef struct {
     uint64_t myers_word_updates;/* 64-row word updates actually computed (SHW + NW) */
     uint64_t myers_cells_bases; /* sum over blocks of query+target fragment bases */
     uint64_t rounds;
+    /* the dominant kernel alone: k_myers<8,16,512,true> (lane-per-block DP of full 512 x 512 blocks) */
+    double   myersA_ms;
+    uint64_t myersA_launches, myersA_blocks;
 } necat_timings;
 
 void        necat_default_options(necat_map_options* o);            /* map_options.c:12-28 */

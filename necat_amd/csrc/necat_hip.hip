@@ -486,6 +486,7 @@ int run_rounds(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, ExtB
         if (nB) NECAT_HIP(ctx, hipStreamSynchronize(sb));
         const double mA = nA ? ev_ms(a0, a1) : 0, tA = nA ? ev_ms(a1, a2) : 0, mB = nB ? ev_ms(b0, b1) : 0, tB = nB ? ev_ms(b1, b2) : 0;
         ctx->tm.myers_ms += mA + mB;
+        if (nA > g_coop_threshold) { ctx->tm.myersA_ms += mA; ctx->tm.myersA_launches += 1; ctx->tm.myersA_blocks += nA; }
         ctx->tm.traceback_ms += tA + tB;
         if (g_trace) fprintf(stderr, "[necat] round %3lu: nA=%7u nB=%7u myers %.3f + %.3f ms traceback %.3f + %.3f ms\n", (unsigned long)ctx->tm.rounds, nA, nB, mA, mB, tA, tB);
         ctx->tm.myers_launches += (nA ? 1 : 0) + (nB ? 1 : 0);
@@ -519,6 +520,7 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
     DevVolume dref = dev_view(ref), drd = dev_view(reads);
     ctx->tm.myers_ms = ctx->tm.traceback_ms = 0; ctx->tm.myers_launches = ctx->tm.myers_blocks = ctx->tm.rounds = 0;
     ctx->tm.myers_word_updates = ctx->tm.myers_cells_bases = 0;
+    ctx->tm.myersA_ms = 0; ctx->tm.myersA_launches = ctx->tm.myersA_blocks = 0;
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
     const u32 batch = (u32)std::min<uint64_t>(n, 393216);      // slab pool <= ~130 GB of the 288 GB HBM
     const u32 groups = (batch + 63) / 64 + 1;
