@@ -31,12 +31,18 @@ def test_oc2pmov_reproduces_reference_records(name, tmp_path, built):
     assert not os.path.exists(out + ".part")
 
 
-def test_oc2pm_wrapper_concatenates_volumes(tmp_path, built):
+@pytest.mark.parametrize("gpus", [None, "0,0"])
+def test_oc2pm_wrapper_concatenates_volumes(tmp_path, built, gpus):
+    """gpus = "0,0": two oc2pmov children at a time (one per listed device - here the same one twice),
+    the multi-GPU scheduling of reference volumes."""
     pmov, pm = built.build_cli()
     d = util.install_golden_volumes("vols_b", tmp_path)
     o = ora.options(**MANIFEST["b_v0_m4_txt"]["options"])
     out = os.path.join(str(tmp_path), "all.m4")
-    r = subprocess.run([pm] + ora.opt_argv(o) + [d, out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    env = dict(os.environ)
+    if gpus:
+        env["NECAT_GPUS"] = gpus
+    r = subprocess.run([pm] + ora.opt_argv(o) + [d, out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
     assert r.returncode == 0, r.stderr
     got = sorted(open(out, "rb").read().splitlines(keepends=True))
     want = []
