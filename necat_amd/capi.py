@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -207,14 +208,15 @@ class Context:
         return dist, qend, tend, o, oo
 
     def _take(self, p: C.c_void_p, n: int, dtype: np.dtype) -> np.ndarray:
+        """Wrap a library-malloc'ed result array without copying; necat_free runs when the array dies."""
         if not p.value:
             return np.zeros(0, dtype=dtype)
-        if n:
-            buf = (C.c_char * (n * dtype.itemsize)).from_address(p.value)
-            arr = np.frombuffer(buf, dtype=dtype, count=n).copy()
-        else:
-            arr = np.zeros(0, dtype=dtype)
-        self.lib.necat_free(p)
+        if n == 0:
+            self.lib.necat_free(p)
+            return np.zeros(0, dtype=dtype)
+        buf = (C.c_char * (n * dtype.itemsize)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=n)
+        weakref.finalize(buf, self.lib.necat_free, C.c_void_p(p.value))   # arr keeps buf alive through .base
         return arr
 
 

@@ -1,21 +1,23 @@
 // ext_kernels.h - __global__ shells of the extension stage (onc_align for 10^5..10^6 candidates at once).
 //
 // Every candidate is a small state machine (ext_core.h) that needs one block alignment per round;
-// a round is four launches over the still-active candidates:
+// its scheduled block sits in list A (full 512 x 512 blocks) or list B (the variable-size last block of
+// an extension, <= 794 x 794).  A round is three launches per list, the two lists on two streams:
 //
-//   k_ext_plan      decide each candidate's next block (or finish it); full 512 x 512 blocks go to
-//                   list A, the variable-size last blocks of an extension (<= 794 x 794) to list B
 //   k_ext_frag      gather the two fragments of every block from the 2-bit volumes: query as two
 //                   complemented bit-planes per 64 rows, target 2-bit packed; written lane-interleaved
 //                   so the DP kernel's loads are fully coalesced
-//   k_myers<NW>     THE hot kernel: one lane = one block alignment, SHW pass + banded NW pass
-//                   (dp_core.h); 64 alignments of similar shape advance in lock-step per wave; the NW
-//                   band (P,M as one 16-byte pair + i16 score) is stored [column][word][lane], i.e.
-//                   every store instruction writes one contiguous 1 KiB line per wave
+//   k_myers<NW>     lane = one block alignment: SHW pass + banded NW pass (dp_core.h); 64 alignments of
+//                   the same shape advance in lock-step per wave; used for big lists
+//   k_myers_coop<G> G lanes = one block alignment (anti-diagonal wavefront over the 64-row words, DPP carry,
+//                   LDS-staged target); 6x lower latency, used for small lists (the tail of the rounds)
 //   k_traceback     walk the stored band back (up > left > diagonal), trim the block tail at the last
-//                   run of 8 matches and fold the kept columns into the candidate's running counters
+//                   run of 8 matches, fold the kept columns into the candidate's running counters, then
+//                   plan the candidate's next block and append it to the next round's lists
 //
-// Groups of 64 work items share one slab of the matrix pool; list A slabs (512 cols x 8 words) come
+// The NW band is stored as 32-byte records [column][word][lane]: every store instruction of the DP
+// kernel writes one contiguous 2 KiB span per wave, every traceback step is one 32-byte load.
+// Groups of 64 work items share one slab of the band pool; list A slabs (512 cols x 8 words) come
 // first, list B slabs (794 x 13) after them.
 #pragma once
 #include "dp_core.h"

@@ -42,7 +42,8 @@ DevVolume dev_view(const necat_volume* v)
 // NECAT_COOP_THRESHOLD overrides it (0 = never, huge = always) for tests and A/B measurements
 u32 g_coop_threshold = 49152;
 int g_trace = 0;
-int g_coop_split = 0;   // NECAT_COOP_SPLIT: percent of a big list A given to the cooperative kernel, run concurrently
+int g_antiphase = 1;
+int g_cohorts = 1;
 int g_dbg = 0;     // NECAT_DBG: profiling-only variants of the DP kernel (1 = no band stores, 2 = no NW pass)
 
 double wall_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
@@ -74,7 +75,8 @@ int necat_ctx_create(int device_id, necat_ctx** out)
     if (const char* e = getenv("NECAT_COOP_THRESHOLD")) g_coop_threshold = (u32)strtoul(e, nullptr, 10);
     if (const char* e = getenv("NECAT_TRACE")) g_trace = atoi(e);
     if (const char* e = getenv("NECAT_DBG")) g_dbg = atoi(e);
-    if (const char* e = getenv("NECAT_COOP_SPLIT")) g_coop_split = atoi(e);
+    if (const char* e = getenv("NECAT_ANTIPHASE")) g_antiphase = atoi(e);
+    if (const char* e = getenv("NECAT_COHORTS")) g_cohorts = atoi(e) == 2 ? 2 : 1;
     memset(&ctx->tm, 0, sizeof ctx->tm);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
@@ -82,8 +84,9 @@ int necat_ctx_create(int device_id, necat_ctx** out)
         ctx->num_cu = prop.multiProcessorCount;
     }
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream_a) != hipSuccess ||
-        hipStreamCreate(&ctx->stream_b) != hipSuccess || hipStreamCreate(&ctx->stream_c) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
-    for (int i = 0; i < 12; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
+        hipStreamCreate(&ctx->stream_b) != hipSuccess || hipStreamCreate(&ctx->stream_c) != hipSuccess ||
+        hipStreamCreate(&ctx->stream_d) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
+    for (int i = 0; i < 20; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
     *out = ctx;
     return NECAT_OK;
 }
@@ -95,8 +98,8 @@ void necat_ctx_destroy(necat_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& b : ctx->scratch) if (b.p) (void)hipFree(b.p);
     for (auto& b : ctx->idx_cache) if (b.p) (void)hipFree(b.p);
-    for (int i = 0; i < 12; ++i) (void)hipEventDestroy(ctx->ev[i]);
-    (void)hipStreamDestroy(ctx->stream); (void)hipStreamDestroy(ctx->stream_a); (void)hipStreamDestroy(ctx->stream_b); (void)hipStreamDestroy(ctx->stream_c);
+    for (int i = 0; i < 20; ++i) (void)hipEventDestroy(ctx->ev[i]);
+    (void)hipStreamDestroy(ctx->stream); (void)hipStreamDestroy(ctx->stream_a); (void)hipStreamDestroy(ctx->stream_b); (void)hipStreamDestroy(ctx->stream_c); (void)hipStreamDestroy(ctx->stream_d);
     delete ctx;
 }
 
@@ -404,96 +407,110 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
 
 namespace {
 
-struct ExtBuffers {
+// A cohort = one batch of candidates advancing through its rounds with its own buffers and stream pair.
+// Rounds inside a cohort are strictly ordered (a candidate's next block starts where its previous,
+// trimmed block ended).  The loop can keep two cohorts in flight (one in its DP kernel while the other
+// walks its tracebacks); on MI355X that measured slower than one cohort of twice the size, so one is
+// the default (see necat_extend).
+struct Cohort {
+    // buffers
     ExtTask* tasks; u32* count; BlockItem* itemsA[2]; BlockItem* itemsB[2];   // count[2][2]: per list parity (nA, nB)
-    u64* fragA; u64* fragB; char* slabs; u8* opsA; u8* opsB; BlockResult* resA; BlockResult* resB; unsigned long long* stats;
+    u64* fragA; u64* fragB; char* slabs; u8* opsA; u8* opsB; BlockResult* resA; BlockResult* resB;
+    hipStream_t sa, sb;
+    hipEvent_t a0, a1, a2, b0, b1, b2;
+    // state
+    u64 base; u32 n; int parity; bool active, in_flight, a1_valid;
+    u32 nA, nB;
 };
 
-// run rounds until every task of the batch is done
-int run_rounds(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, ExtBuffers& B, u32 n_tasks, double error,
-               int tail_match_len, int* d_err)
+struct ExtShared {
+    const necat_candidate* d_cands; necat_m4* d_m4; u8* d_ok; int* d_err; unsigned long long* stats;
+    double error; int tail_match_len, min_align, read_start_id, ref_start_id;
+    const u64* reads_off; const u64* ref_off;
+};
+
+// finish the round a cohort has in flight (if any): wait, account, flip the list parity
+int cohort_retire(necat_ctx* ctx, Cohort& c)
 {
-    hipStream_t s = ctx->stream, sa = ctx->stream_a, sb = ctx->stream_b;
-    (void)n_tasks;
-    hipEvent_t a0 = ctx->ev[4], a1 = ctx->ev[5], a2 = ctx->ev[6], b0 = ctx->ev[7], b1 = ctx->ev[8], b2 = ctx->ev[9];
-    // lists of parity p were filled by k_ext_init (round 0) or by the previous round's tracebacks
-    for (int p = 0;; p ^= 1) {
-        u32 cnt[2] = {0, 0};
-        NECAT_HIP(ctx, hipMemcpyAsync(cnt, B.count + 2 * p, 8, hipMemcpyDeviceToHost, s));
-        NECAT_HIP(ctx, hipMemsetAsync(B.count + 2 * (p ^ 1), 0, 8, s));
-        NECAT_HIP(ctx, hipStreamSynchronize(s));
-        const u32 nA = cnt[0], nB = cnt[1];
-        if (nA + nB == 0) break;
-        const u32 gA = (nA + 63) / 64, gB = (nB + 63) / 64;
-        char* slabsB = B.slabs + (size_t)gA * kSlabA;
-        const BlockItem* itA = B.itemsA[p]; const BlockItem* itB = B.itemsB[p];
-        const u32 epoch = ++ctx->epoch & 0x3fffffu;
-        ExtLists next; next.count = B.count + 2 * (p ^ 1); next.itemsA = B.itemsA[p ^ 1]; next.itemsB = B.itemsB[p ^ 1];
-        // the two shapes of the round are independent: list A on stream_a, list B on stream_b
-        if (nA) {
-            hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)gA * 64 * (kWordsA + kTWordsA), 256)), dim3(256), 0, sa,
-                               drd, dref, itA, nA, B.fragA);
-            NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<A>");
-            NECAT_HIP(ctx, hipEventRecord(a0, sa));
-            if (nA <= g_coop_threshold)
-                hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((nA + 7) / 8), dim3(64), 0, sa, itA, nA,
-                                   (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA, B.stats, epoch, 0u);
-            else {
-                // big list: the register-heavy lane-per-block kernel leaves issue slots idle (<= 4 waves/SIMD);
-                // an optional slice of the list runs through the light cooperative kernel at the same time
-                u32 n1 = nA;
-                if (g_coop_split > 0) n1 = (u32)((u64)nA * (100 - g_coop_split) / 100) & ~63u;
-                hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3((n1 + 63) / 64), dim3(64), 0, sa, itA, n1,
-                                   (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA, B.stats, epoch, 0u);
-                if (n1 < nA) {
-                    hipStream_t sc = ctx->stream_c;
-                    NECAT_HIP(ctx, hipEventRecord(ctx->ev[10], sa));        // after k_ext_frag<A> (and the lane-per-block launch)
-                    NECAT_HIP(ctx, hipStreamWaitEvent(sc, a0, 0));
-                    hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((nA - n1 + 7) / 8), dim3(64), 0, sc, itA, nA,
-                                       (const u64*)B.fragA, B.slabs, kSlabA, error, B.resA, B.stats, epoch, n1);
-                    NECAT_HIP(ctx, hipEventRecord(ctx->ev[11], sc));
-                    NECAT_HIP(ctx, hipStreamWaitEvent(sa, ctx->ev[11], 0));
-                }
-            }
-            NECAT_CHECK_LAUNCH(ctx, "k_myers<A>");
-            NECAT_HIP(ctx, hipEventRecord(a1, sa));
-            hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false>), dim3(gA), dim3(64), 0, sa, itA, nA,
-                               (const u64*)B.fragA, (const char*)B.slabs, kSlabA, (const BlockResult*)B.resA, B.opsA, B.tasks, tail_match_len,
-                               (i32*)nullptr, d_err, next, epoch);
-            NECAT_CHECK_LAUNCH(ctx, "k_traceback<A>");
-            NECAT_HIP(ctx, hipEventRecord(a2, sa));
-        }
-        if (nB) {
-            hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, sb,
-                               drd, dref, itB, nB, B.fragB);
-            NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
-            NECAT_HIP(ctx, hipEventRecord(b0, sb));
-            if (nB <= g_coop_threshold)
-                hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB,
-                                   (const u64*)B.fragB, slabsB, kSlabB, error, B.resB, B.stats, epoch, 0u);
-            else
-                hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB,
-                                   (const u64*)B.fragB, slabsB, kSlabB, error, B.resB, B.stats, epoch, 0u);
-            NECAT_CHECK_LAUNCH(ctx, "k_myers<B>");
-            NECAT_HIP(ctx, hipEventRecord(b1, sb));
-            hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB,
-                               (const u64*)B.fragB, (const char*)slabsB, kSlabB, (const BlockResult*)B.resB, B.opsB, B.tasks, tail_match_len,
-                               (i32*)nullptr, d_err, next, epoch);
-            NECAT_CHECK_LAUNCH(ctx, "k_traceback<B>");
-            NECAT_HIP(ctx, hipEventRecord(b2, sb));
-        }
-        if (nA) NECAT_HIP(ctx, hipStreamSynchronize(sa));
-        if (nB) NECAT_HIP(ctx, hipStreamSynchronize(sb));
-        const double mA = nA ? ev_ms(a0, a1) : 0, tA = nA ? ev_ms(a1, a2) : 0, mB = nB ? ev_ms(b0, b1) : 0, tB = nB ? ev_ms(b1, b2) : 0;
-        ctx->tm.myers_ms += mA + mB;
-        if (nA > g_coop_threshold) { ctx->tm.myersA_ms += mA; ctx->tm.myersA_launches += 1; ctx->tm.myersA_blocks += nA; }
-        ctx->tm.traceback_ms += tA + tB;
-        if (g_trace) fprintf(stderr, "[necat] round %3lu: nA=%7u nB=%7u myers %.3f + %.3f ms traceback %.3f + %.3f ms\n", (unsigned long)ctx->tm.rounds, nA, nB, mA, mB, tA, tB);
-        ctx->tm.myers_launches += (nA ? 1 : 0) + (nB ? 1 : 0);
-        ctx->tm.myers_blocks += nA + nB;
-        ctx->tm.rounds += 1;
-    }
+    if (!c.in_flight) return NECAT_OK;
+    if (c.nA) NECAT_HIP(ctx, hipStreamSynchronize(c.sa));
+    if (c.nB) NECAT_HIP(ctx, hipStreamSynchronize(c.sb));
+    const double mA = c.nA ? ev_ms(c.a0, c.a1) : 0, tA = c.nA ? ev_ms(c.a1, c.a2) : 0, mB = c.nB ? ev_ms(c.b0, c.b1) : 0, tB = c.nB ? ev_ms(c.b1, c.b2) : 0;
+    ctx->tm.myers_ms += mA + mB;
+    ctx->tm.traceback_ms += tA + tB;
+    if (c.nA > g_coop_threshold) { ctx->tm.myersA_ms += mA; ctx->tm.myersA_launches += 1; ctx->tm.myersA_blocks += c.nA; }
+    if (g_trace) fprintf(stderr, "[necat] cohort@%lu round %3lu: nA=%7u nB=%7u myers %.3f + %.3f ms traceback %.3f + %.3f ms\n",
+                         (unsigned long)c.base, (unsigned long)ctx->tm.rounds, c.nA, c.nB, mA, mB, tA, tB);
+    ctx->tm.myers_launches += (c.nA ? 1 : 0) + (c.nB ? 1 : 0);
+    ctx->tm.myers_blocks += c.nA + c.nB;
+    ctx->tm.rounds += 1;
+    c.in_flight = false;
+    c.parity ^= 1;
     return NECAT_OK;
+}
+
+// launch the next round of a cohort; returns 1 when the cohort has no scheduled block left
+int cohort_launch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Cohort& c, const ExtShared& X, const Cohort* other)
+{
+    const int p = c.parity;
+    u32 cnt[2] = {0, 0};
+    NECAT_HIP(ctx, hipMemcpyAsync(cnt, c.count + 2 * p, 8, hipMemcpyDeviceToHost, c.sa));
+    NECAT_HIP(ctx, hipMemsetAsync(c.count + 2 * (p ^ 1), 0, 8, c.sa));
+    NECAT_HIP(ctx, hipStreamSynchronize(c.sa));
+    const u32 nA = cnt[0], nB = cnt[1];
+    c.nA = nA; c.nB = nB;
+    if (nA + nB == 0) return 1;
+    const u32 gA = (nA + 63) / 64, gB = (nB + 63) / 64;
+    char* slabsB = c.slabs + (size_t)gA * kSlabA;
+    const BlockItem* itA = c.itemsA[p]; const BlockItem* itB = c.itemsB[p];
+    const u32 epoch = ++ctx->epoch & 0x3fffffu;
+    ExtLists next; next.count = c.count + 2 * (p ^ 1); next.itemsA = c.itemsA[p ^ 1]; next.itemsB = c.itemsB[p ^ 1];
+    // keep the two cohorts in anti-phase while both are in their bulk rounds: this cohort's DP kernel
+    // starts when the other's DP kernel is done, i.e. it overlaps the other's traceback
+    if (g_antiphase && other && other->in_flight && other->a1_valid && nA > g_coop_threshold && other->nA > g_coop_threshold)
+        NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, other->a1, 0));
+    c.a1_valid = false;
+    if (nA) {
+        hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)gA * 64 * (kWordsA + kTWordsA), 256)), dim3(256), 0, c.sa,
+                           drd, dref, itA, nA, c.fragA);
+        NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<A>");
+        NECAT_HIP(ctx, hipEventRecord(c.a0, c.sa));
+        if (nA <= g_coop_threshold)
+            hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((nA + 7) / 8), dim3(64), 0, c.sa, itA, nA,
+                               (const u64*)c.fragA, c.slabs, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
+        else
+            hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(gA), dim3(64), 0, c.sa, itA, nA,
+                               (const u64*)c.fragA, c.slabs, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
+        NECAT_CHECK_LAUNCH(ctx, "k_myers<A>");
+        NECAT_HIP(ctx, hipEventRecord(c.a1, c.sa));
+        c.a1_valid = true;
+        hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false>), dim3(gA), dim3(64), 0, c.sa, itA, nA,
+                           (const u64*)c.fragA, (const char*)c.slabs, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
+                           (i32*)nullptr, X.d_err, next, epoch);
+        NECAT_CHECK_LAUNCH(ctx, "k_traceback<A>");
+        NECAT_HIP(ctx, hipEventRecord(c.a2, c.sa));
+    }
+    if (nB) {
+        hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, c.sb,
+                           drd, dref, itB, nB, c.fragB);
+        NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
+        NECAT_HIP(ctx, hipEventRecord(c.b0, c.sb));
+        if (nB <= g_coop_threshold)
+            hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, c.sb, itB, nB,
+                               (const u64*)c.fragB, slabsB, kSlabB, X.error, c.resB, X.stats, epoch, 0u);
+        else
+            hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, c.sb, itB, nB,
+                               (const u64*)c.fragB, slabsB, kSlabB, X.error, c.resB, X.stats, epoch, 0u);
+        NECAT_CHECK_LAUNCH(ctx, "k_myers<B>");
+        NECAT_HIP(ctx, hipEventRecord(c.b1, c.sb));
+        hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false>), dim3(gB), dim3(64), 0, c.sb, itB, nB,
+                           (const u64*)c.fragB, (const char*)slabsB, kSlabB, (const BlockResult*)c.resB, c.opsB, c.tasks, X.tail_match_len,
+                           (i32*)nullptr, X.d_err, next, epoch);
+        NECAT_CHECK_LAUNCH(ctx, "k_traceback<B>");
+        NECAT_HIP(ctx, hipEventRecord(c.b2, c.sb));
+    }
+    c.in_flight = true;
+    return 0;
 }
 
 }  // namespace
@@ -522,60 +539,90 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
     ctx->tm.myers_word_updates = ctx->tm.myers_cells_bases = 0;
     ctx->tm.myersA_ms = 0; ctx->tm.myersA_launches = ctx->tm.myersA_blocks = 0;
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
-    const u32 batch = (u32)std::min<uint64_t>(n, 393216);      // slab pool <= ~130 GB of the 288 GB HBM
-    const u32 groups = (batch + 63) / 64 + 1;
+    // the cohorts share the band pool: <= 393 216 candidates in flight in total (~130 GB of the 288 GB HBM).
+    // Default: ONE cohort.  Two (NECAT_COHORTS=2) were measured slower on MI355X (E. coli 129 vs 111 ms,
+    // yeast-size 1.09 vs 1.08 s): both kernels already sit on their per-launch latency floor at half size.
+    constexpr int kMaxCohorts = 2;
+    const int kCohorts = g_cohorts;
+    const u32 cap = (u32)std::min<uint64_t>(((n + kCohorts - 1) / kCohorts + 63) & ~63ULL, 393216 / kCohorts);
+    const u32 groups = cap / 64 + 1;
     int rc;
     // candidate-wide arrays
     const uint64_t n_groups_max = n;
-    const size_t cand_bytes = n * sizeof(necat_candidate) + 2 * n * sizeof(necat_m4) + ((n + 63) & ~63ULL) + (n_groups_max + 1) * 8 + 256;
+    const size_t cand_bytes = n * sizeof(necat_candidate) + 2 * n * sizeof(necat_m4) + ((n + 63) & ~63ULL) + (n_groups_max + 1) * 8 + 512;
     if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_CAND], cand_bytes))) return rc;
     char* cb = (char*)ctx->scratch[SC_EXT_CAND].p;
     necat_candidate* d_cands = (necat_candidate*)cb; cb += n * sizeof(necat_candidate);
     necat_m4* d_m4 = (necat_m4*)cb; cb += n * sizeof(necat_m4);
     necat_m4* d_out = (necat_m4*)cb; cb += n * sizeof(necat_m4);
     u64* d_goff = (u64*)cb; cb += (n_groups_max + 1) * 8;
-    u32* d_outcnt = (u32*)cb; cb += 64;           // [0..1] output counter, [2..5] list counts, [6..9] stats
+    u32* d_outcnt = (u32*)cb; cb += 128;          // [0..1] output counter, [2..9] list counts of the cohorts, [16..19] stats
     int* d_err = (int*)cb; cb += 64;
     u8* d_ok = (u8*)cb;
     NECAT_HIP(ctx, hipMemcpyAsync(d_cands, cands, n * sizeof(necat_candidate), hipMemcpyHostToDevice, s));
-    NECAT_HIP(ctx, hipMemsetAsync(d_outcnt, 0, 128, s));
+    NECAT_HIP(ctx, hipMemsetAsync(d_outcnt, 0, 192, s));
     auto cleanup = [&]() {};
-    if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_TASKS], (size_t)batch * sizeof(ExtTask) + 64)) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], (size_t)batch * 4 * sizeof(BlockItem) + 64)) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_FRAG], (size_t)groups * 64 * (kFragWordsA + kFragWordsB) * 8)) ||
-        (rc = ensure_zeroed(ctx, ctx->scratch[SC_EXT_MAT], (size_t)groups * kSlabB + kSlabA, s)) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_OPS], (size_t)groups * 64 * (kOpsA + kOpsB))) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_RES], (size_t)groups * 64 * 2 * sizeof(BlockResult)))) { cleanup(); return rc; }
-    ExtBuffers B;
-    {
-        char* p = (char*)ctx->scratch[SC_EXT_TASKS].p;
-        B.tasks = (ExtTask*)p;
-        B.count = nullptr;        // set below
-        BlockItem* q = (BlockItem*)ctx->scratch[SC_EXT_LISTS].p;
-        B.itemsA[0] = q; B.itemsB[0] = q + batch; B.itemsA[1] = q + 2 * (size_t)batch; B.itemsB[1] = q + 3 * (size_t)batch;
-        B.fragA = (u64*)ctx->scratch[SC_EXT_FRAG].p; B.fragB = B.fragA + (size_t)groups * 64 * kFragWordsA;
-        B.slabs = (char*)ctx->scratch[SC_EXT_MAT].p;
-        B.opsA = (u8*)ctx->scratch[SC_EXT_OPS].p; B.opsB = B.opsA + (size_t)groups * 64 * kOpsA;
-        B.resA = (BlockResult*)ctx->scratch[SC_EXT_RES].p; B.resB = B.resA + (size_t)groups * 64;
+    const size_t slab_per = (size_t)groups * kSlabB + kSlabA;
+    if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_TASKS], kCohorts * ((size_t)cap * sizeof(ExtTask) + 64))) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], kCohorts * ((size_t)cap * 4 * sizeof(BlockItem) + 64))) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_FRAG], kCohorts * (size_t)groups * 64 * (kFragWordsA + kFragWordsB) * 8)) ||
+        (rc = ensure_zeroed(ctx, ctx->scratch[SC_EXT_MAT], kCohorts * slab_per, s)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_OPS], kCohorts * (size_t)groups * 64 * (kOpsA + kOpsB))) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_RES], kCohorts * (size_t)groups * 64 * 2 * sizeof(BlockResult)))) { cleanup(); return rc; }
+    NECAT_HIP(ctx, hipStreamSynchronize(s));        // candidates + zeroed counters are in place before the cohort streams start
+    Cohort co[kMaxCohorts];
+    hipStream_t cs[4] = {ctx->stream_a, ctx->stream_b, ctx->stream_c, ctx->stream_d};
+    for (int c = 0; c < kCohorts; ++c) {
+        Cohort& k = co[c];
+        k.tasks = (ExtTask*)((char*)ctx->scratch[SC_EXT_TASKS].p + c * ((size_t)cap * sizeof(ExtTask) + 64));
+        BlockItem* q = (BlockItem*)((char*)ctx->scratch[SC_EXT_LISTS].p + c * ((size_t)cap * 4 * sizeof(BlockItem) + 64));
+        k.itemsA[0] = q; k.itemsB[0] = q + cap; k.itemsA[1] = q + 2 * (size_t)cap; k.itemsB[1] = q + 3 * (size_t)cap;
+        k.fragA = (u64*)ctx->scratch[SC_EXT_FRAG].p + c * (size_t)groups * 64 * (kFragWordsA + kFragWordsB); k.fragB = k.fragA + (size_t)groups * 64 * kFragWordsA;
+        k.slabs = (char*)ctx->scratch[SC_EXT_MAT].p + c * slab_per;
+        k.opsA = (u8*)ctx->scratch[SC_EXT_OPS].p + c * (size_t)groups * 64 * (kOpsA + kOpsB); k.opsB = k.opsA + (size_t)groups * 64 * kOpsA;
+        k.resA = (BlockResult*)ctx->scratch[SC_EXT_RES].p + c * (size_t)groups * 64 * 2; k.resB = k.resA + (size_t)groups * 64;
+        k.count = d_outcnt + 2 + 4 * c;
+        k.sa = cs[2 * c]; k.sb = cs[2 * c + 1];
+        k.a0 = ctx->ev[4 + 6 * c]; k.a1 = ctx->ev[5 + 6 * c]; k.a2 = ctx->ev[6 + 6 * c];
+        k.b0 = ctx->ev[7 + 6 * c]; k.b1 = ctx->ev[8 + 6 * c]; k.b2 = ctx->ev[9 + 6 * c];
+        k.active = k.in_flight = k.a1_valid = false; k.nA = k.nB = 0; k.base = 0; k.n = 0; k.parity = 0;
     }
-    u32* d_count = d_outcnt + 2;
-    B.count = d_count;
-    B.stats = (unsigned long long*)(d_outcnt + 6);
-    for (uint64_t base = 0; base < n; base += batch) {
-        const u32 nb = (u32)std::min<uint64_t>(batch, n - base);
-        NECAT_HIP(ctx, hipMemsetAsync(B.count, 0, 16, s));
-        ExtLists L0; L0.count = B.count; L0.itemsA = B.itemsA[0]; L0.itemsB = B.itemsB[0];
-        hipLaunchKernelGGL(k_ext_init, dim3(grid_for(nb, 256)), dim3(256), 0, s, (const necat_candidate*)(d_cands + base), nb, (u32)base,
-                           read_start_id, ref_start_id, (const u64*)reads->seq_off, (const u64*)ref->seq_off, B.tasks, L0);
-        NECAT_CHECK_LAUNCH(ctx, "k_ext_init");
-        if ((rc = run_rounds(ctx, dref, drd, B, nb, opt->error, tail_match_len, d_err))) { cleanup(); return rc; }
-        hipLaunchKernelGGL(k_ext_result, dim3(grid_for(nb, 256)), dim3(256), 0, s, (const ExtTask*)B.tasks, nb, (const necat_candidate*)(d_cands + base),
-                           (u32)base, opt->align_size_cutoff, d_m4 - 0, d_ok);
-        NECAT_CHECK_LAUNCH(ctx, "k_ext_result");
+    ExtShared X;
+    X.d_cands = d_cands; X.d_m4 = d_m4; X.d_ok = d_ok; X.d_err = d_err; X.stats = (unsigned long long*)(d_outcnt + 16);
+    X.error = opt->error; X.tail_match_len = tail_match_len; X.min_align = opt->align_size_cutoff;
+    X.read_start_id = read_start_id; X.ref_start_id = ref_start_id; X.reads_off = reads->seq_off; X.ref_off = ref->seq_off;
+    uint64_t next_base = 0;
+    for (;;) {
+        bool any = false;
+        for (int c = 0; c < kCohorts; ++c) {
+            Cohort& k = co[c];
+            if (!k.active) {
+                if (next_base >= n) continue;
+                // start the next batch on this cohort
+                k.base = next_base; k.n = (u32)std::min<uint64_t>(cap, n - next_base); next_base += k.n;
+                k.parity = 0; k.active = true; k.in_flight = false; k.a1_valid = false;
+                NECAT_HIP(ctx, hipMemsetAsync(k.count, 0, 16, k.sa));
+                ExtLists L0; L0.count = k.count; L0.itemsA = k.itemsA[0]; L0.itemsB = k.itemsB[0];
+                hipLaunchKernelGGL(k_ext_init, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, d_cands + k.base, k.n, (u32)k.base,
+                                   read_start_id, ref_start_id, X.reads_off, X.ref_off, k.tasks, L0);
+                NECAT_CHECK_LAUNCH(ctx, "k_ext_init");
+            } else if ((rc = cohort_retire(ctx, k))) { cleanup(); return rc; }
+            any = true;
+            const int done = cohort_launch(ctx, dref, drd, k, X, kCohorts > 1 ? &co[c ^ 1] : nullptr);
+            if (done < 0) { cleanup(); return done; }
+            if (done == 1) {
+                hipLaunchKernelGGL(k_ext_result, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, (const ExtTask*)k.tasks, k.n, d_cands + k.base,
+                                   (u32)k.base, opt->align_size_cutoff, d_m4, d_ok);
+                NECAT_CHECK_LAUNCH(ctx, "k_ext_result");
+                NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
+                k.active = false;
+            }
+        }
+        if (!any) break;
     }
     {
         unsigned long long hs[2] = {0, 0};
-        NECAT_HIP(ctx, hipMemcpyAsync(hs, B.stats, 16, hipMemcpyDeviceToHost, s));
+        NECAT_HIP(ctx, hipMemcpyAsync(hs, X.stats, 16, hipMemcpyDeviceToHost, s));
         NECAT_HIP(ctx, hipStreamSynchronize(s));
         ctx->tm.myers_word_updates = hs[0]; ctx->tm.myers_cells_bases = hs[1];
     }

@@ -20,21 +20,16 @@ struct DevBuf {
     size_t cap = 0;
 };
 
-struct StageTimer {
-    hipEvent_t a = nullptr, b = nullptr;
-};
-
 }  // namespace necat
 
 struct necat_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream_a = nullptr, stream_b = nullptr;   // the two block shapes of a round run concurrently
-    hipStream_t stream_c = nullptr;                       // second DP kernel of a split list A
+    hipStream_t stream_a = nullptr, stream_b = nullptr;   // first cohort: the two block shapes of a round run concurrently
+    hipStream_t stream_c = nullptr, stream_d = nullptr;   // stream pair of the second cohort
     char err[1024] = {0};
     necat_timings tm;
-    hipEvent_t ev[12];
-    std::vector<void*> owned;          // scratch buffers released at destroy
+    hipEvent_t ev[20];
     necat::DevBuf scratch[24];         // grow-only arenas, indexed by purpose
     char devname[256] = {0};
     int num_cu = 0;

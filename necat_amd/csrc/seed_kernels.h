@@ -1,12 +1,14 @@
 // seed_kernels.h - __global__ shells around seed_core.h.
-//   k_seed_hits   : one wave per query read; lanes stride over the sampled k-mers of both strands and
-//                   sum their occurrence counts.  Random 8-byte gathers into kmer_stats (HBM/L2
-//                   latency bound; SURVEY.md §8d "seeding" row).  The totals bound every per-read
-//                   scratch size, so the second kernel never reallocates.
-//   k_seed_reads  : one lane per query read, replaying the reference's order-dependent seeding state
-//                   machine on a sparse per-lane block table (seed_core.h).  Reads are visited in
-//                   descending hit-count order so the lanes of a wave carry similar work.
-//   k_pack_cands  : compaction of the per-read outputs into one array of necat_candidate (global ids).
+//   k_seed_hits    : one wave per query read; lanes stride over the sampled k-mers of both strands and
+//                    sum their occurrence counts.  Random 8-byte gathers into kmer_stats (HBM/L2
+//                    latency bound; SURVEY.md 8d "seeding" row).  The totals bound every per-read
+//                    scratch size, so the later kernels never reallocate.
+//   k_seed_collect : one lane per (read, strand): collect_seeds on a sparse per-strand block table
+//                    (seed_core.h); uniform loop nest, lanes differ only in trip counts.
+//   k_seed_eval    : one WAVE per read: the order-dependent walk over the touched blocks, with the
+//                    O(n^2) DDF vote and the co-linear gather of every evaluation spread over the lanes.
+//                    Reads are visited in descending hit-count order.
+//   k_pack_cands   : compaction of the per-read outputs into one array of necat_candidate (global ids).
 #pragma once
 #include "seed_core.h"
 
