@@ -56,6 +56,105 @@ k_kmer_pass(DevVolume vol, int k, u32* __restrict__ cnt32, u64 n_offsets, u64* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Partitioned passes (k >= 11).  A k-mer's table entry is a random 4-byte cell of a 4^k table
+// (4.3 GB at k = 15): 2 x N random DRAM read-modify-writes.  Instead the k-mers are first split by
+// the top PB bits of their hash into NB = 2^PB buckets (a streaming pass: hash<<34|pos records written
+// bucket by bucket), and the count / scatter passes then walk one bucket at a time, all blocks of a
+// bucket on the same XCD (block b runs on XCD b % 8): the bucket's table slice (<= 1 MB) and its slot
+// range of the offset list stay resident in that XCD's 4 MB L2 while the bucket is processed.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPartThreads = 256;
+constexpr int kPartPosPerBlock = kPartThreads * 64;   // positions of the volume one block partitions
+constexpr int kBucketChunk = 512;                     // bucket elements one block of the bucket passes handles
+
+// MODE 0: global bucket histogram.  MODE 1: scatter hash<<34|pos records into the bucket regions.
+template <int MODE>
+__global__ void __launch_bounds__(kPartThreads)
+k_part_pass(DevVolume vol, int k, int shift, u32 nb, u32* __restrict__ bucket_cnt, u64* __restrict__ bucket_cursor, u64* __restrict__ part)
+{
+    extern __shared__ u32 lds[];          // [nb] histogram (+ [2*nb] 64-bit bases in MODE 1)
+    u32* hist = lds;
+    u64* base = reinterpret_cast<u64*>(lds + nb);
+    for (u32 i = threadIdx.x; i < nb; i += kPartThreads) hist[i] = 0;
+    __syncthreads();
+    const u64 p0 = (u64)blockIdx.x * kPartPosPerBlock;
+    const u64 p1 = (p0 + kPartPosPerBlock < vol.nbases) ? p0 + kPartPosPerBlock : vol.nbases;
+    for (int pass = 0; pass < (MODE == 0 ? 1 : 2); ++pass) {
+        for (u64 g0 = p0 + (u64)threadIdx.x * kPosPerThread; g0 < p1; g0 += (u64)kPartThreads * kPosPerThread) {
+            u64 r = seq_of_offset(vol.seq_off, vol.nseq, g0);
+            u64 rend = vol.seq_off[r + 1];
+#pragma unroll
+            for (int i = 0; i < kPosPerThread; ++i) {
+                const u64 p = g0 + i;
+                if (p >= p1) break;
+                while (p >= rend) { ++r; rend = vol.seq_off[r + 1]; }
+                if (p + (u64)k <= rend) {
+                    const u64 h = kmer_hash_at(vol.bases, (i64)p, k);
+                    const u32 b = (u32)(h >> shift);
+                    if (MODE == 0 || pass == 0) atomicAdd(&hist[b], 1u);
+                    else part[base[b] + atomicAdd(&hist[b], 1u)] = (h << kOffsetBits) | p;
+                }
+            }
+        }
+        __syncthreads();
+        if (MODE == 0) {
+            for (u32 i = threadIdx.x; i < nb; i += kPartThreads) if (hist[i]) atomicAdd(&bucket_cnt[i], hist[i]);
+        } else if (pass == 0) {
+            // reserve this block's slice of every bucket region, then rank locally
+            for (u32 i = threadIdx.x; i < nb; i += kPartThreads) {
+                const u32 c = hist[i];
+                base[i] = c ? atomicAdd(reinterpret_cast<unsigned long long*>(&bucket_cursor[i]), (unsigned long long)c) : 0ULL;
+                hist[i] = 0;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// exclusive scan of the bucket histogram (nb <= 4096) -> bucket_start[nb + 1]; cursors start there
+__global__ void __launch_bounds__(1024)
+k_bucket_scan(const u32* __restrict__ bucket_cnt, u32 nb, u64* __restrict__ bucket_start, u64* __restrict__ bucket_cursor)
+{
+    __shared__ u64 sh[1024];
+    const u32 per = (nb + 1023) / 1024;
+    const u32 lo = threadIdx.x * per, hi = (lo + per < nb) ? lo + per : nb;
+    u64 s = 0;
+    for (u32 i = lo; i < hi; ++i) s += bucket_cnt[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { u64 run = 0; for (int i = 0; i < 1024; ++i) { const u64 v = sh[i]; sh[i] = run; run += v; } bucket_start[nb] = run; }
+    __syncthreads();
+    u64 run = sh[threadIdx.x];
+    for (u32 i = lo; i < hi; ++i) { bucket_start[i] = run; bucket_cursor[i] = run; run += bucket_cnt[i]; }
+}
+
+// MODE 0: count (atomicAdd on the table).  MODE 1: scatter offsets through the end cursors.
+// Block b -> XCD x = b % 8, sequence number g = b / 8 on that XCD -> bucket (g / chunks) * 8 + x,
+// chunk g % chunks: consecutive blocks of one XCD work on the same bucket.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_bucket_pass(const u64* __restrict__ part, const u64* __restrict__ bucket_start, u32 nb, u32 chunks,
+              u32* __restrict__ cnt32, u64 n_offsets, u64* __restrict__ tmp_list)
+{
+    const u32 x = blockIdx.x & 7u, g = blockIdx.x >> 3;
+    const u32 bucket = (g / chunks) * 8u + x;
+    if (bucket >= nb) return;
+    const u64 lo = bucket_start[bucket], hi = bucket_start[bucket + 1];
+    for (u64 c = g % chunks; lo + c * kBucketChunk < hi; c += chunks) {
+        const u64 e0 = lo + c * kBucketChunk;
+        for (u64 e = e0 + threadIdx.x; e < e0 + kBucketChunk && e < hi; e += 256) {
+            const u64 rec = part[e];
+            const u64 h = rec >> kOffsetBits;
+            if (MODE == 0) atomicAdd(&cnt32[h], 1u);
+            else {
+                const u32 old = atomicSub(&cnt32[h], 1u);
+                if (old != 0u && (u64)old <= n_offsets) tmp_list[old - 1] = rec & kOffsetMask;
+            }
+        }
+    }
+}
+
 NECAT_D u32 filtered_count(u32 c, u32 max_occ) { return c > max_occ ? 0u : c; }   // lookup_table.c:44
 
 __global__ void __launch_bounds__(256)

@@ -199,8 +199,35 @@ int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, in
     NECAT_HIP(ctx, hipMemsetAsync(cnt32, 0, T * 4, s));
     const uint64_t nchunks = (ref->nbases + kPosPerThread - 1) / kPosPerThread;
     const unsigned pass_grid = grid_for(nchunks, 256, 1u << 16);
-    hipLaunchKernelGGL(k_kmer_pass<0>, dim3(pass_grid), dim3(256), 0, s, vol, kmer_size, cnt32, (u64)0, (u64*)nullptr);
-    NECAT_CHECK_LAUNCH(ctx, "k_kmer_pass<count>");
+    // partition parameters: buckets of <= 2^18 table entries (1 MB of counters), at most 4096 buckets
+    int PB = 2 * kmer_size - 18; if (PB > 12) PB = 12;
+    const bool partitioned = PB >= 4 && ref->nbases > 0;
+    const u32 NB = partitioned ? (1u << PB) : 0u;
+    const int pshift = 2 * kmer_size - PB;
+    u32* d_bcnt = nullptr; u64* d_bstart = nullptr; u64* d_bcur = nullptr; u64* d_part = nullptr;
+    u32 bchunks = 1;
+    if (partitioned) {
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_SMALL], (size_t)NB * 4 + (size_t)(NB + 1) * 8 * 2 + 64)) ||
+            (rc = buf_ensure(ctx, ctx->scratch[SC_PART], (ref->nbases + 1) * 8))) { necat_index_free(ctx, ix); return rc; }
+        char* sb = (char*)ctx->scratch[SC_SMALL].p;
+        d_bstart = (u64*)sb; sb += (size_t)(NB + 1) * 8; d_bcur = (u64*)sb; sb += (size_t)(NB + 1) * 8; d_bcnt = (u32*)sb;
+        d_part = (u64*)ctx->scratch[SC_PART].p;
+        const unsigned pgrid = (unsigned)((ref->nbases + kPartPosPerBlock - 1) / kPartPosPerBlock);
+        NECAT_HIP(ctx, hipMemsetAsync(d_bcnt, 0, (size_t)NB * 4, s));
+        hipLaunchKernelGGL(k_part_pass<0>, dim3(pgrid), dim3(kPartThreads), NB * 4, s, vol, kmer_size, pshift, NB, d_bcnt, (u64*)nullptr, (u64*)nullptr);
+        NECAT_CHECK_LAUNCH(ctx, "k_part_pass<hist>");
+        hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, s, (const u32*)d_bcnt, NB, d_bstart, d_bcur);
+        NECAT_CHECK_LAUNCH(ctx, "k_bucket_scan");
+        hipLaunchKernelGGL(k_part_pass<1>, dim3(pgrid), dim3(kPartThreads), NB * 4 + NB * 8, s, vol, kmer_size, pshift, NB, d_bcnt, d_bcur, d_part);
+        NECAT_CHECK_LAUNCH(ctx, "k_part_pass<scatter>");
+        const u64 avg = ref->nbases / NB + 1;
+        bchunks = (u32)std::max<u64>(1, (avg + kBucketChunk - 1) / kBucketChunk);
+        hipLaunchKernelGGL(k_bucket_pass<0>, dim3(NB * bchunks), dim3(256), 0, s, (const u64*)d_part, (const u64*)d_bstart, NB, bchunks, cnt32, (u64)0, (u64*)nullptr);
+        NECAT_CHECK_LAUNCH(ctx, "k_bucket_pass<count>");
+    } else {
+        hipLaunchKernelGGL(k_kmer_pass<0>, dim3(pass_grid), dim3(256), 0, s, vol, kmer_size, cnt32, (u64)0, (u64*)nullptr);
+        NECAT_CHECK_LAUNCH(ctx, "k_kmer_pass<count>");
+    }
     hipLaunchKernelGGL(k_tile_sums, dim3((unsigned)ntiles), dim3(256), 0, s, cnt32, T, (u32)max_occ, partial);
     NECAT_CHECK_LAUNCH(ctx, "k_tile_sums");
     hipLaunchKernelGGL(k_scan_partials, dim3(1), dim3(1024), 0, s, partial, ntiles);
@@ -216,8 +243,13 @@ int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, in
     if (n_off) {
         if ((rc = buf_ensure(ctx, ctx->scratch[SC_TMPLIST], n_off * 8))) { necat_index_free(ctx, ix); return rc; }
         u64* tmp = (u64*)ctx->scratch[SC_TMPLIST].p;
-        hipLaunchKernelGGL(k_kmer_pass<1>, dim3(pass_grid), dim3(256), 0, s, vol, kmer_size, cnt32, n_off, tmp);
-        NECAT_CHECK_LAUNCH(ctx, "k_kmer_pass<scatter>");
+        if (partitioned) {
+            hipLaunchKernelGGL(k_bucket_pass<1>, dim3(NB * bchunks), dim3(256), 0, s, (const u64*)d_part, (const u64*)d_bstart, NB, bchunks, cnt32, n_off, tmp);
+            NECAT_CHECK_LAUNCH(ctx, "k_bucket_pass<scatter>");
+        } else {
+            hipLaunchKernelGGL(k_kmer_pass<1>, dim3(pass_grid), dim3(256), 0, s, vol, kmer_size, cnt32, n_off, tmp);
+            NECAT_CHECK_LAUNCH(ctx, "k_kmer_pass<scatter>");
+        }
         hipLaunchKernelGGL(k_rank_buckets, dim3(grid_for(n_off, 256, 1u << 16)), dim3(256), 0, s, vol, kmer_size, (const u64*)ix->kmer_stats, (const u64*)tmp, n_off, ix->offset_list);
         NECAT_CHECK_LAUNCH(ctx, "k_rank_buckets");
     }
