@@ -91,6 +91,37 @@ k_ext_init(const necat_candidate* __restrict__ cands, u32 n, u32 cand_base, int 
     ext_append_block(t, i, go, L);
 }
 
+// ---- list B ordering: blocks of list B have any size up to 794 x 794; lanes (k_traceback, k_myers) or
+// lane groups (k_myers_coop) of one wave finish together only if their blocks are alike, so the list is
+// counting-sorted by target length (longest first) before the round's kernels run.
+constexpr int kSortBins = kMaxFragLen + 1;
+
+__global__ void __launch_bounds__(256)
+k_items_hist(const BlockItem* __restrict__ items, u32 n, u32* __restrict__ bins)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&bins[kMaxFragLen - items[i].tn], 1u);     // bin 0 = longest
+}
+
+__global__ void __launch_bounds__(1024)
+k_items_scan(u32* __restrict__ bins)          // exclusive scan of kSortBins counters, in place
+{
+    __shared__ u32 sh[1024];
+    const int t = threadIdx.x;
+    const u32 v = t < kSortBins ? bins[t] : 0u;
+    sh[t] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) { const u32 x = t >= o ? sh[t - o] : 0u; __syncthreads(); sh[t] += x; __syncthreads(); }
+    if (t < kSortBins) bins[t] = sh[t] - v;
+}
+
+__global__ void __launch_bounds__(256)
+k_items_scatter(const BlockItem* __restrict__ items, u32 n, u32* __restrict__ bins, BlockItem* __restrict__ out)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const BlockItem it = items[i]; out[atomicAdd(&bins[kMaxFragLen - it.tn], 1u)] = it; }
+}
+
 // frag layout per 64-item group g: word w of lane l at frag[(g * FW + w) * 64 + l];
 // words [0,NW) = ~lo planes, [NW,2NW) = ~hi planes, [2NW, 2NW+TW) = target 2-bit words
 template <int NW, int TW>

@@ -43,6 +43,7 @@ DevVolume dev_view(const necat_volume* v)
 u32 g_coop_threshold = 49152;
 int g_trace = 0;
 int g_antiphase = 1;
+int g_sort_b = 1;       // NECAT_SORT_B=0 disables the size sort of list B
 int g_cohorts = 1;
 int g_dbg = 0;     // NECAT_DBG: profiling-only variants of the DP kernel (1 = no band stores, 2 = no NW pass)
 
@@ -76,6 +77,7 @@ int necat_ctx_create(int device_id, necat_ctx** out)
     if (const char* e = getenv("NECAT_TRACE")) g_trace = atoi(e);
     if (const char* e = getenv("NECAT_DBG")) g_dbg = atoi(e);
     if (const char* e = getenv("NECAT_ANTIPHASE")) g_antiphase = atoi(e);
+    if (const char* e = getenv("NECAT_SORT_B")) g_sort_b = atoi(e);
     if (const char* e = getenv("NECAT_COHORTS")) g_cohorts = atoi(e) == 2 ? 2 : 1;
     memset(&ctx->tm, 0, sizeof ctx->tm);
     hipDeviceProp_t prop;
@@ -448,6 +450,7 @@ struct Cohort {
     // buffers
     ExtTask* tasks; u32* count; BlockItem* itemsA[2]; BlockItem* itemsB[2];   // count[2][2]: per list parity (nA, nB)
     u64* fragA; u64* fragB; char* slabs; u8* opsA; u8* opsB; BlockResult* resA; BlockResult* resB;
+    BlockItem* sortedB; u32* bins;          // list B of the round, sorted by size
     hipStream_t sa, sb;
     hipEvent_t a0, a1, a2, b0, b1, b2;
     // state
@@ -523,6 +526,14 @@ int cohort_launch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, C
         NECAT_HIP(ctx, hipEventRecord(c.a2, c.sa));
     }
     if (nB) {
+        if (nB >= 256 && g_sort_b) {
+            NECAT_HIP(ctx, hipMemsetAsync(c.bins, 0, 1024 * 4, c.sb));
+            hipLaunchKernelGGL(k_items_hist, dim3(grid_for(nB, 256)), dim3(256), 0, c.sb, itB, nB, c.bins);
+            hipLaunchKernelGGL(k_items_scan, dim3(1), dim3(1024), 0, c.sb, c.bins);
+            hipLaunchKernelGGL(k_items_scatter, dim3(grid_for(nB, 256)), dim3(256), 0, c.sb, itB, nB, c.bins, c.sortedB);
+            NECAT_CHECK_LAUNCH(ctx, "k_items_sort");
+            itB = c.sortedB;
+        }
         hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, c.sb,
                            drd, dref, itB, nB, c.fragB);
         NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
@@ -596,7 +607,7 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
     auto cleanup = [&]() {};
     const size_t slab_per = (size_t)groups * kSlabB + kSlabA;
     if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_TASKS], kCohorts * ((size_t)cap * sizeof(ExtTask) + 64))) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], kCohorts * ((size_t)cap * 4 * sizeof(BlockItem) + 64))) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], kCohorts * ((size_t)cap * 5 * sizeof(BlockItem) + 4096 + 64))) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_FRAG], kCohorts * (size_t)groups * 64 * (kFragWordsA + kFragWordsB) * 8)) ||
         (rc = ensure_zeroed(ctx, ctx->scratch[SC_EXT_MAT], kCohorts * slab_per, s)) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_OPS], kCohorts * (size_t)groups * 64 * (kOpsA + kOpsB))) ||
@@ -607,8 +618,9 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
     for (int c = 0; c < kCohorts; ++c) {
         Cohort& k = co[c];
         k.tasks = (ExtTask*)((char*)ctx->scratch[SC_EXT_TASKS].p + c * ((size_t)cap * sizeof(ExtTask) + 64));
-        BlockItem* q = (BlockItem*)((char*)ctx->scratch[SC_EXT_LISTS].p + c * ((size_t)cap * 4 * sizeof(BlockItem) + 64));
+        BlockItem* q = (BlockItem*)((char*)ctx->scratch[SC_EXT_LISTS].p + c * ((size_t)cap * 5 * sizeof(BlockItem) + 4096 + 64));
         k.itemsA[0] = q; k.itemsB[0] = q + cap; k.itemsA[1] = q + 2 * (size_t)cap; k.itemsB[1] = q + 3 * (size_t)cap;
+        k.sortedB = q + 4 * (size_t)cap; k.bins = (u32*)(q + 5 * (size_t)cap);
         k.fragA = (u64*)ctx->scratch[SC_EXT_FRAG].p + c * (size_t)groups * 64 * (kFragWordsA + kFragWordsB); k.fragB = k.fragA + (size_t)groups * 64 * kFragWordsA;
         k.slabs = (char*)ctx->scratch[SC_EXT_MAT].p + c * slab_per;
         k.opsA = (u8*)ctx->scratch[SC_EXT_OPS].p + c * (size_t)groups * 64 * (kOpsA + kOpsB); k.opsB = k.opsA + (size_t)groups * 64 * kOpsA;
