@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--scan-window", type=int, default=20)
     ap.add_argument("--job", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-genome", type=int, default=460_000, help="genome size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-genome", type=int, default=2_300_000, help="genome size of the bounded CPU-baseline sample")
     return ap.parse_args()
 
 
@@ -84,9 +84,10 @@ def cpu_baseline(args, opt_kw):
     oracle port - timed on this host's cores on a bounded sample of the same workload."""
     from necat_amd import synth
     from oracle import oracle_api as ora
-    cores = os.cpu_count() or 1
     tmp = tempfile.mkdtemp(prefix="necat_cpu_")
     rs = synth.simulate_reads(args.cpu_genome, args.coverage, seed=args.seed)
+    # the reference hands out reads in chunks of 500 (pm_worker.c:13,354): more threads than chunks stay idle
+    cores = max(1, min(os.cpu_count() or 1, (rs.nreads + 499) // 500))
     d = os.path.join(tmp, "vols")
     synth.write_volume_dir(d, rs)
     o = ora.options(**dict(opt_kw, job=args.job, binary_output=0, num_threads=cores))
@@ -104,9 +105,10 @@ def cpu_baseline(args, opt_kw):
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)
     return {"value": round(nrec / max(t_map, 1e-9), 1), "unit": "overlaps/s", "cores": cores, "kind": kind,
-            "sample": "%.2f Mb genome x %.0fx (%d reads, %d bp), same options; mapping phase %.2f s "
-                      "(index build excluded, as in the reference's own 'pairwise mapping' timer); whole process %.1f s"
-                      % (args.cpu_genome / 1e6, args.coverage, rs.nreads, rs.nbases, t_map, wall),
+            "sample": "%.2f Mb genome x %.0fx (%d reads, %d bp), same options, -t %d (= number of 500-read chunks, of %d host "
+                      "threads); mapping phase %.2f s (index build excluded, as in the reference's own 'pairwise mapping' "
+                      "timer); whole process %.1f s" % (args.cpu_genome / 1e6, args.coverage, rs.nreads, rs.nbases, cores,
+                                                        os.cpu_count() or 1, t_map, wall),
             "overlaps": nrec, "mapping_s": round(t_map, 3), "whole_process_s": round(wall, 2)}
 
 
