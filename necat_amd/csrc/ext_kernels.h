@@ -287,6 +287,8 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
 {
     constexpr int FW = 2 * NW + TW, BPW = 64 / G;
     const int lane = threadIdx.x, sub = lane / G, b = lane % G;
+    const bool filter = (epoch >> 30) == 0;      // bit 30 of the epoch argument switches the store filter off (A/B tests)
+    epoch &= 0x3fffffffu;
     const u64 item = (u64)item_base + (u64)blockIdx.x * BPW + sub;
     const bool valid = item < n;
     const u64 grp = item >> 6;
@@ -369,9 +371,16 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
             const u64 eq = ((nlo ^ ma) & (nhi ^ mb)) | pad;
             hout = advance_block(P, M, eq, hin, P, M);
             S += hout;
-            ulonglong2* p = rec + ((size_t)c * NW + b) * 128;
-            p[0] = make_ulonglong2(P, M);
-            p[1] = rec_tail(S, Sup, 0, nblk - 1, rec_tag(epoch, c));
+            // store the word only if it can hold a cell of an alignment of cost <= best that still reaches
+            // the end: the reference's own per-word band tests (edlib_ex.c:311-325) with k = best.  The
+            // traceback treats an unstored word as "outside the band" (tag mismatch).
+            const int rb = (b + 1) * 64 - 1;
+            const bool drop = S >= best + 64 || rb > best - S + 2 * 64 - 2 - tn2 + c + qn + 1 || rb < S - best - tn2 + qn + c;
+            if (!drop || !filter) {
+                ulonglong2* p = rec + ((size_t)c * NW + b) * 128;
+                p[0] = make_ulonglong2(P, M);
+                p[1] = rec_tail(S, Sup, 0, nblk - 1, rec_tag(epoch, c));
+            }
         }
     }
     if (is_last) {

@@ -38,11 +38,14 @@ DevVolume dev_view(const necat_volume* v)
     return d;
 }
 
-// rounds with at most this many blocks of a shape use the cooperative (latency-optimised) DP kernel;
-// NECAT_COOP_THRESHOLD overrides it (0 = never, huge = always) for tests and A/B measurements
-u32 g_coop_threshold = 49152;
+// Lists with at most this many blocks use the cooperative DP kernel (k_myers_coop), longer ones the
+// lane-per-block kernel (k_myers).  With the band store filter the cooperative kernel is the faster one at
+// every size measured on MI355X (200 k blocks: 2.66 vs 2.80 ms; 50 k: 0.77 vs 1.38 ms), so the default is
+// "always"; NECAT_COOP_THRESHOLD=0 selects the lane-per-block kernel (tests compare the two).
+u32 g_coop_threshold = 0xffffffffu;
 int g_trace = 0;
 int g_antiphase = 1;
+int g_coop_filter = 1;  // NECAT_COOP_FILTER=0: the cooperative kernel stores every word (A/B tests)
 int g_sort_b = 1;       // NECAT_SORT_B=0 disables the size sort of list B
 int g_cohorts = 1;
 int g_dbg = 0;     // NECAT_DBG: profiling-only variants of the DP kernel (1 = no band stores, 2 = no NW pass)
@@ -78,6 +81,7 @@ int necat_ctx_create(int device_id, necat_ctx** out)
     if (const char* e = getenv("NECAT_DBG")) g_dbg = atoi(e);
     if (const char* e = getenv("NECAT_ANTIPHASE")) g_antiphase = atoi(e);
     if (const char* e = getenv("NECAT_SORT_B")) g_sort_b = atoi(e);
+    if (const char* e = getenv("NECAT_COOP_FILTER")) g_coop_filter = atoi(e);
     if (const char* e = getenv("NECAT_COHORTS")) g_cohorts = atoi(e) == 2 ? 2 : 1;
     memset(&ctx->tm, 0, sizeof ctx->tm);
     hipDeviceProp_t prop;
@@ -512,7 +516,7 @@ int cohort_launch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, C
         NECAT_HIP(ctx, hipEventRecord(c.a0, c.sa));
         if (nA <= g_coop_threshold)
             hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((nA + 7) / 8), dim3(64), 0, c.sa, itA, nA,
-                               (const u64*)c.fragA, c.slabs, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
+                               (const u64*)c.fragA, c.slabs, kSlabA, X.error, c.resA, X.stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
         else
             hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(gA), dim3(64), 0, c.sa, itA, nA,
                                (const u64*)c.fragA, c.slabs, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
@@ -540,7 +544,7 @@ int cohort_launch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, C
         NECAT_HIP(ctx, hipEventRecord(c.b0, c.sb));
         if (nB <= g_coop_threshold)
             hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, c.sb, itB, nB,
-                               (const u64*)c.fragB, slabsB, kSlabB, X.error, c.resB, X.stats, epoch, 0u);
+                               (const u64*)c.fragB, slabsB, kSlabB, X.error, c.resB, X.stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
         else
             hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, c.sb, itB, nB,
                                (const u64*)c.fragB, slabsB, kSlabB, X.error, c.resB, X.stats, epoch, 0u);
@@ -761,9 +765,9 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[4], s));
             const bool coop = m <= g_coop_threshold;
             const u32 epoch = ++ctx->epoch & 0x3fffffu;
-            if (full && coop) hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch, 0u);
+            if (full && coop) hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
             else if (full) hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | ((u32)g_dbg << 28), 0u);
-            else if (coop) hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((m + 3) / 4), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch, 0u);
+            else if (coop) hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((m + 3) / 4), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
             else hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch, 0u);
             NECAT_CHECK_LAUNCH(ctx, "k_myers");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[5], s));
