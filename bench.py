@@ -143,7 +143,7 @@ def main():
     barrier_sync(dist, local)
     t0 = time.perf_counter()
     agg = dict(index_ms=0.0, seed_ms=0.0, extend_ms=0.0, myers_ms=0.0, traceback_ms=0.0, launches=0, blocks=0, words=0, bases=0, rounds=0,
-               a_ms=0.0, a_launches=0, a_blocks=0)
+               a_ms=0.0, a_launches=0, a_blocks=0, tb_a_ms=0.0)
     n_over = 0
     gbp = 0.0
     for _ in range(args.steps):
@@ -155,6 +155,7 @@ def main():
         agg["myers_ms"] += tm.myers_ms; agg["traceback_ms"] += tm.traceback_ms; agg["launches"] += tm.myers_launches
         agg["blocks"] += tm.myers_blocks; agg["words"] += tm.myers_word_updates; agg["bases"] += tm.myers_cells_bases
         agg["rounds"] += tm.rounds
+        agg["tb_a_ms"] += tm.tracebackA_ms
         agg["a_ms"] += tm.myersA_ms; agg["a_launches"] += tm.myersA_launches; agg["a_blocks"] += tm.myersA_blocks
     barrier_sync(dist, local)
     elapsed = time.perf_counter() - t0
@@ -165,11 +166,13 @@ def main():
             dist.destroy_process_group()
         return
     K = max(1, args.steps)
-    # ---- roofline of the dominant kernel: k_myers<8,16,512,true> (lane-per-block DP of full 512 x 512
-    # blocks; largest single entry of the rocprof summary, profiles/r01_kernel_stats.md).  Algorithmic
-    # HBM bytes of one block alignment = its two 2-bit fragments in (2 x 512 / 4 B) + one 16-byte result
-    # out (SURVEY.md 8d "extension" row restated per block); everything else the kernel moves is the
-    # traceback band it stores (reported as `traffic`, from the PMC passes kept in profiles/).
+    # ---- roofline of the dominant kernel: k_myers_coop<8,16,512,8>, the DP of the full 512 x 512 blocks
+    # (list A).  It and its traceback k_traceback<8,16,512,..> / the list-B pair are the four largest
+    # entries of the rocprof summary (profiles/r01_kernel_stats.md), the DP kernel being the one that
+    # does the arithmetic of the path.  Algorithmic HBM bytes of one block alignment = its two 2-bit
+    # fragments in (2 x 512 / 4 B) + one 16-byte result out (SURVEY.md 8d "extension" row restated per
+    # block); everything else the kernel moves is the traceback band it stores (`traffic`, from the PMC
+    # passes kept in profiles/).
     A_BYTES_PER_BLOCK = 2 * 512 / 4.0 + 16.0
     a_launches = max(1, agg["a_launches"])
     avg_launch_ms = agg["a_ms"] / a_launches
@@ -177,22 +180,33 @@ def main():
     achieved = alg_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
     word_rate = agg["words"] / (agg["myers_ms"] * 1e-3) if agg["myers_ms"] > 0 else 0.0
     traffic = None
+    tb_traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
-        k = pmc["void necat::k_myers<8, 16, 512, true>"]
-        # FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section)
-        traffic = (2.0 * k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]) * 1024.0
+
+        def pmc_bytes(prefix):
+            k = next(v for n, v in pmc.items() if n.startswith(prefix))
+            # FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section)
+            return (2.0 * k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]) * 1024.0
+        traffic = pmc_bytes("void necat::k_myers_coop<8, 16, 512, 8>")
+        tb_traffic = pmc_bytes("void necat::k_traceback<8, 16, 512, 1024, false>")
     except Exception:
         pass
-    roofline = {"bound": "hbm", "kernel": "k_myers<8,16,512,true>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    tb_avg_ms = agg["tb_a_ms"] / a_launches
+    roofline = {"bound": "hbm", "kernel": "k_myers_coop<8,16,512,8>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                "traffic_frac": round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_launch_ms > 0 else None,
                 "launches": int(agg["a_launches"]), "avg_launch_ms": round(avg_launch_ms, 4),
                 "algorithmic_bytes_per_launch": round(alg_per_launch, 1),
+                "traceback_kernel": {"kernel": "k_traceback<8,16,512,1024,false>", "avg_launch_ms": round(tb_avg_ms, 4), "traffic": tb_traffic,
+                                     "traffic_frac": round(tb_traffic / (tb_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tb_traffic and tb_avg_ms > 0 else None},
                 "all_dp_kernels": {"launches": int(agg["launches"]), "ms": round(agg["myers_ms"], 2), "blocks": int(agg["blocks"]),
                                    "word_updates_per_s": round(word_rate, 1),
                                    "valu_frac": round(word_rate * OPS_PER_WORD_UPDATE / VALU_LANE_OPS_PER_S, 4)},
-                "note": "integer DP: the HBM fraction is small by construction (SURVEY.md 8d); traffic (PMC, profiles/r01_pmc_hbm_traffic.json) "
-                        "is dominated by the stored traceback band; valu_frac = word updates x %d lane-ops / (256 CU x 128 lanes x 2.4 GHz)" % OPS_PER_WORD_UPDATE}
+                "note": "integer DP: the algorithmic HBM fraction is small by construction (SURVEY.md 8d); the measured traffic (PMC, "
+                        "profiles/r01_pmc_hbm_traffic.json) is the stored traceback band (32-byte records, only words that can lie on an "
+                        "alignment of <= the block's distance) - traffic_frac is that traffic over the launch time against the HBM peak; "
+                        "valu_frac = word updates x %d lane-ops / (256 CU x 128 lanes x 2.4 GHz)" % OPS_PER_WORD_UPDATE}
     out = {
         "metric": "overlaps/sec (all-vs-all, index build + seeding + banded Myers extension -> M4)",
         "value": round(tot_over / elapsed, 1), "unit": "overlaps/s",

@@ -31,7 +31,8 @@ class Timings(C.Structure):
                 ("myers_ms", C.c_double), ("traceback_ms", C.c_double), ("myers_launches", C.c_uint64),
                 ("myers_blocks", C.c_uint64), ("myers_word_updates", C.c_uint64),
                 ("myers_cells_bases", C.c_uint64), ("rounds", C.c_uint64),
-                ("myersA_ms", C.c_double), ("myersA_launches", C.c_uint64), ("myersA_blocks", C.c_uint64)]
+                ("myersA_ms", C.c_double), ("myersA_launches", C.c_uint64), ("myersA_blocks", C.c_uint64),
+                ("tracebackA_ms", C.c_double)]
 
 
 CANDIDATE_DTYPE = np.dtype([("qid", "<i4"), ("sid", "<i4"), ("qdir", "<i4"), ("sdir", "<i4"), ("score", "<i4"),

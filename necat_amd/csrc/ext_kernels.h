@@ -38,8 +38,8 @@ constexpr int kFragWordsB = 2 * kWordsB + kTWordsB;   // 51 u64 per item
 struct __attribute__((aligned(32))) BandRec { u64 P, M; i16 S, Sup; u8 first, last; u8 _pad[10]; };
 static_assert(sizeof(BandRec) == 32, "BandRec must be 32 bytes");
 // bytes of one 64-item slab
-constexpr size_t kSlabA = (size_t)kColsA * kWordsA * 64 * sizeof(BandRec);
-constexpr size_t kSlabB = (size_t)kColsB * kWordsB * 64 * sizeof(BandRec);
+constexpr size_t kSlabA = (size_t)((kColsA + 3) & ~3) * kWordsA * 64 * sizeof(BandRec);
+constexpr size_t kSlabB = (size_t)((kColsB + 3) & ~3) * kWordsB * 64 * sizeof(BandRec);
 
 struct BlockItem {       // one scheduled block alignment
     FragGeom g;
@@ -171,16 +171,29 @@ NECAT_D ulonglong2 rec_tail(int S, int Sup, int f, int l, u32 tag)
 }
 NECAT_D u32 rec_tag(u32 epoch, int c) { return (epoch << 10) | (u32)c; }
 
+// Position of record (column c, word b) of a lane inside its slab, in 16-byte units.  Four consecutive
+// columns of one (word, lane) share a 128-byte line: the traceback walks column by column at a fixed
+// word, so a line it pulls from HBM serves four steps, and the cooperative DP kernel - one lane per
+// word, one column per step - fills that line with four consecutive 32-byte stores of the same lane.
+// (With the records of the 64 lanes interleaved per column every traceback step was its own DRAM access:
+// 55 G random sector reads/s, the limit of k_traceback at 200 k concurrent blocks.)
+template <int NW>
+NECAT_D size_t rec_pos(int c, int b, int lane)
+{
+    return ((((size_t)(c >> 2) * NW + (size_t)b) * 64 + (size_t)lane) * 4 + (size_t)(c & 3)) * 2;
+}
+
 template <int NW>
 struct MatWriter {
-    ulonglong2* rec;   // slab + lane (16-byte units: record r of this lane at rec[r * 128 + {0,1}])
+    ulonglong2* rec;   // slab base (16-byte units)
+    int lane;
     u32 epoch;
     int dbg;
     NECAT_D bool skip_nw() const { return dbg == 2; }
     NECAT_D void store(int c, int b, u64 P, u64 M, int S, int Sup, int f, int l)
     {
         if (dbg == 1) return;
-        ulonglong2* p = rec + ((size_t)c * NW + b) * 128;
+        ulonglong2* p = rec + rec_pos<NW>(c, b, lane);
         p[0] = make_ulonglong2(P, M);
         p[1] = rec_tail(S, Sup, f, l, rec_tag(epoch, c));
     }
@@ -191,16 +204,17 @@ struct MatWriter {
 // the walk pays max(compute, latency) per column instead of their sum.
 template <int NW>
 struct MatReader {
-    const ulonglong2* rec;     // slab + lane
+    const ulonglong2* rec;     // slab base
+    int lane;
     u32 epoch;
     int nc, nb;                // coordinates of the prefetched record
     ulonglong2 na, nt;
     NECAT_D void init() { nc = -100; nb = -100; }
     NECAT_D void fetch(int c, int b, ulonglong2& a, ulonglong2& t) const
     {
-        if (c >= 0) { const ulonglong2* p = rec + ((size_t)c * NW + b) * 128; a = p[0]; t = p[1]; }
+        if (c >= 0) { const ulonglong2* p = rec + rec_pos<NW>(c, b, lane); a = p[0]; t = p[1]; }
     }
-    NECAT_D void cur(int c, int b, u64& P, u64& M) const { const ulonglong2 v = rec[((size_t)c * NW + b) * 128]; P = v.x; M = v.y; }
+    NECAT_D void cur(int c, int b, u64& P, u64& M) const { const ulonglong2 v = rec[rec_pos<NW>(c, b, lane)]; P = v.x; M = v.y; }
     NECAT_D LeftView left(int c, int b)
     {
         ulonglong2 a, t;
@@ -219,7 +233,7 @@ struct MatReader {
             // (edlib_ex.c:447-451); rare, one extra load
             v.up_in = false; v.Sup = 0;
             if (b > 0) {
-                const ulonglong2 u = rec[((size_t)c * NW + (b - 1)) * 128 + 1];
+                const ulonglong2 u = rec[rec_pos<NW>(c, b - 1, lane) + 1];
                 if ((u32)u.y == want) { v.up_in = true; v.Sup = (i16)(u.x & 0xffff); }
             }
         }
@@ -227,7 +241,7 @@ struct MatReader {
     }
 };
 
-NECAT_D ulonglong2* slab_records(char* slab, int lane) { return reinterpret_cast<ulonglong2*>(slab) + (size_t)lane * 2; }
+NECAT_D ulonglong2* slab_records(char* slab) { return reinterpret_cast<ulonglong2*>(slab); }
 
 // The hot kernel.  One wave = 64 block alignments in lock-step.  No LDS: the whole column state is
 // register resident (dp_core.h) and the only memory traffic is the coalesced band store.
@@ -254,7 +268,7 @@ k_myers(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag
     }
     TgtReader<NW> tg; tg.w = fr + (u64)2 * NW * 64; tg.cur = 0;
     MatWriter<NW> mw;
-    mw.rec = slab_records(slabs + (size_t)grp * slab_bytes, lane); mw.epoch = epoch & 0x0fffffffu; mw.dbg = (int)(epoch >> 28);
+    mw.rec = slab_records(slabs + (size_t)grp * slab_bytes); mw.lane = lane; mw.epoch = epoch & 0x0fffffffu; mw.dbg = (int)(epoch >> 28);
     const MyersResult r = myers_block<NW, FULL>(R, qn, tn, error, tg, mw);
     BlockResult br; br.dist = r.dist; br.endc = r.endc; br.err = r.err; br.words = r.words;
     results[item] = br;
@@ -309,7 +323,7 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
     if (valid) for (int w = b; w < TW; w += G) t_lds[sub][w] = (w * 32 < tn) ? fr[(u64)(2 * NW + w) * 64] : 0ULL;
     __syncthreads();
     const u64* tw = t_lds[sub];
-    ulonglong2* rec = slab_records(slabs + (size_t)grp * slab_bytes, il);
+    ulonglong2* rec = slab_records(slabs + (size_t)grp * slab_bytes);
 
     // wave-uniform trip count of the SHW wavefront
     int steps = valid ? tn + nblk - 1 : 0;
@@ -377,7 +391,7 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
             const int rb = (b + 1) * 64 - 1;
             const bool drop = S >= best + 64 || rb > best - S + 2 * 64 - 2 - tn2 + c + qn + 1 || rb < S - best - tn2 + qn + c;
             if (!drop || !filter) {
-                ulonglong2* p = rec + ((size_t)c * NW + b) * 128;
+                ulonglong2* p = rec + rec_pos<NW>(c, b, il);
                 p[0] = make_ulonglong2(P, M);
                 p[1] = rec_tail(S, Sup, 0, nblk - 1, rec_tag(epoch, c));
             }
@@ -447,7 +461,7 @@ k_traceback(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ 
     tail_init(ow.ts, (EXPORT || !done) ? kOcaMatCnt : tail_match_len);
     if (br.dist >= 0) {
         MatReader<NW> mr;
-        mr.rec = slab_records(const_cast<char*>(slabs) + (size_t)grp * slab_bytes, lane); mr.epoch = epoch; mr.init();
+        mr.rec = slab_records(const_cast<char*>(slabs) + (size_t)grp * slab_bytes); mr.lane = lane; mr.epoch = epoch; mr.init();
         traceback_block(it.qn, br.endc + 1, br.dist, mr, ow);
         if (ow.overflow) atomicExch(err_flag, 20);
     }

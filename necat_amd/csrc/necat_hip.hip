@@ -477,7 +477,7 @@ int cohort_retire(necat_ctx* ctx, Cohort& c)
     const double mA = c.nA ? ev_ms(c.a0, c.a1) : 0, tA = c.nA ? ev_ms(c.a1, c.a2) : 0, mB = c.nB ? ev_ms(c.b0, c.b1) : 0, tB = c.nB ? ev_ms(c.b1, c.b2) : 0;
     ctx->tm.myers_ms += mA + mB;
     ctx->tm.traceback_ms += tA + tB;
-    if (c.nA > g_coop_threshold) { ctx->tm.myersA_ms += mA; ctx->tm.myersA_launches += 1; ctx->tm.myersA_blocks += c.nA; }
+    if (c.nA) { ctx->tm.myersA_ms += mA; ctx->tm.tracebackA_ms += tA; ctx->tm.myersA_launches += 1; ctx->tm.myersA_blocks += c.nA; }
     if (g_trace) fprintf(stderr, "[necat] cohort@%lu round %3lu: nA=%7u nB=%7u myers %.3f + %.3f ms traceback %.3f + %.3f ms\n",
                          (unsigned long)c.base, (unsigned long)ctx->tm.rounds, c.nA, c.nB, mA, mB, tA, tB);
     ctx->tm.myers_launches += (c.nA ? 1 : 0) + (c.nB ? 1 : 0);
@@ -584,7 +584,7 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
     DevVolume dref = dev_view(ref), drd = dev_view(reads);
     ctx->tm.myers_ms = ctx->tm.traceback_ms = 0; ctx->tm.myers_launches = ctx->tm.myers_blocks = ctx->tm.rounds = 0;
     ctx->tm.myers_word_updates = ctx->tm.myers_cells_bases = 0;
-    ctx->tm.myersA_ms = 0; ctx->tm.myersA_launches = ctx->tm.myersA_blocks = 0;
+    ctx->tm.myersA_ms = ctx->tm.tracebackA_ms = 0; ctx->tm.myersA_launches = ctx->tm.myersA_blocks = 0;
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
     // the cohorts share the band pool: <= 393 216 candidates in flight in total (~130 GB of the 288 GB HBM).
     // Default: ONE cohort.  Two (NECAT_COHORTS=2) were measured slower on MI355X (E. coli 129 vs 111 ms,

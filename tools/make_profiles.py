@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 outputs (written under gpurun_out/ on the GPU box) into the tracked files under
+profiles/.
+
+  python tools/make_profiles.py stats  <dir> <out.md>  "<command>"   # --kernel-trace --stats run
+  python tools/make_profiles.py pmc    <dir_fetch> <dir_write> <out.json>   # two --pmc passes
+
+The PMC values are per-launch averages of FETCH_SIZE / WRITE_SIZE (KB as the counters report them; the
+gfx950 correction of MI355X_MICROARCH.md's HBM section is applied by the reader, bench.py).
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def find(d, suffix):
+    hits = sorted(glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True))
+    if not hits:
+        raise SystemExit("no *%s under %s" % (suffix, d))
+    return hits
+
+
+def stats(d, out, cmd):
+    rows = []
+    for f in find(d, "kernel_stats.csv"):
+        with open(f) as fh:
+            rows += list(csv.DictReader(fh))
+    agg = defaultdict(lambda: [0, 0])
+    for r in rows:
+        a = agg[r["Name"]]
+        a[0] += int(r["Calls"]); a[1] += int(float(r["TotalDurationNs"]))
+    total = sum(a[1] for a in agg.values()) or 1
+    with open(out, "w") as fh:
+        fh.write("# rocprofv3 --kernel-trace --stats\n\nCommand: `%s`\n\n| kernel | calls | total ns | avg ns | %% |\n|---|---|---|---|---|\n" % cmd)
+        for name, (calls, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            fh.write("| `%s` | %d | %d | %d | %.2f |\n" % (name, calls, ns, ns // max(1, calls), 100.0 * ns / total))
+
+
+def pmc(dirs, out):
+    res = defaultdict(dict)
+    for d in dirs:
+        acc = defaultdict(lambda: defaultdict(float))
+        disp = defaultdict(set)
+        for f in find(d, "counter_collection.csv"):
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    k = r["Kernel_Name"]
+                    acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                    disp[k].add(r["Dispatch_Id"])
+        for k, cs in acc.items():
+            n = max(1, len(disp[k]))
+            res[k]["launches"] = n
+            for c, v in cs.items():
+                res[k][c + "_KB_per_launch"] = v / n
+    with open(out, "w") as fh:
+        json.dump(dict(sorted(res.items())), fh, indent=1)
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "pmc":
+        pmc(sys.argv[2:-1], sys.argv[-1])
