@@ -43,6 +43,7 @@ DevVolume dev_view(const necat_volume* v)
 // every size measured on MI355X (200 k blocks: 2.66 vs 2.80 ms; 50 k: 0.77 vs 1.38 ms), so the default is
 // "always"; NECAT_COOP_THRESHOLD=0 selects the lane-per-block kernel (tests compare the two).
 u32 g_coop_threshold = 0xffffffffu;
+int g_seed_wave = 1;          // wave-per-strand seed collection (0: the lane-per-strand kernel)
 int g_trace = 0;
 int g_antiphase = 1;
 int g_coop_filter = 1;  // NECAT_COOP_FILTER=0: the cooperative kernel stores every word (A/B tests)
@@ -76,6 +77,7 @@ int necat_ctx_create(int device_id, necat_ctx** out)
     if (hipSetDevice(device_id) != hipSuccess) return NECAT_ERR_DEVICE;
     necat_ctx* ctx = new necat_ctx();
     ctx->device = device_id;
+    if (const char* e = getenv("NECAT_SEED_WAVE")) g_seed_wave = atoi(e);
     if (const char* e = getenv("NECAT_COOP_THRESHOLD")) g_coop_threshold = (u32)strtoul(e, nullptr, 10);
     if (const char* e = getenv("NECAT_TRACE")) g_trace = atoi(e);
     if (const char* e = getenv("NECAT_DBG")) g_dbg = atoi(e);
@@ -390,8 +392,12 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
         NECAT_HIP(ctx, hipMemcpyAsync(d_meta, meta.data(), n * sizeof(SeedMeta), hipMemcpyHostToDevice, s));
         NECAT_HIP(ctx, hipMemcpyAsync(d_order, order.data() + pos, (size_t)n * 4, hipMemcpyHostToDevice, s));
         NECAT_HIP(ctx, hipMemsetAsync(A.ht_key, 0xFF, ht_tot * 4, s));
-        hipLaunchKernelGGL(k_seed_collect, dim3(grid_for((u64)2 * n, 64)), dim3(64), 0, s, dref, drd, (const u64*)ix->kmer_stats, (const u64*)ix->offset_list,
-                           P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A, d_nblk, d_err);
+        if (g_seed_wave)
+            hipLaunchKernelGGL(k_seed_collect_wave, dim3(2 * n), dim3(64), 0, s, dref, drd, (const u64*)ix->kmer_stats, (const u64*)ix->offset_list,
+                               P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A, d_nblk, d_err);
+        else
+            hipLaunchKernelGGL(k_seed_collect, dim3(grid_for((u64)2 * n, 64)), dim3(64), 0, s, dref, drd, (const u64*)ix->kmer_stats, (const u64*)ix->offset_list,
+                               P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A, d_nblk, d_err);
         NECAT_CHECK_LAUNCH(ctx, "k_seed_collect");
         hipLaunchKernelGGL(k_seed_eval, dim3(n), dim3(64), 0, s, dref, drd, P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A,
                            (const i32*)d_nblk, d_ncand, d_err);

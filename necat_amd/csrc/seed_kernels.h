@@ -78,6 +78,161 @@ k_seed_collect(DevVolume ref, DevVolume reads, const u64* __restrict__ kmer_stat
     nblk_out[t] = nb < 0 ? 0 : nb;
 }
 
+// Seed collection, one WAVE per (read, strand).  collect_seeds (word_finder.c:107-139) is a strictly
+// ordered walk - sampled k-mers in read order, each k-mer's occurrences in ascending offset order - whose
+// order shows in the results (first-touch order of the blocks, the first 40 seeds of a block, the stale
+// pair score).  The walk is flattened into one seed sequence (k-mers of a group of 64 x their occurrence
+// lists, via a prefix sum in LDS) and taken 64 consecutive seeds at a time; inside such a chunk lane
+// order IS sequence order, so everything the sequential walk would have seen is a count over lower lanes:
+//   * a seed is dropped when the previous occurrence of its k-mer falls into the same block
+//     (the last_kmer_id test of fill_one_seed, word_finder.c:93; occurrence lists are ascending);
+//   * rank = earlier seeds of the chunk in the same block  -> its slot is score + rank, kept while < 40;
+//   * new blocks get pool slots in lane order (= first-touch order);
+//   * the stale score written with a block's last kept seed uses the neighbour's score + the neighbour's
+//     kept seeds from lower lanes.
+// One chunk costs a handful of dependent memory round trips for 64 seeds instead of 64 x that per lane.
+__global__ void __launch_bounds__(64)
+k_seed_collect_wave(DevVolume ref, DevVolume reads, const u64* __restrict__ kmer_stats, const u64* __restrict__ offset_list,
+                    SeedParams P, const u32* __restrict__ order, const SeedMeta* __restrict__ meta, u32 n,
+                    SeedArenas A, i32* __restrict__ nblk_out, int* __restrict__ err_flag)
+{
+    __shared__ u32 s_pre[65];
+    __shared__ u64 s_list[64];
+    const u32 t = blockIdx.x;
+    if (t >= 2 * n) return;
+    const u32 i = t >> 1;
+    const int strand = (int)(t & 1);
+    const int lane = threadIdx.x;
+    const u64 below = (1ULL << lane) - 1ULL;
+    SeedScratch S = seed_scratch(A, meta[i], strand);
+    const int read_id = (int)order[i];
+    const u64 q_goff = reads.seq_off[read_id];
+    const int L = (int)(reads.seq_off[read_id + 1] - q_goff);
+    u64 soff_max = ~0ULL;
+    if (P.pairwise) {
+        const int gid = read_id + P.read_start_id;
+        if (gid >= P.ref_start_id && gid < P.ref_start_id + (int)ref.nseq) soff_max = ref.seq_off[read_id];
+    }
+    const int k = P.k, z = P.z;
+    const double bsd = (double)P.block_size;
+    const u64 bs = (u64)P.block_size;
+    const int nk = L >= k ? (L - k) / z + 1 : 0;
+    int nblk = 0;
+    bool failed = false;
+    for (int kbase = 0; kbase < nk && !failed; kbase += 64) {
+        // ---- the group's k-mers: hash, occurrence list, occurrences below soff_max
+        const int kj = kbase + lane;
+        u32 cnt = 0; u64 lst = 0;
+        if (kj < nk) {
+            const int pos = kj * z;
+            const u64 x = strand == 0 ? load32_dir(reads.bases, (i64)q_goff + pos, +1, 0)
+                                      : load32_dir(reads.bases, (i64)q_goff + L - 1 - pos, -1, 1);
+            const u64 st = kmer_stats[rev2(x) >> (64 - 2 * k)];
+            cnt = (u32)(st >> kOffsetBits); lst = st & kOffsetMask;
+            if (cnt && soff_max != ~0ULL) {
+                u32 lo = 0, hi = cnt;
+                while (lo < hi) { const u32 mid = (lo + hi) >> 1; if (offset_list[lst + mid] < soff_max) lo = mid + 1; else hi = mid; }
+                cnt = lo;
+            }
+        }
+        u32 inc = cnt;
+        for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(inc, o); if (lane >= o) inc += v; }
+        __syncthreads();                       // the previous group's chunks are done with s_pre / s_list
+        s_pre[lane] = inc - cnt; s_list[lane] = lst;
+        if (lane == 63) s_pre[64] = inc;
+        __syncthreads();
+        const u32 T = s_pre[64];
+        for (u32 c0 = 0; c0 < T; c0 += 64) {
+            const u32 sq = c0 + (u32)lane;
+            const bool valid = sq < T;
+            // k-mer of this seed: the last j with s_pre[j] <= sq
+            int j = 0;
+            for (int step = 32; step > 0; step >>= 1) if (s_pre[j + step] <= sq) j += step;
+            const u32 kk = sq - s_pre[j];
+            const u64 lbase = s_list[j];
+            i32 blk = -2; int boff = 0; bool cand = false;
+            if (valid) {
+                const u64 off = offset_list[lbase + kk];
+                u64 q = (u64)((double)off / bsd);
+                if (q * bs > off) --q; else if ((q + 1) * bs <= off) ++q;
+                blk = (i32)q; boff = (int)(off - q * bs);
+                cand = true;
+                if (kk > 0) {
+                    const u64 offp = offset_list[lbase + kk - 1];
+                    cand = !(offp >= q * bs);                 // offp < off: same block iff offp >= block start
+                }
+            }
+            const i32 kmer_id = kbase + j + 1;
+            // ---- counts over the lower / higher lanes of the chunk
+            const u64 cmask = __ballot(cand);
+            int rank = 0, first = lane, later = 0, cprev = 0;
+#pragma unroll
+            for (int l = 0; l < 64; ++l) {
+                if (!((cmask >> l) & 1ULL)) continue;                          // wave-uniform
+                const i32 bl = __builtin_amdgcn_readlane(blk, l);
+                const bool same = bl == blk;
+                if (l < lane) { rank += same; cprev += (bl == blk - 1); if (same && l < first) first = l; }
+                else if (l > lane) later += same;
+            }
+            // ---- block lookup / creation by the first seed of every block
+            const bool is_first = cand && rank == 0;
+            // (keys are inserted with L2 atomics: probe with agent-scope loads so a stale L1 line is never read)
+            auto probe = [&](i32 key, u32& hh) -> i32 {
+                hh = ht_hash(key, S.ht_mask);
+                for (;;) {
+                    const i32 kx = __hip_atomic_load(&S.ht_key[hh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (kx == key) return S.ht_val[hh];
+                    if (kx == -1) return -1;
+                    hh = (hh + 1) & S.ht_mask;
+                }
+            };
+            i32 idx = -1; u32 h = 0;
+            if (is_first) idx = probe(blk, h);
+            const bool create = is_first && idx < 0;
+            const u64 crm = __ballot(create);
+            const int ncreate = popc64(crm);
+            if ((u32)(nblk + ncreate) > S.pool_cap) { failed = true; break; }
+            if (create) {
+                idx = nblk + popc64(crm & below);
+                for (;;) {           // the keys of one chunk's creators are distinct: a lost race just moves on
+                    const i32 old = atomicCAS(&S.ht_key[h], -1, blk);
+                    if (old == -1) break;
+                    h = (h + 1) & S.ht_mask;
+                }
+                S.ht_val[h] = idx;
+                SBlock* sb = S.pool + idx;
+                sb->score = 0; sb->last_kmer_id = -1; sb->block_id = blk; sb->stale = 0; sb->slot = (i32)h;
+            }
+            nblk += ncreate;
+            idx = __shfl(idx, first);
+            __syncthreads();                   // new blocks are initialised before anyone reads a score
+            int s0 = 0;
+            if (cand) s0 = S.pool[idx].score;
+            const bool acc = cand && s0 + rank < kBlkSeeds;
+            const bool is_last = acc && (later == 0 || s0 + rank + 1 >= kBlkSeeds);
+            int sprev = 0;
+            if (is_last) {
+                u32 hp; const i32 ip = blk > 0 ? probe(blk - 1, hp) : -1;
+                const int s0p = ip >= 0 ? (int)S.pool[ip].score : 0;
+                int room = kBlkSeeds - s0p; if (room < 0) room = 0;
+                sprev = s0p + (cprev < room ? cprev : room);
+            }
+            __syncthreads();                   // every score of the chunk is read before any is written
+            if (acc) {
+                SBlock* sb = S.pool + idx;
+                sb->blk_offset[s0 + rank] = (short)boff;
+                sb->kmer_id[s0 + rank] = kmer_id;
+                if (is_last) { sb->score = (short)(s0 + rank + 1); sb->last_kmer_id = kmer_id; sb->stale = s0 + rank + 1 + sprev; }
+            }
+            __syncthreads();
+        }
+    }
+    if (lane == 0) {
+        if (failed) atomicExch(err_flag, 1);
+        nblk_out[t] = failed ? 0 : nblk;
+    }
+}
+
 struct LdsAdder { int* s; NECAT_D void operator()(int j) { atomicAdd(&s[j], 1); } };
 
 // Block evaluation: one WAVE per read.  The touched blocks are still visited strictly in first-touch
