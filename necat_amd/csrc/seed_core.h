@@ -365,9 +365,9 @@ NECAT_HD bool gather_zeroes_block(int relevant, int score) { return 1.0 * releva
 
 // stage E: sort the chain seeds, chain them, choose and emit the candidate (word_finder.c:309-358)
 NECAT_HD int finish_candidate(SeedScratch& S, int ncs, int seed_score, const AnchorGeom& g, const SeedParams& P,
-                              int qid, int qdir, int qsize, int* n_out)
+                              int qid, int qdir, int qsize, int* n_out, bool sorted = false)
 {
-    heap_sort_u64(S.cs, ncs);   // ChainSeedLT: (soff, qoff) ascending
+    if (!sorted) heap_sort_u64(S.cs, ncs);   // ChainSeedLT: (soff, qoff) ascending
     DevCand proto;
     proto.qid = qid; proto.sid = (i32)g.seed_tid; proto.qdir = qdir; proto.score = 0;
     proto.qbeg = proto.qend = 0; proto.qsize = qsize; proto.sbeg = proto.send = 0; proto.ssize = (i32)g.seed_tsize;

@@ -233,6 +233,8 @@ k_seed_collect_wave(DevVolume ref, DevVolume reads, const u64* __restrict__ kmer
     }
 }
 
+constexpr int kLdsChain = 512;
+
 struct LdsAdder { int* s; NECAT_D void operator()(int j) { atomicAdd(&s[j], 1); } };
 
 // Block evaluation: one WAVE per read.  The touched blocks are still visited strictly in first-touch
@@ -249,6 +251,10 @@ k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict_
     __shared__ int s_ctl[4];
     __shared__ u64 s_blk_start;
     __shared__ AnchorGeom s_g;
+    // chain scratch of the common case (<= kLdsChain co-linear seeds) lives in LDS: the sort is a parallel
+    // rank sort and lane 0's chain DP walks LDS instead of global memory
+    __shared__ u64 l_cs[kLdsChain], l_u[kLdsChain];
+    __shared__ i32 l_f[kLdsChain], l_p[kLdsChain], l_t[kLdsChain], l_v[kLdsChain];
     const u32 i = blockIdx.x;
     if (i >= n) return;
     const int lane = threadIdx.x;
@@ -262,8 +268,22 @@ k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict_
     for (int strand = 0; strand < 2 && !failed; ++strand) {
         SeedScratch S = seed_scratch(A, m, strand);
         const int nblk = P.debug_phase == 1 ? 0 : nblk_in[2 * (u64)i + strand];
-        for (int bi = 0; bi < nblk; ++bi) {
+        // Blocks are visited in first-touch order, but only those passing the score test are evaluated and
+        // a block's score only ever drops (accepted candidates zero it) while its stale score is fixed:
+        // 64 blocks are tested at once, the survivors re-tested when their turn comes.
+        u64 pending = 0; int pbase = -64;
+        for (;;) {
             __syncthreads();
+            if (!pending) {
+                pbase += 64;
+                if (pbase >= nblk) break;
+                bool pass = false;
+                if (pbase + lane < nblk) { const SBlock* q = S.pool + pbase + lane; pass = q->score >= cut && q->stale >= 2 * cut; }
+                pending = __ballot(pass);
+                continue;
+            }
+            const int bi = pbase + ctz64(pending);
+            pending &= pending - 1;
             SBlock* sb = S.pool + bi;
             if (!(sb->score >= cut && sb->stale >= 2 * cut)) continue;         // wave-uniform
             // A: seed lists (lane 0)
@@ -304,17 +324,42 @@ k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict_
                     const u64 mask = __ballot(acc);
                     const int rel = popc64(mask);
                     if ((u32)(ncs + rel) >= S.cs_cap) { overflow = true; break; }
-                    if (acc) S.cs[ncs + popc64(mask & below)] = key;
+                    if (acc) { const int w = ncs + popc64(mask & below); if (w < kLdsChain) l_cs[w] = key; else S.cs[w] = key; }
                     ncs += rel; seed_score += rel;
                     if (lane == 0 && b != g.seed_bid && gather_zeroes_block(rel, nsc)) sbi->score = 0;
                 }
                 if (overflow) break;
-                if (pass == 0) { if (lane == 0) S.cs[ncs] = ((u64)g.stoff << 32) | (u64)(u32)g.seed_qoff; ++ncs; }
+                if (pass == 0) {
+                    if (lane == 0) { const u64 key = ((u64)g.stoff << 32) | (u64)(u32)g.seed_qoff; if (ncs < kLdsChain) l_cs[ncs] = key; else S.cs[ncs] = key; }
+                    ++ncs;
+                }
             }
             __syncthreads();
-            // E: chain + choose + emit (lane 0)
+            // E: sort (all lanes when the seeds fit LDS), then chain + choose + emit (lane 0)
+            const bool in_lds = !overflow && ncs <= kLdsChain;
+            if (in_lds) {
+                // rank sort; equal keys (identical seeds) keep their index order
+                for (int a = lane; a < ncs; a += 64) {
+                    const u64 ka = l_cs[a];
+                    int rk = 0;
+                    for (int b = 0; b < ncs; ++b) { const u64 kb = l_cs[b]; rk += (kb < ka) || (kb == ka && b < a); }
+                    l_u[rk] = ka;
+                }
+                __syncthreads();
+                for (int a = lane; a < ncs; a += 64) l_cs[a] = l_u[a];
+            } else if (!overflow) {
+                const int lim = ncs < kLdsChain ? ncs : kLdsChain;
+                for (int a = lane; a < lim; a += 64) S.cs[a] = l_cs[a];
+            }
+            __syncthreads();
             if (lane == 0) {
-                int rc = overflow ? kSeedErrCapacity : finish_candidate(S, ncs, seed_score, g, P, r, strand, L, &n_out);
+                int rc;
+                if (overflow) rc = kSeedErrCapacity;
+                else if (in_lds) {
+                    SeedScratch SL = S;
+                    SL.cs = l_cs; SL.u = l_u; SL.f = l_f; SL.p = l_p; SL.t = l_t; SL.v = l_v;
+                    rc = finish_candidate(SL, ncs, seed_score, g, P, r, strand, L, &n_out, true);
+                } else rc = finish_candidate(S, ncs, seed_score, g, P, r, strand, L, &n_out);
                 s_ctl[2] = rc < 0 ? 1 : 0;
             }
             __syncthreads();
