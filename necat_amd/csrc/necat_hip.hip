@@ -2,6 +2,9 @@
 // kernels.  Written for MI355X only (wave64, 256 CUs, 288 GB HBM3E): buffers are sized for HBM
 // residency of whole volumes, work lists and the traceback band of 10^5 concurrent alignments.
 #include <algorithm>
+#include <chrono>
+#include <mutex>
+#include <unordered_map>
 #include <time.h>
 #include <numeric>
 
@@ -43,6 +46,7 @@ DevVolume dev_view(const necat_volume* v)
 // every size measured on MI355X (200 k blocks: 2.66 vs 2.80 ms; 50 k: 0.77 vs 1.38 ms), so the default is
 // "always"; NECAT_COOP_THRESHOLD=0 selects the lane-per-block kernel (tests compare the two).
 u32 g_coop_threshold = 0xffffffffu;
+unsigned long long g_seed_budget = 48ULL << 20;   // seeding scratch budget per chunk, in k-mer hits
 int g_seed_wave = 1;          // wave-per-strand seed collection (0: the lane-per-strand kernel)
 int g_trace = 0;
 int g_antiphase = 1;
@@ -78,6 +82,8 @@ int necat_ctx_create(int device_id, necat_ctx** out)
     necat_ctx* ctx = new necat_ctx();
     ctx->device = device_id;
     if (const char* e = getenv("NECAT_SEED_WAVE")) g_seed_wave = atoi(e);
+    g_seed_budget = 48ULL << 20;
+    if (const char* e = getenv("NECAT_SEED_BUDGET")) g_seed_budget = strtoull(e, nullptr, 10);
     if (const char* e = getenv("NECAT_COOP_THRESHOLD")) g_coop_threshold = (u32)strtoul(e, nullptr, 10);
     if (const char* e = getenv("NECAT_TRACE")) g_trace = atoi(e);
     if (const char* e = getenv("NECAT_DBG")) g_dbg = atoi(e);
@@ -127,7 +133,54 @@ int necat_get_timings(const necat_ctx* ctx, necat_timings* t)
     return NECAT_OK;
 }
 
-void necat_free(void* p) { free(p); }
+// Result blocks handed to the caller.  Big ones are pinned host memory (the device copies straight into
+// them) and are recycled: necat_free() parks up to kPoolBlocks of them for the next call instead of
+// returning 20 MB of freshly faulted pages to the OS every pass.
+namespace {
+struct ResultPool {
+    std::mutex mu;
+    std::unordered_map<void*, size_t> live;              // pinned blocks currently owned by callers
+    std::vector<std::pair<void*, size_t>> parked;         // never released at exit: the HIP runtime may be gone by then
+};
+ResultPool g_results;
+constexpr size_t kPinnedMin = 256 << 10, kPoolBlocks = 6;
+
+void* result_alloc(size_t bytes)
+{
+    if (bytes < kPinnedMin) return malloc(bytes ? bytes : 1);
+    std::lock_guard<std::mutex> lk(g_results.mu);
+    int best = -1;
+    for (int i = 0; i < (int)g_results.parked.size(); ++i) {
+        const size_t sz = g_results.parked[i].second;
+        if (sz >= bytes && sz <= 2 * bytes + (1 << 20) && (best < 0 || sz < g_results.parked[best].second)) best = i;
+    }
+    void* p = nullptr; size_t sz = 0;
+    if (best >= 0) { p = g_results.parked[best].first; sz = g_results.parked[best].second; g_results.parked.erase(g_results.parked.begin() + best); }
+    else {
+        sz = (bytes + (bytes >> 3) + 4095) & ~(size_t)4095;          // a little slack so the next pass fits too
+        if (hipHostMalloc(&p, sz, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return malloc(bytes); }
+    }
+    g_results.live[p] = sz;
+    return p;
+}
+}  // namespace
+
+void necat_free(void* p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_results.mu);
+        auto it = g_results.live.find(p);
+        if (it != g_results.live.end()) {
+            const size_t sz = it->second;
+            g_results.live.erase(it);
+            if (g_results.parked.size() < kPoolBlocks) g_results.parked.emplace_back(p, sz);
+            else (void)hipHostFree(p);
+            return;
+        }
+    }
+    free(p);
+}
 
 // ------------------------------------------------------------------------------------------ volumes
 
@@ -319,6 +372,13 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
     DevVolume dref = dev_view(ref), drd = dev_view(reads);
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
     int rc;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto tick = [&](const char* what) {
+        if (!(g_trace & 2)) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[necat] seeding %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     // ---- pass 1: hit counts per read-strand
     if ((rc = buf_ensure(ctx, ctx->scratch[SC_MISC], (size_t)nreads * 8 + 64))) return rc;
     u32* d_hits = (u32*)ctx->scratch[SC_MISC].p;
@@ -328,12 +388,13 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
     std::vector<u32> hits((size_t)nreads * 2);
     NECAT_HIP(ctx, hipMemcpyAsync(hits.data(), d_hits, (size_t)nreads * 8, hipMemcpyDeviceToHost, s));
     NECAT_HIP(ctx, hipStreamSynchronize(s));
+    tick("hits kernel + copy");
     // ---- plan: reads in descending work order, chunks bounded by a scratch budget
     std::vector<u32> order(nreads);
     std::iota(order.begin(), order.end(), 0u);
     auto work = [&](u32 r) { return (u64)std::max(hits[2 * (size_t)r], hits[2 * (size_t)r + 1]); };
     std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return work(a) > work(b); });
-    const u64 budget_hits = 48ULL << 20;     // ~48 M pool blocks (~13 GB of SBlocks) per chunk
+    const u64 budget_hits = g_seed_budget;   // default ~48 M pool blocks (~13 GB of SBlocks) per chunk
     SeedParams P;
     P.k = opt->kmer_size; P.z = opt->scan_window; P.block_size = opt->block_size; P.s_cutoff = opt->block_score_cutoff;
     P.align_cutoff = opt->align_size_cutoff; P.num_candidates = opt->num_candidates; P.job = opt->job; P.pairwise = pairwise;
@@ -374,6 +435,7 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
             (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_POOL], pool_tot * sizeof(SBlock))) ||
             (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_CHAIN], chain_tot * (8 + 16 + 8 + sizeof(DevCand)))) ||
             (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_OUT], out_tot * sizeof(DevCand)))) { (void)hipFree(d_err); return rc; }
+        tick("plan + buffers");
         char* mb = (char*)ctx->scratch[SC_SEED_META].p;
         SeedMeta* d_meta = (SeedMeta*)mb; mb += n * sizeof(SeedMeta);
         u64* d_final = (u64*)mb; mb += (size_t)n * 8;
@@ -408,6 +470,36 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
         NECAT_HIP(ctx, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, s));
         NECAT_HIP(ctx, hipStreamSynchronize(s));
         if (herr) { (void)hipFree(d_err); return set_err(ctx, NECAT_ERR_CAPACITY, "seeding scratch overflow (code %d)", herr); }
+        tick("collect + eval kernels");
+        if (pos == 0 && hi == nreads) {
+            // the usual case, one chunk: pack on the device straight into ascending read order and copy
+            // into the (pinned) result block
+            std::vector<u64> by_read((size_t)nreads + 1, 0), foff(n);
+            for (u32 i = 0; i < n; ++i) by_read[order[i] + 1] = (u64)nc[i];
+            for (u32 r = 0; r < nreads; ++r) by_read[r + 1] += by_read[r];
+            for (u32 i = 0; i < n; ++i) foff[i] = by_read[order[i]];
+            const u64 tot = by_read[nreads];
+            necat_candidate* res = (necat_candidate*)result_alloc(std::max<u64>(1, tot) * sizeof(necat_candidate));
+            if (!res) { (void)hipFree(d_err); return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
+            if (tot) {
+                if ((rc = buf_ensure(ctx, ctx->scratch[SC_SEED_FINAL], tot * sizeof(necat_candidate)))) { (void)hipFree(d_err); necat_free(res); return rc; }
+                necat_candidate* d_dst = (necat_candidate*)ctx->scratch[SC_SEED_FINAL].p;
+                hipError_t e1 = hipMemcpyAsync(d_final, foff.data(), (size_t)n * 8, hipMemcpyHostToDevice, s);
+                hipLaunchKernelGGL(k_pack_cands, dim3(grid_for((u64)n * 64, 256)), dim3(256), 0, s, (const DevCand*)A.out, (const SeedMeta*)d_meta,
+                                   (const i32*)d_ncand, (const u64*)d_final, n, read_start_id, ref_start_id, d_dst);
+                hipError_t e2 = hipGetLastError();
+                hipError_t e3 = hipMemcpyAsync(res, d_dst, tot * sizeof(necat_candidate), hipMemcpyDeviceToHost, s);
+                hipError_t e4 = hipEventRecord(ctx->ev[1], s);
+                hipError_t e5 = hipStreamSynchronize(s);
+                for (hipError_t e : {e1, e2, e3, e4, e5})
+                    if (e != hipSuccess) { (void)hipFree(d_err); necat_free(res); return set_err(ctx, NECAT_ERR_DEVICE, "seeding result copy: %s", hipGetErrorString(e)); }
+            } else { NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s)); NECAT_HIP(ctx, hipStreamSynchronize(s)); }
+            (void)hipFree(d_err);
+            ctx->tm.seed_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
+            tick("pack + copy to host");
+            *out = res; *n_out = tot;
+            return NECAT_OK;
+        }
         std::vector<u64> foff(n + 1, 0);
         for (u32 i = 0; i < n; ++i) foff[i + 1] = foff[i] + (u64)nc[i];
         const u64 tot = foff[n];
@@ -424,8 +516,12 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
             NECAT_HIP(ctx, hipStreamSynchronize(s));
         }
         for (u32 i = 0; i < n; ++i) { ncands_by_order[pos + i] = nc[i]; packed_off[pos + i] = base + foff[i]; }
+        tick("pack + copy to host");
         pos = hi;
     }
+#ifdef NECAT_SEED_PROF
+    { unsigned long long hp[16]; (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_seed_prof), sizeof(hp)); fprintf(stderr, "[seedprof]"); for (int q = 0; q < 12; ++q) fprintf(stderr, " %llu", hp[q]); fprintf(stderr, "\n"); }
+#endif
     (void)hipFree(d_err);
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s));
     NECAT_HIP(ctx, hipStreamSynchronize(s));
@@ -434,7 +530,7 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
     std::vector<u32> inv(nreads);
     for (u32 i = 0; i < nreads; ++i) inv[order[i]] = i;
     u64 total = packed_all.size();
-    necat_candidate* res = (necat_candidate*)malloc(std::max<u64>(1, total) * sizeof(necat_candidate));
+    necat_candidate* res = (necat_candidate*)result_alloc(std::max<u64>(1, total) * sizeof(necat_candidate));
     if (!res) return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed");
     u64 w = 0;
     for (u32 r = 0; r < nreads; ++r) {
@@ -443,6 +539,7 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
         if (c) memcpy(res + w, packed_all.data() + packed_off[i], (size_t)c * sizeof(necat_candidate));
         w += (u64)c;
     }
+    tick("assemble in read order");
     *out = res; *n_out = total;
     return NECAT_OK;
 }
@@ -484,7 +581,7 @@ int cohort_retire(necat_ctx* ctx, Cohort& c)
     ctx->tm.myers_ms += mA + mB;
     ctx->tm.traceback_ms += tA + tB;
     if (c.nA) { ctx->tm.myersA_ms += mA; ctx->tm.tracebackA_ms += tA; ctx->tm.myersA_launches += 1; ctx->tm.myersA_blocks += c.nA; }
-    if (g_trace) fprintf(stderr, "[necat] cohort@%lu round %3lu: nA=%7u nB=%7u myers %.3f + %.3f ms traceback %.3f + %.3f ms\n",
+    if (g_trace & 1) fprintf(stderr, "[necat] cohort@%lu round %3lu: nA=%7u nB=%7u myers %.3f + %.3f ms traceback %.3f + %.3f ms\n",
                          (unsigned long)c.base, (unsigned long)ctx->tm.rounds, c.nA, c.nB, mA, mB, tA, tB);
     ctx->tm.myers_launches += (c.nA ? 1 : 0) + (c.nB ? 1 : 0);
     ctx->tm.myers_blocks += c.nA + c.nB;
@@ -695,7 +792,7 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
     NECAT_HIP(ctx, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, s));
     NECAT_HIP(ctx, hipStreamSynchronize(s));
     if (herr) { cleanup(); return set_err(ctx, NECAT_ERR_INTERNAL, "extension kernels reported error code %d", herr); }
-    necat_m4* res = (necat_m4*)malloc(std::max<size_t>(1, nout) * sizeof(necat_m4));
+    necat_m4* res = (necat_m4*)result_alloc(std::max<size_t>(1, nout) * sizeof(necat_m4));
     if (!res) { cleanup(); return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
     if (nout) NECAT_HIP(ctx, hipMemcpyAsync(res, d_out, (size_t)nout * sizeof(necat_m4), hipMemcpyDeviceToHost, s));
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s));

@@ -233,7 +233,13 @@ k_seed_collect_wave(DevVolume ref, DevVolume reads, const u64* __restrict__ kmer
     }
 }
 
-constexpr int kLdsChain = 512;
+constexpr int kLdsChain = 256;
+#ifdef NECAT_SEED_PROF
+__device__ unsigned long long g_seed_prof[16];
+#define SPROF(k) do { if (lane == 0) { const u64 now_ = clock64(); pacc[k] += now_ - tprev; tprev = now_; } } while (0)
+#else
+#define SPROF(k) do {} while (0)
+#endif
 
 struct LdsAdder { int* s; NECAT_D void operator()(int j) { atomicAdd(&s[j], 1); } };
 
@@ -243,7 +249,7 @@ struct LdsAdder { int* s; NECAT_D void operator()(int j) { atomicAdd(&s[j], 1); 
 // chain DP, candidate choice) runs on lane 0.  __syncthreads() (the block is a single wave) separates
 // the lane-0 phases from the cooperative ones - it also stops the compiler from forwarding values
 // across lanes' stores.
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict__ order, const SeedMeta* __restrict__ meta, u32 n,
             SeedArenas A, const i32* __restrict__ nblk_in, i32* __restrict__ n_cands, int* __restrict__ err_flag)
 {
@@ -263,6 +269,9 @@ k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict_
     const SeedMeta m = meta[i];
     const int L = (int)(reads.seq_off[r + 1] - reads.seq_off[r]);
     const int bs = P.block_size, z = P.z, cut = P.s_cutoff;
+#ifdef NECAT_SEED_PROF
+    u64 pacc[10] = {0,0,0,0,0,0,0,0,0,0}; u64 tprev = clock64();
+#endif
     int n_out = 0;            // meaningful on lane 0
     bool failed = false;
     for (int strand = 0; strand < 2 && !failed; ++strand) {
@@ -286,11 +295,13 @@ k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict_
             pending &= pending - 1;
             SBlock* sb = S.pool + bi;
             if (!(sb->score >= cut && sb->stale >= 2 * cut)) continue;         // wave-uniform
+            SPROF(0);
             // A: seed lists (lane 0)
             if (lane == 0) { u64 bst; s_ctl[0] = block_seed_lists(S, sb, bs, s_seedn, s_loc, &bst); s_blk_start = bst; }
             for (int x = lane; x < kBlkSeeds * 2; x += 64) s_score[x] = 0;
             __syncthreads();
             const int ns = s_ctl[0];
+            SPROF(1);
             // B: DDF vote, one row per lane
             for (int ii = lane; ii < ns - 1; ii += 64) {
                 LdsAdder add; add.s = s_score;
@@ -298,6 +309,7 @@ k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict_
                 if (own) atomicAdd(&s_score[ii], own);
             }
             __syncthreads();
+            SPROF(2);
             // C: anchor (lane 0)
             if (lane == 0) {
                 int msid = -1, sc4[4];
@@ -307,6 +319,7 @@ k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict_
                 s_ctl[1] = ok;
             }
             __syncthreads();
+            SPROF(3);
             if (!s_ctl[1]) continue;
             const AnchorGeom g = s_g;
             // D: co-linear gather, one seed per lane (a block holds <= 40 seeds)
@@ -335,6 +348,7 @@ k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict_
                 }
             }
             __syncthreads();
+            SPROF(4);
             // E: sort (all lanes when the seeds fit LDS), then chain + choose + emit (lane 0)
             const bool in_lds = !overflow && ncs <= kLdsChain;
             if (in_lds) {
@@ -352,6 +366,7 @@ k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict_
                 for (int a = lane; a < lim; a += 64) S.cs[a] = l_cs[a];
             }
             __syncthreads();
+            SPROF(5);
             if (lane == 0) {
                 int rc;
                 if (overflow) rc = kSeedErrCapacity;
@@ -363,9 +378,18 @@ k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict_
                 s_ctl[2] = rc < 0 ? 1 : 0;
             }
             __syncthreads();
+            SPROF(6);
+#ifdef NECAT_SEED_PROF
+            if (lane == 0) pacc[8] += 1;
+#endif
             if (s_ctl[2]) { failed = true; break; }
         }
     }
+    SPROF(9);
+#ifdef NECAT_SEED_PROF
+
+    if (lane == 0) { u64 tot = 0; for (int q = 0; q < 10; ++q) { atomicAdd(&g_seed_prof[q], pacc[q]); if (q != 8) tot += pacc[q]; } atomicMax(&g_seed_prof[10], tot); atomicMax(&g_seed_prof[11], pacc[8]); }
+#endif
     if (lane == 0) {
         if (failed) { atomicExch(err_flag, 1); n_cands[i] = 0; }
         else {

@@ -243,3 +243,24 @@ def test_coop_equals_banded(small, tmp_path):
         assert np.array_equal(x, y)
     assert a[5] == b[5] and len(a[5]) > 500
     assert int((a[0] >= 0).sum()) > 500
+
+
+def test_seeding_in_several_chunks(ctx, small, tmp_path):
+    """Seeding scratch is budgeted per chunk of reads; with a tiny budget (many chunks, the multi-chunk
+    host assembly) and with the wave-per-strand / lane-per-strand collection kernels the candidates
+    must be the very same array, in the same order."""
+    from necat_amd import capi
+    d, rs = small
+    opt = capi.default_options(**dict(util.SENSITIVE, job=0))
+    base, _ = capi.pm_main(ctx, opt, 0, d)
+    assert base.shape[0] > 500
+    for env in ({"NECAT_SEED_BUDGET": "30000"}, {"NECAT_SEED_WAVE": "0"}):
+        os.environ.update(env)
+        try:
+            c = capi.Context(0)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        got, _ = capi.pm_main(c, opt, 0, d)
+        c.close()
+        assert got.tobytes() == base.tobytes(), env
