@@ -236,86 +236,62 @@ struct LeftView {
 template <class Mat, class Ops>
 NECAT_HD void traceback_block(int qn, int tn, int bestScore, Mat& mat, Ops& ops)
 {
-    // The state (cur, lS, uS, ulS, curP/M, lP/M, left) and its update rules are those of
-    // edlib_ex.c:400-600; the three move bodies are folded so that the band is read at ONE place per
-    // iteration (64 lanes walk 64 different paths: every extra call site is executed by the whole wave).
+    // The walk of edlib_ex.c:383-621 (up > left > diagonal from the end cell).  The reference carries
+    // incrementally shifted copies of the current and the left word and caches neighbour scores between
+    // moves; here every step recomputes its three neighbour scores from the unshifted words - the cell
+    // itself, the word left of it (P, M, score of its last row, band flags) - which is the same
+    // arithmetic in ~1/3 of the instructions (64 lanes walk 64 different paths, nothing can be skipped
+    // wave-wide, and in the tail rounds the step latency of ONE walk is the round time):
+    //   up   (row-1, c)   = cur - dv(c, row)
+    //   left (row,   c-1) = S(c-1, b) - sum of dv(c-1, r) over the rows r > row of the word
+    //   diag (row-1, c-1) = left - dv(c-1, row)
+    // with dv(c, r) = +1 / -1 / 0 for bit r of P / M of column c.  A left word outside the band makes
+    // left unavailable and the diagonal fall back to the score of the word above it (edlib_ex.c:447-451).
     const int nblk = (qn + 63) / 64, W = nblk * 64 - qn;
-    int c = tn - 1, b = nblk - 1;
-    int cur = bestScore, lS = -1, uS = -1, ulS = -1;
+    int c = tn - 1, b = nblk - 1, pos = 63 - W;
+    int cur = bestScore;
     u64 curP, curM;
     mat.cur(c, b, curP, curM);
     LeftView V; V.P = V.M = 0; V.S = V.Sup = 0; V.in = V.up_in = false;
     if (c > 0) V = mat.left(c - 1, b);
-    bool left = c > 0 && V.in;
-    u64 lP = 0, lM = 0;
-    if (left) { lP = V.P; lM = V.M; }
-    curP <<= W; curM <<= W;
-    int pos = 64 - W - 1;
     int term = 0, term_op = 0;       // how the walk ended (boundary cases push runs of ops)
     for (;;) {
-        if (c == 0) { left = true; lS = b * 64 + pos + 1; ulS = lS - 1; }
-        if (lS == -1 && left) {
-            lS = V.S;
-            const int n = 64 - pos - 1;          // the reference walks n bits from the top
-            if (n > 0) {
-                lS += popc64(lM >> (64 - n)) - popc64(lP >> (64 - n));
-                lP <<= n; lM <<= n;
-            }
-        }
-        if (ulS == -1) {
-            if (lS != -1) {
-                ulS = lS;
-                if (lP & kHighBit) ulS--;
-                if (lM & kHighBit) ulS++;
-            } else if (c > 0 && V.up_in) {
-                ulS = V.Sup;
-            }
-        }
-        if (uS == -1) {
-            uS = cur;
-            if (curP & kHighBit) uS--;
-            if (curM & kHighBit) uS++;
-            curP <<= 1; curM <<= 1;
-        }
+        const int uS = cur - (int)((curP >> pos) & 1ULL) + (int)((curM >> pos) & 1ULL);
+        int lS = -1, ulS = -1;
+        if (c == 0) { lS = b * 64 + pos + 1; ulS = lS - 1; }
+        else if (V.in) {
+            const u64 sP = V.P >> pos, sM = V.M >> pos;
+            lS = V.S + popc64(sM >> 1) - popc64(sP >> 1);
+            ulS = lS - (int)(sP & 1ULL) + (int)(sM & 1ULL);
+        } else if (V.up_in) ulS = V.Sup;
         int op;
-        bool reload_cur = false, reload_left = false, edge_ok = true;
-        if (uS != -1 && uS + 1 == cur) {                 // up: consumes a query base
-            op = 1;
-            cur = uS; lS = ulS; uS = ulS = -1;
+        bool reload_cur = false, reload_left = false;
+        if (uS + 1 == cur) {                             // up: consumes a query base
+            op = 1; cur = uS;
             if (pos == 0) {
                 if (b == 0) { term = 1; break; }
-                pos = 63; b--;
-                reload_cur = true; reload_left = true; edge_ok = false;
-            } else { pos--; lP <<= 1; lM <<= 1; }
+                pos = 63; --b;
+                reload_cur = true; reload_left = true;
+            } else --pos;
         } else if (lS != -1 && lS + 1 == cur) {          // left: consumes a target base
-            op = 2;
-            cur = lS; uS = ulS; lS = ulS = -1;
-            c--;
+            op = 2; cur = lS;
+            --c;
             if (c == -1) { term = 2; break; }
-            curP = lP; curM = lM;
+            curP = V.P; curM = V.M;
             reload_left = true;
         } else if (ulS != -1) {                          // diagonal
-            op = ulS == cur ? 0 : 3;
-            cur = ulS; uS = lS = ulS = -1;
-            c--;
+            op = ulS == cur ? 0 : 3; cur = ulS;
+            --c;
             if (c == -1) { term = 3; term_op = op; break; }
             if (pos == 0) {
                 if (b == 0) { term = 4; term_op = op; break; }
-                pos = 63; b--;
+                pos = 63; --b;
                 reload_cur = true;
-            } else {
-                pos--;
-                curP = lP << 1; curM = lM << 1;
-            }
+            } else { --pos; curP = V.P; curM = V.M; }
             reload_left = true;
         } else break;
         if (reload_cur) mat.cur(c, b, curP, curM);
-        if (reload_left) {
-            if (c > 0) V = mat.left(c - 1, b);
-            if (c > 0 && V.in) { left = true; lP = V.P; lM = V.M; }
-            else if (c == 0 && edge_ok) { left = true; lS = b * 64 + pos + 1; ulS = lS - 1; }
-            else left = false;
-        }
+        if (reload_left && c > 0) V = mat.left(c - 1, b);
         ops.push(op);
     }
     if (term == 1) {                 // up move out of the first row
