@@ -247,6 +247,8 @@ NECAT_HD void traceback_block(int qn, int tn, int bestScore, Mat& mat, Ops& ops)
     //   diag (row-1, c-1) = left - dv(c-1, row)
     // with dv(c, r) = +1 / -1 / 0 for bit r of P / M of column c.  A left word outside the band makes
     // left unavailable and the diagonal fall back to the score of the word above it (edlib_ex.c:447-451).
+    // The step is written with selects, not nested branches: the lanes of a wave are on 64 different
+    // paths, so every divergent region would be executed by the whole wave on every step anyway.
     const int nblk = (qn + 63) / 64, W = nblk * 64 - qn;
     int c = tn - 1, b = nblk - 1, pos = 63 - W;
     int cur = bestScore;
@@ -256,42 +258,34 @@ NECAT_HD void traceback_block(int qn, int tn, int bestScore, Mat& mat, Ops& ops)
     if (c > 0) V = mat.left(c - 1, b);
     int term = 0, term_op = 0;       // how the walk ended (boundary cases push runs of ops)
     for (;;) {
-        const int uS = cur - (int)((curP >> pos) & 1ULL) + (int)((curM >> pos) & 1ULL);
-        int lS = -1, ulS = -1;
-        if (c == 0) { lS = b * 64 + pos + 1; ulS = lS - 1; }
-        else if (V.in) {
-            const u64 sP = V.P >> pos, sM = V.M >> pos;
-            lS = V.S + popc64(sM >> 1) - popc64(sP >> 1);
-            ulS = lS - (int)(sP & 1ULL) + (int)(sM & 1ULL);
-        } else if (V.up_in) ulS = V.Sup;
-        int op;
-        bool reload_cur = false, reload_left = false;
-        if (uS + 1 == cur) {                             // up: consumes a query base
-            op = 1; cur = uS;
-            if (pos == 0) {
-                if (b == 0) { term = 1; break; }
-                pos = 63; --b;
-                reload_cur = true; reload_left = true;
-            } else --pos;
-        } else if (lS != -1 && lS + 1 == cur) {          // left: consumes a target base
-            op = 2; cur = lS;
-            --c;
-            if (c == -1) { term = 2; break; }
-            curP = V.P; curM = V.M;
-            reload_left = true;
-        } else if (ulS != -1) {                          // diagonal
-            op = ulS == cur ? 0 : 3; cur = ulS;
-            --c;
-            if (c == -1) { term = 3; term_op = op; break; }
-            if (pos == 0) {
-                if (b == 0) { term = 4; term_op = op; break; }
-                pos = 63; --b;
-                reload_cur = true;
-            } else { --pos; curP = V.P; curM = V.M; }
-            reload_left = true;
-        } else break;
-        if (reload_cur) mat.cur(c, b, curP, curM);
-        if (reload_left && c > 0) V = mat.left(c - 1, b);
+        const u64 cP = curP >> pos, cM = curM >> pos;
+        const int uS = cur - (int)(cP & 1ULL) + (int)(cM & 1ULL);
+        const u64 sP = V.P >> pos, sM = V.M >> pos;
+        const int lS_in = V.S + popc64(sM >> 1) - popc64(sP >> 1);
+        const int ulS_in = lS_in - (int)(sP & 1ULL) + (int)(sM & 1ULL);
+        const int row1 = b * 64 + pos + 1;
+        const bool c0 = c == 0;
+        const bool lav = c0 || V.in;                                     // left neighbour available
+        const int lS = c0 ? row1 : lS_in;
+        const int ulS = c0 ? row1 - 1 : (V.in ? ulS_in : (V.up_in ? V.Sup : -1));
+        const bool go_up = uS + 1 == cur;                                // up > left > diagonal
+        const bool go_left = !go_up && lav && lS + 1 == cur;
+        const bool go_diag = !go_up && !go_left && ulS != -1;
+        if (!(go_up || go_left || go_diag)) break;
+        const int op = go_up ? 1 : (go_left ? 2 : (ulS == cur ? 0 : 3));
+        cur = go_up ? uS : (go_left ? lS : ulS);
+        const bool drow = !go_left, dcol = !go_up;                       // consumes a query base / a target base
+        const bool cross = drow && pos == 0;                             // leaves the 64-row word upwards
+        c -= dcol ? 1 : 0;
+        int t = 0;
+        if (cross && b == 0) t = go_up ? 1 : 4;                          // out of the first row
+        if (dcol && c == -1) t = go_left ? 2 : 3;                        // out of the first column (tested first, edlib_ex.c)
+        if (t) { term = t; term_op = op; break; }
+        pos = drow ? (cross ? 63 : pos - 1) : pos;
+        b -= cross ? 1 : 0;
+        if (dcol) { curP = V.P; curM = V.M; }                            // the left word becomes the current one ...
+        if (cross) mat.cur(c, b, curP, curM);                            // ... unless the walk moved up a word
+        if ((dcol || cross) && c > 0) V = mat.left(c - 1, b);
         ops.push(op);
     }
     if (term == 1) {                 // up move out of the first row

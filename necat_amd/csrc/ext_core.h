@@ -155,12 +155,14 @@ NECAT_HD void tail_init(TailScan& s, int M) { s.M = M; s.n = s.nq = s.nt = s.nma
 
 NECAT_HD void tail_push(TailScan& s, int op)
 {
+    // branch-free: executed once per traceback step by every lane of the wave
     const int hq = op != 2, ht = op != 1, mt = op == 0;
     s.n += 1; s.nq += hq; s.nt += ht; s.nmat += mt;
-    if (!s.hit) {
-        s.m = mt ? s.m + 1 : 0;
-        if (s.m == s.M) { s.hit = 1; s.acnt = s.n; s.qcnt = s.nq; s.tcnt = s.nt; s.mcnt = s.nmat; }
-    }
+    const int m2 = mt ? s.m + 1 : 0;
+    const bool now = !s.hit && m2 == s.M;
+    s.m = s.hit ? s.m : m2;
+    s.acnt = now ? s.n : s.acnt; s.qcnt = now ? s.nq : s.qcnt; s.tcnt = now ? s.nt : s.tcnt; s.mcnt = now ? s.nmat : s.mcnt;
+    s.hit |= now ? 1 : 0;
 }
 
 // Whether this block ends its extension, known before the traceback: Edlib_align aligns the whole
