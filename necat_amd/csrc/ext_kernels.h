@@ -177,10 +177,11 @@ NECAT_D u32 rec_tag(u32 epoch, int c) { return (epoch << 10) | (u32)c; }
 // word, one column per step - fills that line with four consecutive 32-byte stores of the same lane.
 // (With the records of the 64 lanes interleaved per column every traceback step was its own DRAM access:
 // 55 G random sector reads/s, the limit of k_traceback at 200 k concurrent blocks.)
+// (32-bit: a slab is < 32 MiB, and a wave-uniform slab base + 32-bit lane offset is the cheap addressing mode)
 template <int NW>
-NECAT_D size_t rec_pos(int c, int b, int lane)
+NECAT_D u32 rec_pos(int c, int b, int lane)
 {
-    return ((((size_t)(c >> 2) * NW + (size_t)b) * 64 + (size_t)lane) * 4 + (size_t)(c & 3)) * 2;
+    return (((((u32)c >> 2) * (u32)NW + (u32)b) * 64u + (u32)lane) * 4u + ((u32)c & 3u)) * 2u;
 }
 
 template <int NW>
