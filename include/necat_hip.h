@@ -15,6 +15,8 @@
  *   necat_extend           <- extend_candidates/onc_align
  *                                                     pm_worker.c:29-83, gapped_align/oc_aligner.h:45-55
  *   necat_volume_upload    <- pdb_load                common/packed_db.c:386 (the 2-bit pac + SequenceInfo)
+ *   necat_onc_align_batch  <- onc_align with its gapped strings, for the consensus client
+ *                                                     gapped_align/oc_aligner.h:45-55, consensus_aux.c:124-215
  *
  * Conventions: plain C types only; every function returns 0 on success and a negative code on failure
  * (necat_last_error() gives the text); output arrays are malloc'ed by the library and released with
@@ -80,6 +82,15 @@ typedef struct {
     int32_t  _pad;
 } necat_m4;
 
+/* what onc_align leaves in OcAlignData (gapped_align/oc_aligner.h:6-15): strand coordinates of the
+ * alignment, its length in gapped columns and identity; ok = onc_align's return value */
+typedef struct {
+    int32_t ok;
+    int32_t qoff, qend, toff, tend;
+    int32_t align_size;
+    double  ident_perc;
+} necat_alignment;
+
 /* wall-clock (ms, HIP events) of the last call of each stage + work counters of the extension */
 typedef struct {
     double   index_ms, seed_ms, extend_ms;
@@ -139,6 +150,24 @@ int  necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* r
                   int read_start_id, int ref_start_id,
                   const necat_candidate* cands, uint64_t n, const necat_map_options* opt,
                   int tail_match_len, necat_m4** out, uint64_t* n_out);
+
+/* onc_align (gapped_align/oc_aligner.h:45-55) on every candidate WITH the alignment itself - the call the
+ * consensus stage makes (cns_extension, consensus/consensus_aux.c:124-215, tail_match_len =
+ * ONC_TAIL_MATCH_LEN_LONG = 4).  No containment filter: aln[i] and ops[ops_off[i] .. ops_off[i+1]) belong to
+ * cands[i].  One byte per gapped column, in alignment order: 0 match, 1 query base over '-' in
+ * target_align, 2 '-' in query_align over a target base, 3 mismatch; necat_gapped_strings() turns them
+ * into the reference's two "ACGT-" strings.  ops_off[n] = total columns. */
+int  necat_onc_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_volume* reads,
+                           int read_start_id, int ref_start_id,
+                           const necat_candidate* cands, uint64_t n, const necat_map_options* opt,
+                           int tail_match_len, necat_alignment** aln, uint8_t** ops, uint64_t** ops_off);
+
+/* Host helper: expand `n` columns into query_align / target_align (each n bytes, no terminator).
+ * qseq / tseq: byte codes 0..3 of the query STRAND (reverse complement for qdir = 1) and of the subject;
+ * qoff / toff: the alignment's start in them (necat_alignment.qoff / .toff).  Returns 0, or NECAT_ERR_ARG
+ * if the columns run past qsize / tsize. */
+int  necat_gapped_strings(const uint8_t* ops, uint64_t n, const uint8_t* qseq, uint64_t qsize, uint64_t qoff,
+                          const uint8_t* tseq, uint64_t tsize, uint64_t toff, char* query_align, char* target_align);
 
 /* Test / profiling hook for the dominant kernel: n independent Edlib_align calls
  * (edlib_ex.c:733) on byte-coded (0..3) sequences.  seqs = concatenated fragments, q_off/t_off =

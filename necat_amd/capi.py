@@ -41,13 +41,15 @@ CANDIDATE_DTYPE = np.dtype([("qid", "<i4"), ("sid", "<i4"), ("qdir", "<i4"), ("s
 M4_DTYPE = np.dtype([("qid", "<i4"), ("qdir", "<i4"), ("qoff", "<u8"), ("qend", "<u8"), ("qext", "<u8"),
                      ("qsize", "<u8"), ("sid", "<i4"), ("sdir", "<i4"), ("soff", "<u8"), ("send", "<u8"),
                      ("sext", "<u8"), ("ssize", "<u8"), ("ident_perc", "<f8"), ("vscore", "<i4"), ("_pad", "<i4")])
-assert CANDIDATE_DTYPE.itemsize == 88 and M4_DTYPE.itemsize == 96
+ALIGNMENT_DTYPE = np.dtype([("ok", "<i4"), ("qoff", "<i4"), ("qend", "<i4"), ("toff", "<i4"), ("tend", "<i4"),
+                            ("align_size", "<i4"), ("ident_perc", "<f8")])
+assert CANDIDATE_DTYPE.itemsize == 88 and M4_DTYPE.itemsize == 96 and ALIGNMENT_DTYPE.itemsize == 32
 
 EXPORTED_SYMBOLS = [
     "necat_default_options", "necat_ctx_create", "necat_ctx_destroy", "necat_last_error", "necat_device_name",
     "necat_volume_upload", "necat_volume_free", "necat_index_build", "necat_index_size", "necat_index_download",
-    "necat_index_free", "necat_find_candidates", "necat_extend", "necat_edlib_align_batch", "necat_get_timings",
-    "necat_free",
+    "necat_index_free", "necat_find_candidates", "necat_extend", "necat_onc_align_batch", "necat_gapped_strings",
+    "necat_edlib_align_batch", "necat_get_timings", "necat_free",
 ]
 
 _lib = None
@@ -83,6 +85,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                           C.POINTER(vp), u64p]
     lib.necat_extend.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_uint64, C.POINTER(MapOptions), C.c_int,
                                  C.POINTER(vp), u64p]
+    lib.necat_onc_align_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_uint64, C.POINTER(MapOptions), C.c_int,
+                                          C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.necat_gapped_strings.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, C.c_uint64, vp, vp]
     lib.necat_edlib_align_batch.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, C.c_double,
                                             vp, vp, vp, C.POINTER(vp), C.POINTER(vp)]
     lib.necat_get_timings.argtypes = [vp, C.POINTER(Timings)]
@@ -184,6 +189,19 @@ class Context:
                                           cands.shape[0], C.byref(opt), tail_match_len, C.byref(p), C.byref(n)),
                     "necat_extend")
         return self._take(p, n.value, M4_DTYPE)
+
+    def onc_align_batch(self, ref: "Volume", reads: "Volume", read_start_id: int, ref_start_id: int, cands: np.ndarray,
+                        opt: MapOptions, tail_match_len: int = 4):
+        """onc_align with the alignment itself for every candidate (the consensus stage's call):
+        (alignments[ALIGNMENT_DTYPE], ops[uint8], ops_off[uint64, n + 1])."""
+        cands = np.ascontiguousarray(cands, dtype=CANDIDATE_DTYPE)
+        n = cands.shape[0]
+        a, o, f = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._check(self.lib.necat_onc_align_batch(self.h, ref.h, reads.h, read_start_id, ref_start_id, cands.ctypes.data, n,
+                                                   C.byref(opt), tail_match_len, C.byref(a), C.byref(o), C.byref(f)),
+                    "necat_onc_align_batch")
+        off = self._take(f, n + 1, np.dtype("<u8"))
+        return self._take(a, n, ALIGNMENT_DTYPE), self._take(o, int(off[-1]), np.dtype("u1")), off
 
     def edlib_align_batch(self, seqs: np.ndarray, q_off, q_len, t_off, t_len, error: float = 0.5, want_ops: bool = True):
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
@@ -287,6 +305,20 @@ def load_volumes_info(wrk_dir: str):
             parts = f.readline().split()
             vols.append((parts[0], int(parts[1]), int(parts[2])))
     return nv, nr, vols
+
+
+def gapped_strings(ops: np.ndarray, qseq: np.ndarray, qoff: int, tseq: np.ndarray, toff: int):
+    """necat_gapped_strings: (query_align, target_align) as bytes ("ACGT-")."""
+    ops = np.ascontiguousarray(ops, dtype=np.uint8)
+    q = np.ascontiguousarray(qseq, dtype=np.uint8)
+    t = np.ascontiguousarray(tseq, dtype=np.uint8)
+    n = ops.shape[0]
+    qa = C.create_string_buffer(max(1, n))
+    ta = C.create_string_buffer(max(1, n))
+    rc = load_library().necat_gapped_strings(ops.ctypes.data, n, q.ctypes.data, q.shape[0], qoff, t.ctypes.data, t.shape[0], toff, qa, ta)
+    if rc != 0:
+        raise NecatError("necat_gapped_strings failed with %d" % rc)
+    return qa.raw[:n], ta.raw[:n]
 
 
 def pack_candidates(c: np.ndarray) -> np.ndarray:

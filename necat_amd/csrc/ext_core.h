@@ -36,7 +36,12 @@ struct ExtTask {
     i32 l_cols, l_q, l_t, l_mat;
     // final result (oc_aligner.c:419-450)
     i32 r_qoff, r_qend, r_toff, r_tend, r_cols, r_mat;
+    // alignment columns (only when the caller wants them, necat_onc_align_batch): both streams are written
+    // to one per-task region in stream order, left stream at [0, s_lto), right stream from s_lto on; the
+    // final alignment is region[s_lfrom, s_lto) reversed followed by region[s_lto + s_rfrom, s_lto + s_rto)
+    i32 s_lfrom, s_lto, s_rfrom, s_rto;
     i32 _pad;
+    u64 ops_base;
 };
 
 NECAT_HD void ext_reset_stream(ExtTask& t)
@@ -56,7 +61,8 @@ NECAT_HD void ext_init(ExtTask& t, i32 cand, i32 qdir, i64 q_g0, i32 qlen, i64 s
     t.qblk = t.tblk = t.last = 0;
     t.l_cols = t.l_q = t.l_t = t.l_mat = 0;
     t.r_qoff = t.r_qend = t.r_toff = t.r_tend = t.r_cols = t.r_mat = 0;
-    t._pad = 0;
+    t.s_lfrom = t.s_lto = t.s_rfrom = t.s_rto = 0;
+    t._pad = 0; t.ops_base = 0;
 }
 
 // one alignment column in stream order
@@ -92,17 +98,21 @@ NECAT_HD bool ext_plan(ExtTask& t)
         // the current extension is over
         if (t.phase == 0) {
             // oc_aligner.c:340-367: keep the left alignment only beyond its first run of 8 matches
+            t.s_lto = t.tot_cols; t.s_lfrom = t.tot_cols;
             if (t.found) {
                 t.QS -= t.pre_q; t.TS -= t.pre_t;
                 t.l_cols = t.tot_cols - t.pre_cols; t.l_q = t.tot_q - t.pre_q;
                 t.l_t = t.tot_t - t.pre_t; t.l_mat = t.tot_mat - t.pre_mat;
+                t.s_lfrom = t.pre_cols;
             }
             t.phase = 1;
             t.ext_q = t.qlen - t.QS; t.ext_t = t.slen - t.TS;   // oca_extend(query + QS, query_size - QS, ...)
             ext_reset_stream(t);
         } else {
             int f_cols = 0, f_q = 0, f_t = 0, f_mat = 0;
+            t.s_rfrom = 0; t.s_rto = t.tot_cols;
             if (t.l_cols == 0) {
+                t.s_rfrom = t.found ? t.pre_cols - kOcaMatCnt : t.tot_cols;
                 // oc_aligner.c:386-416: no left part -> start the right alignment at its first run of 8
                 if (t.found) {
                     t.QS += t.pre_q - kOcaMatCnt; t.TS += t.pre_t - kOcaMatCnt;
@@ -182,9 +192,15 @@ NECAT_HD int ext_block_done(const ExtTask& t, int dist, int endc)
 //   rops(j)   : op j of the alignment in END -> START order (only read while the stream has not yet
 //               seen its first run of 8 matches, i.e. on the first block(s) of an extension)
 //   same(i)   : query fragment element i == target fragment element i (exact-prefix fallback)
+// What the block contributes to the stream, for callers that keep the alignment columns: `cols` columns
+// starting at stream column `at`; they are forward columns [0, cols) of the block's alignment, or - exact
+// (the exact-match fallback) - `cols` match columns.
+struct ExtKept { int at, cols, exact; };
+
 template <class ROps, class Same>
-NECAT_HD void ext_finish_block(ExtTask& t, int dist, int endc, int done, const TailScan& ts, ROps& rops, Same& same)
+NECAT_HD ExtKept ext_finish_block(ExtTask& t, int dist, int endc, int done, const TailScan& ts, ROps& rops, Same& same)
 {
+    ExtKept kept; kept.at = t.tot_cols; kept.cols = 0; kept.exact = 0;
     const int qn = t.qblk, tn = t.tblk;
     const int n = dist >= 0 ? ts.n : 0;
     const int kfirst = n - ts.acnt;       // forward index where the tail scan stopped (k in the reference)
@@ -194,7 +210,9 @@ NECAT_HD void ext_finish_block(ExtTask& t, int dist, int endc, int done, const T
         for (int i = 0; i < lim; ++i) {
             if (!same(i)) break;
             ext_stream_col(t, true, true, true);
+            ++kept.cols;
         }
+        kept.exact = 1;
         done = 1;
     } else {
         const int M = ts.M;
@@ -213,8 +231,10 @@ NECAT_HD void ext_finish_block(ExtTask& t, int dist, int endc, int done, const T
         }
         // the rest only adds to the totals
         t.tot_cols = c0 + keep_cols; t.tot_q = q0 + keep_q; t.tot_t = t0 + keep_t; t.tot_mat = m0 + keep_mat;
+        kept.cols = keep_cols;
     }
     t.ext_done = done;
+    return kept;
 }
 
 }  // namespace necat

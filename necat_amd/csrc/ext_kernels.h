@@ -52,6 +52,7 @@ struct BlockResult { i32 dist, endc, err; u32 words; };
 struct ExtLists {
     u32* count;          // [0] = nA, [1] = nB  (this round)
     BlockItem* itemsA; BlockItem* itemsB;
+    u8* task_ops = nullptr;   // per-task alignment columns (necat_onc_align_batch), nullptr = not kept
 };
 
 // Append the scheduled block of task `ti` to list A (full 512 x 512 blocks) or list B (the
@@ -76,7 +77,8 @@ NECAT_D void ext_append_block(const ExtTask& t, u32 ti, bool go, const ExtLists&
 
 __global__ void __launch_bounds__(256)
 k_ext_init(const necat_candidate* __restrict__ cands, u32 n, u32 cand_base, int read_start_id, int ref_start_id,
-           const u64* __restrict__ reads_off, const u64* __restrict__ ref_off, ExtTask* __restrict__ tasks, ExtLists L)
+           const u64* __restrict__ reads_off, const u64* __restrict__ ref_off, ExtTask* __restrict__ tasks, ExtLists L,
+           const u64* __restrict__ ops_base)
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     ExtTask t;
@@ -85,6 +87,7 @@ k_ext_init(const necat_candidate* __restrict__ cands, u32 n, u32 cand_base, int 
         const necat_candidate c = cands[i];
         const int lq = c.qid - read_start_id, ls = c.sid - ref_start_id;
         ext_init(t, (i32)(cand_base + i), c.qdir, (i64)reads_off[lq], (i32)c.qsize, (i64)ref_off[ls], (i32)c.ssize, (i32)c.qoff, (i32)c.soff);
+        if (ops_base) t.ops_base = ops_base[i];
         go = ext_plan(t);          // first block (or an immediately finished candidate)
         tasks[i] = t;
     }
@@ -457,7 +460,8 @@ k_traceback(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ 
     if (!EXPORT) {
         t = tasks[it.task];
         done = ext_block_done(t, br.dist, br.endc);
-        ow.store = !t.found;       // the op list is only replayed until the stream's first run of 8 matches
+        // the op list is only replayed until the stream's first run of 8 matches - unless the caller keeps the columns
+        ow.store = !t.found || next.task_ops != nullptr;
     }
     tail_init(ow.ts, (EXPORT || !done) ? kOcaMatCnt : tail_match_len);
     if (br.dist >= 0) {
@@ -469,7 +473,13 @@ k_traceback(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ 
     if (EXPORT) { n_ops_out[item] = ow.ts.n; return; }
     OpsReader rd; rd.ops = ow.ops;
     SameReader<NW> same; same.fr = frag + (u64)grp * FW * 64 + lane;
-    ext_finish_block(t, br.dist, br.endc, done, ow.ts, rd, same);
+    const int stream_at = t.phase == 1 ? t.s_lto : 0;     // where the block's stream starts in the task's column region
+    const ExtKept kept = ext_finish_block(t, br.dist, br.endc, done, ow.ts, rd, same);
+    if (next.task_ops) {
+        u8* dst = next.task_ops + t.ops_base + (u64)(stream_at + kept.at);
+        const int nops = ow.ts.n;
+        for (int f = 0; f < kept.cols; ++f) dst[f] = kept.exact ? (u8)0 : ow.ops[(size_t)(nops - 1 - f) * 64];
+    }
     const bool go = ext_plan(t);       // schedule the candidate's next block for the next round (or finish it)
     tasks[it.task] = t;
     ext_append_block(t, (u32)it.task, go, next);
@@ -492,6 +502,37 @@ k_ext_result(const ExtTask* __restrict__ tasks, u32 n, const necat_candidate* __
     if (m.qdir == 1) { const u64 qo = m.qsize - m.qend, qe = m.qsize - m.qoff; m.qoff = qo; m.qend = qe; }
     m4[cand_base + i] = m;
     ok[cand_base + i] = t.r_cols >= min_align ? 1 : 0;
+}
+
+// necat_onc_align_batch: per-candidate results in strand coordinates (what onc_align leaves in OcAlignData)
+__global__ void __launch_bounds__(256)
+k_ext_alignment(const ExtTask* __restrict__ tasks, u32 n, u32 cand_base, int min_align, necat_alignment* __restrict__ out, u32* __restrict__ lens)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const ExtTask t = tasks[i];
+    necat_alignment a;
+    a.ok = t.r_cols >= min_align ? 1 : 0;
+    a.qoff = t.r_qoff; a.qend = t.r_qend; a.toff = t.r_toff; a.tend = t.r_tend; a.align_size = t.r_cols;
+    a.ident_perc = t.r_cols ? 100.0 * (double)t.r_mat / (double)t.r_cols : 0.0;
+    out[cand_base + i] = a;
+    lens[i] = (u32)t.r_cols;
+}
+
+// final alignment of task i = its left stream [s_lfrom, s_lto) reversed, then its right stream
+// [s_rfrom, s_rto) (oc_aligner.c:358-366, :404-428); one wave per task, coalesced
+__global__ void __launch_bounds__(256)
+k_ext_strings(const ExtTask* __restrict__ tasks, u32 n, const u8* __restrict__ task_ops, const u64* __restrict__ out_off, u8* __restrict__ out)
+{
+    const u32 wave = (u32)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wave >= n) return;
+    const ExtTask t = tasks[wave];
+    const u8* reg = task_ops + t.ops_base;
+    u8* dst = out + out_off[wave];
+    const int nl = t.s_lto - t.s_lfrom, nr = t.s_rto - t.s_rfrom;
+    for (int j = lane; j < nl; j += 64) dst[j] = reg[t.s_lto - 1 - j];
+    for (int j = lane; j < nr; j += 64) dst[nl + j] = reg[t.s_lto + t.s_rfrom + j];
 }
 
 // extend_candidates' containment rule (pm_worker.c:44, map_aux.c:4-20), one lane per query read:

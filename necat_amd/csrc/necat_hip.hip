@@ -569,6 +569,7 @@ struct ExtShared {
     const necat_candidate* d_cands; necat_m4* d_m4; u8* d_ok; int* d_err; unsigned long long* stats;
     double error; int tail_match_len, min_align, read_start_id, ref_start_id;
     const u64* reads_off; const u64* ref_off;
+    u8* task_ops = nullptr;      // alignment columns per task (necat_onc_align_batch)
 };
 
 // finish the round a cohort has in flight (if any): wait, account, flip the list parity
@@ -606,7 +607,7 @@ int cohort_launch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, C
     char* slabsB = c.slabs + (size_t)gA * kSlabA;
     const BlockItem* itA = c.itemsA[p]; const BlockItem* itB = c.itemsB[p];
     const u32 epoch = ++ctx->epoch & 0x3fffffu;
-    ExtLists next; next.count = c.count + 2 * (p ^ 1); next.itemsA = c.itemsA[p ^ 1]; next.itemsB = c.itemsB[p ^ 1];
+    ExtLists next; next.count = c.count + 2 * (p ^ 1); next.itemsA = c.itemsA[p ^ 1]; next.itemsB = c.itemsB[p ^ 1]; next.task_ops = X.task_ops;
     // keep the two cohorts in anti-phase while both are in their bulk rounds: this cohort's DP kernel
     // starts when the other's DP kernel is done, i.e. it overlaps the other's traceback
     if (g_antiphase && other && other->in_flight && other->a1_valid && nA > g_coop_threshold && other->nA > g_coop_threshold)
@@ -665,13 +666,16 @@ int cohort_launch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, C
 
 }  // namespace
 
-int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* reads, int read_start_id, int ref_start_id,
-                 const necat_candidate* cands, uint64_t n, const necat_map_options* opt, int tail_match_len,
-                 necat_m4** out, uint64_t* n_out)
+namespace {
+// outputs of the alignment-keeping mode (necat_onc_align_batch)
+struct AlignOut { necat_alignment* aln = nullptr; std::vector<u8> cols; std::vector<u64> off; };
+
+// The extension loop behind necat_extend (M4 records, containment filter) and necat_onc_align_batch
+// (every candidate's alignment with its columns, `ao` != nullptr).
+int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* reads, int read_start_id, int ref_start_id,
+                const necat_candidate* cands, uint64_t n, const necat_map_options* opt, int tail_match_len,
+                necat_m4** out, uint64_t* n_out, AlignOut* ao)
 {
-    if (!ctx || !ref || !reads || !opt || !out || !n_out || (n && !cands)) return NECAT_ERR_ARG;
-    *out = nullptr; *n_out = 0;
-    if (n == 0) return NECAT_OK;
     if (n >= (1ULL << 31)) return set_err(ctx, NECAT_ERR_ARG, "too many candidates in one call");
     for (uint64_t i = 0; i < n; ++i) {
         const necat_candidate& c = cands[i];
@@ -693,7 +697,7 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
     // Default: ONE cohort.  Two (NECAT_COHORTS=2) were measured slower on MI355X (E. coli 129 vs 111 ms,
     // yeast-size 1.09 vs 1.08 s): both kernels already sit on their per-launch latency floor at half size.
     constexpr int kMaxCohorts = 2;
-    const int kCohorts = g_cohorts;
+    const int kCohorts = ao ? 1 : g_cohorts;       // the column arena is per batch
     const u32 cap = (u32)std::min<uint64_t>(((n + kCohorts - 1) / kCohorts + 63) & ~63ULL, 393216 / kCohorts);
     const u32 groups = cap / 64 + 1;
     int rc;
@@ -754,18 +758,63 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
                 k.parity = 0; k.active = true; k.in_flight = false; k.a1_valid = false;
                 NECAT_HIP(ctx, hipMemsetAsync(k.count, 0, 16, k.sa));
                 ExtLists L0; L0.count = k.count; L0.itemsA = k.itemsA[0]; L0.itemsB = k.itemsB[0];
+                const u64* d_ops_base = nullptr;
+                if (ao) {
+                    // column region of a task: left stream (<= qoff + soff columns) then right stream
+                    // (<= what is left of both reads from the anchor the left extension moved back)
+                    std::vector<u64> base(k.n + 1, 0);
+                    for (u32 i = 0; i < k.n; ++i) {
+                        const necat_candidate& c = cands[k.base + i];
+                        base[i + 1] = base[i] + ((c.qsize + c.ssize + c.qoff + c.soff + 64) & ~15ULL);
+                    }
+                    if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_COLS], base[k.n] + (size_t)(k.n + 1) * 8 + 64))) { cleanup(); return rc; }
+                    X.task_ops = (u8*)ctx->scratch[SC_EXT_COLS].p;
+                    u64* d_base = (u64*)(X.task_ops + ((base[k.n] + 63) & ~63ULL));
+                    NECAT_HIP(ctx, hipMemcpyAsync(d_base, base.data(), (size_t)k.n * 8, hipMemcpyHostToDevice, k.sa));
+                    NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
+                    d_ops_base = d_base;
+                }
                 hipLaunchKernelGGL(k_ext_init, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, d_cands + k.base, k.n, (u32)k.base,
-                                   read_start_id, ref_start_id, X.reads_off, X.ref_off, k.tasks, L0);
+                                   read_start_id, ref_start_id, X.reads_off, X.ref_off, k.tasks, L0, d_ops_base);
                 NECAT_CHECK_LAUNCH(ctx, "k_ext_init");
             } else if ((rc = cohort_retire(ctx, k))) { cleanup(); return rc; }
             any = true;
             const int done = cohort_launch(ctx, dref, drd, k, X, kCohorts > 1 ? &co[c ^ 1] : nullptr);
             if (done < 0) { cleanup(); return done; }
-            if (done == 1) {
+            if (done == 1 && !ao) {
                 hipLaunchKernelGGL(k_ext_result, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, (const ExtTask*)k.tasks, k.n, d_cands + k.base,
                                    (u32)k.base, opt->align_size_cutoff, d_m4, d_ok);
                 NECAT_CHECK_LAUNCH(ctx, "k_ext_result");
                 NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
+                k.active = false;
+            } else if (done == 1) {
+                // per-candidate results + the batch's alignment columns, packed in candidate order
+                necat_alignment* d_aln = (necat_alignment*)d_m4;          // the M4 arrays are not used in this mode
+                u32* d_len = (u32*)d_out;
+                hipLaunchKernelGGL(k_ext_alignment, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, (const ExtTask*)k.tasks, k.n, 0u,
+                                   opt->align_size_cutoff, d_aln, d_len);
+                NECAT_CHECK_LAUNCH(ctx, "k_ext_alignment");
+                std::vector<u32> len(k.n);
+                NECAT_HIP(ctx, hipMemcpyAsync(len.data(), d_len, (size_t)k.n * 4, hipMemcpyDeviceToHost, k.sa));
+                NECAT_HIP(ctx, hipMemcpyAsync(ao->aln + k.base, d_aln, (size_t)k.n * sizeof(necat_alignment), hipMemcpyDeviceToHost, k.sa));
+                NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
+                std::vector<u64> off(k.n + 1, 0);
+                for (u32 i = 0; i < k.n; ++i) off[i + 1] = off[i] + len[i];
+                const u64 tot = off[k.n], at = ao->cols.size();
+                for (u32 i = 0; i < k.n; ++i) ao->off[k.base + i] = at + off[i];
+                ao->off[k.base + k.n] = at + tot;
+                if (tot) {
+                    if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_COLS_OUT], tot + (size_t)(k.n + 1) * 8 + 64))) { cleanup(); return rc; }
+                    u8* d_cols = (u8*)ctx->scratch[SC_EXT_COLS_OUT].p;
+                    u64* d_off = (u64*)(d_cols + ((tot + 63) & ~63ULL));
+                    NECAT_HIP(ctx, hipMemcpyAsync(d_off, off.data(), (size_t)k.n * 8, hipMemcpyHostToDevice, k.sa));
+                    hipLaunchKernelGGL(k_ext_strings, dim3(grid_for((u64)k.n * 64, 256)), dim3(256), 0, k.sa, (const ExtTask*)k.tasks, k.n,
+                                       (const u8*)X.task_ops, (const u64*)d_off, d_cols);
+                    NECAT_CHECK_LAUNCH(ctx, "k_ext_strings");
+                    ao->cols.resize(at + tot);
+                    NECAT_HIP(ctx, hipMemcpyAsync(ao->cols.data() + at, d_cols, tot, hipMemcpyDeviceToHost, k.sa));
+                    NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
+                }
                 k.active = false;
             }
         }
@@ -776,6 +825,15 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
         NECAT_HIP(ctx, hipMemcpyAsync(hs, X.stats, 16, hipMemcpyDeviceToHost, s));
         NECAT_HIP(ctx, hipStreamSynchronize(s));
         ctx->tm.myers_word_updates = hs[0]; ctx->tm.myers_cells_bases = hs[1];
+    }
+    if (ao) {
+        int herr = 0;
+        NECAT_HIP(ctx, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, s));
+        NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s));
+        NECAT_HIP(ctx, hipStreamSynchronize(s));
+        ctx->tm.extend_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
+        if (herr) return set_err(ctx, NECAT_ERR_INTERNAL, "extension kernels reported error code %d", herr);
+        return NECAT_OK;
     }
     // groups of equal qid (candidates arrive grouped per read: pm_worker.c:100-140)
     std::vector<u64> goff;
@@ -800,6 +858,56 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
     ctx->tm.extend_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
     cleanup();
     *out = res; *n_out = nout;
+    return NECAT_OK;
+}
+}  // namespace
+
+int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* reads, int read_start_id, int ref_start_id,
+                 const necat_candidate* cands, uint64_t n, const necat_map_options* opt, int tail_match_len,
+                 necat_m4** out, uint64_t* n_out)
+{
+    if (!ctx || !ref || !reads || !opt || !out || !n_out || (n && !cands)) return NECAT_ERR_ARG;
+    *out = nullptr; *n_out = 0;
+    if (n == 0) return NECAT_OK;
+    return extend_impl(ctx, ref, reads, read_start_id, ref_start_id, cands, n, opt, tail_match_len, out, n_out, nullptr);
+}
+
+int necat_onc_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_volume* reads, int read_start_id, int ref_start_id,
+                          const necat_candidate* cands, uint64_t n, const necat_map_options* opt, int tail_match_len,
+                          necat_alignment** aln, uint8_t** ops, uint64_t** ops_off)
+{
+    if (!ctx || !ref || !reads || !opt || !aln || !ops || !ops_off || (n && !cands)) return NECAT_ERR_ARG;
+    *aln = nullptr; *ops = nullptr; *ops_off = nullptr;
+    AlignOut ao;
+    ao.aln = (necat_alignment*)result_alloc(std::max<uint64_t>(1, n) * sizeof(necat_alignment));
+    if (!ao.aln) return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed");
+    ao.off.assign(n + 1, 0);
+    if (n) {
+        const int rc = extend_impl(ctx, ref, reads, read_start_id, ref_start_id, cands, n, opt, tail_match_len, nullptr, nullptr, &ao);
+        if (rc) { necat_free(ao.aln); return rc; }
+    }
+    uint8_t* o = (uint8_t*)result_alloc(std::max<size_t>(1, ao.cols.size()));
+    uint64_t* f = (uint64_t*)result_alloc((n + 1) * 8);
+    if (!o || !f) { necat_free(ao.aln); necat_free(o); necat_free(f); return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
+    if (!ao.cols.empty()) memcpy(o, ao.cols.data(), ao.cols.size());
+    memcpy(f, ao.off.data(), (n + 1) * 8);
+    *aln = ao.aln; *ops = o; *ops_off = f;
+    return NECAT_OK;
+}
+
+int necat_gapped_strings(const uint8_t* ops, uint64_t n, const uint8_t* qseq, uint64_t qsize, uint64_t qoff,
+                         const uint8_t* tseq, uint64_t tsize, uint64_t toff, char* query_align, char* target_align)
+{
+    if ((n && (!ops || !query_align || !target_align)) || !qseq || !tseq) return NECAT_ERR_ARG;
+    static const char dec[5] = {'A', 'C', 'G', 'T', '-'};      // DecodeDNA / GAP_CHAR (common/ontcns_defs.h:36-39)
+    uint64_t q = qoff, t = toff;
+    for (uint64_t i = 0; i < n; ++i) {
+        const int op = ops[i];
+        if (op > 3 || (op != 2 && q >= qsize) || (op != 1 && t >= tsize)) return NECAT_ERR_ARG;
+        query_align[i] = op == 2 ? '-' : dec[qseq[q] & 3];
+        target_align[i] = op == 1 ? '-' : dec[tseq[t] & 3];
+        q += op != 2; t += op != 1;
+    }
     return NECAT_OK;
 }
 

@@ -41,7 +41,40 @@ class OraIndex(C.Structure):
                 ("n_offsets", C.c_uint64), ("k", C.c_int)]
 
 
+class OraAlignResult(C.Structure):
+    _fields_ = [("qoff", C.c_int), ("qend", C.c_int), ("toff", C.c_int), ("tend", C.c_int),
+                ("ident_perc", C.c_double), ("align_size", C.c_int),
+                ("query_align", C.c_void_p), ("target_align", C.c_void_p)]
+
+
+class _KString(C.Structure):
+    _fields_ = [("l", C.c_size_t), ("m", C.c_size_t), ("s", C.c_char_p)]
+
+
+class _RefOcAlignData(C.Structure):
+    # leading fields of OcAlignData (gapped_align/oc_aligner.h:6-15): what a caller reads back
+    _fields_ = [("edlib", C.c_void_p), ("qoff", C.c_int), ("qend", C.c_int), ("toff", C.c_int), ("tend", C.c_int),
+                ("ident_perc", C.c_double), ("query_align", _KString), ("target_align", _KString)]
+
+
 _lib = None
+_ref_lib = None
+
+
+def ref_lib() -> C.CDLL:
+    """The reference's own libontcns subset (oracle/_ref/libnecat_ref.so, built from /root/reference by oracle/Makefile)."""
+    global _ref_lib
+    if _ref_lib is None:
+        l = C.CDLL(REF_LIB)
+        l.new_OcAlignData.argtypes = [C.c_double]
+        l.new_OcAlignData.restype = C.POINTER(_RefOcAlignData)
+        l.free_OcAlignData.argtypes = [C.POINTER(_RefOcAlignData)]
+        l.free_OcAlignData.restype = C.c_void_p
+        l.onc_align.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(_RefOcAlignData),
+                                C.c_int, C.c_int, C.c_int]
+        l.onc_align.restype = C.c_int
+        _ref_lib = l
+    return _ref_lib
 
 
 def lib() -> C.CDLL:
@@ -62,6 +95,8 @@ def lib() -> C.CDLL:
         l.ora_aligner_free.argtypes = [C.c_void_p]
         l.ora_edlib_align.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_char_p, C.c_char_p,
                                       C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        l.ora_onc_align.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.POINTER(OraAlignResult)]
         _lib = l
     return _lib
 
@@ -122,6 +157,46 @@ def edlib_align(query: np.ndarray, target: np.ndarray, error: float = 0.5):
             else:
                 ops.append(0 if x == y else 3)
     return bool(ok), d.value, qe.value, te.value, np.asarray(ops, dtype=np.uint8)
+
+
+class Aligner:
+    """onc_align (gapped_align/oc_aligner.c:303) of the oracle, or - impl='ref' - of the reference build itself.
+    align() returns (ok, qoff, qend, toff, tend, ident_perc, query_align, target_align) with the gapped
+    strings as bytes ("ACGT-")."""
+
+    def __init__(self, error: float = 0.5, impl: str = "oracle"):
+        self.impl = impl
+        if impl == "ref":
+            self.h = ref_lib().new_OcAlignData(error)
+        else:
+            self.h = lib().ora_aligner_new(error)
+
+    def align(self, query: np.ndarray, qstart: int, target: np.ndarray, tstart: int, min_align: int, tail_match_len: int,
+              block_size: int = 512):
+        q = np.ascontiguousarray(query, dtype=np.uint8)
+        t = np.ascontiguousarray(target, dtype=np.uint8)
+        if self.impl == "ref":
+            ok = ref_lib().onc_align(q.ctypes.data, qstart, q.shape[0], t.ctypes.data, tstart, t.shape[0], self.h,
+                                     block_size, min_align, tail_match_len)
+            d = self.h.contents
+            qa = C.string_at(d.query_align.s, d.query_align.l) if d.query_align.l else b""
+            ta = C.string_at(d.target_align.s, d.target_align.l) if d.target_align.l else b""
+            return bool(ok), d.qoff, d.qend, d.toff, d.tend, d.ident_perc, qa, ta
+        r = OraAlignResult()
+        ok = lib().ora_onc_align(self.h, q.ctypes.data, qstart, q.shape[0], t.ctypes.data, tstart, t.shape[0],
+                                 block_size, min_align, tail_match_len, C.byref(r))
+        n = r.align_size
+        qa = C.string_at(r.query_align, n) if n else b""
+        ta = C.string_at(r.target_align, n) if n else b""
+        return bool(ok), r.qoff, r.qend, r.toff, r.tend, r.ident_perc, qa, ta
+
+    def close(self):
+        if self.h:
+            if self.impl == "ref":
+                ref_lib().free_OcAlignData(self.h)
+            else:
+                lib().ora_aligner_free(self.h)
+            self.h = None
 
 
 def have_ref() -> bool:

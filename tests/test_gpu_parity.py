@@ -264,3 +264,36 @@ def test_seeding_in_several_chunks(ctx, small, tmp_path):
         got, _ = capi.pm_main(c, opt, 0, d)
         c.close()
         assert got.tobytes() == base.tobytes(), env
+
+
+@pytest.mark.parametrize("tail", [4, 1])
+def test_onc_align_with_strings_matches_oracle(ctx, small, tail):
+    """necat_onc_align_batch (the call the consensus stage makes, tail_match_len = 4) against the
+    oracle's onc_align on every candidate: return value, coordinates, identity and both gapped strings."""
+    from necat_amd import capi
+    d, rs = small
+    opt = capi.default_options(**dict(util.FAST, job=0))
+    cands, _ = capi.pm_main(ctx, opt, 0, d)
+    assert cands.shape[0] > 500
+    _, _, vols = capi.load_volumes_info(d)
+    vol = ctx.load_volume(vols[0][0])
+    aln, ops, off = ctx.onc_align_batch(vol, vol, 0, 0, cands, opt, tail)
+    vol.free()
+    assert aln.shape[0] == cands.shape[0] and off.shape[0] == cands.shape[0] + 1 and int(off[-1]) == ops.shape[0]
+    al = ora.Aligner(opt.error)
+    n_ok = 0
+    for i, c in enumerate(cands):
+        q = rs.codes[rs.offsets[c["qid"]]: rs.offsets[c["qid"]] + rs.sizes[c["qid"]]]
+        if c["qdir"] == 1:
+            q = (3 - q[::-1]).astype(np.uint8)
+        t = rs.codes[rs.offsets[c["sid"]]: rs.offsets[c["sid"]] + rs.sizes[c["sid"]]]
+        ok, qoff, qend, toff, tend, ident, qa, ta = al.align(q, int(c["qoff"]), t, int(c["soff"]), opt.align_size_cutoff, tail)
+        a = aln[i]
+        assert (bool(a["ok"]), int(a["qoff"]), int(a["qend"]), int(a["toff"]), int(a["tend"]), int(a["align_size"])) == \
+               (ok, qoff, qend, toff, tend, len(qa)), i
+        assert float(a["ident_perc"]) == ident, i
+        mine = capi.gapped_strings(ops[int(off[i]):int(off[i + 1])], q, qoff, t, toff)
+        assert mine == (qa, ta), i
+        n_ok += ok
+    al.close()
+    assert n_ok > 300
