@@ -72,7 +72,7 @@ def ref_lib() -> C.CDLL:
         l.free_OcAlignData.restype = C.c_void_p
         l.onc_align.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(_RefOcAlignData),
                                 C.c_int, C.c_int, C.c_int]
-        l.onc_align.restype = C.c_int
+        l.onc_align.restype = C.c_int8        # BOOL is int8_t (common/ontcns_defs.h:19)
         _ref_lib = l
     return _ref_lib
 

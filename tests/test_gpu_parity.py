@@ -297,3 +297,47 @@ def test_onc_align_with_strings_matches_oracle(ctx, small, tail):
         n_ok += ok
     al.close()
     assert n_ok > 300
+
+
+def test_onc_align_arbitrary_anchors(ctx):
+    """Anchors anywhere in the overlap (left AND right extensions of several blocks), at the sequence ends,
+    on unrelated sequences (the extension fails, empty alignment), both query strands, both tail lengths."""
+    from necat_amd import capi
+    from necat_amd.synth import _mutate, pack_2bit
+    rng = np.random.default_rng(321)
+    seqs, cand_rows = [], []
+    for it in range(70):
+        g = rng.integers(0, 4, int(rng.integers(1200, 9000)), dtype=np.uint8)
+        q = _mutate(g, float(rng.uniform(0.03, 0.16)), rng)
+        t = _mutate(g, float(rng.uniform(0.03, 0.16)), rng)
+        if it % 7 == 3:
+            t = rng.integers(0, 4, t.shape[0], dtype=np.uint8)
+        qdir = it & 1
+        stored_q = (3 - q[::-1]).astype(np.uint8) if qdir else q       # the volume holds the forward strand
+        qid, sid = len(seqs), len(seqs) + 1
+        seqs += [stored_q, t]
+        for _ in range(3):
+            frac = float(rng.uniform(0.0, 1.0)) if it % 5 else float(rng.integers(0, 2))
+            cand_rows.append((qid, sid, qdir, int(frac * (q.shape[0] - 1)), int(frac * (t.shape[0] - 1)), q, t))
+    sizes = np.array([s.shape[0] for s in seqs], dtype=np.int64)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+    codes = np.concatenate(seqs)
+    vol = ctx.upload_volume(pack_2bit(codes), int(sizes.sum()), offs, sizes)
+    cands = np.zeros(len(cand_rows), dtype=capi.CANDIDATE_DTYPE)
+    for i, (qid, sid, qdir, qoff, soff, q, t) in enumerate(cand_rows):
+        cands[i]["qid"], cands[i]["sid"], cands[i]["qdir"] = qid, sid, qdir
+        cands[i]["qsize"], cands[i]["ssize"], cands[i]["qoff"], cands[i]["soff"] = q.shape[0], t.shape[0], qoff, soff
+    opt = capi.default_options(**dict(util.FAST, job=1, align_size_cutoff=500))
+    al = ora.Aligner(opt.error)
+    n_ok = n_empty = 0
+    for tail in (4, 1):
+        aln, ops, off = ctx.onc_align_batch(vol, vol, 0, 0, cands, opt, tail)
+        for i, (qid, sid, qdir, qoff, soff, q, t) in enumerate(cand_rows):
+            ok, a0, a1, b0, b1, ident, qa, ta = al.align(q, qoff, t, soff, 500, tail)
+            a = aln[i]
+            assert (bool(a["ok"]), int(a["qoff"]), int(a["qend"]), int(a["toff"]), int(a["tend"]), int(a["align_size"]),
+                    float(a["ident_perc"])) == (ok, a0, a1, b0, b1, len(qa), ident), (i, tail)
+            assert capi.gapped_strings(ops[int(off[i]):int(off[i + 1])], q, a0, t, b0) == (qa, ta), (i, tail)
+            n_ok += ok; n_empty += len(qa) == 0
+    al.close(); vol.free()
+    assert n_ok > 200 and n_empty > 10

@@ -64,3 +64,42 @@ def test_volume_writer_matches_oc2mkdb(tmp_path, built):
         assert np.array_equal(x, y)
     assert a[3] == b[3]
     assert open(os.path.join(d, "reads_info.txt")).read() == open(os.path.join(refd, "reads_info.txt")).read()
+
+
+def test_oracle_onc_align_strings_reproduce_golden(built):
+    """onc_align WITH its gapped strings (what the consensus stage consumes): the oracle
+    against vectors produced by the reference's own onc_align (tests/golden/make_golden_onc_align.py)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mk", os.path.join(util.GOLDEN, "make_golden_onc_align.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    gold = json.load(open(os.path.join(util.GOLDEN, "onc_align_a.json")))
+    mine = mk.run("oracle")
+    assert len(mine) == len(gold) == 2 * mk.N_CAND
+    assert mine == gold
+    assert sum(g["ok"] for g in gold) > 100 and any(g["tail"] == 4 for g in gold)
+
+
+@pytest.mark.skipif(not os.path.exists(ora.REF_LIB), reason="oracle/_ref not built (needs /root/reference)")
+def test_oracle_onc_align_matches_reference_on_fresh_pairs(built):
+    """Random overlapping read pairs with anchors anywhere inside the overlap (left AND right extensions of
+    several blocks, failed extensions, anchors at sequence ends), both tail lengths."""
+    import numpy as np
+    from necat_amd.synth import _mutate
+    rng = np.random.default_rng(123)
+    ao, ar = ora.Aligner(0.5, "oracle"), ora.Aligner(0.5, "ref")
+    n = 0
+    for it in range(60):
+        g = rng.integers(0, 4, int(rng.integers(1500, 9000)), dtype=np.uint8)
+        q = _mutate(g, float(rng.uniform(0.03, 0.16)), rng)
+        t = _mutate(g, float(rng.uniform(0.03, 0.16)), rng)
+        if it % 7 == 3:
+            t = rng.integers(0, 4, t.shape[0], dtype=np.uint8)      # unrelated: the extension fails
+        for _ in range(3):
+            frac = float(rng.uniform(0.0, 1.0)) if it % 5 else float(rng.integers(0, 2))
+            qs, ts = int(frac * (q.shape[0] - 1)), int(frac * (t.shape[0] - 1))
+            for tail in (4, 1):
+                assert ao.align(q, qs, t, ts, 500, tail) == ar.align(q, qs, t, ts, 500, tail), (it, qs, ts, tail)
+                n += 1
+    ao.close(); ar.close()
+    assert n == 360
