@@ -668,7 +668,12 @@ int cohort_launch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, C
 
 namespace {
 // outputs of the alignment-keeping mode (necat_onc_align_batch)
-struct AlignOut { necat_alignment* aln = nullptr; std::vector<u8> cols; std::vector<u64> off; };
+struct AlignOut {
+    necat_alignment* aln = nullptr;
+    std::vector<std::pair<u8*, u64>> parts;     // one pinned block of columns per batch
+    u64 total = 0;
+    std::vector<u64> off;
+};
 
 // The extension loop behind necat_extend (M4 records, containment filter) and necat_onc_align_batch
 // (every candidate's alignment with its columns, `ao` != nullptr).
@@ -800,7 +805,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
                 NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
                 std::vector<u64> off(k.n + 1, 0);
                 for (u32 i = 0; i < k.n; ++i) off[i + 1] = off[i] + len[i];
-                const u64 tot = off[k.n], at = ao->cols.size();
+                const u64 tot = off[k.n], at = ao->total;
                 for (u32 i = 0; i < k.n; ++i) ao->off[k.base + i] = at + off[i];
                 ao->off[k.base + k.n] = at + tot;
                 if (tot) {
@@ -811,8 +816,10 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
                     hipLaunchKernelGGL(k_ext_strings, dim3(grid_for((u64)k.n * 64, 256)), dim3(256), 0, k.sa, (const ExtTask*)k.tasks, k.n,
                                        (const u8*)X.task_ops, (const u64*)d_off, d_cols);
                     NECAT_CHECK_LAUNCH(ctx, "k_ext_strings");
-                    ao->cols.resize(at + tot);
-                    NECAT_HIP(ctx, hipMemcpyAsync(ao->cols.data() + at, d_cols, tot, hipMemcpyDeviceToHost, k.sa));
+                    u8* part = (u8*)result_alloc(tot);
+                    if (!part) { cleanup(); return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
+                    ao->parts.emplace_back(part, tot); ao->total += tot;
+                    NECAT_HIP(ctx, hipMemcpyAsync(part, d_cols, tot, hipMemcpyDeviceToHost, k.sa));
                     NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
                 }
                 k.active = false;
@@ -884,12 +891,19 @@ int necat_onc_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_v
     ao.off.assign(n + 1, 0);
     if (n) {
         const int rc = extend_impl(ctx, ref, reads, read_start_id, ref_start_id, cands, n, opt, tail_match_len, nullptr, nullptr, &ao);
-        if (rc) { necat_free(ao.aln); return rc; }
+        if (rc) { necat_free(ao.aln); for (auto& pr : ao.parts) necat_free(pr.first); return rc; }
     }
-    uint8_t* o = (uint8_t*)result_alloc(std::max<size_t>(1, ao.cols.size()));
     uint64_t* f = (uint64_t*)result_alloc((n + 1) * 8);
+    uint8_t* o = nullptr;
+    if (ao.parts.size() == 1) { o = ao.parts[0].first; ao.parts.clear(); }       // the usual case: one batch, no copy
+    else {
+        o = (uint8_t*)result_alloc(std::max<uint64_t>(1, ao.total));
+        uint64_t at = 0;
+        if (o) for (auto& pr : ao.parts) { memcpy(o + at, pr.first, pr.second); at += pr.second; }
+        for (auto& pr : ao.parts) necat_free(pr.first);
+        ao.parts.clear();
+    }
     if (!o || !f) { necat_free(ao.aln); necat_free(o); necat_free(f); return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
-    if (!ao.cols.empty()) memcpy(o, ao.cols.data(), ao.cols.size());
     memcpy(f, ao.off.data(), (n + 1) * 8);
     *aln = ao.aln; *ops = o; *ops_off = f;
     return NECAT_OK;
