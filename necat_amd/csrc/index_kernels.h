@@ -250,6 +250,151 @@ k_rank_buckets(DevVolume vol, int k, const u64* __restrict__ kmer_stats, const u
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// LDS-slice passes (the default for k >= 11).  After the bucket partition (2^18 table entries per
+// bucket) the records of every bucket are split once more by the next 6 hash bits; a sub-bucket then
+// covers a SLICE of 4096 consecutive table entries whose counters fit LDS (16 KB).  One workgroup per
+// slice counts its records with LDS atomics, scans the kept counts, writes its 32 KB of kmer_stats in
+// one coalesced sweep (the table is written exactly once, never zeroed, never re-read), hands every kept
+// record a slot through an LDS cursor and finally ranks the records of multi-occurrence k-mers by
+// offset.  No global atomic and no dense pass over the 4^k table is left.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSubBits = 6, kSubs = 1 << kSubBits;          // sub-buckets per bucket
+constexpr int kSliceBits = 12, kSlice = 1 << kSliceBits;    // table entries per slice
+static_assert(kSubBits + kSliceBits == 18, "a bucket holds 2^18 table entries");
+
+// part -> part2: the records of bucket b regrouped by sub-bucket; sub_start[b * 64 + j] = first record
+// of slice (b, j) in part2 (absolute), sub_start[nb * 64] = number of records
+__global__ void __launch_bounds__(256)
+k_subpart(const u64* __restrict__ part, const u64* __restrict__ bucket_start, u32 nb, u64* __restrict__ part2, u64* __restrict__ sub_start)
+{
+    __shared__ u32 hist[4][kSubs], base[4][kSubs];
+    const u32 b = blockIdx.x;
+    const u64 lo = bucket_start[b], hi = bucket_start[b + 1];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    hist[w][lane] = 0;
+    __syncthreads();
+    // wave w owns the 64-record chunks w, w + 4, ...: it counts and later scatters the same records
+    for (u64 e0 = lo + (u64)w * 64; e0 < hi; e0 += 256) {
+        const u64 e = e0 + lane;
+        if (e < hi) atomicAdd(&hist[w][(u32)(part[e] >> (kOffsetBits + kSliceBits)) & (kSubs - 1)], 1u);
+    }
+    __syncthreads();
+    if (w == 0) {
+        const u32 c0 = hist[0][lane], c1 = hist[1][lane], c2 = hist[2][lane], c3 = hist[3][lane];
+        const u32 tot = c0 + c1 + c2 + c3;
+        u32 incl = tot;
+        for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        const u32 ex = incl - tot;
+        base[0][lane] = ex; base[1][lane] = ex + c0; base[2][lane] = ex + c0 + c1; base[3][lane] = ex + c0 + c1 + c2;
+        sub_start[(u64)b * kSubs + lane] = lo + ex;
+        if (b == nb - 1 && lane == 0) sub_start[(u64)nb * kSubs] = hi;
+    }
+    __syncthreads();
+    for (u64 e0 = lo + (u64)w * 64; e0 < hi; e0 += 256) {
+        const u64 e = e0 + lane;
+        if (e < hi) {
+            const u64 rec = part[e];
+            part2[lo + atomicAdd(&base[w][(u32)(rec >> (kOffsetBits + kSliceBits)) & (kSubs - 1)], 1u)] = rec;
+        }
+    }
+}
+
+NECAT_D void slice_count(const u64* __restrict__ part2, u64 lo, u64 hi, u32* cnt)
+{
+    for (int i = threadIdx.x; i < kSlice; i += 256) cnt[i] = 0;
+    __syncthreads();
+    for (u64 e = lo + threadIdx.x; e < hi; e += 256) atomicAdd(&cnt[(u32)(part2[e] >> kOffsetBits) & (kSlice - 1)], 1u);
+    __syncthreads();
+}
+
+// kept_tot[s] = number of offset-list entries slice s contributes (k-mers with 1..max_occ occurrences)
+__global__ void __launch_bounds__(256)
+k_slice_count(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u32 max_occ, u32* __restrict__ kept_tot)
+{
+    __shared__ u32 cnt[kSlice];
+    __shared__ u32 red[4];
+    const u64 s = blockIdx.x;
+    slice_count(part2, sub_start[s], sub_start[s + 1], cnt);
+    u32 sum = 0;
+    for (int i = threadIdx.x; i < kSlice; i += 256) sum += filtered_count(cnt[i], max_occ);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) kept_tot[s] = red[0] + red[1] + red[2] + red[3];
+}
+
+// exclusive scan of kept_tot[n] -> slice_base[n + 1] (u64)
+__global__ void __launch_bounds__(1024)
+k_slice_scan(const u32* __restrict__ kept_tot, u64 n, u64* __restrict__ slice_base)
+{
+    __shared__ u64 sh[1024];
+    const u64 per = (n + 1023) / 1024;
+    const u64 lo = (u64)threadIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+    u64 s = 0;
+    for (u64 i = lo; i < hi; ++i) s += kept_tot[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) { u64 run = 0; for (int i = 0; i < 1024; ++i) { const u64 v = sh[i]; sh[i] = run; run += v; } slice_base[n] = run; }
+    __syncthreads();
+    u64 run = sh[threadIdx.x];
+    for (u64 i = lo; i < hi; ++i) { slice_base[i] = run; run += kept_tot[i]; }
+}
+
+// kmer_stats of the slice + its part of the offset list (tmp: same layout, order inside a k-mer not yet fixed)
+__global__ void __launch_bounds__(256)
+k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u32 max_occ, const u64* __restrict__ slice_base,
+             u64* __restrict__ kmer_stats, u32* __restrict__ tmp, u64* __restrict__ offset_list)
+{
+    __shared__ u32 cnt[kSlice];      // occurrences per table entry of the slice
+    __shared__ u32 cur[kSlice];      // start of the entry's group inside the slice, then its fill cursor
+    __shared__ u32 wtot[4];
+    const u64 s = blockIdx.x;
+    const u64 lo = sub_start[s], hi = sub_start[s + 1];
+    const u64 base = slice_base[s];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    slice_count(part2, lo, hi, cnt);
+    // exclusive scan of the kept counts: thread t owns entries [16 t, 16 t + 16)
+    u32 c[16], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { c[i] = filtered_count(cnt[threadIdx.x * 16 + i], max_occ); sum += c[i]; }
+    u32 incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    u32 run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += wtot[w];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { cur[threadIdx.x * 16 + i] = run; run += c[i]; }
+    __syncthreads();
+    // kmer_stats[h] = cnt<<34 | start, 0 for absent / over-represented k-mers (lookup_table.c:43-51, :94-113)
+    u64* stats = kmer_stats + s * kSlice;
+    for (int i = threadIdx.x; i < kSlice; i += 256) {
+        const u32 k = filtered_count(cnt[i], max_occ);
+        stats[i] = k ? ((u64)k << kOffsetBits) | (base + cur[i]) : 0ULL;
+    }
+    __syncthreads();
+    for (u64 e = lo + threadIdx.x; e < hi; e += 256) {
+        const u64 rec = part2[e];
+        const u32 h = (u32)(rec >> kOffsetBits) & (kSlice - 1);
+        if (filtered_count(cnt[h], max_occ)) tmp[base + atomicAdd(&cur[h], 1u)] = (u32)(rec & kOffsetMask);
+    }
+    __syncthreads();        // cur[h] is now the END of the group; the tmp writes of this workgroup are visible to it
+    // radix_sort is stable (hash_list_bucket_sort.c:134): offsets ascend inside a k-mer
+    for (u64 e = lo + threadIdx.x; e < hi; e += 256) {
+        const u64 rec = part2[e];
+        const u32 h = (u32)(rec >> kOffsetBits) & (kSlice - 1);
+        const u32 k = filtered_count(cnt[h], max_occ);
+        if (!k) continue;
+        const u32 p = (u32)(rec & kOffsetMask);
+        const u64 st = base + cur[h] - k;
+        u32 rank = 0;
+        if (k > 1) for (u32 j = 0; j < k; ++j) rank += tmp[st + j] < p;
+        offset_list[st + rank] = (u64)p;
+    }
+}
+
 // NECAT pac (first base of a byte in its top two bits) -> little-endian 2-bit words
 __global__ void __launch_bounds__(256)
 k_repack(const u64* __restrict__ pac_words, u64 nwords, u64* __restrict__ out)

@@ -47,6 +47,7 @@ DevVolume dev_view(const necat_volume* v)
 // "always"; NECAT_COOP_THRESHOLD=0 selects the lane-per-block kernel (tests compare the two).
 u32 g_coop_threshold = 0xffffffffu;
 unsigned long long g_seed_budget = 48ULL << 20;   // seeding scratch budget per chunk, in k-mer hits
+int g_index_lds = 1;          // LDS-slice index passes (0: global-atomic bucket passes)
 int g_seed_wave = 1;          // wave-per-strand seed collection (0: the lane-per-strand kernel)
 int g_trace = 0;
 int g_antiphase = 1;
@@ -81,6 +82,7 @@ int necat_ctx_create(int device_id, necat_ctx** out)
     if (hipSetDevice(device_id) != hipSuccess) return NECAT_ERR_DEVICE;
     necat_ctx* ctx = new necat_ctx();
     ctx->device = device_id;
+    if (const char* e = getenv("NECAT_INDEX_LDS")) g_index_lds = atoi(e);
     if (const char* e = getenv("NECAT_SEED_WAVE")) g_seed_wave = atoi(e);
     g_seed_budget = 48ULL << 20;
     if (const char* e = getenv("NECAT_SEED_BUDGET")) g_seed_budget = strtoull(e, nullptr, 10);
@@ -251,20 +253,24 @@ int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, in
     necat_index* ix = new necat_index();
     ix->k = kmer_size; ix->table_entries = T;
     int rc;
-    if ((rc = buf_ensure(ctx, ctx->scratch[SC_CNT32], T * 4)) || (rc = buf_ensure(ctx, ctx->scratch[SC_PARTIAL], (ntiles + 1) * 8))) { delete ix; return rc; }
-    u32* cnt32 = (u32*)ctx->scratch[SC_CNT32].p;
-    u64* partial = (u64*)ctx->scratch[SC_PARTIAL].p;
-    if (ctx->idx_cache[0].p && ctx->idx_cache[0].cap >= T * 8) { ix->kmer_stats = (uint64_t*)ctx->idx_cache[0].p; ix->stats_cap = ctx->idx_cache[0].cap; ctx->idx_cache[0] = DevBuf(); }
-    else { NECAT_HIP(ctx, hipMalloc((void**)&ix->kmer_stats, T * 8)); ix->stats_cap = T * 8; }
-    NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
-    NECAT_HIP(ctx, hipMemsetAsync(cnt32, 0, T * 4, s));
-    const uint64_t nchunks = (ref->nbases + kPosPerThread - 1) / kPosPerThread;
-    const unsigned pass_grid = grid_for(nchunks, 256, 1u << 16);
     // partition parameters: buckets of <= 2^18 table entries (1 MB of counters), at most 4096 buckets
     int PB = 2 * kmer_size - 18; if (PB > 12) PB = 12;
     const bool partitioned = PB >= 4 && ref->nbases > 0;
+    const bool lds_slices = partitioned && g_index_lds;
     const u32 NB = partitioned ? (1u << PB) : 0u;
     const int pshift = 2 * kmer_size - PB;
+    u32* cnt32 = nullptr; u64* partial = nullptr;
+    if (!lds_slices) {
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_CNT32], T * 4)) || (rc = buf_ensure(ctx, ctx->scratch[SC_PARTIAL], (ntiles + 1) * 8))) { delete ix; return rc; }
+        cnt32 = (u32*)ctx->scratch[SC_CNT32].p;
+        partial = (u64*)ctx->scratch[SC_PARTIAL].p;
+    }
+    if (ctx->idx_cache[0].p && ctx->idx_cache[0].cap >= T * 8) { ix->kmer_stats = (uint64_t*)ctx->idx_cache[0].p; ix->stats_cap = ctx->idx_cache[0].cap; ctx->idx_cache[0] = DevBuf(); }
+    else { NECAT_HIP(ctx, hipMalloc((void**)&ix->kmer_stats, T * 8)); ix->stats_cap = T * 8; }
+    NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
+    if (!lds_slices) NECAT_HIP(ctx, hipMemsetAsync(cnt32, 0, T * 4, s));
+    const uint64_t nchunks = (ref->nbases + kPosPerThread - 1) / kPosPerThread;
+    const unsigned pass_grid = grid_for(nchunks, 256, 1u << 16);
     u32* d_bcnt = nullptr; u64* d_bstart = nullptr; u64* d_bcur = nullptr; u64* d_part = nullptr;
     u32 bchunks = 1;
     if (partitioned) {
@@ -281,6 +287,34 @@ int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, in
         NECAT_CHECK_LAUNCH(ctx, "k_bucket_scan");
         hipLaunchKernelGGL(k_part_pass<1>, dim3(pgrid), dim3(kPartThreads), NB * 4 + NB * 8, s, vol, kmer_size, pshift, NB, d_bcnt, d_bcur, d_part);
         NECAT_CHECK_LAUNCH(ctx, "k_part_pass<scatter>");
+    }
+    uint64_t n_off = 0;
+    if (lds_slices) {
+        // ---- second split + one workgroup per 4096-entry slice of the table (index_kernels.h)
+        const u64 nsub = (u64)NB * kSubs;
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_PART2], (ref->nbases + 1) * 8 + (nsub + 1) * 16 + nsub * 4 + 256))) { necat_index_free(ctx, ix); return rc; }
+        char* pb = (char*)ctx->scratch[SC_PART2].p;
+        u64* d_part2 = (u64*)pb; pb += (ref->nbases + 1) * 8;
+        u64* d_sub = (u64*)pb; pb += (nsub + 1) * 8;
+        u64* d_sbase = (u64*)pb; pb += (nsub + 1) * 8;
+        u32* d_kept = (u32*)pb;
+        hipLaunchKernelGGL(k_subpart, dim3(NB), dim3(256), 0, s, (const u64*)d_part, (const u64*)d_bstart, NB, d_part2, d_sub);
+        NECAT_CHECK_LAUNCH(ctx, "k_subpart");
+        hipLaunchKernelGGL(k_slice_count, dim3((unsigned)nsub), dim3(256), 0, s, (const u64*)d_part2, (const u64*)d_sub, (u32)max_occ, d_kept);
+        NECAT_CHECK_LAUNCH(ctx, "k_slice_count");
+        hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, s, (const u32*)d_kept, nsub, d_sbase);
+        NECAT_CHECK_LAUNCH(ctx, "k_slice_scan");
+        NECAT_HIP(ctx, hipMemcpyAsync(&n_off, d_sbase + nsub, 8, hipMemcpyDeviceToHost, s));
+        NECAT_HIP(ctx, hipStreamSynchronize(s));
+        ix->n_offsets = n_off;
+        if (ctx->idx_cache[1].p && ctx->idx_cache[1].cap >= (n_off + 1) * 8) { ix->offset_list = (uint64_t*)ctx->idx_cache[1].p; ix->offs_cap = ctx->idx_cache[1].cap; ctx->idx_cache[1] = DevBuf(); }
+        else { NECAT_HIP(ctx, hipMalloc((void**)&ix->offset_list, (n_off + 1) * 8 + (n_off >> 4))); ix->offs_cap = (n_off + 1) * 8 + (n_off >> 4); }
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_TMPLIST], (n_off + 1) * 4))) { necat_index_free(ctx, ix); return rc; }
+        hipLaunchKernelGGL(k_slice_emit, dim3((unsigned)nsub), dim3(256), 0, s, (const u64*)d_part2, (const u64*)d_sub, (u32)max_occ, (const u64*)d_sbase,
+                           ix->kmer_stats, (u32*)ctx->scratch[SC_TMPLIST].p, ix->offset_list);
+        NECAT_CHECK_LAUNCH(ctx, "k_slice_emit");
+    } else {
+    if (partitioned) {
         const u64 avg = ref->nbases / NB + 1;
         bchunks = (u32)std::max<u64>(1, (avg + kBucketChunk - 1) / kBucketChunk);
         hipLaunchKernelGGL(k_bucket_pass<0>, dim3(NB * bchunks), dim3(256), 0, s, (const u64*)d_part, (const u64*)d_bstart, NB, bchunks, cnt32, (u64)0, (u64*)nullptr);
@@ -295,7 +329,6 @@ int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, in
     NECAT_CHECK_LAUNCH(ctx, "k_scan_partials");
     hipLaunchKernelGGL(k_write_stats, dim3((unsigned)ntiles), dim3(256), 0, s, cnt32, T, (u32)max_occ, partial, ix->kmer_stats);
     NECAT_CHECK_LAUNCH(ctx, "k_write_stats");
-    uint64_t n_off = 0;
     NECAT_HIP(ctx, hipMemcpyAsync(&n_off, partial + ntiles, 8, hipMemcpyDeviceToHost, s));
     NECAT_HIP(ctx, hipStreamSynchronize(s));
     ix->n_offsets = n_off;
@@ -313,6 +346,7 @@ int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, in
         }
         hipLaunchKernelGGL(k_rank_buckets, dim3(grid_for(n_off, 256, 1u << 16)), dim3(256), 0, s, vol, kmer_size, (const u64*)ix->kmer_stats, (const u64*)tmp, n_off, ix->offset_list);
         NECAT_CHECK_LAUNCH(ctx, "k_rank_buckets");
+    }
     }
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s));
     NECAT_HIP(ctx, hipStreamSynchronize(s));

@@ -27,9 +27,10 @@ def multi(tmp_path_factory):
 
 
 def test_index_matches_oracle(ctx, small):
+    """k = 8: direct passes; k = 11..13: bucket partition + LDS slices (16..256 buckets); cutoffs 500 / 50 / 1."""
     d, rs = small
     vol = ctx.load_volume(os.path.join(d, "vol0"))
-    for k, q in ((11, 50), (13, 500)):
+    for k, q in ((11, 50), (13, 500), (8, 500), (12, 1)):
         ix = ctx.build_index(vol, k, q)
         stats, offs = ix.download()
         ostats, ooffs = ora.build_index(os.path.join(d, "vol0"), k, q)
@@ -341,3 +342,24 @@ def test_onc_align_arbitrary_anchors(ctx):
             n_ok += ok; n_empty += len(qa) == 0
     al.close(); vol.free()
     assert n_ok > 200 and n_empty > 10
+
+
+def test_index_lds_slices_equal_global_atomic_passes(small):
+    """Two implementations of the partitioned index build (LDS slices, the default; global-atomic bucket
+    passes) must give the same arrays; k = 15 (4096 buckets x 64 slices, the bench configuration) is too big
+    for the CPU oracle in a test, so it is checked this way and end-to-end by the E. coli golden records."""
+    from necat_amd import capi
+    d, rs = small
+    out = []
+    for env in ("1", "0"):
+        os.environ["NECAT_INDEX_LDS"] = env
+        try:
+            c = capi.Context(0)
+        finally:
+            os.environ.pop("NECAT_INDEX_LDS", None)
+        vol = c.load_volume(os.path.join(d, "vol0"))
+        ix = c.build_index(vol, 15, 500)
+        out.append(ix.download())
+        ix.free(); vol.free(); c.close()
+    assert np.array_equal(out[0][1], out[1][1]) and out[0][1].shape[0] > 1_000_000
+    assert np.array_equal(out[0][0], out[1][0])
