@@ -616,8 +616,13 @@ int cohort_retire(necat_ctx* ctx, Cohort& c)
     ctx->tm.myers_ms += mA + mB;
     ctx->tm.traceback_ms += tA + tB;
     if (c.nA) { ctx->tm.myersA_ms += mA; ctx->tm.tracebackA_ms += tA; ctx->tm.myersA_launches += 1; ctx->tm.myersA_blocks += c.nA; }
-    if (g_trace & 1) fprintf(stderr, "[necat] cohort@%lu round %3lu: nA=%7u nB=%7u myers %.3f + %.3f ms traceback %.3f + %.3f ms\n",
-                         (unsigned long)c.base, (unsigned long)ctx->tm.rounds, c.nA, c.nB, mA, mB, tA, tB);
+    if (g_trace & 1) {
+        static double last = 0;
+        const double now = wall_ms();
+        fprintf(stderr, "[necat] cohort@%lu round %3lu: nA=%7u nB=%7u myers %.3f + %.3f ms traceback %.3f + %.3f ms | round wall %.3f ms\n",
+                (unsigned long)c.base, (unsigned long)ctx->tm.rounds, c.nA, c.nB, mA, mB, tA, tB, now - last);
+        last = now;
+    }
     ctx->tm.myers_launches += (c.nA ? 1 : 0) + (c.nB ? 1 : 0);
     ctx->tm.myers_blocks += c.nA + c.nB;
     ctx->tm.rounds += 1;
