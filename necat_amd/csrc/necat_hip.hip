@@ -439,8 +439,8 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
     NECAT_HIP(ctx, hipMemsetAsync(d_err, 0, 4, s));
     u32 pos = 0;
     std::vector<i32> ncands_by_order(nreads, 0);
-    // storage of every chunk's compacted candidates in ORDER-index space
-    std::vector<necat_candidate> packed_all;
+    // every chunk's compacted candidates stay on the device (SC_SEED_ALL), in ORDER-index space
+    u64 packed_total = 0;
     std::vector<u64> packed_off(nreads + 1, 0);
     while (pos < nreads) {
         u64 acc = 0; u32 hi = pos;
@@ -534,45 +534,55 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
             *out = res; *n_out = tot;
             return NECAT_OK;
         }
+        // several chunks: pack this chunk's candidates behind the earlier ones, on the device
         std::vector<u64> foff(n + 1, 0);
         for (u32 i = 0; i < n; ++i) foff[i + 1] = foff[i] + (u64)nc[i];
         const u64 tot = foff[n];
-        const size_t base = packed_all.size();
-        packed_all.resize(base + tot);
         if (tot) {
-            if ((rc = buf_ensure(ctx, ctx->scratch[SC_SEED_FINAL], tot * sizeof(necat_candidate)))) { (void)hipFree(d_err); return rc; }
-            necat_candidate* d_dst = (necat_candidate*)ctx->scratch[SC_SEED_FINAL].p;
+            if ((rc = buf_grow(ctx, ctx->scratch[SC_SEED_ALL], (packed_total + tot) * sizeof(necat_candidate), packed_total * sizeof(necat_candidate), s))) { (void)hipFree(d_err); return rc; }
+            necat_candidate* d_dst = (necat_candidate*)ctx->scratch[SC_SEED_ALL].p + packed_total;
             NECAT_HIP(ctx, hipMemcpyAsync(d_final, foff.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_pack_cands, dim3(grid_for((u64)n * 64, 256)), dim3(256), 0, s, (const DevCand*)A.out, (const SeedMeta*)d_meta,
                                (const i32*)d_ncand, (const u64*)d_final, n, read_start_id, ref_start_id, d_dst);
             NECAT_CHECK_LAUNCH(ctx, "k_pack_cands");
-            NECAT_HIP(ctx, hipMemcpyAsync(packed_all.data() + base, d_dst, tot * sizeof(necat_candidate), hipMemcpyDeviceToHost, s));
-            NECAT_HIP(ctx, hipStreamSynchronize(s));
+            NECAT_HIP(ctx, hipStreamSynchronize(s));       // foff / nc are host vectors of this iteration
         }
-        for (u32 i = 0; i < n; ++i) { ncands_by_order[pos + i] = nc[i]; packed_off[pos + i] = base + foff[i]; }
-        tick("pack + copy to host");
+        for (u32 i = 0; i < n; ++i) { ncands_by_order[pos + i] = nc[i]; packed_off[pos + i] = packed_total + foff[i]; }
+        packed_total += tot;
+        tick("pack");
         pos = hi;
     }
-#ifdef NECAT_SEED_PROF
-    { unsigned long long hp[16]; (void)hipMemcpyFromSymbol(hp, HIP_SYMBOL(g_seed_prof), sizeof(hp)); fprintf(stderr, "[seedprof]"); for (int q = 0; q < 12; ++q) fprintf(stderr, " %llu", hp[q]); fprintf(stderr, "\n"); }
-#endif
     (void)hipFree(d_err);
-    NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s));
-    NECAT_HIP(ctx, hipStreamSynchronize(s));
-    ctx->tm.seed_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
-    // ---- assemble in ascending read id
-    std::vector<u32> inv(nreads);
-    for (u32 i = 0; i < nreads; ++i) inv[order[i]] = i;
-    u64 total = packed_all.size();
+    // ---- ascending read id: one move on the device, one copy into the (pinned) result block
+    const u64 total = packed_total;
     necat_candidate* res = (necat_candidate*)result_alloc(std::max<u64>(1, total) * sizeof(necat_candidate));
     if (!res) return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed");
-    u64 w = 0;
-    for (u32 r = 0; r < nreads; ++r) {
-        const u32 i = inv[r];
-        const i32 c = ncands_by_order[i];
-        if (c) memcpy(res + w, packed_all.data() + packed_off[i], (size_t)c * sizeof(necat_candidate));
-        w += (u64)c;
-    }
+    if (total) {
+        std::vector<u64> by_read((size_t)nreads + 1, 0), dst_off(nreads);
+        for (u32 i = 0; i < nreads; ++i) by_read[order[i] + 1] = (u64)ncands_by_order[i];
+        for (u32 r = 0; r < nreads; ++r) by_read[r + 1] += by_read[r];
+        for (u32 i = 0; i < nreads; ++i) dst_off[i] = by_read[order[i]];
+        int rc2;
+        if ((rc2 = buf_ensure(ctx, ctx->scratch[SC_SEED_FINAL], total * sizeof(necat_candidate))) ||
+            (rc2 = buf_ensure(ctx, ctx->scratch[SC_SEED_META], (size_t)nreads * 20 + 64))) { necat_free(res); return rc2; }
+        char* mb = (char*)ctx->scratch[SC_SEED_META].p;
+        u64* d_src = (u64*)mb; mb += (size_t)nreads * 8;
+        u64* d_dsto = (u64*)mb; mb += (size_t)nreads * 8;
+        i32* d_cnt = (i32*)mb;
+        necat_candidate* d_fin = (necat_candidate*)ctx->scratch[SC_SEED_FINAL].p;
+        hipError_t e[7];
+        e[0] = hipMemcpyAsync(d_src, packed_off.data(), (size_t)nreads * 8, hipMemcpyHostToDevice, s);
+        e[1] = hipMemcpyAsync(d_dsto, dst_off.data(), (size_t)nreads * 8, hipMemcpyHostToDevice, s);
+        e[2] = hipMemcpyAsync(d_cnt, ncands_by_order.data(), (size_t)nreads * 4, hipMemcpyHostToDevice, s);
+        hipLaunchKernelGGL(k_move_cands, dim3(grid_for((u64)nreads * 64, 256)), dim3(256), 0, s, (const necat_candidate*)ctx->scratch[SC_SEED_ALL].p,
+                           (const u64*)d_src, (const u64*)d_dsto, (const i32*)d_cnt, nreads, d_fin);
+        e[3] = hipGetLastError();
+        e[4] = hipMemcpyAsync(res, d_fin, total * sizeof(necat_candidate), hipMemcpyDeviceToHost, s);
+        e[5] = hipEventRecord(ctx->ev[1], s);
+        e[6] = hipStreamSynchronize(s);
+        for (hipError_t x : e) if (x != hipSuccess) { necat_free(res); return set_err(ctx, NECAT_ERR_DEVICE, "seeding result assembly: %s", hipGetErrorString(x)); }
+    } else { NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s)); NECAT_HIP(ctx, hipStreamSynchronize(s)); }
+    ctx->tm.seed_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
     tick("assemble in read order");
     *out = res; *n_out = total;
     return NECAT_OK;

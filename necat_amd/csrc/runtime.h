@@ -87,11 +87,29 @@ inline int buf_ensure(necat_ctx* ctx, DevBuf& b, size_t bytes)
     return NECAT_OK;
 }
 
+// grow keeping the first `keep` bytes (device-to-device copy; capacity doubles)
+inline int buf_grow(necat_ctx* ctx, DevBuf& b, size_t bytes, size_t keep, hipStream_t s)
+{
+    if (bytes <= b.cap) return NECAT_OK;
+    size_t want = bytes > 2 * b.cap ? bytes + bytes / 8 + 256 : 2 * b.cap;
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, want);
+    if (e != hipSuccess) return set_err(ctx, NECAT_ERR_MEMORY, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    if (b.p && keep) {
+        e = hipMemcpyAsync(q, b.p, keep, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { (void)hipFree(q); return set_err(ctx, NECAT_ERR_DEVICE, "device copy failed: %s", hipGetErrorString(e)); }
+    }
+    if (b.p) (void)hipFree(b.p);
+    b.p = q; b.cap = want;
+    return NECAT_OK;
+}
+
 enum ScratchId {
     SC_CNT32 = 0, SC_PARTIAL, SC_TMPLIST, SC_MISC,
     SC_SEED_META, SC_SEED_HT, SC_SEED_POOL, SC_SEED_CHAIN, SC_SEED_OUT, SC_SEED_FINAL,
     SC_EXT_TASKS, SC_EXT_LISTS, SC_EXT_FRAG, SC_EXT_MAT, SC_EXT_OPS, SC_EXT_RES, SC_EXT_CAND, SC_SMALL, SC_PART,
-    SC_EXT_COLS, SC_EXT_COLS_OUT, SC_PART2
+    SC_EXT_COLS, SC_EXT_COLS_OUT, SC_PART2, SC_SEED_ALL
 };
 
 }  // namespace necat

@@ -421,3 +421,19 @@ k_pack_cands(const DevCand* __restrict__ out, const SeedMeta* __restrict__ meta,
 }
 
 }  // namespace necat
+
+namespace necat {
+// several seeding chunks: candidates were packed chunk by chunk (reads in work order); move every read's
+// run to its place in ascending read order.  One wave per read.
+__global__ void __launch_bounds__(256)
+k_move_cands(const necat_candidate* __restrict__ src, const u64* __restrict__ src_off, const u64* __restrict__ dst_off,
+             const i32* __restrict__ cnt, u32 n, necat_candidate* __restrict__ dst)
+{
+    const u32 wave = (u32)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wave >= n) return;
+    const necat_candidate* a = src + src_off[wave];
+    necat_candidate* b = dst + dst_off[wave];
+    for (int j = lane; j < cnt[wave]; j += 64) b[j] = a[j];
+}
+}  // namespace necat
