@@ -55,11 +55,13 @@ struct ExtLists {
     u8* task_ops = nullptr;   // per-task alignment columns (necat_onc_align_batch), nullptr = not kept
 };
 
-// Append the scheduled block of task `ti` to list A (full 512 x 512 blocks) or list B (the
-// variable-size last block of an extension); one atomic per wave and list (ballot-aggregated).
+// Append the scheduled block of task `ti` to list A (blocks of at most 512 x 512: the full blocks of an
+// extension and the last blocks that fit - 8 words, 8 lanes per block) or list B (bigger last blocks, up to
+// 794 x 794 - 13 words, 16 lanes per block: 3x the cost, so nothing that fits list A goes here);
+// one atomic per wave and list (ballot-aggregated).
 NECAT_D void ext_append_block(const ExtTask& t, u32 ti, bool go, const ExtLists& L)
 {
-    const bool isA = go && !t.last && t.qblk == kOcaBlockSize && t.tblk == kOcaBlockSize;
+    const bool isA = go && t.qblk <= kOcaBlockSize && t.tblk <= kOcaBlockSize;
     const bool isB = go && !isA;
     const int lane = (int)(threadIdx.x & 63);
     const u64 below = (1ULL << lane) - 1ULL;

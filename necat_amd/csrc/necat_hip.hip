@@ -671,7 +671,7 @@ int cohort_launch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, C
             hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((nA + 7) / 8), dim3(64), 0, c.sa, itA, nA,
                                (const u64*)c.fragA, c.slabs, kSlabA, X.error, c.resA, X.stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
         else
-            hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(gA), dim3(64), 0, c.sa, itA, nA,
+            hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, false>), dim3(gA), dim3(64), 0, c.sa, itA, nA,   // list A also holds last blocks <= 512 x 512
                                (const u64*)c.fragA, c.slabs, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
         NECAT_CHECK_LAUNCH(ctx, "k_myers<A>");
         NECAT_HIP(ctx, hipEventRecord(c.a1, c.sa));
