@@ -309,8 +309,9 @@ NECAT_D void slice_count(const u64* __restrict__ part2, u64 lo, u64 hi, u32* cnt
 }
 
 // kept_tot[s] = number of offset-list entries slice s contributes (k-mers with 1..max_occ occurrences)
+// (+ the same summed per bucket, so that the scan that follows runs over <= 4096 values, not 262 144)
 __global__ void __launch_bounds__(256)
-k_slice_count(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u32 max_occ, u32* __restrict__ kept_tot)
+k_slice_count(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u32 max_occ, u32* __restrict__ kept_tot, u32* __restrict__ bucket_kept)
 {
     __shared__ u32 cnt[kSlice];
     __shared__ u32 red[4];
@@ -321,38 +322,46 @@ k_slice_count(const u64* __restrict__ part2, const u64* __restrict__ sub_start, 
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
     __syncthreads();
-    if (threadIdx.x == 0) kept_tot[s] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) { const u32 t = red[0] + red[1] + red[2] + red[3]; kept_tot[s] = t; if (t) atomicAdd(&bucket_kept[s >> kSubBits], t); }
 }
 
-// exclusive scan of kept_tot[n] -> slice_base[n + 1] (u64)
+// exclusive scan of bucket_kept[nb] (nb <= 4096) -> bucket_base[nb + 1] (u64)
 __global__ void __launch_bounds__(1024)
-k_slice_scan(const u32* __restrict__ kept_tot, u64 n, u64* __restrict__ slice_base)
+k_bucket_base(const u32* __restrict__ bucket_kept, u32 nb, u64* __restrict__ bucket_base)
 {
     __shared__ u64 sh[1024];
-    const u64 per = (n + 1023) / 1024;
-    const u64 lo = (u64)threadIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+    const u32 per = (nb + 1023) / 1024;
+    const u32 lo = threadIdx.x * per, hi = (lo + per < nb) ? lo + per : nb;
     u64 s = 0;
-    for (u64 i = lo; i < hi; ++i) s += kept_tot[i];
+    for (u32 i = lo; i < hi; ++i) s += bucket_kept[i];
     sh[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x == 0) { u64 run = 0; for (int i = 0; i < 1024; ++i) { const u64 v = sh[i]; sh[i] = run; run += v; } slice_base[n] = run; }
-    __syncthreads();
-    u64 run = sh[threadIdx.x];
-    for (u64 i = lo; i < hi; ++i) { slice_base[i] = run; run += kept_tot[i]; }
+    for (int o = 1; o < 1024; o <<= 1) { const u64 v = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0ULL; __syncthreads(); sh[threadIdx.x] += v; __syncthreads(); }
+    u64 run = sh[threadIdx.x] - s;
+    for (u32 i = lo; i < hi; ++i) { bucket_base[i] = run; run += bucket_kept[i]; }
+    if (threadIdx.x == 1023) bucket_base[nb] = sh[1023];
 }
 
 // kmer_stats of the slice + its part of the offset list (tmp: same layout, order inside a k-mer not yet fixed)
 __global__ void __launch_bounds__(256)
-k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u32 max_occ, const u64* __restrict__ slice_base,
-             u64* __restrict__ kmer_stats, u32* __restrict__ tmp, u64* __restrict__ offset_list)
+k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u32 max_occ, const u64* __restrict__ bucket_base,
+             const u32* __restrict__ kept_tot, u64* __restrict__ kmer_stats, u32* __restrict__ tmp, u64* __restrict__ offset_list)
 {
     __shared__ u32 cnt[kSlice];      // occurrences per table entry of the slice
     __shared__ u32 cur[kSlice];      // start of the entry's group inside the slice, then its fill cursor
     __shared__ u32 wtot[4];
+    __shared__ u64 s_base;
     const u64 s = blockIdx.x;
     const u64 lo = sub_start[s], hi = sub_start[s + 1];
-    const u64 base = slice_base[s];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave == 0) {                 // the slice's base = its bucket's base + the kept totals of the bucket's earlier slices
+        const u32 j = (u32)s & (kSubs - 1);
+        u64 before = (u32)lane < j ? (u64)kept_tot[(s & ~(u64)(kSubs - 1)) + lane] : 0ULL;
+        for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o);
+        if (lane == 0) s_base = bucket_base[s >> kSubBits] + before;
+    }
+    __syncthreads();
+    const u64 base = s_base;
     slice_count(part2, lo, hi, cnt);
     // exclusive scan of the kept counts: thread t owns entries [16 t, 16 t + 16)
     u32 c[16], sum = 0;

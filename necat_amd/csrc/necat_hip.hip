@@ -145,7 +145,7 @@ struct ResultPool {
     std::vector<std::pair<void*, size_t>> parked;         // never released at exit: the HIP runtime may be gone by then
 };
 ResultPool g_results;
-constexpr size_t kPinnedMin = 256 << 10, kPoolBlocks = 6;
+constexpr size_t kPinnedMin = 256 << 10, kPoolBlocks = 6, kPoolBytes = (size_t)6 << 30;   // parked: <= 6 blocks, <= 6 GiB
 
 void* result_alloc(size_t bytes)
 {
@@ -176,7 +176,9 @@ void necat_free(void* p)
         if (it != g_results.live.end()) {
             const size_t sz = it->second;
             g_results.live.erase(it);
-            if (g_results.parked.size() < kPoolBlocks) g_results.parked.emplace_back(p, sz);
+            size_t held = sz;
+            for (auto& b : g_results.parked) held += b.second;
+            if (g_results.parked.size() < kPoolBlocks && held <= kPoolBytes) g_results.parked.emplace_back(p, sz);
             else (void)hipHostFree(p);
             return;
         }
@@ -296,21 +298,22 @@ int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, in
         char* pb = (char*)ctx->scratch[SC_PART2].p;
         u64* d_part2 = (u64*)pb; pb += (ref->nbases + 1) * 8;
         u64* d_sub = (u64*)pb; pb += (nsub + 1) * 8;
-        u64* d_sbase = (u64*)pb; pb += (nsub + 1) * 8;
+        u64* d_bbase = (u64*)pb; pb += (nsub + 1) * 8;          // [NB + 1] used
         u32* d_kept = (u32*)pb;
         hipLaunchKernelGGL(k_subpart, dim3(NB), dim3(256), 0, s, (const u64*)d_part, (const u64*)d_bstart, NB, d_part2, d_sub);
         NECAT_CHECK_LAUNCH(ctx, "k_subpart");
-        hipLaunchKernelGGL(k_slice_count, dim3((unsigned)nsub), dim3(256), 0, s, (const u64*)d_part2, (const u64*)d_sub, (u32)max_occ, d_kept);
+        NECAT_HIP(ctx, hipMemsetAsync(d_bcnt, 0, (size_t)NB * 4, s));                // reused: kept entries per bucket
+        hipLaunchKernelGGL(k_slice_count, dim3((unsigned)nsub), dim3(256), 0, s, (const u64*)d_part2, (const u64*)d_sub, (u32)max_occ, d_kept, d_bcnt);
         NECAT_CHECK_LAUNCH(ctx, "k_slice_count");
-        hipLaunchKernelGGL(k_slice_scan, dim3(1), dim3(1024), 0, s, (const u32*)d_kept, nsub, d_sbase);
-        NECAT_CHECK_LAUNCH(ctx, "k_slice_scan");
-        NECAT_HIP(ctx, hipMemcpyAsync(&n_off, d_sbase + nsub, 8, hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(k_bucket_base, dim3(1), dim3(1024), 0, s, (const u32*)d_bcnt, NB, d_bbase);
+        NECAT_CHECK_LAUNCH(ctx, "k_bucket_base");
+        NECAT_HIP(ctx, hipMemcpyAsync(&n_off, d_bbase + NB, 8, hipMemcpyDeviceToHost, s));
         NECAT_HIP(ctx, hipStreamSynchronize(s));
         ix->n_offsets = n_off;
         if (ctx->idx_cache[1].p && ctx->idx_cache[1].cap >= (n_off + 1) * 8) { ix->offset_list = (uint64_t*)ctx->idx_cache[1].p; ix->offs_cap = ctx->idx_cache[1].cap; ctx->idx_cache[1] = DevBuf(); }
         else { NECAT_HIP(ctx, hipMalloc((void**)&ix->offset_list, (n_off + 1) * 8 + (n_off >> 4))); ix->offs_cap = (n_off + 1) * 8 + (n_off >> 4); }
         if ((rc = buf_ensure(ctx, ctx->scratch[SC_TMPLIST], (n_off + 1) * 4))) { necat_index_free(ctx, ix); return rc; }
-        hipLaunchKernelGGL(k_slice_emit, dim3((unsigned)nsub), dim3(256), 0, s, (const u64*)d_part2, (const u64*)d_sub, (u32)max_occ, (const u64*)d_sbase,
+        hipLaunchKernelGGL(k_slice_emit, dim3((unsigned)nsub), dim3(256), 0, s, (const u64*)d_part2, (const u64*)d_sub, (u32)max_occ, (const u64*)d_bbase, (const u32*)d_kept,
                            ix->kmer_stats, (u32*)ctx->scratch[SC_TMPLIST].p, ix->offset_list);
         NECAT_CHECK_LAUNCH(ctx, "k_slice_emit");
     } else {
@@ -414,8 +417,9 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
         t_prev = now;
     };
     // ---- pass 1: hit counts per read-strand
-    if ((rc = buf_ensure(ctx, ctx->scratch[SC_MISC], (size_t)nreads * 8 + 64))) return rc;
+    if ((rc = buf_ensure(ctx, ctx->scratch[SC_MISC], (size_t)nreads * 8 + 128))) return rc;
     u32* d_hits = (u32*)ctx->scratch[SC_MISC].p;
+    int* d_err = (int*)((char*)ctx->scratch[SC_MISC].p + (((size_t)nreads * 8 + 63) & ~(size_t)63));   // error flag of the seeding kernels
     hipLaunchKernelGGL(k_seed_hits, dim3(grid_for((u64)nreads * 64, 256)), dim3(256), 0, s, drd, (const u64*)ix->kmer_stats,
                        opt->kmer_size, opt->scan_window, 0u, nreads, d_hits);
     NECAT_CHECK_LAUNCH(ctx, "k_seed_hits");
@@ -434,8 +438,6 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
     P.align_cutoff = opt->align_size_cutoff; P.num_candidates = opt->num_candidates; P.job = opt->job; P.pairwise = pairwise;
     P.read_start_id = read_start_id; P.ref_start_id = ref_start_id;
     P.debug_phase = getenv("NECAT_SEED_DEBUG") ? atoi(getenv("NECAT_SEED_DEBUG")) : 0;
-    int* d_err = nullptr;
-    NECAT_HIP(ctx, hipMalloc((void**)&d_err, 4));
     NECAT_HIP(ctx, hipMemsetAsync(d_err, 0, 4, s));
     u32 pos = 0;
     std::vector<i32> ncands_by_order(nreads, 0);
@@ -468,7 +470,7 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
             (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_HT], ht_tot * 8)) ||
             (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_POOL], pool_tot * sizeof(SBlock))) ||
             (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_CHAIN], chain_tot * (8 + 16 + 8 + sizeof(DevCand)))) ||
-            (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_OUT], out_tot * sizeof(DevCand)))) { (void)hipFree(d_err); return rc; }
+            (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_OUT], out_tot * sizeof(DevCand)))) { return rc; }
         tick("plan + buffers");
         char* mb = (char*)ctx->scratch[SC_SEED_META].p;
         SeedMeta* d_meta = (SeedMeta*)mb; mb += n * sizeof(SeedMeta);
@@ -503,7 +505,7 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
         int herr = 0;
         NECAT_HIP(ctx, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, s));
         NECAT_HIP(ctx, hipStreamSynchronize(s));
-        if (herr) { (void)hipFree(d_err); return set_err(ctx, NECAT_ERR_CAPACITY, "seeding scratch overflow (code %d)", herr); }
+        if (herr) { return set_err(ctx, NECAT_ERR_CAPACITY, "seeding scratch overflow (code %d)", herr); }
         tick("collect + eval kernels");
         if (pos == 0 && hi == nreads) {
             // the usual case, one chunk: pack on the device straight into ascending read order and copy
@@ -514,9 +516,9 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
             for (u32 i = 0; i < n; ++i) foff[i] = by_read[order[i]];
             const u64 tot = by_read[nreads];
             necat_candidate* res = (necat_candidate*)result_alloc(std::max<u64>(1, tot) * sizeof(necat_candidate));
-            if (!res) { (void)hipFree(d_err); return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
+            if (!res) { return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
             if (tot) {
-                if ((rc = buf_ensure(ctx, ctx->scratch[SC_SEED_FINAL], tot * sizeof(necat_candidate)))) { (void)hipFree(d_err); necat_free(res); return rc; }
+                if ((rc = buf_ensure(ctx, ctx->scratch[SC_SEED_FINAL], tot * sizeof(necat_candidate)))) { necat_free(res); return rc; }
                 necat_candidate* d_dst = (necat_candidate*)ctx->scratch[SC_SEED_FINAL].p;
                 hipError_t e1 = hipMemcpyAsync(d_final, foff.data(), (size_t)n * 8, hipMemcpyHostToDevice, s);
                 hipLaunchKernelGGL(k_pack_cands, dim3(grid_for((u64)n * 64, 256)), dim3(256), 0, s, (const DevCand*)A.out, (const SeedMeta*)d_meta,
@@ -526,9 +528,8 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
                 hipError_t e4 = hipEventRecord(ctx->ev[1], s);
                 hipError_t e5 = hipStreamSynchronize(s);
                 for (hipError_t e : {e1, e2, e3, e4, e5})
-                    if (e != hipSuccess) { (void)hipFree(d_err); necat_free(res); return set_err(ctx, NECAT_ERR_DEVICE, "seeding result copy: %s", hipGetErrorString(e)); }
+                    if (e != hipSuccess) { necat_free(res); return set_err(ctx, NECAT_ERR_DEVICE, "seeding result copy: %s", hipGetErrorString(e)); }
             } else { NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s)); NECAT_HIP(ctx, hipStreamSynchronize(s)); }
-            (void)hipFree(d_err);
             ctx->tm.seed_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
             tick("pack + copy to host");
             *out = res; *n_out = tot;
@@ -539,7 +540,7 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
         for (u32 i = 0; i < n; ++i) foff[i + 1] = foff[i] + (u64)nc[i];
         const u64 tot = foff[n];
         if (tot) {
-            if ((rc = buf_grow(ctx, ctx->scratch[SC_SEED_ALL], (packed_total + tot) * sizeof(necat_candidate), packed_total * sizeof(necat_candidate), s))) { (void)hipFree(d_err); return rc; }
+            if ((rc = buf_grow(ctx, ctx->scratch[SC_SEED_ALL], (packed_total + tot) * sizeof(necat_candidate), packed_total * sizeof(necat_candidate), s))) { return rc; }
             necat_candidate* d_dst = (necat_candidate*)ctx->scratch[SC_SEED_ALL].p + packed_total;
             NECAT_HIP(ctx, hipMemcpyAsync(d_final, foff.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL(k_pack_cands, dim3(grid_for((u64)n * 64, 256)), dim3(256), 0, s, (const DevCand*)A.out, (const SeedMeta*)d_meta,
@@ -552,7 +553,6 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
         tick("pack");
         pos = hi;
     }
-    (void)hipFree(d_err);
     // ---- ascending read id: one move on the device, one copy into the (pinned) result block
     const u64 total = packed_total;
     necat_candidate* res = (necat_candidate*)result_alloc(std::max<u64>(1, total) * sizeof(necat_candidate));
@@ -730,6 +730,13 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
                 const necat_candidate* cands, uint64_t n, const necat_map_options* opt, int tail_match_len,
                 necat_m4** out, uint64_t* n_out, AlignOut* ao)
 {
+    auto t_prev = std::chrono::steady_clock::now();
+    auto tick = [&](const char* what) {
+        if (!(g_trace & 2)) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[necat] extend %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     if (n >= (1ULL << 31)) return set_err(ctx, NECAT_ERR_ARG, "too many candidates in one call");
     for (uint64_t i = 0; i < n; ++i) {
         const necat_candidate& c = cands[i];
@@ -740,6 +747,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
             c.qoff > c.qsize || c.soff > c.ssize)
             return set_err(ctx, NECAT_ERR_ARG, "candidate %lu has inconsistent sizes/anchor", (unsigned long)i);
     }
+    tick("validate candidates");
     NECAT_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     DevVolume dref = dev_view(ref), drd = dev_view(reads);
@@ -778,6 +786,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_OPS], kCohorts * (size_t)groups * 64 * (kOpsA + kOpsB))) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_RES], kCohorts * (size_t)groups * 64 * 2 * sizeof(BlockResult)))) { cleanup(); return rc; }
     NECAT_HIP(ctx, hipStreamSynchronize(s));        // candidates + zeroed counters are in place before the cohort streams start
+    tick("buffers + upload");
     Cohort co[kMaxCohorts];
     hipStream_t cs[4] = {ctx->stream_a, ctx->stream_b, ctx->stream_c, ctx->stream_d};
     for (int c = 0; c < kCohorts; ++c) {
@@ -801,6 +810,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     X.error = opt->error; X.tail_match_len = tail_match_len; X.min_align = opt->align_size_cutoff;
     X.read_start_id = read_start_id; X.ref_start_id = ref_start_id; X.reads_off = reads->seq_off; X.ref_off = ref->seq_off;
     uint64_t next_base = 0;
+    std::vector<u64> goff;
     for (;;) {
         bool any = false;
         for (int c = 0; c < kCohorts; ++c) {
@@ -835,6 +845,13 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
             any = true;
             const int done = cohort_launch(ctx, dref, drd, k, X, kCohorts > 1 ? &co[c ^ 1] : nullptr);
             if (done < 0) { cleanup(); return done; }
+            if (goff.empty() && !ao) {
+                // while the first round runs: groups of equal qid for the containment filter
+                // (candidates arrive grouped per read: pm_worker.c:100-140)
+                goff.push_back(0);
+                for (uint64_t i = 1; i < n; ++i) if (cands[i].qid != cands[i - 1].qid) goff.push_back(i);
+                goff.push_back(n);
+            }
             if (done == 1 && !ao) {
                 hipLaunchKernelGGL(k_ext_result, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, (const ExtTask*)k.tasks, k.n, d_cands + k.base,
                                    (u32)k.base, opt->align_size_cutoff, d_m4, d_ok);
@@ -876,6 +893,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
         }
         if (!any) break;
     }
+    tick("rounds");
     {
         unsigned long long hs[2] = {0, 0};
         NECAT_HIP(ctx, hipMemcpyAsync(hs, X.stats, 16, hipMemcpyDeviceToHost, s));
@@ -891,11 +909,6 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
         if (herr) return set_err(ctx, NECAT_ERR_INTERNAL, "extension kernels reported error code %d", herr);
         return NECAT_OK;
     }
-    // groups of equal qid (candidates arrive grouped per read: pm_worker.c:100-140)
-    std::vector<u64> goff;
-    goff.push_back(0);
-    for (uint64_t i = 1; i < n; ++i) if (cands[i].qid != cands[i - 1].qid) goff.push_back(i);
-    goff.push_back(n);
     const u32 ng = (u32)goff.size() - 1;
     NECAT_HIP(ctx, hipMemcpyAsync(d_goff, goff.data(), goff.size() * 8, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_m4_filter, dim3(grid_for(ng, 64)), dim3(64), 0, s, (const necat_candidate*)d_cands, (const u64*)d_goff, ng,
@@ -912,6 +925,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s));
     NECAT_HIP(ctx, hipStreamSynchronize(s));
     ctx->tm.extend_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
+    tick("filter + copy to host");
     cleanup();
     *out = res; *n_out = nout;
     return NECAT_OK;
