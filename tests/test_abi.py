@@ -76,3 +76,31 @@ def test_cli_usage_and_errors(built, tmp_path):
         d = util.install_golden_volumes("vols_a", tmp_path)
         r = subprocess.run([pmov, "-k", "13", d, "0", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         assert r.returncode == 1 and "no usable gfx950" in r.stderr and not os.path.exists(out)
+
+
+def test_gapped_strings_host_helper(built):
+    """necat_gapped_strings (host code of the library, no GPU): alignment columns -> the reference's two
+    "ACGT-" strings.  Columns are derived from the oracle's onc_align strings; expanding them again must give
+    those strings back; columns that run past a sequence are refused."""
+    import numpy as np
+    from necat_amd import capi
+    from necat_amd.synth import _mutate
+    from oracle import oracle_api as ora
+    rng = np.random.default_rng(9)
+    al = ora.Aligner(0.5)
+    n = 0
+    for it in range(12):
+        g = rng.integers(0, 4, int(rng.integers(900, 4000)), dtype=np.uint8)
+        q, t = _mutate(g, 0.1, rng), _mutate(g, 0.1, rng)
+        qs, ts = int(0.4 * q.shape[0]), int(0.4 * t.shape[0])
+        ok, qoff, qend, toff, tend, ident, qa, ta = al.align(q, qs, t, ts, 300, 4)
+        assert ok and len(qa) == len(ta) > 300
+        qa_b, ta_b = np.frombuffer(qa, dtype=np.uint8), np.frombuffer(ta, dtype=np.uint8)
+        ops = np.where(qa_b == 45, 2, np.where(ta_b == 45, 1, np.where(qa_b == ta_b, 0, 3))).astype(np.uint8)
+        assert capi.gapped_strings(ops, q, qoff, t, toff) == (qa, ta)
+        assert int((ops != 2).sum()) == qend - qoff and int((ops != 1).sum()) == tend - toff
+        with pytest.raises(capi.NecatError):
+            capi.gapped_strings(ops, q[:qend - 1], qoff, t, toff)
+        n += 1
+    al.close()
+    assert n == 12 and capi.gapped_strings(np.zeros(0, dtype=np.uint8), q, 0, t, 0) == (b"", b"")
