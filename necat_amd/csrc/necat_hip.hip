@@ -683,7 +683,8 @@ int cohort_launch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, C
         NECAT_HIP(ctx, hipEventRecord(c.a2, c.sa));
     }
     if (nB) {
-        if (nB >= 256 && g_sort_b) {
+        // (below ~2 k blocks every wave is resident at once and the round lasts as long as its longest walk: order is irrelevant)
+        if (nB >= 2048 && g_sort_b) {
             NECAT_HIP(ctx, hipMemsetAsync(c.bins, 0, 1024 * 4, c.sb));
             hipLaunchKernelGGL(k_items_hist, dim3(grid_for(nB, 256)), dim3(256), 0, c.sb, itB, nB, c.bins);
             hipLaunchKernelGGL(k_items_scan, dim3(1), dim3(1024), 0, c.sb, c.bins);
