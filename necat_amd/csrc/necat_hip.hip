@@ -463,10 +463,10 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
                 Hmax = std::max(Hmax, H);
             }
             m.chain_off = chain_tot; m.cs_cap = (u32)(Hmax + 1); chain_tot += Hmax + 1;
-            const u64 oc = (u64)hits[2 * (size_t)r] + hits[2 * (size_t)r + 1] + 1;
-            m.out_off = out_tot; m.out_cap = (u32)oc; out_tot += oc;
+            const u64 oc = (u64)hits[2 * (size_t)r] + hits[2 * (size_t)r + 1] + 2;
+            m.out_off = out_tot; m.out_cap = (u32)oc; m.out_cap0 = hits[2 * (size_t)r] + 1; m._pad = 0; out_tot += oc;
         }
-        if ((rc = buf_ensure(ctx, ctx->scratch[SC_SEED_META], n * sizeof(SeedMeta) + (size_t)n * (8 + 4 + 4 + 8) + 64)) ||
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_SEED_META], n * sizeof(SeedMeta) + (size_t)n * (8 + 4 + 4 + 8 + 8) + 64)) ||
             (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_HT], ht_tot * 8)) ||
             (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_POOL], pool_tot * sizeof(SBlock))) ||
             (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_CHAIN], chain_tot * (8 + 16 + 8 + sizeof(DevCand)))) ||
@@ -477,7 +477,8 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
         u64* d_final = (u64*)mb; mb += (size_t)n * 8;
         i32* d_nblk = (i32*)mb; mb += (size_t)n * 8;
         u32* d_order = (u32*)mb; mb += (size_t)n * 4;
-        i32* d_ncand = (i32*)mb;
+        i32* d_ncand = (i32*)mb; mb += (size_t)n * 4;
+        i32* d_nstrand = (i32*)mb;
         SeedArenas A;
         A.ht_key = (i32*)ctx->scratch[SC_SEED_HT].p; A.ht_val = A.ht_key + ht_tot;
         A.pool = (SBlock*)ctx->scratch[SC_SEED_POOL].p;
@@ -497,9 +498,11 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
             hipLaunchKernelGGL(k_seed_collect, dim3(grid_for((u64)2 * n, 64)), dim3(64), 0, s, dref, drd, (const u64*)ix->kmer_stats, (const u64*)ix->offset_list,
                                P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A, d_nblk, d_err);
         NECAT_CHECK_LAUNCH(ctx, "k_seed_collect");
-        hipLaunchKernelGGL(k_seed_eval, dim3(n), dim3(64), 0, s, dref, drd, P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A,
-                           (const i32*)d_nblk, d_ncand, d_err);
+        hipLaunchKernelGGL(k_seed_eval, dim3(2 * n), dim3(64), 0, s, dref, drd, P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A,
+                           (const i32*)d_nblk, d_nstrand, d_err);
         NECAT_CHECK_LAUNCH(ctx, "k_seed_eval");
+        hipLaunchKernelGGL(k_seed_finish, dim3(grid_for(n, 64)), dim3(64), 0, s, P, (const SeedMeta*)d_meta, n, A, (const i32*)d_nstrand, d_ncand);
+        NECAT_CHECK_LAUNCH(ctx, "k_seed_finish");
         std::vector<i32> nc(n);
         NECAT_HIP(ctx, hipMemcpyAsync(nc.data(), d_ncand, (size_t)n * 4, hipMemcpyDeviceToHost, s));
         int herr = 0;

@@ -18,8 +18,8 @@ struct SeedMeta {           // per processed read; strand 0 = FWD, 1 = REV
     u64 ht_off[2];          // entries
     u64 pool_off[2];        // SBlocks
     u64 chain_off;          // entries of (max(H0,H1)+1)
-    u64 out_off;            // DevCands
-    u32 ht_mask[2], pool_cap[2], cs_cap, out_cap;
+    u64 out_off;            // DevCands: strand 0 writes at out_off, strand 1 at out_off + out_cap0; k_seed_finish joins them
+    u32 ht_mask[2], pool_cap[2], cs_cap, out_cap, out_cap0, _pad;
 };
 
 __global__ void __launch_bounds__(256)
@@ -57,7 +57,7 @@ NECAT_D SeedScratch seed_scratch(const SeedArenas& A, const SeedMeta& m, int str
     S.pool = A.pool + m.pool_off[strand]; S.pool_cap = m.pool_cap[strand];
     S.cs = A.cs + m.chain_off; S.f = A.f + m.chain_off; S.p = A.p + m.chain_off; S.t = A.t + m.chain_off;
     S.v = A.v + m.chain_off; S.u = A.u + m.chain_off; S.lcan = A.lcan + m.chain_off; S.cs_cap = m.cs_cap;
-    S.out = A.out + m.out_off; S.out_cap = m.out_cap;
+    S.out = A.out + m.out_off + (strand ? m.out_cap0 : 0u); S.out_cap = strand ? m.out_cap - m.out_cap0 : m.out_cap0;
     return S;
 }
 
@@ -251,7 +251,7 @@ struct LdsAdder { int* s; NECAT_D void operator()(int j) { atomicAdd(&s[j], 1); 
 // across lanes' stores.
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict__ order, const SeedMeta* __restrict__ meta, u32 n,
-            SeedArenas A, const i32* __restrict__ nblk_in, i32* __restrict__ n_cands, int* __restrict__ err_flag)
+            SeedArenas A, const i32* __restrict__ nblk_in, i32* __restrict__ n_strand, int* __restrict__ err_flag)
 {
     __shared__ int s_loc[kBlkSeeds * 2], s_seedn[kBlkSeeds * 2], s_score[kBlkSeeds * 2];
     __shared__ int s_ctl[4];
@@ -261,8 +261,9 @@ k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict_
     // rank sort and lane 0's chain DP walks LDS instead of global memory
     __shared__ u64 l_cs[kLdsChain], l_u[kLdsChain];
     __shared__ i32 l_f[kLdsChain], l_p[kLdsChain], l_t[kLdsChain], l_v[kLdsChain];
-    const u32 i = blockIdx.x;
+    const u32 i = blockIdx.x >> 1;         // one wave per (read, strand): the strands share nothing but the output order
     if (i >= n) return;
+    const int strand0 = (int)(blockIdx.x & 1);
     const int lane = threadIdx.x;
     const u64 below = (1ULL << lane) - 1ULL;
     const int r = (int)order[i];
@@ -274,7 +275,7 @@ k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict_
 #endif
     int n_out = 0;            // meaningful on lane 0
     bool failed = false;
-    for (int strand = 0; strand < 2 && !failed; ++strand) {
+    for (int strand = strand0; strand == strand0; ++strand) {
         SeedScratch S = seed_scratch(A, m, strand);
         const int nblk = P.debug_phase == 1 ? 0 : nblk_in[2 * (u64)i + strand];
         // Blocks are visited in first-touch order, but only those passing the score test are evaluated and
@@ -391,12 +392,25 @@ k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict_
     if (lane == 0) { u64 tot = 0; for (int q = 0; q < 10; ++q) { atomicAdd(&g_seed_prof[q], pacc[q]); if (q != 8) tot += pacc[q]; } atomicMax(&g_seed_prof[10], tot); atomicMax(&g_seed_prof[11], pacc[8]); }
 #endif
     if (lane == 0) {
-        if (failed) { atomicExch(err_flag, 1); n_cands[i] = 0; }
-        else {
-            SeedScratch S = seed_scratch(A, m, 0);
-            n_cands[i] = seed_finish_read(P, S, n_out);
-        }
+        if (failed) atomicExch(err_flag, 1);
+        n_strand[blockIdx.x] = failed ? 0 : n_out;
     }
+}
+
+// FWD candidates, then REV candidates (find_candidates is called for FWD first, pm_worker.c:100-131), then the
+// per-read sort / truncation of pm_search_one_volume; one lane per read
+__global__ void __launch_bounds__(64)
+k_seed_finish(SeedParams P, const SeedMeta* __restrict__ meta, u32 n, SeedArenas A, const i32* __restrict__ n_strand, i32* __restrict__ n_cands)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const SeedMeta m = meta[i];
+    const int n0 = n_strand[2 * (u64)i], n1 = n_strand[2 * (u64)i + 1];
+    DevCand* out = A.out + m.out_off;
+    const DevCand* rev = out + m.out_cap0;
+    for (int j = 0; j < n1; ++j) out[n0 + j] = rev[j];        // n0 <= out_cap0: ascending copy never overtakes its source
+    SeedScratch S = seed_scratch(A, m, 0);
+    n_cands[i] = seed_finish_read(P, S, n0 + n1);
 }
 
 // dst[final_off[i] + j] = candidate j of the i-th processed read, ids made global
