@@ -429,9 +429,14 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
     tick("hits kernel + copy");
     // ---- plan: reads in descending work order, chunks bounded by a scratch budget
     std::vector<u32> order(nreads);
-    std::iota(order.begin(), order.end(), 0u);
-    auto work = [&](u32 r) { return (u64)std::max(hits[2 * (size_t)r], hits[2 * (size_t)r + 1]); };
-    std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return work(a) > work(b); });
+    {
+        // descending work, ascending read id inside equal work: one sort of packed keys
+        std::vector<u64> keys(nreads);
+        for (u32 r = 0; r < nreads; ++r)
+            keys[r] = ((u64)(0xffffffffu - std::max(hits[2 * (size_t)r], hits[2 * (size_t)r + 1])) << 32) | r;
+        std::sort(keys.begin(), keys.end());
+        for (u32 i = 0; i < nreads; ++i) order[i] = (u32)keys[i];
+    }
     const u64 budget_hits = g_seed_budget;   // default ~48 M pool blocks (~13 GB of SBlocks) per chunk
     SeedParams P;
     P.k = opt->kmer_size; P.z = opt->scan_window; P.block_size = opt->block_size; P.s_cutoff = opt->block_score_cutoff;
