@@ -1,0 +1,55 @@
+"""Randomised parity sweep (tool): random small datasets x random option sets, the HIP path through the C ABI
+against the oracle - candidates (-j 0, packed 28-byte records) and M4 records (-j 1), every volume.
+
+    python tools/fuzz_parity.py [n_cases] [first_seed]
+"""
+import os, sys, tempfile, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from necat_amd import capi, synth
+from oracle import oracle_api as ora
+from tests import util
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+ctx = capi.Context(0)
+bad = 0
+for case in range(n_cases):
+    rng = np.random.default_rng(seed0 + case)
+    genome = int(rng.integers(40_000, 220_000))
+    cov = float(rng.uniform(8, 30))
+    err = float(rng.choice([0.04, 0.08, 0.12, 0.15]))
+    rep = float(rng.choice([0.0, 0.0, 0.05, 0.2]))
+    multi = bool(rng.integers(0, 3) == 0)
+    kw = dict(kmer_size=int(rng.choice([11, 12, 13, 14])), scan_window=int(rng.choice([5, 10, 20])),
+              kmer_cnt_cutoff=int(rng.choice([20, 100, 500])), block_size=int(rng.choice([1000, 2000, 3000])),
+              block_score_cutoff=int(rng.choice([2, 3, 4])), num_candidates=int(rng.choice([3, 30, 500])),
+              align_size_cutoff=int(rng.choice([500, 1000, 2000])), ddfs_cutoff=0.25, error=float(rng.choice([0.3, 0.5])),
+              num_output=500, num_threads=2, use_hdr_as_id=0)
+    with tempfile.TemporaryDirectory() as td:
+        d, rs, nv = util.make_dataset(td, genome=genome, coverage=cov, seed=seed0 + case, err=err, repeat_frac=rep,
+                                      vol_size=(max(300_000, int(genome * cov / 3)) if multi else synth.DEFAULT_VOL_SIZE))
+        t0 = time.time()
+        for vid in range(nv):
+            for job in (0, 1):
+                o = ora.options(**dict(kw, job=job, binary_output=1))
+                out = os.path.join(td, "o.out")
+                st = ora.pm_main(o, vid, d, out)
+                opt = capi.default_options(**dict(kw, job=job, binary_output=1))
+                cands, m4 = capi.pm_main(ctx, opt, vid, d)
+                if job == 0:
+                    mine = sorted(bytes(r) for r in capi.pack_candidates(cands).astype("<u4"))
+                    ok = mine == ora.sorted_records(out, 28)
+                    nrec = len(mine)
+                else:
+                    ref = np.frombuffer(open(out, "rb").read(), dtype=capi.M4_DTYPE)
+                    ok = util.m4_key_rows(m4) == util.m4_key_rows(ref)
+                    nrec = m4.shape[0]
+                if not ok:
+                    bad += 1
+                    print("MISMATCH case %d vid %d job %d" % (case, vid, job), kw, flush=True)
+        print("case %2d: genome %6d cov %4.1f err %.2f rep %.2f vols %d k=%d z=%d q=%d b=%d s=%d n=%d a=%d e=%.1f -> %d M4 (last vol) %s  %.1f s" % (
+            case, genome, cov, err, rep, nv, kw["kmer_size"], kw["scan_window"], kw["kmer_cnt_cutoff"], kw["block_size"],
+            kw["block_score_cutoff"], kw["num_candidates"], kw["align_size_cutoff"], kw["error"], nrec, "ok" if not bad else "BAD", time.time() - t0), flush=True)
+print("fuzz_parity: %d cases, %d mismatches" % (n_cases, bad))
+sys.exit(1 if bad else 0)
