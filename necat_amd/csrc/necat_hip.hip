@@ -622,6 +622,7 @@ struct ExtShared {
     double error; int tail_match_len, min_align, read_start_id, ref_start_id;
     const u64* reads_off; const u64* ref_off;
     u8* task_ops = nullptr;      // alignment columns per task (necat_onc_align_batch)
+    bool lazy_pool = false;      // one cohort: the band pool grows to what a round needs
 };
 
 // finish the round a cohort has in flight (if any): wait, account, flip the list parity
@@ -661,6 +662,17 @@ int cohort_launch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, C
     c.nA = nA; c.nB = nB;
     if (nA + nB == 0) return 1;
     const u32 gA = (nA + 63) / 64, gB = (nB + 63) / 64;
+    if (X.lazy_pool) {
+        // the band pool is sized by what the round needs (round 0 of the first call sets it; 35 GB instead of the
+        // 76 GB worst case "every block in list B" at E. coli size - hipMalloc costs ~13 ms per GB)
+        const size_t need = (size_t)gA * kSlabA + (size_t)gB * kSlabB;
+        if (need > ctx->scratch[SC_EXT_MAT].cap) {
+            int rc = ensure_zeroed(ctx, ctx->scratch[SC_EXT_MAT], need + need / 8, c.sa);
+            if (rc) return rc;
+            NECAT_HIP(ctx, hipStreamSynchronize(c.sa));
+        }
+        c.slabs = (char*)ctx->scratch[SC_EXT_MAT].p;
+    }
     char* slabsB = c.slabs + (size_t)gA * kSlabA;
     const BlockItem* itA = c.itemsA[p]; const BlockItem* itB = c.itemsB[p];
     const u32 epoch = ++ctx->epoch & 0x3fffffu;
@@ -791,7 +803,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_TASKS], kCohorts * ((size_t)cap * sizeof(ExtTask) + 64))) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], kCohorts * ((size_t)cap * 5 * sizeof(BlockItem) + 4096 + 64))) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_FRAG], kCohorts * (size_t)groups * 64 * (kFragWordsA + kFragWordsB) * 8)) ||
-        (rc = ensure_zeroed(ctx, ctx->scratch[SC_EXT_MAT], kCohorts * slab_per, s)) ||
+        (kCohorts > 1 && (rc = ensure_zeroed(ctx, ctx->scratch[SC_EXT_MAT], kCohorts * slab_per, s))) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_OPS], kCohorts * (size_t)groups * 64 * (kOpsA + kOpsB))) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_RES], kCohorts * (size_t)groups * 64 * 2 * sizeof(BlockResult)))) { cleanup(); return rc; }
     NECAT_HIP(ctx, hipStreamSynchronize(s));        // candidates + zeroed counters are in place before the cohort streams start
@@ -805,7 +817,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
         k.itemsA[0] = q; k.itemsB[0] = q + cap; k.itemsA[1] = q + 2 * (size_t)cap; k.itemsB[1] = q + 3 * (size_t)cap;
         k.sortedB = q + 4 * (size_t)cap; k.bins = (u32*)(q + 5 * (size_t)cap);
         k.fragA = (u64*)ctx->scratch[SC_EXT_FRAG].p + c * (size_t)groups * 64 * (kFragWordsA + kFragWordsB); k.fragB = k.fragA + (size_t)groups * 64 * kFragWordsA;
-        k.slabs = (char*)ctx->scratch[SC_EXT_MAT].p + c * slab_per;
+        k.slabs = kCohorts > 1 ? (char*)ctx->scratch[SC_EXT_MAT].p + c * slab_per : nullptr;
         k.opsA = (u8*)ctx->scratch[SC_EXT_OPS].p + c * (size_t)groups * 64 * (kOpsA + kOpsB); k.opsB = k.opsA + (size_t)groups * 64 * kOpsA;
         k.resA = (BlockResult*)ctx->scratch[SC_EXT_RES].p + c * (size_t)groups * 64 * 2; k.resB = k.resA + (size_t)groups * 64;
         k.count = d_outcnt + 2 + 4 * c;
@@ -818,6 +830,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     X.d_cands = d_cands; X.d_m4 = d_m4; X.d_ok = d_ok; X.d_err = d_err; X.stats = (unsigned long long*)(d_outcnt + 16);
     X.error = opt->error; X.tail_match_len = tail_match_len; X.min_align = opt->align_size_cutoff;
     X.read_start_id = read_start_id; X.ref_start_id = ref_start_id; X.reads_off = reads->seq_off; X.ref_off = ref->seq_off;
+    X.lazy_pool = kCohorts == 1;
     uint64_t next_base = 0;
     std::vector<u64> goff;
     for (;;) {
