@@ -143,7 +143,7 @@ def main():
     barrier_sync(dist, local)
     t0 = time.perf_counter()
     agg = dict(index_ms=0.0, seed_ms=0.0, extend_ms=0.0, myers_ms=0.0, traceback_ms=0.0, launches=0, blocks=0, words=0, bases=0, rounds=0,
-               a_ms=0.0, a_launches=0, a_blocks=0, tb_a_ms=0.0)
+               a_ms=0.0, a_launches=0, a_blocks=0, tb_a_ms=0.0, big_ms=0.0, big_blocks=0)
     n_over = 0
     gbp = 0.0
     for _ in range(args.steps):
@@ -156,6 +156,8 @@ def main():
         agg["blocks"] += tm.myers_blocks; agg["words"] += tm.myers_word_updates; agg["bases"] += tm.myers_cells_bases
         agg["rounds"] += tm.rounds
         agg["tb_a_ms"] += tm.tracebackA_ms
+        if tm.myersA_big_blocks >= agg["big_blocks"]:
+            agg["big_blocks"], agg["big_ms"] = int(tm.myersA_big_blocks), float(tm.myersA_big_ms)
         agg["a_ms"] += tm.myersA_ms; agg["a_launches"] += tm.myersA_launches; agg["a_blocks"] += tm.myersA_blocks
     barrier_sync(dist, local)
     elapsed = time.perf_counter() - t0
@@ -200,6 +202,10 @@ def main():
                 "algorithmic_bytes_per_launch": round(alg_per_launch, 1),
                 "traceback_kernel": {"kernel": "k_traceback<8,16,512,1024,false>", "avg_launch_ms": round(tb_avg_ms, 4), "traffic": tb_traffic,
                                      "traffic_frac": round(tb_traffic / (tb_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tb_traffic and tb_avg_ms > 0 else None},
+                # the launch with the most blocks (throughput regime; the small launches of the late rounds are latency bound):
+                # ~2 x 512 columns x 8 words per block (list A also holds shorter last blocks, so this slightly overstates)
+                "biggest_launch": {"blocks": agg["big_blocks"], "ms": round(agg["big_ms"], 4),
+                                   "valu_frac": round(agg["big_blocks"] * 8192.0 * OPS_PER_WORD_UPDATE / (agg["big_ms"] * 1e-3) / VALU_LANE_OPS_PER_S, 4) if agg["big_ms"] > 0 else None},
                 "all_dp_kernels": {"launches": int(agg["launches"]), "ms": round(agg["myers_ms"], 2), "blocks": int(agg["blocks"]),
                                    "word_updates_per_s": round(word_rate, 1),
                                    "valu_frac": round(word_rate * OPS_PER_WORD_UPDATE / VALU_LANE_OPS_PER_S, 4)},

@@ -106,6 +106,9 @@ typedef struct {
     double   myersA_ms;
     uint64_t myersA_launches, myersA_blocks;
     double   tracebackA_ms;
+    /* the list-A DP launch with the most blocks (the throughput-bound regime of the dominant kernel) */
+    double   myersA_big_ms;
+    uint64_t myersA_big_blocks;
 } necat_timings;
 
 void        necat_default_options(necat_map_options* o);            /* map_options.c:12-28 */

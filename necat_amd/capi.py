@@ -32,7 +32,7 @@ class Timings(C.Structure):
                 ("myers_blocks", C.c_uint64), ("myers_word_updates", C.c_uint64),
                 ("myers_cells_bases", C.c_uint64), ("rounds", C.c_uint64),
                 ("myersA_ms", C.c_double), ("myersA_launches", C.c_uint64), ("myersA_blocks", C.c_uint64),
-                ("tracebackA_ms", C.c_double)]
+                ("tracebackA_ms", C.c_double), ("myersA_big_ms", C.c_double), ("myersA_big_blocks", C.c_uint64)]
 
 
 CANDIDATE_DTYPE = np.dtype([("qid", "<i4"), ("sid", "<i4"), ("qdir", "<i4"), ("sdir", "<i4"), ("score", "<i4"),

@@ -325,10 +325,25 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
     // target words of the wave's blocks staged in LDS: a lane needs a new 32-column word every 32
     // steps, at a step that differs per lane; served from global memory that read would sit in the same
     // vmcnt queue as the NW band stores and stall every step on them
+    // staged as two bit-planes per 32 columns (low / high bit of the base code in the low / high half): a lane then
+    // gets its column's two symbol masks with one v_bfe_i32 each instead of shift + mask + 64-bit shift + extends
     __shared__ u64 t_lds[BPW][TW];
-    if (valid) for (int w = b; w < TW; w += G) t_lds[sub][w] = (w * 32 < tn) ? fr[(u64)(2 * NW + w) * 64] : 0ULL;
+    if (valid) for (int w = b; w < TW; w += G) {
+        const u64 x = (w * 32 < tn) ? fr[(u64)(2 * NW + w) * 64] : 0ULL;
+        t_lds[sub][w] = even_bits(x) | (even_bits(x >> 1) << 32);
+    }
     __syncthreads();
     const u64* tw = t_lds[sub];
+    const u32 nlo_l = (u32)nlo, nlo_h = (u32)(nlo >> 32), nhi_l = (u32)nhi, nhi_h = (u32)(nhi >> 32);
+    const u32 pad_l = (u32)pad, pad_h = (u32)(pad >> 32);
+    u64 tcur = 0;
+    // Eq of column c for this lane's 64 rows: rows whose base code equals the column's
+    auto eq_of = [&](int c) -> u64 {
+        const u32 ma = (u32)__builtin_amdgcn_sbfe((int)(u32)tcur, (u32)c & 31u, 1u);           // all ones iff bit 0 of the code
+        const u32 mb = (u32)__builtin_amdgcn_sbfe((int)(u32)(tcur >> 32), (u32)c & 31u, 1u);   // all ones iff bit 1
+        const u32 el = ((nlo_l ^ ma) & (nhi_l ^ mb)) | pad_l, eh = ((nlo_h ^ ma) & (nhi_h ^ mb)) | pad_h;
+        return ((u64)eh << 32) | el;
+    };
     ulonglong2* rec = slab_records(slabs + (size_t)grp * slab_bytes);
 
     // wave-uniform trip count of the SHW wavefront
@@ -339,16 +354,13 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
     int k = (int)((double)(qn < tn ? qn : tn) * error * 1.1);
     u64 P = ~0ULL, M = 0ULL;
     int S = (b + 1) * 64, best = -1, end0 = -1, hout = 1;
-    u64 tcur = 0;
     for (int s = 0; s < steps; ++s) {
         const int c = s - b;
         int hin = dpp_from_lane_below(hout);
         if (b == 0) hin = 1;
         if (have && c >= 0 && c < tn) {
             if ((c & 31) == 0) tcur = tw[c >> 5];
-            const int tc = (int)((tcur >> ((c & 31) * 2)) & 3);
-            const u64 ma = (tc & 1) ? ~0ULL : 0ULL, mb = (tc & 2) ? ~0ULL : 0ULL;
-            const u64 eq = ((nlo ^ ma) & (nhi ^ mb)) | pad;
+            const u64 eq = eq_of(c);
             hout = advance_block(P, M, eq, hin, P, M);
             S += hout;
             if (is_last && S <= k && (best == -1 || S <= best)) {
@@ -386,9 +398,7 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
         if (b == 0) hin = 1;
         if (go && c >= 0 && c < tn2) {
             if ((c & 31) == 0) tcur = tw[c >> 5];
-            const int tc = (int)((tcur >> ((c & 31) * 2)) & 3);
-            const u64 ma = (tc & 1) ? ~0ULL : 0ULL, mb = (tc & 2) ? ~0ULL : 0ULL;
-            const u64 eq = ((nlo ^ ma) & (nhi ^ mb)) | pad;
+            const u64 eq = eq_of(c);
             hout = advance_block(P, M, eq, hin, P, M);
             S += hout;
             // store the word only if it can hold a cell of an alignment of cost <= best that still reaches

@@ -635,6 +635,7 @@ int cohort_retire(necat_ctx* ctx, Cohort& c)
     ctx->tm.myers_ms += mA + mB;
     ctx->tm.traceback_ms += tA + tB;
     if (c.nA) { ctx->tm.myersA_ms += mA; ctx->tm.tracebackA_ms += tA; ctx->tm.myersA_launches += 1; ctx->tm.myersA_blocks += c.nA; }
+    if (c.nA > ctx->tm.myersA_big_blocks) { ctx->tm.myersA_big_blocks = c.nA; ctx->tm.myersA_big_ms = mA; }
     if (g_trace & 1) {
         static double last = 0;
         const double now = wall_ms();
@@ -775,6 +776,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     ctx->tm.myers_ms = ctx->tm.traceback_ms = 0; ctx->tm.myers_launches = ctx->tm.myers_blocks = ctx->tm.rounds = 0;
     ctx->tm.myers_word_updates = ctx->tm.myers_cells_bases = 0;
     ctx->tm.myersA_ms = ctx->tm.tracebackA_ms = 0; ctx->tm.myersA_launches = ctx->tm.myersA_blocks = 0;
+    ctx->tm.myersA_big_ms = 0; ctx->tm.myersA_big_blocks = 0;
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
     // the cohorts share the band pool: <= 393 216 candidates in flight in total (~130 GB of the 288 GB HBM).
     // Default: ONE cohort.  Two (NECAT_COHORTS=2) were measured slower on MI355X (E. coli 129 vs 111 ms,
