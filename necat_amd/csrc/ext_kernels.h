@@ -358,7 +358,7 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
         const int c = s - b;
         int hin = dpp_from_lane_below(hout);
         if (b == 0) hin = 1;
-        if (have && c >= 0 && c < tn) {
+        if (have && (u32)c < (u32)tn) {
             if ((c & 31) == 0) tcur = tw[c >> 5];
             const u64 eq = eq_of(c);
             hout = advance_block(P, M, eq, hin, P, M);
@@ -396,7 +396,7 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
         int hin = dpp_from_lane_below(hout);
         const int Sup = dpp_from_lane_below(S);     // score of word b-1 at column c (computed one step ago)
         if (b == 0) hin = 1;
-        if (go && c >= 0 && c < tn2) {
+        if (go && (u32)c < (u32)tn2) {
             if ((c & 31) == 0) tcur = tw[c >> 5];
             const u64 eq = eq_of(c);
             hout = advance_block(P, M, eq, hin, P, M);
