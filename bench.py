@@ -128,8 +128,11 @@ def main():
     def step():
         ix = ctx.build_index(vol, opt.kmer_size, opt.kmer_cnt_cutoff)
         t_index = ctx.timings().index_ms
-        cands = ctx.find_candidates(ix, vol, vol, 0, 0, opt, True)
-        m4 = ctx.extend(vol, vol, 0, 0, cands, opt, 1) if args.job == 1 else None
+        if args.job == 1:      # pm_search_one_volume of a mapping job: seeding + extension in one call, candidates stay on the device
+            m4, _ = ctx.map_pair(ix, vol, vol, 0, 0, opt, True, 1)
+            cands = None
+        else:
+            cands, m4 = ctx.find_candidates(ix, vol, vol, 0, 0, opt, True), None
         tm = ctx.timings()
         ix.free()
         return cands, m4, t_index, tm

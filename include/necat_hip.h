@@ -14,6 +14,8 @@
  *                                                     word_finder/word_finder.h:33-45, pm_worker.c:100-140,163-171
  *   necat_extend           <- extend_candidates/onc_align
  *                                                     pm_worker.c:29-83, gapped_align/oc_aligner.h:45-55
+ *   necat_map_pair         <- pm_search_one_volume, -j 1: the two calls above fused (candidates stay on the device)
+ *                                                     pm_worker.c:85-173
  *   necat_volume_upload    <- pdb_load                common/packed_db.c:386 (the 2-bit pac + SequenceInfo)
  *   necat_onc_align_batch  <- onc_align with its gapped strings, for the consensus client
  *                                                     gapped_align/oc_aligner.h:45-55, consensus_aux.c:124-215
@@ -153,6 +155,13 @@ int  necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* r
                   int read_start_id, int ref_start_id,
                   const necat_candidate* cands, uint64_t n, const necat_map_options* opt,
                   int tail_match_len, necat_m4** out, uint64_t* n_out);
+
+/* pm_search_one_volume of a mapping job (pm_worker.c:85-173 with -j 1) for every read of `reads` in one call:
+ * necat_find_candidates followed by necat_extend, with the candidates never leaving the device.  Same M4
+ * records as the two calls made one after the other; *n_candidates (optional) = candidates examined. */
+int  necat_map_pair(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, const necat_volume* reads,
+                    int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt,
+                    int tail_match_len, necat_m4** out, uint64_t* n_out, uint64_t* n_candidates);
 
 /* onc_align (gapped_align/oc_aligner.h:45-55) on every candidate WITH the alignment itself - the call the
  * consensus stage makes (cns_extension, consensus/consensus_aux.c:124-215, tail_match_len =

@@ -48,7 +48,8 @@ assert CANDIDATE_DTYPE.itemsize == 88 and M4_DTYPE.itemsize == 96 and ALIGNMENT_
 EXPORTED_SYMBOLS = [
     "necat_default_options", "necat_ctx_create", "necat_ctx_destroy", "necat_last_error", "necat_device_name",
     "necat_volume_upload", "necat_volume_free", "necat_index_build", "necat_index_size", "necat_index_download",
-    "necat_index_free", "necat_find_candidates", "necat_extend", "necat_onc_align_batch", "necat_gapped_strings",
+    "necat_index_free", "necat_find_candidates", "necat_extend", "necat_map_pair", "necat_onc_align_batch",
+    "necat_gapped_strings",
     "necat_edlib_align_batch", "necat_get_timings", "necat_free",
 ]
 
@@ -85,6 +86,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                           C.POINTER(vp), u64p]
     lib.necat_extend.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_uint64, C.POINTER(MapOptions), C.c_int,
                                  C.POINTER(vp), u64p]
+    lib.necat_map_pair.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(MapOptions), C.c_int,
+                                   C.POINTER(vp), u64p, u64p]
     lib.necat_onc_align_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_uint64, C.POINTER(MapOptions), C.c_int,
                                           C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.necat_gapped_strings.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, C.c_uint64, vp, vp]
@@ -189,6 +192,15 @@ class Context:
                                           cands.shape[0], C.byref(opt), tail_match_len, C.byref(p), C.byref(n)),
                     "necat_extend")
         return self._take(p, n.value, M4_DTYPE)
+
+    def map_pair(self, ix: "Index", ref: "Volume", reads: "Volume", read_start_id: int, ref_start_id: int, opt: MapOptions,
+                 pairwise: bool = True, tail_match_len: int = 1):
+        """find_candidates + extend with the candidates kept on the device: (M4 records, number of candidates)."""
+        p = C.c_void_p()
+        n, nc = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.necat_map_pair(self.h, ix.h, ref.h, reads.h, read_start_id, ref_start_id, 1 if pairwise else 0,
+                                            C.byref(opt), tail_match_len, C.byref(p), C.byref(n), C.byref(nc)), "necat_map_pair")
+        return self._take(p, n.value, M4_DTYPE), int(nc.value)
 
     def onc_align_batch(self, ref: "Volume", reads: "Volume", read_start_id: int, ref_start_id: int, cands: np.ndarray,
                         opt: MapOptions, tail_match_len: int = 4):

@@ -393,12 +393,23 @@ void necat_index_free(necat_ctx* ctx, necat_index* ix)
 
 // ------------------------------------------------------------------------------------------ seeding
 
-int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, const necat_volume* reads,
-                          int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt,
-                          necat_candidate** out, uint64_t* n_out)
+namespace {
+// candidates left on the device for necat_map_pair: array in ascending read order + the first candidate of
+// every read that has any (the groups of the containment filter) + the total
+struct DevCands { const necat_candidate* d = nullptr; uint64_t n = 0; std::vector<u64> group_off; };
+
+void fill_groups(DevCands* dev, const std::vector<u64>& by_read, u32 nreads)
 {
-    if (!ctx || !ix || !ref || !reads || !opt || !out || !n_out) return NECAT_ERR_ARG;
-    *out = nullptr; *n_out = 0;
+    dev->group_off.clear();
+    for (u32 r = 0; r < nreads; ++r) if (by_read[r + 1] > by_read[r]) dev->group_off.push_back(by_read[r]);
+    dev->group_off.push_back(by_read[nreads]);
+    if (dev->group_off.size() == 1) dev->group_off.insert(dev->group_off.begin(), 0);
+}
+
+int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, const necat_volume* reads,
+              int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt,
+              necat_candidate** out, uint64_t* n_out, DevCands* dev)
+{
     if (opt->kmer_size != ix->k) return set_err(ctx, NECAT_ERR_ARG, "index was built for k=%d, options say %d", ix->k, opt->kmer_size);
     if (opt->scan_window < 1 || opt->block_size < 1 || opt->block_size > 32767)
         return set_err(ctx, NECAT_ERR_ARG, "scan_window/block_size out of range (block offsets are 16-bit, word_finder_aux.h:21)");
@@ -523,8 +534,9 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
             for (u32 r = 0; r < nreads; ++r) by_read[r + 1] += by_read[r];
             for (u32 i = 0; i < n; ++i) foff[i] = by_read[order[i]];
             const u64 tot = by_read[nreads];
-            necat_candidate* res = (necat_candidate*)result_alloc(std::max<u64>(1, tot) * sizeof(necat_candidate));
-            if (!res) { return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
+            necat_candidate* res = dev ? nullptr : (necat_candidate*)result_alloc(std::max<u64>(1, tot) * sizeof(necat_candidate));
+            if (!dev && !res) { return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
+            if (dev) { dev->n = tot; fill_groups(dev, by_read, nreads); }
             if (tot) {
                 if ((rc = buf_ensure(ctx, ctx->scratch[SC_SEED_FINAL], tot * sizeof(necat_candidate)))) { necat_free(res); return rc; }
                 necat_candidate* d_dst = (necat_candidate*)ctx->scratch[SC_SEED_FINAL].p;
@@ -532,7 +544,8 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
                 hipLaunchKernelGGL(k_pack_cands, dim3(grid_for((u64)n * 64, 256)), dim3(256), 0, s, (const DevCand*)A.out, (const SeedMeta*)d_meta,
                                    (const i32*)d_ncand, (const u64*)d_final, n, read_start_id, ref_start_id, d_dst);
                 hipError_t e2 = hipGetLastError();
-                hipError_t e3 = hipMemcpyAsync(res, d_dst, tot * sizeof(necat_candidate), hipMemcpyDeviceToHost, s);
+                if (dev) dev->d = d_dst;
+                hipError_t e3 = dev ? hipSuccess : hipMemcpyAsync(res, d_dst, tot * sizeof(necat_candidate), hipMemcpyDeviceToHost, s);
                 hipError_t e4 = hipEventRecord(ctx->ev[1], s);
                 hipError_t e5 = hipStreamSynchronize(s);
                 for (hipError_t e : {e1, e2, e3, e4, e5})
@@ -540,7 +553,7 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
             } else { NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s)); NECAT_HIP(ctx, hipStreamSynchronize(s)); }
             ctx->tm.seed_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
             tick("pack + copy to host");
-            *out = res; *n_out = tot;
+            if (!dev) { *out = res; *n_out = tot; }
             return NECAT_OK;
         }
         // several chunks: pack this chunk's candidates behind the earlier ones, on the device
@@ -563,13 +576,14 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
     }
     // ---- ascending read id: one move on the device, one copy into the (pinned) result block
     const u64 total = packed_total;
-    necat_candidate* res = (necat_candidate*)result_alloc(std::max<u64>(1, total) * sizeof(necat_candidate));
-    if (!res) return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed");
+    necat_candidate* res = dev ? nullptr : (necat_candidate*)result_alloc(std::max<u64>(1, total) * sizeof(necat_candidate));
+    if (!dev && !res) return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed");
+    std::vector<u64> by_read((size_t)nreads + 1, 0), dst_off(nreads);
+    for (u32 i = 0; i < nreads; ++i) by_read[order[i] + 1] = (u64)ncands_by_order[i];
+    for (u32 r = 0; r < nreads; ++r) by_read[r + 1] += by_read[r];
+    for (u32 i = 0; i < nreads; ++i) dst_off[i] = by_read[order[i]];
+    if (dev) { dev->n = total; fill_groups(dev, by_read, nreads); }
     if (total) {
-        std::vector<u64> by_read((size_t)nreads + 1, 0), dst_off(nreads);
-        for (u32 i = 0; i < nreads; ++i) by_read[order[i] + 1] = (u64)ncands_by_order[i];
-        for (u32 r = 0; r < nreads; ++r) by_read[r + 1] += by_read[r];
-        for (u32 i = 0; i < nreads; ++i) dst_off[i] = by_read[order[i]];
         int rc2;
         if ((rc2 = buf_ensure(ctx, ctx->scratch[SC_SEED_FINAL], total * sizeof(necat_candidate))) ||
             (rc2 = buf_ensure(ctx, ctx->scratch[SC_SEED_META], (size_t)nreads * 20 + 64))) { necat_free(res); return rc2; }
@@ -585,15 +599,26 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
         hipLaunchKernelGGL(k_move_cands, dim3(grid_for((u64)nreads * 64, 256)), dim3(256), 0, s, (const necat_candidate*)ctx->scratch[SC_SEED_ALL].p,
                            (const u64*)d_src, (const u64*)d_dsto, (const i32*)d_cnt, nreads, d_fin);
         e[3] = hipGetLastError();
-        e[4] = hipMemcpyAsync(res, d_fin, total * sizeof(necat_candidate), hipMemcpyDeviceToHost, s);
+        if (dev) dev->d = d_fin;
+        e[4] = dev ? hipSuccess : hipMemcpyAsync(res, d_fin, total * sizeof(necat_candidate), hipMemcpyDeviceToHost, s);
         e[5] = hipEventRecord(ctx->ev[1], s);
         e[6] = hipStreamSynchronize(s);
         for (hipError_t x : e) if (x != hipSuccess) { necat_free(res); return set_err(ctx, NECAT_ERR_DEVICE, "seeding result assembly: %s", hipGetErrorString(x)); }
     } else { NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s)); NECAT_HIP(ctx, hipStreamSynchronize(s)); }
     ctx->tm.seed_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
     tick("assemble in read order");
-    *out = res; *n_out = total;
+    if (!dev) { *out = res; *n_out = total; }
     return NECAT_OK;
+}
+}  // namespace
+
+int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, const necat_volume* reads,
+                          int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt,
+                          necat_candidate** out, uint64_t* n_out)
+{
+    if (!ctx || !ix || !ref || !reads || !opt || !out || !n_out) return NECAT_ERR_ARG;
+    *out = nullptr; *n_out = 0;
+    return find_impl(ctx, ix, ref, reads, read_start_id, ref_start_id, pairwise, opt, out, n_out, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------ extension
@@ -750,8 +775,9 @@ struct AlignOut {
 // (every candidate's alignment with its columns, `ao` != nullptr).
 int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* reads, int read_start_id, int ref_start_id,
                 const necat_candidate* cands, uint64_t n, const necat_map_options* opt, int tail_match_len,
-                necat_m4** out, uint64_t* n_out, AlignOut* ao)
+                necat_m4** out, uint64_t* n_out, AlignOut* ao, const DevCands* dev = nullptr)
 {
+    // dev != nullptr (necat_map_pair): the candidates are this library's own, still on the device
     auto t_prev = std::chrono::steady_clock::now();
     auto tick = [&](const char* what) {
         if (!(g_trace & 2)) return;
@@ -760,7 +786,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
         t_prev = now;
     };
     if (n >= (1ULL << 31)) return set_err(ctx, NECAT_ERR_ARG, "too many candidates in one call");
-    for (uint64_t i = 0; i < n; ++i) {
+    for (uint64_t i = 0; i < (dev ? 0 : n); ++i) {
         const necat_candidate& c = cands[i];
         const int64_t lq = (int64_t)c.qid - read_start_id, ls = (int64_t)c.sid - ref_start_id;
         if (lq < 0 || (uint64_t)lq >= reads->nseq || ls < 0 || (uint64_t)ls >= ref->nseq)
@@ -798,7 +824,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     u32* d_outcnt = (u32*)cb; cb += 128;          // [0..1] output counter, [2..9] list counts of the cohorts, [16..19] stats
     int* d_err = (int*)cb; cb += 64;
     u8* d_ok = (u8*)cb;
-    NECAT_HIP(ctx, hipMemcpyAsync(d_cands, cands, n * sizeof(necat_candidate), hipMemcpyHostToDevice, s));
+    NECAT_HIP(ctx, hipMemcpyAsync(d_cands, dev ? dev->d : cands, n * sizeof(necat_candidate), dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     NECAT_HIP(ctx, hipMemsetAsync(d_outcnt, 0, 192, s));
     auto cleanup = [&]() {};
     const size_t slab_per = (size_t)groups * kSlabB + kSlabA;
@@ -869,6 +895,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
             any = true;
             const int done = cohort_launch(ctx, dref, drd, k, X, kCohorts > 1 ? &co[c ^ 1] : nullptr);
             if (done < 0) { cleanup(); return done; }
+            if (goff.empty() && dev) goff = dev->group_off;
             if (goff.empty() && !ao) {
                 // while the first round runs: groups of equal qid for the containment filter
                 // (candidates arrive grouped per read: pm_worker.c:100-140)
@@ -964,6 +991,23 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
     *out = nullptr; *n_out = 0;
     if (n == 0) return NECAT_OK;
     return extend_impl(ctx, ref, reads, read_start_id, ref_start_id, cands, n, opt, tail_match_len, out, n_out, nullptr);
+}
+
+int necat_map_pair(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, const necat_volume* reads,
+                   int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt, int tail_match_len,
+                   necat_m4** out, uint64_t* n_out, uint64_t* n_candidates)
+{
+    if (!ctx || !ix || !ref || !reads || !opt || !out || !n_out) return NECAT_ERR_ARG;
+    *out = nullptr; *n_out = 0;
+    if (n_candidates) *n_candidates = 0;
+    necat_map_options o = *opt;
+    o.job = 1;                                   // the candidates of a mapping job: always sorted, cut to num_candidates
+    DevCands dev;
+    int rc = find_impl(ctx, ix, ref, reads, read_start_id, ref_start_id, pairwise, &o, nullptr, nullptr, &dev);
+    if (rc) return rc;
+    if (n_candidates) *n_candidates = dev.n;
+    if (dev.n == 0) return NECAT_OK;
+    return extend_impl(ctx, ref, reads, read_start_id, ref_start_id, nullptr, dev.n, &o, tail_match_len, out, n_out, nullptr, &dev);
 }
 
 int necat_onc_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_volume* reads, int read_start_id, int ref_start_id,

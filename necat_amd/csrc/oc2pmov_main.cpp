@@ -73,12 +73,11 @@ int main(int argc, char** argv)
         }
         const int read_start = vi.read_start_id[i];
         necat_candidate* cands = nullptr; uint64_t ncand = 0;
-        if ((rc = necat_find_candidates(ctx, ix, ref, reads, read_start, ref_start, 1, &opt, &cands, &ncand)))
-            return fail("necat_find_candidates", necat_last_error(ctx));
         if (opt.job == 1) {
+            // pm_search_one_volume with -j 1: seeding + extension, the candidates stay on the device
             necat_m4* m4 = nullptr; uint64_t nm4 = 0;
-            if ((rc = necat_extend(ctx, ref, reads, read_start, ref_start, cands, ncand, &opt, 1 /* ONC_TAIL_MATCH_LEN_SHORT */, &m4, &nm4)))
-                return fail("necat_extend", necat_last_error(ctx));
+            if ((rc = necat_map_pair(ctx, ix, ref, reads, read_start, ref_start, 1, &opt, 1 /* ONC_TAIL_MATCH_LEN_SHORT */, &m4, &nm4, &ncand)))
+                return fail("necat_map_pair", necat_last_error(ctx));
             for (uint64_t k = 0; k < nm4; ++k) {
                 const necat_m4& m = m4[k];
                 if (opt.binary_output) fwrite(&m, sizeof m, 1, out);
@@ -92,6 +91,8 @@ int main(int argc, char** argv)
             n_records += nm4;
             necat_free(m4);
         } else {
+            if ((rc = necat_find_candidates(ctx, ix, ref, reads, read_start, ref_start, 1, &opt, &cands, &ncand)))
+                return fail("necat_find_candidates", necat_last_error(ctx));
             for (uint64_t k = 0; k < ncand; ++k) {
                 const necat_candidate& c = cands[k];
                 if (opt.binary_output) { uint32_t item[7]; pack_candidate(&c, item); fwrite(item, 28, 1, out); }

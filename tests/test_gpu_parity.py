@@ -363,3 +363,26 @@ def test_index_lds_slices_equal_global_atomic_passes(small):
         ix.free(); vol.free(); c.close()
     assert np.array_equal(out[0][1], out[1][1]) and out[0][1].shape[0] > 1_000_000
     assert np.array_equal(out[0][0], out[1][0])
+
+
+def test_map_pair_equals_find_then_extend(ctx, multi):
+    """necat_map_pair (candidates never leave the device) = necat_find_candidates + necat_extend, for the self
+    pair and a cross-volume pair."""
+    from necat_amd import capi
+    d, rs, nv = multi
+    _, _, vols = capi.load_volumes_info(d)
+    opt = capi.default_options(**dict(util.SENSITIVE, job=1))
+    ref = ctx.load_volume(vols[0][0])
+    ix = ctx.build_index(ref, opt.kmer_size, opt.kmer_cnt_cutoff)
+    total = 0
+    for i in (0, 1):
+        reads = ref if i == 0 else ctx.load_volume(vols[i][0])
+        c = ctx.find_candidates(ix, ref, reads, vols[i][1], vols[0][1], opt, True)
+        a = ctx.extend(ref, reads, vols[i][1], vols[0][1], c, opt, 1)
+        b, nc = ctx.map_pair(ix, ref, reads, vols[i][1], vols[0][1], opt, True, 1)
+        assert nc == c.shape[0] and util.m4_key_rows(a) == util.m4_key_rows(b)
+        total += b.shape[0]
+        if reads is not ref:
+            reads.free()
+    ix.free(); ref.free()
+    assert total > 300
