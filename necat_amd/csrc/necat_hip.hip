@@ -625,21 +625,26 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
 
 namespace {
 
-// A cohort = one batch of candidates advancing through its rounds with its own buffers and stream pair.
-// Rounds inside a cohort are strictly ordered (a candidate's next block starts where its previous,
-// trimmed block ended).  The loop can keep two cohorts in flight (one in its DP kernel while the other
-// walks its tracebacks); on MI355X that measured slower than one cohort of twice the size, so one is
-// the default (see necat_extend).
-struct Cohort {
-    // buffers
-    ExtTask* tasks; u32* count; BlockItem* itemsA[2]; BlockItem* itemsB[2];   // count[2][2]: per list parity (nA, nB)
-    u64* fragA; u64* fragB; char* slabs; u8* opsA; u8* opsB; BlockResult* resA; BlockResult* resB;
+// One batch of candidates advancing through its rounds.  A candidate has one scheduled block at a time; the
+// blocks of a round sit in list A (<= 512 x 512) or list B (bigger last blocks).  The chain that bounds the
+// run is the list-A chain (frag -> DP -> traceback, round after round), so list B trails it by one round:
+//
+//     round r    stream a:  A(r)  = blocks of lists[r % 3].A      appends successors to lists[(r + 1) % 3]
+//                stream b:  B(r)  = blocks of lists[r % 3].B      appends successors to lists[(r + 2) % 3]
+//     round r+1 starts when A(r) and B(r - 1) are done: B(r) runs under A(r + 1).
+//
+// Three list buffers, because lists[(r + 2) % 3] receives appends (from B(r), later from A(r + 1)) while
+// lists[(r + 1) % 3] is still being filled by A(r) and lists[r % 3] is being consumed.  A successor planned by a
+// list-B block simply starts one round later.  The streams order B(r) after B(r - 1), so list B needs one set
+// of buffers; its band records live in their own pool (list A's pool is reused by A(r + 1) while B(r) runs).
+struct Batch {
+    ExtTask* tasks; u32* count;            // count[3][2]: (nA, nB) per list buffer
+    BlockItem* itemsA[3]; BlockItem* itemsB[3];
+    u64* fragA; u64* fragB; u8* opsA; u8* opsB; BlockResult* resA; BlockResult* resB;
     BlockItem* sortedB; u32* bins;          // list B of the round, sorted by size
     hipStream_t sa, sb;
-    hipEvent_t a0, a1, a2, b0, b1, b2;
-    // state
-    u64 base; u32 n; int parity; bool active, in_flight, a1_valid;
-    u32 nA, nB;
+    hipEvent_t a0, a1, a2, b0[2], b1[2], b2[2];
+    u64 base; u32 n;
 };
 
 struct ExtShared {
@@ -647,117 +652,128 @@ struct ExtShared {
     double error; int tail_match_len, min_align, read_start_id, ref_start_id;
     const u64* reads_off; const u64* ref_off;
     u8* task_ops = nullptr;      // alignment columns per task (necat_onc_align_batch)
-    bool lazy_pool = false;      // one cohort: the band pool grows to what a round needs
 };
 
-// finish the round a cohort has in flight (if any): wait, account, flip the list parity
-int cohort_retire(necat_ctx* ctx, Cohort& c)
+// all rounds of one batch (its first blocks are already in lists[0], appended by k_ext_init on stream a)
+int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch& c, const ExtShared& X)
 {
-    if (!c.in_flight) return NECAT_OK;
-    if (c.nA) NECAT_HIP(ctx, hipStreamSynchronize(c.sa));
-    if (c.nB) NECAT_HIP(ctx, hipStreamSynchronize(c.sb));
-    const double mA = c.nA ? ev_ms(c.a0, c.a1) : 0, tA = c.nA ? ev_ms(c.a1, c.a2) : 0, mB = c.nB ? ev_ms(c.b0, c.b1) : 0, tB = c.nB ? ev_ms(c.b1, c.b2) : 0;
-    ctx->tm.myers_ms += mA + mB;
-    ctx->tm.traceback_ms += tA + tB;
-    if (c.nA) { ctx->tm.myersA_ms += mA; ctx->tm.tracebackA_ms += tA; ctx->tm.myersA_launches += 1; ctx->tm.myersA_blocks += c.nA; }
-    if (c.nA > ctx->tm.myersA_big_blocks) { ctx->tm.myersA_big_blocks = c.nA; ctx->tm.myersA_big_ms = mA; }
-    if (g_trace & 1) {
-        static double last = 0;
-        const double now = wall_ms();
-        fprintf(stderr, "[necat] cohort@%lu round %3lu: nA=%7u nB=%7u myers %.3f + %.3f ms traceback %.3f + %.3f ms | round wall %.3f ms\n",
-                (unsigned long)c.base, (unsigned long)ctx->tm.rounds, c.nA, c.nB, mA, mB, tA, tB, now - last);
-        last = now;
-    }
-    ctx->tm.myers_launches += (c.nA ? 1 : 0) + (c.nB ? 1 : 0);
-    ctx->tm.myers_blocks += c.nA + c.nB;
-    ctx->tm.rounds += 1;
-    c.in_flight = false;
-    c.parity ^= 1;
-    return NECAT_OK;
-}
-
-// launch the next round of a cohort; returns 1 when the cohort has no scheduled block left
-int cohort_launch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Cohort& c, const ExtShared& X, const Cohort* other)
-{
-    const int p = c.parity;
-    u32 cnt[2] = {0, 0};
-    NECAT_HIP(ctx, hipMemcpyAsync(cnt, c.count + 2 * p, 8, hipMemcpyDeviceToHost, c.sa));
-    NECAT_HIP(ctx, hipMemsetAsync(c.count + 2 * (p ^ 1), 0, 8, c.sa));
-    NECAT_HIP(ctx, hipStreamSynchronize(c.sa));
-    const u32 nA = cnt[0], nB = cnt[1];
-    c.nA = nA; c.nB = nB;
-    if (nA + nB == 0) return 1;
-    const u32 gA = (nA + 63) / 64, gB = (nB + 63) / 64;
-    if (X.lazy_pool) {
-        // the band pool is sized by what the round needs (round 0 of the first call sets it; 35 GB instead of the
+    bool b_pending[2] = {false, false};
+    u32 b_blocks[2] = {0, 0};
+    u32 prev_nA = 0;
+    double last_wall = wall_ms();
+    auto account_b = [&](int slot) {
+        const double mB = ev_ms(c.b0[slot], c.b1[slot]), tB = ev_ms(c.b1[slot], c.b2[slot]);
+        ctx->tm.myers_ms += mB; ctx->tm.traceback_ms += tB;
+        ctx->tm.myers_launches += 1; ctx->tm.myers_blocks += b_blocks[slot];
+        if (g_trace & 1) fprintf(stderr, "[necat]          list B: %7u blocks  myers %.3f ms traceback %.3f ms\n", b_blocks[slot], mB, tB);
+        b_pending[slot] = false;
+    };
+    int idle = 0;
+    for (u32 r = 0;; ++r) {
+        // ---- A(r - 1) and B(r - 2) are done: lists[r % 3] is complete
+        NECAT_HIP(ctx, hipStreamSynchronize(c.sa));
+        if (prev_nA) {
+            const double mA = ev_ms(c.a0, c.a1), tA = ev_ms(c.a1, c.a2);
+            ctx->tm.myers_ms += mA; ctx->tm.traceback_ms += tA;
+            ctx->tm.myersA_ms += mA; ctx->tm.tracebackA_ms += tA; ctx->tm.myersA_launches += 1; ctx->tm.myersA_blocks += prev_nA;
+            if (prev_nA > ctx->tm.myersA_big_blocks) { ctx->tm.myersA_big_blocks = prev_nA; ctx->tm.myersA_big_ms = mA; }
+            ctx->tm.myers_launches += 1; ctx->tm.myers_blocks += prev_nA;
+            if (g_trace & 1) {
+                const double now = wall_ms();
+                fprintf(stderr, "[necat] batch@%lu round %3u: list A %7u blocks  myers %.3f ms traceback %.3f ms | round wall %.3f ms\n",
+                        (unsigned long)c.base, r - 1, prev_nA, mA, tA, now - last_wall);
+                last_wall = now;
+            }
+        }
+        if (b_pending[r & 1]) { NECAT_HIP(ctx, hipEventSynchronize(c.b2[r & 1])); account_b(r & 1); }
+        const int cur = r % 3, nxt = (r + 1) % 3, nxt2 = (r + 2) % 3;
+        u32 cnt[2] = {0, 0};
+        NECAT_HIP(ctx, hipMemcpyAsync(cnt, c.count + 2 * cur, 8, hipMemcpyDeviceToHost, c.sa));
+        NECAT_HIP(ctx, hipMemsetAsync(c.count + 2 * nxt2, 0, 8, c.sa));      // nobody appends to lists[(r + 2) % 3] before B(r), launched below
+        NECAT_HIP(ctx, hipStreamSynchronize(c.sa));
+        const u32 nA = cnt[0], nB = cnt[1];
+        prev_nA = nA;
+        if (nA + nB == 0) {
+            // nothing scheduled: over, unless a list-B round still in flight plans successors
+            if (!b_pending[0] && !b_pending[1]) { if (++idle >= 2) break; }
+            continue;
+        }
+        idle = 0;
+        ctx->tm.rounds += 1;
+        const u32 gA = (nA + 63) / 64, gB = (nB + 63) / 64;
+        const u32 epoch = ++ctx->epoch & 0x3fffffu;
+        // the band pools are sized by what a round needs (round 0 of the first call sets them: 35 GB instead of the
         // 76 GB worst case "every block in list B" at E. coli size - hipMalloc costs ~13 ms per GB)
-        const size_t need = (size_t)gA * kSlabA + (size_t)gB * kSlabB;
-        if (need > ctx->scratch[SC_EXT_MAT].cap) {
+        if ((size_t)gA * kSlabA > ctx->scratch[SC_EXT_MAT].cap) {
+            const size_t need = (size_t)gA * kSlabA;
             int rc = ensure_zeroed(ctx, ctx->scratch[SC_EXT_MAT], need + need / 8, c.sa);
             if (rc) return rc;
             NECAT_HIP(ctx, hipStreamSynchronize(c.sa));
         }
-        c.slabs = (char*)ctx->scratch[SC_EXT_MAT].p;
-    }
-    char* slabsB = c.slabs + (size_t)gA * kSlabA;
-    const BlockItem* itA = c.itemsA[p]; const BlockItem* itB = c.itemsB[p];
-    const u32 epoch = ++ctx->epoch & 0x3fffffu;
-    ExtLists next; next.count = c.count + 2 * (p ^ 1); next.itemsA = c.itemsA[p ^ 1]; next.itemsB = c.itemsB[p ^ 1]; next.task_ops = X.task_ops;
-    // keep the two cohorts in anti-phase while both are in their bulk rounds: this cohort's DP kernel
-    // starts when the other's DP kernel is done, i.e. it overlaps the other's traceback
-    if (g_antiphase && other && other->in_flight && other->a1_valid && nA > g_coop_threshold && other->nA > g_coop_threshold)
-        NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, other->a1, 0));
-    c.a1_valid = false;
-    if (nA) {
-        hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)gA * 64 * (kWordsA + kTWordsA), 256)), dim3(256), 0, c.sa,
-                           drd, dref, itA, nA, c.fragA);
-        NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<A>");
-        NECAT_HIP(ctx, hipEventRecord(c.a0, c.sa));
-        if (nA <= g_coop_threshold)
-            hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((nA + 7) / 8), dim3(64), 0, c.sa, itA, nA,
-                               (const u64*)c.fragA, c.slabs, kSlabA, X.error, c.resA, X.stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
-        else
-            hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, false>), dim3(gA), dim3(64), 0, c.sa, itA, nA,   // list A also holds last blocks <= 512 x 512
-                               (const u64*)c.fragA, c.slabs, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
-        NECAT_CHECK_LAUNCH(ctx, "k_myers<A>");
-        NECAT_HIP(ctx, hipEventRecord(c.a1, c.sa));
-        c.a1_valid = true;
-        hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false>), dim3(gA), dim3(64), 0, c.sa, itA, nA,
-                           (const u64*)c.fragA, (const char*)c.slabs, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
-                           (i32*)nullptr, X.d_err, next, epoch);
-        NECAT_CHECK_LAUNCH(ctx, "k_traceback<A>");
-        NECAT_HIP(ctx, hipEventRecord(c.a2, c.sa));
-    }
-    if (nB) {
-        // (below ~2 k blocks every wave is resident at once and the round lasts as long as its longest walk: order is irrelevant)
-        if (nB >= 2048 && g_sort_b) {
-            NECAT_HIP(ctx, hipMemsetAsync(c.bins, 0, 1024 * 4, c.sb));
-            hipLaunchKernelGGL(k_items_hist, dim3(grid_for(nB, 256)), dim3(256), 0, c.sb, itB, nB, c.bins);
-            hipLaunchKernelGGL(k_items_scan, dim3(1), dim3(1024), 0, c.sb, c.bins);
-            hipLaunchKernelGGL(k_items_scatter, dim3(grid_for(nB, 256)), dim3(256), 0, c.sb, itB, nB, c.bins, c.sortedB);
-            NECAT_CHECK_LAUNCH(ctx, "k_items_sort");
-            itB = c.sortedB;
+        if ((size_t)gB * kSlabB > ctx->scratch[SC_EXT_MATB].cap) {
+            NECAT_HIP(ctx, hipStreamSynchronize(c.sb));                       // B(r - 1) still walks the old pool
+            if (b_pending[(r + 1) & 1]) account_b((r + 1) & 1);
+            const size_t need = (size_t)gB * kSlabB;
+            int rc = ensure_zeroed(ctx, ctx->scratch[SC_EXT_MATB], need + need / 4, c.sb);
+            if (rc) return rc;
+            NECAT_HIP(ctx, hipStreamSynchronize(c.sb));
         }
-        hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, c.sb,
-                           drd, dref, itB, nB, c.fragB);
-        NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
-        NECAT_HIP(ctx, hipEventRecord(c.b0, c.sb));
-        if (nB <= g_coop_threshold)
-            hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, c.sb, itB, nB,
-                               (const u64*)c.fragB, slabsB, kSlabB, X.error, c.resB, X.stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
-        else
-            hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, c.sb, itB, nB,
-                               (const u64*)c.fragB, slabsB, kSlabB, X.error, c.resB, X.stats, epoch, 0u);
-        NECAT_CHECK_LAUNCH(ctx, "k_myers<B>");
-        NECAT_HIP(ctx, hipEventRecord(c.b1, c.sb));
-        hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false>), dim3(gB), dim3(64), 0, c.sb, itB, nB,
-                           (const u64*)c.fragB, (const char*)slabsB, kSlabB, (const BlockResult*)c.resB, c.opsB, c.tasks, X.tail_match_len,
-                           (i32*)nullptr, X.d_err, next, epoch);
-        NECAT_CHECK_LAUNCH(ctx, "k_traceback<B>");
-        NECAT_HIP(ctx, hipEventRecord(c.b2, c.sb));
+        char* slabsA = (char*)ctx->scratch[SC_EXT_MAT].p;
+        char* slabsB = (char*)ctx->scratch[SC_EXT_MATB].p;
+        const BlockItem* itA = c.itemsA[cur]; const BlockItem* itB = c.itemsB[cur];
+        if (nA) {
+            ExtLists next; next.count = c.count + 2 * nxt; next.itemsA = c.itemsA[nxt]; next.itemsB = c.itemsB[nxt]; next.task_ops = X.task_ops;
+            hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)gA * 64 * (kWordsA + kTWordsA), 256)), dim3(256), 0, c.sa,
+                               drd, dref, itA, nA, c.fragA);
+            NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<A>");
+            NECAT_HIP(ctx, hipEventRecord(c.a0, c.sa));
+            if (nA <= g_coop_threshold)
+                hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((nA + 7) / 8), dim3(64), 0, c.sa, itA, nA,
+                                   (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
+            else
+                hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, false>), dim3(gA), dim3(64), 0, c.sa, itA, nA,   // list A also holds last blocks <= 512 x 512
+                                   (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
+            NECAT_CHECK_LAUNCH(ctx, "k_myers<A>");
+            NECAT_HIP(ctx, hipEventRecord(c.a1, c.sa));
+            hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false>), dim3(gA), dim3(64), 0, c.sa, itA, nA,
+                               (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
+                               (i32*)nullptr, X.d_err, next, epoch);
+            NECAT_CHECK_LAUNCH(ctx, "k_traceback<A>");
+            NECAT_HIP(ctx, hipEventRecord(c.a2, c.sa));
+        }
+        if (nB) {
+            const int slot = r & 1;
+            ExtLists next; next.count = c.count + 2 * nxt2; next.itemsA = c.itemsA[nxt2]; next.itemsB = c.itemsB[nxt2]; next.task_ops = X.task_ops;
+            // (below ~2 k blocks every wave is resident at once and the round lasts as long as its longest walk: order is irrelevant)
+            if (nB >= 2048 && g_sort_b) {
+                NECAT_HIP(ctx, hipMemsetAsync(c.bins, 0, 1024 * 4, c.sb));
+                hipLaunchKernelGGL(k_items_hist, dim3(grid_for(nB, 256)), dim3(256), 0, c.sb, itB, nB, c.bins);
+                hipLaunchKernelGGL(k_items_scan, dim3(1), dim3(1024), 0, c.sb, c.bins);
+                hipLaunchKernelGGL(k_items_scatter, dim3(grid_for(nB, 256)), dim3(256), 0, c.sb, itB, nB, c.bins, c.sortedB);
+                NECAT_CHECK_LAUNCH(ctx, "k_items_sort");
+                itB = c.sortedB;
+            }
+            hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, c.sb,
+                               drd, dref, itB, nB, c.fragB);
+            NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
+            NECAT_HIP(ctx, hipEventRecord(c.b0[slot], c.sb));
+            if (nB <= g_coop_threshold)
+                hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, c.sb, itB, nB,
+                                   (const u64*)c.fragB, slabsB, kSlabB, X.error, c.resB, X.stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
+            else
+                hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, c.sb, itB, nB,
+                                   (const u64*)c.fragB, slabsB, kSlabB, X.error, c.resB, X.stats, epoch, 0u);
+            NECAT_CHECK_LAUNCH(ctx, "k_myers<B>");
+            NECAT_HIP(ctx, hipEventRecord(c.b1[slot], c.sb));
+            hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false>), dim3(gB), dim3(64), 0, c.sb, itB, nB,
+                               (const u64*)c.fragB, (const char*)slabsB, kSlabB, (const BlockResult*)c.resB, c.opsB, c.tasks, X.tail_match_len,
+                               (i32*)nullptr, X.d_err, next, epoch);
+            NECAT_CHECK_LAUNCH(ctx, "k_traceback<B>");
+            NECAT_HIP(ctx, hipEventRecord(c.b2[slot], c.sb));
+            b_pending[slot] = true; b_blocks[slot] = nB;
+        }
     }
-    c.in_flight = true;
-    return 0;
+    return NECAT_OK;
 }
 
 }  // namespace
@@ -804,12 +820,9 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     ctx->tm.myersA_ms = ctx->tm.tracebackA_ms = 0; ctx->tm.myersA_launches = ctx->tm.myersA_blocks = 0;
     ctx->tm.myersA_big_ms = 0; ctx->tm.myersA_big_blocks = 0;
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
-    // the cohorts share the band pool: <= 393 216 candidates in flight in total (~130 GB of the 288 GB HBM).
-    // Default: ONE cohort.  Two (NECAT_COHORTS=2) were measured slower on MI355X (E. coli 129 vs 111 ms,
-    // yeast-size 1.09 vs 1.08 s): both kernels already sit on their per-launch latency floor at half size.
-    constexpr int kMaxCohorts = 2;
-    const int kCohorts = ao ? 1 : g_cohorts;       // the column arena is per batch
-    const u32 cap = (u32)std::min<uint64_t>(((n + kCohorts - 1) / kCohorts + 63) & ~63ULL, 393216 / kCohorts);
+    // batches of <= 393 216 candidates (their band records: <= ~50 GB for list A + what list B needs)
+    const uint64_t n_batches = (n + 393215) / 393216;
+    const u32 cap = (u32)((((n + n_batches - 1) / n_batches) + 63) & ~63ULL);
     const u32 groups = cap / 64 + 1;
     int rc;
     // candidate-wide arrays
@@ -821,128 +834,107 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     necat_m4* d_m4 = (necat_m4*)cb; cb += n * sizeof(necat_m4);
     necat_m4* d_out = (necat_m4*)cb; cb += n * sizeof(necat_m4);
     u64* d_goff = (u64*)cb; cb += (n_groups_max + 1) * 8;
-    u32* d_outcnt = (u32*)cb; cb += 128;          // [0..1] output counter, [2..9] list counts of the cohorts, [16..19] stats
+    u32* d_outcnt = (u32*)cb; cb += 128;          // [0..1] output counter, [2..7] list counts (3 buffers x (nA, nB)), [16..19] stats
     int* d_err = (int*)cb; cb += 64;
     u8* d_ok = (u8*)cb;
     NECAT_HIP(ctx, hipMemcpyAsync(d_cands, dev ? dev->d : cands, n * sizeof(necat_candidate), dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     NECAT_HIP(ctx, hipMemsetAsync(d_outcnt, 0, 192, s));
     auto cleanup = [&]() {};
-    const size_t slab_per = (size_t)groups * kSlabB + kSlabA;
-    if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_TASKS], kCohorts * ((size_t)cap * sizeof(ExtTask) + 64))) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], kCohorts * ((size_t)cap * 5 * sizeof(BlockItem) + 4096 + 64))) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_FRAG], kCohorts * (size_t)groups * 64 * (kFragWordsA + kFragWordsB) * 8)) ||
-        (kCohorts > 1 && (rc = ensure_zeroed(ctx, ctx->scratch[SC_EXT_MAT], kCohorts * slab_per, s))) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_OPS], kCohorts * (size_t)groups * 64 * (kOpsA + kOpsB))) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_RES], kCohorts * (size_t)groups * 64 * 2 * sizeof(BlockResult)))) { cleanup(); return rc; }
-    NECAT_HIP(ctx, hipStreamSynchronize(s));        // candidates + zeroed counters are in place before the cohort streams start
+    if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_TASKS], (size_t)cap * sizeof(ExtTask) + 64)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], (size_t)cap * 7 * sizeof(BlockItem) + 4096 + 64)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_FRAG], (size_t)groups * 64 * (kFragWordsA + kFragWordsB) * 8)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_OPS], (size_t)groups * 64 * (kOpsA + kOpsB))) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_RES], (size_t)groups * 64 * 2 * sizeof(BlockResult)))) { cleanup(); return rc; }
+    NECAT_HIP(ctx, hipStreamSynchronize(s));        // candidates + zeroed counters are in place before the batch streams start
     tick("buffers + upload");
-    Cohort co[kMaxCohorts];
-    hipStream_t cs[4] = {ctx->stream_a, ctx->stream_b, ctx->stream_c, ctx->stream_d};
-    for (int c = 0; c < kCohorts; ++c) {
-        Cohort& k = co[c];
-        k.tasks = (ExtTask*)((char*)ctx->scratch[SC_EXT_TASKS].p + c * ((size_t)cap * sizeof(ExtTask) + 64));
-        BlockItem* q = (BlockItem*)((char*)ctx->scratch[SC_EXT_LISTS].p + c * ((size_t)cap * 5 * sizeof(BlockItem) + 4096 + 64));
-        k.itemsA[0] = q; k.itemsB[0] = q + cap; k.itemsA[1] = q + 2 * (size_t)cap; k.itemsB[1] = q + 3 * (size_t)cap;
-        k.sortedB = q + 4 * (size_t)cap; k.bins = (u32*)(q + 5 * (size_t)cap);
-        k.fragA = (u64*)ctx->scratch[SC_EXT_FRAG].p + c * (size_t)groups * 64 * (kFragWordsA + kFragWordsB); k.fragB = k.fragA + (size_t)groups * 64 * kFragWordsA;
-        k.slabs = kCohorts > 1 ? (char*)ctx->scratch[SC_EXT_MAT].p + c * slab_per : nullptr;
-        k.opsA = (u8*)ctx->scratch[SC_EXT_OPS].p + c * (size_t)groups * 64 * (kOpsA + kOpsB); k.opsB = k.opsA + (size_t)groups * 64 * kOpsA;
-        k.resA = (BlockResult*)ctx->scratch[SC_EXT_RES].p + c * (size_t)groups * 64 * 2; k.resB = k.resA + (size_t)groups * 64;
-        k.count = d_outcnt + 2 + 4 * c;
-        k.sa = cs[2 * c]; k.sb = cs[2 * c + 1];
-        k.a0 = ctx->ev[4 + 6 * c]; k.a1 = ctx->ev[5 + 6 * c]; k.a2 = ctx->ev[6 + 6 * c];
-        k.b0 = ctx->ev[7 + 6 * c]; k.b1 = ctx->ev[8 + 6 * c]; k.b2 = ctx->ev[9 + 6 * c];
-        k.active = k.in_flight = k.a1_valid = false; k.nA = k.nB = 0; k.base = 0; k.n = 0; k.parity = 0;
+    Batch k;
+    {
+        k.tasks = (ExtTask*)ctx->scratch[SC_EXT_TASKS].p;
+        BlockItem* q = (BlockItem*)ctx->scratch[SC_EXT_LISTS].p;
+        for (int j = 0; j < 3; ++j) { k.itemsA[j] = q + (size_t)(2 * j) * cap; k.itemsB[j] = q + (size_t)(2 * j + 1) * cap; }
+        k.sortedB = q + 6 * (size_t)cap; k.bins = (u32*)(q + 7 * (size_t)cap);
+        k.fragA = (u64*)ctx->scratch[SC_EXT_FRAG].p; k.fragB = k.fragA + (size_t)groups * 64 * kFragWordsA;
+        k.opsA = (u8*)ctx->scratch[SC_EXT_OPS].p; k.opsB = k.opsA + (size_t)groups * 64 * kOpsA;
+        k.resA = (BlockResult*)ctx->scratch[SC_EXT_RES].p; k.resB = k.resA + (size_t)groups * 64;
+        k.count = d_outcnt + 2;
+        k.sa = ctx->stream_a; k.sb = ctx->stream_b;
+        k.a0 = ctx->ev[4]; k.a1 = ctx->ev[5]; k.a2 = ctx->ev[6];
+        for (int j = 0; j < 2; ++j) { k.b0[j] = ctx->ev[7 + 3 * j]; k.b1[j] = ctx->ev[8 + 3 * j]; k.b2[j] = ctx->ev[9 + 3 * j]; }
+        k.base = 0; k.n = 0;
     }
     ExtShared X;
     X.d_cands = d_cands; X.d_m4 = d_m4; X.d_ok = d_ok; X.d_err = d_err; X.stats = (unsigned long long*)(d_outcnt + 16);
     X.error = opt->error; X.tail_match_len = tail_match_len; X.min_align = opt->align_size_cutoff;
     X.read_start_id = read_start_id; X.ref_start_id = ref_start_id; X.reads_off = reads->seq_off; X.ref_off = ref->seq_off;
-    X.lazy_pool = kCohorts == 1;
-    uint64_t next_base = 0;
     std::vector<u64> goff;
-    for (;;) {
-        bool any = false;
-        for (int c = 0; c < kCohorts; ++c) {
-            Cohort& k = co[c];
-            if (!k.active) {
-                if (next_base >= n) continue;
-                // start the next batch on this cohort
-                k.base = next_base; k.n = (u32)std::min<uint64_t>(cap, n - next_base); next_base += k.n;
-                k.parity = 0; k.active = true; k.in_flight = false; k.a1_valid = false;
-                NECAT_HIP(ctx, hipMemsetAsync(k.count, 0, 16, k.sa));
-                ExtLists L0; L0.count = k.count; L0.itemsA = k.itemsA[0]; L0.itemsB = k.itemsB[0];
-                const u64* d_ops_base = nullptr;
-                if (ao) {
-                    // column region of a task: left stream (<= qoff + soff columns) then right stream
-                    // (<= what is left of both reads from the anchor the left extension moved back)
-                    std::vector<u64> base(k.n + 1, 0);
-                    for (u32 i = 0; i < k.n; ++i) {
-                        const necat_candidate& c = cands[k.base + i];
-                        base[i + 1] = base[i] + ((c.qsize + c.ssize + c.qoff + c.soff + 64) & ~15ULL);
-                    }
-                    if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_COLS], base[k.n] + (size_t)(k.n + 1) * 8 + 64))) { cleanup(); return rc; }
-                    X.task_ops = (u8*)ctx->scratch[SC_EXT_COLS].p;
-                    u64* d_base = (u64*)(X.task_ops + ((base[k.n] + 63) & ~63ULL));
-                    NECAT_HIP(ctx, hipMemcpyAsync(d_base, base.data(), (size_t)k.n * 8, hipMemcpyHostToDevice, k.sa));
-                    NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
-                    d_ops_base = d_base;
-                }
-                hipLaunchKernelGGL(k_ext_init, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, d_cands + k.base, k.n, (u32)k.base,
-                                   read_start_id, ref_start_id, X.reads_off, X.ref_off, k.tasks, L0, d_ops_base);
-                NECAT_CHECK_LAUNCH(ctx, "k_ext_init");
-            } else if ((rc = cohort_retire(ctx, k))) { cleanup(); return rc; }
-            any = true;
-            const int done = cohort_launch(ctx, dref, drd, k, X, kCohorts > 1 ? &co[c ^ 1] : nullptr);
-            if (done < 0) { cleanup(); return done; }
-            if (goff.empty() && dev) goff = dev->group_off;
-            if (goff.empty() && !ao) {
-                // while the first round runs: groups of equal qid for the containment filter
-                // (candidates arrive grouped per read: pm_worker.c:100-140)
-                goff.push_back(0);
-                for (uint64_t i = 1; i < n; ++i) if (cands[i].qid != cands[i - 1].qid) goff.push_back(i);
-                goff.push_back(n);
+    for (uint64_t next_base = 0; next_base < n;) {
+        k.base = next_base; k.n = (u32)std::min<uint64_t>(cap, n - next_base); next_base += k.n;
+        NECAT_HIP(ctx, hipMemsetAsync(k.count, 0, 24, k.sa));
+        ExtLists L0; L0.count = k.count; L0.itemsA = k.itemsA[0]; L0.itemsB = k.itemsB[0];
+        const u64* d_ops_base = nullptr;
+        if (ao) {
+            // column region of a task: left stream (<= qoff + soff columns) then right stream
+            // (<= what is left of both reads from the anchor the left extension moved back)
+            std::vector<u64> base(k.n + 1, 0);
+            for (u32 i = 0; i < k.n; ++i) {
+                const necat_candidate& c = cands[k.base + i];
+                base[i + 1] = base[i] + ((c.qsize + c.ssize + c.qoff + c.soff + 64) & ~15ULL);
             }
-            if (done == 1 && !ao) {
-                hipLaunchKernelGGL(k_ext_result, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, (const ExtTask*)k.tasks, k.n, d_cands + k.base,
-                                   (u32)k.base, opt->align_size_cutoff, d_m4, d_ok);
-                NECAT_CHECK_LAUNCH(ctx, "k_ext_result");
+            if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_COLS], base[k.n] + (size_t)(k.n + 1) * 8 + 64))) { cleanup(); return rc; }
+            X.task_ops = (u8*)ctx->scratch[SC_EXT_COLS].p;
+            u64* d_base = (u64*)(X.task_ops + ((base[k.n] + 63) & ~63ULL));
+            NECAT_HIP(ctx, hipMemcpyAsync(d_base, base.data(), (size_t)k.n * 8, hipMemcpyHostToDevice, k.sa));
+            NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
+            d_ops_base = d_base;
+        }
+        hipLaunchKernelGGL(k_ext_init, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, d_cands + k.base, k.n, (u32)k.base,
+                           read_start_id, ref_start_id, X.reads_off, X.ref_off, k.tasks, L0, d_ops_base);
+        NECAT_CHECK_LAUNCH(ctx, "k_ext_init");
+        if (goff.empty() && dev) goff = dev->group_off;
+        if (goff.empty() && !ao) {
+            // while the first kernels run: groups of equal qid for the containment filter
+            // (candidates arrive grouped per read: pm_worker.c:100-140)
+            goff.push_back(0);
+            for (uint64_t i = 1; i < n; ++i) if (cands[i].qid != cands[i - 1].qid) goff.push_back(i);
+            goff.push_back(n);
+        }
+        if ((rc = run_batch(ctx, dref, drd, k, X))) { cleanup(); return rc; }
+        if (!ao) {
+            hipLaunchKernelGGL(k_ext_result, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, (const ExtTask*)k.tasks, k.n, d_cands + k.base,
+                               (u32)k.base, opt->align_size_cutoff, d_m4, d_ok);
+            NECAT_CHECK_LAUNCH(ctx, "k_ext_result");
+            NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
+        } else {
+            // per-candidate results + the batch's alignment columns, packed in candidate order
+            necat_alignment* d_aln = (necat_alignment*)d_m4;          // the M4 arrays are not used in this mode
+            u32* d_len = (u32*)d_out;
+            hipLaunchKernelGGL(k_ext_alignment, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, (const ExtTask*)k.tasks, k.n, 0u,
+                               opt->align_size_cutoff, d_aln, d_len);
+            NECAT_CHECK_LAUNCH(ctx, "k_ext_alignment");
+            std::vector<u32> len(k.n);
+            NECAT_HIP(ctx, hipMemcpyAsync(len.data(), d_len, (size_t)k.n * 4, hipMemcpyDeviceToHost, k.sa));
+            NECAT_HIP(ctx, hipMemcpyAsync(ao->aln + k.base, d_aln, (size_t)k.n * sizeof(necat_alignment), hipMemcpyDeviceToHost, k.sa));
+            NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
+            std::vector<u64> off(k.n + 1, 0);
+            for (u32 i = 0; i < k.n; ++i) off[i + 1] = off[i] + len[i];
+            const u64 tot = off[k.n], at = ao->total;
+            for (u32 i = 0; i < k.n; ++i) ao->off[k.base + i] = at + off[i];
+            ao->off[k.base + k.n] = at + tot;
+            if (tot) {
+                if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_COLS_OUT], tot + (size_t)(k.n + 1) * 8 + 64))) { cleanup(); return rc; }
+                u8* d_cols = (u8*)ctx->scratch[SC_EXT_COLS_OUT].p;
+                u64* d_off = (u64*)(d_cols + ((tot + 63) & ~63ULL));
+                NECAT_HIP(ctx, hipMemcpyAsync(d_off, off.data(), (size_t)k.n * 8, hipMemcpyHostToDevice, k.sa));
+                hipLaunchKernelGGL(k_ext_strings, dim3(grid_for((u64)k.n * 64, 256)), dim3(256), 0, k.sa, (const ExtTask*)k.tasks, k.n,
+                                   (const u8*)X.task_ops, (const u64*)d_off, d_cols);
+                NECAT_CHECK_LAUNCH(ctx, "k_ext_strings");
+                u8* part = (u8*)result_alloc(tot);
+                if (!part) { cleanup(); return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
+                ao->parts.emplace_back(part, tot); ao->total += tot;
+                NECAT_HIP(ctx, hipMemcpyAsync(part, d_cols, tot, hipMemcpyDeviceToHost, k.sa));
                 NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
-                k.active = false;
-            } else if (done == 1) {
-                // per-candidate results + the batch's alignment columns, packed in candidate order
-                necat_alignment* d_aln = (necat_alignment*)d_m4;          // the M4 arrays are not used in this mode
-                u32* d_len = (u32*)d_out;
-                hipLaunchKernelGGL(k_ext_alignment, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, (const ExtTask*)k.tasks, k.n, 0u,
-                                   opt->align_size_cutoff, d_aln, d_len);
-                NECAT_CHECK_LAUNCH(ctx, "k_ext_alignment");
-                std::vector<u32> len(k.n);
-                NECAT_HIP(ctx, hipMemcpyAsync(len.data(), d_len, (size_t)k.n * 4, hipMemcpyDeviceToHost, k.sa));
-                NECAT_HIP(ctx, hipMemcpyAsync(ao->aln + k.base, d_aln, (size_t)k.n * sizeof(necat_alignment), hipMemcpyDeviceToHost, k.sa));
-                NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
-                std::vector<u64> off(k.n + 1, 0);
-                for (u32 i = 0; i < k.n; ++i) off[i + 1] = off[i] + len[i];
-                const u64 tot = off[k.n], at = ao->total;
-                for (u32 i = 0; i < k.n; ++i) ao->off[k.base + i] = at + off[i];
-                ao->off[k.base + k.n] = at + tot;
-                if (tot) {
-                    if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_COLS_OUT], tot + (size_t)(k.n + 1) * 8 + 64))) { cleanup(); return rc; }
-                    u8* d_cols = (u8*)ctx->scratch[SC_EXT_COLS_OUT].p;
-                    u64* d_off = (u64*)(d_cols + ((tot + 63) & ~63ULL));
-                    NECAT_HIP(ctx, hipMemcpyAsync(d_off, off.data(), (size_t)k.n * 8, hipMemcpyHostToDevice, k.sa));
-                    hipLaunchKernelGGL(k_ext_strings, dim3(grid_for((u64)k.n * 64, 256)), dim3(256), 0, k.sa, (const ExtTask*)k.tasks, k.n,
-                                       (const u8*)X.task_ops, (const u64*)d_off, d_cols);
-                    NECAT_CHECK_LAUNCH(ctx, "k_ext_strings");
-                    u8* part = (u8*)result_alloc(tot);
-                    if (!part) { cleanup(); return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
-                    ao->parts.emplace_back(part, tot); ao->total += tot;
-                    NECAT_HIP(ctx, hipMemcpyAsync(part, d_cols, tot, hipMemcpyDeviceToHost, k.sa));
-                    NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
-                }
-                k.active = false;
             }
         }
-        if (!any) break;
     }
     tick("rounds");
     {
