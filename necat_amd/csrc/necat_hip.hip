@@ -635,14 +635,16 @@ namespace {
 //
 // Three list buffers, because lists[(r + 2) % 3] receives appends (from B(r), later from A(r + 1)) while
 // lists[(r + 1) % 3] is still being filled by A(r) and lists[r % 3] is being consumed.  A successor planned by a
-// list-B block simply starts one round later.  The streams order B(r) after B(r - 1), so list B needs one set
-// of buffers; its band records live in their own pool (list A's pool is reused by A(r + 1) while B(r) runs).
+// list-B block simply starts one round later.  B(r) and B(r - 1) run side by side on two streams with two
+// sets of buffers and band pools (list A's pool is reused by A(r + 1) while they run).
 struct Batch {
     ExtTask* tasks; u32* count;            // count[3][2]: (nA, nB) per list buffer
     BlockItem* itemsA[3]; BlockItem* itemsB[3];
-    u64* fragA; u64* fragB; u8* opsA; u8* opsB; BlockResult* resA; BlockResult* resB;
-    BlockItem* sortedB; u32* bins;          // list B of the round, sorted by size
-    hipStream_t sa, sb;
+    u64* fragA; u8* opsA; BlockResult* resA;
+    // list B: two sets (round parity) - B(r) and B(r - 1) are independent and run side by side
+    u64* fragB[2]; u8* opsB[2]; BlockResult* resB[2];
+    BlockItem* sortedB[2]; u32* bins[2];    // list B of the round, sorted by size
+    hipStream_t sa, sb[2];
     hipEvent_t a0, a1, a2, b0[2], b1[2], b2[2];
     u64 base; u32 n;
 };
@@ -710,16 +712,16 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
             if (rc) return rc;
             NECAT_HIP(ctx, hipStreamSynchronize(c.sa));
         }
-        if ((size_t)gB * kSlabB > ctx->scratch[SC_EXT_MATB].cap) {
-            NECAT_HIP(ctx, hipStreamSynchronize(c.sb));                       // B(r - 1) still walks the old pool
-            if (b_pending[(r + 1) & 1]) account_b((r + 1) & 1);
+        const int slot = r & 1;                                                // B(r - 2), the previous user of this slot, is done
+        DevBuf& poolB = ctx->scratch[slot ? SC_EXT_MATB2 : SC_EXT_MATB];
+        if ((size_t)gB * kSlabB > poolB.cap) {
             const size_t need = (size_t)gB * kSlabB;
-            int rc = ensure_zeroed(ctx, ctx->scratch[SC_EXT_MATB], need + need / 4, c.sb);
+            int rc = ensure_zeroed(ctx, poolB, need + need / 4, c.sa);
             if (rc) return rc;
-            NECAT_HIP(ctx, hipStreamSynchronize(c.sb));
+            NECAT_HIP(ctx, hipStreamSynchronize(c.sa));
         }
         char* slabsA = (char*)ctx->scratch[SC_EXT_MAT].p;
-        char* slabsB = (char*)ctx->scratch[SC_EXT_MATB].p;
+        char* slabsB = (char*)poolB.p;
         const BlockItem* itA = c.itemsA[cur]; const BlockItem* itB = c.itemsB[cur];
         if (nA) {
             ExtLists next; next.count = c.count + 2 * nxt; next.itemsA = c.itemsA[nxt]; next.itemsB = c.itemsB[nxt]; next.task_ops = X.task_ops;
@@ -742,34 +744,36 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
             NECAT_HIP(ctx, hipEventRecord(c.a2, c.sa));
         }
         if (nB) {
-            const int slot = r & 1;
+            // small lists (the late rounds, where a round lasts as long as its slowest chain) get alternating streams so
+            // that B(r) need not queue behind B(r - 1); big ones stay in one stream - three busy chains only add contention
+            hipStream_t sb = c.sb[nB < 4096 ? slot : 0];
             ExtLists next; next.count = c.count + 2 * nxt2; next.itemsA = c.itemsA[nxt2]; next.itemsB = c.itemsB[nxt2]; next.task_ops = X.task_ops;
             // (below ~2 k blocks every wave is resident at once and the round lasts as long as its longest walk: order is irrelevant)
             if (nB >= 2048 && g_sort_b) {
-                NECAT_HIP(ctx, hipMemsetAsync(c.bins, 0, 1024 * 4, c.sb));
-                hipLaunchKernelGGL(k_items_hist, dim3(grid_for(nB, 256)), dim3(256), 0, c.sb, itB, nB, c.bins);
-                hipLaunchKernelGGL(k_items_scan, dim3(1), dim3(1024), 0, c.sb, c.bins);
-                hipLaunchKernelGGL(k_items_scatter, dim3(grid_for(nB, 256)), dim3(256), 0, c.sb, itB, nB, c.bins, c.sortedB);
+                NECAT_HIP(ctx, hipMemsetAsync(c.bins[slot], 0, 1024 * 4, sb));
+                hipLaunchKernelGGL(k_items_hist, dim3(grid_for(nB, 256)), dim3(256), 0, sb, itB, nB, c.bins[slot]);
+                hipLaunchKernelGGL(k_items_scan, dim3(1), dim3(1024), 0, sb, c.bins[slot]);
+                hipLaunchKernelGGL(k_items_scatter, dim3(grid_for(nB, 256)), dim3(256), 0, sb, itB, nB, c.bins[slot], c.sortedB[slot]);
                 NECAT_CHECK_LAUNCH(ctx, "k_items_sort");
-                itB = c.sortedB;
+                itB = c.sortedB[slot];
             }
-            hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, c.sb,
-                               drd, dref, itB, nB, c.fragB);
+            hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, sb,
+                               drd, dref, itB, nB, c.fragB[slot]);
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
-            NECAT_HIP(ctx, hipEventRecord(c.b0[slot], c.sb));
+            NECAT_HIP(ctx, hipEventRecord(c.b0[slot], sb));
             if (nB <= g_coop_threshold)
-                hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, c.sb, itB, nB,
-                                   (const u64*)c.fragB, slabsB, kSlabB, X.error, c.resB, X.stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
+                hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB,
+                                   (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
             else
-                hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, c.sb, itB, nB,
-                                   (const u64*)c.fragB, slabsB, kSlabB, X.error, c.resB, X.stats, epoch, 0u);
+                hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB,
+                                   (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch, 0u);
             NECAT_CHECK_LAUNCH(ctx, "k_myers<B>");
-            NECAT_HIP(ctx, hipEventRecord(c.b1[slot], c.sb));
-            hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false>), dim3(gB), dim3(64), 0, c.sb, itB, nB,
-                               (const u64*)c.fragB, (const char*)slabsB, kSlabB, (const BlockResult*)c.resB, c.opsB, c.tasks, X.tail_match_len,
+            NECAT_HIP(ctx, hipEventRecord(c.b1[slot], sb));
+            hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB,
+                               (const u64*)c.fragB[slot], (const char*)slabsB, kSlabB, (const BlockResult*)c.resB[slot], c.opsB[slot], c.tasks, X.tail_match_len,
                                (i32*)nullptr, X.d_err, next, epoch);
             NECAT_CHECK_LAUNCH(ctx, "k_traceback<B>");
-            NECAT_HIP(ctx, hipEventRecord(c.b2[slot], c.sb));
+            NECAT_HIP(ctx, hipEventRecord(c.b2[slot], sb));
             b_pending[slot] = true; b_blocks[slot] = nB;
         }
     }
@@ -841,10 +845,10 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     NECAT_HIP(ctx, hipMemsetAsync(d_outcnt, 0, 192, s));
     auto cleanup = [&]() {};
     if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_TASKS], (size_t)cap * sizeof(ExtTask) + 64)) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], (size_t)cap * 7 * sizeof(BlockItem) + 4096 + 64)) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_FRAG], (size_t)groups * 64 * (kFragWordsA + kFragWordsB) * 8)) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_OPS], (size_t)groups * 64 * (kOpsA + kOpsB))) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_RES], (size_t)groups * 64 * 2 * sizeof(BlockResult)))) { cleanup(); return rc; }
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], (size_t)cap * 8 * sizeof(BlockItem) + 2 * 4096 + 64)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_FRAG], (size_t)groups * 64 * (kFragWordsA + 2 * kFragWordsB) * 8)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_OPS], (size_t)groups * 64 * (kOpsA + 2 * kOpsB))) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_RES], (size_t)groups * 64 * 3 * sizeof(BlockResult)))) { cleanup(); return rc; }
     NECAT_HIP(ctx, hipStreamSynchronize(s));        // candidates + zeroed counters are in place before the batch streams start
     tick("buffers + upload");
     Batch k;
@@ -852,12 +856,17 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
         k.tasks = (ExtTask*)ctx->scratch[SC_EXT_TASKS].p;
         BlockItem* q = (BlockItem*)ctx->scratch[SC_EXT_LISTS].p;
         for (int j = 0; j < 3; ++j) { k.itemsA[j] = q + (size_t)(2 * j) * cap; k.itemsB[j] = q + (size_t)(2 * j + 1) * cap; }
-        k.sortedB = q + 6 * (size_t)cap; k.bins = (u32*)(q + 7 * (size_t)cap);
-        k.fragA = (u64*)ctx->scratch[SC_EXT_FRAG].p; k.fragB = k.fragA + (size_t)groups * 64 * kFragWordsA;
-        k.opsA = (u8*)ctx->scratch[SC_EXT_OPS].p; k.opsB = k.opsA + (size_t)groups * 64 * kOpsA;
-        k.resA = (BlockResult*)ctx->scratch[SC_EXT_RES].p; k.resB = k.resA + (size_t)groups * 64;
+        k.fragA = (u64*)ctx->scratch[SC_EXT_FRAG].p;
+        k.opsA = (u8*)ctx->scratch[SC_EXT_OPS].p;
+        k.resA = (BlockResult*)ctx->scratch[SC_EXT_RES].p;
+        for (int j = 0; j < 2; ++j) {
+            k.sortedB[j] = q + (size_t)(6 + j) * cap; k.bins[j] = (u32*)(q + 8 * (size_t)cap) + 1024 * j;
+            k.fragB[j] = k.fragA + (size_t)groups * 64 * (kFragWordsA + j * kFragWordsB);
+            k.opsB[j] = k.opsA + (size_t)groups * 64 * (kOpsA + j * kOpsB);
+            k.resB[j] = k.resA + (size_t)groups * 64 * (1 + j);
+        }
         k.count = d_outcnt + 2;
-        k.sa = ctx->stream_a; k.sb = ctx->stream_b;
+        k.sa = ctx->stream_a; k.sb[0] = ctx->stream_b; k.sb[1] = ctx->stream_c;
         k.a0 = ctx->ev[4]; k.a1 = ctx->ev[5]; k.a2 = ctx->ev[6];
         for (int j = 0; j < 2; ++j) { k.b0[j] = ctx->ev[7 + 3 * j]; k.b1[j] = ctx->ev[8 + 3 * j]; k.b2[j] = ctx->ev[9 + 3 * j]; }
         k.base = 0; k.n = 0;
