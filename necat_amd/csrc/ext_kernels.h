@@ -300,7 +300,11 @@ NECAT_D int dpp_from_lane_below(int v)   // lane i receives v of lane i-1 (withi
     return __builtin_amdgcn_update_dpp(1, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
 }
 
-template <int NW, int TW, int COLS, int G>
+// SINGLE (small lists, where the round is as long as ONE block alignment): the NW pass recomputes exactly what the
+// SHW pass computed for the columns up to the end column (same recurrence, same boundary), its only purpose being
+// to know the distance for the store filter - so when store traffic is irrelevant the SHW pass stores every word
+// itself and the NW pass is skipped: half the latency.
+template <int NW, int TW, int COLS, int G, bool SINGLE = false>
 __global__ void __launch_bounds__(64)
 k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
              double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, u32 epoch, u32 item_base)
@@ -357,12 +361,18 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
     for (int s = 0; s < steps; ++s) {
         const int c = s - b;
         int hin = dpp_from_lane_below(hout);
+        const int Sup1 = SINGLE ? dpp_from_lane_below(S) : 0;     // score of word b-1 at column c (computed one step ago)
         if (b == 0) hin = 1;
         if (have && (u32)c < (u32)tn) {
             if ((c & 31) == 0) tcur = tw[c >> 5];
             const u64 eq = eq_of(c);
             hout = advance_block(P, M, eq, hin, P, M);
             S += hout;
+            if (SINGLE) {
+                ulonglong2* p = rec + rec_pos<NW>(c, b, il);
+                p[0] = make_ulonglong2(P, M);
+                p[1] = rec_tail(S, Sup1, 0, nblk - 1, rec_tag(epoch, c));
+            }
             if (is_last && S <= k && (best == -1 || S <= best)) {
                 if (S != best) { best = S; k = best; end0 = c - W; }
             }
@@ -387,7 +397,7 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
     const int tn2 = end0 + 1;
     int err = 0;
     if (best >= 0) { int ad = tn2 - qn; if (ad < 0) ad = -ad; if (best < ad) err = 1; }
-    const bool go = have && best >= 0 && !err;
+    const bool go = !SINGLE && have && best >= 0 && !err;
     steps = go ? tn2 + nblk - 1 : 0;
     for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
     P = ~0ULL; M = 0ULL; S = (b + 1) * 64; hout = 1;
@@ -414,13 +424,13 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
         }
     }
     if (is_last) {
-        if (best >= 0 && !err) {
+        if (!SINGLE && best >= 0 && !err) {
             int cs = S;
             if (W > 0) cs = S - popc64(P >> ((64 - W) & 63)) + popc64(M >> ((64 - W) & 63));
             if (cs != best) err = 2;
         }
         BlockResult br; br.dist = err ? -1 : best; br.endc = end0; br.err = err;
-        br.words = (u32)(nblk * (tn + (best >= 0 ? tn2 : 0)));
+        br.words = (u32)(nblk * (tn + (!SINGLE && best >= 0 ? tn2 : 0)));
         results[item] = br;
         atomicAdd(&stats[0], (unsigned long long)br.words); atomicAdd(&stats[1], (unsigned long long)(qn + tn));
     }

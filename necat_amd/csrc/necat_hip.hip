@@ -47,6 +47,7 @@ DevVolume dev_view(const necat_volume* v)
 // "always"; NECAT_COOP_THRESHOLD=0 selects the lane-per-block kernel (tests compare the two).
 u32 g_coop_threshold = 0xffffffffu;
 unsigned long long g_seed_budget = 48ULL << 20;   // seeding scratch budget per chunk, in k-mer hits
+u32 g_single_pass = 2048;     // lists up to this many blocks use the single-pass DP kernel (NECAT_SINGLE_PASS; 0 = never)
 int g_index_lds = 1;          // LDS-slice index passes (0: global-atomic bucket passes)
 int g_seed_wave = 1;          // wave-per-strand seed collection (0: the lane-per-strand kernel)
 int g_trace = 0;
@@ -82,6 +83,7 @@ int necat_ctx_create(int device_id, necat_ctx** out)
     if (hipSetDevice(device_id) != hipSuccess) return NECAT_ERR_DEVICE;
     necat_ctx* ctx = new necat_ctx();
     ctx->device = device_id;
+    if (const char* e = getenv("NECAT_SINGLE_PASS")) g_single_pass = (u32)strtoul(e, nullptr, 10);
     if (const char* e = getenv("NECAT_INDEX_LDS")) g_index_lds = atoi(e);
     if (const char* e = getenv("NECAT_SEED_WAVE")) g_seed_wave = atoi(e);
     g_seed_budget = 48ULL << 20;
@@ -729,7 +731,10 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                                drd, dref, itA, nA, c.fragA);
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<A>");
             NECAT_HIP(ctx, hipEventRecord(c.a0, c.sa));
-            if (nA <= g_coop_threshold)
+            if (nA <= g_single_pass)
+                hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8, true>), dim3((nA + 7) / 8), dim3(64), 0, c.sa, itA, nA,
+                                   (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
+            else if (nA <= g_coop_threshold)
                 hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((nA + 7) / 8), dim3(64), 0, c.sa, itA, nA,
                                    (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
             else
@@ -761,7 +766,10 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                                drd, dref, itB, nB, c.fragB[slot]);
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
             NECAT_HIP(ctx, hipEventRecord(c.b0[slot], sb));
-            if (nB <= g_coop_threshold)
+            if (nB <= g_single_pass)
+                hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16, true>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB,
+                                   (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch, 0u);
+            else if (nB <= g_coop_threshold)
                 hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB,
                                    (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
             else
