@@ -45,17 +45,30 @@ DevVolume dev_view(const necat_volume* v)
 // lane-per-block kernel (k_myers).  With the band store filter the cooperative kernel is the faster one at
 // every size measured on MI355X (200 k blocks: 2.66 vs 2.80 ms; 50 k: 0.77 vs 1.38 ms), so the default is
 // "always"; NECAT_COOP_THRESHOLD=0 selects the lane-per-block kernel (tests compare the two).
-u32 g_coop_threshold = 0xffffffffu;
-unsigned long long g_seed_budget = 48ULL << 20;   // seeding scratch budget per chunk, in k-mer hits
-u32 g_single_pass = 2048;     // lists up to this many blocks use the single-pass DP kernel (NECAT_SINGLE_PASS; 0 = never)
-int g_index_lds = 1;          // LDS-slice index passes (0: global-atomic bucket passes)
-int g_seed_wave = 1;          // wave-per-strand seed collection (0: the lane-per-strand kernel)
-int g_trace = 0;
-int g_antiphase = 1;
-int g_coop_filter = 1;  // NECAT_COOP_FILTER=0: the cooperative kernel stores every word (A/B tests)
-int g_sort_b = 1;       // NECAT_SORT_B=0 disables the size sort of list B
-int g_cohorts = 1;
-int g_dbg = 0;     // NECAT_DBG: profiling-only variants of the DP kernel (1 = no band stores, 2 = no NW pass)
+u32 g_coop_threshold;
+unsigned long long g_seed_budget;   // seeding scratch budget per chunk, in k-mer hits
+u32 g_single_pass;     // lists up to this many blocks use the single-pass DP kernel (NECAT_SINGLE_PASS; 0 = never)
+int g_index_lds;       // LDS-slice index passes (NECAT_INDEX_LDS=0: global-atomic bucket passes)
+int g_seed_wave;       // wave-per-strand seed collection (NECAT_SEED_WAVE=0: the lane-per-strand kernel)
+int g_trace;           // NECAT_TRACE: 1 = extension rounds, 2 = host stages
+int g_coop_filter;     // NECAT_COOP_FILTER=0: the cooperative kernel stores every word (A/B tests)
+int g_sort_b;          // NECAT_SORT_B=0 disables the size sort of list B
+int g_dbg;             // NECAT_DBG: profiling-only variants of the lane-per-block DP kernel (1 = no band stores, 2 = no NW pass)
+
+// Tuning / test knobs: process-wide, (re)read from the environment whenever a context is created, defaults otherwise.
+void read_knobs()
+{
+    auto num = [](const char* name, unsigned long long dflt) { const char* e = getenv(name); return e ? strtoull(e, nullptr, 10) : dflt; };
+    g_coop_threshold = (u32)num("NECAT_COOP_THRESHOLD", 0xffffffffu);
+    g_seed_budget = num("NECAT_SEED_BUDGET", 48ULL << 20);
+    g_single_pass = (u32)num("NECAT_SINGLE_PASS", 2048);
+    g_index_lds = (int)num("NECAT_INDEX_LDS", 1);
+    g_seed_wave = (int)num("NECAT_SEED_WAVE", 1);
+    g_trace = (int)num("NECAT_TRACE", 0);
+    g_coop_filter = (int)num("NECAT_COOP_FILTER", 1);
+    g_sort_b = (int)num("NECAT_SORT_B", 1);
+    g_dbg = (int)num("NECAT_DBG", 0);
+}
 
 double wall_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 
@@ -83,18 +96,7 @@ int necat_ctx_create(int device_id, necat_ctx** out)
     if (hipSetDevice(device_id) != hipSuccess) return NECAT_ERR_DEVICE;
     necat_ctx* ctx = new necat_ctx();
     ctx->device = device_id;
-    if (const char* e = getenv("NECAT_SINGLE_PASS")) g_single_pass = (u32)strtoul(e, nullptr, 10);
-    if (const char* e = getenv("NECAT_INDEX_LDS")) g_index_lds = atoi(e);
-    if (const char* e = getenv("NECAT_SEED_WAVE")) g_seed_wave = atoi(e);
-    g_seed_budget = 48ULL << 20;
-    if (const char* e = getenv("NECAT_SEED_BUDGET")) g_seed_budget = strtoull(e, nullptr, 10);
-    if (const char* e = getenv("NECAT_COOP_THRESHOLD")) g_coop_threshold = (u32)strtoul(e, nullptr, 10);
-    if (const char* e = getenv("NECAT_TRACE")) g_trace = atoi(e);
-    if (const char* e = getenv("NECAT_DBG")) g_dbg = atoi(e);
-    if (const char* e = getenv("NECAT_ANTIPHASE")) g_antiphase = atoi(e);
-    if (const char* e = getenv("NECAT_SORT_B")) g_sort_b = atoi(e);
-    if (const char* e = getenv("NECAT_COOP_FILTER")) g_coop_filter = atoi(e);
-    if (const char* e = getenv("NECAT_COHORTS")) g_cohorts = atoi(e) == 2 ? 2 : 1;
+    read_knobs();
     memset(&ctx->tm, 0, sizeof ctx->tm);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
@@ -102,8 +104,7 @@ int necat_ctx_create(int device_id, necat_ctx** out)
         ctx->num_cu = prop.multiProcessorCount;
     }
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream_a) != hipSuccess ||
-        hipStreamCreate(&ctx->stream_b) != hipSuccess || hipStreamCreate(&ctx->stream_c) != hipSuccess ||
-        hipStreamCreate(&ctx->stream_d) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
+        hipStreamCreate(&ctx->stream_b) != hipSuccess || hipStreamCreate(&ctx->stream_c) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
     for (int i = 0; i < 20; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
     *out = ctx;
     return NECAT_OK;
@@ -117,7 +118,7 @@ void necat_ctx_destroy(necat_ctx* ctx)
     for (auto& b : ctx->scratch) if (b.p) (void)hipFree(b.p);
     for (auto& b : ctx->idx_cache) if (b.p) (void)hipFree(b.p);
     for (int i = 0; i < 20; ++i) (void)hipEventDestroy(ctx->ev[i]);
-    (void)hipStreamDestroy(ctx->stream); (void)hipStreamDestroy(ctx->stream_a); (void)hipStreamDestroy(ctx->stream_b); (void)hipStreamDestroy(ctx->stream_c); (void)hipStreamDestroy(ctx->stream_d);
+    (void)hipStreamDestroy(ctx->stream); (void)hipStreamDestroy(ctx->stream_a); (void)hipStreamDestroy(ctx->stream_b); (void)hipStreamDestroy(ctx->stream_c);
     delete ctx;
 }
 

@@ -25,8 +25,8 @@ struct DevBuf {
 struct necat_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream_a = nullptr, stream_b = nullptr;   // first cohort: the two block shapes of a round run concurrently
-    hipStream_t stream_c = nullptr, stream_d = nullptr;   // stream pair of the second cohort
+    hipStream_t stream_a = nullptr, stream_b = nullptr;   // extension rounds: list A / list B run concurrently
+    hipStream_t stream_c = nullptr;                       // second list-B stream (small lists alternate)
     char err[1024] = {0};
     necat_timings tm;
     hipEvent_t ev[20];
