@@ -193,12 +193,12 @@ def main():
             k = next(v for n, v in pmc.items() if n.startswith(prefix))
             # FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section)
             return (2.0 * k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]) * 1024.0
-        traffic = pmc_bytes("void necat::k_myers_coop<8, 16, 512, 8>")
+        traffic = pmc_bytes("void necat::k_myers_coop<8, 16, 512, 8, false>")
         tb_traffic = pmc_bytes("void necat::k_traceback<8, 16, 512, 1024, false>")
     except Exception:
         pass
     tb_avg_ms = agg["tb_a_ms"] / a_launches
-    roofline = {"bound": "hbm", "kernel": "k_myers_coop<8,16,512,8>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "k_myers_coop<8,16,512,8,false>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                 "traffic_frac": round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_launch_ms > 0 else None,
                 "launches": int(agg["a_launches"]), "avg_launch_ms": round(avg_launch_ms, 4),

@@ -103,8 +103,8 @@ typedef struct {
     uint64_t myers_word_updates;/* 64-row word updates actually computed (SHW + NW) */
     uint64_t myers_cells_bases; /* sum over blocks of query+target fragment bases */
     uint64_t rounds;
-    /* the list-A kernels alone (full 512 x 512 blocks): the DP kernel k_myers_coop<8,16,512,8>
-     * (k_myers<8,16,512,true> above NECAT_COOP_THRESHOLD) and its traceback k_traceback<8,16,512,..> */
+    /* the list-A kernels alone (blocks <= 512 x 512), launches of more than NECAT_SINGLE_PASS blocks: the two-pass
+     * DP kernel k_myers_coop<8,16,512,8,false> and its traceback k_traceback<8,16,512,..> */
     double   myersA_ms;
     uint64_t myersA_launches, myersA_blocks;
     double   tracebackA_ms;

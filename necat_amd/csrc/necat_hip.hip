@@ -680,7 +680,9 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         if (prev_nA) {
             const double mA = ev_ms(c.a0, c.a1), tA = ev_ms(c.a1, c.a2);
             ctx->tm.myers_ms += mA; ctx->tm.traceback_ms += tA;
-            ctx->tm.myersA_ms += mA; ctx->tm.tracebackA_ms += tA; ctx->tm.myersA_launches += 1; ctx->tm.myersA_blocks += prev_nA;
+            if (prev_nA > g_single_pass) {      // the two-pass instantiation k_myers_coop<8,16,512,8,false> (bench.py's roofline kernel)
+                ctx->tm.myersA_ms += mA; ctx->tm.tracebackA_ms += tA; ctx->tm.myersA_launches += 1; ctx->tm.myersA_blocks += prev_nA;
+            }
             if (prev_nA > ctx->tm.myersA_big_blocks) { ctx->tm.myersA_big_blocks = prev_nA; ctx->tm.myersA_big_ms = mA; }
             ctx->tm.myers_launches += 1; ctx->tm.myers_blocks += prev_nA;
             if (g_trace & 1) {
