@@ -734,7 +734,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                                drd, dref, itA, nA, c.fragA);
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<A>");
             NECAT_HIP(ctx, hipEventRecord(c.a0, c.sa));
-            if (nA <= g_single_pass)
+            if (nA <= g_single_pass && nA <= g_coop_threshold)
                 hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8, true>), dim3((nA + 7) / 8), dim3(64), 0, c.sa, itA, nA,
                                    (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
             else if (nA <= g_coop_threshold)
@@ -769,7 +769,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                                drd, dref, itB, nB, c.fragB[slot]);
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
             NECAT_HIP(ctx, hipEventRecord(c.b0[slot], sb));
-            if (nB <= g_single_pass)
+            if (nB <= g_single_pass && nB <= g_coop_threshold)
                 hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16, true>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB,
                                    (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch, 0u);
             else if (nB <= g_coop_threshold)
