@@ -47,6 +47,7 @@ DevVolume dev_view(const necat_volume* v)
 // "always"; NECAT_COOP_THRESHOLD=0 selects the lane-per-block kernel (tests compare the two).
 u32 g_coop_threshold;
 unsigned long long g_seed_budget;   // seeding scratch budget per chunk, in k-mer hits
+u32 g_batch_cap;       // candidates per extension batch (NECAT_BATCH)
 u32 g_single_pass;     // lists up to this many blocks use the single-pass DP kernel (NECAT_SINGLE_PASS; 0 = never)
 int g_index_lds;       // LDS-slice index passes (NECAT_INDEX_LDS=0: global-atomic bucket passes)
 int g_seed_wave;       // wave-per-strand seed collection (NECAT_SEED_WAVE=0: the lane-per-strand kernel)
@@ -62,6 +63,7 @@ void read_knobs()
     g_coop_threshold = (u32)num("NECAT_COOP_THRESHOLD", 0xffffffffu);
     g_seed_budget = num("NECAT_SEED_BUDGET", 48ULL << 20);
     g_single_pass = (u32)num("NECAT_SINGLE_PASS", 2048);
+    g_batch_cap = (u32)std::max<unsigned long long>(64, num("NECAT_BATCH", 786432));
     g_index_lds = (int)num("NECAT_INDEX_LDS", 1);
     g_seed_wave = (int)num("NECAT_SEED_WAVE", 1);
     g_trace = (int)num("NECAT_TRACE", 0);
@@ -835,8 +837,10 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     ctx->tm.myersA_ms = ctx->tm.tracebackA_ms = 0; ctx->tm.myersA_launches = ctx->tm.myersA_blocks = 0;
     ctx->tm.myersA_big_ms = 0; ctx->tm.myersA_big_blocks = 0;
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
-    // batches of <= 393 216 candidates (their band records: <= ~50 GB for list A + what list B needs)
-    const uint64_t n_batches = (n + 393215) / 393216;
+    // batches of <= 786 432 candidates: every batch ends in ~20 latency-bound rounds, so fewer and bigger is better
+    // (yeast-size: 654 -> 615 ms against 393 216); their band records need <= 103 GB for list A + a few GB for list B
+    // of the 288 GB (NECAT_BATCH overrides)
+    const uint64_t n_batches = (n + g_batch_cap - 1) / g_batch_cap;
     const u32 cap = (u32)((((n + n_batches - 1) / n_batches) + 63) & ~63ULL);
     const u32 groups = cap / 64 + 1;
     int rc;
