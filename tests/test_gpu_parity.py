@@ -386,3 +386,29 @@ def test_map_pair_equals_find_then_extend(ctx, multi):
             reads.free()
     ix.free(); ref.free()
     assert total > 300
+
+
+def test_extension_in_several_batches(ctx, small):
+    """Candidates go through the extension in batches (NECAT_BATCH, default 786 432); tiny batches - many batch
+    switches, lists far below the single-pass threshold - must give the same M4 records and the same alignments."""
+    from necat_amd import capi
+    d, rs = small
+    opt = capi.default_options(**dict(util.FAST, job=1))
+    _, base = capi.pm_main(ctx, opt, 0, d)
+    os.environ["NECAT_BATCH"] = "320"
+    try:
+        c = capi.Context(0)
+    finally:
+        os.environ.pop("NECAT_BATCH", None)
+    _, got = capi.pm_main(c, opt, 0, d)
+    cands, _ = capi.pm_main(c, capi.default_options(**dict(util.FAST, job=0)), 0, d)
+    _, _, vols = capi.load_volumes_info(d)
+    vol = c.load_volume(vols[0][0])
+    a1 = c.onc_align_batch(vol, vol, 0, 0, cands[:900], opt, 4)
+    vol.free(); c.close()
+    vol = ctx.load_volume(vols[0][0])
+    a0 = ctx.onc_align_batch(vol, vol, 0, 0, cands[:900], opt, 4)
+    vol.free()
+    assert util.m4_key_rows(got) == util.m4_key_rows(base) and base.shape[0] > 500
+    for x, y in zip(a0, a1):
+        assert x.tobytes() == y.tobytes()
