@@ -116,7 +116,10 @@ def main():
     args = parse()
     rank, world, local, dist = dist_setup(args)
     from necat_amd import build, capi, synth
-    build.build_hip()
+    if rank == 0:
+        build.build_hip()          # no-op when the in-tree library is current; one rank only, the others wait
+    if dist is not None:
+        dist.barrier()
     opt_kw = dict(FAST, kmer_size=args.kmer, scan_window=args.scan_window)
     opt = capi.default_options(**dict(opt_kw, job=args.job, num_threads=1))
     # ---- synthetic volume of this rank, made resident in HBM before the clock starts
