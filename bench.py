@@ -114,6 +114,11 @@ def cpu_baseline(args, opt_kw):
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON result: whatever libraries print there (RCCL announces its path on
+    # stdout when the first communicator is created) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank, world, local, dist = dist_setup(args)
     from necat_amd import build, capi, synth
     if rank == 0:
@@ -240,7 +245,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, opt_kw)
         except Exception as e:  # the baseline is a reported extra; never fail the GPU measurement on it
             out["cpu_baseline"] = {"value": None, "unit": "overlaps/s", "cores": os.cpu_count(), "kind": "unavailable", "sample": str(e)}
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 
