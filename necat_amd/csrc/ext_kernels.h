@@ -80,15 +80,17 @@ NECAT_D void ext_append_block(const ExtTask& t, u32 ti, bool go, const ExtLists&
 __global__ void __launch_bounds__(256)
 k_ext_init(const necat_candidate* __restrict__ cands, u32 n, u32 cand_base, int read_start_id, int ref_start_id,
            const u64* __restrict__ reads_off, const u64* __restrict__ ref_off, ExtTask* __restrict__ tasks, ExtLists L,
-           const u64* __restrict__ ops_base)
+           const u64* __restrict__ ops_base, const u32* __restrict__ perm)
 {
+    // task i of the batch = candidate perm[cand_base + i] (batches ordered by expected chain length) or cand_base + i
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     ExtTask t;
     bool go = false;
     if (i < n) {
-        const necat_candidate c = cands[i];
+        const u32 ci = perm ? perm[cand_base + i] : cand_base + i;
+        const necat_candidate c = cands[ci];
         const int lq = c.qid - read_start_id, ls = c.sid - ref_start_id;
-        ext_init(t, (i32)(cand_base + i), c.qdir, (i64)reads_off[lq], (i32)c.qsize, (i64)ref_off[ls], (i32)c.ssize, (i32)c.qoff, (i32)c.soff);
+        ext_init(t, (i32)ci, c.qdir, (i64)reads_off[lq], (i32)c.qsize, (i64)ref_off[ls], (i32)c.ssize, (i32)c.qoff, (i32)c.soff);
         if (ops_base) t.ops_base = ops_base[i];
         go = ext_plan(t);          // first block (or an immediately finished candidate)
         tasks[i] = t;
@@ -509,21 +511,22 @@ k_traceback(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ 
 
 // ---- final records: pm_worker.c:56-80 (M4 fields), oc_aligner.c:419-450 (coordinates, identity) ----
 __global__ void __launch_bounds__(256)
-k_ext_result(const ExtTask* __restrict__ tasks, u32 n, const necat_candidate* __restrict__ cands, u32 cand_base,
+k_ext_result(const ExtTask* __restrict__ tasks, u32 n, const necat_candidate* __restrict__ cands,
              int min_align, necat_m4* __restrict__ m4, u8* __restrict__ ok)
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const ExtTask t = tasks[i];
-    const necat_candidate c = cands[i];
+    const u32 ci = (u32)t.cand;                  // results go to the candidate's own slot, whatever the batch order
+    const necat_candidate c = cands[ci];
     necat_m4 m;
     m.qid = c.qid; m.qdir = c.qdir; m.qoff = (u64)t.r_qoff; m.qend = (u64)t.r_qend; m.qext = c.qoff; m.qsize = c.qsize;
     m.sid = c.sid; m.sdir = 0; m.soff = (u64)t.r_toff; m.send = (u64)t.r_tend; m.sext = c.soff; m.ssize = c.ssize;
     m.ident_perc = t.r_cols ? 100.0 * (double)t.r_mat / (double)t.r_cols : 0.0;
     m.vscore = c.score; m._pad = 0;
     if (m.qdir == 1) { const u64 qo = m.qsize - m.qend, qe = m.qsize - m.qoff; m.qoff = qo; m.qend = qe; }
-    m4[cand_base + i] = m;
-    ok[cand_base + i] = t.r_cols >= min_align ? 1 : 0;
+    m4[ci] = m;
+    ok[ci] = t.r_cols >= min_align ? 1 : 0;
 }
 
 // necat_onc_align_batch: per-candidate results in strand coordinates (what onc_align leaves in OcAlignData)

@@ -864,6 +864,37 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_FRAG], (size_t)groups * 64 * (kFragWordsA + 2 * kFragWordsB) * 8)) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_OPS], (size_t)groups * 64 * (kOpsA + 2 * kOpsB))) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_RES], (size_t)groups * 64 * 3 * sizeof(BlockResult)))) { cleanup(); return rc; }
+    // Several batches: every batch runs as many rounds as its longest chain of blocks and ends in latency-bound rounds,
+    // so the candidates are dealt to the batches by expected chain length (what is left of the two reads beyond the
+    // anchor, in blocks), longest first: the first batch has the ~30-round chains, the last ones a handful of rounds.
+    u32* d_perm = nullptr;
+    if (n_batches > 1 && !ao) {
+        std::vector<necat_candidate> tmp;
+        const necat_candidate* hc = cands;
+        if (dev) {
+            tmp.resize(n);
+            NECAT_HIP(ctx, hipMemcpyAsync(tmp.data(), d_cands, n * sizeof(necat_candidate), hipMemcpyDeviceToHost, s));
+            NECAT_HIP(ctx, hipStreamSynchronize(s));
+            hc = tmp.data();
+        }
+        constexpr u32 kBins = 128;
+        std::vector<u8> bin(n);
+        u64 cnt[kBins + 1] = {0};
+        for (uint64_t i = 0; i < n; ++i) {
+            const necat_candidate& c = hc[i];
+            const u64 right = std::min(c.qsize - c.qoff, c.ssize - c.soff), left = std::min(c.qoff, c.soff);
+            const u64 b = std::min<u64>(kBins - 1, right / 480 + left / 480);
+            bin[i] = (u8)(kBins - 1 - b);                    // longest first
+            ++cnt[bin[i] + 1];
+        }
+        for (u32 b = 0; b < kBins; ++b) cnt[b + 1] += cnt[b];
+        std::vector<u32> perm(n);
+        for (uint64_t i = 0; i < n; ++i) perm[cnt[bin[i]]++] = (u32)i;
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_PERM], n * 4))) { cleanup(); return rc; }
+        d_perm = (u32*)ctx->scratch[SC_EXT_PERM].p;
+        NECAT_HIP(ctx, hipMemcpyAsync(d_perm, perm.data(), n * 4, hipMemcpyHostToDevice, s));
+        NECAT_HIP(ctx, hipStreamSynchronize(s));       // perm is a local
+    }
     NECAT_HIP(ctx, hipStreamSynchronize(s));        // candidates + zeroed counters are in place before the batch streams start
     tick("buffers + upload");
     Batch k;
@@ -911,8 +942,8 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
             NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
             d_ops_base = d_base;
         }
-        hipLaunchKernelGGL(k_ext_init, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, d_cands + k.base, k.n, (u32)k.base,
-                           read_start_id, ref_start_id, X.reads_off, X.ref_off, k.tasks, L0, d_ops_base);
+        hipLaunchKernelGGL(k_ext_init, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, (const necat_candidate*)d_cands, k.n, (u32)k.base,
+                           read_start_id, ref_start_id, X.reads_off, X.ref_off, k.tasks, L0, d_ops_base, (const u32*)d_perm);
         NECAT_CHECK_LAUNCH(ctx, "k_ext_init");
         if (goff.empty() && dev) goff = dev->group_off;
         if (goff.empty() && !ao) {
@@ -924,8 +955,8 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
         }
         if ((rc = run_batch(ctx, dref, drd, k, X))) { cleanup(); return rc; }
         if (!ao) {
-            hipLaunchKernelGGL(k_ext_result, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, (const ExtTask*)k.tasks, k.n, d_cands + k.base,
-                               (u32)k.base, opt->align_size_cutoff, d_m4, d_ok);
+            hipLaunchKernelGGL(k_ext_result, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, (const ExtTask*)k.tasks, k.n, (const necat_candidate*)d_cands,
+                               opt->align_size_cutoff, d_m4, d_ok);
             NECAT_CHECK_LAUNCH(ctx, "k_ext_result");
             NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
         } else {
