@@ -25,7 +25,7 @@ constexpr u64 kHighBit = 1ULL << 63;
 // edlib_ex.c:71-106 calculateBlock (Myers' Advance_Block), written on 32-bit halves: gfx950 has no
 // full-rate 64-bit integer add / shift (v_lshl_add_u64, v_lshlrev_b64 issue at a fraction of the
 // 32-bit rate and were ~1/3 of this function's time); add-with-carry and funnel shifts are full rate.
-NECAT_HD int advance_block(u64 Pv, u64 Mv, u64 Eq, int hin, u64& PvOut, u64& MvOut)
+NECAT_HD int advance_block_ph(u64 Pv, u64 Mv, u64 Eq, int hin, u64& PvOut, u64& MvOut, u64& PhOut)
 {
     const u32 pl = (u32)Pv, ph = (u32)(Pv >> 32), ml = (u32)Mv, mh = (u32)(Mv >> 32);
     u32 el = (u32)Eq;
@@ -40,6 +40,7 @@ NECAT_HD int advance_block(u64 Pv, u64 Mv, u64 Eq, int hin, u64& PvOut, u64& MvO
     const u32 xhl = (sl ^ pl) | el, xhh = (sh ^ ph) | eh;
     u32 Phl = ml | ~(xhl | pl), Phh = mh | ~(xhh | ph);
     u32 Mhl = pl & xhl, Mhh = ph & xhh;
+    PhOut = ((u64)Phh << 32) | Phl;                 // bit r: D[r][c] - D[r][c-1] == +1  (what the traceback asks)
     const int hout = (int)(Phh >> 31) - (int)(Mhh >> 31);
     Phh = (Phh << 1) | (Phl >> 31); Phl = (Phl << 1) | pos;
     Mhh = (Mhh << 1) | (Mhl >> 31); Mhl = (Mhl << 1) | neg;
@@ -50,9 +51,16 @@ NECAT_HD int advance_block(u64 Pv, u64 Mv, u64 Eq, int hin, u64& PvOut, u64& MvO
     return hout;
 }
 
+NECAT_HD int advance_block(u64 Pv, u64 Mv, u64 Eq, int hin, u64& PvOut, u64& MvOut)
+{
+    u64 ph;
+    return advance_block_ph(Pv, Mv, Eq, hin, PvOut, MvOut, ph);
+}
+
 template <int NW>
 struct MyersRegs {
     u64 P[NW], M[NW];
+    u64 H[NW];              // NW pass: positive horizontal deltas (Ph) of the current column
     int S[NW];
     u64 nlo[NW], nhi[NW];   // complemented query bit-planes (bit r = row 64*b + r)
 };
@@ -66,10 +74,8 @@ struct MyersResult {
 
 // Functor contracts:
 //   Tgt::code(c)                      -> 2-bit target code of column c
-//   Mat::store(c, b, P, M, S, Sup, fblk, lblk) -> band word b of column c (NW pass) as ONE self-contained
-//                                        record: its P/M/score, the score of word b-1 of the same column
-//                                        and the column's band limits - everything the traceback needs
-//                                        when it steps into (c, b) comes back with a single 32-byte load
+//   Mat::store(c, b, Pv, Ph)          -> band word b of column c (NW pass): the positive vertical and the positive
+//                                        horizontal deltas of its 64 cells - all the traceback ever asks of a cell
 template <int NW, bool FULL, class Tgt, class Mat>
 NECAT_HD MyersResult myers_block(MyersRegs<NW>& R, int qn, int tn, double error, Tgt& tgt, Mat& mat)
 {
@@ -153,7 +159,7 @@ NECAT_HD MyersResult myers_block(MyersRegs<NW>& R, int qn, int tn, double error,
             if (NECAT_ANY(act | edge)) {
                 const u64 eq = NECAT_EQ(b, ma, mb);
                 if (act) {
-                    hout = advance_block(R.P[b], R.M[b], eq, hout, R.P[b], R.M[b]);
+                    hout = advance_block_ph(R.P[b], R.M[b], eq, hout, R.P[b], R.M[b], R.H[b]);
                     R.S[b] += hout; lastS = R.S[b];
                     if (b == fblk) firstS = R.S[b];
                 } else if (edge) {
@@ -163,7 +169,7 @@ NECAT_HD MyersResult myers_block(MyersRegs<NW>& R, int qn, int tn, double error,
                     const bool r = (lblk0 + 1) * 64 - 1 > k - lastS + 2 * 64 - 2 - tn2 + c + qn;   // edlib_ex.c:305
                     if (!r) {
                         u64 p, m;
-                        const int nh = advance_block(~0ULL, 0ULL, eq, hout, p, m);
+                        const int nh = advance_block_ph(~0ULL, 0ULL, eq, hout, p, m, R.H[b]);
                         R.P[b] = p; R.M[b] = m;
                         R.S[b] = lastS - hout + 64 + nh;
                         lastS = R.S[b]; lblk = b; hout = nh; ++res.words;
@@ -198,7 +204,7 @@ NECAT_HD MyersResult myers_block(MyersRegs<NW>& R, int qn, int tn, double error,
 #pragma unroll
         for (int b = 0; b < NW; ++b) {
             const bool in = (b >= fblk) & (b <= lblk);
-            if (NECAT_ANY(in)) { if (in) mat.store(c, b, R.P[b], R.M[b], R.S[b], b > 0 ? R.S[b > 0 ? b - 1 : 0] : 0, fblk, lblk); }
+            if (NECAT_ANY(in)) { if (in) mat.store(c, b, R.P[b], R.H[b]); }
         }
     }
     int d2 = -1;
@@ -218,62 +224,40 @@ NECAT_HD MyersResult myers_block(MyersRegs<NW>& R, int qn, int tn, double error,
 
 // ---------------------------------------------------------------------------------------------
 // Traceback (edlib_ex.c:383-621, obtainAlignmentTraceback): move priority up > left > diagonal.
-//   Mat::cur(c, b, P, M)   band word (c, b)
-//   Mat::left(c, b)        LeftView of column c (= current column - 1) at word b: whether word b /
-//                          word b-1 are inside that column's band, and their P, M, score.  One call per
-//                          column change lets the reader prefetch the columns ahead (the walk is a chain
-//                          of dependent loads otherwise).
-//   Ops::push(op)          receives ops in END -> START order
+//
+// The reference compares the scores of the three neighbours with the current score (carrying shifted
+// copies of two band words and cached neighbour scores through the walk).  In an exact DP those
+// comparisons are bit tests on the current cell alone:
+//     up   <=> D[r][c] = D[r-1][c] + 1  <=> bit r of Pv(c)        (positive vertical delta)
+//     left <=> D[r][c] = D[r][c-1] + 1  <=> bit r of Ph(c)        (positive horizontal delta)
+//     else diagonal, a match iff the two bases are equal (the cell's value can only come from the diagonal
+//     then: equal bases <=> delta 0).
+// The band only ever leaves out cells that cannot lie on an alignment of cost <= the block's distance, and
+// every cell the walk stands on lies on one, so "is the neighbour inside the band" never decides anything
+// (the reference's availability flags, edlib_ex.c:431-451) - checked on every block of the E. coli workload
+// against the oracle's score-based walk (tests/test_host_core.py on the CPU, the GPU parity tests).
+// So a band record is 16 bytes (Pv, Ph), needs no validity tag, and a step reads one record.
+//   Mat::rec(c, b, Pv, Ph)   band word (c, b)
+//   Eq::operator()(row, c)   query base `row` == target base `c` of the two fragments
+//   Ops::push(op)            receives ops in END -> START order
 // Op codes: 0 match, 1 insert (consumes a query base), 2 delete (consumes a target base),
 // 3 mismatch (edlib_ex.c:10-13).
 // ---------------------------------------------------------------------------------------------
-struct LeftView {
-    u64 P, M;
-    int S, Sup;
-    bool in, up_in;
-};
-
-template <class Mat, class Ops>
-NECAT_HD void traceback_block(int qn, int tn, int bestScore, Mat& mat, Ops& ops)
+template <class Mat, class Ops, class Eq>
+NECAT_HD void traceback_block(int qn, int tn, Mat& mat, Ops& ops, Eq& eqf)
 {
-    // The walk of edlib_ex.c:383-621 (up > left > diagonal from the end cell).  The reference carries
-    // incrementally shifted copies of the current and the left word and caches neighbour scores between
-    // moves; here every step recomputes its three neighbour scores from the unshifted words - the cell
-    // itself, the word left of it (P, M, score of its last row, band flags) - which is the same
-    // arithmetic in ~1/3 of the instructions (64 lanes walk 64 different paths, nothing can be skipped
-    // wave-wide, and in the tail rounds the step latency of ONE walk is the round time):
-    //   up   (row-1, c)   = cur - dv(c, row)
-    //   left (row,   c-1) = S(c-1, b) - sum of dv(c-1, r) over the rows r > row of the word
-    //   diag (row-1, c-1) = left - dv(c-1, row)
-    // with dv(c, r) = +1 / -1 / 0 for bit r of P / M of column c.  A left word outside the band makes
-    // left unavailable and the diagonal fall back to the score of the word above it (edlib_ex.c:447-451).
     // The step is written with selects, not nested branches: the lanes of a wave are on 64 different
     // paths, so every divergent region would be executed by the whole wave on every step anyway.
     const int nblk = (qn + 63) / 64, W = nblk * 64 - qn;
     int c = tn - 1, b = nblk - 1, pos = 63 - W;
-    int cur = bestScore;
-    u64 curP, curM;
-    mat.cur(c, b, curP, curM);
-    LeftView V; V.P = V.M = 0; V.S = V.Sup = 0; V.in = V.up_in = false;
-    if (c > 0) V = mat.left(c - 1, b);
+    u64 Pv, Ph;
+    mat.rec(c, b, Pv, Ph);
     int term = 0, term_op = 0;       // how the walk ended (boundary cases push runs of ops)
     for (;;) {
-        const u64 cP = curP >> pos, cM = curM >> pos;
-        const int uS = cur - (int)(cP & 1ULL) + (int)(cM & 1ULL);
-        const u64 sP = V.P >> pos, sM = V.M >> pos;
-        const int lS_in = V.S + popc64(sM >> 1) - popc64(sP >> 1);
-        const int ulS_in = lS_in - (int)(sP & 1ULL) + (int)(sM & 1ULL);
-        const int row1 = b * 64 + pos + 1;
-        const bool c0 = c == 0;
-        const bool lav = c0 || V.in;                                     // left neighbour available
-        const int lS = c0 ? row1 : lS_in;
-        const int ulS = c0 ? row1 - 1 : (V.in ? ulS_in : (V.up_in ? V.Sup : -1));
-        const bool go_up = uS + 1 == cur;                                // up > left > diagonal
-        const bool go_left = !go_up && lav && lS + 1 == cur;
-        const bool go_diag = !go_up && !go_left && ulS != -1;
-        if (!(go_up || go_left || go_diag)) break;
-        const int op = go_up ? 1 : (go_left ? 2 : (ulS == cur ? 0 : 3));
-        cur = go_up ? uS : (go_left ? lS : ulS);
+        const bool go_up = (Pv >> pos) & 1ULL;                           // up > left > diagonal
+        const bool go_left = !go_up && ((Ph >> pos) & 1ULL);
+        int op = go_up ? 1 : 2;
+        if (!go_up && !go_left) op = eqf(b * 64 + pos, c) ? 0 : 3;
         const bool drow = !go_left, dcol = !go_up;                       // consumes a query base / a target base
         const bool cross = drow && pos == 0;                             // leaves the 64-row word upwards
         c -= dcol ? 1 : 0;
@@ -283,9 +267,7 @@ NECAT_HD void traceback_block(int qn, int tn, int bestScore, Mat& mat, Ops& ops)
         if (t) { term = t; term_op = op; break; }
         pos = drow ? (cross ? 63 : pos - 1) : pos;
         b -= cross ? 1 : 0;
-        if (dcol) { curP = V.P; curM = V.M; }                            // the left word becomes the current one ...
-        if (cross) mat.cur(c, b, curP, curM);                            // ... unless the walk moved up a word
-        if ((dcol || cross) && c > 0) V = mat.left(c - 1, b);
+        if (dcol || cross) mat.rec(c, b, Pv, Ph);
         ops.push(op);
     }
     if (term == 1) {                 // up move out of the first row

@@ -30,16 +30,17 @@ constexpr int kColsB = kMaxFragLen, kWordsB = kMaxWords, kTWordsB = kMaxTWords, 
 constexpr int kFragWordsA = 2 * kWordsA + kTWordsA;   // 32 u64 per item
 constexpr int kFragWordsB = 2 * kWordsB + kTWordsB;   // 51 u64 per item
 
-// One band record per (column, word, lane): P, M, score of the word, score of the word above it in
-// the same column, band limits of the column.  32 bytes, so the traceback - 64 lanes walking 64
-// different paths, every access its own DRAM sector - fetches ONE sector per step instead of four
-// (separate P/M, score, upper score and band arrays made k_traceback HBM-sector bound: measured
-// 5.7 us per step at 200 k concurrent blocks).
-struct __attribute__((aligned(32))) BandRec { u64 P, M; i16 S, Sup; u8 first, last; u8 _pad[10]; };
-static_assert(sizeof(BandRec) == 32, "BandRec must be 32 bytes");
+// One band record per (column, word, lane): Pv and Ph, the positive vertical and horizontal deltas of the word's
+// 64 cells - all the traceback asks of a cell (dp_core.h).  16 bytes, no validity tag: the walk only ever stands on
+// cells of the optimal alignment, and the DP kernels store every word such a cell can be in.
+// (History: separate P/M, score and band arrays cost four DRAM sectors per traceback step - 5.7 us per step at
+// 200 k concurrent blocks; one self-contained 32-byte record with scores and an epoch tag cost one; the bit-rule
+// walk halved that again.)
+struct __attribute__((aligned(16))) BandRec { u64 Pv, Ph; };
+static_assert(sizeof(BandRec) == 16, "BandRec must be 16 bytes");
 // bytes of one 64-item slab
-constexpr size_t kSlabA = (size_t)((kColsA + 3) & ~3) * kWordsA * 64 * sizeof(BandRec);
-constexpr size_t kSlabB = (size_t)((kColsB + 3) & ~3) * kWordsB * 64 * sizeof(BandRec);
+constexpr size_t kSlabA = (size_t)((kColsA + 7) & ~7) * kWordsA * 64 * sizeof(BandRec);
+constexpr size_t kSlabB = (size_t)((kColsB + 7) & ~7) * kWordsB * 64 * sizeof(BandRec);
 
 struct BlockItem {       // one scheduled block alignment
     FragGeom g;
@@ -167,43 +168,28 @@ struct TgtReader {
     }
 };
 
-// Record words: a = (P, M); t.x = S | Sup<<16 | first<<32 | last<<40; t.y = validity tag.
-// A slot (column, word, lane) is written only while that word is inside the column's band, so a read
-// of an out-of-band word returns whatever an earlier round left there: every record carries
-// tag = epoch<<10 | column (epoch = launch counter; the pool is zeroed once at allocation) and a
-// record counts only if its tag is the expected one.
-NECAT_D ulonglong2 rec_tail(int S, int Sup, int f, int l, u32 tag)
-{
-    return make_ulonglong2((u64)(u16)(i16)S | ((u64)(u16)(i16)Sup << 16) | ((u64)(u32)f << 32) | ((u64)(u32)l << 40), (u64)tag);
-}
-NECAT_D u32 rec_tag(u32 epoch, int c) { return (epoch << 10) | (u32)c; }
-
-// Position of record (column c, word b) of a lane inside its slab, in 16-byte units.  Four consecutive
-// columns of one (word, lane) share a 128-byte line: the traceback walks column by column at a fixed
-// word, so a line it pulls from HBM serves four steps, and the cooperative DP kernel - one lane per
-// word, one column per step - fills that line with four consecutive 32-byte stores of the same lane.
-// (With the records of the 64 lanes interleaved per column every traceback step was its own DRAM access:
-// 55 G random sector reads/s, the limit of k_traceback at 200 k concurrent blocks.)
-// (32-bit: a slab is < 32 MiB, and a wave-uniform slab base + 32-bit lane offset is the cheap addressing mode)
+// Position of record (column c, word b) of a lane inside its slab, in 16-byte units.  Eight consecutive
+// columns of one (word, lane) share a 128-byte line: the traceback walks column by column at a (mostly) fixed
+// word, so a line it pulls from HBM serves eight steps, and the cooperative DP kernel - one lane per word, one
+// column per step - fills that line with eight consecutive 16-byte stores of the same lane.
+// (With the records of the 64 lanes interleaved per column every traceback step was its own DRAM access.)
+// (32-bit: a slab is < 16 MiB, and a wave-uniform slab base + 32-bit lane offset is the cheap addressing mode)
 template <int NW>
 NECAT_D u32 rec_pos(int c, int b, int lane)
 {
-    return (((((u32)c >> 2) * (u32)NW + (u32)b) * 64u + (u32)lane) * 4u + ((u32)c & 3u)) * 2u;
+    return ((((u32)c >> 3) * (u32)NW + (u32)b) * 64u + (u32)lane) * 8u + ((u32)c & 7u);
 }
 
 template <int NW>
 struct MatWriter {
     ulonglong2* rec;   // slab base (16-byte units)
     int lane;
-    u32 epoch;
     int dbg;
     NECAT_D bool skip_nw() const { return dbg == 2; }
-    NECAT_D void store(int c, int b, u64 P, u64 M, int S, int Sup, int f, int l)
+    NECAT_D void store(int c, int b, u64 Pv, u64 Ph)
     {
         if (dbg == 1) return;
-        ulonglong2* p = rec + rec_pos<NW>(c, b, lane);
-        p[0] = make_ulonglong2(P, M);
-        p[1] = rec_tail(S, Sup, f, l, rec_tag(epoch, c));
+        rec[rec_pos<NW>(c, b, lane)] = make_ulonglong2(Pv, Ph);
     }
 };
 
@@ -212,40 +198,18 @@ struct MatWriter {
 // the walk pays max(compute, latency) per column instead of their sum.
 template <int NW>
 struct MatReader {
-    const ulonglong2* rec;     // slab base
+    const ulonglong2* base;    // slab base
     int lane;
-    u32 epoch;
     int nc, nb;                // coordinates of the prefetched record
-    ulonglong2 na, nt;
+    ulonglong2 nv;
     NECAT_D void init() { nc = -100; nb = -100; }
-    NECAT_D void fetch(int c, int b, ulonglong2& a, ulonglong2& t) const
+    NECAT_D void rec(int c, int b, u64& Pv, u64& Ph)
     {
-        if (c >= 0) { const ulonglong2* p = rec + rec_pos<NW>(c, b, lane); a = p[0]; t = p[1]; }
-    }
-    NECAT_D void cur(int c, int b, u64& P, u64& M) const { const ulonglong2 v = rec[rec_pos<NW>(c, b, lane)]; P = v.x; M = v.y; }
-    NECAT_D LeftView left(int c, int b)
-    {
-        ulonglong2 a, t;
-        if (c == nc && b == nb) { a = na; t = nt; } else fetch(c, b, a, t);
+        ulonglong2 v = nv;
+        if (!(c == nc && b == nb)) v = base[rec_pos<NW>(c, b, lane)];
+        Pv = v.x; Ph = v.y;
         nc = c - 1; nb = b;
-        fetch(nc, nb, na, nt);
-        LeftView v;
-        const u32 want = rec_tag(epoch, c);
-        v.in = (u32)t.y == want;
-        v.P = a.x; v.M = a.y; v.S = (i16)(t.x & 0xffff);
-        if (v.in) {
-            const int f = (int)((t.x >> 32) & 0xff);
-            v.up_in = b - 1 >= f; v.Sup = (i16)((t.x >> 16) & 0xffff);
-        } else {
-            // word b is outside column c's band: the upper word decides the diagonal fallback
-            // (edlib_ex.c:447-451); rare, one extra load
-            v.up_in = false; v.Sup = 0;
-            if (b > 0) {
-                const ulonglong2 u = rec[rec_pos<NW>(c, b - 1, lane) + 1];
-                if ((u32)u.y == want) { v.up_in = true; v.Sup = (i16)(u.x & 0xffff); }
-            }
-        }
-        return v;
+        if (nc >= 0) nv = base[rec_pos<NW>(nc, nb, lane)];
     }
 };
 
@@ -276,7 +240,7 @@ k_myers(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag
     }
     TgtReader<NW> tg; tg.w = fr + (u64)2 * NW * 64; tg.cur = 0;
     MatWriter<NW> mw;
-    mw.rec = slab_records(slabs + (size_t)grp * slab_bytes); mw.lane = lane; mw.epoch = epoch & 0x0fffffffu; mw.dbg = (int)(epoch >> 28);
+    mw.rec = slab_records(slabs + (size_t)grp * slab_bytes); mw.lane = lane; mw.dbg = (int)(epoch >> 28);
     const MyersResult r = myers_block<NW, FULL>(R, qn, tn, error, tg, mw);
     BlockResult br; br.dist = r.dist; br.endc = r.endc; br.err = r.err; br.words = r.words;
     results[item] = br;
@@ -363,18 +327,14 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
     for (int s = 0; s < steps; ++s) {
         const int c = s - b;
         int hin = dpp_from_lane_below(hout);
-        const int Sup1 = SINGLE ? dpp_from_lane_below(S) : 0;     // score of word b-1 at column c (computed one step ago)
         if (b == 0) hin = 1;
         if (have && (u32)c < (u32)tn) {
             if ((c & 31) == 0) tcur = tw[c >> 5];
             const u64 eq = eq_of(c);
-            hout = advance_block(P, M, eq, hin, P, M);
+            u64 Ph;
+            hout = advance_block_ph(P, M, eq, hin, P, M, Ph);
             S += hout;
-            if (SINGLE) {
-                ulonglong2* p = rec + rec_pos<NW>(c, b, il);
-                p[0] = make_ulonglong2(P, M);
-                p[1] = rec_tail(S, Sup1, 0, nblk - 1, rec_tag(epoch, c));
-            }
+            if (SINGLE) rec[rec_pos<NW>(c, b, il)] = make_ulonglong2(P, Ph);
             if (is_last && S <= k && (best == -1 || S <= best)) {
                 if (S != best) { best = S; k = best; end0 = c - W; }
             }
@@ -406,23 +366,19 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
     for (int s = 0; s < steps; ++s) {
         const int c = s - b;
         int hin = dpp_from_lane_below(hout);
-        const int Sup = dpp_from_lane_below(S);     // score of word b-1 at column c (computed one step ago)
         if (b == 0) hin = 1;
         if (go && (u32)c < (u32)tn2) {
             if ((c & 31) == 0) tcur = tw[c >> 5];
             const u64 eq = eq_of(c);
-            hout = advance_block(P, M, eq, hin, P, M);
+            u64 Ph;
+            hout = advance_block_ph(P, M, eq, hin, P, M, Ph);
             S += hout;
             // store the word only if it can hold a cell of an alignment of cost <= best that still reaches
             // the end: the reference's own per-word band tests (edlib_ex.c:311-325) with k = best.  The
-            // traceback treats an unstored word as "outside the band" (tag mismatch).
+            // traceback never stands on a cell of a dropped word (every cell it visits lies on such an alignment).
             const int rb = (b + 1) * 64 - 1;
             const bool drop = S >= best + 64 || rb > best - S + 2 * 64 - 2 - tn2 + c + qn + 1 || rb < S - best - tn2 + qn + c;
-            if (!drop || !filter) {
-                ulonglong2* p = rec + rec_pos<NW>(c, b, il);
-                p[0] = make_ulonglong2(P, M);
-                p[1] = rec_tail(S, Sup, 0, nblk - 1, rec_tag(epoch, c));
-            }
+            if (!drop || !filter) rec[rec_pos<NW>(c, b, il)] = make_ulonglong2(P, Ph);
         }
     }
     if (is_last) {
@@ -450,6 +406,21 @@ struct OpsWriter {
 struct OpsReader {
     const u8* ops;
     NECAT_D int operator()(int j) const { return ops[(size_t)j * 64]; }
+};
+// query base `row` == target base `c` of the block's two fragments (lane-interleaved fragment buffer); the walk
+// stays in one 64-row word / one 32-column target word for many steps, so both are cached
+template <int NW>
+struct FragEq {
+    const u64* fr;
+    int wb, wc; u64 nlo, nhi, tw;
+    NECAT_D void init() { wb = -1; wc = -1; nlo = nhi = tw = 0; }
+    NECAT_D bool operator()(int row, int c)
+    {
+        if ((row >> 6) != wb) { wb = row >> 6; nlo = fr[(u64)wb * 64]; nhi = fr[(u64)(NW + wb) * 64]; }
+        if ((c >> 5) != wc) { wc = c >> 5; tw = fr[(u64)(2 * NW + wc) * 64]; }
+        const int q = (int)((~nlo >> (row & 63)) & 1) | ((int)((~nhi >> (row & 63)) & 1) << 1);
+        return q == (int)((tw >> ((c & 31) * 2)) & 3);
+    }
 };
 template <int NW>
 struct SameReader {   // query fragment element i == target fragment element i ?
@@ -490,8 +461,9 @@ k_traceback(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ 
     tail_init(ow.ts, (EXPORT || !done) ? kOcaMatCnt : tail_match_len);
     if (br.dist >= 0) {
         MatReader<NW> mr;
-        mr.rec = slab_records(const_cast<char*>(slabs) + (size_t)grp * slab_bytes); mr.lane = lane; mr.epoch = epoch; mr.init();
-        traceback_block(it.qn, br.endc + 1, br.dist, mr, ow);
+        mr.base = slab_records(const_cast<char*>(slabs) + (size_t)grp * slab_bytes); mr.lane = lane; mr.init();
+        FragEq<NW> eqf; eqf.fr = frag + (u64)grp * FW * 64 + lane; eqf.init();
+        traceback_block(it.qn, br.endc + 1, mr, ow, eqf);
         if (ow.overflow) atomicExch(err_flag, 20);
     }
     if (EXPORT) { n_ops_out[item] = ow.ts.n; return; }

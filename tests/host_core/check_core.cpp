@@ -37,20 +37,14 @@ static void make_vol(const ora_volume& v, HostVol& h)
 // ---- host functors for the DP core (lane stride 1)
 struct HTgt { const u64* w; int code(int c) { return (int)((w[c >> 5] >> ((c & 31) * 2)) & 3); } };
 struct HMat {
-    std::vector<u64> P, M; std::vector<int> S, F, L; int nw;
-    void init(int cols, int nw_) { nw = nw_; P.assign((size_t)cols * nw, 0); M.assign((size_t)cols * nw, 0); S.assign((size_t)cols * nw, 0); F.assign(cols, 0); L.assign(cols, 0); }
-    void store(int c, int b, u64 p, u64 m, int s, int sup, int f, int l) { P[(size_t)c * nw + b] = p; M[(size_t)c * nw + b] = m; S[(size_t)c * nw + b] = s; (void)sup; F[c] = f; L[c] = l; }
+    std::vector<u64> Pv, Ph; int nw;
+    void init(int cols, int nw_) { nw = nw_; Pv.assign((size_t)cols * nw, 0); Ph.assign((size_t)cols * nw, 0); }
+    void store(int c, int b, u64 pv, u64 ph) { Pv[(size_t)c * nw + b] = pv; Ph[(size_t)c * nw + b] = ph; }
     bool skip_nw() const { return false; }
 };
 struct HMatR {
     const HMat* m;
-    void cur(int c, int b, u64& P, u64& M) const { P = m->P[(size_t)c * m->nw + b]; M = m->M[(size_t)c * m->nw + b]; }
-    LeftView left(int c, int b) const {
-        LeftView v; v.in = b >= m->F[c] && b <= m->L[c]; v.up_in = b - 1 >= m->F[c] && b - 1 <= m->L[c];
-        v.P = v.in ? m->P[(size_t)c * m->nw + b] : 0; v.M = v.in ? m->M[(size_t)c * m->nw + b] : 0;
-        v.S = v.in ? m->S[(size_t)c * m->nw + b] : 0; v.Sup = v.up_in ? m->S[(size_t)c * m->nw + b - 1] : 0;
-        return v;
-    }
+    void rec(int c, int b, u64& Pv, u64& Ph) const { Pv = m->Pv[(size_t)c * m->nw + b]; Ph = m->Ph[(size_t)c * m->nw + b]; }
 };
 struct HOps { std::vector<int> v; TailScan ts; void push(int op) { v.push_back(op); tail_push(ts, op); } };
 
@@ -69,6 +63,13 @@ static MyersResult run_block(const DevVolume& reads, const DevVolume& ref, const
 }
 
 struct HRops { const std::vector<int>* v; int operator()(int j) const { return (*v)[j]; } };
+template <int NW> struct HEq {
+    const MyersRegs<NW>* R; const u64* tw;
+    bool operator()(int row, int c) const {
+        int q = (int)((~R->nlo[row >> 6] >> (row & 63)) & 1) | ((int)((~R->nhi[row >> 6] >> (row & 63)) & 1) << 1);
+        return q == (int)((tw[c >> 5] >> ((c & 31) * 2)) & 3);
+    }
+};
 template <int NW> struct HSame {
     const MyersRegs<NW>* R; const u64* tw;
     bool operator()(int i) const {
@@ -151,14 +152,14 @@ int main(int argc, char** argv)
                         mr = run_block<8, true>(hrd->dv, href.dv, g, tk.qblk, tk.tblk, opt.error, mat, tw, R8);
                         const int done = ext_block_done(tk, mr.dist, mr.endc);
                         tail_init(ops.ts, done ? 1 : kOcaMatCnt);
-                        if (mr.dist >= 0) { HMatR m{&mat}; traceback_block(tk.qblk, mr.endc + 1, mr.dist, m, ops); }
+                        if (mr.dist >= 0) { HMatR m{&mat}; HEq<8> eq{&R8, tw}; traceback_block(tk.qblk, mr.endc + 1, m, ops, eq); }
                         HRops ro{&ops.v}; HSame<8> sm{&R8, tw};
                         ext_finish_block(tk, mr.dist, mr.endc, done, ops.ts, ro, sm);
                     } else {
                         mr = run_block<13, false>(hrd->dv, href.dv, g, tk.qblk, tk.tblk, opt.error, mat, tw, R13);
                         const int done = ext_block_done(tk, mr.dist, mr.endc);
                         tail_init(ops.ts, done ? 1 : kOcaMatCnt);
-                        if (mr.dist >= 0) { HMatR m{&mat}; traceback_block(tk.qblk, mr.endc + 1, mr.dist, m, ops); }
+                        if (mr.dist >= 0) { HMatR m{&mat}; HEq<13> eq{&R13, tw}; traceback_block(tk.qblk, mr.endc + 1, m, ops, eq); }
                         HRops ro{&ops.v}; HSame<13> sm{&R13, tw};
                         ext_finish_block(tk, mr.dist, mr.endc, done, ops.ts, ro, sm);
                     }
