@@ -221,7 +221,7 @@ def main():
                                    "word_updates_per_s": round(word_rate, 1),
                                    "valu_frac": round(word_rate * OPS_PER_WORD_UPDATE / VALU_LANE_OPS_PER_S, 4)},
                 "note": "integer DP: the algorithmic HBM fraction is small by construction (SURVEY.md 8d); the measured traffic (PMC, "
-                        "profiles/r01_pmc_hbm_traffic.json) is the stored traceback band (32-byte records, only words that can lie on an "
+                        "profiles/r01_pmc_hbm_traffic.json) is the stored traceback band (16-byte records, only words that can lie on an "
                         "alignment of <= the block's distance) - traffic_frac is that traffic over the launch time against the HBM peak; "
                         "valu_frac = word updates x %d lane-ops / (256 CU x 128 lanes x 2.4 GHz)" % OPS_PER_WORD_UPDATE}
     out = {

@@ -15,10 +15,9 @@
 //                   run of 8 matches, fold the kept columns into the candidate's running counters, then
 //                   plan the candidate's next block and append it to the next round's lists
 //
-// The NW band is stored as 32-byte records [column][word][lane]: every store instruction of the DP
-// kernel writes one contiguous 2 KiB span per wave, every traceback step is one 32-byte load.
-// Groups of 64 work items share one slab of the band pool; list A slabs (512 cols x 8 words) come
-// first, list B slabs (794 x 13) after them.
+// The NW band is stored as 16-byte records (Pv, Ph) [column / 8][word][lane][column % 8]: every traceback step is
+// one 16-byte load.  Groups of 64 work items share one slab of a band pool; list A (512 cols x 8 words) and list B
+// (794 x 13) have pools of their own.
 #pragma once
 #include "dp_core.h"
 #include "ext_core.h"

@@ -17,7 +17,8 @@ using namespace necat;
 
 namespace {
 
-// (re)allocate a band-record pool; a fresh allocation is zeroed once so that no stale tag can match
+// (re)allocate a band-record pool; a fresh allocation is zeroed once (not needed for correctness - the walk only reads
+// records its round stored - but it keeps a run reproducible should that invariant ever break)
 int ensure_zeroed(necat_ctx* ctx, DevBuf& b, size_t bytes, hipStream_t s)
 {
     const void* before = b.p; const size_t cap0 = b.cap;
