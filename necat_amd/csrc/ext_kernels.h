@@ -1,16 +1,16 @@
 // ext_kernels.h - __global__ shells of the extension stage (onc_align for 10^5..10^6 candidates at once).
 //
 // Every candidate is a small state machine (ext_core.h) that needs one block alignment per round;
-// its scheduled block sits in list A (full 512 x 512 blocks) or list B (the variable-size last block of
-// an extension, <= 794 x 794).  A round is three launches per list, the two lists on two streams:
+// its scheduled block sits in list A (blocks of at most 512 x 512) or list B (bigger last blocks of an
+// extension, <= 794 x 794).  A round is three launches per list (the host loop: run_batch in necat_hip.hip):
 //
 //   k_ext_frag      gather the two fragments of every block from the 2-bit volumes: query as two
 //                   complemented bit-planes per 64 rows, target 2-bit packed; written lane-interleaved
-//                   so the DP kernel's loads are fully coalesced
-//   k_myers<NW>     lane = one block alignment: SHW pass + banded NW pass (dp_core.h); 64 alignments of
-//                   the same shape advance in lock-step per wave; used for big lists
 //   k_myers_coop<G> G lanes = one block alignment (anti-diagonal wavefront over the 64-row words, DPP carry,
-//                   LDS-staged target); 6x lower latency, used for small lists (the tail of the rounds)
+//                   LDS-staged target bit-planes): SHW pass, then the NW pass that stores the band - or, for
+//                   small lists, one storing pass (SINGLE).  The default DP kernel.
+//   k_myers<NW>     lane = one block alignment, the reference's banded NW pass line by line (dp_core.h); the
+//                   first design, kept as the second implementation the tests compare against
 //   k_traceback     walk the stored band back (up > left > diagonal), trim the block tail at the last
 //                   run of 8 matches, fold the kept columns into the candidate's running counters, then
 //                   plan the candidate's next block and append it to the next round's lists
