@@ -25,7 +25,7 @@ constexpr u64 kHighBit = 1ULL << 63;
 // edlib_ex.c:71-106 calculateBlock (Myers' Advance_Block), written on 32-bit halves: gfx950 has no
 // full-rate 64-bit integer add / shift (v_lshl_add_u64, v_lshlrev_b64 issue at a fraction of the
 // 32-bit rate and were ~1/3 of this function's time); add-with-carry and funnel shifts are full rate.
-NECAT_HD int advance_block_ph(u64 Pv, u64 Mv, u64 Eq, int hin, u64& PvOut, u64& MvOut, u64& PhOut)
+NECAT_HD int advance_block_full(u64 Pv, u64 Mv, u64 Eq, int hin, u64& PvOut, u64& MvOut, u64& PhOut, u64& D0Out)
 {
     const u32 pl = (u32)Pv, ph = (u32)(Pv >> 32), ml = (u32)Mv, mh = (u32)(Mv >> 32);
     u32 el = (u32)Eq;
@@ -40,7 +40,8 @@ NECAT_HD int advance_block_ph(u64 Pv, u64 Mv, u64 Eq, int hin, u64& PvOut, u64& 
     const u32 xhl = (sl ^ pl) | el, xhh = (sh ^ ph) | eh;
     u32 Phl = ml | ~(xhl | pl), Phh = mh | ~(xhh | ph);
     u32 Mhl = pl & xhl, Mhh = ph & xhh;
-    PhOut = ((u64)Phh << 32) | Phl;                 // bit r: D[r][c] - D[r][c-1] == +1  (what the traceback asks)
+    PhOut = ((u64)Phh << 32) | Phl;                 // bit r: D[r][c] - D[r][c-1] == +1
+    D0Out = ((u64)(xhh | mh) << 32) | (xhl | ml);   // bit r: D[r][c] == D[r-1][c-1]  (Hyyro's D0 = Xh | Mv)
     const int hout = (int)(Phh >> 31) - (int)(Mhh >> 31);
     Phh = (Phh << 1) | (Phl >> 31); Phl = (Phl << 1) | pos;
     Mhh = (Mhh << 1) | (Mhl >> 31); Mhl = (Mhl << 1) | neg;
@@ -53,14 +54,57 @@ NECAT_HD int advance_block_ph(u64 Pv, u64 Mv, u64 Eq, int hin, u64& PvOut, u64& 
 
 NECAT_HD int advance_block(u64 Pv, u64 Mv, u64 Eq, int hin, u64& PvOut, u64& MvOut)
 {
-    u64 ph;
-    return advance_block_ph(Pv, Mv, Eq, hin, PvOut, MvOut, ph);
+    u64 ph, d0;
+    return advance_block_full(Pv, Mv, Eq, hin, PvOut, MvOut, ph, d0);
+}
+
+// The traceback's decision at a cell, two bits per cell (one band record = these two words of a 64-row word):
+//     (A, B) = (1, 0) up     : D[r][c] = D[r-1][c] + 1            (Pv; wins over left, edlib_ex.c:458)
+//              (0, 1) left   : D[r][c] = D[r][c-1] + 1, not up    (Ph)
+//              (0, 0) diagonal, match    : D[r][c] = D[r-1][c-1]  (D0)
+//              (1, 1) diagonal, mismatch : D[r][c] = D[r-1][c-1] + 1
+// Pv = the column's updated vertical deltas, Ph / D0 from the same update.
+NECAT_HD void cell_codes(u64 Pv, u64 Ph, u64 D0, u64& A, u64& B)
+{
+    A = Pv | ~(Ph | D0);
+    B = ~Pv & (Ph | ~D0);
+}
+
+// One column update that also yields the band record of the word.  With Pv/Mv the word's deltas BEFORE the
+// update, Pv' after it and Xh as in advance_block_full (P and M are disjoint), cell_codes collapses to
+//     A = Pv' | (Pv & ~Xh)        B = ~Pv' & (Mv | ~Xh)
+// (Ph | D0 = Mv | Xh | ~Pv and Ph | ~D0 = Mv | ~Xh): one 3-input bit-op per half each.
+NECAT_HD int advance_block_rec(u64 Pv, u64 Mv, u64 Eq, int hin, u64& PvOut, u64& MvOut, u64& A, u64& B)
+{
+    const u32 pl = (u32)Pv, ph = (u32)(Pv >> 32), ml = (u32)Mv, mh = (u32)(Mv >> 32);
+    u32 el = (u32)Eq;
+    const u32 eh = (u32)(Eq >> 32);
+    const u32 neg = (u32)hin >> 31;
+    const u32 pos = (u32)(hin + 1) >> 1;
+    const u32 xvl = el | ml, xvh = eh | mh;
+    el |= neg;
+    const u32 al = el & pl, ah = eh & ph;
+    const u32 sl = al + pl;
+    const u32 sh = ah + ph + (u32)(sl < al);
+    const u32 xhl = (sl ^ pl) | el, xhh = (sh ^ ph) | eh;
+    u32 Phl = ml | ~(xhl | pl), Phh = mh | ~(xhh | ph);
+    u32 Mhl = pl & xhl, Mhh = ph & xhh;
+    const int hout = (int)(Phh >> 31) - (int)(Mhh >> 31);
+    Phh = (Phh << 1) | (Phl >> 31); Phl = (Phl << 1) | pos;
+    Mhh = (Mhh << 1) | (Mhl >> 31); Mhl = (Mhl << 1) | neg;
+    const u32 ol = Mhl | ~(xvl | Phl), oh = Mhh | ~(xvh | Phh);
+    const u32 nl = Phl & xvl, nh = Phh & xvh;
+    PvOut = ((u64)oh << 32) | ol;
+    MvOut = ((u64)nh << 32) | nl;
+    A = ((u64)(oh | (ph & ~xhh)) << 32) | (ol | (pl & ~xhl));
+    B = ((u64)(~oh & (mh | ~xhh)) << 32) | (~ol & (ml | ~xhl));
+    return hout;
 }
 
 template <int NW>
 struct MyersRegs {
     u64 P[NW], M[NW];
-    u64 H[NW];              // NW pass: positive horizontal deltas (Ph) of the current column
+    u64 A[NW], B[NW];       // NW pass: the band record (cell_codes) of the current column's words
     int S[NW];
     u64 nlo[NW], nhi[NW];   // complemented query bit-planes (bit r = row 64*b + r)
 };
@@ -74,8 +118,8 @@ struct MyersResult {
 
 // Functor contracts:
 //   Tgt::code(c)                      -> 2-bit target code of column c
-//   Mat::store(c, b, Pv, Ph)          -> band word b of column c (NW pass): the positive vertical and the positive
-//                                        horizontal deltas of its 64 cells - all the traceback ever asks of a cell
+//   Mat::store(c, b, A, B)            -> band word b of column c (NW pass): the traceback's decision at each of its
+//                                        64 cells (cell_codes) - all the traceback ever asks of a cell
 template <int NW, bool FULL, class Tgt, class Mat>
 NECAT_HD MyersResult myers_block(MyersRegs<NW>& R, int qn, int tn, double error, Tgt& tgt, Mat& mat)
 {
@@ -159,7 +203,7 @@ NECAT_HD MyersResult myers_block(MyersRegs<NW>& R, int qn, int tn, double error,
             if (NECAT_ANY(act | edge)) {
                 const u64 eq = NECAT_EQ(b, ma, mb);
                 if (act) {
-                    hout = advance_block_ph(R.P[b], R.M[b], eq, hout, R.P[b], R.M[b], R.H[b]);
+                    hout = advance_block_rec(R.P[b], R.M[b], eq, hout, R.P[b], R.M[b], R.A[b], R.B[b]);
                     R.S[b] += hout; lastS = R.S[b];
                     if (b == fblk) firstS = R.S[b];
                 } else if (edge) {
@@ -169,7 +213,7 @@ NECAT_HD MyersResult myers_block(MyersRegs<NW>& R, int qn, int tn, double error,
                     const bool r = (lblk0 + 1) * 64 - 1 > k - lastS + 2 * 64 - 2 - tn2 + c + qn;   // edlib_ex.c:305
                     if (!r) {
                         u64 p, m;
-                        const int nh = advance_block_ph(~0ULL, 0ULL, eq, hout, p, m, R.H[b]);
+                        const int nh = advance_block_rec(~0ULL, 0ULL, eq, hout, p, m, R.A[b], R.B[b]);
                         R.P[b] = p; R.M[b] = m;
                         R.S[b] = lastS - hout + 64 + nh;
                         lastS = R.S[b]; lblk = b; hout = nh; ++res.words;
@@ -204,7 +248,7 @@ NECAT_HD MyersResult myers_block(MyersRegs<NW>& R, int qn, int tn, double error,
 #pragma unroll
         for (int b = 0; b < NW; ++b) {
             const bool in = (b >= fblk) & (b <= lblk);
-            if (NECAT_ANY(in)) { if (in) mat.store(c, b, R.P[b], R.H[b]); }
+            if (NECAT_ANY(in)) { if (in) mat.store(c, b, R.A[b], R.B[b]); }
         }
     }
     int d2 = -1;
@@ -230,34 +274,33 @@ NECAT_HD MyersResult myers_block(MyersRegs<NW>& R, int qn, int tn, double error,
 // comparisons are bit tests on the current cell alone:
 //     up   <=> D[r][c] = D[r-1][c] + 1  <=> bit r of Pv(c)        (positive vertical delta)
 //     left <=> D[r][c] = D[r][c-1] + 1  <=> bit r of Ph(c)        (positive horizontal delta)
-//     else diagonal, a match iff the two bases are equal (the cell's value can only come from the diagonal
-//     then: equal bases <=> delta 0).
+//     else diagonal: the cell's value can only come from the diagonal then, a match <=> bit r of D0(c)
+//     (diagonal delta 0) <=> the two bases are equal.
 // The band only ever leaves out cells that cannot lie on an alignment of cost <= the block's distance, and
 // every cell the walk stands on lies on one, so "is the neighbour inside the band" never decides anything
 // (the reference's availability flags, edlib_ex.c:431-451) - checked on every block of the E. coli workload
 // against the oracle's score-based walk (tests/test_host_core.py on the CPU, the GPU parity tests).
-// So a band record is 16 bytes (Pv, Ph), needs no validity tag, and a step reads one record.
-//   Mat::rec(c, b, Pv, Ph)   band word (c, b)
-//   Eq::operator()(row, c)   query base `row` == target base `c` of the two fragments
+// The DP kernels fold the three vectors into the walk's decision, two bits per cell (cell_codes): a band
+// record is 16 bytes, needs no validity tag, a step reads one record and never touches the sequences.
+//   Mat::rec(c, b, A, B)     band word (c, b)
 //   Ops::push(op)            receives ops in END -> START order
 // Op codes: 0 match, 1 insert (consumes a query base), 2 delete (consumes a target base),
 // 3 mismatch (edlib_ex.c:10-13).
 // ---------------------------------------------------------------------------------------------
-template <class Mat, class Ops, class Eq>
-NECAT_HD void traceback_block(int qn, int tn, Mat& mat, Ops& ops, Eq& eqf)
+template <class Mat, class Ops>
+NECAT_HD void traceback_block(int qn, int tn, Mat& mat, Ops& ops)
 {
     // The step is written with selects, not nested branches: the lanes of a wave are on 64 different
     // paths, so every divergent region would be executed by the whole wave on every step anyway.
     const int nblk = (qn + 63) / 64, W = nblk * 64 - qn;
     int c = tn - 1, b = nblk - 1, pos = 63 - W;
-    u64 Pv, Ph;
-    mat.rec(c, b, Pv, Ph);
+    u64 A, B;
+    mat.rec(c, b, A, B);
     int term = 0, term_op = 0;       // how the walk ended (boundary cases push runs of ops)
     for (;;) {
-        const bool go_up = (Pv >> pos) & 1ULL;                           // up > left > diagonal
-        const bool go_left = !go_up && ((Ph >> pos) & 1ULL);
-        int op = go_up ? 1 : 2;
-        if (!go_up && !go_left) op = eqf(b * 64 + pos, c) ? 0 : 3;
+        const bool a1 = (A >> pos) & 1ULL, b1 = (B >> pos) & 1ULL;
+        const bool go_up = a1 && !b1, go_left = !a1 && b1;               // up > left > diagonal, decided by the DP kernel
+        const int op = go_up ? 1 : (go_left ? 2 : (a1 ? 3 : 0));
         const bool drow = !go_left, dcol = !go_up;                       // consumes a query base / a target base
         const bool cross = drow && pos == 0;                             // leaves the 64-row word upwards
         c -= dcol ? 1 : 0;
@@ -267,7 +310,7 @@ NECAT_HD void traceback_block(int qn, int tn, Mat& mat, Ops& ops, Eq& eqf)
         if (t) { term = t; term_op = op; break; }
         pos = drow ? (cross ? 63 : pos - 1) : pos;
         b -= cross ? 1 : 0;
-        if (dcol || cross) mat.rec(c, b, Pv, Ph);
+        if (dcol || cross) mat.rec(c, b, A, B);
         ops.push(op);
     }
     if (term == 1) {                 // up move out of the first row

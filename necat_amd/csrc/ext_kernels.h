@@ -15,7 +15,7 @@
 //                   run of 8 matches, fold the kept columns into the candidate's running counters, then
 //                   plan the candidate's next block and append it to the next round's lists
 //
-// The NW band is stored as 16-byte records (Pv, Ph) [column / 8][word][lane][column % 8]: every traceback step is
+// The NW band is stored as 16-byte records (the walk's decisions, dp_core.h) [column / 8][word][lane][column % 8]: every traceback step is
 // one 16-byte load.  Groups of 64 work items share one slab of a band pool; list A (512 cols x 8 words) and list B
 // (794 x 13) have pools of their own.
 #pragma once
@@ -29,13 +29,13 @@ constexpr int kColsB = kMaxFragLen, kWordsB = kMaxWords, kTWordsB = kMaxTWords, 
 constexpr int kFragWordsA = 2 * kWordsA + kTWordsA;   // 32 u64 per item
 constexpr int kFragWordsB = 2 * kWordsB + kTWordsB;   // 51 u64 per item
 
-// One band record per (column, word, lane): Pv and Ph, the positive vertical and horizontal deltas of the word's
-// 64 cells - all the traceback asks of a cell (dp_core.h).  16 bytes, no validity tag: the walk only ever stands on
+// One band record per (column, word, lane): the traceback's decision at each of the word's 64 cells, two bits per
+// cell (cell_codes, dp_core.h).  16 bytes, no validity tag: the walk only ever stands on
 // cells of the optimal alignment, and the DP kernels store every word such a cell can be in.
 // (History: separate P/M, score and band arrays cost four DRAM sectors per traceback step - 5.7 us per step at
 // 200 k concurrent blocks; one self-contained 32-byte record with scores and an epoch tag cost one; the bit-rule
 // walk halved that again.)
-struct __attribute__((aligned(16))) BandRec { u64 Pv, Ph; };
+struct __attribute__((aligned(16))) BandRec { u64 A, B; };
 static_assert(sizeof(BandRec) == 16, "BandRec must be 16 bytes");
 // bytes of one 64-item slab
 constexpr size_t kSlabA = (size_t)((kColsA + 7) & ~7) * kWordsA * 64 * sizeof(BandRec);
@@ -330,10 +330,10 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
         if (have && (u32)c < (u32)tn) {
             if ((c & 31) == 0) tcur = tw[c >> 5];
             const u64 eq = eq_of(c);
-            u64 Ph;
-            hout = advance_block_ph(P, M, eq, hin, P, M, Ph);
+            u64 rA, rB;
+            hout = SINGLE ? advance_block_rec(P, M, eq, hin, P, M, rA, rB) : advance_block(P, M, eq, hin, P, M);
             S += hout;
-            if (SINGLE) rec[rec_pos<NW>(c, b, il)] = make_ulonglong2(P, Ph);
+            if (SINGLE) rec[rec_pos<NW>(c, b, il)] = make_ulonglong2(rA, rB);
             if (is_last && S <= k && (best == -1 || S <= best)) {
                 if (S != best) { best = S; k = best; end0 = c - W; }
             }
@@ -369,15 +369,15 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
         if (go && (u32)c < (u32)tn2) {
             if ((c & 31) == 0) tcur = tw[c >> 5];
             const u64 eq = eq_of(c);
-            u64 Ph;
-            hout = advance_block_ph(P, M, eq, hin, P, M, Ph);
+            u64 rA, rB;
+            hout = advance_block_rec(P, M, eq, hin, P, M, rA, rB);
             S += hout;
             // store the word only if it can hold a cell of an alignment of cost <= best that still reaches
             // the end: the reference's own per-word band tests (edlib_ex.c:311-325) with k = best.  The
             // traceback never stands on a cell of a dropped word (every cell it visits lies on such an alignment).
             const int rb = (b + 1) * 64 - 1;
             const bool drop = S >= best + 64 || rb > best - S + 2 * 64 - 2 - tn2 + c + qn + 1 || rb < S - best - tn2 + qn + c;
-            if (!drop || !filter) rec[rec_pos<NW>(c, b, il)] = make_ulonglong2(P, Ph);
+            if (!drop || !filter) rec[rec_pos<NW>(c, b, il)] = make_ulonglong2(rA, rB);
         }
     }
     if (is_last) {
@@ -405,21 +405,6 @@ struct OpsWriter {
 struct OpsReader {
     const u8* ops;
     NECAT_D int operator()(int j) const { return ops[(size_t)j * 64]; }
-};
-// query base `row` == target base `c` of the block's two fragments (lane-interleaved fragment buffer); the walk
-// stays in one 64-row word / one 32-column target word for many steps, so both are cached
-template <int NW>
-struct FragEq {
-    const u64* fr;
-    int wb, wc; u64 nlo, nhi, tw;
-    NECAT_D void init() { wb = -1; wc = -1; nlo = nhi = tw = 0; }
-    NECAT_D bool operator()(int row, int c)
-    {
-        if ((row >> 6) != wb) { wb = row >> 6; nlo = fr[(u64)wb * 64]; nhi = fr[(u64)(NW + wb) * 64]; }
-        if ((c >> 5) != wc) { wc = c >> 5; tw = fr[(u64)(2 * NW + wc) * 64]; }
-        const int q = (int)((~nlo >> (row & 63)) & 1) | ((int)((~nhi >> (row & 63)) & 1) << 1);
-        return q == (int)((tw >> ((c & 31) * 2)) & 3);
-    }
 };
 template <int NW>
 struct SameReader {   // query fragment element i == target fragment element i ?
@@ -461,8 +446,7 @@ k_traceback(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ 
     if (br.dist >= 0) {
         MatReader<NW> mr;
         mr.base = slab_records(const_cast<char*>(slabs) + (size_t)grp * slab_bytes); mr.lane = lane; mr.init();
-        FragEq<NW> eqf; eqf.fr = frag + (u64)grp * FW * 64 + lane; eqf.init();
-        traceback_block(it.qn, br.endc + 1, mr, ow, eqf);
+        traceback_block(it.qn, br.endc + 1, mr, ow);
         if (ow.overflow) atomicExch(err_flag, 20);
     }
     if (EXPORT) { n_ops_out[item] = ow.ts.n; return; }

@@ -152,14 +152,14 @@ int main(int argc, char** argv)
                         mr = run_block<8, true>(hrd->dv, href.dv, g, tk.qblk, tk.tblk, opt.error, mat, tw, R8);
                         const int done = ext_block_done(tk, mr.dist, mr.endc);
                         tail_init(ops.ts, done ? 1 : kOcaMatCnt);
-                        if (mr.dist >= 0) { HMatR m{&mat}; HEq<8> eq{&R8, tw}; traceback_block(tk.qblk, mr.endc + 1, m, ops, eq); }
+                        if (mr.dist >= 0) { HMatR m{&mat}; traceback_block(tk.qblk, mr.endc + 1, m, ops); }
                         HRops ro{&ops.v}; HSame<8> sm{&R8, tw};
                         ext_finish_block(tk, mr.dist, mr.endc, done, ops.ts, ro, sm);
                     } else {
                         mr = run_block<13, false>(hrd->dv, href.dv, g, tk.qblk, tk.tblk, opt.error, mat, tw, R13);
                         const int done = ext_block_done(tk, mr.dist, mr.endc);
                         tail_init(ops.ts, done ? 1 : kOcaMatCnt);
-                        if (mr.dist >= 0) { HMatR m{&mat}; HEq<13> eq{&R13, tw}; traceback_block(tk.qblk, mr.endc + 1, m, ops, eq); }
+                        if (mr.dist >= 0) { HMatR m{&mat}; traceback_block(tk.qblk, mr.endc + 1, m, ops); }
                         HRops ro{&ops.v}; HSame<13> sm{&R13, tw};
                         ext_finish_block(tk, mr.dist, mr.endc, done, ops.ts, ro, sm);
                     }
