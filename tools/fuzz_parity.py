@@ -45,6 +45,25 @@ for case in range(n_cases):
                     ref = np.frombuffer(open(out, "rb").read(), dtype=capi.M4_DTYPE)
                     ok = util.m4_key_rows(m4) == util.m4_key_rows(ref)
                     nrec = m4.shape[0]
+                if job == 0 and nv == 1 and cands.shape[0]:
+                    # the consensus stage's aligner call on a sample of the candidates: strings vs the oracle's onc_align
+                    sel = cands[:: max(1, cands.shape[0] // 200)][:200]
+                    vol = ctx.load_volume(capi.load_volumes_info(d)[2][0][0])
+                    aln, ops, off = ctx.onc_align_batch(vol, vol, 0, 0, sel, opt, 4)
+                    vol.free()
+                    al = ora.Aligner(opt.error)
+                    for i, cnd in enumerate(sel):
+                        q = rs.codes[rs.offsets[cnd["qid"]]: rs.offsets[cnd["qid"]] + rs.sizes[cnd["qid"]]]
+                        if cnd["qdir"] == 1:
+                            q = (3 - q[::-1]).astype(np.uint8)
+                        t = rs.codes[rs.offsets[cnd["sid"]]: rs.offsets[cnd["sid"]] + rs.sizes[cnd["sid"]]]
+                        r = al.align(q, int(cnd["qoff"]), t, int(cnd["soff"]), opt.align_size_cutoff, 4)
+                        a = aln[i]
+                        mine = (bool(a["ok"]), int(a["qoff"]), int(a["qend"]), int(a["toff"]), int(a["tend"]), float(a["ident_perc"]))
+                        strs = capi.gapped_strings(ops[int(off[i]):int(off[i + 1])], q, r[1], t, r[3]) if mine[:5] == r[:5] else None
+                        if mine != r[:6] or strs != (r[6], r[7]):
+                            ok = False
+                    al.close()
                 if not ok:
                     bad += 1
                     print("MISMATCH case %d vid %d job %d" % (case, vid, job), kw, flush=True)
