@@ -118,6 +118,44 @@ typedef struct {
 int ora_pm_main(const ora_options* opt, int vid, const char* wrk_dir, const char* output,
                 ora_stats* stats);
 
+
+/* ---- consensus stage, extension loop only (cns_oracle.c) ---- */
+#include <stdio.h>
+typedef struct {   /* the fields of consensus/cns_options.h:6-18 the loop reads */
+    int    min_align_size, min_cov, max_cov;
+    double error, mapping_ratio;
+    int    use_fixed_ident_cutoff;
+} ora_cns_options;
+typedef struct {   /* one add_one_align call (tasc/cbcns.c:47) */
+    int    cand;             /* index into the template's candidate list */
+    int    qoff, qend, toff, tend, align_size;
+    double ident_perc, weight;
+    size_t str_at;           /* strs[str_at .. +align_size) = query string, then the target string */
+} ora_cns_overlap;
+typedef struct {
+    int    template_id, template_size, examined;   /* examined = 0: fewer than min_cov candidates */
+    double ident_cutoff;
+    int    num_can, num_ovlps;                     /* CnsSeq fields, common/cns_seq.h:12-14 */
+    size_t ovlp_begin, ovlp_end, range_begin, range_end;
+} ora_cns_template;
+typedef struct {
+    ora_cns_template* templates; size_t n_templates, m_templates;
+    ora_cns_overlap*  overlaps;  size_t n_overlaps, m_overlaps;
+    int*              ranges;    size_t n_ranges, m_ranges;      /* cov_ranges pairs */
+    char*             strs;      size_t n_strs, m_strs;
+} ora_cns_result;
+void ora_unpack_candidate(const uint32_t item[7], ora_candidate* c);
+void ora_change_pcan_roles(const uint32_t src[7], uint32_t dst[7]);
+void ora_normalise_pcan_sdir(uint32_t item[7], uint32_t qsize, uint32_t ssize);
+void ora_cns_sort_candidates(uint32_t* items, size_t n);
+void ora_cns_extension_loop(const ora_volume* reads, const ora_candidate* cands, size_t n, size_t n_all,
+                            const ora_cns_options* opt, ora_aligner* al, ora_cns_result* res);
+int  ora_volumes_merge(const char* wrk_dir, ora_volume* out);
+void ora_cns_partition(const ora_volume* reads, uint32_t* items, size_t n, const ora_cns_options* opt, ora_cns_result* res);
+void ora_cns_write_log(const ora_cns_result* r, FILE* out, int full);
+int  ora_cns_run(const char* wrk_dir, const char* can_prefix, const ora_cns_options* opt, const char* log_path, int full);
+void ora_cns_result_free(ora_cns_result* r);
+
 #ifdef __cplusplus
 }
 #endif

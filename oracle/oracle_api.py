@@ -227,3 +227,71 @@ def sorted_records(path: str, binary_size: int = 0) -> List[bytes]:
     if binary_size:
         return sorted(b[i:i + binary_size] for i in range(0, len(b), binary_size))
     return sorted(b.splitlines(keepends=True))
+
+
+# ---- consensus stage, extension loop (cns_oracle.c; reference side = oracle/cns_ref_harness.c) ----
+
+class OraCnsOptions(C.Structure):
+    """the CnsOptions fields the loop reads (consensus/cns_options.c:10-22 for the defaults)"""
+    _fields_ = [("min_align_size", C.c_int), ("min_cov", C.c_int), ("max_cov", C.c_int), ("error", C.c_double),
+                ("mapping_ratio", C.c_double), ("use_fixed_ident_cutoff", C.c_int)]
+
+
+def cns_options(**kw) -> OraCnsOptions:
+    o = OraCnsOptions(400, 4, 12, 0.5, 0.8, 0)
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise KeyError(k)
+        setattr(o, k, v)
+    return o
+
+
+REF_PCAN = os.path.join(HERE, "_ref", "oc2pcan")
+REF_CNS = os.path.join(HERE, "_ref", "cns_ref_harness")
+
+
+def have_ref_cns() -> bool:
+    return os.path.exists(REF_PCAN) and os.path.exists(REF_CNS)
+
+
+def run_ref_pcan(wrk_dir: str, can_path: str, batch_size: int = 100000) -> None:
+    """the reference's oc2pcan: can_path (28-byte records) -> can_path.p<i> + can_path.partitions"""
+    subprocess.run([REF_PCAN, "-p", str(batch_size), "-t", "1", wrk_dir, can_path], check=True,
+                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+
+
+def cns_argv(o: OraCnsOptions) -> List[str]:
+    return ["-a", str(o.min_align_size), "-x", str(o.min_cov), "-y", str(o.max_cov), "-e", "%f" % o.error,
+            "-p", "%f" % o.mapping_ratio, "-u", str(o.use_fixed_ident_cutoff)]
+
+
+def run_ref_cns(o: OraCnsOptions, wrk_dir: str, can_path: str, log_path: str, full: bool = False) -> None:
+    """the reference's consensus driver with its add_one_align / consensus_broken calls logged"""
+    subprocess.run([REF_CNS] + cns_argv(o) + [wrk_dir, can_path, log_path] + (["full"] if full else []), check=True,
+                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+
+
+def cns_run(o: OraCnsOptions, wrk_dir: str, can_path: str, log_path: str, full: bool = False) -> None:
+    """the oracle's restatement over the same files, same log format"""
+    L = lib()
+    L.ora_cns_run.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(OraCnsOptions), C.c_char_p, C.c_int]
+    rc = L.ora_cns_run(wrk_dir.encode(), can_path.encode(), C.byref(o), log_path.encode(), int(full))
+    if rc:
+        raise RuntimeError("ora_cns_run failed: %d" % rc)
+
+
+def parse_cns_log(path: str):
+    """[(template_id, template_size, ident_cutoff, num_can, num_ovlps, ranges, overlaps)] with overlaps =
+    [(toff, tend, weight, aln_size, hash_q, hash_t[, qaln, taln])]"""
+    out, cur = [], []
+    for ln in open(path):
+        f = ln.rstrip("\n").split("\t")
+        if f[0] == "A":
+            cur.append((int(f[1]), int(f[2]), float(f[3]), int(f[4]), f[5], f[6]) + tuple(f[7:9]))
+        else:
+            nr = int(f[6])
+            rg = [(int(f[7 + 2 * i]), int(f[8 + 2 * i])) for i in range(nr)]
+            out.append((int(f[1]), int(f[2]), float(f[3]), int(f[4]), int(f[5]), rg, cur))
+            cur = []
+    return out
+

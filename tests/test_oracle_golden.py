@@ -4,6 +4,7 @@ reference itself on fresh seeded data."""
 import hashlib
 import json
 import os
+import shutil
 
 import pytest
 
@@ -103,3 +104,47 @@ def test_oracle_onc_align_matches_reference_on_fresh_pairs(built):
                 n += 1
     ao.close(); ar.close()
     assert n == 360
+
+
+# ---- consensus stage, extension loop: oracle/cns_oracle.c vs the reference's own decisions ----
+
+def _cns_cases():
+    man = json.load(open(os.path.join(util.GOLDEN, "cns_c", "manifest.json")))
+    return man
+
+
+@pytest.mark.parametrize("case", ["default", "fixed", "cov6", "a2000"])
+def test_cns_loop_golden(case, tmp_path):
+    """every add_one_align call (target range, weight, both gapped strings) and the per-template numbers the
+    reference logged (tests/golden/make_golden_cns.py) are reproduced by the restatement, byte for byte"""
+    man = _cns_cases()
+    wrk = util.install_golden_volumes(man["volumes"], tmp_path)
+    for fn in ("cands.p0", "cands.partitions"):
+        shutil.copy(os.path.join(util.GOLDEN, "cns_c", fn), os.path.join(str(tmp_path), fn))
+    log = os.path.join(str(tmp_path), "ora.txt")
+    ora.cns_run(ora.cns_options(**man["cases"][case]["options"]), wrk, os.path.join(str(tmp_path), "cands"), log)
+    want = open(os.path.join(util.GOLDEN, "cns_c", "ref_%s.txt" % case)).read()
+    got = open(log).read()
+    assert got.count("\nT\t") + got.startswith("T\t") == man["cases"][case]["templates"]
+    assert got == want
+
+
+@pytest.mark.skipif(not ora.have_ref_cns(), reason="oracle/_ref (reference build) not present")
+def test_cns_loop_fresh_vs_ref(tmp_path):
+    """a fresh multi-volume dataset through reference oc2pmov -> oc2pcan -> consensus driver vs the restatement"""
+    wrk, rs, nv = util.make_dataset(tmp_path, genome=30_000, coverage=30.0, seed=77, err=0.13, vol_size=300_000)
+    assert nv > 1
+    o = ora.options(**dict(util.FAST, job=0, binary_output=1, num_threads=2))
+    can = os.path.join(str(tmp_path), "cands")
+    with open(can, "wb") as f:
+        for v in range(nv):
+            ora.run_ref(o, v, wrk, can + ".v%d" % v)
+            f.write(open(can + ".v%d" % v, "rb").read())
+    ora.run_ref_pcan(wrk, can, batch_size=60)          # several partitions
+    for kw in (dict(), dict(max_cov=8)):
+        a, b = os.path.join(str(tmp_path), "ref.txt"), os.path.join(str(tmp_path), "ora.txt")
+        ora.run_ref_cns(ora.cns_options(**kw), wrk, can, a, full=True)
+        ora.cns_run(ora.cns_options(**kw), wrk, can, b, full=True)
+        assert open(a).read() == open(b).read()
+        assert len(ora.parse_cns_log(a)) > 50
+
