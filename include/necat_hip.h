@@ -181,6 +181,86 @@ int  necat_onc_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_
 int  necat_gapped_strings(const uint8_t* ops, uint64_t n, const uint8_t* qseq, uint64_t qsize, uint64_t qoff,
                           const uint8_t* tseq, uint64_t tsize, uint64_t toff, char* query_align, char* target_align);
 
+/* ---- consensus stage (oc2cns), extension loop only - SURVEY 8f.1 ------------------------------------------
+ * What consensus_one_read (consensus/consensus_one_read.c:221-372) does for ONE template before it hands
+ * over to the consensus proper (tasc/cbcns.c): align its candidates in score order - first until 15
+ * end-to-end overlaps give an identity cutoff (get_good_overlaps, consensus/error_estimate.c:96-183), then in
+ * groups of 50 until the template is covered max_cov deep - and pass every accepted alignment to
+ * add_one_align (tasc/cbcns.c:47) with a weight.  necat_cns_extension_batch does that for MANY templates in
+ * one call: the candidates each template's loop would reach next are aligned speculatively, all templates
+ * together, on the device (the DP kernels of necat_onc_align_batch, tail_match_len = 4); the loop's
+ * sequential decisions (read already used, region already covered, cutoff) are then replayed in order on
+ * the results, so the overlaps, their order and the per-template numbers are those of the sequential loop.
+ * rescue_long_indels (-r, default 0: cns_options.c:19) is not supported. */
+
+/* the fields of CnsOptions (consensus/cns_options.h:6-18) the loop reads; defaults cns_options.c:10-22 */
+typedef struct {
+    int    min_align_size;          /* -a 400 */
+    int    min_cov;                 /* -x 4   */
+    int    max_cov;                 /* -y 12  */
+    double error;                   /* -e 0.5 */
+    double mapping_ratio;           /* -p 0.8 */
+    int    use_fixed_ident_cutoff;  /* -u 0   */
+} necat_cns_options;
+void necat_cns_default_options(necat_cns_options* o);
+
+/* one add_one_align call: the overlap of candidate `cand` with its template */
+typedef struct {
+    uint64_t cand;            /* index into the cands array of the call */
+    int32_t  qoff, qend, toff, tend;   /* as in necat_alignment */
+    int32_t  align_size;      /* gapped columns */
+    uint32_t ops_block;       /* the columns are result->ops[ops_block] + ops_off, align_size bytes,    */
+    uint64_t ops_off;         /* coded as in necat_onc_align_batch                                       */
+    double   ident_perc;
+    double   weight;          /* calc_cns_weight, consensus_one_read.c:11-16 */
+} necat_cns_overlap;
+
+/* what consensus_one_read leaves for one template */
+typedef struct {
+    int32_t  examined;        /* 0: fewer than min_cov candidates, the template is skipped (:223) */
+    int32_t  num_can;         /* CnsSeq.num_can   (common/cns_seq.h:12) */
+    int32_t  num_ovlps;       /* CnsSeq.num_ovlps (:13) = ovlp_end - ovlp_begin */
+    int32_t  _pad;
+    double   ident_cutoff;    /* CnsSeq.ident_cutoff (:14) */
+    uint64_t ovlp_begin, ovlp_end;     /* its add_one_align calls, in call order: overlaps[ovlp_begin .. ovlp_end) */
+    uint64_t range_begin, range_end;   /* its cov_ranges: pairs ranges[2 i], ranges[2 i + 1] */
+} necat_cns_template;
+
+typedef struct {
+    uint64_t            n_templates;
+    necat_cns_template* templates;
+    uint64_t            n_overlaps;
+    necat_cns_overlap*  overlaps;
+    uint64_t            n_ranges;
+    int32_t*            ranges;
+    uint32_t            n_ops_blocks;
+    uint8_t**           ops;           /* blocks of alignment columns (pinned host memory) */
+    /* work counters */
+    uint64_t            n_aligned;     /* alignments computed, speculative ones included */
+    uint64_t            n_used;        /* alignments the sequential loop computes (cns_extension calls) */
+    uint32_t            n_rounds;      /* device passes (one necat_onc_align_batch-like call each) */
+    double              device_ms;     /* sum of the passes (HIP events, result copies included) */
+    double              host_ms;       /* select + replay on the host */
+} necat_cns_result;
+
+/* Order and cut of one partition file's candidates as oc2cns does it: records of one template together
+ * (load_partition_candidates, consensus/consensus_one_partition.c:10-52), subject strand normalised to
+ * forward (normalise_pcan_sdir, common/gapped_candidate.c:71-93), each template's candidates sorted by
+ * PackedGappedCandidate_CnsScoreGT (gapped_candidate.c:95-121) and cut to MAX_EXAMINED_CAN = 300
+ * (consensus_aux.h:15, consensus_one_read.c:250-260).  packed = n 28-byte PackedGappedCandidate records with
+ * ids global in `reads`.  Outputs (necat_free each): cands; tmpl_off[n_templates + 1] (template t owns
+ * cands[tmpl_off[t] .. tmpl_off[t+1])); n_all[n_templates] = candidates of the template before the cut. */
+int  necat_cns_load_partition(necat_ctx* ctx, const necat_volume* reads, const void* packed, uint64_t n,
+                              necat_candidate** cands, uint64_t** tmpl_off, uint64_t** n_all, uint64_t* n_templates);
+
+/* cands: per template in examination order (as necat_cns_load_partition leaves them): sid = the template,
+ * sdir = 0, ids global in `reads` (the merged read set, common/makedb_aux.c:137), qsize / ssize filled.
+ * n_all may be NULL (= the counts given). */
+int  necat_cns_extension_batch(necat_ctx* ctx, const necat_volume* reads, const necat_candidate* cands,
+                               const uint64_t* tmpl_off, const uint64_t* n_all, uint64_t n_templates,
+                               const necat_cns_options* opt, necat_cns_result** out);
+void necat_cns_result_free(necat_cns_result* r);
+
 /* Test / profiling hook for the dominant kernel: n independent Edlib_align calls
  * (edlib_ex.c:733) on byte-coded (0..3) sequences.  seqs = concatenated fragments, q_off/t_off =
  * start of each fragment in `seqs`.  Outputs per block: edit distance (-1 = fail), qend, tend, and

@@ -44,12 +44,33 @@ M4_DTYPE = np.dtype([("qid", "<i4"), ("qdir", "<i4"), ("qoff", "<u8"), ("qend", 
 ALIGNMENT_DTYPE = np.dtype([("ok", "<i4"), ("qoff", "<i4"), ("qend", "<i4"), ("toff", "<i4"), ("tend", "<i4"),
                             ("align_size", "<i4"), ("ident_perc", "<f8")])
 assert CANDIDATE_DTYPE.itemsize == 88 and M4_DTYPE.itemsize == 96 and ALIGNMENT_DTYPE.itemsize == 32
+CNS_OVERLAP_DTYPE = np.dtype([("cand", "<u8"), ("qoff", "<i4"), ("qend", "<i4"), ("toff", "<i4"), ("tend", "<i4"),
+                              ("align_size", "<i4"), ("ops_block", "<u4"), ("ops_off", "<u8"), ("ident_perc", "<f8"),
+                              ("weight", "<f8")])
+CNS_TEMPLATE_DTYPE = np.dtype([("examined", "<i4"), ("num_can", "<i4"), ("num_ovlps", "<i4"), ("_pad", "<i4"),
+                               ("ident_cutoff", "<f8"), ("ovlp_begin", "<u8"), ("ovlp_end", "<u8"),
+                               ("range_begin", "<u8"), ("range_end", "<u8")])
+assert CNS_OVERLAP_DTYPE.itemsize == 56 and CNS_TEMPLATE_DTYPE.itemsize == 56
+
+
+class CnsOptions(C.Structure):
+    """necat_cns_options (include/necat_hip.h) = the CnsOptions fields the extension loop reads"""
+    _fields_ = [("min_align_size", C.c_int), ("min_cov", C.c_int), ("max_cov", C.c_int), ("error", C.c_double),
+                ("mapping_ratio", C.c_double), ("use_fixed_ident_cutoff", C.c_int)]
+
+
+class _CnsResult(C.Structure):
+    _fields_ = [("n_templates", C.c_uint64), ("templates", C.c_void_p), ("n_overlaps", C.c_uint64), ("overlaps", C.c_void_p),
+                ("n_ranges", C.c_uint64), ("ranges", C.c_void_p), ("n_ops_blocks", C.c_uint32), ("ops", C.POINTER(C.c_void_p)),
+                ("n_aligned", C.c_uint64), ("n_used", C.c_uint64), ("n_rounds", C.c_uint32), ("device_ms", C.c_double),
+                ("host_ms", C.c_double)]
 
 EXPORTED_SYMBOLS = [
     "necat_default_options", "necat_ctx_create", "necat_ctx_destroy", "necat_last_error", "necat_device_name",
     "necat_volume_upload", "necat_volume_free", "necat_index_build", "necat_index_size", "necat_index_download",
     "necat_index_free", "necat_find_candidates", "necat_extend", "necat_map_pair", "necat_onc_align_batch",
-    "necat_gapped_strings",
+    "necat_gapped_strings", "necat_cns_default_options", "necat_cns_load_partition", "necat_cns_extension_batch",
+    "necat_cns_result_free",
     "necat_edlib_align_batch", "necat_get_timings", "necat_free",
 ]
 
@@ -91,6 +112,13 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.necat_onc_align_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_uint64, C.POINTER(MapOptions), C.c_int,
                                           C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.necat_gapped_strings.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, C.c_uint64, vp, vp]
+    lib.necat_cns_default_options.argtypes = [C.POINTER(CnsOptions)]
+    lib.necat_cns_default_options.restype = None
+    lib.necat_cns_load_partition.argtypes = [vp, vp, vp, C.c_uint64, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), u64p]
+    lib.necat_cns_extension_batch.argtypes = [vp, vp, vp, vp, vp, C.c_uint64, C.POINTER(CnsOptions),
+                                              C.POINTER(C.POINTER(_CnsResult))]
+    lib.necat_cns_result_free.argtypes = [C.POINTER(_CnsResult)]
+    lib.necat_cns_result_free.restype = None
     lib.necat_edlib_align_batch.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, C.c_double,
                                             vp, vp, vp, C.POINTER(vp), C.POINTER(vp)]
     lib.necat_get_timings.argtypes = [vp, C.POINTER(Timings)]
@@ -169,6 +197,26 @@ class Context:
         v.names = names
         return v
 
+    def load_merged_volumes(self, wrk_dir: str) -> "Volume":
+        """all volumes of a work directory as ONE read set with global ids (merge_volumes, common/makedb_aux.c:137-153) -
+        what the consensus stage works on; .codes keeps the byte-coded bases for the callers' gapped strings"""
+        from .synth import pack_2bit, unpack_2bit
+        _, _, vols = load_volumes_info(wrk_dir)
+        codes, sizes, names = [], [], []
+        for path, _, _ in vols:
+            pac, off, sz, nm = read_volume(path)
+            codes.append(unpack_2bit(pac, int(sz.sum())))
+            sizes.append(sz)
+            names += nm
+        codes = np.concatenate(codes) if codes else np.zeros(0, np.uint8)
+        sizes = np.concatenate(sizes).astype(np.int64) if sizes else np.zeros(0, np.int64)
+        off = np.zeros(sizes.shape[0], dtype=np.int64)
+        if sizes.shape[0]:
+            off[1:] = np.cumsum(sizes)[:-1]
+        v = self.upload_volume(pack_2bit(codes), int(sizes.sum()), off, sizes)
+        v.names, v.codes = names, codes
+        return v
+
     def build_index(self, ref: "Volume", k: int, max_occ: int) -> "Index":
         h = C.c_void_p()
         self._check(self.lib.necat_index_build(self.h, ref.h, k, max_occ, C.byref(h)), "necat_index_build")
@@ -215,6 +263,27 @@ class Context:
         off = self._take(f, n + 1, np.dtype("<u8"))
         return self._take(a, n, ALIGNMENT_DTYPE), self._take(o, int(off[-1]), np.dtype("u1")), off
 
+    def cns_load_partition(self, reads: "Volume", packed: np.ndarray):
+        """order and cut of one candidate partition as oc2cns does it: (cands, tmpl_off, n_all)"""
+        packed = np.ascontiguousarray(packed).view(np.uint8).reshape(-1)
+        n = packed.shape[0] // 28
+        c, o, a, nt = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+        self._check(self.lib.necat_cns_load_partition(self.h, reads.h, packed.ctypes.data, n, C.byref(c), C.byref(o), C.byref(a),
+                                                      C.byref(nt)), "necat_cns_load_partition")
+        off = self._take(o, nt.value + 1, np.dtype("<u8"))
+        return self._take(c, int(off[-1]), CANDIDATE_DTYPE), off, self._take(a, nt.value, np.dtype("<u8"))
+
+    def cns_extension_batch(self, reads: "Volume", cands: np.ndarray, tmpl_off: np.ndarray, n_all, opt: CnsOptions) -> "CnsResult":
+        """the consensus stage's extension loop for all templates of the call (include/necat_hip.h)"""
+        cands = np.ascontiguousarray(cands, dtype=CANDIDATE_DTYPE)
+        tmpl_off = np.ascontiguousarray(tmpl_off, dtype=np.uint64)
+        na = None if n_all is None else np.ascontiguousarray(n_all, dtype=np.uint64)
+        r = C.POINTER(_CnsResult)()
+        self._check(self.lib.necat_cns_extension_batch(self.h, reads.h, cands.ctypes.data, tmpl_off.ctypes.data,
+                                                       None if na is None else na.ctypes.data, tmpl_off.shape[0] - 1,
+                                                       C.byref(opt), C.byref(r)), "necat_cns_extension_batch")
+        return CnsResult(self.lib, r)
+
     def edlib_align_batch(self, seqs: np.ndarray, q_off, q_len, t_off, t_len, error: float = 0.5, want_ops: bool = True):
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
         q_off = np.ascontiguousarray(q_off, dtype=np.uint64)
@@ -249,6 +318,53 @@ class Context:
         arr = np.frombuffer(buf, dtype=dtype, count=n)
         weakref.finalize(buf, self.lib.necat_free, C.c_void_p(p.value))   # arr keeps buf alive through .base
         return arr
+
+
+class CnsResult:
+    """necat_cns_result: templates / overlaps / ranges are numpy views, valid until free()"""
+
+    def __init__(self, lib, r):
+        self.lib, self.r = lib, r
+        c = r.contents
+        self.templates = self._view(c.templates, c.n_templates, CNS_TEMPLATE_DTYPE)
+        self.overlaps = self._view(c.overlaps, c.n_overlaps, CNS_OVERLAP_DTYPE)
+        self.ranges = self._view(c.ranges, 2 * c.n_ranges, np.dtype("<i4")).reshape(-1, 2)
+        self.n_aligned, self.n_used, self.n_rounds = c.n_aligned, c.n_used, c.n_rounds
+        self.device_ms, self.host_ms = c.device_ms, c.host_ms
+
+    @staticmethod
+    def _view(p, n, dtype):
+        if not p or n == 0:
+            return np.zeros(0, dtype=dtype)
+        return np.frombuffer((C.c_char * (n * dtype.itemsize)).from_address(p), dtype=dtype, count=n)
+
+    def ops(self, ov) -> np.ndarray:
+        """the alignment columns of one overlap record"""
+        n = int(ov["align_size"])
+        base = self.r.contents.ops[int(ov["ops_block"])]
+        return np.frombuffer((C.c_char * n).from_address(base + int(ov["ops_off"])), dtype=np.uint8, count=n) if n else np.zeros(0, np.uint8)
+
+    def free(self):
+        if self.r:
+            self.templates = self.overlaps = self.ranges = None
+            self.lib.necat_cns_result_free(self.r)
+            self.r = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def cns_options(**kw) -> CnsOptions:
+    o = CnsOptions()
+    load_library().necat_cns_default_options(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise KeyError(k)
+        setattr(o, k, v)
+    return o
 
 
 class Volume:

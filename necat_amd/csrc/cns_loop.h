@@ -1,0 +1,412 @@
+// cns_loop.h - host side of necat_cns_extension_batch: the consensus stage's extension loop
+// (consensus/consensus_one_read.c:221-372, consensus/error_estimate.c:96-183) run for many templates at once.
+//
+// The reference walks one template's candidates in score order and decides, one candidate at a time,
+// whether to align it (read not used yet, region not yet covered max_cov deep) and whether to keep the
+// alignment; every decision depends on the alignments kept before it.  Here the alignments are the expensive
+// part and live on the device, so the loop is split in two:
+//
+//   select  per template, the next candidates the loop WOULD align if none of the pending alignments changed
+//           its state (a prefix of the walk with distinct reads, at most `spec` of them) - all templates'
+//           selections form one device batch;
+//   replay  with the results in hand the walk is repeated in order with the reference's rules; a selected
+//           candidate the sequential loop would have skipped after all (its region got covered by an overlap
+//           accepted a moment earlier, or the 15 identities were complete) is simply not used.
+//
+// Both conditions that make the loop skip a candidate (read already used, region fully covered) only ever
+// turn from false to true, so a candidate skipped at selection time is skipped by the sequential loop too:
+// the replay sees exactly the alignments it needs, and the overlaps, their order and the per-template
+// numbers are the sequential ones.
+//
+// No HIP in this header: the alignments come from a callback (the device path in necat_hip.hip; the CPU test
+// tests/host_core/check_cns.cpp plugs the oracle's aligner in to check this logic without a GPU).
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <functional>
+#include <thread>
+#include <vector>
+
+#include "../../include/necat_hip.h"
+
+namespace necat {
+namespace cns {
+
+// rules of the loop -----------------------------------------------------------------------------------
+
+// consensus/consensus_aux.c:92-113
+inline bool full_cov_ovlp(int ql, int qr, int qs, int tl, int tr, int ts, int min_len, int tail)
+{
+    const bool q_left = ql <= tail, q_right = qs - qr <= tail, t_left = tl <= tail, t_right = ts - tr <= tail;
+    if ((q_left && q_right) || (t_left && t_right)) return true;
+    if (q_right) { if (!t_left) return false; if (qr - ql >= min_len) return true; }
+    if (t_right) { if (!q_left) return false; if (qr - ql >= min_len) return true; }
+    return false;
+}
+// consensus/consensus_aux.c:115-122
+inline bool mapping_range_ok(int ql, int qr, int qs, int tl, int tr, int ts, int min_len, double ratio)
+{
+    return qr - ql >= min_len || tr - tl >= min_len || qr - ql >= qs * ratio || tr - tl >= ts * ratio;
+}
+// consensus/error_estimate.c:7-29: the overlap reaches an end of a read on both sides (200 bp slack)
+inline bool end_to_end(int qoff, int qend, int qsize, int toff, int tend, int tsize)
+{
+    const int slack = 200;
+    const bool ql = qoff <= slack, qr = qsize - qend <= slack, tl = toff <= slack, tr = tsize - tend <= slack;
+    return (ql && qr) || (tl && tr) || (qr && tl) || (tr && ql);
+}
+// consensus/consensus_one_read.c:11-16
+inline double overlap_weight(double ident_perc)
+{
+    const double e = (100.0 - ident_perc) / 100.0 / 2.0;
+    double w = (1.0 - e) * (1.0 - e) + e * e / 3.0;
+    if (100.0 - ident_perc <= 1.0e-6) w = 1.0;
+    return w;
+}
+// consensus/error_estimate.c:31-63 (same order of floating-point operations)
+inline double ident_lower_bound(const double* ident, int n)
+{
+    if (n < 5) return 0.0;
+    double sum = 0.0;
+    for (int i = 0; i < n; ++i) sum += ident[i];
+    const double avg = sum / n;
+    double se = 0.0;
+    for (int i = 0; i < n; ++i) se += (avg - ident[i]) * (avg - ident[i]);
+    se /= n;
+    se = sqrt(se);
+    return avg - se * 5;
+}
+
+constexpr int kEstimateCandidates = 50;   // error_estimate.c:120
+constexpr int kIdentSamples = 15;         // error_estimate.c:115
+constexpr int kGroup = 50;                // consensus_one_read.c:321
+
+// one computed alignment as the loop sees it
+struct Aligned {
+    necat_alignment a;
+    uint32_t block;       // where its columns are
+    uint64_t off;
+};
+
+// Aligns `n` candidates; fills out[0..n).  Returns 0 or a NECAT_ERR code.
+using AlignFn = std::function<int(const necat_candidate* cands, uint64_t n, Aligned* out)>;
+
+struct Template {
+    // input
+    const necat_candidate* c = nullptr;   // its candidates in examination order
+    uint64_t c_base = 0;                  // index of c[0] in the caller's array
+    uint32_t n = 0, n_all = 0;
+    int tsize = 0;
+    // loop state
+    enum Stage : uint8_t { ESTIMATE, COVER, DONE } stage = DONE;
+    bool examined = false;
+    uint32_t cursor = 0;        // next candidate the walk looks at
+    uint32_t group_end = 0;     // COVER: end of the current group of 50 (0 = a new group starts at cursor)
+    uint32_t stop = 0;          // where this round's selection stopped (exclusive)
+    std::vector<uint32_t> sel;  // this round's selection (candidate indices, ascending)
+    uint64_t sel_at = 0;        // index of sel[0] in the round's batch
+    std::vector<int32_t> used;  // reads already extended for this template (ReadIdPool)
+    std::vector<uint16_t> cov;  // coverage of the template by accepted overlaps
+    struct Pooled { uint32_t cand; Aligned al; int qsize; };
+    std::vector<Pooled> pool;   // OverlapsPool of the estimate stage
+    double ident[kIdentSamples];
+    int n_ident = 0;
+    // output
+    double ident_cutoff = 0.0;
+    int num_can = 0, num_ovlps = 0;
+    std::vector<necat_cns_overlap> overlaps;
+    std::vector<int32_t> ranges;
+    uint64_t n_used = 0;
+
+    bool is_used(int32_t qid) const { return std::find(used.begin(), used.end(), qid) != used.end(); }
+    // consensus_one_read.c:145-151
+    bool region_full(int from, int to, int max_cov) const
+    {
+        for (int i = from; i < to; ++i) if (cov[i] < max_cov) return false;
+        return true;
+    }
+    void cover(int from, int to) { for (int i = from; i < to; ++i) ++cov[i]; }
+    void accept(uint32_t ci, const Aligned& al)
+    {
+        necat_cns_overlap o;
+        o.cand = c_base + ci; o.qoff = al.a.qoff; o.qend = al.a.qend; o.toff = al.a.toff; o.tend = al.a.tend;
+        o.align_size = al.a.align_size; o.ops_block = al.block; o.ops_off = al.off;
+        o.ident_perc = al.a.ident_perc; o.weight = overlap_weight(al.a.ident_perc);
+        overlaps.push_back(o);
+        ++num_ovlps;
+        cover(al.a.toff, al.a.tend);
+    }
+};
+
+struct Knobs {
+    int spec_estimate_extra = 3;   // estimate stage: selected = identities still missing + this
+    int spec_cover = 6;            // cover stage: candidates selected per round
+};
+
+// ---- select -------------------------------------------------------------------------------------------
+
+// true if `qid` is the read of a candidate already selected this round
+inline bool in_selection(const Template& t, int32_t qid)
+{
+    for (uint32_t s : t.sel) if (t.c[s].qid == qid) return true;
+    return false;
+}
+
+inline void finish_estimate(Template& t, uint32_t next, const necat_cns_options& opt);
+
+inline void select(Template& t, const necat_cns_options& opt, const Knobs& kn)
+{
+    t.sel.clear();
+    while (t.stage != Template::DONE) {
+        if (t.stage == Template::ESTIMATE) {
+            const uint32_t limit = std::min<uint32_t>(t.n, kEstimateCandidates);
+            const uint32_t want = (uint32_t)(kIdentSamples - t.n_ident + kn.spec_estimate_extra);
+            uint32_t i = t.cursor;
+            for (; i < limit && t.sel.size() < want; ++i) {
+                const int32_t qid = t.c[i].qid;
+                if (t.is_used(qid)) continue;
+                if (in_selection(t, qid)) break;          // depends on whether the earlier one aligns
+                t.sel.push_back(i);
+            }
+            t.stop = i;
+            if (!t.sel.empty()) return;
+            if (i < limit) { /* cannot happen: a duplicate implies a non-empty selection */ return; }
+            finish_estimate(t, limit, opt);                // ran out of candidates: error_estimate.c:178 with i = limit
+            continue;
+        }
+        // COVER: consensus_one_read.c:317-372
+        if (t.group_end == 0) {
+            if (t.cursor >= t.n || t.region_full(0, t.tsize, opt.max_cov)) { t.stage = Template::DONE; break; }
+            t.group_end = std::min<uint32_t>(t.cursor + kGroup, t.n);
+        }
+        uint32_t i = t.cursor;
+        for (; i < t.group_end && (int)t.sel.size() < kn.spec_cover; ++i) {
+            const necat_candidate& c = t.c[i];
+            if (t.is_used(c.qid)) continue;
+            if (t.region_full((int)c.sbeg, (int)c.send, opt.max_cov)) continue;
+            if (in_selection(t, c.qid)) break;
+            t.sel.push_back(i);
+        }
+        t.stop = i;
+        if (!t.sel.empty()) return;
+        t.cursor = i;                                      // nothing to align up to here
+        if (t.cursor == t.group_end) t.group_end = 0;
+    }
+}
+
+// ---- replay -------------------------------------------------------------------------------------------
+
+// get_idents + the cutoff (error_estimate.c:65-94, :180-183), add_extended_overlaps (consensus_one_read.c:153-190)
+inline void finish_estimate(Template& t, uint32_t next, const necat_cns_options& opt)
+{
+    if (t.n_ident < kIdentSamples) {
+        int k = 0;
+        for (const auto& p : t.pool) {
+            if (k == kIdentSamples) break;
+            if (end_to_end(p.al.a.qoff, p.al.a.qend, p.qsize, p.al.a.toff, p.al.a.tend, t.tsize)) t.ident[k++] = p.al.a.ident_perc;
+        }
+        if (k < kIdentSamples) {
+            k = 0;
+            for (const auto& p : t.pool) {
+                if (k == kIdentSamples) break;
+                if (p.al.a.qend - p.al.a.qoff >= p.qsize * 0.6 || p.al.a.tend - p.al.a.toff >= t.tsize * 0.6) t.ident[k++] = p.al.a.ident_perc;
+            }
+        }
+        t.n_ident = k;
+    }
+    std::sort(t.ident, t.ident + t.n_ident, [](double a, double b) { return a > b; });
+    int n = t.n_ident;
+    if (n >= 8) n = (int)(n * 0.7);
+    t.ident_cutoff = ident_lower_bound(t.ident, n);
+    for (const auto& p : t.pool) {
+        const necat_alignment& a = p.al.a;
+        if (a.ident_perc < t.ident_cutoff) continue;
+        if (!mapping_range_ok(a.qoff, a.qend, p.qsize, a.toff, a.tend, t.tsize, opt.min_align_size, opt.mapping_ratio)) continue;
+        t.accept(p.cand, p.al);
+        if (full_cov_ovlp(a.qoff, a.qend, p.qsize, a.toff, a.tend, t.tsize, 1000, 200)) { t.ranges.push_back(a.toff); t.ranges.push_back(a.tend); }
+    }
+    t.pool.clear(); t.pool.shrink_to_fit();
+    t.num_can = (int)next;                                 // consensus_one_read.c:312-313
+    t.cursor = next; t.group_end = 0;
+    t.stage = Template::COVER;
+}
+
+// `res` = the alignments of t.sel, in that order
+inline void replay(Template& t, const Aligned* res, const necat_cns_options& opt)
+{
+    if (t.sel.empty()) return;
+    size_t k = 0;
+    if (t.stage == Template::ESTIMATE) {
+        for (uint32_t i = t.cursor; i < t.stop; ++i) {
+            const necat_candidate& c = t.c[i];
+            if (t.is_used(c.qid)) continue;
+            const Aligned& al = res[k++];                  // candidates that pass the test were all selected
+            ++t.n_used;
+            if (!al.a.ok) continue;
+            t.pool.push_back({i, al, (int)c.qsize});
+            t.used.push_back(c.qid);
+            if (end_to_end(al.a.qoff, al.a.qend, (int)c.qsize, al.a.toff, al.a.tend, t.tsize)) {
+                t.ident[t.n_ident++] = al.a.ident_perc;
+                if (t.n_ident == kIdentSamples) { finish_estimate(t, i, opt); return; }   // error_estimate.c:172-178: i stays
+            }
+        }
+        t.cursor = t.stop;
+        if (t.cursor >= std::min<uint32_t>(t.n, kEstimateCandidates)) finish_estimate(t, t.cursor, opt);
+        return;
+    }
+    for (uint32_t i = t.cursor; i < t.stop; ++i) {
+        const necat_candidate& c = t.c[i];
+        if (t.is_used(c.qid)) continue;
+        const bool selected = k < t.sel.size() && t.sel[k] == i;
+        if (!selected) continue;                           // skipped at selection time: still skipped
+        const Aligned& al = res[k++];
+        if (t.region_full((int)c.sbeg, (int)c.send, opt.max_cov)) continue;   // covered in the meantime: not aligned by the loop
+        ++t.n_used;
+        ++t.num_can;
+        if (!al.a.ok) continue;
+        const necat_alignment& a = al.a;
+        if (a.ident_perc < t.ident_cutoff && !full_cov_ovlp(a.qoff, a.qend, (int)c.qsize, a.toff, a.tend, t.tsize, 5000, 100)) continue;
+        if (!mapping_range_ok(a.qoff, a.qend, (int)c.qsize, a.toff, a.tend, t.tsize, opt.min_align_size, opt.mapping_ratio)) continue;
+        t.accept(i, al);
+        t.used.push_back(c.qid);
+    }
+    t.cursor = t.stop;
+    if (t.cursor == t.group_end) t.group_end = 0;
+}
+
+// ---- driver -------------------------------------------------------------------------------------------
+
+template <class F>
+inline void parallel_for(size_t n, F&& fn)
+{
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 1;
+    nt = (unsigned)std::min<size_t>(std::min<unsigned>(nt, 32), (n + 63) / 64);
+    if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<size_t> next(0);
+    std::vector<std::thread> th;
+    auto work = [&]() { for (;;) { const size_t b = next.fetch_add(64); if (b >= n) break; for (size_t i = b; i < std::min(n, b + 64); ++i) fn(i); } };
+    for (unsigned t = 0; t + 1 < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+}
+
+struct Stats { uint64_t n_aligned = 0, n_used = 0; uint32_t n_rounds = 0; };
+
+// Runs the loop of every template to its end.  Returns 0 or the callback's error.
+inline int run(std::vector<Template>& ts, const necat_cns_options& opt, const Knobs& kn, const AlignFn& align, Stats* st)
+{
+    parallel_for(ts.size(), [&](size_t i) {
+        Template& t = ts[i];
+        t.examined = t.n > 0 && (uint32_t)opt.min_cov <= t.n_all;      // consensus_one_read.c:223
+        if (!t.examined) { t.stage = Template::DONE; return; }
+        t.cov.assign((size_t)t.tsize + 1, 0);
+        t.used.reserve(64);
+        if (opt.use_fixed_ident_cutoff) {                               // :267-272
+            t.ident_cutoff = 100.0 * (1.0 - opt.error);
+            t.stage = Template::COVER;
+        } else {
+            t.stage = Template::ESTIMATE;
+        }
+    });
+    std::vector<necat_candidate> batch;
+    std::vector<Aligned> res;
+    for (;;) {
+        parallel_for(ts.size(), [&](size_t i) { if (ts[i].stage != Template::DONE) select(ts[i], opt, kn); else ts[i].sel.clear(); });
+        uint64_t total = 0;
+        for (auto& t : ts) { t.sel_at = total; total += t.sel.size(); }
+        if (total == 0) break;
+        batch.resize(total); res.resize(total);
+        parallel_for(ts.size(), [&](size_t i) {
+            Template& t = ts[i];
+            for (size_t k = 0; k < t.sel.size(); ++k) batch[t.sel_at + k] = t.c[t.sel[k]];
+        });
+        const int rc = align(batch.data(), total, res.data());
+        if (rc) return rc;
+        parallel_for(ts.size(), [&](size_t i) { if (!ts[i].sel.empty()) replay(ts[i], res.data() + ts[i].sel_at, opt); });
+        st->n_aligned += total; ++st->n_rounds;
+    }
+    for (auto& t : ts) { st->n_used += t.n_used; std::vector<uint16_t>().swap(t.cov); }
+    return 0;
+}
+
+// ---- candidate partitions (the records between oc2pmov -j 0 / oc2pcan and oc2cns) ----------------------
+
+struct Packed { uint32_t w[7]; };          // PackedGappedCandidate, common/gapped_candidate.h:64-85
+constexpr uint32_t kSdirBit = 1u << 31, kQdirBit = 1u << 30, kOffBit = 1u << 29, kScoreMask = kOffBit - 1;
+constexpr uint32_t kMaxExamined = 300;     // MAX_EXAMINED_CAN, consensus/consensus_aux.h:15
+
+// common/gapped_candidate.c:71-93: the same pair seen with the subject on its forward strand
+inline void normalise_sdir(Packed& p, uint32_t qsize, uint32_t ssize)
+{
+    if (!(p.w[0] & kSdirBit)) return;
+    p.w[0] = (p.w[0] & kScoreMask) | ((p.w[0] & kQdirBit) ? 0 : kQdirBit) | ((p.w[0] & kOffBit) ? 0 : kOffBit);
+    const uint32_t qb = qsize - p.w[6], qe = qsize - p.w[5], sb = ssize - p.w[3], se = ssize - p.w[2];
+    p.w[5] = qb; p.w[6] = qe; p.w[2] = sb; p.w[3] = se;
+}
+
+// PackedGappedCandidate_CnsScoreGT (gapped_candidate.c:95-121): score down, then qid, qdir, qbeg, sbeg up;
+// records equal under it are ordered by their remaining words (the reference leaves them to its introsort)
+inline bool examined_before(const Packed& a, const Packed& b)
+{
+    const int sa = (int)(a.w[0] & kScoreMask), sb = (int)(b.w[0] & kScoreMask);
+    if (sa != sb) return sa > sb;
+    if (a.w[4] != b.w[4]) return (int)a.w[4] < (int)b.w[4];
+    const int da = (a.w[0] & kQdirBit) != 0, db = (b.w[0] & kQdirBit) != 0;
+    if (da != db) return da < db;
+    if (a.w[5] != b.w[5]) return (int)a.w[5] < (int)b.w[5];
+    if (a.w[2] != b.w[2]) return (int)a.w[2] < (int)b.w[2];
+    for (int k = 0; k < 7; ++k) if (a.w[k] != b.w[k]) return a.w[k] < b.w[k];
+    return false;
+}
+
+// common/gapped_candidate.c:31-52
+inline necat_candidate unpack(const Packed& p)
+{
+    necat_candidate c;
+    memset(&c, 0, sizeof c);
+    c.sdir = (p.w[0] & kSdirBit) ? 1 : 0; c.qdir = (p.w[0] & kQdirBit) ? 1 : 0; c.score = (int32_t)(p.w[0] & kScoreMask);
+    c.sid = (int32_t)p.w[1]; c.sbeg = p.w[2]; c.send = p.w[3];
+    c.qid = (int32_t)p.w[4]; c.qbeg = p.w[5]; c.qend = p.w[6];
+    if (p.w[0] & kOffBit) { c.qoff = c.qbeg; c.soff = c.sbeg; } else { c.qoff = c.qend; c.soff = c.send; }
+    return c;
+}
+
+// consensus_one_partition.c:10-96 + consensus_one_read.c:250-260.  seq_off = the read set's prefix offsets.
+// Returns the index of the first bad record + 1, or 0.
+inline uint64_t load_partition(std::vector<Packed>& recs, const uint64_t* seq_off, uint64_t nseq,
+                               std::vector<necat_candidate>& cands, std::vector<uint64_t>& off, std::vector<uint64_t>& n_all)
+{
+    for (uint64_t i = 0; i < recs.size(); ++i) {
+        Packed& p = recs[i];
+        if (p.w[1] >= nseq || p.w[4] >= nseq) return i + 1;
+        const uint64_t qsize = seq_off[p.w[4] + 1] - seq_off[p.w[4]], ssize = seq_off[p.w[1] + 1] - seq_off[p.w[1]];
+        if (p.w[5] > p.w[6] || p.w[6] > qsize || p.w[2] > p.w[3] || p.w[3] > ssize) return i + 1;
+        normalise_sdir(p, (uint32_t)qsize, (uint32_t)ssize);
+    }
+    std::sort(recs.begin(), recs.end(), [](const Packed& a, const Packed& b) {
+        if (a.w[1] != b.w[1]) return (int)a.w[1] < (int)b.w[1];
+        return examined_before(a, b);
+    });
+    cands.clear(); off.assign(1, 0); n_all.clear();
+    for (uint64_t i = 0; i < recs.size();) {
+        uint64_t j = i + 1;
+        while (j < recs.size() && recs[j].w[1] == recs[i].w[1]) ++j;
+        const uint64_t keep = std::min<uint64_t>(j - i, kMaxExamined);
+        for (uint64_t k = 0; k < keep; ++k) {
+            necat_candidate c = unpack(recs[i + k]);
+            c.qsize = seq_off[c.qid + 1] - seq_off[c.qid]; c.ssize = seq_off[c.sid + 1] - seq_off[c.sid];
+            cands.push_back(c);
+        }
+        off.push_back(cands.size()); n_all.push_back(j - i);
+        i = j;
+    }
+    return 0;
+}
+
+}  // namespace cns
+}  // namespace necat

@@ -12,6 +12,7 @@
 #include "index_kernels.h"
 #include "seed_kernels.h"
 #include "ext_kernels.h"
+#include "cns_loop.h"
 
 using namespace necat;
 
@@ -55,6 +56,7 @@ int g_seed_wave;       // wave-per-strand seed collection (NECAT_SEED_WAVE=0: th
 int g_trace;           // NECAT_TRACE: 1 = extension rounds, 2 = host stages
 int g_coop_filter;     // NECAT_COOP_FILTER=0: the cooperative kernel stores every word (A/B tests)
 int g_sort_b;          // NECAT_SORT_B=0 disables the size sort of list B
+int g_cns_spec_extra, g_cns_spec_cover;   // NECAT_CNS_SPEC_EXTRA / NECAT_CNS_SPEC: speculation width of the consensus loop
 int g_dbg;             // NECAT_DBG: profiling-only variants of the lane-per-block DP kernel (1 = no band stores, 2 = no NW pass)
 
 // Tuning / test knobs: process-wide, (re)read from the environment whenever a context is created, defaults otherwise.
@@ -71,6 +73,8 @@ void read_knobs()
     g_coop_filter = (int)num("NECAT_COOP_FILTER", 1);
     g_sort_b = (int)num("NECAT_SORT_B", 1);
     g_dbg = (int)num("NECAT_DBG", 0);
+    g_cns_spec_extra = (int)num("NECAT_CNS_SPEC_EXTRA", 3);
+    g_cns_spec_cover = (int)std::max<unsigned long long>(1, num("NECAT_CNS_SPEC", 6));
 }
 
 double wall_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
@@ -1101,6 +1105,135 @@ int necat_gapped_strings(const uint8_t* ops, uint64_t n, const uint8_t* qseq, ui
         target_align[i] = op == 1 ? '-' : dec[tseq[t] & 3];
         q += op != 2; t += op != 1;
     }
+    return NECAT_OK;
+}
+
+// ------------------------------------------------------------------------------------------ consensus stage: the extension loop
+
+void necat_cns_default_options(necat_cns_options* o)
+{   // consensus/cns_options.c:10-22
+    o->min_align_size = 400; o->min_cov = 4; o->max_cov = 12; o->error = 0.5; o->mapping_ratio = 0.8; o->use_fixed_ident_cutoff = 0;
+}
+
+int necat_cns_load_partition(necat_ctx* ctx, const necat_volume* reads, const void* packed, uint64_t n,
+                             necat_candidate** cands, uint64_t** tmpl_off, uint64_t** n_all, uint64_t* n_templates)
+{
+    if (!ctx || !reads || (n && !packed) || !cands || !tmpl_off || !n_all || !n_templates) return NECAT_ERR_ARG;
+    *cands = nullptr; *tmpl_off = nullptr; *n_all = nullptr; *n_templates = 0;
+    std::vector<cns::Packed> recs(n);
+    if (n) memcpy(recs.data(), packed, n * sizeof(cns::Packed));
+    std::vector<necat_candidate> c; std::vector<uint64_t> off, na;
+    const uint64_t bad = cns::load_partition(recs, reads->h_seq_off.data(), reads->nseq, c, off, na);
+    if (bad) return set_err(ctx, NECAT_ERR_ARG, "candidate record %lu refers to a read outside the read set or has a range outside its reads", (unsigned long)(bad - 1));
+    necat_candidate* oc = (necat_candidate*)malloc(std::max<size_t>(1, c.size()) * sizeof(necat_candidate));
+    uint64_t* oo = (uint64_t*)malloc(off.size() * 8);
+    uint64_t* on = (uint64_t*)malloc(std::max<size_t>(1, na.size()) * 8);
+    if (!oc || !oo || !on) { free(oc); free(oo); free(on); return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
+    if (!c.empty()) memcpy(oc, c.data(), c.size() * sizeof(necat_candidate));
+    memcpy(oo, off.data(), off.size() * 8);
+    if (!na.empty()) memcpy(on, na.data(), na.size() * 8);
+    *cands = oc; *tmpl_off = oo; *n_all = on; *n_templates = na.size();
+    return NECAT_OK;
+}
+
+void necat_cns_result_free(necat_cns_result* r)
+{
+    if (!r) return;
+    for (uint32_t b = 0; b < r->n_ops_blocks; ++b) necat_free(r->ops[b]);
+    free(r->ops); free(r->templates); free(r->overlaps); free(r->ranges);
+    free(r);
+}
+
+int necat_cns_extension_batch(necat_ctx* ctx, const necat_volume* reads, const necat_candidate* cands, const uint64_t* tmpl_off,
+                              const uint64_t* n_all, uint64_t n_templates, const necat_cns_options* opt, necat_cns_result** out)
+{
+    if (!ctx || !reads || !opt || !out || (n_templates && (!tmpl_off || !cands))) return NECAT_ERR_ARG;
+    *out = nullptr;
+    if (opt->max_cov < 1 || opt->max_cov > 60000 || opt->min_align_size < 0 || !(opt->error > 0.0 && opt->error <= 1.0))
+        return set_err(ctx, NECAT_ERR_ARG, "consensus options out of range");
+    const double w0 = wall_ms();
+    std::vector<cns::Template> ts(n_templates);
+    for (uint64_t t = 0; t < n_templates; ++t) {
+        const uint64_t lo = tmpl_off[t], hi = tmpl_off[t + 1];
+        if (hi < lo || hi - lo >= (1ULL << 31)) return set_err(ctx, NECAT_ERR_ARG, "template %lu: bad candidate range", (unsigned long)t);
+        cns::Template& T = ts[t];
+        T.c = cands + lo; T.c_base = lo; T.n = (uint32_t)(hi - lo); T.n_all = n_all ? (uint32_t)std::min<uint64_t>(n_all[t], 0xffffffffu) : T.n;
+        for (uint64_t i = lo; i < hi; ++i) {
+            const necat_candidate& c = cands[i];
+            if (c.sid != cands[lo].sid || c.sdir != 0 || c.sid < 0 || (uint64_t)c.sid >= reads->nseq || c.qid < 0 || (uint64_t)c.qid >= reads->nseq ||
+                c.ssize != reads->h_seq_off[c.sid + 1] - reads->h_seq_off[c.sid] || c.qsize != reads->h_seq_off[c.qid + 1] - reads->h_seq_off[c.qid] ||
+                c.sbeg > c.send || c.send > c.ssize || c.qoff > c.qsize || c.soff > c.ssize || c.ssize >= (1ULL << 31) || c.qsize >= (1ULL << 31))
+                return set_err(ctx, NECAT_ERR_ARG, "candidate %lu of template %lu is inconsistent (one forward subject per template, ranges inside the reads)",
+                               (unsigned long)(i - lo), (unsigned long)t);
+        }
+        T.tsize = T.n ? (int)cands[lo].ssize : 0;
+    }
+    necat_map_options mo; necat_default_options(&mo);
+    mo.error = opt->error; mo.align_size_cutoff = opt->min_align_size;
+    std::vector<u8*> blocks;
+    double device_ms = 0, align_wall = 0;
+    cns::AlignFn fn = [&](const necat_candidate* c, uint64_t m, cns::Aligned* res) -> int {
+        const double a0 = wall_ms();
+        AlignOut ao;
+        ao.aln = (necat_alignment*)result_alloc(std::max<uint64_t>(1, m) * sizeof(necat_alignment));
+        if (!ao.aln) return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed");
+        ao.off.assign(m + 1, 0);
+        const int rc = extend_impl(ctx, reads, reads, 0, 0, c, m, &mo, 4 /* ONC_TAIL_MATCH_LEN_LONG, oc_aligner.h:42 */, nullptr, nullptr, &ao);
+        if (rc) { necat_free(ao.aln); for (auto& pr : ao.parts) necat_free(pr.first); return rc; }
+        device_ms += ctx->tm.extend_ms;
+        // the columns stay where the device copied them: one block per batch of the pass
+        size_t p = 0; u64 p_start = 0;
+        const u32 b0 = (u32)blocks.size();
+        for (auto& pr : ao.parts) blocks.push_back(pr.first);
+        for (uint64_t i = 0; i < m; ++i) {
+            res[i].a = ao.aln[i];
+            const u64 at = ao.off[i];
+            while (p < ao.parts.size() && at >= p_start + ao.parts[p].second && ao.off[i + 1] > at) { p_start += ao.parts[p].second; ++p; }
+            res[i].block = b0 + (u32)std::min(p, ao.parts.empty() ? 0 : ao.parts.size() - 1);
+            res[i].off = at - p_start;
+        }
+        necat_free(ao.aln);
+        align_wall += wall_ms() - a0;
+        if (g_trace & 2) fprintf(stderr, "[necat] cns pass: %lu alignments, %.2f ms\n", (unsigned long)m, wall_ms() - a0);
+        return NECAT_OK;
+    };
+    cns::Knobs kn; kn.spec_estimate_extra = g_cns_spec_extra; kn.spec_cover = g_cns_spec_cover;
+    cns::Stats st;
+    const int rc = cns::run(ts, *opt, kn, fn, &st);
+    auto drop = [&]() { for (u8* b : blocks) necat_free(b); };
+    if (rc) { drop(); return rc; }
+    necat_cns_result* r = (necat_cns_result*)calloc(1, sizeof(necat_cns_result));
+    uint64_t n_ov = 0, n_rg = 0;
+    for (auto& T : ts) { n_ov += T.overlaps.size(); n_rg += T.ranges.size() / 2; }
+    if (r) {
+        r->templates = (necat_cns_template*)calloc(std::max<uint64_t>(1, n_templates), sizeof(necat_cns_template));
+        r->overlaps = (necat_cns_overlap*)malloc(std::max<uint64_t>(1, n_ov) * sizeof(necat_cns_overlap));
+        r->ranges = (int32_t*)malloc(std::max<uint64_t>(1, n_rg) * 8);
+        r->ops = (uint8_t**)malloc(std::max<size_t>(1, blocks.size()) * sizeof(uint8_t*));
+    }
+    if (!r || !r->templates || !r->overlaps || !r->ranges || !r->ops) {
+        drop();
+        if (r) { free(r->templates); free(r->overlaps); free(r->ranges); free(r->ops); free(r); }
+        return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed");
+    }
+    uint64_t ov = 0, rg = 0;
+    for (uint64_t t = 0; t < n_templates; ++t) {
+        const cns::Template& T = ts[t];
+        necat_cns_template& o = r->templates[t];
+        o.examined = T.examined ? 1 : 0; o.num_can = T.num_can; o.num_ovlps = T.num_ovlps; o.ident_cutoff = T.ident_cutoff;
+        o.ovlp_begin = ov; o.range_begin = rg;
+        if (!T.overlaps.empty()) memcpy(r->overlaps + ov, T.overlaps.data(), T.overlaps.size() * sizeof(necat_cns_overlap));
+        if (!T.ranges.empty()) memcpy(r->ranges + 2 * rg, T.ranges.data(), T.ranges.size() * 4);
+        ov += T.overlaps.size(); rg += T.ranges.size() / 2;
+        o.ovlp_end = ov; o.range_end = rg;
+    }
+    r->n_templates = n_templates; r->n_overlaps = n_ov; r->n_ranges = n_rg;
+    r->n_ops_blocks = (uint32_t)blocks.size();
+    for (size_t b = 0; b < blocks.size(); ++b) r->ops[b] = blocks[b];
+    r->n_aligned = st.n_aligned; r->n_used = st.n_used; r->n_rounds = st.n_rounds;
+    r->device_ms = device_ms; r->host_ms = wall_ms() - w0 - align_wall;
+    ctx->tm.extend_ms = device_ms;
+    *out = r;
     return NECAT_OK;
 }
 

@@ -5,7 +5,7 @@
  *
  * TEST INFRASTRUCTURE ONLY - same rules as necat_oracle.c (only tests/, smoke() and bench.py's cpu_baseline
  * leg may use it, as the checker).  Pinned against the reference's own consensus_one_partition run through
- * oracle/cns_ref_harness.c (tests/test_oracle_golden.py::test_cns_loop_*; tests/golden/cns_loop_*.txt).
+ * oracle/cns_ref_harness.c (tests/test_oracle_golden.py::test_cns_loop_*; tests/golden/cns_c/ref_*.txt).
  *
  * Reference paths are relative to /root/reference/src/.
  */
@@ -382,7 +382,7 @@ void ora_cns_partition(const ora_volume* reads, uint32_t* items, size_t n, const
     ora_aligner_free(al);
 }
 
-static unsigned long long fnv64(const char* s, size_t n)
+unsigned long long ora_fnv64(const char* s, size_t n)
 {
     unsigned long long h = 1469598103934665603ULL;
     for (size_t i = 0; i < n; ++i) { h ^= (unsigned char)s[i]; h *= 1099511628211ULL; }
@@ -401,7 +401,7 @@ void ora_cns_write_log(const ora_cns_result* r, FILE* out, int full)
             const ora_cns_overlap* o = &r->overlaps[k];
             const size_t n = (size_t)o->align_size;
             fprintf(out, "A\t%d\t%d\t%.17g\t%zu\t%016llx\t%016llx", o->toff, o->tend, o->weight, n,
-                    fnv64(r->strs + o->str_at, n), fnv64(r->strs + o->str_at + n, n));
+                    ora_fnv64(r->strs + o->str_at, n), ora_fnv64(r->strs + o->str_at + n, n));
             if (full) {
                 if (2 * n + 2 > cap) { cap = 4 * n + 2; q = (char*)realloc(q, cap); }
                 memcpy(q, r->strs + o->str_at, n); q[n] = '\t'; memcpy(q + n + 1, r->strs + o->str_at + n, n); q[2 * n + 1] = 0;

@@ -155,6 +155,7 @@ void ora_cns_partition(const ora_volume* reads, uint32_t* items, size_t n, const
 void ora_cns_write_log(const ora_cns_result* r, FILE* out, int full);
 int  ora_cns_run(const char* wrk_dir, const char* can_prefix, const ora_cns_options* opt, const char* log_path, int full);
 void ora_cns_result_free(ora_cns_result* r);
+unsigned long long ora_fnv64(const char* s, size_t n);   /* the hash of the logs (FNV-1a, 64 bit) */
 
 #ifdef __cplusplus
 }

@@ -295,3 +295,11 @@ def parse_cns_log(path: str):
             cur = []
     return out
 
+
+def fnv64(b: bytes) -> str:
+    """the string hash of the consensus logs, as 16 hex digits"""
+    L = lib()
+    L.ora_fnv64.restype = C.c_uint64
+    L.ora_fnv64.argtypes = [C.c_char_p, C.c_size_t]
+    return "%016x" % L.ora_fnv64(b, len(b))
+

@@ -1,0 +1,80 @@
+"""GPU parity of the consensus stage's extension loop: necat_cns_extension_batch through the C ABI
+vs (a) what the REFERENCE decided on the golden partition (tests/golden/cns_c, logged from the reference's own
+consensus driver) and (b) the oracle's sequential restatement on fresh data.  Compared as text in the log format
+of oracle/cns_ref_harness.c: every add_one_align call (target range, weight, length, both gapped strings) in call
+order + per template ident_cutoff, num_can, num_ovlps, cov_ranges."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+
+from necat_amd import capi
+from oracle import oracle_api as ora
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(ctx, wrk, partition_bytes, okw, full=False):
+    vol = ctx.load_merged_volumes(wrk)
+    cands, off, n_all = ctx.cns_load_partition(vol, np.frombuffer(partition_bytes, dtype=np.uint8))
+    res = ctx.cns_extension_batch(vol, cands, off, n_all, capi.cns_options(**okw))
+    roff = np.zeros(len(vol.names) + 1, dtype=np.int64)
+    roff[1:] = np.cumsum(vol.sizes)
+    txt = util.cns_log_text(res, cands, off, vol.codes, roff, ora.fnv64, full=full)
+    stats = (res.n_aligned, res.n_used, res.n_rounds)
+    res.free()
+    vol.free()
+    return txt, stats
+
+
+@pytest.mark.parametrize("case", ["default", "fixed", "cov6", "a2000"])
+def test_cns_loop_golden(ctx, tmp_path, case):
+    man = json.load(open(os.path.join(util.GOLDEN, "cns_c", "manifest.json")))
+    wrk = util.install_golden_volumes(man["volumes"], tmp_path)
+    part = open(os.path.join(util.GOLDEN, "cns_c", "cands.p0"), "rb").read()
+    txt, stats = _run(ctx, wrk, part, man["cases"][case]["options"])
+    want = open(os.path.join(util.GOLDEN, "cns_c", "ref_%s.txt" % case)).read()
+    assert txt.count("\nT\t") + txt.startswith("T\t") == man["cases"][case]["templates"]
+    assert txt == want
+    assert stats[1] <= stats[0]
+
+
+@pytest.mark.parametrize("okw,knobs", [
+    (dict(), {}),
+    (dict(max_cov=8, min_cov=2), {"NECAT_CNS_SPEC": "1", "NECAT_CNS_SPEC_EXTRA": "0"}),     # no speculation at all
+    (dict(use_fixed_ident_cutoff=1, error=0.3), {"NECAT_CNS_SPEC": "40", "NECAT_CNS_SPEC_EXTRA": "35"}),
+    (dict(), {"NECAT_BATCH": "1024"}),                                                        # passes of several batches
+])
+def test_cns_loop_fresh_vs_oracle(built, tmp_path, okw, knobs):
+    wrk, rs, nv = util.make_dataset(tmp_path, genome=40_000, coverage=35.0, seed=91, err=0.13, vol_size=500_000)
+    o = ora.options(**dict(util.FAST, job=0, binary_output=1, num_threads=4))
+    rec = b""
+    for v in range(nv):
+        out = os.path.join(str(tmp_path), "pm_%d" % v)
+        ora.pm_main(o, v, wrk, out)
+        rec += open(out, "rb").read()
+    part = util.pcan_single_partition(rec)
+    prefix = os.path.join(str(tmp_path), "cands")
+    util.write_partition(prefix, part)
+    log = os.path.join(str(tmp_path), "ora.txt")
+    ora.cns_run(ora.cns_options(**okw), wrk, prefix, log, full=True)
+    old = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        c = capi.Context(0)        # knobs are read when a context is created
+        txt, stats = _run(c, wrk, part, okw, full=True)
+        c.close()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    want = open(log).read()
+    assert want.count("\nT\t") > 100
+    assert txt == want
+    if knobs.get("NECAT_CNS_SPEC") == "1":
+        assert stats[0] == stats[1]            # nothing speculative was computed

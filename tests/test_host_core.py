@@ -32,3 +32,40 @@ def test_cores_match_oracle(check_core, tmp_path, ds, vid, args):
     assert r.returncode == 0, r.stdout
     assert "seed_mismatch=0 ext_mismatch=0" in r.stdout
     assert "candidates=0 " not in r.stdout
+
+
+# ---- the host side of necat_cns_extension_batch (necat_amd/csrc/cns_loop.h): select / replay vs the sequential loop ----
+
+@pytest.fixture(scope="module")
+def check_cns(tmp_path_factory, built):
+    d = tmp_path_factory.mktemp("hcc")
+    exe = os.path.join(str(d), "check_cns")
+    objs = []
+    for src in ("necat_oracle.c", "cns_oracle.c"):
+        obj = os.path.join(str(d), src[:-2] + ".o")
+        subprocess.run(["gcc", "-O2", "-std=gnu99", "-c", os.path.join(util.ROOT, "oracle", src), "-o", obj], check=True)
+        objs.append(obj)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe,
+                    os.path.join(util.ROOT, "tests", "host_core", "check_cns.cpp")] + objs + ["-lm", "-lpthread"], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("args", [
+    [],                                                  # defaults
+    "400 4 12 0.5 0.8 1 3 6".split(),                    # fixed identity cutoff
+    "400 2 6 0.5 0.8 0 0 1".split(),                     # no speculation: one candidate per template and pass
+    "2000 4 12 0.5 0.5 0 40 50".split(),                 # speculate whole groups
+    "400 4 30 0.5 0.8 0 1 2".split(),                    # deeper coverage than the data has
+])
+def test_cns_loop_matches_sequential(check_cns, tmp_path, args):
+    """the batched loop (speculative selection + in-order replay) takes exactly the decisions of the sequential
+    loop - overlaps, order, weights, gapped strings, cutoff, counters - whatever the speculation width"""
+    import shutil
+    wrk = util.install_golden_volumes("vols_c", tmp_path)
+    for fn in ("cands.p0", "cands.partitions"):
+        shutil.copy(os.path.join(util.GOLDEN, "cns_c", fn), os.path.join(str(tmp_path), fn))
+    r = subprocess.run([check_cns, wrk, os.path.join(str(tmp_path), "cands")] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "cns_mismatch=0 templates=98 " in r.stdout
+    assert " overlaps=0 " not in r.stdout
+

@@ -148,3 +148,17 @@ def test_cns_loop_fresh_vs_ref(tmp_path):
         assert open(a).read() == open(b).read()
         assert len(ora.parse_cns_log(a)) > 50
 
+
+@pytest.mark.skipif(not ora.have_ref_cns(), reason="oracle/_ref (reference build) not present")
+def test_pcan_single_partition_vs_ref(tmp_path):
+    """tests/util.py's role swap (used to build candidate partitions on the GPU box) = the reference's oc2pcan"""
+    wrk = util.install_golden_volumes("vols_a", tmp_path)
+    rec = open(os.path.join(util.GOLDEN, "a_fast_can_bin.bin"), "rb").read()
+    can = os.path.join(str(tmp_path), "cands")
+    open(can, "wb").write(rec)
+    ora.run_ref_pcan(wrk, can)
+    want = open(can + ".p0", "rb").read()
+    got = util.pcan_single_partition(rec)
+    key = lambda b: sorted(b[i:i + 28] for i in range(0, len(b), 28))
+    assert len(want) == 2 * len(rec) and key(got) == key(want)
+

@@ -62,3 +62,54 @@ def m4_text_rows(m):
     """The 12 printed columns of DUMP_ASM_M4 as tuples (ident as the %.2f string)."""
     return sorted((int(r["qid"]), int(r["sid"]), "%.2f" % r["ident_perc"], int(r["vscore"]), int(r["qdir"]), int(r["qoff"]),
                    int(r["qend"]), int(r["qsize"]), int(r["sdir"]), int(r["soff"]), int(r["send"]), int(r["ssize"])) for r in m)
+
+
+# ---- consensus stage (SURVEY 8f.1) -----------------------------------------------------------------------
+
+def pcan_single_partition(packed: bytes) -> bytes:
+    """oc2pcan (partition_candidates/pcan.c:39-103) when all reads fall in ONE partition: every record is kept
+    and followed by its role-swapped twin (change_pcan_roles, common/gapped_candidate.c:54-69: the subject
+    becomes the query, strands swap with them).  Record order inside a partition file is free."""
+    a = np.frombuffer(packed, dtype="<u4").reshape(-1, 7)
+    b = np.empty_like(a)
+    w0 = a[:, 0]
+    b[:, 0] = (w0 & np.uint32((1 << 30) - 1)) | ((w0 >> 31) << 30) | (((w0 >> 30) & 1) << 31)
+    b[:, 1:4] = a[:, 4:7]
+    b[:, 4:7] = a[:, 1:4]
+    return np.concatenate([a, b]).tobytes()
+
+
+def write_partition(prefix: str, records: bytes) -> None:
+    with open(prefix + ".p0", "wb") as f:
+        f.write(records)
+    with open(prefix + ".partitions", "w") as f:
+        f.write("1\n")
+
+
+def cns_log_text(res, cands, tmpl_off, reads_codes, reads_off, fnv, full=False) -> str:
+    """the log of oracle/cns_ref_harness.c rebuilt from a necat_cns_result (capi.CnsResult)"""
+    from necat_amd import capi
+    out = []
+    for t in range(res.templates.shape[0]):
+        T = res.templates[t]
+        if not T["examined"]:
+            continue
+        for k in range(int(T["ovlp_begin"]), int(T["ovlp_end"])):
+            ov = res.overlaps[k]
+            c = cands[int(ov["cand"])]
+            q = reads_codes[reads_off[c["qid"]]:reads_off[c["qid"] + 1]]
+            if c["qdir"]:
+                q = (3 - q[::-1]).astype(np.uint8)
+            tg = reads_codes[reads_off[c["sid"]]:reads_off[c["sid"] + 1]]
+            qa, ta = capi.gapped_strings(res.ops(ov), q, int(ov["qoff"]), tg, int(ov["toff"]))
+            ln = "A\t%d\t%d\t%.17g\t%d\t%s\t%s" % (ov["toff"], ov["tend"], ov["weight"], ov["align_size"], fnv(qa), fnv(ta))
+            if full:
+                ln += "\t%s\t%s" % (qa.decode(), ta.decode())
+            out.append(ln)
+        c0 = cands[int(tmpl_off[t])]
+        rg = res.ranges[int(T["range_begin"]):int(T["range_end"])]
+        ln = "T\t%d\t%d\t%.17g\t%d\t%d\t%d" % (c0["sid"], c0["ssize"], T["ident_cutoff"], T["num_can"], T["num_ovlps"], rg.shape[0])
+        for a, b in rg:
+            ln += "\t%d\t%d" % (a, b)
+        out.append(ln)
+    return "\n".join(out) + ("\n" if out else "")
