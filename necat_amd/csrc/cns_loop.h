@@ -143,8 +143,8 @@ struct Template {
 };
 
 struct Knobs {
-    int spec_estimate_extra = 3;   // estimate stage: selected = identities still missing + this
-    int spec_cover = 6;            // cover stage: candidates selected per round
+    int spec_estimate_extra = 1;   // estimate stage: selected = identities still missing + this
+    int spec_cover = 12;           // cover stage: candidates selected per round
 };
 
 // ---- select -------------------------------------------------------------------------------------------

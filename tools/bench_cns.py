@@ -52,6 +52,26 @@ def main():
         res.free()
         if best is None or dt < best["wall_s"]:
             best = line
+    if "--cpu" in sys.argv:
+        # the oracle's sequential restatement of the same loop (one thread) on the first templates
+        import tempfile
+        from oracle import oracle_api as ora
+        k2 = int(sys.argv[sys.argv.index("--cpu") + 1])
+        k1 = max(1, k2 // 5)
+        tmp = tempfile.mkdtemp(prefix="cns_cpu_")
+        synth.write_volume_dir(os.path.join(tmp, "vols"), rs, 1 << 40)
+        rec = np.frombuffer(part, dtype="<u4").reshape(-1, 7)
+        ts = {}
+        for k in (k1, k2):
+            util.write_partition(os.path.join(tmp, "c%d" % k), rec[rec[:, 1] < k].tobytes())
+            t = time.time()
+            ora.cns_run(ora.cns_options(), os.path.join(tmp, "vols"), os.path.join(tmp, "c%d" % k), os.path.join(tmp, "log%d" % k))
+            ts[k] = time.time() - t
+        n_al = sum(1 for ln in open(os.path.join(tmp, "log%d" % k2)) if ln[0] == "A") - sum(1 for ln in open(os.path.join(tmp, "log%d" % k1)) if ln[0] == "A")
+        best["cpu_port_templates_per_s_1thread"] = round((k2 - k1) / (ts[k2] - ts[k1]), 2)
+        best["cpu_port_sample"] = "templates %d..%d of the same partition, %d overlaps, %.1f s" % (k1, k2, n_al, ts[k2] - ts[k1])
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
     best["load_partition_s"] = round(t_load, 3)
     best["templates_per_s"] = round(best["templates"] / best["wall_s"], 1)
     best["alignments_per_s"] = round(best["aligned"] / best["wall_s"], 1)
