@@ -17,7 +17,13 @@ from necat_amd import capi, synth  # noqa: E402
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    argv = sys.argv[1:]
+    cpu_n = 0
+    if "--cpu" in argv:
+        i = argv.index("--cpu")
+        cpu_n = int(argv[i + 1])
+        del argv[i:i + 2]
+    args = argv
     glen = int(args[0]) if len(args) > 0 else 4_600_000
     cov = float(args[1]) if len(args) > 1 else 40.0
     import util
@@ -52,11 +58,11 @@ def main():
         res.free()
         if best is None or dt < best["wall_s"]:
             best = line
-    if "--cpu" in sys.argv:
+    if cpu_n:
         # the oracle's sequential restatement of the same loop (one thread) on the first templates
         import tempfile
         from oracle import oracle_api as ora
-        k2 = int(sys.argv[sys.argv.index("--cpu") + 1])
+        k2 = cpu_n
         k1 = max(1, k2 // 5)
         tmp = tempfile.mkdtemp(prefix="cns_cpu_")
         synth.write_volume_dir(os.path.join(tmp, "vols"), rs, 1 << 40)
