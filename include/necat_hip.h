@@ -165,16 +165,18 @@ int  necat_map_pair(necat_ctx* ctx, const necat_index* ix, const necat_volume* r
 
 /* onc_align (gapped_align/oc_aligner.h:45-55) on every candidate WITH the alignment itself - the call the
  * consensus stage makes (cns_extension, consensus/consensus_aux.c:124-215, tail_match_len =
- * ONC_TAIL_MATCH_LEN_LONG = 4).  No containment filter: aln[i] and ops[ops_off[i] .. ops_off[i+1]) belong to
- * cands[i].  One byte per gapped column, in alignment order: 0 match, 1 query base over '-' in
- * target_align, 2 '-' in query_align over a target base, 3 mismatch; necat_gapped_strings() turns them
- * into the reference's two "ACGT-" strings.  ops_off[n] = total columns. */
+ * ONC_TAIL_MATCH_LEN_LONG = 4).  No containment filter: aln[i] and the columns at ops + ops_off[i] belong to
+ * cands[i].  TWO BITS per gapped column, in alignment order, four columns per byte from the low bits up
+ * (column j of an alignment = bits 2 (j & 3) of its byte j >> 2): 0 match, 1 query base over '-' in
+ * target_align, 2 '-' in query_align over a target base, 3 mismatch; aln[i].align_size columns, every alignment
+ * starts on an 8-byte boundary (ops_off[i] = byte offset, ops_off[n] = total bytes); necat_gapped_strings()
+ * turns them into the reference's two "ACGT-" strings. */
 int  necat_onc_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_volume* reads,
                            int read_start_id, int ref_start_id,
                            const necat_candidate* cands, uint64_t n, const necat_map_options* opt,
                            int tail_match_len, necat_alignment** aln, uint8_t** ops, uint64_t** ops_off);
 
-/* Host helper: expand `n` columns into query_align / target_align (each n bytes, no terminator).
+/* Host helper: expand `n` packed columns into query_align / target_align (each n bytes, no terminator).
  * qseq / tseq: byte codes 0..3 of the query STRAND (reverse complement for qdir = 1) and of the subject;
  * qoff / toff: the alignment's start in them (necat_alignment.qoff / .toff).  Returns 0, or NECAT_ERR_ARG
  * if the columns run past qsize / tsize. */
@@ -209,8 +211,8 @@ typedef struct {
     uint64_t cand;            /* index into the cands array of the call */
     int32_t  qoff, qend, toff, tend;   /* as in necat_alignment */
     int32_t  align_size;      /* gapped columns */
-    uint32_t ops_block;       /* the columns are result->ops[ops_block] + ops_off, align_size bytes,    */
-    uint64_t ops_off;         /* coded as in necat_onc_align_batch                                       */
+    uint32_t ops_block;       /* the columns start at result->ops[ops_block] + ops_off (bytes), align_size of them, */
+    uint64_t ops_off;         /* packed 2 bits per column as in necat_onc_align_batch                               */
     double   ident_perc;
     double   weight;          /* calc_cns_weight, consensus_one_read.c:11-16 */
 } necat_cns_overlap;

@@ -253,7 +253,7 @@ class Context:
     def onc_align_batch(self, ref: "Volume", reads: "Volume", read_start_id: int, ref_start_id: int, cands: np.ndarray,
                         opt: MapOptions, tail_match_len: int = 4):
         """onc_align with the alignment itself for every candidate (the consensus stage's call):
-        (alignments[ALIGNMENT_DTYPE], ops[uint8], ops_off[uint64, n + 1])."""
+        (alignments[ALIGNMENT_DTYPE], ops[uint8: 2 bits per column], ops_off[uint64, n + 1: byte offsets])."""
         cands = np.ascontiguousarray(cands, dtype=CANDIDATE_DTYPE)
         n = cands.shape[0]
         a, o, f = C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -339,8 +339,8 @@ class CnsResult:
         return np.frombuffer((C.c_char * (n * dtype.itemsize)).from_address(p), dtype=dtype, count=n)
 
     def ops(self, ov) -> np.ndarray:
-        """the alignment columns of one overlap record"""
-        n = int(ov["align_size"])
+        """the packed alignment columns (2 bits each) of one overlap record"""
+        n = (int(ov["align_size"]) + 3) // 4
         base = self.r.contents.ops[int(ov["ops_block"])]
         return np.frombuffer((C.c_char * n).from_address(base + int(ov["ops_off"])), dtype=np.uint8, count=n) if n else np.zeros(0, np.uint8)
 
@@ -435,12 +435,28 @@ def load_volumes_info(wrk_dir: str):
     return nv, nr, vols
 
 
-def gapped_strings(ops: np.ndarray, qseq: np.ndarray, qoff: int, tseq: np.ndarray, toff: int):
-    """necat_gapped_strings: (query_align, target_align) as bytes ("ACGT-")."""
+def pack_columns(ops: np.ndarray) -> np.ndarray:
+    """one op code (0..3) per column -> the library's packed form: 2 bits per column, 4 per byte, low bits first"""
     ops = np.ascontiguousarray(ops, dtype=np.uint8)
+    n = ops.shape[0]
+    pad = np.zeros(((n + 3) // 4) * 4, dtype=np.uint8)
+    pad[:n] = ops & 3
+    q = pad.reshape(-1, 4)
+    return (q[:, 0] | (q[:, 1] << 2) | (q[:, 2] << 4) | (q[:, 3] << 6)).astype(np.uint8)
+
+
+def unpack_columns(packed: np.ndarray, n: int) -> np.ndarray:
+    p = np.ascontiguousarray(packed, dtype=np.uint8)[:(n + 3) // 4]
+    return np.stack([p & 3, (p >> 2) & 3, (p >> 4) & 3, (p >> 6) & 3], axis=1).reshape(-1)[:n].astype(np.uint8)
+
+
+def gapped_strings(ops: np.ndarray, n: int, qseq: np.ndarray, qoff: int, tseq: np.ndarray, toff: int):
+    """necat_gapped_strings: `n` packed columns (2 bits each) -> (query_align, target_align) as bytes ("ACGT-")."""
+    ops = np.ascontiguousarray(ops, dtype=np.uint8)
+    if ops.shape[0] * 4 < n:
+        raise ValueError("%d columns need %d bytes, got %d" % (n, (n + 3) // 4, ops.shape[0]))
     q = np.ascontiguousarray(qseq, dtype=np.uint8)
     t = np.ascontiguousarray(tseq, dtype=np.uint8)
-    n = ops.shape[0]
     qa = C.create_string_buffer(max(1, n))
     ta = C.create_string_buffer(max(1, n))
     rc = load_library().necat_gapped_strings(ops.ctypes.data, n, q.ctypes.data, q.shape[0], qoff, t.ctypes.data, t.shape[0], toff, qa, ta)

@@ -393,6 +393,18 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__
     }
 }
 
+// maximum over the active lanes of a value below 2048 (bit by bit with ballots: exited lanes do not take part)
+NECAT_D int wave_max_u11(int v)
+{
+    int best = 0;
+    bool in = true;
+    for (int bit = 10; bit >= 0; --bit) {
+        const bool has = in && ((v >> bit) & 1);
+        if (__ballot(has)) { best |= 1 << bit; in = has; }
+    }
+    return best;
+}
+
 struct OpsWriter {
     u8* ops; int cap; int overflow; bool store;
     TailScan ts;
@@ -455,9 +467,29 @@ k_traceback(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ 
     const int stream_at = t.phase == 1 ? t.s_lto : 0;     // where the block's stream starts in the task's column region
     const ExtKept kept = ext_finish_block(t, br.dist, br.endc, done, ow.ts, rd, same);
     if (next.task_ops) {
-        u8* dst = next.task_ops + t.ops_base + (u64)(stream_at + kept.at);
+        // The kept columns join the task's stream, packed 2 bits per column (32 per 64-bit word).  The op pool is
+        // lane-interleaved by op index, and op r of a lane is forward column nops - 1 - r: the wave walks the pool
+        // rows from the highest one down, every lane reading the SAME row (one 64-byte line per step) and packing
+        // its own op while it is inside its kept range; a word goes out once it is full.
+        u64* reg = reinterpret_cast<u64*>(next.task_ops + t.ops_base);
+        const u32 pos = (u32)(stream_at + kept.at);
+        u32 w = pos >> 5; int sh = (int)(pos & 31) * 2;
+        u64 acc = sh ? (reg[w] & ((1ULL << sh) - 1)) : 0;       // the columns of earlier blocks in the same word
         const int nops = ow.ts.n;
-        for (int f = 0; f < kept.cols; ++f) dst[f] = kept.exact ? (u8)0 : ow.ops[(size_t)(nops - 1 - f) * 64];
+        if (kept.exact) {
+            for (int f = 0; f < kept.cols; ++f) { sh += 2; if (sh == 64) { reg[w++] = acc; acc = 0; sh = 0; } }
+        } else {
+            const int mine = kept.cols > 0 ? nops : 0;          // rows [nops - cols, nops) hold forward [0, cols)
+            const int lo = nops - kept.cols;
+            int r = wave_max_u11(mine) - 1;
+            for (; r >= 0; --r) {
+                if (r < mine && r >= lo) {
+                    acc |= (u64)ow.ops[(size_t)r * 64] << sh; sh += 2;
+                    if (sh == 64) { reg[w++] = acc; acc = 0; sh = 0; }
+                }
+            }
+        }
+        if (sh) reg[w] = acc;                                   // the bits above `sh` are zero: the next block ORs into them
     }
     const bool go = ext_plan(t);       // schedule the candidate's next block for the next round (or finish it)
     tasks[it.task] = t;
@@ -501,18 +533,37 @@ k_ext_alignment(const ExtTask* __restrict__ tasks, u32 n, u32 cand_base, int min
 
 // final alignment of task i = its left stream [s_lfrom, s_lto) reversed, then its right stream
 // [s_rfrom, s_rto) (oc_aligner.c:358-366, :404-428); one wave per task, coalesced
+// Columns are 2 bits each, 32 per 64-bit word, column j of an alignment at bits 2 (j & 31) of its word j >> 5.
 __global__ void __launch_bounds__(256)
-k_ext_strings(const ExtTask* __restrict__ tasks, u32 n, const u8* __restrict__ task_ops, const u64* __restrict__ out_off, u8* __restrict__ out)
+k_ext_strings(const ExtTask* __restrict__ tasks, u32 n, const u8* __restrict__ task_ops, const u64* __restrict__ out_off, u64* __restrict__ out)
 {
     const u32 wave = (u32)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (wave >= n) return;
     const ExtTask t = tasks[wave];
-    const u8* reg = task_ops + t.ops_base;
-    u8* dst = out + out_off[wave];
+    const u64* reg = reinterpret_cast<const u64*>(task_ops + t.ops_base);
+    u64* dst = out + out_off[wave];
     const int nl = t.s_lto - t.s_lfrom, nr = t.s_rto - t.s_rfrom;
-    for (int j = lane; j < nl; j += 64) dst[j] = reg[t.s_lto - 1 - j];
-    for (int j = lane; j < nr; j += 64) dst[nl + j] = reg[t.s_lto + t.s_rfrom + j];
+    const int nw = (nl + nr + 31) >> 5;
+    for (int w = lane; w < nw; w += 64) {
+        u64 acc = 0;
+        const int j0 = w * 32;
+        if (j0 >= nl && j0 + 32 <= nl + nr) {
+            // inside the right stream: 32 consecutive columns = 64 consecutive bits of the region
+            const u32 src = (u32)(t.s_lto + t.s_rfrom + (j0 - nl));
+            const u32 sw = src >> 5; const int sh = (int)(src & 31) * 2;
+            acc = reg[sw] >> sh;
+            if (sh) acc |= reg[sw + 1] << (64 - sh);
+        } else {
+            for (int c = 0; c < 32; ++c) {
+                const int j = j0 + c;
+                if (j >= nl + nr) break;
+                const u32 src = j < nl ? (u32)(t.s_lto - 1 - j) : (u32)(t.s_lto + t.s_rfrom + (j - nl));
+                acc |= ((reg[src >> 5] >> ((src & 31) * 2)) & 3ULL) << (2 * c);
+            }
+        }
+        dst[w] = acc;
+    }
 }
 
 // extend_candidates' containment rule (pm_worker.c:44, map_aux.c:4-20), one lane per query read:

@@ -938,7 +938,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
             std::vector<u64> base(k.n + 1, 0);
             for (u32 i = 0; i < k.n; ++i) {
                 const necat_candidate& c = cands[k.base + i];
-                base[i + 1] = base[i] + ((c.qsize + c.ssize + c.qoff + c.soff + 64) & ~15ULL);
+                base[i + 1] = base[i] + ((c.qsize + c.ssize + c.qoff + c.soff + 64) / 32 + 2) * 8;      // bytes: 2 bits per column
             }
             if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_COLS], base[k.n] + (size_t)(k.n + 1) * 8 + 64))) { cleanup(); return rc; }
             X.task_ops = (u8*)ctx->scratch[SC_EXT_COLS].p;
@@ -975,10 +975,11 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
             NECAT_HIP(ctx, hipMemcpyAsync(len.data(), d_len, (size_t)k.n * 4, hipMemcpyDeviceToHost, k.sa));
             NECAT_HIP(ctx, hipMemcpyAsync(ao->aln + k.base, d_aln, (size_t)k.n * sizeof(necat_alignment), hipMemcpyDeviceToHost, k.sa));
             NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
+            // every alignment starts on a 64-bit word: 32 columns per word
             std::vector<u64> off(k.n + 1, 0);
-            for (u32 i = 0; i < k.n; ++i) off[i + 1] = off[i] + len[i];
-            const u64 tot = off[k.n], at = ao->total;
-            for (u32 i = 0; i < k.n; ++i) ao->off[k.base + i] = at + off[i];
+            for (u32 i = 0; i < k.n; ++i) off[i + 1] = off[i] + (len[i] + 31) / 32;
+            const u64 tot = off[k.n] * 8, at = ao->total;
+            for (u32 i = 0; i < k.n; ++i) ao->off[k.base + i] = at + off[i] * 8;
             ao->off[k.base + k.n] = at + tot;
             if (tot) {
                 if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_COLS_OUT], tot + (size_t)(k.n + 1) * 8 + 64))) { cleanup(); return rc; }
@@ -986,7 +987,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
                 u64* d_off = (u64*)(d_cols + ((tot + 63) & ~63ULL));
                 NECAT_HIP(ctx, hipMemcpyAsync(d_off, off.data(), (size_t)k.n * 8, hipMemcpyHostToDevice, k.sa));
                 hipLaunchKernelGGL(k_ext_strings, dim3(grid_for((u64)k.n * 64, 256)), dim3(256), 0, k.sa, (const ExtTask*)k.tasks, k.n,
-                                   (const u8*)X.task_ops, (const u64*)d_off, d_cols);
+                                   (const u8*)X.task_ops, (const u64*)d_off, (u64*)d_cols);
                 NECAT_CHECK_LAUNCH(ctx, "k_ext_strings");
                 u8* part = (u8*)result_alloc(tot);
                 if (!part) { cleanup(); return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
@@ -1099,8 +1100,8 @@ int necat_gapped_strings(const uint8_t* ops, uint64_t n, const uint8_t* qseq, ui
     static const char dec[5] = {'A', 'C', 'G', 'T', '-'};      // DecodeDNA / GAP_CHAR (common/ontcns_defs.h:36-39)
     uint64_t q = qoff, t = toff;
     for (uint64_t i = 0; i < n; ++i) {
-        const int op = ops[i];
-        if (op > 3 || (op != 2 && q >= qsize) || (op != 1 && t >= tsize)) return NECAT_ERR_ARG;
+        const int op = (ops[i >> 2] >> ((i & 3) * 2)) & 3;
+        if ((op != 2 && q >= qsize) || (op != 1 && t >= tsize)) return NECAT_ERR_ARG;
         query_align[i] = op == 2 ? '-' : dec[qseq[q] & 3];
         target_align[i] = op == 1 ? '-' : dec[tseq[t] & 3];
         q += op != 2; t += op != 1;

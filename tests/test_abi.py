@@ -97,10 +97,12 @@ def test_gapped_strings_host_helper(built):
         assert ok and len(qa) == len(ta) > 300
         qa_b, ta_b = np.frombuffer(qa, dtype=np.uint8), np.frombuffer(ta, dtype=np.uint8)
         ops = np.where(qa_b == 45, 2, np.where(ta_b == 45, 1, np.where(qa_b == ta_b, 0, 3))).astype(np.uint8)
-        assert capi.gapped_strings(ops, q, qoff, t, toff) == (qa, ta)
+        packed = capi.pack_columns(ops)
+        assert np.array_equal(capi.unpack_columns(packed, ops.shape[0]), ops)
+        assert capi.gapped_strings(packed, ops.shape[0], q, qoff, t, toff) == (qa, ta)
         assert int((ops != 2).sum()) == qend - qoff and int((ops != 1).sum()) == tend - toff
         with pytest.raises(capi.NecatError):
-            capi.gapped_strings(ops, q[:qend - 1], qoff, t, toff)
+            capi.gapped_strings(packed, ops.shape[0], q[:qend - 1], qoff, t, toff)
         n += 1
     al.close()
-    assert n == 12 and capi.gapped_strings(np.zeros(0, dtype=np.uint8), q, 0, t, 0) == (b"", b"")
+    assert n == 12 and capi.gapped_strings(np.zeros(0, dtype=np.uint8), 0, q, 0, t, 0) == (b"", b"")

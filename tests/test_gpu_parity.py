@@ -293,7 +293,7 @@ def test_onc_align_with_strings_matches_oracle(ctx, small, tail):
         assert (bool(a["ok"]), int(a["qoff"]), int(a["qend"]), int(a["toff"]), int(a["tend"]), int(a["align_size"])) == \
                (ok, qoff, qend, toff, tend, len(qa)), i
         assert float(a["ident_perc"]) == ident, i
-        mine = capi.gapped_strings(ops[int(off[i]):int(off[i + 1])], q, qoff, t, toff)
+        mine = capi.gapped_strings(ops[int(off[i]):int(off[i + 1])], int(a["align_size"]), q, qoff, t, toff)
         assert mine == (qa, ta), i
         n_ok += ok
     al.close()
@@ -338,7 +338,7 @@ def test_onc_align_arbitrary_anchors(ctx):
             a = aln[i]
             assert (bool(a["ok"]), int(a["qoff"]), int(a["qend"]), int(a["toff"]), int(a["tend"]), int(a["align_size"]),
                     float(a["ident_perc"])) == (ok, a0, a1, b0, b1, len(qa), ident), (i, tail)
-            assert capi.gapped_strings(ops[int(off[i]):int(off[i + 1])], q, a0, t, b0) == (qa, ta), (i, tail)
+            assert capi.gapped_strings(ops[int(off[i]):int(off[i + 1])], int(a["align_size"]), q, a0, t, b0) == (qa, ta), (i, tail)
             n_ok += ok; n_empty += len(qa) == 0
     al.close(); vol.free()
     assert n_ok > 200 and n_empty > 10

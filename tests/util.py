@@ -101,7 +101,7 @@ def cns_log_text(res, cands, tmpl_off, reads_codes, reads_off, fnv, full=False) 
             if c["qdir"]:
                 q = (3 - q[::-1]).astype(np.uint8)
             tg = reads_codes[reads_off[c["sid"]]:reads_off[c["sid"] + 1]]
-            qa, ta = capi.gapped_strings(res.ops(ov), q, int(ov["qoff"]), tg, int(ov["toff"]))
+            qa, ta = capi.gapped_strings(res.ops(ov), int(ov["align_size"]), q, int(ov["qoff"]), tg, int(ov["toff"]))
             ln = "A\t%d\t%d\t%.17g\t%d\t%s\t%s" % (ov["toff"], ov["tend"], ov["weight"], ov["align_size"], fnv(qa), fnv(ta))
             if full:
                 ln += "\t%s\t%s" % (qa.decode(), ta.decode())

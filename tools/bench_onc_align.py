@@ -18,5 +18,5 @@ for it in range(3):
     t0 = time.perf_counter(); m4 = ctx.extend(vol, vol, 0, 0, cands, opt, 1); t1 = time.perf_counter()
     aln, ops, off = ctx.onc_align_batch(vol, vol, 0, 0, cands, opt, 4); t2 = time.perf_counter()
     gbp = float((aln["qend"] - aln["qoff"])[aln["ok"] == 1].sum()) / 1e9
-    print("extend %.1f ms (%d M4) | onc_align_batch tail 4: %.1f ms, %d ok, %.2f Gbp aligned -> %.2f Gbp/s, %.2f G columns returned" % (
-        1e3 * (t1 - t0), m4.shape[0], 1e3 * (t2 - t1), int(aln["ok"].sum()), gbp, gbp / (t2 - t1), ops.shape[0] / 1e9))
+    print("extend %.1f ms (%d M4) | onc_align_batch tail 4: %.1f ms, %d ok, %.2f Gbp aligned -> %.2f Gbp/s, %.2f G columns returned in %.2f GB" % (
+        1e3 * (t1 - t0), m4.shape[0], 1e3 * (t2 - t1), int(aln["ok"].sum()), gbp, gbp / (t2 - t1), float(aln["align_size"].sum()) / 1e9, ops.shape[0] / 1e9))

@@ -60,7 +60,7 @@ for case in range(n_cases):
                         r = al.align(q, int(cnd["qoff"]), t, int(cnd["soff"]), opt.align_size_cutoff, 4)
                         a = aln[i]
                         mine = (bool(a["ok"]), int(a["qoff"]), int(a["qend"]), int(a["toff"]), int(a["tend"]), float(a["ident_perc"]))
-                        strs = capi.gapped_strings(ops[int(off[i]):int(off[i + 1])], q, r[1], t, r[3]) if mine[:5] == r[:5] else None
+                        strs = capi.gapped_strings(ops[int(off[i]):int(off[i + 1])], int(a["align_size"]), q, r[1], t, r[3]) if mine[:5] == r[:5] else None
                         if mine != r[:6] or strs != (r[6], r[7]):
                             ok = False
                     al.close()
