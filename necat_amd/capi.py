@@ -465,6 +465,19 @@ def gapped_strings(ops: np.ndarray, n: int, qseq: np.ndarray, qoff: int, tseq: n
     return qa.raw[:n], ta.raw[:n]
 
 
+def pcan_single_partition(packed: bytes) -> bytes:
+    """oc2pcan (partition_candidates/pcan.c:39-103) when all reads fall in ONE partition: every record is kept
+    and followed by its role-swapped twin (change_pcan_roles, common/gapped_candidate.c:54-69: the subject
+    becomes the query, strands swap with them).  Record order inside a partition file is free."""
+    a = np.frombuffer(packed, dtype="<u4").reshape(-1, 7)
+    b = np.empty_like(a)
+    w0 = a[:, 0]
+    b[:, 0] = (w0 & np.uint32((1 << 30) - 1)) | ((w0 >> 31) << 30) | (((w0 >> 30) & 1) << 31)
+    b[:, 1:4] = a[:, 4:7]
+    b[:, 4:7] = a[:, 1:4]
+    return np.concatenate([a, b]).tobytes()
+
+
 def pack_candidates(c: np.ndarray) -> np.ndarray:
     """pack_candidate (common/gapped_candidate.c:13-30): 7 x u32 records."""
     out = np.zeros((c.shape[0], 7), dtype=np.uint32)

@@ -121,6 +121,7 @@ struct Template {
     std::vector<necat_cns_overlap> overlaps;
     std::vector<int32_t> ranges;
     uint64_t n_used = 0;
+    uint64_t covered_bp = 0;     // sum of the accepted overlaps' target ranges
 
     bool is_used(int32_t qid) const { return std::find(used.begin(), used.end(), qid) != used.end(); }
     // consensus_one_read.c:145-151
@@ -139,12 +140,15 @@ struct Template {
         overlaps.push_back(o);
         ++num_ovlps;
         cover(al.a.toff, al.a.tend);
+        covered_bp += (uint64_t)(al.a.tend - al.a.toff);
     }
 };
 
 struct Knobs {
     int spec_estimate_extra = 1;   // estimate stage: selected = identities still missing + this
-    int spec_cover = 12;           // cover stage: candidates selected per round
+    int spec_cover = 12;           // cover stage: candidates selected per round; 0 = from the coverage still missing:
+    double adapt_mult = 1.25;      //   max(adapt_min, 2 + adapt_mult * missing coverage / mean accepted overlap length)
+    int adapt_min = 2;
 };
 
 // ---- select -------------------------------------------------------------------------------------------
@@ -183,8 +187,16 @@ inline void select(Template& t, const necat_cns_options& opt, const Knobs& kn)
             if (t.cursor >= t.n || t.region_full(0, t.tsize, opt.max_cov)) { t.stage = Template::DONE; break; }
             t.group_end = std::min<uint32_t>(t.cursor + kGroup, t.n);
         }
+        int want = kn.spec_cover;
+        if (want <= 0) {
+            // as many as the missing coverage asks for, at the mean length of the overlaps accepted so far (+ 25 %)
+            uint64_t missing = 0;
+            for (int x = 0; x < t.tsize; ++x) missing += t.cov[x] < opt.max_cov ? (uint64_t)(opt.max_cov - t.cov[x]) : 0;
+            const double mean = t.num_ovlps ? (double)t.covered_bp / t.num_ovlps : 0.6 * t.tsize;
+            want = (int)std::min<double>(kGroup, std::max<double>(kn.adapt_min, 2.0 + kn.adapt_mult * (double)missing / std::max(1.0, mean)));
+        }
         uint32_t i = t.cursor;
-        for (; i < t.group_end && (int)t.sel.size() < kn.spec_cover; ++i) {
+        for (; i < t.group_end && (int)t.sel.size() < want; ++i) {
             const necat_candidate& c = t.c[i];
             if (t.is_used(c.qid)) continue;
             if (t.region_full((int)c.sbeg, (int)c.send, opt.max_cov)) continue;

@@ -74,7 +74,7 @@ void read_knobs()
     g_sort_b = (int)num("NECAT_SORT_B", 1);
     g_dbg = (int)num("NECAT_DBG", 0);
     g_cns_spec_extra = (int)num("NECAT_CNS_SPEC_EXTRA", 1);
-    g_cns_spec_cover = (int)std::max<unsigned long long>(1, num("NECAT_CNS_SPEC", 12));
+    g_cns_spec_cover = (int)num("NECAT_CNS_SPEC", 12);     // 0 = adaptive
 }
 
 double wall_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }

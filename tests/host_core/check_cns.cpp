@@ -26,6 +26,7 @@ int main(int argc, char** argv)
         opt.error = atof(argv[6]); opt.mapping_ratio = atof(argv[7]); opt.use_fixed_ident_cutoff = atoi(argv[8]);
     }
     if (argc >= 11) { kn.spec_estimate_extra = atoi(argv[9]); kn.spec_cover = atoi(argv[10]); }
+    if (argc >= 13) { kn.adapt_mult = atof(argv[11]); kn.adapt_min = atoi(argv[12]); }
     ora_cns_options oo = {opt.min_align_size, opt.min_cov, opt.max_cov, opt.error, opt.mapping_ratio, opt.use_fixed_ident_cutoff};
     ora_volume reads;
     if (ora_volumes_merge(argv[1], &reads)) { fprintf(stderr, "cannot load %s\n", argv[1]); return 2; }

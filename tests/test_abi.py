@@ -106,3 +106,24 @@ def test_gapped_strings_host_helper(built):
         n += 1
     al.close()
     assert n == 12 and capi.gapped_strings(np.zeros(0, dtype=np.uint8), 0, q, 0, t, 0) == (b"", b"")
+
+
+def test_cns_entry_points_without_gpu(built):
+    """the consensus-loop entry points: defaults as consensus/cns_options.c:10-22, argument errors reported, and no
+    way around the device (a context cannot be created here, so nothing can be computed)"""
+    import ctypes as C
+    from necat_amd import capi
+    lib = capi.load_library()
+    o = capi.cns_options()
+    assert (o.min_align_size, o.min_cov, o.max_cov, o.error, o.mapping_ratio, o.use_fixed_ident_cutoff) == (400, 4, 12, 0.5, 0.8, 0)
+    r = C.POINTER(capi._CnsResult)()
+    assert lib.necat_cns_extension_batch(None, None, None, None, None, 0, C.byref(o), C.byref(r)) == -1      # NECAT_ERR_ARG
+    assert not r
+    lib.necat_cns_result_free(r)                                                                             # NULL is fine
+    # the role swap of oc2pcan: twice the records, the twin has query and subject exchanged
+    import numpy as np
+    rec = np.array([[(1 << 31) | (1 << 29) | 77, 5, 10, 20, 9, 30, 40]], dtype=np.uint32)
+    both = np.frombuffer(capi.pcan_single_partition(rec.tobytes()), dtype=np.uint32).reshape(-1, 7)
+    assert both.shape == (2, 7) and (both[0] == rec[0]).all()
+    assert both[1].tolist() == [(1 << 30) | (1 << 29) | 77, 9, 30, 40, 5, 10, 20]
+

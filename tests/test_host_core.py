@@ -56,6 +56,7 @@ def check_cns(tmp_path_factory, built):
     "400 2 6 0.5 0.8 0 0 1".split(),                     # no speculation: one candidate per template and pass
     "2000 4 12 0.5 0.5 0 40 50".split(),                 # speculate whole groups
     "400 4 30 0.5 0.8 0 1 2".split(),                    # deeper coverage than the data has
+    "400 4 12 0.5 0.8 0 1 0".split(),                    # speculation width from the missing coverage
 ])
 def test_cns_loop_matches_sequential(check_cns, tmp_path, args):
     """the batched loop (speculative selection + in-order replay) takes exactly the decisions of the sequential
