@@ -155,7 +155,7 @@ struct ResultPool {
     std::vector<std::pair<void*, size_t>> parked;         // never released at exit: the HIP runtime may be gone by then
 };
 ResultPool g_results;
-constexpr size_t kPinnedMin = 256 << 10, kPoolBlocks = 6, kPoolBytes = (size_t)6 << 30;   // parked: <= 6 blocks, <= 6 GiB
+constexpr size_t kPinnedMin = 256 << 10, kPoolBlocks = 16, kPoolBytes = (size_t)8 << 30;   // parked: <= 16 blocks, <= 8 GiB
 
 void* result_alloc(size_t bytes)
 {
@@ -186,10 +186,18 @@ void necat_free(void* p)
         if (it != g_results.live.end()) {
             const size_t sz = it->second;
             g_results.live.erase(it);
-            size_t held = sz;
+            // park it; when the pool is full the smallest blocks go first (pinning costs ~0.15 s per GB, so the big
+            // ones are the ones worth keeping)
+            g_results.parked.emplace_back(p, sz);
+            size_t held = 0;
             for (auto& b : g_results.parked) held += b.second;
-            if (g_results.parked.size() < kPoolBlocks && held <= kPoolBytes) g_results.parked.emplace_back(p, sz);
-            else (void)hipHostFree(p);
+            while (g_results.parked.size() > kPoolBlocks || (held > kPoolBytes && !g_results.parked.empty())) {
+                size_t k = 0;
+                for (size_t i = 1; i < g_results.parked.size(); ++i) if (g_results.parked[i].second < g_results.parked[k].second) k = i;
+                held -= g_results.parked[k].second;
+                (void)hipHostFree(g_results.parked[k].first);
+                g_results.parked.erase(g_results.parked.begin() + k);
+            }
             return;
         }
     }
