@@ -24,6 +24,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <atomic>
@@ -307,11 +308,14 @@ inline void parallel_for(size_t n, F&& fn)
     for (auto& x : th) x.join();
 }
 
-struct Stats { uint64_t n_aligned = 0, n_used = 0; uint32_t n_rounds = 0; };
+struct Stats { uint64_t n_aligned = 0, n_used = 0; uint32_t n_rounds = 0; double init_ms = 0, select_ms = 0, gather_ms = 0, replay_ms = 0; };
+
+inline double now_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 
 // Runs the loop of every template to its end.  Returns 0 or the callback's error.
 inline int run(std::vector<Template>& ts, const necat_cns_options& opt, const Knobs& kn, const AlignFn& align, Stats* st)
 {
+    double t0 = now_ms();
     parallel_for(ts.size(), [&](size_t i) {
         Template& t = ts[i];
         t.examined = t.n > 0 && (uint32_t)opt.min_cov <= t.n_all;      // consensus_one_read.c:223
@@ -327,8 +331,11 @@ inline int run(std::vector<Template>& ts, const necat_cns_options& opt, const Kn
     });
     std::vector<necat_candidate> batch;
     std::vector<Aligned> res;
+    st->init_ms += now_ms() - t0;
     for (;;) {
+        t0 = now_ms();
         parallel_for(ts.size(), [&](size_t i) { if (ts[i].stage != Template::DONE) select(ts[i], opt, kn); else ts[i].sel.clear(); });
+        st->select_ms += now_ms() - t0; t0 = now_ms();
         uint64_t total = 0;
         for (auto& t : ts) { t.sel_at = total; total += t.sel.size(); }
         if (total == 0) break;
@@ -337,9 +344,12 @@ inline int run(std::vector<Template>& ts, const necat_cns_options& opt, const Kn
             Template& t = ts[i];
             for (size_t k = 0; k < t.sel.size(); ++k) batch[t.sel_at + k] = t.c[t.sel[k]];
         });
+        st->gather_ms += now_ms() - t0;
         const int rc = align(batch.data(), total, res.data());
         if (rc) return rc;
+        t0 = now_ms();
         parallel_for(ts.size(), [&](size_t i) { if (!ts[i].sel.empty()) replay(ts[i], res.data() + ts[i].sel_at, opt); });
+        st->replay_ms += now_ms() - t0;
         st->n_aligned += total; ++st->n_rounds;
     }
     for (auto& t : ts) { st->n_used += t.n_used; std::vector<uint16_t>().swap(t.cov); }

@@ -1208,7 +1208,10 @@ int necat_cns_extension_batch(necat_ctx* ctx, const necat_volume* reads, const n
     };
     cns::Knobs kn; kn.spec_estimate_extra = g_cns_spec_extra; kn.spec_cover = g_cns_spec_cover;
     cns::Stats st;
+    const double w_run = wall_ms();
     const int rc = cns::run(ts, *opt, kn, fn, &st);
+    if (g_trace & 2) fprintf(stderr, "[necat] cns host: setup %.2f ms, init %.2f, select %.2f, gather %.2f, replay %.2f ms\n", w_run - w0, st.init_ms, st.select_ms,
+                             st.gather_ms, st.replay_ms);
     auto drop = [&]() { for (u8* b : blocks) necat_free(b); };
     if (rc) { drop(); return rc; }
     necat_cns_result* r = (necat_cns_result*)calloc(1, sizeof(necat_cns_result));
@@ -1241,6 +1244,7 @@ int necat_cns_extension_batch(necat_ctx* ctx, const necat_volume* reads, const n
     for (size_t b = 0; b < blocks.size(); ++b) r->ops[b] = blocks[b];
     r->n_aligned = st.n_aligned; r->n_used = st.n_used; r->n_rounds = st.n_rounds;
     r->device_ms = device_ms; r->host_ms = wall_ms() - w0 - align_wall;
+    if (g_trace & 2) fprintf(stderr, "[necat] cns total %.2f ms: passes %.2f (device events %.2f), host %.2f\n", wall_ms() - w0, align_wall, device_ms, r->host_ms);
     ctx->tm.extend_ms = device_ms;
     *out = r;
     return NECAT_OK;

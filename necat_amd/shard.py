@@ -27,6 +27,35 @@ def volume_pairs(vids: Sequence[int], num_volumes: int) -> List[Tuple[int, int]]
     return [(v, j) for v in vids for j in range(v, num_volumes)]
 
 
+def consensus_partitions(num_partitions: int, rank: int, world: int) -> List[int]:
+    """Candidate partitions of the consensus stage a rank owns: the reference's own multi-node rule
+    (`oc2cns ... -mn node_id num_nodes`, consensus/main.c:68-72: i = node_id; i < n; i += num_nodes).  Partitions are
+    independent (every template lives in exactly one), so necat_cns_extension_batch needs no collective either."""
+    return list(range(rank, num_partitions, world))
+
+
+def split_templates(tmpl_off: Sequence[int], world: int) -> List[Tuple[int, int]]:
+    """One partition on several GPUs: contiguous template ranges [lo, hi) with balanced CANDIDATE counts
+    (tmpl_off = the prefix offsets necat_cns_load_partition returns).  Templates are independent units of the loop."""
+    n = len(tmpl_off) - 1
+    total = tmpl_off[n] - tmpl_off[0]
+    cuts = [0]
+    for r in range(1, world):
+        want = tmpl_off[0] + total * r // world
+        lo, hi = cuts[-1], n
+        while lo < hi:                              # first template whose offset reaches the target
+            mid = (lo + hi) // 2
+            if tmpl_off[mid] < want:
+                lo = mid + 1
+            else:
+                hi = mid
+        if lo > cuts[-1] and want - tmpl_off[lo - 1] < tmpl_off[lo] - want:
+            lo -= 1                                 # the boundary nearest to the target
+        cuts.append(lo)
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
 def reduce_step_stats(dist, elapsed: float, overlaps: float, gbp: float, device=None):
     """(max elapsed, total overlaps, total Gbp) over all ranks; identity when dist is None."""
     if dist is None:

@@ -20,6 +20,20 @@ def test_assignment_covers_every_volume_once_and_balances():
     assert pairs == [(0, 0), (0, 1), (0, 2), (2, 2)]
 
 
+def test_consensus_units_partition_exactly():
+    for n in (0, 1, 7, 100):
+        for w in (1, 2, 8):
+            got = sorted(p for r in range(w) for p in shard.consensus_partitions(n, r, w))
+            assert got == list(range(n))
+    off = [0, 5, 5, 30, 31, 60, 100, 100, 130]
+    for w in (1, 2, 3, 8, 20):
+        rs = shard.split_templates(off, w)
+        assert rs[0][0] == 0 and rs[-1][1] == len(off) - 1
+        assert all(a[1] == b[0] for a, b in zip(rs, rs[1:])) and all(lo <= hi for lo, hi in rs)
+    lo, hi = shard.split_templates(off, 2)[0]
+    assert abs((off[hi] - off[lo]) - 65) <= 30          # about half of the 130 candidates
+
+
 def _worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
