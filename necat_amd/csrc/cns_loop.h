@@ -7,7 +7,7 @@
 // part and live on the device, so the loop is split in two:
 //
 //   select  per template, the next candidates the loop WOULD align if none of the pending alignments changed
-//           its state (a prefix of the walk with distinct reads, at most `spec` of them) - all templates'
+//           its state (a prefix of the walk, at most `spec` candidates) - all templates'
 //           selections form one device batch;
 //   replay  with the results in hand the walk is repeated in order with the reference's rules; a selected
 //           candidate the sequential loop would have skipped after all (its region got covered by an overlap
@@ -123,6 +123,8 @@ struct Template {
     std::vector<int32_t> ranges;
     uint64_t n_used = 0;
     uint64_t covered_bp = 0;     // sum of the accepted overlaps' target ranges
+    uint32_t est_aligned = 0;    // alignments consumed by the estimate stage
+    uint32_t cover_passes = 0;   // device passes this template took part in during the cover stage
 
     bool is_used(int32_t qid) const { return std::find(used.begin(), used.end(), qid) != used.end(); }
     // consensus_one_read.c:145-151
@@ -146,13 +148,17 @@ struct Template {
 };
 
 struct Knobs {
-    int spec_estimate_extra = 1;   // estimate stage: selected = identities still missing + this
+    int spec_estimate_extra = 1;   // estimate stage: selected = identities still missing (x alignments per identity so far) + this;
+                                   // < 0: strict mode for tests - only the identities still missing, one read once per
+                                   //      pass, no widening: with spec_cover = 1 no alignment is ever computed in vain
     int spec_cover = 12;           // cover stage: candidates selected per round; 0 = from the coverage still missing:
     double adapt_mult = 1.25;      //   max(adapt_min, 2 + adapt_mult * missing coverage / mean accepted overlap length)
     int adapt_min = 2;
 };
 
 // ---- select -------------------------------------------------------------------------------------------
+
+inline void finish_estimate(Template& t, uint32_t next, const necat_cns_options& opt);
 
 // true if `qid` is the read of a candidate already selected this round
 inline bool in_selection(const Template& t, int32_t qid)
@@ -161,25 +167,26 @@ inline bool in_selection(const Template& t, int32_t qid)
     return false;
 }
 
-inline void finish_estimate(Template& t, uint32_t next, const necat_cns_options& opt);
-
 inline void select(Template& t, const necat_cns_options& opt, const Knobs& kn)
 {
+    const bool strict = kn.spec_estimate_extra < 0;      // test mode: never select what the loop might not reach
     t.sel.clear();
     while (t.stage != Template::DONE) {
         if (t.stage == Template::ESTIMATE) {
             const uint32_t limit = std::min<uint32_t>(t.n, kEstimateCandidates);
-            const uint32_t want = (uint32_t)(kIdentSamples - t.n_ident + kn.spec_estimate_extra);
+            // identities still missing, scaled by how many alignments it took per identity so far
+            const uint32_t need = (uint32_t)(kIdentSamples - t.n_ident);
+            const uint32_t want = kn.spec_estimate_extra < 0 ? need :      // exactly what the loop aligns whatever the results
+                std::min<uint32_t>(kEstimateCandidates,
+                (t.n_ident > 0 ? (need * t.est_aligned + t.n_ident - 1) / t.n_ident : need * (t.est_aligned ? 2u : 1u)) + (uint32_t)kn.spec_estimate_extra);
             uint32_t i = t.cursor;
             for (; i < limit && t.sel.size() < want; ++i) {
-                const int32_t qid = t.c[i].qid;
-                if (t.is_used(qid)) continue;
-                if (in_selection(t, qid)) break;          // depends on whether the earlier one aligns
-                t.sel.push_back(i);
-            }
+                if (t.is_used(t.c[i].qid)) continue;
+                if (strict && in_selection(t, t.c[i].qid)) break;
+                t.sel.push_back(i);                       // a second candidate of a selected read is selected too: whether
+            }                                             // the loop reaches it depends on the first one's alignment
             t.stop = i;
             if (!t.sel.empty()) return;
-            if (i < limit) { /* cannot happen: a duplicate implies a non-empty selection */ return; }
             finish_estimate(t, limit, opt);                // ran out of candidates: error_estimate.c:178 with i = limit
             continue;
         }
@@ -188,8 +195,10 @@ inline void select(Template& t, const necat_cns_options& opt, const Knobs& kn)
             if (t.cursor >= t.n || t.region_full(0, t.tsize, opt.max_cov)) { t.stage = Template::DONE; break; }
             t.group_end = std::min<uint32_t>(t.cursor + kGroup, t.n);
         }
-        int want = kn.spec_cover;
-        if (want <= 0) {
+        // the few templates that need a third, fourth ... pass select twice as many each time: a pass of a handful of
+        // alignments costs as much as one of ten thousand
+        int want = strict ? kn.spec_cover : std::min(kGroup, kn.spec_cover << std::min<uint32_t>(t.cover_passes, 3));
+        if (kn.spec_cover <= 0) {
             // as many as the missing coverage asks for, at the mean length of the overlaps accepted so far (+ 25 %)
             uint64_t missing = 0;
             for (int x = 0; x < t.tsize; ++x) missing += t.cov[x] < opt.max_cov ? (uint64_t)(opt.max_cov - t.cov[x]) : 0;
@@ -201,11 +210,11 @@ inline void select(Template& t, const necat_cns_options& opt, const Knobs& kn)
             const necat_candidate& c = t.c[i];
             if (t.is_used(c.qid)) continue;
             if (t.region_full((int)c.sbeg, (int)c.send, opt.max_cov)) continue;
-            if (in_selection(t, c.qid)) break;
+            if (strict && in_selection(t, c.qid)) break;
             t.sel.push_back(i);
         }
         t.stop = i;
-        if (!t.sel.empty()) return;
+        if (!t.sel.empty()) { ++t.cover_passes; return; }
         t.cursor = i;                                      // nothing to align up to here
         if (t.cursor == t.group_end) t.group_end = 0;
     }
@@ -256,9 +265,11 @@ inline void replay(Template& t, const Aligned* res, const necat_cns_options& opt
     if (t.stage == Template::ESTIMATE) {
         for (uint32_t i = t.cursor; i < t.stop; ++i) {
             const necat_candidate& c = t.c[i];
-            if (t.is_used(c.qid)) continue;
-            const Aligned& al = res[k++];                  // candidates that pass the test were all selected
-            ++t.n_used;
+            const bool selected = k < t.sel.size() && t.sel[k] == i;
+            const Aligned* alp = selected ? &res[k++] : nullptr;
+            if (t.is_used(c.qid)) continue;               // at selection time already, or by an earlier candidate of this pass
+            const Aligned& al = *alp;                      // candidates that pass the test were all selected
+            ++t.n_used; ++t.est_aligned;
             if (!al.a.ok) continue;
             t.pool.push_back({i, al, (int)c.qsize});
             t.used.push_back(c.qid);
@@ -273,10 +284,10 @@ inline void replay(Template& t, const Aligned* res, const necat_cns_options& opt
     }
     for (uint32_t i = t.cursor; i < t.stop; ++i) {
         const necat_candidate& c = t.c[i];
-        if (t.is_used(c.qid)) continue;
         const bool selected = k < t.sel.size() && t.sel[k] == i;
         if (!selected) continue;                           // skipped at selection time: still skipped
         const Aligned& al = res[k++];
+        if (t.is_used(c.qid)) continue;                    // a candidate of the same read was accepted earlier in this pass
         if (t.region_full((int)c.sbeg, (int)c.send, opt.max_cov)) continue;   // covered in the meantime: not aligned by the loop
         ++t.n_used;
         ++t.num_can;
@@ -298,7 +309,7 @@ inline void parallel_for(size_t n, F&& fn)
 {
     unsigned nt = std::thread::hardware_concurrency();
     if (nt == 0) nt = 1;
-    nt = (unsigned)std::min<size_t>(std::min<unsigned>(nt, 32), (n + 63) / 64);
+    nt = (unsigned)std::min<size_t>(std::min<unsigned>(nt, 64), (n + 63) / 64);
     if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
     std::atomic<size_t> next(0);
     std::vector<std::thread> th;

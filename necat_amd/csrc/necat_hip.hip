@@ -73,7 +73,7 @@ void read_knobs()
     g_coop_filter = (int)num("NECAT_COOP_FILTER", 1);
     g_sort_b = (int)num("NECAT_SORT_B", 1);
     g_dbg = (int)num("NECAT_DBG", 0);
-    g_cns_spec_extra = (int)num("NECAT_CNS_SPEC_EXTRA", 1);
+    g_cns_spec_extra = getenv("NECAT_CNS_SPEC_EXTRA") ? atoi(getenv("NECAT_CNS_SPEC_EXTRA")) : 1;
     g_cns_spec_cover = (int)num("NECAT_CNS_SPEC", 12);     // 0 = adaptive
 }
 

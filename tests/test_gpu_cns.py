@@ -44,7 +44,7 @@ def test_cns_loop_golden(ctx, tmp_path, case):
 
 @pytest.mark.parametrize("okw,knobs", [
     (dict(), {}),
-    (dict(max_cov=8, min_cov=2), {"NECAT_CNS_SPEC": "1", "NECAT_CNS_SPEC_EXTRA": "0"}),     # no speculation at all
+    (dict(max_cov=8, min_cov=2), {"NECAT_CNS_SPEC": "1", "NECAT_CNS_SPEC_EXTRA": "-1"}),     # no speculation at all
     (dict(use_fixed_ident_cutoff=1, error=0.3), {"NECAT_CNS_SPEC": "40", "NECAT_CNS_SPEC_EXTRA": "35"}),
     (dict(), {"NECAT_BATCH": "1024"}),                                                        # passes of several batches
 ])

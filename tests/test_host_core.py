@@ -53,7 +53,7 @@ def check_cns(tmp_path_factory, built):
 @pytest.mark.parametrize("args", [
     [],                                                  # defaults
     "400 4 12 0.5 0.8 1 3 6".split(),                    # fixed identity cutoff
-    "400 2 6 0.5 0.8 0 0 1".split(),                     # no speculation: one candidate per template and pass
+    "400 2 6 0.5 0.8 0 -1 1".split(),                    # no speculation: nothing is aligned in vain
     "2000 4 12 0.5 0.5 0 40 50".split(),                 # speculate whole groups
     "400 4 30 0.5 0.8 0 1 2".split(),                    # deeper coverage than the data has
     "400 4 12 0.5 0.8 0 1 0".split(),                    # speculation width from the missing coverage
@@ -69,4 +69,7 @@ def test_cns_loop_matches_sequential(check_cns, tmp_path, args):
     assert r.returncode == 0, r.stdout
     assert "cns_mismatch=0 templates=98 " in r.stdout
     assert " overlaps=0 " not in r.stdout
+    if args[-2:] == ["-1", "1"]:
+        f = dict(kv.split("=") for kv in r.stdout.split())
+        assert f["aligned"] == f["used"]
 
