@@ -23,6 +23,7 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #include <time.h>
 
@@ -307,9 +308,10 @@ inline void replay(Template& t, const Aligned* res, const necat_cns_options& opt
 template <class F>
 inline void parallel_for(size_t n, F&& fn)
 {
+    static const unsigned cap = []() { const char* e = getenv("NECAT_CNS_THREADS"); const int v = e ? atoi(e) : 0; return v > 0 ? (unsigned)v : 32u; }();
     unsigned nt = std::thread::hardware_concurrency();
     if (nt == 0) nt = 1;
-    nt = (unsigned)std::min<size_t>(std::min<unsigned>(nt, 64), (n + 63) / 64);
+    nt = (unsigned)std::min<size_t>(std::min<unsigned>(nt, cap), (n + 63) / 64);
     if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
     std::atomic<size_t> next(0);
     std::vector<std::thread> th;
