@@ -97,6 +97,28 @@ struct Aligned {
 // Aligns `n` candidates; fills out[0..n).  Returns 0 or a NECAT_ERR code.
 using AlignFn = std::function<int(const necat_candidate* cands, uint64_t n, Aligned* out)>;
 
+// The two loops over a template's coverage array, compiled for AVX2 as well (picked at load time): they are most
+// of the replay's time.  (Host code; the attribute is dropped in hipcc's device pass over this header.)
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#define NECAT_HOST_SIMD __attribute__((target_clones("avx2", "default")))
+#else
+#define NECAT_HOST_SIMD
+#endif
+NECAT_HOST_SIMD
+inline bool all_covered(const uint16_t* c, int n, uint16_t m)
+{
+    int i = 0;
+    for (; i + 64 <= n; i += 64) {                  // branch-free inside a chunk so that the comparison vectorises
+        unsigned below = 0;
+        for (int k = 0; k < 64; ++k) below |= (unsigned)(c[i + k] < m);
+        if (below) return false;
+    }
+    for (; i < n; ++i) if (c[i] < m) return false;
+    return true;
+}
+NECAT_HOST_SIMD
+inline void add_one(uint16_t* c, int n) { for (int i = 0; i < n; ++i) ++c[i]; }
+
 struct Template {
     // input
     const necat_candidate* c = nullptr;   // its candidates in examination order
@@ -129,12 +151,8 @@ struct Template {
 
     bool is_used(int32_t qid) const { return std::find(used.begin(), used.end(), qid) != used.end(); }
     // consensus_one_read.c:145-151
-    bool region_full(int from, int to, int max_cov) const
-    {
-        for (int i = from; i < to; ++i) if (cov[i] < max_cov) return false;
-        return true;
-    }
-    void cover(int from, int to) { for (int i = from; i < to; ++i) ++cov[i]; }
+    bool region_full(int from, int to, int max_cov) const { return from >= to || all_covered(cov.data() + from, to - from, (uint16_t)max_cov); }
+    void cover(int from, int to) { if (to > from) add_one(cov.data() + from, to - from); }
     void accept(uint32_t ci, const Aligned& al)
     {
         necat_cns_overlap o;
@@ -171,6 +189,7 @@ inline bool in_selection(const Template& t, int32_t qid)
 inline void select(Template& t, const necat_cns_options& opt, const Knobs& kn)
 {
     const bool strict = kn.spec_estimate_extra < 0;      // test mode: never select what the loop might not reach
+    bool have_prefix = false;
     t.sel.clear();
     while (t.stage != Template::DONE) {
         if (t.stage == Template::ESTIMATE) {
@@ -191,9 +210,19 @@ inline void select(Template& t, const necat_cns_options& opt, const Knobs& kn)
             finish_estimate(t, limit, opt);                // ran out of candidates: error_estimate.c:178 with i = limit
             continue;
         }
-        // COVER: consensus_one_read.c:317-372
+        // COVER: consensus_one_read.c:317-372.  The coverage does not change during a selection: one prefix count of
+        // the positions still below max_cov answers every "is this region full" of the walk in O(1).
+        static thread_local std::vector<uint32_t> below;
+        if (!have_prefix) {
+            below.resize((size_t)t.tsize + 1);
+            uint32_t acc = 0;
+            for (int x = 0; x < t.tsize; ++x) { below[x] = acc; acc += t.cov[x] < opt.max_cov; }
+            below[t.tsize] = acc;
+            have_prefix = true;
+        }
+        auto full = [&](int from, int to) { return from >= to || below[to] == below[from]; };
         if (t.group_end == 0) {
-            if (t.cursor >= t.n || t.region_full(0, t.tsize, opt.max_cov)) { t.stage = Template::DONE; break; }
+            if (t.cursor >= t.n || full(0, t.tsize)) { t.stage = Template::DONE; break; }
             t.group_end = std::min<uint32_t>(t.cursor + kGroup, t.n);
         }
         // the few templates that need a third, fourth ... pass select twice as many each time: a pass of a handful of
@@ -210,7 +239,7 @@ inline void select(Template& t, const necat_cns_options& opt, const Knobs& kn)
         for (; i < t.group_end && (int)t.sel.size() < want; ++i) {
             const necat_candidate& c = t.c[i];
             if (t.is_used(c.qid)) continue;
-            if (t.region_full((int)c.sbeg, (int)c.send, opt.max_cov)) continue;
+            if (full((int)c.sbeg, (int)c.send)) continue;
             if (strict && in_selection(t, c.qid)) break;
             t.sel.push_back(i);
         }
@@ -334,7 +363,8 @@ inline int run(std::vector<Template>& ts, const necat_cns_options& opt, const Kn
         t.examined = t.n > 0 && (uint32_t)opt.min_cov <= t.n_all;      // consensus_one_read.c:223
         if (!t.examined) { t.stage = Template::DONE; return; }
         t.cov.assign((size_t)t.tsize + 1, 0);
-        t.used.reserve(64);
+        t.used.reserve(64); t.overlaps.reserve(32); t.ranges.reserve(32);
+        if (!opt.use_fixed_ident_cutoff) t.pool.reserve(24);
         if (opt.use_fixed_ident_cutoff) {                               // :267-272
             t.ident_cutoff = 100.0 * (1.0 - opt.error);
             t.stage = Template::COVER;
@@ -412,34 +442,53 @@ inline necat_candidate unpack(const Packed& p)
 }
 
 // consensus_one_partition.c:10-96 + consensus_one_read.c:250-260.  seq_off = the read set's prefix offsets.
-// Returns the index of the first bad record + 1, or 0.
+// Returns the index of the first bad record + 1, or 0.  Records are bucketed by template with a counting sort,
+// the (small) buckets are ordered and unpacked in parallel.
 inline uint64_t load_partition(std::vector<Packed>& recs, const uint64_t* seq_off, uint64_t nseq,
                                std::vector<necat_candidate>& cands, std::vector<uint64_t>& off, std::vector<uint64_t>& n_all)
 {
-    for (uint64_t i = 0; i < recs.size(); ++i) {
+    const uint64_t n = recs.size();
+    std::atomic<uint64_t> bad(0);
+    parallel_for(n, [&](size_t i) {
         Packed& p = recs[i];
-        if (p.w[1] >= nseq || p.w[4] >= nseq) return i + 1;
-        const uint64_t qsize = seq_off[p.w[4] + 1] - seq_off[p.w[4]], ssize = seq_off[p.w[1] + 1] - seq_off[p.w[1]];
-        if (p.w[5] > p.w[6] || p.w[6] > qsize || p.w[2] > p.w[3] || p.w[3] > ssize) return i + 1;
-        normalise_sdir(p, (uint32_t)qsize, (uint32_t)ssize);
-    }
-    std::sort(recs.begin(), recs.end(), [](const Packed& a, const Packed& b) {
-        if (a.w[1] != b.w[1]) return (int)a.w[1] < (int)b.w[1];
-        return examined_before(a, b);
-    });
-    cands.clear(); off.assign(1, 0); n_all.clear();
-    for (uint64_t i = 0; i < recs.size();) {
-        uint64_t j = i + 1;
-        while (j < recs.size() && recs[j].w[1] == recs[i].w[1]) ++j;
-        const uint64_t keep = std::min<uint64_t>(j - i, kMaxExamined);
-        for (uint64_t k = 0; k < keep; ++k) {
-            necat_candidate c = unpack(recs[i + k]);
-            c.qsize = seq_off[c.qid + 1] - seq_off[c.qid]; c.ssize = seq_off[c.sid + 1] - seq_off[c.sid];
-            cands.push_back(c);
+        bool ok = p.w[1] < nseq && p.w[4] < nseq;
+        if (ok) {
+            const uint64_t qsize = seq_off[p.w[4] + 1] - seq_off[p.w[4]], ssize = seq_off[p.w[1] + 1] - seq_off[p.w[1]];
+            ok = p.w[5] <= p.w[6] && p.w[6] <= qsize && p.w[2] <= p.w[3] && p.w[3] <= ssize;
+            if (ok) normalise_sdir(p, (uint32_t)qsize, (uint32_t)ssize);
         }
-        off.push_back(cands.size()); n_all.push_back(j - i);
-        i = j;
+        if (!ok) { uint64_t cur = bad.load(); while ((cur == 0 || i + 1 < cur) && !bad.compare_exchange_weak(cur, i + 1)) {} }
+    });
+    if (bad.load()) return bad.load();
+    // bucket by template id
+    std::vector<uint64_t> start(nseq + 1, 0);
+    for (uint64_t i = 0; i < n; ++i) ++start[recs[i].w[1] + 1];
+    std::vector<uint32_t> tmpl;                       // templates that have candidates, ascending
+    for (uint64_t s = 0; s < nseq; ++s) { if (start[s + 1]) tmpl.push_back((uint32_t)s); start[s + 1] += start[s]; }
+    std::vector<Packed> sorted(n);
+    {
+        std::vector<uint64_t> at(start.begin(), start.end() - 1);
+        for (uint64_t i = 0; i < n; ++i) sorted[at[recs[i].w[1]]++] = recs[i];
     }
+    const size_t nt = tmpl.size();
+    off.assign(nt + 1, 0); n_all.assign(nt, 0);
+    for (size_t t = 0; t < nt; ++t) {
+        const uint64_t cnt = start[tmpl[t] + 1] - start[tmpl[t]];
+        n_all[t] = cnt;
+        off[t + 1] = off[t] + std::min<uint64_t>(cnt, kMaxExamined);
+    }
+    cands.resize(off[nt]);
+    parallel_for(nt, [&](size_t t) {
+        Packed* b = sorted.data() + start[tmpl[t]];
+        const uint64_t cnt = n_all[t], keep = off[t + 1] - off[t];
+        std::sort(b, b + cnt, examined_before);
+        for (uint64_t k = 0; k < keep; ++k) {
+            necat_candidate c = unpack(b[k]);
+            c.qsize = seq_off[c.qid + 1] - seq_off[c.qid]; c.ssize = seq_off[c.sid + 1] - seq_off[c.sid];
+            cands[off[t] + k] = c;
+        }
+    });
+    recs.swap(sorted);
     return 0;
 }
 
