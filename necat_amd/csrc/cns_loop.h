@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <atomic>
 #include <functional>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -119,6 +120,26 @@ inline bool all_covered(const uint16_t* c, int n, uint16_t m)
 NECAT_HOST_SIMD
 inline void add_one(uint16_t* c, int n) { for (int i = 0; i < n; ++i) ++c[i]; }
 
+// A fixed-capacity array inside one of the call-wide arenas of run(): the per-template lists (selection, used
+// reads, pooled / accepted overlaps, ranges) are bounded by the template's candidate count, and 23 000 templates
+// growing four std::vectors each cost more in malloc and first-touch page faults than the loop's own arithmetic.
+template <class T>
+struct Span {
+    T* p = nullptr;
+    uint32_t n = 0;
+    uint32_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+    T* begin() { return p; }
+    T* end() { return p + n; }
+    const T* begin() const { return p; }
+    const T* end() const { return p + n; }
+    const T* data() const { return p; }
+    void push_back(const T& v) { p[n++] = v; }
+    void clear() { n = 0; }
+};
+
 struct Template {
     // input
     const necat_candidate* c = nullptr;   // its candidates in examination order
@@ -131,19 +152,19 @@ struct Template {
     uint32_t cursor = 0;        // next candidate the walk looks at
     uint32_t group_end = 0;     // COVER: end of the current group of 50 (0 = a new group starts at cursor)
     uint32_t stop = 0;          // where this round's selection stopped (exclusive)
-    std::vector<uint32_t> sel;  // this round's selection (candidate indices, ascending)
+    Span<uint32_t> sel;         // this round's selection (candidate indices, ascending); capacity min(n, 50)
     uint64_t sel_at = 0;        // index of sel[0] in the round's batch
-    std::vector<int32_t> used;  // reads already extended for this template (ReadIdPool)
-    std::vector<uint16_t> cov;  // coverage of the template by accepted overlaps
-    struct Pooled { uint32_t cand; Aligned al; int qsize; };
-    std::vector<Pooled> pool;   // OverlapsPool of the estimate stage
+    Span<int32_t> used;         // reads already extended for this template (ReadIdPool); capacity n
+    Span<uint16_t> cov;         // coverage of the template by accepted overlaps (tsize + 1 entries, zeroed by the arena)
+    Span<necat_cns_overlap> pool;   // OverlapsPool of the estimate stage: lives in the slot of `overlaps` (which is empty
+                                    // until the stage ends) and is compacted into it in place
     double ident[kIdentSamples];
     int n_ident = 0;
     // output
     double ident_cutoff = 0.0;
     int num_can = 0, num_ovlps = 0;
-    std::vector<necat_cns_overlap> overlaps;
-    std::vector<int32_t> ranges;
+    Span<necat_cns_overlap> overlaps;   // capacity n (a candidate is accepted at most once)
+    Span<int32_t> ranges;               // capacity 2 x min(n, 50): only the estimate stage's overlaps add ranges
     uint64_t n_used = 0;
     uint64_t covered_bp = 0;     // sum of the accepted overlaps' target ranges
     uint32_t est_aligned = 0;    // alignments consumed by the estimate stage
@@ -151,18 +172,23 @@ struct Template {
 
     bool is_used(int32_t qid) const { return std::find(used.begin(), used.end(), qid) != used.end(); }
     // consensus_one_read.c:145-151
-    bool region_full(int from, int to, int max_cov) const { return from >= to || all_covered(cov.data() + from, to - from, (uint16_t)max_cov); }
-    void cover(int from, int to) { if (to > from) add_one(cov.data() + from, to - from); }
-    void accept(uint32_t ci, const Aligned& al)
+    bool region_full(int from, int to, int max_cov) const { return from >= to || all_covered(cov.p + from, to - from, (uint16_t)max_cov); }
+    void cover(int from, int to) { if (to > from) add_one(cov.p + from, to - from); }
+    static necat_cns_overlap record(uint64_t cand, const Aligned& al)
     {
         necat_cns_overlap o;
-        o.cand = c_base + ci; o.qoff = al.a.qoff; o.qend = al.a.qend; o.toff = al.a.toff; o.tend = al.a.tend;
+        o.cand = cand; o.qoff = al.a.qoff; o.qend = al.a.qend; o.toff = al.a.toff; o.tend = al.a.tend;
         o.align_size = al.a.align_size; o.ops_block = al.block; o.ops_off = al.off;
-        o.ident_perc = al.a.ident_perc; o.weight = overlap_weight(al.a.ident_perc);
+        o.ident_perc = al.a.ident_perc; o.weight = 0.0;
+        return o;
+    }
+    void accept(necat_cns_overlap o)
+    {
+        o.weight = overlap_weight(o.ident_perc);
         overlaps.push_back(o);
         ++num_ovlps;
-        cover(al.a.toff, al.a.tend);
-        covered_bp += (uint64_t)(al.a.tend - al.a.toff);
+        cover(o.toff, o.tend);
+        covered_bp += (uint64_t)(o.tend - o.toff);
     }
 };
 
@@ -255,17 +281,18 @@ inline void select(Template& t, const necat_cns_options& opt, const Knobs& kn)
 // get_idents + the cutoff (error_estimate.c:65-94, :180-183), add_extended_overlaps (consensus_one_read.c:153-190)
 inline void finish_estimate(Template& t, uint32_t next, const necat_cns_options& opt)
 {
+    auto qsize_of = [&](const necat_cns_overlap& p) { return (int)t.c[p.cand - t.c_base].qsize; };
     if (t.n_ident < kIdentSamples) {
         int k = 0;
         for (const auto& p : t.pool) {
             if (k == kIdentSamples) break;
-            if (end_to_end(p.al.a.qoff, p.al.a.qend, p.qsize, p.al.a.toff, p.al.a.tend, t.tsize)) t.ident[k++] = p.al.a.ident_perc;
+            if (end_to_end(p.qoff, p.qend, qsize_of(p), p.toff, p.tend, t.tsize)) t.ident[k++] = p.ident_perc;
         }
         if (k < kIdentSamples) {
             k = 0;
             for (const auto& p : t.pool) {
                 if (k == kIdentSamples) break;
-                if (p.al.a.qend - p.al.a.qoff >= p.qsize * 0.6 || p.al.a.tend - p.al.a.toff >= t.tsize * 0.6) t.ident[k++] = p.al.a.ident_perc;
+                if (p.qend - p.qoff >= qsize_of(p) * 0.6 || p.tend - p.toff >= t.tsize * 0.6) t.ident[k++] = p.ident_perc;
             }
         }
         t.n_ident = k;
@@ -274,14 +301,15 @@ inline void finish_estimate(Template& t, uint32_t next, const necat_cns_options&
     int n = t.n_ident;
     if (n >= 8) n = (int)(n * 0.7);
     t.ident_cutoff = ident_lower_bound(t.ident, n);
-    for (const auto& p : t.pool) {
-        const necat_alignment& a = p.al.a;
-        if (a.ident_perc < t.ident_cutoff) continue;
-        if (!mapping_range_ok(a.qoff, a.qend, p.qsize, a.toff, a.tend, t.tsize, opt.min_align_size, opt.mapping_ratio)) continue;
-        t.accept(p.cand, p.al);
-        if (full_cov_ovlp(a.qoff, a.qend, p.qsize, a.toff, a.tend, t.tsize, 1000, 200)) { t.ranges.push_back(a.toff); t.ranges.push_back(a.tend); }
+    for (uint32_t j = 0; j < t.pool.size(); ++j) {
+        const necat_cns_overlap p = t.pool[j];            // by value: accept() writes into the same slot, at or before j
+        const int qs = qsize_of(p);
+        if (p.ident_perc < t.ident_cutoff) continue;
+        if (!mapping_range_ok(p.qoff, p.qend, qs, p.toff, p.tend, t.tsize, opt.min_align_size, opt.mapping_ratio)) continue;
+        t.accept(p);
+        if (full_cov_ovlp(p.qoff, p.qend, qs, p.toff, p.tend, t.tsize, 1000, 200)) { t.ranges.push_back(p.toff); t.ranges.push_back(p.tend); }
     }
-    t.pool.clear(); t.pool.shrink_to_fit();
+    t.pool.clear();
     t.num_can = (int)next;                                 // consensus_one_read.c:312-313
     t.cursor = next; t.group_end = 0;
     t.stage = Template::COVER;
@@ -301,7 +329,7 @@ inline void replay(Template& t, const Aligned* res, const necat_cns_options& opt
             const Aligned& al = *alp;                      // candidates that pass the test were all selected
             ++t.n_used; ++t.est_aligned;
             if (!al.a.ok) continue;
-            t.pool.push_back({i, al, (int)c.qsize});
+            t.pool.push_back(Template::record(t.c_base + i, al));
             t.used.push_back(c.qid);
             if (end_to_end(al.a.qoff, al.a.qend, (int)c.qsize, al.a.toff, al.a.tend, t.tsize)) {
                 t.ident[t.n_ident++] = al.a.ident_perc;
@@ -325,7 +353,7 @@ inline void replay(Template& t, const Aligned* res, const necat_cns_options& opt
         const necat_alignment& a = al.a;
         if (a.ident_perc < t.ident_cutoff && !full_cov_ovlp(a.qoff, a.qend, (int)c.qsize, a.toff, a.tend, t.tsize, 5000, 100)) continue;
         if (!mapping_range_ok(a.qoff, a.qend, (int)c.qsize, a.toff, a.tend, t.tsize, opt.min_align_size, opt.mapping_ratio)) continue;
-        t.accept(i, al);
+        t.accept(Template::record(t.c_base + i, al));
         t.used.push_back(c.qid);
     }
     t.cursor = t.stop;
@@ -350,21 +378,58 @@ inline void parallel_for(size_t n, F&& fn)
     for (auto& x : th) x.join();
 }
 
-struct Stats { uint64_t n_aligned = 0, n_used = 0; uint32_t n_rounds = 0; double init_ms = 0, select_ms = 0, gather_ms = 0, replay_ms = 0; };
+struct Stats {
+    uint64_t n_aligned = 0, n_used = 0; uint32_t n_rounds = 0; double init_ms = 0, select_ms = 0, gather_ms = 0, replay_ms = 0;
+    std::unique_ptr<necat_cns_overlap[]> ov_arena;     // Template::overlaps / ::ranges of a finished run() point into these
+    std::unique_ptr<int32_t[]> rg_arena;
+};
 
 inline double now_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 
 // Runs the loop of every template to its end.  Returns 0 or the callback's error.
-inline int run(std::vector<Template>& ts, const necat_cns_options& opt, const Knobs& kn, const AlignFn& align, Stats* st)
+// buffers a caller may keep between calls (the library keeps one per context)
+struct Scratch {
+    uint16_t* cov = nullptr;
+    size_t cov_cap = 0;
+    Scratch() = default;
+    Scratch(const Scratch&) = delete;
+    Scratch& operator=(const Scratch&) = delete;
+    ~Scratch() { free(cov); }
+};
+
+inline int run(std::vector<Template>& ts, const necat_cns_options& opt, const Knobs& kn, const AlignFn& align, Stats* st, Scratch* sc = nullptr)
 {
     double t0 = now_ms();
+    // call-wide arenas for the per-template lists
+    std::vector<uint64_t> at_n(ts.size() + 1, 0), at_50(ts.size() + 1, 0);
+    for (size_t i = 0; i < ts.size(); ++i) { at_n[i + 1] = at_n[i] + ts[i].n; at_50[i + 1] = at_50[i] + std::min<uint32_t>(ts[i].n, kGroup); }
+    std::unique_ptr<necat_cns_overlap[]> ov_arena(new necat_cns_overlap[at_n.back() + 1]);
+    std::unique_ptr<int32_t[]> used_arena(new int32_t[at_n.back() + 1]), rg_arena(new int32_t[2 * at_50.back() + 1]);
+    std::unique_ptr<uint32_t[]> sel_arena(new uint32_t[at_50.back() + 1]);
+    // coverage arrays: one allocation kept between calls (first-touch page faults of a fresh 0.4 GB block cost more than
+    // the whole replay: 168 ms from 32 threads at once), zeroed per template in the parallel loop below
+    std::vector<uint64_t> at_cov(ts.size() + 1, 0);
+    for (size_t i = 0; i < ts.size(); ++i) at_cov[i + 1] = at_cov[i] + (uint64_t)ts[i].tsize + 1;
+    Scratch local;
+    if (!sc) sc = &local;
+    if (at_cov.back() + 1 > sc->cov_cap) {
+        free(sc->cov);
+        sc->cov_cap = (at_cov.back() + 1) + (at_cov.back() + 1) / 4;
+        sc->cov = (uint16_t*)malloc(sc->cov_cap * sizeof(uint16_t));
+        if (!sc->cov) { sc->cov_cap = 0; return NECAT_ERR_MEMORY; }
+    }
+    uint16_t* const cov_arena = sc->cov;
+    st->ov_arena = std::move(ov_arena); st->rg_arena = std::move(rg_arena);       // the results point into these two
     parallel_for(ts.size(), [&](size_t i) {
         Template& t = ts[i];
+        t.overlaps.p = st->ov_arena.get() + at_n[i]; t.pool.p = t.overlaps.p;
+        t.used.p = used_arena.get() + at_n[i];
+        t.ranges.p = st->rg_arena.get() + 2 * at_50[i];
+        t.sel.p = sel_arena.get() + at_50[i];
         t.examined = t.n > 0 && (uint32_t)opt.min_cov <= t.n_all;      // consensus_one_read.c:223
         if (!t.examined) { t.stage = Template::DONE; return; }
-        t.cov.assign((size_t)t.tsize + 1, 0);
-        t.used.reserve(64); t.overlaps.reserve(32); t.ranges.reserve(32);
-        if (!opt.use_fixed_ident_cutoff) t.pool.reserve(24);
+        t.cov.p = cov_arena + at_cov[i]; t.cov.n = (uint32_t)t.tsize + 1;
+        memset(t.cov.p, 0, (size_t)t.cov.n * sizeof(uint16_t));
         if (opt.use_fixed_ident_cutoff) {                               // :267-272
             t.ident_cutoff = 100.0 * (1.0 - opt.error);
             t.stage = Template::COVER;
@@ -395,7 +460,7 @@ inline int run(std::vector<Template>& ts, const necat_cns_options& opt, const Kn
         st->replay_ms += now_ms() - t0;
         st->n_aligned += total; ++st->n_rounds;
     }
-    for (auto& t : ts) { st->n_used += t.n_used; std::vector<uint16_t>().swap(t.cov); }
+    for (auto& t : ts) { st->n_used += t.n_used; t.cov.p = nullptr; t.cov.n = 0; }
     return 0;
 }
 

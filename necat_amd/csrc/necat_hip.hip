@@ -124,6 +124,7 @@ void necat_ctx_destroy(necat_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& b : ctx->scratch) if (b.p) (void)hipFree(b.p);
     for (auto& b : ctx->idx_cache) if (b.p) (void)hipFree(b.p);
+    delete (cns::Scratch*)ctx->cns_scratch;
     for (int i = 0; i < 20; ++i) (void)hipEventDestroy(ctx->ev[i]);
     (void)hipStreamDestroy(ctx->stream); (void)hipStreamDestroy(ctx->stream_a); (void)hipStreamDestroy(ctx->stream_b); (void)hipStreamDestroy(ctx->stream_c);
     delete ctx;
@@ -1209,7 +1210,8 @@ int necat_cns_extension_batch(necat_ctx* ctx, const necat_volume* reads, const n
     cns::Knobs kn; kn.spec_estimate_extra = g_cns_spec_extra; kn.spec_cover = g_cns_spec_cover;
     cns::Stats st;
     const double w_run = wall_ms();
-    const int rc = cns::run(ts, *opt, kn, fn, &st);
+    if (!ctx->cns_scratch) ctx->cns_scratch = new cns::Scratch();
+    const int rc = cns::run(ts, *opt, kn, fn, &st, (cns::Scratch*)ctx->cns_scratch);
     if (g_trace & 2) fprintf(stderr, "[necat] cns host: setup %.2f ms, init %.2f, select %.2f, gather %.2f, replay %.2f ms\n", w_run - w0, st.init_ms, st.select_ms,
                              st.gather_ms, st.replay_ms);
     auto drop = [&]() { for (u8* b : blocks) necat_free(b); };
@@ -1228,17 +1230,22 @@ int necat_cns_extension_batch(necat_ctx* ctx, const necat_volume* reads, const n
         if (r) { free(r->templates); free(r->overlaps); free(r->ranges); free(r->ops); free(r); }
         return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed");
     }
-    uint64_t ov = 0, rg = 0;
-    for (uint64_t t = 0; t < n_templates; ++t) {
+    {
+        uint64_t ov = 0, rg = 0;
+        for (uint64_t t = 0; t < n_templates; ++t) {
+            necat_cns_template& o = r->templates[t];
+            o.ovlp_begin = ov; o.range_begin = rg;
+            ov += ts[t].overlaps.size(); rg += ts[t].ranges.size() / 2;
+            o.ovlp_end = ov; o.range_end = rg;
+        }
+    }
+    cns::parallel_for(n_templates, [&](size_t t) {
         const cns::Template& T = ts[t];
         necat_cns_template& o = r->templates[t];
         o.examined = T.examined ? 1 : 0; o.num_can = T.num_can; o.num_ovlps = T.num_ovlps; o.ident_cutoff = T.ident_cutoff;
-        o.ovlp_begin = ov; o.range_begin = rg;
-        if (!T.overlaps.empty()) memcpy(r->overlaps + ov, T.overlaps.data(), T.overlaps.size() * sizeof(necat_cns_overlap));
-        if (!T.ranges.empty()) memcpy(r->ranges + 2 * rg, T.ranges.data(), T.ranges.size() * 4);
-        ov += T.overlaps.size(); rg += T.ranges.size() / 2;
-        o.ovlp_end = ov; o.range_end = rg;
-    }
+        if (!T.overlaps.empty()) memcpy(r->overlaps + o.ovlp_begin, T.overlaps.data(), T.overlaps.size() * sizeof(necat_cns_overlap));
+        if (!T.ranges.empty()) memcpy(r->ranges + 2 * o.range_begin, T.ranges.data(), T.ranges.size() * 4);
+    });
     r->n_templates = n_templates; r->n_overlaps = n_ov; r->n_ranges = n_rg;
     r->n_ops_blocks = (uint32_t)blocks.size();
     for (size_t b = 0; b < blocks.size(); ++b) r->ops[b] = blocks[b];

@@ -34,6 +34,7 @@ struct necat_ctx {
     char devname[256] = {0};
     int num_cu = 0;
     uint32_t epoch = 0;
+    void* cns_scratch = nullptr;       // host buffers of the consensus loop kept between calls (necat::cns::Scratch)
     necat::DevBuf idx_cache[2];        // released index arrays kept for the next build (8.6 GB hipMalloc/hipFree per step otherwise)                // launch counter stamped into the traceback band records
 };
 
