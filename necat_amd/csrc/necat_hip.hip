@@ -111,7 +111,8 @@ int necat_ctx_create(int device_id, necat_ctx** out)
         ctx->num_cu = prop.multiProcessorCount;
     }
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream_a) != hipSuccess ||
-        hipStreamCreate(&ctx->stream_b) != hipSuccess || hipStreamCreate(&ctx->stream_c) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
+        hipStreamCreate(&ctx->stream_b) != hipSuccess || hipStreamCreate(&ctx->stream_c) != hipSuccess ||
+        hipStreamCreate(&ctx->stream_copy) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
     for (int i = 0; i < 20; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
     *out = ctx;
     return NECAT_OK;
@@ -122,11 +123,13 @@ void necat_ctx_destroy(necat_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream_copy);
     for (auto& b : ctx->scratch) if (b.p) (void)hipFree(b.p);
     for (auto& b : ctx->idx_cache) if (b.p) (void)hipFree(b.p);
     delete (cns::Scratch*)ctx->cns_scratch;
     for (int i = 0; i < 20; ++i) (void)hipEventDestroy(ctx->ev[i]);
     (void)hipStreamDestroy(ctx->stream); (void)hipStreamDestroy(ctx->stream_a); (void)hipStreamDestroy(ctx->stream_b); (void)hipStreamDestroy(ctx->stream_c);
+    (void)hipStreamDestroy(ctx->stream_copy);
     delete ctx;
 }
 
@@ -816,6 +819,8 @@ struct AlignOut {
     std::vector<std::pair<u8*, u64>> parts;     // one pinned block of columns per batch
     u64 total = 0;
     std::vector<u64> off;
+    bool defer_copy = false;    // the columns' device-to-host copy runs on ctx->stream_copy and is NOT waited for: the caller
+                                // synchronises that stream before it reads (or frees) the blocks
 };
 
 // The extension loop behind necat_extend (M4 records, containment filter) and necat_onc_align_batch
@@ -991,7 +996,12 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
             for (u32 i = 0; i < k.n; ++i) ao->off[k.base + i] = at + off[i] * 8;
             ao->off[k.base + k.n] = at + tot;
             if (tot) {
-                if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_COLS_OUT], tot + (size_t)(k.n + 1) * 8 + 64))) { cleanup(); return rc; }
+                const size_t need_out = tot + (size_t)(k.n + 1) * 8 + 64;
+                if (ctx->copy_pending && need_out > ctx->scratch[SC_EXT_COLS_OUT].cap) {      // the buffer is about to be replaced
+                    NECAT_HIP(ctx, hipStreamSynchronize(ctx->stream_copy)); ctx->copy_pending = false;
+                }
+                if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_COLS_OUT], need_out))) { cleanup(); return rc; }
+                if (ctx->copy_pending) { NECAT_HIP(ctx, hipStreamWaitEvent(k.sa, ctx->ev[17], 0)); ctx->copy_pending = false; }
                 u8* d_cols = (u8*)ctx->scratch[SC_EXT_COLS_OUT].p;
                 u64* d_off = (u64*)(d_cols + ((tot + 63) & ~63ULL));
                 NECAT_HIP(ctx, hipMemcpyAsync(d_off, off.data(), (size_t)k.n * 8, hipMemcpyHostToDevice, k.sa));
@@ -1001,8 +1011,17 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
                 u8* part = (u8*)result_alloc(tot);
                 if (!part) { cleanup(); return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
                 ao->parts.emplace_back(part, tot); ao->total += tot;
-                NECAT_HIP(ctx, hipMemcpyAsync(part, d_cols, tot, hipMemcpyDeviceToHost, k.sa));
-                NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
+                if (ao->defer_copy) {
+                    NECAT_HIP(ctx, hipEventRecord(ctx->ev[16], k.sa));
+                    NECAT_HIP(ctx, hipStreamWaitEvent(ctx->stream_copy, ctx->ev[16], 0));
+                    NECAT_HIP(ctx, hipMemcpyAsync(part, d_cols, tot, hipMemcpyDeviceToHost, ctx->stream_copy));
+                    NECAT_HIP(ctx, hipEventRecord(ctx->ev[17], ctx->stream_copy));
+                    ctx->copy_pending = true;
+                    NECAT_HIP(ctx, hipStreamSynchronize(k.sa));      // the batch's kernels are done (its buffers are reused next)
+                } else {
+                    NECAT_HIP(ctx, hipMemcpyAsync(part, d_cols, tot, hipMemcpyDeviceToHost, k.sa));
+                    NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
+                }
             }
         }
     }
@@ -1185,11 +1204,15 @@ int necat_cns_extension_batch(necat_ctx* ctx, const necat_volume* reads, const n
     cns::AlignFn fn = [&](const necat_candidate* c, uint64_t m, cns::Aligned* res) -> int {
         const double a0 = wall_ms();
         AlignOut ao;
+        ao.defer_copy = true;       // the loop only needs the coordinates to go on; the columns arrive while it does
         ao.aln = (necat_alignment*)result_alloc(std::max<uint64_t>(1, m) * sizeof(necat_alignment));
         if (!ao.aln) return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed");
         ao.off.assign(m + 1, 0);
         const int rc = extend_impl(ctx, reads, reads, 0, 0, c, m, &mo, 4 /* ONC_TAIL_MATCH_LEN_LONG, oc_aligner.h:42 */, nullptr, nullptr, &ao);
-        if (rc) { necat_free(ao.aln); for (auto& pr : ao.parts) necat_free(pr.first); return rc; }
+        if (rc) {
+            (void)hipStreamSynchronize(ctx->stream_copy); ctx->copy_pending = false;
+            necat_free(ao.aln); for (auto& pr : ao.parts) necat_free(pr.first); return rc;
+        }
         device_ms += ctx->tm.extend_ms;
         // the columns stay where the device copied them: one block per batch of the pass
         size_t p = 0; u64 p_start = 0;
@@ -1215,6 +1238,11 @@ int necat_cns_extension_batch(necat_ctx* ctx, const necat_volume* reads, const n
     if (g_trace & 2) fprintf(stderr, "[necat] cns host: setup %.2f ms, init %.2f, select %.2f, gather %.2f, replay %.2f ms\n", w_run - w0, st.init_ms, st.select_ms,
                              st.gather_ms, st.replay_ms);
     auto drop = [&]() { for (u8* b : blocks) necat_free(b); };
+    {   // the last columns may still be on their way
+        const hipError_t e = hipStreamSynchronize(ctx->stream_copy);
+        ctx->copy_pending = false;
+        if (e != hipSuccess && !rc) { drop(); return set_err(ctx, NECAT_ERR_DEVICE, "column copy failed: %s", hipGetErrorString(e)); }
+    }
     if (rc) { drop(); return rc; }
     necat_cns_result* r = (necat_cns_result*)calloc(1, sizeof(necat_cns_result));
     uint64_t n_ov = 0, n_rg = 0;
