@@ -73,3 +73,25 @@ def test_cns_loop_matches_sequential(check_cns, tmp_path, args):
         f = dict(kv.split("=") for kv in r.stdout.split())
         assert f["aligned"] == f["used"]
 
+
+def test_cns_loop_deep_coverage_cut_to_300(check_cns, tmp_path):
+    """templates with more than MAX_EXAMINED_CAN = 300 candidates (tiny genome, 400x): the cut after the sort, the
+    min_cov test on the count before the cut, several groups of 50 - batched loop vs sequential oracle"""
+    from oracle import oracle_api as ora
+    wrk, rs, nv = util.make_dataset(tmp_path, genome=5_000, coverage=400.0, seed=23, err=0.12)
+    o = ora.options(**dict(util.FAST, job=0, binary_output=1, num_threads=4))
+    rec = b""
+    for v in range(nv):
+        out = os.path.join(str(tmp_path), "pm_%d" % v)
+        ora.pm_main(o, v, wrk, out)
+        rec += open(out, "rb").read()
+    part = util.pcan_single_partition(rec)
+    import numpy as np
+    per_template = np.bincount(np.frombuffer(part, dtype="<u4").reshape(-1, 7)[:, 1])
+    assert per_template.max() > 300
+    util.write_partition(os.path.join(str(tmp_path), "cands"), part)
+    r = subprocess.run([check_cns, wrk, os.path.join(str(tmp_path), "cands")] + "400 4 30 0.5 0.8 0 1 12".split(),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "cns_mismatch=0 " in r.stdout and " overlaps=0 " not in r.stdout
+

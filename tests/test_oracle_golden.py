@@ -162,3 +162,23 @@ def test_pcan_single_partition_vs_ref(tmp_path):
     key = lambda b: sorted(b[i:i + 28] for i in range(0, len(b), 28))
     assert len(want) == 2 * len(rec) and key(got) == key(want)
 
+
+@pytest.mark.skipif(not ora.have_ref_cns(), reason="oracle/_ref (reference build) not present")
+def test_cns_loop_deep_coverage_vs_ref(tmp_path):
+    """more than MAX_EXAMINED_CAN = 300 candidates per template: the reference's sort + cut (consensus_one_read.c:250-260)
+    and its loop over several groups of 50 vs the restatement"""
+    wrk, rs, nv = util.make_dataset(tmp_path, genome=5_000, coverage=400.0, seed=23, err=0.12)
+    o = ora.options(**dict(util.FAST, job=0, binary_output=1, num_threads=4))
+    can = os.path.join(str(tmp_path), "cands")
+    with open(can, "wb") as f:
+        for v in range(nv):
+            ora.run_ref(o, v, wrk, can + ".v%d" % v)
+            f.write(open(can + ".v%d" % v, "rb").read())
+    ora.run_ref_pcan(wrk, can)
+    a, b = os.path.join(str(tmp_path), "ref.txt"), os.path.join(str(tmp_path), "ora.txt")
+    kw = dict(max_cov=30)
+    ora.run_ref_cns(ora.cns_options(**kw), wrk, can, a)
+    ora.cns_run(ora.cns_options(**kw), wrk, can, b)
+    assert open(a).read() == open(b).read()
+    assert max(t[3] for t in ora.parse_cns_log(a)) > 50          # num_can: the loop went beyond the first group
+
