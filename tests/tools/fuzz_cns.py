@@ -2,10 +2,10 @@
 x random speculation widths, necat_cns_extension_batch through the C ABI against the oracle's sequential loop, compared
 as logs (every add_one_align call with both gapped strings, per-template cutoff / counters / ranges).
 
-    python tools/fuzz_cns.py [n_cases] [first_seed]
+    python tests/tools/fuzz_cns.py [n_cases] [first_seed]
 """
 import os, sys, tempfile, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 from necat_amd import capi, synth
 from oracle import oracle_api as ora

@@ -1,10 +1,10 @@
 """Randomised parity sweep (tool): random small datasets x random option sets, the HIP path through the C ABI
 against the oracle - candidates (-j 0, packed 28-byte records) and M4 records (-j 1), every volume.
 
-    python tools/fuzz_parity.py [n_cases] [first_seed]
+    python tests/tools/fuzz_parity.py [n_cases] [first_seed]
 """
 import os, sys, tempfile, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 from necat_amd import capi, synth
 from oracle import oracle_api as ora

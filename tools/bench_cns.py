@@ -2,7 +2,8 @@
 """Throughput of necat_cns_extension_batch on the bench workload: E. coli-size synthetic reads,
 candidates from this library's own oc2pmov -j 0 path, role-swapped into one partition as oc2pcan does.
 
-    python tools/bench_cns.py [genome_len coverage] [--cpu N]   (--cpu: time the oracle's sequential loop on N templates)
+    python tools/bench_cns.py [genome_len coverage]
+(the CPU port of the same loop is timed by tests/tools/cns_cpu_port.py)
 """
 import os
 import sys
@@ -17,13 +18,7 @@ from necat_amd import capi, synth  # noqa: E402
 
 
 def main():
-    argv = sys.argv[1:]
-    cpu_n = 0
-    if "--cpu" in argv:
-        i = argv.index("--cpu")
-        cpu_n = int(argv[i + 1])
-        del argv[i:i + 2]
-    args = argv
+    args = sys.argv[1:]
     glen = int(args[0]) if len(args) > 0 else 4_600_000
     cov = float(args[1]) if len(args) > 1 else 40.0
     import util
@@ -58,26 +53,6 @@ def main():
         res.free()
         if best is None or dt < best["wall_s"]:
             best = line
-    if cpu_n:
-        # the oracle's sequential restatement of the same loop (one thread) on the first templates
-        import tempfile
-        from oracle import oracle_api as ora
-        k2 = cpu_n
-        k1 = max(1, k2 // 5)
-        tmp = tempfile.mkdtemp(prefix="cns_cpu_")
-        synth.write_volume_dir(os.path.join(tmp, "vols"), rs, 1 << 40)
-        rec = np.frombuffer(part, dtype="<u4").reshape(-1, 7)
-        ts = {}
-        for k in (k1, k2):
-            util.write_partition(os.path.join(tmp, "c%d" % k), rec[rec[:, 1] < k].tobytes())
-            t = time.time()
-            ora.cns_run(ora.cns_options(), os.path.join(tmp, "vols"), os.path.join(tmp, "c%d" % k), os.path.join(tmp, "log%d" % k))
-            ts[k] = time.time() - t
-        n_al = sum(1 for ln in open(os.path.join(tmp, "log%d" % k2)) if ln[0] == "A") - sum(1 for ln in open(os.path.join(tmp, "log%d" % k1)) if ln[0] == "A")
-        best["cpu_port_templates_per_s_1thread"] = round((k2 - k1) / (ts[k2] - ts[k1]), 2)
-        best["cpu_port_sample"] = "templates %d..%d of the same partition, %d overlaps, %.1f s" % (k1, k2, n_al, ts[k2] - ts[k1])
-        import shutil
-        shutil.rmtree(tmp, ignore_errors=True)
     best["load_partition_s"] = round(t_load, 3)
     best["templates_per_s"] = round(best["templates"] / best["wall_s"], 1)
     best["alignments_per_s"] = round(best["aligned"] / best["wall_s"], 1)
