@@ -78,3 +78,33 @@ def test_cns_loop_fresh_vs_oracle(built, tmp_path, okw, knobs):
     assert txt == want
     if knobs.get("NECAT_CNS_SPEC") == "1":
         assert stats[0] == stats[1]            # nothing speculative was computed
+
+
+def test_cns_argument_errors(ctx, tmp_path):
+    """inconsistent input is refused with NECAT_ERR_ARG and a message, nothing is computed"""
+    man = json.load(open(os.path.join(util.GOLDEN, "cns_c", "manifest.json")))
+    wrk = util.install_golden_volumes(man["volumes"], tmp_path)
+    part = np.frombuffer(open(os.path.join(util.GOLDEN, "cns_c", "cands.p0"), "rb").read(), dtype=np.uint8)
+    vol = ctx.load_merged_volumes(wrk)
+    cands, off, n_all = ctx.cns_load_partition(vol, part)
+    co = capi.cns_options()
+    for field, value in (("sdir", 1), ("sid", int(cands[0]["sid"]) + 1), ("send", int(cands[0]["ssize"]) + 1), ("qsize", 17)):
+        bad = cands.copy()
+        bad[field][3] = value
+        with pytest.raises(capi.NecatError, match="inconsistent"):
+            ctx.cns_extension_batch(vol, bad, off, n_all, co)
+    with pytest.raises(capi.NecatError, match="out of range"):
+        ctx.cns_extension_batch(vol, cands, off, n_all, capi.cns_options(max_cov=0))
+    rec = part.copy().view("<u4").reshape(-1, 7)
+    rec[5, 1] = 10 ** 6                                    # a template id outside the read set
+    with pytest.raises(capi.NecatError, match="outside the read set"):
+        ctx.cns_load_partition(vol, rec.view(np.uint8).reshape(-1))
+    # an empty call and a call whose templates all have fewer than min_cov candidates are fine
+    r = ctx.cns_extension_batch(vol, cands[:0], np.zeros(1, dtype=np.uint64), None, co)
+    assert r.templates.shape[0] == 0 and r.overlaps.shape[0] == 0
+    r.free()
+    r = ctx.cns_extension_batch(vol, cands, off, n_all, capi.cns_options(min_cov=10 ** 6))
+    assert r.templates.shape[0] == off.shape[0] - 1 and not r.templates["examined"].any() and r.n_aligned == 0
+    r.free()
+    vol.free()
+
