@@ -18,6 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libnecat_hip.so")
 OC2PMOV = os.path.join(CSRC, "oc2pmov")
 OC2PM = os.path.join(CSRC, "oc2pm")
+OC2MKDB = os.path.join(CSRC, "oc2mkdb")
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
 
@@ -66,6 +67,8 @@ def build_cli(force: bool = False):
               "-Wl,-rpath,$ORIGIN", "-lpthread"], cwd=CSRC)
     if force or _stale(OC2PM, ["oc2pm_main.cpp", "host_io.h"]):
         _run([shutil.which("g++") or "g++", "-O2", "-std=c++17", "-o", OC2PM, "oc2pm_main.cpp"], cwd=CSRC)
+    if force or _stale(OC2MKDB, ["oc2mkdb_main.cpp"]):          # host-only drop-in of the volume writer
+        _run([shutil.which("g++") or "g++", "-O2", "-std=c++17", "-o", OC2MKDB, "oc2mkdb_main.cpp", "-lz"], cwd=CSRC)
     return OC2PMOV, OC2PM
 
 
