@@ -19,6 +19,7 @@ LIB = os.path.join(CSRC, "libnecat_hip.so")
 OC2PMOV = os.path.join(CSRC, "oc2pmov")
 OC2PM = os.path.join(CSRC, "oc2pm")
 OC2MKDB = os.path.join(CSRC, "oc2mkdb")
+OC2PCAN = os.path.join(CSRC, "oc2pcan")
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
 
@@ -69,6 +70,8 @@ def build_cli(force: bool = False):
         _run([shutil.which("g++") or "g++", "-O2", "-std=c++17", "-o", OC2PM, "oc2pm_main.cpp"], cwd=CSRC)
     if force or _stale(OC2MKDB, ["oc2mkdb_main.cpp"]):          # host-only drop-in of the volume writer
         _run([shutil.which("g++") or "g++", "-O2", "-std=c++17", "-o", OC2MKDB, "oc2mkdb_main.cpp", "-lz"], cwd=CSRC)
+    if force or _stale(OC2PCAN, ["oc2pcan_main.cpp"]):          # host-only drop-in of the candidate partitioner
+        _run([shutil.which("g++") or "g++", "-O2", "-std=c++17", "-o", OC2PCAN, "oc2pcan_main.cpp"], cwd=CSRC)
     return OC2PMOV, OC2PM
 
 

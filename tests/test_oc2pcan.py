@@ -1,0 +1,80 @@
+"""oc2pcan drop-in (necat_amd/csrc/oc2pcan_main.cpp): the same partition files as the reference's
+candidate partitioner - same file set, same `.partitions` count, same records per partition (their order inside a
+file is unspecified in the reference: worker threads append chunks)."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from necat_amd import build, capi
+from oracle import oracle_api as ora
+from tests import util
+
+
+@pytest.fixture(scope="module")
+def oc2pcan(built):
+    build.build_cli()
+    return build.OC2PCAN
+
+
+def _records(path):
+    b = open(path, "rb").read()
+    assert len(b) % 28 == 0
+    return sorted(b[i:i + 28] for i in range(0, len(b), 28))
+
+
+def _candidates(tmp_path, ds):
+    """all-vs-all candidates of a golden data set by the oracle's oc2pmov -j 0 -u 1, every volume"""
+    wrk = util.install_golden_volumes(ds, tmp_path)
+    nv, nr, _ = capi.load_volumes_info(wrk)
+    o = ora.options(**dict(util.FAST, kmer_size=13, job=0, binary_output=1, num_threads=2))
+    rec = b""
+    for v in range(nv):
+        out = os.path.join(str(tmp_path), "pm_%d" % v)
+        ora.pm_main(o, v, wrk, out)
+        rec += open(out, "rb").read()
+    return wrk, nr, rec
+
+
+@pytest.mark.skipif(not ora.have_ref_cns(), reason="oracle/_ref (reference build) not present")
+@pytest.mark.parametrize("ds,args", [("vols_a", []), ("vols_b", ["-p", "7"]), ("vols_b", ["-p", "5", "-f", "3"]), ("vols_a", ["-p", "1000000", "-t", "4"])])
+def test_oc2pcan_vs_reference(oc2pcan, tmp_path, ds, args):
+    wrk, nr, rec = _candidates(tmp_path, ds)
+    assert len(rec) > 28 * 50
+    outs = {}
+    for tag, exe in (("ref", ora.REF_PCAN), ("mine", oc2pcan)):
+        d = os.path.join(str(tmp_path), tag)
+        os.makedirs(d)
+        can = os.path.join(d, "cands")
+        open(can, "wb").write(rec)
+        r = subprocess.run([exe] + args + [wrk, can], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+        outs[tag] = d
+    assert sorted(os.listdir(outs["ref"])) == sorted(os.listdir(outs["mine"]))
+    assert open(os.path.join(outs["ref"], "cands.partitions")).read() == open(os.path.join(outs["mine"], "cands.partitions")).read()
+    n_parts = int(open(os.path.join(outs["mine"], "cands.partitions")).read())
+    total = 0
+    for p in range(n_parts):
+        a, b = _records(os.path.join(outs["ref"], "cands.p%d" % p)), _records(os.path.join(outs["mine"], "cands.p%d" % p))
+        assert a == b, p
+        total += len(b)
+    assert total == 2 * (len(rec) // 28)            # every read id is inside some batch: each record lands twice
+
+
+def test_oc2pcan_single_partition_is_role_swap(oc2pcan, tmp_path):
+    """no reference build needed: with one batch the partition is the input plus its role-swapped twin
+    (capi.pcan_single_partition, itself pinned to the reference in tests/test_oracle_golden.py)"""
+    wrk = util.install_golden_volumes("vols_a", tmp_path)
+    rec = open(os.path.join(util.GOLDEN, "a_fast_can_bin.bin"), "rb").read()
+    can = os.path.join(str(tmp_path), "cands")
+    open(can, "wb").write(rec)
+    r = subprocess.run([oc2pcan, wrk, can], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert open(can + ".partitions").read() == "1\n"
+    want = capi.pcan_single_partition(rec)
+    assert _records(can + ".p0") == sorted(want[i:i + 28] for i in range(0, len(want), 28))
+    # a missing work directory is an error, not an empty result
+    r = subprocess.run([oc2pcan, os.path.join(str(tmp_path), "nowhere"), can], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode != 0
