@@ -108,3 +108,42 @@ def test_cns_argument_errors(ctx, tmp_path):
     r.free()
     vol.free()
 
+
+def test_front_half_chain_reads_to_overlaps(ctx, built, tmp_path):
+    """The whole front half of the correction pipeline with this repo's programs only - FASTA -> oc2mkdb -> oc2pmov
+    -j 0 -u 1 per volume (GPU) -> oc2pcan -> necat_cns_extension_batch (GPU) - must hand the consensus exactly the
+    overlaps the REFERENCE chain (its oc2mkdb, oc2pmov, oc2pcan, consensus driver) produced for the same reads:
+    tests/golden/cns_c/ref_default.txt."""
+    import subprocess
+    from necat_amd import build, synth
+    pmov, _ = built.build_cli()
+    man = json.load(open(os.path.join(util.GOLDEN, "cns_c", "manifest.json")))
+    src = util.install_golden_volumes(man["volumes"], os.path.join(str(tmp_path), "src"))
+    fa = os.path.join(str(tmp_path), "reads.fasta")
+    with open(fa, "w") as f:
+        for path, _, _ in capi.load_volumes_info(src)[2]:
+            pac, off, sz, names = synth.read_volume(path)
+            codes = synth.unpack_2bit(pac, int(sz.sum()))
+            for i, nm in enumerate(names):
+                f.write(">%s\n%s\n" % (nm, bytes(b"ACGT"[c] for c in codes[int(off[i]):int(off[i] + sz[i])]).decode()))
+    lst = os.path.join(str(tmp_path), "list.txt")
+    open(lst, "w").write(fa + "\n")
+    wrk = os.path.join(str(tmp_path), "wrk")
+    env = dict(os.environ, NECAT_MKDB_VOLSIZE="500000")           # the golden set was cut into volumes of >= 500 kbp
+    assert subprocess.run([build.OC2MKDB, wrk, lst], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT).returncode == 0
+    nv, nr, _ = capi.load_volumes_info(wrk)
+    assert nv == man["n_volumes"]
+    o = ora.options(**dict(util.FAST, job=0, binary_output=1, num_threads=1))
+    can = os.path.join(str(tmp_path), "cands")
+    with open(can, "wb") as f:
+        for v in range(nv):
+            out = os.path.join(str(tmp_path), "pm_result_%d" % v)
+            r = subprocess.run([pmov] + ora.opt_argv(o) + [wrk, str(v), out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+            assert r.returncode == 0, r.stderr
+            f.write(open(out, "rb").read())
+    assert os.path.getsize(can) // 28 == man["candidates"]
+    assert subprocess.run([build.OC2PCAN, wrk, can], stdout=subprocess.PIPE, stderr=subprocess.STDOUT).returncode == 0
+    assert open(can + ".partitions").read() == "1\n"
+    txt, stats = _run(ctx, wrk, open(can + ".p0", "rb").read(), {})
+    assert txt == open(os.path.join(util.GOLDEN, "cns_c", "ref_default.txt")).read()
+
