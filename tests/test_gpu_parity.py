@@ -412,3 +412,42 @@ def test_extension_in_several_batches(ctx, small):
     assert util.m4_key_rows(got) == util.m4_key_rows(base) and base.shape[0] > 500
     for x, y in zip(a0, a1):
         assert x.tobytes() == y.tobytes()
+
+
+def test_ultra_long_reads(ctx, tmp_path):
+    """reads of 60-200 kb (hundreds of 512-bp blocks per alignment, hundreds of extension rounds, long chains in the
+    seeding stage): candidates, M4 records and the alignments with their strings equal the oracle's"""
+    from necat_amd import capi
+    d, rs, nv = util.make_dataset(tmp_path, genome=260_000, coverage=5.0, seed=41, err=0.12, mean_len=130_000.0, sd_len=40_000.0,
+                                  min_len=60_000)
+    assert int(rs.sizes.max()) > 150_000 and nv == 1
+    kw = dict(util.FAST, kmer_size=13)
+    for job in (0, 1):
+        o = ora.options(**dict(kw, job=job, binary_output=1))
+        out = os.path.join(str(tmp_path), "o%d.out" % job)
+        ora.pm_main(o, 0, d, out)
+        cands, m4 = capi.pm_main(ctx, capi.default_options(**dict(kw, job=job, binary_output=1)), 0, d)
+        if job == 0:
+            assert sorted(bytes(r) for r in capi.pack_candidates(cands).astype("<u4")) == ora.sorted_records(out, 28)
+            assert cands.shape[0] > 5
+            keep = cands
+        else:
+            ref = np.frombuffer(open(out, "rb").read(), dtype=capi.M4_DTYPE)
+            assert util.m4_key_rows(m4) == util.m4_key_rows(ref) and m4.shape[0] > 3
+            assert int((ref["qend"] - ref["qoff"]).max()) > 60_000
+    vol = ctx.load_volume(os.path.join(d, "vol0"))
+    opt = capi.default_options(**dict(kw, job=1))
+    sel = keep[:12]
+    aln, ops, off = ctx.onc_align_batch(vol, vol, 0, 0, sel, opt, 4)
+    al = ora.Aligner(opt.error)
+    for i, c in enumerate(sel):
+        q = rs.codes[rs.offsets[c["qid"]]: rs.offsets[c["qid"]] + rs.sizes[c["qid"]]]
+        if c["qdir"] == 1:
+            q = (3 - q[::-1]).astype(np.uint8)
+        t = rs.codes[rs.offsets[c["sid"]]: rs.offsets[c["sid"]] + rs.sizes[c["sid"]]]
+        ok, a0, a1, b0, b1, ident, qa, ta = al.align(q, int(c["qoff"]), t, int(c["soff"]), opt.align_size_cutoff, 4)
+        a = aln[i]
+        assert (bool(a["ok"]), int(a["qoff"]), int(a["qend"]), int(a["toff"]), int(a["tend"]), float(a["ident_perc"])) == (ok, a0, a1, b0, b1, ident), i
+        assert capi.gapped_strings(ops[int(off[i]):int(off[i + 1])], int(a["align_size"]), q, a0, t, b0) == (qa, ta), i
+    al.close(); vol.free()
+
