@@ -300,11 +300,12 @@ k_subpart(const u64* __restrict__ part, const u64* __restrict__ bucket_start, u3
     }
 }
 
+template <int T = 256>
 NECAT_D void slice_count(const u64* __restrict__ part2, u64 lo, u64 hi, u32* cnt)
 {
-    for (int i = threadIdx.x; i < kSlice; i += 256) cnt[i] = 0;
+    for (int i = threadIdx.x; i < kSlice; i += T) cnt[i] = 0;
     __syncthreads();
-    for (u64 e = lo + threadIdx.x; e < hi; e += 256) atomicAdd(&cnt[(u32)(part2[e] >> kOffsetBits) & (kSlice - 1)], 1u);
+    for (u64 e = lo + threadIdx.x; e < hi; e += T) atomicAdd(&cnt[(u32)(part2[e] >> kOffsetBits) & (kSlice - 1)], 1u);
     __syncthreads();
 }
 
@@ -343,13 +344,14 @@ k_bucket_base(const u32* __restrict__ bucket_kept, u32 nb, u64* __restrict__ buc
 }
 
 // kmer_stats of the slice + its part of the offset list (tmp: same layout, order inside a k-mer not yet fixed)
-__global__ void __launch_bounds__(256)
+template <int T>
+__global__ void __launch_bounds__(T)
 k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u32 max_occ, const u64* __restrict__ bucket_base,
              const u32* __restrict__ kept_tot, u64* __restrict__ kmer_stats, u32* __restrict__ tmp, u64* __restrict__ offset_list)
 {
     __shared__ u32 cnt[kSlice];      // occurrences per table entry of the slice
     __shared__ u32 cur[kSlice];      // start of the entry's group inside the slice, then its fill cursor
-    __shared__ u32 wtot[4];
+    __shared__ u32 wtot[T / 64];
     __shared__ u64 s_base;
     const u64 s = blockIdx.x;
     const u64 lo = sub_start[s], hi = sub_start[s + 1];
@@ -362,11 +364,12 @@ k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u
     }
     __syncthreads();
     const u64 base = s_base;
-    slice_count(part2, lo, hi, cnt);
-    // exclusive scan of the kept counts: thread t owns entries [16 t, 16 t + 16)
-    u32 c[16], sum = 0;
+    slice_count<T>(part2, lo, hi, cnt);
+    // exclusive scan of the kept counts: thread t owns entries [E t, E t + E)
+    constexpr int E = kSlice / T;
+    u32 c[E], sum = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { c[i] = filtered_count(cnt[threadIdx.x * 16 + i], max_occ); sum += c[i]; }
+    for (int i = 0; i < E; ++i) { c[i] = filtered_count(cnt[threadIdx.x * E + i], max_occ); sum += c[i]; }
     u32 incl = sum;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o); if (lane >= o) incl += v; }
@@ -375,23 +378,23 @@ k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u
     u32 run = incl - sum;
     for (int w = 0; w < wave; ++w) run += wtot[w];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { cur[threadIdx.x * 16 + i] = run; run += c[i]; }
+    for (int i = 0; i < E; ++i) { cur[threadIdx.x * E + i] = run; run += c[i]; }
     __syncthreads();
     // kmer_stats[h] = cnt<<34 | start, 0 for absent / over-represented k-mers (lookup_table.c:43-51, :94-113)
     u64* stats = kmer_stats + s * kSlice;
-    for (int i = threadIdx.x; i < kSlice; i += 256) {
+    for (int i = threadIdx.x; i < kSlice; i += T) {
         const u32 k = filtered_count(cnt[i], max_occ);
         stats[i] = k ? ((u64)k << kOffsetBits) | (base + cur[i]) : 0ULL;
     }
     __syncthreads();
-    for (u64 e = lo + threadIdx.x; e < hi; e += 256) {
+    for (u64 e = lo + threadIdx.x; e < hi; e += T) {
         const u64 rec = part2[e];
         const u32 h = (u32)(rec >> kOffsetBits) & (kSlice - 1);
         if (filtered_count(cnt[h], max_occ)) tmp[base + atomicAdd(&cur[h], 1u)] = (u32)(rec & kOffsetMask);
     }
     __syncthreads();        // cur[h] is now the END of the group; the tmp writes of this workgroup are visible to it
     // radix_sort is stable (hash_list_bucket_sort.c:134): offsets ascend inside a k-mer
-    for (u64 e = lo + threadIdx.x; e < hi; e += 256) {
+    for (u64 e = lo + threadIdx.x; e < hi; e += T) {
         const u64 rec = part2[e];
         const u32 h = (u32)(rec >> kOffsetBits) & (kSlice - 1);
         const u32 k = filtered_count(cnt[h], max_occ);
