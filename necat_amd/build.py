@@ -1,9 +1,9 @@
-"""Build helpers: compile the gfx950 library, the oc2pmov/oc2pm host programs and the test oracle.
+"""Build helpers: compile the gfx950 library and the host programs on top of its C ABI.
 
 Everything is built IN-TREE (the .so / binaries travel to the GPU box with the source snapshot):
   necat_amd/csrc/libnecat_hip.so   hipcc --offload-arch=gfx950   (the product)
   necat_amd/csrc/oc2pmov, oc2pm    host programs on top of the C ABI
-  oracle/liboracle.so, oc2pmov_oracle, _ref/*   test infrastructure (oracle/Makefile)
+The test oracle (oracle/) is built by tests/oracle_build.py - this package knows nothing about it.
 """
 from __future__ import annotations
 
@@ -20,12 +20,17 @@ OC2PMOV = os.path.join(CSRC, "oc2pmov")
 OC2PM = os.path.join(CSRC, "oc2pm")
 OC2MKDB = os.path.join(CSRC, "oc2mkdb")
 OC2PCAN = os.path.join(CSRC, "oc2pcan")
-ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_LIB = os.path.join(ORACLE_DIR, "liboracle.so")
 
 HIP_SOURCES = ["necat_hip.hip"]
-HIP_DEPS = ["necat_hip.hip", "runtime.h", "dev_common.h", "index_kernels.h", "seed_core.h", "seed_kernels.h",
-            "dp_core.h", "ext_core.h", "ext_kernels.h", os.path.join(ROOT, "include", "necat_hip.h")]
+
+
+def _hip_deps():
+    """every header next to the translation unit + the public header: editing any of them rebuilds the library"""
+    import glob
+    return HIP_SOURCES + sorted(os.path.basename(h) for h in glob.glob(os.path.join(CSRC, "*.h"))) + \
+        sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
+
+
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 
 
@@ -56,7 +61,7 @@ def _run(cmd, cwd=None):
 
 
 def build_hip(force: bool = False) -> str:
-    if force or _stale(LIB, HIP_DEPS):
+    if force or _stale(LIB, _hip_deps()):
         _run([_hipcc()] + HIPCC_FLAGS + ["-shared", "-o", LIB] + HIP_SOURCES, cwd=CSRC)
     return LIB
 
@@ -75,20 +80,9 @@ def build_cli(force: bool = False):
     return OC2PMOV, OC2PM
 
 
-def build_oracle(force: bool = False) -> str:
-    """liboracle.so (+ oracle/_ref when /root/reference is present).  Building the checker is not
-    using it: only tests/, smoke() and bench.py's cpu_baseline leg load these."""
-    args = ["make", "-s", "-C", ORACLE_DIR, "all"]
-    if force:
-        _run(["make", "-s", "-C", ORACLE_DIR, "clean"])
-    _run(args)
-    return ORACLE_LIB
-
-
 def build_all(force: bool = False):
     build_hip(force)
     build_cli(force)
-    build_oracle(False)
 
 
 if __name__ == "__main__":

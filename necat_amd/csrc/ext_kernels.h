@@ -55,6 +55,23 @@ struct ExtLists {
     u8* task_ops = nullptr;   // per-task alignment columns (necat_onc_align_batch), nullptr = not kept
 };
 
+// Round bookkeeping done by the first kernel of a round's list-A chain (k_ext_frag): the host never synchronises
+// with the device inside the round loop (run_batch) - it learns the sizes of the round's lists from a pinned
+// ring the kernel publishes to, and sizes the NEXT round's grids from them (a candidate has one block at a time,
+// so a round's lists are never longer than what was alive a round earlier); every kernel reads the exact list
+// size from device memory and workgroups beyond it exit.
+struct RoundPub { u32 nA, nB; unsigned long long seq; };
+struct RoundCtl {
+    const u32* count = nullptr;     // (nA, nB) of THIS round's lists, final when the kernel starts
+    u32* zero = nullptr;            // (nA, nB) of the list buffer the round after next appends to: reset here
+    RoundPub* pub = nullptr;        // host-visible slot of this round
+    unsigned long long seq = 0;
+    u32* zero_bins = nullptr;       // list B chain: the size-sort counters of the slot, reset for their next use
+};
+
+// exact number of work items of a launch: host-known (n_dev == nullptr) or read from the device-side list counter
+NECAT_D u32 live_count(u32 n_host, const u32* __restrict__ n_dev) { return n_dev ? *n_dev : n_host; }
+
 // Append the scheduled block of task `ti` to list A (blocks of at most 512 x 512: the full blocks of an
 // extension and the last blocks that fit - 8 words, 8 lanes per block) or list B (bigger last blocks, up to
 // 794 x 794 - 13 words, 16 lanes per block: 3x the cost, so nothing that fits list A goes here);
@@ -133,9 +150,23 @@ k_items_scatter(const BlockItem* __restrict__ items, u32 n, u32* __restrict__ bi
 // words [0,NW) = ~lo planes, [NW,2NW) = ~hi planes, [2NW, 2NW+TW) = target 2-bit words
 template <int NW, int TW>
 __global__ void __launch_bounds__(256)
-k_ext_frag(DevVolume reads, DevVolume ref, const BlockItem* __restrict__ items, u32 n, u64* __restrict__ frag)
+k_ext_frag(DevVolume reads, DevVolume ref, const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u64* __restrict__ frag,
+           RoundCtl ctl)
 {
     constexpr int FW = 2 * NW + TW, CH = NW + TW;
+    const u32 n = live_count(n_host, n_dev);
+    if (blockIdx.x == 0) {
+        if (ctl.zero_bins) for (int i = threadIdx.x; i < 1024; i += blockDim.x) ctl.zero_bins[i] = 0u;
+        if (threadIdx.x == 0 && ctl.pub) {
+            const u32 a = ctl.count[0], b = ctl.count[1];
+            ctl.zero[0] = 0u; ctl.zero[1] = 0u;
+            volatile RoundPub* p = ctl.pub;
+            p->nA = a; p->nB = b;
+            __threadfence_system();
+            p->seq = ctl.seq;
+            __threadfence_system();
+        }
+    }
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const u64 grp = gid / (64 * CH);
     const u32 r = (u32)(gid % (64 * CH));
@@ -218,10 +249,11 @@ NECAT_D ulonglong2* slab_records(char* slab) { return reinterpret_cast<ulonglong
 // register resident (dp_core.h) and the only memory traffic is the coalesced band store.
 template <int NW, int TW, int COLS, bool FULL>
 __global__ void __launch_bounds__(64)
-k_myers(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
+k_myers(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
         double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, u32 epoch, u32 item_base)
 {
     constexpr int FW = 2 * NW + TW;
+    const u32 n = live_count(n_host, n_dev);
     const u32 grp = blockIdx.x + (item_base >> 6);      // item_base is a multiple of 64; n = end of this launch's range
     const int lane = threadIdx.x;
     const u64 item = (u64)grp * 64 + lane;
@@ -271,10 +303,12 @@ NECAT_D int dpp_from_lane_below(int v)   // lane i receives v of lane i-1 (withi
 // itself and the NW pass is skipped: half the latency.
 template <int NW, int TW, int COLS, int G, bool SINGLE = false>
 __global__ void __launch_bounds__(64)
-k_myers_coop(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
+k_myers_coop(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
              double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, u32 epoch, u32 item_base)
 {
     constexpr int FW = 2 * NW + TW, BPW = 64 / G;
+    const u32 n = live_count(n_host, n_dev);
+    if ((u64)item_base + (u64)blockIdx.x * BPW >= n) return;      // a whole wave beyond the list (grids are sized from an upper bound)
     const int lane = threadIdx.x, sub = lane / G, b = lane % G;
     const bool filter = (epoch >> 30) == 0;      // bit 30 of the epoch argument switches the store filter off (A/B tests)
     epoch &= 0x3fffffffu;
@@ -433,11 +467,12 @@ struct SameReader {   // query fragment element i == target fragment element i ?
 // EXPORT = false: fold the block into its ExtTask.  EXPORT = true (batch API): keep the ops.
 template <int NW, int TW, int COLS, int MAXOPS, bool EXPORT>
 __global__ void __launch_bounds__(64)
-k_traceback(const BlockItem* __restrict__ items, u32 n, const u64* __restrict__ frag, const char* __restrict__ slabs, size_t slab_bytes,
+k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, const u64* __restrict__ frag, const char* __restrict__ slabs, size_t slab_bytes,
             const BlockResult* __restrict__ results, u8* __restrict__ ops_pool, ExtTask* __restrict__ tasks, int tail_match_len,
             i32* __restrict__ n_ops_out, int* __restrict__ err_flag, ExtLists next, u32 epoch)
 {
     constexpr int FW = 2 * NW + TW;
+    const u32 n = live_count(n_host, n_dev);
     const u32 grp = blockIdx.x;
     const int lane = threadIdx.x;
     const u64 item = (u64)grp * 64 + lane;

@@ -113,7 +113,11 @@ int necat_ctx_create(int device_id, necat_ctx** out)
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream_a) != hipSuccess ||
         hipStreamCreate(&ctx->stream_b) != hipSuccess || hipStreamCreate(&ctx->stream_c) != hipSuccess ||
         hipStreamCreate(&ctx->stream_copy) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
-    for (int i = 0; i < 20; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
+    for (int i = 0; i < kNumEvents; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
+    // the list sizes of the extension rounds reach the host through this pinned ring (RoundPub, ext_kernels.h)
+    if (hipHostMalloc(&ctx->round_ring, kRoundRing * sizeof(RoundPub), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(&ctx->round_ring_dev, ctx->round_ring, 0) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
+    memset(ctx->round_ring, 0, kRoundRing * sizeof(RoundPub));
     *out = ctx;
     return NECAT_OK;
 }
@@ -127,7 +131,8 @@ void necat_ctx_destroy(necat_ctx* ctx)
     for (auto& b : ctx->scratch) if (b.p) (void)hipFree(b.p);
     for (auto& b : ctx->idx_cache) if (b.p) (void)hipFree(b.p);
     delete (cns::Scratch*)ctx->cns_scratch;
-    for (int i = 0; i < 20; ++i) (void)hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < kNumEvents; ++i) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->round_ring) (void)hipHostFree(ctx->round_ring);
     (void)hipStreamDestroy(ctx->stream); (void)hipStreamDestroy(ctx->stream_a); (void)hipStreamDestroy(ctx->stream_b); (void)hipStreamDestroy(ctx->stream_c);
     (void)hipStreamDestroy(ctx->stream_copy);
     delete ctx;
@@ -653,23 +658,26 @@ namespace {
 // blocks of a round sit in list A (<= 512 x 512) or list B (bigger last blocks).  The chain that bounds the
 // run is the list-A chain (frag -> DP -> traceback, round after round), so list B trails it by one round:
 //
-//     round r    stream a:  A(r)  = blocks of lists[r % 3].A      appends successors to lists[(r + 1) % 3]
-//                stream b:  B(r)  = blocks of lists[r % 3].B      appends successors to lists[(r + 2) % 3]
-//     round r+1 starts when A(r) and B(r - 1) are done: B(r) runs under A(r + 1).
+//     round r    stream a:  A(r)  = blocks of lists[r % 4].A      appends successors to lists[(r + 1) % 4]
+//                stream b:  B(r)  = blocks of lists[r % 4].B      appends successors to lists[(r + 2) % 4]
+//     lists[r] is complete when A(r - 1) and B(r - 2) are done; B(r) runs under A(r + 1).
 //
-// Three list buffers, because lists[(r + 2) % 3] receives appends (from B(r), later from A(r + 1)) while
-// lists[(r + 1) % 3] is still being filled by A(r) and lists[r % 3] is being consumed.  A successor planned by a
-// list-B block simply starts one round later.  B(r) and B(r - 1) run side by side on two streams with two
-// sets of buffers and band pools (list A's pool is reused by A(r + 1) while they run).
+// The host never waits for the device inside the loop.  The first kernel of A(r) publishes the sizes of lists[r]
+// to a pinned ring and resets the counters of lists[(r + 2) % 4]; the host, one round behind, launches B(r - 1)
+// with its exact size and A(r) with an upper bound (what was alive a round earlier - every kernel reads the exact
+// size on the device); stream-to-stream order is kept by events.  Four list buffers: lists[(r + 2) % 4] receives
+// appends from B(r) and A(r + 1) while lists[(r + 1) % 4] is filled by A(r) and B(r - 1), lists[r % 4] is consumed by
+// A(r) and B(r), and lists[(r - 1) % 4] may still be read by B(r - 1).  B(r) and B(r - 1) run side by side on two
+// streams with two sets of buffers and band pools (list A's pool is reused by A(r + 1) while they run).
 struct Batch {
-    ExtTask* tasks; u32* count;            // count[3][2]: (nA, nB) per list buffer
-    BlockItem* itemsA[3]; BlockItem* itemsB[3];
+    ExtTask* tasks; u32* count;            // count[4][2]: (nA, nB) per list buffer
+    BlockItem* itemsA[4]; BlockItem* itemsB[4];
     u64* fragA; u8* opsA; BlockResult* resA;
     // list B: two sets (round parity) - B(r) and B(r - 1) are independent and run side by side
     u64* fragB[2]; u8* opsB[2]; BlockResult* resB[2];
     BlockItem* sortedB[2]; u32* bins[2];    // list B of the round, sorted by size
     hipStream_t sa, sb[2];
-    hipEvent_t a0, a1, a2, b0[2], b1[2], b2[2];
+    hipEvent_t a0[4], a1[4], a2[4], b0[2], b1[2], b2[2];
     u64 base; u32 n;
 };
 
@@ -680,135 +688,191 @@ struct ExtShared {
     u8* task_ops = nullptr;      // alignment columns per task (necat_onc_align_batch)
 };
 
-// all rounds of one batch (its first blocks are already in lists[0], appended by k_ext_init on stream a)
+// all rounds of one batch (its first blocks are already in lists[0], appended by k_ext_init on stream a; every list
+// counter but lists[0]'s is zero)
 int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch& c, const ExtShared& X)
 {
+    struct Cnt { u32 nA, nB; };
+    std::vector<Cnt> hist;                      // published sizes of lists[r]
+    std::vector<u8> a_timed;                    // A(r) ran its DP + traceback kernels (events recorded)
+    const unsigned long long seq0 = ctx->round_seq;
+    volatile RoundPub* ring = (volatile RoundPub*)ctx->round_ring;
+    RoundPub* ring_dev = (RoundPub*)ctx->round_ring_dev;
     bool b_pending[2] = {false, false};
     u32 b_blocks[2] = {0, 0};
-    u32 prev_nA = 0;
     double last_wall = wall_ms();
+    auto wait_pub = [&](u32 r, Cnt& out) -> int {
+        const unsigned long long want = seq0 + r + 1;
+        volatile RoundPub* e = &ring[(seq0 + r) % kRoundRing];
+        const double t0 = wall_ms();
+        for (u64 spin = 0; e->seq != want; ++spin) {
+            if ((spin & 0xfffff) == 0xfffff) {
+                // a failed kernel never publishes: look at the stream instead of spinning forever
+                const hipError_t q = hipStreamQuery(c.sa);
+                if (q != hipSuccess && q != hipErrorNotReady) return set_err(ctx, NECAT_ERR_DEVICE, "extension round %u failed: %s", r, hipGetErrorString(q));
+                if (wall_ms() - t0 > 120e3) return set_err(ctx, NECAT_ERR_DEVICE, "extension round %u: no progress for 120 s", r);
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        out.nA = e->nA; out.nB = e->nB;
+        return NECAT_OK;
+    };
+    auto account_a = [&](u32 r) {
+        if (r >= a_timed.size() || !a_timed[r]) return;
+        const int q = r % 4;
+        const u32 nA = hist[r].nA;
+        const double mA = ev_ms(c.a0[q], c.a1[q]), tA = ev_ms(c.a1[q], c.a2[q]);
+        ctx->tm.myers_ms += mA; ctx->tm.traceback_ms += tA;
+        if (nA > g_single_pass) {      // the two-pass instantiation k_myers_coop<8,16,512,8,false> (bench.py's roofline kernel)
+            ctx->tm.myersA_ms += mA; ctx->tm.tracebackA_ms += tA; ctx->tm.myersA_launches += 1; ctx->tm.myersA_blocks += nA;
+        }
+        if (nA > ctx->tm.myersA_big_blocks) { ctx->tm.myersA_big_blocks = nA; ctx->tm.myersA_big_ms = mA; }
+        ctx->tm.myers_launches += 1; ctx->tm.myers_blocks += nA;
+        if (g_trace & 1) {
+            const double now = wall_ms();
+            fprintf(stderr, "[necat] batch@%lu round %3u: list A %7u blocks  myers %.3f ms traceback %.3f ms | host wall since last %.3f ms\n",
+                    (unsigned long)c.base, r, nA, mA, tA, now - last_wall);
+            last_wall = now;
+        }
+        a_timed[r] = 0;
+    };
     auto account_b = [&](int slot) {
+        if (!b_pending[slot]) return;
         const double mB = ev_ms(c.b0[slot], c.b1[slot]), tB = ev_ms(c.b1[slot], c.b2[slot]);
         ctx->tm.myers_ms += mB; ctx->tm.traceback_ms += tB;
         ctx->tm.myers_launches += 1; ctx->tm.myers_blocks += b_blocks[slot];
         if (g_trace & 1) fprintf(stderr, "[necat]          list B: %7u blocks  myers %.3f ms traceback %.3f ms\n", b_blocks[slot], mB, tB);
         b_pending[slot] = false;
     };
-    int idle = 0;
-    for (u32 r = 0;; ++r) {
-        // ---- A(r - 1) and B(r - 2) are done: lists[r % 3] is complete
-        NECAT_HIP(ctx, hipStreamSynchronize(c.sa));
-        if (prev_nA) {
-            const double mA = ev_ms(c.a0, c.a1), tA = ev_ms(c.a1, c.a2);
-            ctx->tm.myers_ms += mA; ctx->tm.traceback_ms += tA;
-            if (prev_nA > g_single_pass) {      // the two-pass instantiation k_myers_coop<8,16,512,8,false> (bench.py's roofline kernel)
-                ctx->tm.myersA_ms += mA; ctx->tm.tracebackA_ms += tA; ctx->tm.myersA_launches += 1; ctx->tm.myersA_blocks += prev_nA;
-            }
-            if (prev_nA > ctx->tm.myersA_big_blocks) { ctx->tm.myersA_big_blocks = prev_nA; ctx->tm.myersA_big_ms = mA; }
-            ctx->tm.myers_launches += 1; ctx->tm.myers_blocks += prev_nA;
-            if (g_trace & 1) {
-                const double now = wall_ms();
-                fprintf(stderr, "[necat] batch@%lu round %3u: list A %7u blocks  myers %.3f ms traceback %.3f ms | round wall %.3f ms\n",
-                        (unsigned long)c.base, r - 1, prev_nA, mA, tA, now - last_wall);
-                last_wall = now;
-            }
+    // ---- B(q): exact size known (published by A(q)'s first kernel)
+    auto launch_b = [&](u32 q, u32 nB) -> int {
+        const int slot = q & 1, cur = q % 4, nxt2 = (q + 2) % 4;
+        account_b(slot);                                        // B(q - 2), the previous user of this slot, is done (A(q + 0) started after it)
+        const u32 gB = (nB + 63) / 64;
+        // small lists (the late rounds, where a round lasts as long as its slowest chain) get alternating streams so
+        // that B(q) need not queue behind B(q - 1); big ones stay in one stream - three busy chains only add contention
+        hipStream_t sb = c.sb[nB < 4096 ? slot : 0];
+        DevBuf& poolB = ctx->scratch[slot ? SC_EXT_MATB2 : SC_EXT_MATB];
+        if ((size_t)gB * kSlabB > poolB.cap) {
+            const size_t need = (size_t)gB * kSlabB;
+            int rc = ensure_zeroed(ctx, poolB, need + need / 4, sb);
+            if (rc) return rc;
         }
-        if (b_pending[r & 1]) { NECAT_HIP(ctx, hipEventSynchronize(c.b2[r & 1])); account_b(r & 1); }
-        const int cur = r % 3, nxt = (r + 1) % 3, nxt2 = (r + 2) % 3;
-        u32 cnt[2] = {0, 0};
-        NECAT_HIP(ctx, hipMemcpyAsync(cnt, c.count + 2 * cur, 8, hipMemcpyDeviceToHost, c.sa));
-        NECAT_HIP(ctx, hipMemsetAsync(c.count + 2 * nxt2, 0, 8, c.sa));      // nobody appends to lists[(r + 2) % 3] before B(r), launched below
-        NECAT_HIP(ctx, hipStreamSynchronize(c.sa));
-        const u32 nA = cnt[0], nB = cnt[1];
-        prev_nA = nA;
-        if (nA + nB == 0) {
-            // nothing scheduled: over, unless a list-B round still in flight plans successors
-            if (!b_pending[0] && !b_pending[1]) { if (++idle >= 2) break; }
-            continue;
-        }
-        idle = 0;
-        ctx->tm.rounds += 1;
-        const u32 gA = (nA + 63) / 64, gB = (nB + 63) / 64;
+        char* slabsB = (char*)poolB.p;
+        const BlockItem* itB = c.itemsB[cur];
+        const u32* d_nB = c.count + 2 * cur + 1;
+        NECAT_HIP(ctx, hipStreamWaitEvent(sb, c.a0[cur], 0));     // lists[q] complete (A(q - 1) done), counters of lists[q + 2] reset
+        NECAT_HIP(ctx, hipStreamWaitEvent(sb, c.b2[slot], 0));    // B(q - 2): appended to lists[q], previous user of the slot's buffers
+        // (B(q - 1) on the other stream reads lists[q - 1] and appends to lists[q + 1]; this round appends to lists[q + 2]:
+        // four list buffers keep the two apart - with three, lists[q + 2] WAS lists[q - 1])
         const u32 epoch = ++ctx->epoch & 0x3fffffu;
+        ExtLists next; next.count = c.count + 2 * nxt2; next.itemsA = c.itemsA[nxt2]; next.itemsB = c.itemsB[nxt2]; next.task_ops = X.task_ops;
+        // (below ~2 k blocks every wave is resident at once and the round lasts as long as its longest walk: order is irrelevant)
+        if (nB >= 2048 && g_sort_b) {
+            hipLaunchKernelGGL(k_items_hist, dim3(grid_for(nB, 256)), dim3(256), 0, sb, itB, nB, c.bins[slot]);
+            hipLaunchKernelGGL(k_items_scan, dim3(1), dim3(1024), 0, sb, c.bins[slot]);
+            hipLaunchKernelGGL(k_items_scatter, dim3(grid_for(nB, 256)), dim3(256), 0, sb, itB, nB, c.bins[slot], c.sortedB[slot]);
+            NECAT_CHECK_LAUNCH(ctx, "k_items_sort");
+            itB = c.sortedB[slot];
+        }
+        RoundCtl ctl; ctl.zero_bins = c.bins[slot];
+        hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, sb,
+                           drd, dref, itB, nB, d_nB, c.fragB[slot], ctl);
+        NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
+        NECAT_HIP(ctx, hipEventRecord(c.b0[slot], sb));
+        if (nB <= g_single_pass && nB <= g_coop_threshold)
+            hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16, true>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB, d_nB,
+                               (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch, 0u);
+        else if (nB <= g_coop_threshold)
+            hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB, d_nB,
+                               (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
+        else
+            hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB, d_nB,
+                               (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch, 0u);
+        NECAT_CHECK_LAUNCH(ctx, "k_myers<B>");
+        NECAT_HIP(ctx, hipEventRecord(c.b1[slot], sb));
+        hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB, d_nB,
+                           (const u64*)c.fragB[slot], (const char*)slabsB, kSlabB, (const BlockResult*)c.resB[slot], c.opsB[slot], c.tasks, X.tail_match_len,
+                           (i32*)nullptr, X.d_err, next, epoch);
+        NECAT_CHECK_LAUNCH(ctx, "k_traceback<B>");
+        NECAT_HIP(ctx, hipEventRecord(c.b2[slot], sb));
+        b_pending[slot] = true; b_blocks[slot] = nB;
+        return NECAT_OK;
+    };
+    // ---- A(r): grid sized by an upper bound, the kernels read the exact size of lists[r]
+    auto launch_a = [&](u32 r, u32 bound) -> int {
+        const int cur = r % 4, nxt = (r + 1) % 4, nxt2 = (r + 2) % 4;
+        const u32 gA = (bound + 63) / 64;
         // the band pools are sized by what a round needs (round 0 of the first call sets them: 35 GB instead of the
         // 76 GB worst case "every block in list B" at E. coli size - hipMalloc costs ~13 ms per GB)
         if ((size_t)gA * kSlabA > ctx->scratch[SC_EXT_MAT].cap) {
             const size_t need = (size_t)gA * kSlabA;
             int rc = ensure_zeroed(ctx, ctx->scratch[SC_EXT_MAT], need + need / 8, c.sa);
             if (rc) return rc;
-            NECAT_HIP(ctx, hipStreamSynchronize(c.sa));
-        }
-        const int slot = r & 1;                                                // B(r - 2), the previous user of this slot, is done
-        DevBuf& poolB = ctx->scratch[slot ? SC_EXT_MATB2 : SC_EXT_MATB];
-        if ((size_t)gB * kSlabB > poolB.cap) {
-            const size_t need = (size_t)gB * kSlabB;
-            int rc = ensure_zeroed(ctx, poolB, need + need / 4, c.sa);
-            if (rc) return rc;
-            NECAT_HIP(ctx, hipStreamSynchronize(c.sa));
         }
         char* slabsA = (char*)ctx->scratch[SC_EXT_MAT].p;
-        char* slabsB = (char*)poolB.p;
-        const BlockItem* itA = c.itemsA[cur]; const BlockItem* itB = c.itemsB[cur];
-        if (nA) {
-            ExtLists next; next.count = c.count + 2 * nxt; next.itemsA = c.itemsA[nxt]; next.itemsB = c.itemsB[nxt]; next.task_ops = X.task_ops;
-            hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)gA * 64 * (kWordsA + kTWordsA), 256)), dim3(256), 0, c.sa,
-                               drd, dref, itA, nA, c.fragA);
-            NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<A>");
-            NECAT_HIP(ctx, hipEventRecord(c.a0, c.sa));
-            if (nA <= g_single_pass && nA <= g_coop_threshold)
-                hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8, true>), dim3((nA + 7) / 8), dim3(64), 0, c.sa, itA, nA,
-                                   (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
-            else if (nA <= g_coop_threshold)
-                hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((nA + 7) / 8), dim3(64), 0, c.sa, itA, nA,
-                                   (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
-            else
-                hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, false>), dim3(gA), dim3(64), 0, c.sa, itA, nA,   // list A also holds last blocks <= 512 x 512
-                                   (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
-            NECAT_CHECK_LAUNCH(ctx, "k_myers<A>");
-            NECAT_HIP(ctx, hipEventRecord(c.a1, c.sa));
-            hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false>), dim3(gA), dim3(64), 0, c.sa, itA, nA,
-                               (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
-                               (i32*)nullptr, X.d_err, next, epoch);
-            NECAT_CHECK_LAUNCH(ctx, "k_traceback<A>");
-            NECAT_HIP(ctx, hipEventRecord(c.a2, c.sa));
+        const BlockItem* itA = c.itemsA[cur];
+        const u32* d_nA = c.count + 2 * cur;
+        if (r >= 2) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, c.b2[r & 1], 0));        // B(r - 2) appended to lists[r]
+        const u32 epoch = ++ctx->epoch & 0x3fffffu;
+        RoundCtl ctl; ctl.count = d_nA; ctl.zero = c.count + 2 * nxt2; ctl.seq = seq0 + r + 1; ctl.pub = ring_dev + (seq0 + r) % kRoundRing;
+        hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)std::max(gA, 1u) * 64 * (kWordsA + kTWordsA), 256)), dim3(256), 0, c.sa,
+                           drd, dref, itA, bound, d_nA, c.fragA, ctl);
+        NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<A>");
+        NECAT_HIP(ctx, hipEventRecord(c.a0[cur], c.sa));
+        a_timed.push_back(0);
+        if (!bound) return NECAT_OK;
+        ExtLists next; next.count = c.count + 2 * nxt; next.itemsA = c.itemsA[nxt]; next.itemsB = c.itemsB[nxt]; next.task_ops = X.task_ops;
+        if (bound <= g_single_pass && bound <= g_coop_threshold)
+            hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8, true>), dim3((bound + 7) / 8), dim3(64), 0, c.sa, itA, bound, d_nA,
+                               (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
+        else if (bound <= g_coop_threshold)
+            hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((bound + 7) / 8), dim3(64), 0, c.sa, itA, bound, d_nA,
+                               (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
+        else
+            hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, false>), dim3(gA), dim3(64), 0, c.sa, itA, bound, d_nA,   // list A also holds last blocks <= 512 x 512
+                               (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
+        NECAT_CHECK_LAUNCH(ctx, "k_myers<A>");
+        NECAT_HIP(ctx, hipEventRecord(c.a1[cur], c.sa));
+        hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false>), dim3(gA), dim3(64), 0, c.sa, itA, bound, d_nA,
+                           (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
+                           (i32*)nullptr, X.d_err, next, epoch);
+        NECAT_CHECK_LAUNCH(ctx, "k_traceback<A>");
+        NECAT_HIP(ctx, hipEventRecord(c.a2[cur], c.sa));
+        a_timed[r] = 1;
+        return NECAT_OK;
+    };
+    int rc = NECAT_OK;
+    u32 launched = 0;
+    for (u32 r = 0;; ++r) {
+        u32 bound = c.n;
+        if (r > 0) {
+            Cnt prev;
+            if ((rc = wait_pub(r - 1, prev))) break;          // A(r - 1) has started: A(r - 2) and B(r - 3) are done
+            hist.push_back(prev);
+            if (r >= 2) account_a(r - 2);
+            const u32 nB2 = r >= 2 ? hist[r - 2].nB : 0;     // B(r - 2) may still be running: its successors join lists[r]
+            if (prev.nA + prev.nB + nB2 == 0) break;          // nothing alive
+            if (prev.nB) { if ((rc = launch_b(r - 1, prev.nB))) break; }
+            bound = prev.nA + nB2;
         }
-        if (nB) {
-            // small lists (the late rounds, where a round lasts as long as its slowest chain) get alternating streams so
-            // that B(r) need not queue behind B(r - 1); big ones stay in one stream - three busy chains only add contention
-            hipStream_t sb = c.sb[nB < 4096 ? slot : 0];
-            ExtLists next; next.count = c.count + 2 * nxt2; next.itemsA = c.itemsA[nxt2]; next.itemsB = c.itemsB[nxt2]; next.task_ops = X.task_ops;
-            // (below ~2 k blocks every wave is resident at once and the round lasts as long as its longest walk: order is irrelevant)
-            if (nB >= 2048 && g_sort_b) {
-                NECAT_HIP(ctx, hipMemsetAsync(c.bins[slot], 0, 1024 * 4, sb));
-                hipLaunchKernelGGL(k_items_hist, dim3(grid_for(nB, 256)), dim3(256), 0, sb, itB, nB, c.bins[slot]);
-                hipLaunchKernelGGL(k_items_scan, dim3(1), dim3(1024), 0, sb, c.bins[slot]);
-                hipLaunchKernelGGL(k_items_scatter, dim3(grid_for(nB, 256)), dim3(256), 0, sb, itB, nB, c.bins[slot], c.sortedB[slot]);
-                NECAT_CHECK_LAUNCH(ctx, "k_items_sort");
-                itB = c.sortedB[slot];
-            }
-            hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, sb,
-                               drd, dref, itB, nB, c.fragB[slot]);
-            NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
-            NECAT_HIP(ctx, hipEventRecord(c.b0[slot], sb));
-            if (nB <= g_single_pass && nB <= g_coop_threshold)
-                hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16, true>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB,
-                                   (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch, 0u);
-            else if (nB <= g_coop_threshold)
-                hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB,
-                                   (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
-            else
-                hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB,
-                                   (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch, 0u);
-            NECAT_CHECK_LAUNCH(ctx, "k_myers<B>");
-            NECAT_HIP(ctx, hipEventRecord(c.b1[slot], sb));
-            hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB,
-                               (const u64*)c.fragB[slot], (const char*)slabsB, kSlabB, (const BlockResult*)c.resB[slot], c.opsB[slot], c.tasks, X.tail_match_len,
-                               (i32*)nullptr, X.d_err, next, epoch);
-            NECAT_CHECK_LAUNCH(ctx, "k_traceback<B>");
-            NECAT_HIP(ctx, hipEventRecord(c.b2[slot], sb));
-            b_pending[slot] = true; b_blocks[slot] = nB;
-        }
+        if ((rc = launch_a(r, bound))) break;
+        launched = r + 1;
     }
+    // drain: whatever is still in flight
+    hipError_t e1 = hipStreamSynchronize(c.sa), e2 = hipStreamSynchronize(c.sb[0]), e3 = hipStreamSynchronize(c.sb[1]);
+    ctx->round_seq = seq0 + launched;
+    if (!rc) for (hipError_t e : {e1, e2, e3}) if (e != hipSuccess) rc = set_err(ctx, NECAT_ERR_DEVICE, "extension rounds: %s", hipGetErrorString(e));
+    if (rc) return rc;
+    if (launched) {
+        // the last launched round published too (its lists are empty unless the loop ended on an error)
+        Cnt last; if ((rc = wait_pub(launched - 1, last))) return rc;
+        if (hist.size() < launched) hist.push_back(last);
+        if (launched >= 2) account_a(launched - 2);
+        account_a(launched - 1);
+    }
+    account_b(0); account_b(1);
+    for (const Cnt& h : hist) ctx->tm.rounds += (h.nA + h.nB) ? 1 : 0;
     return NECAT_OK;
 }
 
@@ -874,14 +938,14 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     necat_m4* d_m4 = (necat_m4*)cb; cb += n * sizeof(necat_m4);
     necat_m4* d_out = (necat_m4*)cb; cb += n * sizeof(necat_m4);
     u64* d_goff = (u64*)cb; cb += (n_groups_max + 1) * 8;
-    u32* d_outcnt = (u32*)cb; cb += 128;          // [0..1] output counter, [2..7] list counts (3 buffers x (nA, nB)), [16..19] stats
+    u32* d_outcnt = (u32*)cb; cb += 128;          // [0..1] output counter, [2..9] list counts (4 buffers x (nA, nB)), [16..19] stats
     int* d_err = (int*)cb; cb += 64;
     u8* d_ok = (u8*)cb;
     NECAT_HIP(ctx, hipMemcpyAsync(d_cands, dev ? dev->d : cands, n * sizeof(necat_candidate), dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     NECAT_HIP(ctx, hipMemsetAsync(d_outcnt, 0, 192, s));
     auto cleanup = [&]() {};
     if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_TASKS], (size_t)cap * sizeof(ExtTask) + 64)) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], (size_t)cap * 8 * sizeof(BlockItem) + 2 * 4096 + 64)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], (size_t)cap * 10 * sizeof(BlockItem) + 2 * 4096 + 64)) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_FRAG], (size_t)groups * 64 * (kFragWordsA + 2 * kFragWordsB) * 8)) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_OPS], (size_t)groups * 64 * (kOpsA + 2 * kOpsB))) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_RES], (size_t)groups * 64 * 3 * sizeof(BlockResult)))) { cleanup(); return rc; }
@@ -922,20 +986,21 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     {
         k.tasks = (ExtTask*)ctx->scratch[SC_EXT_TASKS].p;
         BlockItem* q = (BlockItem*)ctx->scratch[SC_EXT_LISTS].p;
-        for (int j = 0; j < 3; ++j) { k.itemsA[j] = q + (size_t)(2 * j) * cap; k.itemsB[j] = q + (size_t)(2 * j + 1) * cap; }
+        for (int j = 0; j < 4; ++j) { k.itemsA[j] = q + (size_t)(2 * j) * cap; k.itemsB[j] = q + (size_t)(2 * j + 1) * cap; }
         k.fragA = (u64*)ctx->scratch[SC_EXT_FRAG].p;
         k.opsA = (u8*)ctx->scratch[SC_EXT_OPS].p;
         k.resA = (BlockResult*)ctx->scratch[SC_EXT_RES].p;
         for (int j = 0; j < 2; ++j) {
-            k.sortedB[j] = q + (size_t)(6 + j) * cap; k.bins[j] = (u32*)(q + 8 * (size_t)cap) + 1024 * j;
+            k.sortedB[j] = q + (size_t)(8 + j) * cap; k.bins[j] = (u32*)(q + 10 * (size_t)cap) + 1024 * j;
             k.fragB[j] = k.fragA + (size_t)groups * 64 * (kFragWordsA + j * kFragWordsB);
             k.opsB[j] = k.opsA + (size_t)groups * 64 * (kOpsA + j * kOpsB);
             k.resB[j] = k.resA + (size_t)groups * 64 * (1 + j);
         }
         k.count = d_outcnt + 2;
         k.sa = ctx->stream_a; k.sb[0] = ctx->stream_b; k.sb[1] = ctx->stream_c;
-        k.a0 = ctx->ev[4]; k.a1 = ctx->ev[5]; k.a2 = ctx->ev[6];
-        for (int j = 0; j < 2; ++j) { k.b0[j] = ctx->ev[7 + 3 * j]; k.b1[j] = ctx->ev[8 + 3 * j]; k.b2[j] = ctx->ev[9 + 3 * j]; }
+        for (int j = 0; j < 4; ++j) { k.a0[j] = ctx->ev[4 + 3 * j]; k.a1[j] = ctx->ev[5 + 3 * j]; k.a2[j] = ctx->ev[6 + 3 * j]; }     // ev[4..15]
+        for (int j = 0; j < 2; ++j) { k.b0[j] = ctx->ev[18 + 3 * j]; k.b1[j] = ctx->ev[19 + 3 * j]; k.b2[j] = ctx->ev[20 + 3 * j]; } // ev[18..23]
+        NECAT_HIP(ctx, hipMemsetAsync(k.bins[0], 0, 2 * 4096, k.sa));     // size-sort counters of list B: reset by the kernels after every use
         k.base = 0; k.n = 0;
     }
     ExtShared X;
@@ -945,7 +1010,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     std::vector<u64> goff;
     for (uint64_t next_base = 0; next_base < n;) {
         k.base = next_base; k.n = (u32)std::min<uint64_t>(cap, n - next_base); next_base += k.n;
-        NECAT_HIP(ctx, hipMemsetAsync(k.count, 0, 24, k.sa));
+        NECAT_HIP(ctx, hipMemsetAsync(k.count, 0, 32, k.sa));
         ExtLists L0; L0.count = k.count; L0.itemsA = k.itemsA[0]; L0.itemsB = k.itemsB[0];
         const u64* d_ops_base = nullptr;
         if (ao) {
@@ -1346,21 +1411,21 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
             BlockResult* d_res = (BlockResult*)ctx->scratch[SC_EXT_RES].p;
             i32* d_nops = (i32*)(d_res + (size_t)g * 64);
             NECAT_HIP(ctx, hipMemcpyAsync(d_items, items.data() + base, (size_t)m * sizeof(BlockItem), hipMemcpyHostToDevice, s));
-            if (full) hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)g * 64 * (kWordsA + kTWordsA), 256)), dim3(256), 0, s, dv, dv, (const BlockItem*)d_items, m, d_frag);
-            else hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)g * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, s, dv, dv, (const BlockItem*)d_items, m, d_frag);
+            if (full) hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)g * 64 * (kWordsA + kTWordsA), 256)), dim3(256), 0, s, dv, dv, (const BlockItem*)d_items, m, (const u32*)nullptr, d_frag, RoundCtl());
+            else hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)g * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, s, dv, dv, (const BlockItem*)d_items, m, (const u32*)nullptr, d_frag, RoundCtl());
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[4], s));
             const bool coop = m <= g_coop_threshold;
             const u32 epoch = ++ctx->epoch & 0x3fffffu;
-            if (full && coop) hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
-            else if (full) hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | ((u32)g_dbg << 28), 0u);
-            else if (coop) hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((m + 3) / 4), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
-            else hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch, 0u);
+            if (full && coop) hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
+            else if (full) hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | ((u32)g_dbg << 28), 0u);
+            else if (coop) hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((m + 3) / 4), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
+            else hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch, 0u);
             NECAT_CHECK_LAUNCH(ctx, "k_myers");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[5], s));
-            if (full) hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, (const char*)d_slabs, slab,
+            if (full) hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, (const char*)d_slabs, slab,
                                          (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), epoch);
-            else hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u64*)d_frag, (const char*)d_slabs, slab,
+            else hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, (const char*)d_slabs, slab,
                                     (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), epoch);
             NECAT_CHECK_LAUNCH(ctx, "k_traceback");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[6], s));

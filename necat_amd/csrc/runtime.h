@@ -22,6 +22,9 @@ struct DevBuf {
 
 }  // namespace necat
 
+constexpr int kNumEvents = 32;
+constexpr unsigned kRoundRing = 1024;  // entries of necat_ctx::round_ring
+
 struct necat_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -31,7 +34,10 @@ struct necat_ctx {
     bool copy_pending = false;                            // a copy on stream_copy still reads SC_EXT_COLS_OUT (ev[17] marks its end)
     char err[1024] = {0};
     necat_timings tm;
-    hipEvent_t ev[20];
+    hipEvent_t ev[kNumEvents];
+    void* round_ring = nullptr;        // pinned, device-visible ring of RoundPub entries: list sizes published by the round kernels
+    void* round_ring_dev = nullptr;    // the same memory as the device addresses it
+    unsigned long long round_seq = 0;  // rounds published so far (the next round publishes round_seq + 1)
     necat::DevBuf scratch[32];         // grow-only arenas, indexed by purpose (ScratchId)
     char devname[256] = {0};
     int num_cu = 0;

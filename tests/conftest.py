@@ -17,7 +17,8 @@ def built():
     """Build (or reuse) the in-tree libraries.  hipcc cross-compiles without a GPU."""
     from necat_amd import build
     build.build_hip()
-    build.build_oracle()
+    from tests import oracle_build
+    oracle_build.build_oracle()
     return build
 
 

@@ -451,3 +451,28 @@ def test_ultra_long_reads(ctx, tmp_path):
         assert capi.gapped_strings(ops[int(off[i]):int(off[i + 1])], int(a["align_size"]), q, a0, t, b0) == (qa, ta), i
     al.close(); vol.free()
 
+
+
+def test_short_reads_list_b_chains_repeatable(ctx, tmp_path, monkeypatch):
+    """Reads of 1.0 - 1.7 kb: an overlap is short on both sides of its anchor, so a left LAST block bigger than 512 (list
+    B) is followed by a right block that is also last and bigger than 512 (list B again) - the case in which, with three
+    list buffers, round r's list-B kernels appended into the buffer round r - 1's list-B kernels were still reading.
+    Unsorted list B (NECAT_SORT_B=0: the kernels read the very buffer that receives appends), several runs, every run
+    against the oracle."""
+    from necat_amd import capi
+    monkeypatch.setenv("NECAT_SORT_B", "0")
+    kw = dict(util.FAST, kmer_size=12, align_size_cutoff=400, num_threads=4)
+    d, rs, nv = util.make_dataset(tmp_path, genome=60_000, coverage=40.0, seed=41, err=0.10, mean_len=1350.0, sd_len=200.0, min_len=1000)
+    out, st = _oracle_records(kw, d, 0, tmp_path, 1, 1)
+    ref = np.frombuffer(open(out, "rb").read(), dtype=capi.M4_DTYPE)
+    assert ref.shape[0] > 2000
+    want = util.m4_key_rows(ref)
+    c2 = capi.Context(0)          # knobs are read when a context is created
+    try:
+        opt = capi.default_options(**dict(kw, job=1))
+        for it in range(6):
+            _, m4 = capi.pm_main(c2, opt, 0, d)
+            assert util.m4_key_rows(m4) == want, "run %d differs from the oracle" % it
+        assert c2.timings().rounds >= 3
+    finally:
+        c2.close()
