@@ -41,10 +41,12 @@ extern "C" {
 #define NECAT_ERR_MEMORY   (-3)
 #define NECAT_ERR_CAPACITY (-4)   /* an internal device buffer overflowed (reported, never silent) */
 #define NECAT_ERR_INTERNAL (-5)
+#define NECAT_ERR_COMM     (-6)   /* rank-to-rank exchange failed (RCCL / HIP IPC / the host all-gather callback) */
 
 typedef struct necat_ctx necat_ctx;
 typedef struct necat_volume necat_volume;
 typedef struct necat_index necat_index;
+typedef struct necat_comm necat_comm;
 
 /* common/map_options.h:10-25 (same fields, same meaning) */
 typedef struct {
@@ -262,6 +264,61 @@ int  necat_cns_extension_batch(necat_ctx* ctx, const necat_volume* reads, const 
                                const uint64_t* tmpl_off, const uint64_t* n_all, uint64_t n_templates,
                                const necat_cns_options* opt, necat_cns_result** out);
 void necat_cns_result_free(necat_cns_result* r);
+
+/* ---- one reference volume on several GPUs (fine granularity) -------------------------------------
+ * The reference parallelises ONE volume over threads that pull 500-read chunks from a counter
+ * (pm_worker.c:13,354-362; common/map_aux.c:59-77) against one shared lookup table.  The multi-GPU equivalent:
+ * one process per GPU (rank), every rank holds the volume,
+ *   - the index is built in hash-range slices - rank g counts, filters and ranks only the k-mers whose hash falls
+ *     in its range of the 4^k table - and the slices of kmer_stats / offset_list are all-gathered (starts rebased
+ *     by the exclusive scan of the slice sizes), so every rank ends up with the COMPLETE reference-layout index:
+ *     necat_index_build_sharded;
+ *   - the query reads are dealt out in chunks of `chunk_reads` reads, chunk c to rank c % nranks (reads late in the
+ *     volume see more subjects - word_finder.c:121-127 - so contiguous ranges would not balance); every read is
+ *     processed exactly as on one GPU, so the union of the ranks' records IS the single-GPU record set;
+ *   - the records are gathered (gather-v, device to device) on rank `root`.
+ * Device memory moves by RCCL send/recv groups (direct all-pairs over xGMI) or, for ranks that share a device,
+ * by HIP IPC copies (transport "ipc"; "auto" picks RCCL unless two ranks sit on one device).  Small host-side
+ * values (slice sizes, the RCCL id, IPC handles) travel through the caller's all-gather callback. */
+
+/* all-gather of `bytes` bytes per rank among the job's ranks: recv = nranks * bytes, rank order; returns 0 on success */
+typedef int (*necat_host_allgather_fn)(void* user, const void* send, void* recv, size_t bytes);
+
+int  necat_comm_create(necat_ctx* ctx, int rank, int nranks, necat_host_allgather_fn fn, void* user,
+                       const char* transport /* "auto" | "rccl" | "ipc" */, necat_comm** out);
+void necat_comm_destroy(necat_comm* c);
+/* "rccl" or "ipc" */
+int  necat_comm_transport(const necat_comm* c, char* buf, size_t n);
+
+/* wall-clock of the last sharded calls on this rank */
+typedef struct {
+    double   index_local_ms;     /* this rank's slice of the build (HIP events) */
+    double   index_exchange_ms;  /* all-gather of the kmer_stats and offset_list slices (wall) */
+    uint64_t index_exchange_bytes; /* bytes this rank received */
+    double   gather_ms;          /* gather-v of the records on the root (wall) */
+    uint64_t gather_bytes;
+    uint64_t reads_local;        /* query reads this rank processed */
+} necat_shard_timings;
+int  necat_get_shard_timings(const necat_ctx* ctx, necat_shard_timings* t);
+
+/* necat_index_build with the work split by hash range and the result all-gathered: the returned index is the
+ * complete one, bit-identical to necat_index_build's, on every rank.  Collective: every rank of `comm` calls it.
+ * (k < 11 - tables that fit the L2 - are simply built whole on every rank.) */
+int  necat_index_build_sharded(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, int kmer_size, int max_occ,
+                               necat_index** out);
+
+/* necat_find_candidates / necat_map_pair for this rank's chunks of the query reads, then the gather-v on `root`.
+ * On the root: out = the records of ALL ranks (this rank's first), *n_out their number.  On the other ranks: out =
+ * this rank's own records.  *n_local (optional) = this rank's own records, *n_candidates its candidates examined.
+ * Collective. */
+int  necat_find_candidates_sharded(necat_ctx* ctx, necat_comm* comm, const necat_index* ix, const necat_volume* ref,
+                                   const necat_volume* reads, int read_start_id, int ref_start_id, int pairwise,
+                                   const necat_map_options* opt, int chunk_reads, int root,
+                                   necat_candidate** out, uint64_t* n_out, uint64_t* n_local);
+int  necat_map_pair_sharded(necat_ctx* ctx, necat_comm* comm, const necat_index* ix, const necat_volume* ref,
+                            const necat_volume* reads, int read_start_id, int ref_start_id, int pairwise,
+                            const necat_map_options* opt, int tail_match_len, int chunk_reads, int root,
+                            necat_m4** out, uint64_t* n_out, uint64_t* n_local, uint64_t* n_candidates);
 
 /* Test / profiling hook for the dominant kernel: n independent Edlib_align calls
  * (edlib_ex.c:733) on byte-coded (0..3) sequences.  seqs = concatenated fragments, q_off/t_off =

@@ -222,8 +222,21 @@ def run_ref(o, vid: int, wrk_dir: str, output: str, binary: Optional[str] = None
     return t
 
 
+def record_size(opt) -> int:
+    """bytes per record of an oc2pmov output file, 0 = text lines: 28-byte PackedGappedCandidate (-j 0 -u 1),
+    96-byte M4Record (-j 1 -u 1)"""
+    if not opt.binary_output:
+        return 0
+    return 96 if opt.job == 1 else 28
+
+
 def sorted_records(path: str, binary_size: int = 0) -> List[bytes]:
+    """Records of an output file, sorted (the order threads flush in is unspecified).  The 4 padding bytes that end
+    a binary M4Record (m4_record.h:10-25: int vscore, then alignment padding) are zeroed: the reference dumps an
+    uninitialised stack struct there (pm_worker.c:41,79)."""
     b = open(path, "rb").read()
+    if binary_size == 96:
+        return sorted(b[i:i + 92] + b"\0\0\0\0" for i in range(0, len(b), 96))
     if binary_size:
         return sorted(b[i:i + binary_size] for i in range(0, len(b), binary_size))
     return sorted(b.splitlines(keepends=True))

@@ -27,6 +27,7 @@ CASES = {
     "a_fast_can_bin": ("vols_a", 0, dict(kmer_size=13, scan_window=20, job=0, binary_output=1)),
     "a_fast_can_txt": ("vols_a", 0, dict(kmer_size=13, scan_window=20, job=0, binary_output=0)),
     "a_fast_m4_txt": ("vols_a", 0, dict(kmer_size=13, scan_window=20, job=1, binary_output=0, use_hdr_as_id=0)),
+    "a_fast_m4_bin": ("vols_a", 0, dict(kmer_size=13, scan_window=20, job=1, binary_output=1, use_hdr_as_id=0)),   # 96-byte M4Record
     "a_fast_m4_hdr": ("vols_a", 0, dict(kmer_size=13, scan_window=20, job=1, binary_output=0, use_hdr_as_id=1)),
     "a_sens_m4_txt": ("vols_a", 0, dict(kmer_size=13, scan_window=10, job=1, binary_output=0, use_hdr_as_id=0)),
     "a_k15_m4_txt": ("vols_a", 0, dict(kmer_size=15, scan_window=20, job=1, binary_output=0, use_hdr_as_id=0)),
@@ -66,7 +67,7 @@ def main():
         o = ora.options(**dict(BASE, **kw))
         out = os.path.join(tmp, name + ".out")
         ora.run_ref(o, vid, d, out)
-        recs = ora.sorted_records(out, 28 if o.binary_output else 0)
+        recs = ora.sorted_records(out, ora.record_size(o))
         dst = os.path.join(GOLD, name + (".bin" if o.binary_output else ".txt"))
         with open(dst, "wb") as f:
             f.write(b"".join(recs))

@@ -25,7 +25,7 @@ def test_oc2pmov_reproduces_reference_records(name, tmp_path, built):
     r = subprocess.run([pmov] + ora.opt_argv(o) + [d, str(m["vid"]), out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0, r.stderr
     assert "'pairwise mapping v%d vs v%d' takes" % (m["vid"], m["vid"]) in r.stdout
-    recs = ora.sorted_records(out, 28 if o.binary_output else 0)
+    recs = ora.sorted_records(out, ora.record_size(o))
     assert len(recs) == m["records"]
     assert hashlib.md5(b"".join(recs)).hexdigest() == m["md5"]
     assert not os.path.exists(out + ".part")

@@ -1,7 +1,8 @@
-"""Full-size parity (BASELINE.json configs[1]): E. coli 4.6 Mb x 40 synthetic reads, k = 15.  The
-expected fingerprints were produced by the REFERENCE binary (oracle/_ref/oc2pmov, built from
-/root/reference) on the same seeded dataset and are committed as tests/golden/ecoli_full_reference.json;
-nothing here needs /root/reference at run time."""
+"""Full-size parity: BASELINE.json configs[1] (E. coli 4.6 Mb x 40, OVLP_FAST_OPTIONS) and configs[2] (S. cerevisiae-size
+12 Mb x 50, OVLP_SENSITIVE_OPTIONS -z 10: 2.46 M candidates, several seeding chunks and extension batches at their real
+sizes), k = 15.  The expected fingerprints were produced by the REFERENCE binary (oracle/_ref/oc2pmov, built from
+/root/reference) on the same seeded datasets by tests/golden/make_golden_full.py and are committed as
+tests/golden/{ecoli,yeast}_full_reference.json; nothing here needs /root/reference at run time."""
 import hashlib
 import json
 import os
@@ -12,33 +13,35 @@ import pytest
 from tests import util
 
 pytestmark = pytest.mark.gpu
-GOLD = json.load(open(os.path.join(util.GOLDEN, "ecoli_full_reference.json")))
+GOLDS = {n: json.load(open(os.path.join(util.GOLDEN, "%s_full_reference.json" % n))) for n in ("ecoli", "yeast")}
 
 
-@pytest.fixture(scope="module")
-def ecoli(ctx):
+@pytest.fixture(scope="module", params=["ecoli", "yeast"])
+def ecoli(ctx, request):
     from necat_amd import synth
+    GOLD = GOLDS[request.param]
     g = GOLD["generator"]
     rs = synth.simulate_reads(g["genome"], g["coverage"], seed=g["seed"], err=g["err"])
     if hashlib.md5(rs.codes.tobytes()).hexdigest() != GOLD["reads_md5"]:
         pytest.skip("numpy generator drift: the seeded dataset differs from the one the golden was made on")
     vol = ctx.upload_volume(synth.pack_2bit(rs.codes), rs.nbases, rs.offsets, rs.sizes)
     ix = ctx.build_index(vol, 15, 500)
-    yield rs, vol, ix
+    yield rs, vol, ix, GOLD
     ix.free()
     vol.free()
 
 
-def _opt(job):
+def _opt(job, gold):
     from necat_amd import capi
-    return capi.default_options(kmer_size=15, scan_window=20, kmer_cnt_cutoff=500, block_size=2000, block_score_cutoff=3,
+    flags = gold["options"].split()
+    return capi.default_options(kmer_size=15, scan_window=int(flags[flags.index("-z") + 1]), kmer_cnt_cutoff=500, block_size=2000, block_score_cutoff=3,
                                 num_candidates=500, align_size_cutoff=1000, error=0.5, job=job, use_hdr_as_id=0)
 
 
 def test_candidates_identical_to_reference(ctx, ecoli):
     from necat_amd import capi
-    rs, vol, ix = ecoli
-    c = ctx.find_candidates(ix, vol, vol, 0, 0, _opt(0), True)
+    rs, vol, ix, GOLD = ecoli
+    c = ctx.find_candidates(ix, vol, vol, 0, 0, _opt(0, GOLD), True)
     recs = sorted(bytes(r) for r in capi.pack_candidates(c).astype("<u4"))
     assert len(recs) == GOLD["candidate_records"]
     assert hashlib.md5(b"".join(recs)).hexdigest() == GOLD["candidates_packed_sorted_md5"]
@@ -46,8 +49,8 @@ def test_candidates_identical_to_reference(ctx, ecoli):
 
 def test_m4_identical_to_reference(ctx, ecoli):
     from necat_amd import capi
-    rs, vol, ix = ecoli
-    opt = _opt(1)
+    rs, vol, ix, GOLD = ecoli
+    opt = _opt(1, GOLD)
     c = ctx.find_candidates(ix, vol, vol, 0, 0, opt, True)
     m4 = ctx.extend(vol, vol, 0, 0, c, opt, 1)
     assert m4.shape[0] == GOLD["m4_records"]

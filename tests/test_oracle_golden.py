@@ -21,7 +21,7 @@ def test_oracle_reproduces_golden(name, tmp_path, built):
     o = ora.options(**m["options"])
     out = os.path.join(str(tmp_path), "o.out")
     st = ora.pm_main(o, m["vid"], d, out)
-    recs = ora.sorted_records(out, 28 if o.binary_output else 0)
+    recs = ora.sorted_records(out, ora.record_size(o))
     gold = open(os.path.join(util.GOLDEN, m["file"]), "rb").read()
     assert st.n_records == m["records"] == len(recs)
     assert hashlib.md5(gold).hexdigest() == m["md5"]

@@ -59,8 +59,34 @@ def pmc(dirs, out):
         json.dump(dict(sorted(res.items())), fh, indent=1)
 
 
+def counters(dirs, out):
+    """raw per-kernel sums of every counter of several --pmc passes (+ dispatch counts), tolerant of failed passes"""
+    res = defaultdict(dict)
+    for d in dirs:
+        try:
+            files = find(d, "counter_collection.csv")
+        except SystemExit:
+            continue
+        acc = defaultdict(lambda: defaultdict(float))
+        disp = defaultdict(set)
+        for f in files:
+            with open(f) as fh:
+                for r in csv.DictReader(fh):
+                    k = r["Kernel_Name"]
+                    acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                    disp[k].add(r["Dispatch_Id"])
+        for k, cs in acc.items():
+            res[k].setdefault("launches", len(disp[k]))
+            for c, v in cs.items():
+                res[k][c] = v
+    with open(out, "w") as fh:
+        json.dump(dict(sorted(res.items())), fh, indent=1)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "counters":
+        counters(sys.argv[2:-1], sys.argv[-1])
     elif sys.argv[1] == "pmc":
         pmc(sys.argv[2:-1], sys.argv[-1])
