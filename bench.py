@@ -6,10 +6,13 @@ HBM: k-mer index build -> candidate search (both strands of every read) -> block
 extension -> M4 records back on the host.  Workload at N=1 = BASELINE.json configs[1]:
 E. coli-size (4.6 Mb) 40x synthetic ONT reads, OVLP_FAST_OPTIONS with -j 1 (M4 output).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank owns one independent
-reference volume of the same size (seed + rank) - the unit necat.pl itself distributes
-(necat.pl:190-202) - so there is no data-path collective and scaling is weak; the barrier and the
-max-over-ranks time follow the driver's contract.
+N > 1 (launched by torch.distributed.run, one rank per GPU), default `--parallelism single-volume`: STRONG scaling of
+the same workload - every rank holds the same volume, the index is built in hash-range slices and all-gathered
+(RCCL send/recv groups over xGMI), the query reads are dealt out in chunks, the M4 records are gathered on rank 0
+(necat_index_build_sharded / necat_map_pair_sharded, include/necat_hip.h).  `--parallelism volumes` keeps the coarse
+mode: every rank owns one independent reference volume (seed + rank) - the unit necat.pl itself distributes
+(necat.pl:190-202) - no data-path collective, weak scaling.  The barrier and the max-over-ranks time follow the
+driver's contract.
 
 Prints ONE JSON line (rank 0).
 """
@@ -50,7 +53,12 @@ def parse():
     ap.add_argument("--job", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-widened", action="store_true", help="skip the extra measurements of the SURVEY 8f.1 rows")
-    ap.add_argument("--cpu-genome", type=int, default=2_300_000, help="genome size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-genome", type=int, default=0, help="genome size of the CPU-baseline input (0 = the bench workload itself)")
+    ap.add_argument("--cpu-t1", action="store_true", help="also time the reference with -t 1 (minutes)")
+    ap.add_argument("--parallelism", choices=["single-volume", "volumes"], default="single-volume",
+                    help="N > 1: one volume on all GPUs (strong scaling, RCCL data path) or one volume per GPU (weak)")
+    ap.add_argument("--chunk-reads", type=int, default=64, help="query reads per chunk dealt to the ranks (single-volume mode)")
+    ap.add_argument("--transport", default="auto", help="auto | rccl | ipc (single-volume mode)")
     return ap.parse_args()
 
 
@@ -63,8 +71,14 @@ def dist_setup(args):
         import torch
         import torch.distributed as dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist_.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if os.environ.get("NECAT_BENCH_ONE_DEVICE") == "1":
+            # test mode for a 1-GPU box: every rank on device 0 (RCCL refuses that, so the process group is gloo and the
+            # library moves device memory by HIP IPC) - exercises the multi-rank code path of this script, not a measurement
+            local = 0
+            dist_.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist_.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         dist = dist_
     return rank, world, local, dist
 
@@ -80,37 +94,91 @@ def barrier_sync(dist, local):
         dist.barrier()
 
 
-def cpu_baseline(args, opt_kw):
-    """The reference's own oc2pmov (oracle/_ref, built from /root/reference) - or, when absent, the
-    oracle port - timed on this host's cores on a bounded sample of the same workload."""
-    from necat_amd import synth
+def host_cpu():
+    """(model name, physical cores, hardware threads) of this host"""
+    model, cores = "unknown", set()
+    phys = core = None
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name") and model == "unknown":
+                model = ln.split(":", 1)[1].strip()
+            elif ln.startswith("physical id"):
+                phys = ln.split(":", 1)[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":", 1)[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+    except OSError:
+        pass
+    threads = os.cpu_count() or 1
+    return model, (len(cores) or threads), threads
+
+
+def cpu_baseline(args, opt_kw, rs, vol_dir):
+    """The reference's own oc2pmov (oracle/_ref, built from /root/reference) - or, when absent, the oracle port - on
+    this host's cores, on the SAME volume the GPU steps ran on, with the thread policy of SURVEY.md 8d: -t = physical
+    cores, capped by the number of 500-read chunks the reference hands out (pm_worker.c:13,354: more threads stay idle).
+    Both of the reference's own timers are reported: the mapping phase ('pairwise mapping', index build excluded) and the
+    whole process (index build = one thread walking the 8.6 GB table, ~60 s regardless of the input)."""
     from oracle import oracle_api as ora
-    tmp = tempfile.mkdtemp(prefix="necat_cpu_")
-    rs = synth.simulate_reads(args.cpu_genome, args.coverage, seed=args.seed)
-    # the reference hands out reads in chunks of 500 (pm_worker.c:13,354): more threads than chunks stay idle
-    cores = max(1, min(os.cpu_count() or 1, (rs.nreads + 499) // 500))
-    d = os.path.join(tmp, "vols")
-    synth.write_volume_dir(d, rs)
-    o = ora.options(**dict(opt_kw, job=args.job, binary_output=0, num_threads=cores))
-    out = os.path.join(tmp, "out.txt")
+    model, phys, threads = host_cpu()
+    chunks = (rs.nreads + 499) // 500
+    cores = max(1, min(phys, chunks))
     kind = "reference" if ora.have_ref() else "port"
-    t0 = time.time()
-    if kind == "reference":
-        t_map = ora.run_ref(o, 0, d, out)
+
+    def run(nthreads):
+        o = ora.options(**dict(opt_kw, job=args.job, binary_output=0, num_threads=nthreads))
+        out = os.path.join(vol_dir, "cpu_out_%d.txt" % nthreads)
+        t0 = time.time()
+        if kind == "reference":
+            t_map = ora.run_ref(o, 0, vol_dir, out)
+        else:
+            t_map = ora.pm_main(o, 0, vol_dir, out).t_map
         wall = time.time() - t0
-    else:
-        st = ora.pm_main(o, 0, d, out)
-        wall = time.time() - t0
-        t_map = st.t_map
-    nrec = sum(1 for _ in open(out, "rb"))
-    import shutil
-    shutil.rmtree(tmp, ignore_errors=True)
-    return {"value": round(nrec / max(t_map, 1e-9), 1), "unit": "overlaps/s", "cores": cores, "kind": kind,
-            "sample": "%.2f Mb genome x %.0fx (%d reads, %d bp), same options, -t %d (= number of 500-read chunks, of %d host "
-                      "threads); mapping phase %.2f s (index build excluded, as in the reference's own 'pairwise mapping' "
-                      "timer); whole process %.1f s" % (args.cpu_genome / 1e6, args.coverage, rs.nreads, rs.nbases, cores,
-                                                        os.cpu_count() or 1, t_map, wall),
-            "overlaps": nrec, "mapping_s": round(t_map, 3), "whole_process_s": round(wall, 2)}
+        nrec = sum(1 for _ in open(out, "rb"))
+        os.remove(out)
+        return nrec, t_map, wall
+    nrec, t_map, wall = run(cores)
+    res = {"value": round(nrec / max(t_map, 1e-9), 1), "unit": "overlaps/s", "cores": cores, "kind": kind,
+           "cpu_model": model, "host_physical_cores": phys, "host_threads": threads,
+           "sample": "the bench workload itself (%d reads, %d bp, same volume file, same options), -t %d = min(physical cores %d, "
+                     "500-read chunks %d); value = records / mapping phase %.2f s (the reference's 'pairwise mapping' timer, index "
+                     "build excluded); whole process %.1f s" % (rs.nreads, rs.nbases, cores, phys, chunks, t_map, wall),
+           "overlaps": nrec, "mapping_s": round(t_map, 3), "whole_process_s": round(wall, 2),
+           "whole_process_overlaps_per_s": round(nrec / max(wall, 1e-9), 1)}
+    if args.cpu_t1:
+        n1, t1, w1 = run(1)
+        res["t1"] = {"overlaps": n1, "mapping_s": round(t1, 2), "whole_process_s": round(w1, 2), "overlaps_per_s": round(n1 / max(t1, 1e-9), 1)}
+    return res
+
+
+def cold_start_cli(args, opt_kw, vol_dir, device):
+    """wall time of the oc2pmov PROGRAM (what necat.pl launches per volume, necat.pl:197), cold: process start, HIP
+    initialisation, volume read + upload, pools, the three stages, M4 text out"""
+    from necat_amd import build
+    pmov, _ = build.build_cli()
+    res = {}
+    for job, binary in ((1, 0), (0, 1)):
+        out = os.path.join(vol_dir, "cli_out")
+        argv = ["-k", str(opt_kw["kmer_size"]), "-z", str(opt_kw["scan_window"]), "-q", str(opt_kw["kmer_cnt_cutoff"]), "-b", str(opt_kw["block_size"]),
+                "-s", str(opt_kw["block_score_cutoff"]), "-n", str(opt_kw["num_candidates"]), "-a", str(opt_kw["align_size_cutoff"]),
+                "-d", "%f" % opt_kw["ddfs_cutoff"], "-e", "%f" % opt_kw["error"], "-m", str(opt_kw["num_output"]), "-t", "1",
+                "-j", str(job), "-u", str(binary), "-i", "0"]
+        env = dict(os.environ, HIP_VISIBLE_DEVICES=str(device))
+        best = None
+        for _ in range(2):
+            t0 = time.time()
+            r = subprocess.run([pmov] + argv + [vol_dir, "0", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+            dt = time.time() - t0
+            if r.returncode != 0:
+                return {"error": r.stderr[-300:]}
+            best = dt if best is None else min(best, dt)
+        nrec = os.path.getsize(out) // 28 if binary else sum(1 for _ in open(out, "rb"))
+        os.remove(out)
+        res["-j %d -u %d" % (job, binary)] = {"wall_s": round(best, 3), "records": nrec, "overlaps_per_s": round(nrec / best, 1)}
+    return res
 
 
 def widened_paths(ctx, vol, capi, opt_kw):
@@ -165,26 +233,46 @@ def main():
         dist.barrier()
     opt_kw = dict(FAST, kmer_size=args.kmer, scan_window=args.scan_window)
     opt = capi.default_options(**dict(opt_kw, job=args.job, num_threads=1))
-    # ---- synthetic volume of this rank, made resident in HBM before the clock starts
-    rs = synth.simulate_reads(args.genome, args.coverage, seed=args.seed + 1000 * rank)
+    single = world > 1 and args.parallelism == "single-volume"
+    # ---- synthetic volume, made resident in HBM before the clock starts (single-volume mode: the SAME volume on every rank)
+    rs = synth.simulate_reads(args.genome, args.coverage, seed=args.seed + (0 if single or world == 1 else 1000 * rank))
     pac = synth.pack_2bit(rs.codes)
     ctx = capi.Context(local)
     vol = ctx.upload_volume(pac, rs.nbases, rs.offsets, rs.sizes)
+    comm = None
+    if single:
+        import torch
+        from necat_amd import dist as ndist
+        one_dev = os.environ.get("NECAT_BENCH_ONE_DEVICE") == "1"
+        comm = ctx.comm(rank, world, ndist.torch_allgather(dist, device=None if one_dev else torch.device("cuda", local)), args.transport)
 
-    def step():
-        ix = ctx.build_index(vol, opt.kmer_size, opt.kmer_cnt_cutoff)
-        t_index = ctx.timings().index_ms
-        if args.job == 1:      # pm_search_one_volume of a mapping job: seeding + extension in one call, candidates stay on the device
-            m4, _ = ctx.map_pair(ix, vol, vol, 0, 0, opt, True, 1)
-            cands = None
+    def step(job=args.job):
+        o = opt if job == args.job else capi.default_options(**dict(opt_kw, job=job, num_threads=1))
+        if comm is not None:
+            ix = ctx.build_index_sharded(comm, vol, o.kmer_size, o.kmer_cnt_cutoff)
+            t_index = ctx.timings().index_ms
+            sh_ix = ctx.shard_timings()
+            if job == 1:
+                m4, _, _ = ctx.map_pair_sharded(comm, ix, vol, vol, 0, 0, o, True, 1, args.chunk_reads, 0)
+                cands = None
+            else:
+                (cands, _), m4 = ctx.find_candidates_sharded(comm, ix, vol, vol, 0, 0, o, True, args.chunk_reads, 0), None
+            sh = ctx.shard_timings()
+            sh.index_local_ms, sh.index_exchange_ms, sh.index_exchange_bytes = sh_ix.index_local_ms, sh_ix.index_exchange_ms, sh_ix.index_exchange_bytes
         else:
-            cands, m4 = ctx.find_candidates(ix, vol, vol, 0, 0, opt, True), None
+            sh = None
+            ix = ctx.build_index(vol, o.kmer_size, o.kmer_cnt_cutoff)
+            t_index = ctx.timings().index_ms
+            if job == 1:      # pm_search_one_volume of a mapping job: seeding + extension in one call, candidates stay on the device
+                m4, _ = ctx.map_pair(ix, vol, vol, 0, 0, o, True, 1)
+                cands = None
+            else:
+                cands, m4 = ctx.find_candidates(ix, vol, vol, 0, 0, o, True), None
         tm = ctx.timings()
         ix.free()
-        return cands, m4, t_index, tm
+        return cands, m4, t_index, tm, sh
 
     # setup (untimed): initialise the torch/HIP runtimes and let the library size its HBM pools once
-    # (the traceback band pool alone is tens of GB: allocating + zeroing it is a one-off of ~2 s)
     barrier_sync(dist, local)
     step()
     for _ in range(args.warmup):
@@ -192,14 +280,16 @@ def main():
     barrier_sync(dist, local)
     t0 = time.perf_counter()
     agg = dict(index_ms=0.0, seed_ms=0.0, extend_ms=0.0, myers_ms=0.0, traceback_ms=0.0, launches=0, blocks=0, words=0, bases=0, rounds=0,
-               a_ms=0.0, a_launches=0, a_blocks=0, tb_a_ms=0.0, big_ms=0.0, big_blocks=0)
+               a_ms=0.0, a_launches=0, a_blocks=0, tb_a_ms=0.0, big_ms=0.0, big_blocks=0,
+               ix_local_ms=0.0, ix_xchg_ms=0.0, ix_xchg_bytes=0, gather_ms=0.0, gather_bytes=0, reads_local=0)
     n_over = 0
     gbp = 0.0
     for _ in range(args.steps):
-        cands, m4, t_index, tm = step()
-        n_over += (m4.shape[0] if m4 is not None else cands.shape[0])
-        if m4 is not None:
-            gbp += float((m4["qend"] - m4["qoff"]).sum()) / 1e9
+        cands, m4, t_index, tm, sh = step()
+        if comm is None or rank == 0:        # single-volume mode: rank 0 holds the gathered records of all ranks
+            n_over += (m4.shape[0] if m4 is not None else cands.shape[0])
+            if m4 is not None:
+                gbp += float((m4["qend"] - m4["qoff"]).sum()) / 1e9
         agg["index_ms"] += t_index; agg["seed_ms"] += tm.seed_ms; agg["extend_ms"] += tm.extend_ms
         agg["myers_ms"] += tm.myers_ms; agg["traceback_ms"] += tm.traceback_ms; agg["launches"] += tm.myers_launches
         agg["blocks"] += tm.myers_blocks; agg["words"] += tm.myers_word_updates; agg["bases"] += tm.myers_cells_bases
@@ -208,11 +298,34 @@ def main():
         if tm.myersA_big_blocks >= agg["big_blocks"]:
             agg["big_blocks"], agg["big_ms"] = int(tm.myersA_big_blocks), float(tm.myersA_big_ms)
         agg["a_ms"] += tm.myersA_ms; agg["a_launches"] += tm.myersA_launches; agg["a_blocks"] += tm.myersA_blocks
+        if sh is not None:
+            agg["ix_local_ms"] += sh.index_local_ms; agg["ix_xchg_ms"] += sh.index_exchange_ms; agg["ix_xchg_bytes"] += sh.index_exchange_bytes
+            agg["gather_ms"] += sh.gather_ms; agg["gather_bytes"] += sh.gather_bytes; agg["reads_local"] = int(sh.reads_local)
     barrier_sync(dist, local)
     elapsed = time.perf_counter() - t0
     from necat_amd import shard
-    elapsed, tot_over, tot_gbp = shard.reduce_step_stats(dist, elapsed, float(n_over), gbp, device="cuda" if dist is not None else None)
+    elapsed, tot_over, tot_gbp = shard.reduce_step_stats(dist, elapsed, float(n_over), gbp,
+                                                         device="cuda" if (dist is not None and dist.get_backend() == "nccl") else None)
+    # extras measured after the timed region, on every rank when collective
+    extras = {}
+    try:
+        t1 = time.perf_counter()
+        n0 = 0
+        for _ in range(3):
+            c0, _, _, _, _ = step(job=0)
+            if comm is None or rank == 0:
+                n0 += c0.shape[0]
+        barrier_sync(dist, local)
+        dt0 = time.perf_counter() - t1
+        extras["candidates_job0"] = {"overlaps_per_s": round(n0 / dt0, 1), "ms_per_step": round(1e3 * dt0 / 3, 2), "records_per_step": n0 // 3,
+                                     "note": "-j 0 -u 1, what necat.pl runs in the correction pipeline (necat.pl:31-32): index build + candidate search, "
+                                             "28-byte records; same volume, measured after the timed region"}
+    except Exception as e:
+        extras["candidates_job0"] = {"error": str(e)}
+    transport = comm.transport() if comm is not None else None
     if rank != 0:
+        if comm is not None:
+            comm.close()
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -267,17 +380,28 @@ def main():
         "value": round(tot_over / elapsed, 1), "unit": "overlaps/s",
         "gbp_aligned_per_s": round(tot_gbp / elapsed, 4),
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / K, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-        "config": {"workload": "E. coli-size %.1f Mb genome, %.0fx synthetic ONT reads (12%% errors), %d reads / %d bp per GPU, "
-                               "OVLP_FAST_OPTIONS (-k %d -z %d -q 500 -b 2000 -s 3 -n 500 -a 1000 -e 0.5) with -j %d; one reference volume per GPU"
-                               % (args.genome / 1e6, args.coverage, rs.nreads, rs.nbases, args.kmer, args.scan_window, args.job),
-                   "overlaps_per_step_per_gpu": n_over // K, "parallelism": "volume-per-gpu x%d" % world},
+        "higher_is_better": True, "scaling": "weak" if (world > 1 and not single) else "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "E. coli-size %.1f Mb genome, %.0fx synthetic ONT reads (12%% errors), %d reads / %d bp%s, "
+                               "OVLP_FAST_OPTIONS (-k %d -z %d -q 500 -b 2000 -s 3 -n 500 -a 1000 -e 0.5) with -j %d; one reference volume%s"
+                               % (args.genome / 1e6, args.coverage, rs.nreads, rs.nbases, "" if (single or world == 1) else " per GPU", args.kmer,
+                                  args.scan_window, args.job, " per GPU" if (world > 1 and not single) else " in total"),
+                   "overlaps_per_step": int(tot_over) // K,
+                   "parallelism": ("single-volume x%d: hash-range sharded index build + all-gather (%s), query chunks of %d reads per rank, gather-v of the records"
+                                   % (world, transport, args.chunk_reads)) if single else ("volume-per-gpu x%d" % world if world > 1 else "1 gpu")},
         "phases_ms_per_step": {"index": round(agg["index_ms"] / K, 2), "seed": round(agg["seed_ms"] / K, 2),
                                "extend": round(agg["extend_ms"] / K, 2), "myers_kernel": round(agg["myers_ms"] / K, 2),
                                "traceback_kernel": round(agg["traceback_ms"] / K, 2), "rounds": agg["rounds"] // K},
         "device": ctx.device_name(),
         "roofline": roofline,
     }
+    out.update(extras)
+    if single:
+        out["multi_gpu"] = {"transport": transport, "rank0_index_local_ms": round(agg["ix_local_ms"] / K, 3),
+                            "rank0_index_allgather_ms": round(agg["ix_xchg_ms"] / K, 3),
+                            "rank0_index_allgather_bytes": int(agg["ix_xchg_bytes"] // K),
+                            "rank0_record_gather_ms": round(agg["gather_ms"] / K, 3), "rank0_record_gather_bytes": int(agg["gather_bytes"] // K),
+                            "rank0_query_reads": agg["reads_local"], "chunk_reads": args.chunk_reads,
+                            "note": "phases_ms_per_step are rank 0's; index = local slice build + all-gather of the kmer_stats / offset_list slices"}
     if world == 1 and not args.no_widened:
         # SURVEY 8f.1 rows built on the same kernels, measured right AFTER the timed region (before the CPU baseline, while the GPU clocks are still up) on the same resident volume; reported
         # extras, not part of `value`
@@ -286,12 +410,29 @@ def main():
         except Exception as e:
             out["widened_paths"] = {"error": str(e)}
     if world == 1 and not args.no_cpu_baseline:
+        import shutil
+        tmp = tempfile.mkdtemp(prefix="necat_bench_")
+        vol_dir = os.path.join(tmp, "vols")
         try:
-            out["cpu_baseline"] = cpu_baseline(args, opt_kw)
+            if args.cpu_genome:
+                rs_cpu = synth.simulate_reads(args.cpu_genome, args.coverage, seed=args.seed)
+            else:
+                rs_cpu = rs
+            synth.write_volume_dir(vol_dir, rs_cpu)
+            if not args.cpu_genome:
+                # what the pipeline sees: the oc2pmov program, cold, on the same volume file
+                try:
+                    out["oc2pmov_cold_start"] = cold_start_cli(args, opt_kw, vol_dir, local)
+                except Exception as e:
+                    out["oc2pmov_cold_start"] = {"error": str(e)}
+            out["cpu_baseline"] = cpu_baseline(args, opt_kw, rs_cpu, vol_dir)
         except Exception as e:  # the baseline is a reported extra; never fail the GPU measurement on it
             out["cpu_baseline"] = {"value": None, "unit": "overlaps/s", "cores": os.cpu_count(), "kind": "unavailable", "sample": str(e)}
+        shutil.rmtree(tmp, ignore_errors=True)
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
 

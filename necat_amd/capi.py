@@ -35,6 +35,14 @@ class Timings(C.Structure):
                 ("tracebackA_ms", C.c_double), ("myersA_big_ms", C.c_double), ("myersA_big_blocks", C.c_uint64)]
 
 
+class ShardTimings(C.Structure):
+    """necat_shard_timings"""
+    _fields_ = [("index_local_ms", C.c_double), ("index_exchange_ms", C.c_double), ("index_exchange_bytes", C.c_uint64),
+                ("gather_ms", C.c_double), ("gather_bytes", C.c_uint64), ("reads_local", C.c_uint64)]
+
+
+HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
 CANDIDATE_DTYPE = np.dtype([("qid", "<i4"), ("sid", "<i4"), ("qdir", "<i4"), ("sdir", "<i4"), ("score", "<i4"),
                             ("_pad", "<i4"), ("qbeg", "<u8"), ("qend", "<u8"), ("qsize", "<u8"),
                             ("sbeg", "<u8"), ("send", "<u8"), ("ssize", "<u8"), ("qoff", "<u8"), ("soff", "<u8")])
@@ -72,6 +80,8 @@ EXPORTED_SYMBOLS = [
     "necat_gapped_strings", "necat_cns_default_options", "necat_cns_load_partition", "necat_cns_extension_batch",
     "necat_cns_result_free",
     "necat_edlib_align_batch", "necat_get_timings", "necat_free",
+    "necat_comm_create", "necat_comm_destroy", "necat_comm_transport", "necat_get_shard_timings",
+    "necat_index_build_sharded", "necat_find_candidates_sharded", "necat_map_pair_sharded",
 ]
 
 _lib = None
@@ -122,6 +132,16 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.necat_edlib_align_batch.argtypes = [vp, vp, C.c_uint64, vp, vp, vp, vp, C.c_uint64, C.c_double,
                                             vp, vp, vp, C.POINTER(vp), C.POINTER(vp)]
     lib.necat_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    lib.necat_comm_create.argtypes = [vp, C.c_int, C.c_int, HOST_ALLGATHER_FN, vp, C.c_char_p, C.POINTER(vp)]
+    lib.necat_comm_destroy.argtypes = [vp]
+    lib.necat_comm_destroy.restype = None
+    lib.necat_comm_transport.argtypes = [vp, C.c_char_p, C.c_size_t]
+    lib.necat_get_shard_timings.argtypes = [vp, C.POINTER(ShardTimings)]
+    lib.necat_index_build_sharded.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.necat_find_candidates_sharded.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(MapOptions), C.c_int, C.c_int,
+                                                  C.POINTER(vp), u64p, u64p]
+    lib.necat_map_pair_sharded.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(MapOptions), C.c_int, C.c_int, C.c_int,
+                                           C.POINTER(vp), u64p, u64p, u64p]
     lib.necat_free.argtypes = [vp]
     lib.necat_free.restype = None
     for name in EXPORTED_SYMBOLS:
@@ -180,6 +200,42 @@ class Context:
         t = Timings()
         self.lib.necat_get_timings(self.h, C.byref(t))
         return t
+
+    # ---- one volume on several GPUs (include/necat_hip.h, "one reference volume on several GPUs")
+    def shard_timings(self) -> ShardTimings:
+        t = ShardTimings()
+        self.lib.necat_get_shard_timings(self.h, C.byref(t))
+        return t
+
+    def comm(self, rank: int, nranks: int, allgather, transport: str = "auto") -> "Comm":
+        """allgather(send: bytes) -> list of nranks bytes objects (rank order): the host-side exchange of the job's launcher
+        (necat_amd.dist.torch_allgather for torch.distributed)"""
+        return Comm(self, rank, nranks, allgather, transport)
+
+    def build_index_sharded(self, comm: "Comm", ref: "Volume", k: int, max_occ: int) -> "Index":
+        h = C.c_void_p()
+        self._check(self.lib.necat_index_build_sharded(self.h, comm.h, ref.h, k, max_occ, C.byref(h)), "necat_index_build_sharded")
+        return Index(self, h, k)
+
+    def find_candidates_sharded(self, comm: "Comm", ix: "Index", ref: "Volume", reads: "Volume", read_start_id: int, ref_start_id: int,
+                                opt: MapOptions, pairwise: bool = True, chunk_reads: int = 64, root: int = 0):
+        """(records - all ranks' on the root, this rank's elsewhere -, this rank's own count)"""
+        p = C.c_void_p()
+        n, nl = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.necat_find_candidates_sharded(self.h, comm.h, ix.h, ref.h, reads.h, read_start_id, ref_start_id, 1 if pairwise else 0,
+                                                           C.byref(opt), chunk_reads, root, C.byref(p), C.byref(n), C.byref(nl)),
+                    "necat_find_candidates_sharded")
+        return self._take(p, n.value, CANDIDATE_DTYPE), int(nl.value)
+
+    def map_pair_sharded(self, comm: "Comm", ix: "Index", ref: "Volume", reads: "Volume", read_start_id: int, ref_start_id: int, opt: MapOptions,
+                         pairwise: bool = True, tail_match_len: int = 1, chunk_reads: int = 64, root: int = 0):
+        """(M4 records - all ranks' on the root -, this rank's own record count, this rank's candidates)"""
+        p = C.c_void_p()
+        n, nl, nc = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.lib.necat_map_pair_sharded(self.h, comm.h, ix.h, ref.h, reads.h, read_start_id, ref_start_id, 1 if pairwise else 0,
+                                                    C.byref(opt), tail_match_len, chunk_reads, root, C.byref(p), C.byref(n), C.byref(nl), C.byref(nc)),
+                    "necat_map_pair_sharded")
+        return self._take(p, n.value, M4_DTYPE), int(nl.value), int(nc.value)
 
     # ---- volumes
     def upload_volume(self, pac: np.ndarray, nbases: int, offsets: np.ndarray, sizes: np.ndarray) -> "Volume":
@@ -318,6 +374,45 @@ class Context:
         arr = np.frombuffer(buf, dtype=dtype, count=n)
         weakref.finalize(buf, self.lib.necat_free, C.c_void_p(p.value))   # arr keeps buf alive through .base
         return arr
+
+
+class Comm:
+    """necat_comm: the rank-to-rank data path (RCCL or HIP IPC) + the caller's host all-gather as a C callback"""
+
+    def __init__(self, ctx: Context, rank: int, nranks: int, allgather, transport: str = "auto"):
+        self.ctx, self.rank, self.nranks = ctx, rank, nranks
+
+        def cb(_user, send, recv, nbytes):
+            try:
+                parts = allgather(C.string_at(send, nbytes))
+                if len(parts) != nranks or any(len(x) != nbytes for x in parts):
+                    return 2
+                C.memmove(recv, b"".join(parts), nbytes * nranks)
+                return 0
+            except Exception:      # an exception must not cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = HOST_ALLGATHER_FN(cb)          # kept alive as long as the communicator
+        h = C.c_void_p()
+        ctx._check(ctx.lib.necat_comm_create(ctx.h, rank, nranks, self._cb, None, transport.encode(), C.byref(h)), "necat_comm_create")
+        self.h = h
+
+    def transport(self) -> str:
+        b = C.create_string_buffer(16)
+        self.ctx.lib.necat_comm_transport(self.h, b, 16)
+        return b.value.decode()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx.lib.necat_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class CnsResult:

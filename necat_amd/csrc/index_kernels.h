@@ -71,8 +71,9 @@ constexpr int kBucketChunk = 512;                     // bucket elements one blo
 // MODE 0: global bucket histogram.  MODE 1: scatter hash<<34|pos records into the bucket regions.
 template <int MODE>
 __global__ void __launch_bounds__(kPartThreads)
-k_part_pass(DevVolume vol, int k, int shift, u32 nb, u32* __restrict__ bucket_cnt, u64* __restrict__ bucket_cursor, u64* __restrict__ part)
+k_part_pass(DevVolume vol, int k, int shift, u32 nb, u32 b_lo, u32 b_hi, u32* __restrict__ bucket_cnt, u64* __restrict__ bucket_cursor, u64* __restrict__ part)
 {
+    // [b_lo, b_hi): the buckets (= the hash range) this rank builds - all of them on one GPU (necat_index_build_sharded)
     extern __shared__ u32 lds[];          // [nb] histogram (+ [2*nb] 64-bit bases in MODE 1)
     u32* hist = lds;
     u64* base = reinterpret_cast<u64*>(lds + nb);
@@ -92,6 +93,7 @@ k_part_pass(DevVolume vol, int k, int shift, u32 nb, u32* __restrict__ bucket_cn
                 if (p + (u64)k <= rend) {
                     const u64 h = kmer_hash_at(vol.bases, (i64)p, k);
                     const u32 b = (u32)(h >> shift);
+                    if (b < b_lo || b >= b_hi) continue;
                     if (MODE == 0 || pass == 0) atomicAdd(&hist[b], 1u);
                     else part[base[b] + atomicAdd(&hist[b], 1u)] = (h << kOffsetBits) | p;
                 }
@@ -312,11 +314,11 @@ NECAT_D void slice_count(const u64* __restrict__ part2, u64 lo, u64 hi, u32* cnt
 // kept_tot[s] = number of offset-list entries slice s contributes (k-mers with 1..max_occ occurrences)
 // (+ the same summed per bucket, so that the scan that follows runs over <= 4096 values, not 262 144)
 __global__ void __launch_bounds__(256)
-k_slice_count(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u32 max_occ, u32* __restrict__ kept_tot, u32* __restrict__ bucket_kept)
+k_slice_count(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u32 max_occ, u32* __restrict__ kept_tot, u32* __restrict__ bucket_kept, u32 s0)
 {
     __shared__ u32 cnt[kSlice];
     __shared__ u32 red[4];
-    const u64 s = blockIdx.x;
+    const u64 s = (u64)blockIdx.x + s0;           // s0 = first slice of this rank's hash range
     slice_count(part2, sub_start[s], sub_start[s + 1], cnt);
     u32 sum = 0;
     for (int i = threadIdx.x; i < kSlice; i += 256) sum += filtered_count(cnt[i], max_occ);
@@ -347,20 +349,22 @@ k_bucket_base(const u32* __restrict__ bucket_kept, u32 nb, u64* __restrict__ buc
 template <int T>
 __global__ void __launch_bounds__(T)
 k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u32 max_occ, const u64* __restrict__ bucket_base,
-             const u32* __restrict__ kept_tot, u64* __restrict__ kmer_stats, u32* __restrict__ tmp, u64* __restrict__ offset_list)
+             const u32* __restrict__ kept_tot, u64* __restrict__ kmer_stats, u32* __restrict__ tmp, u64* __restrict__ offset_list, u32 s0, u64 base_add)
 {
+    // s0 / base_add: first slice of this rank's hash range / offset-list entries of the ranks before it (the starts written
+    // here are final: positions in the gathered list; tmp is addressed the same way by a pointer shifted back by base_add)
     __shared__ u32 cnt[kSlice];      // occurrences per table entry of the slice
     __shared__ u32 cur[kSlice];      // start of the entry's group inside the slice, then its fill cursor
     __shared__ u32 wtot[T / 64];
     __shared__ u64 s_base;
-    const u64 s = blockIdx.x;
+    const u64 s = (u64)blockIdx.x + s0;
     const u64 lo = sub_start[s], hi = sub_start[s + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave == 0) {                 // the slice's base = its bucket's base + the kept totals of the bucket's earlier slices
         const u32 j = (u32)s & (kSubs - 1);
         u64 before = (u32)lane < j ? (u64)kept_tot[(s & ~(u64)(kSubs - 1)) + lane] : 0ULL;
         for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o);
-        if (lane == 0) s_base = bucket_base[s >> kSubBits] + before;
+        if (lane == 0) s_base = bucket_base[s >> kSubBits] + before + base_add;
     }
     __syncthreads();
     const u64 base = s_base;

@@ -6,6 +6,7 @@
 #include <mutex>
 #include <unordered_map>
 #include <time.h>
+#include <unistd.h>
 #include <numeric>
 
 #include "runtime.h"
@@ -13,6 +14,7 @@
 #include "seed_kernels.h"
 #include "ext_kernels.h"
 #include "cns_loop.h"
+#include "comm.h"
 
 using namespace necat;
 
@@ -105,6 +107,7 @@ int necat_ctx_create(int device_id, necat_ctx** out)
     ctx->device = device_id;
     read_knobs();
     memset(&ctx->tm, 0, sizeof ctx->tm);
+    memset(&ctx->shard_tm, 0, sizeof ctx->shard_tm);
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
         snprintf(ctx->devname, sizeof ctx->devname, "%s (%s), %d CUs", prop.name, prop.gcnArchName, prop.multiProcessorCount);
@@ -267,7 +270,23 @@ void necat_volume_free(necat_ctx* ctx, necat_volume* v)
 
 // ------------------------------------------------------------------------------------------ index
 
+namespace {
+int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, int kmer_size, int max_occ, necat_index** out);
+}
 int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, int max_occ, necat_index** out)
+{
+    return index_build_impl(ctx, nullptr, ref, kmer_size, max_occ, out);
+}
+
+int necat_index_build_sharded(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, int kmer_size, int max_occ, necat_index** out)
+{
+    if (!comm) return NECAT_ERR_ARG;
+    return index_build_impl(ctx, comm, ref, kmer_size, max_occ, out);
+}
+
+namespace {
+// comm != nullptr: this rank builds the slice of the table its hash range covers, then the slices are all-gathered
+int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, int kmer_size, int max_occ, necat_index** out)
 {
     const double w0 = wall_ms();
     if (!ctx || !ref || !out) return NECAT_ERR_ARG;
@@ -288,6 +307,12 @@ int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, in
     const bool lds_slices = partitioned && g_index_lds;
     const u32 NB = partitioned ? (1u << PB) : 0u;
     const int pshift = 2 * kmer_size - PB;
+    // hash-range sharding: rank g owns buckets [g NB / G, (g + 1) NB / G) = table entries [that << pshift); small tables
+    // (k < 11) and the global-atomic fallback are built whole on every rank
+    const int G = comm ? comm->nranks : 1, rk = comm ? comm->rank : 0;
+    const bool sharded = G > 1 && lds_slices && NB >= (u32)G;
+    const u32 b_lo = sharded ? (u32)((u64)rk * NB / G) : 0u, b_hi = sharded ? (u32)((u64)(rk + 1) * NB / G) : NB;
+    ctx->shard_tm.index_local_ms = 0; ctx->shard_tm.index_exchange_ms = 0; ctx->shard_tm.index_exchange_bytes = 0;
     u32* cnt32 = nullptr; u64* partial = nullptr;
     if (!lds_slices) {
         if ((rc = buf_ensure(ctx, ctx->scratch[SC_CNT32], T * 4)) || (rc = buf_ensure(ctx, ctx->scratch[SC_PARTIAL], (ntiles + 1) * 8))) { delete ix; return rc; }
@@ -310,11 +335,11 @@ int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, in
         d_part = (u64*)ctx->scratch[SC_PART].p;
         const unsigned pgrid = (unsigned)((ref->nbases + kPartPosPerBlock - 1) / kPartPosPerBlock);
         NECAT_HIP(ctx, hipMemsetAsync(d_bcnt, 0, (size_t)NB * 4, s));
-        hipLaunchKernelGGL(k_part_pass<0>, dim3(pgrid), dim3(kPartThreads), NB * 4, s, vol, kmer_size, pshift, NB, d_bcnt, (u64*)nullptr, (u64*)nullptr);
+        hipLaunchKernelGGL(k_part_pass<0>, dim3(pgrid), dim3(kPartThreads), NB * 4, s, vol, kmer_size, pshift, NB, b_lo, b_hi, d_bcnt, (u64*)nullptr, (u64*)nullptr);
         NECAT_CHECK_LAUNCH(ctx, "k_part_pass<hist>");
         hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, s, (const u32*)d_bcnt, NB, d_bstart, d_bcur);
         NECAT_CHECK_LAUNCH(ctx, "k_bucket_scan");
-        hipLaunchKernelGGL(k_part_pass<1>, dim3(pgrid), dim3(kPartThreads), NB * 4 + NB * 8, s, vol, kmer_size, pshift, NB, d_bcnt, d_bcur, d_part);
+        hipLaunchKernelGGL(k_part_pass<1>, dim3(pgrid), dim3(kPartThreads), NB * 4 + NB * 8, s, vol, kmer_size, pshift, NB, b_lo, b_hi, d_bcnt, d_bcur, d_part);
         NECAT_CHECK_LAUNCH(ctx, "k_part_pass<scatter>");
     }
     uint64_t n_off = 0;
@@ -330,21 +355,49 @@ int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, in
         hipLaunchKernelGGL(k_subpart, dim3(NB), dim3(256), 0, s, (const u64*)d_part, (const u64*)d_bstart, NB, d_part2, d_sub);
         NECAT_CHECK_LAUNCH(ctx, "k_subpart");
         NECAT_HIP(ctx, hipMemsetAsync(d_bcnt, 0, (size_t)NB * 4, s));                // reused: kept entries per bucket
-        hipLaunchKernelGGL(k_slice_count, dim3((unsigned)nsub), dim3(256), 0, s, (const u64*)d_part2, (const u64*)d_sub, (u32)max_occ, d_kept, d_bcnt);
+        const unsigned nsl = (b_hi - b_lo) * kSubs;                 // slices of this rank's hash range
+        const u32 s0 = b_lo * kSubs;
+        hipLaunchKernelGGL(k_slice_count, dim3(nsl), dim3(256), 0, s, (const u64*)d_part2, (const u64*)d_sub, (u32)max_occ, d_kept, d_bcnt, s0);
         NECAT_CHECK_LAUNCH(ctx, "k_slice_count");
         hipLaunchKernelGGL(k_bucket_base, dim3(1), dim3(1024), 0, s, (const u32*)d_bcnt, NB, d_bbase);
         NECAT_CHECK_LAUNCH(ctx, "k_bucket_base");
         NECAT_HIP(ctx, hipMemcpyAsync(&n_off, d_bbase + NB, 8, hipMemcpyDeviceToHost, s));
         NECAT_HIP(ctx, hipStreamSynchronize(s));
+        // the slice sizes of all ranks -> where this rank's entries sit in the gathered offset list
+        const uint64_t n_local = n_off;
+        std::vector<unsigned long long> counts(G, n_local);
+        uint64_t base_add = 0;
+        if (sharded) {
+            const unsigned long long mine = n_local;
+            if ((rc = comm::host_allgather(ctx, comm, &mine, counts.data(), 8))) { necat_index_free(ctx, ix); return rc; }
+            n_off = 0;
+            for (int g = 0; g < G; ++g) { if (g < rk) base_add += counts[g]; n_off += counts[g]; }
+            if (n_off >= (1ULL << 32)) { necat_index_free(ctx, ix); return set_err(ctx, NECAT_ERR_INTERNAL, "ranks disagree on the volume (offset list of %llu entries)", (unsigned long long)n_off); }
+        }
         ix->n_offsets = n_off;
         if (ctx->idx_cache[1].p && ctx->idx_cache[1].cap >= (n_off + 1) * 8) { ix->offset_list = (uint64_t*)ctx->idx_cache[1].p; ix->offs_cap = ctx->idx_cache[1].cap; ctx->idx_cache[1] = DevBuf(); }
         else { NECAT_HIP(ctx, hipMalloc((void**)&ix->offset_list, (n_off + 1) * 8 + (n_off >> 4))); ix->offs_cap = (n_off + 1) * 8 + (n_off >> 4); }
-        if ((rc = buf_ensure(ctx, ctx->scratch[SC_TMPLIST], (n_off + 1) * 4))) { necat_index_free(ctx, ix); return rc; }
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_TMPLIST], (n_local + 1) * 4))) { necat_index_free(ctx, ix); return rc; }
         // 512 threads per slice: 4 workgroups (32 waves) per CU instead of 5 x 4 waves with 256 - the kernel is a chain of short
         // barrier-separated phases and needs the waves to hide their latencies (10.6 -> 9.8 ms for the whole build)
-        hipLaunchKernelGGL(k_slice_emit<512>, dim3((unsigned)nsub), dim3(512), 0, s, (const u64*)d_part2, (const u64*)d_sub, (u32)max_occ, (const u64*)d_bbase, (const u32*)d_kept,
-                           ix->kmer_stats, (u32*)ctx->scratch[SC_TMPLIST].p, ix->offset_list);
+        hipLaunchKernelGGL(k_slice_emit<512>, dim3(nsl), dim3(512), 0, s, (const u64*)d_part2, (const u64*)d_sub, (u32)max_occ, (const u64*)d_bbase, (const u32*)d_kept,
+                           ix->kmer_stats, (u32*)ctx->scratch[SC_TMPLIST].p - base_add, ix->offset_list, s0, base_add);
         NECAT_CHECK_LAUNCH(ctx, "k_slice_emit");
+        if (sharded) {
+            NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s));
+            std::vector<comm::Part> ps(G), po(G);
+            uint64_t run = 0;
+            for (int g = 0; g < G; ++g) {
+                const u64 lo = (u64)g * NB / G, hi = (u64)(g + 1) * NB / G;
+                ps[g].off = (size_t)(lo << pshift) * 8; ps[g].bytes = (size_t)((hi - lo) << pshift) * 8;
+                po[g].off = (size_t)run * 8; po[g].bytes = (size_t)counts[g] * 8; run += counts[g];
+            }
+            if ((rc = comm::allgatherv_inplace(ctx, comm, ix->kmer_stats, ps, s))) { necat_index_free(ctx, ix); return rc; }
+            ctx->shard_tm.index_exchange_ms += comm->last_ms; ctx->shard_tm.index_exchange_bytes += comm->last_bytes;
+            if ((rc = comm::allgatherv_inplace(ctx, comm, ix->offset_list, po, s))) { necat_index_free(ctx, ix); return rc; }
+            ctx->shard_tm.index_exchange_ms += comm->last_ms; ctx->shard_tm.index_exchange_bytes += comm->last_bytes;
+            ctx->shard_tm.index_local_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
+        }
     } else {
     if (partitioned) {
         const u64 avg = ref->nbases / NB + 1;
@@ -383,10 +436,13 @@ int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, in
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s));
     NECAT_HIP(ctx, hipStreamSynchronize(s));
     ctx->tm.index_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
-    if (g_trace) fprintf(stderr, "[necat] index: events %.2f ms, host wall %.2f ms\n", ctx->tm.index_ms, wall_ms() - w0);
+    if (!sharded) ctx->shard_tm.index_local_ms = ctx->tm.index_ms;
+    if (g_trace) fprintf(stderr, "[necat] index: events %.2f ms, host wall %.2f ms (local %.2f ms, exchange %.2f ms, %.1f MB received)\n", ctx->tm.index_ms, wall_ms() - w0,
+                         ctx->shard_tm.index_local_ms, ctx->shard_tm.index_exchange_ms, ctx->shard_tm.index_exchange_bytes / 1e6);
     *out = ix;
     return NECAT_OK;
 }
+}  // namespace
 
 int necat_index_size(const necat_index* ix, uint64_t* table_entries, uint64_t* n_offsets)
 {
@@ -435,9 +491,15 @@ void fill_groups(DevCands* dev, const std::vector<u64>& by_read, u32 nreads)
     if (dev->group_off.size() == 1) dev->group_off.insert(dev->group_off.begin(), 0);
 }
 
+// the query reads one rank of a multi-GPU job processes: chunks of `chunk` reads, chunk c on rank c % nparts
+struct ReadSel {
+    int part = 0, nparts = 1, chunk = 64;
+    bool has(u32 r) const { return nparts <= 1 || (int)((r / (u32)chunk) % (u32)nparts) == part; }
+};
+
 int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, const necat_volume* reads,
               int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt,
-              necat_candidate** out, uint64_t* n_out, DevCands* dev)
+              necat_candidate** out, uint64_t* n_out, DevCands* dev, const ReadSel* sel = nullptr)
 {
     if (opt->kmer_size != ix->k) return set_err(ctx, NECAT_ERR_ARG, "index was built for k=%d, options say %d", ix->k, opt->kmer_size);
     if (opt->scan_window < 1 || opt->block_size < 1 || opt->block_size > 32767)
@@ -468,14 +530,24 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
     NECAT_HIP(ctx, hipStreamSynchronize(s));
     tick("hits kernel + copy");
     // ---- plan: reads in descending work order, chunks bounded by a scratch budget
-    std::vector<u32> order(nreads);
+    std::vector<u32> order;
     {
-        // descending work, ascending read id inside equal work: one sort of packed keys
-        std::vector<u64> keys(nreads);
+        // descending work, ascending read id inside equal work: one sort of packed keys (only this rank's reads)
+        std::vector<u64> keys;
+        keys.reserve(nreads);
         for (u32 r = 0; r < nreads; ++r)
-            keys[r] = ((u64)(0xffffffffu - std::max(hits[2 * (size_t)r], hits[2 * (size_t)r + 1])) << 32) | r;
+            if (!sel || sel->has(r)) keys.push_back(((u64)(0xffffffffu - std::max(hits[2 * (size_t)r], hits[2 * (size_t)r + 1])) << 32) | r);
         std::sort(keys.begin(), keys.end());
-        for (u32 i = 0; i < nreads; ++i) order[i] = (u32)keys[i];
+        order.resize(keys.size());
+        for (size_t i = 0; i < keys.size(); ++i) order[i] = (u32)keys[i];
+    }
+    const u32 nsel = (u32)order.size();
+    ctx->shard_tm.reads_local = nsel;
+    if (nsel == 0) {
+        if (dev) { dev->n = 0; dev->d = nullptr; dev->group_off.assign(2, 0); }
+        else { *out = (necat_candidate*)result_alloc(sizeof(necat_candidate)); *n_out = 0; }
+        ctx->tm.seed_ms = 0;
+        return NECAT_OK;
     }
     const u64 budget_hits = g_seed_budget;   // default ~48 M pool blocks (~13 GB of SBlocks) per chunk
     SeedParams P;
@@ -485,14 +557,14 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
     P.debug_phase = getenv("NECAT_SEED_DEBUG") ? atoi(getenv("NECAT_SEED_DEBUG")) : 0;
     NECAT_HIP(ctx, hipMemsetAsync(d_err, 0, 4, s));
     u32 pos = 0;
-    std::vector<i32> ncands_by_order(nreads, 0);
+    std::vector<i32> ncands_by_order(nsel, 0);
     // every chunk's compacted candidates stay on the device (SC_SEED_ALL), in ORDER-index space
     u64 packed_total = 0;
-    std::vector<u64> packed_off(nreads + 1, 0);
-    while (pos < nreads) {
+    std::vector<u64> packed_off(nsel + 1, 0);
+    while (pos < nsel) {
         u64 acc = 0; u32 hi = pos;
         auto both = [&](u32 r) { return (u64)hits[2 * (size_t)r] + hits[2 * (size_t)r + 1] + 2; };
-        while (hi < nreads && (hi == pos || acc + both(order[hi]) <= budget_hits)) { acc += both(order[hi]); ++hi; }
+        while (hi < nsel && (hi == pos || acc + both(order[hi]) <= budget_hits)) { acc += both(order[hi]); ++hi; }
         const u32 n = hi - pos;
         std::vector<SeedMeta> meta(n);
         u64 ht_tot = 0, pool_tot = 0, chain_tot = 0, out_tot = 0;
@@ -555,7 +627,7 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
         NECAT_HIP(ctx, hipStreamSynchronize(s));
         if (herr) { return set_err(ctx, NECAT_ERR_CAPACITY, "seeding scratch overflow (code %d)", herr); }
         tick("collect + eval kernels");
-        if (pos == 0 && hi == nreads) {
+        if (pos == 0 && hi == nsel) {
             // the usual case, one chunk: pack on the device straight into ascending read order and copy
             // into the (pinned) result block
             std::vector<u64> by_read((size_t)nreads + 1, 0), foff(n);
@@ -607,10 +679,10 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
     const u64 total = packed_total;
     necat_candidate* res = dev ? nullptr : (necat_candidate*)result_alloc(std::max<u64>(1, total) * sizeof(necat_candidate));
     if (!dev && !res) return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed");
-    std::vector<u64> by_read((size_t)nreads + 1, 0), dst_off(nreads);
-    for (u32 i = 0; i < nreads; ++i) by_read[order[i] + 1] = (u64)ncands_by_order[i];
+    std::vector<u64> by_read((size_t)nreads + 1, 0), dst_off(nsel);
+    for (u32 i = 0; i < nsel; ++i) by_read[order[i] + 1] = (u64)ncands_by_order[i];
     for (u32 r = 0; r < nreads; ++r) by_read[r + 1] += by_read[r];
-    for (u32 i = 0; i < nreads; ++i) dst_off[i] = by_read[order[i]];
+    for (u32 i = 0; i < nsel; ++i) dst_off[i] = by_read[order[i]];
     if (dev) { dev->n = total; fill_groups(dev, by_read, nreads); }
     if (total) {
         int rc2;
@@ -622,11 +694,11 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
         i32* d_cnt = (i32*)mb;
         necat_candidate* d_fin = (necat_candidate*)ctx->scratch[SC_SEED_FINAL].p;
         hipError_t e[7];
-        e[0] = hipMemcpyAsync(d_src, packed_off.data(), (size_t)nreads * 8, hipMemcpyHostToDevice, s);
-        e[1] = hipMemcpyAsync(d_dsto, dst_off.data(), (size_t)nreads * 8, hipMemcpyHostToDevice, s);
-        e[2] = hipMemcpyAsync(d_cnt, ncands_by_order.data(), (size_t)nreads * 4, hipMemcpyHostToDevice, s);
-        hipLaunchKernelGGL(k_move_cands, dim3(grid_for((u64)nreads * 64, 256)), dim3(256), 0, s, (const necat_candidate*)ctx->scratch[SC_SEED_ALL].p,
-                           (const u64*)d_src, (const u64*)d_dsto, (const i32*)d_cnt, nreads, d_fin);
+        e[0] = hipMemcpyAsync(d_src, packed_off.data(), (size_t)nsel * 8, hipMemcpyHostToDevice, s);
+        e[1] = hipMemcpyAsync(d_dsto, dst_off.data(), (size_t)nsel * 8, hipMemcpyHostToDevice, s);
+        e[2] = hipMemcpyAsync(d_cnt, ncands_by_order.data(), (size_t)nsel * 4, hipMemcpyHostToDevice, s);
+        hipLaunchKernelGGL(k_move_cands, dim3(grid_for((u64)nsel * 64, 256)), dim3(256), 0, s, (const necat_candidate*)ctx->scratch[SC_SEED_ALL].p,
+                           (const u64*)d_src, (const u64*)d_dsto, (const i32*)d_cnt, nsel, d_fin);
         e[3] = hipGetLastError();
         if (dev) dev->d = d_fin;
         e[4] = dev ? hipSuccess : hipMemcpyAsync(res, d_fin, total * sizeof(necat_candidate), hipMemcpyDeviceToHost, s);
@@ -891,9 +963,11 @@ struct AlignOut {
 
 // The extension loop behind necat_extend (M4 records, containment filter) and necat_onc_align_batch
 // (every candidate's alignment with its columns, `ao` != nullptr).
+struct DevOut { const necat_m4* d = nullptr; uint64_t n = 0; };      // records left on the device (sharded calls gather them there)
+
 int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* reads, int read_start_id, int ref_start_id,
                 const necat_candidate* cands, uint64_t n, const necat_map_options* opt, int tail_match_len,
-                necat_m4** out, uint64_t* n_out, AlignOut* ao, const DevCands* dev = nullptr)
+                necat_m4** out, uint64_t* n_out, AlignOut* ao, const DevCands* dev = nullptr, DevOut* devout = nullptr)
 {
     // dev != nullptr (necat_map_pair): the candidates are this library's own, still on the device
     auto t_prev = std::chrono::steady_clock::now();
@@ -1118,6 +1192,13 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     NECAT_HIP(ctx, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, s));
     NECAT_HIP(ctx, hipStreamSynchronize(s));
     if (herr) { cleanup(); return set_err(ctx, NECAT_ERR_INTERNAL, "extension kernels reported error code %d", herr); }
+    if (devout) {
+        devout->d = d_out; devout->n = nout;
+        NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s));
+        NECAT_HIP(ctx, hipStreamSynchronize(s));
+        ctx->tm.extend_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
+        return NECAT_OK;
+    }
     necat_m4* res = (necat_m4*)result_alloc(std::max<size_t>(1, nout) * sizeof(necat_m4));
     if (!res) { cleanup(); return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
     if (nout) NECAT_HIP(ctx, hipMemcpyAsync(res, d_out, (size_t)nout * sizeof(necat_m4), hipMemcpyDeviceToHost, s));
@@ -1156,6 +1237,163 @@ int necat_map_pair(necat_ctx* ctx, const necat_index* ix, const necat_volume* re
     if (n_candidates) *n_candidates = dev.n;
     if (dev.n == 0) return NECAT_OK;
     return extend_impl(ctx, ref, reads, read_start_id, ref_start_id, nullptr, dev.n, &o, tail_match_len, out, n_out, nullptr, &dev);
+}
+
+// ------------------------------------------------------------------------------------------ one volume on several GPUs
+
+int necat_comm_create(necat_ctx* ctx, int rank, int nranks, necat_host_allgather_fn fn, void* user, const char* transport, necat_comm** out)
+{
+    if (!ctx || !out || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn)) return NECAT_ERR_ARG;
+    *out = nullptr;
+    NECAT_HIP(ctx, hipSetDevice(ctx->device));
+    necat_comm* c = new necat_comm();
+    c->rank = rank; c->nranks = nranks; c->gather = fn; c->user = user;
+    int want = -1;                                   // -1 = auto
+    const char* env = getenv("NECAT_COMM");
+    const char* t = (transport && *transport && strcmp(transport, "auto")) ? transport : (env && *env ? env : "auto");
+    if (!strcmp(t, "rccl")) want = 0; else if (!strcmp(t, "ipc")) want = 1;
+    else if (strcmp(t, "auto")) { delete c; return set_err(ctx, NECAT_ERR_ARG, "unknown transport '%s' (auto, rccl, ipc)", t); }
+    int rc = NECAT_OK;
+    if (nranks > 1) {
+        // who shares a device with whom: (host, PCI bus id) of every rank
+        struct Where { char host[64]; char bus[32]; } me, *all;
+        std::vector<Where> ws(nranks);
+        all = ws.data();
+        memset(&me, 0, sizeof me);
+        (void)gethostname(me.host, sizeof me.host - 1);
+        if (hipDeviceGetPCIBusId(me.bus, sizeof me.bus, ctx->device) != hipSuccess) snprintf(me.bus, sizeof me.bus, "dev%d", ctx->device);
+        if ((rc = comm::host_allgather(ctx, c, &me, all, sizeof(Where)))) { delete c; return rc; }
+        bool shared = false;
+        for (int a = 0; a < nranks; ++a) for (int b = a + 1; b < nranks; ++b)
+            if (!strcmp(all[a].host, all[b].host) && !strcmp(all[a].bus, all[b].bus)) shared = true;
+        if (want < 0) want = shared ? 1 : 0;
+        if (want == 0 && shared) { delete c; return set_err(ctx, NECAT_ERR_COMM, "RCCL cannot run two ranks on one device (use transport \"ipc\")"); }
+    }
+    c->transport = want < 0 ? 0 : want;
+    if (c->transport == 0 && nranks > 1) {
+        if ((rc = comm::load_rccl(ctx, c))) { delete c; return rc; }
+        ncclUniqueId id, *ids;
+        std::vector<ncclUniqueId> all_ids(nranks);
+        ids = all_ids.data();
+        memset(&id, 0, sizeof id);
+        if (rank == 0) { ncclResult_t r = c->p_GetUniqueId(&id); if (r != ncclSuccess) { delete c; return set_err(ctx, NECAT_ERR_COMM, "ncclGetUniqueId: %s", c->p_GetErrorString(r)); } }
+        if ((rc = comm::host_allgather(ctx, c, &id, ids, sizeof id))) { delete c; return rc; }
+        ncclResult_t r = c->p_CommInitRank(&c->nccl, nranks, ids[0], rank);
+        if (r != ncclSuccess) { const int e = set_err(ctx, NECAT_ERR_COMM, "ncclCommInitRank: %s", c->p_GetErrorString(r)); delete c; return e; }
+    }
+    *out = c;
+    return NECAT_OK;
+}
+
+void necat_comm_destroy(necat_comm* c)
+{
+    if (!c) return;
+    if (c->nccl && c->p_CommDestroy) (void)c->p_CommDestroy(c->nccl);
+    delete c;                                       // librccl stays loaded: other users in the process may share it
+}
+
+int necat_comm_transport(const necat_comm* c, char* buf, size_t n)
+{
+    if (!c || !buf || !n) return NECAT_ERR_ARG;
+    snprintf(buf, n, "%s", c->transport == 0 ? "rccl" : "ipc");
+    return NECAT_OK;
+}
+
+int necat_get_shard_timings(const necat_ctx* ctx, necat_shard_timings* t)
+{
+    if (!ctx || !t) return NECAT_ERR_ARG;
+    *t = ctx->shard_tm;
+    return NECAT_OK;
+}
+
+namespace {
+// gather-v of fixed-size records on `root`: every rank's `n_local` records at d_local (device memory; may be null when 0).
+// Root: host_out = all records (its own first), *n_out their number; other ranks: their own records.
+int gather_records(necat_ctx* ctx, necat_comm* comm, int root, const void* d_local, uint64_t n_local, size_t rec, void** host_out, uint64_t* n_out)
+{
+    hipStream_t s = ctx->stream;
+    const int G = comm->nranks;
+    std::vector<unsigned long long> cnt(G, 0);
+    const unsigned long long mine = n_local;
+    int rc = comm::host_allgather(ctx, comm, &mine, cnt.data(), 8);
+    if (rc) return rc;
+    // the root's own records come first in its output
+    std::vector<size_t> bytes(G);
+    uint64_t total = 0;
+    for (int g = 0; g < G; ++g) { bytes[g] = (size_t)cnt[g] * rec; total += cnt[g]; }
+    const bool is_root = comm->rank == root;
+    void* d_all = nullptr;
+    if (is_root) {
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_GATHER], std::max<size_t>(256, (size_t)total * rec)))) return rc;
+        d_all = ctx->scratch[SC_GATHER].p;
+    }
+    if ((rc = comm::gatherv(ctx, comm, d_local, bytes, root, d_all, s))) return rc;
+    ctx->shard_tm.gather_ms = comm->last_ms; ctx->shard_tm.gather_bytes = comm->last_bytes;
+    const uint64_t n_ret = is_root ? total : n_local;
+    void* res = result_alloc(std::max<size_t>(1, (size_t)n_ret * rec));
+    if (!res) return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed");
+    if (is_root) {
+        // rank order on the device; own records first on the host
+        size_t off_root = 0; for (int g = 0; g < root; ++g) off_root += bytes[g];
+        hipError_t e = hipSuccess;
+        size_t at = 0;
+        if (bytes[root]) { e = hipMemcpyAsync(res, (const char*)d_all + off_root, bytes[root], hipMemcpyDeviceToHost, s); at += bytes[root]; }
+        if (e == hipSuccess && off_root) { e = hipMemcpyAsync((char*)res + at, d_all, off_root, hipMemcpyDeviceToHost, s); at += off_root; }
+        const size_t after = off_root + bytes[root], rest = (size_t)total * rec - after;
+        if (e == hipSuccess && rest) e = hipMemcpyAsync((char*)res + at, (const char*)d_all + after, rest, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { necat_free(res); return set_err(ctx, NECAT_ERR_DEVICE, "record copy failed: %s", hipGetErrorString(e)); }
+    } else if (n_local) {
+        hipError_t e = hipMemcpyAsync(res, d_local, (size_t)n_local * rec, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { necat_free(res); return set_err(ctx, NECAT_ERR_DEVICE, "record copy failed: %s", hipGetErrorString(e)); }
+    }
+    *host_out = res; *n_out = n_ret;
+    return NECAT_OK;
+}
+}  // namespace
+
+int necat_find_candidates_sharded(necat_ctx* ctx, necat_comm* comm, const necat_index* ix, const necat_volume* ref, const necat_volume* reads,
+                                  int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt, int chunk_reads, int root,
+                                  necat_candidate** out, uint64_t* n_out, uint64_t* n_local)
+{
+    if (!ctx || !comm || !ix || !ref || !reads || !opt || !out || !n_out || chunk_reads < 1 || root < 0 || root >= comm->nranks) return NECAT_ERR_ARG;
+    *out = nullptr; *n_out = 0;
+    if (n_local) *n_local = 0;
+    ReadSel sel; sel.part = comm->rank; sel.nparts = comm->nranks; sel.chunk = chunk_reads;
+    DevCands dev;
+    int rc = find_impl(ctx, ix, ref, reads, read_start_id, ref_start_id, pairwise, opt, nullptr, nullptr, &dev, &sel);
+    if (rc) return rc;
+    if (n_local) *n_local = dev.n;
+    void* res = nullptr;
+    if ((rc = gather_records(ctx, comm, root, dev.d, dev.n, sizeof(necat_candidate), &res, n_out))) return rc;
+    *out = (necat_candidate*)res;
+    return NECAT_OK;
+}
+
+int necat_map_pair_sharded(necat_ctx* ctx, necat_comm* comm, const necat_index* ix, const necat_volume* ref, const necat_volume* reads,
+                           int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt, int tail_match_len, int chunk_reads, int root,
+                           necat_m4** out, uint64_t* n_out, uint64_t* n_local, uint64_t* n_candidates)
+{
+    if (!ctx || !comm || !ix || !ref || !reads || !opt || !out || !n_out || chunk_reads < 1 || root < 0 || root >= comm->nranks) return NECAT_ERR_ARG;
+    *out = nullptr; *n_out = 0;
+    if (n_local) *n_local = 0;
+    if (n_candidates) *n_candidates = 0;
+    necat_map_options o = *opt;
+    o.job = 1;
+    ReadSel sel; sel.part = comm->rank; sel.nparts = comm->nranks; sel.chunk = chunk_reads;
+    DevCands dev;
+    int rc = find_impl(ctx, ix, ref, reads, read_start_id, ref_start_id, pairwise, &o, nullptr, nullptr, &dev, &sel);
+    if (rc) return rc;
+    if (n_candidates) *n_candidates = dev.n;
+    DevOut dout;
+    ctx->tm.extend_ms = 0;
+    if (dev.n && (rc = extend_impl(ctx, ref, reads, read_start_id, ref_start_id, nullptr, dev.n, &o, tail_match_len, nullptr, nullptr, nullptr, &dev, &dout))) return rc;
+    if (n_local) *n_local = dout.n;
+    void* res = nullptr;
+    if ((rc = gather_records(ctx, comm, root, dout.d, dout.n, sizeof(necat_m4), &res, n_out))) return rc;
+    *out = (necat_m4*)res;
+    return NECAT_OK;
 }
 
 int necat_onc_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_volume* reads, int read_start_id, int ref_start_id,

@@ -56,6 +56,62 @@ def split_templates(tmpl_off: Sequence[int], world: int) -> List[Tuple[int, int]
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
+# ---- fine granularity: ONE volume on several GPUs (necat_index_build_sharded / necat_*_sharded, include/necat_hip.h).
+# The arithmetic of the C library restated on numpy arrays: what the multi-process CPU tests check, and what a launcher
+# needs to reason about balance.
+
+OFFSET_BITS = 34          # kmer_stats[h] = cnt << 34 | start   (lookup_table.h:6-21)
+OFFSET_MASK = (1 << OFFSET_BITS) - 1
+
+
+def index_buckets(k: int) -> Tuple[int, int]:
+    """(number of hash-prefix buckets NB, log2 of the table entries per bucket) of the partitioned build: buckets of
+    2^18 table entries, at most 4096 of them; (0, 0) for the small tables every rank builds whole (k < 11)"""
+    pb = min(12, 2 * k - 18)
+    if pb < 4:
+        return 0, 0
+    return 1 << pb, 2 * k - pb
+
+
+def hash_range(k: int, rank: int, world: int) -> Tuple[int, int]:
+    """table entries [lo, hi) rank `rank` builds: buckets [rank NB / world, (rank + 1) NB / world)"""
+    nb, shift = index_buckets(k)
+    if nb < world:
+        return (0, 4 ** k)
+    return ((rank * nb // world) << shift, ((rank + 1) * nb // world) << shift)
+
+
+def index_slice(stats, offs, lo: int, hi: int):
+    """What the rank that owns table entries [lo, hi) produces before the exchange: its kmer_stats slice with starts
+    counted from ITS first offset, and its run of the offset list (the list is grouped by ascending hash, so a hash
+    range is a contiguous run).  numpy uint64 arrays in the reference layout."""
+    import numpy as np
+    sl = stats[lo:hi].copy()
+    cnt = sl >> np.uint64(OFFSET_BITS)
+    n_before = int((stats[:lo] >> np.uint64(OFFSET_BITS)).sum())
+    n_mine = int(cnt.sum())
+    nz = cnt > 0
+    sl[nz] -= np.uint64(n_before)
+    return sl, offs[n_before:n_before + n_mine].copy()
+
+
+def rebase_slice(stats_slice, base: int):
+    """starts of a received kmer_stats slice moved by the number of offset entries of the ranks before its owner
+    (the exclusive scan of the slice sizes); absent k-mers stay 0"""
+    import numpy as np
+    out = stats_slice.copy()
+    nz = (out >> np.uint64(OFFSET_BITS)) > 0
+    out[nz] += np.uint64(base)
+    return out
+
+
+def read_chunks(nreads: int, chunk_reads: int, rank: int, world: int):
+    """query reads of rank `rank`: chunk c (reads [c chunk, (c + 1) chunk)) belongs to rank c % world"""
+    import numpy as np
+    r = np.arange(nreads)
+    return r[(r // chunk_reads) % world == rank]
+
+
 def reduce_step_stats(dist, elapsed: float, overlaps: float, gbp: float, device=None):
     """(max elapsed, total overlaps, total Gbp) over all ranks; identity when dist is None."""
     if dist is None:

@@ -62,3 +62,65 @@ def test_world_size_2_reduction():
     assert total_pairs == 15                     # V (V + 1) / 2 for V = 5
     for rank, (tmax, n, gbp), _ in res:
         assert tmax == 2.0 and n == 15.0 and gbp == 1.5
+
+
+# ---- fine granularity: one volume on several ranks (the arithmetic of necat_index_build_sharded on real arrays) ----
+
+def _index_worker(rank, world, port, vol_path, k, q):
+    """Each rank cuts ITS hash-range slice out of the single-rank index (= what its local build produces: starts counted
+    from its own first offset), the ranks all-gather slice sizes, slices and offset runs over gloo (through the very
+    callback glue bench.py hands to the C library), rebase the starts by the exclusive scan of the sizes, and must end
+    up with the single-rank index again."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from necat_amd import dist as ndist
+    from oracle import oracle_api as ora
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    allgather = ndist.torch_allgather(dist)
+    stats, offs = ora.build_index(vol_path, k, 500)
+    lo, hi = shard.hash_range(k, rank, world)
+    my_stats, my_offs = shard.index_slice(stats, offs, lo, hi)
+    # 1. slice sizes (the host all-gather of 8 bytes per rank the library does mid-build)
+    sizes = [int(np.frombuffer(b, dtype=np.uint64)[0]) for b in allgather(np.uint64(my_offs.shape[0]).tobytes())]
+    base = [sum(sizes[:g]) for g in range(world)]
+    # 2. the owner writes final starts (the library adds its base inside k_slice_emit), then the slices travel
+    mine_final = shard.rebase_slice(my_stats, base[rank])
+    parts = allgather(mine_final.tobytes()) if len(set(hi2 - lo2 for lo2, hi2 in (shard.hash_range(k, g, world) for g in range(world)))) == 1 else None
+    if parts is None:      # unequal slices (world does not divide the bucket count): gather-v through object lists
+        objs = [None] * world
+        dist.all_gather_object(objs, mine_final.tobytes())
+        parts = objs
+    full_stats = np.concatenate([np.frombuffer(b, dtype=np.uint64) for b in parts])
+    objs = [None] * world
+    dist.all_gather_object(objs, my_offs.tobytes())
+    full_offs = np.concatenate([np.frombuffer(b, dtype=np.uint64) for b in objs])
+    ok = bool(np.array_equal(full_stats, stats) and np.array_equal(full_offs, offs))
+    # the slices tile the table and the reads
+    covered = sum(h - l for l, h in (shard.hash_range(k, g, world) for g in range(world)))
+    reads = np.concatenate([shard.read_chunks(1000, 64, g, world) for g in range(world)])
+    q.put((rank, ok, sizes, covered == 4 ** k, sorted(reads.tolist()) == list(range(1000)), int(stats.shape[0])))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,k", [(2, 12), (3, 11)])
+def test_sharded_index_arithmetic_over_gloo(tmp_path, world, k):
+    import torch.multiprocessing as mp
+    from tests import util
+    d, rs, nv = util.make_dataset(tmp_path, genome=60_000, coverage=10.0, seed=9)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_index_worker, args=(r, world, port, os.path.join(d, "vol0"), k, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok, sizes, tiles, reads_ok, T in res:
+        assert ok, "rank %d: gathered index differs from the single-rank one" % rank
+        assert tiles and reads_ok and T == 4 ** k
+        assert sum(sizes) > 10_000 and min(sizes) > 0
