@@ -11,6 +11,7 @@
 // columns and tracebacks are bit-identical.
 #pragma once
 #include "dev_common.h"
+#include "ext_core.h"      // TailScan (walk_block)
 
 namespace necat {
 
@@ -328,6 +329,56 @@ NECAT_HD void traceback_block(int qn, int tn, Mat& mat, Ops& ops)
         ops.push(term_op);
         for (int i = 0; i < c + 1; ++i) ops.push(2);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same walk, restated for the GPU's instruction mix (this is what k_traceback runs; traceback_block above is the
+// reference formulation the CPU tests replay both against).  With r the query row and c the column of the cell, the two
+// record bits of the cell ARE the op code (a | b << 1: 0 match, 1 up / insert, 2 left / delete, 3 mismatch); a move
+// consumes a row unless it is "left" and a column unless it is "up"; the walk ends when a row or a column runs out and
+// the rest of the other one is one run of inserts / deletes.  The tail statistics (TailScan) are only kept up step by step
+// until the first run of M matches has been seen - a few dozen steps - after that a step only counts matches: every row
+// and every column is consumed exactly once, so nq = qn and nt = tn at the end, and n is the step count.
+//   Mat::rec(c, b, A, B)     band word (c, b)
+//   Sink::put(i, op)         op number i (END -> START order), called only while Sink::storing()
+// ---------------------------------------------------------------------------------------------
+
+template <class Mat, class Sink>
+NECAT_HD void walk_block(int qn, int tn, Mat& mat, Sink& sink, TailScan& ts)
+{
+    const int M = ts.M;
+    const bool storing = sink.storing();
+    int r = qn - 1, c = tn - 1, wb = r >> 6;
+    u64 A, B;
+    mat.rec(c, wb, A, B);
+    int n = 0, nmat = 0;
+    int m = 0, hit = 0, nq = 0, nt = 0, acnt = 0, qcnt = 0, tcnt = 0, mcnt = 0;
+    for (;;) {
+        const int sh = r & 63;
+        const u32 a = (u32)(A >> sh) & 1u, b = (u32)(B >> sh) & 1u;
+        const int op = (int)(a | (b << 1));
+        const int drow = 1 - (int)(b & (a ^ 1u)), dcol = 1 - (int)(a & (b ^ 1u));    // not "left" / not "up"
+        const int mt = (int)((a | b) ^ 1u);
+        if (storing) sink.put(n, op);
+        ++n; nmat += mt;
+        if (!hit) {
+            nq += drow; nt += dcol;
+            m = mt ? m + 1 : 0;
+            if (m == M) { hit = 1; acnt = n; qcnt = nq; tcnt = nt; mcnt = nmat; }
+        }
+        r -= drow; c -= dcol;
+        if ((r | c) < 0) break;
+        const int wb2 = r >> 6;
+        if (dcol | (wb2 ^ wb)) mat.rec(c, wb2, A, B);
+        wb = wb2;
+    }
+    // out of the first column: the rows left are inserts; out of the first row: the columns left are deletes
+    const int kop = c < 0 ? 1 : 2, k = c < 0 ? r + 1 : c + 1;
+    if (storing) for (int i = 0; i < k; ++i) sink.put(n + i, kop);
+    n += k;
+    if (!hit && k > 0) m = 0;
+    ts.n = n; ts.nq = qn; ts.nt = tn; ts.nmat = nmat; ts.m = m; ts.hit = hit;
+    ts.acnt = acnt; ts.qcnt = qcnt; ts.tcnt = tcnt; ts.mcnt = mcnt;
 }
 
 }  // namespace necat

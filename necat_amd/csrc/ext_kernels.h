@@ -80,16 +80,23 @@ NECAT_D void ext_append_block(const ExtTask& t, u32 ti, bool go, const ExtLists&
 {
     const bool isA = go && t.qblk <= kOcaBlockSize && t.tblk <= kOcaBlockSize;
     const bool isB = go && !isA;
+    // inside a wave's share of list A the FULL blocks (512 x 512) come first: the DP kernel takes 8 consecutive items per
+    // wave and has a faster path for waves made of full blocks only, so the last blocks should sit together, not one in
+    // every wave
+    const bool isF = isA && t.qblk == kOcaBlockSize && t.tblk == kOcaBlockSize;
+    const bool isP = isA && !isF;
     const int lane = (int)(threadIdx.x & 63);
     const u64 below = (1ULL << lane) - 1ULL;
-    const u64 mA = __ballot(isA), mB = __ballot(isB);
+    const u64 mF = __ballot(isF), mP = __ballot(isP), mB = __ballot(isB);
+    const u64 mA = mF | mP;
     u32 baseA = 0, baseB = 0;
     if (mA) { const int leader = ctz64(mA); if (lane == leader) baseA = atomicAdd(&L.count[0], (u32)popc64(mA)); baseA = __shfl(baseA, leader); }
     if (mB) { const int leader = ctz64(mB); if (lane == leader) baseB = atomicAdd(&L.count[1], (u32)popc64(mB)); baseB = __shfl(baseB, leader); }
     if (go) {
         BlockItem it;
         it.g = ext_frag_geom(t); it.task = (i32)ti; it.qn = (i16)t.qblk; it.tn = (i16)t.tblk;
-        if (isA) L.itemsA[baseA + (u32)popc64(mA & below)] = it;
+        if (isF) L.itemsA[baseA + (u32)popc64(mF & below)] = it;
+        else if (isP) L.itemsA[baseA + (u32)popc64(mF) + (u32)popc64(mP & below)] = it;
         else L.itemsB[baseB + (u32)popc64(mB & below)] = it;
     }
 }
@@ -297,6 +304,180 @@ NECAT_D int dpp_from_lane_below(int v)   // lane i receives v of lane i-1 (withi
     return __builtin_amdgcn_update_dpp(1, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fast path of the list-A DP kernel: every block of the wave is a FULL block (512 x 512, 8 words, no pad rows).
+// Same recurrence, same results; what changes is how it is issued.  Measured on MI355X (tools/valu_microbench2.hip,
+// profiles/r02_valu_microbench2.txt): 32-bit add / and / or / xor / v_bitop3 issue in 2 SIMD cycles per wave64, but
+// shifts, v_alignbit, v_bfe, DPP moves, compares, v_cndmask, carry adds and every 64-bit op take 3.5 - and a 64-bit
+// v_lshl_add_u64 costs one such slot where the add_co / addc pair costs two.  So here:
+//   * (Eq & Pv) + Pv is ONE 64-bit add;
+//   * the horizontal carries travel as the raw high words of Ph / Mh (two DPP moves) and enter the next word's
+//     shift-by-one through the funnel shift itself (v_alignbit takes bit 31 of the neighbour's word): no hout
+//     arithmetic, no +1 / -1 decoding, no select for the top word - the lane of word 7 publishes the constant
+//     boundary carry (+1) for the top word of the next block in its DPP row;
+//   * the target stream of lane b is skewed by b columns when a 32-column window is loaded, so every lane reads bit
+//     (step & 31) of its window: the reload is wave-uniform (a scalar branch, no exec-mask games), and the step loop has
+//     a scalar trip count;
+//   * no per-step predicate: all 64 lanes are inside their blocks for steps 7 .. 511; the 7 fill / 7 drain steps run
+//     the same body under a lane mask;
+//   * the SHW result (smallest bottom-row value, FIRST column attaining it) is one running minimum of
+//     (score << 10 | step) - no compare / branch chain;
+//   * in the NW pass lanes past their block's end column keep computing (nothing reads them) and only the store is
+//     masked.
+// The sanity re-derivation of the distance at the end of the NW pass (err = 2 in the general path) is not repeated here.
+struct FastWord {
+    u64 Pv, Mv;
+    u32 pubP, pubM;      // high words of Ph / Mh of this lane's last step: what the lane below reads (bit 31 = carry +1 / -1)
+};
+
+// v_bitop3_b32: any function of three words in one full-rate instruction.  IMM = the function evaluated on a = 0xf0, b = 0xcc, c = 0xaa.
+template <unsigned IMM> NECAT_D u32 bop(u32 a, u32 b, u32 c) { return (u32)__builtin_amdgcn_bitop3_b32(a, b, c, IMM); }
+
+template <bool REC>
+NECAT_D void fast_advance(FastWord& w, u32 el, u32 eh, u32 cph, u32 cmh, u32 cm, u32& phh_out, u32& mhh_out, u64& A, u64& B)
+{
+    const u32 pl = (u32)w.Pv, ph = (u32)(w.Pv >> 32), ml = (u32)w.Mv, mh = (u32)(w.Mv >> 32);
+    const u32 xvl = el | ml, xvh = eh | mh;                        // Xv = Eq | Mv (before the hin fix-up of Eq, edlib_ex.c:71-106)
+    const u32 e2l = el | (cmh >> 31);                              // hin == -1
+    const u64 sum = (((u64)(eh & ph) << 32) | (e2l & pl)) + w.Pv;  // ONE 64-bit add (v_lshl_add_u64)
+    const u32 sl = (u32)sum, sh = (u32)(sum >> 32);
+    const u32 xhl = bop<0xbe>(sl, pl, e2l), xhh = bop<0xbe>(sh, ph, eh);      // Xh = (sum ^ Pv) | Eq
+    const u32 phl = bop<0xf1>(ml, xhl, pl), phh = bop<0xf1>(mh, xhh, ph);      // Ph = Mv | ~(Xh | Pv)
+    const u32 mhl = pl & xhl, mhh = ph & xhh;                                  // Mh = Pv & Xh
+    phh_out = phh; mhh_out = mhh;
+    w.pubP = phh | cm; w.pubM = mhh & ~cm;                         // word 7 publishes the top-row boundary (+1) for the next block
+    const u32 p2l = __builtin_amdgcn_alignbit(phl, cph, 31), p2h = __builtin_amdgcn_alignbit(phh, phl, 31);   // (Ph << 1) | (hin == +1)
+    const u32 m2l = __builtin_amdgcn_alignbit(mhl, cmh, 31), m2h = __builtin_amdgcn_alignbit(mhh, mhl, 31);   // (Mh << 1) | (hin == -1)
+    const u32 ol = bop<0xf1>(m2l, xvl, p2l), oh = bop<0xf1>(m2h, xvh, p2h);    // Pv' = Mh | ~(Xv | Ph)
+    const u32 nl = p2l & xvl, nh = p2h & xvh;                                  // Mv' = Ph & Xv
+    if (REC) {    // the walk's decision per cell (dp_core.h: advance_block_rec): A = Pv' | (Pv & ~Xh), B = ~Pv' & (Mv | ~Xh)
+        A = ((u64)bop<0xf4>(oh, ph, xhh) << 32) | bop<0xf4>(ol, pl, xhl);
+        B = ((u64)bop<0x0d>(oh, mh, xhh) << 32) | bop<0x0d>(ol, ml, xhl);
+    }
+    w.Pv = ((u64)oh << 32) | ol; w.Mv = ((u64)nh << 32) | nl;
+}
+
+NECAT_D u32 dpp_row_shr1(u32 v, u32 keep)     // lane i receives v of lane i - 1 (within a row of 16); row lane 0 keeps `keep`
+{
+    return (u32)__builtin_amdgcn_update_dpp((int)keep, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+}
+
+// all 8 blocks of the wave: 512 x 512.  tw = the wave's staged target planes (LDS), nlo / nhi = this lane's query word.
+template <int NW, int TW>
+NECAT_D void myers_fast_full(const int lane, const u64* __restrict__ tw, const u64 nlo, const u64 nhi, ulonglong2* __restrict__ rec, const int il,
+                             const double error, const bool valid_item, BlockResult* __restrict__ result, unsigned long long* __restrict__ stats,
+                             const bool no_store)
+{
+    constexpr int G = 8, N = kOcaBlockSize;
+    const int b = lane & (G - 1);
+    const u32 cm = b == G - 1 ? 0x80000000u : 0u;
+    const u32 nlo_l = (u32)nlo, nlo_h = (u32)(nlo >> 32), nhi_l = (u32)nhi, nhi_h = (u32)(nhi >> 32);
+    const u32 sk = (u32)(32 - b) & 31u;
+    u32 tlo = 0, thi = 0, plo = 0, phi = 0;       // this lane's 32-column window (two bit-planes) and the previous raw planes
+    auto reload = [&](int w) {
+        const u64 x = w < TW ? tw[w] : 0ULL;
+        const u32 xl = (u32)x, xh = (u32)(x >> 32);
+        // lane b lags b columns behind lane 0: its window = the planes shifted up by b bits (column c of the block = step c + b)
+        tlo = b ? __builtin_amdgcn_alignbit(xl, plo, sk) : xl;
+        thi = b ? __builtin_amdgcn_alignbit(xh, phi, sk) : xh;
+        plo = xl; phi = xh;
+    };
+    // Eq of this lane's column at step 32 w + j: rows whose base code equals the column's (two 3-input ops per half)
+    auto eq_of = [&](int j, u32& el, u32& eh) {
+        const u32 ma = (u32)__builtin_amdgcn_sbfe((int)tlo, (u32)j, 1u), mb = (u32)__builtin_amdgcn_sbfe((int)thi, (u32)j, 1u);
+        el = bop<0x60>(nlo_l ^ ma, nhi_l, mb); eh = bop<0x60>(nlo_h ^ ma, nhi_h, mb);      // (nlo ^ ma) & (nhi ^ mb)
+    };
+    constexpr int kSteps = N + G - 1;             // 519: lane b computes column c at step c + b
+
+    // ------------------------------------------------------------------ SHW: best prefix distance, first best end column
+    FastWord w; w.Pv = ~0ULL; w.Mv = 0ULL; w.pubP = 0x80000000u; w.pubM = 0u;
+    u32 S = (u32)(b + 1) * 64u;
+    u32 key = 0xffffffffu;                        // min over columns of (bottom-row value << 10 | step)
+    u64 dA, dB;
+    u32 cph = 0x80000000u, cmh = 0u;              // carries from the word above; the top word of a DPP row keeps the boundary (+1)
+    for (int s0 = 0; s0 < kSteps; s0 += 32) {
+        reload(s0 >> 5);
+        const int jn = kSteps - s0 < 32 ? kSteps - s0 : 32;
+        for (int j = 0; j < jn; ++j) {
+            const int s = s0 + j;
+            cph = dpp_row_shr1(w.pubP, cph); cmh = dpp_row_shr1(w.pubM, cmh);
+            const bool edge = s < G - 1 || s >= N;                         // fill / drain: some lanes are outside their block
+            if (!edge || (s >= b && s - b < N)) {
+                u32 phh, mhh, el, eh;
+                eq_of(j, el, eh);
+                fast_advance<false>(w, el, eh, cph, cmh, cm, phh, mhh, dA, dB);
+                S += (phh >> 31) - (mhh >> 31);
+                const u32 k2 = (S << 10) + (u32)s;
+                key = k2 < key ? k2 : key;
+            }
+        }
+    }
+    // word 7 holds the bottom row: its minimum is the block's (best, first end column); column = step - 7
+    const int owner = (lane & ~(G - 1)) | (G - 1);
+    const u32 bkey = (u32)__shfl((int)key, owner);
+    int best = (int)(bkey >> 10), end0 = (int)(bkey & 1023u) - (G - 1);
+    const int k0 = (int)((double)N * error * 1.1);                       // edlib_ex.c:751
+    if (best > k0 || !valid_item) best = -1;
+    const int tn2 = end0 + 1;
+    int err = 0;
+    if (best >= 0) { int ad = tn2 - N; if (ad < 0) ad = -ad; if (best < ad) err = 1; }
+    const bool go = best >= 0 && !err;
+
+    // ------------------------------------------------------------------ NW on target[0 .. end0] with k = best: store the band
+    int steps = go ? tn2 + G - 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
+    steps = __builtin_amdgcn_readfirstlane(steps);
+    w.Pv = ~0ULL; w.Mv = 0ULL; w.pubP = 0x80000000u; w.pubM = 0u;
+    int Sn = (b + 1) * 64;
+    plo = phi = 0;
+    // store filter (the reference's per-word band tests with k = best, edlib_ex.c:311-325, as in the general path), in terms of
+    // the step s = c + b:   drop iff S >= K1  ||  S - s > K2  ||  S + s > K3;   nothing is stored from column tn2 on
+    const int rb = (b + 1) * 64 - 1;
+    const int K1 = best + 64, K2 = best + 127 + N - tn2 - rb - b, K3 = rb + best + tn2 - N + b;
+    const int s_end = go ? tn2 + b : 0;            // first step past the block's last column
+    // byte offset of record (c, b) of this lane's block in the slab (rec_pos): + 16 per column, + 4089 * 16 when c & 7 wraps -
+    // which, c being s - b, happens at a fixed position of every group of 8 steps: one precomputed increment per position
+    char* const rbase = reinterpret_cast<char*>(rec);
+    auto rec_off = [&](int c) -> u32 { return (((((u32)c >> 3) * (u32)NW + (u32)b) * 64u + (u32)il) * 8u + ((u32)c & 7u)) * 16u; };
+    u32 inc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) inc[q] = (((b + 7) & 7) == q) ? (u32)(NW * 64 * 8 - 7) * 16u : 16u;    // from step s (s & 7 == q) to s + 1
+    cph = 0x80000000u; cmh = 0u;
+    auto nw_step = [&](int s, int j, u32 off) {
+        u32 phh, mhh, el, eh;
+        u64 rA, rB;
+        eq_of(j, el, eh);
+        fast_advance<true>(w, el, eh, cph, cmh, cm, phh, mhh, rA, rB);
+        Sn += (int)(phh >> 31) - (int)(mhh >> 31);
+        const bool keep = s < s_end && Sn < K1 && Sn - s <= K2 && Sn + s <= K3;
+        if (keep && !no_store) *reinterpret_cast<ulonglong2*>(rbase + off) = make_ulonglong2(rA, rB);
+    };
+    // the first 8 steps: lane b enters at step b
+    reload(0);
+    for (int s = 0; s < 8 && s < steps; ++s) {
+        cph = dpp_row_shr1(w.pubP, cph); cmh = dpp_row_shr1(w.pubM, cmh);
+        if (s >= b) nw_step(s, s, rec_off(s - b));
+    }
+    // then every lane is inside its block (or past its end: computing on, storing nothing): groups of 8 steps
+    u32 off = rec_off(8 - b);
+    for (int s0 = 8; s0 < steps; s0 += 8) {
+        if ((s0 & 31) == 0) reload(s0 >> 5);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            cph = dpp_row_shr1(w.pubP, cph); cmh = dpp_row_shr1(w.pubM, cmh);
+            nw_step(s0 + q, (s0 & 31) + q, off);
+            off += inc[q];
+        }
+    }
+    if (b == G - 1 && valid_item) {
+        BlockResult br; br.dist = err ? -1 : best; br.endc = end0; br.err = err;
+        br.words = (u32)(NW * (N + (go ? tn2 : 0)));
+        *result = br;
+        atomicAdd(&stats[0], (unsigned long long)br.words); atomicAdd(&stats[1], (unsigned long long)(2 * N));
+    }
+}
+
 // SINGLE (small lists, where the round is as long as ONE block alignment): the NW pass recomputes exactly what the
 // SHW pass computed for the columns up to the end column (same recurrence, same boundary), its only purpose being
 // to know the distance for the store filter - so when store traffic is irrelevant the SHW pass stores every word
@@ -310,8 +491,10 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n_host, const u32* __restr
     const u32 n = live_count(n_host, n_dev);
     if ((u64)item_base + (u64)blockIdx.x * BPW >= n) return;      // a whole wave beyond the list (grids are sized from an upper bound)
     const int lane = threadIdx.x, sub = lane / G, b = lane % G;
-    const bool filter = (epoch >> 30) == 0;      // bit 30 of the epoch argument switches the store filter off (A/B tests)
-    epoch &= 0x3fffffffu;
+    const bool filter = ((epoch >> 30) & 1u) == 0;      // bit 30 of the epoch argument switches the store filter off (A/B tests)
+    const bool fast_ok = ((epoch >> 29) & 1u) == 0;     // bit 29: never take the full-block fast path (A/B measurements)
+    const bool fast_nostore = ((epoch >> 28) & 1u) != 0; // bit 28: fast path without band stores (profiling only)
+    epoch &= 0x0fffffffu;
     const u64 item = (u64)item_base + (u64)blockIdx.x * BPW + sub;
     const bool valid = item < n;
     const u64 grp = item >> 6;
@@ -337,6 +520,14 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n_host, const u32* __restr
     }
     __syncthreads();
     const u64* tw = t_lds[sub];
+    if (!SINGLE && G == 8 && NW == kWordsA && TW == kTWordsA && filter && fast_ok) {
+        // every block of the wave a full 512 x 512 one (most waves of the big rounds): the predicate-free path
+        if (__all(valid && qn == kOcaBlockSize && tn == kOcaBlockSize)) {
+            const u64 ugrp = (u64)__builtin_amdgcn_readfirstlane((int)grp);      // the 8 items of a wave share a slab
+            myers_fast_full<NW, TW>(lane, tw, nlo, nhi, slab_records(slabs + (size_t)ugrp * slab_bytes), il, error, valid, results + item, stats, fast_nostore);
+            return;
+        }
+    }
     const u32 nlo_l = (u32)nlo, nlo_h = (u32)(nlo >> 32), nhi_l = (u32)nhi, nhi_h = (u32)(nhi >> 32);
     const u32 pad_l = (u32)pad, pad_h = (u32)(pad >> 32);
     u64 tcur = 0;
@@ -448,6 +639,11 @@ struct OpsWriter {
         tail_push(ts, op);
     }
 };
+struct OpsSink {        // walk_block's op store: op number i of the lane's block at ops[i * 64]
+    u8* ops; int cap; int overflow; bool store;
+    NECAT_D bool storing() const { return store; }
+    NECAT_D void put(int i, int op) { if (i < cap) ops[(size_t)i * 64] = (u8)op; else overflow = 1; }
+};
 struct OpsReader {
     const u8* ops;
     NECAT_D int operator()(int j) const { return ops[(size_t)j * 64]; }
@@ -493,7 +689,12 @@ k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
     if (br.dist >= 0) {
         MatReader<NW> mr;
         mr.base = slab_records(const_cast<char*>(slabs) + (size_t)grp * slab_bytes); mr.lane = lane; mr.init();
-        traceback_block(it.qn, br.endc + 1, mr, ow);
+        if ((epoch >> 27) & 1u) traceback_block(it.qn, br.endc + 1, mr, ow);        // NECAT_WALK=0: the reference formulation (A/B measurements)
+        else {
+            OpsSink sk; sk.ops = ow.ops; sk.cap = ow.cap; sk.overflow = 0; sk.store = ow.store;
+            walk_block(it.qn, br.endc + 1, mr, sk, ow.ts);
+            ow.overflow = sk.overflow;
+        }
         if (ow.overflow) atomicExch(err_flag, 20);
     }
     if (EXPORT) { n_ops_out[item] = ow.ts.n; return; }

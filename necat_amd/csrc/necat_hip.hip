@@ -59,6 +59,8 @@ int g_trace;           // NECAT_TRACE: 1 = extension rounds, 2 = host stages
 int g_coop_filter;     // NECAT_COOP_FILTER=0: the cooperative kernel stores every word (A/B tests)
 int g_sort_b;          // NECAT_SORT_B=0 disables the size sort of list B
 int g_cns_spec_extra, g_cns_spec_cover;   // NECAT_CNS_SPEC_EXTRA / NECAT_CNS_SPEC: speculation width of the consensus loop
+int g_fast;            // NECAT_FAST=0: the list-A DP kernel never takes its full-block fast path (A/B measurements); 2: fast path without band stores (profiling only, results invalid)
+int g_walk;            // NECAT_WALK=0: k_traceback runs the reference formulation of the walk (A/B measurements)
 int g_dbg;             // NECAT_DBG: profiling-only variants of the lane-per-block DP kernel (1 = no band stores, 2 = no NW pass)
 
 // Tuning / test knobs: process-wide, (re)read from the environment whenever a context is created, defaults otherwise.
@@ -75,6 +77,8 @@ void read_knobs()
     g_coop_filter = (int)num("NECAT_COOP_FILTER", 1);
     g_sort_b = (int)num("NECAT_SORT_B", 1);
     g_dbg = (int)num("NECAT_DBG", 0);
+    g_fast = (int)num("NECAT_FAST", 1);
+    g_walk = (int)num("NECAT_WALK", 1);
     g_cns_spec_extra = getenv("NECAT_CNS_SPEC_EXTRA") ? atoi(getenv("NECAT_CNS_SPEC_EXTRA")) : 1;
     g_cns_spec_cover = (int)num("NECAT_CNS_SPEC", 12);     // 0 = adaptive
 }
@@ -857,7 +861,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                                (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch, 0u);
         else if (nB <= g_coop_threshold)
             hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB, d_nB,
-                               (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
+                               (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch | (g_coop_filter ? 0u : 1u << 30) | (g_fast == 0 ? 1u << 29 : 0u) | (g_fast == 2 ? 1u << 28 : 0u), 0u);
         else
             hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB, d_nB,
                                (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch, 0u);
@@ -865,7 +869,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         NECAT_HIP(ctx, hipEventRecord(c.b1[slot], sb));
         hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB, d_nB,
                            (const u64*)c.fragB[slot], (const char*)slabsB, kSlabB, (const BlockResult*)c.resB[slot], c.opsB[slot], c.tasks, X.tail_match_len,
-                           (i32*)nullptr, X.d_err, next, epoch);
+                           (i32*)nullptr, X.d_err, next, epoch | (g_walk ? 0u : 1u << 27));
         NECAT_CHECK_LAUNCH(ctx, "k_traceback<B>");
         NECAT_HIP(ctx, hipEventRecord(c.b2[slot], sb));
         b_pending[slot] = true; b_blocks[slot] = nB;
@@ -900,7 +904,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                                (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
         else if (bound <= g_coop_threshold)
             hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((bound + 7) / 8), dim3(64), 0, c.sa, itA, bound, d_nA,
-                               (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
+                               (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch | (g_coop_filter ? 0u : 1u << 30) | (g_fast == 0 ? 1u << 29 : 0u) | (g_fast == 2 ? 1u << 28 : 0u), 0u);
         else
             hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, false>), dim3(gA), dim3(64), 0, c.sa, itA, bound, d_nA,   // list A also holds last blocks <= 512 x 512
                                (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
@@ -908,7 +912,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         NECAT_HIP(ctx, hipEventRecord(c.a1[cur], c.sa));
         hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false>), dim3(gA), dim3(64), 0, c.sa, itA, bound, d_nA,
                            (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
-                           (i32*)nullptr, X.d_err, next, epoch);
+                           (i32*)nullptr, X.d_err, next, epoch | (g_walk ? 0u : 1u << 27));
         NECAT_CHECK_LAUNCH(ctx, "k_traceback<A>");
         NECAT_HIP(ctx, hipEventRecord(c.a2[cur], c.sa));
         a_timed[r] = 1;
@@ -1655,16 +1659,16 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[4], s));
             const bool coop = m <= g_coop_threshold;
             const u32 epoch = ++ctx->epoch & 0x3fffffu;
-            if (full && coop) hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
+            if (full && coop) hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | (g_coop_filter ? 0u : 1u << 30) | (g_fast == 0 ? 1u << 29 : 0u) | (g_fast == 2 ? 1u << 28 : 0u), 0u);
             else if (full) hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | ((u32)g_dbg << 28), 0u);
-            else if (coop) hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((m + 3) / 4), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | (g_coop_filter ? 0u : 1u << 30), 0u);
+            else if (coop) hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((m + 3) / 4), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | (g_coop_filter ? 0u : 1u << 30) | (g_fast == 0 ? 1u << 29 : 0u) | (g_fast == 2 ? 1u << 28 : 0u), 0u);
             else hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch, 0u);
             NECAT_CHECK_LAUNCH(ctx, "k_myers");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[5], s));
             if (full) hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, (const char*)d_slabs, slab,
-                                         (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), epoch);
+                                         (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), epoch | (g_walk ? 0u : 1u << 27));
             else hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, (const char*)d_slabs, slab,
-                                    (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), epoch);
+                                    (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), epoch | (g_walk ? 0u : 1u << 27));
             NECAT_CHECK_LAUNCH(ctx, "k_traceback");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[6], s));
             std::vector<BlockResult> hres(m); std::vector<i32> hn(m); std::vector<u8> hops((size_t)g * 64 * maxops);

@@ -47,6 +47,20 @@ struct HMatR {
     void rec(int c, int b, u64& Pv, u64& Ph) const { Pv = m->Pv[(size_t)c * m->nw + b]; Ph = m->Ph[(size_t)c * m->nw + b]; }
 };
 struct HOps { std::vector<int> v; TailScan ts; void push(int op) { v.push_back(op); tail_push(ts, op); } };
+// the GPU formulation of the same walk (walk_block): must give the same ops and the same tail statistics
+struct HSink { std::vector<int> v; bool storing() const { return true; } void put(int i, int op) { if ((int)v.size() <= i) v.resize(i + 1, -1); v[i] = op; } };
+static long g_bad_walk = 0;
+template <class M>
+static void check_walk(int qn, int tn, M& m, const HOps& ref)
+{
+    HSink sk; TailScan ts; tail_init(ts, ref.ts.M);
+    walk_block(qn, tn, m, sk, ts);
+    const TailScan& a = ref.ts;
+    const bool same = sk.v == ref.v && ts.n == a.n && ts.nq == a.nq && ts.nt == a.nt && ts.nmat == a.nmat && ts.hit == a.hit &&
+                      ts.acnt == a.acnt && ts.qcnt == a.qcnt && ts.tcnt == a.tcnt && ts.mcnt == a.mcnt && (ts.hit || ts.m == a.m);
+    if (!same) { if (g_bad_walk < 5) fprintf(stderr, "WALK MISMATCH %d x %d: n %d/%d nq %d/%d nt %d/%d nmat %d/%d hit %d/%d acnt %d/%d\n", qn, tn, ts.n, a.n, ts.nq, a.nq,
+                 ts.nt, a.nt, ts.nmat, a.nmat, ts.hit, a.hit, ts.acnt, a.acnt); ++g_bad_walk; }
+}
 
 template <int NW, bool FULL>
 static MyersResult run_block(const DevVolume& reads, const DevVolume& ref, const FragGeom& g, int qn, int tn, double error, HMat& mat, u64* tw, MyersRegs<NW>& R)
@@ -152,14 +166,14 @@ int main(int argc, char** argv)
                         mr = run_block<8, true>(hrd->dv, href.dv, g, tk.qblk, tk.tblk, opt.error, mat, tw, R8);
                         const int done = ext_block_done(tk, mr.dist, mr.endc);
                         tail_init(ops.ts, done ? 1 : kOcaMatCnt);
-                        if (mr.dist >= 0) { HMatR m{&mat}; traceback_block(tk.qblk, mr.endc + 1, m, ops); }
+                        if (mr.dist >= 0) { HMatR m{&mat}; traceback_block(tk.qblk, mr.endc + 1, m, ops); check_walk(tk.qblk, mr.endc + 1, m, ops); }
                         HRops ro{&ops.v}; HSame<8> sm{&R8, tw};
                         ext_finish_block(tk, mr.dist, mr.endc, done, ops.ts, ro, sm);
                     } else {
                         mr = run_block<13, false>(hrd->dv, href.dv, g, tk.qblk, tk.tblk, opt.error, mat, tw, R13);
                         const int done = ext_block_done(tk, mr.dist, mr.endc);
                         tail_init(ops.ts, done ? 1 : kOcaMatCnt);
-                        if (mr.dist >= 0) { HMatR m{&mat}; traceback_block(tk.qblk, mr.endc + 1, m, ops); }
+                        if (mr.dist >= 0) { HMatR m{&mat}; traceback_block(tk.qblk, mr.endc + 1, m, ops); check_walk(tk.qblk, mr.endc + 1, m, ops); }
                         HRops ro{&ops.v}; HSame<13> sm{&R13, tw};
                         ext_finish_block(tk, mr.dist, mr.endc, done, ops.ts, ro, sm);
                     }
@@ -176,6 +190,6 @@ int main(int argc, char** argv)
         ora_wfd_free(w); ora_aligner_free(al); free(oc.a);
         if (v != vid) ora_volume_free(&rd_own);
     }
-    printf("check_core: candidates=%ld blocks=%ld m4=%ld seed_mismatch=%ld ext_mismatch=%ld\n", n_cand, n_blocks, n_m4, bad_seed, bad_ext);
-    return (bad_seed || bad_ext) ? 1 : 0;
+    printf("check_core: candidates=%ld blocks=%ld m4=%ld seed_mismatch=%ld ext_mismatch=%ld walk_mismatch=%ld\n", n_cand, n_blocks, n_m4, bad_seed, bad_ext, g_bad_walk);
+    return (bad_seed || bad_ext || g_bad_walk) ? 1 : 0;
 }

@@ -30,7 +30,7 @@ def test_cores_match_oracle(check_core, tmp_path, ds, vid, args):
     d = util.install_golden_volumes(ds, tmp_path)
     r = subprocess.run([check_core, d, str(vid)] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
-    assert "seed_mismatch=0 ext_mismatch=0" in r.stdout
+    assert "seed_mismatch=0 ext_mismatch=0 walk_mismatch=0" in r.stdout
     assert "candidates=0 " not in r.stdout
 
 
