@@ -280,7 +280,7 @@ def main():
     barrier_sync(dist, local)
     t0 = time.perf_counter()
     agg = dict(index_ms=0.0, seed_ms=0.0, extend_ms=0.0, myers_ms=0.0, traceback_ms=0.0, launches=0, blocks=0, words=0, bases=0, rounds=0,
-               a_ms=0.0, a_launches=0, a_blocks=0, tb_a_ms=0.0, big_ms=0.0, big_blocks=0,
+               a_ms=0.0, a_launches=0, a_blocks=0, tb_a_ms=0.0, big_ms=0.0, big_blocks=0, band_words=0,
                ix_local_ms=0.0, ix_xchg_ms=0.0, ix_xchg_bytes=0, gather_ms=0.0, gather_bytes=0, reads_local=0)
     n_over = 0
     gbp = 0.0
@@ -293,7 +293,7 @@ def main():
         agg["index_ms"] += t_index; agg["seed_ms"] += tm.seed_ms; agg["extend_ms"] += tm.extend_ms
         agg["myers_ms"] += tm.myers_ms; agg["traceback_ms"] += tm.traceback_ms; agg["launches"] += tm.myers_launches
         agg["blocks"] += tm.myers_blocks; agg["words"] += tm.myers_word_updates; agg["bases"] += tm.myers_cells_bases
-        agg["rounds"] += tm.rounds
+        agg["rounds"] += tm.rounds; agg["band_words"] += tm.myers_band_words
         agg["tb_a_ms"] += tm.tracebackA_ms
         if tm.myersA_big_blocks >= agg["big_blocks"]:
             agg["big_blocks"], agg["big_ms"] = int(tm.myersA_big_blocks), float(tm.myersA_big_ms)
@@ -330,23 +330,40 @@ def main():
             dist.destroy_process_group()
         return
     K = max(1, args.steps)
-    # ---- roofline of the dominant kernel: k_myers_coop<8,16,512,8>, the DP of the full 512 x 512 blocks
-    # (list A).  It and its traceback k_traceback<8,16,512,..> / the list-B pair are the four largest
-    # entries of the rocprof summary (profiles/r01_kernel_stats.md), the DP kernel being the one that
-    # does the arithmetic of the path.  Algorithmic HBM bytes of one block alignment = its two 2-bit
-    # fragments in (2 x 512 / 4 B) + one 16-byte result out (SURVEY.md 8d "extension" row restated per
-    # block); everything else the kernel moves is the traceback band it stores (`traffic`, from the PMC
-    # passes kept in profiles/).
+    # ---- roofline of the dominant kernel: k_myers_coop<8,16,512,8,false>, the DP of the list-A blocks (<= 512 x 512).
+    # Integer DP: the bound is VALU issue, not HBM.  Work unit = one 64-row Myers word update, priced at
+    # OPS_PER_WORD_UPDATE 32-bit lane-ops against the chip's full-rate 32-bit VALU peak (256 CU x 4 SIMD-32
+    # x 2.4 GHz; tools/valu_microbench2.hip measures which instructions reach that rate).  `achieved` counts only the
+    # ALGORITHMIC word updates - what the reference's banded passes compute (6.25 of 8 words per SHW column,
+    # measured there; the NW band words are counted by the kernel itself) - `computed_frac` the updates actually executed.
+    # The HBM side is kept as a sub-field: algorithmic bytes per block alignment = its two 2-bit fragments in + one 16-byte
+    # result out; `traffic` = HBM bytes per launch from the PMC passes kept in profiles/ (the stored traceback band).
     A_BYTES_PER_BLOCK = 2 * 512 / 4.0 + 16.0
+    SHW_BANDED_FRACTION = 6.25 / 8.0
     a_launches = max(1, agg["a_launches"])
     avg_launch_ms = agg["a_ms"] / a_launches
     alg_per_launch = A_BYTES_PER_BLOCK * agg["a_blocks"] / a_launches
-    achieved = alg_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-    word_rate = agg["words"] / (agg["myers_ms"] * 1e-3) if agg["myers_ms"] > 0 else 0.0
-    traffic = None
-    tb_traffic = None
+    achieved_hbm = alg_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+    words, band = float(agg["words"]), float(agg["band_words"])
+    # computed = SHW (every word of every column) + NW (every word up to the end column); algorithmic = banded SHW + NW band
+    nw_computed = words / 2.0            # the two passes cover (almost) the same columns; exact split is not needed for a fraction
+    useful_words = (words - nw_computed) * SHW_BANDED_FRACTION + band
+    word_rate = words / (agg["myers_ms"] * 1e-3) if agg["myers_ms"] > 0 else 0.0
+    useful_rate = useful_words / (agg["myers_ms"] * 1e-3) if agg["myers_ms"] > 0 else 0.0
+    # the list-A two-pass kernel alone (launches of > NECAT_SINGLE_PASS blocks): its share of the word updates ~ its share of the blocks
+    a_share = agg["a_blocks"] / max(1, agg["blocks"])
+    a_useful_rate = useful_words * a_share / (agg["a_ms"] * 1e-3) if agg["a_ms"] > 0 else 0.0
+    achieved_tops = a_useful_rate * OPS_PER_WORD_UPDATE / 1e12
+    peak_tops = VALU_LANE_OPS_PER_S / 1e12
+    traffic = tb_traffic = None
+    pmc_file = None
+    for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        pth = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pth):
+            pmc_file = name
+            break
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
 
         def pmc_bytes(prefix):
             k = next(v for n, v in pmc.items() if n.startswith(prefix))
@@ -357,24 +374,30 @@ def main():
     except Exception:
         pass
     tb_avg_ms = agg["tb_a_ms"] / a_launches
-    roofline = {"bound": "hbm", "kernel": "k_myers_coop<8,16,512,8,false>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                "traffic_frac": round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_launch_ms > 0 else None,
+    roofline = {"bound": "valu", "kernel": "k_myers_coop<8,16,512,8,false>", "achieved": round(achieved_tops, 3), "peak": round(peak_tops, 2),
+                "unit": "T lane-op/s (32-bit VALU)", "frac": round(achieved_tops / peak_tops, 4),
+                "traffic": traffic,
                 "launches": int(agg["a_launches"]), "avg_launch_ms": round(avg_launch_ms, 4),
-                "algorithmic_bytes_per_launch": round(alg_per_launch, 1),
+                "useful_word_updates_per_s": round(a_useful_rate, 1), "ops_per_word_update": OPS_PER_WORD_UPDATE,
+                "computed_frac": round(word_rate * OPS_PER_WORD_UPDATE / VALU_LANE_OPS_PER_S, 4),
+                "useful_over_computed": round(useful_words / words, 4) if words else None,
+                "band_words_per_block": round(band / max(1, agg["blocks"]), 1),
+                "hbm": {"achieved": round(achieved_hbm, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_hbm / HBM_PEAK_GBS, 6),
+                        "algorithmic_bytes_per_launch": round(alg_per_launch, 1),
+                        "traffic_frac": round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_launch_ms > 0 else None,
+                        "traffic_source": "profiles/%s" % pmc_file if traffic else None},
                 "traceback_kernel": {"kernel": "k_traceback<8,16,512,1024,false>", "avg_launch_ms": round(tb_avg_ms, 4), "traffic": tb_traffic,
                                      "traffic_frac": round(tb_traffic / (tb_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tb_traffic and tb_avg_ms > 0 else None},
-                # the launch with the most blocks (throughput regime; the small launches of the late rounds are latency bound):
-                # ~2 x 512 columns x 8 words per block (list A also holds shorter last blocks, so this slightly overstates)
+                # the launch with the most blocks (throughput regime; the small launches of the late rounds are latency bound)
                 "biggest_launch": {"blocks": agg["big_blocks"], "ms": round(agg["big_ms"], 4),
-                                   "valu_frac": round(agg["big_blocks"] * 8192.0 * OPS_PER_WORD_UPDATE / (agg["big_ms"] * 1e-3) / VALU_LANE_OPS_PER_S, 4) if agg["big_ms"] > 0 else None},
+                                   "computed_frac": round(agg["big_blocks"] * 8192.0 * OPS_PER_WORD_UPDATE / (agg["big_ms"] * 1e-3) / VALU_LANE_OPS_PER_S, 4) if agg["big_ms"] > 0 else None},
                 "all_dp_kernels": {"launches": int(agg["launches"]), "ms": round(agg["myers_ms"], 2), "blocks": int(agg["blocks"]),
-                                   "word_updates_per_s": round(word_rate, 1),
-                                   "valu_frac": round(word_rate * OPS_PER_WORD_UPDATE / VALU_LANE_OPS_PER_S, 4)},
-                "note": "integer DP: the algorithmic HBM fraction is small by construction (SURVEY.md 8d); the measured traffic (PMC, "
-                        "profiles/r01_pmc_hbm_traffic.json) is the stored traceback band (16-byte records, only words that can lie on an "
-                        "alignment of <= the block's distance) - traffic_frac is that traffic over the launch time against the HBM peak; "
-                        "valu_frac = word updates x %d lane-ops / (256 CU x 128 lanes x 2.4 GHz)" % OPS_PER_WORD_UPDATE}
+                                   "word_updates_per_s": round(word_rate, 1), "useful_word_updates_per_s": round(useful_rate, 1),
+                                   "useful_frac": round(useful_rate * OPS_PER_WORD_UPDATE / VALU_LANE_OPS_PER_S, 4)},
+                "note": "integer DP, VALU-issue bound: frac = algorithmic word updates (banded SHW 6.25/8 words per column per SURVEY 8d + the NW band words the "
+                        "kernel counts) x %d lane-ops / launch time / (256 CU x 4 SIMD-32 x 2.4 GHz); computed_frac = the same for the word updates actually "
+                        "executed (both passes compute every word). Issue-rate evidence: profiles/r02_valu_microbench2.txt, profiles/r02_sq_counters*.json. "
+                        "hbm.* = the contract's HBM view (small by construction)." % OPS_PER_WORD_UPDATE}
     out = {
         "metric": "overlaps/sec (all-vs-all, index build + seeding + banded Myers extension -> M4)",
         "value": round(tot_over / elapsed, 1), "unit": "overlaps/s",

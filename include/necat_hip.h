@@ -113,6 +113,9 @@ typedef struct {
     /* the list-A DP launch with the most blocks (the throughput-bound regime of the dominant kernel) */
     double   myersA_big_ms;
     uint64_t myersA_big_blocks;
+    /* band words the NW passes stored (= the word updates the reference's banded NW pass needs, edlib_ex.c:311-325 with
+     * k = the block's distance): with myers_word_updates, the redundant part of the computed work */
+    uint64_t myers_band_words;
 } necat_timings;
 
 void        necat_default_options(necat_map_options* o);            /* map_options.c:12-28 */

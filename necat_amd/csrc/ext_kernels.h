@@ -239,9 +239,11 @@ struct MatReader {
     int lane;
     int nc, nb;                // coordinates of the prefetched record
     ulonglong2 nv;
+    bool no_prefetch = false;  // A/B switch (NECAT_WALK=2)
     NECAT_D void init() { nc = -100; nb = -100; }
     NECAT_D void rec(int c, int b, u64& Pv, u64& Ph)
     {
+        if (no_prefetch) { const ulonglong2 v = base[rec_pos<NW>(c, b, lane)]; Pv = v.x; Ph = v.y; return; }
         ulonglong2 v = nv;
         if (!(c == nc && b == nb)) v = base[rec_pos<NW>(c, b, lane)];
         Pv = v.x; Ph = v.y;
@@ -444,6 +446,7 @@ NECAT_D void myers_fast_full(const int lane, const u64* __restrict__ tw, const u
 #pragma unroll
     for (int q = 0; q < 8; ++q) inc[q] = (((b + 7) & 7) == q) ? (u32)(NW * 64 * 8 - 7) * 16u : 16u;    // from step s (s & 7 == q) to s + 1
     cph = 0x80000000u; cmh = 0u;
+    u32 kept = 0;                                  // band words stored by this lane (work counter)
     auto nw_step = [&](int s, int j, u32 off) {
         u32 phh, mhh, el, eh;
         u64 rA, rB;
@@ -451,7 +454,7 @@ NECAT_D void myers_fast_full(const int lane, const u64* __restrict__ tw, const u
         fast_advance<true>(w, el, eh, cph, cmh, cm, phh, mhh, rA, rB);
         Sn += (int)(phh >> 31) - (int)(mhh >> 31);
         const bool keep = s < s_end && Sn < K1 && Sn - s <= K2 && Sn + s <= K3;
-        if (keep && !no_store) *reinterpret_cast<ulonglong2*>(rbase + off) = make_ulonglong2(rA, rB);
+        if (keep && !no_store) { *reinterpret_cast<ulonglong2*>(rbase + off) = make_ulonglong2(rA, rB); ++kept; }
     };
     // the first 8 steps: lane b enters at step b
     reload(0);
@@ -470,6 +473,8 @@ NECAT_D void myers_fast_full(const int lane, const u64* __restrict__ tw, const u
             off += inc[q];
         }
     }
+    for (int o = 32; o > 0; o >>= 1) kept += (u32)__shfl_xor((int)kept, o);
+    if (lane == 0) atomicAdd(&stats[2], (unsigned long long)kept);
     if (b == G - 1 && valid_item) {
         BlockResult br; br.dist = err ? -1 : best; br.endc = end0; br.err = err;
         br.words = (u32)(NW * (N + (go ? tn2 : 0)));
@@ -587,6 +592,7 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n_host, const u32* __restr
     steps = go ? tn2 + nblk - 1 : 0;
     for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
     P = ~0ULL; M = 0ULL; S = (b + 1) * 64; hout = 1;
+    u32 kept = 0;
     for (int s = 0; s < steps; ++s) {
         const int c = s - b;
         int hin = dpp_from_lane_below(hout);
@@ -602,8 +608,12 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n_host, const u32* __restr
             // traceback never stands on a cell of a dropped word (every cell it visits lies on such an alignment).
             const int rb = (b + 1) * 64 - 1;
             const bool drop = S >= best + 64 || rb > best - S + 2 * 64 - 2 - tn2 + c + qn + 1 || rb < S - best - tn2 + qn + c;
-            if (!drop || !filter) rec[rec_pos<NW>(c, b, il)] = make_ulonglong2(rA, rB);
+            if (!drop || !filter) { rec[rec_pos<NW>(c, b, il)] = make_ulonglong2(rA, rB); ++kept; }
         }
+    }
+    if (!SINGLE) {
+        for (int o = 32; o > 0; o >>= 1) kept += (u32)__shfl_xor((int)kept, o);
+        if (lane == 0 && kept) atomicAdd(&stats[2], (unsigned long long)kept);
     }
     if (is_last) {
         if (!SINGLE && best >= 0 && !err) {
@@ -689,6 +699,7 @@ k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
     if (br.dist >= 0) {
         MatReader<NW> mr;
         mr.base = slab_records(const_cast<char*>(slabs) + (size_t)grp * slab_bytes); mr.lane = lane; mr.init();
+        mr.no_prefetch = ((epoch >> 26) & 1u) != 0;
         if ((epoch >> 27) & 1u) traceback_block(it.qn, br.endc + 1, mr, ow);        // NECAT_WALK=0: the reference formulation (A/B measurements)
         else {
             OpsSink sk; sk.ops = ow.ops; sk.cap = ow.cap; sk.overflow = 0; sk.store = ow.store;

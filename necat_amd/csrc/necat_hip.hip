@@ -78,7 +78,7 @@ void read_knobs()
     g_sort_b = (int)num("NECAT_SORT_B", 1);
     g_dbg = (int)num("NECAT_DBG", 0);
     g_fast = (int)num("NECAT_FAST", 1);
-    g_walk = (int)num("NECAT_WALK", 1);
+    g_walk = (int)num("NECAT_WALK", 0);      // 0: reference formulation (default until the restated walk wins), 1: walk_block, 2: walk_block without record prefetch
     g_cns_spec_extra = getenv("NECAT_CNS_SPEC_EXTRA") ? atoi(getenv("NECAT_CNS_SPEC_EXTRA")) : 1;
     g_cns_spec_cover = (int)num("NECAT_CNS_SPEC", 12);     // 0 = adaptive
 }
@@ -869,7 +869,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         NECAT_HIP(ctx, hipEventRecord(c.b1[slot], sb));
         hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB, d_nB,
                            (const u64*)c.fragB[slot], (const char*)slabsB, kSlabB, (const BlockResult*)c.resB[slot], c.opsB[slot], c.tasks, X.tail_match_len,
-                           (i32*)nullptr, X.d_err, next, epoch | (g_walk ? 0u : 1u << 27));
+                           (i32*)nullptr, X.d_err, next, epoch | (g_walk == 0 ? 1u << 27 : 0u) | (g_walk == 2 ? 1u << 26 : 0u));
         NECAT_CHECK_LAUNCH(ctx, "k_traceback<B>");
         NECAT_HIP(ctx, hipEventRecord(c.b2[slot], sb));
         b_pending[slot] = true; b_blocks[slot] = nB;
@@ -912,7 +912,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         NECAT_HIP(ctx, hipEventRecord(c.a1[cur], c.sa));
         hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false>), dim3(gA), dim3(64), 0, c.sa, itA, bound, d_nA,
                            (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
-                           (i32*)nullptr, X.d_err, next, epoch | (g_walk ? 0u : 1u << 27));
+                           (i32*)nullptr, X.d_err, next, epoch | (g_walk == 0 ? 1u << 27 : 0u) | (g_walk == 2 ? 1u << 26 : 0u));
         NECAT_CHECK_LAUNCH(ctx, "k_traceback<A>");
         NECAT_HIP(ctx, hipEventRecord(c.a2[cur], c.sa));
         a_timed[r] = 1;
@@ -996,7 +996,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     hipStream_t s = ctx->stream;
     DevVolume dref = dev_view(ref), drd = dev_view(reads);
     ctx->tm.myers_ms = ctx->tm.traceback_ms = 0; ctx->tm.myers_launches = ctx->tm.myers_blocks = ctx->tm.rounds = 0;
-    ctx->tm.myers_word_updates = ctx->tm.myers_cells_bases = 0;
+    ctx->tm.myers_word_updates = ctx->tm.myers_cells_bases = ctx->tm.myers_band_words = 0;
     ctx->tm.myersA_ms = ctx->tm.tracebackA_ms = 0; ctx->tm.myersA_launches = ctx->tm.myersA_blocks = 0;
     ctx->tm.myersA_big_ms = 0; ctx->tm.myersA_big_blocks = 0;
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
@@ -1172,10 +1172,10 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     }
     tick("rounds");
     {
-        unsigned long long hs[2] = {0, 0};
-        NECAT_HIP(ctx, hipMemcpyAsync(hs, X.stats, 16, hipMemcpyDeviceToHost, s));
+        unsigned long long hs[3] = {0, 0, 0};
+        NECAT_HIP(ctx, hipMemcpyAsync(hs, X.stats, 24, hipMemcpyDeviceToHost, s));
         NECAT_HIP(ctx, hipStreamSynchronize(s));
-        ctx->tm.myers_word_updates = hs[0]; ctx->tm.myers_cells_bases = hs[1];
+        ctx->tm.myers_word_updates = hs[0]; ctx->tm.myers_cells_bases = hs[1]; ctx->tm.myers_band_words = hs[2];
     }
     if (ao) {
         int herr = 0;
@@ -1630,8 +1630,8 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
     ctx->tm.myers_cells_bases = 0;
     std::vector<std::vector<uint8_t>> fwd_ops(n);
     int* d_err = nullptr;
-    NECAT_HIP(ctx, hipMalloc((void**)&d_err, 4 + 4 + 16));
-    NECAT_HIP(ctx, hipMemsetAsync(d_err, 0, 24, s));
+    NECAT_HIP(ctx, hipMalloc((void**)&d_err, 4 + 4 + 24));
+    NECAT_HIP(ctx, hipMemsetAsync(d_err, 0, 32, s));
     unsigned long long* d_stats = (unsigned long long*)(d_err + 2);
     const u32 chunk = getenv("NECAT_BATCH_CHUNK") ? (u32)strtoul(getenv("NECAT_BATCH_CHUNK"), nullptr, 10) : 65536u;
     auto run_shape = [&](std::vector<BlockItem>& items, std::vector<u64>& ids, bool full) -> int {
@@ -1666,9 +1666,9 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
             NECAT_CHECK_LAUNCH(ctx, "k_myers");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[5], s));
             if (full) hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, (const char*)d_slabs, slab,
-                                         (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), epoch | (g_walk ? 0u : 1u << 27));
+                                         (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), epoch | (g_walk == 0 ? 1u << 27 : 0u) | (g_walk == 2 ? 1u << 26 : 0u));
             else hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, (const char*)d_slabs, slab,
-                                    (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), epoch | (g_walk ? 0u : 1u << 27));
+                                    (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), epoch | (g_walk == 0 ? 1u << 27 : 0u) | (g_walk == 2 ? 1u << 26 : 0u));
             NECAT_CHECK_LAUNCH(ctx, "k_traceback");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[6], s));
             std::vector<BlockResult> hres(m); std::vector<i32> hn(m); std::vector<u8> hops((size_t)g * 64 * maxops);
