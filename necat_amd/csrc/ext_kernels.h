@@ -671,7 +671,9 @@ struct SameReader {   // query fragment element i == target fragment element i ?
 };
 
 // EXPORT = false: fold the block into its ExtTask.  EXPORT = true (batch API): keep the ops.
-template <int NW, int TW, int COLS, int MAXOPS, bool EXPORT>
+// WALK: 0 = traceback_block (the reference formulation, the default), 1 = walk_block, 2 = walk_block without record prefetch
+// (a template parameter, not a run-time switch: the two walks in one kernel cost the faster one its registers)
+template <int NW, int TW, int COLS, int MAXOPS, bool EXPORT, int WALK = 0>
 __global__ void __launch_bounds__(64)
 k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, const u64* __restrict__ frag, const char* __restrict__ slabs, size_t slab_bytes,
             const BlockResult* __restrict__ results, u8* __restrict__ ops_pool, ExtTask* __restrict__ tasks, int tail_match_len,
@@ -699,8 +701,8 @@ k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
     if (br.dist >= 0) {
         MatReader<NW> mr;
         mr.base = slab_records(const_cast<char*>(slabs) + (size_t)grp * slab_bytes); mr.lane = lane; mr.init();
-        mr.no_prefetch = ((epoch >> 26) & 1u) != 0;
-        if ((epoch >> 27) & 1u) traceback_block(it.qn, br.endc + 1, mr, ow);        // NECAT_WALK=0: the reference formulation (A/B measurements)
+        mr.no_prefetch = WALK == 2;
+        if (WALK == 0) traceback_block(it.qn, br.endc + 1, mr, ow);
         else {
             OpsSink sk; sk.ops = ow.ops; sk.cap = ow.cap; sk.overflow = 0; sk.store = ow.store;
             walk_block(it.qn, br.endc + 1, mr, sk, ow.ts);

@@ -867,9 +867,11 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                                (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch, 0u);
         NECAT_CHECK_LAUNCH(ctx, "k_myers<B>");
         NECAT_HIP(ctx, hipEventRecord(c.b1[slot], sb));
-        hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB, d_nB,
-                           (const u64*)c.fragB[slot], (const char*)slabsB, kSlabB, (const BlockResult*)c.resB[slot], c.opsB[slot], c.tasks, X.tail_match_len,
-                           (i32*)nullptr, X.d_err, next, epoch | (g_walk == 0 ? 1u << 27 : 0u) | (g_walk == 2 ? 1u << 26 : 0u));
+#define NECAT_TB_LAUNCH(WALK) hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false, WALK>), dim3(gB), dim3(64), 0, sb, itB, nB, d_nB, \
+                           (const u64*)c.fragB[slot], (const char*)slabsB, kSlabB, (const BlockResult*)c.resB[slot], c.opsB[slot], c.tasks, X.tail_match_len, \
+                           (i32*)nullptr, X.d_err, next, epoch)
+        if (g_walk == 1) NECAT_TB_LAUNCH(1); else if (g_walk == 2) NECAT_TB_LAUNCH(2); else NECAT_TB_LAUNCH(0);
+#undef NECAT_TB_LAUNCH
         NECAT_CHECK_LAUNCH(ctx, "k_traceback<B>");
         NECAT_HIP(ctx, hipEventRecord(c.b2[slot], sb));
         b_pending[slot] = true; b_blocks[slot] = nB;
@@ -910,9 +912,11 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                                (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
         NECAT_CHECK_LAUNCH(ctx, "k_myers<A>");
         NECAT_HIP(ctx, hipEventRecord(c.a1[cur], c.sa));
-        hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false>), dim3(gA), dim3(64), 0, c.sa, itA, bound, d_nA,
-                           (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
-                           (i32*)nullptr, X.d_err, next, epoch | (g_walk == 0 ? 1u << 27 : 0u) | (g_walk == 2 ? 1u << 26 : 0u));
+#define NECAT_TB_LAUNCH(WALK) hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, WALK>), dim3(gA), dim3(64), 0, c.sa, itA, bound, d_nA, \
+                           (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len, \
+                           (i32*)nullptr, X.d_err, next, epoch)
+        if (g_walk == 1) NECAT_TB_LAUNCH(1); else if (g_walk == 2) NECAT_TB_LAUNCH(2); else NECAT_TB_LAUNCH(0);
+#undef NECAT_TB_LAUNCH
         NECAT_CHECK_LAUNCH(ctx, "k_traceback<A>");
         NECAT_HIP(ctx, hipEventRecord(c.a2[cur], c.sa));
         a_timed[r] = 1;
@@ -1665,10 +1669,11 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
             else hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch, 0u);
             NECAT_CHECK_LAUNCH(ctx, "k_myers");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[5], s));
-            if (full) hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, (const char*)d_slabs, slab,
-                                         (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), epoch | (g_walk == 0 ? 1u << 27 : 0u) | (g_walk == 2 ? 1u << 26 : 0u));
-            else hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, (const char*)d_slabs, slab,
-                                    (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), epoch | (g_walk == 0 ? 1u << 27 : 0u) | (g_walk == 2 ? 1u << 26 : 0u));
+#define NECAT_TB_LAUNCH(NWX, TWX, COLSX, OPSX, WALK) hipLaunchKernelGGL((k_traceback<NWX, TWX, COLSX, OPSX, true, WALK>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, \
+                                         (const u64*)d_frag, (const char*)d_slabs, slab, (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), epoch)
+            if (full) { if (g_walk == 1) NECAT_TB_LAUNCH(kWordsA, kTWordsA, kColsA, kOpsA, 1); else if (g_walk == 2) NECAT_TB_LAUNCH(kWordsA, kTWordsA, kColsA, kOpsA, 2); else NECAT_TB_LAUNCH(kWordsA, kTWordsA, kColsA, kOpsA, 0); }
+            else { if (g_walk == 1) NECAT_TB_LAUNCH(kWordsB, kTWordsB, kColsB, kOpsB, 1); else if (g_walk == 2) NECAT_TB_LAUNCH(kWordsB, kTWordsB, kColsB, kOpsB, 2); else NECAT_TB_LAUNCH(kWordsB, kTWordsB, kColsB, kOpsB, 0); }
+#undef NECAT_TB_LAUNCH
             NECAT_CHECK_LAUNCH(ctx, "k_traceback");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[6], s));
             std::vector<BlockResult> hres(m); std::vector<i32> hn(m); std::vector<u8> hops((size_t)g * 64 * maxops);

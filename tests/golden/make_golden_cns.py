@@ -27,6 +27,9 @@ from make_golden import write_rel_dir  # noqa: E402
 GOLD = os.path.join(ROOT, "tests", "golden")
 CASES = {"default": {}, "fixed": dict(use_fixed_ident_cutoff=1), "cov6": dict(max_cov=6, min_cov=2),
          "a2000": dict(min_align_size=2000, mapping_ratio=0.5)}
+# the reference's oc2cns itself on the partition: (CnsOptions overrides, extra argv)
+OC2CNS_CASES = {"default": ({}, []), "full": ({}, ["-f", "1"]), "cov6_l300": (dict(max_cov=6, min_cov=2), ["-l", "300"]),
+                "x9_l3000": (dict(min_cov=9, max_cov=10), ["-l", "3000"])}
 FULL = ()      # the gapped strings are logged as 64-bit FNV hashes (a full log is 32 MB)
 
 
@@ -55,6 +58,19 @@ def main():
         L = ora.parse_cns_log(log)
         manifest["cases"][name] = {"options": kw, "templates": len(L), "overlaps": sum(len(t[6]) for t in L), "full": name in FULL}
         print(name, manifest["cases"][name])
+    # the whole stage: the reference's oc2cns on the same partition (-t 1: records in template order); committed are the
+    # md5s and sizes of its two output files
+    import hashlib
+    import subprocess
+    manifest["oc2cns"] = {}
+    for name, (kw, extra) in OC2CNS_CASES.items():
+        o = ora.cns_options(**kw)
+        co, ro = os.path.join(tmp, "cns_" + name), os.path.join(tmp, "raw_" + name)
+        subprocess.run([ora.REF_OC2CNS] + ora.cns_argv(o) + extra + ["-t", "1", wrk, can, co, ro], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        a, b = open(co, "rb").read(), open(ro, "rb").read()
+        manifest["oc2cns"][name] = {"options": kw, "extra_argv": extra, "cns_md5": hashlib.md5(a).hexdigest(), "cns_bytes": len(a), "cns_records": a.count(b">"),
+                                    "raw_md5": hashlib.md5(b).hexdigest(), "raw_bytes": len(b), "raw_records": b.count(b">")}
+        print("oc2cns", name, manifest["oc2cns"][name])
     with open(os.path.join(dst, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     shutil.rmtree(tmp, ignore_errors=True)

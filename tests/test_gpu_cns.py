@@ -6,6 +6,7 @@ order + per template ident_cutoff, num_can, num_ovlps, cov_ranges."""
 import json
 import os
 import shutil
+import subprocess
 
 import numpy as np
 import pytest
@@ -147,3 +148,50 @@ def test_front_half_chain_reads_to_overlaps(ctx, built, tmp_path):
     txt, stats = _run(ctx, wrk, open(can + ".p0", "rb").read(), {})
     assert txt == open(os.path.join(util.GOLDEN, "cns_c", "ref_default.txt")).read()
 
+
+
+# ---- the oc2cns PROGRAM (necat_amd/csrc/oc2cns: GPU extension loop + host consensus) against the reference's oc2cns ----
+
+def _run_oc2cns(built, argv, wrk, can, tmp, tag, mn=None):
+    built.build_cli()
+    co, ro = os.path.join(tmp, "cns_" + tag), os.path.join(tmp, "raw_" + tag)
+    cmd = [built.OC2CNS] + argv + [wrk, can, co, ro] + (["-mn", str(mn[0]), str(mn[1])] if mn else [])
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+    return open(co, "rb").read(), open(ro, "rb").read()
+
+
+@pytest.mark.parametrize("name", sorted(json.load(open(os.path.join(util.GOLDEN, "cns_c", "manifest.json")))["oc2cns"]))
+def test_oc2cns_program_reproduces_reference_files(built, tmp_path, name):
+    """both output files byte-identical to what the reference's oc2cns -t 1 wrote for the golden partition"""
+    import hashlib
+    m = json.load(open(os.path.join(util.GOLDEN, "cns_c", "manifest.json")))["oc2cns"][name]
+    wrk = util.install_golden_volumes("vols_c", tmp_path)
+    can = os.path.join(str(tmp_path), "cands")
+    for fn in ("cands.p0", "cands.partitions"):
+        shutil.copy(os.path.join(util.GOLDEN, "cns_c", fn), os.path.join(str(tmp_path), fn))
+    cns, raw = _run_oc2cns(built, ora.cns_argv(ora.cns_options(**m["options"])) + m["extra_argv"] + ["-t", "3"], wrk, can, str(tmp_path), name)
+    assert (len(cns), cns.count(b">")) == (m["cns_bytes"], m["cns_records"]) and hashlib.md5(cns).hexdigest() == m["cns_md5"]
+    assert (len(raw), raw.count(b">")) == (m["raw_bytes"], m["raw_records"]) and hashlib.md5(raw).hexdigest() == m["raw_md5"]
+
+
+@pytest.mark.skipif(not os.path.exists(ora.REF_OC2CNS), reason="needs oracle/_ref (built from /root/reference; it travels to the GPU box)")
+def test_oc2cns_program_sparse_partitions_and_nodes(built, tmp_path):
+    """sparse coverage (raw intervals, uncorrected reads), several partitions, and the -mn node split: node 0 + node 1 together
+    write what one run writes, and that is what the reference writes"""
+    d, rs, nv = util.make_dataset(tmp_path, genome=80_000, coverage=7.0, seed=77, err=0.12, vol_size=300_000)
+    can = util.reference_candidate_partitions(d, nv, str(tmp_path))
+    # re-partition into several files (reference oc2pcan, small batch size) so that -mn has something to split
+    subprocess.run([ora.REF_PCAN, "-p", "20", "-t", "1", d, can], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    nparts = int(open(can + ".partitions").read().split()[0])
+    assert nparts >= 2
+    o = ora.cns_options(min_cov=3)
+    argv = ora.cns_argv(o)
+    rc, rr = os.path.join(str(tmp_path), "ref_cns"), os.path.join(str(tmp_path), "ref_raw")
+    subprocess.run([ora.REF_OC2CNS] + argv + ["-t", "1", d, can, rc, rr], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    cns, raw = _run_oc2cns(built, argv + ["-t", "2"], d, can, str(tmp_path), "all")
+    assert cns == open(rc, "rb").read() and cns.count(b">") > 40
+    assert raw == open(rr, "rb").read() and raw.count(b">") > 0
+    parts = [_run_oc2cns(built, argv, d, can, str(tmp_path), "n%d" % n, mn=(n, 2)) for n in range(2)]
+    recs = lambda b: sorted(b.split(b">"))
+    assert recs(parts[0][0] + parts[1][0]) == recs(cns) and recs(parts[0][1] + parts[1][1]) == recs(raw)

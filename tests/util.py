@@ -69,6 +69,20 @@ def m4_text_rows(m):
 from necat_amd.capi import pcan_single_partition  # noqa: E402,F401  (the role swap of oc2pcan, one partition)
 
 
+def reference_candidate_partitions(wrk_dir: str, nv: int, tmp: str, kmer_size: int = 13) -> str:
+    """candidates of every volume by the REFERENCE's oc2pmov (-j 0 -u 1), partitioned by the reference's oc2pcan; returns the
+    candidates path (needs oracle/_ref)"""
+    from oracle import oracle_api as ora
+    o = ora.options(**dict(FAST, kmer_size=kmer_size, job=0, binary_output=1, num_threads=2))
+    can = os.path.join(tmp, "cands")
+    with open(can, "wb") as f:
+        for v in range(nv):
+            ora.run_ref(o, v, wrk_dir, can + ".v%d" % v)
+            f.write(open(can + ".v%d" % v, "rb").read())
+    ora.run_ref_pcan(wrk_dir, can)
+    return can
+
+
 def write_partition(prefix: str, records: bytes) -> None:
     with open(prefix + ".p0", "wb") as f:
         f.write(records)
