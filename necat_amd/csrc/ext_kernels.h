@@ -50,10 +50,12 @@ struct BlockItem {       // one scheduled block alignment
 struct BlockResult { i32 dist, endc, err; u32 words; };
 
 struct ExtLists {
-    u32* count;          // [0] = nA, [1] = nB  (this round)
+    u32* count;          // [0] = full blocks of list A (front), [1] = nB, [2] = other list-A blocks (back)
     BlockItem* itemsA; BlockItem* itemsB;
     u8* task_ops = nullptr;   // per-task alignment columns (necat_onc_align_batch), nullptr = not kept
+    u32 capA = 0;        // capacity of itemsA (its back end is itemsA[capA - 1])
 };
+
 
 // Round bookkeeping done by the first kernel of a round's list-A chain (k_ext_frag): the host never synchronises
 // with the device inside the round loop (run_batch) - it learns the sizes of the round's lists from a pinned
@@ -72,6 +74,28 @@ struct RoundCtl {
 // exact number of work items of a launch: host-known (n_dev == nullptr) or read from the device-side list counter
 NECAT_D u32 live_count(u32 n_host, const u32* __restrict__ n_dev) { return n_dev ? *n_dev : n_host; }
 
+// List A is filled from both ends (ext_append_block): the FULL blocks (512 x 512) from the front - itemsA[0 .. nf) -, the shorter
+// last blocks from the back - itemsA[cap - 1], itemsA[cap - 2], ... - so that the DP kernels' waves of 8 / 16 consecutive work items
+// are all-full almost everywhere (they have a faster path for those).  Work index space of a round: [0, nf) the full blocks,
+// [nf, nf16) holes (nf16 = nf rounded up to 16), [nf16, nf16 + np) the others; fragments, band slabs, results and op pools are
+// addressed by work index.  cap == 0: a plain list of n items (list B, the batch API).  cnt = the list buffer's counters
+// [0] = nf, [1] = nB, [2] = np.
+struct ListView { u32 n, nf, nf16, cap; };
+NECAT_D ListView list_view(u32 n_host, const u32* __restrict__ cnt, u32 cap)
+{
+    ListView v; v.cap = cap;
+    if (!cap) { v.n = cnt ? *cnt : n_host; v.nf = v.n; v.nf16 = v.n; }
+    else { v.nf = cnt[0]; v.nf16 = (v.nf + 15u) & ~15u; v.n = v.nf16 + cnt[2]; }
+    return v;
+}
+NECAT_D bool list_item(const ListView& v, const BlockItem* __restrict__ items, u64 i, BlockItem& it)
+{
+    if (i < v.nf) { it = items[i]; return true; }
+    if (i < v.nf16 || i >= v.n) return false;
+    it = items[(u64)v.cap - 1 - (i - v.nf16)];
+    return true;
+}
+
 // Append the scheduled block of task `ti` to list A (blocks of at most 512 x 512: the full blocks of an
 // extension and the last blocks that fit - 8 words, 8 lanes per block) or list B (bigger last blocks, up to
 // 794 x 794 - 13 words, 16 lanes per block: 3x the cost, so nothing that fits list A goes here);
@@ -80,23 +104,21 @@ NECAT_D void ext_append_block(const ExtTask& t, u32 ti, bool go, const ExtLists&
 {
     const bool isA = go && t.qblk <= kOcaBlockSize && t.tblk <= kOcaBlockSize;
     const bool isB = go && !isA;
-    // inside a wave's share of list A the FULL blocks (512 x 512) come first: the DP kernel takes 8 consecutive items per
-    // wave and has a faster path for waves made of full blocks only, so the last blocks should sit together, not one in
-    // every wave
+    // list A from both ends: full blocks from the front, the others from the back (ListView)
     const bool isF = isA && t.qblk == kOcaBlockSize && t.tblk == kOcaBlockSize;
     const bool isP = isA && !isF;
     const int lane = (int)(threadIdx.x & 63);
     const u64 below = (1ULL << lane) - 1ULL;
     const u64 mF = __ballot(isF), mP = __ballot(isP), mB = __ballot(isB);
-    const u64 mA = mF | mP;
-    u32 baseA = 0, baseB = 0;
-    if (mA) { const int leader = ctz64(mA); if (lane == leader) baseA = atomicAdd(&L.count[0], (u32)popc64(mA)); baseA = __shfl(baseA, leader); }
+    u32 baseF = 0, baseP = 0, baseB = 0;
+    if (mF) { const int leader = ctz64(mF); if (lane == leader) baseF = atomicAdd(&L.count[0], (u32)popc64(mF)); baseF = __shfl(baseF, leader); }
+    if (mP) { const int leader = ctz64(mP); if (lane == leader) baseP = atomicAdd(&L.count[2], (u32)popc64(mP)); baseP = __shfl(baseP, leader); }
     if (mB) { const int leader = ctz64(mB); if (lane == leader) baseB = atomicAdd(&L.count[1], (u32)popc64(mB)); baseB = __shfl(baseB, leader); }
     if (go) {
         BlockItem it;
         it.g = ext_frag_geom(t); it.task = (i32)ti; it.qn = (i16)t.qblk; it.tn = (i16)t.tblk;
-        if (isF) L.itemsA[baseA + (u32)popc64(mF & below)] = it;
-        else if (isP) L.itemsA[baseA + (u32)popc64(mF) + (u32)popc64(mP & below)] = it;
+        if (isF) L.itemsA[baseF + (u32)popc64(mF & below)] = it;
+        else if (isP) L.itemsA[L.capA - 1u - (baseP + (u32)popc64(mP & below))] = it;
         else L.itemsB[baseB + (u32)popc64(mB & below)] = it;
     }
 }
@@ -157,16 +179,16 @@ k_items_scatter(const BlockItem* __restrict__ items, u32 n, u32* __restrict__ bi
 // words [0,NW) = ~lo planes, [NW,2NW) = ~hi planes, [2NW, 2NW+TW) = target 2-bit words
 template <int NW, int TW>
 __global__ void __launch_bounds__(256)
-k_ext_frag(DevVolume reads, DevVolume ref, const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u64* __restrict__ frag,
+k_ext_frag(DevVolume reads, DevVolume ref, const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u32 capA, u64* __restrict__ frag,
            RoundCtl ctl)
 {
     constexpr int FW = 2 * NW + TW, CH = NW + TW;
-    const u32 n = live_count(n_host, n_dev);
+    const ListView lv = list_view(n_host, n_dev, capA);
     if (blockIdx.x == 0) {
         if (ctl.zero_bins) for (int i = threadIdx.x; i < 1024; i += blockDim.x) ctl.zero_bins[i] = 0u;
         if (threadIdx.x == 0 && ctl.pub) {
-            const u32 a = ctl.count[0], b = ctl.count[1];
-            ctl.zero[0] = 0u; ctl.zero[1] = 0u;
+            const u32 a = ctl.count[0] + ctl.count[2], b = ctl.count[1];      // list A: full blocks + the others
+            ctl.zero[0] = 0u; ctl.zero[1] = 0u; ctl.zero[2] = 0u;
             volatile RoundPub* p = ctl.pub;
             p->nA = a; p->nB = b;
             __threadfence_system();
@@ -179,8 +201,8 @@ k_ext_frag(DevVolume reads, DevVolume ref, const BlockItem* __restrict__ items, 
     const u32 r = (u32)(gid % (64 * CH));
     const int ch = (int)(r >> 6), lane = (int)(r & 63);
     const u64 item = grp * 64 + lane;
-    if (item >= n) return;
-    const BlockItem it = items[item];
+    BlockItem it;
+    if (!list_item(lv, items, item, it)) return;
     u64* dst = frag + grp * FW * 64 + lane;
     if (ch < NW) {
         if (ch * 64 < it.qn) {
@@ -258,17 +280,19 @@ NECAT_D ulonglong2* slab_records(char* slab) { return reinterpret_cast<ulonglong
 // register resident (dp_core.h) and the only memory traffic is the coalesced band store.
 template <int NW, int TW, int COLS, bool FULL>
 __global__ void __launch_bounds__(64)
-k_myers(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
+k_myers(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
         double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, u32 epoch, u32 item_base)
 {
     constexpr int FW = 2 * NW + TW;
-    const u32 n = live_count(n_host, n_dev);
+    const ListView lv = list_view(n_host, n_dev, capA);
+    const u32 n = lv.n;
     const u32 grp = blockIdx.x + (item_base >> 6);      // item_base is a multiple of 64; n = end of this launch's range
     const int lane = threadIdx.x;
     const u64 item = (u64)grp * 64 + lane;
-    if (item >= n) return;
-    const int qn = FULL ? kOcaBlockSize : items[item].qn;
-    const int tn = FULL ? kOcaBlockSize : items[item].tn;
+    BlockItem it0;
+    if (!list_item(lv, items, item, it0)) return;
+    const int qn = FULL ? kOcaBlockSize : it0.qn;
+    const int tn = FULL ? kOcaBlockSize : it0.tn;
     const u64* fr = frag + (u64)grp * FW * 64 + lane;
     MyersRegs<NW> R;
     const int nblk = (qn + 63) >> 6;
@@ -286,7 +310,7 @@ k_myers(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__
     results[item] = br;
     // work counters for the roofline report: one atomic per wave
     u32 w = r.words, bases = (u32)(qn + tn);
-    if ((u64)n - (u64)grp * 64 >= 64) {      // full wave: every lane is alive, shuffles are safe
+    if (__popcll(__ballot(1)) == 64) {       // full wave: every lane is alive, shuffles are safe
         for (int o = 32; o > 0; o >>= 1) { w += __shfl_down(w, o); bases += __shfl_down(bases, o); }
         if (lane == 0) { atomicAdd(&stats[0], (unsigned long long)w); atomicAdd(&stats[1], (unsigned long long)bases); }
     } else { atomicAdd(&stats[0], (unsigned long long)w); atomicAdd(&stats[1], (unsigned long long)bases); }
@@ -365,74 +389,38 @@ NECAT_D u32 dpp_row_shr1(u32 v, u32 keep)     // lane i receives v of lane i - 1
     return (u32)__builtin_amdgcn_update_dpp((int)keep, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
 }
 
-// all 8 blocks of the wave: 512 x 512.  tw = the wave's staged target planes (LDS), nlo / nhi = this lane's query word.
+// NW pass of 8 full blocks with 8 lanes per block (lane = 8 sub + b): target[0 .. end0] with k = best, the band stored through the
+// reference's per-word band tests.  best / end0 / go are the block's (the same on its 8 lanes).
 template <int NW, int TW>
-NECAT_D void myers_fast_full(const int lane, const u64* __restrict__ tw, const u64 nlo, const u64 nhi, ulonglong2* __restrict__ rec, const int il,
-                             const double error, const bool valid_item, BlockResult* __restrict__ result, unsigned long long* __restrict__ stats,
-                             const bool no_store)
+NECAT_D void fast_nw8(const int lane, const u64* __restrict__ tw, const u64 nlo, const u64 nhi, ulonglong2* __restrict__ rec, const int il,
+                      const int best, const int end0, const bool go, unsigned long long* __restrict__ stats, const bool no_store)
 {
     constexpr int G = 8, N = kOcaBlockSize;
     const int b = lane & (G - 1);
     const u32 cm = b == G - 1 ? 0x80000000u : 0u;
     const u32 nlo_l = (u32)nlo, nlo_h = (u32)(nlo >> 32), nhi_l = (u32)nhi, nhi_h = (u32)(nhi >> 32);
     const u32 sk = (u32)(32 - b) & 31u;
-    u32 tlo = 0, thi = 0, plo = 0, phi = 0;       // this lane's 32-column window (two bit-planes) and the previous raw planes
+    u32 tlo = 0, thi = 0, plo = 0, phi = 0;
     auto reload = [&](int w) {
         const u64 x = w < TW ? tw[w] : 0ULL;
         const u32 xl = (u32)x, xh = (u32)(x >> 32);
-        // lane b lags b columns behind lane 0: its window = the planes shifted up by b bits (column c of the block = step c + b)
         tlo = b ? __builtin_amdgcn_alignbit(xl, plo, sk) : xl;
         thi = b ? __builtin_amdgcn_alignbit(xh, phi, sk) : xh;
         plo = xl; phi = xh;
     };
-    // Eq of this lane's column at step 32 w + j: rows whose base code equals the column's (two 3-input ops per half)
     auto eq_of = [&](int j, u32& el, u32& eh) {
         const u32 ma = (u32)__builtin_amdgcn_sbfe((int)tlo, (u32)j, 1u), mb = (u32)__builtin_amdgcn_sbfe((int)thi, (u32)j, 1u);
-        el = bop<0x60>(nlo_l ^ ma, nhi_l, mb); eh = bop<0x60>(nlo_h ^ ma, nhi_h, mb);      // (nlo ^ ma) & (nhi ^ mb)
+        el = bop<0x60>(nlo_l ^ ma, nhi_l, mb); eh = bop<0x60>(nlo_h ^ ma, nhi_h, mb);
     };
-    constexpr int kSteps = N + G - 1;             // 519: lane b computes column c at step c + b
-
-    // ------------------------------------------------------------------ SHW: best prefix distance, first best end column
-    FastWord w; w.Pv = ~0ULL; w.Mv = 0ULL; w.pubP = 0x80000000u; w.pubM = 0u;
-    u32 S = (u32)(b + 1) * 64u;
-    u32 key = 0xffffffffu;                        // min over columns of (bottom-row value << 10 | step)
-    u64 dA, dB;
-    u32 cph = 0x80000000u, cmh = 0u;              // carries from the word above; the top word of a DPP row keeps the boundary (+1)
-    for (int s0 = 0; s0 < kSteps; s0 += 32) {
-        reload(s0 >> 5);
-        const int jn = kSteps - s0 < 32 ? kSteps - s0 : 32;
-        for (int j = 0; j < jn; ++j) {
-            const int s = s0 + j;
-            cph = dpp_row_shr1(w.pubP, cph); cmh = dpp_row_shr1(w.pubM, cmh);
-            const bool edge = s < G - 1 || s >= N;                         // fill / drain: some lanes are outside their block
-            if (!edge || (s >= b && s - b < N)) {
-                u32 phh, mhh, el, eh;
-                eq_of(j, el, eh);
-                fast_advance<false>(w, el, eh, cph, cmh, cm, phh, mhh, dA, dB);
-                S += (phh >> 31) - (mhh >> 31);
-                const u32 k2 = (S << 10) + (u32)s;
-                key = k2 < key ? k2 : key;
-            }
-        }
-    }
-    // word 7 holds the bottom row: its minimum is the block's (best, first end column); column = step - 7
-    const int owner = (lane & ~(G - 1)) | (G - 1);
-    const u32 bkey = (u32)__shfl((int)key, owner);
-    int best = (int)(bkey >> 10), end0 = (int)(bkey & 1023u) - (G - 1);
-    const int k0 = (int)((double)N * error * 1.1);                       // edlib_ex.c:751
-    if (best > k0 || !valid_item) best = -1;
     const int tn2 = end0 + 1;
-    int err = 0;
-    if (best >= 0) { int ad = tn2 - N; if (ad < 0) ad = -ad; if (best < ad) err = 1; }
-    const bool go = best >= 0 && !err;
-
+    FastWord w;
+    u32 cph, cmh;
     // ------------------------------------------------------------------ NW on target[0 .. end0] with k = best: store the band
     int steps = go ? tn2 + G - 1 : 0;
     for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
     steps = __builtin_amdgcn_readfirstlane(steps);
     w.Pv = ~0ULL; w.Mv = 0ULL; w.pubP = 0x80000000u; w.pubM = 0u;
     int Sn = (b + 1) * 64;
-    plo = phi = 0;
     // store filter (the reference's per-word band tests with k = best, edlib_ex.c:311-325, as in the general path), in terms of
     // the step s = c + b:   drop iff S >= K1  ||  S - s > K2  ||  S + s > K3;   nothing is stored from column tn2 on
     const int rb = (b + 1) * 64 - 1;
@@ -474,7 +462,33 @@ NECAT_D void myers_fast_full(const int lane, const u64* __restrict__ tw, const u
         }
     }
     for (int o = 32; o > 0; o >>= 1) kept += (u32)__shfl_xor((int)kept, o);
-    if (lane == 0) atomicAdd(&stats[2], (unsigned long long)kept);
+    if (lane == 0 && kept) atomicAdd(&stats[2], (unsigned long long)kept);
+}
+
+}  // namespace necat
+#include "ext_fast16.h"      // fast_shw8, myers_fast16 (on top of FastWord / fast_advance / fast_nw8 above)
+namespace necat {
+
+// all 8 blocks of the wave: 512 x 512.  tw = the wave's staged target planes (LDS), nlo / nhi = this lane's query word.
+template <int NW, int TW>
+NECAT_D void myers_fast_full(const int lane, const u64* __restrict__ tw, const u64 nlo, const u64 nhi, ulonglong2* __restrict__ rec, const int il,
+                             const double error, const bool valid_item, BlockResult* __restrict__ result, unsigned long long* __restrict__ stats,
+                             const bool no_store)
+{
+    constexpr int G = 8, N = kOcaBlockSize;
+    const int b = lane & (G - 1);
+    // ---- SHW: best prefix distance, first best end column (word 7 holds the bottom row; column = step - 7)
+    const u32 key = fast_shw8<TW>(b, tw, nlo, nhi);
+    const int owner = (lane & ~(G - 1)) | (G - 1);
+    const u32 bkey = (u32)__shfl((int)key, owner);
+    int best = (int)(bkey >> 10), end0 = (int)(bkey & 1023u) - (G - 1);
+    const int k0 = (int)((double)N * error * 1.1);                       // edlib_ex.c:751
+    if (best > k0 || !valid_item) best = -1;
+    const int tn2 = end0 + 1;
+    int err = 0;
+    if (best >= 0) { int ad = tn2 - N; if (ad < 0) ad = -ad; if (best < ad) err = 1; }
+    const bool go = best >= 0 && !err;
+    fast_nw8<NW, TW>(lane, tw, nlo, nhi, rec, il, best, end0, go, stats, no_store);
     if (b == G - 1 && valid_item) {
         BlockResult br; br.dist = err ? -1 : best; br.endc = end0; br.err = err;
         br.words = (u32)(NW * (N + (go ? tn2 : 0)));
@@ -487,25 +501,27 @@ NECAT_D void myers_fast_full(const int lane, const u64* __restrict__ tw, const u
 // SHW pass computed for the columns up to the end column (same recurrence, same boundary), its only purpose being
 // to know the distance for the store filter - so when store traffic is irrelevant the SHW pass stores every word
 // itself and the NW pass is skipped: half the latency.
-template <int NW, int TW, int COLS, int G, bool SINGLE = false>
-__global__ void __launch_bounds__(64)
-k_myers_coop(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
-             double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, u32 epoch, u32 item_base)
+// The body of one wave: BPW = 64 / G consecutive work items starting at `wave_first`; t_lds = the wave's [BPW][TW] staging area (LDS).
+// Every wave of the workgroup must call it (it synchronises the workgroup once).
+template <int NW, int TW, int COLS, int G, bool SINGLE>
+NECAT_D void myers_coop_wave(const ListView& lv, const BlockItem* __restrict__ items, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
+                             double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, u32 epoch, const u64 wave_first,
+                             u64 (*t_lds)[TW], const int lane)
 {
     constexpr int FW = 2 * NW + TW, BPW = 64 / G;
-    const u32 n = live_count(n_host, n_dev);
-    if ((u64)item_base + (u64)blockIdx.x * BPW >= n) return;      // a whole wave beyond the list (grids are sized from an upper bound)
-    const int lane = threadIdx.x, sub = lane / G, b = lane % G;
+    const u32 n = lv.n;
+    const int sub = lane / G, b = lane % G;
     const bool filter = ((epoch >> 30) & 1u) == 0;      // bit 30 of the epoch argument switches the store filter off (A/B tests)
     const bool fast_ok = ((epoch >> 29) & 1u) == 0;     // bit 29: never take the full-block fast path (A/B measurements)
     const bool fast_nostore = ((epoch >> 28) & 1u) != 0; // bit 28: fast path without band stores (profiling only)
-    epoch &= 0x0fffffffu;
-    const u64 item = (u64)item_base + (u64)blockIdx.x * BPW + sub;
-    const bool valid = item < n;
+    epoch &= 0x07ffffffu;
+    const u64 item = wave_first + (u64)sub;
+    BlockItem it0;
+    const bool valid = list_item(lv, items, item, it0);
     const u64 grp = item >> 6;
     const int il = (int)(item & 63);
     int qn = 0, tn = 0;
-    if (valid) { qn = items[item].qn; tn = items[item].tn; }
+    if (valid) { qn = it0.qn; tn = it0.tn; }
     const int nblk = (qn + 63) >> 6, W = nblk * 64 - qn;
     const bool have = valid && b < nblk;
     const bool is_last = have && b == nblk - 1;
@@ -518,7 +534,6 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n_host, const u32* __restr
     // vmcnt queue as the NW band stores and stall every step on them
     // staged as two bit-planes per 32 columns (low / high bit of the base code in the low / high half): a lane then
     // gets its column's two symbol masks with one v_bfe_i32 each instead of shift + mask + 64-bit shift + extends
-    __shared__ u64 t_lds[BPW][TW];
     if (valid) for (int w = b; w < TW; w += G) {
         const u64 x = (w * 32 < tn) ? fr[(u64)(2 * NW + w) * 64] : 0ULL;
         t_lds[sub][w] = even_bits(x) | (even_bits(x >> 1) << 32);
@@ -628,6 +643,48 @@ k_myers_coop(const BlockItem* __restrict__ items, u32 n_host, const u32* __restr
     }
 }
 
+template <int NW, int TW, int COLS, int G, bool SINGLE = false>
+__global__ void __launch_bounds__(64)
+k_myers_coop(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
+             double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, u32 epoch, u32 item_base)
+{
+    constexpr int BPW = 64 / G;
+    const ListView lv = list_view(n_host, n_dev, capA);
+    const u64 first = (u64)item_base + (u64)blockIdx.x * BPW;
+    if (first >= lv.n) return;      // a whole wave beyond the list (grids are sized from an upper bound)
+    __shared__ u64 t_lds[BPW][TW];
+    myers_coop_wave<NW, TW, COLS, G, SINGLE>(lv, items, frag, slabs, slab_bytes, error, results, stats, epoch, first, t_lds, (int)threadIdx.x);
+}
+
+// The list-A DP kernel of the big rounds.  One workgroup of two waves = 16 consecutive work items.  All 16 full 512 x 512 blocks
+// (with the list filled from both ends: almost every group of the front part): SHW with 8 lanes per block, the two waves side by
+// side, then NW with 4 lanes per block on one wave (ext_fast16.h).  Anything else: each wave does its 8 items the general way
+// (myers_coop_wave, which itself has the 8-lane fast path for 8 full blocks).
+template <int NW, int TW, int COLS>
+__global__ void __launch_bounds__(128)
+k_myers_a16(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
+            double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, u32 epoch)
+{
+    constexpr int FW = 2 * NW + TW;
+    const ListView lv = list_view(n_host, n_dev, capA);
+    const u64 first = (u64)blockIdx.x * 16;
+    if (first >= lv.n) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ u64 tl[16][TW];
+    __shared__ int res[16][2];
+    BlockItem it;
+    bool full = list_item(lv, items, first + (u64)(lane & 15), it);
+    if (full) full = it.qn == kOcaBlockSize && it.tn == kOcaBlockSize;
+    const bool f16 = ((epoch >> 27) & 1u) != 0;
+    if (f16 && __all(full)) {
+        const u64 grp = first >> 6;
+        const int il0 = (int)(first & 63);
+        myers_fast16<NW, TW>(lane, frag + grp * FW * 64 + il0, slabs + (size_t)grp * slab_bytes, il0, error, results + first, stats, tl, res, ((epoch >> 28) & 1u) != 0);
+        return;
+    }
+    myers_coop_wave<NW, TW, COLS, 8, false>(lv, items, frag, slabs, slab_bytes, error, results, stats, epoch, first + 8ull * wv, tl + 8 * wv, lane);
+}
+
 // maximum over the active lanes of a value below 2048 (bit by bit with ballots: exited lanes do not take part)
 NECAT_D int wave_max_u11(int v)
 {
@@ -675,17 +732,17 @@ struct SameReader {   // query fragment element i == target fragment element i ?
 // (a template parameter, not a run-time switch: the two walks in one kernel cost the faster one its registers)
 template <int NW, int TW, int COLS, int MAXOPS, bool EXPORT, int WALK = 0>
 __global__ void __launch_bounds__(64)
-k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, const u64* __restrict__ frag, const char* __restrict__ slabs, size_t slab_bytes,
+k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, const char* __restrict__ slabs, size_t slab_bytes,
             const BlockResult* __restrict__ results, u8* __restrict__ ops_pool, ExtTask* __restrict__ tasks, int tail_match_len,
             i32* __restrict__ n_ops_out, int* __restrict__ err_flag, ExtLists next, u32 epoch)
 {
     constexpr int FW = 2 * NW + TW;
-    const u32 n = live_count(n_host, n_dev);
+    const ListView lv = list_view(n_host, n_dev, capA);
     const u32 grp = blockIdx.x;
     const int lane = threadIdx.x;
     const u64 item = (u64)grp * 64 + lane;
-    if (item >= n) return;
-    const BlockItem it = items[item];
+    BlockItem it;
+    if (!list_item(lv, items, item, it)) return;
     const BlockResult br = results[item];
     if (br.err) atomicExch(err_flag, 10 + br.err);
     OpsWriter ow; ow.ops = ops_pool + (size_t)grp * MAXOPS * 64 + lane; ow.cap = MAXOPS; ow.overflow = 0; ow.store = true;

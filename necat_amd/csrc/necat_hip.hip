@@ -60,6 +60,7 @@ int g_coop_filter;     // NECAT_COOP_FILTER=0: the cooperative kernel stores eve
 int g_sort_b;          // NECAT_SORT_B=0 disables the size sort of list B
 int g_cns_spec_extra, g_cns_spec_cover;   // NECAT_CNS_SPEC_EXTRA / NECAT_CNS_SPEC: speculation width of the consensus loop
 int g_fast;            // NECAT_FAST=0: the list-A DP kernel never takes its full-block fast path (A/B measurements); 2: fast path without band stores (profiling only, results invalid)
+int g_fast16;          // NECAT_FAST16=1: list A's big rounds through k_myers_a16 (16 full blocks per workgroup: SHW 8 lanes, NW 4 lanes per block)
 int g_walk;            // NECAT_WALK=0: k_traceback runs the reference formulation of the walk (A/B measurements)
 int g_dbg;             // NECAT_DBG: profiling-only variants of the lane-per-block DP kernel (1 = no band stores, 2 = no NW pass)
 
@@ -78,6 +79,7 @@ void read_knobs()
     g_sort_b = (int)num("NECAT_SORT_B", 1);
     g_dbg = (int)num("NECAT_DBG", 0);
     g_fast = (int)num("NECAT_FAST", 1);
+    g_fast16 = (int)num("NECAT_FAST16", 0);      // measured: no gain on the bench workload, off by default
     g_walk = (int)num("NECAT_WALK", 0);      // 0: reference formulation (default until the restated walk wins), 1: walk_block, 2: walk_block without record prefetch
     g_cns_spec_extra = getenv("NECAT_CNS_SPEC_EXTRA") ? atoi(getenv("NECAT_CNS_SPEC_EXTRA")) : 1;
     g_cns_spec_cover = (int)num("NECAT_CNS_SPEC", 12);     // 0 = adaptive
@@ -119,7 +121,7 @@ int necat_ctx_create(int device_id, necat_ctx** out)
     }
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream_a) != hipSuccess ||
         hipStreamCreate(&ctx->stream_b) != hipSuccess || hipStreamCreate(&ctx->stream_c) != hipSuccess ||
-        hipStreamCreate(&ctx->stream_copy) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
+        hipStreamCreate(&ctx->stream_copy) != hipSuccess || hipStreamCreate(&ctx->stream_d) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
     for (int i = 0; i < kNumEvents; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
     // the list sizes of the extension rounds reach the host through this pinned ring (RoundPub, ext_kernels.h)
     if (hipHostMalloc(&ctx->round_ring, kRoundRing * sizeof(RoundPub), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -141,7 +143,7 @@ void necat_ctx_destroy(necat_ctx* ctx)
     for (int i = 0; i < kNumEvents; ++i) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->round_ring) (void)hipHostFree(ctx->round_ring);
     (void)hipStreamDestroy(ctx->stream); (void)hipStreamDestroy(ctx->stream_a); (void)hipStreamDestroy(ctx->stream_b); (void)hipStreamDestroy(ctx->stream_c);
-    (void)hipStreamDestroy(ctx->stream_copy);
+    (void)hipStreamDestroy(ctx->stream_copy); (void)hipStreamDestroy(ctx->stream_d);
     delete ctx;
 }
 
@@ -746,7 +748,8 @@ namespace {
 // A(r) and B(r), and lists[(r - 1) % 4] may still be read by B(r - 1).  B(r) and B(r - 1) run side by side on two
 // streams with two sets of buffers and band pools (list A's pool is reused by A(r + 1) while they run).
 struct Batch {
-    ExtTask* tasks; u32* count;            // count[4][2]: (nA, nB) per list buffer
+    ExtTask* tasks; u32* count;            // count[4][4]: (full list-A blocks, nB, other list-A blocks, -) per list buffer
+    u32 cap;                               // capacity of every item array (list A is filled from both ends)
     BlockItem* itemsA[4]; BlockItem* itemsB[4];
     u64* fragA; u8* opsA; BlockResult* resA;
     // list B: two sets (round parity) - B(r) and B(r - 1) are independent and run side by side
@@ -836,13 +839,13 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         }
         char* slabsB = (char*)poolB.p;
         const BlockItem* itB = c.itemsB[cur];
-        const u32* d_nB = c.count + 2 * cur + 1;
+        const u32* d_nB = c.count + 4 * cur + 1;
         NECAT_HIP(ctx, hipStreamWaitEvent(sb, c.a0[cur], 0));     // lists[q] complete (A(q - 1) done), counters of lists[q + 2] reset
         NECAT_HIP(ctx, hipStreamWaitEvent(sb, c.b2[slot], 0));    // B(q - 2): appended to lists[q], previous user of the slot's buffers
         // (B(q - 1) on the other stream reads lists[q - 1] and appends to lists[q + 1]; this round appends to lists[q + 2]:
         // four list buffers keep the two apart - with three, lists[q + 2] WAS lists[q - 1])
         const u32 epoch = ++ctx->epoch & 0x3fffffu;
-        ExtLists next; next.count = c.count + 2 * nxt2; next.itemsA = c.itemsA[nxt2]; next.itemsB = c.itemsB[nxt2]; next.task_ops = X.task_ops;
+        ExtLists next; next.count = c.count + 4 * nxt2; next.itemsA = c.itemsA[nxt2]; next.itemsB = c.itemsB[nxt2]; next.task_ops = X.task_ops; next.capA = c.cap;
         // (below ~2 k blocks every wave is resident at once and the round lasts as long as its longest walk: order is irrelevant)
         if (nB >= 2048 && g_sort_b) {
             hipLaunchKernelGGL(k_items_hist, dim3(grid_for(nB, 256)), dim3(256), 0, sb, itB, nB, c.bins[slot]);
@@ -853,21 +856,21 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         }
         RoundCtl ctl; ctl.zero_bins = c.bins[slot];
         hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, sb,
-                           drd, dref, itB, nB, d_nB, c.fragB[slot], ctl);
+                           drd, dref, itB, nB, d_nB, 0u, c.fragB[slot], ctl);
         NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
         NECAT_HIP(ctx, hipEventRecord(c.b0[slot], sb));
         if (nB <= g_single_pass && nB <= g_coop_threshold)
-            hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16, true>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB, d_nB,
+            hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16, true>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB, d_nB, 0u,
                                (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch, 0u);
         else if (nB <= g_coop_threshold)
-            hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB, d_nB,
+            hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB, d_nB, 0u,
                                (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch | (g_coop_filter ? 0u : 1u << 30) | (g_fast == 0 ? 1u << 29 : 0u) | (g_fast == 2 ? 1u << 28 : 0u), 0u);
         else
-            hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB, d_nB,
+            hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB, d_nB, 0u,
                                (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch, 0u);
         NECAT_CHECK_LAUNCH(ctx, "k_myers<B>");
         NECAT_HIP(ctx, hipEventRecord(c.b1[slot], sb));
-#define NECAT_TB_LAUNCH(WALK) hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false, WALK>), dim3(gB), dim3(64), 0, sb, itB, nB, d_nB, \
+#define NECAT_TB_LAUNCH(WALK) hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false, WALK>), dim3(gB), dim3(64), 0, sb, itB, nB, d_nB, 0u, \
                            (const u64*)c.fragB[slot], (const char*)slabsB, kSlabB, (const BlockResult*)c.resB[slot], c.opsB[slot], c.tasks, X.tail_match_len, \
                            (i32*)nullptr, X.d_err, next, epoch)
         if (g_walk == 1) NECAT_TB_LAUNCH(1); else if (g_walk == 2) NECAT_TB_LAUNCH(2); else NECAT_TB_LAUNCH(0);
@@ -890,29 +893,36 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         }
         char* slabsA = (char*)ctx->scratch[SC_EXT_MAT].p;
         const BlockItem* itA = c.itemsA[cur];
-        const u32* d_nA = c.count + 2 * cur;
+        const u32* d_nA = c.count + 4 * cur;            // [0] full blocks (front of itemsA), [2] the others (back)
         if (r >= 2) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, c.b2[r & 1], 0));        // B(r - 2) appended to lists[r]
         const u32 epoch = ++ctx->epoch & 0x3fffffu;
-        RoundCtl ctl; ctl.count = d_nA; ctl.zero = c.count + 2 * nxt2; ctl.seq = seq0 + r + 1; ctl.pub = ring_dev + (seq0 + r) % kRoundRing;
+        RoundCtl ctl; ctl.count = d_nA; ctl.zero = c.count + 4 * nxt2; ctl.seq = seq0 + r + 1; ctl.pub = ring_dev + (seq0 + r) % kRoundRing;
         hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)std::max(gA, 1u) * 64 * (kWordsA + kTWordsA), 256)), dim3(256), 0, c.sa,
-                           drd, dref, itA, bound, d_nA, c.fragA, ctl);
+                           drd, dref, itA, bound, d_nA, c.cap, c.fragA, ctl);
         NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<A>");
         NECAT_HIP(ctx, hipEventRecord(c.a0[cur], c.sa));
         a_timed.push_back(0);
         if (!bound) return NECAT_OK;
-        ExtLists next; next.count = c.count + 2 * nxt; next.itemsA = c.itemsA[nxt]; next.itemsB = c.itemsB[nxt]; next.task_ops = X.task_ops;
+        ExtLists next; next.count = c.count + 4 * nxt; next.itemsA = c.itemsA[nxt]; next.itemsB = c.itemsB[nxt]; next.task_ops = X.task_ops; next.capA = c.cap;
         if (bound <= g_single_pass && bound <= g_coop_threshold)
-            hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8, true>), dim3((bound + 7) / 8), dim3(64), 0, c.sa, itA, bound, d_nA,
+            hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8, true>), dim3((bound + 7) / 8), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap,
                                (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
-        else if (bound <= g_coop_threshold)
-            hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((bound + 7) / 8), dim3(64), 0, c.sa, itA, bound, d_nA,
-                               (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch | (g_coop_filter ? 0u : 1u << 30) | (g_fast == 0 ? 1u << 29 : 0u) | (g_fast == 2 ? 1u << 28 : 0u), 0u);
+        else if (bound <= g_coop_threshold) {
+            const bool f16 = g_fast16 && g_fast == 1 && g_coop_filter;
+            const u32 fl = epoch | (g_coop_filter ? 0u : 1u << 30) | (g_fast == 0 ? 1u << 29 : 0u) | (g_fast == 2 ? 1u << 28 : 0u);
+            if (f16)      // workgroups of 16 work items: 16 full blocks take the 16-block path (ext_fast16.h), anything else the general one
+                hipLaunchKernelGGL((k_myers_a16<kWordsA, kTWordsA, kColsA>), dim3((bound + 15) / 16), dim3(128), 0, c.sa, itA, bound, d_nA, c.cap,
+                                   (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, fl | 1u << 27);
+            else
+                hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((bound + 7) / 8), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap,
+                                   (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, fl, 0u);
+        }
         else
-            hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, false>), dim3(gA), dim3(64), 0, c.sa, itA, bound, d_nA,   // list A also holds last blocks <= 512 x 512
+            hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, false>), dim3(gA), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap,   // list A also holds last blocks <= 512 x 512
                                (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
         NECAT_CHECK_LAUNCH(ctx, "k_myers<A>");
         NECAT_HIP(ctx, hipEventRecord(c.a1[cur], c.sa));
-#define NECAT_TB_LAUNCH(WALK) hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, WALK>), dim3(gA), dim3(64), 0, c.sa, itA, bound, d_nA, \
+#define NECAT_TB_LAUNCH(WALK) hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, WALK>), dim3(gA), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap, \
                            (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len, \
                            (i32*)nullptr, X.d_err, next, epoch)
         if (g_walk == 1) NECAT_TB_LAUNCH(1); else if (g_walk == 2) NECAT_TB_LAUNCH(2); else NECAT_TB_LAUNCH(0);
@@ -925,7 +935,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
     int rc = NECAT_OK;
     u32 launched = 0;
     for (u32 r = 0;; ++r) {
-        u32 bound = c.n;
+        u32 bound = c.n + 16;
         if (r > 0) {
             Cnt prev;
             if ((rc = wait_pub(r - 1, prev))) break;          // A(r - 1) has started: A(r - 2) and B(r - 3) are done
@@ -934,7 +944,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
             const u32 nB2 = r >= 2 ? hist[r - 2].nB : 0;     // B(r - 2) may still be running: its successors join lists[r]
             if (prev.nA + prev.nB + nB2 == 0) break;          // nothing alive
             if (prev.nB) { if ((rc = launch_b(r - 1, prev.nB))) break; }
-            bound = prev.nA + nB2;
+            bound = prev.nA + nB2 + 16;                     // work indices: the full blocks rounded up to 16, then the others
         }
         if ((rc = launch_a(r, bound))) break;
         launched = r + 1;
@@ -1020,7 +1030,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     necat_m4* d_m4 = (necat_m4*)cb; cb += n * sizeof(necat_m4);
     necat_m4* d_out = (necat_m4*)cb; cb += n * sizeof(necat_m4);
     u64* d_goff = (u64*)cb; cb += (n_groups_max + 1) * 8;
-    u32* d_outcnt = (u32*)cb; cb += 128;          // [0..1] output counter, [2..9] list counts (4 buffers x (nA, nB)), [16..19] stats
+    u32* d_outcnt = (u32*)cb; cb += 128;          // [0..1] output counter, [2..17] list counters (4 buffers x 4), [18..23] work counters
     int* d_err = (int*)cb; cb += 64;
     u8* d_ok = (u8*)cb;
     NECAT_HIP(ctx, hipMemcpyAsync(d_cands, dev ? dev->d : cands, n * sizeof(necat_candidate), dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
@@ -1078,7 +1088,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
             k.opsB[j] = k.opsA + (size_t)groups * 64 * (kOpsA + j * kOpsB);
             k.resB[j] = k.resA + (size_t)groups * 64 * (1 + j);
         }
-        k.count = d_outcnt + 2;
+        k.count = d_outcnt + 2; k.cap = cap;
         k.sa = ctx->stream_a; k.sb[0] = ctx->stream_b; k.sb[1] = ctx->stream_c;
         for (int j = 0; j < 4; ++j) { k.a0[j] = ctx->ev[4 + 3 * j]; k.a1[j] = ctx->ev[5 + 3 * j]; k.a2[j] = ctx->ev[6 + 3 * j]; }     // ev[4..15]
         for (int j = 0; j < 2; ++j) { k.b0[j] = ctx->ev[18 + 3 * j]; k.b1[j] = ctx->ev[19 + 3 * j]; k.b2[j] = ctx->ev[20 + 3 * j]; } // ev[18..23]
@@ -1086,14 +1096,14 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
         k.base = 0; k.n = 0;
     }
     ExtShared X;
-    X.d_cands = d_cands; X.d_m4 = d_m4; X.d_ok = d_ok; X.d_err = d_err; X.stats = (unsigned long long*)(d_outcnt + 16);
+    X.d_cands = d_cands; X.d_m4 = d_m4; X.d_ok = d_ok; X.d_err = d_err; X.stats = (unsigned long long*)(d_outcnt + 18);
     X.error = opt->error; X.tail_match_len = tail_match_len; X.min_align = opt->align_size_cutoff;
     X.read_start_id = read_start_id; X.ref_start_id = ref_start_id; X.reads_off = reads->seq_off; X.ref_off = ref->seq_off;
     std::vector<u64> goff;
     for (uint64_t next_base = 0; next_base < n;) {
         k.base = next_base; k.n = (u32)std::min<uint64_t>(cap, n - next_base); next_base += k.n;
-        NECAT_HIP(ctx, hipMemsetAsync(k.count, 0, 32, k.sa));
-        ExtLists L0; L0.count = k.count; L0.itemsA = k.itemsA[0]; L0.itemsB = k.itemsB[0];
+        NECAT_HIP(ctx, hipMemsetAsync(k.count, 0, 64, k.sa));
+        ExtLists L0; L0.count = k.count; L0.itemsA = k.itemsA[0]; L0.itemsB = k.itemsB[0]; L0.capA = cap;
         const u64* d_ops_base = nullptr;
         if (ao) {
             // column region of a task: left stream (<= qoff + soff columns) then right stream
@@ -1657,19 +1667,24 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
             BlockResult* d_res = (BlockResult*)ctx->scratch[SC_EXT_RES].p;
             i32* d_nops = (i32*)(d_res + (size_t)g * 64);
             NECAT_HIP(ctx, hipMemcpyAsync(d_items, items.data() + base, (size_t)m * sizeof(BlockItem), hipMemcpyHostToDevice, s));
-            if (full) hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)g * 64 * (kWordsA + kTWordsA), 256)), dim3(256), 0, s, dv, dv, (const BlockItem*)d_items, m, (const u32*)nullptr, d_frag, RoundCtl());
-            else hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)g * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, s, dv, dv, (const BlockItem*)d_items, m, (const u32*)nullptr, d_frag, RoundCtl());
+            if (full) hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)g * 64 * (kWordsA + kTWordsA), 256)), dim3(256), 0, s, dv, dv, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, d_frag, RoundCtl());
+            else hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)g * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, s, dv, dv, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, d_frag, RoundCtl());
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[4], s));
             const bool coop = m <= g_coop_threshold;
             const u32 epoch = ++ctx->epoch & 0x3fffffu;
-            if (full && coop) hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | (g_coop_filter ? 0u : 1u << 30) | (g_fast == 0 ? 1u << 29 : 0u) | (g_fast == 2 ? 1u << 28 : 0u), 0u);
-            else if (full) hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | ((u32)g_dbg << 28), 0u);
-            else if (coop) hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((m + 3) / 4), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | (g_coop_filter ? 0u : 1u << 30) | (g_fast == 0 ? 1u << 29 : 0u) | (g_fast == 2 ? 1u << 28 : 0u), 0u);
-            else hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch, 0u);
+            if (full && coop) {
+                const bool f16 = g_fast16 && g_fast >= 1 && g_coop_filter;
+                const u32 fl = epoch | (g_coop_filter ? 0u : 1u << 30) | (g_fast == 0 ? 1u << 29 : 0u) | (g_fast == 2 ? 1u << 28 : 0u);
+                if (f16) hipLaunchKernelGGL((k_myers_a16<kWordsA, kTWordsA, kColsA>), dim3((m + 15) / 16), dim3(128), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, fl | 1u << 27);
+                else hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, fl, 0u);
+            }
+            else if (full) hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, true>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | ((u32)g_dbg << 28), 0u);
+            else if (coop) hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((m + 3) / 4), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch | (g_coop_filter ? 0u : 1u << 30) | (g_fast == 0 ? 1u << 29 : 0u) | (g_fast == 2 ? 1u << 28 : 0u), 0u);
+            else hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag, d_slabs, slab, error, d_res, d_stats, epoch, 0u);
             NECAT_CHECK_LAUNCH(ctx, "k_myers");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[5], s));
-#define NECAT_TB_LAUNCH(NWX, TWX, COLSX, OPSX, WALK) hipLaunchKernelGGL((k_traceback<NWX, TWX, COLSX, OPSX, true, WALK>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, \
+#define NECAT_TB_LAUNCH(NWX, TWX, COLSX, OPSX, WALK) hipLaunchKernelGGL((k_traceback<NWX, TWX, COLSX, OPSX, true, WALK>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, \
                                          (const u64*)d_frag, (const char*)d_slabs, slab, (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), epoch)
             if (full) { if (g_walk == 1) NECAT_TB_LAUNCH(kWordsA, kTWordsA, kColsA, kOpsA, 1); else if (g_walk == 2) NECAT_TB_LAUNCH(kWordsA, kTWordsA, kColsA, kOpsA, 2); else NECAT_TB_LAUNCH(kWordsA, kTWordsA, kColsA, kOpsA, 0); }
             else { if (g_walk == 1) NECAT_TB_LAUNCH(kWordsB, kTWordsB, kColsB, kOpsB, 1); else if (g_walk == 2) NECAT_TB_LAUNCH(kWordsB, kTWordsB, kColsB, kOpsB, 2); else NECAT_TB_LAUNCH(kWordsB, kTWordsB, kColsB, kOpsB, 0); }
