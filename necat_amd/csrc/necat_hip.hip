@@ -561,6 +561,7 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
     P.align_cutoff = opt->align_size_cutoff; P.num_candidates = opt->num_candidates; P.job = opt->job; P.pairwise = pairwise;
     P.read_start_id = read_start_id; P.ref_start_id = ref_start_id;
     P.debug_phase = getenv("NECAT_SEED_DEBUG") ? atoi(getenv("NECAT_SEED_DEBUG")) : 0;
+    P.chain_wave = getenv("NECAT_CHAIN_WAVE") ? atoi(getenv("NECAT_CHAIN_WAVE")) : 1;
     NECAT_HIP(ctx, hipMemsetAsync(d_err, 0, 4, s));
     u32 pos = 0;
     std::vector<i32> ncands_by_order(nsel, 0);

@@ -33,6 +33,7 @@ struct SeedParams {
     int k, z, block_size, s_cutoff, align_cutoff, num_candidates, job, pairwise;
     int read_start_id, ref_start_id;
     int debug_phase;      // 0 = normal; 1 = stop after seed collection (profiling only)
+    int chain_wave;       // chain DP of an evaluation on all lanes of its wave (default) or on lane 0 (NECAT_CHAIN_WAVE=0)
 };
 
 struct SeedScratch {      // all per-lane, sized from the lane's hit bound H (see seed.hip)
@@ -203,60 +204,88 @@ NECAT_HD int scoring_seeds(const int* t_loc, const int* t_seedn, int* t_score, i
     return scoring_pick(t_loc, t_seedn, t_score, loc, k, rep_loc, scan_window, read_size);
 }
 
-// chain_dp.c:37-159.  Seeds are S.cs[0..n) sorted ascending by (soff, qoff); chains land in S.lcan.
-NECAT_HD int chain_dp(SeedScratch& S, int n_seeds, int kmer_size, int min_cnt, DevCand proto)
+// chain_dp.c:37-159 in three steps (the wave kernel runs the first two on all lanes, seed_kernels.h).  Seeds are S.cs[0..n)
+// sorted ascending by (soff, qoff); chains land in S.lcan.
+constexpr int kChainMaxDist = 5000, kChainBw = 500, kChainMaxSkip = 25, kChainMinSc = 30;   // chain_dp.c:174-178
+
+// score of seed j as predecessor of seed i (chain_dp.c:60-71), false = not a predecessor
+NECAT_HD bool chain_pair_score(u64 ci, u64 cj, int kmer_size, int fj, int* sc_out)
 {
-    const int max_dist = 5000, bw = 500, max_skip = 25, min_sc = 30;   // chain_dp.c:174-178
+    const i64 ri = (i64)(ci >> 32), qi = (i64)(ci & 0xffffffffu);
+    const i64 rj = (i64)(cj >> 32), qj = (i64)(cj & 0xffffffffu);
+    if (ri <= rj || qi <= qj || qi - qj > kChainMaxDist) return false;
+    const i64 dr = ri - rj, dq = qi - qj;
+    const i64 dd = dr > dq ? dr - dq : dq - dr;
+    if (dd > kChainBw) return false;
+    const i64 min_d = dq < dr ? dq : dr;
+    int sc = (int)(min_d < kmer_size ? min_d : kmer_size);
+    const int log_dd = dd ? ilog2_u32((u32)dd) : 0;
+    sc -= (int)((double)dd * 0.01 * (double)kmer_size) + (log_dd >> 1);
+    *sc_out = sc + fj;
+    return true;
+}
+
+// step 1: f / p / v of every seed (chain_dp.c:46-85)
+NECAT_HD void chain_fill(SeedScratch& S, int n_seeds, int kmer_size)
+{
     const u64* cs = S.cs;
     i32 *f = S.f, *p = S.p, *t = S.t, *v = S.v;
     for (int i = 0; i < n_seeds; ++i) { f[i] = 0; p[i] = -1; t[i] = 0; v[i] = 0; }
-    int i, j, k, st = 0;
-    for (i = 0; i < n_seeds; ++i) {
-        const i64 ri = (i64)(cs[i] >> 32), qi = (i64)(cs[i] & 0xffffffffu);
+    int st = 0;
+    for (int i = 0; i < n_seeds; ++i) {
+        const i64 ri = (i64)(cs[i] >> 32);
         int max_j = -1, max_f = kmer_size, n_skip = 0;
-        while (st < i && ri - (i64)(cs[st] >> 32) > max_dist) ++st;
-        for (j = i - 1; j >= st; --j) {
-            const i64 rj = (i64)(cs[j] >> 32), qj = (i64)(cs[j] & 0xffffffffu);
-            if (ri <= rj || qi <= qj || qi - qj > max_dist) continue;
-            i64 dr = ri - rj, dq = qi - qj;
-            i64 dd = dr > dq ? dr - dq : dq - dr;
-            if (dd > bw) continue;
-            i64 min_d = dq < dr ? dq : dr;
-            int sc = (int)(min_d < kmer_size ? min_d : kmer_size);
-            int log_dd = dd ? ilog2_u32((u32)dd) : 0;
-            sc -= (int)((double)dd * 0.01 * (double)kmer_size) + (log_dd >> 1);
-            sc += f[j];
+        while (st < i && ri - (i64)(cs[st] >> 32) > kChainMaxDist) ++st;
+        for (int j = i - 1; j >= st; --j) {
+            int sc;
+            if (!chain_pair_score(cs[i], cs[j], kmer_size, f[j], &sc)) continue;
             if (sc > max_f) {
                 max_f = sc; max_j = j;
                 if (n_skip > 0) --n_skip;
             } else if (t[j] == i) {
-                if (++n_skip > max_skip) break;
+                if (++n_skip > kChainMaxSkip) break;
             }
             if (p[j] >= 0) t[p[j]] = i;
         }
         f[i] = max_f; p[i] = max_j;
         v[i] = (max_j >= 0 && v[max_j] > max_f) ? v[max_j] : max_f;
     }
-    for (i = 0; i < n_seeds; ++i) t[i] = 0;
-    for (i = 0; i < n_seeds; ++i) if (p[i] >= 0) t[p[i]] = 1;
+}
+
+// the peak of the chain that ends at seed i, as the sort key of IntPair_ChainDpGT (chain_dp.c:8: first desc, second asc
+// -> ascending u64 key); chain_dp.c:93-100
+NECAT_HD u64 chain_end_key(const i32* f, const i32* p, const i32* v, int i)
+{
+    int j = i;
+    while (j >= 0 && f[j] < v[j]) j = p[j];
+    if (j < 0) j = i;
+    return ((u64)(u32)(0x7fffffff - f[j]) << 32) | (u32)j;
+}
+
+// step 2: the chain ends, best first (chain_dp.c:87-104).  Returns their number.
+NECAT_HD int chain_ends(SeedScratch& S, int n_seeds)
+{
+    i32 *f = S.f, *p = S.p, *t = S.t, *v = S.v;
+    for (int i = 0; i < n_seeds; ++i) t[i] = 0;
+    for (int i = 0; i < n_seeds; ++i) if (p[i] >= 0) t[p[i]] = 1;
     int n_u = 0;
-    for (i = 0; i < n_seeds; ++i) {
-        if (t[i] == 0 && v[i] >= min_sc) {
-            j = i;
-            while (j >= 0 && f[j] < v[j]) j = p[j];
-            if (j < 0) j = i;
-            // IntPair_ChainDpGT (chain_dp.c:8): first desc, second asc  -> ascending u64 key
-            S.u[n_u++] = ((u64)(u32)(0x7fffffff - f[j]) << 32) | (u32)j;
-        }
-    }
-    if (n_u == 0) return 0;
-    heap_sort_u64(S.u, n_u);
-    for (i = 0; i < n_seeds; ++i) t[i] = 0;
-    int n_v = 0, ncan = 0;
-    for (i = n_v = k = 0; i < n_u; ++i) {
-        int n_v0 = n_v, k0 = k;
+    for (int i = 0; i < n_seeds; ++i)
+        if (t[i] == 0 && v[i] >= kChainMinSc) S.u[n_u++] = chain_end_key(f, p, v, i);
+    if (n_u) heap_sort_u64(S.u, n_u);
+    return n_u;
+}
+
+// step 3: walk the chains back, best first, every seed used once (chain_dp.c:106-159)
+NECAT_HD int chain_emit(SeedScratch& S, int n_seeds, int n_u, int kmer_size, int min_cnt, DevCand proto)
+{
+    const u64* cs = S.cs;
+    i32 *f = S.f, *p = S.p, *t = S.t;
+    for (int i = 0; i < n_seeds; ++i) t[i] = 0;
+    int n_v = 0, ncan = 0, k = 0;
+    for (int i = 0; i < n_u; ++i) {
+        const int n_v0 = n_v, k0 = k;
         const int first = 0x7fffffff - (int)(u32)(S.u[i] >> 32);
-        j = (int)(u32)(S.u[i] & 0xffffffffu);
+        int j = (int)(u32)(S.u[i] & 0xffffffffu);
         DevCand can = proto;
         can.qend = (i32)(cs[j] & 0xffffffffu) + kmer_size;
         can.send = (i32)(cs[j] >> 32) + kmer_size;
@@ -266,7 +295,7 @@ NECAT_HD int chain_dp(SeedScratch& S, int n_seeds, int kmer_size, int min_cnt, D
         bool emit = false;
         if (j < 0) {
             if (n_v - n_v0 >= min_cnt) { can.score = first; emit = true; }
-        } else if (first - f[j] >= min_sc) {
+        } else if (first - f[j] >= kChainMinSc) {
             if (n_v - n_v0 >= min_cnt) { can.score = first - f[j]; emit = true; }
         }
         if (emit) {
@@ -277,6 +306,14 @@ NECAT_HD int chain_dp(SeedScratch& S, int n_seeds, int kmer_size, int min_cnt, D
     }
     if (ncan > 1) sort_cands<false>(S.lcan, ncan);
     return ncan;
+}
+
+NECAT_HD int chain_dp(SeedScratch& S, int n_seeds, int kmer_size, int min_cnt, DevCand proto)
+{
+    chain_fill(S, n_seeds, kmer_size);
+    const int n_u = chain_ends(S, n_seeds);
+    if (n_u == 0) return 0;
+    return chain_emit(S, n_seeds, n_u, kmer_size, min_cnt, proto);
 }
 
 // word_finder.c:171-182 (only touched blocks exist in the sparse table; zeroing an untouched block
@@ -365,14 +402,15 @@ NECAT_HD bool gather_zeroes_block(int relevant, int score) { return 1.0 * releva
 
 // stage E: sort the chain seeds, chain them, choose and emit the candidate (word_finder.c:309-358)
 NECAT_HD int finish_candidate(SeedScratch& S, int ncs, int seed_score, const AnchorGeom& g, const SeedParams& P,
-                              int qid, int qdir, int qsize, int* n_out, bool sorted = false)
+                              int qid, int qdir, int qsize, int* n_out, bool sorted = false, int chained = -1)
 {
     if (!sorted) heap_sort_u64(S.cs, ncs);   // ChainSeedLT: (soff, qoff) ascending
     DevCand proto;
     proto.qid = qid; proto.sid = (i32)g.seed_tid; proto.qdir = qdir; proto.score = 0;
     proto.qbeg = proto.qend = 0; proto.qsize = qsize; proto.sbeg = proto.send = 0; proto.ssize = (i32)g.seed_tsize;
     proto.qoff = proto.soff = 0;
-    const int ncan = chain_dp(S, ncs, P.k, P.s_cutoff, proto);
+    // chained = number of chain ends already found by the caller (the wave kernel runs chain_fill / chain_ends on all lanes), < 0: do it here
+    const int ncan = chained < 0 ? chain_dp(S, ncs, P.k, P.s_cutoff, proto) : (chained ? chain_emit(S, ncs, chained, P.k, P.s_cutoff, proto) : 0);
     if (!ncan) return 0;
     const i64 seed_qoff = g.seed_qoff, stoff = g.stoff;
     auto contains = [&](const DevCand& c) {

@@ -234,6 +234,129 @@ k_seed_collect_wave(DevVolume ref, DevVolume reads, const u64* __restrict__ kmer
 }
 
 constexpr int kLdsChain = 256;
+
+// ---- chain DP on all 64 lanes (chain_fill / chain_ends of seed_core.h are the sequential statement of the same thing)
+// inclusive prefix max / min over the lanes of a wave, DPP: Kogge-Stone inside the rows of 16, then lane 15 -> next row, lane 31 -> rows 2, 3
+#define NECAT_DPP_SCAN(NAME, OP)                                                                                  \
+NECAT_D int NAME(int x)                                                                                           \
+{                                                                                                                 \
+    x = OP(x, __builtin_amdgcn_update_dpp(x, x, 0x111, 0xf, 0xf, false));   /* row_shr:1 (lanes without a source keep x) */ \
+    x = OP(x, __builtin_amdgcn_update_dpp(x, x, 0x112, 0xf, 0xf, false));                                         \
+    x = OP(x, __builtin_amdgcn_update_dpp(x, x, 0x114, 0xf, 0xf, false));                                         \
+    x = OP(x, __builtin_amdgcn_update_dpp(x, x, 0x118, 0xf, 0xf, false));                                         \
+    x = OP(x, __builtin_amdgcn_update_dpp(x, x, 0x142, 0xa, 0xf, false));   /* row_bcast:15 into rows 1, 3 */      \
+    x = OP(x, __builtin_amdgcn_update_dpp(x, x, 0x143, 0xc, 0xf, false));   /* row_bcast:31 into rows 2, 3 */      \
+    return x;                                                                                                     \
+}
+NECAT_D int imax2(int a, int b) { return a > b ? a : b; }
+NECAT_D int imin2(int a, int b) { return a < b ? a : b; }
+NECAT_DPP_SCAN(wave_prefix_max, imax2)
+NECAT_DPP_SCAN(wave_prefix_min, imin2)
+#undef NECAT_DPP_SCAN
+
+// chain_fill for a workgroup of ONE wave.  The predecessor scan j = i - 1 ... st of seed i runs 64 candidates at a time, lane l
+// = the l-th j of the chunk, so lane order is the order of the sequential loop and its running state becomes prefix operations:
+//   * "sc > max_f" (a new best, strictly): sc above the prefix maximum of the lanes before (and of the chunks before);
+//     the last such lane holds the final best.
+//   * "t[j] == i" (j is the predecessor of a j' seen earlier in this scan): every lane stores its mark first; a mark can only
+//     come from a HIGHER j, i.e. an earlier lane or chunk, so reading after a barrier sees exactly the sequential loop's marks.
+//   * n_skip is a walk floored at zero: + 1 for a marked lane that is no new best, - 1 (if > 0) for a new best.  With S_l the
+//     plain prefix sum of the steps, n_skip after lane l = S_l - min(-n_skip_before, min_{m <= l} S_m); the scan stops at the
+//     first lane where it exceeds max_skip (always a + 1 lane).  Lanes behind the stop still stored their marks: t[] == i is
+//     never tested again once the scan of i is over.
+NECAT_D void chain_fill_wave(const u64* cs, i32* f, i32* p, i32* t, i32* v, int n, int kmer_size, int lane)
+{
+    const u64 below = (1ULL << lane) - 1ULL;
+    for (int a = lane; a < n; a += 64) { f[a] = 0; p[a] = -1; t[a] = 0; v[a] = 0; }
+    __syncthreads();
+    int st = 0;
+    for (int i = 0; i < n; ++i) {
+        const u64 ci = cs[i];
+        const i64 ri = (i64)(ci >> 32);
+        while (st < i && ri - (i64)(cs[st] >> 32) > kChainMaxDist) ++st;
+        int max_f = kmer_size, max_j = -1, n_skip = 0;
+        for (int top = i - 1; top >= st; top -= 64) {
+            const int j = top - lane;
+            int sc = INT32_MIN;
+            bool valid = false;
+            if (j >= st) {
+                valid = chain_pair_score(ci, cs[j], kmer_size, f[j], &sc);
+                if (valid) { const int pj = p[j]; if (pj >= 0) t[pj] = i; }
+                else sc = INT32_MIN;
+            }
+            __syncthreads();
+            const bool marked = valid && t[j] == i;
+            const int incl = wave_prefix_max(sc);
+            int before = __shfl_up(incl, 1);
+            if (lane == 0 || before < max_f) before = max_f;
+            const bool newmax = valid && sc > before;
+            const u64 NM = __ballot(newmax), SK = __ballot(marked && !newmax);
+            u64 live = ~0ULL;                  // lanes the sequential loop reaches
+            if (SK) {
+                const u64 upto = below | (1ULL << lane);
+                const int S = popc64(SK & upto) - popc64(NM & upto);
+                int floor_ = wave_prefix_min(S);
+                if (floor_ > -n_skip) floor_ = -n_skip;
+                const int W = S - floor_;
+                const u64 stop = __ballot(W > kChainMaxSkip);
+                if (stop) live = (1ULL << ctz64(stop)) - 1ULL;       // the stopping lane is no new best: lanes below it count
+                else n_skip = __shfl(W, 63);
+            } else {
+                n_skip -= popc64(NM); if (n_skip < 0) n_skip = 0;
+            }
+            const u64 best = NM & live;
+            if (best) { const int lb = 63 - __clzll((long long)best); max_f = __shfl(sc, lb); max_j = top - lb; }
+            if (live != ~0ULL) break;
+        }
+        if (lane == 0) {
+            f[i] = max_f; p[i] = max_j;
+            v[i] = (max_j >= 0 && v[max_j] > max_f) ? v[max_j] : max_f;
+        }
+        __syncthreads();
+    }
+}
+
+// chain_ends for one wave; u[] receives the keys sorted ascending.  Needs n <= 64 * kEndsPerLane keys at most (the callers'
+// LDS case); returns the number of chain ends.
+NECAT_D int chain_ends_wave(const i32* f, const i32* p, i32* t, const i32* v, u64* u, int n, int lane)
+{
+    const u64 below = (1ULL << lane) - 1ULL;
+    for (int a = lane; a < n; a += 64) t[a] = 0;
+    __syncthreads();
+    for (int a = lane; a < n; a += 64) if (p[a] >= 0) t[p[a]] = 1;
+    __syncthreads();
+    int n_u = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int a = base + lane;
+        const bool ok = a < n && t[a] == 0 && v[a] >= kChainMinSc;
+        const u64 m = __ballot(ok);
+        if (ok) u[n_u + popc64(m & below)] = chain_end_key(f, p, v, a);       // equal keys are equal chains: their order is free
+        n_u += popc64(m);
+    }
+    __syncthreads();
+    if (n_u > 1) {
+        // rank sort in place: every lane keeps its keys (<= kLdsChain / 64 of them) in registers
+        constexpr int kPer = kLdsChain / 64;
+        u64 key[kPer]; int rk[kPer];
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const int a = lane + 64 * q;
+            rk[q] = -1; key[q] = 0;
+            if (a < n_u) {
+                const u64 ka = u[a];
+                int r = 0;
+                for (int b = 0; b < n_u; ++b) { const u64 kb = u[b]; r += (kb < ka) || (kb == ka && b < a); }
+                rk[q] = r; key[q] = ka;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) if (rk[q] >= 0) u[rk[q]] = key[q];
+        __syncthreads();
+    }
+    return n_u;
+}
+
 #ifdef NECAT_SEED_PROF
 __device__ unsigned long long g_seed_prof[16];
 #define SPROF(k) do { if (lane == 0) { const u64 now_ = clock64(); pacc[k] += now_ - tprev; tprev = now_; } } while (0)
@@ -368,13 +491,20 @@ k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict_
             }
             __syncthreads();
             SPROF(5);
+            // chain DP and chain ends on all lanes when the seeds are in LDS (NECAT_CHAIN_WAVE=0: lane 0 does it all)
+            int chained = -1;
+            if (in_lds && P.chain_wave) {
+                chain_fill_wave(l_cs, l_f, l_p, l_t, l_v, ncs, P.k, lane);
+                chained = chain_ends_wave(l_f, l_p, l_t, l_v, l_u, ncs, lane);
+            }
+            SPROF(7);
             if (lane == 0) {
                 int rc;
                 if (overflow) rc = kSeedErrCapacity;
                 else if (in_lds) {
                     SeedScratch SL = S;
                     SL.cs = l_cs; SL.u = l_u; SL.f = l_f; SL.p = l_p; SL.t = l_t; SL.v = l_v;
-                    rc = finish_candidate(SL, ncs, seed_score, g, P, r, strand, L, &n_out, true);
+                    rc = finish_candidate(SL, ncs, seed_score, g, P, r, strand, L, &n_out, true, chained);
                 } else rc = finish_candidate(S, ncs, seed_score, g, P, r, strand, L, &n_out);
                 s_ctl[2] = rc < 0 ? 1 : 0;
             }

@@ -34,6 +34,17 @@ def test_cores_match_oracle(check_core, tmp_path, ds, vid, args):
     assert "candidates=0 " not in r.stdout
 
 
+def test_wave_chain_dp_model_equals_sequential(tmp_path):
+    """chain_fill_wave (seed_kernels.h) turns the order-dependent predecessor scan of chain_dp.c:46-85 into prefix operations over
+    64 lanes; its lane-by-lane host transcription must give the f / p / v of the sequential loop, max_skip stops included."""
+    exe = os.path.join(str(tmp_path), "check_chain")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I", os.path.join(util.ROOT, "include"), "-o", exe,
+                    os.path.join(util.ROOT, "tests", "host_core", "check_chain.cpp")], check=True)
+    r = subprocess.run([exe, "300"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert " mismatches 0 " in r.stdout
+
+
 # ---- the host side of necat_cns_extension_batch (necat_amd/csrc/cns_loop.h): select / replay vs the sequential loop ----
 
 @pytest.fixture(scope="module")
