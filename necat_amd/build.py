@@ -32,7 +32,9 @@ def _hip_deps():
         sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
 
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+# -disable-promote-alloca-to-lds: the compiler otherwise parks k_seed_eval's small per-lane arrays in LDS (3.8 KB per wave), and that
+# kernel's occupancy is bounded by its LDS (no other kernel changes)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-mllvm", "-disable-promote-alloca-to-lds"]
 
 
 def _hipcc() -> str:

@@ -93,7 +93,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    p = path or _build.LIB
+    p = path or os.environ.get("NECAT_HIP_LIB") or _build.LIB       # NECAT_HIP_LIB: an instrumented build of the same sources (tools/seed_prof.sh)
     if not os.path.exists(p):
         raise RuntimeError("libnecat_hip.so is not built (%s): run `python -m necat_amd.build`" % p)
     lib = C.CDLL(p)

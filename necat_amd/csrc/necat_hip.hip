@@ -140,6 +140,7 @@ void necat_ctx_destroy(necat_ctx* ctx)
     for (auto& b : ctx->scratch) if (b.p) (void)hipFree(b.p);
     for (auto& b : ctx->idx_cache) if (b.p) (void)hipFree(b.p);
     delete (cns::Scratch*)ctx->cns_scratch;
+    if (ctx->pin_plan) (void)hipHostFree(ctx->pin_plan);
     for (int i = 0; i < kNumEvents; ++i) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->round_ring) (void)hipHostFree(ctx->round_ring);
     (void)hipStreamDestroy(ctx->stream); (void)hipStreamDestroy(ctx->stream_a); (void)hipStreamDestroy(ctx->stream_b); (void)hipStreamDestroy(ctx->stream_c);
@@ -531,23 +532,41 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
     hipLaunchKernelGGL(k_seed_hits, dim3(grid_for((u64)nreads * 64, 256)), dim3(256), 0, s, drd, (const u64*)ix->kmer_stats,
                        opt->kmer_size, opt->scan_window, 0u, nreads, d_hits);
     NECAT_CHECK_LAUNCH(ctx, "k_seed_hits");
-    std::vector<u32> hits((size_t)nreads * 2);
-    NECAT_HIP(ctx, hipMemcpyAsync(hits.data(), d_hits, (size_t)nreads * 8, hipMemcpyDeviceToHost, s));
+    // pinned host scratch: [hits: 2 u32 per read][order: u32 per read][SeedMeta per read] - pageable copies cost more than the plan
+    {
+        const size_t need = (size_t)nreads * (8 + 4 + sizeof(SeedMeta)) + 256;
+        if (need > ctx->pin_plan_cap) {
+            if (ctx->pin_plan) (void)hipHostFree(ctx->pin_plan);
+            ctx->pin_plan = nullptr; ctx->pin_plan_cap = 0;
+            if (hipHostMalloc(&ctx->pin_plan, need + need / 4, hipHostMallocDefault) != hipSuccess) return set_err(ctx, NECAT_ERR_MEMORY, "pinned host scratch (%zu bytes)", need);
+            ctx->pin_plan_cap = need + need / 4;
+        }
+    }
+    u32* hits = (u32*)ctx->pin_plan;
+    u32* order = hits + (size_t)nreads * 2;
+    SeedMeta* meta_all = (SeedMeta*)(((uintptr_t)(order + nreads) + 63) & ~(uintptr_t)63);
+    NECAT_HIP(ctx, hipMemcpyAsync(hits, d_hits, (size_t)nreads * 8, hipMemcpyDeviceToHost, s));
     NECAT_HIP(ctx, hipStreamSynchronize(s));
     tick("hits kernel + copy");
     // ---- plan: reads in descending work order, chunks bounded by a scratch budget
-    std::vector<u32> order;
+    u32 nsel = 0;
     {
-        // descending work, ascending read id inside equal work: one sort of packed keys (only this rank's reads)
-        std::vector<u64> keys;
-        keys.reserve(nreads);
+        // descending work, ascending read id inside equal work (only this rank's reads): a stable LSD radix sort of the
+        // complemented hit counts, 3 x 11 bits (std::sort of the same keys took ~1 ms for 23 k reads)
+        std::vector<u32> key(nreads), ida(nreads), idb(nreads);
         for (u32 r = 0; r < nreads; ++r)
-            if (!sel || sel->has(r)) keys.push_back(((u64)(0xffffffffu - std::max(hits[2 * (size_t)r], hits[2 * (size_t)r + 1])) << 32) | r);
-        std::sort(keys.begin(), keys.end());
-        order.resize(keys.size());
-        for (size_t i = 0; i < keys.size(); ++i) order[i] = (u32)keys[i];
+            if (!sel || sel->has(r)) { key[r] = 0xffffffffu - std::max(hits[2 * (size_t)r], hits[2 * (size_t)r + 1]); ida[nsel++] = r; }
+        u32* src = ida.data(); u32* dst = idb.data();
+        for (int pass = 0; pass < 3; ++pass) {
+            const int sh = 11 * pass;
+            u32 cnt[2049] = {0};
+            for (u32 i = 0; i < nsel; ++i) ++cnt[((key[src[i]] >> sh) & 2047u) + 1];
+            for (int b = 0; b < 2048; ++b) cnt[b + 1] += cnt[b];
+            for (u32 i = 0; i < nsel; ++i) dst[cnt[(key[src[i]] >> sh) & 2047u]++] = src[i];
+            std::swap(src, dst);
+        }
+        for (u32 i = 0; i < nsel; ++i) order[i] = src[i];
     }
-    const u32 nsel = (u32)order.size();
     ctx->shard_tm.reads_local = nsel;
     if (nsel == 0) {
         if (dev) { dev->n = 0; dev->d = nullptr; dev->group_off.assign(2, 0); }
@@ -573,7 +592,7 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
         auto both = [&](u32 r) { return (u64)hits[2 * (size_t)r] + hits[2 * (size_t)r + 1] + 2; };
         while (hi < nsel && (hi == pos || acc + both(order[hi]) <= budget_hits)) { acc += both(order[hi]); ++hi; }
         const u32 n = hi - pos;
-        std::vector<SeedMeta> meta(n);
+        SeedMeta* meta = meta_all + pos;
         u64 ht_tot = 0, pool_tot = 0, chain_tot = 0, out_tot = 0;
         for (u32 i = 0; i < n; ++i) {
             const u32 r = order[pos + i];
@@ -612,8 +631,8 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
         A.lcan = (DevCand*)cb; cb += chain_tot * sizeof(DevCand);
         A.f = (i32*)cb; cb += chain_tot * 4; A.p = (i32*)cb; cb += chain_tot * 4; A.t = (i32*)cb; cb += chain_tot * 4; A.v = (i32*)cb;
         A.out = (DevCand*)ctx->scratch[SC_SEED_OUT].p;
-        NECAT_HIP(ctx, hipMemcpyAsync(d_meta, meta.data(), n * sizeof(SeedMeta), hipMemcpyHostToDevice, s));
-        NECAT_HIP(ctx, hipMemcpyAsync(d_order, order.data() + pos, (size_t)n * 4, hipMemcpyHostToDevice, s));
+        NECAT_HIP(ctx, hipMemcpyAsync(d_meta, meta, n * sizeof(SeedMeta), hipMemcpyHostToDevice, s));
+        NECAT_HIP(ctx, hipMemcpyAsync(d_order, order + pos, (size_t)n * 4, hipMemcpyHostToDevice, s));
         NECAT_HIP(ctx, hipMemsetAsync(A.ht_key, 0xFF, ht_tot * 4, s));
         if (g_seed_wave)
             hipLaunchKernelGGL(k_seed_collect_wave, dim3(2 * n), dim3(64), 0, s, dref, drd, (const u64*)ix->kmer_stats, (const u64*)ix->offset_list,
@@ -633,6 +652,19 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
         NECAT_HIP(ctx, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, s));
         NECAT_HIP(ctx, hipStreamSynchronize(s));
         if (herr) { return set_err(ctx, NECAT_ERR_CAPACITY, "seeding scratch overflow (code %d)", herr); }
+#ifdef NECAT_SEED_PROF
+        {   // tools/seed_prof.sh: cycles of lane 0 per phase of k_seed_eval, summed over the waves
+            unsigned long long h[32], z[32] = {0};
+            if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_seed_prof), sizeof h) == hipSuccess) {
+                static const char* nm[10] = {"block test", "A seed lists", "B vote", "C anchor", "D gather", "E sort", "emit (lane 0)", "chain DP (wave)", "evaluations", "exit"};
+                unsigned long long tot = 0; for (int q = 0; q < 10; ++q) if (q != 8) tot += h[q];
+                for (int q = 0; q < 10; ++q) fprintf(stderr, "[seed prof] %-16s %14llu %5.1f %%\n", nm[q], h[q], q == 8 ? 0.0 : 100.0 * h[q] / (double)tot);
+                fprintf(stderr, "[seed prof] longest wave %llu cycles, most evaluations in a wave %llu\n", h[10], h[11]);
+                if (h[26]) for (int q = 0; q < 10; ++q) fprintf(stderr, "[seed prof] waves over 3 M cycles (%llu): %-16s %12llu per wave\n", h[26], nm[q], h[16 + q] / h[26]);
+            }
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_seed_prof), z, sizeof z);
+        }
+#endif
         tick("collect + eval kernels");
         if (pos == 0 && hi == nsel) {
             // the usual case, one chunk: pack on the device straight into ascending read order and copy

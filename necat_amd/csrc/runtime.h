@@ -37,6 +37,7 @@ struct necat_ctx {
     necat_timings tm;
     necat_shard_timings shard_tm;      // last sharded calls (necat_index_build_sharded, necat_*_sharded)
     hipEvent_t ev[kNumEvents];
+    void* pin_plan = nullptr; size_t pin_plan_cap = 0;   // pinned host scratch of the seeding plan (hit counts down, order + scratch layout up)
     void* round_ring = nullptr;        // pinned, device-visible ring of RoundPub entries: list sizes published by the round kernels
     void* round_ring_dev = nullptr;    // the same memory as the device addresses it
     unsigned long long round_seq = 0;  // rounds published so far (the next round publishes round_seq + 1)

@@ -254,7 +254,8 @@ NECAT_HD void chain_fill(SeedScratch& S, int n_seeds, int kmer_size)
 
 // the peak of the chain that ends at seed i, as the sort key of IntPair_ChainDpGT (chain_dp.c:8: first desc, second asc
 // -> ascending u64 key); chain_dp.c:93-100
-NECAT_HD u64 chain_end_key(const i32* f, const i32* p, const i32* v, int i)
+template <class I>
+NECAT_HD u64 chain_end_key(const I* f, const I* p, const I* v, int i)
 {
     int j = i;
     while (j >= 0 && f[j] < v[j]) j = p[j];
@@ -275,17 +276,18 @@ NECAT_HD int chain_ends(SeedScratch& S, int n_seeds)
     return n_u;
 }
 
-// step 3: walk the chains back, best first, every seed used once (chain_dp.c:106-159)
-NECAT_HD int chain_emit(SeedScratch& S, int n_seeds, int n_u, int kmer_size, int min_cnt, DevCand proto)
+// step 3: walk the chains back, best first, every seed used once (chain_dp.c:106-159).  I = i32 (the global scratch) or
+// i16 (the wave kernel's LDS copy: <= 256 seeds, scores <= 256 * k)
+template <class I>
+NECAT_HD int chain_emit_t(const u64* cs, const I* f, const I* p, I* t, const u64* u, DevCand* lcan,
+                          int n_seeds, int n_u, int kmer_size, int min_cnt, DevCand proto)
 {
-    const u64* cs = S.cs;
-    i32 *f = S.f, *p = S.p, *t = S.t;
     for (int i = 0; i < n_seeds; ++i) t[i] = 0;
     int n_v = 0, ncan = 0, k = 0;
     for (int i = 0; i < n_u; ++i) {
         const int n_v0 = n_v, k0 = k;
-        const int first = 0x7fffffff - (int)(u32)(S.u[i] >> 32);
-        int j = (int)(u32)(S.u[i] & 0xffffffffu);
+        const int first = 0x7fffffff - (int)(u32)(u[i] >> 32);
+        int j = (int)(u32)(u[i] & 0xffffffffu);
         DevCand can = proto;
         can.qend = (i32)(cs[j] & 0xffffffffu) + kmer_size;
         can.send = (i32)(cs[j] >> 32) + kmer_size;
@@ -300,12 +302,17 @@ NECAT_HD int chain_emit(SeedScratch& S, int n_seeds, int n_u, int kmer_size, int
         }
         if (emit) {
             can.qbeg = (i32)(cs[last_j] & 0xffffffffu); can.sbeg = (i32)(cs[last_j] >> 32);
-            S.lcan[ncan++] = can; ++k;
+            lcan[ncan++] = can; ++k;
         }
         if (k0 == k) n_v = n_v0;
     }
-    if (ncan > 1) sort_cands<false>(S.lcan, ncan);
+    if (ncan > 1) sort_cands<false>(lcan, ncan);
     return ncan;
+}
+
+NECAT_HD int chain_emit(SeedScratch& S, int n_seeds, int n_u, int kmer_size, int min_cnt, DevCand proto)
+{
+    return chain_emit_t<i32>(S.cs, S.f, S.p, S.t, S.u, S.lcan, n_seeds, n_u, kmer_size, min_cnt, proto);
 }
 
 NECAT_HD int chain_dp(SeedScratch& S, int n_seeds, int kmer_size, int min_cnt, DevCand proto)
@@ -351,13 +358,14 @@ struct AnchorGeom {       // word_finder.c:230-246
     int seed_bid, bid_start, bid_end;
 };
 
-NECAT_HD AnchorGeom anchor_geometry(const DevVolume& ref, int loc0, int seedn0, u64 blk_start, int bs, int z, int qsize)
+NECAT_HD AnchorGeom anchor_geometry(const DevVolume& ref, int loc0, int seedn0, u64 blk_start, int bs, int z, int qsize, i64 tid = -1)
 {
+    // tid >= 0: the caller already knows the subject of the anchor (the wave kernel searches seq_off on all lanes)
     AnchorGeom g;
     u64 seed_toff = (u64)loc0 + blk_start;
     g.seed_qoff = (i64)(seedn0 - 1) * z;
     g.seed_bid = (int)(seed_toff / (u64)bs);
-    g.seed_tid = seq_of_offset(ref.seq_off, ref.nseq, seed_toff);
+    g.seed_tid = tid >= 0 ? (u64)tid : seq_of_offset(ref.seq_off, ref.nseq, seed_toff);
     g.seed_tstart = ref.seq_off[g.seed_tid];
     g.seed_tend = ref.seq_off[g.seed_tid + 1];
     g.seed_tsize = (i64)(g.seed_tend - g.seed_tstart);
@@ -401,45 +409,60 @@ NECAT_HD bool gather_test(const AnchorGeom& g, const SBlock* sb, int k, int bloc
 NECAT_HD bool gather_zeroes_block(int relevant, int score) { return 1.0 * relevant / score >= 0.4; }
 
 // stage E: sort the chain seeds, chain them, choose and emit the candidate (word_finder.c:309-358)
-NECAT_HD int finish_candidate(SeedScratch& S, int ncs, int seed_score, const AnchorGeom& g, const SeedParams& P,
-                              int qid, int qdir, int qsize, int* n_out, bool sorted = false, int chained = -1)
+NECAT_HD DevCand finish_proto(const AnchorGeom& g, int qid, int qdir, int qsize)
 {
-    if (!sorted) heap_sort_u64(S.cs, ncs);   // ChainSeedLT: (soff, qoff) ascending
     DevCand proto;
     proto.qid = qid; proto.sid = (i32)g.seed_tid; proto.qdir = qdir; proto.score = 0;
     proto.qbeg = proto.qend = 0; proto.qsize = qsize; proto.sbeg = proto.send = 0; proto.ssize = (i32)g.seed_tsize;
     proto.qoff = proto.soff = 0;
-    // chained = number of chain ends already found by the caller (the wave kernel runs chain_fill / chain_ends on all lanes), < 0: do it here
-    const int ncan = chained < 0 ? chain_dp(S, ncs, P.k, P.s_cutoff, proto) : (chained ? chain_emit(S, ncs, chained, P.k, P.s_cutoff, proto) : 0);
+    return proto;
+}
+
+// the choice among the chains lcan[0 .. ncan) (word_finder.c:318-358).  clear_range != nullptr: the caller zeroes the blocks
+// [clear_range[0], clear_range[1]] (word_finder.c:171-182) itself.
+NECAT_HD int finish_choose(SeedScratch& S, const DevCand* lcan, int ncan, int seed_score, const AnchorGeom& g, const SeedParams& P,
+                           int* n_out, i64* clear_range = nullptr)
+{
     if (!ncan) return 0;
     const i64 seed_qoff = g.seed_qoff, stoff = g.stoff;
     auto contains = [&](const DevCand& c) {
         return seed_qoff >= c.qbeg && seed_qoff < c.qend && stoff >= c.sbeg && stoff < c.send;
     };
-    DevCand can = S.lcan[0];
+    DevCand can = lcan[0];
     bool emit = contains(can);
     if (!emit) {
         int max_i = ncan, max_cov = 0;
         for (int i = 0; i < ncan; ++i) {
-            can = S.lcan[i];
+            can = lcan[i];
             if (contains(can)) { int cov = can.qend - can.qbeg; if (cov > max_cov) { max_cov = cov; max_i = i; } }
         }
         // word_finder.c:335-343 emits `can` as the loop left it (the LAST chain), not lcanv[max_i]
         if (max_i < ncan) emit = true;
         else {
-            can = S.lcan[0];
+            can = lcan[0];
             if (can.qend - can.qbeg >= 5000) emit = true;
         }
     }
     if (!emit) return 0;
     can.score = seed_score; can.qoff = (i32)seed_qoff; can.soff = (i32)stoff;
-    clear_block_scores(S, can, g.seed_tstart, P.block_size);
+    if (clear_range) {
+        clear_range[0] = (i64)(((u64)can.sbeg + g.seed_tstart) / (u64)P.block_size);
+        clear_range[1] = (i64)(((u64)can.send + g.seed_tstart) / (u64)P.block_size);
+    } else clear_block_scores(S, can, g.seed_tstart, P.block_size);
     const bool ok = (can.send - can.sbeg >= P.align_cutoff) || (can.qend - can.qbeg >= P.align_cutoff);
     if (ok) {
         if ((u32)*n_out >= S.out_cap) return kSeedErrCapacity;
         S.out[(*n_out)++] = can;
     }
     return ok ? 1 : 0;
+}
+
+NECAT_HD int finish_candidate(SeedScratch& S, int ncs, int seed_score, const AnchorGeom& g, const SeedParams& P,
+                              int qid, int qdir, int qsize, int* n_out, bool sorted = false, i64* clear_range = nullptr)
+{
+    if (!sorted) heap_sort_u64(S.cs, ncs);   // ChainSeedLT: (soff, qoff) ascending
+    const int ncan = chain_dp(S, ncs, P.k, P.s_cutoff, finish_proto(g, qid, qdir, qsize));
+    return finish_choose(S, S.lcan, ncan, seed_score, g, P, n_out, clear_range);
 }
 
 // word_finder.c:184-360, scalar composition of the stages.  Returns 1 if a candidate was appended,

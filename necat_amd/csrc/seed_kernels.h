@@ -234,6 +234,7 @@ k_seed_collect_wave(DevVolume ref, DevVolume reads, const u64* __restrict__ kmer
 }
 
 constexpr int kLdsChain = 256;
+constexpr int kLdsCan = 8;          // chains of one evaluation kept in LDS (more: the global scratch)
 
 // ---- chain DP on all 64 lanes (chain_fill / chain_ends of seed_core.h are the sequential statement of the same thing)
 // inclusive prefix max / min over the lanes of a wave, DPP: Kogge-Stone inside the rows of 16, then lane 15 -> next row, lane 31 -> rows 2, 3
@@ -252,6 +253,20 @@ NECAT_D int imax2(int a, int b) { return a > b ? a : b; }
 NECAT_D int imin2(int a, int b) { return a < b ? a : b; }
 NECAT_DPP_SCAN(wave_prefix_max, imax2)
 NECAT_DPP_SCAN(wave_prefix_min, imin2)
+// (the scans above rely on "lanes without a source keep x": right for max / min, for the sum those lanes must add nothing)
+NECAT_D int wave_prefix_sum(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+// value of lane `l` (the same l on every lane) / of the lane below (lane 0 gets `first`)
+NECAT_D int wave_read(int x, int l) { return __builtin_amdgcn_readlane(x, __builtin_amdgcn_readfirstlane(l)); }
+NECAT_D int wave_from_below(int x, int first) { return __builtin_amdgcn_update_dpp(first, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
 #undef NECAT_DPP_SCAN
 
 // chain_fill for a workgroup of ONE wave.  The predecessor scan j = i - 1 ... st of seed i runs 64 candidates at a time, lane l
@@ -264,10 +279,11 @@ NECAT_DPP_SCAN(wave_prefix_min, imin2)
 //     plain prefix sum of the steps, n_skip after lane l = S_l - min(-n_skip_before, min_{m <= l} S_m); the scan stops at the
 //     first lane where it exceeds max_skip (always a + 1 lane).  Lanes behind the stop still stored their marks: t[] == i is
 //     never tested again once the scan of i is over.
-NECAT_D void chain_fill_wave(const u64* cs, i32* f, i32* p, i32* t, i32* v, int n, int kmer_size, int lane)
+template <class I>
+NECAT_D void chain_fill_wave(const u64* cs, I* f, I* p, I* t, I* v, int n, int kmer_size, int lane)
 {
     const u64 below = (1ULL << lane) - 1ULL;
-    for (int a = lane; a < n; a += 64) { f[a] = 0; p[a] = -1; t[a] = 0; v[a] = 0; }
+    for (int a = lane; a < n; a += 64) { f[a] = 0; p[a] = (I)-1; t[a] = 0; v[a] = 0; }
     __syncthreads();
     int st = 0;
     for (int i = 0; i < n; ++i) {
@@ -281,14 +297,14 @@ NECAT_D void chain_fill_wave(const u64* cs, i32* f, i32* p, i32* t, i32* v, int 
             bool valid = false;
             if (j >= st) {
                 valid = chain_pair_score(ci, cs[j], kmer_size, f[j], &sc);
-                if (valid) { const int pj = p[j]; if (pj >= 0) t[pj] = i; }
+                if (valid) { const int pj = p[j]; if (pj >= 0) t[pj] = (I)i; }
                 else sc = INT32_MIN;
             }
             __syncthreads();
             const bool marked = valid && t[j] == i;
             const int incl = wave_prefix_max(sc);
-            int before = __shfl_up(incl, 1);
-            if (lane == 0 || before < max_f) before = max_f;
+            int before = wave_from_below(incl, max_f);
+            if (before < max_f) before = max_f;
             const bool newmax = valid && sc > before;
             const u64 NM = __ballot(newmax), SK = __ballot(marked && !newmax);
             u64 live = ~0ULL;                  // lanes the sequential loop reaches
@@ -300,43 +316,52 @@ NECAT_D void chain_fill_wave(const u64* cs, i32* f, i32* p, i32* t, i32* v, int 
                 const int W = S - floor_;
                 const u64 stop = __ballot(W > kChainMaxSkip);
                 if (stop) live = (1ULL << ctz64(stop)) - 1ULL;       // the stopping lane is no new best: lanes below it count
-                else n_skip = __shfl(W, 63);
+                else n_skip = wave_read(W, 63);
             } else {
                 n_skip -= popc64(NM); if (n_skip < 0) n_skip = 0;
             }
             const u64 best = NM & live;
-            if (best) { const int lb = 63 - __clzll((long long)best); max_f = __shfl(sc, lb); max_j = top - lb; }
+            if (best) { const int lb = 63 - __clzll((long long)best); max_f = wave_read(sc, lb); max_j = top - lb; }
             if (live != ~0ULL) break;
         }
         if (lane == 0) {
-            f[i] = max_f; p[i] = max_j;
-            v[i] = (max_j >= 0 && v[max_j] > max_f) ? v[max_j] : max_f;
+            f[i] = (I)max_f; p[i] = (I)max_j;
+            v[i] = (max_j >= 0 && v[max_j] > max_f) ? v[max_j] : (I)max_f;
         }
         __syncthreads();
     }
 }
 
-// chain_ends for one wave; u[] receives the keys sorted ascending.  Needs n <= 64 * kEndsPerLane keys at most (the callers'
-// LDS case); returns the number of chain ends.
-NECAT_D int chain_ends_wave(const i32* f, const i32* p, i32* t, const i32* v, u64* u, int n, int lane)
+// chain_ends for one wave (n <= kLdsChain seeds).  The keys land sorted ascending in u_lds when there are at most kLdsEnds of
+// them, else in u_glb; *u_out says where.  Returns the number of chain ends.
+constexpr int kLdsEnds = 64;
+template <class I>
+NECAT_D int chain_ends_wave(const I* f, const I* p, I* t, const I* v, u64* u_lds, u64* u_glb, int n, int lane, u64** u_out)
 {
+    constexpr int kPer = kLdsChain / 64;
     const u64 below = (1ULL << lane) - 1ULL;
     for (int a = lane; a < n; a += 64) t[a] = 0;
     __syncthreads();
     for (int a = lane; a < n; a += 64) if (p[a] >= 0) t[p[a]] = 1;
     __syncthreads();
-    int n_u = 0;
-    for (int base = 0; base < n; base += 64) {
-        const int a = base + lane;
-        const bool ok = a < n && t[a] == 0 && v[a] >= kChainMinSc;
-        const u64 m = __ballot(ok);
-        if (ok) u[n_u + popc64(m & below)] = chain_end_key(f, p, v, a);       // equal keys are equal chains: their order is free
-        n_u += popc64(m);
+    u64 m[kPer]; int n_u = 0;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        const int a = lane + 64 * q;
+        m[q] = __ballot(a < n && t[a] == 0 && v[a] >= kChainMinSc);
+        n_u += popc64(m[q]);
+    }
+    u64* u = n_u <= kLdsEnds ? u_lds : u_glb;
+    *u_out = u;
+    int at = 0;
+#pragma unroll
+    for (int q = 0; q < kPer; ++q) {
+        if ((m[q] >> lane) & 1ULL) u[at + popc64(m[q] & below)] = chain_end_key(f, p, v, lane + 64 * q);     // equal keys are equal chains: their order is free
+        at += popc64(m[q]);
     }
     __syncthreads();
     if (n_u > 1) {
-        // rank sort in place: every lane keeps its keys (<= kLdsChain / 64 of them) in registers
-        constexpr int kPer = kLdsChain / 64;
+        // rank sort in place: every lane keeps its keys in registers
         u64 key[kPer]; int rk[kPer];
 #pragma unroll
         for (int q = 0; q < kPer; ++q) {
@@ -358,11 +383,63 @@ NECAT_D int chain_ends_wave(const i32* f, const i32* p, i32* t, const i32* v, u6
 }
 
 #ifdef NECAT_SEED_PROF
-__device__ unsigned long long g_seed_prof[16];
+__device__ unsigned long long g_seed_prof[32];
 #define SPROF(k) do { if (lane == 0) { const u64 now_ = clock64(); pacc[k] += now_ - tprev; tprev = now_; } } while (0)
 #else
 #define SPROF(k) do {} while (0)
 #endif
+
+// scoring_pick (seed_core.h = word_finder.c:150-168 second half) on the lanes of a wave: only the anchor (loc[0], loc[1], its
+// index) is used by the callers.  The sequential code walks [j < maxi that agree with maxi ..., maxi, j > maxi that agree ...] and
+// keeps overwriting the anchor while it is "unset" - which it tests as loc == 0 - so the anchor is the first element of that
+// walk with a non-zero offset, or its last element when none has one.
+NECAT_D int scoring_pick_wave(const int* s_loc, const int* s_seedn, const int* s_score, int k, float scan_window, int read_size, int lane, int* msid)
+{
+    // k <= 2 * kBlkSeeds = 80: indices lane and lane + 64
+    const int a0 = lane, a1 = lane + 64;
+    const int v0 = a0 < k ? s_score[a0] : -1, v1 = a1 < k ? s_score[a1] : -1;
+    const int maxval = wave_read(wave_prefix_max(v0 > v1 ? v0 : v1), 63);
+    if (maxval < 5) return 0;
+    const u64 e0 = __ballot(v0 == maxval), e1 = __ballot(v1 == maxval);
+    const int maxi = e0 ? ctz64(e0) : 64 + ctz64(e1);
+    const int rep = popc64(e0) + popc64(e1) - 1;        // later indices with the same vote
+    if (rep == maxval) { *msid = maxi; return 1; }
+    const int lm = s_loc[maxi], sm = s_seedn[maxi];
+    auto agrees = [&](int j) {
+        if (j >= k || j == maxi) return j == maxi;
+        const int lj = s_loc[j], sj = s_seedn[j];
+        if (j < maxi) return sm - sj > 0 && lm - lj > 0 && lm - lj < read_size && ddf_ok(lm - lj, sm - sj, scan_window);
+        return sj - sm > 0 && lj - lm > 0 && lj - lm <= read_size && ddf_ok(lj - lm, sj - sm, scan_window);
+    };
+    const bool g0 = agrees(a0), g1 = agrees(a1);
+    const u64 w0 = __ballot(g0), w1 = __ballot(g1);                                 // the walk, in index order
+    const u64 n0 = __ballot(g0 && s_loc[a0 < k ? a0 : 0] != 0), n1 = __ballot(g1 && s_loc[a1 < k ? a1 : 0] != 0);
+    int pick;
+    if (n0) pick = ctz64(n0);
+    else if (n1) pick = 64 + ctz64(n1);
+    else pick = w1 ? 64 + 63 - __clzll((long long)w1) : 63 - __clzll((long long)w0);       // maxi itself is in the walk
+    *msid = pick;
+    return 1;
+}
+
+// seq_of_offset (dev_common.h) with 64 pivots per step instead of one
+NECAT_D u64 seq_of_offset_wave(const u64* __restrict__ seq_off, u64 nseq, u64 g, int lane)
+{
+    u64 lo = 0, hi = nseq;       // invariant: seq_off[lo] <= g < seq_off[hi]
+    while (hi - lo > 1) {
+        const u64 span = hi - lo;
+        // pivots lo + 1 + lane * step ... (at most 64 of them inside (lo, hi))
+        const u64 step = (span + 63) / 64;
+        const u64 pv = lo + 1 + (u64)lane * step;
+        const bool le = pv < hi && seq_off[pv] <= g;
+        const u64 m = __ballot(le);          // a prefix of the lanes (seq_off ascends)
+        const int c = popc64(m);
+        const u64 nlo = c ? lo + 1 + (u64)(c - 1) * step : lo;
+        u64 nhi = lo + 1 + (u64)c * step; if (nhi > hi) nhi = hi;
+        lo = nlo; hi = nhi;
+    }
+    return lo;
+}
 
 struct LdsAdder { int* s; NECAT_D void operator()(int j) { atomicAdd(&s[j], 1); } };
 
@@ -372,18 +449,27 @@ struct LdsAdder { int* s; NECAT_D void operator()(int j) { atomicAdd(&s[j], 1); 
 // chain DP, candidate choice) runs on lane 0.  __syncthreads() (the block is a single wave) separates
 // the lane-0 phases from the cooperative ones - it also stops the compiler from forwarding values
 // across lanes' stores.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+#ifndef NECAT_SEED_WAVES
+#define NECAT_SEED_WAVES 6
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NECAT_SEED_WAVES, NECAT_SEED_WAVES)))
 k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict__ order, const SeedMeta* __restrict__ meta, u32 n,
             SeedArenas A, const i32* __restrict__ nblk_in, i32* __restrict__ n_strand, int* __restrict__ err_flag)
 {
-    __shared__ int s_loc[kBlkSeeds * 2], s_seedn[kBlkSeeds * 2], s_score[kBlkSeeds * 2];
+    // LDS per wave: 6 KB, so that the CU holds as many of these latency-bound waves as their registers allow.
+    // votes (phases A - C) and the gather's slot table (phase D) share one buffer
+    __shared__ __attribute__((aligned(8))) int s_ab[264];
+    int* const s_loc = s_ab; int* const s_seedn = s_ab + 2 * kBlkSeeds; int* const s_score = s_ab + 4 * kBlkSeeds;
+    int* const s_pre = s_ab;                       // [65] seeds before slot j
+    int* const s_rel = s_ab + 66;                  // [64] accepted seeds of slot j
+    SBlock** const s_sb = (SBlock**)(s_ab + 130);  // [64]
     __shared__ int s_ctl[4];
-    __shared__ u64 s_blk_start;
-    __shared__ AnchorGeom s_g;
-    // chain scratch of the common case (<= kLdsChain co-linear seeds) lives in LDS: the sort is a parallel
-    // rank sort and lane 0's chain DP walks LDS instead of global memory
-    __shared__ u64 l_cs[kLdsChain], l_u[kLdsChain];
-    __shared__ i32 l_f[kLdsChain], l_p[kLdsChain], l_t[kLdsChain], l_v[kLdsChain];
+    __shared__ i64 s_clear[2];
+    __shared__ DevCand l_can[kLdsCan];
+    // chain scratch of the common case (<= kLdsChain co-linear seeds): sort, chain DP and chain ends run on all lanes in LDS
+    // (16-bit f / p / t / v: indices < 256, scores <= 256 * k)
+    __shared__ u64 l_cs[kLdsChain], l_u[kLdsEnds];
+    __shared__ i16 l_f[kLdsChain], l_p[kLdsChain], l_t[kLdsChain], l_v[kLdsChain];
     const u32 i = blockIdx.x >> 1;         // one wave per (read, strand): the strands share nothing but the output order
     if (i >= n) return;
     const int strand0 = (int)(blockIdx.x & 1);
@@ -421,10 +507,19 @@ k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict_
             if (!(sb->score >= cut && sb->stale >= 2 * cut)) continue;         // wave-uniform
             SPROF(0);
             // A: seed lists (lane 0)
-            if (lane == 0) { u64 bst; s_ctl[0] = block_seed_lists(S, sb, bs, s_seedn, s_loc, &bst); s_blk_start = bst; }
+            // (block_seed_lists of seed_core.h: the seeds of block b - 1, if it has any, then those of block b shifted by one block)
+            int ns; u64 blk_start;
+            {
+                const int block_id = sb->block_id;
+                const SBlock* prev = sb_find(S, block_id - 1);           // the same probe on every lane
+                const int np = prev ? prev->score : 0, nc = sb->score;
+                if (lane < np) { s_seedn[lane] = prev->kmer_id[lane]; s_loc[lane] = prev->blk_offset[lane]; }
+                if (lane < nc) { s_seedn[np + lane] = sb->kmer_id[lane]; s_loc[np + lane] = sb->blk_offset[lane] + (np ? bs : 0); }
+                ns = np + nc;
+                blk_start = (u64)bs * (u64)(np ? block_id - 1 : block_id);
+            }
             for (int x = lane; x < kBlkSeeds * 2; x += 64) s_score[x] = 0;
             __syncthreads();
-            const int ns = s_ctl[0];
             SPROF(1);
             // B: DDF vote, one row per lane
             for (int ii = lane; ii < ns - 1; ii += 64) {
@@ -435,80 +530,112 @@ k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict_
             __syncthreads();
             SPROF(2);
             // C: anchor (lane 0)
-            if (lane == 0) {
-                int msid = -1, sc4[4];
-                int ok = scoring_pick(s_loc, s_seedn, s_score, sc4, ns, &msid, (float)z, L);
-                if (ok && s_score[msid] < 2 * cut) ok = 0;
-                if (ok) s_g = anchor_geometry(ref, sc4[0], sc4[1], s_blk_start, bs, z, L);
-                s_ctl[1] = ok;
-            }
-            __syncthreads();
+            int msid = -1;
+            if (!scoring_pick_wave(s_loc, s_seedn, s_score, ns, (float)z, L, lane, &msid)) { SPROF(3); continue; }
+            if (s_score[msid] < 2 * cut) { SPROF(3); continue; }
+            const i64 tid = (i64)seq_of_offset_wave(ref.seq_off, ref.nseq, (u64)s_loc[msid] + blk_start, lane);
+            const AnchorGeom g = anchor_geometry(ref, s_loc[msid], s_seedn[msid], blk_start, bs, z, L, tid);     // the same on every lane
             SPROF(3);
-            if (!s_ctl[1]) continue;
-            const AnchorGeom g = s_g;
-            // D: co-linear gather, one seed per lane (a block holds <= 40 seeds)
-            int ncs = 0, seed_score = 0;
+            // D: co-linear gather (word_finder.c:249-307).  Slots = the blocks from bid_start to the anchor's own, tested on the left
+            // side, then the anchor's block and the ones up to bid_end, tested on the right side.  All probes at once (one slot per
+            // lane), then the seeds of all slots as ONE flat sequence taken 64 at a time: a handful of dependent memory round trips
+            // per evaluation instead of four per block.  The chain seeds are sorted afterwards, so their order here is free; the
+            // anchor's own seed (word_finder.c:277) goes first.
+            int ncs = 1, seed_score = 0;
             bool overflow = false;
-            for (int pass = 0; pass < 2; ++pass) {
-                const int lo = pass == 0 ? g.bid_start : g.seed_bid, hi = pass == 0 ? g.seed_bid : g.bid_end;
-                for (int b = lo; b <= hi; ++b) {
-                    SBlock* sbi = sb_find(S, b);
-                    if (!sbi) continue;
-                    const int nsc = sbi->score;
-                    if (!nsc) continue;
-                    u64 key = 0;
-                    const bool acc = lane < nsc && gather_test(g, sbi, lane, b, bs, z, pass == 1, &key);
-                    const u64 mask = __ballot(acc);
-                    const int rel = popc64(mask);
-                    if ((u32)(ncs + rel) >= S.cs_cap) { overflow = true; break; }
-                    if (acc) { const int w = ncs + popc64(mask & below); if (w < kLdsChain) l_cs[w] = key; else S.cs[w] = key; }
-                    ncs += rel; seed_score += rel;
-                    if (lane == 0 && b != g.seed_bid && gather_zeroes_block(rel, nsc)) sbi->score = 0;
+            if (lane == 0) l_cs[0] = ((u64)g.stoff << 32) | (u64)(u32)g.seed_qoff;
+            {
+                const int nleft = g.seed_bid - g.bid_start + 1, nslot = nleft + (g.bid_end - g.seed_bid + 1);
+                for (int s0 = 0; s0 < nslot; s0 += 64) {
+                    const int sl = s0 + lane;
+                    const int b = sl >= nleft ? g.seed_bid + (sl - nleft) : g.bid_start + sl;
+                    SBlock* sbi = sl < nslot ? sb_find(S, b) : nullptr;
+                    const int nsc = sbi ? sbi->score : 0;
+                    const int inc = wave_prefix_sum(nsc);
+                    __syncthreads();
+                    s_pre[lane] = inc - nsc; s_rel[lane] = 0; s_sb[lane] = sbi;
+                    if (lane == 63) s_pre[64] = inc;
+                    __syncthreads();
+                    const int T = s_pre[64];
+                    for (int c0 = 0; c0 < T; c0 += 64) {
+                        const int q = c0 + lane;
+                        int lo = 0;                                   // slot of seed q: the last one that starts at or before q
+                        for (int st = 32; st > 0; st >>= 1) if (s_pre[lo + st] <= q) lo += st;
+                        const int sl2 = s0 + lo;
+                        const bool right = sl2 >= nleft;
+                        const int b2 = right ? g.seed_bid + (sl2 - nleft) : g.bid_start + sl2;
+                        u64 key = 0;
+                        const bool acc = q < T && gather_test(g, s_sb[lo], q - s_pre[lo], b2, bs, z, right, &key);
+                        const u64 mask = __ballot(acc);
+                        if (acc) {
+                            const int w = ncs + popc64(mask & below);
+                            if (w < kLdsChain) l_cs[w] = key; else if ((u32)w < S.cs_cap) S.cs[w] = key;
+                            atomicAdd(&s_rel[lo], 1);
+                        }
+                        ncs += popc64(mask);
+                    }
+                    __syncthreads();
+                    // the 40 % rule (word_finder.c:273, :305), never for the anchor's own block
+                    if (nsc && b != g.seed_bid && gather_zeroes_block(s_rel[lane], nsc)) sbi->score = 0;
                 }
-                if (overflow) break;
-                if (pass == 0) {
-                    if (lane == 0) { const u64 key = ((u64)g.stoff << 32) | (u64)(u32)g.seed_qoff; if (ncs < kLdsChain) l_cs[ncs] = key; else S.cs[ncs] = key; }
-                    ++ncs;
-                }
+                seed_score = ncs - 1;
+                overflow = (u32)ncs >= S.cs_cap;
             }
             __syncthreads();
             SPROF(4);
-            // E: sort (all lanes when the seeds fit LDS), then chain + choose + emit (lane 0)
+            // E: sort (all lanes when the seeds fit LDS), then chain + choose + emit
             const bool in_lds = !overflow && ncs <= kLdsChain;
+            const bool wave_chain = in_lds && P.chain_wave;
             if (in_lds) {
-                // rank sort; equal keys (identical seeds) keep their index order
-                for (int a = lane; a < ncs; a += 64) {
-                    const u64 ka = l_cs[a];
-                    int rk = 0;
-                    for (int b = 0; b < ncs; ++b) { const u64 kb = l_cs[b]; rk += (kb < ka) || (kb == ka && b < a); }
-                    l_u[rk] = ka;
+                // rank sort in place, the keys of a lane in registers; equal keys (identical seeds) keep their index order
+                constexpr int kPer = kLdsChain / 64;
+                u64 key[kPer]; int rk[kPer];
+#pragma unroll
+                for (int q = 0; q < kPer; ++q) {
+                    const int a = lane + 64 * q;
+                    rk[q] = -1; key[q] = 0;
+                    if (a < ncs) {
+                        const u64 ka = l_cs[a];
+                        int r2 = 0;
+                        for (int b = 0; b < ncs; ++b) { const u64 kb = l_cs[b]; r2 += (kb < ka) || (kb == ka && b < a); }
+                        rk[q] = r2; key[q] = ka;
+                    }
                 }
                 __syncthreads();
-                for (int a = lane; a < ncs; a += 64) l_cs[a] = l_u[a];
+                if (wave_chain) {
+#pragma unroll
+                    for (int q = 0; q < kPer; ++q) if (rk[q] >= 0) l_cs[rk[q]] = key[q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < kPer; ++q) if (rk[q] >= 0) S.cs[rk[q]] = key[q];       // NECAT_CHAIN_WAVE=0: lane 0 chains in the global scratch
+                }
             } else if (!overflow) {
                 const int lim = ncs < kLdsChain ? ncs : kLdsChain;
                 for (int a = lane; a < lim; a += 64) S.cs[a] = l_cs[a];
             }
             __syncthreads();
             SPROF(5);
-            // chain DP and chain ends on all lanes when the seeds are in LDS (NECAT_CHAIN_WAVE=0: lane 0 does it all)
-            int chained = -1;
-            if (in_lds && P.chain_wave) {
-                chain_fill_wave(l_cs, l_f, l_p, l_t, l_v, ncs, P.k, lane);
-                chained = chain_ends_wave(l_f, l_p, l_t, l_v, l_u, ncs, lane);
+            // chain DP and chain ends on all lanes when the seeds are in LDS
+            int chained = 0; u64* u_at = l_u;
+            if (wave_chain) {
+                chain_fill_wave<i16>(l_cs, l_f, l_p, l_t, l_v, ncs, P.k, lane);
+                chained = chain_ends_wave<i16>(l_f, l_p, l_t, l_v, l_u, S.u, ncs, lane, &u_at);
             }
             SPROF(7);
             if (lane == 0) {
                 int rc;
+                s_clear[0] = 1; s_clear[1] = 0;
                 if (overflow) rc = kSeedErrCapacity;
-                else if (in_lds) {
-                    SeedScratch SL = S;
-                    SL.cs = l_cs; SL.u = l_u; SL.f = l_f; SL.p = l_p; SL.t = l_t; SL.v = l_v;
-                    rc = finish_candidate(SL, ncs, seed_score, g, P, r, strand, L, &n_out, true, chained);
-                } else rc = finish_candidate(S, ncs, seed_score, g, P, r, strand, L, &n_out);
+                else if (wave_chain) {
+                    DevCand* lc = chained <= kLdsCan ? l_can : S.lcan;
+                    const int ncan = chained ? chain_emit_t<i16>(l_cs, l_f, l_p, l_t, u_at, lc, ncs, chained, P.k, P.s_cutoff, finish_proto(g, r, strand, L)) : 0;
+                    rc = finish_choose(S, lc, ncan, seed_score, g, P, &n_out, s_clear);
+                } else rc = finish_candidate(S, ncs, seed_score, g, P, r, strand, L, &n_out, in_lds, s_clear);
                 s_ctl[2] = rc < 0 ? 1 : 0;
             }
             __syncthreads();
+            // an accepted candidate zeroes the blocks it covers (word_finder.c:171-182): one probe per lane
+            for (i64 cb = s_clear[0] + lane; cb <= s_clear[1]; cb += 64) { SBlock* x = sb_find(S, (i32)cb); if (x) x->score = 0; }
             SPROF(6);
 #ifdef NECAT_SEED_PROF
             if (lane == 0) pacc[8] += 1;
@@ -519,7 +646,11 @@ k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict_
     SPROF(9);
 #ifdef NECAT_SEED_PROF
 
-    if (lane == 0) { u64 tot = 0; for (int q = 0; q < 10; ++q) { atomicAdd(&g_seed_prof[q], pacc[q]); if (q != 8) tot += pacc[q]; } atomicMax(&g_seed_prof[10], tot); atomicMax(&g_seed_prof[11], pacc[8]); }
+    if (lane == 0) {
+        u64 tot = 0; for (int q = 0; q < 10; ++q) { atomicAdd(&g_seed_prof[q], pacc[q]); if (q != 8) tot += pacc[q]; }
+        atomicMax(&g_seed_prof[10], tot); atomicMax(&g_seed_prof[11], pacc[8]);
+        if (tot > 3000000) { for (int q = 0; q < 10; ++q) atomicAdd(&g_seed_prof[16 + q], pacc[q]); atomicAdd(&g_seed_prof[26], 1ULL); }     // what the long waves do
+    }
 #endif
     if (lane == 0) {
         if (failed) atomicExch(err_flag, 1);
