@@ -12,6 +12,7 @@
 //                                          -> k_rank_buckets  (buckets hold <= max_occ entries)
 //   build_kmer_starts/clear_hash           -> folded into k_write_stats / k_rank_buckets
 #pragma once
+#include <type_traits>
 #include "dev_common.h"
 
 namespace necat {
@@ -65,58 +66,144 @@ k_kmer_pass(DevVolume vol, int k, u32* __restrict__ cnt32, u64 n_offsets, u64* _
 // range of the offset list stay resident in that XCD's 4 MB L2 while the bucket is processed.
 // ---------------------------------------------------------------------------------------------
 constexpr int kPartThreads = 256;
-constexpr int kPartPosPerBlock = kPartThreads * 64;   // positions of the volume one block partitions
+constexpr int kPartPosPerBlock = kPartThreads * 64;   // positions of the volume one block partitions (16 and 256 per thread: slower)
 constexpr int kBucketChunk = 512;                     // bucket elements one block of the bucket passes handles
 
-// MODE 0: global bucket histogram.  MODE 1: scatter hash<<34|pos records into the bucket regions.
-template <int MODE>
+// Global bucket histogram.  LDS per block: a 16-bit counter per bucket (a block sees kPartPosPerBlock = 16 384 positions, two
+// counters share a word and are bumped with one 32-bit LDS atomic).
+static_assert(kPartPosPerBlock < 65536, "16-bit bucket counters per block");
 __global__ void __launch_bounds__(kPartThreads)
-k_part_pass(DevVolume vol, int k, int shift, u32 nb, u32 b_lo, u32 b_hi, u32* __restrict__ bucket_cnt, u64* __restrict__ bucket_cursor, u64* __restrict__ part)
+k_part_hist(DevVolume vol, int k, int shift, u32 nb, u32 b_lo, u32 b_hi, u32* __restrict__ bucket_cnt)
 {
     // [b_lo, b_hi): the buckets (= the hash range) this rank builds - all of them on one GPU (necat_index_build_sharded)
-    extern __shared__ u32 lds[];          // [nb] histogram (+ [2*nb] 64-bit bases in MODE 1)
+    extern __shared__ u32 lds[];          // [nb / 2] packed histogram
     u32* hist = lds;
-    u64* base = reinterpret_cast<u64*>(lds + nb);
-    for (u32 i = threadIdx.x; i < nb; i += kPartThreads) hist[i] = 0;
+    for (u32 i = threadIdx.x; i < nb / 2; i += kPartThreads) hist[i] = 0;
     __syncthreads();
     const u64 p0 = (u64)blockIdx.x * kPartPosPerBlock;
     const u64 p1 = (p0 + kPartPosPerBlock < vol.nbases) ? p0 + kPartPosPerBlock : vol.nbases;
-    for (int pass = 0; pass < (MODE == 0 ? 1 : 2); ++pass) {
-        for (u64 g0 = p0 + (u64)threadIdx.x * kPosPerThread; g0 < p1; g0 += (u64)kPartThreads * kPosPerThread) {
-            u64 r = seq_of_offset(vol.seq_off, vol.nseq, g0);
-            u64 rend = vol.seq_off[r + 1];
+    for (u64 g0 = p0 + (u64)threadIdx.x * kPosPerThread; g0 < p1; g0 += (u64)kPartThreads * kPosPerThread) {
+        u64 r = seq_of_offset(vol.seq_off, vol.nseq, g0);
+        u64 rend = vol.seq_off[r + 1];
 #pragma unroll
-            for (int i = 0; i < kPosPerThread; ++i) {
-                const u64 p = g0 + i;
-                if (p >= p1) break;
-                while (p >= rend) { ++r; rend = vol.seq_off[r + 1]; }
-                if (p + (u64)k <= rend) {
-                    const u64 h = kmer_hash_at(vol.bases, (i64)p, k);
-                    const u32 b = (u32)(h >> shift);
-                    if (b < b_lo || b >= b_hi) continue;
-                    if (MODE == 0 || pass == 0) atomicAdd(&hist[b], 1u);
-                    else part[base[b] + atomicAdd(&hist[b], 1u)] = (h << kOffsetBits) | p;
-                }
+        for (int i = 0; i < kPosPerThread; ++i) {
+            const u64 p = g0 + i;
+            if (p >= p1) break;
+            while (p >= rend) { ++r; rend = vol.seq_off[r + 1]; }
+            if (p + (u64)k <= rend) {
+                const u32 b = (u32)(kmer_hash_at(vol.bases, (i64)p, k) >> shift);
+                if (b < b_lo || b >= b_hi) continue;
+                atomicAdd(&hist[b >> 1], 1u << ((b & 1u) * 16));
             }
-        }
-        __syncthreads();
-        if (MODE == 0) {
-            for (u32 i = threadIdx.x; i < nb; i += kPartThreads) if (hist[i]) atomicAdd(&bucket_cnt[i], hist[i]);
-        } else if (pass == 0) {
-            // reserve this block's slice of every bucket region, then rank locally
-            for (u32 i = threadIdx.x; i < nb; i += kPartThreads) {
-                const u32 c = hist[i];
-                base[i] = c ? atomicAdd(reinterpret_cast<unsigned long long*>(&bucket_cursor[i]), (unsigned long long)c) : 0ULL;
-                hist[i] = 0;
-            }
-            __syncthreads();
         }
     }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < nb; i += kPartThreads) { const u32 c = (hist[i >> 1] >> ((i & 1u) * 16)) & 0xffffu; if (c) atomicAdd(&bucket_cnt[i], c); }
 }
 
-// exclusive scan of the bucket histogram (nb <= 4096) -> bucket_start[nb + 1]; cursors start there
+// ---- the split passes.  A one-pass scatter of hash<<34|pos records into 4096 bucket regions writes 8 bytes per lane to 64
+// different places per store instruction (1.6 of that pass's 2.6 ms were the stores); a split into <= 64 parts whose tile is
+// first sorted by part in LDS writes runs of consecutive records from consecutive lanes instead.  So the 12 partition bits are
+// split 6 + 6 (k_split_bases: volume -> coarse buckets; k_split_recs: coarse -> fine buckets), and k_subpart (the next 6 bits)
+// scatters through the same staging.  The order of the records inside a part is free (k_slice_emit ranks by offset).
+constexpr int kSplitTile = 2048;                  // records per tile = kPosPerThread per thread of a 256-thread block
+constexpr int kSplitPer = kSplitTile / 256;
+constexpr int kCurStride = 16;                   // the 64 coarse cursors of k_split_bases sit on their own 128-byte lines: every block bumps all of them
+static_assert(kSplitPer == kPosPerThread, "a thread of k_split_bases hashes the positions of one tile slot");
+struct SplitLds { u64 rec[kSplitTile]; u64 gbase[64]; u32 cnt[64]; u32 lstart[65]; };
+
+// One tile: r[q] (valid if bit q of `valid`) -> part digit(rec) in [0, 64); reserve(d, c) = where the tile's c records of part
+// d go in `out` (called by lane d of wave 0 for the parts with c > 0).  All 256 threads call.
+template <class Digit, class Reserve>
+NECAT_D void split_tile(SplitLds& L, const u64 (&r)[kSplitPer], u32 valid, Digit digit, Reserve reserve, u64* __restrict__ out)
+{
+    const int tid = threadIdx.x;
+    if (tid < 64) L.cnt[tid] = 0;
+    __syncthreads();
+    u32 rk[kSplitPer];
+#pragma unroll
+    for (int q = 0; q < kSplitPer; ++q) rk[q] = (valid >> q) & 1u ? atomicAdd(&L.cnt[digit(r[q])], 1u) : 0u;
+    __syncthreads();
+    if (tid < 64) {
+        const u32 c = L.cnt[tid];
+        u32 incl = c;
+        for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o); if (tid >= o) incl += v; }
+        L.lstart[tid] = incl - c;
+        if (tid == 63) L.lstart[64] = incl;
+        L.gbase[tid] = c ? reserve((u32)tid, c) : 0ULL;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kSplitPer; ++q) if ((valid >> q) & 1u) L.rec[L.lstart[digit(r[q])] + rk[q]] = r[q];
+    __syncthreads();
+    const u32 total = L.lstart[64];
+    for (u32 idx = tid; idx < total; idx += 256) {
+        const u64 rec = L.rec[idx];
+        const u32 d = digit(rec);
+        out[L.gbase[d] + (idx - L.lstart[d])] = rec;
+    }
+    __syncthreads();
+}
+
+// volume -> records in coarse buckets (top bits1 of the bucket id); cursor[c] runs from the coarse bucket's start
+__global__ void __launch_bounds__(256)
+k_split_bases(DevVolume vol, int k, int shift, u32 b_lo, u32 b_hi, int bits2, u64* __restrict__ cursor, int cur_stride, u64* __restrict__ out)
+{
+    __shared__ SplitLds L;
+    const u64 g0 = (u64)blockIdx.x * kSplitTile + (u64)threadIdx.x * kPosPerThread;
+    u64 r[kSplitPer]; u32 valid = 0;
+    if (g0 < vol.nbases) {
+        u64 sq = seq_of_offset(vol.seq_off, vol.nseq, g0);
+        u64 rend = vol.seq_off[sq + 1];
+#pragma unroll
+        for (int i = 0; i < kPosPerThread; ++i) {
+            const u64 p = g0 + i;
+            r[i] = 0;
+            if (p >= vol.nbases) continue;
+            while (p >= rend) { ++sq; rend = vol.seq_off[sq + 1]; }
+            if (p + (u64)k <= rend) {
+                const u64 h = kmer_hash_at(vol.bases, (i64)p, k);
+                const u32 b = (u32)(h >> shift);
+                if (b >= b_lo && b < b_hi) { r[i] = (h << kOffsetBits) | p; valid |= 1u << i; }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kSplitPer; ++i) r[i] = 0;
+    }
+    const int dsh = kOffsetBits + shift + bits2;
+    split_tile(L, r, valid, [=](u64 rec) { return (u32)(rec >> dsh) & 63u; },
+               [=](u32 d, u32 c) { return (u64)atomicAdd(reinterpret_cast<unsigned long long*>(&cursor[(u64)d * cur_stride]), (unsigned long long)c); }, out);
+}
+
+// tiles of the coarse buckets: tile_pre[c] = tiles of the coarse buckets before c (k_bucket_scan), cstart = bucket_start
+// at stride 1 << bits2.  Records of coarse bucket c -> its fine buckets (c << bits2) + d through bucket_cursor.
+__global__ void __launch_bounds__(256)
+k_split_recs(const u64* __restrict__ in, const u64* __restrict__ bucket_start, const u32* __restrict__ tile_pre, int nc, int shift, int bits2,
+             u64* __restrict__ bucket_cursor, u64* __restrict__ out)
+{
+    __shared__ SplitLds L;
+    const u32 t = blockIdx.x;
+    if (t >= tile_pre[nc]) return;
+    int c = 0;
+    for (int st = 32; st > 0; st >>= 1) if (c + st < nc && tile_pre[c + st] <= t) c += st;       // the last c with tile_pre[c] <= t
+    const u64 lo = bucket_start[(u64)c << bits2] + (u64)(t - tile_pre[c]) * kSplitTile, hi = bucket_start[(u64)(c + 1) << bits2];
+    u64 r[kSplitPer]; u32 valid = 0;
+#pragma unroll
+    for (int q = 0; q < kSplitPer; ++q) { const u64 e = lo + (u64)q * 256 + threadIdx.x; r[q] = 0; if (e < hi) { r[q] = in[e]; valid |= 1u << q; } }
+    const int dsh = kOffsetBits + shift;
+    const u32 dmask = (1u << bits2) - 1u;
+    u64* cur = bucket_cursor + ((u64)c << bits2);
+    split_tile(L, r, valid, [=](u64 rec) { return (u32)(rec >> dsh) & dmask; },
+               [=](u32 d, u32 n) { return (u64)atomicAdd(reinterpret_cast<unsigned long long*>(&cur[d]), (unsigned long long)n); }, out);
+}
+
+// exclusive scan of the bucket histogram (nb <= 4096) -> bucket_start[nb + 1]; cursors start there.  For the split passes:
+// coarse_cur[c] = start of coarse bucket c (= bucket_start[c << bits2]), tile_pre[c] = kSplitTile-record tiles of the coarse
+// buckets before c (tile_pre[nc] = all of them).
 __global__ void __launch_bounds__(1024)
-k_bucket_scan(const u32* __restrict__ bucket_cnt, u32 nb, u64* __restrict__ bucket_start, u64* __restrict__ bucket_cursor)
+k_bucket_scan(const u32* __restrict__ bucket_cnt, u32 nb, u64* __restrict__ bucket_start, u64* __restrict__ bucket_cursor,
+              int bits2, u64* __restrict__ coarse_cur, u32* __restrict__ tile_pre)
 {
     __shared__ u64 sh[1024];
     const u32 per = (nb + 1023) / 1024;
@@ -129,6 +216,17 @@ k_bucket_scan(const u32* __restrict__ bucket_cnt, u32 nb, u64* __restrict__ buck
     __syncthreads();
     u64 run = sh[threadIdx.x];
     for (u32 i = lo; i < hi; ++i) { bucket_start[i] = run; bucket_cursor[i] = run; run += bucket_cnt[i]; }
+    __syncthreads();
+    if (coarse_cur && threadIdx.x == 0) {
+        const u32 nc = nb >> bits2;
+        u32 tiles = 0;
+        for (u32 c = 0; c < nc; ++c) {
+            const u64 a = bucket_start[(u64)c << bits2], b = bucket_start[(u64)(c + 1) << bits2];
+            coarse_cur[(u64)c * kCurStride] = a; tile_pre[c] = tiles;
+            tiles += (u32)((b - a + kSplitTile - 1) / kSplitTile);
+        }
+        tile_pre[nc] = tiles;
+    }
 }
 
 // MODE 0: count (atomicAdd on the table).  MODE 1: scatter offsets through the end cursors.
@@ -266,39 +364,43 @@ constexpr int kSliceBits = 12, kSlice = 1 << kSliceBits;    // table entries per
 static_assert(kSubBits + kSliceBits == 18, "a bucket holds 2^18 table entries");
 
 // part -> part2: the records of bucket b regrouped by sub-bucket; sub_start[b * 64 + j] = first record
-// of slice (b, j) in part2 (absolute), sub_start[nb * 64] = number of records
+// of slice (b, j) in part2 (absolute), sub_start[nb * 64] = number of records.  One workgroup per bucket: a histogram pass,
+// then the scatter tile by tile through LDS (split_tile) with running cursors.
 __global__ void __launch_bounds__(256)
 k_subpart(const u64* __restrict__ part, const u64* __restrict__ bucket_start, u32 nb, u64* __restrict__ part2, u64* __restrict__ sub_start)
 {
-    __shared__ u32 hist[4][kSubs], base[4][kSubs];
+    __shared__ SplitLds L;
+    __shared__ u32 hist[4][kSubs];
+    __shared__ u64 run[kSubs];
     const u32 b = blockIdx.x;
     const u64 lo = bucket_start[b], hi = bucket_start[b + 1];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     hist[w][lane] = 0;
     __syncthreads();
-    // wave w owns the 64-record chunks w, w + 4, ...: it counts and later scatters the same records
-    for (u64 e0 = lo + (u64)w * 64; e0 < hi; e0 += 256) {
-        const u64 e = e0 + lane;
-        if (e < hi) atomicAdd(&hist[w][(u32)(part[e] >> (kOffsetBits + kSliceBits)) & (kSubs - 1)], 1u);
+    constexpr int kSubUnroll = 4;
+    for (u64 e0 = lo + (u64)w * 64; e0 < hi; e0 += 256 * kSubUnroll) {
+        u64 rec[kSubUnroll];
+#pragma unroll
+        for (int q = 0; q < kSubUnroll; ++q) { const u64 e = e0 + 256 * q + lane; rec[q] = e < hi ? part[e] : ~0ULL; }
+#pragma unroll
+        for (int q = 0; q < kSubUnroll; ++q) if (e0 + 256 * q + lane < hi) atomicAdd(&hist[w][(u32)(rec[q] >> (kOffsetBits + kSliceBits)) & (kSubs - 1)], 1u);
     }
     __syncthreads();
     if (w == 0) {
-        const u32 c0 = hist[0][lane], c1 = hist[1][lane], c2 = hist[2][lane], c3 = hist[3][lane];
-        const u32 tot = c0 + c1 + c2 + c3;
+        const u32 tot = hist[0][lane] + hist[1][lane] + hist[2][lane] + hist[3][lane];
         u32 incl = tot;
         for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-        const u32 ex = incl - tot;
-        base[0][lane] = ex; base[1][lane] = ex + c0; base[2][lane] = ex + c0 + c1; base[3][lane] = ex + c0 + c1 + c2;
-        sub_start[(u64)b * kSubs + lane] = lo + ex;
+        run[lane] = lo + (incl - tot);
+        sub_start[(u64)b * kSubs + lane] = lo + (incl - tot);
         if (b == nb - 1 && lane == 0) sub_start[(u64)nb * kSubs] = hi;
     }
     __syncthreads();
-    for (u64 e0 = lo + (u64)w * 64; e0 < hi; e0 += 256) {
-        const u64 e = e0 + lane;
-        if (e < hi) {
-            const u64 rec = part[e];
-            part2[lo + atomicAdd(&base[w][(u32)(rec >> (kOffsetBits + kSliceBits)) & (kSubs - 1)], 1u)] = rec;
-        }
+    for (u64 t0 = lo; t0 < hi; t0 += kSplitTile) {
+        u64 r[kSplitPer]; u32 valid = 0;
+#pragma unroll
+        for (int q = 0; q < kSplitPer; ++q) { const u64 e = t0 + (u64)q * 256 + threadIdx.x; r[q] = 0; if (e < hi) { r[q] = part[e]; valid |= 1u << q; } }
+        split_tile(L, r, valid, [](u64 rec) { return (u32)(rec >> (kOffsetBits + kSliceBits)) & (u32)(kSubs - 1); },
+                   [&](u32 d, u32 c) { const u64 at = run[d]; run[d] = at + c; return at; }, part2);
     }
 }
 

@@ -342,12 +342,29 @@ int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
         d_part = (u64*)ctx->scratch[SC_PART].p;
         const unsigned pgrid = (unsigned)((ref->nbases + kPartPosPerBlock - 1) / kPartPosPerBlock);
         NECAT_HIP(ctx, hipMemsetAsync(d_bcnt, 0, (size_t)NB * 4, s));
-        hipLaunchKernelGGL(k_part_pass<0>, dim3(pgrid), dim3(kPartThreads), NB * 4, s, vol, kmer_size, pshift, NB, b_lo, b_hi, d_bcnt, (u64*)nullptr, (u64*)nullptr);
-        NECAT_CHECK_LAUNCH(ctx, "k_part_pass<hist>");
-        hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, s, (const u32*)d_bcnt, NB, d_bstart, d_bcur);
+        // the PB partition bits in two splits of <= 6 bits (index_kernels.h): volume -> coarse buckets (in SC_PART2), coarse ->
+        // fine buckets (in SC_PART); at most 64 buckets: one split
+        const int bits2 = PB > 6 ? PB - 6 : 0;
+        const u32 NC = NB >> bits2;
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_SPLIT], (size_t)(NC + 1) * 8 * kCurStride + (size_t)(NC + 1) * 4 + 64)) ||
+            (bits2 && (rc = buf_ensure(ctx, ctx->scratch[SC_PART2], (ref->nbases + 1) * 8 + ((u64)NB * kSubs + 1) * 16 + (u64)NB * kSubs * 4 + 256)))) { necat_index_free(ctx, ix); return rc; }
+        u64* d_ccur = (u64*)ctx->scratch[SC_SPLIT].p;
+        u32* d_tpre = (u32*)(d_ccur + (size_t)(NC + 1) * kCurStride);
+        hipLaunchKernelGGL(k_part_hist, dim3(pgrid), dim3(kPartThreads), NB * 2, s, vol, kmer_size, pshift, NB, b_lo, b_hi, d_bcnt);
+        NECAT_CHECK_LAUNCH(ctx, "k_part_hist");
+        hipLaunchKernelGGL(k_bucket_scan, dim3(1), dim3(1024), 0, s, (const u32*)d_bcnt, NB, d_bstart, d_bcur, bits2, d_ccur, d_tpre);
         NECAT_CHECK_LAUNCH(ctx, "k_bucket_scan");
-        hipLaunchKernelGGL(k_part_pass<1>, dim3(pgrid), dim3(kPartThreads), NB * 4 + NB * 8, s, vol, kmer_size, pshift, NB, b_lo, b_hi, d_bcnt, d_bcur, d_part);
-        NECAT_CHECK_LAUNCH(ctx, "k_part_pass<scatter>");
+        const unsigned tgrid = (unsigned)((ref->nbases + kSplitTile - 1) / kSplitTile);
+        if (bits2) {
+            u64* d_coarse = (u64*)ctx->scratch[SC_PART2].p;
+            hipLaunchKernelGGL(k_split_bases, dim3(tgrid), dim3(256), 0, s, vol, kmer_size, pshift, b_lo, b_hi, bits2, d_ccur, kCurStride, d_coarse);
+            NECAT_CHECK_LAUNCH(ctx, "k_split_bases");
+            hipLaunchKernelGGL(k_split_recs, dim3(tgrid + NC), dim3(256), 0, s, (const u64*)d_coarse, (const u64*)d_bstart, (const u32*)d_tpre, (int)NC, pshift, bits2, d_bcur, d_part);
+            NECAT_CHECK_LAUNCH(ctx, "k_split_recs");
+        } else {
+            hipLaunchKernelGGL(k_split_bases, dim3(tgrid), dim3(256), 0, s, vol, kmer_size, pshift, b_lo, b_hi, 0, d_bcur, 1, d_part);
+            NECAT_CHECK_LAUNCH(ctx, "k_split_bases");
+        }
     }
     uint64_t n_off = 0;
     if (lds_slices) {
