@@ -447,7 +447,11 @@ k_bucket_base(const u32* __restrict__ bucket_kept, u32 nb, u64* __restrict__ buc
     if (threadIdx.x == 1023) bucket_base[nb] = sh[1023];
 }
 
-// kmer_stats of the slice + its part of the offset list (tmp: same layout, order inside a k-mer not yet fixed)
+// kmer_stats of the slice + its part of the offset list (tmp: same layout, order inside a k-mer not yet fixed).
+// The kernel is a chain of short barrier-separated phases, latency bound at full occupancy, so the common case - a slice of at
+// most 2 T records of which at most kLdsTmp are kept - keeps its records in registers from the first load on and ranks inside
+// LDS; anything bigger reloads per phase and ranks through the global tmp array.
+constexpr int kLdsTmp = 2048;
 template <int T>
 __global__ void __launch_bounds__(T)
 k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u32 max_occ, const u64* __restrict__ bucket_base,
@@ -457,20 +461,35 @@ k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u
     // here are final: positions in the gathered list; tmp is addressed the same way by a pointer shifted back by base_add)
     __shared__ u32 cnt[kSlice];      // occurrences per table entry of the slice
     __shared__ u32 cur[kSlice];      // start of the entry's group inside the slice, then its fill cursor
+    __shared__ u32 ltmp[kLdsTmp];    // the kept offsets of the slice, grouped by entry (small slices)
     __shared__ u32 wtot[T / 64];
     __shared__ u64 s_base;
     const u64 s = (u64)blockIdx.x + s0;
     const u64 lo = sub_start[s], hi = sub_start[s + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (wave == 0) {                 // the slice's base = its bucket's base + the kept totals of the bucket's earlier slices
+    const bool small = hi - lo <= (u64)(2 * T);
+    // the records first: their loads fly while the counters are zeroed and the slice's base is summed
+    u64 r0 = ~0ULL, r1 = ~0ULL;
+    if (small) {
+        if (lo + threadIdx.x < hi) r0 = part2[lo + threadIdx.x];
+        if (lo + T + threadIdx.x < hi) r1 = part2[lo + T + threadIdx.x];
+    }
+    if (wave == T / 64 - 1) {        // the slice's base = its bucket's base + the kept totals of the bucket's earlier slices
         const u32 j = (u32)s & (kSubs - 1);
         u64 before = (u32)lane < j ? (u64)kept_tot[(s & ~(u64)(kSubs - 1)) + lane] : 0ULL;
         for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o);
         if (lane == 0) s_base = bucket_base[s >> kSubBits] + before + base_add;
     }
+    for (int i = threadIdx.x; i < kSlice; i += T) cnt[i] = 0;
+    __syncthreads();
+    if (small) {
+        if (r0 != ~0ULL) atomicAdd(&cnt[(u32)(r0 >> kOffsetBits) & (kSlice - 1)], 1u);
+        if (r1 != ~0ULL) atomicAdd(&cnt[(u32)(r1 >> kOffsetBits) & (kSlice - 1)], 1u);
+    } else {
+        for (u64 e = lo + threadIdx.x; e < hi; e += T) atomicAdd(&cnt[(u32)(part2[e] >> kOffsetBits) & (kSlice - 1)], 1u);
+    }
     __syncthreads();
     const u64 base = s_base;
-    slice_count<T>(part2, lo, hi, cnt);
     // exclusive scan of the kept counts: thread t owns entries [E t, E t + E)
     constexpr int E = kSlice / T;
     u32 c[E], sum = 0;
@@ -481,8 +500,9 @@ k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u
     for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o); if (lane >= o) incl += v; }
     if (lane == 63) wtot[wave] = incl;
     __syncthreads();
-    u32 run = incl - sum;
-    for (int w = 0; w < wave; ++w) run += wtot[w];
+    u32 run = incl - sum, kept_all = 0;
+#pragma unroll
+    for (int w = 0; w < T / 64; ++w) { if (w < wave) run += wtot[w]; kept_all += wtot[w]; }
 #pragma unroll
     for (int i = 0; i < E; ++i) { cur[threadIdx.x * E + i] = run; run += c[i]; }
     __syncthreads();
@@ -493,13 +513,24 @@ k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u
         stats[i] = k ? ((u64)k << kOffsetBits) | (base + cur[i]) : 0ULL;
     }
     __syncthreads();
+    if (small && kept_all <= (u32)kLdsTmp) {
+        // radix_sort is stable (hash_list_bucket_sort.c:134): offsets ascend inside a k-mer
+        const u32 h0 = (u32)(r0 >> kOffsetBits) & (kSlice - 1), h1 = (u32)(r1 >> kOffsetBits) & (kSlice - 1);
+        const u32 k0 = r0 != ~0ULL ? filtered_count(cnt[h0], max_occ) : 0u, k1 = r1 != ~0ULL ? filtered_count(cnt[h1], max_occ) : 0u;
+        const u32 p0 = (u32)(r0 & kOffsetMask), p1 = (u32)(r1 & kOffsetMask);
+        if (k0) ltmp[atomicAdd(&cur[h0], 1u)] = p0;
+        if (k1) ltmp[atomicAdd(&cur[h1], 1u)] = p1;
+        __syncthreads();        // cur[h] is now the END of the group
+        if (k0) { const u32 st = cur[h0] - k0; u32 rank = 0; if (k0 > 1) for (u32 j = 0; j < k0; ++j) rank += ltmp[st + j] < p0; offset_list[base + st + rank] = (u64)p0; }
+        if (k1) { const u32 st = cur[h1] - k1; u32 rank = 0; if (k1 > 1) for (u32 j = 0; j < k1; ++j) rank += ltmp[st + j] < p1; offset_list[base + st + rank] = (u64)p1; }
+        return;
+    }
     for (u64 e = lo + threadIdx.x; e < hi; e += T) {
         const u64 rec = part2[e];
         const u32 h = (u32)(rec >> kOffsetBits) & (kSlice - 1);
         if (filtered_count(cnt[h], max_occ)) tmp[base + atomicAdd(&cur[h], 1u)] = (u32)(rec & kOffsetMask);
     }
     __syncthreads();        // cur[h] is now the END of the group; the tmp writes of this workgroup are visible to it
-    // radix_sort is stable (hash_list_bucket_sort.c:134): offsets ascend inside a k-mer
     for (u64 e = lo + threadIdx.x; e < hi; e += T) {
         const u64 rec = part2[e];
         const u32 h = (u32)(rec >> kOffsetBits) & (kSlice - 1);
