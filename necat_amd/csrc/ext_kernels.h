@@ -734,11 +734,11 @@ template <int NW, int TW, int COLS, int MAXOPS, bool EXPORT, int WALK = 0>
 __global__ void __launch_bounds__(64)
 k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, const char* __restrict__ slabs, size_t slab_bytes,
             const BlockResult* __restrict__ results, u8* __restrict__ ops_pool, ExtTask* __restrict__ tasks, int tail_match_len,
-            i32* __restrict__ n_ops_out, int* __restrict__ err_flag, ExtLists next, u32 epoch)
+            i32* __restrict__ n_ops_out, int* __restrict__ err_flag, ExtLists next, u32 epoch, u32 item_base = 0)
 {
     constexpr int FW = 2 * NW + TW;
     const ListView lv = list_view(n_host, n_dev, capA);
-    const u32 grp = blockIdx.x;
+    const u32 grp = blockIdx.x + (item_base >> 6);      // item_base: a multiple of 64 (a list handled in several launches: bounded band pool)
     const int lane = threadIdx.x;
     const u64 item = (u64)grp * 64 + lane;
     BlockItem it;

@@ -61,6 +61,7 @@ int g_sort_b;          // NECAT_SORT_B=0 disables the size sort of list B
 int g_cns_spec_extra, g_cns_spec_cover;   // NECAT_CNS_SPEC_EXTRA / NECAT_CNS_SPEC: speculation width of the consensus loop
 int g_fast;            // NECAT_FAST=0: the list-A DP kernel never takes its full-block fast path (A/B measurements); 2: fast path without band stores (profiling only, results invalid)
 int g_fast16;          // NECAT_FAST16=1: list A's big rounds through k_myers_a16 (16 full blocks per workgroup: SHW 8 lanes, NW 4 lanes per block)
+size_t g_band_pool;    // NECAT_BAND_POOL_MB: cap of one band-record pool; a round's list then runs in several DP + walk launches (0 = whole list)
 int g_walk;            // NECAT_WALK=0: k_traceback runs the reference formulation of the walk (A/B measurements)
 int g_dbg;             // NECAT_DBG: profiling-only variants of the lane-per-block DP kernel (1 = no band stores, 2 = no NW pass)
 
@@ -79,6 +80,7 @@ void read_knobs()
     g_sort_b = (int)num("NECAT_SORT_B", 1);
     g_dbg = (int)num("NECAT_DBG", 0);
     g_fast = (int)num("NECAT_FAST", 1);
+    g_band_pool = (size_t)num("NECAT_BAND_POOL_MB", 0) << 20;
     g_fast16 = (int)num("NECAT_FAST16", 0);      // measured: no gain on the bench workload, off by default
     g_walk = (int)num("NECAT_WALK", 0);      // 0: reference formulation (default until the restated walk wins), 1: walk_block, 2: walk_block without record prefetch
     g_cns_spec_extra = getenv("NECAT_CNS_SPEC_EXTRA") ? atoi(getenv("NECAT_CNS_SPEC_EXTRA")) : 1;
@@ -119,9 +121,9 @@ int necat_ctx_create(int device_id, necat_ctx** out)
         snprintf(ctx->devname, sizeof ctx->devname, "%s (%s), %d CUs", prop.name, prop.gcnArchName, prop.multiProcessorCount);
         ctx->num_cu = prop.multiProcessorCount;
     }
-    if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreate(&ctx->stream_a) != hipSuccess ||
-        hipStreamCreate(&ctx->stream_b) != hipSuccess || hipStreamCreate(&ctx->stream_c) != hipSuccess ||
-        hipStreamCreate(&ctx->stream_copy) != hipSuccess || hipStreamCreate(&ctx->stream_d) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
+    // one stream now; the extension's streams when the first extension runs (a stream costs 8 - 15 ms to create: a candidates-only
+    // process never pays for them)
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
     for (int i = 0; i < kNumEvents; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
     // the list sizes of the extension rounds reach the host through this pinned ring (RoundPub, ext_kernels.h)
     if (hipHostMalloc(&ctx->round_ring, kRoundRing * sizeof(RoundPub), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -136,15 +138,14 @@ void necat_ctx_destroy(necat_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamSynchronize(ctx->stream_copy);
+    if (ctx->stream_copy) (void)hipStreamSynchronize(ctx->stream_copy);
     for (auto& b : ctx->scratch) if (b.p) (void)hipFree(b.p);
     for (auto& b : ctx->idx_cache) if (b.p) (void)hipFree(b.p);
     delete (cns::Scratch*)ctx->cns_scratch;
     if (ctx->pin_plan) (void)hipHostFree(ctx->pin_plan);
     for (int i = 0; i < kNumEvents; ++i) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->round_ring) (void)hipHostFree(ctx->round_ring);
-    (void)hipStreamDestroy(ctx->stream); (void)hipStreamDestroy(ctx->stream_a); (void)hipStreamDestroy(ctx->stream_b); (void)hipStreamDestroy(ctx->stream_c);
-    (void)hipStreamDestroy(ctx->stream_copy); (void)hipStreamDestroy(ctx->stream_d);
+    for (hipStream_t st : {ctx->stream, ctx->stream_a, ctx->stream_b, ctx->stream_c, ctx->stream_copy}) if (st) (void)hipStreamDestroy(st);
     delete ctx;
 }
 
@@ -882,12 +883,14 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         // that B(q) need not queue behind B(q - 1); big ones stay in one stream - three busy chains only add contention
         hipStream_t sb = c.sb[nB < 4096 ? slot : 0];
         DevBuf& poolB = ctx->scratch[slot ? SC_EXT_MATB2 : SC_EXT_MATB];
-        if ((size_t)gB * kSlabB > poolB.cap) {
-            const size_t need = (size_t)gB * kSlabB;
-            int rc = ensure_zeroed(ctx, poolB, need + need / 4, sb);
+        // a capped band pool (NECAT_BAND_POOL_MB): the list in chunks of what the pool holds, DP + walk per chunk
+        u32 gchunk = gB;
+        if (g_band_pool && (size_t)gB * kSlabB > g_band_pool) gchunk = (u32)std::max<size_t>(1, g_band_pool / kSlabB);
+        if ((size_t)gchunk * kSlabB > poolB.cap) {
+            const size_t need = (size_t)gchunk * kSlabB;
+            int rc = ensure_zeroed(ctx, poolB, gchunk < gB ? need : need + need / 4, sb);
             if (rc) return rc;
         }
-        char* slabsB = (char*)poolB.p;
         const BlockItem* itB = c.itemsB[cur];
         const u32* d_nB = c.count + 4 * cur + 1;
         NECAT_HIP(ctx, hipStreamWaitEvent(sb, c.a0[cur], 0));     // lists[q] complete (A(q - 1) done), counters of lists[q + 2] reset
@@ -909,23 +912,27 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                            drd, dref, itB, nB, d_nB, 0u, c.fragB[slot], ctl);
         NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
         NECAT_HIP(ctx, hipEventRecord(c.b0[slot], sb));
-        if (nB <= g_single_pass && nB <= g_coop_threshold)
-            hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16, true>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB, d_nB, 0u,
-                               (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch, 0u);
-        else if (nB <= g_coop_threshold)
-            hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((nB + 3) / 4), dim3(64), 0, sb, itB, nB, d_nB, 0u,
-                               (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch | (g_coop_filter ? 0u : 1u << 30) | (g_fast == 0 ? 1u << 29 : 0u) | (g_fast == 2 ? 1u << 28 : 0u), 0u);
-        else
-            hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3(gB), dim3(64), 0, sb, itB, nB, d_nB, 0u,
-                               (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch, 0u);
-        NECAT_CHECK_LAUNCH(ctx, "k_myers<B>");
-        NECAT_HIP(ctx, hipEventRecord(c.b1[slot], sb));
-#define NECAT_TB_LAUNCH(WALK) hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false, WALK>), dim3(gB), dim3(64), 0, sb, itB, nB, d_nB, 0u, \
+        for (u32 g0 = 0; g0 < gB; g0 += gchunk) {
+            const u32 lo = g0 * 64, hi = std::min(nB, (g0 + gchunk) * 64), cn = hi - lo;       // work items of this chunk
+            char* slabsB = (char*)poolB.p - (size_t)g0 * kSlabB;                              // the kernels index slabs by item / 64
+            if (nB <= g_single_pass && nB <= g_coop_threshold)
+                hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16, true>), dim3((cn + 3) / 4), dim3(64), 0, sb, itB, hi, d_nB, 0u,
+                                   (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch, lo);
+            else if (nB <= g_coop_threshold)
+                hipLaunchKernelGGL((k_myers_coop<kWordsB, kTWordsB, kColsB, 16>), dim3((cn + 3) / 4), dim3(64), 0, sb, itB, hi, d_nB, 0u,
+                                   (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch | (g_coop_filter ? 0u : 1u << 30) | (g_fast == 0 ? 1u << 29 : 0u) | (g_fast == 2 ? 1u << 28 : 0u), lo);
+            else
+                hipLaunchKernelGGL((k_myers<kWordsB, kTWordsB, kColsB, false>), dim3((cn + 63) / 64), dim3(64), 0, sb, itB, hi, d_nB, 0u,
+                                   (const u64*)c.fragB[slot], slabsB, kSlabB, X.error, c.resB[slot], X.stats, epoch, lo);
+            NECAT_CHECK_LAUNCH(ctx, "k_myers<B>");
+            if (g0 + gchunk >= gB) NECAT_HIP(ctx, hipEventRecord(c.b1[slot], sb));
+#define NECAT_TB_LAUNCH(WALK) hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false, WALK>), dim3((cn + 63) / 64), dim3(64), 0, sb, itB, hi, d_nB, 0u, \
                            (const u64*)c.fragB[slot], (const char*)slabsB, kSlabB, (const BlockResult*)c.resB[slot], c.opsB[slot], c.tasks, X.tail_match_len, \
-                           (i32*)nullptr, X.d_err, next, epoch)
-        if (g_walk == 1) NECAT_TB_LAUNCH(1); else if (g_walk == 2) NECAT_TB_LAUNCH(2); else NECAT_TB_LAUNCH(0);
+                           (i32*)nullptr, X.d_err, next, epoch, lo)
+            if (g_walk == 1) NECAT_TB_LAUNCH(1); else if (g_walk == 2) NECAT_TB_LAUNCH(2); else NECAT_TB_LAUNCH(0);
 #undef NECAT_TB_LAUNCH
-        NECAT_CHECK_LAUNCH(ctx, "k_traceback<B>");
+            NECAT_CHECK_LAUNCH(ctx, "k_traceback<B>");
+        }
         NECAT_HIP(ctx, hipEventRecord(c.b2[slot], sb));
         b_pending[slot] = true; b_blocks[slot] = nB;
         return NECAT_OK;
@@ -935,13 +942,16 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         const int cur = r % 4, nxt = (r + 1) % 4, nxt2 = (r + 2) % 4;
         const u32 gA = (bound + 63) / 64;
         // the band pools are sized by what a round needs (round 0 of the first call sets them: 35 GB instead of the
-        // 76 GB worst case "every block in list B" at E. coli size - hipMalloc costs ~13 ms per GB)
-        if ((size_t)gA * kSlabA > ctx->scratch[SC_EXT_MAT].cap) {
-            const size_t need = (size_t)gA * kSlabA;
-            int rc = ensure_zeroed(ctx, ctx->scratch[SC_EXT_MAT], need + need / 8, c.sa);
+        // 76 GB worst case "every block in list B" at E. coli size - hipMalloc costs ~13 ms per GB); with a capped pool
+        // (NECAT_BAND_POOL_MB, the command-line programs: a fresh process pays 30 - 55 ms per GB of VRAM the previous one
+        // dirtied) the list runs in chunks of what the pool holds, DP + walk per chunk
+        u32 gchunk = gA;
+        if (g_band_pool && (size_t)gA * kSlabA > g_band_pool) gchunk = (u32)std::max<size_t>(1, g_band_pool / kSlabA);
+        if ((size_t)gchunk * kSlabA > ctx->scratch[SC_EXT_MAT].cap) {
+            const size_t need = (size_t)gchunk * kSlabA;
+            int rc = ensure_zeroed(ctx, ctx->scratch[SC_EXT_MAT], gchunk < gA ? need : need + need / 8, c.sa);
             if (rc) return rc;
         }
-        char* slabsA = (char*)ctx->scratch[SC_EXT_MAT].p;
         const BlockItem* itA = c.itemsA[cur];
         const u32* d_nA = c.count + 4 * cur;            // [0] full blocks (front of itemsA), [2] the others (back)
         if (r >= 2) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, c.b2[r & 1], 0));        // B(r - 2) appended to lists[r]
@@ -954,30 +964,34 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         a_timed.push_back(0);
         if (!bound) return NECAT_OK;
         ExtLists next; next.count = c.count + 4 * nxt; next.itemsA = c.itemsA[nxt]; next.itemsB = c.itemsB[nxt]; next.task_ops = X.task_ops; next.capA = c.cap;
-        if (bound <= g_single_pass && bound <= g_coop_threshold)
-            hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8, true>), dim3((bound + 7) / 8), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap,
-                               (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
-        else if (bound <= g_coop_threshold) {
-            const bool f16 = g_fast16 && g_fast == 1 && g_coop_filter;
-            const u32 fl = epoch | (g_coop_filter ? 0u : 1u << 30) | (g_fast == 0 ? 1u << 29 : 0u) | (g_fast == 2 ? 1u << 28 : 0u);
-            if (f16)      // workgroups of 16 work items: 16 full blocks take the 16-block path (ext_fast16.h), anything else the general one
-                hipLaunchKernelGGL((k_myers_a16<kWordsA, kTWordsA, kColsA>), dim3((bound + 15) / 16), dim3(128), 0, c.sa, itA, bound, d_nA, c.cap,
-                                   (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, fl | 1u << 27);
+        for (u32 g0 = 0; g0 < gA; g0 += gchunk) {
+            const u32 lo = g0 * 64, hi = std::min(gA, g0 + gchunk) * 64, cn = hi - lo;           // work indices of this chunk (the kernels know the exact list)
+            char* slabsA = (char*)ctx->scratch[SC_EXT_MAT].p - (size_t)g0 * kSlabA;             // the kernels index slabs by work index / 64
+            if (bound <= g_single_pass && bound <= g_coop_threshold)
+                hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8, true>), dim3(cn / 8), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap,
+                                   (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch, lo);
+            else if (bound <= g_coop_threshold) {
+                const bool f16 = g_fast16 && g_fast == 1 && g_coop_filter && gchunk == gA;
+                const u32 fl = epoch | (g_coop_filter ? 0u : 1u << 30) | (g_fast == 0 ? 1u << 29 : 0u) | (g_fast == 2 ? 1u << 28 : 0u);
+                if (f16)      // workgroups of 16 work items: 16 full blocks take the 16-block path (ext_fast16.h), anything else the general one
+                    hipLaunchKernelGGL((k_myers_a16<kWordsA, kTWordsA, kColsA>), dim3((bound + 15) / 16), dim3(128), 0, c.sa, itA, bound, d_nA, c.cap,
+                                       (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, fl | 1u << 27);
+                else
+                    hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3(cn / 8), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap,
+                                       (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, fl, lo);
+            }
             else
-                hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3((bound + 7) / 8), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap,
-                                   (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, fl, 0u);
-        }
-        else
-            hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, false>), dim3(gA), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap,   // list A also holds last blocks <= 512 x 512
-                               (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch, 0u);
-        NECAT_CHECK_LAUNCH(ctx, "k_myers<A>");
-        NECAT_HIP(ctx, hipEventRecord(c.a1[cur], c.sa));
-#define NECAT_TB_LAUNCH(WALK) hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, WALK>), dim3(gA), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap, \
+                hipLaunchKernelGGL((k_myers<kWordsA, kTWordsA, kColsA, false>), dim3(cn / 64), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap,   // list A also holds last blocks <= 512 x 512
+                                   (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch, lo);
+            NECAT_CHECK_LAUNCH(ctx, "k_myers<A>");
+            if (g0 + gchunk >= gA) NECAT_HIP(ctx, hipEventRecord(c.a1[cur], c.sa));
+#define NECAT_TB_LAUNCH(WALK) hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, WALK>), dim3(cn / 64), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap, \
                            (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len, \
-                           (i32*)nullptr, X.d_err, next, epoch)
-        if (g_walk == 1) NECAT_TB_LAUNCH(1); else if (g_walk == 2) NECAT_TB_LAUNCH(2); else NECAT_TB_LAUNCH(0);
+                           (i32*)nullptr, X.d_err, next, epoch, lo)
+            if (g_walk == 1) NECAT_TB_LAUNCH(1); else if (g_walk == 2) NECAT_TB_LAUNCH(2); else NECAT_TB_LAUNCH(0);
 #undef NECAT_TB_LAUNCH
-        NECAT_CHECK_LAUNCH(ctx, "k_traceback<A>");
+            NECAT_CHECK_LAUNCH(ctx, "k_traceback<A>");
+        }
         NECAT_HIP(ctx, hipEventRecord(c.a2[cur], c.sa));
         a_timed[r] = 1;
         return NECAT_OK;
@@ -1033,10 +1047,18 @@ struct AlignOut {
 // (every candidate's alignment with its columns, `ao` != nullptr).
 struct DevOut { const necat_m4* d = nullptr; uint64_t n = 0; };      // records left on the device (sharded calls gather them there)
 
+int ext_streams(necat_ctx* ctx)
+{
+    for (hipStream_t* st : {&ctx->stream_a, &ctx->stream_b, &ctx->stream_c, &ctx->stream_copy})
+        if (!*st && hipStreamCreate(st) != hipSuccess) return set_err(ctx, NECAT_ERR_DEVICE, "hipStreamCreate failed");
+    return NECAT_OK;
+}
+
 int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* reads, int read_start_id, int ref_start_id,
                 const necat_candidate* cands, uint64_t n, const necat_map_options* opt, int tail_match_len,
                 necat_m4** out, uint64_t* n_out, AlignOut* ao, const DevCands* dev = nullptr, DevOut* devout = nullptr)
 {
+    if (int rc0 = ext_streams(ctx)) return rc0;
     // dev != nullptr (necat_map_pair): the candidates are this library's own, still on the device
     auto t_prev = std::chrono::steady_clock::now();
     auto tick = [&](const char* what) {

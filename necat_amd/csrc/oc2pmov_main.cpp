@@ -4,6 +4,7 @@
 // through libnecat_hip.so (device from NECAT_GPU, default 0).  There is no CPU fallback: without a
 // usable GPU the program exits 1, like every other fatal error of the reference (OC_ERROR).
 #include "host_io.h"
+#include "host_fmt.h"
 
 using namespace necat_host;
 
@@ -13,8 +14,17 @@ static int fail(const char* what, const char* detail)
     return 1;
 }
 
+// NECAT_CLI_TRACE=1: wall clock of the program's stages on stderr (where a cold start goes)
+static double g_t0;
+static void stage(const char* what)
+{
+    static const bool on = getenv("NECAT_CLI_TRACE") && atoi(getenv("NECAT_CLI_TRACE"));
+    if (on) fprintf(stderr, "[oc2pmov] %8.1f ms  %s\n", (now_sec() - g_t0) * 1e3, what);
+}
+
 int main(int argc, char** argv)
 {
+    g_t0 = now_sec();
     necat_map_options opt;
     necat_default_options(&opt);
     if (argc < 4) {     // pm_one_volume/main.c:30-33
@@ -37,21 +47,27 @@ int main(int argc, char** argv)
     if (!load_volumes_info(wrk_dir, &vi, &err)) return fail("volume directory", err.c_str());
     if (vid < 0 || vid >= vi.num_volumes) return fail("volume id", "out of range");
     const char* dev_env = getenv("NECAT_GPU");
+    // a fresh process pays for the VRAM the previous one dirtied (30 - 55 ms per GB on MI355X): keep the band-record pools small
+    setenv("NECAT_BAND_POOL_MB", "4096", 0);
     necat_ctx* ctx = nullptr;
     int rc = necat_ctx_create(dev_env ? atoi(dev_env) : 0, &ctx);
     if (rc) return fail("GPU", "no usable gfx950 device (libnecat_hip has no CPU fallback)");
+    stage("context created");
 
     HostVolume href;
     if (!load_volume(vi.names[vid].c_str(), &href, &err)) return fail("volume", err.c_str());
+    stage("volume read");
     necat_volume* ref = nullptr;
     if ((rc = necat_volume_upload(ctx, href.pac.data(), href.nbases, href.offset.data(), href.size.data(), href.offset.size(), &ref)))
         return fail("necat_volume_upload", necat_last_error(ctx));
+    stage("volume uploaded");
     log_line("", "build_lookup_table");
     double t0 = now_sec();
     necat_index* ix = nullptr;
     if ((rc = necat_index_build(ctx, ref, opt.kmer_size, opt.kmer_cnt_cutoff, &ix))) return fail("necat_index_build", necat_last_error(ctx));
     log_line("[%s] INFO: '%s' takes %.2lf secs.\n", "build_lookup_table", now_sec() - t0);
 
+    stage("index built");
     // write to a temporary name first: a failed run never leaves a complete-looking pm_result_i
     const std::string tmp_out = std::string(output) + ".part";
     FILE* out = fopen(tmp_out.c_str(), "w");
@@ -78,28 +94,33 @@ int main(int argc, char** argv)
             necat_m4* m4 = nullptr; uint64_t nm4 = 0;
             if ((rc = necat_map_pair(ctx, ix, ref, reads, read_start, ref_start, 1, &opt, 1 /* ONC_TAIL_MATCH_LEN_SHORT */, &m4, &nm4, &ncand)))
                 return fail("necat_map_pair", necat_last_error(ctx));
-            for (uint64_t k = 0; k < nm4; ++k) {
-                const necat_m4& m = m4[k];
-                if (opt.binary_output) fwrite(&m, sizeof m, 1, out);
-                else if (opt.use_hdr_as_id)      // DUMP_ASM_M4_HDR_ID (m4_record.h:99-124)
-                    fprintf(out, "%s\t%s\t%.2f\t%d\t%d\t%lu\t%lu\t%lu\t%d\t%lu\t%lu\t%lu\n", hreads->name((uint64_t)(m.qid - read_start)),
-                            href.name((uint64_t)(m.sid - ref_start)), m.ident_perc, m.vscore, m.qdir, m.qoff, m.qend, m.qsize, m.sdir, m.soff, m.send, m.ssize);
-                else                              // DUMP_ASM_M4 (m4_record.h:72-97)
-                    fprintf(out, "%d\t%d\t%.2f\t%d\t%d\t%lu\t%lu\t%lu\t%d\t%lu\t%lu\t%lu\n", m.qid, m.sid, m.ident_perc, m.vscore, m.qdir,
-                            m.qoff, m.qend, m.qsize, m.sdir, m.soff, m.send, m.ssize);
+            stage("mapped");
+            bool wok;
+            if (opt.binary_output) wok = nm4 == 0 || fwrite(m4, sizeof(necat_m4), nm4, out) == nm4;
+            else {
+                const bool hdr = opt.use_hdr_as_id != 0;
+                size_t max_len = 12 * 24;
+                if (hdr) { size_t lq = 0, ls = 0; for (uint64_t r = 0; r < hreads->offset.size(); ++r) lq = std::max(lq, strlen(hreads->name(r)));
+                           for (uint64_t r = 0; r < href.offset.size(); ++r) ls = std::max(ls, strlen(href.name(r))); max_len += lq + ls; }
+                wok = write_records(out, nm4, max_len, opt.num_threads, [&](char* p, uint64_t k) {
+                    const necat_m4& m = m4[k];
+                    return hdr ? put_m4(p, m, hreads->name((uint64_t)(m.qid - read_start)), href.name((uint64_t)(m.sid - ref_start))) : put_m4(p, m, nullptr, nullptr);
+                });
             }
+            if (!wok) return fail("output", "write failed");
             n_records += nm4;
             necat_free(m4);
+            stage("records written");
         } else {
             if ((rc = necat_find_candidates(ctx, ix, ref, reads, read_start, ref_start, 1, &opt, &cands, &ncand)))
                 return fail("necat_find_candidates", necat_last_error(ctx));
-            for (uint64_t k = 0; k < ncand; ++k) {
-                const necat_candidate& c = cands[k];
-                if (opt.binary_output) { uint32_t item[7]; pack_candidate(&c, item); fwrite(item, 28, 1, out); }
-                else                              // DUMP_GAPPED_CANDIDATE (gapped_candidate.h:26-42)
-                    fprintf(out, "%d\t%d\t%d\t%d\t%lu\t%lu\t%lu\t%lu\t%d\t%lu\t%lu\t%lu\t%lu\n", c.qid, c.sid, c.score, c.qdir, c.qbeg, c.qend, c.qoff,
-                            c.qsize, c.sdir, c.sbeg, c.send, c.soff, c.ssize);
-            }
+            bool wok;
+            if (opt.binary_output) {
+                std::vector<uint32_t> items((size_t)ncand * 7);
+                for (uint64_t k = 0; k < ncand; ++k) pack_candidate(&cands[k], items.data() + 7 * k);
+                wok = ncand == 0 || fwrite(items.data(), 28, ncand, out) == ncand;
+            } else wok = write_records(out, ncand, 13 * 24, opt.num_threads, [&](char* p, uint64_t k) { return put_candidate(p, cands[k]); });
+            if (!wok) return fail("output", "write failed");
             n_records += ncand;
         }
         necat_free(cands);
@@ -108,8 +129,10 @@ int main(int argc, char** argv)
     }
     if (fclose(out) != 0) return fail("output", "write failed");
     if (rename(tmp_out.c_str(), output) != 0) return fail("output", "rename failed");
+    stage("output closed");
     necat_index_free(ctx, ix);
     necat_volume_free(ctx, ref);
     necat_ctx_destroy(ctx);
+    stage("context destroyed");
     return 0;
 }

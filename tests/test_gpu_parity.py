@@ -414,6 +414,30 @@ def test_extension_in_several_batches(ctx, small):
         assert x.tobytes() == y.tobytes()
 
 
+def test_capped_band_pool_runs_lists_in_chunks(ctx, small, tmp_path, monkeypatch):
+    """NECAT_BAND_POOL_MB (set by the command-line programs: a fresh process pays for every GB of VRAM it touches) caps the
+    band-record pools; a round's list then runs as several DP + walk launches over the same pool.  An 8 MB cap = chunks of
+    128 list-A blocks / 64 list-B blocks: same M4 records as the uncapped run, and the short-read case (long list-B chains)
+    against the oracle."""
+    from necat_amd import capi
+    d, rs = small
+    opt = capi.default_options(**dict(util.FAST, job=1))
+    _, base = capi.pm_main(ctx, opt, 0, d)
+    monkeypatch.setenv("NECAT_BAND_POOL_MB", "8")
+    c = capi.Context(0)
+    try:
+        _, got = capi.pm_main(c, opt, 0, d)
+        assert util.m4_key_rows(got) == util.m4_key_rows(base) and base.shape[0] > 500
+        kw = dict(util.FAST, kmer_size=12, align_size_cutoff=400, num_threads=4)
+        d2, rs2, nv = util.make_dataset(tmp_path, genome=60_000, coverage=40.0, seed=43, err=0.10, mean_len=1350.0, sd_len=200.0, min_len=1000)
+        out, st = _oracle_records(kw, d2, 0, tmp_path, 1, 1)
+        ref = np.frombuffer(open(out, "rb").read(), dtype=capi.M4_DTYPE)
+        _, m4 = capi.pm_main(c, capi.default_options(**dict(kw, job=1)), 0, d2)
+        assert ref.shape[0] > 2000 and util.m4_key_rows(m4) == util.m4_key_rows(ref)
+    finally:
+        c.close()
+
+
 def test_ultra_long_reads(ctx, tmp_path):
     """reads of 60-200 kb (hundreds of 512-bp blocks per alignment, hundreds of extension rounds, long chains in the
     seeding stage): candidates, M4 records and the alignments with their strings equal the oracle's"""

@@ -45,6 +45,38 @@ def test_wave_chain_dp_model_equals_sequential(tmp_path):
     assert " mismatches 0 " in r.stdout
 
 
+def test_record_writer_matches_printf(tmp_path):
+    """host_fmt.h writes the M4 / candidate text lines without printf; its "%.2f" (exact integer rounding) and integer fields
+    must be what printf gives."""
+    src = os.path.join(str(tmp_path), "t.cpp")
+    open(src, "w").write(r'''
+#include "necat_amd/csrc/host_fmt.h"
+#include <random>
+int main() {
+    std::mt19937_64 g(1); long bad = 0, n = 0; char a[512], b[512];
+    auto chk = [&](double x) { *necat_host::put_f2(a, x) = 0; sprintf(b, "%.2f", x); ++n; if (strcmp(a, b)) { if (bad < 10) printf("%.17g: %s vs %s\n", x, a, b); ++bad; } };
+    for (int i = 0; i < 3000000; ++i) chk((double)(g() % 10000001) / 100000.0);
+    for (int i = 0; i < 300000; ++i) { double x = (g() % 100000) / 1000.0 + (g() % 8) * 0.125; chk(x); chk(x * 1e-3); chk(x * 1e-9); chk(100.0 * (double)(g() % 5000) / (double)(1 + g() % 5000)); }
+    for (int i = 0; i <= 10000; ++i) { chk(i / 100.0); chk(i / 100.0 + 0.005); chk(i * 0.125); }
+    chk(0.0); chk(1e-300); chk(99.995); chk(100.0); chk(4e15); chk(-1.5);
+    for (int i = 0; i < 200000; ++i) {
+        necat_m4 m; memset(&m, 0, sizeof m);
+        m.qid = (int)(g() % 2000000) - 5; m.sid = (int)(g() % 2000000); m.ident_perc = (double)(g() % 100001) / 1000.0; m.vscore = (int)(g() % 100000);
+        m.qdir = g() & 1; m.qoff = g() % 100000; m.qend = g() % 100000; m.qsize = g() % 1000000; m.sdir = 0; m.soff = g() >> (g() % 60); m.send = g() % 77; m.ssize = g() % 100000;
+        *necat_host::put_m4(a, m, nullptr, nullptr) = 0;
+        sprintf(b, "%d\t%d\t%.2f\t%d\t%d\t%lu\t%lu\t%lu\t%d\t%lu\t%lu\t%lu\n", m.qid, m.sid, m.ident_perc, m.vscore, m.qdir, m.qoff, m.qend, m.qsize, m.sdir, m.soff, m.send, m.ssize);
+        ++n; if (strcmp(a, b)) { if (bad < 10) printf("%s vs %s", a, b); ++bad; }
+    }
+    printf("%ld checked, %ld bad\n", n, bad);
+    return bad != 0;
+}
+''')
+    exe = os.path.join(str(tmp_path), "t")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", util.ROOT, "-I", os.path.join(util.ROOT, "include"), "-o", exe, src, "-lpthread"], check=True)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+
+
 # ---- the host side of necat_cns_extension_batch (necat_amd/csrc/cns_loop.h): select / replay vs the sequential loop ----
 
 @pytest.fixture(scope="module")
