@@ -131,6 +131,26 @@ NECAT_HD void load64_planes(const u64* bases, i64 g0, int dir, int comp, int e0,
     *hi = even_bits(a >> 1) | (even_bits(b >> 1) << 32);
 }
 
+// The k-mer table as the kernels read it.  Dense: kmer_stats[h] = cnt << 34 | start, the reference layout (4^k entries,
+// 8.6 GB at k = 15, 82 % of them zero at E. coli size).  Sparse (what the LDS-slice build writes): one IdxWord per 64 table
+// entries - which of them are non-zero and where the first of those sits in `compact`, the non-zero entries in hash order.
+// A lookup is a 16-byte load + (for a k-mer that exists) an 8-byte load; 0.27 + 1.5 GB instead of 8.6 GB to write, to
+// exchange between ranks and to hold.
+struct __attribute__((aligned(16))) IdxWord { u64 bits, base; };
+struct IndexView {
+    const u64* dense;
+    const IdxWord* words;
+    const u64* compact;
+    NECAT_HD u64 lookup(u64 h) const
+    {
+        if (dense) return dense[h];
+        const IdxWord w = words[h >> 6];
+        const u64 bit = 1ULL << (h & 63);
+        if (!(w.bits & bit)) return 0ULL;
+        return compact[w.base + (u64)popc64(w.bits & (bit - 1))];
+    }
+};
+
 // lower-bound style search: id of the sequence containing global offset g (packed_db.c:173-189
 // returns the same id for every in-range offset).
 NECAT_HD u64 seq_of_offset(const u64* seq_off, u64 nseq, u64 g)

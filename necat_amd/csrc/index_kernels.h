@@ -413,21 +413,27 @@ NECAT_D void slice_count(const u64* __restrict__ part2, u64 lo, u64 hi, u32* cnt
     __syncthreads();
 }
 
-// kept_tot[s] = number of offset-list entries slice s contributes (k-mers with 1..max_occ occurrences)
-// (+ the same summed per bucket, so that the scan that follows runs over <= 4096 values, not 262 144)
+// kept_tot[s] = number of offset-list entries slice s contributes (k-mers with 1..max_occ occurrences), pres_tot[s] = number of
+// those k-mers = entries of the compact table (+ both summed per bucket, so that the scans that follow run over <= 4096 values,
+// not 262 144)
 __global__ void __launch_bounds__(256)
-k_slice_count(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u32 max_occ, u32* __restrict__ kept_tot, u32* __restrict__ bucket_kept, u32 s0)
+k_slice_count(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u32 max_occ, u32* __restrict__ kept_tot, u32* __restrict__ bucket_kept,
+              u32* __restrict__ pres_tot, u32* __restrict__ bucket_pres, u32 s0)
 {
     __shared__ u32 cnt[kSlice];
-    __shared__ u32 red[4];
+    __shared__ u32 red[4], redp[4];
     const u64 s = (u64)blockIdx.x + s0;           // s0 = first slice of this rank's hash range
     slice_count(part2, sub_start[s], sub_start[s + 1], cnt);
-    u32 sum = 0;
-    for (int i = threadIdx.x; i < kSlice; i += 256) sum += filtered_count(cnt[i], max_occ);
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    u32 sum = 0, pres = 0;
+    for (int i = threadIdx.x; i < kSlice; i += 256) { const u32 c = filtered_count(cnt[i], max_occ); sum += c; pres += c ? 1u : 0u; }
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_down(sum, o); pres += __shfl_down(pres, o); }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = sum; redp[threadIdx.x >> 6] = pres; }
     __syncthreads();
-    if (threadIdx.x == 0) { const u32 t = red[0] + red[1] + red[2] + red[3]; kept_tot[s] = t; if (t) atomicAdd(&bucket_kept[s >> kSubBits], t); }
+    if (threadIdx.x == 0) {
+        const u32 t = red[0] + red[1] + red[2] + red[3], q = redp[0] + redp[1] + redp[2] + redp[3];
+        kept_tot[s] = t; pres_tot[s] = q;
+        if (t) { atomicAdd(&bucket_kept[s >> kSubBits], t); atomicAdd(&bucket_pres[s >> kSubBits], q); }
+    }
 }
 
 // exclusive scan of bucket_kept[nb] (nb <= 4096) -> bucket_base[nb + 1] (u64)
@@ -447,38 +453,43 @@ k_bucket_base(const u32* __restrict__ bucket_kept, u32 nb, u64* __restrict__ buc
     if (threadIdx.x == 1023) bucket_base[nb] = sh[1023];
 }
 
-// kmer_stats of the slice + its part of the offset list (tmp: same layout, order inside a k-mer not yet fixed).
+// The slice's part of the sparse table (IdxWord per 64 entries + the non-zero entries, dev_common.h) and of the offset list (tmp:
+// same layout, order inside a k-mer not yet fixed).
 // The kernel is a chain of short barrier-separated phases, latency bound at full occupancy, so the common case - a slice of at
 // most 2 T records of which at most kLdsTmp are kept - keeps its records in registers from the first load on and ranks inside
 // LDS; anything bigger reloads per phase and ranks through the global tmp array.
 constexpr int kLdsTmp = 2048;
 template <int T>
 __global__ void __launch_bounds__(T)
-k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u32 max_occ, const u64* __restrict__ bucket_base,
-             const u32* __restrict__ kept_tot, u64* __restrict__ kmer_stats, u32* __restrict__ tmp, u64* __restrict__ offset_list, u32 s0, u64 base_add)
+k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u32 max_occ, const u64* __restrict__ bucket_base, const u32* __restrict__ kept_tot,
+             const u64* __restrict__ bucket_cbase, const u32* __restrict__ pres_tot, IdxWord* __restrict__ words, u64* __restrict__ compact,
+             u32* __restrict__ tmp, u64* __restrict__ offset_list, u32 s0, u64 base_add, u64 cbase_add)
 {
-    // s0 / base_add: first slice of this rank's hash range / offset-list entries of the ranks before it (the starts written
-    // here are final: positions in the gathered list; tmp is addressed the same way by a pointer shifted back by base_add)
+    // s0 / base_add / cbase_add: first slice of this rank's hash range / offset-list entries / compact entries of the ranks before it
+    // (the starts and bases written here are final: positions in the gathered arrays; tmp and compact are addressed the same way by
+    // pointers shifted back by base_add / cbase_add)
+    static_assert(kSlice / T == 8, "a thread owns the 8 table entries of one byte of an IdxWord");
     __shared__ u32 cnt[kSlice];      // occurrences per table entry of the slice
     __shared__ u32 cur[kSlice];      // start of the entry's group inside the slice, then its fill cursor
     __shared__ u32 ltmp[kLdsTmp];    // the kept offsets of the slice, grouped by entry (small slices)
-    __shared__ u32 wtot[T / 64];
-    __shared__ u64 s_base;
+    __shared__ u32 wtot[T / 64], ptot[T / 64];
+    __shared__ u64 s_base, s_cbase;
     const u64 s = (u64)blockIdx.x + s0;
     const u64 lo = sub_start[s], hi = sub_start[s + 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool small = hi - lo <= (u64)(2 * T);
-    // the records first: their loads fly while the counters are zeroed and the slice's base is summed
+    // the records first: their loads fly while the counters are zeroed and the slice's bases are summed
     u64 r0 = ~0ULL, r1 = ~0ULL;
     if (small) {
         if (lo + threadIdx.x < hi) r0 = part2[lo + threadIdx.x];
         if (lo + T + threadIdx.x < hi) r1 = part2[lo + T + threadIdx.x];
     }
-    if (wave == T / 64 - 1) {        // the slice's base = its bucket's base + the kept totals of the bucket's earlier slices
+    if (wave == T / 64 - 1) {        // the slice's bases = its bucket's bases + the totals of the bucket's earlier slices
         const u32 j = (u32)s & (kSubs - 1);
-        u64 before = (u32)lane < j ? (u64)kept_tot[(s & ~(u64)(kSubs - 1)) + lane] : 0ULL;
-        for (int o = 32; o > 0; o >>= 1) before += __shfl_down(before, o);
-        if (lane == 0) s_base = bucket_base[s >> kSubBits] + before + base_add;
+        const u64 first = s & ~(u64)(kSubs - 1);
+        u64 before = (u32)lane < j ? (u64)kept_tot[first + lane] : 0ULL, pbefore = (u32)lane < j ? (u64)pres_tot[first + lane] : 0ULL;
+        for (int o = 32; o > 0; o >>= 1) { before += __shfl_down(before, o); pbefore += __shfl_down(pbefore, o); }
+        if (lane == 0) { s_base = bucket_base[s >> kSubBits] + before + base_add; s_cbase = bucket_cbase[s >> kSubBits] + pbefore + cbase_add; }
     }
     for (int i = threadIdx.x; i < kSlice; i += T) cnt[i] = 0;
     __syncthreads();
@@ -489,28 +500,29 @@ k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u
         for (u64 e = lo + threadIdx.x; e < hi; e += T) atomicAdd(&cnt[(u32)(part2[e] >> kOffsetBits) & (kSlice - 1)], 1u);
     }
     __syncthreads();
-    const u64 base = s_base;
-    // exclusive scan of the kept counts: thread t owns entries [E t, E t + E)
+    const u64 base = s_base, cbase = s_cbase;
+    // exclusive scans of the kept counts and of the non-zero entries: thread t owns entries [8 t, 8 t + 8)
     constexpr int E = kSlice / T;
-    u32 c[E], sum = 0;
+    u32 c[E], sum = 0, pres = 0, fb = 0;
 #pragma unroll
-    for (int i = 0; i < E; ++i) { c[i] = filtered_count(cnt[threadIdx.x * E + i], max_occ); sum += c[i]; }
-    u32 incl = sum;
+    for (int i = 0; i < E; ++i) { c[i] = filtered_count(cnt[threadIdx.x * E + i], max_occ); sum += c[i]; if (c[i]) { ++pres; fb |= 1u << i; } }
+    u32 incl = sum, pincl = pres;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-    if (lane == 63) wtot[wave] = incl;
+    for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o), q = __shfl_up(pincl, o); if (lane >= o) { incl += v; pincl += q; } }
+    if (lane == 63) { wtot[wave] = incl; ptot[wave] = pincl; }
     __syncthreads();
-    u32 run = incl - sum, kept_all = 0;
+    u32 run = incl - sum, prun = pincl - pres, kept_all = 0;
 #pragma unroll
-    for (int w = 0; w < T / 64; ++w) { if (w < wave) run += wtot[w]; kept_all += wtot[w]; }
+    for (int w = 0; w < T / 64; ++w) { if (w < wave) { run += wtot[w]; prun += ptot[w]; } kept_all += wtot[w]; }
+    // kmer_stats[h] = cnt<<34 | start for the k-mers that exist and pass the cutoff (lookup_table.c:43-51, :94-113): the non-zero
+    // entries in hash order; the word of 64 entries = the flag bytes of 8 neighbouring threads
+    {
+        u64 bits = (u64)fb << (8 * (lane & 7));
+        bits |= __shfl_xor(bits, 1); bits |= __shfl_xor(bits, 2); bits |= __shfl_xor(bits, 4);
+        if ((lane & 7) == 0) { IdxWord w; w.bits = bits; w.base = cbase + prun; words[s * (kSlice / 64) + (threadIdx.x >> 3)] = w; }
+        u32 at = run; u64 q = cbase + prun;
 #pragma unroll
-    for (int i = 0; i < E; ++i) { cur[threadIdx.x * E + i] = run; run += c[i]; }
-    __syncthreads();
-    // kmer_stats[h] = cnt<<34 | start, 0 for absent / over-represented k-mers (lookup_table.c:43-51, :94-113)
-    u64* stats = kmer_stats + s * kSlice;
-    for (int i = threadIdx.x; i < kSlice; i += T) {
-        const u32 k = filtered_count(cnt[i], max_occ);
-        stats[i] = k ? ((u64)k << kOffsetBits) | (base + cur[i]) : 0ULL;
+        for (int i = 0; i < E; ++i) { cur[threadIdx.x * E + i] = at; if (c[i]) compact[q++] = ((u64)c[i] << kOffsetBits) | (base + at); at += c[i]; }
     }
     __syncthreads();
     if (small && kept_all <= (u32)kLdsTmp) {
@@ -542,6 +554,14 @@ k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u
         if (k > 1) for (u32 j = 0; j < k; ++j) rank += tmp[st + j] < p;
         offset_list[st + rank] = (u64)p;
     }
+}
+
+// the sparse table written out in the reference layout (necat_index_download): dense[h] = kmer_stats[h]
+__global__ void __launch_bounds__(256)
+k_index_expand(IndexView index, u64 n, u64* __restrict__ dense)
+{
+    const u64 nthreads = (u64)gridDim.x * blockDim.x;
+    for (u64 h = (u64)blockIdx.x * blockDim.x + threadIdx.x; h < n; h += nthreads) dense[h] = index.lookup(h);
 }
 
 // NECAT pac (first base of a byte in its top two bits) -> little-endian 2-bit words

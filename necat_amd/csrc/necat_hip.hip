@@ -293,6 +293,21 @@ int necat_index_build_sharded(necat_ctx* ctx, necat_comm* comm, const necat_volu
 }
 
 namespace {
+IndexView index_view(const necat_index* ix)
+{
+    IndexView v; v.dense = ix->kmer_stats; v.words = (const IdxWord*)ix->words; v.compact = ix->compact;
+    return v;
+}
+
+// the table's allocation: the cached one of an earlier index of this context if it is big enough (a fresh hipMalloc of
+// gigabytes costs tens of ms)
+int table_alloc(necat_ctx* ctx, necat_index* ix, size_t bytes)
+{
+    if (ctx->idx_cache[0].p && ctx->idx_cache[0].cap >= bytes) { ix->table = ctx->idx_cache[0].p; ix->stats_cap = ctx->idx_cache[0].cap; ctx->idx_cache[0] = DevBuf(); }
+    else { NECAT_HIP(ctx, hipMalloc(&ix->table, bytes)); ix->stats_cap = bytes; }
+    return NECAT_OK;
+}
+
 // comm != nullptr: this rank builds the slice of the table its hash range covers, then the slices are all-gathered
 int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, int kmer_size, int max_occ, necat_index** out)
 {
@@ -327,8 +342,10 @@ int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
         cnt32 = (u32*)ctx->scratch[SC_CNT32].p;
         partial = (u64*)ctx->scratch[SC_PARTIAL].p;
     }
-    if (ctx->idx_cache[0].p && ctx->idx_cache[0].cap >= T * 8) { ix->kmer_stats = (uint64_t*)ctx->idx_cache[0].p; ix->stats_cap = ctx->idx_cache[0].cap; ctx->idx_cache[0] = DevBuf(); }
-    else { NECAT_HIP(ctx, hipMalloc((void**)&ix->kmer_stats, T * 8)); ix->stats_cap = T * 8; }
+    if (!lds_slices) {      // the dense reference layout (small tables, NECAT_INDEX_LDS=0); the slice build sizes its sparse table later
+        if ((rc = table_alloc(ctx, ix, T * 8))) { delete ix; return rc; }
+        ix->kmer_stats = (uint64_t*)ix->table;
+    }
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
     if (!lds_slices) NECAT_HIP(ctx, hipMemsetAsync(cnt32, 0, T * 4, s));
     const uint64_t nchunks = (ref->nbases + kPosPerThread - 1) / kPosPerThread;
@@ -371,56 +388,72 @@ int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
     if (lds_slices) {
         // ---- second split + one workgroup per 4096-entry slice of the table (index_kernels.h)
         const u64 nsub = (u64)NB * kSubs;
-        if ((rc = buf_ensure(ctx, ctx->scratch[SC_PART2], (ref->nbases + 1) * 8 + (nsub + 1) * 16 + nsub * 4 + 256))) { necat_index_free(ctx, ix); return rc; }
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_PART2], (ref->nbases + 1) * 8 + (nsub + 1) * 16 + nsub * 4 + 256)) ||
+            (rc = buf_ensure(ctx, ctx->scratch[SC_SPLIT2], nsub * 4 + (size_t)(NB + 1) * 8 + (size_t)NB * 4 + 256))) { necat_index_free(ctx, ix); return rc; }
         char* pb = (char*)ctx->scratch[SC_PART2].p;
         u64* d_part2 = (u64*)pb; pb += (ref->nbases + 1) * 8;
         u64* d_sub = (u64*)pb; pb += (nsub + 1) * 8;
         u64* d_bbase = (u64*)pb; pb += (nsub + 1) * 8;          // [NB + 1] used
         u32* d_kept = (u32*)pb;
+        char* qb = (char*)ctx->scratch[SC_SPLIT2].p;            // the same for the non-zero table entries
+        u64* d_cbase = (u64*)qb; qb += (size_t)(NB + 1) * 8;
+        u32* d_pres = (u32*)qb; qb += nsub * 4;
+        u32* d_bpres = (u32*)qb;
         hipLaunchKernelGGL(k_subpart, dim3(NB), dim3(256), 0, s, (const u64*)d_part, (const u64*)d_bstart, NB, d_part2, d_sub);
         NECAT_CHECK_LAUNCH(ctx, "k_subpart");
         NECAT_HIP(ctx, hipMemsetAsync(d_bcnt, 0, (size_t)NB * 4, s));                // reused: kept entries per bucket
+        NECAT_HIP(ctx, hipMemsetAsync(d_bpres, 0, (size_t)NB * 4, s));
         const unsigned nsl = (b_hi - b_lo) * kSubs;                 // slices of this rank's hash range
         const u32 s0 = b_lo * kSubs;
-        hipLaunchKernelGGL(k_slice_count, dim3(nsl), dim3(256), 0, s, (const u64*)d_part2, (const u64*)d_sub, (u32)max_occ, d_kept, d_bcnt, s0);
+        hipLaunchKernelGGL(k_slice_count, dim3(nsl), dim3(256), 0, s, (const u64*)d_part2, (const u64*)d_sub, (u32)max_occ, d_kept, d_bcnt, d_pres, d_bpres, s0);
         NECAT_CHECK_LAUNCH(ctx, "k_slice_count");
         hipLaunchKernelGGL(k_bucket_base, dim3(1), dim3(1024), 0, s, (const u32*)d_bcnt, NB, d_bbase);
+        hipLaunchKernelGGL(k_bucket_base, dim3(1), dim3(1024), 0, s, (const u32*)d_bpres, NB, d_cbase);
         NECAT_CHECK_LAUNCH(ctx, "k_bucket_base");
-        NECAT_HIP(ctx, hipMemcpyAsync(&n_off, d_bbase + NB, 8, hipMemcpyDeviceToHost, s));
+        unsigned long long mine[2] = {0, 0};                        // offset-list entries, non-zero table entries of this rank
+        NECAT_HIP(ctx, hipMemcpyAsync(&mine[0], d_bbase + NB, 8, hipMemcpyDeviceToHost, s));
+        NECAT_HIP(ctx, hipMemcpyAsync(&mine[1], d_cbase + NB, 8, hipMemcpyDeviceToHost, s));
         NECAT_HIP(ctx, hipStreamSynchronize(s));
-        // the slice sizes of all ranks -> where this rank's entries sit in the gathered offset list
-        const uint64_t n_local = n_off;
-        std::vector<unsigned long long> counts(G, n_local);
-        uint64_t base_add = 0;
+        // the sizes of all ranks -> where this rank's entries sit in the gathered offset list / compact table
+        const uint64_t n_local = mine[0];
+        std::vector<unsigned long long> counts(2 * (size_t)G);
+        counts[0] = mine[0]; counts[1] = mine[1];
+        uint64_t base_add = 0, cbase_add = 0, n_comp = mine[1];
+        n_off = mine[0];
         if (sharded) {
-            const unsigned long long mine = n_local;
-            if ((rc = comm::host_allgather(ctx, comm, &mine, counts.data(), 8))) { necat_index_free(ctx, ix); return rc; }
-            n_off = 0;
-            for (int g = 0; g < G; ++g) { if (g < rk) base_add += counts[g]; n_off += counts[g]; }
+            if ((rc = comm::host_allgather(ctx, comm, mine, counts.data(), 16))) { necat_index_free(ctx, ix); return rc; }
+            n_off = 0; n_comp = 0;
+            for (int g = 0; g < G; ++g) { if (g < rk) { base_add += counts[2 * g]; cbase_add += counts[2 * g + 1]; } n_off += counts[2 * g]; n_comp += counts[2 * g + 1]; }
             if (n_off >= (1ULL << 32)) { necat_index_free(ctx, ix); return set_err(ctx, NECAT_ERR_INTERNAL, "ranks disagree on the volume (offset list of %llu entries)", (unsigned long long)n_off); }
         }
-        ix->n_offsets = n_off;
+        ix->n_offsets = n_off; ix->n_compact = n_comp;
+        const size_t words_bytes = (size_t)(T / 64) * sizeof(IdxWord);
+        if ((rc = table_alloc(ctx, ix, words_bytes + (n_comp + 1) * 8))) { necat_index_free(ctx, ix); return rc; }
+        ix->words = ix->table; ix->compact = (uint64_t*)((char*)ix->table + words_bytes);
         if (ctx->idx_cache[1].p && ctx->idx_cache[1].cap >= (n_off + 1) * 8) { ix->offset_list = (uint64_t*)ctx->idx_cache[1].p; ix->offs_cap = ctx->idx_cache[1].cap; ctx->idx_cache[1] = DevBuf(); }
         else { NECAT_HIP(ctx, hipMalloc((void**)&ix->offset_list, (n_off + 1) * 8 + (n_off >> 4))); ix->offs_cap = (n_off + 1) * 8 + (n_off >> 4); }
         if ((rc = buf_ensure(ctx, ctx->scratch[SC_TMPLIST], (n_local + 1) * 4))) { necat_index_free(ctx, ix); return rc; }
         // 512 threads per slice: 4 workgroups (32 waves) per CU instead of 5 x 4 waves with 256 - the kernel is a chain of short
         // barrier-separated phases and needs the waves to hide their latencies (10.6 -> 9.8 ms for the whole build)
         hipLaunchKernelGGL(k_slice_emit<512>, dim3(nsl), dim3(512), 0, s, (const u64*)d_part2, (const u64*)d_sub, (u32)max_occ, (const u64*)d_bbase, (const u32*)d_kept,
-                           ix->kmer_stats, (u32*)ctx->scratch[SC_TMPLIST].p - base_add, ix->offset_list, s0, base_add);
+                           (const u64*)d_cbase, (const u32*)d_pres, (IdxWord*)ix->words, ix->compact,
+                           (u32*)ctx->scratch[SC_TMPLIST].p - base_add, ix->offset_list, s0, base_add, cbase_add);
         NECAT_CHECK_LAUNCH(ctx, "k_slice_emit");
         if (sharded) {
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s));
-            std::vector<comm::Part> ps(G), po(G);
-            uint64_t run = 0;
+            std::vector<comm::Part> pw(G), pc(G), po(G);
+            uint64_t run = 0, crun = 0;
             for (int g = 0; g < G; ++g) {
                 const u64 lo = (u64)g * NB / G, hi = (u64)(g + 1) * NB / G;
-                ps[g].off = (size_t)(lo << pshift) * 8; ps[g].bytes = (size_t)((hi - lo) << pshift) * 8;
-                po[g].off = (size_t)run * 8; po[g].bytes = (size_t)counts[g] * 8; run += counts[g];
+                pw[g].off = (size_t)((lo << pshift) / 64) * sizeof(IdxWord); pw[g].bytes = (size_t)(((hi - lo) << pshift) / 64) * sizeof(IdxWord);
+                pc[g].off = (size_t)crun * 8; pc[g].bytes = (size_t)counts[2 * g + 1] * 8; crun += counts[2 * g + 1];
+                po[g].off = (size_t)run * 8; po[g].bytes = (size_t)counts[2 * g] * 8; run += counts[2 * g];
             }
-            if ((rc = comm::allgatherv_inplace(ctx, comm, ix->kmer_stats, ps, s))) { necat_index_free(ctx, ix); return rc; }
-            ctx->shard_tm.index_exchange_ms += comm->last_ms; ctx->shard_tm.index_exchange_bytes += comm->last_bytes;
-            if ((rc = comm::allgatherv_inplace(ctx, comm, ix->offset_list, po, s))) { necat_index_free(ctx, ix); return rc; }
-            ctx->shard_tm.index_exchange_ms += comm->last_ms; ctx->shard_tm.index_exchange_bytes += comm->last_bytes;
+            for (auto* parts : {&pw, &pc, &po}) {
+                void* basep = parts == &pw ? ix->words : parts == &pc ? (void*)ix->compact : (void*)ix->offset_list;
+                if ((rc = comm::allgatherv_inplace(ctx, comm, basep, *parts, s))) { necat_index_free(ctx, ix); return rc; }
+                ctx->shard_tm.index_exchange_ms += comm->last_ms; ctx->shard_tm.index_exchange_bytes += comm->last_bytes;
+            }
             ctx->shard_tm.index_local_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
         }
     } else {
@@ -481,7 +514,23 @@ int necat_index_download(necat_ctx* ctx, const necat_index* ix, uint64_t* kmer_s
 {
     if (!ctx || !ix) return NECAT_ERR_ARG;
     NECAT_HIP(ctx, hipSetDevice(ctx->device));
-    if (kmer_stats) NECAT_HIP(ctx, hipMemcpy(kmer_stats, ix->kmer_stats, ix->table_entries * 8, hipMemcpyDeviceToHost));
+    if (kmer_stats) {
+        if (ix->kmer_stats) NECAT_HIP(ctx, hipMemcpy(kmer_stats, ix->kmer_stats, ix->table_entries * 8, hipMemcpyDeviceToHost));
+        else {
+            // the sparse table written out in the reference layout, a piece at a time (the dense table need not fit beside everything else)
+            const uint64_t piece = std::min<uint64_t>(ix->table_entries, 1ULL << 27);
+            if (int rc = buf_ensure(ctx, ctx->scratch[SC_CNT32], piece * 8)) return rc;
+            u64* d = (u64*)ctx->scratch[SC_CNT32].p;
+            IndexView v = index_view(ix);
+            for (uint64_t h0 = 0; h0 < ix->table_entries; h0 += piece) {
+                IndexView w = v; w.words = v.words + h0 / 64;       // lookup(h) of the shifted view = the entry h0 + h (h0 is a multiple of 64)
+                hipLaunchKernelGGL(k_index_expand, dim3(grid_for(piece, 256, 1u << 16)), dim3(256), 0, ctx->stream, w, piece, d);
+                NECAT_CHECK_LAUNCH(ctx, "k_index_expand");
+                NECAT_HIP(ctx, hipMemcpyAsync(kmer_stats + h0, d, piece * 8, hipMemcpyDeviceToHost, ctx->stream));
+                NECAT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            }
+        }
+    }
     if (offset_list && ix->n_offsets) NECAT_HIP(ctx, hipMemcpy(offset_list, ix->offset_list, ix->n_offsets * 8, hipMemcpyDeviceToHost));
     return NECAT_OK;
 }
@@ -496,7 +545,7 @@ void necat_index_free(necat_ctx* ctx, necat_index* ix)
         else (void)hipFree(p);
     };
     DevBuf none;
-    give(ix->kmer_stats, ix->stats_cap, ctx ? ctx->idx_cache[0] : none);
+    give(ix->table, ix->stats_cap, ctx ? ctx->idx_cache[0] : none);
     give(ix->offset_list, ix->offs_cap, ctx ? ctx->idx_cache[1] : none);
     delete ix;
 }
@@ -547,7 +596,7 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
     if ((rc = buf_ensure(ctx, ctx->scratch[SC_MISC], (size_t)nreads * 8 + 128))) return rc;
     u32* d_hits = (u32*)ctx->scratch[SC_MISC].p;
     int* d_err = (int*)((char*)ctx->scratch[SC_MISC].p + (((size_t)nreads * 8 + 63) & ~(size_t)63));   // error flag of the seeding kernels
-    hipLaunchKernelGGL(k_seed_hits, dim3(grid_for((u64)nreads * 64, 256)), dim3(256), 0, s, drd, (const u64*)ix->kmer_stats,
+    hipLaunchKernelGGL(k_seed_hits, dim3(grid_for((u64)nreads * 64, 256)), dim3(256), 0, s, drd, index_view(ix),
                        opt->kmer_size, opt->scan_window, 0u, nreads, d_hits);
     NECAT_CHECK_LAUNCH(ctx, "k_seed_hits");
     // pinned host scratch: [hits: 2 u32 per read][order: u32 per read][SeedMeta per read] - pageable copies cost more than the plan
@@ -653,10 +702,10 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
         NECAT_HIP(ctx, hipMemcpyAsync(d_order, order + pos, (size_t)n * 4, hipMemcpyHostToDevice, s));
         NECAT_HIP(ctx, hipMemsetAsync(A.ht_key, 0xFF, ht_tot * 4, s));
         if (g_seed_wave)
-            hipLaunchKernelGGL(k_seed_collect_wave, dim3(2 * n), dim3(64), 0, s, dref, drd, (const u64*)ix->kmer_stats, (const u64*)ix->offset_list,
+            hipLaunchKernelGGL(k_seed_collect_wave, dim3(2 * n), dim3(64), 0, s, dref, drd, index_view(ix), (const u64*)ix->offset_list,
                                P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A, d_nblk, d_err);
         else
-            hipLaunchKernelGGL(k_seed_collect, dim3(grid_for((u64)2 * n, 64)), dim3(64), 0, s, dref, drd, (const u64*)ix->kmer_stats, (const u64*)ix->offset_list,
+            hipLaunchKernelGGL(k_seed_collect, dim3(grid_for((u64)2 * n, 64)), dim3(64), 0, s, dref, drd, index_view(ix), (const u64*)ix->offset_list,
                                P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A, d_nblk, d_err);
         NECAT_CHECK_LAUNCH(ctx, "k_seed_collect");
         hipLaunchKernelGGL(k_seed_eval, dim3(2 * n), dim3(64), 0, s, dref, drd, P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A,

@@ -59,7 +59,13 @@ struct necat_volume {
 struct necat_index {
     int k = 0;
     uint64_t table_entries = 0, n_offsets = 0;
+    // the table: ONE allocation (`table`, stats_cap bytes) holding either the dense reference layout (kmer_stats) or the sparse
+    // one (words: table_entries / 64 IdxWords, then n_compact non-zero entries) - necat::IndexView in dev_common.h
+    void* table = nullptr;
     uint64_t* kmer_stats = nullptr;
+    void* words = nullptr;
+    uint64_t* compact = nullptr;
+    uint64_t n_compact = 0;
     uint64_t* offset_list = nullptr;
     size_t stats_cap = 0, offs_cap = 0;   // allocation sizes in bytes
 };
@@ -120,7 +126,7 @@ enum ScratchId {
     SC_CNT32 = 0, SC_PARTIAL, SC_TMPLIST, SC_MISC,
     SC_SEED_META, SC_SEED_HT, SC_SEED_POOL, SC_SEED_CHAIN, SC_SEED_OUT, SC_SEED_FINAL,
     SC_EXT_TASKS, SC_EXT_LISTS, SC_EXT_FRAG, SC_EXT_MAT, SC_EXT_OPS, SC_EXT_RES, SC_EXT_CAND, SC_SMALL, SC_PART,
-    SC_EXT_COLS, SC_EXT_COLS_OUT, SC_PART2, SC_SEED_ALL, SC_EXT_MATB, SC_EXT_MATB2, SC_EXT_PERM, SC_GATHER, SC_SPLIT,
+    SC_EXT_COLS, SC_EXT_COLS_OUT, SC_PART2, SC_SEED_ALL, SC_EXT_MATB, SC_EXT_MATB2, SC_EXT_PERM, SC_GATHER, SC_SPLIT, SC_SPLIT2,
     SC_COUNT
 };
 

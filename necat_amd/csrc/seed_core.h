@@ -506,7 +506,7 @@ NECAT_HD int find_candidate_for_one_block(SeedScratch& S, SBlock* cur, const Dev
 // collect_seeds (word_finder.c:107-139) incl. extract_hash_values (:66-83) and fill_one_seed (:85-104)
 // for one strand of one read.  Returns the number of touched blocks (pool entries, in first-touch
 // order) or kSeedErrCapacity.
-NECAT_HD int seed_collect_strand(const DevVolume& ref, const u64* kmer_stats, const u64* offset_list,
+NECAT_HD int seed_collect_strand(const DevVolume& ref, const IndexView& index, const u64* offset_list,
                                  const DevVolume& reads, int read_id, int qdir, const SeedParams& P, SeedScratch& S)
 {
     const u64 q_goff = reads.seq_off[read_id];
@@ -524,7 +524,7 @@ NECAT_HD int seed_collect_strand(const DevVolume& ref, const u64* kmer_stats, co
         const u64 x = qdir == 0 ? load32_dir(reads.bases, (i64)q_goff + i, +1, 0)
                                 : load32_dir(reads.bases, (i64)q_goff + L - 1 - i, -1, 1);
         const u64 hash = rev2(x) >> (64 - 2 * k);
-        const u64 st = kmer_stats[hash];                    // extract_kmer_list (lookup_table.c:176)
+        const u64 st = index.lookup(hash);                  // extract_kmer_list (lookup_table.c:176)
         const u64 cnt = st >> kOffsetBits;
         const u64* list = offset_list + (st & kOffsetMask);
         for (u64 kk = 0; kk < cnt; ++kk) {
@@ -569,12 +569,12 @@ NECAT_HD void seed_reset_table(SeedScratch& S, int nblk)
 
 // One strand of one read: word_finder.c:364-412 (find_candidates).  Candidates are appended to S.out
 // with LOCAL ids.  Returns 0 or kSeedErrCapacity.
-NECAT_HD int seed_one_strand(const DevVolume& ref, const u64* kmer_stats, const u64* offset_list,
+NECAT_HD int seed_one_strand(const DevVolume& ref, const IndexView& index, const u64* offset_list,
                              const DevVolume& reads, int read_id, int qdir, const SeedParams& P,
                              SeedScratch& S, int* n_out)
 {
     const int L = (int)(reads.seq_off[read_id + 1] - reads.seq_off[read_id]);
-    const int nblk = seed_collect_strand(ref, kmer_stats, offset_list, reads, read_id, qdir, P, S);
+    const int nblk = seed_collect_strand(ref, index, offset_list, reads, read_id, qdir, P, S);
     if (nblk < 0) return nblk;
     int rc = 0;
     for (int i = 0; i < (P.debug_phase == 1 ? 0 : nblk); ++i) {
@@ -600,13 +600,13 @@ NECAT_HD int seed_finish_read(const SeedParams& P, SeedScratch& S, int n)
 
 // Both strands of one read, scalar.  Returns the number of candidates left in S.out (local ids), or
 // <0 on capacity error.
-NECAT_HD int seed_one_read(const DevVolume& ref, const u64* kmer_stats, const u64* offset_list,
+NECAT_HD int seed_one_read(const DevVolume& ref, const IndexView& index, const u64* offset_list,
                            const DevVolume& reads, int read_id, const SeedParams& P, SeedScratch& S)
 {
     int n = 0;
-    int rc = seed_one_strand(ref, kmer_stats, offset_list, reads, read_id, 0, P, S, &n);
+    int rc = seed_one_strand(ref, index, offset_list, reads, read_id, 0, P, S, &n);
     if (rc < 0) return rc;
-    rc = seed_one_strand(ref, kmer_stats, offset_list, reads, read_id, 1, P, S, &n);
+    rc = seed_one_strand(ref, index, offset_list, reads, read_id, 1, P, S, &n);
     if (rc < 0) return rc;
     return seed_finish_read(P, S, n);
 }

@@ -23,7 +23,7 @@ struct SeedMeta {           // per processed read; strand 0 = FWD, 1 = REV
 };
 
 __global__ void __launch_bounds__(256)
-k_seed_hits(DevVolume reads, const u64* __restrict__ kmer_stats, int k, int z, u32 read_lo, u32 read_hi, u32* __restrict__ hits)
+k_seed_hits(DevVolume reads, IndexView index, int k, int z, u32 read_lo, u32 read_hi, u32* __restrict__ hits)
 {
     const u32 wave = (u32)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
@@ -37,8 +37,8 @@ k_seed_hits(DevVolume reads, const u64* __restrict__ kmer_stats, int k, int z, u
         const int pos = i * z;
         const u64 xf = load32_dir(reads.bases, (i64)g0 + pos, +1, 0);
         const u64 xr = load32_dir(reads.bases, (i64)g0 + L - 1 - pos, -1, 1);
-        hf += (u32)(kmer_stats[rev2(xf) >> (64 - 2 * k)] >> kOffsetBits);
-        hr += (u32)(kmer_stats[rev2(xr) >> (64 - 2 * k)] >> kOffsetBits);
+        hf += (u32)(index.lookup(rev2(xf) >> (64 - 2 * k)) >> kOffsetBits);
+        hr += (u32)(index.lookup(rev2(xr) >> (64 - 2 * k)) >> kOffsetBits);
     }
     for (int o = 32; o > 0; o >>= 1) { hf += __shfl_down(hf, o); hr += __shfl_down(hr, o); }
     if (lane == 0) { hits[2 * (u64)r] = hf; hits[2 * (u64)r + 1] = hr; }
@@ -64,7 +64,7 @@ NECAT_D SeedScratch seed_scratch(const SeedArenas& A, const SeedMeta& m, int str
 // Seed collection: one lane per (read, strand); every lane runs the same loop nest (sampled k-mers x
 // their occurrence lists), so lanes diverge only in trip counts.
 __global__ void __launch_bounds__(64)
-k_seed_collect(DevVolume ref, DevVolume reads, const u64* __restrict__ kmer_stats, const u64* __restrict__ offset_list,
+k_seed_collect(DevVolume ref, DevVolume reads, IndexView index, const u64* __restrict__ offset_list,
                SeedParams P, const u32* __restrict__ order, const SeedMeta* __restrict__ meta, u32 n,
                SeedArenas A, i32* __restrict__ nblk_out, int* __restrict__ err_flag)
 {
@@ -73,7 +73,7 @@ k_seed_collect(DevVolume ref, DevVolume reads, const u64* __restrict__ kmer_stat
     const u32 i = t >> 1;
     const int strand = (int)(t & 1);
     SeedScratch S = seed_scratch(A, meta[i], strand);
-    const int nb = seed_collect_strand(ref, kmer_stats, offset_list, reads, (int)order[i], strand, P, S);
+    const int nb = seed_collect_strand(ref, index, offset_list, reads, (int)order[i], strand, P, S);
     if (nb < 0) atomicExch(err_flag, 1);
     nblk_out[t] = nb < 0 ? 0 : nb;
 }
@@ -92,7 +92,7 @@ k_seed_collect(DevVolume ref, DevVolume reads, const u64* __restrict__ kmer_stat
 //     kept seeds from lower lanes.
 // One chunk costs a handful of dependent memory round trips for 64 seeds instead of 64 x that per lane.
 __global__ void __launch_bounds__(64)
-k_seed_collect_wave(DevVolume ref, DevVolume reads, const u64* __restrict__ kmer_stats, const u64* __restrict__ offset_list,
+k_seed_collect_wave(DevVolume ref, DevVolume reads, IndexView index, const u64* __restrict__ offset_list,
                     SeedParams P, const u32* __restrict__ order, const SeedMeta* __restrict__ meta, u32 n,
                     SeedArenas A, i32* __restrict__ nblk_out, int* __restrict__ err_flag)
 {
@@ -127,7 +127,7 @@ k_seed_collect_wave(DevVolume ref, DevVolume reads, const u64* __restrict__ kmer
             const int pos = kj * z;
             const u64 x = strand == 0 ? load32_dir(reads.bases, (i64)q_goff + pos, +1, 0)
                                       : load32_dir(reads.bases, (i64)q_goff + L - 1 - pos, -1, 1);
-            const u64 st = kmer_stats[rev2(x) >> (64 - 2 * k)];
+            const u64 st = index.lookup(rev2(x) >> (64 - 2 * k));
             cnt = (u32)(st >> kOffsetBits); lst = st & kOffsetMask;
             if (cnt && soff_max != ~0ULL) {
                 u32 lo = 0, hi = cnt;

@@ -140,7 +140,8 @@ int main(int argc, char** argv)
                 if (a.score != b.score) return a.score > b.score; if (a.qdir != b.qdir) return a.qdir < b.qdir;
                 if (a.sid != b.sid) return a.sid < b.sid; if (a.qoff != b.qoff) return a.qoff < b.qoff; return a.soff < b.soff; };
             if (opt.job == 1 || (int)ocv.size() > opt.num_candidates) { std::sort(ocv.begin(), ocv.end(), before); if ((int)ocv.size() > opt.num_candidates) ocv.resize(opt.num_candidates); }
-            int n = seed_one_read(href.dv, ix->kmer_stats, ix->offset_list, hrd->dv, r, P, S);
+            IndexView iv; iv.dense = ix->kmer_stats; iv.words = nullptr; iv.compact = nullptr;
+            int n = seed_one_read(href.dv, iv, ix->offset_list, hrd->dv, r, P, S);
             bool same = n == (int)ocv.size();
             for (int i = 0; same && i < n; ++i) {
                 const DevCand& a = outc[i]; const ora_candidate& b = ocv[i];

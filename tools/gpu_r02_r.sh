@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_shard.py tests/test_gpu_full_size.py -m gpu -x -q 2>&1 | tail -3
+python tools/bench_index.py
+timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-widened 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print(d['ms_per_step'], d['phases_ms_per_step'])"
+NECAT_TRACE=2 timeout 600 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-widened 2>&1 | grep "seeding" | tail -4
