@@ -121,6 +121,11 @@ typedef struct {
 void        necat_default_options(necat_map_options* o);            /* map_options.c:12-28 */
 int         necat_ctx_create(int device_id, necat_ctx** out);
 void        necat_ctx_destroy(necat_ctx* ctx);
+
+/* Release the context's cached device scratch (index-build partitions, seeding arenas, band pools ...); it is allocated again on
+ * demand.  For short-lived processes that build an index once: on MI355X a fresh process pays tens of ms per GB of VRAM that is
+ * still being cleaned after the previous one, so a command-line program keeps its peak small.  (No reference counterpart.) */
+void        necat_ctx_trim(necat_ctx* ctx);
 const char* necat_last_error(const necat_ctx* ctx);
 int         necat_device_name(const necat_ctx* ctx, char* buf, size_t n);
 

@@ -75,7 +75,7 @@ class _CnsResult(C.Structure):
                 ("host_ms", C.c_double)]
 
 EXPORTED_SYMBOLS = [
-    "necat_default_options", "necat_ctx_create", "necat_ctx_destroy", "necat_last_error", "necat_device_name",
+    "necat_default_options", "necat_ctx_create", "necat_ctx_destroy", "necat_ctx_trim", "necat_last_error", "necat_device_name",
     "necat_volume_upload", "necat_volume_free", "necat_index_build", "necat_index_size", "necat_index_download",
     "necat_index_free", "necat_find_candidates", "necat_extend", "necat_map_pair", "necat_onc_align_batch",
     "necat_gapped_strings", "necat_cns_default_options", "necat_cns_load_partition", "necat_cns_extension_batch",
@@ -103,6 +103,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.necat_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.necat_ctx_destroy.argtypes = [vp]
     lib.necat_ctx_destroy.restype = None
+    lib.necat_ctx_trim.argtypes = [vp]
+    lib.necat_ctx_trim.restype = None
     lib.necat_last_error.argtypes = [vp]
     lib.necat_last_error.restype = C.c_char_p
     lib.necat_device_name.argtypes = [vp, C.c_char_p, C.c_size_t]

@@ -149,6 +149,15 @@ void necat_ctx_destroy(necat_ctx* ctx)
     delete ctx;
 }
 
+void necat_ctx_trim(necat_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& b : ctx->scratch) if (b.p) { (void)hipFree(b.p); b = DevBuf(); }
+    for (auto& b : ctx->idx_cache) if (b.p) { (void)hipFree(b.p); b = DevBuf(); }
+}
+
 const char* necat_last_error(const necat_ctx* ctx) { return ctx ? ctx->err : "no context"; }
 
 int necat_device_name(const necat_ctx* ctx, char* buf, size_t n)

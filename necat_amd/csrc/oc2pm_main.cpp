@@ -1,14 +1,16 @@
 // oc2pm - drop-in replacement of NECAT's oc2pm wrapper (pairwise_mapping/main.c:79-118):
 //   oc2pm [options] wrk-dir output
-// For every volume not yet marked wrk-dir/pm<i>.finished, run `oc2pmov <options> wrk-dir i
-// wrk-dir/pm_result_i`, then concatenate the per-volume results in volume order into `output` and
-// delete them.  The child is looked up next to this binary first, then on PATH (as the reference does).
-#include <libgen.h>
+// For every volume not yet marked wrk-dir/pm<i>.finished, do what `oc2pmov <options> wrk-dir i wrk-dir/pm_result_i` does, then
+// concatenate the per-volume results in volume order into `output` and delete them.  The reference forks one oc2pmov per volume;
+// here ONE resident worker process per GPU (NECAT_GPUS=0,1,2,3; default the single device NECAT_GPU or 0) takes volumes from a
+// shared counter and runs their jobs on one context (pm_job.h): HIP start-up, stream creation and pool allocation are paid once
+// per GPU, not once per volume, and the next volume is read from disk while the current one is mapped.
 #include <limits.h>
 #include <unistd.h>
+#include <sys/mman.h>
 #include <sys/wait.h>
 
-#include "host_io.h"
+#include "pm_job.h"
 
 using namespace necat_host;
 
@@ -29,14 +31,9 @@ int main(int argc, char** argv)
     std::string err;
     VolumesInfo vi;
     if (!load_volumes_info(wrk_dir, &vi, &err)) { fprintf(stderr, "[oc2pm] ERROR: %s\n", err.c_str()); return 1; }
-    char self[PATH_MAX];
-    std::string child = "oc2pmov";
-    ssize_t n = readlink("/proc/self/exe", self, sizeof self - 1);
-    if (n > 0) { self[n] = 0; std::string cand = std::string(dirname(self)) + "/oc2pmov"; if (access(cand.c_str(), X_OK) == 0) child = cand; }
     const std::string base = dir_prefix(wrk_dir);
-    // NECAT_GPUS=0,1,2,3 (default: the single device NECAT_GPU or 0): reference volumes are independent
-    // jobs (necat.pl:190-202 sends them to grid nodes), so up to one child per GPU runs at a time,
-    // heaviest volumes first (volume i is mapped against V - i volumes).
+    // reference volumes are independent jobs (necat.pl:190-202 sends them to grid nodes); heaviest first (volume i is mapped
+    // against V - i volumes)
     std::vector<int> gpus;
     if (const char* e = getenv("NECAT_GPUS")) {
         for (const char* p = e; *p;) { gpus.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
@@ -48,52 +45,67 @@ int main(int argc, char** argv)
         snprintf(fin, sizeof fin, "%s/pm%d.finished", wrk_dir, i);            // main.c:55-70
         if (access(fin, F_OK) != 0) todo.push_back(i);
     }
-    std::vector<pid_t> running(gpus.size(), 0);
-    std::vector<int> running_vol(gpus.size(), -1);
-    size_t next = 0, active = 0;
     bool failed = false;
-    auto reap = [&](pid_t pid, int status) {
-        for (size_t g = 0; g < gpus.size(); ++g) if (running[g] == pid) {
-            const int v = running_vol[g];
-            running[g] = 0; running_vol[g] = -1; --active;
-            if (!WIFEXITED(status) || WEXITSTATUS(status) != 0) { fprintf(stderr, "[oc2pm] ERROR: oc2pmov for volume %d failed\n", v); failed = true; }
-            else { char fin[4096]; snprintf(fin, sizeof fin, "%s/pm%d.finished", wrk_dir, v); FILE* f = fopen(fin, "w"); if (f) fclose(f); }
-        }
-    };
-    while ((next < todo.size() && !failed) || active) {
-        bool launched = false;
-        for (size_t g = 0; g < gpus.size() && next < todo.size() && !failed; ++g) {
-            if (running[g]) continue;
-            const int v = todo[next++];
-            char cmd[8192];
-            snprintf(cmd, sizeof cmd, "NECAT_GPU=%d %s %s %s %d %spm_result_%d", gpus[g], child.c_str(), options_to_string(&opt).c_str(), wrk_dir, v, base.c_str(), v);
-            fprintf(stdout, "Running command '%s'\n", cmd);
-            fflush(stdout);
+    if (!todo.empty()) {
+        // the next volume to take, shared by the workers (forked before anything touches HIP)
+        int* counter = (int*)mmap(nullptr, 4096, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+        if (counter == MAP_FAILED) { fprintf(stderr, "[oc2pm] ERROR: mmap failed\n"); return 1; }
+        *counter = 0;
+        const size_t nworkers = std::min(gpus.size(), todo.size());
+        // a worker that runs a single job is as short-lived as oc2pmov: same small band pools (see there)
+        if (todo.size() <= gpus.size()) setenv("NECAT_BAND_POOL_MB", "1024", 0);
+        fflush(stdout); fflush(stderr);
+        std::vector<pid_t> pids;
+        for (size_t g = 0; g < nworkers; ++g) {
             const pid_t pid = fork();
-            if (pid < 0) { fprintf(stderr, "[oc2pm] ERROR: fork failed\n"); return 1; }
-            if (pid == 0) { execl("/bin/sh", "sh", "-c", cmd, (char*)nullptr); _exit(127); }
-            running[g] = pid; running_vol[g] = v; ++active; launched = true;
+            if (pid < 0) { fprintf(stderr, "[oc2pm] ERROR: fork failed\n"); failed = true; break; }
+            if (pid == 0) {
+                const PmTrace tr;
+                necat_ctx* ctx = nullptr;
+                if (necat_ctx_create(gpus[g], &ctx)) { fprintf(stderr, "[oc2pm] ERROR: GPU %d: no usable gfx950 device (libnecat_hip has no CPU fallback)\n", gpus[g]); _exit(1); }
+                tr.stage("context created");
+                int status = 0;
+                for (;;) {
+                    const int idx = __atomic_fetch_add(counter, 1, __ATOMIC_RELAXED);
+                    if (idx >= (int)todo.size()) break;
+                    const int v = todo[idx];
+                    char res[4096], fin[4096];
+                    snprintf(res, sizeof res, "%spm_result_%d", base.c_str(), v);
+                    fprintf(stdout, "Running job 'oc2pmov %s %s %d %s' on GPU %d\n", options_to_string(&opt).c_str(), wrk_dir, v, res, gpus[g]);
+                    fflush(stdout);
+                    if ((status = pm_run_volume(ctx, vi, v, opt, res, "oc2pm", tr))) { fprintf(stderr, "[oc2pm] ERROR: the job of volume %d failed\n", v); break; }
+                    snprintf(fin, sizeof fin, "%s/pm%d.finished", wrk_dir, v);
+                    FILE* f = fopen(fin, "w"); if (f) fclose(f);
+                }
+                necat_ctx_destroy(ctx);
+                fflush(stdout); fflush(stderr);
+                _exit(status ? 1 : 0);
+            }
+            pids.push_back(pid);
         }
-        if (active && !(launched && next < todo.size() && active < gpus.size())) {
+        for (pid_t pid : pids) {
             int status = 0;
-            const pid_t pid = wait(&status);
-            if (pid > 0) reap(pid, status);
+            if (waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) failed = true;
         }
+        munmap(counter, 4096);
     }
     if (failed) return 1;
     FILE* out = fopen(output, "w");
     if (!out) { fprintf(stderr, "[oc2pm] ERROR: cannot open %s\n", output); return 1; }
     std::vector<char> buf(1 << 20);
-    for (int i = 0; i < vi.num_volumes; ++i) {
+    bool wok = true;
+    for (int i = 0; i < vi.num_volumes && wok; ++i) {
         char res[4096];
         snprintf(res, sizeof res, "%spm_result_%d", base.c_str(), i);
         FILE* in = fopen(res, "r");
         if (!in) { fprintf(stderr, "[oc2pm] ERROR: missing %s\n", res); fclose(out); return 1; }
         size_t k;
-        while ((k = fread(buf.data(), 1, buf.size(), in)) > 0) fwrite(buf.data(), 1, k, out);
+        while ((k = fread(buf.data(), 1, buf.size(), in)) > 0) if (fwrite(buf.data(), 1, k, out) != k) { wok = false; break; }
+        if (ferror(in)) wok = false;
         fclose(in);
-        remove(res);
+        if (wok) remove(res);
     }
-    fclose(out);
+    if (fclose(out) != 0) wok = false;
+    if (!wok) { fprintf(stderr, "[oc2pm] ERROR: writing %s failed\n", output); return 1; }
     return 0;
 }

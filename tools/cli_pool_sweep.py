@@ -18,4 +18,4 @@ with tempfile.TemporaryDirectory() as td:
             ts.append(time.perf_counter() - t0)
             last = r.stdout
         print("pool cap %5s MB: %s" % (mb, " ".join("%.3f" % t for t in ts)))
-        print("   " + " | ".join(l.split("ms")[0].split("]")[1].strip() + " " + l.split("ms")[1].strip() for l in last.splitlines() if l.startswith("[oc2pmov]")))
+        print("   " + " | ".join(l.split("ms")[0].split("]")[1].strip() + " " + l.split("ms")[1].strip() for l in last.splitlines() if l.startswith("[pm]")))

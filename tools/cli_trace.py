@@ -17,4 +17,4 @@ with tempfile.TemporaryDirectory() as td:
             dt = time.perf_counter() - t0
             print("oc2pmov -j %d -u %d: %.3f s wall, rc %d, output %d bytes" % (job, binary, dt, r.returncode, os.path.getsize(out)))
             if it == 2:
-                print("\n".join(l for l in r.stdout.splitlines() if l.startswith("[oc2pmov]") or l.startswith("[necat]"))[:6000])
+                print("\n".join(l for l in r.stdout.splitlines() if l.startswith("[pm]") or l.startswith("[necat]"))[:6000])
