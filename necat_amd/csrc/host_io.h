@@ -125,6 +125,11 @@ inline bool load_volume(const char* path, HostVolume* v, std::string* err)
     bool ok = fread(m, 1, ml, in) == ml && memcmp(m, magic, ml) == 0;
     uint64_t ns = 0, nb = 0, hb = 0;
     ok = ok && fread(&ns, 8, 1, in) == 1 && fread(&nb, 8, 1, in) == 1;
+    // the header's sizes are checked against the file before anything is sized by them (a truncated or foreign file is an
+    // error message and exit 1 like every other failure, not a bad_alloc)
+    uint64_t fsize = 0;
+    if (ok) { const long at = ftell(in); ok = at >= 0 && fseek(in, 0, SEEK_END) == 0; if (ok) { fsize = (uint64_t)ftell(in); ok = fseek(in, at, SEEK_SET) == 0; } }
+    ok = ok && ns <= fsize / 32 && nb / 4 <= fsize;
     if (ok) {
         v->offset.resize(ns); v->size.resize(ns); v->hdr_offset.resize(ns);
         for (uint64_t i = 0; ok && i < ns; ++i) {
@@ -133,8 +138,11 @@ inline bool load_volume(const char* path, HostVolume* v, std::string* err)
             v->offset[i] = rec[0]; v->size[i] = rec[1]; v->hdr_offset[i] = rec[2];
         }
     }
-    ok = ok && fread(&hb, 8, 1, in) == 1;
+    ok = ok && fread(&hb, 8, 1, in) == 1 && hb <= fsize;
     if (ok) { v->hdr.resize(hb); ok = hb == 0 || fread(&v->hdr[0], 1, hb, in) == hb; }
+    // names are read through hdr_offset (-i 1): every one must start inside the header block, which must end in a NUL
+    for (uint64_t i = 0; ok && i < ns; ++i) ok = v->hdr_offset[i] < hb;
+    ok = ok && (ns == 0 || hb == 0 || v->hdr[hb - 1] == 0);
     if (ok) { v->pac.resize((nb + 3) / 4 + 8); ok = nb == 0 || fread(v->pac.data(), 1, (nb + 3) / 4, in) == (nb + 3) / 4; }
     fclose(in);
     if (!ok) { *err = std::string("Invalid pac format database: '") + path + "'"; return false; }

@@ -251,27 +251,33 @@ int necat_volume_upload(necat_ctx* ctx, const uint8_t* pac, uint64_t nbases, con
     if (nbases >= (1ULL << 32)) return set_err(ctx, NECAT_ERR_ARG, "volume too large (>= 2^32 bases; oc2mkdb cuts volumes at 2e9, makedb/main.c:8)");
     necat_volume* v = new necat_volume();
     v->nbases = nbases; v->nseq = nseq;
-    const uint64_t nwords = (nbases + 31) / 32;
-    const uint64_t pac_bytes = (nbases + 3) / 4;
-    NECAT_HIP(ctx, hipMalloc((void**)&v->bases_alloc, (nwords + 2 * kGuardWords) * 8));
-    NECAT_HIP(ctx, hipMemsetAsync(v->bases_alloc, 0, (nwords + 2 * kGuardWords) * 8, ctx->stream));
-    v->bases = v->bases_alloc + kGuardWords;
-    if (nwords) {
-        uint64_t* staging = nullptr;
-        NECAT_HIP(ctx, hipMalloc((void**)&staging, nwords * 8));
-        NECAT_HIP(ctx, hipMemsetAsync(staging, 0, nwords * 8, ctx->stream));
-        NECAT_HIP(ctx, hipMemcpyAsync(staging, pac, pac_bytes, hipMemcpyHostToDevice, ctx->stream));
-        hipLaunchKernelGGL(k_repack, dim3(grid_for(nwords, 256, 65536)), dim3(256), 0, ctx->stream, staging, nwords, v->bases);
-        NECAT_CHECK_LAUNCH(ctx, "k_repack");
+    uint64_t* staging = nullptr;
+    // everything allocated so far goes when a step fails (a long-lived context must not leak device memory on an error)
+    auto upload = [&]() -> int {
+        const uint64_t nwords = (nbases + 31) / 32;
+        const uint64_t pac_bytes = (nbases + 3) / 4;
+        NECAT_HIP(ctx, hipMalloc((void**)&v->bases_alloc, (nwords + 2 * kGuardWords) * 8));
+        NECAT_HIP(ctx, hipMemsetAsync(v->bases_alloc, 0, (nwords + 2 * kGuardWords) * 8, ctx->stream));
+        v->bases = v->bases_alloc + kGuardWords;
+        if (nwords) {
+            NECAT_HIP(ctx, hipMalloc((void**)&staging, nwords * 8));
+            NECAT_HIP(ctx, hipMemsetAsync(staging, 0, nwords * 8, ctx->stream));
+            NECAT_HIP(ctx, hipMemcpyAsync(staging, pac, pac_bytes, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_repack, dim3(grid_for(nwords, 256, 65536)), dim3(256), 0, ctx->stream, staging, nwords, v->bases);
+            NECAT_CHECK_LAUNCH(ctx, "k_repack");
+            NECAT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        v->h_seq_off.resize(nseq + 1);
+        for (uint64_t i = 0; i < nseq; ++i) v->h_seq_off[i] = seq_offset[i];
+        v->h_seq_off[nseq] = nbases;
+        NECAT_HIP(ctx, hipMalloc((void**)&v->seq_off, (nseq + 1) * 8));
+        NECAT_HIP(ctx, hipMemcpyAsync(v->seq_off, v->h_seq_off.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
         NECAT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        NECAT_HIP(ctx, hipFree(staging));
-    }
-    v->h_seq_off.resize(nseq + 1);
-    for (uint64_t i = 0; i < nseq; ++i) v->h_seq_off[i] = seq_offset[i];
-    v->h_seq_off[nseq] = nbases;
-    NECAT_HIP(ctx, hipMalloc((void**)&v->seq_off, (nseq + 1) * 8));
-    NECAT_HIP(ctx, hipMemcpyAsync(v->seq_off, v->h_seq_off.data(), (nseq + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    NECAT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return NECAT_OK;
+    };
+    const int rc = upload();
+    if (staging) (void)hipFree(staging);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); necat_volume_free(ctx, v); return rc; }
     *out = v;
     return NECAT_OK;
 }
@@ -317,12 +323,11 @@ int table_alloc(necat_ctx* ctx, necat_index* ix, size_t bytes)
     return NECAT_OK;
 }
 
-// comm != nullptr: this rank builds the slice of the table its hash range covers, then the slices are all-gathered
-int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, int kmer_size, int max_occ, necat_index** out)
+// comm != nullptr: this rank builds the slice of the table its hash range covers, then the slices are all-gathered.
+// `ix` belongs to the caller (index_build_impl), which frees it with everything it holds when a step fails.
+int index_build_body(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, int kmer_size, int max_occ, necat_index* ix)
 {
     const double w0 = wall_ms();
-    if (!ctx || !ref || !out) return NECAT_ERR_ARG;
-    *out = nullptr;
     if (kmer_size < 1 || kmer_size > 15) return set_err(ctx, NECAT_ERR_ARG, "kmer_size %d outside 1..15 (HashBits = 30, lookup_table.h:13)", kmer_size);
     if (max_occ < 0) return set_err(ctx, NECAT_ERR_ARG, "negative kmer_cnt_cutoff");
     NECAT_HIP(ctx, hipSetDevice(ctx->device));
@@ -330,7 +335,6 @@ int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
     const uint64_t T = 1ULL << (2 * kmer_size);
     const uint64_t ntiles = (T + kScanTile - 1) / kScanTile;
     DevVolume vol = dev_view(ref);
-    necat_index* ix = new necat_index();
     ix->k = kmer_size; ix->table_entries = T;
     int rc;
     // partition parameters: buckets of <= 2^18 table entries (1 MB of counters), at most 4096 buckets
@@ -347,12 +351,12 @@ int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
     ctx->shard_tm.index_local_ms = 0; ctx->shard_tm.index_exchange_ms = 0; ctx->shard_tm.index_exchange_bytes = 0;
     u32* cnt32 = nullptr; u64* partial = nullptr;
     if (!lds_slices) {
-        if ((rc = buf_ensure(ctx, ctx->scratch[SC_CNT32], T * 4)) || (rc = buf_ensure(ctx, ctx->scratch[SC_PARTIAL], (ntiles + 1) * 8))) { delete ix; return rc; }
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_CNT32], T * 4)) || (rc = buf_ensure(ctx, ctx->scratch[SC_PARTIAL], (ntiles + 1) * 8))) return rc;
         cnt32 = (u32*)ctx->scratch[SC_CNT32].p;
         partial = (u64*)ctx->scratch[SC_PARTIAL].p;
     }
     if (!lds_slices) {      // the dense reference layout (small tables, NECAT_INDEX_LDS=0); the slice build sizes its sparse table later
-        if ((rc = table_alloc(ctx, ix, T * 8))) { delete ix; return rc; }
+        if ((rc = table_alloc(ctx, ix, T * 8))) return rc;
         ix->kmer_stats = (uint64_t*)ix->table;
     }
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
@@ -363,7 +367,7 @@ int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
     u32 bchunks = 1;
     if (partitioned) {
         if ((rc = buf_ensure(ctx, ctx->scratch[SC_SMALL], (size_t)NB * 4 + (size_t)(NB + 1) * 8 * 2 + 64)) ||
-            (rc = buf_ensure(ctx, ctx->scratch[SC_PART], (ref->nbases + 1) * 8))) { necat_index_free(ctx, ix); return rc; }
+            (rc = buf_ensure(ctx, ctx->scratch[SC_PART], (ref->nbases + 1) * 8))) return rc;
         char* sb = (char*)ctx->scratch[SC_SMALL].p;
         d_bstart = (u64*)sb; sb += (size_t)(NB + 1) * 8; d_bcur = (u64*)sb; sb += (size_t)(NB + 1) * 8; d_bcnt = (u32*)sb;
         d_part = (u64*)ctx->scratch[SC_PART].p;
@@ -374,7 +378,7 @@ int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
         const int bits2 = PB > 6 ? PB - 6 : 0;
         const u32 NC = NB >> bits2;
         if ((rc = buf_ensure(ctx, ctx->scratch[SC_SPLIT], (size_t)(NC + 1) * 8 * kCurStride + (size_t)(NC + 1) * 4 + 64)) ||
-            (bits2 && (rc = buf_ensure(ctx, ctx->scratch[SC_PART2], (ref->nbases + 1) * 8 + ((u64)NB * kSubs + 1) * 16 + (u64)NB * kSubs * 4 + 256)))) { necat_index_free(ctx, ix); return rc; }
+            (bits2 && (rc = buf_ensure(ctx, ctx->scratch[SC_PART2], (ref->nbases + 1) * 8 + ((u64)NB * kSubs + 1) * 16 + (u64)NB * kSubs * 4 + 256)))) return rc;
         u64* d_ccur = (u64*)ctx->scratch[SC_SPLIT].p;
         u32* d_tpre = (u32*)(d_ccur + (size_t)(NC + 1) * kCurStride);
         hipLaunchKernelGGL(k_part_hist, dim3(pgrid), dim3(kPartThreads), NB * 2, s, vol, kmer_size, pshift, NB, b_lo, b_hi, d_bcnt);
@@ -398,7 +402,7 @@ int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
         // ---- second split + one workgroup per 4096-entry slice of the table (index_kernels.h)
         const u64 nsub = (u64)NB * kSubs;
         if ((rc = buf_ensure(ctx, ctx->scratch[SC_PART2], (ref->nbases + 1) * 8 + (nsub + 1) * 16 + nsub * 4 + 256)) ||
-            (rc = buf_ensure(ctx, ctx->scratch[SC_SPLIT2], nsub * 4 + (size_t)(NB + 1) * 8 + (size_t)NB * 4 + 256))) { necat_index_free(ctx, ix); return rc; }
+            (rc = buf_ensure(ctx, ctx->scratch[SC_SPLIT2], nsub * 4 + (size_t)(NB + 1) * 8 + (size_t)NB * 4 + 256))) return rc;
         char* pb = (char*)ctx->scratch[SC_PART2].p;
         u64* d_part2 = (u64*)pb; pb += (ref->nbases + 1) * 8;
         u64* d_sub = (u64*)pb; pb += (nsub + 1) * 8;
@@ -430,18 +434,18 @@ int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
         uint64_t base_add = 0, cbase_add = 0, n_comp = mine[1];
         n_off = mine[0];
         if (sharded) {
-            if ((rc = comm::host_allgather(ctx, comm, mine, counts.data(), 16))) { necat_index_free(ctx, ix); return rc; }
+            if ((rc = comm::host_allgather(ctx, comm, mine, counts.data(), 16))) return rc;
             n_off = 0; n_comp = 0;
             for (int g = 0; g < G; ++g) { if (g < rk) { base_add += counts[2 * g]; cbase_add += counts[2 * g + 1]; } n_off += counts[2 * g]; n_comp += counts[2 * g + 1]; }
-            if (n_off >= (1ULL << 32)) { necat_index_free(ctx, ix); return set_err(ctx, NECAT_ERR_INTERNAL, "ranks disagree on the volume (offset list of %llu entries)", (unsigned long long)n_off); }
+            if (n_off >= (1ULL << 32)) return set_err(ctx, NECAT_ERR_INTERNAL, "ranks disagree on the volume (offset list of %llu entries)", (unsigned long long)n_off);
         }
         ix->n_offsets = n_off; ix->n_compact = n_comp;
         const size_t words_bytes = (size_t)(T / 64) * sizeof(IdxWord);
-        if ((rc = table_alloc(ctx, ix, words_bytes + (n_comp + 1) * 8))) { necat_index_free(ctx, ix); return rc; }
+        if ((rc = table_alloc(ctx, ix, words_bytes + (n_comp + 1) * 8))) return rc;
         ix->words = ix->table; ix->compact = (uint64_t*)((char*)ix->table + words_bytes);
         if (ctx->idx_cache[1].p && ctx->idx_cache[1].cap >= (n_off + 1) * 8) { ix->offset_list = (uint64_t*)ctx->idx_cache[1].p; ix->offs_cap = ctx->idx_cache[1].cap; ctx->idx_cache[1] = DevBuf(); }
         else { NECAT_HIP(ctx, hipMalloc((void**)&ix->offset_list, (n_off + 1) * 8 + (n_off >> 4))); ix->offs_cap = (n_off + 1) * 8 + (n_off >> 4); }
-        if ((rc = buf_ensure(ctx, ctx->scratch[SC_TMPLIST], (n_local + 1) * 4))) { necat_index_free(ctx, ix); return rc; }
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_TMPLIST], (n_local + 1) * 4))) return rc;
         // 512 threads per slice: 4 workgroups (32 waves) per CU instead of 5 x 4 waves with 256 - the kernel is a chain of short
         // barrier-separated phases and needs the waves to hide their latencies (10.6 -> 9.8 ms for the whole build)
         hipLaunchKernelGGL(k_slice_emit<512>, dim3(nsl), dim3(512), 0, s, (const u64*)d_part2, (const u64*)d_sub, (u32)max_occ, (const u64*)d_bbase, (const u32*)d_kept,
@@ -460,7 +464,7 @@ int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
             }
             for (auto* parts : {&pw, &pc, &po}) {
                 void* basep = parts == &pw ? ix->words : parts == &pc ? (void*)ix->compact : (void*)ix->offset_list;
-                if ((rc = comm::allgatherv_inplace(ctx, comm, basep, *parts, s))) { necat_index_free(ctx, ix); return rc; }
+                if ((rc = comm::allgatherv_inplace(ctx, comm, basep, *parts, s))) return rc;
                 ctx->shard_tm.index_exchange_ms += comm->last_ms; ctx->shard_tm.index_exchange_bytes += comm->last_bytes;
             }
             ctx->shard_tm.index_local_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
@@ -487,7 +491,7 @@ int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
     if (ctx->idx_cache[1].p && ctx->idx_cache[1].cap >= (n_off + 1) * 8) { ix->offset_list = (uint64_t*)ctx->idx_cache[1].p; ix->offs_cap = ctx->idx_cache[1].cap; ctx->idx_cache[1] = DevBuf(); }
     else { NECAT_HIP(ctx, hipMalloc((void**)&ix->offset_list, (n_off + 1) * 8 + (n_off >> 4))); ix->offs_cap = (n_off + 1) * 8 + (n_off >> 4); }
     if (n_off) {
-        if ((rc = buf_ensure(ctx, ctx->scratch[SC_TMPLIST], n_off * 8))) { necat_index_free(ctx, ix); return rc; }
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_TMPLIST], n_off * 8))) return rc;
         u64* tmp = (u64*)ctx->scratch[SC_TMPLIST].p;
         if (partitioned) {
             hipLaunchKernelGGL(k_bucket_pass<1>, dim3(NB * bchunks), dim3(256), 0, s, (const u64*)d_part, (const u64*)d_bstart, NB, bchunks, cnt32, n_off, tmp);
@@ -506,6 +510,16 @@ int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
     if (!sharded) ctx->shard_tm.index_local_ms = ctx->tm.index_ms;
     if (g_trace) fprintf(stderr, "[necat] index: events %.2f ms, host wall %.2f ms (local %.2f ms, exchange %.2f ms, %.1f MB received)\n", ctx->tm.index_ms, wall_ms() - w0,
                          ctx->shard_tm.index_local_ms, ctx->shard_tm.index_exchange_ms, ctx->shard_tm.index_exchange_bytes / 1e6);
+    return NECAT_OK;
+}
+
+int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, int kmer_size, int max_occ, necat_index** out)
+{
+    if (!ctx || !ref || !out) return NECAT_ERR_ARG;
+    *out = nullptr;
+    necat_index* ix = new necat_index();
+    const int rc = index_build_body(ctx, comm, ref, kmer_size, max_occ, ix);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); necat_index_free(ctx, ix); return rc; }
     *out = ix;
     return NECAT_OK;
 }

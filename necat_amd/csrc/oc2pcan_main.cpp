@@ -95,10 +95,11 @@ int main(int argc, char** argv)
         FILE* cin = fopen(can_path, "rb");
         if (!cin) { fprintf(stderr, "cannot open %s\n", can_path); return 1; }
         auto in_range = [&](uint32_t id) { return (int64_t)(int32_t)id >= lo && (int64_t)(int32_t)id < hi; };
+        bool wok = true;          // every write is checked: a full disk must not leave short candidates.p<i> files behind exit code 0
         auto put = [&](const Rec& r) {
             std::vector<Rec>& b = buf[(size_t)(((int64_t)(int32_t)r.w[1] - lo) / batch_size)];
             b.push_back(r);
-            if (b.size() >= 65536) { fwrite(b.data(), sizeof(Rec), b.size(), out[&b - buf.data()]); b.clear(); }
+            if (b.size() >= 65536) { wok = fwrite(b.data(), sizeof(Rec), b.size(), out[&b - buf.data()]) == b.size() && wok; b.clear(); }
         };
         size_t n;
         while ((n = fread(in.data(), sizeof(Rec), kChunk, cin)) > 0) {
@@ -109,8 +110,9 @@ int main(int argc, char** argv)
                 if (q_in) put(swapped(r));        // the query is one: the record with the roles exchanged
             }
         }
+        const bool rok = !ferror(cin);
         fclose(cin);
-        bool ok = true;
+        bool ok = wok && rok;
         for (size_t k = 0; k < buf.size(); ++k) {
             if (!buf[k].empty()) ok = fwrite(buf[k].data(), sizeof(Rec), buf[k].size(), out[k]) == buf[k].size() && ok;
             ok = fclose(out[k]) == 0 && ok;
