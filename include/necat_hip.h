@@ -278,9 +278,9 @@ void necat_cns_result_free(necat_cns_result* r);
  * (pm_worker.c:13,354-362; common/map_aux.c:59-77) against one shared lookup table.  The multi-GPU equivalent:
  * one process per GPU (rank), every rank holds the volume,
  *   - the index is built in hash-range slices - rank g counts, filters and ranks only the k-mers whose hash falls
- *     in its range of the 4^k table - and the slices of kmer_stats / offset_list are all-gathered (starts rebased
- *     by the exclusive scan of the slice sizes), so every rank ends up with the COMPLETE reference-layout index:
- *     necat_index_build_sharded;
+ *     in its range of the 4^k table - and the slices of the table / of offset_list are all-gathered (starts already
+ *     final: shifted by the exclusive scan of the slice sizes before they are written), so every rank ends up with the
+ *     COMPLETE index (necat_index_download gives the reference-layout arrays): necat_index_build_sharded;
  *   - the query reads are dealt out in chunks of `chunk_reads` reads, chunk c to rank c % nranks (reads late in the
  *     volume see more subjects - word_finder.c:121-127 - so contiguous ranges would not balance); every read is
  *     processed exactly as on one GPU, so the union of the ranks' records IS the single-GPU record set;
@@ -301,7 +301,7 @@ int  necat_comm_transport(const necat_comm* c, char* buf, size_t n);
 /* wall-clock of the last sharded calls on this rank */
 typedef struct {
     double   index_local_ms;     /* this rank's slice of the build (HIP events) */
-    double   index_exchange_ms;  /* all-gather of the kmer_stats and offset_list slices (wall) */
+    double   index_exchange_ms;  /* all-gather of the table and offset_list slices (wall) */
     uint64_t index_exchange_bytes; /* bytes this rank received */
     double   gather_ms;          /* gather-v of the records on the root (wall) */
     uint64_t gather_bytes;
