@@ -309,6 +309,10 @@ typedef struct {
 } necat_shard_timings;
 int  necat_get_shard_timings(const necat_ctx* ctx, necat_shard_timings* t);
 
+/* Test hook: runs the RCCL transport's call path (librccl opened at run time, communicator, send/recv group on the context's
+ * stream) with ONE rank sending `bytes` bytes to itself, and compares them. */
+int  necat_comm_selftest_rccl(necat_ctx* ctx, uint64_t bytes);
+
 /* necat_index_build with the work split by hash range and the result all-gathered: the returned index is the
  * complete one, bit-identical to necat_index_build's, on every rank.  Collective: every rank of `comm` calls it.
  * (k < 11 - tables that fit the L2 - are simply built whole on every rank.) */

@@ -1431,20 +1431,70 @@ int necat_comm_create(necat_ctx* ctx, int rank, int nranks, necat_host_allgather
         if (want < 0) want = shared ? 1 : 0;
         if (want == 0 && shared) { delete c; return set_err(ctx, NECAT_ERR_COMM, "RCCL cannot run two ranks on one device (use transport \"ipc\")"); }
     }
+    const bool was_auto = want < 0 || !strcmp(t, "auto");
     c->transport = want < 0 ? 0 : want;
     if (c->transport == 0 && nranks > 1) {
-        if ((rc = comm::load_rccl(ctx, c))) { delete c; return rc; }
-        ncclUniqueId id, *ids;
+        // bring RCCL up; every rank reports, and with transport "auto" ANY failure sends all ranks to the IPC transport
+        // (device-to-device copies through HIP IPC handles: the same pull pattern, xGMI underneath) instead of failing the job
+        int ok = comm::load_rccl(ctx, c) == NECAT_OK;
+        ncclUniqueId id;
         std::vector<ncclUniqueId> all_ids(nranks);
-        ids = all_ids.data();
         memset(&id, 0, sizeof id);
-        if (rank == 0) { ncclResult_t r = c->p_GetUniqueId(&id); if (r != ncclSuccess) { delete c; return set_err(ctx, NECAT_ERR_COMM, "ncclGetUniqueId: %s", c->p_GetErrorString(r)); } }
-        if ((rc = comm::host_allgather(ctx, c, &id, ids, sizeof id))) { delete c; return rc; }
-        ncclResult_t r = c->p_CommInitRank(&c->nccl, nranks, ids[0], rank);
-        if (r != ncclSuccess) { const int e = set_err(ctx, NECAT_ERR_COMM, "ncclCommInitRank: %s", c->p_GetErrorString(r)); delete c; return e; }
+        if (ok && rank == 0) { const ncclResult_t r = c->p_GetUniqueId(&id); if (r != ncclSuccess) { set_err(ctx, NECAT_ERR_COMM, "ncclGetUniqueId: %s", c->p_GetErrorString(r)); ok = 0; } }
+        if ((rc = comm::host_allgather(ctx, c, &id, all_ids.data(), sizeof id))) { delete c; return rc; }
+        std::vector<int> oks(nranks, 0);
+        if ((rc = comm::host_allgather(ctx, c, &ok, oks.data(), sizeof(int)))) { delete c; return rc; }
+        bool all_ok = true; for (int v : oks) all_ok = all_ok && v;
+        if (all_ok) {
+            const ncclResult_t r = c->p_CommInitRank(&c->nccl, nranks, all_ids[0], rank);
+            if (r != ncclSuccess) { set_err(ctx, NECAT_ERR_COMM, "ncclCommInitRank: %s", c->p_GetErrorString(r)); ok = 0; c->nccl = nullptr; }
+            if ((rc = comm::host_allgather(ctx, c, &ok, oks.data(), sizeof(int)))) { delete c; return rc; }
+            all_ok = true; for (int v : oks) all_ok = all_ok && v;
+        }
+        if (!all_ok) {
+            if (c->nccl && c->p_CommDestroy) { (void)c->p_CommDestroy(c->nccl); c->nccl = nullptr; }
+            if (!was_auto) { const int e = ok ? set_err(ctx, NECAT_ERR_COMM, "RCCL could not be initialised on another rank") : NECAT_ERR_COMM; delete c; return e; }
+            if (rank == 0) fprintf(stderr, "[necat] RCCL transport unavailable (%s): using HIP IPC copies\n", ok ? "another rank failed" : ctx->err);
+            c->transport = 1;
+        }
     }
     *out = c;
     return NECAT_OK;
+}
+
+// Test hook: the RCCL transport's whole call path in ONE process - librccl opened at run time, a communicator of one rank, a
+// send/recv group to itself on the context's stream - so that it runs on hardware even where a second GPU is not available.
+int necat_comm_selftest_rccl(necat_ctx* ctx, uint64_t bytes)
+{
+    if (!ctx || !bytes) return NECAT_ERR_ARG;
+    NECAT_HIP(ctx, hipSetDevice(ctx->device));
+    necat_comm c;
+    c.rank = 0; c.nranks = 1;
+    int rc = comm::load_rccl(ctx, &c);
+    if (rc) return rc;
+    ncclUniqueId id;
+    NECAT_NCCL(ctx, &c, c.p_GetUniqueId(&id));
+    NECAT_NCCL(ctx, &c, c.p_CommInitRank(&c.nccl, 1, id, 0));
+    unsigned char *a = nullptr, *b = nullptr;
+    std::vector<unsigned char> h(bytes), g(bytes);
+    for (uint64_t i = 0; i < bytes; ++i) h[i] = (unsigned char)(i * 131u + 7u);
+    auto body = [&]() -> int {
+        NECAT_HIP(ctx, hipMalloc((void**)&a, bytes)); NECAT_HIP(ctx, hipMalloc((void**)&b, bytes));
+        NECAT_HIP(ctx, hipMemcpyAsync(a, h.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+        NECAT_HIP(ctx, hipMemsetAsync(b, 0, bytes, ctx->stream));
+        NECAT_NCCL(ctx, &c, c.p_GroupStart());
+        NECAT_NCCL(ctx, &c, c.p_Send(a, bytes, ncclChar, 0, c.nccl, ctx->stream));
+        NECAT_NCCL(ctx, &c, c.p_Recv(b, bytes, ncclChar, 0, c.nccl, ctx->stream));
+        NECAT_NCCL(ctx, &c, c.p_GroupEnd());
+        NECAT_HIP(ctx, hipMemcpyAsync(g.data(), b, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        NECAT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return memcmp(h.data(), g.data(), bytes) ? set_err(ctx, NECAT_ERR_COMM, "RCCL self send/recv returned different bytes") : NECAT_OK;
+    };
+    rc = body();
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    (void)c.p_CommDestroy(c.nccl);
+    return rc;
 }
 
 void necat_comm_destroy(necat_comm* c)

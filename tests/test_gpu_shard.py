@@ -85,3 +85,11 @@ def test_sharded_k15_records(ctx, data, tmp_path):
     assert m1.shape[0] > 300 and util.m4_key_rows(m0) == util.m4_key_rows(m1)
     info = json.load(open(prefix + "_info_0.json"))
     assert info["index_exchange_bytes"] >= (1 << 30) // 64 * 16 // 2        # half of the table's words came from the other rank
+
+
+def test_rccl_transport_call_path_runs(ctx):
+    """The RCCL transport cannot be exercised between ranks on a 1-GPU box (RCCL refuses two ranks on one device; the multi-rank
+    tests above use HIP IPC).  Its call path - librccl opened at run time, ncclGetUniqueId / ncclCommInitRank, an
+    ncclSend / ncclRecv group on the context's stream - runs here with one rank sending to itself."""
+    rc = ctx.lib.necat_comm_selftest_rccl(ctx.h, 1 << 20)
+    assert rc == 0, ctx.lib.necat_last_error(ctx.h).decode()
