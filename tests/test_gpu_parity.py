@@ -438,6 +438,29 @@ def test_capped_band_pool_runs_lists_in_chunks(ctx, small, tmp_path, monkeypatch
         c.close()
 
 
+@pytest.mark.parametrize("knob", ["NECAT_CHAIN_WAVE=0", "NECAT_FAST16=1", "NECAT_WALK=1", "NECAT_FAST=0", "NECAT_SEED_WAVE=0"])
+def test_alternative_kernel_paths_give_the_same_records(ctx, small, monkeypatch, knob):
+    """Code paths kept behind a knob (the lane-0 chain DP, the 16-block / 4-lane NW kernel, the restated walk, the general DP
+    path without the full-block fast path, lane-per-strand seed collection) must stay correct: same candidates and same M4
+    records as the default paths (which the other tests pin to the oracle)."""
+    from necat_amd import capi
+    d, rs = small
+    o1 = capi.default_options(**dict(util.FAST, job=1))
+    o0 = capi.default_options(**dict(util.FAST, job=0))
+    c_base, _ = capi.pm_main(ctx, o0, 0, d)
+    _, m_base = capi.pm_main(ctx, o1, 0, d)
+    name, val = knob.split("=")
+    monkeypatch.setenv(name, val)
+    c = capi.Context(0)          # knobs are read when a context is created
+    try:
+        c_got, _ = capi.pm_main(c, o0, 0, d)
+        _, m_got = capi.pm_main(c, o1, 0, d)
+    finally:
+        c.close()
+    assert c_got.tobytes() == c_base.tobytes() and c_base.shape[0] > 500
+    assert util.m4_key_rows(m_got) == util.m4_key_rows(m_base) and m_base.shape[0] > 500
+
+
 def test_ultra_long_reads(ctx, tmp_path):
     """reads of 60-200 kb (hundreds of 512-bp blocks per alignment, hundreds of extension rounds, long chains in the
     seeding stage): candidates, M4 records and the alignments with their strings equal the oracle's"""
