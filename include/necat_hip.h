@@ -134,6 +134,12 @@ int         necat_device_name(const necat_ctx* ctx, char* buf, size_t n);
 int  necat_volume_upload(necat_ctx* ctx, const uint8_t* pac, uint64_t nbases,
                          const uint64_t* seq_offset, const uint64_t* seq_size, uint64_t nseq,
                          necat_volume** out);
+/* <- pdb_add_one_seq (packed_db.c:229-252) for a whole volume: ASCII bases (A C G T in either case; '-' and every other
+ * character as common/nst_nt4_table.c codes them, OR-ed into the pac byte exactly like the reference) packed on the device.
+ * pac_out (may be NULL): (nbases + 3) / 4 bytes, what oc2mkdb writes after the volume's headers.  out (may be NULL): the
+ * uploaded volume, as necat_volume_upload of those bytes would give. */
+int  necat_volume_pack(necat_ctx* ctx, const char* ascii, uint64_t nbases, const uint64_t* seq_offset,
+                       const uint64_t* seq_size, uint64_t nseq, uint8_t* pac_out, necat_volume** out);
 void necat_volume_free(necat_ctx* ctx, necat_volume* v);
 
 /* Final LookupTable contents (lookup_table.h:6-21): kmer_stats[h] = cnt<<34 | start for k-mers with

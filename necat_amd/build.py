@@ -77,7 +77,7 @@ def build_cli(force: bool = False):
     if force or _stale(OC2PM, ["oc2pm_main.cpp", "pm_job.h", "host_fmt.h", "host_io.h", LIB]):       # one resident worker per GPU runs the volume jobs itself
         _run([_hipcc(), "-O2", "-std=c++17", "-o", OC2PM, "oc2pm_main.cpp", "-L" + CSRC, "-lnecat_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"], cwd=CSRC)
     if force or _stale(OC2MKDB, ["oc2mkdb_main.cpp"]):          # host-only drop-in of the volume writer
-        _run([shutil.which("g++") or "g++", "-O2", "-std=c++17", "-o", OC2MKDB, "oc2mkdb_main.cpp", "-lz"], cwd=CSRC)
+        _run([shutil.which("g++") or "g++", "-O2", "-std=c++17", "-o", OC2MKDB, "oc2mkdb_main.cpp", "-lz", "-ldl"], cwd=CSRC)
     if force or _stale(OC2PCAN, ["oc2pcan_main.cpp"]):          # host-only drop-in of the candidate partitioner
         _run([shutil.which("g++") or "g++", "-O2", "-std=c++17", "-o", OC2PCAN, "oc2pcan_main.cpp"], cwd=CSRC)
     if force or _stale(OC2CNS, ["oc2cns_main.cpp", "cns_consensus.h", "host_io.h", LIB]):   # consensus stage: GPU extension loop + host consensus

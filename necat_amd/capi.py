@@ -76,7 +76,7 @@ class _CnsResult(C.Structure):
 
 EXPORTED_SYMBOLS = [
     "necat_default_options", "necat_ctx_create", "necat_ctx_destroy", "necat_ctx_trim", "necat_last_error", "necat_device_name",
-    "necat_volume_upload", "necat_volume_free", "necat_index_build", "necat_index_size", "necat_index_download",
+    "necat_volume_upload", "necat_volume_pack", "necat_volume_free", "necat_index_build", "necat_index_size", "necat_index_download",
     "necat_index_free", "necat_find_candidates", "necat_extend", "necat_map_pair", "necat_onc_align_batch",
     "necat_gapped_strings", "necat_cns_default_options", "necat_cns_load_partition", "necat_cns_extension_batch",
     "necat_cns_result_free",
@@ -111,6 +111,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.necat_device_name.argtypes = [vp, C.c_char_p, C.c_size_t]
     lib.necat_volume_upload.argtypes = [vp, vp, C.c_uint64, vp, vp, C.c_uint64, C.POINTER(vp)]
     lib.necat_volume_free.argtypes = [vp, vp]
+    lib.necat_volume_pack.argtypes = [vp, C.c_char_p, C.c_uint64, vp, vp, C.c_uint64, vp, C.POINTER(vp)]
     lib.necat_volume_free.restype = None
     lib.necat_index_build.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
     lib.necat_index_size.argtypes = [vp, u64p, u64p]

@@ -564,6 +564,33 @@ k_index_expand(IndexView index, u64 n, u64* __restrict__ dense)
     for (u64 h = (u64)blockIdx.x * blockDim.x + threadIdx.x; h < n; h += nthreads) dense[h] = index.lookup(h);
 }
 
+// ASCII bases -> NECAT pac bytes (pdb_add_one_seq / _set_pac, packed_db.c:229-252, with common/nst_nt4_table.c: A C G T in either
+// case -> 0..3, '-' -> 5, everything else -> 4): the code is OR-ed in at the base's 2-bit slot, first base of a byte in its top
+// bits; codes 4 and 5 spill into the neighbouring slot (or out of the byte) exactly as in the reference.  One thread per pac byte.
+NECAT_D u32 nt4_code(u32 ch)
+{
+    const u32 u = ch & 0xdfu;                  // upper case for letters
+    if (u == 'A') return 0u;
+    if (u == 'C') return 1u;
+    if (u == 'G') return 2u;
+    if (u == 'T') return 3u;
+    return ch == '-' ? 5u : 4u;
+}
+__global__ void __launch_bounds__(256)
+k_pack_ascii(const unsigned char* __restrict__ ascii, u64 nbases, u64 base0, unsigned char* __restrict__ pac)
+{
+    // base0 (a multiple of 4): the first base of this piece within the volume; ascii / pac point at the piece
+    const u64 nthreads = (u64)gridDim.x * blockDim.x;
+    const u64 nbytes = (nbases + 3) / 4;
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < nbytes; j += nthreads) {
+        u32 b = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const u64 i = 4 * j + q; if (i < nbases) b |= nt4_code(ascii[i]) << (6 - 2 * q); }
+        pac[j] = (unsigned char)b;
+    }
+    (void)base0;
+}
+
 // NECAT pac (first base of a byte in its top two bits) -> little-endian 2-bit words
 __global__ void __launch_bounds__(256)
 k_repack(const u64* __restrict__ pac_words, u64 nwords, u64* __restrict__ out)

@@ -282,6 +282,43 @@ int necat_volume_upload(necat_ctx* ctx, const uint8_t* pac, uint64_t nbases, con
     return NECAT_OK;
 }
 
+// oc2mkdb's packing step on the device: ASCII bases -> pac bytes (what the volume file holds) and, when the
+// caller wants it, the resident device volume in the same go.
+int necat_volume_pack(necat_ctx* ctx, const char* ascii, uint64_t nbases, const uint64_t* seq_offset, const uint64_t* seq_size,
+                      uint64_t nseq, uint8_t* pac_out, necat_volume** out)
+{
+    if (!ctx || (nbases && !ascii) || (!pac_out && !out)) return NECAT_ERR_ARG;
+    if (out) *out = nullptr;
+    NECAT_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t pac_bytes = (nbases + 3) / 4;
+    std::vector<uint8_t> own;
+    uint8_t* pac = pac_out;
+    if (!pac) { own.resize(pac_bytes + 8); pac = own.data(); }
+    // pieces of <= 256 M bases: 256 MB of text + 64 MB of pac on the device at a time
+    const uint64_t piece = 1ULL << 28;
+    unsigned char *d_txt = nullptr, *d_pac = nullptr;
+    auto body = [&]() -> int {
+        if (!nbases) return NECAT_OK;
+        const uint64_t cap = std::min(piece, nbases);
+        NECAT_HIP(ctx, hipMalloc((void**)&d_txt, cap)); NECAT_HIP(ctx, hipMalloc((void**)&d_pac, cap / 4 + 8));
+        for (uint64_t b0 = 0; b0 < nbases; b0 += piece) {
+            const uint64_t nb = std::min(piece, nbases - b0);
+            NECAT_HIP(ctx, hipMemcpyAsync(d_txt, ascii + b0, nb, hipMemcpyHostToDevice, ctx->stream));
+            hipLaunchKernelGGL(k_pack_ascii, dim3(grid_for((nb + 3) / 4, 256, 1u << 16)), dim3(256), 0, ctx->stream, d_txt, nb, b0, d_pac);
+            NECAT_CHECK_LAUNCH(ctx, "k_pack_ascii");
+            NECAT_HIP(ctx, hipMemcpyAsync(pac + b0 / 4, d_pac, (nb + 3) / 4, hipMemcpyDeviceToHost, ctx->stream));
+            NECAT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        return NECAT_OK;
+    };
+    int rc = body();
+    if (d_txt) (void)hipFree(d_txt);
+    if (d_pac) (void)hipFree(d_pac);
+    if (rc) return rc;
+    if (out) rc = necat_volume_upload(ctx, pac, nbases, seq_offset, seq_size, nseq, out);
+    return rc;
+}
+
 void necat_volume_free(necat_ctx* ctx, necat_volume* v)
 {
     if (!v) return;

@@ -18,6 +18,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <dlfcn.h>
 
 #include <string>
 #include <vector>
@@ -122,8 +123,34 @@ struct Reader {
 struct SeqInfo { uint64_t offset, size, hdr_offset; int32_t platform; int32_t pad; };   // SequenceInfo, common/packed_db.h:12-18
 static_assert(sizeof(SeqInfo) == 32, "SequenceInfo layout");
 
+// NECAT_MKDB_GPU=1: the 2-bit packing runs on the GPU (necat_volume_pack of libnecat_hip.so, opened at run time so that this
+// program stays usable on a host without one): the volume's text is kept and packed in one go when the volume is written.
+struct GpuPacker {
+    void* lib = nullptr; void* ctx = nullptr;
+    int (*create)(int, void**) = nullptr; void (*destroy)(void*) = nullptr; const char* (*last_error)(const void*) = nullptr;
+    int (*pack)(void*, const char*, uint64_t, const uint64_t*, const uint64_t*, uint64_t, uint8_t*, void**) = nullptr;
+    bool open(std::string* err)
+    {
+        char self[4096]; std::string dir = ".";
+        const ssize_t n = readlink("/proc/self/exe", self, sizeof self - 1);
+        if (n > 0) { self[n] = 0; dir = self; dir = dir.substr(0, dir.find_last_of('/')); }
+        lib = dlopen((dir + "/libnecat_hip.so").c_str(), RTLD_NOW);
+        if (!lib) lib = dlopen("libnecat_hip.so", RTLD_NOW);
+        if (!lib) { *err = std::string("cannot open libnecat_hip.so: ") + dlerror(); return false; }
+        *(void**)&create = dlsym(lib, "necat_ctx_create"); *(void**)&destroy = dlsym(lib, "necat_ctx_destroy");
+        *(void**)&last_error = dlsym(lib, "necat_last_error"); *(void**)&pack = dlsym(lib, "necat_volume_pack");
+        if (!create || !destroy || !last_error || !pack) { *err = "libnecat_hip.so lacks necat_volume_pack"; return false; }
+        const char* dev = getenv("NECAT_GPU");
+        if (create(dev ? atoi(dev) : 0, &ctx)) { *err = "no usable gfx950 device"; return false; }
+        return true;
+    }
+    ~GpuPacker() { if (ctx && destroy) destroy(ctx); }
+};
+
 struct Volume {
     std::vector<uint8_t> pac;
+    std::string text;                 // NECAT_MKDB_GPU=1: the bases as read, packed by the device at dump time
+    GpuPacker* gpu = nullptr;
     uint64_t nbases = 0;
     std::vector<SeqInfo> info;
     std::string hdr;
@@ -133,6 +160,7 @@ struct Volume {
         si.offset = nbases; si.size = seq.size(); si.hdr_offset = hdr.size(); si.platform = kPlatform;
         info.push_back(si);
         hdr.append(name); hdr.push_back('\0');
+        if (gpu) { text.append(seq); nbases += seq.size(); return; }
         if (pac.size() < (nbases + seq.size() + 3) / 4 + 1) pac.resize(((nbases + seq.size() + 3) / 4 + 1) * 2, 0);
         // _set_pac: the code is OR-ed in at the base's 2-bit slot, first base in the top bits; codes 4 and 5 spill
         // into the neighbouring slot (or out of the byte) exactly as in the reference
@@ -144,8 +172,15 @@ struct Volume {
             out[nbases >> 2] = (uint8_t)((kCode.t[p[i]] << 6) | (kCode.t[p[i + 1]] << 4) | (kCode.t[p[i + 2]] << 2) | kCode.t[p[i + 3]]);
         for (; i < n; ++i, ++nbases) out[nbases >> 2] = (uint8_t)(out[nbases >> 2] | (kCode.t[p[i]] << ((~nbases & 3) << 1)));
     }
-    bool dump(const std::string& path) const                            // pdb_dump, packed_db.c:291-315
+    bool dump(const std::string& path)                                  // pdb_dump, packed_db.c:291-315
     {
+        if (gpu) {
+            pac.assign((nbases + 3) / 4 + 8, 0);
+            if (gpu->pack(gpu->ctx, text.data(), nbases, nullptr, nullptr, 0, pac.data(), nullptr)) {
+                fprintf(stderr, "necat_volume_pack: %s\n", gpu->last_error(gpu->ctx));
+                return false;
+            }
+        }
         FILE* out = fopen(path.c_str(), "wb");
         if (!out) return false;
         const uint64_t ns = info.size(), hs = hdr.size(), pb = (nbases + 3) >> 2;
@@ -156,7 +191,7 @@ struct Volume {
         ok = fclose(out) == 0 && ok;
         return ok;
     }
-    void clear() { std::fill(pac.begin(), pac.end(), 0); nbases = 0; info.clear(); hdr.clear(); }
+    void clear() { std::fill(pac.begin(), pac.end(), 0); nbases = 0; info.clear(); hdr.clear(); text.clear(); }
 };
 
 std::string in_dir(const char* wrk_dir, const char* leaf)              // copy_wrk_dir_name, makedb_aux.c:6-10
@@ -181,6 +216,12 @@ int main(int argc, char** argv)
     FILE* vn_out = fopen(in_dir(wrk_dir, "volume_names.txt").c_str(), "w");
     if (!vn_out) { fprintf(stderr, "cannot write %s\n", in_dir(wrk_dir, "volume_names.txt").c_str()); return 1; }
     Volume vol;
+    GpuPacker packer;
+    if (const char* e = getenv("NECAT_MKDB_GPU")) if (atoi(e)) {
+        std::string err;
+        if (!packer.open(&err)) { fprintf(stderr, "NECAT_MKDB_GPU: %s\n", err.c_str()); return 1; }      // asked for the GPU: no silent host packing
+        vol.gpu = &packer;
+    }
     int vid = 0, num_reads = 0, read_start_id = 0;
     auto flush = [&]() -> bool {
         const std::string vname = in_dir(wrk_dir, ("vol" + std::to_string(vid)).c_str());

@@ -121,3 +121,47 @@ def test_oc2mkdb_reproduces_golden_volumes(oc2mkdb, tmp_path, ds):
             assert _masked(p1) == _masked(p2)
     else:
         pytest.skip("volume boundaries of the golden set are not reproducible from one size threshold")
+
+
+@pytest.mark.gpu
+def test_oc2mkdb_device_packing_equals_host_packing(oc2mkdb, tmp_path):
+    """NECAT_MKDB_GPU=1: the 2-bit packing of a volume runs on the GPU (necat_volume_pack).  On the tricky inputs - lower case,
+    N, '-', IUPAC codes whose nst_nt4 codes 4 / 5 spill into the neighbouring 2-bit slot, sequences that start in the middle of
+    a pac byte, several volumes - every output file equals the host-packed one (which test_oc2mkdb_vs_reference pins to the
+    reference's own oc2mkdb)."""
+    d = str(tmp_path)
+    lists = _tricky_inputs(d)
+    for out, env in (("host", {}), ("gpu", {"NECAT_MKDB_GPU": "1"})):
+        r = subprocess.run([oc2mkdb, os.path.join(d, out)] + lists, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           env=dict(os.environ, NECAT_MKDB_VOLSIZE="150000", **env))
+        assert r.returncode == 0, r.stdout
+    _same_dirs(os.path.join(d, "host"), os.path.join(d, "gpu"))
+    assert int(open(os.path.join(d, "gpu", "reads_info.txt")).read().split()[0]) >= 3
+
+
+@pytest.mark.gpu
+def test_volume_pack_gives_the_uploaded_volume(ctx, tmp_path):
+    """necat_volume_pack(text) = necat_volume_upload(host-packed pac): the same index comes out of both volumes"""
+    import ctypes as C
+    from necat_amd import capi
+    rng = np.random.default_rng(9)
+    sizes = rng.integers(300, 4000, 60).astype(np.uint64)
+    offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.uint64)
+    codes = rng.integers(0, 4, int(sizes.sum()), dtype=np.uint8)
+    text = bytes(b"ACGT"[c] for c in codes)
+    pac = np.zeros((len(text) + 3) // 4 + 8, dtype=np.uint8)
+    vol = C.c_void_p()
+    rc = ctx.lib.necat_volume_pack(ctx.h, text, len(text), offs.ctypes.data_as(C.c_void_p), sizes.ctypes.data_as(C.c_void_p), len(sizes),
+                                   pac.ctypes.data_as(C.c_void_p), C.byref(vol))
+    assert rc == 0, ctx.lib.necat_last_error(ctx.h).decode()
+    want = synth.pack_2bit(codes)
+    assert pac[:want.shape[0]].tobytes() == want.tobytes()
+    v2 = ctx.upload_volume(want, len(text), offs, sizes)
+    ix2 = ctx.build_index(v2, 11, 100)
+    a2 = ix2.download()
+    ix2.free(); v2.free()
+    v1 = capi.Volume(ctx, vol, len(text), offs.astype(np.int64), sizes.astype(np.int64))
+    ix1 = ctx.build_index(v1, 11, 100)
+    a1 = ix1.download()
+    ix1.free(); v1.free()
+    assert all(np.array_equal(x, y) for x, y in zip(a1, a2))
