@@ -279,6 +279,16 @@ int  necat_cns_extension_batch(necat_ctx* ctx, const necat_volume* reads, const 
                                const necat_cns_options* opt, necat_cns_result** out);
 void necat_cns_result_free(necat_cns_result* r);
 
+/* ---- the candidate partitioner of the consensus stage ------------------------------------------
+ * <- partition_candidates/pcan.c:39-103 for candidates that are still in this process (what necat_find_candidates just
+ * returned), instead of the write + read of the candidates file: every candidate is offered as it is (template = its subject)
+ * and with the roles exchanged (change_pcan_roles, common/gapped_candidate.c:54-69); partition i holds the records whose
+ * template id lies in [i * batch_size, (i + 1) * batch_size), i < num_parts = ceil(num_reads / batch_size).  Outputs (necat_free
+ * both): records = 28-byte PackedGappedCandidate records (7 x uint32), grouped by partition, in no particular order inside one
+ * (as in the reference); part_off[num_parts + 1] in records. */
+int  necat_pcan_partition(necat_ctx* ctx, const necat_candidate* cands, uint64_t n, int batch_size, int num_reads,
+                          uint32_t** records, uint64_t** part_off, int* num_parts);
+
 /* ---- one reference volume on several GPUs (fine granularity) -------------------------------------
  * The reference parallelises ONE volume over threads that pull 500-read chunks from a counter
  * (pm_worker.c:13,354-362; common/map_aux.c:59-77) against one shared lookup table.  The multi-GPU equivalent:

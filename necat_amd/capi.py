@@ -80,7 +80,7 @@ EXPORTED_SYMBOLS = [
     "necat_index_free", "necat_find_candidates", "necat_extend", "necat_map_pair", "necat_onc_align_batch",
     "necat_gapped_strings", "necat_cns_default_options", "necat_cns_load_partition", "necat_cns_extension_batch",
     "necat_cns_result_free",
-    "necat_edlib_align_batch", "necat_get_timings", "necat_free",
+    "necat_edlib_align_batch", "necat_get_timings", "necat_free", "necat_pcan_partition",
     "necat_comm_create", "necat_comm_destroy", "necat_comm_transport", "necat_get_shard_timings", "necat_comm_selftest_rccl",
     "necat_index_build_sharded", "necat_find_candidates_sharded", "necat_map_pair_sharded",
 ]
@@ -105,6 +105,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.necat_ctx_destroy.restype = None
     lib.necat_ctx_trim.argtypes = [vp]
     lib.necat_ctx_trim.restype = None
+    lib.necat_pcan_partition.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]
     lib.necat_comm_selftest_rccl.argtypes = [vp, C.c_uint64]
     lib.necat_last_error.argtypes = [vp]
     lib.necat_last_error.restype = C.c_char_p

@@ -106,6 +106,31 @@ int main(int argc, char** argv)
         if (wok) remove(res);
     }
     if (fclose(out) != 0) wok = false;
+    // NECAT_PM_PARTITIONS=<batch size> (-j 0): the jobs also wrote their share of the consensus partitions (pm_job.h); merged
+    // here into <output>.p<i> + <output>.partitions, the files oc2pcan would make from <output>
+    const int pcan_batch = (opt.job == 0 && getenv("NECAT_PM_PARTITIONS")) ? atoi(getenv("NECAT_PM_PARTITIONS")) : 0;
+    if (pcan_batch > 0 && wok) {
+        const int np = (vi.num_reads + pcan_batch - 1) / pcan_batch;
+        for (int p = 0; p < np && wok; ++p) {
+            const std::string dst = std::string(output) + ".p" + std::to_string(p);
+            FILE* po = fopen(dst.c_str(), "wb");
+            if (!po) { wok = false; break; }
+            for (int i = 0; i < vi.num_volumes && wok; ++i) {
+                const std::string src = base + "pm_result_" + std::to_string(i) + ".p" + std::to_string(p);
+                FILE* in = fopen(src.c_str(), "rb");
+                if (!in) continue;                       // no record of that volume in this partition
+                size_t k;
+                while ((k = fread(buf.data(), 1, buf.size(), in)) > 0) if (fwrite(buf.data(), 1, k, po) != k) { wok = false; break; }
+                if (ferror(in)) wok = false;
+                fclose(in);
+                if (wok) remove(src.c_str());
+            }
+            if (fclose(po) != 0) wok = false;
+        }
+        FILE* pn = fopen((std::string(output) + ".partitions").c_str(), "w");       // dump_num_partitions, pcan_aux.c:42-51
+        if (!pn || fprintf(pn, "%d\n", np) < 0) wok = false;
+        if (pn && fclose(pn) != 0) wok = false;
+    }
     if (!wok) { fprintf(stderr, "[oc2pm] ERROR: writing %s failed\n", output); return 1; }
     return 0;
 }

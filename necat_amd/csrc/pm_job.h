@@ -46,6 +46,9 @@ inline int pm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const n
     FILE* out = fopen(tmp_out.c_str(), "w");
     if (!out) return fail("output", "cannot open for writing");
     const int ref_start = vi.read_start_id[vid];
+    const int pcan_batch = (opt.job == 0 && getenv("NECAT_PM_PARTITIONS")) ? atoi(getenv("NECAT_PM_PARTITIONS")) : 0;
+    if (pcan_batch > 0)      // this job's partition files are appended to: start from nothing
+        for (int p = 0; p < (vi.num_reads + pcan_batch - 1) / pcan_batch; ++p) remove((std::string(output) + ".p" + std::to_string(p)).c_str());
     // the next volume is read from disk while this one is mapped
     struct Loaded { HostVolume v; bool ok = false; std::string err; };
     auto load_async = [&](int i) {
@@ -102,6 +105,24 @@ inline int pm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const n
                 status = fail("necat_find_candidates", necat_last_error(ctx));
             else {
                 tr.stage("candidates found", i, vid);
+                // NECAT_PM_PARTITIONS=<batch size>: the consensus stage's partitions (oc2pcan's candidates.p<i>) straight from the
+                // candidates of this job, partitioned on the device (necat_pcan_partition) - the pipeline can then skip oc2pcan's
+                // write + read of the whole candidates file
+                if (pcan_batch > 0) {
+                    uint32_t* recs = nullptr; uint64_t* poff = nullptr; int np = 0;
+                    if ((rc = necat_pcan_partition(ctx, cands, ncand, pcan_batch, vi.num_reads, &recs, &poff, &np)))
+                        status = fail("necat_pcan_partition", necat_last_error(ctx));
+                    else {
+                        for (int p = 0; p < np && wok; ++p) {
+                            if (poff[p + 1] == poff[p]) continue;
+                            FILE* pf = fopen((std::string(output) + ".p" + std::to_string(p)).c_str(), "ab");
+                            wok = pf && fwrite(recs + 7 * poff[p], 28, poff[p + 1] - poff[p], pf) == poff[p + 1] - poff[p];
+                            if (pf && fclose(pf) != 0) wok = false;
+                        }
+                        tr.stage("partitions written", i, vid);
+                    }
+                    necat_free(recs); necat_free(poff);
+                }
                 if (opt.binary_output) {
                     std::vector<uint32_t> items((size_t)ncand * 7);
                     for (uint64_t k = 0; k < ncand; ++k) pack_candidate(&cands[k], items.data() + 7 * k);

@@ -78,3 +78,33 @@ def test_oc2pcan_single_partition_is_role_swap(oc2pcan, tmp_path):
     # a missing work directory is an error, not an empty result
     r = subprocess.run([oc2pcan, os.path.join(str(tmp_path), "nowhere"), can], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ds,batch", [("vols_b", 100), ("vols_b", 37), ("vols_a", 100000)])
+def test_oc2pm_writes_the_partitions_oc2pcan_would(oc2pcan, tmp_path, ds, batch):
+    """NECAT_PM_PARTITIONS=<batch size>: `oc2pm -j 0 -u 1` partitions the candidates of every job on the device
+    (necat_pcan_partition) and leaves <output>.p<i> + <output>.partitions next to <output>.  They must hold what oc2pcan makes
+    from <output> (same file set, same records per partition; the order inside a file is free in the reference too)."""
+    pmov, pm = build.build_cli()
+    wrk = util.install_golden_volumes(ds, tmp_path)
+    o = ora.options(**dict(util.FAST, kmer_size=13, job=0, binary_output=1, num_threads=2))
+    out = os.path.join(str(tmp_path), "cands.bin")
+    r = subprocess.run([pm] + ora.opt_argv(o) + [wrk, out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       env=dict(os.environ, NECAT_PM_PARTITIONS=str(batch)))
+    assert r.returncode == 0, r.stderr
+    ref = os.path.join(str(tmp_path), "ref")
+    os.makedirs(ref)
+    shutil.copy(out, os.path.join(ref, "cands.bin"))
+    r = subprocess.run([oc2pcan, "-p", str(batch), "-f", "7", wrk, os.path.join(ref, "cands.bin")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    n = int(open(os.path.join(ref, "cands.bin.partitions")).read())
+    assert int(open(out + ".partitions").read()) == n and n >= 1
+    total = 0
+    for p in range(n):
+        want = _records(os.path.join(ref, "cands.bin.p%d" % p))
+        got = _records(out + ".p%d" % p) if os.path.exists(out + ".p%d" % p) else []
+        assert got == want, "partition %d" % p
+        total += len(got)
+    assert total > 100
+    assert not [f for f in os.listdir(wrk) if f.startswith("pm_result_")]
