@@ -62,7 +62,7 @@ int g_sort_b;          // NECAT_SORT_B=0 disables the size sort of list B
 int g_cns_spec_extra, g_cns_spec_cover;   // NECAT_CNS_SPEC_EXTRA / NECAT_CNS_SPEC: speculation width of the consensus loop
 int g_fast;            // NECAT_FAST=0: the list-A DP kernel never takes its full-block fast path (A/B measurements); 2: fast path without band stores (profiling only, results invalid)
 int g_fast16;          // NECAT_FAST16=1: list A's big rounds through k_myers_a16 (16 full blocks per workgroup: SHW 8 lanes, NW 4 lanes per block)
-size_t g_band_pool;    // NECAT_BAND_POOL_MB: cap of one band-record pool; a round's list then runs in several DP + walk launches (0 = whole list)
+size_t g_band_pool;    // NECAT_BAND_POOL_MB (default 16384): cap of one band-record pool; a bigger list runs in several DP + walk launches (0 = no cap)
 int g_walk;            // NECAT_WALK=0: k_traceback runs the reference formulation of the walk (A/B measurements)
 int g_dbg;             // NECAT_DBG: profiling-only variants of the lane-per-block DP kernel (1 = no band stores, 2 = no NW pass)
 
@@ -81,7 +81,7 @@ void read_knobs()
     g_sort_b = (int)num("NECAT_SORT_B", 1);
     g_dbg = (int)num("NECAT_DBG", 0);
     g_fast = (int)num("NECAT_FAST", 1);
-    g_band_pool = (size_t)num("NECAT_BAND_POOL_MB", 0) << 20;
+    g_band_pool = (size_t)num("NECAT_BAND_POOL_MB", 16384) << 20;   // 16 GB = 250 k list-A blocks per launch: as efficient as the whole list, and the first call does not allocate 50 - 100 GB
     g_fast16 = (int)num("NECAT_FAST16", 0);      // measured: no gain on the bench workload, off by default
     g_walk = (int)num("NECAT_WALK", 0);      // 0: reference formulation (default until the restated walk wins), 1: walk_block, 2: walk_block without record prefetch
     g_cns_spec_extra = getenv("NECAT_CNS_SPEC_EXTRA") ? atoi(getenv("NECAT_CNS_SPEC_EXTRA")) : 1;
