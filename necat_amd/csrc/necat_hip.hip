@@ -751,7 +751,7 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
         i32* d_ncand = (i32*)mb; mb += (size_t)n * 4;
         i32* d_nstrand = (i32*)mb;
         SeedArenas A;
-        A.ht_key = (i32*)ctx->scratch[SC_SEED_HT].p; A.ht_val = A.ht_key + ht_tot;
+        A.ht = (u64*)ctx->scratch[SC_SEED_HT].p;
         A.pool = (SBlock*)ctx->scratch[SC_SEED_POOL].p;
         char* cb = (char*)ctx->scratch[SC_SEED_CHAIN].p;
         A.cs = (u64*)cb; cb += chain_tot * 8;
@@ -761,7 +761,7 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
         A.out = (DevCand*)ctx->scratch[SC_SEED_OUT].p;
         NECAT_HIP(ctx, hipMemcpyAsync(d_meta, meta, n * sizeof(SeedMeta), hipMemcpyHostToDevice, s));
         NECAT_HIP(ctx, hipMemcpyAsync(d_order, order + pos, (size_t)n * 4, hipMemcpyHostToDevice, s));
-        NECAT_HIP(ctx, hipMemsetAsync(A.ht_key, 0xFF, ht_tot * 4, s));
+        NECAT_HIP(ctx, hipMemsetAsync(A.ht, 0xFF, ht_tot * 8, s));
         if (g_seed_wave)
             hipLaunchKernelGGL(k_seed_collect_wave, dim3(2 * n), dim3(64), 0, s, dref, drd, index_view(ix), (const u64*)ix->offset_list,
                                P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A, d_nblk, d_err);

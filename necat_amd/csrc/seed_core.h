@@ -37,8 +37,7 @@ struct SeedParams {
 };
 
 struct SeedScratch {      // all per-lane, sized from the lane's hit bound H (see seed.hip)
-    i32* ht_key;          // [ht_mask+1], -1 = empty
-    i32* ht_val;
+    u64* ht;              // [ht_mask+1] open addressing: block id (low word) | pool slot << 32, all ones = empty - one load per probe
     u32 ht_mask;
     SBlock* pool;         // [H]
     u32 pool_cap;
@@ -55,14 +54,17 @@ constexpr int kSeedErrCapacity = -1;
 
 NECAT_HD u32 ht_hash(i32 key, u32 mask) { return ((u32)key * 2654435761u) & mask; }
 
+constexpr u64 kHtEmpty = ~0ULL;
+NECAT_HD u64 ht_entry(i32 block_id, i32 slot) { return (u64)(u32)block_id | ((u64)(u32)slot << 32); }
+
 NECAT_HD SBlock* sb_find(const SeedScratch& S, i32 block_id)
 {
     if (block_id < 0) return nullptr;
     u32 h = ht_hash(block_id, S.ht_mask);
     for (;;) {
-        i32 kx = S.ht_key[h];
-        if (kx == block_id) return S.pool + S.ht_val[h];
-        if (kx == -1) return nullptr;
+        const u64 e = S.ht[h];
+        if ((i32)(u32)e == block_id && e != kHtEmpty) return S.pool + (u32)(e >> 32);
+        if (e == kHtEmpty) return nullptr;
         h = (h + 1) & S.ht_mask;
     }
 }
@@ -536,15 +538,15 @@ NECAT_HD int seed_collect_strand(const DevVolume& ref, const IndexView& index, c
             u32 h = ht_hash(blk_id, S.ht_mask);
             SBlock* sb = nullptr;
             for (;;) {
-                const i32 kx = S.ht_key[h];
-                if (kx == blk_id) { sb = S.pool + S.ht_val[h]; break; }
-                if (kx == -1) break;
+                const u64 e = S.ht[h];
+                if (e == kHtEmpty) break;
+                if ((i32)(u32)e == blk_id) { sb = S.pool + (u32)(e >> 32); break; }
                 h = (h + 1) & S.ht_mask;
             }
             if (!sb) {
                 if ((u32)nblk >= S.pool_cap) return kSeedErrCapacity;
                 sb = S.pool + nblk;
-                S.ht_key[h] = blk_id; S.ht_val[h] = nblk;
+                S.ht[h] = ht_entry(blk_id, nblk);
                 sb->score = 0; sb->last_kmer_id = -1; sb->block_id = blk_id; sb->stale = 0; sb->slot = (i32)h;
                 ++nblk;
             }
@@ -564,7 +566,7 @@ NECAT_HD int seed_collect_strand(const DevVolume& ref, const IndexView& index, c
 // clear_WordFindData (word_finder.c:40-52): only touched blocks are reset
 NECAT_HD void seed_reset_table(SeedScratch& S, int nblk)
 {
-    for (int i = 0; i < nblk; ++i) S.ht_key[S.pool[i].slot] = -1;
+    for (int i = 0; i < nblk; ++i) S.ht[S.pool[i].slot] = kHtEmpty;
 }
 
 // One strand of one read: word_finder.c:364-412 (find_candidates).  Candidates are appended to S.out

@@ -45,7 +45,7 @@ k_seed_hits(DevVolume reads, IndexView index, int k, int z, u32 read_lo, u32 rea
 }
 
 struct SeedArenas {
-    i32* ht_key; i32* ht_val; SBlock* pool;
+    u64* ht; SBlock* pool;
     u64* cs; i32* f; i32* p; i32* t; i32* v; u64* u; DevCand* lcan;
     DevCand* out;
 };
@@ -53,7 +53,7 @@ struct SeedArenas {
 NECAT_D SeedScratch seed_scratch(const SeedArenas& A, const SeedMeta& m, int strand)
 {
     SeedScratch S;
-    S.ht_key = A.ht_key + m.ht_off[strand]; S.ht_val = A.ht_val + m.ht_off[strand]; S.ht_mask = m.ht_mask[strand];
+    S.ht = A.ht + m.ht_off[strand]; S.ht_mask = m.ht_mask[strand];
     S.pool = A.pool + m.pool_off[strand]; S.pool_cap = m.pool_cap[strand];
     S.cs = A.cs + m.chain_off; S.f = A.f + m.chain_off; S.p = A.p + m.chain_off; S.t = A.t + m.chain_off;
     S.v = A.v + m.chain_off; S.u = A.u + m.chain_off; S.lcan = A.lcan + m.chain_off; S.cs_cap = m.cs_cap;
@@ -176,18 +176,26 @@ k_seed_collect_wave(DevVolume ref, DevVolume reads, IndexView index, const u64* 
             }
             // ---- block lookup / creation by the first seed of every block
             const bool is_first = cand && rank == 0;
-            // (keys are inserted with L2 atomics: probe with agent-scope loads so a stale L1 line is never read)
-            auto probe = [&](i32 key, u32& hh) -> i32 {
-                hh = ht_hash(key, S.ht_mask);
-                for (;;) {
-                    const i32 kx = __hip_atomic_load(&S.ht_key[hh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (kx == key) return S.ht_val[hh];
-                    if (kx == -1) return -1;
-                    hh = (hh + 1) & S.ht_mask;
+            // (entries are inserted with L2 atomics: probed with agent-scope loads so that a stale L1 line is never read)
+            // the first seed of a block looks the block up; every candidate looks up the LEFT neighbour too (its score goes into
+            // the stale pair score written with the block's last kept seed): both first loads fly together.  A neighbour created
+            // by this very chunk may be missed here - it has no seeds yet, which is what a miss counts as.
+            i32 idx = -1, ip = -1; u32 h = 0;
+            {
+                u32 hp = 0;
+                const bool want_own = is_first, want_prev = cand && blk > 0;
+                u64 e_own = kHtEmpty, e_prev = kHtEmpty;
+                if (want_own) { h = ht_hash(blk, S.ht_mask); e_own = __hip_atomic_load(&S.ht[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                if (want_prev) { hp = ht_hash(blk - 1, S.ht_mask); e_prev = __hip_atomic_load(&S.ht[hp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                if (want_own) {
+                    while (e_own != kHtEmpty && (i32)(u32)e_own != blk) { h = (h + 1) & S.ht_mask; e_own = __hip_atomic_load(&S.ht[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    idx = e_own == kHtEmpty ? -1 : (i32)(u32)(e_own >> 32);
                 }
-            };
-            i32 idx = -1; u32 h = 0;
-            if (is_first) idx = probe(blk, h);
+                if (want_prev) {
+                    while (e_prev != kHtEmpty && (i32)(u32)e_prev != blk - 1) { hp = (hp + 1) & S.ht_mask; e_prev = __hip_atomic_load(&S.ht[hp], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                    ip = e_prev == kHtEmpty ? -1 : (i32)(u32)(e_prev >> 32);
+                }
+            }
             const bool create = is_first && idx < 0;
             const u64 crm = __ballot(create);
             const int ncreate = popc64(crm);
@@ -195,25 +203,23 @@ k_seed_collect_wave(DevVolume ref, DevVolume reads, IndexView index, const u64* 
             if (create) {
                 idx = nblk + popc64(crm & below);
                 for (;;) {           // the keys of one chunk's creators are distinct: a lost race just moves on
-                    const i32 old = atomicCAS(&S.ht_key[h], -1, blk);
-                    if (old == -1) break;
+                    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long*>(&S.ht[h]), (unsigned long long)kHtEmpty, (unsigned long long)ht_entry(blk, idx));
+                    if (old == (unsigned long long)kHtEmpty) break;
                     h = (h + 1) & S.ht_mask;
                 }
-                S.ht_val[h] = idx;
                 SBlock* sb = S.pool + idx;
                 sb->score = 0; sb->last_kmer_id = -1; sb->block_id = blk; sb->stale = 0; sb->slot = (i32)h;
             }
             nblk += ncreate;
             idx = __shfl(idx, first);
             __syncthreads();                   // new blocks are initialised before anyone reads a score
-            int s0 = 0;
+            int s0 = 0, s0p = 0;
             if (cand) s0 = S.pool[idx].score;
+            if (cand && ip >= 0) s0p = (int)S.pool[ip].score;
             const bool acc = cand && s0 + rank < kBlkSeeds;
             const bool is_last = acc && (later == 0 || s0 + rank + 1 >= kBlkSeeds);
             int sprev = 0;
             if (is_last) {
-                u32 hp; const i32 ip = blk > 0 ? probe(blk - 1, hp) : -1;
-                const int s0p = ip >= 0 ? (int)S.pool[ip].score : 0;
                 int room = kBlkSeeds - s0p; if (room < 0) room = 0;
                 sprev = s0p + (cprev < room ? cprev : room);
             }

@@ -119,9 +119,9 @@ int main(int argc, char** argv)
         P.align_cutoff = opt.align_size_cutoff; P.num_candidates = opt.num_candidates; P.job = opt.job; P.pairwise = 1;
         P.read_start_id = vi.read_start_id[v]; P.ref_start_id = vi.read_start_id[vid]; P.debug_phase = 0;
         const int H = 1 << 20;
-        std::vector<i32> htk(4 * H, -1), htv(4 * H, 0); std::vector<SBlock> pool(H); std::vector<u64> cs(H + 1), uu(H + 1);
+        std::vector<u64> htab(4 * H, kHtEmpty); std::vector<SBlock> pool(H); std::vector<u64> cs(H + 1), uu(H + 1);
         std::vector<i32> f(H + 1), p(H + 1), t(H + 1), vv(H + 1); std::vector<DevCand> lcan(H + 1), outc(H);
-        SeedScratch S; S.ht_key = htk.data(); S.ht_val = htv.data(); S.ht_mask = 4 * H - 1; S.pool = pool.data(); S.pool_cap = H;
+        SeedScratch S; S.ht = htab.data(); S.ht_mask = 4 * H - 1; S.pool = pool.data(); S.pool_cap = H;
         S.cs = cs.data(); S.f = f.data(); S.p = p.data(); S.t = t.data(); S.v = vv.data(); S.u = uu.data(); S.lcan = lcan.data(); S.cs_cap = H + 1;
         S.out = outc.data(); S.out_cap = H;
         static MyersRegs<8> R8; static MyersRegs<13> R13; HMat mat; u64 tw[32];
