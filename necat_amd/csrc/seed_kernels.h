@@ -165,14 +165,17 @@ k_seed_collect_wave(DevVolume ref, DevVolume reads, IndexView index, const u64* 
             const i32 kmer_id = kbase + j + 1;
             // ---- counts over the lower / higher lanes of the chunk
             const u64 cmask = __ballot(cand);
+            // one step per DISTINCT block of the chunk (consecutive k-mers of a read hit the same few blocks of an overlapping
+            // read), not one per lane
             int rank = 0, first = lane, later = 0, cprev = 0;
-#pragma unroll
-            for (int l = 0; l < 64; ++l) {
-                if (!((cmask >> l) & 1ULL)) continue;                          // wave-uniform
+            for (u64 todo = cmask; todo;) {
+                const int l = ctz64(todo);
                 const i32 bl = __builtin_amdgcn_readlane(blk, l);
-                const bool same = bl == blk;
-                if (l < lane) { rank += same; cprev += (bl == blk - 1); if (same && l < first) first = l; }
-                else if (l > lane) later += same;
+                const bool mine = cand && blk == bl;
+                const u64 same = __ballot(mine);                      // the candidates of block bl; l is the lowest of them
+                if (mine) { rank = popc64(same & below); later = popc64(same >> lane) - 1; first = l; }
+                if (cand && blk == bl + 1) cprev = popc64(same & below);
+                todo &= ~same;
             }
             // ---- block lookup / creation by the first seed of every block
             const bool is_first = cand && rank == 0;
