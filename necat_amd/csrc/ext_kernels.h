@@ -384,6 +384,36 @@ NECAT_D void fast_advance(FastWord& w, u32 el, u32 eh, u32 cph, u32 cmh, u32 cm,
     w.Pv = ((u64)oh << 32) | ol; w.Mv = ((u64)nh << 32) | nl;
 }
 
+// advance_block / advance_block_rec (dp_core.h) issued like fast_advance - one 64-bit add, 3-input logic through v_bitop3 - for the
+// general path (ragged blocks, list B, the single-pass kernel of the small rounds), whose horizontal carry is the int hin / hout
+// in {-1, 0, +1} of the reference (edlib_ex.c:71-106).  Same results bit for bit.
+template <bool REC>
+NECAT_D int advance_dev(u64& Pv, u64& Mv, const u64 Eq, const int hin, u64& A, u64& B)
+{
+    const u32 pl = (u32)Pv, ph = (u32)(Pv >> 32), ml = (u32)Mv, mh = (u32)(Mv >> 32);
+    const u32 el = (u32)Eq, eh = (u32)(Eq >> 32);
+    const u32 neg = (u32)hin >> 31;                                // 1 iff hin == -1
+    const u32 pos = (u32)(hin + 1) >> 1;                           // 1 iff hin == +1
+    const u32 xvl = el | ml, xvh = eh | mh;                        // Xv = Eq | Mv (before the hin fix-up of Eq)
+    const u32 e2l = el | neg;
+    const u64 sum = (((u64)(eh & ph) << 32) | (e2l & pl)) + Pv;
+    const u32 sl = (u32)sum, sh = (u32)(sum >> 32);
+    const u32 xhl = bop<0xbe>(sl, pl, e2l), xhh = bop<0xbe>(sh, ph, eh);      // Xh = (sum ^ Pv) | Eq
+    const u32 phl = bop<0xf1>(ml, xhl, pl), phh = bop<0xf1>(mh, xhh, ph);      // Ph = Mv | ~(Xh | Pv)
+    const u32 mhl = pl & xhl, mhh = ph & xhh;                                  // Mh = Pv & Xh
+    const int hout = (int)(phh >> 31) - (int)(mhh >> 31);
+    const u32 p2l = (phl << 1) | pos, p2h = __builtin_amdgcn_alignbit(phh, phl, 31);
+    const u32 m2l = (mhl << 1) | neg, m2h = __builtin_amdgcn_alignbit(mhh, mhl, 31);
+    const u32 ol = bop<0xf1>(m2l, xvl, p2l), oh = bop<0xf1>(m2h, xvh, p2h);    // Pv' = Mh | ~(Xv | Ph)
+    const u32 nl = p2l & xvl, nh = p2h & xvh;                                  // Mv' = Ph & Xv
+    if (REC) {
+        A = ((u64)bop<0xf4>(oh, ph, xhh) << 32) | bop<0xf4>(ol, pl, xhl);      // Pv' | (Pv & ~Xh)
+        B = ((u64)bop<0x0d>(oh, mh, xhh) << 32) | bop<0x0d>(ol, ml, xhl);      // ~Pv' & (Mv | ~Xh)
+    }
+    Pv = ((u64)oh << 32) | ol; Mv = ((u64)nh << 32) | nl;
+    return hout;
+}
+
 NECAT_D u32 dpp_row_shr1(u32 v, u32 keep)     // lane i receives v of lane i - 1 (within a row of 16); row lane 0 keeps `keep`
 {
     return (u32)__builtin_amdgcn_update_dpp((int)keep, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
@@ -576,7 +606,7 @@ NECAT_D void myers_coop_wave(const ListView& lv, const BlockItem* __restrict__ i
             if ((c & 31) == 0) tcur = tw[c >> 5];
             const u64 eq = eq_of(c);
             u64 rA, rB;
-            hout = SINGLE ? advance_block_rec(P, M, eq, hin, P, M, rA, rB) : advance_block(P, M, eq, hin, P, M);
+            hout = SINGLE ? advance_dev<true>(P, M, eq, hin, rA, rB) : advance_dev<false>(P, M, eq, hin, rA, rB);
             S += hout;
             if (SINGLE) rec[rec_pos<NW>(c, b, il)] = make_ulonglong2(rA, rB);
             if (is_last && S <= k && (best == -1 || S <= best)) {
@@ -616,7 +646,7 @@ NECAT_D void myers_coop_wave(const ListView& lv, const BlockItem* __restrict__ i
             if ((c & 31) == 0) tcur = tw[c >> 5];
             const u64 eq = eq_of(c);
             u64 rA, rB;
-            hout = advance_block_rec(P, M, eq, hin, P, M, rA, rB);
+            hout = advance_dev<true>(P, M, eq, hin, rA, rB);
             S += hout;
             // store the word only if it can hold a cell of an alignment of cost <= best that still reaches
             // the end: the reference's own per-word band tests (edlib_ex.c:311-325) with k = best.  The
@@ -643,8 +673,14 @@ NECAT_D void myers_coop_wave(const ListView& lv, const BlockItem* __restrict__ i
     }
 }
 
+#ifndef NECAT_COOP_WAVES
+#define NECAT_COOP_WAVES 0
+#endif
 template <int NW, int TW, int COLS, int G, bool SINGLE = false>
 __global__ void __launch_bounds__(64)
+#if NECAT_COOP_WAVES
+__attribute__((amdgpu_waves_per_eu(NECAT_COOP_WAVES, NECAT_COOP_WAVES)))
+#endif
 k_myers_coop(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
              double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, u32 epoch, u32 item_base)
 {
