@@ -156,16 +156,22 @@ k_items_hist(const BlockItem* __restrict__ items, u32 n, u32* __restrict__ bins)
     if (i < n) atomicAdd(&bins[kMaxFragLen - items[i].tn], 1u);     // bin 0 = longest
 }
 
-__global__ void __launch_bounds__(1024)
+// one wave, no barrier: lane l owns kBinsPerLane consecutive bins.  (As a 1024-thread workgroup with a barrier per scan step this
+// 5 us kernel took 0.6 - 1.5 ms whenever the DP kernel of list A filled the chip: its 16 waves queued behind that kernel's at
+// every barrier.)
+constexpr int kBinsPerLane = (kSortBins + 63) / 64;
+__global__ void __launch_bounds__(64)
 k_items_scan(u32* __restrict__ bins)          // exclusive scan of kSortBins counters, in place
 {
-    __shared__ u32 sh[1024];
-    const int t = threadIdx.x;
-    const u32 v = t < kSortBins ? bins[t] : 0u;
-    sh[t] = v;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) { const u32 x = t >= o ? sh[t - o] : 0u; __syncthreads(); sh[t] += x; __syncthreads(); }
-    if (t < kSortBins) bins[t] = sh[t] - v;
+    const int lane = threadIdx.x;
+    u32 v[kBinsPerLane], sum = 0;
+#pragma unroll
+    for (int q = 0; q < kBinsPerLane; ++q) { const int i = lane * kBinsPerLane + q; v[q] = i < kSortBins ? bins[i] : 0u; sum += v[q]; }
+    u32 incl = sum;
+    for (int o = 1; o < 64; o <<= 1) { const u32 x = __shfl_up(incl, o); if (lane >= o) incl += x; }
+    u32 run = incl - sum;
+#pragma unroll
+    for (int q = 0; q < kBinsPerLane; ++q) { const int i = lane * kBinsPerLane + q; if (i < kSortBins) bins[i] = run; run += v[q]; }
 }
 
 __global__ void __launch_bounds__(256)

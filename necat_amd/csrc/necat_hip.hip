@@ -1012,7 +1012,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         // (below ~2 k blocks every wave is resident at once and the round lasts as long as its longest walk: order is irrelevant)
         if (nB >= 2048 && g_sort_b) {
             hipLaunchKernelGGL(k_items_hist, dim3(grid_for(nB, 256)), dim3(256), 0, sb, itB, nB, c.bins[slot]);
-            hipLaunchKernelGGL(k_items_scan, dim3(1), dim3(1024), 0, sb, c.bins[slot]);
+            hipLaunchKernelGGL(k_items_scan, dim3(1), dim3(64), 0, sb, c.bins[slot]);
             hipLaunchKernelGGL(k_items_scatter, dim3(grid_for(nB, 256)), dim3(256), 0, sb, itB, nB, c.bins[slot], c.sortedB[slot]);
             NECAT_CHECK_LAUNCH(ctx, "k_items_sort");
             itB = c.sortedB[slot];
