@@ -34,7 +34,12 @@ def stats(d, out, cmd):
         a[0] += int(r["Calls"]); a[1] += int(float(r["TotalDurationNs"]))
     total = sum(a[1] for a in agg.values()) or 1
     with open(out, "w") as fh:
-        fh.write("# rocprofv3 --kernel-trace --stats\n\nCommand: `%s`\n\n| kernel | calls | total ns | avg ns | %% |\n|---|---|---|---|---|\n" % cmd)
+        fh.write("# rocprofv3 --kernel-trace --stats\n\nCommand: `%s`\n\n"
+                 "Durations are per kernel, start to end, and the extension runs three chains side by side (list A on one stream, list B on\n"
+                 "two more): the totals add up to more than the wall time, and a small kernel of the list-B chain (`k_items_*`, `k_ext_frag<13, 25>`,\n"
+                 "the 794-column DP / walk kernels) that starts while list A's issue-bound DP kernel fills the chip is timed with its wait for\n"
+                 "issue slots included (`profiles/r02_round_timeline.txt` shows one step launch by launch).\n\n"
+                 "| kernel | calls | total ns | avg ns | %% |\n|---|---|---|---|---|\n" % cmd)
         for name, (calls, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             fh.write("| `%s` | %d | %d | %d | %.2f |\n" % (name, calls, ns, ns // max(1, calls), 100.0 * ns / total))
 
