@@ -72,7 +72,7 @@ void read_knobs()
     auto num = [](const char* name, unsigned long long dflt) { const char* e = getenv(name); return e ? strtoull(e, nullptr, 10) : dflt; };
     g_coop_threshold = (u32)num("NECAT_COOP_THRESHOLD", 0xffffffffu);
     g_seed_budget = num("NECAT_SEED_BUDGET", 48ULL << 20);
-    g_single_pass = (u32)num("NECAT_SINGLE_PASS", 2048);
+    g_single_pass = (u32)num("NECAT_SINGLE_PASS", 4096);
     g_batch_cap = (u32)std::max<unsigned long long>(64, num("NECAT_BATCH", 786432));
     g_index_lds = (int)num("NECAT_INDEX_LDS", 1);
     g_seed_wave = (int)num("NECAT_SEED_WAVE", 1);

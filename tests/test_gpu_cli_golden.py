@@ -54,3 +54,19 @@ def test_oc2pm_wrapper_concatenates_volumes(tmp_path, built, gpus):
     for vid in range(3):       # pairwise_mapping/main.c:55-70, :104-112
         assert os.path.exists(os.path.join(d, "pm%d.finished" % vid))
         assert not os.path.exists(os.path.join(d, "pm_result_%d" % vid))
+
+
+def test_oc2pm_worker_failure_is_reported(tmp_path, built):
+    """a volume job that fails (here: an unreadable volume file) makes oc2pm exit 1, leaves no pm<i>.finished for that volume and no
+    merged output - the grid driver re-queues the script (pairwise_mapping/main.c:95-112 checks the child's exit status)"""
+    pmov, pm = built.build_cli()
+    d = util.install_golden_volumes("vols_b", tmp_path)
+    o = ora.options(**MANIFEST["b_v0_m4_txt"]["options"])
+    nv, nr, vols = __import__("necat_amd.capi", fromlist=["x"]).load_volumes_info(d)
+    os.truncate(vols[2][0], 40)                     # volume 2 is needed by every job
+    out = os.path.join(str(tmp_path), "all.m4")
+    r = subprocess.run([pm] + ora.opt_argv(o) + [d, out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1
+    assert "ERROR" in r.stderr
+    assert not os.path.exists(out)
+    assert not any(os.path.exists(os.path.join(d, "pm%d.finished" % v)) for v in range(3))
