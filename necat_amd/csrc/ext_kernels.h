@@ -679,14 +679,10 @@ NECAT_D void myers_coop_wave(const ListView& lv, const BlockItem* __restrict__ i
     }
 }
 
-#ifndef NECAT_COOP_WAVES
-#define NECAT_COOP_WAVES 0
-#endif
+// (list A's instantiations need 68 VGPRs as compiled freely: asked for 8 waves per SIMD they fit 64 with 28 bytes of scratch, and
+// the issue-bound kernel gains ~1 % from the extra wave; list B's keep what they need)
 template <int NW, int TW, int COLS, int G, bool SINGLE = false>
-__global__ void __launch_bounds__(64)
-#if NECAT_COOP_WAVES
-__attribute__((amdgpu_waves_per_eu(NECAT_COOP_WAVES, NECAT_COOP_WAVES)))
-#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NW == kWordsA ? 8 : 1, 8)))
 k_myers_coop(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, char* __restrict__ slabs, size_t slab_bytes,
              double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, u32 epoch, u32 item_base)
 {
