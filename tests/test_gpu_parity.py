@@ -428,6 +428,13 @@ def test_capped_band_pool_runs_lists_in_chunks(ctx, small, tmp_path, monkeypatch
     try:
         _, got = capi.pm_main(c, opt, 0, d)
         assert util.m4_key_rows(got) == util.m4_key_rows(base) and base.shape[0] > 500
+        # the alignment-keeping mode (columns exported by the walk) through the same chunks
+        cands, _ = capi.pm_main(c, capi.default_options(**dict(util.FAST, job=0)), 0, d)
+        _, _, vols = capi.load_volumes_info(d)
+        v1 = c.load_volume(vols[0][0]); a1 = c.onc_align_batch(v1, v1, 0, 0, cands[:1500], opt, 4); v1.free()
+        v0 = ctx.load_volume(vols[0][0]); a0 = ctx.onc_align_batch(v0, v0, 0, 0, cands[:1500], opt, 4); v0.free()
+        for x, y in zip(a0, a1):
+            assert x.tobytes() == y.tobytes()
         kw = dict(util.FAST, kmer_size=12, align_size_cutoff=400, num_threads=4)
         d2, rs2, nv = util.make_dataset(tmp_path, genome=60_000, coverage=40.0, seed=43, err=0.10, mean_len=1350.0, sd_len=200.0, min_len=1000)
         out, st = _oracle_records(kw, d2, 0, tmp_path, 1, 1)
