@@ -725,17 +725,16 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
         for (u32 i = 0; i < n; ++i) {
             const u32 r = order[pos + i];
             SeedMeta& m = meta[i];
-            u64 Hmax = 1;
             for (int st = 0; st < 2; ++st) {
                 const u64 H = std::max<u64>(1, hits[2 * (size_t)r + st]);
                 u64 cap = 4; while (cap < 2 * H) cap <<= 1;
                 m.ht_off[st] = ht_tot; m.ht_mask[st] = (u32)(cap - 1); ht_tot += cap;
                 m.pool_off[st] = pool_tot; m.pool_cap[st] = (u32)H; pool_tot += H;
-                Hmax = std::max(Hmax, H);
+                // chain scratch per strand: the two strands of a read are evaluated by two waves at the same time
+                m.chain_off[st] = chain_tot; m.cs_cap[st] = (u32)(H + 1); chain_tot += H + 1;
             }
-            m.chain_off = chain_tot; m.cs_cap = (u32)(Hmax + 1); chain_tot += Hmax + 1;
             const u64 oc = (u64)hits[2 * (size_t)r] + hits[2 * (size_t)r + 1] + 2;
-            m.out_off = out_tot; m.out_cap = (u32)oc; m.out_cap0 = hits[2 * (size_t)r] + 1; m._pad = 0; out_tot += oc;
+            m.out_off = out_tot; m.out_cap = (u32)oc; m.out_cap0 = hits[2 * (size_t)r] + 1; out_tot += oc;
         }
         if ((rc = buf_ensure(ctx, ctx->scratch[SC_SEED_META], n * sizeof(SeedMeta) + (size_t)n * (8 + 4 + 4 + 8 + 8) + 64)) ||
             (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_HT], ht_tot * 8)) ||

@@ -17,9 +17,9 @@ namespace necat {
 struct SeedMeta {           // per processed read; strand 0 = FWD, 1 = REV
     u64 ht_off[2];          // entries
     u64 pool_off[2];        // SBlocks
-    u64 chain_off;          // entries of (max(H0,H1)+1)
+    u64 chain_off[2];       // chain scratch per strand, H + 1 entries each: the strands are evaluated by two waves at the same time
     u64 out_off;            // DevCands: strand 0 writes at out_off, strand 1 at out_off + out_cap0; k_seed_finish joins them
-    u32 ht_mask[2], pool_cap[2], cs_cap, out_cap, out_cap0, _pad;
+    u32 ht_mask[2], pool_cap[2], cs_cap[2], out_cap, out_cap0;
 };
 
 __global__ void __launch_bounds__(256)
@@ -55,8 +55,9 @@ NECAT_D SeedScratch seed_scratch(const SeedArenas& A, const SeedMeta& m, int str
     SeedScratch S;
     S.ht = A.ht + m.ht_off[strand]; S.ht_mask = m.ht_mask[strand];
     S.pool = A.pool + m.pool_off[strand]; S.pool_cap = m.pool_cap[strand];
-    S.cs = A.cs + m.chain_off; S.f = A.f + m.chain_off; S.p = A.p + m.chain_off; S.t = A.t + m.chain_off;
-    S.v = A.v + m.chain_off; S.u = A.u + m.chain_off; S.lcan = A.lcan + m.chain_off; S.cs_cap = m.cs_cap;
+    const u64 co = m.chain_off[strand];
+    S.cs = A.cs + co; S.f = A.f + co; S.p = A.p + co; S.t = A.t + co;
+    S.v = A.v + co; S.u = A.u + co; S.lcan = A.lcan + co; S.cs_cap = m.cs_cap[strand];
     S.out = A.out + m.out_off + (strand ? m.out_cap0 : 0u); S.out_cap = strand ? m.out_cap - m.out_cap0 : m.out_cap0;
     return S;
 }

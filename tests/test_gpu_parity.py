@@ -468,6 +468,34 @@ def test_alternative_kernel_paths_give_the_same_records(ctx, small, monkeypatch,
     assert util.m4_key_rows(m_got) == util.m4_key_rows(m_base) and m_base.shape[0] > 500
 
 
+@pytest.mark.parametrize("knob", [None, "NECAT_CHAIN_WAVE=0"])
+def test_long_chains_on_both_strands(ctx, tmp_path, monkeypatch, knob):
+    """Low error, high coverage, k = 11, z = 5: evaluations with more than 256 co-linear seeds (the chain scratch in global memory
+    instead of LDS) on BOTH strands of a read, which two waves evaluate at the same time.  Found by tests/tools/fuzz_parity.py
+    (seed 7015): the strands used to share one chain scratch per read and a chain of one strand could surface under the other.
+    Also with the lane-0 chain DP, which keeps every evaluation's seeds in that scratch."""
+    from necat_amd import capi
+    kw = dict(kmer_size=11, scan_window=5, kmer_cnt_cutoff=20, block_size=2000, block_score_cutoff=3, num_candidates=500,
+              align_size_cutoff=1000, ddfs_cutoff=0.25, error=0.3, num_output=500, num_threads=2, use_hdr_as_id=0)
+    d, rs, nv = util.make_dataset(tmp_path, genome=173352, coverage=25.2, seed=7015, err=0.04, repeat_frac=0.0)
+    o = ora.options(**dict(kw, job=0, binary_output=1))
+    out = os.path.join(str(tmp_path), "o.out")
+    ora.pm_main(o, 0, d, out)
+    want = ora.sorted_records(out, 28)
+    assert len(want) > 5000
+    if knob:
+        monkeypatch.setenv(*knob.split("="))
+    c = capi.Context(0)
+    try:
+        for it in range(3):
+            cands, _ = capi.pm_main(c, capi.default_options(**dict(kw, job=0, binary_output=1)), 0, d)
+            got = sorted(bytes(r) for r in capi.pack_candidates(cands).astype("<u4"))
+            assert got == want, "run %d" % it
+            assert int(cands["score"].max()) > 256          # such evaluations exist
+    finally:
+        c.close()
+
+
 def test_ultra_long_reads(ctx, tmp_path):
     """reads of 60-200 kb (hundreds of 512-bp blocks per alignment, hundreds of extension rounds, long chains in the
     seeding stage): candidates, M4 records and the alignments with their strings equal the oracle's"""

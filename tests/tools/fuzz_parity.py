@@ -30,6 +30,7 @@ for case in range(n_cases):
         d, rs, nv = util.make_dataset(td, genome=genome, coverage=cov, seed=seed0 + case, err=err, repeat_frac=rep,
                                       vol_size=(max(300_000, int(genome * cov / 3)) if multi else synth.DEFAULT_VOL_SIZE))
         t0 = time.time()
+        bad0 = bad
         for vid in range(nv):
             for job in (0, 1):
                 o = ora.options(**dict(kw, job=job, binary_output=1))
@@ -69,6 +70,6 @@ for case in range(n_cases):
                     print("MISMATCH case %d vid %d job %d" % (case, vid, job), kw, flush=True)
         print("case %2d: genome %6d cov %4.1f err %.2f rep %.2f vols %d k=%d z=%d q=%d b=%d s=%d n=%d a=%d e=%.1f -> %d M4 (last vol) %s  %.1f s" % (
             case, genome, cov, err, rep, nv, kw["kmer_size"], kw["scan_window"], kw["kmer_cnt_cutoff"], kw["block_size"],
-            kw["block_score_cutoff"], kw["num_candidates"], kw["align_size_cutoff"], kw["error"], nrec, "ok" if not bad else "BAD", time.time() - t0), flush=True)
+            kw["block_score_cutoff"], kw["num_candidates"], kw["align_size_cutoff"], kw["error"], nrec, "ok" if bad == bad0 else "BAD", time.time() - t0), flush=True)
 print("fuzz_parity: %d cases, %d mismatches" % (n_cases, bad))
 sys.exit(1 if bad else 0)
