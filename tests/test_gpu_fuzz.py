@@ -18,3 +18,13 @@ def test_random_option_sets_match_oracle():
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:]
     assert "5 cases, 0 mismatches" in r.stdout
+
+
+def test_random_option_sets_with_random_scheduling_knobs():
+    """the same sweep, every case in a context with random band-pool cap / batch size / seeding budget / single-pass threshold:
+    lists in chunks, several batches, several seeding chunks - the records must not depend on any of them"""
+    env = dict(os.environ, GRAFT_REPO_ROOT=util.ROOT)
+    r = subprocess.run([sys.executable, os.path.join(util.ROOT, "tests", "tools", "fuzz_parity.py"), "5", "15000", "1"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "5 cases, 0 mismatches" in r.stdout

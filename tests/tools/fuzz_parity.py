@@ -1,7 +1,10 @@
 """Randomised parity sweep (tool): random small datasets x random option sets, the HIP path through the C ABI
 against the oracle - candidates (-j 0, packed 28-byte records) and M4 records (-j 1), every volume.
 
-    python tests/tools/fuzz_parity.py [n_cases] [first_seed]
+    python tests/tools/fuzz_parity.py [n_cases] [first_seed] [knobs]
+
+knobs = 1: every case runs in a context of its own with random scheduling knobs (band-pool cap, candidates per batch, seeding
+scratch budget: lists in chunks, several batches, several seeding chunks) - the records must not depend on them.
 """
 import os, sys, tempfile, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
@@ -12,10 +15,19 @@ from tests import util
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-ctx = capi.Context(0)
+knobs = len(sys.argv) > 3 and sys.argv[3] == "1"
+ctx = None if knobs else capi.Context(0)
 bad = 0
 for case in range(n_cases):
     rng = np.random.default_rng(seed0 + case)
+    if knobs:
+        krng = np.random.default_rng(77 + seed0 + case)
+        env = {"NECAT_BAND_POOL_MB": str(int(krng.choice([4, 16, 64, 16384]))), "NECAT_BATCH": str(int(krng.choice([192, 1024, 786432]))),
+               "NECAT_SEED_BUDGET": str(int(krng.choice([20000, 200000, 48000000]))), "NECAT_SINGLE_PASS": str(int(krng.choice([0, 64, 4096])))}
+        os.environ.update(env)
+        if ctx is not None:
+            ctx.close()
+        ctx = capi.Context(0)
     genome = int(rng.integers(40_000, 220_000))
     cov = float(rng.uniform(8, 30))
     err = float(rng.choice([0.04, 0.08, 0.12, 0.15]))
@@ -67,7 +79,7 @@ for case in range(n_cases):
                     al.close()
                 if not ok:
                     bad += 1
-                    print("MISMATCH case %d vid %d job %d" % (case, vid, job), kw, flush=True)
+                    print("MISMATCH case %d vid %d job %d" % (case, vid, job), kw, env if knobs else "", flush=True)
         print("case %2d: genome %6d cov %4.1f err %.2f rep %.2f vols %d k=%d z=%d q=%d b=%d s=%d n=%d a=%d e=%.1f -> %d M4 (last vol) %s  %.1f s" % (
             case, genome, cov, err, rep, nv, kw["kmer_size"], kw["scan_window"], kw["kmer_cnt_cutoff"], kw["block_size"],
             kw["block_score_cutoff"], kw["num_candidates"], kw["align_size_cutoff"], kw["error"], nrec, "ok" if bad == bad0 else "BAD", time.time() - t0), flush=True)
