@@ -108,3 +108,40 @@ def test_oc2pm_writes_the_partitions_oc2pcan_would(oc2pcan, tmp_path, ds, batch)
         total += len(got)
     assert total > 100
     assert not [f for f in os.listdir(wrk) if f.startswith("pm_result_")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch,nreads", [(1, 5000), (7, 5000), (100000, 5000)])
+def test_pcan_partition_many_partitions(ctx, batch, nreads):
+    """necat_pcan_partition against a numpy statement of pcan.c:47-75 on random candidates: more partitions than the kernel counts
+    in LDS (batch 1: 5000 partitions, global counters), a few hundred, and one; ids outside [0, num_reads) go nowhere."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    n = 40000
+    c = np.zeros(n, dtype=capi.CANDIDATE_DTYPE)
+    c["qid"] = rng.integers(-3, nreads + 5, n); c["sid"] = rng.integers(-3, nreads + 5, n)
+    c["qdir"] = rng.integers(0, 2, n); c["sdir"] = rng.integers(0, 2, n); c["score"] = rng.integers(1, 2000000, n)
+    for f in ("qbeg", "qend", "sbeg", "send", "qoff", "soff"):
+        c[f] = rng.integers(0, 50000, n)
+    c["qoff"][::3] = c["qbeg"][::3]
+    rec, off, npart = C.c_void_p(), C.c_void_p(), C.c_int()
+    rc = ctx.lib.necat_pcan_partition(ctx.h, c.ctypes.data_as(C.c_void_p), n, batch, nreads, C.byref(rec), C.byref(off), C.byref(npart))
+    assert rc == 0, ctx.lib.necat_last_error(ctx.h).decode()
+    want_parts = (nreads + batch - 1) // batch
+    assert npart.value == want_parts
+    poff = np.ctypeslib.as_array(C.cast(off, C.POINTER(C.c_uint64)), shape=(want_parts + 1,)).copy()
+    total = int(poff[-1])
+    got = np.ctypeslib.as_array(C.cast(rec, C.POINTER(C.c_uint32)), shape=(max(total, 1) * 7,))[: total * 7].reshape(-1, 7).copy()
+    ctx.lib.necat_free(rec); ctx.lib.necat_free(off)
+    a = capi.pack_candidates(c).astype(np.uint32)
+    b = np.frombuffer(capi.pcan_single_partition(a.tobytes()), dtype="<u4").reshape(-1, 7)[n:]        # the role-swapped twins
+    allrec = np.concatenate([a, b])
+    tid = allrec[:, 1].astype(np.int32).astype(np.int64)
+    part = np.where((tid >= 0) & (tid // batch < want_parts), tid // batch, -1)
+    assert total == int((part >= 0).sum())
+    for p in np.unique(np.concatenate([rng.integers(0, want_parts, 40), [0, want_parts - 1]])):
+        mine = sorted(map(bytes, got[int(poff[p]):int(poff[p + 1])]))
+        want = sorted(map(bytes, allrec[part == p]))
+        assert mine == want, "partition %d" % p
+    counts = np.bincount(part[part >= 0], minlength=want_parts)
+    assert np.array_equal(np.diff(poff).astype(np.int64), counts)
