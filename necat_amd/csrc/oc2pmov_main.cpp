@@ -40,11 +40,12 @@ int main(int argc, char** argv)
     const char* dev_env = getenv("NECAT_GPU");
     // a fresh process pays for the VRAM the previous one dirtied (30 - 55 ms per GB on MI355X): keep the band-record pools small
     setenv("NECAT_BAND_POOL_MB", "1024", 0);
+    auto ref_volume = pm_load_async(vi, vid);        // read while the HIP runtime starts (0.1 - 0.2 s)
     necat_ctx* ctx = nullptr;
     int rc = necat_ctx_create(dev_env ? atoi(dev_env) : 0, &ctx);
-    if (rc) return fail("GPU", "no usable gfx950 device (libnecat_hip has no CPU fallback)");
+    if (rc) { ref_volume.wait(); return fail("GPU", "no usable gfx950 device (libnecat_hip has no CPU fallback)"); }
     tr.stage("context created");
-    const int status = pm_run_volume(ctx, vi, vid, opt, output, "oc2pmov", tr);
+    const int status = pm_run_volume(ctx, vi, vid, opt, output, "oc2pmov", tr, &ref_volume);
     necat_ctx_destroy(ctx);
     tr.stage("context destroyed");
     return status;

@@ -22,13 +22,22 @@ struct PmTrace {       // NECAT_CLI_TRACE=1: wall clock of the stages on stderr
 };
 
 // returns 0, or 1 after printing "[tag] ERROR: ..." (every fatal error of the reference is OC_ERROR -> exit 1)
-inline int pm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const necat_map_options& opt, const char* output, const char* tag, const PmTrace& tr)
+struct PmLoaded { HostVolume v; bool ok = false; std::string err; };
+inline std::future<std::unique_ptr<PmLoaded>> pm_load_async(const VolumesInfo& vi, int i)
+{
+    return std::async(std::launch::async, [&vi, i]() { auto l = std::make_unique<PmLoaded>(); l->ok = load_volume(vi.names[i].c_str(), &l->v, &l->err); return l; });
+}
+
+// `preloaded` (optional): the reference volume, already being read (oc2pmov reads it while the HIP runtime starts)
+inline int pm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const necat_map_options& opt, const char* output, const char* tag, const PmTrace& tr,
+                         std::future<std::unique_ptr<PmLoaded>>* preloaded = nullptr)
 {
     auto fail = [&](const char* what, const char* detail) { fprintf(stderr, "[%s] ERROR: %s: %s\n", tag, what, detail); return 1; };
     std::string err;
     int rc;
-    HostVolume href;
-    if (!load_volume(vi.names[vid].c_str(), &href, &err)) return fail("volume", err.c_str());
+    std::unique_ptr<PmLoaded> ref_l = preloaded ? preloaded->get() : pm_load_async(vi, vid).get();
+    if (!ref_l->ok) return fail("volume", ref_l->err.c_str());
+    HostVolume& href = ref_l->v;
     tr.stage("volume read");
     necat_volume* ref = nullptr;
     if ((rc = necat_volume_upload(ctx, href.pac.data(), href.nbases, href.offset.data(), href.size.data(), href.offset.size(), &ref)))
@@ -50,10 +59,8 @@ inline int pm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const n
     if (pcan_batch > 0)      // this job's partition files are appended to: start from nothing
         for (int p = 0; p < (vi.num_reads + pcan_batch - 1) / pcan_batch; ++p) remove((std::string(output) + ".p" + std::to_string(p)).c_str());
     // the next volume is read from disk while this one is mapped
-    struct Loaded { HostVolume v; bool ok = false; std::string err; };
-    auto load_async = [&](int i) {
-        return std::async(std::launch::async, [&vi, i]() { auto l = std::make_unique<Loaded>(); l->ok = load_volume(vi.names[i].c_str(), &l->v, &l->err); return l; });
-    };
+    typedef PmLoaded Loaded;
+    auto load_async = [&](int i) { return pm_load_async(vi, i); };
     std::future<std::unique_ptr<Loaded>> next;
     if (vid + 1 < vi.num_volumes) next = load_async(vid + 1);
     int status = 0;
