@@ -143,25 +143,34 @@ k_seed_collect_wave(DevVolume ref, DevVolume reads, IndexView index, const u64* 
         if (lane == 63) s_pre[64] = inc;
         __syncthreads();
         const u32 T = s_pre[64];
-        for (u32 c0 = 0; c0 < T; c0 += 64) {
+        // the seed of lane `lane` in the chunk that starts at c0: its k-mer (the last j with s_pre[j] <= sq), its offset and the
+        // previous occurrence of the k-mer.  Fetched one chunk ahead: these loads depend on nothing the chunk loop produces, and
+        // the loop is a chain of dependent memory round trips.
+        auto fetch = [&](u32 c0, int& j, u32& kk, u64& off, u64& offp) -> bool {
             const u32 sq = c0 + (u32)lane;
-            const bool valid = sq < T;
-            // k-mer of this seed: the last j with s_pre[j] <= sq
-            int j = 0;
+            j = 0;
             for (int step = 32; step > 0; step >>= 1) if (s_pre[j + step] <= sq) j += step;
-            const u32 kk = sq - s_pre[j];
+            kk = sq - s_pre[j];
+            off = 0; offp = 0;
+            if (sq >= T) return false;
             const u64 lbase = s_list[j];
+            off = offset_list[lbase + kk];
+            if (kk > 0) offp = offset_list[lbase + kk - 1];
+            return true;
+        };
+        int nj = 0; u32 nkk = 0; u64 noff = 0, noffp = 0;
+        bool nvalid = T ? fetch(0, nj, nkk, noff, noffp) : false;
+        for (u32 c0 = 0; c0 < T; c0 += 64) {
+            const int j = nj; const u32 kk = nkk; const u64 off = noff, offp = noffp;
+            const bool valid = nvalid;
+            if (c0 + 64 < T) nvalid = fetch(c0 + 64, nj, nkk, noff, noffp);
             i32 blk = -2; int boff = 0; bool cand = false;
             if (valid) {
-                const u64 off = offset_list[lbase + kk];
                 u64 q = (u64)((double)off / bsd);
                 if (q * bs > off) --q; else if ((q + 1) * bs <= off) ++q;
                 blk = (i32)q; boff = (int)(off - q * bs);
                 cand = true;
-                if (kk > 0) {
-                    const u64 offp = offset_list[lbase + kk - 1];
-                    cand = !(offp >= q * bs);                 // offp < off: same block iff offp >= block start
-                }
+                if (kk > 0) cand = !(offp >= q * bs);                 // offp < off: same block iff offp >= block start
             }
             const i32 kmer_id = kbase + j + 1;
             // ---- counts over the lower / higher lanes of the chunk
