@@ -105,6 +105,35 @@ def rebase_slice(stats_slice, base: int):
     return out
 
 
+def sparse_table(stats, compact_base: int = 0):
+    """The sparse layout the slice build writes (IndexView, dev_common.h) of a dense kmer_stats array whose length is a multiple
+    of 64: (bits[n / 64], base[n / 64], compact) - bit j of bits[w] says entry 64 w + j is non-zero, base[w] = position in
+    `compact` of the word's first non-zero entry (+ compact_base: the non-zero entries of the ranks before the owner), compact =
+    the non-zero entries in hash order."""
+    import numpy as np
+    nz = stats != 0
+    w = nz.reshape(-1, 64)
+    bits = (w.astype(np.uint64) << np.arange(64, dtype=np.uint64)).sum(axis=1).astype(np.uint64)
+    per = w.sum(axis=1).astype(np.uint64)
+    base = np.concatenate([[0], np.cumsum(per)[:-1]]).astype(np.uint64) + np.uint64(compact_base)
+    return bits, base, stats[nz].copy()
+
+
+def sparse_lookup(bits, base, compact, h):
+    """kmer_stats[h] through the sparse layout (IndexView::lookup), vectorised over h"""
+    import numpy as np
+    h = np.asarray(h, dtype=np.uint64)
+    w = (h >> np.uint64(6)).astype(np.int64)
+    bit = np.uint64(1) << (h & np.uint64(63))
+    present = (bits[w] & bit) != 0
+    below = bits[w] & (bit - np.uint64(1))
+    pop = np.array([bin(int(x)).count("1") for x in below], dtype=np.uint64)
+    out = np.zeros(h.shape, dtype=np.uint64)
+    idx = (base[w] + pop)[present].astype(np.int64)
+    out[present] = compact[idx]
+    return out
+
+
 def read_chunks(nreads: int, chunk_reads: int, rank: int, world: int):
     """query reads of rank `rank`: chunk c (reads [c chunk, (c + 1) chunk)) belongs to rank c % world"""
     import numpy as np

@@ -98,6 +98,19 @@ def _index_worker(rank, world, port, vol_path, k, q):
     dist.all_gather_object(objs, my_offs.tobytes())
     full_offs = np.concatenate([np.frombuffer(b, dtype=np.uint64) for b in objs])
     ok = bool(np.array_equal(full_stats, stats) and np.array_equal(full_offs, offs))
+    # 3. the same exchange in the layout the library really moves (necat_index_build_sharded): the owner's IdxWords with FINAL
+    # compact bases (its first non-zero entry sits behind those of the ranks before it) + its run of non-zero entries
+    n_nz = [int(np.frombuffer(b, dtype=np.uint64)[0]) for b in allgather(np.uint64(int((my_stats != 0).sum())).tobytes())]
+    bits, cbase, comp = shard.sparse_table(mine_final, sum(n_nz[:rank]))
+    objs = [None] * world
+    dist.all_gather_object(objs, (bits.tobytes(), cbase.tobytes(), comp.tobytes()))
+    g_bits = np.concatenate([np.frombuffer(o[0], dtype=np.uint64) for o in objs])
+    g_base = np.concatenate([np.frombuffer(o[1], dtype=np.uint64) for o in objs])
+    g_comp = np.concatenate([np.frombuffer(o[2], dtype=np.uint64) for o in objs])
+    w_bits, w_base, w_comp = shard.sparse_table(stats)
+    ok = ok and bool(np.array_equal(g_bits, w_bits) and np.array_equal(g_base, w_base) and np.array_equal(g_comp, w_comp))
+    probe = np.random.default_rng(rank).integers(0, stats.shape[0], 4000).astype(np.uint64)
+    ok = ok and bool(np.array_equal(shard.sparse_lookup(g_bits, g_base, g_comp, probe), stats[probe.astype(np.int64)]))
     # the slices tile the table and the reads
     covered = sum(h - l for l, h in (shard.hash_range(k, g, world) for g in range(world)))
     reads = np.concatenate([shard.read_chunks(1000, 64, g, world) for g in range(world)])
