@@ -15,7 +15,7 @@ from tests import util
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
-knobs = len(sys.argv) > 3 and sys.argv[3] == "1"
+knobs = len(sys.argv) > 3 and sys.argv[3] in ("1", "2")
 ctx = None if knobs else capi.Context(0)
 bad = 0
 for case in range(n_cases):
@@ -33,6 +33,11 @@ for case in range(n_cases):
     err = float(rng.choice([0.04, 0.08, 0.12, 0.15]))
     rep = float(rng.choice([0.0, 0.0, 0.05, 0.2]))
     multi = bool(rng.integers(0, 3) == 0)
+    # knobs = 2: also random read-length distributions (short reads: list-B chains; long ones: many rounds, chains of > 256 seeds)
+    lens = {}
+    if len(sys.argv) > 3 and sys.argv[3] == "2":
+        ml = float(rng.choice([1400.0, 3000.0, 8000.0, 20000.0]))
+        lens = dict(mean_len=ml, sd_len=ml * float(rng.choice([0.1, 0.4])), min_len=int(max(1000, ml * 0.3)))
     kw = dict(kmer_size=int(rng.choice([11, 12, 13, 14])), scan_window=int(rng.choice([5, 10, 20])),
               kmer_cnt_cutoff=int(rng.choice([20, 100, 500])), block_size=int(rng.choice([1000, 2000, 3000])),
               block_score_cutoff=int(rng.choice([2, 3, 4])), num_candidates=int(rng.choice([3, 30, 500])),
@@ -40,7 +45,7 @@ for case in range(n_cases):
               num_output=500, num_threads=2, use_hdr_as_id=0)
     with tempfile.TemporaryDirectory() as td:
         d, rs, nv = util.make_dataset(td, genome=genome, coverage=cov, seed=seed0 + case, err=err, repeat_frac=rep,
-                                      vol_size=(max(300_000, int(genome * cov / 3)) if multi else synth.DEFAULT_VOL_SIZE))
+                                      vol_size=(max(300_000, int(genome * cov / 3)) if multi else synth.DEFAULT_VOL_SIZE), **lens)
         t0 = time.time()
         bad0 = bad
         for vid in range(nv):
