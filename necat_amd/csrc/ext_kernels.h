@@ -144,6 +144,34 @@ k_ext_init(const necat_candidate* __restrict__ cands, u32 n, u32 cand_base, int 
     ext_append_block(t, i, go, L);
 }
 
+// ---- batch order: with several batches the candidates are dealt out by expected chain length (what is left of the two reads beyond
+// the anchor, in 480-base blocks), longest first.  MODE 0: candidates per length bin.  MODE 1: perm[cursor[bin]++] = candidate
+// (one reservation per (block, bin); the order inside a bin is free - a candidate's records do not depend on its batch).
+constexpr int kLenBins = 128;
+NECAT_D u32 chain_len_bin(const necat_candidate& c)
+{
+    const u64 r1 = c.qsize - c.qoff, r2 = c.ssize - c.soff, right = r1 < r2 ? r1 : r2, left = c.qoff < c.soff ? c.qoff : c.soff;
+    const u64 b = right / 480 + left / 480;
+    return (u32)(kLenBins - 1) - (u32)(b < (u64)(kLenBins - 1) ? b : (u64)(kLenBins - 1));     // longest first
+}
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_len_order(const necat_candidate* __restrict__ cands, u32 n, u32* __restrict__ cursor, u32* __restrict__ perm)
+{
+    __shared__ u32 cnt[kLenBins], base[kLenBins];
+    if (threadIdx.x < kLenBins) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const u32 i = blockIdx.x * 256 + threadIdx.x;
+    u32 bin = 0, rk = 0;
+    if (i < n) { bin = chain_len_bin(cands[i]); rk = atomicAdd(&cnt[bin], 1u); }
+    __syncthreads();
+    if (threadIdx.x < kLenBins) { const u32 c = cnt[threadIdx.x]; base[threadIdx.x] = c ? atomicAdd(&cursor[threadIdx.x], c) : 0u; }
+    if (MODE == 1) {
+        __syncthreads();
+        if (i < n) perm[base[bin] + rk] = i;
+    }
+}
+
 // ---- list B ordering: blocks of list B have any size up to 794 x 794; lanes (k_traceback, k_myers) or
 // lane groups (k_myers_coop) of one wave finish together only if their blocks are alike, so the list is
 // counting-sorted by target length (longest first) before the round's kernels run.

@@ -1227,31 +1227,22 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     // anchor, in blocks), longest first: the first batch has the ~30-round chains, the last ones a handful of rounds.
     u32* d_perm = nullptr;
     if (n_batches > 1 && !ao) {
-        std::vector<necat_candidate> tmp;
-        const necat_candidate* hc = cands;
-        if (dev) {
-            tmp.resize(n);
-            NECAT_HIP(ctx, hipMemcpyAsync(tmp.data(), d_cands, n * sizeof(necat_candidate), hipMemcpyDeviceToHost, s));
-            NECAT_HIP(ctx, hipStreamSynchronize(s));
-            hc = tmp.data();
-        }
-        constexpr u32 kBins = 128;
-        std::vector<u8> bin(n);
-        u64 cnt[kBins + 1] = {0};
-        for (uint64_t i = 0; i < n; ++i) {
-            const necat_candidate& c = hc[i];
-            const u64 right = std::min(c.qsize - c.qoff, c.ssize - c.soff), left = std::min(c.qoff, c.soff);
-            const u64 b = std::min<u64>(kBins - 1, right / 480 + left / 480);
-            bin[i] = (u8)(kBins - 1 - b);                    // longest first
-            ++cnt[bin[i] + 1];
-        }
-        for (u32 b = 0; b < kBins; ++b) cnt[b + 1] += cnt[b];
-        std::vector<u32> perm(n);
-        for (uint64_t i = 0; i < n; ++i) perm[cnt[bin[i]]++] = (u32)i;
-        if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_PERM], n * 4))) { cleanup(); return rc; }
+        // on the device (k_len_order): the candidates may never have been on the host (necat_map_pair), and a host counting sort of
+        // millions of 88-byte records costs more than a batch's first rounds
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_PERM], n * 4 + 2 * kLenBins * 4 + 64))) { cleanup(); return rc; }
         d_perm = (u32*)ctx->scratch[SC_EXT_PERM].p;
-        NECAT_HIP(ctx, hipMemcpyAsync(d_perm, perm.data(), n * 4, hipMemcpyHostToDevice, s));
-        NECAT_HIP(ctx, hipStreamSynchronize(s));       // perm is a local
+        u32* d_cur = d_perm + n;
+        NECAT_HIP(ctx, hipMemsetAsync(d_cur, 0, kLenBins * 4, s));
+        hipLaunchKernelGGL(k_len_order<0>, dim3(grid_for(n, 256, 1u << 23)), dim3(256), 0, s, (const necat_candidate*)d_cands, (u32)n, d_cur, (u32*)nullptr);
+        u32 cnt[kLenBins], start[kLenBins];
+        NECAT_HIP(ctx, hipMemcpyAsync(cnt, d_cur, sizeof cnt, hipMemcpyDeviceToHost, s));
+        NECAT_HIP(ctx, hipStreamSynchronize(s));
+        u32 run = 0;
+        for (int b = 0; b < kLenBins; ++b) { start[b] = run; run += cnt[b]; }
+        NECAT_HIP(ctx, hipMemcpyAsync(d_cur, start, sizeof start, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_len_order<1>, dim3(grid_for(n, 256, 1u << 23)), dim3(256), 0, s, (const necat_candidate*)d_cands, (u32)n, d_cur, d_perm);
+        NECAT_CHECK_LAUNCH(ctx, "k_len_order");
+        NECAT_HIP(ctx, hipStreamSynchronize(s));       // `start` is a local
     }
     NECAT_HIP(ctx, hipStreamSynchronize(s));        // candidates + zeroed counters are in place before the batch streams start
     tick("buffers + upload");
