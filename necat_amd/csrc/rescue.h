@@ -15,6 +15,8 @@
 #include <cstdint>
 #include <climits>
 #include <cstddef>
+#include <algorithm>
+#include <string>
 #include <vector>
 
 namespace rescue {
@@ -208,6 +210,190 @@ struct Dalign {
         const int asize = r.aepos - r.abpos, bsize = r.bepos - r.bbpos;
         if (!(asize >= min_align_size && bsize >= min_align_size)) return false;
         ident_perc = 100.0 - 200.0 * r.diffs / (asize + bsize);
+        return true;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// edlib_go (edlib/edlib_wrapper.c:111-242): the global alignment of query[query_from, query_to) with target[target_from,
+// target_to), accepted when its distance is at most `tolerance` and at most error * (target_size - 1), as the path edlib's NW mode
+// returns for it (edlib/edlib.cpp: edlibAlign :149, obtainAlignment :1106, obtainAlignmentHirschberg :1177,
+// obtainAlignmentTraceback :887), trimmed at both ends to the first run of kMatchSize matches.
+//
+// Among the optimal alignments edlib returns one particular path, and the callers read the alignment strings, so the choice is
+// restated with it: a problem whose traceback store (20 bytes per 64-row block and column + 8 per column) stays under 1 MB is
+// walked back from its last cell preferring "up" (a query base against a gap), then "left" (a target base against a gap), then
+// the diagonal; a larger one is split at the middle column of the target, at the FIRST query row (ascending; then the row above
+// the first, then the last) where the prefix cost to the left column plus the suffix cost from the next row and column add up to
+// the optimum, and both parts are solved the same way with those two costs as their optima.  edlib computes the columns inside
+// Ukkonen's band for that optimum; every cell either rule can select lies on an optimal path and so inside the band with its exact
+// value, which is why plain, unbanded columns give the same path (the tests pin this against the reference's build).
+namespace detail {
+
+enum : uint8_t { kOpMatch = 0, kOpInsert = 1, kOpDelete = 2, kOpMismatch = 3 };   // EDLIB_EDOP_*
+
+struct BitColumns {          // Myers' bit-vector columns over the whole query height, one 64-row word per block
+    int m = 0, nb = 0;
+    std::vector<uint64_t> eq, P, M;
+    void set_query(const uint8_t* q, int m_)
+    {
+        m = m_; nb = (m + 63) / 64;
+        eq.assign((size_t)4 * nb, 0);
+        for (int r = 0; r < m; ++r) eq[(size_t)(q[r] & 3) * nb + (r >> 6)] |= 1ULL << (r & 63);
+    }
+    // D(r, n - 1) for r in [0, m): the cost of query[0..r] against target[0..n-1], global on both (rows and columns start at r + 1, c + 1)
+    void last_column(const uint8_t* t, int n, std::vector<int>& col)
+    {
+        P.assign((size_t)nb, ~0ULL); M.assign((size_t)nb, 0ULL);
+        for (int c = 0; c < n; ++c) {
+            const uint64_t* e = &eq[(size_t)(t[c] & 3) * nb];
+            int hin = 1;
+            for (int b = 0; b < nb; ++b) {
+                uint64_t pv = P[b], mv = M[b], x = e[b];
+                const uint64_t hneg = hin < 0 ? 1ULL : 0ULL;
+                const uint64_t xv = x | mv;
+                x |= hneg;
+                const uint64_t xh = (((x & pv) + pv) ^ pv) | x;
+                uint64_t ph = mv | ~(xh | pv), mh = pv & xh;
+                const int hout = (int)(ph >> 63) - (int)(mh >> 63);
+                ph = (ph << 1) | (hin > 0 ? 1ULL : 0ULL); mh = (mh << 1) | hneg;
+                P[b] = mh | ~(xv | ph); M[b] = ph & xv;
+                hin = hout;
+            }
+        }
+        col.resize((size_t)m);
+        int s = n;
+        for (int r = 0; r < m; ++r) { s += (int)((P[r >> 6] >> (r & 63)) & 1) - (int)((M[r >> 6] >> (r & 63)) & 1); col[(size_t)r] = s; }
+    }
+};
+
+struct NwPath {
+    std::vector<uint8_t> ops;
+    std::vector<int> D, L, R;
+    std::vector<uint8_t> rq, rt;
+    BitColumns bc;
+
+    // obtainAlignmentTraceback's walk over the whole table of a small problem
+    void leaf(const uint8_t* q, int m, const uint8_t* t, int n)
+    {
+        const size_t h = (size_t)m + 1;
+        D.resize(h * ((size_t)n + 1));
+        for (int r = 0; r <= m; ++r) D[(size_t)r] = r;
+        for (int c = 1; c <= n; ++c) {
+            int* cur = &D[(size_t)c * h];
+            const int* prv = cur - h;
+            const uint8_t tc = t[c - 1];
+            cur[0] = c;
+            for (int r = 1; r <= m; ++r) {
+                int v = prv[r - 1] + (q[r - 1] != tc);
+                v = std::min(v, prv[r] + 1);
+                v = std::min(v, cur[r - 1] + 1);
+                cur[r] = v;
+            }
+        }
+        const size_t at0 = ops.size();
+        int r = m, c = n;
+        while (r > 0 || c > 0) {
+            const int cur = D[(size_t)c * h + r];
+            if (r > 0 && D[(size_t)c * h + r - 1] + 1 == cur) { ops.push_back(kOpInsert); --r; }
+            else if (c > 0 && D[(size_t)(c - 1) * h + r] + 1 == cur) { ops.push_back(kOpDelete); --c; }
+            else { ops.push_back(D[(size_t)(c - 1) * h + r - 1] == cur ? kOpMatch : kOpMismatch); --r; --c; }
+        }
+        std::reverse(ops.begin() + (ptrdiff_t)at0, ops.end());
+    }
+
+    // obtainAlignment: appends the path of q[0, m) against t[0, n), whose optimum is `best`
+    bool solve(const uint8_t* q, int m, const uint8_t* t, int n, int best)
+    {
+        if (m == 0 || n == 0) { ops.insert(ops.end(), (size_t)(m + n), m == 0 ? kOpDelete : kOpInsert); return true; }
+        const long long blocks = (m + 63) / 64;
+        if (20LL * blocks * n + 8LL * n < 1024 * 1024) { leaf(q, m, t, n); return true; }
+        const int lw = n / 2, rw = n - lw;
+        bc.set_query(q, m);
+        bc.last_column(t, lw, L);
+        rq.assign(q, q + m); std::reverse(rq.begin(), rq.end());
+        rt.assign(t + lw, t + n); std::reverse(rt.begin(), rt.end());
+        bc.set_query(rq.data(), m);
+        bc.last_column(rt.data(), rw, R);            // R[i]: query[m-1-i, m) against the right half
+        int row = -2, ls = 0, rs = 0;
+        for (int i = 0; i + 1 < m; ++i)
+            if (L[(size_t)i] + R[(size_t)(m - 2 - i)] == best) { row = i; ls = L[(size_t)i]; rs = R[(size_t)(m - 2 - i)]; break; }
+        if (row == -2 && lw + R[(size_t)m - 1] == best) { row = -1; ls = lw; rs = R[(size_t)m - 1]; }
+        if (row == -2 && L[(size_t)m - 1] + rw == best) { row = m - 1; ls = L[(size_t)m - 1]; rs = rw; }
+        if (row == -2) return false;
+        const int uh = row + 1;
+        return solve(q, uh, t, lw, ls) && solve(q + uh, m - uh, t + lw, rw, rs);
+    }
+};
+
+}  // namespace detail
+
+struct EdlibGo {
+    double error;
+    int qoff = 0, qend = 0, toff = 0, tend = 0, dist = 0;
+    double ident_perc = 0.0;
+    std::string query_align, target_align;       // gapped, 'A' 'C' 'G' 'T' '-'
+    detail::NwPath path;
+    std::vector<int> col;
+    std::string qa, ta;
+    explicit EdlibGo(double error_) : error(error_) {}
+
+    // find_path = TRUE, as consensus_aux.c:179 and rm_worker.c:115 call it
+    bool go(const char* query, int query_from, int query_to, const char* target, int target_from, int target_to, int tolerance,
+            int min_align_size, int match_size = 4)
+    {
+        const int m = query_to - query_from, n = target_to - target_from;
+        if (m <= 0 || n <= 0 || tolerance < 0) return false;
+        const uint8_t* q = (const uint8_t*)query + query_from;
+        const uint8_t* t = (const uint8_t*)target + target_from;
+        if (tolerance < (m > n ? m - n : n - m)) return false;
+        path.bc.set_query(q, m);
+        path.bc.last_column(t, n, col);
+        const int best = col[(size_t)m - 1];
+        if (best > tolerance) return false;
+        const int align_len = n - 1;
+        if (align_len < min_align_size) return false;
+        if ((double)best / (double)align_len > error) return false;
+        path.ops.clear();
+        if (!path.solve(q, m, t, n, best)) return false;
+        const int len = (int)path.ops.size();
+        qa.resize((size_t)len); ta.resize((size_t)len);
+        for (int a = 0, x = 0, y = 0; a < len; ++a) {
+            const uint8_t op = path.ops[(size_t)a];
+            if (op == detail::kOpMatch || op == detail::kOpMismatch) { qa[(size_t)a] = "ACGT"[q[x++] & 3]; ta[(size_t)a] = "ACGT"[t[y++] & 3]; }
+            else if (op == detail::kOpInsert) { qa[(size_t)a] = "ACGT"[q[x++] & 3]; ta[(size_t)a] = '-'; }
+            else { qa[(size_t)a] = '-'; ta[(size_t)a] = "ACGT"[t[y++] & 3]; }
+        }
+        // both ends are cut back to their first run of match_size matches
+        int from = 0, pq = 0, pt = 0, run = 0;
+        while (from < len) {
+            run = qa[(size_t)from] == ta[(size_t)from] ? run + 1 : 0;
+            if (qa[(size_t)from] != '-') ++pq;
+            if (ta[(size_t)from] != '-') ++pt;
+            ++from;
+            if (run == match_size) break;
+        }
+        if (run != match_size) return false;
+        from -= match_size; pq -= match_size; pt -= match_size;
+        int to = len, tq = 0, tt = 0;
+        run = 0;
+        while (to) {
+            run = qa[(size_t)to - 1] == ta[(size_t)to - 1] ? run + 1 : 0;
+            if (qa[(size_t)to - 1] != '-') ++tq;
+            if (ta[(size_t)to - 1] != '-') ++tt;
+            --to;
+            if (run == match_size) break;
+        }
+        to += match_size; tq -= match_size; tt -= match_size;
+        query_align.assign(qa, (size_t)from, (size_t)(to - from));
+        target_align.assign(ta, (size_t)from, (size_t)(to - from));
+        qoff = query_from + pq; qend = query_from + m - tq;
+        toff = target_from + pt; tend = target_from + n - tt;
+        const int asz = to - from;
+        int same = 0;
+        for (int i = 0; i < asz; ++i) same += query_align[(size_t)i] == target_align[(size_t)i];
+        if (asz == 0) { ident_perc = 0.0; }
+        else { dist = asz - same; ident_perc = 100.0 * same / asz; }
         return true;
     }
 };
