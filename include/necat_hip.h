@@ -209,7 +209,10 @@ int  necat_gapped_strings(const uint8_t* ops, uint64_t n, const uint8_t* qseq, u
  * together, on the device (the DP kernels of necat_onc_align_batch, tail_match_len = 4); the loop's
  * sequential decisions (read already used, region already covered, cutoff) are then replayed in order on
  * the results, so the overlaps, their order and the per-template numbers are those of the sequential loop.
- * rescue_long_indels (-r, default 0: cns_options.c:19) is not supported. */
+ * With rescue_long_indels (-r 1; default 0: cns_options.c:19) a candidate whose block-wise extension failed or stopped more than
+ * 200 bp short of its chained range is aligned again on the HOST, as in the reference (consensus_aux.c:168-199): DALIGNER's local
+ * alignment around the anchor, then edlib's global path over that range (necat_amd/csrc/rescue.h, cns_rescue.h) - after each
+ * device pass, for the candidates that need it, on all host threads. */
 
 /* the fields of CnsOptions (consensus/cns_options.h:6-18) the loop reads; defaults cns_options.c:10-22 */
 typedef struct {
@@ -219,6 +222,7 @@ typedef struct {
     double error;                   /* -e 0.5 */
     double mapping_ratio;           /* -p 0.8 */
     int    use_fixed_ident_cutoff;  /* -u 0   */
+    int    rescue_long_indels;      /* -r 0   */
 } necat_cns_options;
 void necat_cns_default_options(necat_cns_options* o);
 
@@ -259,6 +263,9 @@ typedef struct {
     uint32_t            n_rounds;      /* device passes (one necat_onc_align_batch-like call each) */
     double              device_ms;     /* sum of the passes (HIP events, result copies included) */
     double              host_ms;       /* select + replay on the host */
+    /* -r 1 */
+    uint64_t            n_rescue_tried, n_rescued;   /* candidates handed to the host pair / alignments it replaced */
+    double              rescue_ms;     /* wall time of the pair over all passes (not part of host_ms) */
 } necat_cns_result;
 
 /* Order and cut of one partition file's candidates as oc2cns does it: records of one template together

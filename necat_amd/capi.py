@@ -65,14 +65,14 @@ assert CNS_OVERLAP_DTYPE.itemsize == 56 and CNS_TEMPLATE_DTYPE.itemsize == 56
 class CnsOptions(C.Structure):
     """necat_cns_options (include/necat_hip.h) = the CnsOptions fields the extension loop reads"""
     _fields_ = [("min_align_size", C.c_int), ("min_cov", C.c_int), ("max_cov", C.c_int), ("error", C.c_double),
-                ("mapping_ratio", C.c_double), ("use_fixed_ident_cutoff", C.c_int)]
+                ("mapping_ratio", C.c_double), ("use_fixed_ident_cutoff", C.c_int), ("rescue_long_indels", C.c_int)]
 
 
 class _CnsResult(C.Structure):
     _fields_ = [("n_templates", C.c_uint64), ("templates", C.c_void_p), ("n_overlaps", C.c_uint64), ("overlaps", C.c_void_p),
                 ("n_ranges", C.c_uint64), ("ranges", C.c_void_p), ("n_ops_blocks", C.c_uint32), ("ops", C.POINTER(C.c_void_p)),
                 ("n_aligned", C.c_uint64), ("n_used", C.c_uint64), ("n_rounds", C.c_uint32), ("device_ms", C.c_double),
-                ("host_ms", C.c_double)]
+                ("host_ms", C.c_double), ("n_rescue_tried", C.c_uint64), ("n_rescued", C.c_uint64), ("rescue_ms", C.c_double)]
 
 EXPORTED_SYMBOLS = [
     "necat_default_options", "necat_ctx_create", "necat_ctx_destroy", "necat_ctx_trim", "necat_last_error", "necat_device_name",
@@ -432,6 +432,7 @@ class CnsResult:
         self.ranges = self._view(c.ranges, 2 * c.n_ranges, np.dtype("<i4")).reshape(-1, 2)
         self.n_aligned, self.n_used, self.n_rounds = c.n_aligned, c.n_used, c.n_rounds
         self.device_ms, self.host_ms = c.device_ms, c.host_ms
+        self.n_rescue_tried, self.n_rescued, self.rescue_ms = c.n_rescue_tried, c.n_rescued, c.rescue_ms
 
     @staticmethod
     def _view(p, n, dtype):

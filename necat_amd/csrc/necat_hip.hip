@@ -15,6 +15,7 @@
 #include "pcan_kernels.h"
 #include "ext_kernels.h"
 #include "cns_loop.h"
+#include "cns_rescue.h"
 #include "comm.h"
 
 using namespace necat;
@@ -1731,6 +1732,7 @@ int necat_gapped_strings(const uint8_t* ops, uint64_t n, const uint8_t* qseq, ui
 void necat_cns_default_options(necat_cns_options* o)
 {   // consensus/cns_options.c:10-22
     o->min_align_size = 400; o->min_cov = 4; o->max_cov = 12; o->error = 0.5; o->mapping_ratio = 0.8; o->use_fixed_ident_cutoff = 0;
+    o->rescue_long_indels = 0;
 }
 
 int necat_cns_load_partition(necat_ctx* ctx, const necat_volume* reads, const void* packed, uint64_t n,
@@ -1790,6 +1792,74 @@ int necat_cns_extension_batch(necat_ctx* ctx, const necat_volume* reads, const n
     mo.error = opt->error; mo.align_size_cutoff = opt->min_align_size;
     std::vector<u8*> blocks;
     double device_ms = 0, align_wall = 0;
+    // -r 1: the host pair (cns_rescue.h) on the candidates of a pass whose block-wise extension failed or fell short.  The reads
+    // come back from the device once per call (2-bit words, base i in bits 2 (i & 31) of word i >> 5).
+    std::vector<u64> h_words;
+    const rescue::DalignSpec dspec = opt->rescue_long_indels ? rescue::spec_for_error(opt->error) : rescue::DalignSpec();
+    uint64_t n_rescue_tried = 0, n_rescued = 0;
+    double rescue_ms = 0;
+    auto rescue_pass = [&](const necat_candidate* c, uint64_t m, cns::Aligned* res) -> int {
+        const double r0 = wall_ms();
+        std::vector<uint64_t> need;
+        for (uint64_t i = 0; i < m; ++i) if (cns::extension_short(c[i], res[i].a)) need.push_back(i);
+        if (need.empty()) return NECAT_OK;
+        if (h_words.empty()) {
+            h_words.resize((reads->nbases + 31) / 32 + 1);
+            NECAT_HIP(ctx, hipMemcpy(h_words.data(), reads->bases, (h_words.size() - 1) * 8, hipMemcpyDeviceToHost));
+        }
+        struct Got { bool ok = false; necat_alignment a; std::vector<u8> packed; };
+        std::vector<Got> got(need.size());
+        std::atomic<size_t> next(0);
+        auto work = [&]() {
+            cns::Rescuer rs(dspec, opt->error);
+            std::vector<u8> q, t;
+            auto decode = [&](int32_t id, int rev, std::vector<u8>& dst) {
+                const u64 b = reads->h_seq_off[id], n = reads->h_seq_off[id + 1] - b;
+                dst.resize(n);
+                if (!rev) for (u64 i = 0; i < n; ++i) dst[i] = (u8)((h_words[(b + i) >> 5] >> (((b + i) & 31) * 2)) & 3);
+                else for (u64 i = 0; i < n; ++i) { const u64 g = b + n - 1 - i; dst[i] = (u8)(3 - ((h_words[g >> 5] >> ((g & 31) * 2)) & 3)); }
+            };
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= need.size()) break;
+                const necat_candidate& cc = c[need[k]];
+                decode(cc.qid, cc.qdir, q); decode(cc.sid, 0, t);
+                Got& g = got[k];
+                g.a = res[need[k]].a;
+                g.ok = rs.go(cc, q.data(), t.data(), opt->min_align_size, &g.a);
+                if (!g.ok) continue;
+                g.packed.assign((rs.cols.size() + 3) / 4, 0);
+                for (size_t j = 0; j < rs.cols.size(); ++j) g.packed[j >> 2] |= (u8)(rs.cols[j] << (2 * (j & 3)));
+            }
+        };
+        unsigned nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 32u));
+        nt = (unsigned)std::min<size_t>(nt, need.size());
+        std::vector<std::thread> th;
+        for (unsigned x = 0; x + 1 < nt; ++x) th.emplace_back(work);
+        work();
+        for (auto& x : th) x.join();
+        u64 bytes = 0;
+        for (const Got& g : got) if (g.ok) bytes += (g.packed.size() + 7) & ~(u64)7;
+        n_rescue_tried += need.size();
+        if (bytes) {
+            u8* blk = (u8*)result_alloc(bytes);
+            if (!blk) return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed");
+            const u32 bi = (u32)blocks.size();
+            blocks.push_back(blk);
+            u64 at = 0;
+            for (size_t k = 0; k < got.size(); ++k) {
+                const Got& g = got[k];
+                if (!g.ok) continue;
+                memcpy(blk + at, g.packed.data(), g.packed.size());
+                res[need[k]].a = g.a; res[need[k]].block = bi; res[need[k]].off = at;
+                at += (g.packed.size() + 7) & ~(u64)7;
+                ++n_rescued;
+            }
+        }
+        rescue_ms += wall_ms() - r0;
+        if (g_trace & 2) fprintf(stderr, "[necat] cns rescue: %zu of %lu candidates tried, %.2f ms\n", need.size(), (unsigned long)m, wall_ms() - r0);
+        return NECAT_OK;
+    };
     cns::AlignFn fn = [&](const necat_candidate* c, uint64_t m, cns::Aligned* res) -> int {
         const double a0 = wall_ms();
         AlignOut ao;
@@ -1817,7 +1887,7 @@ int necat_cns_extension_batch(necat_ctx* ctx, const necat_volume* reads, const n
         necat_free(ao.aln);
         align_wall += wall_ms() - a0;
         if (g_trace & 2) fprintf(stderr, "[necat] cns pass: %lu alignments, %.2f ms\n", (unsigned long)m, wall_ms() - a0);
-        return NECAT_OK;
+        return opt->rescue_long_indels ? rescue_pass(c, m, res) : NECAT_OK;
     };
     cns::Knobs kn; kn.spec_estimate_extra = g_cns_spec_extra; kn.spec_cover = g_cns_spec_cover;
     cns::Stats st;
@@ -1867,7 +1937,8 @@ int necat_cns_extension_batch(necat_ctx* ctx, const necat_volume* reads, const n
     r->n_ops_blocks = (uint32_t)blocks.size();
     for (size_t b = 0; b < blocks.size(); ++b) r->ops[b] = blocks[b];
     r->n_aligned = st.n_aligned; r->n_used = st.n_used; r->n_rounds = st.n_rounds;
-    r->device_ms = device_ms; r->host_ms = wall_ms() - w0 - align_wall;
+    r->device_ms = device_ms; r->host_ms = wall_ms() - w0 - align_wall - rescue_ms;
+    r->n_rescue_tried = n_rescue_tried; r->n_rescued = n_rescued; r->rescue_ms = rescue_ms;
     if (g_trace & 2) fprintf(stderr, "[necat] cns total %.2f ms: passes %.2f (device events %.2f), host %.2f\n", wall_ms() - w0, align_wall, device_ms, r->host_ms);
     ctx->tm.extend_ms = device_ms;
     *out = r;

@@ -8,9 +8,10 @@
 // aligned, which alignments count, with what weight - consensus/consensus_one_read.c:221-372), the consensus proper
 // (tasc/) on the host threads (cns_consensus.h).  Records come out in template order (the reference's order with -t 1;
 // with more threads the reference's order depends on scheduling).
-// Not supported: -r 1 (rescue_long_indels: DALIGNER + full edlib on candidates the block aligner rejects) - accepted with
-// a note, those candidates are simply dropped; -s 1 (small memory: reads loaded per partition) behaves like -s 0 - the read
-// set is resident in HBM either way.  There is no CPU fallback for the alignments: without a usable GPU the program exits 1.
+// -r 1 (rescue_long_indels): candidates whose block-wise extension failed or fell short go through DALIGNER's local alignment and
+// edlib's global path on the host threads after each device pass, as in the reference (cns_rescue.h).  -s 1 (small memory: reads
+// loaded per partition) behaves like -s 0 - the read set is resident in HBM either way.  There is no CPU fallback for the
+// block-wise alignments: without a usable GPU the program exits 1.
 #include <atomic>
 #include <thread>
 
@@ -93,7 +94,6 @@ int main(int argc, char** argv)
     const std::string can_path = argv[ac - 3];
     const char* cns_out_path = argv[ac - 2];
     const char* raw_out_path = argv[ac - 1];
-    if (opt.rescue_long_indels) fprintf(stderr, "[oc2cns] NOTE: -r 1 (rescue long indels) is not implemented: candidates the block aligner rejects are dropped\n");
     if (opt.max_cov < 1 || opt.min_cov < 0) return fail("options", "coverage limits out of range");
 
     std::string err;
@@ -147,6 +147,7 @@ int main(int argc, char** argv)
     necat_cns_options co; necat_cns_default_options(&co);
     co.min_align_size = opt.min_align_size; co.min_cov = opt.min_cov; co.max_cov = opt.max_cov; co.error = opt.error;
     co.mapping_ratio = opt.mapping_ratio; co.use_fixed_ident_cutoff = opt.use_fixed_ident_cutoff;
+    co.rescue_long_indels = opt.rescue_long_indels != 0;
     const int nthreads = std::max(1, std::min(opt.num_threads, 256));       // -t: host threads of the consensus proper
 
     for (int pid = spid; pid < num_partitions; pid += nnode) {

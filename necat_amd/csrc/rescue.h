@@ -194,12 +194,16 @@ inline DalignResult local_alignment(const char* aseq, int alen, const char* bseq
 }
 
 // ocda_go (gapped_align/oc_daligner.c:36-79): the local alignment through the anchor (query_start, target_start); base codes 0..3
+inline DalignSpec spec_for_error(double error) { const float f[4] = {.25f, .25f, .25f, .25f}; return make_spec(1.0 - error, f); }   // oc_daligner.c:7-17
+
 struct Dalign {
-    DalignSpec spec;
+    DalignSpec own;
+    const DalignSpec& spec;
     DalignResult r;
     double ident_perc = 0.0;
     std::vector<char> a, b;
-    explicit Dalign(double error) { const float f[4] = {.25f, .25f, .25f, .25f}; spec = make_spec(1.0 - error, f); }
+    explicit Dalign(double error) : own(spec_for_error(error)), spec(own) {}
+    explicit Dalign(const DalignSpec& shared) : spec(shared) {}      // many workers, one pair of 32 K-entry tables
     bool go(const char* query, int query_start, int query_size, const char* target, int target_start, int target_size, int min_align_size)
     {
         a.assign((size_t)query_size + 2, 4); b.assign((size_t)target_size + 2, 4);
@@ -225,30 +229,45 @@ struct Dalign {
 // walked back from its last cell preferring "up" (a query base against a gap), then "left" (a target base against a gap), then
 // the diagonal; a larger one is split at the middle column of the target, at the FIRST query row (ascending; then the row above
 // the first, then the last) where the prefix cost to the left column plus the suffix cost from the next row and column add up to
-// the optimum, and both parts are solved the same way with those two costs as their optima.  edlib computes the columns inside
-// Ukkonen's band for that optimum; every cell either rule can select lies on an optimal path and so inside the band with its exact
-// value, which is why plain, unbanded columns give the same path (the tests pin this against the reference's build).
+// the optimum, and both parts are solved the same way with those two costs as their optima.  Every cell either rule can select lies
+// on an optimal path, so any computation that is exact on the cells of paths within the optimum - edlib's banded blocks, the
+// banded columns below - makes the same choices (the tests pin this against the reference's build).
 namespace detail {
 
 enum : uint8_t { kOpMatch = 0, kOpInsert = 1, kOpDelete = 2, kOpMismatch = 3 };   // EDLIB_EDOP_*
 
-struct BitColumns {          // Myers' bit-vector columns over the whole query height, one 64-row word per block
-    int m = 0, nb = 0;
+constexpr int kFar = INT32_MAX / 4;     // "outside the band"
+
+// Myers' bit-vector columns, 64 query rows per word, inside Ukkonen's band for an optimum of at most k: a cell (r, c) of a path
+// that costs at most k in total has |r - c| + |(m - n) - (r - c)| <= k.  Whatever lies outside enters as an upper bound (a new
+// block below starts one more per row than the block above it, the row above the band one more per column), so every cell whose
+// true value can matter - those on a path within k - comes out exact, the others at least as large as they are.
+struct BitColumns {
+    int m = 0, nb = 0, dmin = 0, dmax = 0, fb = 0, lb = -1;
     std::vector<uint64_t> eq, P, M;
+    std::vector<int> bot;            // value at the last row of each block in the current column
+    std::vector<uint64_t> sv, sh;    // traceback store: per column and block, the vertical (after the column) and horizontal +1 flags
     void set_query(const uint8_t* q, int m_)
     {
         m = m_; nb = (m + 63) / 64;
         eq.assign((size_t)4 * nb, 0);
         for (int r = 0; r < m; ++r) eq[(size_t)(q[r] & 3) * nb + (r >> 6)] |= 1ULL << (r & 63);
     }
-    // D(r, n - 1) for r in [0, m): the cost of query[0..r] against target[0..n-1], global on both (rows and columns start at r + 1, c + 1)
-    void last_column(const uint8_t* t, int n, std::vector<int>& col)
+    void set_band(int n_total, int k) { const int delta = m - n_total; dmin = -((k - delta) / 2); dmax = (delta + k) / 2; }
+    // columns 0 .. n_stop - 1 of the target
+    template <bool STORE>
+    void run(const uint8_t* t, int n_stop)
     {
-        P.assign((size_t)nb, ~0ULL); M.assign((size_t)nb, 0ULL);
-        for (int c = 0; c < n; ++c) {
+        P.resize((size_t)nb); M.resize((size_t)nb); bot.resize((size_t)nb);
+        if (STORE) { sv.resize((size_t)n_stop * nb); sh.resize((size_t)n_stop * nb); }
+        lb = -1; fb = 0;
+        for (int c = 0; c < n_stop; ++c) {
+            const int nfb = std::max(0, c + dmin) >> 6, nlb = std::min(m - 1, c + dmax) >> 6;
+            for (int b = lb + 1; b <= nlb; ++b) { P[b] = ~0ULL; M[b] = 0; bot[b] = (b ? bot[b - 1] : c) + 64; }
+            fb = nfb; lb = nlb;
             const uint64_t* e = &eq[(size_t)(t[c] & 3) * nb];
             int hin = 1;
-            for (int b = 0; b < nb; ++b) {
+            for (int b = fb; b <= lb; ++b) {
                 uint64_t pv = P[b], mv = M[b], x = e[b];
                 const uint64_t hneg = hin < 0 ? 1ULL : 0ULL;
                 const uint64_t xv = x | mv;
@@ -256,49 +275,54 @@ struct BitColumns {          // Myers' bit-vector columns over the whole query h
                 const uint64_t xh = (((x & pv) + pv) ^ pv) | x;
                 uint64_t ph = mv | ~(xh | pv), mh = pv & xh;
                 const int hout = (int)(ph >> 63) - (int)(mh >> 63);
+                if (STORE) sh[(size_t)c * nb + b] = ph;
                 ph = (ph << 1) | (hin > 0 ? 1ULL : 0ULL); mh = (mh << 1) | hneg;
                 P[b] = mh | ~(xv | ph); M[b] = ph & xv;
+                if (STORE) sv[(size_t)c * nb + b] = P[b];
+                bot[b] += hout;
                 hin = hout;
             }
         }
-        col.resize((size_t)m);
-        int s = n;
-        for (int r = 0; r < m; ++r) { s += (int)((P[r >> 6] >> (r & 63)) & 1) - (int)((M[r >> 6] >> (r & 63)) & 1); col[(size_t)r] = s; }
+    }
+    // D(r, n_stop - 1) for r in [0, m) after run(): the cost of query[0..r] against target[0..n_stop-1]; kFar outside the band
+    void column(std::vector<int>& col) const
+    {
+        col.assign((size_t)m, kFar);
+        for (int b = fb; b <= lb; ++b) {
+            int s = bot[b];
+            for (int r = 64 * b + 63; r >= 64 * b; --r) {
+                if (r < m) col[(size_t)r] = s;
+                s -= (int)((P[b] >> (r & 63)) & 1) - (int)((M[b] >> (r & 63)) & 1);
+            }
+        }
     }
 };
 
 struct NwPath {
     std::vector<uint8_t> ops;
-    std::vector<int> D, L, R;
+    std::vector<int> L, R;
     std::vector<uint8_t> rq, rt;
     BitColumns bc;
 
-    // obtainAlignmentTraceback's walk over the whole table of a small problem
-    void leaf(const uint8_t* q, int m, const uint8_t* t, int n)
+    // obtainAlignmentTraceback's walk.  Its three tests read, for a cell on an optimal path: is the cell above one less (the
+    // vertical +1 flag), else is the cell to the left one less (the horizontal +1 flag), else the diagonal - a match exactly when
+    // the two bases are equal, since neither neighbour being one less leaves "diagonal + mismatch" or "diagonal, equal bases".
+    void leaf(const uint8_t* q, int m, const uint8_t* t, int n, int best)
     {
-        const size_t h = (size_t)m + 1;
-        D.resize(h * ((size_t)n + 1));
-        for (int r = 0; r <= m; ++r) D[(size_t)r] = r;
-        for (int c = 1; c <= n; ++c) {
-            int* cur = &D[(size_t)c * h];
-            const int* prv = cur - h;
-            const uint8_t tc = t[c - 1];
-            cur[0] = c;
-            for (int r = 1; r <= m; ++r) {
-                int v = prv[r - 1] + (q[r - 1] != tc);
-                v = std::min(v, prv[r] + 1);
-                v = std::min(v, cur[r - 1] + 1);
-                cur[r] = v;
-            }
-        }
+        bc.set_query(q, m);
+        bc.set_band(n, best);
+        bc.run<true>(t, n);
         const size_t at0 = ops.size();
-        int r = m, c = n;
-        while (r > 0 || c > 0) {
-            const int cur = D[(size_t)c * h + r];
-            if (r > 0 && D[(size_t)c * h + r - 1] + 1 == cur) { ops.push_back(kOpInsert); --r; }
-            else if (c > 0 && D[(size_t)(c - 1) * h + r] + 1 == cur) { ops.push_back(kOpDelete); --c; }
-            else { ops.push_back(D[(size_t)(c - 1) * h + r - 1] == cur ? kOpMatch : kOpMismatch); --r; --c; }
+        const int nb = bc.nb;
+        int r = m - 1, c = n - 1;
+        while (r >= 0 && c >= 0) {
+            const size_t w = (size_t)c * nb + (r >> 6);
+            if ((bc.sv[w] >> (r & 63)) & 1) { ops.push_back(kOpInsert); --r; }
+            else if ((bc.sh[w] >> (r & 63)) & 1) { ops.push_back(kOpDelete); --c; }
+            else { ops.push_back(q[r] == t[c] ? kOpMatch : kOpMismatch); --r; --c; }
         }
+        for (; r >= 0; --r) ops.push_back(kOpInsert);
+        for (; c >= 0; --c) ops.push_back(kOpDelete);
         std::reverse(ops.begin() + (ptrdiff_t)at0, ops.end());
     }
 
@@ -307,14 +331,18 @@ struct NwPath {
     {
         if (m == 0 || n == 0) { ops.insert(ops.end(), (size_t)(m + n), m == 0 ? kOpDelete : kOpInsert); return true; }
         const long long blocks = (m + 63) / 64;
-        if (20LL * blocks * n + 8LL * n < 1024 * 1024) { leaf(q, m, t, n); return true; }
+        if (20LL * blocks * n + 8LL * n < 1024 * 1024) { leaf(q, m, t, n, best); return true; }
         const int lw = n / 2, rw = n - lw;
         bc.set_query(q, m);
-        bc.last_column(t, lw, L);
+        bc.set_band(n, best);
+        bc.run<false>(t, lw);
+        bc.column(L);
         rq.assign(q, q + m); std::reverse(rq.begin(), rq.end());
         rt.assign(t + lw, t + n); std::reverse(rt.begin(), rt.end());
         bc.set_query(rq.data(), m);
-        bc.last_column(rt.data(), rw, R);            // R[i]: query[m-1-i, m) against the right half
+        bc.set_band(n, best);
+        bc.run<false>(rt.data(), rw);
+        bc.column(R);                                // R[i]: query[m-1-i, m) against the right half
         int row = -2, ls = 0, rs = 0;
         for (int i = 0; i + 1 < m; ++i)
             if (L[(size_t)i] + R[(size_t)(m - 2 - i)] == best) { row = i; ls = L[(size_t)i]; rs = R[(size_t)(m - 2 - i)]; break; }
@@ -348,7 +376,9 @@ struct EdlibGo {
         const uint8_t* t = (const uint8_t*)target + target_from;
         if (tolerance < (m > n ? m - n : n - m)) return false;
         path.bc.set_query(q, m);
-        path.bc.last_column(t, n, col);
+        path.bc.set_band(n, std::min(tolerance, std::max(m, n)));
+        path.bc.run<false>(t, n);
+        path.bc.column(col);
         const int best = col[(size_t)m - 1];
         if (best > tolerance) return false;
         const int align_len = n - 1;

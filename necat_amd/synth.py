@@ -128,6 +128,31 @@ def simulate_reads(genome_len: int = 4_600_000, coverage: float = 40.0, seed: in
     return ReadSet(codes=codes, offsets=off, sizes=sz, names=names)
 
 
+def add_long_indels(rs: ReadSet, frac: float = 0.4, seed: int = 1, lo: int = 250, hi: int = 900) -> ReadSet:
+    """A copy of `rs` in which a fraction of the reads carries one or two long indels (a stretch removed, or random bases
+    put in): the overlaps the block-wise extension cannot bridge, which oc2cns -r 1 hands to its rescue pair."""
+    rng = np.random.default_rng(seed)
+    chunks: List[np.ndarray] = []
+    for i in range(rs.nreads):
+        r = rs.read(i)
+        if rng.random() < frac:
+            for _ in range(int(rng.integers(1, 3))):
+                n = int(rng.integers(lo, hi))
+                if r.shape[0] < 3 * n + 600:
+                    break
+                at = int(rng.integers(300, r.shape[0] - n - 300))
+                if rng.random() < 0.5:
+                    r = np.concatenate([r[:at], r[at + n:]])
+                else:
+                    r = np.concatenate([r[:at], rng.integers(0, 4, n, dtype=np.uint8), r[at:]])
+        chunks.append(np.ascontiguousarray(r, dtype=np.uint8))
+    sz = np.asarray([c.shape[0] for c in chunks], dtype=np.int64)
+    off = np.zeros_like(sz)
+    if sz.shape[0] > 1:
+        np.cumsum(sz[:-1], out=off[1:])
+    return ReadSet(codes=np.concatenate(chunks) if chunks else np.zeros(0, dtype=np.uint8), offsets=off, sizes=sz, names=list(rs.names))
+
+
 def pack_2bit(codes: np.ndarray) -> np.ndarray:
     """2-bit pack, first base of each byte in the top two bits (ontcns_aux.h:118-119)."""
     n = codes.shape[0]

@@ -3,7 +3,11 @@
 // by template, with the oracle's sequential restatement of the reference loop (oracle/cns_oracle.c).
 // The oracle appears here only as the checker and as a stand-in aligner for a machine without a GPU.
 //
-//   check_cns wrk_dir can_prefix [min_align min_cov max_cov error ratio fixed [spec_extra spec_cover]]
+//   check_cns wrk_dir can_prefix [min_align min_cov max_cov error ratio fixed [spec_extra spec_cover [adapt_mult adapt_min [rescue log]]]]
+//
+// rescue = 1: cns_rescue.h runs behind the stand-in aligner as it does behind the device pass in the library (oc2cns -r 1).  The
+// oracle's loop has no rescue, so nothing is compared in-process; `log` receives the loop's decisions in the format of
+// oracle/cns_ref_harness.c ("full"), for the test to compare with the REFERENCE's own log.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -12,6 +16,7 @@
 #include <vector>
 
 #include "../../necat_amd/csrc/cns_loop.h"
+#include "../../necat_amd/csrc/cns_rescue.h"
 #include "../../oracle/necat_oracle.h"
 
 using namespace necat;
@@ -19,7 +24,7 @@ using namespace necat;
 int main(int argc, char** argv)
 {
     if (argc < 3) { fprintf(stderr, "usage\n"); return 2; }
-    necat_cns_options opt = {400, 4, 12, 0.5, 0.8, 0};
+    necat_cns_options opt = {400, 4, 12, 0.5, 0.8, 0, 0};
     cns::Knobs kn;
     if (argc >= 9) {
         opt.min_align_size = atoi(argv[3]); opt.min_cov = atoi(argv[4]); opt.max_cov = atoi(argv[5]);
@@ -27,6 +32,11 @@ int main(int argc, char** argv)
     }
     if (argc >= 11) { kn.spec_estimate_extra = atoi(argv[9]); kn.spec_cover = atoi(argv[10]); }
     if (argc >= 13) { kn.adapt_mult = atof(argv[11]); kn.adapt_min = atoi(argv[12]); }
+    FILE* log = nullptr;
+    if (argc >= 15) { opt.rescue_long_indels = atoi(argv[13]); log = fopen(argv[14], "w"); if (!log) return 2; }
+    const rescue::DalignSpec dspec = rescue::spec_for_error(opt.error);
+    cns::Rescuer rescuer(dspec, opt.error);
+    uint64_t n_tried = 0, n_rescued = 0;
     ora_cns_options oo = {opt.min_align_size, opt.min_cov, opt.max_cov, opt.error, opt.mapping_ratio, opt.use_fixed_ident_cutoff};
     ora_volume reads;
     if (ora_volumes_merge(argv[1], &reads)) { fprintf(stderr, "cannot load %s\n", argv[1]); return 2; }
@@ -70,6 +80,15 @@ int main(int argc, char** argv)
                 out[i].a.ok = ok; out[i].a.qoff = r.qoff; out[i].a.qend = r.qend; out[i].a.toff = r.toff; out[i].a.tend = r.tend;
                 out[i].a.align_size = r.align_size; out[i].a.ident_perc = r.ident_perc;
                 out[i].block = (uint32_t)blocks.size() - 1; out[i].off = blk.size();
+                if (opt.rescue_long_indels && cns::extension_short(c[i], out[i].a)) {
+                    ++n_tried;
+                    if (rescuer.go(c[i], qbuf.data(), tbuf.data(), opt.min_align_size, &out[i].a)) {
+                        ++n_rescued;
+                        blk.insert(blk.end(), rescuer.cols.begin(), rescuer.cols.end());
+                        continue;
+                    }
+                }
+                if (!ok) continue;
                 for (int k = 0; k < r.align_size; ++k) {
                     const char q = r.query_align[k], t = r.target_align[k];
                     blk.push_back(q == '-' ? 2 : (t == '-' ? 1 : (q == t ? 0 : 3)));
@@ -80,9 +99,39 @@ int main(int argc, char** argv)
         cns::Stats st;
         if (cns::run(ts, opt, kn, fn, &st)) return 2;
         n_aligned += st.n_aligned; n_used += st.n_used; n_rounds += st.n_rounds;
+        static const char dec[5] = {'A', 'C', 'G', 'T', '-'};
+        if (log) {
+            // the log of oracle/cns_ref_harness.c, "full"
+            std::string qa, ta;
+            for (size_t t = 0; t < ts.size(); ++t) {
+                const cns::Template& G = ts[t];
+                if (!G.examined) continue;
+                for (size_t k = 0; k < G.overlaps.size(); ++k) {
+                    const necat_cns_overlap& g = G.overlaps[k];
+                    const necat_candidate& c = cands[g.cand];
+                    qbuf.resize(c.qsize + 1); tbuf.resize(c.ssize + 1);
+                    ora_volume_extract(&reads, (uint64_t)c.qid, c.qdir, qbuf.data());
+                    ora_volume_extract(&reads, (uint64_t)c.sid, 0, tbuf.data());
+                    const uint8_t* ops = blocks[g.ops_block].data() + g.ops_off;
+                    qa.clear(); ta.clear();
+                    int q = g.qoff, tt = g.toff;
+                    for (int x = 0; x < g.align_size; ++x) {
+                        qa.push_back(ops[x] == 2 ? '-' : dec[qbuf[q]]); ta.push_back(ops[x] == 1 ? '-' : dec[tbuf[tt]]);
+                        q += ops[x] != 2; tt += ops[x] != 1;
+                    }
+                    auto fnv = [](const std::string& s) { unsigned long long h = 1469598103934665603ULL; for (unsigned char ch : s) { h ^= ch; h *= 1099511628211ULL; } return h; };
+                    fprintf(log, "A\t%d\t%d\t%.17g\t%d\t%016llx\t%016llx\t%s\t%s\n", g.toff, g.tend, g.weight, g.align_size, fnv(qa), fnv(ta), qa.c_str(), ta.c_str());
+                    ++n_overlaps;
+                }
+                fprintf(log, "T\t%d\t%d\t%.17g\t%d\t%d\t%zu", G.c[0].sid, G.tsize, G.ident_cutoff, G.num_can, G.num_ovlps, (size_t)G.ranges.size() / 2);
+                for (size_t k = 0; k < G.ranges.size(); ++k) fprintf(log, "\t%d", G.ranges[k]);
+                fprintf(log, "\n");
+                ++n_templates;
+            }
+        }
+        if (opt.rescue_long_indels) { ora_cns_result_free(&want); continue; }
         // compare
         if (want.n_templates != ts.size()) { printf("partition %d: %zu templates, oracle %zu\n", p, ts.size(), want.n_templates); ++mism; continue; }
-        static const char dec[5] = {'A', 'C', 'G', 'T', '-'};
         for (size_t t = 0; t < ts.size(); ++t) {
             const ora_cns_template& W = want.templates[t];
             const cns::Template& G = ts[t];
@@ -120,7 +169,9 @@ int main(int argc, char** argv)
         }
         ora_cns_result_free(&want);
     }
-    printf("cns_mismatch=%lu templates=%lu overlaps=%lu aligned=%lu used=%lu rounds=%lu\n", (unsigned long)mism, (unsigned long)n_templates,
-           (unsigned long)n_overlaps, (unsigned long)n_aligned, (unsigned long)n_used, (unsigned long)n_rounds);
+    if (log) fclose(log);
+    printf("cns_mismatch=%lu templates=%lu overlaps=%lu aligned=%lu used=%lu rounds=%lu rescue_tried=%lu rescued=%lu\n", (unsigned long)mism,
+           (unsigned long)n_templates, (unsigned long)n_overlaps, (unsigned long)n_aligned, (unsigned long)n_used, (unsigned long)n_rounds,
+           (unsigned long)n_tried, (unsigned long)n_rescued);
     return mism ? 1 : 0;
 }

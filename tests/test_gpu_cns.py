@@ -195,3 +195,37 @@ def test_oc2cns_program_sparse_partitions_and_nodes(built, tmp_path):
     parts = [_run_oc2cns(built, argv, d, can, str(tmp_path), "n%d" % n, mn=(n, 2)) for n in range(2)]
     recs = lambda b: sorted(b.split(b">"))
     assert recs(parts[0][0] + parts[1][0]) == recs(cns) and recs(parts[0][1] + parts[1][1]) == recs(raw)
+
+
+# ---- -r 1: the host rescue pair behind the device pass (cns_rescue.h) ----
+
+@pytest.mark.skipif(not (ora.have_ref_cns() and os.path.exists(ora.REF_OC2CNS)),
+                    reason="needs oracle/_ref (built from /root/reference; it travels to the GPU box)")
+def test_cns_rescue_long_indels_vs_reference(ctx, built, tmp_path):
+    """reads with long indels, rescue_long_indels = 1: the loop's decisions and alignments through the C ABI against the log of the
+    REFERENCE's consensus driver run with -r 1, then the oc2cns program's two files against the reference's oc2cns -r 1"""
+    wrk, can, part = util.make_long_indel_partition(tmp_path)
+    want = os.path.join(str(tmp_path), "ref_r1.txt")
+    subprocess.run([ora.REF_CNS] + ora.cns_argv(ora.cns_options()) + ["-r", "1", wrk, can, want, "full"], check=True,
+                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    vol = ctx.load_merged_volumes(wrk)
+    cands, off, n_all = ctx.cns_load_partition(vol, np.frombuffer(part, dtype=np.uint8))
+    res = ctx.cns_extension_batch(vol, cands, off, n_all, capi.cns_options(rescue_long_indels=1))
+    roff = np.zeros(len(vol.names) + 1, dtype=np.int64)
+    roff[1:] = np.cumsum(vol.sizes)
+    txt = util.cns_log_text(res, cands, off, vol.codes, roff, ora.fnv64, full=True)
+    assert res.n_rescued > 150 and res.n_rescue_tried >= res.n_rescued
+    res.free()
+    res0 = ctx.cns_extension_batch(vol, cands, off, n_all, capi.cns_options())
+    assert res0.n_rescue_tried == 0 and res0.n_rescued == 0
+    txt0 = util.cns_log_text(res0, cands, off, vol.codes, roff, ora.fnv64, full=True)
+    res0.free()
+    vol.free()
+    assert txt == open(want).read()
+    assert txt0 != txt
+    argv = ora.cns_argv(ora.cns_options()) + ["-r", "1"]
+    rc, rr = os.path.join(str(tmp_path), "ref_cns"), os.path.join(str(tmp_path), "ref_raw")
+    subprocess.run([ora.REF_OC2CNS] + argv + ["-t", "1", wrk, can, rc, rr], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    cns, raw = _run_oc2cns(built, argv + ["-t", "3"], wrk, can, str(tmp_path), "r1")
+    assert cns == open(rc, "rb").read() and cns.count(b">") > 40
+    assert raw == open(rr, "rb").read()

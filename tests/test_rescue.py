@@ -141,3 +141,31 @@ def test_edlib_go_edges(libs):
     for i, c in enumerate(cases):
         a, b = edlib_case(ref, mine, *c)
         assert a == b, i
+
+
+def test_cns_loop_with_rescue_matches_reference(tmp_path):
+    """oc2cns -r 1 without a GPU: the extension loop (cns_loop.h) with the oracle's block-wise aligner and cns_rescue.h behind it,
+    as the library runs it behind the device pass, on reads with long indels - every add_one_align call (gapped strings included)
+    and every template's numbers as logged from the REFERENCE's own consensus driver run with -r 1."""
+    from oracle import oracle_api as ora
+    if not ora.have_ref_cns():
+        pytest.skip("oracle/_ref/cns_ref_harness is absent")
+    d = str(tmp_path)
+    objs = []
+    for src in ("necat_oracle.c", "cns_oracle.c"):
+        obj = os.path.join(d, src[:-2] + ".o")
+        subprocess.run(["gcc", "-O2", "-std=gnu99", "-c", os.path.join(util.ROOT, "oracle", src), "-o", obj], check=True)
+        objs.append(obj)
+    exe = os.path.join(d, "check_cns")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe,
+                    os.path.join(util.ROOT, "tests", "host_core", "check_cns.cpp")] + objs + ["-lm", "-lpthread"], check=True)
+    wrk, can, _ = util.make_long_indel_partition(tmp_path)
+    want = os.path.join(d, "ref_r1.txt")
+    subprocess.run([ora.REF_CNS] + ora.cns_argv(ora.cns_options()) + ["-r", "1", wrk, can, want, "full"], check=True,
+                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    got = os.path.join(d, "mine_r1.txt")
+    r = subprocess.run([exe, wrk, can] + "400 4 12 0.5 0.8 0 1 12 1.25 2 1".split() + [got], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    f = dict(kv.split("=") for kv in r.stdout.split())
+    assert int(f["rescued"]) > 150 and int(f["templates"]) > 50
+    assert open(got).read() == open(want).read()

@@ -26,6 +26,25 @@ def make_dataset(tmpdir, genome=200_000, coverage=20.0, seed=3, err=0.12, vol_si
     return d, rs, nv
 
 
+def make_long_indel_partition(tmpdir, genome=24_000, coverage=28.0, seed=5, frac=0.5):
+    """A read set in which half of the reads carry long indels (synth.add_long_indels) and its candidate partition (oracle
+    oc2pmov -j 0 + single-partition pcan): work dir, candidate prefix, partition bytes.  What oc2cns -r 1 has to rescue."""
+    from oracle import oracle_api as ora
+    rs = synth.add_long_indels(synth.simulate_reads(genome, coverage, seed=seed, err=0.12, repeat_frac=0.1), frac, seed=seed + 1)
+    d = os.path.join(str(tmpdir), "vols_indel")
+    nv = synth.write_volume_dir(d, rs, 500_000)
+    o = ora.options(**dict(FAST, job=0, binary_output=1, num_threads=4))
+    rec = b""
+    for v in range(nv):
+        out = os.path.join(str(tmpdir), "pm_indel_%d" % v)
+        ora.pm_main(o, v, d, out)
+        rec += open(out, "rb").read()
+    part = pcan_single_partition(rec)
+    prefix = os.path.join(str(tmpdir), "cands_indel")
+    write_partition(prefix, part)
+    return d, prefix, part
+
+
 def install_golden_volumes(name, tmpdir):
     """Copy tests/golden/<name> (vol files) to tmpdir and write directory files with absolute paths."""
     src = os.path.join(GOLDEN, name)
