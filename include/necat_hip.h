@@ -179,6 +179,18 @@ int  necat_map_pair(necat_ctx* ctx, const necat_index* ix, const necat_volume* r
                     int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt,
                     int tail_match_len, necat_m4** out, uint64_t* n_out, uint64_t* n_candidates);
 
+/* rm_search_one_volume (reference_mapping/rm_worker.c:198-291) for every read of `reads` against the reference volume `ref`
+ * (oc2rm_worker, necat.pl:661): candidates of both strands against the whole reference (pairwise = FALSE), sorted and cut to
+ * num_candidates; every candidate is aligned block-wise against the stretch of its reference sequence the read can reach from the
+ * anchor (calc_reference_range, :43-59; tail_match_len = ONC_TAIL_MATCH_LEN_SHORT) on the device; then, per read and in candidate
+ * order on the host threads (rm_extend_candidates, :165-196): anchors inside an accepted record are skipped, failed alignments
+ * dropped, alignments more than 500 bp short of the chained range replaced by the rescue pair's (ocda_go + edlib_go, :113-140) or
+ * dropped with it.  Records as rm_extend_candidate leaves them (:143-163), ids global.  *n_rescued (optional) = records that came
+ * from the rescue pair. */
+int  necat_map_reference(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, const necat_volume* reads,
+                         int read_start_id, int ref_start_id, const necat_map_options* opt,
+                         necat_m4** out, uint64_t* n_out, uint64_t* n_candidates, uint64_t* n_rescued);
+
 /* onc_align (gapped_align/oc_aligner.h:45-55) on every candidate WITH the alignment itself - the call the
  * consensus stage makes (cns_extension, consensus/consensus_aux.c:124-215, tail_match_len =
  * ONC_TAIL_MATCH_LEN_LONG = 4).  No containment filter: aln[i] and the columns at ops + ops_off[i] belong to

@@ -21,6 +21,7 @@ OC2PM = os.path.join(CSRC, "oc2pm")
 OC2MKDB = os.path.join(CSRC, "oc2mkdb")
 OC2PCAN = os.path.join(CSRC, "oc2pcan")
 OC2CNS = os.path.join(CSRC, "oc2cns")
+OC2RM = os.path.join(CSRC, "oc2rm_worker")
 
 HIP_SOURCES = ["necat_hip.hip"]
 
@@ -82,6 +83,8 @@ def build_cli(force: bool = False):
         _run([shutil.which("g++") or "g++", "-O2", "-std=c++17", "-o", OC2PCAN, "oc2pcan_main.cpp"], cwd=CSRC)
     if force or _stale(OC2CNS, ["oc2cns_main.cpp", "cns_consensus.h", "host_io.h", LIB]):   # consensus stage: GPU extension loop + host consensus
         _run([_hipcc(), "-O2", "-std=c++17", "-o", OC2CNS, "oc2cns_main.cpp", "-L" + CSRC, "-lnecat_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"], cwd=CSRC)
+    if force or _stale(OC2RM, ["oc2rm_worker_main.cpp", "pm_job.h", "host_fmt.h", "host_io.h", LIB]):   # reads against a reference (second half of SURVEY 8f.4)
+        _run([_hipcc(), "-O2", "-std=c++17", "-o", OC2RM, "oc2rm_worker_main.cpp", "-L" + CSRC, "-lnecat_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"], cwd=CSRC)
     return OC2PMOV, OC2PM
 
 

@@ -77,7 +77,7 @@ class _CnsResult(C.Structure):
 EXPORTED_SYMBOLS = [
     "necat_default_options", "necat_ctx_create", "necat_ctx_destroy", "necat_ctx_trim", "necat_last_error", "necat_device_name",
     "necat_volume_upload", "necat_volume_pack", "necat_volume_free", "necat_index_build", "necat_index_size", "necat_index_download",
-    "necat_index_free", "necat_find_candidates", "necat_extend", "necat_map_pair", "necat_onc_align_batch",
+    "necat_index_free", "necat_find_candidates", "necat_extend", "necat_map_pair", "necat_map_reference", "necat_onc_align_batch",
     "necat_gapped_strings", "necat_cns_default_options", "necat_cns_load_partition", "necat_cns_extension_batch",
     "necat_cns_result_free",
     "necat_edlib_align_batch", "necat_get_timings", "necat_free", "necat_pcan_partition",
@@ -125,6 +125,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                  C.POINTER(vp), u64p]
     lib.necat_map_pair.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(MapOptions), C.c_int,
                                    C.POINTER(vp), u64p, u64p]
+    lib.necat_map_reference.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.POINTER(MapOptions), C.POINTER(vp), u64p, u64p, u64p]
     lib.necat_onc_align_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_uint64, C.POINTER(MapOptions), C.c_int,
                                           C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.necat_gapped_strings.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, C.c_uint64, vp, vp]
@@ -311,6 +312,14 @@ class Context:
         self._check(self.lib.necat_map_pair(self.h, ix.h, ref.h, reads.h, read_start_id, ref_start_id, 1 if pairwise else 0,
                                             C.byref(opt), tail_match_len, C.byref(p), C.byref(n), C.byref(nc)), "necat_map_pair")
         return self._take(p, n.value, M4_DTYPE), int(nc.value)
+
+    def map_reference(self, ix: "Index", ref: "Volume", reads: "Volume", read_start_id: int, ref_start_id: int, opt: MapOptions):
+        """rm_search_one_volume for every read of `reads`: (M4 records, number of candidates, records from the rescue pair)."""
+        p = C.c_void_p()
+        n, nc, nr = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self.lib.necat_map_reference(self.h, ix.h, ref.h, reads.h, read_start_id, ref_start_id, C.byref(opt), C.byref(p), C.byref(n),
+                                                 C.byref(nc), C.byref(nr)), "necat_map_reference")
+        return self._take(p, n.value, M4_DTYPE), int(nc.value), int(nr.value)
 
     def onc_align_batch(self, ref: "Volume", reads: "Volume", read_start_id: int, ref_start_id: int, cands: np.ndarray,
                         opt: MapOptions, tail_match_len: int = 4):

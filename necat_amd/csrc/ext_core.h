@@ -52,6 +52,20 @@ NECAT_HD void ext_reset_stream(ExtTask& t)
     t.qidx = t.tidx = 0; t.ext_done = 0;
 }
 
+// calc_reference_range (reference_mapping/rm_worker.c:43-59): a read is mapped against the stretch of a reference sequence it can
+// reach from the anchor - 1.3 x what is left of the read on either side, cut at the sequence ends.  from / to: the stretch,
+// woff: the anchor inside it.
+NECAT_HD void rm_window(i64 qoff, i64 qsize, i64 soff, i64 ssize, i64* from, i64* to, i64* woff)
+{
+    i64 n = qoff < soff ? (i64)((double)qoff * 1.3) : soff;
+    if (n > soff) n = soff;
+    *from = soff - n; *woff = n;
+    const i64 sr = ssize - soff, qr = qsize - qoff;
+    n = qr < sr ? (i64)((double)qr * 1.3) : sr;
+    if (n > sr) n = sr;
+    *to = soff + n;
+}
+
 NECAT_HD void ext_init(ExtTask& t, i32 cand, i32 qdir, i64 q_g0, i32 qlen, i64 s_g0, i32 slen, i32 qoff, i32 soff)
 {
     t.cand = cand; t.qdir = qdir; t.q_g0 = q_g0; t.s_g0 = s_g0; t.qlen = qlen; t.slen = slen;

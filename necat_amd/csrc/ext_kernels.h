@@ -126,7 +126,7 @@ NECAT_D void ext_append_block(const ExtTask& t, u32 ti, bool go, const ExtLists&
 __global__ void __launch_bounds__(256)
 k_ext_init(const necat_candidate* __restrict__ cands, u32 n, u32 cand_base, int read_start_id, int ref_start_id,
            const u64* __restrict__ reads_off, const u64* __restrict__ ref_off, ExtTask* __restrict__ tasks, ExtLists L,
-           const u64* __restrict__ ops_base, const u32* __restrict__ perm)
+           const u64* __restrict__ ops_base, const u32* __restrict__ perm, int window)
 {
     // task i of the batch = candidate perm[cand_base + i] (batches ordered by expected chain length) or cand_base + i
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -136,6 +136,11 @@ k_ext_init(const necat_candidate* __restrict__ cands, u32 n, u32 cand_base, int 
         const u32 ci = perm ? perm[cand_base + i] : cand_base + i;
         const necat_candidate c = cands[ci];
         const int lq = c.qid - read_start_id, ls = c.sid - ref_start_id;
+        if (window) {      // read-to-reference mapping: the subject is the stretch rm_window gives, not the whole sequence
+            i64 from, to, woff;
+            rm_window((i64)c.qoff, (i64)c.qsize, (i64)c.soff, (i64)c.ssize, &from, &to, &woff);
+            ext_init(t, (i32)ci, c.qdir, (i64)reads_off[lq], (i32)c.qsize, (i64)ref_off[ls] + from, (i32)(to - from), (i32)c.qoff, (i32)woff);
+        } else
         ext_init(t, (i32)ci, c.qdir, (i64)reads_off[lq], (i32)c.qsize, (i64)ref_off[ls], (i32)c.ssize, (i32)c.qoff, (i32)c.soff);
         if (ops_base) t.ops_base = ops_base[i];
         go = ext_plan(t);          // first block (or an immediately finished candidate)
@@ -871,7 +876,7 @@ k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
 // ---- final records: pm_worker.c:56-80 (M4 fields), oc_aligner.c:419-450 (coordinates, identity) ----
 __global__ void __launch_bounds__(256)
 k_ext_result(const ExtTask* __restrict__ tasks, u32 n, const necat_candidate* __restrict__ cands,
-             int min_align, necat_m4* __restrict__ m4, u8* __restrict__ ok)
+             int min_align, necat_m4* __restrict__ m4, u8* __restrict__ ok, int window)
 {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -883,6 +888,11 @@ k_ext_result(const ExtTask* __restrict__ tasks, u32 n, const necat_candidate* __
     m.sid = c.sid; m.sdir = 0; m.soff = (u64)t.r_toff; m.send = (u64)t.r_tend; m.sext = c.soff; m.ssize = c.ssize;
     m.ident_perc = t.r_cols ? 100.0 * (double)t.r_mat / (double)t.r_cols : 0.0;
     m.vscore = c.score; m._pad = 0;
+    if (window) {          // rm_worker.c:148-149: back to coordinates of the whole reference sequence
+        i64 from, to, woff;
+        rm_window((i64)c.qoff, (i64)c.qsize, (i64)c.soff, (i64)c.ssize, &from, &to, &woff);
+        m.soff += (u64)from; m.send += (u64)from;
+    }
     if (m.qdir == 1) { const u64 qo = m.qsize - m.qend, qe = m.qsize - m.qoff; m.qoff = qo; m.qend = qe; }
     m4[ci] = m;
     ok[ci] = t.r_cols >= min_align ? 1 : 0;

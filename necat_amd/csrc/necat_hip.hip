@@ -16,6 +16,7 @@
 #include "ext_kernels.h"
 #include "cns_loop.h"
 #include "cns_rescue.h"
+#include "rm_host.h"
 #include "comm.h"
 
 using namespace necat;
@@ -1156,6 +1157,9 @@ struct AlignOut {
 // The extension loop behind necat_extend (M4 records, containment filter) and necat_onc_align_batch
 // (every candidate's alignment with its columns, `ao` != nullptr).
 struct DevOut { const necat_m4* d = nullptr; uint64_t n = 0; };      // records left on the device (sharded calls gather them there)
+// read-to-reference mapping (necat_map_reference): every candidate aligned against its stretch of the reference (rm_window), and
+// instead of the filtered records every candidate's own record + flag come back, with the candidates: the caller's loop decides
+struct RmOut { std::vector<necat_candidate> cands; std::vector<necat_m4> m4; std::vector<u8> ok; std::vector<u64> group_off; };
 
 int ext_streams(necat_ctx* ctx)
 {
@@ -1166,7 +1170,7 @@ int ext_streams(necat_ctx* ctx)
 
 int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* reads, int read_start_id, int ref_start_id,
                 const necat_candidate* cands, uint64_t n, const necat_map_options* opt, int tail_match_len,
-                necat_m4** out, uint64_t* n_out, AlignOut* ao, const DevCands* dev = nullptr, DevOut* devout = nullptr)
+                necat_m4** out, uint64_t* n_out, AlignOut* ao, const DevCands* dev = nullptr, DevOut* devout = nullptr, RmOut* rm = nullptr)
 {
     if (int rc0 = ext_streams(ctx)) return rc0;
     // dev != nullptr (necat_map_pair): the candidates are this library's own, still on the device
@@ -1294,7 +1298,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
             d_ops_base = d_base;
         }
         hipLaunchKernelGGL(k_ext_init, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, (const necat_candidate*)d_cands, k.n, (u32)k.base,
-                           read_start_id, ref_start_id, X.reads_off, X.ref_off, k.tasks, L0, d_ops_base, (const u32*)d_perm);
+                           read_start_id, ref_start_id, X.reads_off, X.ref_off, k.tasks, L0, d_ops_base, (const u32*)d_perm, rm ? 1 : 0);
         NECAT_CHECK_LAUNCH(ctx, "k_ext_init");
         if (goff.empty() && dev) goff = dev->group_off;
         if (goff.empty() && !ao) {
@@ -1307,7 +1311,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
         if ((rc = run_batch(ctx, dref, drd, k, X))) { cleanup(); return rc; }
         if (!ao) {
             hipLaunchKernelGGL(k_ext_result, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, (const ExtTask*)k.tasks, k.n, (const necat_candidate*)d_cands,
-                               opt->align_size_cutoff, d_m4, d_ok);
+                               opt->align_size_cutoff, d_m4, d_ok, rm ? 1 : 0);
             NECAT_CHECK_LAUNCH(ctx, "k_ext_result");
             NECAT_HIP(ctx, hipStreamSynchronize(k.sa));
         } else {
@@ -1373,6 +1377,20 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
         if (herr) return set_err(ctx, NECAT_ERR_INTERNAL, "extension kernels reported error code %d", herr);
         return NECAT_OK;
     }
+    if (rm) {
+        int herr = 0;
+        rm->cands.resize(n); rm->m4.resize(n); rm->ok.resize(n); rm->group_off = goff;
+        NECAT_HIP(ctx, hipMemcpyAsync(rm->cands.data(), d_cands, n * sizeof(necat_candidate), hipMemcpyDeviceToHost, s));
+        NECAT_HIP(ctx, hipMemcpyAsync(rm->m4.data(), d_m4, n * sizeof(necat_m4), hipMemcpyDeviceToHost, s));
+        NECAT_HIP(ctx, hipMemcpyAsync(rm->ok.data(), d_ok, n, hipMemcpyDeviceToHost, s));
+        NECAT_HIP(ctx, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, s));
+        NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s));
+        NECAT_HIP(ctx, hipStreamSynchronize(s));
+        ctx->tm.extend_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
+        cleanup();
+        if (herr) return set_err(ctx, NECAT_ERR_INTERNAL, "extension kernels reported error code %d", herr);
+        return NECAT_OK;
+    }
     const u32 ng = (u32)goff.size() - 1;
     NECAT_HIP(ctx, hipMemcpyAsync(d_goff, goff.data(), goff.size() * 8, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_m4_filter, dim3(grid_for(ng, 64)), dim3(64), 0, s, (const necat_candidate*)d_cands, (const u64*)d_goff, ng,
@@ -1428,6 +1446,76 @@ int necat_map_pair(necat_ctx* ctx, const necat_index* ix, const necat_volume* re
     if (n_candidates) *n_candidates = dev.n;
     if (dev.n == 0) return NECAT_OK;
     return extend_impl(ctx, ref, reads, read_start_id, ref_start_id, nullptr, dev.n, &o, tail_match_len, out, n_out, nullptr, &dev);
+}
+
+// ------------------------------------------------------------------------------------------ reads against a reference (oc2rm_worker)
+
+int necat_map_reference(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, const necat_volume* reads,
+                        int read_start_id, int ref_start_id, const necat_map_options* opt,
+                        necat_m4** out, uint64_t* n_out, uint64_t* n_candidates, uint64_t* n_rescued)
+{
+    if (!ctx || !ix || !ref || !reads || !opt || !out || !n_out) return NECAT_ERR_ARG;
+    *out = nullptr; *n_out = 0;
+    if (n_candidates) *n_candidates = 0;
+    if (n_rescued) *n_rescued = 0;
+    necat_map_options o = *opt;
+    o.job = 1;                                   // rm_worker.c:251-252: sorted, cut to num_candidates
+    DevCands dev;
+    int rc = find_impl(ctx, ix, ref, reads, read_start_id, ref_start_id, 0 /* pairwise = FALSE, rm_worker.c:231 */, &o, nullptr, nullptr, &dev);
+    if (rc) return rc;
+    if (n_candidates) *n_candidates = dev.n;
+    if (dev.n == 0) { *out = (necat_m4*)result_alloc(sizeof(necat_m4)); return *out ? NECAT_OK : set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
+    RmOut ro;
+    necat_m4* unused = nullptr; uint64_t unused_n = 0;
+    if ((rc = extend_impl(ctx, ref, reads, read_start_id, ref_start_id, nullptr, dev.n, &o, 1 /* ONC_TAIL_MATCH_LEN_SHORT, rm_worker.c:92 */,
+                          &unused, &unused_n, nullptr, &dev, nullptr, &ro))) return rc;
+    const double w0 = wall_ms();
+    // the bases come back to the host only if some candidate needs the rescue pair
+    const uint64_t ng = ro.group_off.empty() ? 0 : ro.group_off.size() - 1;
+    bool any = false;
+    for (uint64_t i = 0; i < dev.n && !any; ++i) any = ro.ok[i] && rm::needs_rescue(ro.cands[i], ro.m4[i]);
+    std::vector<u64> w_reads, w_ref;
+    if (any) {
+        w_reads.resize((reads->nbases + 31) / 32 + 1); w_ref.resize((ref->nbases + 31) / 32 + 1);
+        NECAT_HIP(ctx, hipMemcpy(w_reads.data(), reads->bases, (w_reads.size() - 1) * 8, hipMemcpyDeviceToHost));
+        NECAT_HIP(ctx, hipMemcpy(w_ref.data(), ref->bases, (w_ref.size() - 1) * 8, hipMemcpyDeviceToHost));
+    }
+    rm::Words hr, hf;
+    hr.w = w_reads.data(); hr.seq_off = reads->h_seq_off.data();
+    hf.w = w_ref.data(); hf.seq_off = ref->h_seq_off.data();
+    const rescue::DalignSpec dspec = rescue::spec_for_error(o.error);
+    // groups (reads) are dealt out in runs of 16; every run's records are kept apart and joined in read order
+    const uint64_t run = 16, nruns = (ng + run - 1) / run;
+    std::vector<std::vector<necat_m4>> parts(nruns);
+    std::atomic<uint64_t> next(0), tried(0), rescued(0);
+    auto work = [&]() {
+        rm::Worker wk(dspec, o.error);
+        for (;;) {
+            const uint64_t r = next.fetch_add(1);
+            if (r >= nruns) break;
+            for (uint64_t g = r * run; g < std::min(ng, (r + 1) * run); ++g)
+                wk.replay(ro.cands.data(), ro.m4.data(), ro.ok.data(), ro.group_off[g], ro.group_off[g + 1], hr, hf, read_start_id, ref_start_id,
+                          o.align_size_cutoff, parts[r]);
+        }
+        tried += wk.n_rescue_tried; rescued += wk.n_rescued;
+    };
+    unsigned nt = std::max(1u, std::min<unsigned>(std::thread::hardware_concurrency(), 32u));
+    nt = (unsigned)std::min<uint64_t>(nt, std::max<uint64_t>(1, nruns));
+    std::vector<std::thread> th;
+    for (unsigned x = 0; x + 1 < nt; ++x) th.emplace_back(work);
+    work();
+    for (auto& x : th) x.join();
+    uint64_t total = 0;
+    for (auto& p : parts) total += p.size();
+    necat_m4* res = (necat_m4*)result_alloc(std::max<uint64_t>(1, total) * sizeof(necat_m4));
+    if (!res) return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed");
+    uint64_t at = 0;
+    for (auto& p : parts) { if (!p.empty()) memcpy(res + at, p.data(), p.size() * sizeof(necat_m4)); at += p.size(); }
+    if (n_rescued) *n_rescued = rescued.load();
+    if (g_trace & 2) fprintf(stderr, "[necat] map_reference host: %.2f ms, %lu candidates, %lu rescue attempts, %lu rescued, %lu records\n", wall_ms() - w0,
+                             (unsigned long)dev.n, (unsigned long)tried.load(), (unsigned long)rescued.load(), (unsigned long)total);
+    *out = res; *n_out = total;
+    return NECAT_OK;
 }
 
 // ------------------------------------------------------------------------------------------ candidate partitions (oc2pcan)

@@ -261,6 +261,7 @@ def cns_options(**kw) -> OraCnsOptions:
 
 REF_PCAN = os.path.join(HERE, "_ref", "oc2pcan")
 REF_CNS = os.path.join(HERE, "_ref", "cns_ref_harness")
+REF_RM = os.path.join(HERE, "_ref", "oc2rm_worker")      # the reference's read-to-reference mapper (reference_mapping/rm_one_vol_main.c)
 REF_OC2CNS = os.path.join(HERE, "_ref", "oc2cns")          # the reference's oc2cns itself (consensus/main.c)
 
 

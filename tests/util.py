@@ -45,6 +45,21 @@ def make_long_indel_partition(tmpdir, genome=24_000, coverage=28.0, seed=5, frac
     return d, prefix, part
 
 
+def make_rm_dataset(tmpdir, seed=13, repeat_frac=0.6, genome_len=150_000, coverage=6.0):
+    """Reads (half of them with long indels) in a volume directory and a reference volume file holding the genome they come from
+    as three contigs plus an unrelated sequence: what oc2rm_worker maps.  Returns (wrk_dir, reference_path, number of volumes)."""
+    import numpy as np
+    G = synth.make_genome(genome_len, seed, repeat_frac)
+    rs = synth.add_long_indels(synth.simulate_reads(coverage=coverage, seed=seed, err=0.12, genome=G), 0.5, seed=seed + 1, lo=300, hi=1500)
+    wrk = os.path.join(str(tmpdir), "vols_rm")
+    nv = synth.write_volume_dir(wrk, rs, 300_000)
+    cuts = [0, genome_len * 4 // 15, genome_len * 11 // 15, genome_len]
+    seqs = [G[cuts[i]:cuts[i + 1]] for i in range(3)] + [np.random.default_rng(seed + 2).integers(0, 4, 20_000, dtype=np.uint8)]
+    ref = os.path.join(str(tmpdir), "ref.vol")
+    synth.write_volume(ref, np.concatenate(seqs), [len(x) for x in seqs], ["ctg%d" % i for i in range(4)])
+    return wrk, ref, nv
+
+
 def install_golden_volumes(name, tmpdir):
     """Copy tests/golden/<name> (vol files) to tmpdir and write directory files with absolute paths."""
     src = os.path.join(GOLDEN, name)
