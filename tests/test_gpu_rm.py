@@ -38,7 +38,14 @@ def test_oc2rm_worker_reproduces_reference(built, tmp_path, seed, repeat, args):
     want = _ref(args.split(), wrk, ref, os.path.join(str(tmp_path), "ref.m4"))
     got = _mine(built, args.split(), wrk, ref, os.path.join(str(tmp_path), "mine.m4"))
     assert len(want) > 5000
-    assert got == want
+    if "-u 1" in args:          # 96-byte records: the reference writes whatever its stack held into the 4 padding bytes
+        a, b = np.frombuffer(got, dtype=capi.M4_DTYPE), np.frombuffer(want, dtype=capi.M4_DTYPE)
+        assert a.shape == b.shape
+        for f in capi.M4_DTYPE.names:
+            if not f.startswith("_"):
+                assert (a[f] == b[f]).all(), f
+    else:
+        assert got == want
 
 
 def test_oc2rm_worker_node_split_and_abi(ctx, built, tmp_path):
