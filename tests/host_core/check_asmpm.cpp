@@ -1,0 +1,86 @@
+// check_asmpm.cpp - CPU test of necat_amd/csrc/asm_core.h (oc2asmpm restated: block vote, MEM chain, 2048-bp block extension with
+// DALIGNER end extension) behind the ORACLE's volume reader, lookup table and block aligner (ora_onc_align with 2048-bp blocks and
+// tail match length 8 = the clone in asm_pm/blockwise_edlib.c).  Writes what the reference's oc2asmpm -u 0 writes, for the test to
+// compare with the output of the REFERENCE's own program (oracle/_ref/oc2asmpm -t 1).
+//
+//   check_asmpm [map options] wrk_dir volume_id out
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "../../necat_amd/csrc/asm_core.h"
+#include "../../oracle/necat_oracle.h"
+
+using namespace necat;
+
+int main(int argc, char** argv)
+{
+    if (argc < 4) return 2;
+    ora_options opt;
+    ora_options_default(&opt);
+    opt.num_candidates = opt.num_output = 100;          // asmpm.c:14 (MAXC)
+    if (ora_options_parse(argc - 3, argv, &opt)) return 2;
+    const char* wrk = argv[argc - 3];
+    const int vid = atoi(argv[argc - 2]);
+    FILE* out = fopen(argv[argc - 1], "w");
+    if (!out) return 2;
+    ora_volumes_info vi;
+    if (ora_volumes_info_load(wrk, &vi)) return 2;
+    ora_volume ref;
+    if (ora_volume_load(vi.names[vid], &ref)) return 2;
+    const int ref_start = vi.read_start_id[vid];
+    ora_index* ix = ora_index_build(&ref, opt.kmer_size, opt.kmer_cnt_cutoff);
+    std::vector<uint64_t> ref_off(ref.nseq + 1, 0);
+    for (uint64_t i = 0; i < ref.nseq; ++i) ref_off[i + 1] = ref_off[i] + ref.size[i];
+    asmpm::RefView rv;
+    rv.seq_off = ref_off.data(); rv.nseq = ref.nseq;
+    rv.kmer_list = [&](uint64_t h, uint64_t* n) -> const uint64_t* {
+        const uint64_t u = ix->kmer_stats[h], cnt = u >> 34, start = u & ((1ULL << 34) - 1);
+        *n = cnt;
+        return cnt ? ix->offset_list + start : nullptr;
+    };
+    ora_aligner* al = ora_aligner_new(0.5);
+    asmpm::BlockAlignFn block_align = [&](const uint8_t* read, int qoff, int qsize, const uint8_t* subject, int soff, int ssize, int min_align, asmpm::BlockAlignment* a) {
+        ora_align_result r;
+        if (!ora_onc_align(al, read, qoff, qsize, subject, soff, ssize, 2048, min_align, 8, &r)) return false;
+        a->qoff = r.qoff; a->qend = r.qend; a->toff = r.toff; a->tend = r.tend; a->ident_perc = r.ident_perc;
+        a->qaln.assign(r.query_align, (size_t)r.align_size); a->taln.assign(r.target_align, (size_t)r.align_size);
+        return true;
+    };
+    auto subject_of = [&](int sid, int strand, std::vector<uint8_t>& s) { s.resize(ref.size[sid] + 1); ora_volume_extract(&ref, (uint64_t)sid, strand, s.data()); s.resize(ref.size[sid]); };
+    asmpm::Voter voter;
+    voter.init(ref.nbases);
+    asmpm::ReadMapper mapper;
+    uint64_t n_records = 0, n_votes = 0;
+    for (int v = vid; v < vi.num_volumes; ++v) {
+        ora_volume reads;
+        if (ora_volume_load(vi.names[v], &reads)) return 2;
+        const int read_start = vi.read_start_id[v];
+        std::vector<uint8_t> fwd, rev;
+        std::vector<asmpm::VoteCandidate> votes;
+        std::vector<necat_m4> recs;
+        for (uint64_t i = 0; i < reads.nseq; ++i) {
+            const int L = (int)reads.size[i], gid = (int)i + read_start;
+            fwd.resize((size_t)L + 1); rev.resize((size_t)L + 1);
+            ora_volume_extract(&reads, i, 0, fwd.data());
+            ora_volume_extract(&reads, i, 1, rev.data());
+            int64_t soff_max = INT32_MAX;
+            if (gid >= ref_start && gid < ref_start + (int)ref.nseq) soff_max = (int64_t)ref_off[(size_t)(gid - ref_start)];
+            votes.clear();
+            voter.strand(fwd.data(), L, 0, (int)i, gid, ref_start, rv, opt.kmer_size, opt.scan_window, soff_max, votes);
+            voter.strand(rev.data(), L, 1, (int)i, gid, ref_start, rv, opt.kmer_size, opt.scan_window, soff_max, votes);
+            n_votes += votes.size();
+            recs.clear();
+            mapper.go(votes, opt.num_candidates, fwd.data(), (int)i, L, subject_of, block_align, recs);
+            for (const necat_m4& m : recs) {        // DUMP_ASM_M4_HDR_ID (m4_record.h:99-124)
+                fprintf(out, "%s\t%s\t%.2f\t%d\t%d\t%lu\t%lu\t%lu\t%d\t%lu\t%lu\t%lu\n", reads.hdr + reads.hdr_offset[m.qid], ref.hdr + ref.hdr_offset[m.sid], m.ident_perc,
+                        m.vscore, m.qdir, (unsigned long)m.qoff, (unsigned long)m.qend, (unsigned long)m.qsize, m.sdir, (unsigned long)m.soff, (unsigned long)m.send,
+                        (unsigned long)m.ssize);
+                ++n_records;
+            }
+        }
+        ora_volume_free(&reads);
+    }
+    fclose(out);
+    printf("records=%lu votes=%lu\n", (unsigned long)n_records, (unsigned long)n_votes);
+    return 0;
+}

@@ -1,0 +1,49 @@
+"""oc2asmpm without a GPU: necat_amd/csrc/asm_core.h - block vote, MEM chain, 2048-bp block extension with DALIGNER
+end extension - behind the oracle's lookup table and block aligner (tests/host_core/check_asmpm.cpp), against the output of the
+REFERENCE's own oc2asmpm -t 1 (oracle/_ref, built from /root/reference) on corrected-read-like data: byte-identical files."""
+import os
+import subprocess
+
+import pytest
+
+from necat_amd import synth
+from oracle import oracle_api as ora
+from tests import util
+
+REF_ASMPM = os.path.join(os.path.dirname(ora.REF_PMOV), "oc2asmpm")
+pytestmark = pytest.mark.skipif(not os.path.exists(REF_ASMPM), reason="oracle/_ref/oc2asmpm (the reference's build) is absent")
+
+
+@pytest.fixture(scope="module")
+def check_asmpm(tmp_path_factory):
+    d = str(tmp_path_factory.mktemp("asmpm"))
+    obj = os.path.join(d, "necat_oracle.o")
+    subprocess.run(["gcc", "-O2", "-std=gnu99", "-c", os.path.join(util.ROOT, "oracle", "necat_oracle.c"), "-o", obj], check=True)
+    exe = os.path.join(d, "check_asmpm")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(util.ROOT, "tests", "host_core", "check_asmpm.cpp"),
+                    obj, "-lm", "-lpthread"], check=True)
+    return exe
+
+
+@pytest.mark.parametrize("seed,err,repeat,indels,args", [
+    (41, 0.03, 0.3, False, "-n 100 -z 10 -b 2000 -e 0.5 -j 1 -u 0 -a 400 -k 13"),      # necat.pl:36 (ASM_OVLP_OPTIONS)
+    (42, 0.06, 0.5, False, "-z 5 -k 12 -n 20 -u 0"),
+    (43, 0.01, 0.2, True, "-n 100 -z 10 -b 2000 -e 0.5 -j 1 -u 0 -a 400 -k 13"),
+])
+def test_asmpm_matches_reference(check_asmpm, tmp_path, seed, err, repeat, indels, args):
+    rs = synth.simulate_reads(60_000, 12.0, seed=seed, err=err, repeat_frac=repeat)
+    if indels:
+        rs = synth.add_long_indels(rs, 0.3, seed=seed + 1)
+    wrk = os.path.join(str(tmp_path), "vols")
+    nv = synth.write_volume_dir(wrk, rs, 300_000)
+    assert nv >= 2
+    total = 0
+    for v in range(nv):
+        want, got = os.path.join(str(tmp_path), "ref_%d.m4" % v), os.path.join(str(tmp_path), "mine_%d.m4" % v)
+        subprocess.run([REF_ASMPM] + args.split() + ["-t", "1", wrk, str(v), want], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        r = subprocess.run([check_asmpm] + args.split() + [wrk, str(v), got], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+        a, b = open(want, "rb").read(), open(got, "rb").read()
+        assert a == b, v
+        total += len(a.splitlines())
+    assert total > 1000
