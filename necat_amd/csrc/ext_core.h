@@ -94,6 +94,8 @@ NECAT_HD void ext_stream_col(ExtTask& t, bool is_match, bool has_q, bool has_t)
 
 // Decide the next block of the task, or finish it.  Returns true when a block (t.qblk x t.tblk) is
 // scheduled; false when the task is done (results in t.r_*).
+// BLOCK: the desired block size - kOcaBlockSize for onc_align, 2048 for its clone in asm_pm/blockwise_edlib.c
+template <int BLOCK = kOcaBlockSize>
 NECAT_HD bool ext_plan(ExtTask& t)
 {
     for (;;) {
@@ -102,11 +104,11 @@ NECAT_HD bool ext_plan(ExtTask& t)
             // get_next_sequence_block (oc_aligner.c:111-155)
             const int qleft = t.ext_q - t.qidx, tleft = t.ext_t - t.tidx;
             int qblk, tblk, last;
-            if (qleft < kOcaBlockSize + 100 || tleft < kOcaBlockSize + 100) {
+            if (qleft < BLOCK + 100 || tleft < BLOCK + 100) {
                 qblk = (int)((double)tleft * 1.3); if (qleft < qblk) qblk = qleft;
                 tblk = (int)((double)qleft * 1.3); if (tleft < tblk) tblk = tleft;
                 last = 1;
-            } else { qblk = kOcaBlockSize; tblk = kOcaBlockSize; last = 0; }
+            } else { qblk = BLOCK; tblk = BLOCK; last = 0; }
             if (qblk != 0 && tblk != 0) { t.qblk = qblk; t.tblk = tblk; t.last = last; return true; }
         }
         // the current extension is over

@@ -3,6 +3,9 @@
 // validated on a machine without a GPU.  Nothing here is part of the product path.
 //
 // usage: check_core <wrk_dir> <vid> k z q b s n a e [max_reads]
+//
+// -DCHECK_BLOCK=2048 -DCHECK_TAIL=8: the same replay with the block size and tail match length of the block aligner's clone in
+// asm_pm/blockwise_edlib.c (oc2asmpm): the cores are generic in both, and the 2048-bp device path is built from them.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -16,6 +19,15 @@ extern "C" {
 #include "../../oracle/necat_oracle.h"
 }
 using namespace necat;
+
+#ifndef CHECK_BLOCK
+#define CHECK_BLOCK 512
+#endif
+#ifndef CHECK_TAIL
+#define CHECK_TAIL 1
+#endif
+constexpr int kBlk = CHECK_BLOCK, kNwFull = kBlk / 64, kNwMax = (int)((kBlk + 99) * 1.3) / 64 + 1, kTail = CHECK_TAIL;
+static_assert(kBlk % 64 == 0, "block size");
 
 struct HostVol { std::vector<u64> words; std::vector<u64> off; DevVolume dv; };
 
@@ -124,7 +136,7 @@ int main(int argc, char** argv)
         SeedScratch S; S.ht = htab.data(); S.ht_mask = 4 * H - 1; S.pool = pool.data(); S.pool_cap = H;
         S.cs = cs.data(); S.f = f.data(); S.p = p.data(); S.t = t.data(); S.v = vv.data(); S.u = uu.data(); S.lcan = lcan.data(); S.cs_cap = H + 1;
         S.out = outc.data(); S.out_cap = H;
-        static MyersRegs<8> R8; static MyersRegs<13> R13; HMat mat; u64 tw[32];
+        static MyersRegs<kNwFull> R8; static MyersRegs<kNwMax> R13; HMat mat; static u64 tw[2 * kNwMax + 2];
         int nreads = (int)std::min<u64>(rd->nseq, (u64)max_reads);
         for (int r = 0; r < nreads; ++r) {
             size_t L = rd->size[r];
@@ -157,25 +169,25 @@ int main(int argc, char** argv)
                 subj.resize((size_t)c.ssize + 1);
                 ora_volume_extract(&ref, (uint64_t)c.sid, 0, subj.data());
                 ora_align_result ar;
-                int ok = ora_onc_align(al, c.qdir == 0 ? fwd.data() : rev.data(), (int)c.qoff, (int)c.qsize, subj.data(), (int)c.soff, (int)c.ssize, 512, opt.align_size_cutoff, 1, &ar);
+                int ok = ora_onc_align(al, c.qdir == 0 ? fwd.data() : rev.data(), (int)c.qoff, (int)c.qsize, subj.data(), (int)c.soff, (int)c.ssize, kBlk, opt.align_size_cutoff, kTail, &ar);
                 ExtTask tk;
                 ext_init(tk, 0, c.qdir, (i64)rd->offset[c.qid], (i32)c.qsize, (i64)ref.offset[c.sid], (i32)c.ssize, (i32)c.qoff, (i32)c.soff);
-                while (ext_plan(tk)) {
+                while (ext_plan<kBlk>(tk)) {
                     FragGeom g = ext_frag_geom(tk);
                     MyersResult mr; HOps ops; ++n_blocks;
-                    if (!tk.last && tk.qblk == 512 && tk.tblk == 512) {
-                        mr = run_block<8, true>(hrd->dv, href.dv, g, tk.qblk, tk.tblk, opt.error, mat, tw, R8);
+                    if (!tk.last && tk.qblk == kBlk && tk.tblk == kBlk) {
+                        mr = run_block<kNwFull, true>(hrd->dv, href.dv, g, tk.qblk, tk.tblk, opt.error, mat, tw, R8);
                         const int done = ext_block_done(tk, mr.dist, mr.endc);
-                        tail_init(ops.ts, done ? 1 : kOcaMatCnt);
+                        tail_init(ops.ts, done ? kTail : kOcaMatCnt);
                         if (mr.dist >= 0) { HMatR m{&mat}; traceback_block(tk.qblk, mr.endc + 1, m, ops); check_walk(tk.qblk, mr.endc + 1, m, ops); }
-                        HRops ro{&ops.v}; HSame<8> sm{&R8, tw};
+                        HRops ro{&ops.v}; HSame<kNwFull> sm{&R8, tw};
                         ext_finish_block(tk, mr.dist, mr.endc, done, ops.ts, ro, sm);
                     } else {
-                        mr = run_block<13, false>(hrd->dv, href.dv, g, tk.qblk, tk.tblk, opt.error, mat, tw, R13);
+                        mr = run_block<kNwMax, false>(hrd->dv, href.dv, g, tk.qblk, tk.tblk, opt.error, mat, tw, R13);
                         const int done = ext_block_done(tk, mr.dist, mr.endc);
-                        tail_init(ops.ts, done ? 1 : kOcaMatCnt);
+                        tail_init(ops.ts, done ? kTail : kOcaMatCnt);
                         if (mr.dist >= 0) { HMatR m{&mat}; traceback_block(tk.qblk, mr.endc + 1, m, ops); check_walk(tk.qblk, mr.endc + 1, m, ops); }
-                        HRops ro{&ops.v}; HSame<13> sm{&R13, tw};
+                        HRops ro{&ops.v}; HSame<kNwMax> sm{&R13, tw};
                         ext_finish_block(tk, mr.dist, mr.endc, done, ops.ts, ro, sm);
                     }
                     if (mr.err) { fprintf(stderr, "DP internal error %d\n", mr.err); ++bad_ext; }

@@ -34,6 +34,28 @@ def test_cores_match_oracle(check_core, tmp_path, ds, vid, args):
     assert "candidates=0 " not in r.stdout
 
 
+@pytest.mark.parametrize("err,args", [
+    (0.03, "13 10 500 2000 3 100 400 0.5 150"),      # corrected reads, the options of necat.pl:36
+    (0.13, "13 20 500 2000 3 40 400 0.5 60"),        # raw reads: wide bands at 2048 x 2048
+])
+def test_cores_at_block_2048_match_oracle(built, tmp_path, err, args):
+    """the block aligner of oc2asmpm (asm_pm/blockwise_edlib.c = onc_align with 2048-bp blocks and tail match length 8)
+    from the SAME per-lane cores: ext_plan<2048>, myers_block<32 / 44 words>, traceback_block / walk_block, ext_finish_block replayed
+    on the CPU against the oracle's onc_align(2048, 8) - every candidate's coordinates, columns and identity"""
+    d = str(tmp_path)
+    obj = os.path.join(d, "necat_oracle.o")
+    exe = os.path.join(d, "check_core2048")
+    subprocess.run(["gcc", "-O2", "-std=gnu99", "-c", os.path.join(util.ROOT, "oracle", "necat_oracle.c"), "-o", obj], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-DCHECK_BLOCK=2048", "-DCHECK_TAIL=8", "-o", exe,
+                    os.path.join(util.ROOT, "tests", "host_core", "check_core.cpp"), obj, "-lm", "-lpthread"], check=True)
+    wrk, rs, nv = util.make_dataset(tmp_path, genome=60_000, coverage=12.0, seed=52, err=err, vol_size=400_000)
+    r = subprocess.run([exe, wrk, "0"] + args.split(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "seed_mismatch=0 ext_mismatch=0 walk_mismatch=0" in r.stdout
+    f = dict(kv.split("=") for kv in r.stdout.split()[1:])
+    assert int(f["blocks"]) > 1000 and int(f["m4"]) > 300
+
+
 def test_wave_chain_dp_model_equals_sequential(tmp_path):
     """chain_fill_wave (seed_kernels.h) turns the order-dependent predecessor scan of chain_dp.c:46-85 into prefix operations over
     64 lanes; its lane-by-lane host transcription must give the f / p / v of the sequential loop, max_skip stops included."""
