@@ -204,6 +204,17 @@ int  necat_onc_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_
                            const necat_candidate* cands, uint64_t n, const necat_map_options* opt,
                            int tail_match_len, necat_alignment** aln, uint8_t** ops, uint64_t** ops_off);
 
+/* blockwise_edlib_align (asm_pm/blockwise_edlib.c:1205-1371) for n anchors at once: the block aligner of oc2asmpm = onc_align with
+ * 2048-bp blocks and tail match length 8 (hbn_align.c:8, blockwise_edlib.c:910-911), the read on its forward strand against the subject
+ * on strand sdir (asm_pm_common.c:133-143 turns a reverse query into a reverse subject).  anchors[i]: ids global, qoff on the forward
+ * read, soff on strand sdir of the subject.  Outputs as necat_onc_align_batch: aln[i] (ok = at least min_align_size columns; the
+ * identity test, hbn_align.c / blockwise_edlib.c:1357, is the caller's) and the columns, two bits each, at ops + ops_off[i]; expand them
+ * with necat_gapped_strings (tseq = the subject ON ITS STRAND). */
+typedef struct { int32_t qid, sid, sdir, qoff, soff; } necat_asm_anchor;
+int  necat_asm_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_volume* reads, int read_start_id, int ref_start_id,
+                           const necat_asm_anchor* anchors, uint64_t n, double error, int min_align_size,
+                           necat_alignment** aln, uint8_t** ops, uint64_t** ops_off);
+
 /* Host helper: expand `n` packed columns into query_align / target_align (each n bytes, no terminator).
  * qseq / tseq: byte codes 0..3 of the query STRAND (reverse complement for qdir = 1) and of the subject;
  * qoff / toff: the alignment's start in them (necat_alignment.qoff / .toff).  Returns 0, or NECAT_ERR_ARG

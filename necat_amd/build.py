@@ -22,6 +22,7 @@ OC2MKDB = os.path.join(CSRC, "oc2mkdb")
 OC2PCAN = os.path.join(CSRC, "oc2pcan")
 OC2CNS = os.path.join(CSRC, "oc2cns")
 OC2RM = os.path.join(CSRC, "oc2rm_worker")
+OC2ASMPM = os.path.join(CSRC, "oc2asmpm")
 
 HIP_SOURCES = ["necat_hip.hip"]
 
@@ -85,6 +86,8 @@ def build_cli(force: bool = False):
         _run([_hipcc(), "-O2", "-std=c++17", "-o", OC2CNS, "oc2cns_main.cpp", "-L" + CSRC, "-lnecat_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"], cwd=CSRC)
     if force or _stale(OC2RM, ["oc2rm_worker_main.cpp", "pm_job.h", "host_fmt.h", "host_io.h", LIB]):   # reads against a reference (second half of SURVEY 8f.4)
         _run([_hipcc(), "-O2", "-std=c++17", "-o", OC2RM, "oc2rm_worker_main.cpp", "-L" + CSRC, "-lnecat_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"], cwd=CSRC)
+    if force or _stale(OC2ASMPM, ["oc2asmpm_main.cpp", "asm_job.h", "asm_core.h", "rescue.h", "host_fmt.h", "host_io.h", LIB]):   # overlapper of corrected reads
+        _run([_hipcc(), "-O2", "-std=c++17", "-ffp-contract=off", "-o", OC2ASMPM, "oc2asmpm_main.cpp", "-L" + CSRC, "-lnecat_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"], cwd=CSRC)
     return OC2PMOV, OC2PM
 
 

@@ -514,5 +514,58 @@ struct ReadMapper {
     }
 };
 
+// The same walk in two halves, for a block aligner that takes all reads' anchors at once (the device: necat_asm_align_batch).  What a candidate's
+// range and alignment come out as depends only on (read, subject, strand), so a later candidate of the same subject and strand is either skipped -
+// a record exists - or fails exactly as the first one did: one anchor per (subject, strand), in the walk's order, gives the same records.
+struct Planned { int sid, sdir, qoff, soff, score, ssize; };
+
+struct BatchMapper {
+    RangeFinder range;
+    Extender ext;
+    std::vector<KmerInfo> read_kmif;
+    std::vector<uint8_t> subject;
+
+    void plan(std::vector<VoteCandidate>& cands, int num_extended, const uint8_t* fwd_read, int read_size,
+              const std::function<void(int sid, int strand, std::vector<uint8_t>& out)>& subject_of, std::vector<Planned>& out)
+    {
+        if (cands.empty()) return;
+        std::sort(cands.begin(), cands.end(), vote_before);
+        build_kmif(fwd_read, (size_t)read_size, 10, 1, read_kmif);
+        sort_kmif(read_kmif);
+        const size_t first = out.size();
+        for (size_t i = 0; i < cands.size() && (int)i < num_extended; ++i) {
+            const int sid = cands[i].target_id, sdir = cands[i].chain;
+            bool seen = false;
+            for (size_t j = first; j < out.size() && !seen; ++j) seen = out[j].sid == sid && out[j].sdir == sdir;
+            if (seen) continue;
+            subject_of(sid, sdir, subject);
+            ChainRange r;
+            Planned p;
+            p.sid = sid; p.sdir = sdir; p.ssize = (int)subject.size(); p.qoff = p.soff = -1; p.score = 0;        // qoff < 0: no chain, nothing to align
+            if (range.go(subject.data(), p.ssize, fwd_read, read_size, read_kmif, 10, 6, 15, &r)) { p.qoff = r.soff; p.soff = r.qoff; p.score = r.score; }
+            out.push_back(p);
+        }
+    }
+
+    // a[k]: the block-wise alignment of planned[k] (ok = at least 400 columns), strings filled
+    void finish(const Planned* planned, size_t n, const bool* ok, BlockAlignment* a, const uint8_t* fwd_read, int read_id, int read_size,
+                const std::function<void(int sid, int strand, std::vector<uint8_t>& out)>& subject_of, std::vector<necat_m4>& out)
+    {
+        for (size_t k = 0; k < n; ++k) {
+            const Planned& p = planned[k];
+            if (p.qoff < 0 || !ok[k] || !(a[k].ident_perc >= 65.0)) continue;
+            subject_of(p.sid, p.sdir, subject);
+            ext.ends(fwd_read, read_size, subject.data(), p.ssize, a[k]);
+            necat_m4 m;
+            memset(&m, 0, sizeof m);
+            m.qid = read_id; m.sid = p.sid; m.ident_perc = a[k].ident_perc; m.vscore = p.score; m.qdir = 0;
+            m.qoff = (uint64_t)a[k].qoff; m.qend = (uint64_t)a[k].qend; m.qext = (uint64_t)p.qoff; m.qsize = (uint64_t)read_size;
+            m.sdir = p.sdir; m.soff = (uint64_t)a[k].toff; m.send = (uint64_t)a[k].tend; m.sext = (uint64_t)p.soff; m.ssize = (uint64_t)p.ssize;
+            if (m.sdir == 1) { const uint64_t so = m.ssize - m.send, se = m.ssize - m.soff; m.soff = so; m.send = se; }
+            out.push_back(m);
+        }
+    }
+};
+
 }  // namespace asmpm
 }  // namespace necat

@@ -1,0 +1,195 @@
+// asm_job.h - one oc2asmpm job (asm_pm/asmpm.c:11-68): reference volume `vid` against the volumes vid .. V-1.  Per volume pair: the vote and the
+// chained range of every read on the host threads (asm_core.h; 4 % + 20 % of the reference's time), ALL anchors of the pair in one call of the
+// device's block aligner (necat_asm_align_batch; 74 %), then the end extension and the records on the host threads again.
+#pragma once
+#include <atomic>
+#include <thread>
+
+#include "asm_core.h"
+#include "host_fmt.h"
+#include "host_io.h"
+
+namespace necat_host {
+
+struct HostCodes {       // a volume's bases, one code per byte
+    std::vector<uint8_t> c;
+    const HostVolume* v = nullptr;
+    void set(const HostVolume& hv)
+    {
+        v = &hv; c.resize(hv.nbases);
+        for (uint64_t i = 0; i < hv.nbases; ++i) c[i] = (uint8_t)((hv.pac[i >> 2] >> ((~i & 3) << 1)) & 3);
+    }
+    void strand(uint64_t id, int rev, std::vector<uint8_t>& out) const
+    {
+        const uint64_t b = v->offset[id], n = v->size[id];
+        out.resize(n);
+        if (!rev) memcpy(out.data(), c.data() + b, n);
+        else for (uint64_t i = 0; i < n; ++i) out[i] = (uint8_t)(3 - c[b + n - 1 - i]);
+    }
+};
+
+template <class F>
+inline void asm_parallel(uint64_t n, int threads, F&& fn)
+{
+    unsigned nt = (unsigned)std::max(1, threads);
+    nt = (unsigned)std::min<uint64_t>(nt, std::max<uint64_t>(1, n));
+    std::atomic<uint64_t> next(0);
+    auto work = [&](unsigned tid) { for (;;) { const uint64_t b = next.fetch_add(8); if (b >= n) break; for (uint64_t i = b; i < std::min(n, b + 8); ++i) fn(i, tid); } };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+}
+
+// returns 0, or 1 after printing "[tag] ERROR: ..."
+inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const necat_map_options& opt, const char* output, const char* tag)
+{
+    using namespace necat;
+    auto fail = [&](const char* what, const char* detail) { fprintf(stderr, "[%s] ERROR: %s: %s\n", tag, what, detail); return 1; };
+    std::string err;
+    HostVolume href;
+    if (!load_volume(vi.names[vid].c_str(), &href, &err)) return fail("volume", err.c_str());
+    necat_volume* ref = nullptr;
+    if (necat_volume_upload(ctx, href.pac.data(), href.nbases, href.offset.data(), href.size.data(), href.offset.size(), &ref)) return fail("necat_volume_upload", necat_last_error(ctx));
+    log_line("", "build_lookup_table");
+    double t0 = now_sec();
+    necat_index* ix = nullptr;
+    if (necat_index_build(ctx, ref, opt.kmer_size, opt.kmer_cnt_cutoff, &ix)) return fail("necat_index_build", necat_last_error(ctx));
+    // the vote reads the table on the host
+    uint64_t n_table = 0, n_offsets = 0;
+    necat_index_size(ix, &n_table, &n_offsets);
+    std::vector<uint64_t> kmer_stats(n_table), offset_list(n_offsets + 1);
+    if (necat_index_download(ctx, ix, kmer_stats.data(), offset_list.data())) return fail("necat_index_download", necat_last_error(ctx));
+    necat_index_free(ctx, ix);
+    log_line("[%s] INFO: '%s' takes %.2lf secs.\n", "build_lookup_table", now_sec() - t0);
+    HostCodes cref; cref.set(href);
+    std::vector<uint64_t> ref_off(href.offset.size() + 1, 0);
+    for (size_t i = 0; i < href.offset.size(); ++i) ref_off[i + 1] = href.offset[i] + href.size[i];
+    asmpm::RefView rv;
+    rv.seq_off = ref_off.data(); rv.nseq = href.offset.size();
+    rv.kmer_list = [&](uint64_t h, uint64_t* n) -> const uint64_t* {
+        const uint64_t u = kmer_stats[h], cnt = u >> 34, start = u & ((1ULL << 34) - 1);
+        *n = cnt;
+        return cnt ? offset_list.data() + start : nullptr;
+    };
+    auto subject_of = [&](int sid, int strand, std::vector<uint8_t>& s) { cref.strand((uint64_t)sid, strand, s); };
+
+    const std::string tmp_out = std::string(output) + ".part";
+    FILE* out = fopen(tmp_out.c_str(), "w");
+    if (!out) return fail("output", "cannot open for writing");
+    const int ref_start = vi.read_start_id[vid];
+    const int nthreads = std::max(1, std::min(opt.num_threads, 256));
+    int status = 0;
+    for (int i = vid; i < vi.num_volumes && !status; ++i) {         // asmpm.c:38-58
+        char job[256];
+        snprintf(job, sizeof job, "pairwise mapping v%d vs v%d", vid, i);
+        log_line("", job);
+        t0 = now_sec();
+        HostVolume own;
+        const HostVolume* hreads = &href;
+        necat_volume* reads = ref;
+        HostCodes cown;
+        const HostCodes* crd = &cref;
+        if (i != vid) {
+            if (!load_volume(vi.names[i].c_str(), &own, &err)) { status = fail("volume", err.c_str()); break; }
+            hreads = &own;
+            if (necat_volume_upload(ctx, own.pac.data(), own.nbases, own.offset.data(), own.size.data(), own.offset.size(), &reads)) { status = fail("necat_volume_upload", necat_last_error(ctx)); break; }
+            cown.set(own); crd = &cown;
+        }
+        const int read_start = vi.read_start_id[i];
+        const uint64_t nreads = hreads->offset.size();
+        // phase A: votes and ranges
+        std::vector<std::vector<asmpm::Planned>> planned(nreads);
+        {
+            std::vector<asmpm::Voter> voters((size_t)nthreads);
+            std::vector<asmpm::BatchMapper> mappers((size_t)nthreads);
+            std::vector<char> inited((size_t)nthreads, 0);
+            asm_parallel(nreads, nthreads, [&](uint64_t r, unsigned tid) {
+                if (!inited[tid]) { voters[tid].init(href.nbases); inited[tid] = 1; }
+                std::vector<uint8_t> fwd, rev;
+                crd->strand(r, 0, fwd); crd->strand(r, 1, rev);
+                const int L = (int)fwd.size(), gid = (int)r + read_start;
+                int64_t soff_max = INT32_MAX;
+                if (gid >= ref_start && gid < ref_start + (int)rv.nseq) soff_max = (int64_t)ref_off[(size_t)(gid - ref_start)];
+                std::vector<asmpm::VoteCandidate> votes;
+                voters[tid].strand(fwd.data(), L, 0, (int)r, gid, ref_start, rv, opt.kmer_size, opt.scan_window, soff_max, votes);
+                voters[tid].strand(rev.data(), L, 1, (int)r, gid, ref_start, rv, opt.kmer_size, opt.scan_window, soff_max, votes);
+                mappers[tid].plan(votes, opt.num_candidates, fwd.data(), L, subject_of, planned[r]);
+            });
+        }
+        // phase B: every anchor of the pair through the device's block aligner
+        std::vector<uint64_t> first(nreads + 1, 0);
+        std::vector<necat_asm_anchor> anchors;
+        std::vector<int64_t> slot;                 // per planned candidate: its anchor or -1
+        for (uint64_t r = 0; r < nreads; ++r) {
+            first[r] = slot.size();
+            for (const asmpm::Planned& p : planned[r]) {
+                if (p.qoff < 0) { slot.push_back(-1); continue; }
+                necat_asm_anchor a;
+                a.qid = (int)r + read_start; a.sid = p.sid + ref_start; a.sdir = p.sdir; a.qoff = p.qoff; a.soff = p.soff;
+                slot.push_back((int64_t)anchors.size());
+                anchors.push_back(a);
+            }
+        }
+        first[nreads] = slot.size();
+        necat_alignment* aln = nullptr; uint8_t* cols = nullptr; uint64_t* cols_off = nullptr;
+        if (necat_asm_align_batch(ctx, ref, reads, read_start, ref_start, anchors.data(), anchors.size(), 0.5 /* hbn_align.c:8 */, 400 /* asm_pm_common.c:354 */,
+                                  &aln, &cols, &cols_off)) { status = fail("necat_asm_align_batch", necat_last_error(ctx)); }
+        // phase C: end extension, records
+        std::vector<std::vector<necat_m4>> recs(nreads);
+        if (!status) {
+            std::vector<asmpm::BatchMapper> mappers((size_t)nthreads);
+            asm_parallel(nreads, nthreads, [&](uint64_t r, unsigned tid) {
+                const size_t n = planned[r].size();
+                if (n == 0) return;
+                std::vector<uint8_t> fwd, subj;
+                crd->strand(r, 0, fwd);
+                std::vector<asmpm::BlockAlignment> ba(n);
+                std::unique_ptr<bool[]> ok(new bool[n]);
+                for (size_t k = 0; k < n; ++k) {
+                    ok[k] = false;
+                    const int64_t s = slot[first[r] + k];
+                    if (s < 0) continue;
+                    const necat_alignment& a = aln[s];
+                    ok[k] = a.ok != 0;
+                    if (!ok[k]) continue;
+                    ba[k].qoff = a.qoff; ba[k].qend = a.qend; ba[k].toff = a.toff; ba[k].tend = a.tend; ba[k].ident_perc = a.ident_perc;
+                    ba[k].qaln.resize((size_t)a.align_size); ba[k].taln.resize((size_t)a.align_size);
+                    cref.strand((uint64_t)planned[r][k].sid, planned[r][k].sdir, subj);
+                    if (necat_gapped_strings(cols + cols_off[s], (uint64_t)a.align_size, fwd.data(), fwd.size(), (uint64_t)a.qoff, subj.data(), subj.size(), (uint64_t)a.toff,
+                                             &ba[k].qaln[0], &ba[k].taln[0])) ok[k] = false;
+                }
+                mappers[tid].finish(planned[r].data(), n, ok.get(), ba.data(), fwd.data(), (int)r + read_start, (int)fwd.size(), subject_of, recs[r]);
+                for (necat_m4& m : recs[r]) m.sid += ref_start;
+            });
+        }
+        necat_free(aln); necat_free(cols); necat_free(cols_off);
+        if (!status) {
+            std::vector<necat_m4> all;
+            for (auto& v : recs) all.insert(all.end(), v.begin(), v.end());
+            bool wok;
+            if (opt.binary_output) {        // asm_pm_common.c:66-73: ids + 1
+                for (necat_m4& m : all) { ++m.qid; ++m.sid; }
+                wok = all.empty() || fwrite(all.data(), sizeof(necat_m4), all.size(), out) == all.size();
+            } else {                        // DUMP_ASM_M4_HDR_ID (:74-83)
+                size_t lq = 0, ls = 0;
+                for (uint64_t r = 0; r < nreads; ++r) lq = std::max(lq, strlen(hreads->name(r)));
+                for (uint64_t r = 0; r < href.offset.size(); ++r) ls = std::max(ls, strlen(href.name(r)));
+                wok = write_records(out, all.size(), 12 * 24 + lq + ls, opt.num_threads, [&](char* p, uint64_t k) {
+                    const necat_m4& m = all[k];
+                    return put_m4(p, m, hreads->name((uint64_t)(m.qid - read_start)), href.name((uint64_t)(m.sid - ref_start)));
+                });
+            }
+            if (!wok) status = fail("output", "write failed");
+        }
+        if (reads != ref) necat_volume_free(ctx, reads);
+        if (!status) log_line("[%s] INFO: '%s' takes %.2lf secs.\n", job, now_sec() - t0);
+    }
+    if (fclose(out) != 0 && !status) status = fail("output", "write failed");
+    if (!status && rename(tmp_out.c_str(), output) != 0) status = fail("output", "rename failed");
+    if (status) remove(tmp_out.c_str());
+    necat_volume_free(ctx, ref);
+    return status;
+}
+
+}  // namespace necat_host

@@ -14,6 +14,7 @@
 #include "seed_kernels.h"
 #include "pcan_kernels.h"
 #include "ext_kernels.h"
+#include "asm_kernels.h"
 #include "cns_loop.h"
 #include "cns_rescue.h"
 #include "rm_host.h"
@@ -1446,6 +1447,97 @@ int necat_map_pair(necat_ctx* ctx, const necat_index* ix, const necat_volume* re
     if (n_candidates) *n_candidates = dev.n;
     if (dev.n == 0) return NECAT_OK;
     return extend_impl(ctx, ref, reads, read_start_id, ref_start_id, nullptr, dev.n, &o, tail_match_len, out, n_out, nullptr, &dev);
+}
+
+// ------------------------------------------------------------------------------------------ the block aligner of oc2asmpm
+
+int necat_asm_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_volume* reads, int read_start_id, int ref_start_id,
+                          const necat_asm_anchor* anchors, uint64_t n, double error, int min_align_size,
+                          necat_alignment** aln, uint8_t** ops, uint64_t** ops_off)
+{
+    if (!ctx || !ref || !reads || !aln || !ops || !ops_off || (n && !anchors)) return NECAT_ERR_ARG;
+    *aln = nullptr; *ops = nullptr; *ops_off = nullptr;
+    if (!(error > 0.0 && error <= 1.0) || n >= (1ULL << 31)) return set_err(ctx, NECAT_ERR_ARG, "error rate / count out of range");
+    NECAT_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    std::vector<AsmAnchor> h(n);
+    std::vector<u64> coff(n + 1, 0);
+    for (uint64_t i = 0; i < n; ++i) {
+        const necat_asm_anchor& a = anchors[i];
+        const int64_t lq = (int64_t)a.qid - read_start_id, ls = (int64_t)a.sid - ref_start_id;
+        if (lq < 0 || (uint64_t)lq >= reads->nseq || ls < 0 || (uint64_t)ls >= ref->nseq || (a.sdir != 0 && a.sdir != 1))
+            return set_err(ctx, NECAT_ERR_ARG, "anchor %lu refers to a read outside the volumes", (unsigned long)i);
+        const u64 ql = reads->h_seq_off[lq + 1] - reads->h_seq_off[lq], sl = ref->h_seq_off[ls + 1] - ref->h_seq_off[ls];
+        if (a.qoff < 0 || (u64)a.qoff > ql || a.soff < 0 || (u64)a.soff > sl || ql >= (1ULL << 31) || sl >= (1ULL << 31))
+            return set_err(ctx, NECAT_ERR_ARG, "anchor %lu lies outside its reads", (unsigned long)i);
+        h[i].q = (i32)lq; h[i].s = (i32)ls; h[i].sdir = a.sdir; h[i].qoff = a.qoff; h[i].soff = a.soff;
+        coff[i + 1] = coff[i] + ((ql + sl + 64 + 7) & ~7ULL);          // a column consumes at least one base of one of the two
+    }
+    necat_alignment* res = (necat_alignment*)result_alloc(std::max<uint64_t>(1, n) * sizeof(necat_alignment));
+    uint64_t* off = (uint64_t*)result_alloc((n + 1) * 8);
+    if (!res || !off) { necat_free(res); necat_free(off); return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
+    off[0] = 0;
+    auto fail = [&](int rc) { necat_free(res); necat_free(off); return rc; };
+    if (n == 0) { *aln = res; *ops_off = off; *ops = (uint8_t*)result_alloc(8); return NECAT_OK; }
+    // waves per launch: one band slab (126 MB) per wave inside the band-pool cap
+    const size_t pool = g_band_pool ? std::max<size_t>(g_band_pool, kAsmBandWave) : (size_t)32 << 30;
+    const u32 waves_total = (u32)((n + 63) / 64);
+    const u32 waves_max = (u32)std::max<size_t>(1, std::min<size_t>(pool / kAsmBandWave, waves_total));
+    int rc;
+    if ((rc = buf_ensure(ctx, ctx->scratch[SC_ASM_BAND], (size_t)waves_max * kAsmBandWave)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_OPS], (size_t)waves_max * kAsmOpsWave)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_COLS], coff[n] + 64)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_MISC], n * (sizeof(AsmAnchor) + sizeof(AsmOut) + 8) + 1024))) return fail(rc);
+    char* mb = (char*)ctx->scratch[SC_ASM_MISC].p;
+    u64* d_coff = (u64*)mb; mb += ((n + 1) * 8 + 63) & ~63ULL;
+    AsmOut* d_out = (AsmOut*)mb; mb += (n * sizeof(AsmOut) + 63) & ~63ULL;
+    AsmAnchor* d_anchor = (AsmAnchor*)mb;
+    u8* d_cols = (u8*)ctx->scratch[SC_ASM_COLS].p;
+    if (hipMemcpyAsync(d_anchor, h.data(), n * sizeof(AsmAnchor), hipMemcpyHostToDevice, s) != hipSuccess ||
+        hipMemcpyAsync(d_coff, coff.data(), (n + 1) * 8, hipMemcpyHostToDevice, s) != hipSuccess) return fail(set_err(ctx, NECAT_ERR_DEVICE, "anchor upload failed"));
+    const DevVolume drd = dev_view(reads), dref = dev_view(ref);
+    (void)hipEventRecord(ctx->ev[0], s);
+    for (u32 w0 = 0; w0 < waves_total; w0 += waves_max) {
+        const u32 nw = std::min(waves_max, waves_total - w0);
+        const u64 first = (u64)w0 * 64, cnt = std::min<u64>((u64)nw * 64, n - first);
+        hipLaunchKernelGGL(k_asm_align, dim3(nw), dim3(64), 0, s, (const AsmAnchor*)(d_anchor + first), (u32)cnt, drd, dref, error, 8 /* kMatchCnt2 */,
+                           (char*)ctx->scratch[SC_ASM_BAND].p, (u8*)ctx->scratch[SC_ASM_OPS].p, d_cols, (const u64*)(d_coff + first), d_out + first);
+        if (hipGetLastError() != hipSuccess) return fail(set_err(ctx, NECAT_ERR_DEVICE, "k_asm_align launch failed"));
+    }
+    std::vector<AsmOut> ho(n);
+    std::vector<u8> hc(coff[n] + 8);
+    (void)hipEventRecord(ctx->ev[1], s);
+    if (hipMemcpyAsync(ho.data(), d_out, n * sizeof(AsmOut), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(hc.data(), d_cols, coff[n], hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) return fail(set_err(ctx, NECAT_ERR_DEVICE, "k_asm_align failed: %s", hipGetErrorString(hipGetLastError())));
+    ctx->tm.extend_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
+    // the alignment of an anchor: its left stream [lfrom, lto) read backwards, then its right stream [lto + rfrom, lto + rto); packed two bits per
+    // column, every alignment on an 8-byte boundary
+    for (uint64_t i = 0; i < n; ++i) {
+        if (ho[i].err) return fail(set_err(ctx, NECAT_ERR_INTERNAL, "k_asm_align: anchor %lu reported error code %d", (unsigned long)i, ho[i].err));
+        const int nl = ho[i].lto - ho[i].lfrom, nr = ho[i].rto - ho[i].rfrom;
+        if (nl < 0 || nr < 0 || nl + nr != ho[i].cols) return fail(set_err(ctx, NECAT_ERR_INTERNAL, "k_asm_align: anchor %lu has inconsistent streams", (unsigned long)i));
+        off[i + 1] = off[i] + (((uint64_t)(nl + nr) + 3) / 4 + 7 & ~7ULL);
+    }
+    uint8_t* packed = (uint8_t*)result_alloc(std::max<uint64_t>(8, off[n]));
+    if (!packed) return fail(set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"));
+    memset(packed, 0, std::max<uint64_t>(8, off[n]));
+    cns::parallel_for(n, [&](size_t i) {
+        const AsmOut& o = ho[i];
+        const u8* c = hc.data() + coff[i];
+        uint8_t* dst = packed + off[i];
+        const int nl = o.lto - o.lfrom, nr = o.rto - o.rfrom;
+        for (int j = 0; j < nl + nr; ++j) {
+            const u8 op = j < nl ? c[o.lto - 1 - j] : c[o.lto + o.rfrom + (j - nl)];
+            dst[j >> 2] |= (uint8_t)((op & 3) << (2 * (j & 3)));
+        }
+        necat_alignment& a = res[i];
+        a.ok = o.cols >= min_align_size ? 1 : 0;
+        a.qoff = o.qoff; a.qend = o.qend; a.toff = o.toff; a.tend = o.tend; a.align_size = o.cols;
+        a.ident_perc = o.cols ? 100.0 * (double)o.mat / (double)o.cols : 0.0;
+    });
+    *aln = res; *ops = packed; *ops_off = off;
+    return NECAT_OK;
 }
 
 // ------------------------------------------------------------------------------------------ reads against a reference (oc2rm_worker)

@@ -4,8 +4,13 @@
 // compare with the output of the REFERENCE's own program (oracle/_ref/oc2asmpm -t 1).
 //
 //   check_asmpm [map options] wrk_dir volume_id out
+//
+// CHECK_ASM_BATCH=1 in the environment: the two-phase walk the program uses (BatchMapper: plan all anchors, align them, finish) instead of the
+// candidate-by-candidate one.
 #include <stdio.h>
 #include <stdlib.h>
+
+#include <memory>
 
 #include "../../necat_amd/csrc/asm_core.h"
 #include "../../oracle/necat_oracle.h"
@@ -50,6 +55,8 @@ int main(int argc, char** argv)
     asmpm::Voter voter;
     voter.init(ref.nbases);
     asmpm::ReadMapper mapper;
+    asmpm::BatchMapper batch;
+    const bool use_batch = getenv("CHECK_ASM_BATCH") && atoi(getenv("CHECK_ASM_BATCH"));
     uint64_t n_records = 0, n_votes = 0;
     for (int v = vid; v < vi.num_volumes; ++v) {
         ora_volume reads;
@@ -70,7 +77,21 @@ int main(int argc, char** argv)
             voter.strand(rev.data(), L, 1, (int)i, gid, ref_start, rv, opt.kmer_size, opt.scan_window, soff_max, votes);
             n_votes += votes.size();
             recs.clear();
-            mapper.go(votes, opt.num_candidates, fwd.data(), (int)i, L, subject_of, block_align, recs);
+            if (!use_batch) mapper.go(votes, opt.num_candidates, fwd.data(), (int)i, L, subject_of, block_align, recs);
+            else {
+                std::vector<asmpm::Planned> pl;
+                batch.plan(votes, opt.num_candidates, fwd.data(), L, subject_of, pl);
+                std::vector<asmpm::BlockAlignment> ba(pl.size());
+                std::unique_ptr<bool[]> ok(new bool[pl.size() + 1]);
+                std::vector<uint8_t> subj;
+                for (size_t k = 0; k < pl.size(); ++k) {
+                    ok[k] = false;
+                    if (pl[k].qoff < 0) continue;
+                    subject_of(pl[k].sid, pl[k].sdir, subj);
+                    ok[k] = block_align(fwd.data(), pl[k].qoff, L, subj.data(), pl[k].soff, pl[k].ssize, 400, &ba[k]);
+                }
+                batch.finish(pl.data(), pl.size(), ok.get(), ba.data(), fwd.data(), (int)i, L, subject_of, recs);
+            }
             for (const necat_m4& m : recs) {        // DUMP_ASM_M4_HDR_ID (m4_record.h:99-124)
                 fprintf(out, "%s\t%s\t%.2f\t%d\t%d\t%lu\t%lu\t%lu\t%d\t%lu\t%lu\t%lu\n", reads.hdr + reads.hdr_offset[m.qid], ref.hdr + ref.hdr_offset[m.sid], m.ident_perc,
                         m.vscore, m.qdir, (unsigned long)m.qoff, (unsigned long)m.qend, (unsigned long)m.qsize, m.sdir, (unsigned long)m.soff, (unsigned long)m.send,

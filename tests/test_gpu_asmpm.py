@@ -1,0 +1,46 @@
+"""GPU parity of oc2asmpm: this repo's program - vote and chained ranges on the host threads (asm_core.h), every anchor of a volume pair through
+the device's 2048-bp block aligner (necat_asm_align_batch, asm_kernels.h), end extension on the host - against the REFERENCE's own oc2asmpm -t 1
+(oracle/_ref/oc2asmpm, built from /root/reference; it travels to the GPU box): byte-identical text records, field-identical binary records."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from necat_amd import build, capi, synth
+from oracle import oracle_api as ora
+
+REF_ASMPM = os.path.join(os.path.dirname(ora.REF_PMOV), "oc2asmpm")
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(REF_ASMPM), reason="needs oracle/_ref/oc2asmpm")]
+
+
+@pytest.mark.parametrize("seed,err,repeat,indels,args", [
+    (61, 0.03, 0.3, False, "-n 100 -z 10 -b 2000 -e 0.5 -j 1 -u 0 -a 400 -k 13"),      # necat.pl:36 (ASM_OVLP_OPTIONS)
+    (62, 0.06, 0.4, True, "-z 5 -k 12 -n 20 -u 1"),                                     # TRIM_OVLP_OPTIONS write binary records (-u 1)
+])
+def test_oc2asmpm_reproduces_reference(built, tmp_path, seed, err, repeat, indels, args):
+    built.build_cli()
+    rs = synth.simulate_reads(40_000, 10.0, seed=seed, err=err, repeat_frac=repeat)
+    if indels:
+        rs = synth.add_long_indels(rs, 0.3, seed=seed + 1)
+    wrk = os.path.join(str(tmp_path), "vols")
+    nv = synth.write_volume_dir(wrk, rs, 200_000)
+    assert nv >= 2
+    total = 0
+    for v in range(nv):
+        want, got = os.path.join(str(tmp_path), "ref_%d.m4" % v), os.path.join(str(tmp_path), "mine_%d.m4" % v)
+        subprocess.run([REF_ASMPM] + args.split() + ["-t", "1", wrk, str(v), want], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        r = subprocess.run([build.OC2ASMPM] + args.split() + ["-t", "4", wrk, str(v), got], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr
+        a, b = open(want, "rb").read(), open(got, "rb").read()
+        if "-u 1" in args:          # the reference leaves the records' 4 padding bytes uninitialised
+            x, y = np.frombuffer(b, dtype=capi.M4_DTYPE), np.frombuffer(a, dtype=capi.M4_DTYPE)
+            assert x.shape == y.shape
+            for f in capi.M4_DTYPE.names:
+                if not f.startswith("_"):
+                    assert (x[f] == y[f]).all(), (v, f)
+            total += x.shape[0]
+        else:
+            assert a == b, v
+            total += len(a.splitlines())
+    assert total > 300
