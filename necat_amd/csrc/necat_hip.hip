@@ -1536,6 +1536,7 @@ int necat_asm_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_v
         a.qoff = o.qoff; a.qend = o.qend; a.toff = o.toff; a.tend = o.tend; a.align_size = o.cols;
         a.ident_perc = o.cols ? 100.0 * (double)o.mat / (double)o.cols : 0.0;
     });
+    if (g_trace & 2) fprintf(stderr, "[necat] asm_align: %lu anchors, %u waves (%u per launch), kernels %.2f ms\n", (unsigned long)n, waves_total, waves_max, ctx->tm.extend_ms);
     *aln = res; *ops = packed; *ops_off = off;
     return NECAT_OK;
 }
