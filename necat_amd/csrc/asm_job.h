@@ -117,53 +117,64 @@ inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const 
                 mappers[tid].plan(votes, opt.num_candidates, fwd.data(), L, subject_of, planned[r]);
             });
         }
-        // phase B: every anchor of the pair through the device's block aligner
-        std::vector<uint64_t> first(nreads + 1, 0);
-        std::vector<necat_asm_anchor> anchors;
-        std::vector<int64_t> slot;                 // per planned candidate: its anchor or -1
-        for (uint64_t r = 0; r < nreads; ++r) {
-            first[r] = slot.size();
-            for (const asmpm::Planned& p : planned[r]) {
-                if (p.qoff < 0) { slot.push_back(-1); continue; }
-                necat_asm_anchor a;
-                a.qid = (int)r + read_start; a.sid = p.sid + ref_start; a.sdir = p.sdir; a.qoff = p.qoff; a.soff = p.soff;
-                slot.push_back((int64_t)anchors.size());
-                anchors.push_back(a);
-            }
-        }
-        first[nreads] = slot.size();
-        necat_alignment* aln = nullptr; uint8_t* cols = nullptr; uint64_t* cols_off = nullptr;
-        if (necat_asm_align_batch(ctx, ref, reads, read_start, ref_start, anchors.data(), anchors.size(), 0.5 /* hbn_align.c:8 */, 400 /* asm_pm_common.c:354 */,
-                                  &aln, &cols, &cols_off)) { status = fail("necat_asm_align_batch", necat_last_error(ctx)); }
-        // phase C: end extension, records
+        // phases B and C over runs of reads whose anchors fit one call (the aligner keeps every anchor's columns: read + subject bytes each)
         std::vector<std::vector<necat_m4>> recs(nreads);
-        if (!status) {
-            std::vector<asmpm::BatchMapper> mappers((size_t)nthreads);
-            asm_parallel(nreads, nthreads, [&](uint64_t r, unsigned tid) {
-                const size_t n = planned[r].size();
-                if (n == 0) return;
-                std::vector<uint8_t> fwd, subj;
-                crd->strand(r, 0, fwd);
-                std::vector<asmpm::BlockAlignment> ba(n);
-                std::unique_ptr<bool[]> ok(new bool[n]);
-                for (size_t k = 0; k < n; ++k) {
-                    ok[k] = false;
-                    const int64_t s = slot[first[r] + k];
-                    if (s < 0) continue;
-                    const necat_alignment& a = aln[s];
-                    ok[k] = a.ok != 0;
-                    if (!ok[k]) continue;
-                    ba[k].qoff = a.qoff; ba[k].qend = a.qend; ba[k].toff = a.toff; ba[k].tend = a.tend; ba[k].ident_perc = a.ident_perc;
-                    ba[k].qaln.resize((size_t)a.align_size); ba[k].taln.resize((size_t)a.align_size);
-                    cref.strand((uint64_t)planned[r][k].sid, planned[r][k].sdir, subj);
-                    if (necat_gapped_strings(cols + cols_off[s], (uint64_t)a.align_size, fwd.data(), fwd.size(), (uint64_t)a.qoff, subj.data(), subj.size(), (uint64_t)a.toff,
-                                             &ba[k].qaln[0], &ba[k].taln[0])) ok[k] = false;
+        std::vector<asmpm::BatchMapper> mappers((size_t)nthreads);
+        const uint64_t kMaxCallBytes = 2ULL << 30;
+        const uint64_t kMaxCallAnchors = getenv("NECAT_ASM_CALL_ANCHORS") ? (uint64_t)std::max(1, atoi(getenv("NECAT_ASM_CALL_ANCHORS"))) : 1ULL << 20;      // (tests: several calls per pair)
+        for (uint64_t r0 = 0; r0 < nreads && !status;) {
+            // phase B: the anchors of reads [r0, r1) through the device's block aligner
+            std::vector<uint64_t> first;
+            std::vector<necat_asm_anchor> anchors;
+            std::vector<int64_t> slot;                 // per planned candidate: its anchor or -1
+            uint64_t r1 = r0, bytes = 0;
+            for (; r1 < nreads; ++r1) {
+                uint64_t add = 0, cnt = 0;
+                for (const asmpm::Planned& p : planned[r1]) if (p.qoff >= 0) { add += hreads->size[r1] + (uint64_t)p.ssize + 64; ++cnt; }
+                if (r1 > r0 && (bytes + add > kMaxCallBytes || anchors.size() + cnt > kMaxCallAnchors)) break;
+                bytes += add;
+                first.push_back(slot.size());
+                for (const asmpm::Planned& p : planned[r1]) {
+                    if (p.qoff < 0) { slot.push_back(-1); continue; }
+                    necat_asm_anchor a;
+                    a.qid = (int)r1 + read_start; a.sid = p.sid + ref_start; a.sdir = p.sdir; a.qoff = p.qoff; a.soff = p.soff;
+                    slot.push_back((int64_t)anchors.size());
+                    anchors.push_back(a);
                 }
-                mappers[tid].finish(planned[r].data(), n, ok.get(), ba.data(), fwd.data(), (int)r + read_start, (int)fwd.size(), subject_of, recs[r]);
-                for (necat_m4& m : recs[r]) m.sid += ref_start;
-            });
+            }
+            necat_alignment* aln = nullptr; uint8_t* cols = nullptr; uint64_t* cols_off = nullptr;
+            if (necat_asm_align_batch(ctx, ref, reads, read_start, ref_start, anchors.data(), anchors.size(), 0.5 /* hbn_align.c:8 */, 400 /* asm_pm_common.c:354 */,
+                                      &aln, &cols, &cols_off)) { status = fail("necat_asm_align_batch", necat_last_error(ctx)); }
+            // phase C: end extension, records
+            if (!status) {
+                asm_parallel(r1 - r0, nthreads, [&](uint64_t k0, unsigned tid) {
+                    const uint64_t r = r0 + k0;
+                    const size_t n = planned[r].size();
+                    if (n == 0) return;
+                    std::vector<uint8_t> fwd, subj;
+                    crd->strand(r, 0, fwd);
+                    std::vector<asmpm::BlockAlignment> ba(n);
+                    std::unique_ptr<bool[]> ok(new bool[n]);
+                    for (size_t k = 0; k < n; ++k) {
+                        ok[k] = false;
+                        const int64_t s = slot[first[k0] + k];
+                        if (s < 0) continue;
+                        const necat_alignment& a = aln[s];
+                        ok[k] = a.ok != 0;
+                        if (!ok[k]) continue;
+                        ba[k].qoff = a.qoff; ba[k].qend = a.qend; ba[k].toff = a.toff; ba[k].tend = a.tend; ba[k].ident_perc = a.ident_perc;
+                        ba[k].qaln.resize((size_t)a.align_size); ba[k].taln.resize((size_t)a.align_size);
+                        cref.strand((uint64_t)planned[r][k].sid, planned[r][k].sdir, subj);
+                        if (necat_gapped_strings(cols + cols_off[s], (uint64_t)a.align_size, fwd.data(), fwd.size(), (uint64_t)a.qoff, subj.data(), subj.size(), (uint64_t)a.toff,
+                                                 &ba[k].qaln[0], &ba[k].taln[0])) ok[k] = false;
+                    }
+                    mappers[tid].finish(planned[r].data(), n, ok.get(), ba.data(), fwd.data(), (int)r + read_start, (int)fwd.size(), subject_of, recs[r]);
+                    for (necat_m4& m : recs[r]) m.sid += ref_start;
+                });
+            }
+            necat_free(aln); necat_free(cols); necat_free(cols_off);
+            r0 = r1;
         }
-        necat_free(aln); necat_free(cols); necat_free(cols_off);
         if (!status) {
             std::vector<necat_m4> all;
             for (auto& v : recs) all.insert(all.end(), v.begin(), v.end());
