@@ -11,7 +11,7 @@ from oracle import oracle_api as ora
 from tests import util
 
 REF_ASMPM = os.path.join(os.path.dirname(ora.REF_PMOV), "oc2asmpm")
-pytestmark = pytest.mark.skipif(not os.path.exists(REF_ASMPM), reason="oracle/_ref/oc2asmpm (the reference's build) is absent")
+needs_ref = pytest.mark.skipif(not os.path.exists(REF_ASMPM), reason="oracle/_ref/oc2asmpm (the reference's build) is absent")
 
 
 @pytest.fixture(scope="module")
@@ -25,6 +25,23 @@ def check_asmpm(tmp_path_factory):
     return exe
 
 
+def test_asmpm_golden(check_asmpm, tmp_path):
+    """the committed vectors (tests/golden/asm_d: what the reference's oc2asmpm wrote for tests/golden/vols_d; make_golden_asm_rm.py)"""
+    import json
+    m = json.load(open(os.path.join(util.GOLDEN, "manifest_asm_rm.json")))["asm_d"]
+    wrk = util.install_golden_volumes(m["volumes"], tmp_path)
+    n = 0
+    for v in range(m["n_volumes"]):
+        got = os.path.join(str(tmp_path), "mine_%d.m4" % v)
+        r = subprocess.run([check_asmpm] + m["args"].split() + [wrk, str(v), got], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+        want = open(os.path.join(util.GOLDEN, "asm_d", "ref_v%d.m4" % v), "rb").read()
+        assert open(got, "rb").read() == want, v
+        n += len(want.splitlines())
+    assert n == m["records"] and n > 300
+
+
+@needs_ref
 @pytest.mark.parametrize("seed,err,repeat,indels,args", [
     (41, 0.03, 0.3, False, "-n 100 -z 10 -b 2000 -e 0.5 -j 1 -u 0 -a 400 -k 13"),      # necat.pl:36 (ASM_OVLP_OPTIONS)
     (42, 0.06, 0.5, False, "-z 5 -k 12 -n 20 -u 0"),

@@ -11,9 +11,26 @@ from necat_amd import build, capi, synth
 from oracle import oracle_api as ora
 
 REF_ASMPM = os.path.join(os.path.dirname(ora.REF_PMOV), "oc2asmpm")
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(REF_ASMPM), reason="needs oracle/_ref/oc2asmpm")]
+pytestmark = pytest.mark.gpu
+needs_ref = pytest.mark.skipif(not os.path.exists(REF_ASMPM), reason="needs oracle/_ref/oc2asmpm")
 
 
+def test_oc2asmpm_golden(built, tmp_path):
+    """the committed vectors: tests/golden/asm_d = what the reference's oc2asmpm wrote for tests/golden/vols_d"""
+    import json
+    from tests import util
+    built.build_cli()
+    m = json.load(open(os.path.join(util.GOLDEN, "manifest_asm_rm.json")))["asm_d"]
+    wrk = util.install_golden_volumes(m["volumes"], tmp_path)
+    for v in range(m["n_volumes"]):
+        got = os.path.join(str(tmp_path), "mine_%d.m4" % v)
+        r = subprocess.run([build.OC2ASMPM] + m["args"].split() + ["-t", "3", wrk, str(v), got], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr
+        assert open(got, "rb").read() == open(os.path.join(util.GOLDEN, "asm_d", "ref_v%d.m4" % v), "rb").read(), v
+
+
+
+@needs_ref
 @pytest.mark.parametrize("seed,err,repeat,indels,args", [
     (61, 0.03, 0.3, False, "-n 100 -z 10 -b 2000 -e 0.5 -j 1 -u 0 -a 400 -k 13"),      # necat.pl:36 (ASM_OVLP_OPTIONS)
     (62, 0.06, 0.4, True, "-z 5 -k 12 -n 20 -u 1"),                                     # TRIM_OVLP_OPTIONS write binary records (-u 1)

@@ -11,7 +11,8 @@ from necat_amd import build, capi
 from oracle import oracle_api as ora
 from tests import util
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(ora.REF_RM), reason="needs oracle/_ref/oc2rm_worker")]
+pytestmark = pytest.mark.gpu
+needs_ref = pytest.mark.skipif(not os.path.exists(ora.REF_RM), reason="needs oracle/_ref/oc2rm_worker")
 
 
 def _ref(args, wrk, ref, out, mn=None):
@@ -28,6 +29,16 @@ def _mine(built, args, wrk, ref, out, mn=None):
     return open(out, "rb").read()
 
 
+def test_oc2rm_worker_golden(built, tmp_path):
+    """the committed vectors: tests/golden/rm_e/ref.m4 = what the reference's oc2rm_worker wrote for tests/golden/vols_e against rm_e/ref.vol"""
+    import json
+    m = json.load(open(os.path.join(util.GOLDEN, "manifest_asm_rm.json")))["rm_e"]
+    wrk = util.install_golden_volumes(m["volumes"], tmp_path)
+    got = _mine(built, m["args"].split(), wrk, os.path.join(util.GOLDEN, "rm_e", "ref.vol"), os.path.join(str(tmp_path), "mine.m4"))
+    assert got == open(os.path.join(util.GOLDEN, "rm_e", "ref.m4"), "rb").read()
+
+
+@needs_ref
 @pytest.mark.parametrize("seed,repeat,args", [
     (13, 0.6, "-k 13 -i 0"),
     (12, 0.4, "-k 12 -z 10 -n 8 -a 1000"),          # names as ids (the default)
@@ -48,6 +59,7 @@ def test_oc2rm_worker_reproduces_reference(built, tmp_path, seed, repeat, args):
         assert got == want
 
 
+@needs_ref
 def test_oc2rm_worker_node_split_and_abi(ctx, built, tmp_path):
     wrk, ref, nv = util.make_rm_dataset(tmp_path, seed=21, repeat_frac=0.5)
     assert nv >= 3

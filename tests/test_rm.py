@@ -10,7 +10,7 @@ import pytest
 from oracle import oracle_api as ora
 from tests import util
 
-pytestmark = pytest.mark.skipif(not os.path.exists(ora.REF_RM), reason="oracle/_ref/oc2rm_worker (the reference's build) is absent")
+needs_ref = pytest.mark.skipif(not os.path.exists(ora.REF_RM), reason="oracle/_ref/oc2rm_worker (the reference's build) is absent")
 
 
 @pytest.fixture(scope="module")
@@ -24,6 +24,20 @@ def check_rm(tmp_path_factory):
     return exe
 
 
+def test_rm_golden(check_rm, tmp_path):
+    """the committed vectors (tests/golden/rm_e: what the reference's oc2rm_worker wrote for tests/golden/vols_e against rm_e/ref.vol)"""
+    import json
+    m = json.load(open(os.path.join(util.GOLDEN, "manifest_asm_rm.json")))["rm_e"]
+    wrk = util.install_golden_volumes(m["volumes"], tmp_path)
+    got = os.path.join(str(tmp_path), "mine.m4")
+    r = subprocess.run([check_rm] + m["args"].split() + [wrk, os.path.join(util.GOLDEN, "rm_e", "ref.vol"), got], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    want = open(os.path.join(util.GOLDEN, "rm_e", "ref.m4")).read()
+    assert open(got).read() == want
+    assert len(want.splitlines()) == m["records"] and int(dict(kv.split("=") for kv in r.stdout.split())["rescued"]) > 3
+
+
+@needs_ref
 @pytest.mark.parametrize("seed,repeat,args", [
     (13, 0.6, "-k 13 -i 0"),
     (12, 0.4, "-k 12 -z 10 -n 8 -a 1000 -i 0"),
