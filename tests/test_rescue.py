@@ -12,16 +12,21 @@ import pytest
 from tests import util
 
 REF = os.path.join(util.ROOT, "oracle", "_ref", "librescue_ref.so")
-pytestmark = pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/librescue_ref.so (the reference's build) is absent")
+needs_ref = pytest.mark.skipif(not os.path.exists(REF), reason="oracle/_ref/librescue_ref.so (the reference's build) is absent")
 
 
 @pytest.fixture(scope="module")
-def libs(tmp_path_factory):
+def mine_lib(tmp_path_factory):
     d = tmp_path_factory.mktemp("rescue")
     so = os.path.join(str(d), "librescue_mine.so")
     subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so,
                     os.path.join(util.ROOT, "tests", "host_core", "rescue_capi.cpp")], check=True)
-    return C.CDLL(REF), C.CDLL(so)
+    return C.CDLL(so)
+
+
+@pytest.fixture(scope="module")
+def libs(mine_lib):
+    return C.CDLL(REF), mine_lib
 
 
 def mutate(t, rng, err, gap=None):
@@ -61,6 +66,58 @@ def ptr(a):
     return a.ctypes.data_as(C.c_char_p)
 
 
+def ocda_inputs(seed):
+    rng, q, t, lo = read_pair(seed)
+    if len(q) < 300:
+        return None
+    qs = int(rng.integers(50, len(q) - 50))
+    ts = min(len(t) - 1, max(0, lo + qs + int(rng.integers(-30, 30))))
+    return q, t, qs, ts, float(rng.choice([0.5, 0.3, 0.2]))
+
+
+def edlib_inputs(seed, big):
+    rng, q, t, lo = read_pair(seed, 300 if not big else 3000, 3000 if not big else 9000)
+    if len(q) < 200:
+        return None
+    qf = int(rng.integers(0, 40))
+    qt = len(q) - int(rng.integers(0, 40))
+    tf = max(0, lo + int(rng.integers(-20, 20)))
+    tt = min(len(t), lo + int((qt - qf) * rng.uniform(0.9, 1.1)) + int(rng.integers(0, 300)))
+    if tt - tf < 150:
+        return None
+    return q, t, qf, qt, tf, tt, float(rng.choice([0.5, 0.3])), int(rng.choice([0.1, 0.3, 0.6]) * (qt - qf)) + 10
+
+
+def test_rescue_golden(mine_lib):
+    """the committed vectors (tests/golden/rescue_cases.json: what the reference's ocda_go / edlib_go returned; make_golden_rescue.py)"""
+    import json
+    from oracle import oracle_api as ora
+    g = json.load(open(os.path.join(util.GOLDEN, "rescue_cases.json")))
+    n_ok = 0
+    for c in g["ocda_go"]:
+        q, t, qs, ts, e = ocda_inputs(c["seed"])
+        o, ident = (C.c_int * 6)(), C.c_double()
+        r = mine_lib.mine_ocda_go(ptr(q), qs, len(q), ptr(t), ts, len(t), C.c_double(e), 100, o, C.byref(ident))
+        assert (r, list(o)[:5]) == (c["ret"], c["out"]), c["seed"]
+        if r:
+            assert ident.value == c["ident"], c["seed"]
+            n_ok += 1
+    assert n_ok > 20
+    n_ok = 0
+    for c in g["edlib_go"]:
+        q, t, qf, qt, tf, tt, error, tol = edlib_inputs(c["seed"], c["seed"] % 4 == 3)
+        cap = (qt - qf) + (tt - tf) + 16
+        o, ident = (C.c_int * 6)(), C.c_double()
+        qa, ta = C.create_string_buffer(cap), C.create_string_buffer(cap)
+        r = mine_lib.mine_edlib_go(ptr(q), qf, qt, ptr(t), tf, tt, C.c_double(error), tol, 100, o, C.byref(ident), qa, ta, cap)
+        assert r == c["ret"], c["seed"]
+        if r:
+            assert (list(o), ident.value, ora.fnv64(qa.value), ora.fnv64(ta.value)) == (c["out"], c["ident"], c["qaln"], c["taln"]), c["seed"]
+            n_ok += 1
+    assert n_ok > 15
+
+
+@needs_ref
 def test_ocda_go_matches_reference(libs):
     ref, mine = libs
     n = ok = 0
@@ -94,6 +151,7 @@ def edlib_case(ref, mine, q, t, qf, qt, tf, tt, error, tol, min_size=100):
     return res
 
 
+@needs_ref
 def test_edlib_go_matches_reference(libs):
     """Sizes on both sides of edlib's 1 MB traceback limit, so that the plain walk, one split and nested splits all occur."""
     ref, mine = libs
@@ -119,6 +177,7 @@ def test_edlib_go_matches_reference(libs):
     assert n > 100 and ok > 40
 
 
+@needs_ref
 def test_edlib_go_edges(libs):
     ref, mine = libs
     rng = np.random.default_rng(5)
@@ -143,6 +202,7 @@ def test_edlib_go_edges(libs):
         assert a == b, i
 
 
+@needs_ref
 def test_cns_loop_with_rescue_matches_reference(tmp_path):
     """oc2cns -r 1 without a GPU: the extension loop (cns_loop.h) with the oracle's block-wise aligner and cns_rescue.h behind it,
     as the library runs it behind the device pass, on reads with long indels - every add_one_align call (gapped strings included)
