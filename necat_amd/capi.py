@@ -52,6 +52,7 @@ M4_DTYPE = np.dtype([("qid", "<i4"), ("qdir", "<i4"), ("qoff", "<u8"), ("qend", 
                      ("sext", "<u8"), ("ssize", "<u8"), ("ident_perc", "<f8"), ("vscore", "<i4"), ("_pad", "<i4")])
 ALIGNMENT_DTYPE = np.dtype([("ok", "<i4"), ("qoff", "<i4"), ("qend", "<i4"), ("toff", "<i4"), ("tend", "<i4"),
                             ("align_size", "<i4"), ("ident_perc", "<f8")])
+ASM_ANCHOR_DTYPE = np.dtype([("qid", "<i4"), ("sid", "<i4"), ("sdir", "<i4"), ("qoff", "<i4"), ("soff", "<i4")])      # necat_asm_anchor
 assert CANDIDATE_DTYPE.itemsize == 88 and M4_DTYPE.itemsize == 96 and ALIGNMENT_DTYPE.itemsize == 32
 CNS_OVERLAP_DTYPE = np.dtype([("cand", "<u8"), ("qoff", "<i4"), ("qend", "<i4"), ("toff", "<i4"), ("tend", "<i4"),
                               ("align_size", "<i4"), ("ops_block", "<u4"), ("ops_off", "<u8"), ("ident_perc", "<f8"),
@@ -334,6 +335,17 @@ class Context:
                     "necat_onc_align_batch")
         off = self._take(f, n + 1, np.dtype("<u8"))
         return self._take(a, n, ALIGNMENT_DTYPE), self._take(o, int(off[-1]), np.dtype("u1")), off
+
+    def asm_align_batch(self, ref: "Volume", reads: "Volume", read_start_id: int, ref_start_id: int, anchors: np.ndarray, error: float = 0.5,
+                        min_align_size: int = 400):
+        """blockwise_edlib_align (oc2asmpm's block aligner: 2048-bp blocks, tail match length 8) for every anchor; returns as onc_align_batch"""
+        anchors = np.ascontiguousarray(anchors, dtype=ASM_ANCHOR_DTYPE)
+        n = anchors.shape[0]
+        a, o, f = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._check(self.lib.necat_asm_align_batch(self.h, ref.h, reads.h, read_start_id, ref_start_id, anchors.ctypes.data, n, error, min_align_size,
+                                                   C.byref(a), C.byref(o), C.byref(f)), "necat_asm_align_batch")
+        off = self._take(f, n + 1, np.dtype("<u8"))
+        return self._take(a, n, ALIGNMENT_DTYPE), self._take(o, max(8, int(off[-1])), np.dtype("u1")), off
 
     def cns_load_partition(self, reads: "Volume", packed: np.ndarray):
         """order and cut of one candidate partition as oc2cns does it: (cands, tmpl_off, n_all)"""
