@@ -58,6 +58,30 @@ struct HMatR {
     const HMat* m;
     void rec(int c, int b, u64& Pv, u64& Ph) const { Pv = m->Pv[(size_t)c * m->nw + b]; Ph = m->Ph[(size_t)c * m->nw + b]; }
 };
+// -DCHECK_WINDOW: the band records the walk can reach.  The block's distance d and end column e are known after the SHW pass; a cell (r, c) of an
+// alignment of cost d from (0, 0) to (qn - 1, e) has |r - c| + |(qn - 1 - e) - (r - c)| <= d, so the NW pass only needs to keep, per column, the
+// words that meet rows c + ceil((D - d) / 2) .. c + floor((D + d) / 2), D = qn - 1 - e.  HMatW keeps exactly those; a read of anything else is counted.
+struct HMatW {
+    std::vector<u64> A, B; std::vector<char> have; int nw = 0, qn = 0, dlo = 0, dhi = 0;
+    long stored = 0, offered = 0, bad_reads = 0;
+    int cur_col = -1, cur_n = 0, max_per_col = 0;
+    void init(int cols, int nw_, int qn_, int dist, int endc)
+    {
+        nw = nw_; qn = qn_;
+        const int D = qn - 1 - endc;
+        dlo = -((dist - D) / 2); dhi = (D + dist) / 2;
+        A.assign((size_t)cols * nw, 0); B.assign((size_t)cols * nw, 0); have.assign((size_t)cols * nw, 0);
+    }
+    bool in_window(int c, int b) const
+    {
+        const int lo = std::max(0, c + dlo), hi = std::min(qn - 1, c + dhi);
+        return lo <= hi && b >= (lo >> 6) && b <= (hi >> 6);
+    }
+    void store(int c, int b, u64 a, u64 bb) { ++offered; if (c != cur_col) { cur_col = c; cur_n = 0; } if (++cur_n > max_per_col) max_per_col = cur_n; if (!in_window(c, b)) return; ++stored; A[(size_t)c * nw + b] = a; B[(size_t)c * nw + b] = bb; have[(size_t)c * nw + b] = 1; }
+    bool skip_nw() const { return false; }
+    void rec(int c, int b, u64& a, u64& bb) { if (!have[(size_t)c * nw + b]) ++bad_reads; a = A[(size_t)c * nw + b]; bb = B[(size_t)c * nw + b]; }
+};
+static long g_win_stored = 0, g_win_offered = 0, g_win_bad = 0, g_win_diff = 0, g_win_cols = 0, g_win_hist[64] = {0};
 struct HOps { std::vector<int> v; TailScan ts; void push(int op) { v.push_back(op); tail_push(ts, op); } };
 // the GPU formulation of the same walk (walk_block): must give the same ops and the same tail statistics
 struct HSink { std::vector<int> v; bool storing() const { return true; } void put(int i, int op) { if ((int)v.size() <= i) v.resize(i + 1, -1); v[i] = op; } };
@@ -174,6 +198,7 @@ int main(int argc, char** argv)
                 ext_init(tk, 0, c.qdir, (i64)rd->offset[c.qid], (i32)c.qsize, (i64)ref.offset[c.sid], (i32)c.ssize, (i32)c.qoff, (i32)c.soff);
                 while (ext_plan<kBlk>(tk)) {
                     FragGeom g = ext_frag_geom(tk);
+                    const int tk_qblk = tk.qblk, tk_tblk = tk.tblk; (void)tk_qblk; (void)tk_tblk;
                     MyersResult mr; HOps ops; ++n_blocks;
                     if (!tk.last && tk.qblk == kBlk && tk.tblk == kBlk) {
                         mr = run_block<kNwFull, true>(hrd->dv, href.dv, g, tk.qblk, tk.tblk, opt.error, mat, tw, R8);
@@ -190,6 +215,21 @@ int main(int argc, char** argv)
                         HRops ro{&ops.v}; HSame<kNwMax> sm{&R13, tw};
                         ext_finish_block(tk, mr.dist, mr.endc, done, ops.ts, ro, sm);
                     }
+#ifdef CHECK_WINDOW
+                    if (mr.dist >= 0) {
+                        // the same block again, keeping only the window's records: the walk must read nothing else and give the same ops
+                        static MyersRegs<kNwMax> RW;
+                        for (int b = 0; b < kNwMax; ++b) { u64 lo = 0, hi = 0; if (b * 64 < tk_qblk) load64_planes(hrd->dv.bases, g.q_base, g.q_dir, g.q_comp, b * 64, &lo, &hi); RW.nlo[b] = ~lo; RW.nhi[b] = ~hi; }
+                        HTgt tgw; tgw.w = tw;
+                        HMatW mw; mw.init(tk_tblk, kNwMax, tk_qblk, mr.dist, mr.endc);
+                        const MyersResult m2 = myers_block<kNwMax, false>(RW, tk_qblk, tk_tblk, opt.error, tgw, mw);
+                        HOps o2; tail_init(o2.ts, ops.ts.M);
+                        traceback_block(tk_qblk, m2.endc + 1, mw, o2);
+                        ++g_win_hist[std::min(63, mw.max_per_col)];
+                        g_win_stored += mw.stored; g_win_offered += mw.offered; g_win_bad += mw.bad_reads; g_win_cols += m2.endc + 1;
+                        if (m2.dist != mr.dist || m2.endc != mr.endc || o2.v != ops.v) ++g_win_diff;
+                    }
+#endif
                     if (mr.err) { fprintf(stderr, "DP internal error %d\n", mr.err); ++bad_ext; }
                 }
                 double ident = tk.r_cols ? 100.0 * (double)tk.r_mat / (double)tk.r_cols : 0.0;
@@ -203,6 +243,14 @@ int main(int argc, char** argv)
         ora_wfd_free(w); ora_aligner_free(al); free(oc.a);
         if (v != vid) ora_volume_free(&rd_own);
     }
+#ifdef CHECK_WINDOW
+    printf("window: records kept %ld of %ld offered (%.2f / %.2f words per column), reads outside the window %ld, blocks with a different walk %ld\n", g_win_stored, g_win_offered,
+           g_win_cols ? (double)g_win_stored / g_win_cols : 0.0, g_win_cols ? (double)g_win_offered / g_win_cols : 0.0, g_win_bad, g_win_diff);
+    printf("window: blocks by their widest column (words):");
+    for (int w = 0; w < 64; ++w) if (g_win_hist[w]) printf(" %d:%ld", w, g_win_hist[w]);
+    printf("\n");
+    if (g_win_bad || g_win_diff) return 1;
+#endif
     printf("check_core: candidates=%ld blocks=%ld m4=%ld seed_mismatch=%ld ext_mismatch=%ld walk_mismatch=%ld\n", n_cand, n_blocks, n_m4, bad_seed, bad_ext, g_bad_walk);
     return (bad_seed || bad_ext || g_bad_walk) ? 1 : 0;
 }
