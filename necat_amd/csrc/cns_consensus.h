@@ -26,22 +26,24 @@
 namespace necat_host {
 namespace cns {
 
-struct Tag {                // tasc/align_tags.h:8-16
+// tasc/align_tags.h:8-16.  The six keys are kept as two words in AlignTag_LT's order (tasc/align_tags.c:6-18: t_pos, delta, q_base, then p_t_pos,
+// p_delta, p_q_base; positions biased so that -1 sorts first), so that the sort - two thirds of the consensus proper's time - compares two integers
+// instead of walking six fields; the comparisons' outcomes, and with them the permutation klib's introsort leaves, are the same.
+struct Tag {
     double weight;
-    int t_pos, p_t_pos;
-    uint8_t delta, p_delta;
-    char q_base, p_q_base;
+    uint64_t hi, lo;
+    static uint64_t key(int pos, uint8_t delta, char base) { return (uint64_t)((uint32_t)pos ^ 0x80000000u) << 32 | (uint64_t)delta << 24 | (uint64_t)(uint8_t)base << 16; }
+    void set(int t_pos_, uint8_t delta_, char q_base_, int p_t_pos_, uint8_t p_delta_, char p_q_base_) { hi = key(t_pos_, delta_, q_base_); lo = key(p_t_pos_, p_delta_, p_q_base_); }
+    int t_pos() const { return (int)((uint32_t)(hi >> 32) ^ 0x80000000u); }
+    int p_t_pos() const { return (int)((uint32_t)(lo >> 32) ^ 0x80000000u); }
+    uint8_t delta() const { return (uint8_t)(hi >> 24); }
+    uint8_t p_delta() const { return (uint8_t)(lo >> 24); }
+    char q_base() const { return (char)(uint8_t)(hi >> 16); }
+    char p_q_base() const { return (char)(uint8_t)(lo >> 16); }
 };
 
-inline bool tag_less(const Tag& a, const Tag& b)     // AlignTag_LT, tasc/align_tags.c:6-18
-{
-    if (a.t_pos != b.t_pos) return a.t_pos < b.t_pos;
-    if (a.delta != b.delta) return a.delta < b.delta;
-    if (a.q_base != b.q_base) return a.q_base < b.q_base;
-    if (a.p_t_pos != b.p_t_pos) return a.p_t_pos < b.p_t_pos;
-    if (a.p_delta != b.p_delta) return a.p_delta < b.p_delta;
-    return a.p_q_base < b.p_q_base;
-}
+struct TagLess { bool operator()(const Tag& a, const Tag& b) const { return a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo; } };
+inline bool tag_less(const Tag& a, const Tag& b) { return TagLess()(a, b); }
 
 // ---- klib's introsort, same decisions in the same order (see the header comment) ----
 template <class T, class Less>
@@ -138,7 +140,7 @@ bool overlap_tags(const uint8_t* ops, int ncols, QBase qbase, int toff, double w
         char q = '-';
         if (op != 2) { q = dec[qbase(qi) & 3]; ++qi; ++jj; }
         if (op != 1) { ++j; jj = 0; }
-        tag.t_pos = j; tag.p_t_pos = p_j; tag.delta = (uint8_t)jj; tag.p_delta = (uint8_t)p_jj; tag.q_base = q; tag.p_q_base = p_q;
+        tag.set(j, (uint8_t)jj, q, p_j, (uint8_t)p_jj, p_q);
         p_j = j; p_jj = jj; p_q = q;
         out[i] = tag;
     }
@@ -169,35 +171,35 @@ struct Backbone {
         coverage.assign((size_t)template_size, 0);
         deltas.clear(); links.clear();
         const int ntag = (int)tags.size();
-        klib_introsort((size_t)ntag, tags.data(), tag_less);
+        klib_introsort((size_t)ntag, tags.data(), TagLess());
         const Tag* T = tags.data();
         int i = 0;
         while (i < ntag) {                                               // one target position (build_backbone :110-124)
             int j = i + 1;
-            while (j < ntag && T[i].t_pos == T[j].t_pos) ++j;
-            Item& it = items[(size_t)T[i].t_pos];
-            it.n_delta = T[j - 1].delta + 1;
+            while (j < ntag && T[i].t_pos() == T[j].t_pos()) ++j;
+            Item& it = items[(size_t)T[i].t_pos()];
+            it.n_delta = T[j - 1].delta() + 1;
             it.first = (uint32_t)deltas.size();
             deltas.resize(deltas.size() + (size_t)it.n_delta);           // value-initialised: a delta without tags keeps coverage 0
             int a = i;
             while (a < j) {                                              // one delta (build_backbone_item :84-94)
                 int b = a + 1;
-                while (b < j && T[a].delta == T[b].delta) ++b;
-                DeltaCov& dc = deltas[it.first + T[a].delta];
+                while (b < j && T[a].delta() == T[b].delta()) ++b;
+                DeltaCov& dc = deltas[it.first + T[a].delta()];
                 for (int q = 0; q < 5; ++q) dc.links[q] = BaseLinks();
                 int c = a;
                 while (c < b) {                                          // one query base (build_delta_links :66-73)
                     int e = c;
-                    while (e < b && T[c].q_base == T[e].q_base) ++e;
-                    BaseLinks& bl = dc.links[base_code(T[c].q_base)];
+                    while (e < b && T[c].q_base() == T[e].q_base()) ++e;
+                    BaseLinks& bl = dc.links[base_code(T[c].q_base())];
                     bl.coverage = e - c;
                     bl.first = (uint32_t)links.size();
                     int n_link = 0;
                     int g = c;
                     while (g < e) {                                      // one predecessor (build_base_links :36-51)
                         int h = g + 1;
-                        while (h < e && T[g].p_t_pos == T[h].p_t_pos && T[g].p_delta == T[h].p_delta && T[g].p_q_base == T[h].p_q_base) ++h;
-                        Link L; L.p_t_pos = T[g].p_t_pos; L.p_delta = T[g].p_delta; L.p_q_base = T[g].p_q_base; L.count = h - g; L.weight = 0;
+                        while (h < e && T[g].p_t_pos() == T[h].p_t_pos() && T[g].p_delta() == T[h].p_delta() && T[g].p_q_base() == T[h].p_q_base()) ++h;
+                        Link L; L.p_t_pos = T[g].p_t_pos(); L.p_delta = T[g].p_delta(); L.p_q_base = T[g].p_q_base(); L.count = h - g; L.weight = 0;
                         for (int k = g; k < h; ++k) L.weight += T[k].weight;
                         links.push_back(L);
                         ++n_link;
@@ -206,7 +208,7 @@ struct Backbone {
                     bl.n_link = n_link;
                     c = e;
                 }
-                if (T[a].delta == 0) coverage[(size_t)T[a].t_pos] = b - a;
+                if (T[a].delta() == 0) coverage[(size_t)T[a].t_pos()] = b - a;
                 a = b;
             }
             i = j;
