@@ -115,8 +115,9 @@ struct Voter {
     void strand(const uint8_t* read, int read_len, int chain, int read_local_id, int read_global_id, int ref_start_id, const RefView& ref,
                 int seed_len, int bc, int64_t soff_max, std::vector<VoteCandidate>& out)
     {
-        const int cleave = (read_len - seed_len) / bc + 1;
         index_list.clear(); index_score.clear();
+        if (read_len < seed_len) return;          // (the reference reads past the end of such a read, asm_pm_common.c:429-446; none survive oc2mkdb's users)
+        const int cleave = (read_len - seed_len) / bc + 1;
         for (int k = 0; k < cleave; ++k) {
             uint64_t h = 0;
             for (int j = 0; j < seed_len; ++j) h = (h << 2) | (uint64_t)(read[k * bc + j] & 3);
