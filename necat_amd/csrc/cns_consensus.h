@@ -29,20 +29,21 @@ namespace cns {
 // tasc/align_tags.h:8-16.  The six keys are kept as two words in AlignTag_LT's order (tasc/align_tags.c:6-18: t_pos, delta, q_base, then p_t_pos,
 // p_delta, p_q_base; positions biased so that -1 sorts first), so that the sort - two thirds of the consensus proper's time - compares two integers
 // instead of walking six fields; the comparisons' outcomes, and with them the permutation klib's introsort leaves, are the same.
-struct Tag {
-    double weight;
+struct Tag {                // 16 bytes: the keys, and in the 16 low bits of `lo` (not part of the order) which overlap of the template the tag comes from - its weight is looked up
     uint64_t hi, lo;
     static uint64_t key(int pos, uint8_t delta, char base) { return (uint64_t)((uint32_t)pos ^ 0x80000000u) << 32 | (uint64_t)delta << 24 | (uint64_t)(uint8_t)base << 16; }
-    void set(int t_pos_, uint8_t delta_, char q_base_, int p_t_pos_, uint8_t p_delta_, char p_q_base_) { hi = key(t_pos_, delta_, q_base_); lo = key(p_t_pos_, p_delta_, p_q_base_); }
+    void set(int t_pos_, uint8_t delta_, char q_base_, int p_t_pos_, uint8_t p_delta_, char p_q_base_, uint32_t ovl) { hi = key(t_pos_, delta_, q_base_); lo = key(p_t_pos_, p_delta_, p_q_base_) | (ovl & 0xffffu); }
     int t_pos() const { return (int)((uint32_t)(hi >> 32) ^ 0x80000000u); }
     int p_t_pos() const { return (int)((uint32_t)(lo >> 32) ^ 0x80000000u); }
     uint8_t delta() const { return (uint8_t)(hi >> 24); }
     uint8_t p_delta() const { return (uint8_t)(lo >> 24); }
     char q_base() const { return (char)(uint8_t)(hi >> 16); }
     char p_q_base() const { return (char)(uint8_t)(lo >> 16); }
+    uint32_t ovl() const { return (uint32_t)(lo & 0xffffu); }
 };
+constexpr size_t kMaxTagOverlaps = 65536;       // overlaps of one template (MAX_EXAMINED_CAN = 300, consensus_aux.h:15)
 
-struct TagLess { bool operator()(const Tag& a, const Tag& b) const { return a.hi != b.hi ? a.hi < b.hi : a.lo < b.lo; } };
+struct TagLess { bool operator()(const Tag& a, const Tag& b) const { typedef unsigned __int128 u128; return ((u128)a.hi << 64 | (a.lo & ~0xffffULL)) < ((u128)b.hi << 64 | (b.lo & ~0xffffULL)); } };
 inline bool tag_less(const Tag& a, const Tag& b) { return TagLess()(a, b); }
 
 // ---- klib's introsort, same decisions in the same order (see the header comment) ----
@@ -117,7 +118,7 @@ void klib_introsort(size_t n, T* a, Less lt)
 // qbase(i): byte code 0..3 of base i of the query STRAND, starting at the alignment's qoff.
 // Returns false (no tags added) when a run of >= 255 query bases sits between two target bases (:38-42).
 template <class QBase>
-bool overlap_tags(const uint8_t* ops, int ncols, QBase qbase, int toff, double weight, std::vector<Tag>& tags)
+bool overlap_tags(const uint8_t* ops, int ncols, QBase qbase, int toff, uint32_t ovl, std::vector<Tag>& tags)
 {
     auto op_at = [&](int i) { return (ops[i >> 2] >> ((i & 3) * 2)) & 3; };
     int jj = 0;
@@ -128,7 +129,7 @@ bool overlap_tags(const uint8_t* ops, int ncols, QBase qbase, int toff, double w
         if (jj >= 255) return false;
     }
     static const char dec[4] = {'A', 'C', 'G', 'T'};
-    Tag tag; tag.weight = weight;
+    Tag tag;
     jj = 0;
     int j = toff - 1, p_j = -1, p_jj = 0, qi = 0;
     char p_q = '-';
@@ -140,7 +141,7 @@ bool overlap_tags(const uint8_t* ops, int ncols, QBase qbase, int toff, double w
         char q = '-';
         if (op != 2) { q = dec[qbase(qi) & 3]; ++qi; ++jj; }
         if (op != 1) { ++j; jj = 0; }
-        tag.set(j, (uint8_t)jj, q, p_j, (uint8_t)p_jj, p_q);
+        tag.set(j, (uint8_t)jj, q, p_j, (uint8_t)p_jj, p_q, ovl);
         p_j = j; p_jj = jj; p_q = q;
         out[i] = tag;
     }
@@ -164,8 +165,8 @@ struct Backbone {
     std::vector<Link> links;          // the LinkInfo allocator
     std::vector<int> coverage;        // [template_size]
 
-    // tags: all overlaps' tags of the template; sorted in place
-    void build(std::vector<Tag>& tags, int template_size)
+    // tags: all overlaps' tags of the template; sorted in place.  weight[tag.ovl()]: the weight of the overlap a tag comes from
+    void build(std::vector<Tag>& tags, const double* weight, int template_size)
     {
         items.assign((size_t)template_size, Item());
         coverage.assign((size_t)template_size, 0);
@@ -200,7 +201,7 @@ struct Backbone {
                         int h = g + 1;
                         while (h < e && T[g].p_t_pos() == T[h].p_t_pos() && T[g].p_delta() == T[h].p_delta() && T[g].p_q_base() == T[h].p_q_base()) ++h;
                         Link L; L.p_t_pos = T[g].p_t_pos(); L.p_delta = T[g].p_delta(); L.p_q_base = T[g].p_q_base(); L.count = h - g; L.weight = 0;
-                        for (int k = g; k < h; ++k) L.weight += T[k].weight;
+                        for (int k = g; k < h; ++k) L.weight += weight[T[k].ovl()];
                         links.push_back(L);
                         ++n_link;
                         g = h;
@@ -381,6 +382,7 @@ struct OverlapIn {            // one add_one_align call (tasc/cbcns.c:47)
 struct Worker {               // per-thread scratch
     Backbone bb;
     std::vector<Tag> tags;
+    std::vector<double> weights;      // of the template's overlaps, by Tag::ovl()
     std::vector<Segment> segs;
     std::vector<std::pair<int, int>> raw;
     std::string seq;
@@ -392,15 +394,17 @@ inline bool consensus_template(Worker& w, const OverlapIn* ov, size_t n_ov, cons
                                int min_cov, int min_size, bool full_consensus, int num_can, int num_ovlps, double ident_cutoff,
                                std::string& cns_txt, std::string& raw_txt)
 {
-    w.tags.clear();
+    w.tags.clear(); w.weights.resize(n_ov);
+    if (n_ov > kMaxTagOverlaps) { fprintf(stderr, "[cns] template %d: %zu overlaps exceed the tag format\n", tid, n_ov); abort(); }
     for (size_t k = 0; k < n_ov; ++k) {
         const OverlapIn& o = ov[k];
         const uint8_t* q = o.qfwd;
         const int qsize = o.qsize, qoff = o.qoff;
-        if (o.qdir == 0) overlap_tags(o.ops, o.ncols, [&](int i) { return q[qoff + i]; }, o.toff, o.weight, w.tags);
-        else overlap_tags(o.ops, o.ncols, [&](int i) { return (uint8_t)(3 - q[qsize - 1 - (qoff + i)]); }, o.toff, o.weight, w.tags);
+        w.weights[k] = o.weight;
+        if (o.qdir == 0) overlap_tags(o.ops, o.ncols, [&](int i) { return q[qoff + i]; }, o.toff, (uint32_t)k, w.tags);
+        else overlap_tags(o.ops, o.ncols, [&](int i) { return (uint8_t)(3 - q[qsize - 1 - (qoff + i)]); }, o.toff, (uint32_t)k, w.tags);
     }
-    w.bb.build(w.tags, tsize);
+    w.bb.build(w.tags, w.weights.data(), tsize);
     static const char dec[4] = {'A', 'C', 'G', 'T'};
     if (full_consensus) {
         const int n = consensus_unbroken(w.bb, min_cov, min_size, [&](int k) { return tseq[k]; }, tsize, w.seq);
