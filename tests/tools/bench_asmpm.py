@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""oc2asmpm on a synthetic corrected-read set: this repo's program (GPU block aligner) and, when oracle/_ref is there, the reference's own program on all
+"""(Under tests/: it runs the reference's program from oracle/_ref as the comparison.)  oc2asmpm on a synthetic corrected-read set: this repo's program (GPU block aligner) and, when oracle/_ref is there, the reference's own program on all
 host cores; checks that the records are the same and prints the wall times.  NECAT_TRACE=2 shows the library's stage times.
 
-    python tools/bench_asmpm.py [genome_len] [coverage] [error]
+    python tests/tools/bench_asmpm.py [genome_len] [coverage] [error]
 """
 import os
 import subprocess
@@ -10,7 +10,7 @@ import sys
 import tempfile
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from necat_amd import build, synth  # noqa: E402
 

@@ -1,7 +1,7 @@
 """Re-run ONE case of tests/tools/fuzz_parity.py and show where the HIP path and the oracle differ (debugging tool).
-    python tools/fuzz_case.py <seed0> <case>"""
+    python tests/tools/fuzz_case.py <seed0> <case>"""
 import os, sys, tempfile
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 from necat_amd import capi, synth
 from oracle import oracle_api as ora
