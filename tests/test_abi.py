@@ -78,6 +78,31 @@ def test_cli_usage_and_errors(built, tmp_path):
         assert r.returncode == 1 and "no usable gfx950" in r.stderr and not os.path.exists(out)
 
 
+def test_new_programs_usage_and_errors(built, tmp_path):
+    """oc2rm_worker / oc2asmpm: usage on bad argv (rm_one_vol_main.c:9-21, asmpm.c:3-19), exit 1 + message and no output file on a missing volume
+    directory or reference and - on a machine without a GPU - on the missing device (there is no CPU fallback)"""
+    built.build_cli()
+    rm, asm = built.OC2RM, built.OC2ASMPM
+    r = subprocess.run([rm], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "USAGE" in r.stderr and "wrk-dir reference output" in r.stderr
+    r = subprocess.run([asm], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "USAGE" in r.stdout and "wrk_dir volume_id output" in r.stdout
+    out = os.path.join(str(tmp_path), "o")
+    r = subprocess.run([rm, "-k", "13", os.path.join(str(tmp_path), "nope"), "ref", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "ERROR" in r.stderr and not os.path.exists(out)
+    r = subprocess.run([asm, "-k", "13", os.path.join(str(tmp_path), "nope"), "0", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "ERROR" in r.stderr and not os.path.exists(out)
+    d = util.install_golden_volumes("vols_d", tmp_path)
+    r = subprocess.run([asm, "-k", "13", d, "7", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 1 and "out of range" in r.stderr
+    if not HAVE_GPU:
+        r = subprocess.run([asm, "-k", "13", d, "0", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 1 and "no usable gfx950" in r.stderr and not os.path.exists(out)
+        e = util.install_golden_volumes("vols_e", tmp_path)
+        r = subprocess.run([rm, "-k", "13", e, os.path.join(util.GOLDEN, "rm_e", "ref.vol"), out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 1 and "no usable gfx950" in r.stderr and not os.path.exists(out)
+
+
 def test_gapped_strings_host_helper(built):
     """necat_gapped_strings (host code of the library, no GPU): alignment columns -> the reference's two
     "ACGT-" strings.  Columns are derived from the oracle's onc_align strings; expanding them again must give
