@@ -81,6 +81,28 @@ struct HMatW {
     bool skip_nw() const { return false; }
     void rec(int c, int b, u64& a, u64& bb) { if (!have[(size_t)c * nw + b]) ++bad_reads; a = A[(size_t)c * nw + b]; bb = B[(size_t)c * nw + b]; }
 };
+// The compact slab the device path wants: [column][word - first stored word of the column], kSlots per column, one byte per column for the first
+// word.  A block whose band is wider than kSlots somewhere is counted as an overflow (the device would redo it on a full slab).
+struct HMatC {
+    static constexpr int kSlots = 20;
+    std::vector<u64> A, B; std::vector<int> first; int overflow = 0; long bad_reads = 0;
+    void init(int cols) { A.assign((size_t)cols * kSlots, 0); B.assign((size_t)cols * kSlots, 0); first.assign((size_t)cols, -1); overflow = 0; }
+    void store(int c, int b, u64 a, u64 bb)
+    {
+        if (first[(size_t)c] < 0) first[(size_t)c] = b;
+        const int s = b - first[(size_t)c];
+        if (s < 0 || s >= kSlots) { overflow = 1; return; }
+        A[(size_t)c * kSlots + s] = a; B[(size_t)c * kSlots + s] = bb;
+    }
+    bool skip_nw() const { return false; }
+    void rec(int c, int b, u64& a, u64& bb)
+    {
+        const int s = first[(size_t)c] < 0 ? -1 : b - first[(size_t)c];
+        if (s < 0 || s >= kSlots) { ++bad_reads; a = bb = 0; return; }
+        a = A[(size_t)c * kSlots + s]; bb = B[(size_t)c * kSlots + s];
+    }
+};
+static long g_cmp_overflow = 0, g_cmp_bad = 0, g_cmp_diff = 0;
 static long g_win_stored = 0, g_win_offered = 0, g_win_bad = 0, g_win_diff = 0, g_win_cols = 0, g_win_hist[64] = {0};
 struct HOps { std::vector<int> v; TailScan ts; void push(int op) { v.push_back(op); tail_push(ts, op); } };
 // the GPU formulation of the same walk (walk_block): must give the same ops and the same tail statistics
@@ -228,6 +250,18 @@ int main(int argc, char** argv)
                         ++g_win_hist[std::min(63, mw.max_per_col)];
                         g_win_stored += mw.stored; g_win_offered += mw.offered; g_win_bad += mw.bad_reads; g_win_cols += m2.endc + 1;
                         if (m2.dist != mr.dist || m2.endc != mr.endc || o2.v != ops.v) ++g_win_diff;
+                        {   // and on the compact slab
+                            for (int b = 0; b < kNwMax; ++b) { u64 lo = 0, hi = 0; if (b * 64 < tk_qblk) load64_planes(hrd->dv.bases, g.q_base, g.q_dir, g.q_comp, b * 64, &lo, &hi); RW.nlo[b] = ~lo; RW.nhi[b] = ~hi; }
+                            HMatC mc; mc.init(tk_tblk);
+                            const MyersResult m3 = myers_block<kNwMax, false>(RW, tk_qblk, tk_tblk, opt.error, tgw, mc);
+                            if (mc.overflow) ++g_cmp_overflow;
+                            else {
+                                HOps o3; tail_init(o3.ts, ops.ts.M);
+                                traceback_block(tk_qblk, m3.endc + 1, mc, o3);
+                                g_cmp_bad += mc.bad_reads;
+                                if (m3.dist != mr.dist || m3.endc != mr.endc || o3.v != ops.v) ++g_cmp_diff;
+                            }
+                        }
                     }
 #endif
                     if (mr.err) { fprintf(stderr, "DP internal error %d\n", mr.err); ++bad_ext; }
@@ -249,7 +283,8 @@ int main(int argc, char** argv)
     printf("window: blocks by their widest column (words):");
     for (int w = 0; w < 64; ++w) if (g_win_hist[w]) printf(" %d:%ld", w, g_win_hist[w]);
     printf("\n");
-    if (g_win_bad || g_win_diff) return 1;
+    printf("compact slab of %d slots: blocks that overflow it %ld, reads outside it %ld, blocks with a different walk %ld\n", HMatC::kSlots, g_cmp_overflow, g_cmp_bad, g_cmp_diff);
+    if (g_win_bad || g_win_diff || g_cmp_bad || g_cmp_diff) return 1;
 #endif
     printf("check_core: candidates=%ld blocks=%ld m4=%ld seed_mismatch=%ld ext_mismatch=%ld walk_mismatch=%ld\n", n_cand, n_blocks, n_m4, bad_seed, bad_ext, g_bad_walk);
     return (bad_seed || bad_ext || g_bad_walk) ? 1 : 0;
