@@ -56,6 +56,23 @@ def test_cores_at_block_2048_match_oracle(built, tmp_path, err, args):
     assert int(f["blocks"]) > 1000 and int(f["m4"]) > 300
 
 
+@pytest.mark.parametrize("npairs,seed", [(60, 7), (45, 1234)])
+def test_asm_kernel_source_on_the_cpu(built, tmp_path, npairs, seed):
+    """asm_kernels.h (k_asm_align, the device's block aligner for oc2asmpm) compiled with g++ behind stand-ins for the HIP built-ins and run lane by
+    lane, wave by wave, in launches of two waves that reuse the slabs - as necat_asm_align_batch launches it - against the oracle's onc_align at block
+    size 2048 / tail 8: coordinates, identity and every column, anchors anywhere, both subject strands, unrelated sequences"""
+    d = str(tmp_path)
+    obj = os.path.join(d, "necat_oracle.o")
+    exe = os.path.join(d, "check_asm_kernel")
+    subprocess.run(["gcc", "-O2", "-std=gnu99", "-c", os.path.join(util.ROOT, "oracle", "necat_oracle.c"), "-o", obj], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe, os.path.join(util.ROOT, "tests", "host_core", "check_asm_kernel.cpp"), obj,
+                    "-lm", "-lpthread"], check=True)
+    r = subprocess.run([exe, str(npairs), str(seed)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    f = dict(kv.split("=") for kv in r.stdout.split()[1:])
+    assert int(f["mismatches"]) == 0 and int(f["aligned"]) > 100 and int(f["empty"]) > 3 and int(f["blocks"]) > 300
+
+
 def test_wave_chain_dp_model_equals_sequential(tmp_path):
     """chain_fill_wave (seed_kernels.h) turns the order-dependent predecessor scan of chain_dp.c:46-85 into prefix operations over
     64 lanes; its lane-by-lane host transcription must give the f / p / v of the sequential loop, max_skip stops included."""
