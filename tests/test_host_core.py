@@ -73,6 +73,22 @@ def test_asm_kernel_source_on_the_cpu(built, tmp_path, npairs, seed):
     assert int(f["mismatches"]) == 0 and int(f["aligned"]) > 100 and int(f["empty"]) > 3 and int(f["blocks"]) > 300
 
 
+def test_asm_kernel_source_under_sanitizers(built, tmp_path):
+    """the same harness built with -fsanitize=address,undefined: the slabs, the op pool and the column regions have exactly the sizes the library gives
+    them, so an out-of-range access of the kernel is an error here"""
+    d = str(tmp_path)
+    obj = os.path.join(d, "necat_oracle.o")
+    exe = os.path.join(d, "check_asm_kernel_asan")
+    subprocess.run(["gcc", "-O2", "-std=gnu99", "-c", os.path.join(util.ROOT, "oracle", "necat_oracle.c"), "-o", obj], check=True)
+    c = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", exe,
+                        os.path.join(util.ROOT, "tests", "host_core", "check_asm_kernel.cpp"), obj, "-lm", "-lpthread"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if c.returncode != 0:
+        pytest.skip("no sanitizer runtime for g++ here")
+    r = subprocess.run([exe, "30", "99"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "mismatches=0" in r.stdout and "ERROR" not in r.stdout and "runtime error" not in r.stdout
+
+
 def test_wave_chain_dp_model_equals_sequential(tmp_path):
     """chain_fill_wave (seed_kernels.h) turns the order-dependent predecessor scan of chain_dp.c:46-85 into prefix operations over
     64 lanes; its lane-by-lane host transcription must give the f / p / v of the sequential loop, max_skip stops included."""
