@@ -3,6 +3,7 @@
 // device's block aligner (necat_asm_align_batch; 74 %), then the end extension and the records on the host threads again.
 #pragma once
 #include <atomic>
+#include <memory>
 #include <thread>
 
 #include "asm_core.h"
@@ -58,8 +59,9 @@ inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const 
     // the vote reads the table on the host
     uint64_t n_table = 0, n_offsets = 0;
     necat_index_size(ix, &n_table, &n_offsets);
-    std::vector<uint64_t> kmer_stats(n_table), offset_list(n_offsets + 1);
-    if (necat_index_download(ctx, ix, kmer_stats.data(), offset_list.data())) return fail("necat_index_download", necat_last_error(ctx));
+    // (not value-initialised: the table is 8.6 GB at k = 15 and the download writes all of it)
+    std::unique_ptr<uint64_t[]> kmer_stats(new uint64_t[n_table + 1]), offset_list(new uint64_t[n_offsets + 1]);
+    if (necat_index_download(ctx, ix, kmer_stats.get(), offset_list.get())) return fail("necat_index_download", necat_last_error(ctx));
     necat_index_free(ctx, ix);
     log_line("[%s] INFO: '%s' takes %.2lf secs.\n", "build_lookup_table", now_sec() - t0);
     HostCodes cref; cref.set(href);
@@ -70,7 +72,7 @@ inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const 
     rv.kmer_list = [&](uint64_t h, uint64_t* n) -> const uint64_t* {
         const uint64_t u = kmer_stats[h], cnt = u >> 34, start = u & ((1ULL << 34) - 1);
         *n = cnt;
-        return cnt ? offset_list.data() + start : nullptr;
+        return cnt ? offset_list.get() + start : nullptr;
     };
     auto subject_of = [&](int sid, int strand, std::vector<uint8_t>& s) { cref.strand((uint64_t)sid, strand, s); };
 
