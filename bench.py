@@ -6,13 +6,20 @@ HBM: k-mer index build -> candidate search (both strands of every read) -> block
 extension -> M4 records back on the host.  Workload at N=1 = BASELINE.json configs[1]:
 E. coli-size (4.6 Mb) 40x synthetic ONT reads, OVLP_FAST_OPTIONS with -j 1 (M4 output).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU), default `--parallelism single-volume`: STRONG scaling of
+`--gpus N` with N > 1 and no RANK in the environment: the script re-launches itself under `python -m torch.distributed.run
+--nproc-per-node N` (one rank per GPU) and relays that run's JSON line; under a launcher it insists that WORLD_SIZE == --gpus.
+
+N > 1 (one rank per GPU), default `--parallelism single-volume`: STRONG scaling of
 the same workload - every rank holds the same volume, the index is built in hash-range slices and all-gathered
 (RCCL send/recv groups over xGMI), the query reads are dealt out in chunks, the M4 records are gathered on rank 0
 (necat_index_build_sharded / necat_map_pair_sharded, include/necat_hip.h).  `--parallelism volumes` keeps the coarse
 mode: every rank owns one independent reference volume (seed + rank) - the unit necat.pl itself distributes
-(necat.pl:190-202) - no data-path collective, weak scaling.  The barrier and the max-over-ranks time follow the
-driver's contract.
+(necat.pl:190-202) - no data-path collective, weak scaling.  `--parallelism pairs --volumes V` is the multi-volume shape of
+BASELINE configs[3] / [4]: the read set is cut into V volumes, the V (V + 1) / 2 (reference volume, query volume) jobs are laid on
+one cost line and every rank takes an equal stretch of it (necat_pair_schedule, necat_amd/csrc/pair_sched.h): pairs a boundary cuts
+are split by query reads, a reference volume whose pairs span several ranks has its index built in hash-range slices by exactly
+those ranks (necat_index_build_sharded over a communicator of the team); strong scaling, records stay on the rank that made them
+(as necat.pl's jobs each write their own pm_result file).  The barrier and the max-over-ranks time follow the driver's contract.
 
 Prints ONE JSON line (rank 0).
 """
@@ -55,17 +62,39 @@ def parse():
     ap.add_argument("--no-widened", action="store_true", help="skip the extra measurements of the SURVEY 8f.1 rows")
     ap.add_argument("--cpu-genome", type=int, default=0, help="genome size of the CPU-baseline input (0 = the bench workload itself)")
     ap.add_argument("--cpu-t1", action="store_true", help="also time the reference with -t 1 (minutes)")
-    ap.add_argument("--parallelism", choices=["single-volume", "volumes"], default="single-volume",
-                    help="N > 1: one volume on all GPUs (strong scaling, RCCL data path) or one volume per GPU (weak)")
+    ap.add_argument("--parallelism", choices=["single-volume", "volumes", "pairs"], default="single-volume",
+                    help="N > 1: one volume on all GPUs (strong scaling, RCCL data path), one volume per GPU (weak), or the (reference, query) "
+                         "volume pairs of a --volumes V project dealt to the GPUs by cost (strong)")
+    ap.add_argument("--volumes", type=int, default=3, help="pairs mode: volumes the read set is cut into (the last one is a 40 %% remainder)")
+    ap.add_argument("--slots", type=int, default=64, help="pairs mode: granularity of a pair's split by query reads")
+    ap.add_argument("--dump-records", default=None, help="write every rank's records of the LAST step to <prefix>_<rank>.npy (tests)")
     ap.add_argument("--chunk-reads", type=int, default=64, help="query reads per chunk dealt to the ranks (single-volume mode)")
     ap.add_argument("--transport", default="auto", help="auto | rccl | ipc (single-volume mode)")
     return ap.parse_args()
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script under torch.distributed.run (what the
+    driver's own multi-GPU command does) and relay its stdout - the one JSON line rank 0 prints - and its exit code."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
 
 
 def dist_setup(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) (WORLD_SIZE): refusing to report N = %d work under another N"
+                         % (args.gpus, world, args.gpus))
     dist = None
     if world > 1 or "RANK" in os.environ:      # launched by torch.distributed.run (also with one rank)
         import torch
@@ -218,118 +247,168 @@ def widened_paths(ctx, vol, capi, opt_kw):
     return res
 
 
-def main():
-    args = parse()
-    # stdout carries exactly ONE line, the JSON result: whatever libraries print there (RCCL announces its path on
-    # stdout when the first communicator is created) goes to stderr instead
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
-    rank, world, local, dist = dist_setup(args)
-    from necat_amd import build, capi, synth
-    if rank == 0:
-        build.build_hip()          # no-op when the in-tree library is current; one rank only, the others wait
-    if dist is not None:
-        dist.barrier()
+def new_agg():
+    return dict(index_ms=0.0, seed_ms=0.0, extend_ms=0.0, myers_ms=0.0, traceback_ms=0.0, launches=0, blocks=0, words=0, bases=0, rounds=0,
+                a_ms=0.0, a_launches=0, a_blocks=0, tb_a_ms=0.0, big_ms=0.0, big_blocks=0, band_words=0,
+                ix_local_ms=0.0, ix_xchg_ms=0.0, ix_xchg_bytes=0, gather_ms=0.0, gather_bytes=0, reads_local=0)
+
+
+def agg_add(agg, tm, t_index=0.0):
+    """add one library call's timings / work counters (necat_timings) to the step totals"""
+    agg["index_ms"] += t_index; agg["seed_ms"] += tm.seed_ms; agg["extend_ms"] += tm.extend_ms
+    agg["myers_ms"] += tm.myers_ms; agg["traceback_ms"] += tm.traceback_ms; agg["launches"] += tm.myers_launches
+    agg["blocks"] += tm.myers_blocks; agg["words"] += tm.myers_word_updates; agg["bases"] += tm.myers_cells_bases
+    agg["rounds"] += tm.rounds; agg["band_words"] += tm.myers_band_words
+    agg["tb_a_ms"] += tm.tracebackA_ms
+    if tm.myersA_big_blocks >= agg["big_blocks"]:
+        agg["big_blocks"], agg["big_ms"] = int(tm.myersA_big_blocks), float(tm.myersA_big_ms)
+    agg["a_ms"] += tm.myersA_ms; agg["a_launches"] += tm.myersA_launches; agg["a_blocks"] += tm.myersA_blocks
+
+
+def gather_rank_stats(dist, mine):
+    """every rank's dict, in rank order, on every rank (identity without a process group)"""
+    if dist is None:
+        return [mine]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, mine)
+    return out
+
+
+def main_pairs(args, rank, world, local, dist, json_fd):
+    """--parallelism pairs: the (reference volume, query volume) jobs of a V-volume project on `world` GPUs (module docstring)"""
+    import torch  # noqa: F401  (process group already initialised when world > 1)
+    from necat_amd import capi, synth, dist as ndist, shard
     opt_kw = dict(FAST, kmer_size=args.kmer, scan_window=args.scan_window)
     opt = capi.default_options(**dict(opt_kw, job=args.job, num_threads=1))
-    single = world > 1 and args.parallelism == "single-volume"
-    # ---- synthetic volume, made resident in HBM before the clock starts (single-volume mode: the SAME volume on every rank)
-    rs = synth.simulate_reads(args.genome, args.coverage, seed=args.seed + (0 if single or world == 1 else 1000 * rank))
-    pac = synth.pack_2bit(rs.codes)
+    rs = synth.simulate_reads(args.genome, args.coverage, seed=args.seed)            # the same project on every rank
+    ranges = synth.cut_ranges(rs, synth.remainder_cuts(rs, args.volumes))
+    V = len(ranges)
+    vol_bases = [int(rs.sizes[a:b].sum()) for a, b in ranges]
+    units, off, team = capi.pair_schedule(vol_bases, world, args.slots)
+    mine = units[off[rank]:off[rank + 1]]
+    ref_vols = sorted(set(int(u["ref_vol"]) for u in mine))
+    need = sorted(set(ref_vols) | set(int(u["query_vol"]) for u in mine))
     ctx = capi.Context(local)
-    vol = ctx.upload_volume(pac, rs.nbases, rs.offsets, rs.sizes)
-    comm = None
-    if single:
-        import torch
-        from necat_amd import dist as ndist
-        one_dev = os.environ.get("NECAT_BENCH_ONE_DEVICE") == "1"
-        comm = ctx.comm(rank, world, ndist.torch_allgather(dist, device=None if one_dev else torch.device("cuda", local)), args.transport)
+    vols = {}
+    for v in need:                                                                      # resident before the clock starts
+        a, b = ranges[v]
+        o0, o1 = int(rs.offsets[a]), int(rs.offsets[b - 1] + rs.sizes[b - 1])
+        vols[v] = ctx.upload_volume(synth.pack_2bit(rs.codes[o0:o1]), o1 - o0, rs.offsets[a:b] - o0, rs.sizes[a:b])
+    # one communicator per reference volume whose pairs span several ranks (consecutive ranks: its team)
+    one_dev = os.environ.get("NECAT_BENCH_ONE_DEVICE") == "1"
+    comms = {}
+    if dist is not None:
+        for v in range(V):
+            lo, hi = int(team[v, 0]), int(team[v, 1])
+            if hi > lo:
+                grp = dist.new_group(ranks=list(range(lo, hi + 1)))                       # collective over ALL ranks, same order everywhere
+                if lo <= rank <= hi:
+                    ag = ndist.torch_allgather(dist, group=grp, device=None if one_dev else torch.device("cuda", local))
+                    comms[v] = ctx.comm(rank - lo, hi - lo + 1, ag, args.transport)
+                    if not one_dev and args.transport in ("auto", "rccl") and comms[v].transport() != "rccl":
+                        raise SystemExit("bench.py: ranks on distinct devices but the team of volume %d runs on transport %s" % (v, comms[v].transport()))
+    last = {}
 
-    def step(job=args.job):
+    def step(job=args.job, keep=False):
         o = opt if job == args.job else capi.default_options(**dict(opt_kw, job=job, num_threads=1))
-        if comm is not None:
-            ix = ctx.build_index_sharded(comm, vol, o.kmer_size, o.kmer_cnt_cutoff)
-            t_index = ctx.timings().index_ms
-            sh_ix = ctx.shard_timings()
+        agg1 = new_agg()
+        # all indexes first: a team's build is a collective, and a rank that sits in two teams would otherwise make the second
+        # team wait for all its work on the first volume
+        ix = {}
+        for v in ref_vols:
+            if v in comms:
+                ix[v] = ctx.build_index_sharded(comms[v], vols[v], o.kmer_size, o.kmer_cnt_cutoff)
+                sh = ctx.shard_timings()
+                agg1["ix_local_ms"] += sh.index_local_ms; agg1["ix_xchg_ms"] += sh.index_exchange_ms; agg1["ix_xchg_bytes"] += sh.index_exchange_bytes
+            else:
+                ix[v] = ctx.build_index(vols[v], o.kmer_size, o.kmer_cnt_cutoff)
+            agg1["index_ms"] += ctx.timings().index_ms
+        n, gbp, recs = 0, 0.0, []
+        for u in mine:
+            rv, qv = int(u["ref_vol"]), int(u["query_vol"])
+            chunk = min(args.chunk_reads, capi.pair_chunk_reads(ranges[qv][1] - ranges[qv][0], args.slots))
             if job == 1:
-                m4, _, _ = ctx.map_pair_sharded(comm, ix, vol, vol, 0, 0, o, True, 1, args.chunk_reads, 0)
-                cands = None
+                r, _ = ctx.map_pair_part(ix[rv], vols[rv], vols[qv], ranges[qv][0], ranges[rv][0], o, chunk, int(u["slot_lo"]), int(u["slot_hi"]), args.slots)
+                gbp += float((r["qend"] - r["qoff"]).sum()) / 1e9
             else:
-                (cands, _), m4 = ctx.find_candidates_sharded(comm, ix, vol, vol, 0, 0, o, True, args.chunk_reads, 0), None
-            sh = ctx.shard_timings()
-            sh.index_local_ms, sh.index_exchange_ms, sh.index_exchange_bytes = sh_ix.index_local_ms, sh_ix.index_exchange_ms, sh_ix.index_exchange_bytes
-        else:
-            sh = None
-            ix = ctx.build_index(vol, o.kmer_size, o.kmer_cnt_cutoff)
-            t_index = ctx.timings().index_ms
-            if job == 1:      # pm_search_one_volume of a mapping job: seeding + extension in one call, candidates stay on the device
-                m4, _ = ctx.map_pair(ix, vol, vol, 0, 0, o, True, 1)
-                cands = None
-            else:
-                cands, m4 = ctx.find_candidates(ix, vol, vol, 0, 0, o, True), None
-        tm = ctx.timings()
-        ix.free()
-        return cands, m4, t_index, tm, sh
+                r = ctx.find_candidates_part(ix[rv], vols[rv], vols[qv], ranges[qv][0], ranges[rv][0], o, chunk, int(u["slot_lo"]), int(u["slot_hi"]), args.slots)
+            agg_add(agg1, ctx.timings())
+            n += r.shape[0]
+            if keep:
+                recs.append(r.copy())
+        for v in ref_vols:
+            ix[v].free()
+        if keep:
+            last["recs"] = recs
+        return n, gbp, agg1
 
-    # setup (untimed): initialise the torch/HIP runtimes and let the library size its HBM pools once
     barrier_sync(dist, local)
-    step()
+    step()                                   # setup (untimed): runtimes up, HBM pools sized
     for _ in range(args.warmup):
         step()
     barrier_sync(dist, local)
     t0 = time.perf_counter()
-    agg = dict(index_ms=0.0, seed_ms=0.0, extend_ms=0.0, myers_ms=0.0, traceback_ms=0.0, launches=0, blocks=0, words=0, bases=0, rounds=0,
-               a_ms=0.0, a_launches=0, a_blocks=0, tb_a_ms=0.0, big_ms=0.0, big_blocks=0, band_words=0,
-               ix_local_ms=0.0, ix_xchg_ms=0.0, ix_xchg_bytes=0, gather_ms=0.0, gather_bytes=0, reads_local=0)
-    n_over = 0
-    gbp = 0.0
-    for _ in range(args.steps):
-        cands, m4, t_index, tm, sh = step()
-        if comm is None or rank == 0:        # single-volume mode: rank 0 holds the gathered records of all ranks
-            n_over += (m4.shape[0] if m4 is not None else cands.shape[0])
-            if m4 is not None:
-                gbp += float((m4["qend"] - m4["qoff"]).sum()) / 1e9
-        agg["index_ms"] += t_index; agg["seed_ms"] += tm.seed_ms; agg["extend_ms"] += tm.extend_ms
-        agg["myers_ms"] += tm.myers_ms; agg["traceback_ms"] += tm.traceback_ms; agg["launches"] += tm.myers_launches
-        agg["blocks"] += tm.myers_blocks; agg["words"] += tm.myers_word_updates; agg["bases"] += tm.myers_cells_bases
-        agg["rounds"] += tm.rounds; agg["band_words"] += tm.myers_band_words
-        agg["tb_a_ms"] += tm.tracebackA_ms
-        if tm.myersA_big_blocks >= agg["big_blocks"]:
-            agg["big_blocks"], agg["big_ms"] = int(tm.myersA_big_blocks), float(tm.myersA_big_ms)
-        agg["a_ms"] += tm.myersA_ms; agg["a_launches"] += tm.myersA_launches; agg["a_blocks"] += tm.myersA_blocks
-        if sh is not None:
-            agg["ix_local_ms"] += sh.index_local_ms; agg["ix_xchg_ms"] += sh.index_exchange_ms; agg["ix_xchg_bytes"] += sh.index_exchange_bytes
-            agg["gather_ms"] += sh.gather_ms; agg["gather_bytes"] += sh.gather_bytes; agg["reads_local"] = int(sh.reads_local)
+    agg = new_agg()
+    n_over, gbp, busy = 0, 0.0, 0.0
+    for k in range(args.steps):
+        tb = time.perf_counter()
+        n, g, a1 = step(keep=bool(args.dump_records) and k == args.steps - 1)
+        busy += time.perf_counter() - tb
+        n_over += n; gbp += g
+        for key, val in a1.items():
+            if key in ("big_blocks", "big_ms"):
+                continue
+            agg[key] += val
+        if a1["big_blocks"] >= agg["big_blocks"]:
+            agg["big_blocks"], agg["big_ms"] = a1["big_blocks"], a1["big_ms"]
     barrier_sync(dist, local)
     elapsed = time.perf_counter() - t0
-    from necat_amd import shard
     elapsed, tot_over, tot_gbp = shard.reduce_step_stats(dist, elapsed, float(n_over), gbp,
                                                          device="cuda" if (dist is not None and dist.get_backend() == "nccl") else None)
-    # extras measured after the timed region, on every rank when collective
-    extras = {}
-    try:
-        t1 = time.perf_counter()
-        n0 = 0
-        for _ in range(3):
-            c0, _, _, _, _ = step(job=0)
-            if comm is None or rank == 0:
-                n0 += c0.shape[0]
-        barrier_sync(dist, local)
-        dt0 = time.perf_counter() - t1
-        extras["candidates_job0"] = {"overlaps_per_s": round(n0 / dt0, 1), "ms_per_step": round(1e3 * dt0 / 3, 2), "records_per_step": n0 // 3,
-                                     "note": "-j 0 -u 1, what necat.pl runs in the correction pipeline (necat.pl:31-32): index build + candidate search, "
-                                             "28-byte records; same volume, measured after the timed region"}
-    except Exception as e:
-        extras["candidates_job0"] = {"error": str(e)}
-    transport = comm.transport() if comm is not None else None
+    if args.dump_records and "recs" in last:
+        dt = capi.M4_DTYPE if args.job == 1 else capi.CANDIDATE_DTYPE
+        np.save("%s_%d.npy" % (args.dump_records, rank), np.concatenate(last["recs"]) if last["recs"] else np.zeros(0, dtype=dt))
+    K = max(1, args.steps)
+    per_rank = gather_rank_stats(dist, {
+        "rank": rank, "units": [[int(u["ref_vol"]), int(u["query_vol"]), int(u["slot_lo"]), int(u["slot_hi"])] for u in mine],
+        "records_per_step": n_over // K, "busy_ms_per_step": round(1e3 * busy / K, 2),
+        "index_ms": round(agg["index_ms"] / K, 3), "index_local_ms": round(agg["ix_local_ms"] / K, 3),
+        "index_allgather_ms": round(agg["ix_xchg_ms"] / K, 3), "index_allgather_bytes": int(agg["ix_xchg_bytes"] // K),
+        "transport": {str(v): c.transport() for v, c in comms.items()}})
+    for c in comms.values():
+        c.close()
     if rank != 0:
-        if comm is not None:
-            comm.close()
         if dist is not None:
             dist.destroy_process_group()
         return
-    K = max(1, args.steps)
+    out = {
+        "metric": "overlaps/sec (all-vs-all, index build + seeding + banded Myers extension -> M4)",
+        "value": round(tot_over / elapsed, 1), "unit": "overlaps/s", "gbp_aligned_per_s": round(tot_gbp / elapsed, 4),
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / K, 2),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": "%.1f Mb genome, %.0fx synthetic ONT reads (12%% errors), %d reads / %d bp in %d volumes of %s bp (the last one a remainder), all %d "
+                               "(reference volume, query volume) pairs, OVLP_FAST_OPTIONS (-k %d -z %d -q 500 -b 2000 -s 3 -n 500 -a 1000 -e 0.5) with -j %d"
+                               % (args.genome / 1e6, args.coverage, rs.nreads, rs.nbases, V, "/".join(str(b) for b in vol_bases), V * (V + 1) // 2,
+                                  args.kmer, args.scan_window, args.job),
+                   "overlaps_per_step": int(tot_over) // K,
+                   "parallelism": "pairs x%d: cost-line schedule of the volume pairs (necat_pair_schedule, %d slots per pair, query chunks of %d reads), "
+                                  "team-sharded index builds, records stay on their rank" % (world, args.slots, args.chunk_reads)},
+        "phases_ms_per_step": {"index": round(agg["index_ms"] / K, 2), "seed": round(agg["seed_ms"] / K, 2), "extend": round(agg["extend_ms"] / K, 2),
+                               "myers_kernel": round(agg["myers_ms"] / K, 2), "traceback_kernel": round(agg["traceback_ms"] / K, 2), "rounds": agg["rounds"] // K,
+                               "note": "rank 0's share"},
+        "device": ctx.device_name(),
+        "roofline": roofline_report(agg),
+        "multi_gpu": {"ranks": per_rank, "teams": {str(v): [int(team[v, 0]), int(team[v, 1])] for v in range(V)},
+                      "note": "units = [reference volume, query volume, slot_lo, slot_hi] of %d slots" % args.slots},
+    }
+    sys.stdout.flush()
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def roofline_report(agg):
+    """roofline object of the bench line from the summed per-step timings / work counters of one rank"""
     # ---- roofline of the dominant kernel: k_myers_coop<8,16,512,8,false>, the DP of the list-A blocks (<= 512 x 512).
     # Integer DP: the bound is VALU issue, not HBM (SURVEY.md 8d).  Work unit = one 64-row Myers word update, priced at
     # OPS_PER_WORD_UPDATE 32-bit lane-ops (DESIGN.md 5.3) against the chip's full-rate 32-bit VALU peak (256 CU x 4 SIMD-32
@@ -398,6 +477,127 @@ def main():
                         "kernel counts) x %d lane-ops / launch time / (256 CU x 4 SIMD-32 x 2.4 GHz); computed_frac = the same for the word updates actually "
                         "executed (both passes compute every word). Issue-rate evidence: profiles/r02_valu_microbench2.txt, profiles/r02_sq_counters*.json. "
                         "hbm.* = the contract's HBM view (small by construction)." % OPS_PER_WORD_UPDATE}
+    return roofline
+
+
+def main():
+    args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
+    # stdout carries exactly ONE line, the JSON result: whatever libraries print there (RCCL announces its path on
+    # stdout when the first communicator is created) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    rank, world, local, dist = dist_setup(args)
+    from necat_amd import build, capi, synth
+    if rank == 0:
+        build.build_hip()          # no-op when the in-tree library is current; one rank only, the others wait
+    if dist is not None:
+        dist.barrier()
+    if args.parallelism == "pairs":
+        return main_pairs(args, rank, world, local, dist, json_fd)
+    opt_kw = dict(FAST, kmer_size=args.kmer, scan_window=args.scan_window)
+    opt = capi.default_options(**dict(opt_kw, job=args.job, num_threads=1))
+    single = world > 1 and args.parallelism == "single-volume"
+    # ---- synthetic volume, made resident in HBM before the clock starts (single-volume mode: the SAME volume on every rank)
+    rs = synth.simulate_reads(args.genome, args.coverage, seed=args.seed + (0 if single or world == 1 else 1000 * rank))
+    pac = synth.pack_2bit(rs.codes)
+    ctx = capi.Context(local)
+    vol = ctx.upload_volume(pac, rs.nbases, rs.offsets, rs.sizes)
+    comm = None
+    if single:
+        import torch
+        from necat_amd import dist as ndist
+        one_dev = os.environ.get("NECAT_BENCH_ONE_DEVICE") == "1"
+        comm = ctx.comm(rank, world, ndist.torch_allgather(dist, device=None if one_dev else torch.device("cuda", local)), args.transport)
+        if not one_dev and args.transport in ("auto", "rccl") and comm.transport() != "rccl":
+            raise SystemExit("bench.py: ranks on distinct devices but the data path is %s, not rccl" % comm.transport())
+
+    def step(job=args.job):
+        o = opt if job == args.job else capi.default_options(**dict(opt_kw, job=job, num_threads=1))
+        if comm is not None:
+            ix = ctx.build_index_sharded(comm, vol, o.kmer_size, o.kmer_cnt_cutoff)
+            t_index = ctx.timings().index_ms
+            sh_ix = ctx.shard_timings()
+            if job == 1:
+                m4, _, _ = ctx.map_pair_sharded(comm, ix, vol, vol, 0, 0, o, True, 1, args.chunk_reads, 0)
+                cands = None
+            else:
+                (cands, _), m4 = ctx.find_candidates_sharded(comm, ix, vol, vol, 0, 0, o, True, args.chunk_reads, 0), None
+            sh = ctx.shard_timings()
+            sh.index_local_ms, sh.index_exchange_ms, sh.index_exchange_bytes = sh_ix.index_local_ms, sh_ix.index_exchange_ms, sh_ix.index_exchange_bytes
+        else:
+            sh = None
+            ix = ctx.build_index(vol, o.kmer_size, o.kmer_cnt_cutoff)
+            t_index = ctx.timings().index_ms
+            if job == 1:      # pm_search_one_volume of a mapping job: seeding + extension in one call, candidates stay on the device
+                m4, _ = ctx.map_pair(ix, vol, vol, 0, 0, o, True, 1)
+                cands = None
+            else:
+                cands, m4 = ctx.find_candidates(ix, vol, vol, 0, 0, o, True), None
+        tm = ctx.timings()
+        ix.free()
+        return cands, m4, t_index, tm, sh
+
+    # setup (untimed): initialise the torch/HIP runtimes and let the library size its HBM pools once
+    barrier_sync(dist, local)
+    step()
+    for _ in range(args.warmup):
+        step()
+    barrier_sync(dist, local)
+    t0 = time.perf_counter()
+    agg = new_agg()
+    n_over = 0
+    gbp = 0.0
+    for _ in range(args.steps):
+        cands, m4, t_index, tm, sh = step()
+        if comm is None or rank == 0:        # single-volume mode: rank 0 holds the gathered records of all ranks
+            n_over += (m4.shape[0] if m4 is not None else cands.shape[0])
+            if m4 is not None:
+                gbp += float((m4["qend"] - m4["qoff"]).sum()) / 1e9
+        agg_add(agg, tm, t_index)
+        if sh is not None:
+            agg["ix_local_ms"] += sh.index_local_ms; agg["ix_xchg_ms"] += sh.index_exchange_ms; agg["ix_xchg_bytes"] += sh.index_exchange_bytes
+            agg["gather_ms"] += sh.gather_ms; agg["gather_bytes"] += sh.gather_bytes; agg["reads_local"] = int(sh.reads_local)
+    barrier_sync(dist, local)
+    elapsed = time.perf_counter() - t0
+    from necat_amd import shard
+    elapsed, tot_over, tot_gbp = shard.reduce_step_stats(dist, elapsed, float(n_over), gbp,
+                                                         device="cuda" if (dist is not None and dist.get_backend() == "nccl") else None)
+    # extras measured after the timed region, on every rank when collective
+    extras = {}
+    try:
+        t1 = time.perf_counter()
+        n0 = 0
+        for _ in range(3):
+            c0, _, _, _, _ = step(job=0)
+            if comm is None or rank == 0:
+                n0 += c0.shape[0]
+        barrier_sync(dist, local)
+        dt0 = time.perf_counter() - t1
+        extras["candidates_job0"] = {"overlaps_per_s": round(n0 / dt0, 1), "ms_per_step": round(1e3 * dt0 / 3, 2), "records_per_step": n0 // 3,
+                                     "note": "-j 0 -u 1, what necat.pl runs in the correction pipeline (necat.pl:31-32): index build + candidate search, "
+                                             "28-byte records; same volume, measured after the timed region"}
+    except Exception as e:
+        extras["candidates_job0"] = {"error": str(e)}
+    transport = comm.transport() if comm is not None else None
+    K0 = max(1, args.steps)
+    per_rank = gather_rank_stats(dist, {
+        "rank": rank, "transport": transport, "query_reads": agg["reads_local"], "index_local_ms": round(agg["ix_local_ms"] / K0, 3),
+        "index_allgather_ms": round(agg["ix_xchg_ms"] / K0, 3), "index_allgather_bytes": int(agg["ix_xchg_bytes"] // K0),
+        "record_gather_ms": round(agg["gather_ms"] / K0, 3), "record_gather_bytes": int(agg["gather_bytes"] // K0),
+        "seed_ms": round(agg["seed_ms"] / K0, 2), "extend_ms": round(agg["extend_ms"] / K0, 2)}) if single else None
+    if rank != 0:
+        if comm is not None:
+            comm.close()
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    K = max(1, args.steps)
+    roofline = roofline_report(agg)
     out = {
         "metric": "overlaps/sec (all-vs-all, index build + seeding + banded Myers extension -> M4)",
         "value": round(tot_over / elapsed, 1), "unit": "overlaps/s",
@@ -423,7 +623,7 @@ def main():
                             "rank0_index_allgather_ms": round(agg["ix_xchg_ms"] / K, 3),
                             "rank0_index_allgather_bytes": int(agg["ix_xchg_bytes"] // K),
                             "rank0_record_gather_ms": round(agg["gather_ms"] / K, 3), "rank0_record_gather_bytes": int(agg["gather_bytes"] // K),
-                            "rank0_query_reads": agg["reads_local"], "chunk_reads": args.chunk_reads,
+                            "rank0_query_reads": agg["reads_local"], "chunk_reads": args.chunk_reads, "ranks": per_rank,
                             "note": "phases_ms_per_step are rank 0's; index = local slice build + all-gather of the kmer_stats / offset_list slices"}
     if world == 1 and not args.no_widened:
         # SURVEY 8f.1 rows built on the same kernels, measured right AFTER the timed region (before the CPU baseline, while the GPU clocks are still up) on the same resident volume; reported

@@ -378,6 +378,34 @@ int  necat_map_pair_sharded(necat_ctx* ctx, necat_comm* comm, const necat_index*
                             const necat_map_options* opt, int tail_match_len, int chunk_reads, int root,
                             necat_m4** out, uint64_t* n_out, uint64_t* n_local, uint64_t* n_candidates);
 
+/* ---- several volumes on several GPUs (both granularities combined; BASELINE configs[3] / [4]) ---------------------
+ * <- the job list of pm_main (pm_worker.c:372-390: reference volume v against query volumes v .. V - 1) and its distribution
+ * over grid nodes (necat.pl:190-202), re-cut for the GPUs of one node.  The V (V + 1) / 2 (reference, query) pairs are laid end to
+ * end on one cost line (cost ~ bases(query) x bases(reference), halved for the self pair) and rank g takes the g-th of nranks equal
+ * stretches; a pair a boundary cuts through is split by query reads - chunks of `chunk_reads` reads, chunk c in slot c % slots, a
+ * rank takes a contiguous slot range (necat_amd/csrc/pair_sched.h).  A rank's units are consecutive pairs, so it touches few
+ * reference volumes, in ascending order, and the ranks of one reference volume are consecutive ranks: team_lo[v] .. team_hi[v]
+ * (inclusive).  A team of several ranks builds that volume's index with necat_index_build_sharded over a communicator of the team.
+ * Host-only arithmetic (no device is touched).  Outputs (necat_free each): units = all ranks' units, rank by rank;
+ * rank_off[nranks + 1]; team[2 * num_volumes] = (team_lo, team_hi) per reference volume. */
+typedef struct { int32_t ref_vol, query_vol, slot_lo, slot_hi; } necat_pair_unit;
+/* query reads per chunk for a query volume of `query_reads` reads: 64, fewer for small volumes so that every slot gets several chunks */
+int  necat_pair_chunk_reads(uint64_t query_reads, int slots);
+int  necat_pair_schedule(const uint64_t* vol_bases, int num_volumes, int nranks, int slots,
+                         necat_pair_unit** units, uint64_t** rank_off, int32_t** team);
+
+/* necat_find_candidates / necat_map_pair for ONE share of a pair: only the query chunks c (of chunk_reads reads) with
+ * slot_lo <= c % slots < slot_hi are processed, each read exactly as in a whole-pair call - the union of the shares [0, slots) IS the
+ * whole pair's record set.  No collective; the records come back on the host as from the whole-pair calls. */
+int  necat_find_candidates_part(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, const necat_volume* reads,
+                                int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt,
+                                int chunk_reads, int slot_lo, int slot_hi, int slots,
+                                necat_candidate** out, uint64_t* n_out);
+int  necat_map_pair_part(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, const necat_volume* reads,
+                         int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt, int tail_match_len,
+                         int chunk_reads, int slot_lo, int slot_hi, int slots,
+                         necat_m4** out, uint64_t* n_out, uint64_t* n_candidates);
+
 /* Test / profiling hook for the dominant kernel: n independent Edlib_align calls
  * (edlib_ex.c:733) on byte-coded (0..3) sequences.  seqs = concatenated fragments, q_off/t_off =
  * start of each fragment in `seqs`.  Outputs per block: edit distance (-1 = fail), qend, tend, and

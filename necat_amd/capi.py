@@ -84,6 +84,7 @@ EXPORTED_SYMBOLS = [
     "necat_edlib_align_batch", "necat_get_timings", "necat_free", "necat_pcan_partition",
     "necat_comm_create", "necat_comm_destroy", "necat_comm_transport", "necat_get_shard_timings", "necat_comm_selftest_rccl",
     "necat_index_build_sharded", "necat_find_candidates_sharded", "necat_map_pair_sharded",
+    "necat_pair_schedule", "necat_pair_chunk_reads", "necat_find_candidates_part", "necat_map_pair_part",
 ]
 
 _lib = None
@@ -151,6 +152,12 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                                   C.POINTER(vp), u64p, u64p]
     lib.necat_map_pair_sharded.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(MapOptions), C.c_int, C.c_int, C.c_int,
                                            C.POINTER(vp), u64p, u64p, u64p]
+    lib.necat_pair_chunk_reads.argtypes = [C.c_uint64, C.c_int]
+    lib.necat_pair_schedule.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.necat_find_candidates_part.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(MapOptions), C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.POINTER(vp), u64p]
+    lib.necat_map_pair_part.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(MapOptions), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(vp), u64p, u64p]
     lib.necat_free.argtypes = [vp]
     lib.necat_free.restype = None
     for name in EXPORTED_SYMBOLS:
@@ -313,6 +320,24 @@ class Context:
         n, nc = C.c_uint64(), C.c_uint64()
         self._check(self.lib.necat_map_pair(self.h, ix.h, ref.h, reads.h, read_start_id, ref_start_id, 1 if pairwise else 0,
                                             C.byref(opt), tail_match_len, C.byref(p), C.byref(n), C.byref(nc)), "necat_map_pair")
+        return self._take(p, n.value, M4_DTYPE), int(nc.value)
+
+    def find_candidates_part(self, ix: "Index", ref: "Volume", reads: "Volume", read_start_id: int, ref_start_id: int, opt: MapOptions,
+                             chunk_reads: int, slot_lo: int, slot_hi: int, slots: int, pairwise: bool = True) -> np.ndarray:
+        """necat_find_candidates for the query chunks c with slot_lo <= c % slots < slot_hi (one unit of the pair scheduler)"""
+        p = C.c_void_p()
+        n = C.c_uint64()
+        self._check(self.lib.necat_find_candidates_part(self.h, ix.h, ref.h, reads.h, read_start_id, ref_start_id, 1 if pairwise else 0, C.byref(opt),
+                                                        chunk_reads, slot_lo, slot_hi, slots, C.byref(p), C.byref(n)), "necat_find_candidates_part")
+        return self._take(p, n.value, CANDIDATE_DTYPE)
+
+    def map_pair_part(self, ix: "Index", ref: "Volume", reads: "Volume", read_start_id: int, ref_start_id: int, opt: MapOptions,
+                      chunk_reads: int, slot_lo: int, slot_hi: int, slots: int, pairwise: bool = True, tail_match_len: int = 1):
+        """necat_map_pair for one unit of the pair scheduler: (M4 records, number of candidates)"""
+        p = C.c_void_p()
+        n, nc = C.c_uint64(), C.c_uint64()
+        self._check(self.lib.necat_map_pair_part(self.h, ix.h, ref.h, reads.h, read_start_id, ref_start_id, 1 if pairwise else 0, C.byref(opt), tail_match_len,
+                                                 chunk_reads, slot_lo, slot_hi, slots, C.byref(p), C.byref(n), C.byref(nc)), "necat_map_pair_part")
         return self._take(p, n.value, M4_DTYPE), int(nc.value)
 
     def map_reference(self, ix: "Index", ref: "Volume", reads: "Volume", read_start_id: int, ref_start_id: int, opt: MapOptions):
@@ -631,6 +656,32 @@ def candidate_text_lines(c: np.ndarray) -> List[bytes]:
     return [b"%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%d\n" %
             (r["qid"], r["sid"], r["score"], r["qdir"], r["qbeg"], r["qend"], r["qoff"], r["qsize"], r["sdir"],
              r["sbeg"], r["send"], r["soff"], r["ssize"]) for r in c]
+
+
+PAIR_UNIT_DTYPE = np.dtype([("ref_vol", "<i4"), ("query_vol", "<i4"), ("slot_lo", "<i4"), ("slot_hi", "<i4")])
+
+
+def pair_chunk_reads(query_reads: int, slots: int = 64) -> int:
+    return int(load_library().necat_pair_chunk_reads(int(query_reads), slots))
+
+
+def pair_schedule(vol_bases, nranks: int, slots: int = 64):
+    """necat_pair_schedule (host arithmetic only, no device): (units[PAIR_UNIT_DTYPE], rank_off[nranks + 1], team[V, 2]) - rank g
+    owns units[rank_off[g]:rank_off[g + 1]]; ranks team[v, 0] .. team[v, 1] (inclusive) work on reference volume v."""
+    lib = load_library()
+    vb = np.ascontiguousarray(vol_bases, dtype=np.uint64)
+    V = int(vb.shape[0])
+    pu, po, pt = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    rc = lib.necat_pair_schedule(vb.ctypes.data, V, nranks, slots, C.byref(pu), C.byref(po), C.byref(pt))
+    if rc:
+        raise NecatError("necat_pair_schedule failed (%d)" % rc)
+    off = np.frombuffer((C.c_char * (8 * (nranks + 1))).from_address(po.value), dtype=np.uint64).copy()
+    n = int(off[nranks])
+    units = np.frombuffer((C.c_char * (16 * max(n, 1))).from_address(pu.value), dtype=PAIR_UNIT_DTYPE)[:n].copy()
+    team = np.frombuffer((C.c_char * (8 * V)).from_address(pt.value), dtype=np.int32).reshape(V, 2).copy()
+    for q in (pu, po, pt):
+        lib.necat_free(q)
+    return units, off.astype(np.int64), team
 
 
 def pm_main(ctx: Context, opt: MapOptions, vid: int, wrk_dir: str):

@@ -75,8 +75,43 @@ inline int load_rccl(necat_ctx* ctx, necat_comm* c)
     return NECAT_OK;
 }
 
+// Every rank reports the status of the step it has just finished; all ranks leave with the same verdict.  A rank-local
+// failure (an allocation, a kernel error flag, a capacity overflow) must not let this rank return while its peers walk into
+// the next collective and wait for it forever: the sharded entry points call this before every exchange.
+// Returns `rc` itself when this rank failed, NECAT_ERR_COMM when only another rank did, NECAT_OK when nobody did.
+inline int agree(necat_ctx* ctx, necat_comm* c, int rc)
+{
+    if (c->nranks == 1) return rc;
+    std::vector<int> all(c->nranks, 0);
+    const int rg = c->gather(c->user, &rc, all.data(), sizeof(int));
+    if (rc) return rc;
+    if (rg) return set_err(ctx, NECAT_ERR_COMM, "host all-gather callback failed (%d)", rg);
+    for (int r = 0; r < c->nranks; ++r)
+        if (all[r]) return set_err(ctx, NECAT_ERR_COMM, "rank %d failed (status %d): the collective step is abandoned on every rank", r, all[r]);
+    return NECAT_OK;
+}
+
+// first error of a sequence of calls that must ALL be issued (an open ncclGroup has to be closed, opened IPC handles
+// closed, the barrier reached) whatever the earlier ones returned
+struct FirstErr {
+    necat_ctx* ctx; necat_comm* c; int rc = NECAT_OK;
+    void hip(hipError_t e, const char* what) { if (e != hipSuccess && !rc) rc = set_err(ctx, NECAT_ERR_DEVICE, "%s failed: %s", what, hipGetErrorString(e)); }
+    void nccl(ncclResult_t r, const char* what) { if (r != ncclSuccess && !rc) rc = set_err(ctx, NECAT_ERR_COMM, "%s failed: %s", what, c->p_GetErrorString ? c->p_GetErrorString(r) : "?"); }
+    void keep(int r) { if (r && !rc) rc = r; }
+};
+
 // One part of a distributed buffer: `bytes` bytes at `off` from the buffer's base on every rank.
 struct Part { size_t off, bytes; };
+
+// the (peer, direction) steps of an all-gather-v among nranks ranks as rank `rank` issues them: in step d it sends its own
+// part to rank + d and receives part `from` from rank - d (staggered, so no peer is everybody's first target)
+struct Xfer { int to, from; };
+inline std::vector<Xfer> allgather_steps(int rank, int nranks)
+{
+    std::vector<Xfer> v;
+    for (int d = 1; d < nranks; ++d) v.push_back(Xfer{(rank + d) % nranks, (rank - d + nranks) % nranks});
+    return v;
+}
 
 // In-place all-gather-v: every rank holds its own part (parts[rank]) of `base` already in place and receives all others.
 // The data of this rank must be complete on `s` (the exchange is ordered behind the stream's earlier work).
@@ -85,43 +120,46 @@ inline int allgatherv_inplace(necat_ctx* ctx, necat_comm* c, void* base, const s
     const double t0 = now_ms();
     unsigned long long got = 0;
     char* b = (char*)base;
+    FirstErr fe{ctx, c};
     if (c->nranks > 1 && c->transport == 0) {
-        NECAT_NCCL(ctx, c, c->p_GroupStart());
-        for (int d = 1; d < c->nranks; ++d) {
-            // staggered peer order: in step d every rank sends to rank + d and receives from rank - d, so no peer is everybody's first target
-            const int to = (c->rank + d) % c->nranks, from = (c->rank - d + c->nranks) % c->nranks;
-            if (parts[c->rank].bytes) NECAT_NCCL(ctx, c, c->p_Send(b + parts[c->rank].off, parts[c->rank].bytes, ncclChar, to, c->nccl, s));
-            if (parts[from].bytes) { NECAT_NCCL(ctx, c, c->p_Recv(b + parts[from].off, parts[from].bytes, ncclChar, from, c->nccl, s)); got += parts[from].bytes; }
+        fe.nccl(c->p_GroupStart(), "ncclGroupStart");
+        if (!fe.rc) for (const Xfer& x : allgather_steps(c->rank, c->nranks)) {
+            if (parts[c->rank].bytes) fe.nccl(c->p_Send(b + parts[c->rank].off, parts[c->rank].bytes, ncclChar, x.to, c->nccl, s), "ncclSend");
+            if (parts[x.from].bytes) { fe.nccl(c->p_Recv(b + parts[x.from].off, parts[x.from].bytes, ncclChar, x.from, c->nccl, s), "ncclRecv"); got += parts[x.from].bytes; }
         }
-        NECAT_NCCL(ctx, c, c->p_GroupEnd());
-        NECAT_HIP(ctx, hipStreamSynchronize(s));
+        fe.nccl(c->p_GroupEnd(), "ncclGroupEnd");            // the group is closed whatever was queued
+        fe.hip(hipStreamSynchronize(s), "hipStreamSynchronize");
     } else if (c->nranks > 1) {
         // IPC pull: publish the handle of the allocation that holds `base`, open the peers', copy their parts
         void* abase = nullptr; size_t asize = 0;
-        NECAT_HIP(ctx, hipMemGetAddressRange((hipDeviceptr_t*)&abase, &asize, (hipDeviceptr_t)base));
-        struct Msg { hipIpcMemHandle_t h; unsigned long long delta; } mine, *all;
+        struct Msg { hipIpcMemHandle_t h; unsigned long long delta; int ok; } mine, *all;
         std::vector<Msg> msgs(c->nranks);
         all = msgs.data();
-        NECAT_HIP(ctx, hipIpcGetMemHandle(&mine.h, abase));
+        memset(&mine, 0, sizeof mine);
+        fe.hip(hipMemGetAddressRange((hipDeviceptr_t*)&abase, &asize, (hipDeviceptr_t)base), "hipMemGetAddressRange");
+        if (!fe.rc) fe.hip(hipIpcGetMemHandle(&mine.h, abase), "hipIpcGetMemHandle");
         mine.delta = (unsigned long long)((char*)base - (char*)abase);
-        NECAT_HIP(ctx, hipStreamSynchronize(s));                                   // my part is complete before anybody reads it
-        int rc = host_allgather(ctx, c, &mine, all, sizeof(Msg));                  // (doubles as the "data ready" barrier)
-        if (rc) return rc;
+        fe.hip(hipStreamSynchronize(s), "hipStreamSynchronize");                   // my part is complete before anybody reads it
+        mine.ok = fe.rc == NECAT_OK;
+        fe.keep(host_allgather(ctx, c, &mine, all, sizeof(Msg)));                  // (doubles as the "data ready" barrier)
+        bool all_ok = !fe.rc;
+        for (int r = 0; r < c->nranks && all_ok; ++r) if (!all[r].ok) { all_ok = false; fe.keep(set_err(ctx, NECAT_ERR_COMM, "rank %d could not publish its buffer", r)); }
         std::vector<void*> opened(c->nranks, nullptr);
-        for (int d = 1; d < c->nranks; ++d) {
-            const int from = (c->rank - d + c->nranks) % c->nranks;
-            if (!parts[from].bytes) continue;
-            NECAT_HIP(ctx, hipIpcOpenMemHandle(&opened[from], all[from].h, hipIpcMemLazyEnablePeerAccess));
+        if (all_ok) for (const Xfer& x : allgather_steps(c->rank, c->nranks)) {
+            const int from = x.from;
+            if (!parts[from].bytes || fe.rc) continue;
+            fe.hip(hipIpcOpenMemHandle(&opened[from], all[from].h, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle");
+            if (fe.rc) { opened[from] = nullptr; continue; }
             const char* src = (const char*)opened[from] + all[from].delta + parts[from].off;
-            NECAT_HIP(ctx, hipMemcpyAsync(b + parts[from].off, src, parts[from].bytes, hipMemcpyDeviceToDevice, s));
+            fe.hip(hipMemcpyAsync(b + parts[from].off, src, parts[from].bytes, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync (peer)");
             got += parts[from].bytes;
         }
-        NECAT_HIP(ctx, hipStreamSynchronize(s));
-        for (void* p : opened) if (p) NECAT_HIP(ctx, hipIpcCloseMemHandle(p));
-        if ((rc = barrier(ctx, c))) return rc;                                      // nobody reuses its buffer while a peer still reads it
+        fe.hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+        for (void* p : opened) if (p) fe.hip(hipIpcCloseMemHandle(p), "hipIpcCloseMemHandle");
+        fe.keep(barrier(ctx, c));                                                   // nobody reuses its buffer while a peer still reads it
     }
     c->last_ms = now_ms() - t0; c->last_bytes = got;
-    return NECAT_OK;
+    return fe.rc;
 }
 
 // Gather-v to `root`: every rank contributes `bytes` bytes at `send` (device memory); the root receives rank r's
@@ -133,44 +171,50 @@ inline int gatherv(necat_ctx* ctx, necat_comm* c, const void* send, const std::v
     std::vector<size_t> offs(c->nranks + 1, 0);
     for (int r = 0; r < c->nranks; ++r) offs[r + 1] = offs[r] + counts[r];
     const size_t mine = counts[c->rank];
-    if (c->rank == root && mine) NECAT_HIP(ctx, hipMemcpyAsync((char*)recv + offs[root], send, mine, hipMemcpyDeviceToDevice, s));
+    FirstErr fe{ctx, c};
+    if (c->rank == root && mine) fe.hip(hipMemcpyAsync((char*)recv + offs[root], send, mine, hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
     if (c->nranks > 1 && c->transport == 0) {
-        NECAT_NCCL(ctx, c, c->p_GroupStart());
-        if (c->rank == root) {
-            for (int r = 0; r < c->nranks; ++r)
-                if (r != root && counts[r]) { NECAT_NCCL(ctx, c, c->p_Recv((char*)recv + offs[r], counts[r], ncclChar, r, c->nccl, s)); got += counts[r]; }
-        } else if (mine) NECAT_NCCL(ctx, c, c->p_Send(send, mine, ncclChar, root, c->nccl, s));
-        NECAT_NCCL(ctx, c, c->p_GroupEnd());
-        NECAT_HIP(ctx, hipStreamSynchronize(s));
+        fe.nccl(c->p_GroupStart(), "ncclGroupStart");
+        if (!fe.rc) {
+            if (c->rank == root) {
+                for (int r = 0; r < c->nranks; ++r)
+                    if (r != root && counts[r]) { fe.nccl(c->p_Recv((char*)recv + offs[r], counts[r], ncclChar, r, c->nccl, s), "ncclRecv"); got += counts[r]; }
+            } else if (mine) fe.nccl(c->p_Send(send, mine, ncclChar, root, c->nccl, s), "ncclSend");
+        }
+        fe.nccl(c->p_GroupEnd(), "ncclGroupEnd");
+        fe.hip(hipStreamSynchronize(s), "hipStreamSynchronize");
     } else if (c->nranks > 1) {
-        struct Msg { hipIpcMemHandle_t h; unsigned long long delta; } mine_m, *all;
+        struct Msg { hipIpcMemHandle_t h; unsigned long long delta; int ok; } mine_m, *all;
         std::vector<Msg> msgs(c->nranks);
         all = msgs.data();
         memset(&mine_m, 0, sizeof mine_m);
         if (mine) {
             void* abase = nullptr; size_t asize = 0;
-            NECAT_HIP(ctx, hipMemGetAddressRange((hipDeviceptr_t*)&abase, &asize, (hipDeviceptr_t)send));
-            NECAT_HIP(ctx, hipIpcGetMemHandle(&mine_m.h, abase));
+            fe.hip(hipMemGetAddressRange((hipDeviceptr_t*)&abase, &asize, (hipDeviceptr_t)send), "hipMemGetAddressRange");
+            if (!fe.rc) fe.hip(hipIpcGetMemHandle(&mine_m.h, abase), "hipIpcGetMemHandle");
             mine_m.delta = (unsigned long long)((const char*)send - (const char*)abase);
         }
-        NECAT_HIP(ctx, hipStreamSynchronize(s));
-        int rc = host_allgather(ctx, c, &mine_m, all, sizeof(Msg));
-        if (rc) return rc;
-        if (c->rank == root) {
+        fe.hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+        mine_m.ok = fe.rc == NECAT_OK;
+        fe.keep(host_allgather(ctx, c, &mine_m, all, sizeof(Msg)));
+        bool all_ok = !fe.rc;
+        for (int r = 0; r < c->nranks && all_ok; ++r) if (!all[r].ok) { all_ok = false; fe.keep(set_err(ctx, NECAT_ERR_COMM, "rank %d could not publish its records", r)); }
+        if (c->rank == root && all_ok) {
             std::vector<void*> opened(c->nranks, nullptr);
             for (int r = 0; r < c->nranks; ++r) {
-                if (r == root || !counts[r]) continue;
-                NECAT_HIP(ctx, hipIpcOpenMemHandle(&opened[r], all[r].h, hipIpcMemLazyEnablePeerAccess));
-                NECAT_HIP(ctx, hipMemcpyAsync((char*)recv + offs[r], (const char*)opened[r] + all[r].delta, counts[r], hipMemcpyDeviceToDevice, s));
+                if (r == root || !counts[r] || fe.rc) continue;
+                fe.hip(hipIpcOpenMemHandle(&opened[r], all[r].h, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle");
+                if (fe.rc) { opened[r] = nullptr; continue; }
+                fe.hip(hipMemcpyAsync((char*)recv + offs[r], (const char*)opened[r] + all[r].delta, counts[r], hipMemcpyDeviceToDevice, s), "hipMemcpyAsync (peer)");
                 got += counts[r];
             }
-            NECAT_HIP(ctx, hipStreamSynchronize(s));
-            for (void* p : opened) if (p) NECAT_HIP(ctx, hipIpcCloseMemHandle(p));
+            fe.hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+            for (void* p : opened) if (p) fe.hip(hipIpcCloseMemHandle(p), "hipIpcCloseMemHandle");
         }
-        if ((rc = barrier(ctx, c))) return rc;
-    } else NECAT_HIP(ctx, hipStreamSynchronize(s));
+        fe.keep(barrier(ctx, c));
+    } else fe.hip(hipStreamSynchronize(s), "hipStreamSynchronize");
     c->last_ms = now_ms() - t0; c->last_bytes = got;
-    return NECAT_OK;
+    return fe.rc;
 }
 
 }  // namespace comm

@@ -150,6 +150,19 @@ inline bool load_volume(const char* path, HostVolume* v, std::string* err)
     return true;
 }
 
+// number of bases of a volume file, from its header alone (packed_db.c:291-296: magic, nseq, nbases)
+inline bool volume_bases(const char* path, uint64_t* nbases, std::string* err)
+{
+    FILE* in = fopen(path, "rb");
+    if (!in) { *err = std::string("cannot open volume ") + path; return false; }
+    unsigned char h[31 + 16];
+    const bool ok = fread(h, 1, sizeof h, in) == sizeof h && memcmp(h, "ontcns_pac_header_hofuwhogfuewo", 31) == 0;
+    fclose(in);
+    if (!ok) { *err = std::string("Invalid pac format database: '") + path + "'"; return false; }
+    memcpy(nbases, h + 31 + 8, 8);
+    return true;
+}
+
 inline void pack_candidate(const necat_candidate* c, uint32_t item[7])   // gapped_candidate.c:13-30
 {
     memset(item, 0, 28);

@@ -19,6 +19,7 @@
 #include "cns_rescue.h"
 #include "rm_host.h"
 #include "comm.h"
+#include "pair_sched.h"
 
 using namespace necat;
 
@@ -390,7 +391,19 @@ int index_build_body(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
     const bool sharded = G > 1 && lds_slices && NB >= (u32)G;
     const u32 b_lo = sharded ? (u32)((u64)rk * NB / G) : 0u, b_hi = sharded ? (u32)((u64)(rk + 1) * NB / G) : NB;
     ctx->shard_tm.index_local_ms = 0; ctx->shard_tm.index_exchange_ms = 0; ctx->shard_tm.index_exchange_bytes = 0;
+    // A sharded build is a sequence of collective steps.  Whatever fails on ONE rank between two of them (an allocation, a launch)
+    // is reported to all ranks at the next step (comm::agree) instead of leaving the peers waiting in an exchange this rank never
+    // joins: the rank-local work runs in lambdas (`local_phase`, `emit_phase`) whose status is agreed on before the data moves.
     u32* cnt32 = nullptr; u64* partial = nullptr;
+    u32* d_bcnt = nullptr; u64* d_bstart = nullptr; u64* d_bcur = nullptr; u64* d_part = nullptr;
+    u32 bchunks = 1;
+    u64 *d_part2 = nullptr, *d_sub = nullptr, *d_bbase = nullptr, *d_cbase = nullptr;
+    u32 *d_kept = nullptr, *d_pres = nullptr, *d_bpres = nullptr;
+    unsigned nsl = 0; u32 s0 = 0;
+    unsigned long long mine[2] = {0, 0};                        // offset-list entries, non-zero table entries of this rank
+    const uint64_t nchunks = (ref->nbases + kPosPerThread - 1) / kPosPerThread;
+    const unsigned pass_grid = grid_for(nchunks, 256, 1u << 16);
+    auto local_phase = [&]() -> int {
     if (!lds_slices) {
         if ((rc = buf_ensure(ctx, ctx->scratch[SC_CNT32], T * 4)) || (rc = buf_ensure(ctx, ctx->scratch[SC_PARTIAL], (ntiles + 1) * 8))) return rc;
         cnt32 = (u32*)ctx->scratch[SC_CNT32].p;
@@ -402,10 +415,6 @@ int index_build_body(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
     }
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
     if (!lds_slices) NECAT_HIP(ctx, hipMemsetAsync(cnt32, 0, T * 4, s));
-    const uint64_t nchunks = (ref->nbases + kPosPerThread - 1) / kPosPerThread;
-    const unsigned pass_grid = grid_for(nchunks, 256, 1u << 16);
-    u32* d_bcnt = nullptr; u64* d_bstart = nullptr; u64* d_bcur = nullptr; u64* d_part = nullptr;
-    u32 bchunks = 1;
     if (partitioned) {
         if ((rc = buf_ensure(ctx, ctx->scratch[SC_SMALL], (size_t)NB * 4 + (size_t)(NB + 1) * 8 * 2 + 64)) ||
             (rc = buf_ensure(ctx, ctx->scratch[SC_PART], (ref->nbases + 1) * 8))) return rc;
@@ -438,49 +447,64 @@ int index_build_body(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
             NECAT_CHECK_LAUNCH(ctx, "k_split_bases");
         }
     }
-    uint64_t n_off = 0;
     if (lds_slices) {
         // ---- second split + one workgroup per 4096-entry slice of the table (index_kernels.h)
         const u64 nsub = (u64)NB * kSubs;
         if ((rc = buf_ensure(ctx, ctx->scratch[SC_PART2], (ref->nbases + 1) * 8 + (nsub + 1) * 16 + nsub * 4 + 256)) ||
             (rc = buf_ensure(ctx, ctx->scratch[SC_SPLIT2], nsub * 4 + (size_t)(NB + 1) * 8 + (size_t)NB * 4 + 256))) return rc;
         char* pb = (char*)ctx->scratch[SC_PART2].p;
-        u64* d_part2 = (u64*)pb; pb += (ref->nbases + 1) * 8;
-        u64* d_sub = (u64*)pb; pb += (nsub + 1) * 8;
-        u64* d_bbase = (u64*)pb; pb += (nsub + 1) * 8;          // [NB + 1] used
-        u32* d_kept = (u32*)pb;
+        d_part2 = (u64*)pb; pb += (ref->nbases + 1) * 8;
+        d_sub = (u64*)pb; pb += (nsub + 1) * 8;
+        d_bbase = (u64*)pb; pb += (nsub + 1) * 8;          // [NB + 1] used
+        d_kept = (u32*)pb;
         char* qb = (char*)ctx->scratch[SC_SPLIT2].p;            // the same for the non-zero table entries
-        u64* d_cbase = (u64*)qb; qb += (size_t)(NB + 1) * 8;
-        u32* d_pres = (u32*)qb; qb += nsub * 4;
-        u32* d_bpres = (u32*)qb;
+        d_cbase = (u64*)qb; qb += (size_t)(NB + 1) * 8;
+        d_pres = (u32*)qb; qb += nsub * 4;
+        d_bpres = (u32*)qb;
         hipLaunchKernelGGL(k_subpart, dim3(NB), dim3(256), 0, s, (const u64*)d_part, (const u64*)d_bstart, NB, d_part2, d_sub);
         NECAT_CHECK_LAUNCH(ctx, "k_subpart");
         NECAT_HIP(ctx, hipMemsetAsync(d_bcnt, 0, (size_t)NB * 4, s));                // reused: kept entries per bucket
         NECAT_HIP(ctx, hipMemsetAsync(d_bpres, 0, (size_t)NB * 4, s));
-        const unsigned nsl = (b_hi - b_lo) * kSubs;                 // slices of this rank's hash range
-        const u32 s0 = b_lo * kSubs;
+        nsl = (b_hi - b_lo) * kSubs;                 // slices of this rank's hash range
+        s0 = b_lo * kSubs;
         hipLaunchKernelGGL(k_slice_count, dim3(nsl), dim3(256), 0, s, (const u64*)d_part2, (const u64*)d_sub, (u32)max_occ, d_kept, d_bcnt, d_pres, d_bpres, s0);
         NECAT_CHECK_LAUNCH(ctx, "k_slice_count");
         hipLaunchKernelGGL(k_bucket_base, dim3(1), dim3(1024), 0, s, (const u32*)d_bcnt, NB, d_bbase);
         hipLaunchKernelGGL(k_bucket_base, dim3(1), dim3(1024), 0, s, (const u32*)d_bpres, NB, d_cbase);
         NECAT_CHECK_LAUNCH(ctx, "k_bucket_base");
-        unsigned long long mine[2] = {0, 0};                        // offset-list entries, non-zero table entries of this rank
         NECAT_HIP(ctx, hipMemcpyAsync(&mine[0], d_bbase + NB, 8, hipMemcpyDeviceToHost, s));
         NECAT_HIP(ctx, hipMemcpyAsync(&mine[1], d_cbase + NB, 8, hipMemcpyDeviceToHost, s));
         NECAT_HIP(ctx, hipStreamSynchronize(s));
-        // the sizes of all ranks -> where this rank's entries sit in the gathered offset list / compact table
+    }
+    return NECAT_OK;
+    };   // local_phase
+    rc = local_phase();
+    uint64_t n_off = 0;
+    if (lds_slices) {
+        // the sizes of all ranks -> where this rank's entries sit in the gathered offset list / compact table; the third word is
+        // this rank's status so far (a failed rank still takes part in the exchange: nobody waits for it in vain)
         const uint64_t n_local = mine[0];
         std::vector<unsigned long long> counts(2 * (size_t)G);
         counts[0] = mine[0]; counts[1] = mine[1];
         uint64_t base_add = 0, cbase_add = 0, n_comp = mine[1];
         n_off = mine[0];
         if (sharded) {
-            if ((rc = comm::host_allgather(ctx, comm, mine, counts.data(), 16))) return rc;
+            unsigned long long msg[3] = {mine[0], mine[1], (unsigned long long)(unsigned)rc};
+            std::vector<unsigned long long> all(3 * (size_t)G);
+            const int rg = comm::host_allgather(ctx, comm, msg, all.data(), 24);
+            if (rc) return rc;
+            if (rg) return rg;
+            for (int g = 0; g < G; ++g) if (all[3 * g + 2]) return set_err(ctx, NECAT_ERR_COMM, "rank %d failed in its slice of the index build (status %d)", g, (int)all[3 * g + 2]);
             n_off = 0; n_comp = 0;
-            for (int g = 0; g < G; ++g) { if (g < rk) { base_add += counts[2 * g]; cbase_add += counts[2 * g + 1]; } n_off += counts[2 * g]; n_comp += counts[2 * g + 1]; }
+            for (int g = 0; g < G; ++g) {
+                counts[2 * g] = all[3 * g]; counts[2 * g + 1] = all[3 * g + 1];
+                if (g < rk) { base_add += counts[2 * g]; cbase_add += counts[2 * g + 1]; }
+                n_off += counts[2 * g]; n_comp += counts[2 * g + 1];
+            }
             if (n_off >= (1ULL << 32)) return set_err(ctx, NECAT_ERR_INTERNAL, "ranks disagree on the volume (offset list of %llu entries)", (unsigned long long)n_off);
-        }
+        } else if (rc) return rc;
         ix->n_offsets = n_off; ix->n_compact = n_comp;
+        auto emit_phase = [&]() -> int {
         const size_t words_bytes = (size_t)(T / 64) * sizeof(IdxWord);
         if ((rc = table_alloc(ctx, ix, words_bytes + (n_comp + 1) * 8))) return rc;
         ix->words = ix->table; ix->compact = (uint64_t*)((char*)ix->table + words_bytes);
@@ -493,8 +517,13 @@ int index_build_body(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
                            (const u64*)d_cbase, (const u32*)d_pres, (IdxWord*)ix->words, ix->compact,
                            (u32*)ctx->scratch[SC_TMPLIST].p - base_add, ix->offset_list, s0, base_add, cbase_add);
         NECAT_CHECK_LAUNCH(ctx, "k_slice_emit");
+        if (sharded) NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s));
+        return NECAT_OK;
+        };   // emit_phase
+        rc = emit_phase();
+        if (sharded) rc = comm::agree(ctx, comm, rc);            // every rank has its buffers and its slice under way, or nobody exchanges
+        if (rc) return rc;
         if (sharded) {
-            NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s));
             std::vector<comm::Part> pw(G), pc(G), po(G);
             uint64_t run = 0, crun = 0;
             for (int g = 0; g < G; ++g) {
@@ -505,12 +534,13 @@ int index_build_body(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
             }
             for (auto* parts : {&pw, &pc, &po}) {
                 void* basep = parts == &pw ? ix->words : parts == &pc ? (void*)ix->compact : (void*)ix->offset_list;
-                if ((rc = comm::allgatherv_inplace(ctx, comm, basep, *parts, s))) return rc;
+                if ((rc = comm::agree(ctx, comm, comm::allgatherv_inplace(ctx, comm, basep, *parts, s)))) return rc;
                 ctx->shard_tm.index_exchange_ms += comm->last_ms; ctx->shard_tm.index_exchange_bytes += comm->last_bytes;
             }
             ctx->shard_tm.index_local_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
         }
     } else {
+    if (rc) return rc;
     if (partitioned) {
         const u64 avg = ref->nbases / NB + 1;
         bchunks = (u32)std::max<u64>(1, (avg + kBucketChunk - 1) / kBucketChunk);
@@ -629,10 +659,18 @@ void fill_groups(DevCands* dev, const std::vector<u64>& by_read, u32 nreads)
     if (dev->group_off.size() == 1) dev->group_off.insert(dev->group_off.begin(), 0);
 }
 
-// the query reads one rank of a multi-GPU job processes: chunks of `chunk` reads, chunk c on rank c % nparts
+// the query reads one rank of a multi-GPU job processes: chunks of `chunk` reads, chunk c in slot c % nparts
+// (one rank of a sharded call: slots [rank, rank + 1) of nranks; a share of a scheduled volume pair: slots [lo, hi) of `nparts`
+// - interleaved either way, because a read late in a volume sees more subjects in the self pair, word_finder.c:121-127)
 struct ReadSel {
-    int part = 0, nparts = 1, chunk = 64;
-    bool has(u32 r) const { return nparts <= 1 || (int)((r / (u32)chunk) % (u32)nparts) == part; }
+    int lo = 0, hi = 1, nparts = 1, chunk = 64;
+    bool always = false;            // apply the slot test even when nparts == 1 (an empty share selects nothing)
+    bool has(u32 r) const
+    {
+        if (nparts <= 1 && !always) return true;
+        const int sl = (int)((r / (u32)chunk) % (u32)nparts);
+        return sl >= lo && sl < hi;
+    }
 };
 
 int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, const necat_volume* reads,
@@ -1775,14 +1813,18 @@ int necat_get_shard_timings(const necat_ctx* ctx, necat_shard_timings* t)
 namespace {
 // gather-v of fixed-size records on `root`: every rank's `n_local` records at d_local (device memory; may be null when 0).
 // Root: host_out = all records (its own first), *n_out their number; other ranks: their own records.
-int gather_records(necat_ctx* ctx, necat_comm* comm, int root, const void* d_local, uint64_t n_local, size_t rec, void** host_out, uint64_t* n_out)
+// `status`: what this rank's part of the job returned.  A rank that failed still joins the count exchange, with a sentinel count, so
+// that every rank leaves together with an error instead of waiting for records that never come.
+int gather_records(necat_ctx* ctx, necat_comm* comm, int root, const void* d_local, uint64_t n_local, size_t rec, void** host_out, uint64_t* n_out, int status)
 {
     hipStream_t s = ctx->stream;
     const int G = comm->nranks;
     std::vector<unsigned long long> cnt(G, 0);
-    const unsigned long long mine = n_local;
+    const unsigned long long mine = status ? ~0ULL : n_local;
     int rc = comm::host_allgather(ctx, comm, &mine, cnt.data(), 8);
+    if (status) return status;
     if (rc) return rc;
+    for (int g = 0; g < G; ++g) if (cnt[g] == ~0ULL) return set_err(ctx, NECAT_ERR_COMM, "rank %d failed in its share of the job: no records are gathered", g);
     // the root's own records come first in its output
     std::vector<size_t> bytes(G);
     uint64_t total = 0;
@@ -1790,10 +1832,11 @@ int gather_records(necat_ctx* ctx, necat_comm* comm, int root, const void* d_loc
     const bool is_root = comm->rank == root;
     void* d_all = nullptr;
     if (is_root) {
-        if ((rc = buf_ensure(ctx, ctx->scratch[SC_GATHER], std::max<size_t>(256, (size_t)total * rec)))) return rc;
+        rc = buf_ensure(ctx, ctx->scratch[SC_GATHER], std::max<size_t>(256, (size_t)total * rec));
         d_all = ctx->scratch[SC_GATHER].p;
     }
-    if ((rc = comm::gatherv(ctx, comm, d_local, bytes, root, d_all, s))) return rc;
+    if ((rc = comm::agree(ctx, comm, rc))) return rc;          // the root has its receive buffer, or nobody sends
+    if ((rc = comm::agree(ctx, comm, comm::gatherv(ctx, comm, d_local, bytes, root, d_all, s)))) return rc;
     ctx->shard_tm.gather_ms = comm->last_ms; ctx->shard_tm.gather_bytes = comm->last_bytes;
     const uint64_t n_ret = is_root ? total : n_local;
     void* res = result_alloc(std::max<size_t>(1, (size_t)n_ret * rec));
@@ -1826,13 +1869,12 @@ int necat_find_candidates_sharded(necat_ctx* ctx, necat_comm* comm, const necat_
     if (!ctx || !comm || !ix || !ref || !reads || !opt || !out || !n_out || chunk_reads < 1 || root < 0 || root >= comm->nranks) return NECAT_ERR_ARG;
     *out = nullptr; *n_out = 0;
     if (n_local) *n_local = 0;
-    ReadSel sel; sel.part = comm->rank; sel.nparts = comm->nranks; sel.chunk = chunk_reads;
+    ReadSel sel; sel.lo = comm->rank; sel.hi = comm->rank + 1; sel.nparts = comm->nranks; sel.chunk = chunk_reads;
     DevCands dev;
     int rc = find_impl(ctx, ix, ref, reads, read_start_id, ref_start_id, pairwise, opt, nullptr, nullptr, &dev, &sel);
-    if (rc) return rc;
-    if (n_local) *n_local = dev.n;
+    if (!rc && n_local) *n_local = dev.n;
     void* res = nullptr;
-    if ((rc = gather_records(ctx, comm, root, dev.d, dev.n, sizeof(necat_candidate), &res, n_out))) return rc;
+    if ((rc = gather_records(ctx, comm, root, dev.d, dev.n, sizeof(necat_candidate), &res, n_out, rc))) return rc;
     *out = (necat_candidate*)res;
     return NECAT_OK;
 }
@@ -1847,18 +1889,65 @@ int necat_map_pair_sharded(necat_ctx* ctx, necat_comm* comm, const necat_index* 
     if (n_candidates) *n_candidates = 0;
     necat_map_options o = *opt;
     o.job = 1;
-    ReadSel sel; sel.part = comm->rank; sel.nparts = comm->nranks; sel.chunk = chunk_reads;
+    ReadSel sel; sel.lo = comm->rank; sel.hi = comm->rank + 1; sel.nparts = comm->nranks; sel.chunk = chunk_reads;
+    DevCands dev;
+    int rc = find_impl(ctx, ix, ref, reads, read_start_id, ref_start_id, pairwise, &o, nullptr, nullptr, &dev, &sel);
+    if (!rc && n_candidates) *n_candidates = dev.n;
+    DevOut dout;
+    ctx->tm.extend_ms = 0;
+    if (!rc && dev.n) rc = extend_impl(ctx, ref, reads, read_start_id, ref_start_id, nullptr, dev.n, &o, tail_match_len, nullptr, nullptr, nullptr, &dev, &dout);
+    if (!rc && n_local) *n_local = dout.n;
+    void* res = nullptr;
+    if ((rc = gather_records(ctx, comm, root, dout.d, dout.n, sizeof(necat_m4), &res, n_out, rc))) return rc;
+    *out = (necat_m4*)res;
+    return NECAT_OK;
+}
+
+// ---- a share of one (reference volume, query volume) pair: the building block of the pair scheduler (pair_sched.h).  No collective.
+int necat_find_candidates_part(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, const necat_volume* reads,
+                               int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt,
+                               int chunk_reads, int slot_lo, int slot_hi, int slots, necat_candidate** out, uint64_t* n_out)
+{
+    if (!ctx || !ix || !ref || !reads || !opt || !out || !n_out || chunk_reads < 1 || slots < 1 || slot_lo < 0 || slot_hi < slot_lo || slot_hi > slots) return NECAT_ERR_ARG;
+    *out = nullptr; *n_out = 0;
+    ReadSel sel; sel.lo = slot_lo; sel.hi = slot_hi; sel.nparts = slots; sel.chunk = chunk_reads; sel.always = true;
+    return find_impl(ctx, ix, ref, reads, read_start_id, ref_start_id, pairwise, opt, out, n_out, nullptr, &sel);
+}
+
+int necat_map_pair_part(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, const necat_volume* reads,
+                        int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt, int tail_match_len,
+                        int chunk_reads, int slot_lo, int slot_hi, int slots, necat_m4** out, uint64_t* n_out, uint64_t* n_candidates)
+{
+    if (!ctx || !ix || !ref || !reads || !opt || !out || !n_out || chunk_reads < 1 || slots < 1 || slot_lo < 0 || slot_hi < slot_lo || slot_hi > slots) return NECAT_ERR_ARG;
+    *out = nullptr; *n_out = 0;
+    if (n_candidates) *n_candidates = 0;
+    necat_map_options o = *opt;
+    o.job = 1;
+    ReadSel sel; sel.lo = slot_lo; sel.hi = slot_hi; sel.nparts = slots; sel.chunk = chunk_reads; sel.always = true;
     DevCands dev;
     int rc = find_impl(ctx, ix, ref, reads, read_start_id, ref_start_id, pairwise, &o, nullptr, nullptr, &dev, &sel);
     if (rc) return rc;
     if (n_candidates) *n_candidates = dev.n;
-    DevOut dout;
     ctx->tm.extend_ms = 0;
-    if (dev.n && (rc = extend_impl(ctx, ref, reads, read_start_id, ref_start_id, nullptr, dev.n, &o, tail_match_len, nullptr, nullptr, nullptr, &dev, &dout))) return rc;
-    if (n_local) *n_local = dout.n;
-    void* res = nullptr;
-    if ((rc = gather_records(ctx, comm, root, dout.d, dout.n, sizeof(necat_m4), &res, n_out))) return rc;
-    *out = (necat_m4*)res;
+    if (dev.n == 0) return NECAT_OK;
+    return extend_impl(ctx, ref, reads, read_start_id, ref_start_id, nullptr, dev.n, &o, tail_match_len, out, n_out, nullptr, &dev);
+}
+
+int necat_pair_chunk_reads(uint64_t query_reads, int slots) { return slots < 1 ? NECAT_ERR_ARG : necat_host::pair_chunk_reads(query_reads, slots); }
+
+int necat_pair_schedule(const uint64_t* vol_bases, int num_volumes, int nranks, int slots, necat_pair_unit** units, uint64_t** rank_off, int32_t** team)
+{
+    if (!vol_bases || num_volumes < 1 || nranks < 1 || slots < 1 || !units || !rank_off) return NECAT_ERR_ARG;
+    const necat_host::PairSchedule S = necat_host::pair_schedule(vol_bases, num_volumes, nranks, slots);
+    necat_pair_unit* u = (necat_pair_unit*)malloc(std::max<size_t>(1, S.units.size()) * sizeof(necat_pair_unit));
+    uint64_t* ro = (uint64_t*)malloc(((size_t)nranks + 1) * 8);
+    int32_t* tm = team ? (int32_t*)malloc((size_t)num_volumes * 8) : nullptr;
+    if (!u || !ro || (team && !tm)) { free(u); free(ro); free(tm); return NECAT_ERR_MEMORY; }
+    for (size_t i = 0; i < S.units.size(); ++i) { u[i].ref_vol = S.units[i].ref_vol; u[i].query_vol = S.units[i].query_vol; u[i].slot_lo = S.units[i].slot_lo; u[i].slot_hi = S.units[i].slot_hi; }
+    for (int g = 0; g <= nranks; ++g) ro[g] = S.rank_off[(size_t)g];
+    if (team) for (int v = 0; v < num_volumes; ++v) { tm[2 * v] = S.team_lo[(size_t)v]; tm[2 * v + 1] = S.team_hi[(size_t)v]; }
+    *units = u; *rank_off = ro;
+    if (team) *team = tm;
     return NECAT_OK;
 }
 

@@ -214,8 +214,9 @@ int main(int argc, char** argv)
             if (!out_raw[t].empty()) wok = wok && fwrite(out_raw[t].data(), 1, out_raw[t].size(), raw_out) == out_raw[t].size();
         }
         // the reads of the partition's id range nobody corrected go out whole (consensus_one_partition.c:172-194; the last id
-        // of the range is left out there: `i < max_read_id`)
-        {
+        // of the range is left out there: `i < max_read_id`) - only with -s 0: the reference does this inside `if (reads)`, and with
+        // -s 1 it never loads `reads` (the small-memory path reads sequences per partition), so it writes none of them
+        if (!opt.small_memory) {
             std::vector<uint8_t> done;
             int min_id = cands[tmpl_off[0]].sid, max_id = min_id;
             for (uint64_t t = 0; t < nt; ++t) { const int id = cands[tmpl_off[t]].sid; min_id = std::min(min_id, id); max_id = std::max(max_id, id); }

@@ -5,12 +5,19 @@
 // here ONE resident worker process per GPU (NECAT_GPUS=0,1,2,3; default the single device NECAT_GPU or 0) takes volumes from a
 // shared counter and runs their jobs on one context (pm_job.h): HIP start-up, stream creation and pool allocation are paid once
 // per GPU, not once per volume, and the next volume is read from disk while the current one is mapped.
+// With several GPUs the unit of work is not the volume but the (reference volume, query volume) PAIR (NECAT_PM_SCHEDULE=pairs, the
+// default for more than one GPU; =volumes keeps whole volumes from a shared counter): the pairs of all unfinished volumes are laid on
+// one cost line and every worker takes an equal stretch of it, pairs at a boundary split by query reads (pair_sched.h) - the jobs
+// of a project are very unequal (volume 0 has V query volumes, volume V - 1 one, the last volume is a remainder), and whole volumes
+// would leave most GPUs idle while the first ones work.  Every worker writes its share of job v to pm_result_v.r<g>; the shares
+// are concatenated to pm_result_v (then pm<v>.finished) - the same records the job run whole would have written.
 #include <limits.h>
 #include <unistd.h>
 #include <sys/mman.h>
 #include <sys/wait.h>
 
 #include "pm_job.h"
+#include "pair_sched.h"
 
 using namespace necat_host;
 
@@ -46,7 +53,92 @@ int main(int argc, char** argv)
         if (access(fin, F_OK) != 0) todo.push_back(i);
     }
     bool failed = false;
-    if (!todo.empty()) {
+    const char* sched = getenv("NECAT_PM_SCHEDULE");
+    const bool pairs = !todo.empty() && (sched ? !strcmp(sched, "pairs") : gpus.size() > 1);
+    std::vector<char> buf(1 << 20);
+    // append the file `src` to `out`; a missing file is an error unless `optional`
+    auto append_file = [&](FILE* out, const std::string& src, bool optional) -> bool {
+        FILE* in = fopen(src.c_str(), "rb");
+        if (!in) return optional;
+        size_t k; bool ok = true;
+        while (ok && (k = fread(buf.data(), 1, buf.size(), in)) > 0) ok = fwrite(buf.data(), 1, k, out) == k;
+        if (ferror(in)) ok = false;
+        fclose(in);
+        return ok;
+    };
+    if (pairs) {
+        const int V = vi.num_volumes, G = (int)gpus.size();
+        std::vector<uint64_t> bases((size_t)V, 0);
+        std::vector<uint8_t> skip((size_t)V, 1);
+        for (int v : todo) skip[(size_t)v] = 0;
+        for (int v = 0; v < V; ++v) if (!volume_bases(vi.names[(size_t)v].c_str(), &bases[(size_t)v], &err)) { fprintf(stderr, "[oc2pm] ERROR: %s\n", err.c_str()); return 1; }
+        const PairSchedule S = pair_schedule(bases.data(), V, G, kPmSlots, skip.data());
+        const int pcan_batch = (opt.job == 0 && getenv("NECAT_PM_PARTITIONS")) ? atoi(getenv("NECAT_PM_PARTITIONS")) : 0;
+        const int np = pcan_batch > 0 ? (vi.num_reads + pcan_batch - 1) / pcan_batch : 0;
+        fflush(stdout); fflush(stderr);
+        std::vector<pid_t> pids;
+        for (int g = 0; g < G; ++g) {
+            if (S.rank_off[(size_t)g + 1] == S.rank_off[(size_t)g]) continue;          // nothing for this worker
+            const pid_t pid = fork();
+            if (pid < 0) { fprintf(stderr, "[oc2pm] ERROR: fork failed\n"); failed = true; break; }
+            if (pid == 0) {
+                const PmTrace tr;
+                necat_ctx* ctx = nullptr;
+                if (necat_ctx_create(gpus[(size_t)g], &ctx)) { fprintf(stderr, "[oc2pm] ERROR: GPU %d: no usable gfx950 device (libnecat_hip has no CPU fallback)\n", gpus[(size_t)g]); _exit(1); }
+                int status = 0;
+                for (uint64_t k = S.rank_off[(size_t)g]; k < S.rank_off[(size_t)g + 1] && !status;) {
+                    const int v = S.units[k].ref_vol;
+                    std::vector<PmUnit> mine;
+                    for (; k < S.rank_off[(size_t)g + 1] && S.units[k].ref_vol == v; ++k) mine.push_back(PmUnit{S.units[k].query_vol, S.units[k].slot_lo, S.units[k].slot_hi});
+                    char res[4096];
+                    snprintf(res, sizeof res, "%spm_result_%d.r%d", base.c_str(), v, g);
+                    fprintf(stdout, "Running %zu unit(s) of job 'oc2pmov %s %s %d %spm_result_%d' on GPU %d (worker %d)\n", mine.size(), options_to_string(&opt).c_str(), wrk_dir, v,
+                            base.c_str(), v, gpus[(size_t)g], g);
+                    fflush(stdout);
+                    if ((status = pm_run_volume(ctx, vi, v, opt, res, "oc2pm", tr, nullptr, &mine))) fprintf(stderr, "[oc2pm] ERROR: worker %d failed in the job of volume %d\n", g, v);
+                }
+                necat_ctx_destroy(ctx);
+                fflush(stdout); fflush(stderr);
+                _exit(status ? 1 : 0);
+            }
+            pids.push_back(pid);
+        }
+        for (pid_t pid : pids) {
+            int status = 0;
+            if (waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) failed = true;
+        }
+        // the shares of a job, in worker order, make the job's file (written under a temporary name first, like the job itself does)
+        for (size_t t = 0; t < todo.size() && !failed; ++t) {
+            const int v = todo[t];
+            const std::string res = base + "pm_result_" + std::to_string(v), tmp = res + ".part";
+            FILE* out = fopen(tmp.c_str(), "w");
+            bool ok = out != nullptr;
+            for (int g = S.team_lo[(size_t)v]; ok && g <= S.team_hi[(size_t)v]; ++g) {
+                // (a worker of the team range that got no unit of v - its stretch rounded to nothing - wrote no file)
+                bool has = false;
+                for (uint64_t k = S.rank_off[(size_t)g]; k < S.rank_off[(size_t)g + 1]; ++k) has = has || S.units[k].ref_vol == v;
+                if (has) ok = append_file(out, res + ".r" + std::to_string(g), false);
+            }
+            if (out && fclose(out) != 0) ok = false;
+            for (int p = 0; ok && p < np; ++p) {
+                FILE* po = nullptr;
+                for (int g = S.team_lo[(size_t)v]; ok && g <= S.team_hi[(size_t)v]; ++g) {
+                    const std::string src = res + ".r" + std::to_string(g) + ".p" + std::to_string(p);
+                    if (access(src.c_str(), F_OK) != 0) continue;
+                    if (!po) { po = fopen((res + ".p" + std::to_string(p)).c_str(), "wb"); if (!po) { ok = false; break; } }
+                    ok = append_file(po, src, false);
+                    if (ok) remove(src.c_str());
+                }
+                if (po && fclose(po) != 0) ok = false;
+            }
+            if (ok) ok = rename(tmp.c_str(), res.c_str()) == 0;
+            if (!ok) { fprintf(stderr, "[oc2pm] ERROR: assembling %s failed\n", res.c_str()); failed = true; break; }
+            for (int g = S.team_lo[(size_t)v]; g <= S.team_hi[(size_t)v]; ++g) remove((res + ".r" + std::to_string(g)).c_str());
+            char fin[4096];
+            snprintf(fin, sizeof fin, "%s/pm%d.finished", wrk_dir, v);
+            FILE* f = fopen(fin, "w"); if (f) fclose(f);
+        }
+    } else if (!todo.empty()) {
         // the next volume to take, shared by the workers (forked before anything touches HIP)
         int* counter = (int*)mmap(nullptr, 4096, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
         if (counter == MAP_FAILED) { fprintf(stderr, "[oc2pm] ERROR: mmap failed\n"); return 1; }
@@ -92,7 +184,6 @@ int main(int argc, char** argv)
     if (failed) return 1;
     FILE* out = fopen(output, "w");
     if (!out) { fprintf(stderr, "[oc2pm] ERROR: cannot open %s\n", output); return 1; }
-    std::vector<char> buf(1 << 20);
     bool wok = true;
     for (int i = 0; i < vi.num_volumes && wok; ++i) {
         char res[4096];

@@ -28,23 +28,81 @@ def file_allgather(directory: str, rank: int, nranks: int, timeout_s: float = 12
     import os
     import time
     seq = [0]
+    token = [None]
+
+    def wait_for(p: str, who: int, t0: float) -> None:
+        while not os.path.exists(p):
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError("rank %d never wrote %s" % (who, p))
+            time.sleep(0.0005)
+
+    def put(path: str, text: str) -> None:
+        with open(path + ".tmp%d" % rank, "w") as f:
+            f.write(text)
+        os.rename(path + ".tmp%d" % rank, path)
+
+    def get(path: str):
+        try:
+            return open(path).read()
+        except OSError:
+            return None
+
+    def run_token() -> str:
+        """One name per RUN: a second communicator or a re-run in the same directory must never read the previous run's files
+        (they have the right lengths and stale IPC handles / ncclUniqueIds).  Handshake through atomically replaced files: every
+        rank r > 0 publishes a nonce (hello_r); rank 0 announces its token together with the nonces it has seen and re-announces
+        whenever a hello file changes; a rank accepts only an announcement that carries ITS nonce and acknowledges it; rank 0
+        returns once every rank has acknowledged the current token.  Stale files of an earlier run carry other nonces."""
+        import json
+        nonce = "%d_%d" % (os.getpid(), time.time_ns())
+        ann = os.path.join(directory, "run_token")
+        t0 = time.time()
+        if rank != 0:
+            put(os.path.join(directory, "hello_%d" % rank), nonce)
+            while True:
+                try:
+                    a = json.loads(get(ann) or "{}")
+                    if a.get("nonces", {}).get(str(rank)) == nonce:
+                        put(os.path.join(directory, "ack_%s_%d" % (a["token"], rank)), nonce)
+                        return a["token"]
+                except ValueError:
+                    pass
+                if time.time() - t0 > timeout_s:
+                    raise TimeoutError("rank 0 never announced a run token for rank %d in %s" % (rank, directory))
+                time.sleep(0.0005)
+        seen = None
+        while True:
+            nonces = {str(r): get(os.path.join(directory, "hello_%d" % r)) for r in range(1, nranks)}
+            if all(nonces.values()):
+                if nonces != seen:
+                    put(ann, json.dumps({"token": nonce, "nonces": nonces}))
+                    seen = nonces
+                if all(get(os.path.join(directory, "ack_%s_%d" % (nonce, r))) == nonces[str(r)] for r in range(1, nranks)):
+                    return nonce
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError("the other ranks never showed up in %s" % directory)
+            time.sleep(0.0005)
 
     def allgather(b: bytes) -> List[bytes]:
+        if token[0] is None:
+            token[0] = run_token()
         k = seq[0]
         seq[0] += 1
-        mine = os.path.join(directory, "ag_%d_%d" % (k, rank))
+        mine = os.path.join(directory, "ag_%s_%d_%d" % (token[0], k, rank))
         with open(mine + ".tmp", "wb") as f:
             f.write(b)
         os.rename(mine + ".tmp", mine)
         out = []
         t0 = time.time()
         for r in range(nranks):
-            p = os.path.join(directory, "ag_%d_%d" % (k, r))
-            while not os.path.exists(p):
-                if time.time() - t0 > timeout_s:
-                    raise TimeoutError("rank %d never wrote %s" % (r, p))
-                time.sleep(0.0005)
+            p = os.path.join(directory, "ag_%s_%d_%d" % (token[0], k, r))
+            wait_for(p, r, t0)
             with open(p, "rb") as f:
                 out.append(f.read())
+        if k >= 2:      # everybody has finished exchange k - 1 (it wrote file k): nobody reads my file k - 2 any more
+            try:
+                os.remove(os.path.join(directory, "ag_%s_%d_%d" % (token[0], k - 2, rank)))
+            except OSError:
+                pass
         return out
     return allgather

@@ -259,6 +259,51 @@ def write_volume_dir(wrk_dir: str, rs: ReadSet, vol_size: int = DEFAULT_VOL_SIZE
     return vid
 
 
+def cut_ranges(rs: ReadSet, cuts: Sequence[int]) -> List[Tuple[int, int]]:
+    """Read ranges [start, end) of the volumes of `rs` when volume v is closed once it holds >= cuts[v] bases and the last volume
+    takes the rest (oc2mkdb's rule, makedb/main.c:29, with a threshold per volume)."""
+    out: List[Tuple[int, int]] = []
+    start = cur = 0
+    for i in range(rs.nreads):
+        cur += int(rs.sizes[i])
+        if len(out) < len(cuts) and cur >= int(cuts[len(out)]):
+            out.append((start, i + 1))
+            start = i + 1
+            cur = 0
+    if start < rs.nreads:
+        out.append((start, rs.nreads))
+    return out
+
+
+def remainder_cuts(rs: ReadSet, num_volumes: int, last_frac: float = 0.4) -> List[int]:
+    """thresholds for `num_volumes` volumes: equal ones and a last one of ~last_frac of their size - a project's last volume
+    is a remainder, which is what makes its (reference, query) volume pairs unequal"""
+    if num_volumes <= 1:
+        return []
+    return [int(rs.nbases / (num_volumes - 1 + last_frac))] * (num_volumes - 1)
+
+
+def write_volume_dir_cuts(wrk_dir: str, rs: ReadSet, cuts: Sequence[int]) -> int:
+    """Like write_volume_dir, but volume v is closed once it holds >= cuts[v] bases (the last volume takes the rest):
+    volume sets of UNEQUAL sizes, the shape a real project has - its last volume is a remainder (makedb/main.c:29) - and what the
+    (reference volume, query volume) pair scheduler has to balance."""
+    os.makedirs(wrk_dir, exist_ok=True)
+    base = wrk_dir if wrk_dir.endswith("/") else wrk_dir + "/"
+    lines = []
+    ranges = cut_ranges(rs, cuts)
+    for vid, (a, b) in enumerate(ranges):
+        o0 = int(rs.offsets[a])
+        o1 = int(rs.offsets[b - 1] + rs.sizes[b - 1])
+        vname = base + "vol%d" % vid
+        write_volume(vname, rs.codes[o0:o1], rs.sizes[a:b], rs.names[a:b])
+        lines.append("%s\t%d\t%d\n" % (vname, a, b - a))
+    with open(base + "volume_names.txt", "w") as f:
+        f.writelines(lines)
+    with open(base + "reads_info.txt", "w") as f:
+        f.write("%d\t%d\n" % (len(ranges), rs.nreads))
+    return len(ranges)
+
+
 def write_fasta(path: str, rs: ReadSet) -> None:
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)
     with open(path, "wb") as f:

@@ -195,6 +195,12 @@ def test_oc2cns_program_sparse_partitions_and_nodes(built, tmp_path):
     parts = [_run_oc2cns(built, argv, d, can, str(tmp_path), "n%d" % n, mn=(n, 2)) for n in range(2)]
     recs = lambda b: sorted(b.split(b">"))
     assert recs(parts[0][0] + parts[1][0]) == recs(cns) and recs(parts[0][1] + parts[1][1]) == recs(raw)
+    # -s 1 (SMALL_MEMORY pipelines): the reference never loads `reads` then, so the partition-end dump of the reads nobody corrected
+    # (consensus_one_partition.c:172-194, inside `if (reads)`) does not happen: raw_out is shorter, cns_out the same
+    subprocess.run([ora.REF_OC2CNS] + argv + ["-s", "1", "-t", "1", d, can, rc + "_s1", rr + "_s1"], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    cns_s, raw_s = _run_oc2cns(built, argv + ["-s", "1", "-t", "2"], d, can, str(tmp_path), "s1")
+    assert cns_s == open(rc + "_s1", "rb").read() == cns
+    assert raw_s == open(rr + "_s1", "rb").read() and len(raw_s) < len(raw)
 
 
 # ---- -r 1: the host rescue pair behind the device pass (cns_rescue.h) ----

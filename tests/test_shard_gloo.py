@@ -137,3 +137,25 @@ def test_sharded_index_arithmetic_over_gloo(tmp_path, world, k):
         assert ok, "rank %d: gathered index differs from the single-rank one" % rank
         assert tiles and reads_ok and T == 4 ** k
         assert sum(sizes) > 10_000 and min(sizes) > 0
+
+
+def _file_ag_worker(d, r, n, tag, q):
+    from necat_amd import dist as ndist
+    ag = ndist.file_allgather(d, r, n, timeout_s=30)
+    q.put((r, [ag(("%s-%d-%d" % (tag, r, k)).encode()) for k in range(5)]))
+
+
+def test_file_allgather_rerun_in_the_same_directory(tmp_path):
+    """the launcher-less all-gather (files in a shared directory) run twice in ONE directory: the second run must not read the
+    first run's files - same names, same lengths, other contents (stale IPC handles / ncclUniqueIds in real use)"""
+    import multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    for tag in ("A", "B"):
+        q = ctxm.Queue()
+        ps = [ctxm.Process(target=_file_ag_worker, args=(str(tmp_path), r, 3, tag, q)) for r in range(3)]
+        [p.start() for p in ps]
+        res = [q.get(timeout=120) for _ in ps]
+        [p.join() for p in ps]
+        for r, out in res:
+            for k, parts in enumerate(out):
+                assert parts == [("%s-%d-%d" % (tag, x, k)).encode() for x in range(3)]
