@@ -250,7 +250,8 @@ def widened_paths(ctx, vol, capi, opt_kw):
 def new_agg():
     return dict(index_ms=0.0, seed_ms=0.0, extend_ms=0.0, myers_ms=0.0, traceback_ms=0.0, launches=0, blocks=0, words=0, bases=0, rounds=0,
                 a_ms=0.0, a_launches=0, a_blocks=0, tb_a_ms=0.0, big_ms=0.0, big_blocks=0, band_words=0,
-                ix_local_ms=0.0, ix_xchg_ms=0.0, ix_xchg_bytes=0, gather_ms=0.0, gather_bytes=0, reads_local=0)
+                ix_local_ms=0.0, ix_xchg_ms=0.0, ix_xchg_bytes=0, gather_ms=0.0, gather_bytes=0, reads_local=0,
+                fused_ms=0.0, fused_launches=0, fused_blocks=0)
 
 
 def agg_add(agg, tm, t_index=0.0):
@@ -263,6 +264,7 @@ def agg_add(agg, tm, t_index=0.0):
     if tm.myersA_big_blocks >= agg["big_blocks"]:
         agg["big_blocks"], agg["big_ms"] = int(tm.myersA_big_blocks), float(tm.myersA_big_ms)
     agg["a_ms"] += tm.myersA_ms; agg["a_launches"] += tm.myersA_launches; agg["a_blocks"] += tm.myersA_blocks
+    agg["fused_ms"] += tm.fused_ms; agg["fused_launches"] += tm.fused_launches; agg["fused_blocks"] += tm.fused_blocks
 
 
 def gather_rank_stats(dist, mine):
@@ -613,7 +615,9 @@ def main():
                                    % (world, transport, args.chunk_reads)) if single else ("volume-per-gpu x%d" % world if world > 1 else "1 gpu")},
         "phases_ms_per_step": {"index": round(agg["index_ms"] / K, 2), "seed": round(agg["seed_ms"] / K, 2),
                                "extend": round(agg["extend_ms"] / K, 2), "myers_kernel": round(agg["myers_ms"] / K, 2),
-                               "traceback_kernel": round(agg["traceback_ms"] / K, 2), "rounds": agg["rounds"] // K},
+                               "traceback_kernel": round(agg["traceback_ms"] / K, 2),
+                               "fused_tail_kernel": round(agg["fused_ms"] / K, 2), "fused_tail_launches": agg["fused_launches"] // K,
+                               "fused_tail_blocks": agg["fused_blocks"] // K, "rounds": agg["rounds"] // K},
         "device": ctx.device_name(),
         "roofline": roofline,
     }

@@ -116,6 +116,11 @@ typedef struct {
     /* band words the NW passes stored (= the word updates the reference's banded NW pass needs, edlib_ex.c:311-325 with
      * k = the block's distance): with myers_word_updates, the redundant part of the computed work */
     uint64_t myers_band_words;
+    /* the small lists of the late rounds: fragments + single-pass DP + walk + plan of the next block in ONE launch per list and
+     * round, the band in LDS (necat_amd/csrc/ext_tail.h); their blocks are part of myers_blocks, their time is not in myers_ms /
+     * traceback_ms */
+    double   fused_ms;
+    uint64_t fused_launches, fused_blocks;
 } necat_timings;
 
 void        necat_default_options(necat_map_options* o);            /* map_options.c:12-28 */

@@ -33,7 +33,8 @@ class Timings(C.Structure):
                 ("myers_cells_bases", C.c_uint64), ("rounds", C.c_uint64),
                 ("myersA_ms", C.c_double), ("myersA_launches", C.c_uint64), ("myersA_blocks", C.c_uint64),
                 ("tracebackA_ms", C.c_double), ("myersA_big_ms", C.c_double), ("myersA_big_blocks", C.c_uint64),
-                ("myers_band_words", C.c_uint64)]
+                ("myers_band_words", C.c_uint64),
+                ("fused_ms", C.c_double), ("fused_launches", C.c_uint64), ("fused_blocks", C.c_uint64)]
 
 
 class ShardTimings(C.Structure):

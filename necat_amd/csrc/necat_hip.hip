@@ -14,6 +14,7 @@
 #include "seed_kernels.h"
 #include "pcan_kernels.h"
 #include "ext_kernels.h"
+#include "ext_tail.h"
 #include "asm_kernels.h"
 #include "cns_loop.h"
 #include "cns_rescue.h"
@@ -68,6 +69,7 @@ int g_fast;            // NECAT_FAST=0: the list-A DP kernel never takes its ful
 int g_fast16;          // NECAT_FAST16=1: list A's big rounds through k_myers_a16 (16 full blocks per workgroup: SHW 8 lanes, NW 4 lanes per block)
 size_t g_band_pool;    // NECAT_BAND_POOL_MB (default 16384): cap of one band-record pool; a bigger list runs in several DP + walk launches (0 = no cap)
 int g_walk;            // NECAT_WALK=0: k_traceback runs the reference formulation of the walk (A/B measurements)
+u32 g_tail_fused;      // NECAT_TAIL_FUSED (default 640; 0 = off): lists of at most this many blocks run as ONE launch per round with the band in LDS (ext_tail.h)
 int g_dbg;             // NECAT_DBG: profiling-only variants of the lane-per-block DP kernel (1 = no band stores, 2 = no NW pass)
 
 // Tuning / test knobs: process-wide, (re)read from the environment whenever a context is created, defaults otherwise.
@@ -77,6 +79,7 @@ void read_knobs()
     g_coop_threshold = (u32)num("NECAT_COOP_THRESHOLD", 0xffffffffu);
     g_seed_budget = num("NECAT_SEED_BUDGET", 48ULL << 20);
     g_single_pass = (u32)num("NECAT_SINGLE_PASS", 4096);
+    g_tail_fused = (u32)num("NECAT_TAIL_FUSED", 640);
     g_batch_cap = (u32)std::max<unsigned long long>(64, num("NECAT_BATCH", 786432));
     g_index_lds = (int)num("NECAT_INDEX_LDS", 1);
     g_seed_wave = (int)num("NECAT_SEED_WAVE", 1);
@@ -974,11 +977,11 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
 {
     struct Cnt { u32 nA, nB; };
     std::vector<Cnt> hist;                      // published sizes of lists[r]
-    std::vector<u8> a_timed;                    // A(r) ran its DP + traceback kernels (events recorded)
+    std::vector<u8> a_timed;                    // A(r) ran its DP + traceback kernels (events recorded); 2 = as one fused launch (ext_tail.h)
     const unsigned long long seq0 = ctx->round_seq;
     volatile RoundPub* ring = (volatile RoundPub*)ctx->round_ring;
     RoundPub* ring_dev = (RoundPub*)ctx->round_ring_dev;
-    bool b_pending[2] = {false, false};
+    bool b_pending[2] = {false, false}, b_fused[2] = {false, false};
     u32 b_blocks[2] = {0, 0};
     double last_wall = wall_ms();
     auto wait_pub = [&](u32 r, Cnt& out) -> int {
@@ -1001,6 +1004,14 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         if (r >= a_timed.size() || !a_timed[r]) return;
         const int q = r % 4;
         const u32 nA = hist[r].nA;
+        if (a_timed[r] == 2) {
+            const double f = ev_ms(c.a0[q], c.a2[q]);
+            ctx->tm.fused_ms += f; ctx->tm.fused_launches += 1; ctx->tm.fused_blocks += nA;
+            ctx->tm.myers_blocks += nA;
+            if (g_trace & 1) fprintf(stderr, "[necat] batch@%lu round %3u: list A %7u blocks  fused DP + walk %.3f ms\n", (unsigned long)c.base, r, nA, f);
+            a_timed[r] = 0;
+            return;
+        }
         const double mA = ev_ms(c.a0[q], c.a1[q]), tA = ev_ms(c.a1[q], c.a2[q]);
         ctx->tm.myers_ms += mA; ctx->tm.traceback_ms += tA;
         if (nA > g_single_pass) {      // the two-pass instantiation k_myers_coop<8,16,512,8,false> (bench.py's roofline kernel)
@@ -1018,6 +1029,13 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
     };
     auto account_b = [&](int slot) {
         if (!b_pending[slot]) return;
+        if (b_fused[slot]) {
+            const double f = ev_ms(c.b0[slot], c.b2[slot]);
+            ctx->tm.fused_ms += f; ctx->tm.fused_launches += 1; ctx->tm.fused_blocks += b_blocks[slot]; ctx->tm.myers_blocks += b_blocks[slot];
+            if (g_trace & 1) fprintf(stderr, "[necat]          list B: %7u blocks  fused DP + walk %.3f ms\n", b_blocks[slot], f);
+            b_pending[slot] = false; b_fused[slot] = false;
+            return;
+        }
         const double mB = ev_ms(c.b0[slot], c.b1[slot]), tB = ev_ms(c.b1[slot], c.b2[slot]);
         ctx->tm.myers_ms += mB; ctx->tm.traceback_ms += tB;
         ctx->tm.myers_launches += 1; ctx->tm.myers_blocks += b_blocks[slot];
@@ -1026,12 +1044,27 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
     };
     // ---- B(q): exact size known (published by A(q)'s first kernel)
     auto launch_b = [&](u32 q, u32 nB) -> int {
-        const int slot = q & 1, cur = q % 4, nxt2 = (q + 2) % 4;
+        const int slot = q & 1;
         account_b(slot);                                        // B(q - 2), the previous user of this slot, is done (A(q + 0) started after it)
         const u32 gB = (nB + 63) / 64;
         // small lists (the late rounds, where a round lasts as long as its slowest chain) get alternating streams so
         // that B(q) need not queue behind B(q - 1); big ones stay in one stream - three busy chains only add contention
         hipStream_t sb = c.sb[nB < 4096 ? slot : 0];
+        if (g_tail_fused && nB <= g_tail_fused) {
+            // a small list: fragments, DP, walk and the next block's plan in one launch, the band in LDS (ext_tail.h)
+            const int cur = q % 4, nxt2 = (q + 2) % 4;
+            NECAT_HIP(ctx, hipStreamWaitEvent(sb, c.a0[cur], 0));
+            NECAT_HIP(ctx, hipStreamWaitEvent(sb, c.b2[slot], 0));
+            ExtLists next; next.count = c.count + 4 * nxt2; next.itemsA = c.itemsA[nxt2]; next.itemsB = c.itemsB[nxt2]; next.task_ops = X.task_ops; next.capA = c.cap;
+            NECAT_HIP(ctx, hipEventRecord(c.b0[slot], sb));
+            hipLaunchKernelGGL((k_tail_fused<kWordsB, kTWordsB, kTailCapB, kOpsB>), dim3(nB), dim3(kTailThreads), 0, sb, drd, dref, (const BlockItem*)c.itemsB[cur], nB,
+                               (const u32*)(c.count + 4 * cur + 1), 0u, X.error, c.tasks, X.tail_match_len, X.d_err, next, X.stats);
+            NECAT_CHECK_LAUNCH(ctx, "k_tail_fused<B>");
+            NECAT_HIP(ctx, hipEventRecord(c.b1[slot], sb));
+            NECAT_HIP(ctx, hipEventRecord(c.b2[slot], sb));
+            b_pending[slot] = true; b_fused[slot] = true; b_blocks[slot] = nB;
+            return NECAT_OK;
+        }
         DevBuf& poolB = ctx->scratch[slot ? SC_EXT_MATB2 : SC_EXT_MATB];
         // a capped band pool (NECAT_BAND_POOL_MB): the list in chunks of what the pool holds, DP + walk per chunk
         u32 gchunk = gB;
@@ -1041,6 +1074,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
             int rc = ensure_zeroed(ctx, poolB, gchunk < gB ? need : need + need / 4, sb);
             if (rc) return rc;
         }
+        const int cur = q % 4, nxt2 = (q + 2) % 4;
         const BlockItem* itB = c.itemsB[cur];
         const u32* d_nB = c.count + 4 * cur + 1;
         NECAT_HIP(ctx, hipStreamWaitEvent(sb, c.a0[cur], 0));     // lists[q] complete (A(q - 1) done), counters of lists[q + 2] reset
@@ -1090,6 +1124,24 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
     // ---- A(r): grid sized by an upper bound, the kernels read the exact size of lists[r]
     auto launch_a = [&](u32 r, u32 bound) -> int {
         const int cur = r % 4, nxt = (r + 1) % 4, nxt2 = (r + 2) % 4;
+        if (g_tail_fused && bound && bound <= g_tail_fused) {
+            // a small list: one launch for the round (ext_tail.h); the round's bookkeeping first, as a launch of its own - list B's
+            // chain of this round waits for a0, not for the fused kernel
+            if (r >= 2) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, c.b2[r & 1], 0));        // B(r - 2) appended to lists[r]
+            const u32* d_nA = c.count + 4 * cur;
+            RoundCtl ctl; ctl.count = d_nA; ctl.zero = c.count + 4 * nxt2; ctl.seq = seq0 + r + 1; ctl.pub = ring_dev + (seq0 + r) % kRoundRing;
+            hipLaunchKernelGGL(k_round_ctl, dim3(1), dim3(64), 0, c.sa, ctl);
+            NECAT_CHECK_LAUNCH(ctx, "k_round_ctl");
+            NECAT_HIP(ctx, hipEventRecord(c.a0[cur], c.sa));
+            ExtLists next; next.count = c.count + 4 * nxt; next.itemsA = c.itemsA[nxt]; next.itemsB = c.itemsB[nxt]; next.task_ops = X.task_ops; next.capA = c.cap;
+            hipLaunchKernelGGL((k_tail_fused<kWordsA, kTWordsA, kColsA * kWordsA, kOpsA>), dim3(bound), dim3(kTailThreads), 0, c.sa, drd, dref, (const BlockItem*)c.itemsA[cur], bound,
+                               d_nA, c.cap, X.error, c.tasks, X.tail_match_len, X.d_err, next, X.stats);
+            NECAT_CHECK_LAUNCH(ctx, "k_tail_fused<A>");
+            NECAT_HIP(ctx, hipEventRecord(c.a1[cur], c.sa));
+            NECAT_HIP(ctx, hipEventRecord(c.a2[cur], c.sa));
+            a_timed.push_back(2);
+            return NECAT_OK;
+        }
         const u32 gA = (bound + 63) / 64;
         // the band pools are sized by what a round needs (round 0 of the first call sets them: 35 GB instead of the
         // 76 GB worst case "every block in list B" at E. coli size - hipMalloc costs ~13 ms per GB); with a capped pool
@@ -1238,6 +1290,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     ctx->tm.myers_word_updates = ctx->tm.myers_cells_bases = ctx->tm.myers_band_words = 0;
     ctx->tm.myersA_ms = ctx->tm.tracebackA_ms = 0; ctx->tm.myersA_launches = ctx->tm.myersA_blocks = 0;
     ctx->tm.myersA_big_ms = 0; ctx->tm.myersA_big_blocks = 0;
+    ctx->tm.fused_ms = 0; ctx->tm.fused_launches = ctx->tm.fused_blocks = 0;
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
     // batches of <= 786 432 candidates: every batch ends in ~20 latency-bound rounds, so fewer and bigger is better
     // (yeast-size: 654 -> 615 ms against 393 216); their band records need <= 103 GB for list A + a few GB for list B

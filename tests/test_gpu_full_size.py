@@ -62,3 +62,50 @@ def test_m4_identical_to_reference(ctx, ecoli):
     assert np.all(m4["soff"] < m4["send"]) and np.all(m4["send"] <= m4["ssize"])
     assert np.all(m4["sid"] < m4["qid"])            # self-volume: only subjects before the query (word_finder.c:121-127)
     assert np.all((m4["ident_perc"] > 50.0) & (m4["ident_perc"] <= 100.0))
+
+
+# ---- a multi-volume project at real volume sizes (the shape of BASELINE configs[3] / [4]) through the oc2pm PROGRAM ----
+MV = json.load(open(os.path.join(util.GOLDEN, "multivol_full_reference.json")))
+
+
+@pytest.fixture(scope="module")
+def multivol_dir(tmp_path_factory):
+    """1.48 Gbp in three volumes of 1.05 / 0.30 / 0.13 Gbp (synth.write_volume_dir_cuts): volume 0 sits where 34-bit offsets, 32-bit
+    slot counts and the 786 432-candidate batch cap matter (1.68 M candidates in its own job)"""
+    from necat_amd import synth
+    g = MV["generator"]
+    rs = synth.simulate_reads(g["genome"], g["coverage"], seed=g["seed"], err=g["err"])
+    if hashlib.md5(rs.codes.tobytes()).hexdigest() != MV["reads_md5"]:
+        pytest.skip("numpy generator drift: the seeded dataset differs from the one the golden was made on")
+    d = os.path.join(str(tmp_path_factory.mktemp("mv")), "vols")
+    assert synth.write_volume_dir_cuts(d, rs, g["cuts"]) == MV["volumes"]
+    return d
+
+
+@pytest.mark.parametrize("mode", ["can", "m4"])
+def test_multivolume_project_through_oc2pm_equals_the_reference(multivol_dir, built, mode):
+    """all six (reference volume, query volume) pairs, two oc2pm workers on the device splitting them by the pair schedule
+    (pair_sched.h): the concatenated output holds exactly the records the REFERENCE's three oc2pmov jobs wrote
+    (tests/golden/make_golden_multivol.py: sorted md5 over all volumes)"""
+    import subprocess
+    pmov, pm = built.build_cli()
+    d = multivol_dir
+    for f in os.listdir(d):
+        if f.startswith("pm") and f.endswith(".finished"):
+            os.remove(os.path.join(d, f))
+    out = os.path.join(d, "all_" + mode)
+    extra = ["-j", "0", "-u", "1", "-i", "1"] if mode == "can" else ["-j", "1", "-u", "0", "-i", "0"]
+    env = dict(os.environ, NECAT_GPUS="0,0")
+    r = subprocess.run([pm] + MV["options"].split() + extra + ["-t", "8", d, out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.count("unit(s) of job") >= 3          # both workers ran units, volume 0's pairs were split between them
+    if mode == "can":
+        raw = np.fromfile(out, dtype="<u4").reshape(-1, 7)
+        recs = sorted(bytes(x) for x in raw)
+        assert len(recs) == MV["candidate_records"]
+        assert hashlib.md5(b"".join(recs)).hexdigest() == MV["candidates_packed_sorted_md5"]
+    else:
+        lines = sorted(open(out, "rb").read().splitlines(keepends=True))
+        assert len(lines) == MV["m4_records"]
+        assert hashlib.md5(b"".join(lines)).hexdigest() == MV["m4_text_sorted_md5"]
+    os.remove(out)
