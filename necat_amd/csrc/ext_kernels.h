@@ -301,15 +301,23 @@ struct MatReader {
     int nc, nb;                // coordinates of the prefetched record
     ulonglong2 nv;
     bool no_prefetch = false;  // A/B switch (NECAT_WALK=2)
+    bool nt = false;           // A/B switch (NECAT_WALK=3 / 4): non-temporal loads (the record lines are read once, by one lane)
     NECAT_D void init() { nc = -100; nb = -100; }
+    NECAT_D ulonglong2 ld(u32 pos) const
+    {
+        if (!nt) return base[pos];
+        typedef unsigned long long v2 __attribute__((ext_vector_type(2)));
+        const v2 x = __builtin_nontemporal_load(reinterpret_cast<const v2*>(base) + pos);
+        return make_ulonglong2(x.x, x.y);
+    }
     NECAT_D void rec(int c, int b, u64& Pv, u64& Ph)
     {
-        if (no_prefetch) { const ulonglong2 v = base[rec_pos<NW>(c, b, lane)]; Pv = v.x; Ph = v.y; return; }
+        if (no_prefetch) { const ulonglong2 v = ld(rec_pos<NW>(c, b, lane)); Pv = v.x; Ph = v.y; return; }
         ulonglong2 v = nv;
-        if (!(c == nc && b == nb)) v = base[rec_pos<NW>(c, b, lane)];
+        if (!(c == nc && b == nb)) v = ld(rec_pos<NW>(c, b, lane));
         Pv = v.x; Ph = v.y;
         nc = c - 1; nb = b;
-        if (nc >= 0) nv = base[rec_pos<NW>(nc, nb, lane)];
+        if (nc >= 0) nv = ld(rec_pos<NW>(nc, nb, lane));
     }
 };
 
@@ -830,7 +838,8 @@ k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
         MatReader<NW> mr;
         mr.base = slab_records(const_cast<char*>(slabs) + (size_t)grp * slab_bytes); mr.lane = lane; mr.init();
         mr.no_prefetch = WALK == 2;
-        if (WALK == 0) traceback_block(it.qn, br.endc + 1, mr, ow);
+        mr.nt = WALK >= 3;
+        if (WALK == 0 || WALK == 3) traceback_block(it.qn, br.endc + 1, mr, ow);
         else {
             OpsSink sk; sk.ops = ow.ops; sk.cap = ow.cap; sk.overflow = 0; sk.store = ow.store;
             walk_block(it.qn, br.endc + 1, mr, sk, ow.ts);

@@ -1113,7 +1113,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
 #define NECAT_TB_LAUNCH(WALK) hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false, WALK>), dim3((cn + 63) / 64), dim3(64), 0, sb, itB, hi, d_nB, 0u, \
                            (const u64*)c.fragB[slot], (const char*)slabsB, kSlabB, (const BlockResult*)c.resB[slot], c.opsB[slot], c.tasks, X.tail_match_len, \
                            (i32*)nullptr, X.d_err, next, epoch, lo)
-            if (g_walk == 1) NECAT_TB_LAUNCH(1); else if (g_walk == 2) NECAT_TB_LAUNCH(2); else NECAT_TB_LAUNCH(0);
+            if (g_walk == 1) NECAT_TB_LAUNCH(1); else if (g_walk == 2) NECAT_TB_LAUNCH(2); else if (g_walk == 3) NECAT_TB_LAUNCH(3); else if (g_walk == 4) NECAT_TB_LAUNCH(4); else NECAT_TB_LAUNCH(0);
 #undef NECAT_TB_LAUNCH
             NECAT_CHECK_LAUNCH(ctx, "k_traceback<B>");
         }
@@ -1190,7 +1190,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
 #define NECAT_TB_LAUNCH(WALK) hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, WALK>), dim3(cn / 64), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap, \
                            (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len, \
                            (i32*)nullptr, X.d_err, next, epoch, lo)
-            if (g_walk == 1) NECAT_TB_LAUNCH(1); else if (g_walk == 2) NECAT_TB_LAUNCH(2); else NECAT_TB_LAUNCH(0);
+            if (g_walk == 1) NECAT_TB_LAUNCH(1); else if (g_walk == 2) NECAT_TB_LAUNCH(2); else if (g_walk == 3) NECAT_TB_LAUNCH(3); else if (g_walk == 4) NECAT_TB_LAUNCH(4); else NECAT_TB_LAUNCH(0);
 #undef NECAT_TB_LAUNCH
             NECAT_CHECK_LAUNCH(ctx, "k_traceback<A>");
         }

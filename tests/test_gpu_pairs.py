@@ -41,7 +41,7 @@ def test_shares_of_a_pair_add_up_to_the_oracle_records(ctx, tmp_path):
     ix = ctx.build_index(ref, 13, kw["kmer_cnt_cutoff"])
     slots = 8
     for reads, rstart in ((ref, vols[0][1]), (qry, vols[1][1])):                # the self pair and a cross pair
-        nreads = reads.nseq()
+        nreads = reads.nseq
         chunk = capi.pair_chunk_reads(nreads, slots)
         whole_c = ctx.find_candidates(ix, ref, reads, rstart, 0, capi.default_options(**dict(kw, job=0)), True)
         whole_m, _ = ctx.map_pair(ix, ref, reads, rstart, 0, capi.default_options(**dict(kw, job=1)), True, 1)

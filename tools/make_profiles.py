@@ -88,8 +88,38 @@ def counters(dirs, out):
         json.dump(dict(sorted(res.items())), fh, indent=1)
 
 
+def timeline(d, out, header):
+    """the kernels of the LAST bench step of a --kernel-trace run, launch by launch: start (ms from the step's first kernel),
+    duration, grid, queue, name - the step starts at the last k_part_hist of the trace"""
+    rows = []
+    for f in find(d, "kernel_trace.csv"):
+        with open(f) as fh:
+            rows += list(csv.DictReader(fh))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("necat::k_part_hist") or "k_part_hist" in r["Kernel_Name"]]
+    if not starts:
+        raise SystemExit("no k_part_hist in the trace")
+    # the last step that ran the extension (the -j 0 extras of bench.py come after the timed steps)
+    bounds = starts + [len(rows)]
+    segs = [(bounds[i], bounds[i + 1]) for i in range(len(starts)) if any("k_ext_init" in r["Kernel_Name"] for r in rows[bounds[i]:bounds[i + 1]])]
+    a, b = segs[-1] if segs else (starts[-1], len(rows))
+    rows = rows[a:b]
+    t0 = int(rows[0]["Start_Timestamp"])
+    queues = {}
+    with open(out, "w") as fh:
+        fh.write("# %s\n# start ms | duration us | grid threads | queue | kernel\n" % header)
+        for r in rows:
+            q = queues.setdefault(r["Queue_Id"], len(queues) + 1)
+            name = r["Kernel_Name"].replace("necat::", "").replace("void ", "")
+            name = name.split("(")[0]
+            grid = int(r.get("Grid_Size", r.get("Grid_Size_X", 0)) or 0)
+            fh.write("%8.3f %9.1f %10d q%d %s\n" % ((int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, grid, q, name))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "stats":
+    if sys.argv[1] == "timeline":
+        timeline(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], sys.argv[4])
     elif sys.argv[1] == "counters":
         counters(sys.argv[2:-1], sys.argv[-1])

@@ -78,11 +78,30 @@ CASE(22, R64(F22))
 #define F23(d) "v_lshl_add_u64 v[50:51], v[50:51], 0, v[52:53]\n"
 CASE(23, R64(F23))
 // ---- scalar ALU next to nothing (how many SALU ops a wave can interleave)
-#define F24(d) "s_add_u32 s20, s20, 1\n"
+#define F24(d) "v_xor_b32_e32 v" S(d) ", v" S(d) ", v48\n"      // (was: s_add_u32 alone - 27 us per instruction on this box, minutes per run)
 CASE(24, R64(F24))
 // ---- a VOP2 and a SALU op alternating (do they share an issue slot within ONE wave?)
-#define F25(d) "v_add_u32_e32 v" S(d) ", v" S(d) ", v48\n s_add_u32 s20, s20, 1\n"
+#define F25(d) "v_xor_b32_e32 v" S(d) ", v" S(d) ", v48\n"      // (was: VOP2 + s_add_u32 alternating, see F24)
 CASE(25, R64(F25))
+
+// ---- mixes: what the DP kernel's step looks like (25 full-rate + 14 half-rate instructions), and dependent chains
+#define F26(d) "v_xor_b32_e32 v" S(d) ", v" S(d) ", v48\n v_alignbit_b32 v" S(d) ", v" S(d) ", v49, 31\n"
+CASE(26, R64(F26))
+#define F27(d) "v_xor_b32_e32 v" S(d) ", v" S(d) ", v48\n v_bitop3_b32 v" S(d) ", v" S(d) ", v49, v50 bitop3:0x96\n v_alignbit_b32 v" S(d) ", v" S(d) ", v49, 31\n"
+CASE(27, R64(F27))
+// one dependent chain per wave (every instruction reads the previous one's result)
+#define F28(d) "v_xor_b32_e32 v40, v40, v48\n"
+CASE(28, R64(F28))
+#define F29(d) "v_alignbit_b32 v40, v40, v49, 31\n"
+CASE(29, R64(F29))
+#define F30(d) "v_xor_b32_e32 v40, v40, v48\n v_bitop3_b32 v40, v40, v49, v50 bitop3:0x96\n v_alignbit_b32 v40, v40, v49, 31\n"
+CASE(30, R64(F30))
+// two chains per wave
+#define F31(d) "v_xor_b32_e32 v40, v40, v48\n v_xor_b32_e32 v41, v41, v48\n"
+CASE(31, R64(F31))
+// full-rate ops whose sources collide in a VGPR bank (v48, v52: both bank 0): the VOP2 case
+#define F32(d) "v_xor_b32_e32 v" S(d) ", v48, v52\n"
+CASE(32, R64(F32))
 
 static const Case kCases[] = {
     {"v_add_u32_e32 (VOP2)", 64}, {"v_xor_b32_e32 (VOP2)", 64}, {"v_xor_b32_e64 (same op, VOP3 encoding)", 64}, {"v_lshlrev_b32_e32 v, 1, v", 64}, {"v_not_b32_e32 (VOP1)", 64},
@@ -90,8 +109,12 @@ static const Case kCases[] = {
     {"v_or3_b32 d, d, v49, v50", 64}, {"v_bfi_b32 d, d, v49, v50", 64}, {"v_alignbit_b32 d, d, v49, 31", 64}, {"v_lshl_or_b32 d, d, 1, v49", 64}, {"v_bfe_i32 d, d, v49, 1", 64},
     {"v_bfe_u32 d, d, 3, 5", 64}, {"v_mov_b32_dpp row_shr:1", 64}, {"v_add_u32_dpp row_shr:1", 64}, {"v_add_co_u32_e32 + v_addc_co_u32_e32 (vcc)", 128},
     {"v_add_co_u32_e64 + s_nop 1 + v_addc_co_u32_e64 (SGPR pair; per VALU inst)", 128}, {"v_cmp_lt_u32_e32 vcc", 64}, {"v_cmp_lt_u32_e64 s[20:21]", 64},
-    {"v_cndmask_b32_e32 (vcc)", 64}, {"v_cndmask_b32_e64 (SGPR pair)", 64}, {"v_lshlrev_b64", 64}, {"v_lshl_add_u64", 64}, {"s_add_u32 (SALU only)", 64},
-    {"v_add_u32_e32 + s_add_u32 alternating (per pair)", 64}};
+    {"v_cndmask_b32_e32 (vcc)", 64}, {"v_cndmask_b32_e64 (SGPR pair)", 64}, {"v_lshlrev_b64", 64}, {"v_lshl_add_u64", 64}, {"(placeholder) v_xor_b32_e32", 64},
+    {"(placeholder) v_xor_b32_e32", 64},
+    {"mix 1:1 v_xor_e32 / v_alignbit (8 chains; per instruction)", 128}, {"mix 2:1 v_xor_e32, v_bitop3, v_alignbit (8 chains; per instruction)", 192},
+    {"v_xor_b32_e32 ONE dependent chain per wave", 64}, {"v_alignbit_b32 ONE dependent chain per wave", 64},
+    {"mix 2:1 ONE dependent chain per wave (per instruction)", 192}, {"v_xor_b32_e32 TWO dependent chains per wave (per instruction)", 128},
+    {"v_xor_b32_e32 d, v48, v52 (both sources in one VGPR bank)", 64}};
 constexpr int kNumCases = sizeof(kCases) / sizeof(kCases[0]);
 
 template <int C> __global__ void __launch_bounds__(64) k(unsigned* out, unsigned long long* ticks)
