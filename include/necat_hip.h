@@ -155,6 +155,14 @@ int  necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, i
 int  necat_index_size(const necat_index* ix, uint64_t* table_entries, uint64_t* n_offsets);
 /* copy the index to host buffers (either may be NULL); used by parity tests */
 int  necat_index_download(necat_ctx* ctx, const necat_index* ix, uint64_t* kmer_stats, uint64_t* offset_list);
+/* The table as the device holds it when it was built in the sparse layout (k >= 11): per 64 table entries one pair of words
+ * (bits: which of the 64 entries are non-zero; base: position in `compact` of the first of them), and `compact`, the non-zero
+ * `cnt<<34 | start` entries in hash order - kmer_stats[h] = bit (h & 63) of bits[h >> 6] set ? compact[base[h >> 6] + popcount(bits
+ * below it)] : 0.  0.27 + (8 bytes per distinct kept k-mer) GB at k = 15 instead of the 8.6 GB of the dense table: what a host-side
+ * reader of the table (the vote of oc2asmpm, asm_pm_common.c:509-702) copies.  necat_index_sparse_size: n_pairs = 0 for an index in
+ * the dense layout (small k: use necat_index_download).  Outputs of the download may be NULL (skipped); pairs = 2 * n_pairs words. */
+int  necat_index_sparse_size(const necat_index* ix, uint64_t* n_pairs, uint64_t* n_compact);
+int  necat_index_download_sparse(necat_ctx* ctx, const necat_index* ix, uint64_t* pairs, uint64_t* compact, uint64_t* offset_list);
 void necat_index_free(necat_ctx* ctx, necat_index* ix);
 
 /* All reads of `reads` (both strands) against `ref`.  Output: per read, its candidates in exactly the

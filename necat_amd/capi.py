@@ -79,7 +79,7 @@ class _CnsResult(C.Structure):
 EXPORTED_SYMBOLS = [
     "necat_default_options", "necat_ctx_create", "necat_ctx_destroy", "necat_ctx_trim", "necat_last_error", "necat_device_name",
     "necat_volume_upload", "necat_volume_pack", "necat_volume_free", "necat_index_build", "necat_index_size", "necat_index_download",
-    "necat_index_free", "necat_find_candidates", "necat_extend", "necat_map_pair", "necat_map_reference", "necat_onc_align_batch", "necat_asm_align_batch",
+    "necat_index_free", "necat_index_sparse_size", "necat_index_download_sparse", "necat_find_candidates", "necat_extend", "necat_map_pair", "necat_map_reference", "necat_onc_align_batch", "necat_asm_align_batch",
     "necat_gapped_strings", "necat_cns_default_options", "necat_cns_load_partition", "necat_cns_extension_batch",
     "necat_cns_result_free",
     "necat_edlib_align_batch", "necat_get_timings", "necat_free", "necat_pcan_partition",
@@ -121,6 +121,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.necat_index_size.argtypes = [vp, u64p, u64p]
     lib.necat_index_download.argtypes = [vp, vp, vp, vp]
     lib.necat_index_free.argtypes = [vp, vp]
+    lib.necat_index_sparse_size.argtypes = [vp, u64p, u64p]
+    lib.necat_index_download_sparse.argtypes = [vp, vp, vp, vp, vp]
     lib.necat_index_free.restype = None
     lib.necat_find_candidates.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(MapOptions),
                                           C.POINTER(vp), u64p]
@@ -554,6 +556,19 @@ class Index:
         self.ctx._check(self.ctx.lib.necat_index_download(self.ctx.h, self.h, stats.ctypes.data if want_stats else None,
                                                           offs.ctypes.data if n else None), "necat_index_download")
         return stats, offs
+
+    def download_sparse(self):
+        """(bits[T / 64], base[T / 64], compact, offset_list) of an index held in the sparse layout (IndexView, dev_common.h); None for a dense one"""
+        npairs, ncomp = C.c_uint64(), C.c_uint64()
+        self.ctx._check(self.ctx.lib.necat_index_sparse_size(self.h, C.byref(npairs), C.byref(ncomp)), "necat_index_sparse_size")
+        if npairs.value == 0:
+            return None
+        _, n_off = self.sizes()
+        pairs = np.empty(2 * npairs.value, dtype=np.uint64)
+        comp = np.empty(max(1, ncomp.value), dtype=np.uint64)
+        offs = np.empty(max(1, n_off), dtype=np.uint64)
+        self.ctx._check(self.ctx.lib.necat_index_download_sparse(self.ctx.h, self.h, pairs.ctypes.data, comp.ctypes.data, offs.ctypes.data), "necat_index_download_sparse")
+        return pairs[0::2].copy(), pairs[1::2].copy(), comp[:ncomp.value], offs[:n_off]
 
     def free(self):
         if self.h and self.ctx.h:

@@ -1,0 +1,49 @@
+// asm_coop.h - the block aligner of oc2asmpm (blockwise_edlib_align, asm_pm/blockwise_edlib.c:1205-1371 = onc_align with 2048-bp blocks, tail
+// match length 8; called by hbn_map_extend, asm_pm/hbn_align.c:282-326) through the extension stage's own machinery at a bigger geometry:
+//
+//   every (read, subject strand, anchor) triple is an ExtTask that advances one block per ROUND (ext_plan<2048>); a round is
+//   k_ext_frag<44, 88>           fragments of every scheduled block from the 2-bit volumes (the subject on either strand)
+//   k_myers_coop<44, 88, .., 64> the cooperative, register-resident DP of the 512-bp stage: lane b of the wave owns 64-row word b of ONE block
+//                                (a full 2048 x 2048 block has 32 words, the longest last block - (2048 + 99) x 1.3 = 2791 - has 44), anti-diagonal
+//                                wavefront, the carry between words by DPP wave_shr:1, target bit-planes staged in LDS, SHW pass then NW pass whose
+//                                band records are stored only for the words the walk can reach (the reference's own band tests with k = the
+//                                block's distance)
+//   k_traceback<44, 88, ..>      the walk (up > left > diagonal), the tail trimmed at the last run of 8 matches, the kept columns appended to the
+//                                task's 2-bit column stream, the next block planned and appended to the next round's list
+//   and after the last round k_ext_alignment / k_ext_strings give every anchor's coordinates, identity and alignment columns - exactly the outputs
+//   of necat_onc_align_batch.
+// One list per round (ExtLists' list B arrays used as a plain list: ONE_LIST), rounds synchronous on the host - a corrected read is 3 - 5 blocks
+// long, so a call is a handful of rounds.  The lane-per-alignment kernel this replaces (k_asm_align, asm_kernels.h: 512 registers + scratch per lane,
+// a 126 MB band slab per wave, one wave per SIMD) stays as the second implementation the tests compare with (NECAT_ASM_LANE=1).
+#pragma once
+#include "asm_kernels.h"
+#include "ext_kernels.h"
+
+namespace necat {
+
+constexpr int kAsmTWords = (kAsmCols + 31) / 32;                  // 88 target words of 32 columns
+constexpr int kAsmFragWords = 2 * kAsmWords + kAsmTWords;         // u64 per item in the fragment buffer
+constexpr int kAsmMaxOps = 2 * kAsmCols + 16;                     // ops of one block alignment (<= qn + tn)
+constexpr size_t kAsmSlab = (size_t)((kAsmCols + 7) & ~7) * kAsmWords * 64 * sizeof(BandRec);     // band records of 64 items (126 MB, sparsely written)
+
+// tasks from anchors: the query is the forward read, the subject on strand sdir (ExtTask::sdir; ext_frag_geom reads it backwards and
+// complemented); first block planned and appended to the round-0 list
+__global__ void __launch_bounds__(256)
+k_asm_init(const AsmAnchor* __restrict__ anchors, u32 n, const u64* __restrict__ reads_off, const u64* __restrict__ ref_off, ExtTask* __restrict__ tasks,
+           ExtLists L, const u64* __restrict__ ops_base)
+{
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    ExtTask t;
+    bool go = false;
+    if (i < n) {
+        const AsmAnchor a = anchors[i];
+        ext_init(t, (i32)i, 0, (i64)reads_off[a.q], (i32)(reads_off[a.q + 1] - reads_off[a.q]), (i64)ref_off[a.s], (i32)(ref_off[a.s + 1] - ref_off[a.s]), a.qoff, a.soff);
+        t.sdir = a.sdir;
+        t.ops_base = ops_base[i];
+        go = ext_plan<kAsmBlock>(t);
+        tasks[i] = t;
+    }
+    ext_append_block<kAsmBlock, true>(t, i, go, L);
+}
+
+}  // namespace necat

@@ -50,19 +50,38 @@ inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const 
     std::string err;
     HostVolume href;
     if (!load_volume(vi.names[vid].c_str(), &href, &err)) return fail("volume", err.c_str());
-    necat_volume* ref = nullptr;
-    if (necat_volume_upload(ctx, href.pac.data(), href.nbases, href.offset.data(), href.size.data(), href.offset.size(), &ref)) return fail("necat_volume_upload", necat_last_error(ctx));
+    // everything the job holds on the device / in files, released on every way out (the context may outlive a failed job)
+    struct Held {
+        necat_ctx* ctx; necat_volume* ref = nullptr; necat_volume* reads = nullptr; necat_index* ix = nullptr; FILE* out = nullptr; std::string tmp_out;
+        ~Held()
+        {
+            if (out) { fclose(out); remove(tmp_out.c_str()); }
+            if (ix) necat_index_free(ctx, ix);
+            if (reads && reads != ref) necat_volume_free(ctx, reads);
+            if (ref) necat_volume_free(ctx, ref);
+        }
+    } H{ctx};
+    if (necat_volume_upload(ctx, href.pac.data(), href.nbases, href.offset.data(), href.size.data(), href.offset.size(), &H.ref)) return fail("necat_volume_upload", necat_last_error(ctx));
+    necat_volume* const ref = H.ref;
     log_line("", "build_lookup_table");
     double t0 = now_sec();
-    necat_index* ix = nullptr;
-    if (necat_index_build(ctx, ref, opt.kmer_size, opt.kmer_cnt_cutoff, &ix)) return fail("necat_index_build", necat_last_error(ctx));
-    // the vote reads the table on the host
-    uint64_t n_table = 0, n_offsets = 0;
-    necat_index_size(ix, &n_table, &n_offsets);
-    // (not value-initialised: the table is 8.6 GB at k = 15 and the download writes all of it)
-    std::unique_ptr<uint64_t[]> kmer_stats(new uint64_t[n_table + 1]), offset_list(new uint64_t[n_offsets + 1]);
-    if (necat_index_download(ctx, ix, kmer_stats.get(), offset_list.get())) return fail("necat_index_download", necat_last_error(ctx));
-    necat_index_free(ctx, ix);
+    if (necat_index_build(ctx, ref, opt.kmer_size, opt.kmer_cnt_cutoff, &H.ix)) return fail("necat_index_build", necat_last_error(ctx));
+    // The vote reads the table on the host - in the layout the device built it in: the sparse one (k >= 11: one (bits, base) pair per 64
+    // table entries + the non-zero entries, 0.27 GB + 8 bytes per kept k-mer at k = 15) instead of the reference's dense kmer_stats
+    // (8.6 GB at k = 15, 1.7 s to download per job); the dense layout only for the small tables that are built dense.
+    uint64_t n_table = 0, n_offsets = 0, n_pairs = 0, n_compact = 0;
+    necat_index_size(H.ix, &n_table, &n_offsets);
+    necat_index_sparse_size(H.ix, &n_pairs, &n_compact);
+    // (not value-initialised: the downloads write all of them)
+    std::unique_ptr<uint64_t[]> kmer_stats, pairs, compact, offset_list(new uint64_t[n_offsets + 1]);
+    if (n_pairs) {
+        pairs.reset(new uint64_t[2 * n_pairs]); compact.reset(new uint64_t[n_compact + 1]);
+        if (necat_index_download_sparse(ctx, H.ix, pairs.get(), compact.get(), offset_list.get())) return fail("necat_index_download_sparse", necat_last_error(ctx));
+    } else {
+        kmer_stats.reset(new uint64_t[n_table + 1]);
+        if (necat_index_download(ctx, H.ix, kmer_stats.get(), offset_list.get())) return fail("necat_index_download", necat_last_error(ctx));
+    }
+    necat_index_free(ctx, H.ix); H.ix = nullptr;
     log_line("[%s] INFO: '%s' takes %.2lf secs.\n", "build_lookup_table", now_sec() - t0);
     HostCodes cref; cref.set(href);
     std::vector<uint64_t> ref_off(href.offset.size() + 1, 0);
@@ -70,15 +89,22 @@ inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const 
     asmpm::RefView rv;
     rv.seq_off = ref_off.data(); rv.nseq = href.offset.size();
     rv.kmer_list = [&](uint64_t h, uint64_t* n) -> const uint64_t* {
-        const uint64_t u = kmer_stats[h], cnt = u >> 34, start = u & ((1ULL << 34) - 1);
+        uint64_t u;
+        if (pairs) {        // IndexView::lookup (dev_common.h) on the host copy
+            const uint64_t bits = pairs[2 * (h >> 6)], bit = 1ULL << (h & 63);
+            u = (bits & bit) ? compact[pairs[2 * (h >> 6) + 1] + (uint64_t)__builtin_popcountll(bits & (bit - 1))] : 0;
+        } else u = kmer_stats[h];
+        const uint64_t cnt = u >> 34, start = u & ((1ULL << 34) - 1);
         *n = cnt;
         return cnt ? offset_list.get() + start : nullptr;
     };
     auto subject_of = [&](int sid, int strand, std::vector<uint8_t>& s) { cref.strand((uint64_t)sid, strand, s); };
 
-    const std::string tmp_out = std::string(output) + ".part";
-    FILE* out = fopen(tmp_out.c_str(), "w");
-    if (!out) return fail("output", "cannot open for writing");
+    H.tmp_out = std::string(output) + ".part";
+    const std::string& tmp_out = H.tmp_out;
+    H.out = fopen(tmp_out.c_str(), "w");
+    if (!H.out) return fail("output", "cannot open for writing");
+    FILE* const out = H.out;
     const int ref_start = vi.read_start_id[vid];
     const int nthreads = std::max(1, std::min(opt.num_threads, 256));
     int status = 0;
@@ -89,15 +115,17 @@ inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const 
         t0 = now_sec();
         HostVolume own;
         const HostVolume* hreads = &href;
-        necat_volume* reads = ref;
+        H.reads = ref;
         HostCodes cown;
         const HostCodes* crd = &cref;
         if (i != vid) {
             if (!load_volume(vi.names[i].c_str(), &own, &err)) { status = fail("volume", err.c_str()); break; }
             hreads = &own;
-            if (necat_volume_upload(ctx, own.pac.data(), own.nbases, own.offset.data(), own.size.data(), own.offset.size(), &reads)) { status = fail("necat_volume_upload", necat_last_error(ctx)); break; }
+            H.reads = nullptr;
+            if (necat_volume_upload(ctx, own.pac.data(), own.nbases, own.offset.data(), own.size.data(), own.offset.size(), &H.reads)) { H.reads = nullptr; status = fail("necat_volume_upload", necat_last_error(ctx)); break; }
             cown.set(own); crd = &cown;
         }
+        necat_volume* const reads = H.reads;
         const int read_start = vi.read_start_id[i];
         const uint64_t nreads = hreads->offset.size();
         // phase A: votes and ranges
@@ -196,12 +224,13 @@ inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const 
             if (!wok) status = fail("output", "write failed");
         }
         if (reads != ref) necat_volume_free(ctx, reads);
+        H.reads = nullptr;
         if (!status) log_line("[%s] INFO: '%s' takes %.2lf secs.\n", job, now_sec() - t0);
     }
+    H.out = nullptr;                  // closed here: the guard only cleans up after an early return
     if (fclose(out) != 0 && !status) status = fail("output", "write failed");
     if (!status && rename(tmp_out.c_str(), output) != 0) status = fail("output", "rename failed");
     if (status) remove(tmp_out.c_str());
-    necat_volume_free(ctx, ref);
     return status;
 }
 

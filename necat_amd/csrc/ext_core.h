@@ -40,7 +40,7 @@ struct ExtTask {
     // to one per-task region in stream order, left stream at [0, s_lto), right stream from s_lto on; the
     // final alignment is region[s_lfrom, s_lto) reversed followed by region[s_lto + s_rfrom, s_lto + s_rto)
     i32 s_lfrom, s_lto, s_rfrom, s_rto;
-    i32 _pad;
+    i32 sdir;            // strand of the SUBJECT (0 everywhere but in the overlapper of corrected reads, asm_pm: the query stays forward there)
     u64 ops_base;
 };
 
@@ -76,7 +76,7 @@ NECAT_HD void ext_init(ExtTask& t, i32 cand, i32 qdir, i64 q_g0, i32 qlen, i64 s
     t.l_cols = t.l_q = t.l_t = t.l_mat = 0;
     t.r_qoff = t.r_qend = t.r_toff = t.r_tend = t.r_cols = t.r_mat = 0;
     t.s_lfrom = t.s_lto = t.s_rfrom = t.s_rto = 0;
-    t._pad = 0; t.ops_base = 0;
+    t.sdir = 0; t.ops_base = 0;
 }
 
 // one alignment column in stream order
@@ -149,7 +149,7 @@ NECAT_HD bool ext_plan(ExtTask& t)
 
 // Fragment geometry of the scheduled block: element i of the query fragment is base
 // (q_base + q_dir * i) of the reads volume (complemented when q_comp), same for the target.
-struct FragGeom { i64 q_base; int q_dir, q_comp; i64 t_base; int t_dir; };
+struct FragGeom { i64 q_base; int q_dir, q_comp; i64 t_base; int t_dir, t_comp; };
 
 NECAT_HD FragGeom ext_frag_geom(const ExtTask& t)
 {
@@ -161,7 +161,8 @@ NECAT_HD FragGeom ext_frag_geom(const ExtTask& t)
     if (t.qdir == 0) { g.q_base = t.q_g0 + p0; g.q_dir = right ? +1 : -1; g.q_comp = 0; }
     else { g.q_base = t.q_g0 + t.qlen - 1 - p0; g.q_dir = right ? -1 : +1; g.q_comp = 1; }
     const i64 s0 = right ? (i64)t.TS + t.tidx : (i64)t.TS - 1 - t.tidx;
-    g.t_base = t.s_g0 + s0; g.t_dir = right ? +1 : -1;
+    if (!t.sdir) { g.t_base = t.s_g0 + s0; g.t_dir = right ? +1 : -1; g.t_comp = 0; }
+    else { g.t_base = t.s_g0 + t.slen - 1 - s0; g.t_dir = right ? -1 : +1; g.t_comp = 1; }      // reverse strand: read backwards, complemented
     return g;
 }
 

@@ -100,12 +100,15 @@ NECAT_D bool list_item(const ListView& v, const BlockItem* __restrict__ items, u
 // extension and the last blocks that fit - 8 words, 8 lanes per block) or list B (bigger last blocks, up to
 // 794 x 794 - 13 words, 16 lanes per block: 3x the cost, so nothing that fits list A goes here);
 // one atomic per wave and list (ballot-aggregated).
+// BLOCK: the full block size (512; 2048 in the overlapper of corrected reads).  ONE_LIST: every block goes to list B's arrays, used
+// as one plain list (the round loop of necat_asm_align_batch).
+template <int BLOCK = kOcaBlockSize, bool ONE_LIST = false>
 NECAT_D void ext_append_block(const ExtTask& t, u32 ti, bool go, const ExtLists& L)
 {
-    const bool isA = go && t.qblk <= kOcaBlockSize && t.tblk <= kOcaBlockSize;
+    const bool isA = !ONE_LIST && go && t.qblk <= BLOCK && t.tblk <= BLOCK;
     const bool isB = go && !isA;
     // list A from both ends: full blocks from the front, the others from the back (ListView)
-    const bool isF = isA && t.qblk == kOcaBlockSize && t.tblk == kOcaBlockSize;
+    const bool isF = isA && t.qblk == BLOCK && t.tblk == BLOCK;
     const bool isP = isA && !isF;
     const int lane = (int)(threadIdx.x & 63);
     const u64 below = (1ULL << lane) - 1ULL;
@@ -252,7 +255,7 @@ k_ext_frag(DevVolume reads, DevVolume ref, const BlockItem* __restrict__ items, 
     } else {
         const int tw = ch - NW;
         if (tw * 32 < it.tn)
-            dst[(u64)(2 * NW + tw) * 64] = load32_dir(ref.bases, it.g.t_base + (i64)it.g.t_dir * (tw * 32), it.g.t_dir, 0);
+            dst[(u64)(2 * NW + tw) * 64] = load32_dir(ref.bases, it.g.t_base + (i64)it.g.t_dir * (tw * 32), it.g.t_dir, it.g.t_comp);
     }
 }
 
@@ -375,6 +378,14 @@ k_myers(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__
 NECAT_D int dpp_from_lane_below(int v)   // lane i receives v of lane i-1 (within a row of 16); row lane 0 gets 1
 {
     return __builtin_amdgcn_update_dpp(1, v, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+}
+// the same for lane groups wider than a DPP row (the 32 / 44 words of a 2048-bp block): wave_shr:1, lane i receives v of lane i - 1
+// across the whole wave (GFX9 DPP control 0x138); wave lane 0 gets 1
+template <int G>
+NECAT_D int lane_below(int v)
+{
+    if (G <= 16) return dpp_from_lane_below(v);
+    return __builtin_amdgcn_update_dpp(1, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 
 
@@ -647,7 +658,7 @@ NECAT_D void myers_coop_wave(const ListView& lv, const BlockItem* __restrict__ i
     int S = (b + 1) * 64, best = -1, end0 = -1, hout = 1;
     for (int s = 0; s < steps; ++s) {
         const int c = s - b;
-        int hin = dpp_from_lane_below(hout);
+        int hin = lane_below<G>(hout);
         if (b == 0) hin = 1;
         if (have && (u32)c < (u32)tn) {
             if ((c & 31) == 0) tcur = tw[c >> 5];
@@ -687,7 +698,7 @@ NECAT_D void myers_coop_wave(const ListView& lv, const BlockItem* __restrict__ i
     u32 kept = 0;
     for (int s = 0; s < steps; ++s) {
         const int c = s - b;
-        int hin = dpp_from_lane_below(hout);
+        int hin = lane_below<G>(hout);
         if (b == 0) hin = 1;
         if (go && (u32)c < (u32)tn2) {
             if ((c & 31) == 0) tcur = tw[c >> 5];
@@ -764,12 +775,12 @@ k_myers_a16(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
     myers_coop_wave<NW, TW, COLS, 8, false>(lv, items, frag, slabs, slab_bytes, error, results, stats, epoch, first + 8ull * wv, tl + 8 * wv, lane);
 }
 
-// maximum over the active lanes of a value below 2048 (bit by bit with ballots: exited lanes do not take part)
+// maximum over the active lanes of a value below 8192 (bit by bit with ballots: exited lanes do not take part)
 NECAT_D int wave_max_u11(int v)
 {
     int best = 0;
     bool in = true;
-    for (int bit = 10; bit >= 0; --bit) {
+    for (int bit = 12; bit >= 0; --bit) {
         const bool has = in && ((v >> bit) & 1);
         if (__ballot(has)) { best |= 1 << bit; in = has; }
     }
@@ -809,7 +820,7 @@ struct SameReader {   // query fragment element i == target fragment element i ?
 // EXPORT = false: fold the block into its ExtTask.  EXPORT = true (batch API): keep the ops.
 // WALK: 0 = traceback_block (the reference formulation, the default), 1 = walk_block, 2 = walk_block without record prefetch
 // (a template parameter, not a run-time switch: the two walks in one kernel cost the faster one its registers)
-template <int NW, int TW, int COLS, int MAXOPS, bool EXPORT, int WALK = 0>
+template <int NW, int TW, int COLS, int MAXOPS, bool EXPORT, int WALK = 0, int BLOCK = kOcaBlockSize, bool ONE_LIST = false>
 __global__ void __launch_bounds__(64)
 k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, const char* __restrict__ slabs, size_t slab_bytes,
             const BlockResult* __restrict__ results, u8* __restrict__ ops_pool, ExtTask* __restrict__ tasks, int tail_match_len,
@@ -877,9 +888,9 @@ k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
         }
         if (sh) reg[w] = acc;                                   // the bits above `sh` are zero: the next block ORs into them
     }
-    const bool go = ext_plan(t);       // schedule the candidate's next block for the next round (or finish it)
+    const bool go = ext_plan<BLOCK>(t);       // schedule the candidate's next block for the next round (or finish it)
     tasks[it.task] = t;
-    ext_append_block(t, (u32)it.task, go, next);
+    ext_append_block<BLOCK, ONE_LIST>(t, (u32)it.task, go, next);
 }
 
 // ---- final records: pm_worker.c:56-80 (M4 fields), oc_aligner.c:419-450 (coordinates, identity) ----

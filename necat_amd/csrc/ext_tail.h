@@ -84,7 +84,7 @@ k_tail_fused(DevVolume reads, DevVolume ref, const BlockItem* __restrict__ items
         fr[lane] = nlo; fr[NW + lane] = nhi;
     } else if (lane < NW + TW) {
         const int tw = lane - NW;
-        const u64 x = tw * 32 < tn ? load32_dir(ref.bases, it.g.t_base + (i64)it.g.t_dir * (tw * 32), it.g.t_dir, 0) : 0ULL;
+        const u64 x = tw * 32 < tn ? load32_dir(ref.bases, it.g.t_base + (i64)it.g.t_dir * (tw * 32), it.g.t_dir, it.g.t_comp) : 0ULL;
         fr[2 * NW + tw] = x;
         tpl[tw] = even_bits(x) | (even_bits(x >> 1) << 32);
     }

@@ -16,6 +16,7 @@
 #include "ext_kernels.h"
 #include "ext_tail.h"
 #include "asm_kernels.h"
+#include "asm_coop.h"
 #include "cns_loop.h"
 #include "cns_rescue.h"
 #include "rm_host.h"
@@ -69,7 +70,8 @@ int g_fast;            // NECAT_FAST=0: the list-A DP kernel never takes its ful
 int g_fast16;          // NECAT_FAST16=1: list A's big rounds through k_myers_a16 (16 full blocks per workgroup: SHW 8 lanes, NW 4 lanes per block)
 size_t g_band_pool;    // NECAT_BAND_POOL_MB (default 16384): cap of one band-record pool; a bigger list runs in several DP + walk launches (0 = no cap)
 int g_walk;            // NECAT_WALK=0: k_traceback runs the reference formulation of the walk (A/B measurements)
-u32 g_tail_fused;      // NECAT_TAIL_FUSED (default 640; 0 = off): lists of at most this many blocks run as ONE launch per round with the band in LDS (ext_tail.h)
+u32 g_tail_fused;      // NECAT_TAIL_FUSED (default 512 = one workgroup per block at 2 per CU; 0 = off): lists of at most this many blocks run as ONE launch per round with the band in LDS (ext_tail.h)
+int g_asm_lane;        // NECAT_ASM_LANE=1: necat_asm_align_batch through the lane-per-alignment kernel (k_asm_align), the second implementation
 int g_dbg;             // NECAT_DBG: profiling-only variants of the lane-per-block DP kernel (1 = no band stores, 2 = no NW pass)
 
 // Tuning / test knobs: process-wide, (re)read from the environment whenever a context is created, defaults otherwise.
@@ -79,7 +81,8 @@ void read_knobs()
     g_coop_threshold = (u32)num("NECAT_COOP_THRESHOLD", 0xffffffffu);
     g_seed_budget = num("NECAT_SEED_BUDGET", 48ULL << 20);
     g_single_pass = (u32)num("NECAT_SINGLE_PASS", 4096);
-    g_tail_fused = (u32)num("NECAT_TAIL_FUSED", 640);
+    g_tail_fused = (u32)num("NECAT_TAIL_FUSED", 512);
+    g_asm_lane = (int)num("NECAT_ASM_LANE", 0);
     g_batch_cap = (u32)std::max<unsigned long long>(64, num("NECAT_BATCH", 786432));
     g_index_lds = (int)num("NECAT_INDEX_LDS", 1);
     g_seed_wave = (int)num("NECAT_SEED_WAVE", 1);
@@ -628,6 +631,26 @@ int necat_index_download(necat_ctx* ctx, const necat_index* ix, uint64_t* kmer_s
             }
         }
     }
+    if (offset_list && ix->n_offsets) NECAT_HIP(ctx, hipMemcpy(offset_list, ix->offset_list, ix->n_offsets * 8, hipMemcpyDeviceToHost));
+    return NECAT_OK;
+}
+
+int necat_index_sparse_size(const necat_index* ix, uint64_t* n_pairs, uint64_t* n_compact)
+{
+    if (!ix) return NECAT_ERR_ARG;
+    const bool sparse = ix->words != nullptr && ix->kmer_stats == nullptr;
+    if (n_pairs) *n_pairs = sparse ? ix->table_entries / 64 : 0;
+    if (n_compact) *n_compact = sparse ? ix->n_compact : 0;
+    return NECAT_OK;
+}
+
+int necat_index_download_sparse(necat_ctx* ctx, const necat_index* ix, uint64_t* pairs, uint64_t* compact, uint64_t* offset_list)
+{
+    if (!ctx || !ix) return NECAT_ERR_ARG;
+    if (!ix->words || ix->kmer_stats) return set_err(ctx, NECAT_ERR_ARG, "the index holds the dense table (k = %d): use necat_index_download", ix->k);
+    NECAT_HIP(ctx, hipSetDevice(ctx->device));
+    if (pairs) NECAT_HIP(ctx, hipMemcpy(pairs, ix->words, (size_t)(ix->table_entries / 64) * sizeof(IdxWord), hipMemcpyDeviceToHost));
+    if (compact && ix->n_compact) NECAT_HIP(ctx, hipMemcpy(compact, ix->compact, ix->n_compact * 8, hipMemcpyDeviceToHost));
     if (offset_list && ix->n_offsets) NECAT_HIP(ctx, hipMemcpy(offset_list, ix->offset_list, ix->n_offsets * 8, hipMemcpyDeviceToHost));
     return NECAT_OK;
 }
@@ -1542,6 +1565,131 @@ int necat_map_pair(necat_ctx* ctx, const necat_index* ix, const necat_volume* re
 
 // ------------------------------------------------------------------------------------------ the block aligner of oc2asmpm
 
+namespace {
+// The cooperative path (asm_coop.h): every anchor an ExtTask, one block per task and round, the extension stage's kernels at the
+// 2048-bp geometry.  h: validated anchors with local ids.
+int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* reads, const std::vector<AsmAnchor>& h, double error, int min_align_size,
+                   necat_alignment** aln, uint8_t** ops, uint64_t** ops_off)
+{
+    const uint64_t n = h.size();
+    hipStream_t s = ctx->stream;
+    const DevVolume drd = dev_view(reads), dref = dev_view(ref);
+    // per-task column region: left stream (<= qoff + soff columns) then right stream (<= what is left of both reads), 2 bits per column
+    std::vector<u64> base(n + 1, 0);
+    for (uint64_t i = 0; i < n; ++i) {
+        const u64 ql = reads->h_seq_off[h[i].q + 1] - reads->h_seq_off[h[i].q], sl = ref->h_seq_off[h[i].s + 1] - ref->h_seq_off[h[i].s];
+        base[i + 1] = base[i] + ((ql + sl + (u64)h[i].qoff + (u64)h[i].soff + 64) / 32 + 2) * 8;
+    }
+    const u32 groups = (u32)((n + 63) / 64);
+    // band pool: a list runs in chunks of what the pool holds (as the 512-bp stage's capped pools), at least one group
+    const size_t pool_cap = g_band_pool ? std::max<size_t>(g_band_pool, kAsmSlab) : (size_t)64 << 30;
+    const u32 gchunk = (u32)std::max<size_t>(1, std::min<size_t>(groups, pool_cap / kAsmSlab));
+    int rc;
+    const size_t misc = n * (sizeof(AsmAnchor) + sizeof(ExtTask) + 2 * sizeof(BlockItem) + 8 + sizeof(BlockResult)) + 64 * sizeof(BlockResult) + (n + 1) * 8 + 4096;
+    if ((rc = buf_ensure(ctx, ctx->scratch[SC_ASM_BAND], (size_t)gchunk * kAsmSlab)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_OPS], (size_t)groups * 64 * kAsmMaxOps)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_FRAG], (size_t)groups * 64 * kAsmFragWords * 8)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_COLS], base[n] + 64)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_MISC], misc))) return rc;
+    char* mb = (char*)ctx->scratch[SC_ASM_MISC].p;
+    auto take = [&](size_t bytes) { char* p = mb; mb += (bytes + 255) & ~(size_t)255; return p; };
+    u32* d_count = (u32*)take(256);                    // [0..3] list 0, [4..7] list 1 (ExtLists counters: [1] = the plain list), [16] error flag, [32..] work counters
+    int* d_err = (int*)(d_count + 16);
+    unsigned long long* d_stats = (unsigned long long*)(d_count + 32);
+    AsmAnchor* d_anchor = (AsmAnchor*)take(n * sizeof(AsmAnchor));
+    ExtTask* d_tasks = (ExtTask*)take(n * sizeof(ExtTask));
+    BlockItem* d_items[2]; d_items[0] = (BlockItem*)take(n * sizeof(BlockItem)); d_items[1] = (BlockItem*)take(n * sizeof(BlockItem));
+    u64* d_base = (u64*)take((n + 1) * 8);
+    BlockResult* d_res = (BlockResult*)take(((size_t)groups * 64) * sizeof(BlockResult));
+    u8* d_cols = (u8*)ctx->scratch[SC_ASM_COLS].p;
+    NECAT_HIP(ctx, hipMemcpyAsync(d_anchor, h.data(), n * sizeof(AsmAnchor), hipMemcpyHostToDevice, s));
+    NECAT_HIP(ctx, hipMemcpyAsync(d_base, base.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+    NECAT_HIP(ctx, hipMemsetAsync(d_count, 0, 256, s));
+    NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
+    ctx->tm.myers_ms = ctx->tm.traceback_ms = 0; ctx->tm.myers_launches = ctx->tm.myers_blocks = ctx->tm.rounds = 0;
+    auto lists = [&](int k) { ExtLists L; L.count = d_count + 4 * k; L.itemsA = nullptr; L.itemsB = d_items[k]; L.task_ops = d_cols; L.capA = 0; return L; };
+    hipLaunchKernelGGL(k_asm_init, dim3(grid_for(n, 256)), dim3(256), 0, s, (const AsmAnchor*)d_anchor, (u32)n, (const u64*)reads->seq_off, (const u64*)ref->seq_off, d_tasks, lists(0),
+                       (const u64*)d_base);
+    NECAT_CHECK_LAUNCH(ctx, "k_asm_init");
+    for (u32 r = 0;; ++r) {
+        if (r > 4096) return set_err(ctx, NECAT_ERR_INTERNAL, "asm aligner: no end of rounds");
+        const int cur = (int)(r & 1), nxt = cur ^ 1;
+        u32 nb = 0;
+        NECAT_HIP(ctx, hipMemcpyAsync(&nb, d_count + 4 * cur + 1, 4, hipMemcpyDeviceToHost, s));
+        NECAT_HIP(ctx, hipStreamSynchronize(s));
+        if (nb == 0) break;
+        NECAT_HIP(ctx, hipMemsetAsync(d_count + 4 * nxt, 0, 16, s));
+        const u32 gB = (nb + 63) / 64;
+        RoundCtl ctl;
+        hipLaunchKernelGGL((k_ext_frag<kAsmWords, kAsmTWords>), dim3(grid_for((u64)gB * 64 * (kAsmWords + kAsmTWords), 256)), dim3(256), 0, s,
+                           drd, dref, (const BlockItem*)d_items[cur], nb, (const u32*)nullptr, 0u, (u64*)ctx->scratch[SC_ASM_FRAG].p, ctl);
+        NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<asm>");
+        const ExtLists next = lists(nxt);
+        for (u32 g0 = 0; g0 < gB; g0 += gchunk) {
+            const u32 lo = g0 * 64, hi = std::min(nb, (g0 + gchunk) * 64), cn = hi - lo;
+            char* slabs = (char*)ctx->scratch[SC_ASM_BAND].p - (size_t)g0 * kAsmSlab;            // the kernels index slabs by item / 64
+            const u32 epoch = ++ctx->epoch & 0x3fffffu;
+            NECAT_HIP(ctx, hipEventRecord(ctx->ev[2], s));
+            hipLaunchKernelGGL((k_myers_coop<kAsmWords, kAsmTWords, kAsmCols, 64>), dim3(cn), dim3(64), 0, s, (const BlockItem*)d_items[cur], hi, (const u32*)nullptr, 0u,
+                               (const u64*)ctx->scratch[SC_ASM_FRAG].p, slabs, kAsmSlab, error, d_res, d_stats, epoch, lo);
+            NECAT_CHECK_LAUNCH(ctx, "k_myers_coop<asm>");
+            NECAT_HIP(ctx, hipEventRecord(ctx->ev[3], s));
+            hipLaunchKernelGGL((k_traceback<kAsmWords, kAsmTWords, kAsmCols, kAsmMaxOps, false, 0, kAsmBlock, true>), dim3((cn + 63) / 64), dim3(64), 0, s,
+                               (const BlockItem*)d_items[cur], hi, (const u32*)nullptr, 0u, (const u64*)ctx->scratch[SC_ASM_FRAG].p, (const char*)slabs, kAsmSlab,
+                               (const BlockResult*)d_res, (u8*)ctx->scratch[SC_ASM_OPS].p, d_tasks, 8 /* kMatchCnt2: the tail match length of hbn_align */, (i32*)nullptr, d_err, next, epoch, lo);
+            NECAT_CHECK_LAUNCH(ctx, "k_traceback<asm>");
+            NECAT_HIP(ctx, hipEventRecord(ctx->ev[24], s));
+            NECAT_HIP(ctx, hipStreamSynchronize(s));
+            ctx->tm.myers_ms += ev_ms(ctx->ev[2], ctx->ev[3]); ctx->tm.traceback_ms += ev_ms(ctx->ev[3], ctx->ev[24]);
+            ctx->tm.myers_launches += 1;
+        }
+        ctx->tm.myers_blocks += nb; ctx->tm.rounds += 1;
+        if (g_trace & 1) fprintf(stderr, "[necat] asm round %u: %u blocks, DP %.3f ms + walk %.3f ms so far\n", r, nb, ctx->tm.myers_ms, ctx->tm.traceback_ms);
+    }
+    // results: coordinates + identity per anchor, the alignment columns packed in anchor order (as necat_onc_align_batch)
+    const size_t out_fixed = n * (sizeof(necat_alignment) + 4 + 8) + 1024;
+    if ((rc = buf_ensure(ctx, ctx->scratch[SC_ASM_OUT], out_fixed))) return rc;
+    char* ob = (char*)ctx->scratch[SC_ASM_OUT].p;
+    necat_alignment* d_aln = (necat_alignment*)ob; ob += (n * sizeof(necat_alignment) + 255) & ~(size_t)255;
+    u32* d_len = (u32*)ob; ob += (n * 4 + 255) & ~(size_t)255;
+    u64* d_off = (u64*)ob;
+    hipLaunchKernelGGL(k_ext_alignment, dim3(grid_for(n, 256)), dim3(256), 0, s, (const ExtTask*)d_tasks, (u32)n, 0u, min_align_size, d_aln, d_len);
+    NECAT_CHECK_LAUNCH(ctx, "k_ext_alignment");
+    necat_alignment* res = (necat_alignment*)result_alloc(n * sizeof(necat_alignment));
+    uint64_t* off = (uint64_t*)result_alloc((n + 1) * 8);
+    std::vector<u32> len(n);
+    int herr = 0;
+    auto fail = [&](int code) { necat_free(res); necat_free(off); return code; };
+    if (!res || !off) return fail(set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"));
+    if (hipMemcpyAsync(len.data(), d_len, n * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipMemcpyAsync(res, d_aln, n * sizeof(necat_alignment), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return fail(set_err(ctx, NECAT_ERR_DEVICE, "asm aligner: result copy failed: %s", hipGetErrorString(hipGetLastError())));
+    if (herr) return fail(set_err(ctx, NECAT_ERR_INTERNAL, "asm aligner: the kernels reported error code %d", herr));
+    // every alignment starts on a 64-bit word: 32 columns per word (offsets in bytes)
+    std::vector<u64> woff(n + 1, 0);
+    for (uint64_t i = 0; i < n; ++i) woff[i + 1] = woff[i] + (len[i] + 31) / 32;
+    for (uint64_t i = 0; i <= n; ++i) off[i] = woff[i] * 8;
+    const u64 tot = woff[n] * 8;
+    uint8_t* packed = (uint8_t*)result_alloc(std::max<u64>(8, tot));
+    if (!packed) return fail(set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"));
+    if (tot) {
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_COLS_OUT], tot + 64))) { necat_free(packed); return fail(rc); }
+        hipError_t e = hipMemcpyAsync(d_off, woff.data(), n * 8, hipMemcpyHostToDevice, s);
+        hipLaunchKernelGGL(k_ext_strings, dim3(grid_for((u64)n * 64, 256)), dim3(256), 0, s, (const ExtTask*)d_tasks, (u32)n, (const u8*)d_cols, (const u64*)d_off, (u64*)ctx->scratch[SC_EXT_COLS_OUT].p);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(packed, ctx->scratch[SC_EXT_COLS_OUT].p, tot, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev[1], s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) { necat_free(packed); return fail(set_err(ctx, NECAT_ERR_DEVICE, "asm aligner: column copy failed: %s", hipGetErrorString(e))); }
+    } else { (void)hipEventRecord(ctx->ev[1], s); (void)hipStreamSynchronize(s); }
+    ctx->tm.extend_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
+    if (g_trace & 2) fprintf(stderr, "[necat] asm_align (cooperative): %lu anchors, %lu rounds, %lu blocks, DP %.2f ms, walk %.2f ms, whole call %.2f ms\n", (unsigned long)n,
+                             (unsigned long)ctx->tm.rounds, (unsigned long)ctx->tm.myers_blocks, ctx->tm.myers_ms, ctx->tm.traceback_ms, ctx->tm.extend_ms);
+    *aln = res; *ops = packed; *ops_off = off;
+    return NECAT_OK;
+}
+}  // namespace
+
 int necat_asm_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_volume* reads, int read_start_id, int ref_start_id,
                           const necat_asm_anchor* anchors, uint64_t n, double error, int min_align_size,
                           necat_alignment** aln, uint8_t** ops, uint64_t** ops_off)
@@ -1564,6 +1712,7 @@ int necat_asm_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_v
         h[i].q = (i32)lq; h[i].s = (i32)ls; h[i].sdir = a.sdir; h[i].qoff = a.qoff; h[i].soff = a.soff;
         coff[i + 1] = coff[i] + ((ql + sl + 64 + 7) & ~7ULL);          // a column consumes at least one base of one of the two
     }
+    if (n && !g_asm_lane) return asm_align_coop(ctx, ref, reads, h, error, min_align_size, aln, ops, ops_off);
     necat_alignment* res = (necat_alignment*)result_alloc(std::max<uint64_t>(1, n) * sizeof(necat_alignment));
     uint64_t* off = (uint64_t*)result_alloc((n + 1) * 8);
     if (!res || !off) { necat_free(res); necat_free(off); return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }

@@ -36,6 +36,16 @@ def test_index_matches_oracle(ctx, small):
         ostats, ooffs = ora.build_index(os.path.join(d, "vol0"), k, q)
         assert np.array_equal(stats, ostats)
         assert np.array_equal(offs, ooffs)
+        # the table as the device holds it (what a host-side reader copies instead of the dense array: necat_index_download_sparse)
+        sp = ix.download_sparse()
+        assert (sp is None) == (k < 11)
+        if sp is not None:
+            from necat_amd import shard
+            bits, base, compact, soffs = sp
+            assert np.array_equal(soffs, ooffs)
+            assert int((ostats != 0).sum()) == compact.shape[0]
+            h = np.concatenate([np.flatnonzero(ostats)[:5000], np.random.default_rng(k).integers(0, ostats.shape[0], 5000)]).astype(np.uint64)
+            assert np.array_equal(shard.sparse_lookup(bits, base, compact, h), ostats[h.astype(np.int64)])
         ix.free()
     vol.free()
 

@@ -11,7 +11,14 @@ from oracle import oracle_api as ora
 pytestmark = pytest.mark.gpu
 
 
-def test_asm_align_arbitrary_anchors(ctx):
+@pytest.mark.parametrize("impl", ["cooperative", "lane"])
+def test_asm_align_arbitrary_anchors(ctx, monkeypatch, impl):
+    """cooperative: the default path (asm_coop.h - the extension stage's round structure and kernels at the 2048-bp geometry);
+    lane: the lane-per-alignment kernel it replaced, kept as the second implementation (NECAT_ASM_LANE=1)"""
+    own = None
+    if impl == "lane":
+        monkeypatch.setenv("NECAT_ASM_LANE", "1")
+        own = ctx = capi.Context(0)          # knobs are read when a context is created
     rng = np.random.default_rng(654)
     seqs, rows = [], []
     for it in range(60):
@@ -58,4 +65,9 @@ def test_asm_align_arbitrary_anchors(ctx):
         ctx.asm_align_batch(vol, vol, 0, 0, bad)
     aln, ops, off = ctx.asm_align_batch(vol, vol, 0, 0, anchors[:0])
     assert aln.shape[0] == 0 and off.shape[0] == 1
+    if impl == "cooperative":
+        tm = ctx.timings()
+        assert tm.rounds >= 1 or len(rows) == 0          # (the empty call above ran no round; the counters are the last non-empty call's only if > 0)
     vol.free()
+    if own is not None:
+        own.close()
