@@ -12,8 +12,8 @@
 //                                task's 2-bit column stream, the next block planned and appended to the next round's list
 //   and after the last round k_ext_alignment / k_ext_strings give every anchor's coordinates, identity and alignment columns - exactly the outputs
 //   of necat_onc_align_batch.
-// One list per round (ExtLists' list B arrays used as a plain list: ONE_LIST), rounds synchronous on the host - a corrected read is 3 - 5 blocks
-// long, so a call is a handful of rounds.  The lane-per-alignment kernel this replaces (k_asm_align, asm_kernels.h: 512 registers + scratch per lane,
+// Two lists per round as in the 512-bp stage (A: blocks up to 2048 x 2048 - 32 words, 32 lanes per block; B: the longer last blocks - 44 words, one
+// block per wave), rounds synchronous on the host - a corrected read is 3 - 5 blocks long, so a call is a handful of rounds.  The lane-per-alignment kernel this replaces (k_asm_align, asm_kernels.h: 512 registers + scratch per lane,
 // a 126 MB band slab per wave, one wave per SIMD) stays as the second implementation the tests compare with (NECAT_ASM_LANE=1).
 #pragma once
 #include "asm_kernels.h"
@@ -21,6 +21,11 @@
 
 namespace necat {
 
+// two lists as in the 512-bp stage: A = blocks of at most 2048 x 2048 (32 words: 32 lanes per block, two blocks per wave), B = the
+// longer last blocks (up to 2791 x 2791, 44 words: one block per wave)
+constexpr int kAsmWordsA = kAsmBlock / 64, kAsmTWordsA = kAsmBlock / 32, kAsmOpsA = 2 * kAsmBlock + 16;
+constexpr int kAsmFragWordsA = 2 * kAsmWordsA + kAsmTWordsA;
+constexpr size_t kAsmSlabA = (size_t)kAsmBlock * kAsmWordsA * 64 * sizeof(BandRec);          // 67 MB per 64 items (sparsely written)
 constexpr int kAsmTWords = (kAsmCols + 31) / 32;                  // 88 target words of 32 columns
 constexpr int kAsmFragWords = 2 * kAsmWords + kAsmTWords;         // u64 per item in the fragment buffer
 constexpr int kAsmMaxOps = 2 * kAsmCols + 16;                     // ops of one block alignment (<= qn + tn)
@@ -43,7 +48,7 @@ k_asm_init(const AsmAnchor* __restrict__ anchors, u32 n, const u64* __restrict__
         go = ext_plan<kAsmBlock>(t);
         tasks[i] = t;
     }
-    ext_append_block<kAsmBlock, true>(t, i, go, L);
+    ext_append_block<kAsmBlock, false>(t, i, go, L);
 }
 
 }  // namespace necat

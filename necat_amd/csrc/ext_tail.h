@@ -27,12 +27,116 @@ struct LdsBand {          // Mat of walk_block: band[c * nblk + b]
     const ulonglong2* band; int nblk;
     NECAT_D void rec(int c, int b, u64& A, u64& B) const { const ulonglong2 v = band[c * nblk + b]; A = v.x; B = v.y; }
 };
-struct LdsOpsSink {       // Sink of walk_block: op i at ops[i]
-    u8* ops; int cap; int overflow; bool store;
-    NECAT_D bool storing() const { return store; }
-    NECAT_D void put(int i, int op) { if (i < cap) ops[i] = (u8)op; else overflow = 1; }
-};
 struct LdsOpsReader { const u8* ops; NECAT_D int operator()(int j) const { return ops[j]; } };
+struct LdsOpsSink {       // Sink of walk_block: op i at ops[i] (every lane of the wave runs the same walk; lane 0 writes)
+    u8* ops; int cap; int overflow; bool store, writer;
+    NECAT_D bool storing() const { return store; }
+    NECAT_D void put(int i, int op) { if (i < cap) { if (writer) ops[i] = (u8)op; } else overflow = 1; }
+};
+
+// Band records of ONE block read from its slab in global memory through a window staged in LDS by the whole wave: every lane runs
+// the same walk (same values, uniform control flow), and when the walk asks for a record outside the window all 64 lanes fetch
+// the 64 columns (c, c - 1, .., c - 63) of the word asked for and of the word above it - one load instruction per word, eight
+// 128-byte lines each ([column / 8][word][lane][column % 8], rec_pos) - so the walk waits for memory once per <= 64 columns instead
+// of once per step (the lane-per-block walk of k_traceback: one dependent 16-byte load per step, ~ 0.45 - 1 us each when few
+// blocks are in flight).
+template <int NW>
+struct WinBand {
+    const ulonglong2* slab; ulonglong2* win;      // win[2][64] in LDS
+    int il, lane, wb, chi;
+    NECAT_D void init() { wb = -1000; chi = -1000; }
+    NECAT_D void rec(int c, int b, u64& A, u64& B)
+    {
+        const bool hit = (b == wb || b == wb - 1) && c <= chi && c > chi - 64;
+        if (!hit) {                 // wave-uniform
+            __syncthreads();        // (one wave per workgroup) nobody still reads the old window
+            wb = b; chi = c;
+            const int col = c - lane;
+            if (col >= 0) {
+                win[lane] = slab[rec_pos<NW>(col, b, il)];
+                if (b > 0) win[64 + lane] = slab[rec_pos<NW>(col, b - 1, il)];
+            }
+            __syncthreads();
+        }
+        const ulonglong2 v = win[(b == wb ? 0 : 64) + (chi - c)];
+        A = v.x; B = v.y;
+    }
+};
+
+// What follows a block's DP, by ONE wave that owns the block: the walk (every lane runs it, see WinBand / LdsBand), then on lane 0
+// the tail trimming + the candidate's counters (ext_finish_block), by all lanes the kept alignment columns into the task's 2-bit
+// stream (when the caller keeps them), on lane 0 the plan of the next block, and the append to the next round's lists.
+// ops: MAXOPS bytes of LDS.  The tail of k_traceback, for a wave instead of a lane.
+template <int MAXOPS, int BLOCK, class Mat, class Same>
+NECAT_D void wave_after_dp(const int lane, const BlockItem& it, const int dist, const int endc, Mat& mat, Same& same, u8* ops,
+                           ExtTask* __restrict__ tasks, const int tail_match_len, int* __restrict__ err_flag, const ExtLists& next)
+{
+    ExtTask t;
+    ExtKept kept; kept.at = 0; kept.cols = 0; kept.exact = 0;
+    int nops = 0, stream_at = 0, done = 0, found = 0;
+    bool go = false;
+    if (lane == 0) { t = tasks[it.task]; done = ext_block_done(t, dist, endc); found = t.found; }
+    done = __shfl(done, 0); found = __shfl(found, 0);
+    TailScan ts;
+    tail_init(ts, !done ? kOcaMatCnt : tail_match_len);
+    LdsOpsSink sk; sk.ops = ops; sk.cap = MAXOPS; sk.overflow = 0; sk.writer = lane == 0;
+    sk.store = !found || next.task_ops != nullptr;       // the op list is only replayed until the stream's first run of 8 matches - unless the columns are kept
+    if (dist >= 0) {
+        walk_block(it.qn, endc + 1, mat, sk, ts);
+        if (sk.overflow && lane == 0) atomicExch(err_flag, 20);
+    }
+    __syncthreads();              // lane 0's ops are in LDS
+    if (lane == 0) {
+        LdsOpsReader rd; rd.ops = ops;
+        stream_at = t.phase == 1 ? t.s_lto : 0;
+        kept = ext_finish_block(t, dist, endc, done, ts, rd, same);
+        nops = ts.n;
+    }
+    if (next.task_ops) {
+        // the kept columns join the task's stream, 2 bits per column: forward column f of the block is op nops - 1 - f (k_traceback)
+        const u64 ops_base = __shfl(lane == 0 ? t.ops_base : 0ULL, 0);
+        const int at = __shfl(stream_at + kept.at, 0), ncol = __shfl(kept.cols, 0), exact = __shfl(kept.exact, 0), n = __shfl(nops, 0);
+        u64* reg = reinterpret_cast<u64*>(next.task_ops + ops_base);
+        // words of the stream this block touches: [at, at + ncol) columns; the first one may hold earlier columns (kept), the last
+        // one's upper bits are zero (the next block ORs into them)
+        const int w0 = at >> 5, w1 = (at + ncol + 31) >> 5;
+        for (int w = w0 + lane; w < w1; w += 64) {
+            u64 acc = 0;
+            const int c_lo = w * 32 > at ? w * 32 : at, c_hi = (w + 1) * 32 < at + ncol ? (w + 1) * 32 : at + ncol;
+            if (w * 32 < at) acc = reg[w] & ((1ULL << ((at & 31) * 2)) - 1);
+            if (!exact) for (int col = c_lo; col < c_hi; ++col) acc |= (u64)ops[n - 1 - (col - at)] << ((col & 31) * 2);
+            reg[w] = acc;
+        }
+    }
+    if (lane == 0) {
+        go = ext_plan<BLOCK>(t);
+        tasks[it.task] = t;
+    }
+    ext_append_block<BLOCK>(t, (u32)it.task, go, next);
+}
+
+// The walk of a SMALL list with one wave per block (WinBand): the DP kernels ran as usual (band records in the list's slabs), this
+// replaces k_traceback for lists where a lane-per-block walk would leave the chip empty and pay a memory round trip per step.
+template <int NW, int TW, int MAXOPS, int BLOCK = kOcaBlockSize>
+__global__ void __launch_bounds__(64)
+k_walk_wave(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, const char* __restrict__ slabs, size_t slab_bytes,
+            const BlockResult* __restrict__ results, ExtTask* __restrict__ tasks, int tail_match_len, int* __restrict__ err_flag, ExtLists next, u32 item_base)
+{
+    constexpr int FW = 2 * NW + TW;
+    __shared__ ulonglong2 win[128];
+    __shared__ u8 ops[MAXOPS];
+    const int lane = (int)threadIdx.x;
+    const ListView lv = list_view(n_host, n_dev, capA);
+    const u64 item = (u64)item_base + blockIdx.x;
+    BlockItem it;
+    if (!list_item(lv, items, item, it)) return;          // uniform: the workgroup is one work item
+    const BlockResult br = results[item];
+    if (br.err && lane == 0) atomicExch(err_flag, 10 + br.err);
+    const u64 grp = item >> 6;
+    WinBand<NW> mat; mat.slab = slab_records(const_cast<char*>(slabs) + (size_t)grp * slab_bytes); mat.win = win; mat.il = (int)(item & 63); mat.lane = lane; mat.init();
+    SameReader<NW> same; same.fr = frag + grp * FW * 64 + (item & 63);
+    wave_after_dp<MAXOPS, BLOCK>(lane, it, br.dist, br.endc, mat, same, ops, tasks, tail_match_len, err_flag, next);
+}
 template <int NW>
 struct LdsSame {          // query fragment element i == target fragment element i ?  (fr: [~lo planes NW][~hi planes NW][target 2-bit words])
     const u64* fr;
@@ -138,53 +242,12 @@ k_tail_fused(DevVolume reads, DevVolume ref, const BlockItem* __restrict__ items
         }
     }
     __syncthreads();
-    // ---- walk, trimming, the candidate's counters, its next block: lane 0 (the other lanes join for the kept columns and the append)
+    // ---- walk, trimming, the candidate's counters, its kept columns, its next block
     const int dist = res[0], endc = res[1];
-    ExtTask t;
-    ExtKept kept; kept.at = 0; kept.cols = 0; kept.exact = 0;
-    int nops = 0, stream_at = 0;
-    bool go = false;
-    if (lane == 0) {
-        t = tasks[it.task];
-        const int done = ext_block_done(t, dist, endc);
-        TailScan ts;
-        tail_init(ts, !done ? kOcaMatCnt : tail_match_len);
-        LdsOpsSink sk; sk.ops = ops; sk.cap = MAXOPS; sk.overflow = 0;
-        sk.store = !t.found || next.task_ops != nullptr;       // the op list is only replayed until the stream's first run of 8 matches - unless the columns are kept
-        if (dist >= 0) {
-            LdsBand mr; mr.band = band; mr.nblk = nblk;
-            walk_block(qn, endc + 1, mr, sk, ts);
-            if (sk.overflow) atomicExch(err_flag, 20);
-        }
-        LdsOpsReader rd; rd.ops = ops;
-        LdsSame<NW> same; same.fr = fr;
-        stream_at = t.phase == 1 ? t.s_lto : 0;
-        kept = ext_finish_block(t, dist, endc, done, ts, rd, same);
-        nops = ts.n;
-        atomicAdd(&stats[0], (unsigned long long)(nblk * tn)); atomicAdd(&stats[1], (unsigned long long)(qn + tn));
-    }
-    if (next.task_ops) {
-        // the kept columns join the task's stream, 2 bits per column: forward column f of the block is op nops - 1 - f (k_traceback)
-        __syncthreads();          // lane 0's ops are in LDS
-        const u64 ops_base = __shfl(lane == 0 ? t.ops_base : 0ULL, 0);
-        const int at = __shfl(stream_at + kept.at, 0), ncol = __shfl(kept.cols, 0), exact = __shfl(kept.exact, 0), n = __shfl(nops, 0);
-        u64* reg = reinterpret_cast<u64*>(next.task_ops + ops_base);
-        // words of the stream this block touches: [at, at + ncol) columns; the first one may hold earlier columns (kept), the last
-        // one's upper bits are zero (the next block ORs into them)
-        const int w0 = at >> 5, w1 = (at + ncol + 31) >> 5;
-        for (int w = w0 + lane; w < w1; w += kTailThreads) {
-            u64 acc = 0;
-            const int c_lo = w * 32 > at ? w * 32 : at, c_hi = (w + 1) * 32 < at + ncol ? (w + 1) * 32 : at + ncol;
-            if (w * 32 < at) acc = reg[w] & ((1ULL << ((at & 31) * 2)) - 1);
-            if (!exact) for (int col = c_lo; col < c_hi; ++col) acc |= (u64)ops[n - 1 - (col - at)] << ((col & 31) * 2);
-            reg[w] = acc;
-        }
-    }
-    if (lane == 0) {
-        go = ext_plan(t);
-        tasks[it.task] = t;
-    }
-    ext_append_block(t, (u32)it.task, go, next);
+    if (lane == 0) { atomicAdd(&stats[0], (unsigned long long)(nblk * tn)); atomicAdd(&stats[1], (unsigned long long)(qn + tn)); }
+    LdsBand mr; mr.band = band; mr.nblk = nblk;
+    LdsSame<NW> same; same.fr = fr;
+    wave_after_dp<MAXOPS, kOcaBlockSize>(lane, it, dist, endc, mr, same, ops, tasks, tail_match_len, err_flag, next);
 }
 
 }  // namespace necat

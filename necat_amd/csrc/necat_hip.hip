@@ -71,6 +71,7 @@ int g_fast16;          // NECAT_FAST16=1: list A's big rounds through k_myers_a1
 size_t g_band_pool;    // NECAT_BAND_POOL_MB (default 16384): cap of one band-record pool; a bigger list runs in several DP + walk launches (0 = no cap)
 int g_walk;            // NECAT_WALK=0: k_traceback runs the reference formulation of the walk (A/B measurements)
 u32 g_tail_fused;      // NECAT_TAIL_FUSED (default 512 = one workgroup per block at 2 per CU; 0 = off): lists of at most this many blocks run as ONE launch per round with the band in LDS (ext_tail.h)
+u32 g_walk_wave;       // NECAT_WALK_WAVE (default 12288; 0 = off): lists of at most this many blocks are walked by one WAVE per block through an LDS window (k_walk_wave, ext_tail.h)
 int g_asm_lane;        // NECAT_ASM_LANE=1: necat_asm_align_batch through the lane-per-alignment kernel (k_asm_align), the second implementation
 int g_dbg;             // NECAT_DBG: profiling-only variants of the lane-per-block DP kernel (1 = no band stores, 2 = no NW pass)
 
@@ -83,6 +84,7 @@ void read_knobs()
     g_single_pass = (u32)num("NECAT_SINGLE_PASS", 4096);
     g_tail_fused = (u32)num("NECAT_TAIL_FUSED", 512);
     g_asm_lane = (int)num("NECAT_ASM_LANE", 0);
+    g_walk_wave = (u32)num("NECAT_WALK_WAVE", 12288);
     g_batch_cap = (u32)std::max<unsigned long long>(64, num("NECAT_BATCH", 786432));
     g_index_lds = (int)num("NECAT_INDEX_LDS", 1);
     g_seed_wave = (int)num("NECAT_SEED_WAVE", 1);
@@ -1136,7 +1138,10 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
 #define NECAT_TB_LAUNCH(WALK) hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false, WALK>), dim3((cn + 63) / 64), dim3(64), 0, sb, itB, hi, d_nB, 0u, \
                            (const u64*)c.fragB[slot], (const char*)slabsB, kSlabB, (const BlockResult*)c.resB[slot], c.opsB[slot], c.tasks, X.tail_match_len, \
                            (i32*)nullptr, X.d_err, next, epoch, lo)
-            if (g_walk == 1) NECAT_TB_LAUNCH(1); else if (g_walk == 2) NECAT_TB_LAUNCH(2); else if (g_walk == 3) NECAT_TB_LAUNCH(3); else if (g_walk == 4) NECAT_TB_LAUNCH(4); else NECAT_TB_LAUNCH(0);
+            if (g_walk_wave && nB <= g_walk_wave)       // a small list: one wave per block, band records through an LDS window
+                hipLaunchKernelGGL((k_walk_wave<kWordsB, kTWordsB, kOpsB>), dim3(cn), dim3(64), 0, sb, itB, hi, d_nB, 0u, (const u64*)c.fragB[slot], (const char*)slabsB, kSlabB,
+                                   (const BlockResult*)c.resB[slot], c.tasks, X.tail_match_len, X.d_err, next, lo);
+            else if (g_walk == 1) NECAT_TB_LAUNCH(1); else if (g_walk == 2) NECAT_TB_LAUNCH(2); else if (g_walk == 3) NECAT_TB_LAUNCH(3); else if (g_walk == 4) NECAT_TB_LAUNCH(4); else NECAT_TB_LAUNCH(0);
 #undef NECAT_TB_LAUNCH
             NECAT_CHECK_LAUNCH(ctx, "k_traceback<B>");
         }
@@ -1213,7 +1218,10 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
 #define NECAT_TB_LAUNCH(WALK) hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, WALK>), dim3(cn / 64), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap, \
                            (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len, \
                            (i32*)nullptr, X.d_err, next, epoch, lo)
-            if (g_walk == 1) NECAT_TB_LAUNCH(1); else if (g_walk == 2) NECAT_TB_LAUNCH(2); else if (g_walk == 3) NECAT_TB_LAUNCH(3); else if (g_walk == 4) NECAT_TB_LAUNCH(4); else NECAT_TB_LAUNCH(0);
+            if (g_walk_wave && bound <= g_walk_wave)
+                hipLaunchKernelGGL((k_walk_wave<kWordsA, kTWordsA, kOpsA>), dim3(cn), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap, (const u64*)c.fragA, (const char*)slabsA, kSlabA,
+                                   (const BlockResult*)c.resA, c.tasks, X.tail_match_len, X.d_err, next, lo);
+            else if (g_walk == 1) NECAT_TB_LAUNCH(1); else if (g_walk == 2) NECAT_TB_LAUNCH(2); else if (g_walk == 3) NECAT_TB_LAUNCH(3); else if (g_walk == 4) NECAT_TB_LAUNCH(4); else NECAT_TB_LAUNCH(0);
 #undef NECAT_TB_LAUNCH
             NECAT_CHECK_LAUNCH(ctx, "k_traceback<A>");
         }
@@ -1580,25 +1588,28 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
         const u64 ql = reads->h_seq_off[h[i].q + 1] - reads->h_seq_off[h[i].q], sl = ref->h_seq_off[h[i].s + 1] - ref->h_seq_off[h[i].s];
         base[i + 1] = base[i] + ((ql + sl + (u64)h[i].qoff + (u64)h[i].soff + 64) / 32 + 2) * 8;
     }
-    const u32 groups = (u32)((n + 63) / 64);
-    // band pool: a list runs in chunks of what the pool holds (as the 512-bp stage's capped pools), at least one group
+    const u32 cap = (u32)((n + 63) & ~63ULL) + 64;          // capacity of every item array (list A is filled from both ends)
+    const u32 groups = cap / 64 + 1;
+    // band pools: a list runs in chunks of what its pool holds (as the 512-bp stage's capped pools), at least one group
     const size_t pool_cap = g_band_pool ? std::max<size_t>(g_band_pool, kAsmSlab) : (size_t)64 << 30;
-    const u32 gchunk = (u32)std::max<size_t>(1, std::min<size_t>(groups, pool_cap / kAsmSlab));
+    const u32 gchunkA = (u32)std::max<size_t>(1, std::min<size_t>(groups, pool_cap / kAsmSlabA));
+    const u32 gchunkB = (u32)std::max<size_t>(1, std::min<size_t>(groups, pool_cap / kAsmSlab));
     int rc;
-    const size_t misc = n * (sizeof(AsmAnchor) + sizeof(ExtTask) + 2 * sizeof(BlockItem) + 8 + sizeof(BlockResult)) + 64 * sizeof(BlockResult) + (n + 1) * 8 + 4096;
-    if ((rc = buf_ensure(ctx, ctx->scratch[SC_ASM_BAND], (size_t)gchunk * kAsmSlab)) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_OPS], (size_t)groups * 64 * kAsmMaxOps)) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_FRAG], (size_t)groups * 64 * kAsmFragWords * 8)) ||
+    const size_t misc = n * (sizeof(AsmAnchor) + sizeof(ExtTask) + 8) + (size_t)cap * 4 * sizeof(BlockItem) + (size_t)groups * 64 * 2 * sizeof(BlockResult) + (n + 1) * 8 + 8192;
+    if ((rc = buf_ensure(ctx, ctx->scratch[SC_ASM_BAND], std::max((size_t)gchunkA * kAsmSlabA, (size_t)gchunkB * kAsmSlab))) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_OPS], (size_t)groups * 64 * std::max(kAsmMaxOps, kAsmOpsA))) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_FRAG], (size_t)groups * 64 * std::max(kAsmFragWords, kAsmFragWordsA) * 8)) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_COLS], base[n] + 64)) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_MISC], misc))) return rc;
     char* mb = (char*)ctx->scratch[SC_ASM_MISC].p;
     auto take = [&](size_t bytes) { char* p = mb; mb += (bytes + 255) & ~(size_t)255; return p; };
-    u32* d_count = (u32*)take(256);                    // [0..3] list 0, [4..7] list 1 (ExtLists counters: [1] = the plain list), [16] error flag, [32..] work counters
+    u32* d_count = (u32*)take(256);                    // [0..3] list buffer 0, [4..7] list buffer 1 (ExtLists counters: full A blocks, B blocks, other A blocks), [16] error flag, [32..] work counters
     int* d_err = (int*)(d_count + 16);
     unsigned long long* d_stats = (unsigned long long*)(d_count + 32);
     AsmAnchor* d_anchor = (AsmAnchor*)take(n * sizeof(AsmAnchor));
     ExtTask* d_tasks = (ExtTask*)take(n * sizeof(ExtTask));
-    BlockItem* d_items[2]; d_items[0] = (BlockItem*)take(n * sizeof(BlockItem)); d_items[1] = (BlockItem*)take(n * sizeof(BlockItem));
+    BlockItem* d_itemsA[2]; BlockItem* d_itemsB[2];
+    for (int k = 0; k < 2; ++k) { d_itemsA[k] = (BlockItem*)take((size_t)cap * sizeof(BlockItem)); d_itemsB[k] = (BlockItem*)take((size_t)cap * sizeof(BlockItem)); }
     u64* d_base = (u64*)take((n + 1) * 8);
     BlockResult* d_res = (BlockResult*)take(((size_t)groups * 64) * sizeof(BlockResult));
     u8* d_cols = (u8*)ctx->scratch[SC_ASM_COLS].p;
@@ -1607,44 +1618,87 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
     NECAT_HIP(ctx, hipMemsetAsync(d_count, 0, 256, s));
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
     ctx->tm.myers_ms = ctx->tm.traceback_ms = 0; ctx->tm.myers_launches = ctx->tm.myers_blocks = ctx->tm.rounds = 0;
-    auto lists = [&](int k) { ExtLists L; L.count = d_count + 4 * k; L.itemsA = nullptr; L.itemsB = d_items[k]; L.task_ops = d_cols; L.capA = 0; return L; };
+    auto lists = [&](int k) { ExtLists L; L.count = d_count + 4 * k; L.itemsA = d_itemsA[k]; L.itemsB = d_itemsB[k]; L.task_ops = d_cols; L.capA = cap; return L; };
     hipLaunchKernelGGL(k_asm_init, dim3(grid_for(n, 256)), dim3(256), 0, s, (const AsmAnchor*)d_anchor, (u32)n, (const u64*)reads->seq_off, (const u64*)ref->seq_off, d_tasks, lists(0),
                        (const u64*)d_base);
     NECAT_CHECK_LAUNCH(ctx, "k_asm_init");
+    u64* const d_frag = (u64*)ctx->scratch[SC_ASM_FRAG].p;
+    u8* const d_ops = (u8*)ctx->scratch[SC_ASM_OPS].p;
     for (u32 r = 0;; ++r) {
         if (r > 4096) return set_err(ctx, NECAT_ERR_INTERNAL, "asm aligner: no end of rounds");
         const int cur = (int)(r & 1), nxt = cur ^ 1;
-        u32 nb = 0;
-        NECAT_HIP(ctx, hipMemcpyAsync(&nb, d_count + 4 * cur + 1, 4, hipMemcpyDeviceToHost, s));
+        u32 cnt[4] = {0, 0, 0, 0};
+        NECAT_HIP(ctx, hipMemcpyAsync(cnt, d_count + 4 * cur, 16, hipMemcpyDeviceToHost, s));
         NECAT_HIP(ctx, hipStreamSynchronize(s));
-        if (nb == 0) break;
+        const u32 nf = cnt[0], nB = cnt[1], np = cnt[2];
+        if (nf + nB + np == 0) break;
         NECAT_HIP(ctx, hipMemsetAsync(d_count + 4 * nxt, 0, 16, s));
-        const u32 gB = (nb + 63) / 64;
-        RoundCtl ctl;
-        hipLaunchKernelGGL((k_ext_frag<kAsmWords, kAsmTWords>), dim3(grid_for((u64)gB * 64 * (kAsmWords + kAsmTWords), 256)), dim3(256), 0, s,
-                           drd, dref, (const BlockItem*)d_items[cur], nb, (const u32*)nullptr, 0u, (u64*)ctx->scratch[SC_ASM_FRAG].p, ctl);
-        NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<asm>");
         const ExtLists next = lists(nxt);
-        for (u32 g0 = 0; g0 < gB; g0 += gchunk) {
-            const u32 lo = g0 * 64, hi = std::min(nb, (g0 + gchunk) * 64), cn = hi - lo;
-            char* slabs = (char*)ctx->scratch[SC_ASM_BAND].p - (size_t)g0 * kAsmSlab;            // the kernels index slabs by item / 64
-            const u32 epoch = ++ctx->epoch & 0x3fffffu;
-            NECAT_HIP(ctx, hipEventRecord(ctx->ev[2], s));
-            hipLaunchKernelGGL((k_myers_coop<kAsmWords, kAsmTWords, kAsmCols, 64>), dim3(cn), dim3(64), 0, s, (const BlockItem*)d_items[cur], hi, (const u32*)nullptr, 0u,
-                               (const u64*)ctx->scratch[SC_ASM_FRAG].p, slabs, kAsmSlab, error, d_res, d_stats, epoch, lo);
-            NECAT_CHECK_LAUNCH(ctx, "k_myers_coop<asm>");
-            NECAT_HIP(ctx, hipEventRecord(ctx->ev[3], s));
-            hipLaunchKernelGGL((k_traceback<kAsmWords, kAsmTWords, kAsmCols, kAsmMaxOps, false, 0, kAsmBlock, true>), dim3((cn + 63) / 64), dim3(64), 0, s,
-                               (const BlockItem*)d_items[cur], hi, (const u32*)nullptr, 0u, (const u64*)ctx->scratch[SC_ASM_FRAG].p, (const char*)slabs, kAsmSlab,
-                               (const BlockResult*)d_res, (u8*)ctx->scratch[SC_ASM_OPS].p, d_tasks, 8 /* kMatchCnt2: the tail match length of hbn_align */, (i32*)nullptr, d_err, next, epoch, lo);
-            NECAT_CHECK_LAUNCH(ctx, "k_traceback<asm>");
-            NECAT_HIP(ctx, hipEventRecord(ctx->ev[24], s));
-            NECAT_HIP(ctx, hipStreamSynchronize(s));
-            ctx->tm.myers_ms += ev_ms(ctx->ev[2], ctx->ev[3]); ctx->tm.traceback_ms += ev_ms(ctx->ev[3], ctx->ev[24]);
-            ctx->tm.myers_launches += 1;
+        RoundCtl ctl;
+        double dp = 0, wk = 0;
+        // ---- list A: work indices [0, nf) the full blocks, [nf16, nf16 + np) the others (ListView)
+        const u32 boundA = (nf + np) ? ((nf + 15u) & ~15u) + np : 0u;
+        if (boundA) {
+            const u32 gA = (boundA + 63) / 64;
+            const u32* d_nA = d_count + 4 * cur;
+            hipLaunchKernelGGL((k_ext_frag<kAsmWordsA, kAsmTWordsA>), dim3(grid_for((u64)gA * 64 * (kAsmWordsA + kAsmTWordsA), 256)), dim3(256), 0, s,
+                               drd, dref, (const BlockItem*)d_itemsA[cur], boundA, d_nA, cap, d_frag, ctl);
+            NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<asm A>");
+            for (u32 g0 = 0; g0 < gA; g0 += gchunkA) {
+                const u32 lo = g0 * 64, hi = std::min(gA, g0 + gchunkA) * 64, cn = hi - lo;
+                char* slabs = (char*)ctx->scratch[SC_ASM_BAND].p - (size_t)g0 * kAsmSlabA;         // the kernels index slabs by work index / 64
+                const u32 epoch = ++ctx->epoch & 0x3fffffu;
+                NECAT_HIP(ctx, hipEventRecord(ctx->ev[2], s));
+                hipLaunchKernelGGL((k_myers_coop<kAsmWordsA, kAsmTWordsA, kAsmBlock, 32>), dim3(cn / 2), dim3(64), 0, s, (const BlockItem*)d_itemsA[cur], boundA, d_nA, cap,
+                                   (const u64*)d_frag, slabs, kAsmSlabA, error, d_res, d_stats, epoch, lo);
+                NECAT_CHECK_LAUNCH(ctx, "k_myers_coop<asm A>");
+                NECAT_HIP(ctx, hipEventRecord(ctx->ev[3], s));
+                if (g_walk_wave)
+                    hipLaunchKernelGGL((k_walk_wave<kAsmWordsA, kAsmTWordsA, kAsmOpsA, kAsmBlock>), dim3(cn), dim3(64), 0, s, (const BlockItem*)d_itemsA[cur], boundA, d_nA, cap,
+                                       (const u64*)d_frag, (const char*)slabs, kAsmSlabA, (const BlockResult*)d_res, d_tasks, 8 /* kMatchCnt2: the tail match length of hbn_align */, d_err, next, lo);
+                else
+                hipLaunchKernelGGL((k_traceback<kAsmWordsA, kAsmTWordsA, kAsmBlock, kAsmOpsA, false, 0, kAsmBlock>), dim3(cn / 64), dim3(64), 0, s,
+                                   (const BlockItem*)d_itemsA[cur], boundA, d_nA, cap, (const u64*)d_frag, (const char*)slabs, kAsmSlabA,
+                                   (const BlockResult*)d_res, d_ops, d_tasks, 8 /* kMatchCnt2: the tail match length of hbn_align */, (i32*)nullptr, d_err, next, epoch, lo);
+                NECAT_CHECK_LAUNCH(ctx, "k_traceback<asm A>");
+                NECAT_HIP(ctx, hipEventRecord(ctx->ev[24], s));
+                NECAT_HIP(ctx, hipStreamSynchronize(s));
+                dp += ev_ms(ctx->ev[2], ctx->ev[3]); wk += ev_ms(ctx->ev[3], ctx->ev[24]);
+                ctx->tm.myers_launches += 1;
+            }
         }
-        ctx->tm.myers_blocks += nb; ctx->tm.rounds += 1;
-        if (g_trace & 1) fprintf(stderr, "[necat] asm round %u: %u blocks, DP %.3f ms + walk %.3f ms so far\n", r, nb, ctx->tm.myers_ms, ctx->tm.traceback_ms);
+        // ---- list B: a plain list of nB items
+        if (nB) {
+            const u32 gB = (nB + 63) / 64;
+            hipLaunchKernelGGL((k_ext_frag<kAsmWords, kAsmTWords>), dim3(grid_for((u64)gB * 64 * (kAsmWords + kAsmTWords), 256)), dim3(256), 0, s,
+                               drd, dref, (const BlockItem*)d_itemsB[cur], nB, (const u32*)nullptr, 0u, d_frag, ctl);
+            NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<asm B>");
+            for (u32 g0 = 0; g0 < gB; g0 += gchunkB) {
+                const u32 lo = g0 * 64, hi = std::min(nB, (g0 + gchunkB) * 64), cn = hi - lo;
+                char* slabs = (char*)ctx->scratch[SC_ASM_BAND].p - (size_t)g0 * kAsmSlab;
+                const u32 epoch = ++ctx->epoch & 0x3fffffu;
+                NECAT_HIP(ctx, hipEventRecord(ctx->ev[2], s));
+                hipLaunchKernelGGL((k_myers_coop<kAsmWords, kAsmTWords, kAsmCols, 64>), dim3(cn), dim3(64), 0, s, (const BlockItem*)d_itemsB[cur], hi, (const u32*)nullptr, 0u,
+                                   (const u64*)d_frag, slabs, kAsmSlab, error, d_res, d_stats, epoch, lo);
+                NECAT_CHECK_LAUNCH(ctx, "k_myers_coop<asm B>");
+                NECAT_HIP(ctx, hipEventRecord(ctx->ev[3], s));
+                if (g_walk_wave)
+                    hipLaunchKernelGGL((k_walk_wave<kAsmWords, kAsmTWords, kAsmMaxOps, kAsmBlock>), dim3(cn), dim3(64), 0, s, (const BlockItem*)d_itemsB[cur], hi, (const u32*)nullptr, 0u,
+                                       (const u64*)d_frag, (const char*)slabs, kAsmSlab, (const BlockResult*)d_res, d_tasks, 8, d_err, next, lo);
+                else
+                hipLaunchKernelGGL((k_traceback<kAsmWords, kAsmTWords, kAsmCols, kAsmMaxOps, false, 0, kAsmBlock>), dim3((cn + 63) / 64), dim3(64), 0, s,
+                                   (const BlockItem*)d_itemsB[cur], hi, (const u32*)nullptr, 0u, (const u64*)d_frag, (const char*)slabs, kAsmSlab,
+                                   (const BlockResult*)d_res, d_ops, d_tasks, 8, (i32*)nullptr, d_err, next, epoch, lo);
+                NECAT_CHECK_LAUNCH(ctx, "k_traceback<asm B>");
+                NECAT_HIP(ctx, hipEventRecord(ctx->ev[24], s));
+                NECAT_HIP(ctx, hipStreamSynchronize(s));
+                dp += ev_ms(ctx->ev[2], ctx->ev[3]); wk += ev_ms(ctx->ev[3], ctx->ev[24]);
+                ctx->tm.myers_launches += 1;
+            }
+        }
+        ctx->tm.myers_ms += dp; ctx->tm.traceback_ms += wk;
+        ctx->tm.myers_blocks += nf + np + nB; ctx->tm.rounds += 1;
+        if (g_trace & 1) fprintf(stderr, "[necat] asm round %u: list A %u full + %u other blocks, list B %u blocks: DP %.3f ms, walk %.3f ms\n", r, nf, np, nB, dp, wk);
     }
     // results: coordinates + identity per anchor, the alignment columns packed in anchor order (as necat_onc_align_batch)
     const size_t out_fixed = n * (sizeof(necat_alignment) + 4 + 8) + 1024;
@@ -2445,7 +2499,7 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
     // split into the two kernel shapes
     std::vector<BlockItem> itA, itB; std::vector<u64> idA, idB;
     for (uint64_t i = 0; i < n; ++i) {
-        BlockItem it; it.g.q_base = (i64)q_off[i]; it.g.q_dir = 1; it.g.q_comp = 0; it.g.t_base = (i64)t_off[i]; it.g.t_dir = 1;
+        BlockItem it; it.g.q_base = (i64)q_off[i]; it.g.q_dir = 1; it.g.q_comp = 0; it.g.t_base = (i64)t_off[i]; it.g.t_dir = 1; it.g.t_comp = 0;
         it.task = -1; it.qn = (i16)q_len[i]; it.tn = (i16)t_len[i];
         if (q_len[i] == kOcaBlockSize && t_len[i] == kOcaBlockSize) { itA.push_back(it); idA.push_back(i); } else { itB.push_back(it); idB.push_back(i); }
     }

@@ -456,11 +456,11 @@ def test_capped_band_pool_runs_lists_in_chunks(ctx, small, tmp_path, monkeypatch
 
 
 @pytest.mark.parametrize("knob", ["NECAT_CHAIN_WAVE=0", "NECAT_FAST16=1", "NECAT_WALK=1", "NECAT_FAST=0", "NECAT_SEED_WAVE=0",
-                                  "NECAT_TAIL_FUSED=0", "NECAT_TAIL_FUSED=100000000"])
+                                  "NECAT_TAIL_FUSED=0", "NECAT_TAIL_FUSED=100000000", "NECAT_WALK_WAVE=0", "NECAT_WALK_WAVE=100000000 NECAT_TAIL_FUSED=0"])
 def test_alternative_kernel_paths_give_the_same_records(ctx, small, monkeypatch, knob):
     """Code paths kept behind a knob (the lane-0 chain DP, the 16-block / 4-lane NW kernel, the restated walk, the general DP
     path without the full-block fast path, lane-per-strand seed collection, every round / no round through the one-launch
-    LDS-band kernel of the late rounds) must stay correct: same candidates and same M4 records as the default paths (which the
+    LDS-band kernel of the late rounds, every list / no list walked by one wave per block) must stay correct: same candidates and same M4 records as the default paths (which the
     other tests pin to the oracle)."""
     from necat_amd import capi
     d, rs = small
@@ -468,8 +468,9 @@ def test_alternative_kernel_paths_give_the_same_records(ctx, small, monkeypatch,
     o0 = capi.default_options(**dict(util.FAST, job=0))
     c_base, _ = capi.pm_main(ctx, o0, 0, d)
     _, m_base = capi.pm_main(ctx, o1, 0, d)
-    name, val = knob.split("=")
-    monkeypatch.setenv(name, val)
+    for kv in knob.split():
+        name, val = kv.split("=")
+        monkeypatch.setenv(name, val)
     c = capi.Context(0)          # knobs are read when a context is created
     try:
         c_got, _ = capi.pm_main(c, o0, 0, d)
