@@ -61,7 +61,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-widened", action="store_true", help="skip the extra measurements of the SURVEY 8f.1 rows")
     ap.add_argument("--cpu-genome", type=int, default=0, help="genome size of the CPU-baseline input (0 = the bench workload itself)")
-    ap.add_argument("--cpu-t1", action="store_true", help="also time the reference with -t 1 (minutes)")
+    ap.add_argument("--cpu-t1", action="store_true", help="also time the reference with -t 1 on the bench workload itself (minutes)")
+    ap.add_argument("--cpu-t1-genome", type=int, default=460_000,
+                    help="genome size of the reduced sample the reference's -t 1 leg runs on by default (SURVEY 8d asks for -t 1; at full size it takes minutes); 0 = no -t 1 leg")
     ap.add_argument("--parallelism", choices=["single-volume", "volumes", "pairs"], default="single-volume",
                     help="N > 1: one volume on all GPUs (strong scaling, RCCL data path), one volume per GPU (weak), or the (reference, query) "
                          "volume pairs of a --volumes V project dealt to the GPUs by cost (strong)")
@@ -158,6 +160,7 @@ def cpu_baseline(args, opt_kw, rs, vol_dir):
     kind = "reference" if ora.have_ref() else "port"
 
     def run(nthreads):
+        nonlocal vol_dir
         o = ora.options(**dict(opt_kw, job=args.job, binary_output=0, num_threads=nthreads))
         out = os.path.join(vol_dir, "cpu_out_%d.txt" % nthreads)
         t0 = time.time()
@@ -179,7 +182,22 @@ def cpu_baseline(args, opt_kw, rs, vol_dir):
            "whole_process_overlaps_per_s": round(nrec / max(wall, 1e-9), 1)}
     if args.cpu_t1:
         n1, t1, w1 = run(1)
-        res["t1"] = {"overlaps": n1, "mapping_s": round(t1, 2), "whole_process_s": round(w1, 2), "overlaps_per_s": round(n1 / max(t1, 1e-9), 1)}
+        res["t1"] = {"overlaps": n1, "mapping_s": round(t1, 2), "whole_process_s": round(w1, 2), "overlaps_per_s": round(n1 / max(t1, 1e-9), 1),
+                     "sample": "the bench workload itself"}
+    elif args.cpu_t1_genome:
+        # one core: a tenth of the genome at the same coverage (the full workload is ~ 3 minutes of one core + the index build)
+        from necat_amd import synth
+        rs1 = synth.simulate_reads(args.cpu_t1_genome, args.coverage, seed=args.seed)
+        d1 = os.path.join(os.path.dirname(vol_dir), "vols_t1")
+        synth.write_volume_dir(d1, rs1)
+        vol_dir_saved, vol_dir = vol_dir, d1
+        try:
+            n1, t1, w1 = run(1)
+        finally:
+            vol_dir = vol_dir_saved
+        res["t1"] = {"overlaps": n1, "mapping_s": round(t1, 2), "whole_process_s": round(w1, 2), "overlaps_per_s": round(n1 / max(t1, 1e-9), 1),
+                     "sample": "%.2f Mb genome x %.0f, %d reads / %d bp, same options, -t 1 (a reduced sample: -t 1 on the bench workload itself is minutes)"
+                               % (args.cpu_t1_genome / 1e6, args.coverage, rs1.nreads, rs1.nbases)}
     return res
 
 
@@ -244,6 +262,38 @@ def widened_paths(ctx, vol, capi, opt_kw):
             best = (dt, line)
     best[1]["templates_per_s"] = round(best[1]["templates"] / best[0], 1)
     res["cns_extension_loop"] = best[1]
+    res["_partition"] = part
+    return res
+
+
+def oc2cns_program(vol_dir, part, threads):
+    """the oc2cns PROGRAM end to end on the bench partition (all templates of the volume in one partition): wall, the GPU extension
+    loop and the host consensus proper (tags, klib-order sort, backbone, best path: cns_consensus.h) as the program reports them"""
+    import re
+    from necat_amd import build
+    build.build_cli()
+    can = os.path.join(vol_dir, "bench_cands")
+    with open(can + ".p0", "wb") as f:
+        f.write(part)
+    with open(can + ".partitions", "w") as f:
+        f.write("1\n")
+    out_c, out_r = os.path.join(vol_dir, "cns_out.fa"), os.path.join(vol_dir, "raw_out.fa")
+    t0 = time.time()
+    r = subprocess.run([build.OC2CNS, "-t", str(threads), vol_dir, can, out_c, out_r], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    wall = time.time() - t0
+    if r.returncode != 0:
+        return {"error": r.stderr[-300:]}
+    m = re.search(r"partition 0: (\d+) templates, extension loop ([0-9.]+) s, consensus ([0-9.]+) s \((\d+) host threads\)", r.stdout)
+    res = {"wall_s": round(wall, 2), "host_threads": threads, "corrected_bytes": os.path.getsize(out_c)}
+    if m:
+        res.update(templates=int(m.group(1)), extension_loop_s=float(m.group(2)), host_consensus_s=float(m.group(3)),
+                   templates_per_s=round(int(m.group(1)) / wall, 1),
+                   host_over_device=round(float(m.group(3)) / max(float(m.group(2)), 1e-9), 2))
+    for f in (can + ".p0", can + ".partitions", out_c, out_r):
+        try:
+            os.remove(f)
+        except OSError:
+            pass
     return res
 
 
@@ -409,6 +459,52 @@ def main_pairs(args, rank, world, local, dist, json_fd):
         dist.destroy_process_group()
 
 
+INDEX_KERNELS = ("k_part_hist", "k_bucket_scan", "k_split_bases", "k_split_recs", "k_subpart", "k_slice_count", "k_bucket_base", "k_slice_emit")
+
+
+def roofline_index(index_ms, nbases, k, n_offsets, n_distinct):
+    """HBM roofline of the index build (SURVEY.md 8d names HBM as that stage's bound).  Algorithmic bytes = SURVEY 8d's
+    reference-layout formula for one volume: 2 (N / 4) + 8 T + 16 N + 16 T + 8 N + 8 M + 4 x 16 M + 8 M + 8 distinct + 16 M with
+    N bases, M kept k-mer positions, T = 4^k table entries - what build_lookup_table's passes move (lookup_table.c:15-147); the
+    build here moves fewer (sparse table, LDS-sliced passes: DESIGN.md 3), `achieved` stays priced on the reference layout so that
+    numbers compare.  `traffic` = HBM bytes of the build's kernels from the PMC passes kept under profiles/."""
+    T, N, M = float(4 ** k), float(nbases), float(n_offsets)
+    alg = 2 * (N / 4) + 8 * T + 16 * N + 16 * T + 8 * N + 8 * M + 4 * 16 * M + 8 * M + 8 * float(n_distinct) + 16 * M
+    achieved = alg / (index_ms * 1e-3) / 1e9 if index_ms > 0 else 0.0
+    traffic = src = None
+    for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
+        pth = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(pth):
+            continue
+        try:
+            pmc = json.load(open(pth))
+            tot = 0.0
+            for kn, v in pmc.items():
+                if any(("necat::" + q) in kn for q in INDEX_KERNELS):
+                    # per-launch averages x launches / builds: every build launches each kernel the same number of times
+                    per_build = v.get("launches", 1) / max(1, pmc_builds(pmc))
+                    tot += (2.0 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0 * per_build
+            if tot > 0:
+                traffic, src = tot, "profiles/" + name
+                break
+        except Exception:
+            pass
+    return {"bound": "hbm", "kernels": "the index build: " + ", ".join(INDEX_KERNELS), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "algorithmic_bytes": round(alg), "ms": round(index_ms, 3),
+            "traffic": traffic, "traffic_frac": round(traffic / (index_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and index_ms > 0 else None,
+            "traffic_source": src,
+            "note": "algorithmic bytes of the REFERENCE layout (dense 4^k table: 24 T of the bytes are table sweeps the sparse build never does), so frac can "
+                    "approach or pass 1 while the bytes actually moved (`traffic`, FETCH x 2 + WRITE per MI355X_MICROARCH.md) stay far below the HBM peak"}
+
+
+def pmc_builds(pmc):
+    """index builds in a PMC profile = launches of k_slice_emit"""
+    for kn, v in pmc.items():
+        if "k_slice_emit" in kn:
+            return int(v.get("launches", 1))
+    return 1
+
+
 def roofline_report(agg):
     """roofline object of the bench line from the summed per-step timings / work counters of one rank"""
     # ---- roofline of the dominant kernel: k_myers_coop<8,16,512,8,false>, the DP of the list-A blocks (<= 512 x 512).
@@ -518,6 +614,8 @@ def main():
         if not one_dev and args.transport in ("auto", "rccl") and comm.transport() != "rccl":
             raise SystemExit("bench.py: ranks on distinct devices but the data path is %s, not rccl" % comm.transport())
 
+    ix_info = {}
+
     def step(job=args.job):
         o = opt if job == args.job else capi.default_options(**dict(opt_kw, job=job, num_threads=1))
         if comm is not None:
@@ -535,6 +633,9 @@ def main():
             sh = None
             ix = ctx.build_index(vol, o.kmer_size, o.kmer_cnt_cutoff)
             t_index = ctx.timings().index_ms
+            if "n_offsets" not in ix_info:
+                ix_info["n_offsets"] = ix.sizes()[1]
+                ix_info["n_distinct"] = ix.sparse_sizes()[1] or ix.sizes()[1]
             if job == 1:      # pm_search_one_volume of a mapping job: seeding + extension in one call, candidates stay on the device
                 m4, _ = ctx.map_pair(ix, vol, vol, 0, 0, o, True, 1)
                 cands = None
@@ -621,6 +722,8 @@ def main():
         "device": ctx.device_name(),
         "roofline": roofline,
     }
+    if ix_info:
+        out["roofline_index"] = roofline_index(agg["index_ms"] / K, rs.nbases, args.kmer, ix_info["n_offsets"], ix_info["n_distinct"])
     out.update(extras)
     if single:
         out["multi_gpu"] = {"transport": transport, "rank0_index_local_ms": round(agg["ix_local_ms"] / K, 3),
@@ -636,6 +739,7 @@ def main():
             out["widened_paths"] = widened_paths(ctx, vol, capi, opt_kw)
         except Exception as e:
             out["widened_paths"] = {"error": str(e)}
+    cns_part = out.get("widened_paths", {}).pop("_partition", None) if isinstance(out.get("widened_paths"), dict) else None
     if world == 1 and not args.no_cpu_baseline:
         import shutil
         tmp = tempfile.mkdtemp(prefix="necat_bench_")
@@ -652,6 +756,12 @@ def main():
                     out["oc2pmov_cold_start"] = cold_start_cli(args, opt_kw, vol_dir, local)
                 except Exception as e:
                     out["oc2pmov_cold_start"] = {"error": str(e)}
+                # ... and the consumer of its candidates: the oc2cns program (GPU extension loop + host consensus) on the same reads
+                if cns_part is not None:
+                    try:
+                        out["widened_paths"]["oc2cns_program"] = oc2cns_program(vol_dir, cns_part, host_cpu()[1])
+                    except Exception as e:
+                        out["widened_paths"]["oc2cns_program"] = {"error": str(e)}
             out["cpu_baseline"] = cpu_baseline(args, opt_kw, rs_cpu, vol_dir)
         except Exception as e:  # the baseline is a reported extra; never fail the GPU measurement on it
             out["cpu_baseline"] = {"value": None, "unit": "overlaps/s", "cores": os.cpu_count(), "kind": "unavailable", "sample": str(e)}

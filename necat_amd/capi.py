@@ -557,6 +557,12 @@ class Index:
                                                           offs.ctypes.data if n else None), "necat_index_download")
         return stats, offs
 
+    def sparse_sizes(self) -> Tuple[int, int]:
+        """(pairs of (bits, base) words, non-zero table entries) of an index in the sparse layout; (0, 0) for a dense one"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self.ctx.lib.necat_index_sparse_size(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
     def download_sparse(self):
         """(bits[T / 64], base[T / 64], compact, offset_list) of an index held in the sparse layout (IndexView, dev_common.h); None for a dense one"""
         npairs, ncomp = C.c_uint64(), C.c_uint64()

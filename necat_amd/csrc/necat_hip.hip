@@ -1516,7 +1516,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     }
     const u32 ng = (u32)goff.size() - 1;
     NECAT_HIP(ctx, hipMemcpyAsync(d_goff, goff.data(), goff.size() * 8, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_m4_filter, dim3(grid_for(ng, 64)), dim3(64), 0, s, (const necat_candidate*)d_cands, (const u64*)d_goff, ng,
+    hipLaunchKernelGGL(k_m4_filter, dim3(grid_for((u64)ng * 64, 256)), dim3(256), 0, s, (const necat_candidate*)d_cands, (const u64*)d_goff, ng,
                        (const necat_m4*)d_m4, d_ok, d_out, d_outcnt);
     NECAT_CHECK_LAUNCH(ctx, "k_m4_filter");
     u32 nout = 0; int herr = 0;

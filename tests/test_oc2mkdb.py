@@ -137,6 +137,14 @@ def test_oc2mkdb_device_packing_equals_host_packing(oc2mkdb, tmp_path):
         assert r.returncode == 0, r.stdout
     _same_dirs(os.path.join(d, "host"), os.path.join(d, "gpu"))
     assert int(open(os.path.join(d, "gpu", "reads_info.txt")).read().split()[0]) >= 3
+    # and directly against the REFERENCE's own oc2mkdb (oracle/_ref travels to the GPU box): one volume (its 2 Gbp cut is a constant)
+    ref_exe = os.path.join(os.path.dirname(ora.REF_PMOV), "oc2mkdb")
+    if os.path.exists(ref_exe):
+        r = subprocess.run([ref_exe, os.path.join(d, "ref")] + lists, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout
+        r = subprocess.run([oc2mkdb, os.path.join(d, "gpu1")] + lists, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, NECAT_MKDB_GPU="1"))
+        assert r.returncode == 0, r.stdout
+        _same_dirs(os.path.join(d, "ref"), os.path.join(d, "gpu1"))
 
 
 @pytest.mark.gpu

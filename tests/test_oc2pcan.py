@@ -96,7 +96,9 @@ def test_oc2pm_writes_the_partitions_oc2pcan_would(oc2pcan, tmp_path, ds, batch)
     ref = os.path.join(str(tmp_path), "ref")
     os.makedirs(ref)
     shutil.copy(out, os.path.join(ref, "cands.bin"))
-    r = subprocess.run([oc2pcan, "-p", str(batch), "-f", "7", wrk, os.path.join(ref, "cands.bin")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    # the partitioner to compare with: the REFERENCE's own oc2pcan when oracle/_ref is there (it travels to the GPU box), else this repo's
+    exe = ora.REF_PCAN if os.path.exists(ora.REF_PCAN) else oc2pcan
+    r = subprocess.run([exe, "-p", str(batch), "-f", "7", wrk, os.path.join(ref, "cands.bin")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode == 0, r.stdout
     n = int(open(os.path.join(ref, "cands.bin.partitions")).read())
     assert int(open(out + ".partitions").read()) == n and n >= 1
