@@ -159,3 +159,18 @@ def test_file_allgather_rerun_in_the_same_directory(tmp_path):
         for r, out in res:
             for k, parts in enumerate(out):
                 assert parts == [("%s-%d-%d" % (tag, x, k)).encode() for x in range(3)]
+
+
+def test_rccl_branch_of_comm_h_with_a_fake_rccl(tmp_path):
+    """tests/host_core/check_comm.cpp: the SOURCE of necat_amd/csrc/comm.h (allgatherv_inplace, gatherv, agree) compiled with g++, the ranks
+    as threads, ncclSend / ncclRecv / group calls replaced by an in-process mailbox that logs every call - peer order, byte counts, empty parts,
+    root != 0 at world 1, 2, 3, 8, and a rank whose ncclSend fails (the group is closed, every rank gets a verdict, nobody blocks).  The RCCL
+    transport itself has only ever run with ranks on ONE device here (1-GPU boxes): this is what pins its call pattern."""
+    import subprocess
+    exe = os.path.join(str(tmp_path), "check_comm")
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", exe,
+                        os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_core", "check_comm.cpp"), "-lpthread", "-ldl"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "ok" in r.stdout
