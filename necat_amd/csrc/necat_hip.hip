@@ -62,6 +62,7 @@ u32 g_batch_cap;       // candidates per extension batch (NECAT_BATCH)
 u32 g_single_pass;     // lists up to this many blocks use the single-pass DP kernel (NECAT_SINGLE_PASS; 0 = never)
 int g_index_lds;       // LDS-slice index passes (NECAT_INDEX_LDS=0: global-atomic bucket passes)
 int g_seed_wave;       // wave-per-strand seed collection (NECAT_SEED_WAVE=0: the lane-per-strand kernel)
+int g_seed_kst;        // NECAT_SEED_KST=0: k_seed_collect_wave looks the table up again instead of reading the words k_seed_hits kept (A/B tests)
 int g_trace;           // NECAT_TRACE: 1 = extension rounds, 2 = host stages
 int g_coop_filter;     // NECAT_COOP_FILTER=0: the cooperative kernel stores every word (A/B tests)
 int g_sort_b;          // NECAT_SORT_B=0 disables the size sort of list B
@@ -88,6 +89,7 @@ void read_knobs()
     g_batch_cap = (u32)std::max<unsigned long long>(64, num("NECAT_BATCH", 786432));
     g_index_lds = (int)num("NECAT_INDEX_LDS", 1);
     g_seed_wave = (int)num("NECAT_SEED_WAVE", 1);
+    g_seed_kst = (int)num("NECAT_SEED_KST", 1);
     g_trace = (int)num("NECAT_TRACE", 0);
     g_coop_filter = (int)num("NECAT_COOP_FILTER", 1);
     g_sort_b = (int)num("NECAT_SORT_B", 1);
@@ -169,6 +171,7 @@ void necat_ctx_trim(necat_ctx* ctx)
     (void)hipDeviceSynchronize();
     for (auto& b : ctx->scratch) if (b.p) { (void)hipFree(b.p); b = DevBuf(); }
     for (auto& b : ctx->idx_cache) if (b.p) { (void)hipFree(b.p); b = DevBuf(); }
+    ctx->seed_ht_ptr = nullptr; ctx->seed_ht_clean = 0;
 }
 
 const char* necat_last_error(const necat_ctx* ctx) { return ctx ? ctx->err : "no context"; }
@@ -726,8 +729,14 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
     if ((rc = buf_ensure(ctx, ctx->scratch[SC_MISC], (size_t)nreads * 8 + 128))) return rc;
     u32* d_hits = (u32*)ctx->scratch[SC_MISC].p;
     int* d_err = (int*)((char*)ctx->scratch[SC_MISC].p + (((size_t)nreads * 8 + 63) & ~(size_t)63));   // error flag of the seeding kernels
+    // the table words k_seed_hits fetches are kept for the collection pass (seed_kst_base): one lookup per sampled k-mer, not two
+    u64* d_kst = nullptr;
+    if (g_seed_wave && g_seed_kst) {
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_SEED_KST], 2 * (reads->nbases / (u64)opt->scan_window + nreads + 2) * 8))) return rc;
+        d_kst = (u64*)ctx->scratch[SC_SEED_KST].p;
+    }
     hipLaunchKernelGGL(k_seed_hits, dim3(grid_for((u64)nreads * 64, 256)), dim3(256), 0, s, drd, index_view(ix),
-                       opt->kmer_size, opt->scan_window, 0u, nreads, d_hits);
+                       opt->kmer_size, opt->scan_window, 0u, nreads, d_hits, d_kst);
     NECAT_CHECK_LAUNCH(ctx, "k_seed_hits");
     // pinned host scratch: [hits: 2 u32 per read][order: u32 per read][SeedMeta per read] - pageable copies cost more than the plan
     {
@@ -829,10 +838,14 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
         A.out = (DevCand*)ctx->scratch[SC_SEED_OUT].p;
         NECAT_HIP(ctx, hipMemcpyAsync(d_meta, meta, n * sizeof(SeedMeta), hipMemcpyHostToDevice, s));
         NECAT_HIP(ctx, hipMemcpyAsync(d_order, order + pos, (size_t)n * 4, hipMemcpyHostToDevice, s));
-        NECAT_HIP(ctx, hipMemsetAsync(A.ht, 0xFF, ht_tot * 8, s));
+        // the hash arena is all-empty between calls (k_seed_clear below): filled only when it is new or a failed call left it dirty
+        if (ctx->seed_ht_ptr != ctx->scratch[SC_SEED_HT].p || ctx->seed_ht_clean < ht_tot * 8) {
+            NECAT_HIP(ctx, hipMemsetAsync(A.ht, 0xFF, ctx->scratch[SC_SEED_HT].cap, s));
+        }
+        ctx->seed_ht_ptr = ctx->scratch[SC_SEED_HT].p; ctx->seed_ht_clean = 0;      // in use: clean again once this chunk's kernels (k_seed_clear last) are known to have run
         if (g_seed_wave)
             hipLaunchKernelGGL(k_seed_collect_wave, dim3(2 * n), dim3(64), 0, s, dref, drd, index_view(ix), (const u64*)ix->offset_list,
-                               P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A, d_nblk, d_err);
+                               P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A, d_nblk, d_err, (const u64*)d_kst);
         else
             hipLaunchKernelGGL(k_seed_collect, dim3(grid_for((u64)2 * n, 64)), dim3(64), 0, s, dref, drd, index_view(ix), (const u64*)ix->offset_list,
                                P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A, d_nblk, d_err);
@@ -840,6 +853,8 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
         hipLaunchKernelGGL(k_seed_eval, dim3(2 * n), dim3(64), 0, s, dref, drd, P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A,
                            (const i32*)d_nblk, d_nstrand, d_err);
         NECAT_CHECK_LAUNCH(ctx, "k_seed_eval");
+        hipLaunchKernelGGL(k_seed_clear, dim3(2 * n), dim3(64), 0, s, (const SeedMeta*)d_meta, n, A, (const i32*)d_nblk);
+        NECAT_CHECK_LAUNCH(ctx, "k_seed_clear");
         hipLaunchKernelGGL(k_seed_finish, dim3(grid_for(n, 64)), dim3(64), 0, s, P, (const SeedMeta*)d_meta, n, A, (const i32*)d_nstrand, d_ncand);
         NECAT_CHECK_LAUNCH(ctx, "k_seed_finish");
         std::vector<i32> nc(n);
@@ -848,6 +863,7 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
         NECAT_HIP(ctx, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, s));
         NECAT_HIP(ctx, hipStreamSynchronize(s));
         if (herr) { return set_err(ctx, NECAT_ERR_CAPACITY, "seeding scratch overflow (code %d)", herr); }
+        ctx->seed_ht_clean = ctx->scratch[SC_SEED_HT].cap;
 #ifdef NECAT_SEED_PROF
         {   // tools/seed_prof.sh: cycles of lane 0 per phase of k_seed_eval, summed over the waves
             unsigned long long h[32], z[32] = {0};

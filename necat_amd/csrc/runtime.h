@@ -41,6 +41,8 @@ struct necat_ctx {
     void* round_ring_dev = nullptr;    // the same memory as the device addresses it
     unsigned long long round_seq = 0;  // rounds published so far (the next round publishes round_seq + 1)
     necat::DevBuf scratch[40];         // grow-only arenas, indexed by purpose (ScratchId)
+    void* seed_ht_ptr = nullptr;       // the seeding hash arena (SC_SEED_HT) whose first seed_ht_clean bytes are known to be all-empty (0xFF):
+    size_t seed_ht_clean = 0;          // every call leaves the arena as it found it (k_seed_clear resets the slots it used), so it is filled once per allocation
     char devname[256] = {0};
     int num_cu = 0;
     uint32_t epoch = 0;
@@ -127,7 +129,7 @@ enum ScratchId {
     SC_SEED_META, SC_SEED_HT, SC_SEED_POOL, SC_SEED_CHAIN, SC_SEED_OUT, SC_SEED_FINAL,
     SC_EXT_TASKS, SC_EXT_LISTS, SC_EXT_FRAG, SC_EXT_MAT, SC_EXT_OPS, SC_EXT_RES, SC_EXT_CAND, SC_SMALL, SC_PART,
     SC_EXT_COLS, SC_EXT_COLS_OUT, SC_PART2, SC_SEED_ALL, SC_EXT_MATB, SC_EXT_MATB2, SC_EXT_PERM, SC_GATHER, SC_SPLIT, SC_SPLIT2,
-    SC_ASM_BAND, SC_ASM_OPS, SC_ASM_COLS, SC_ASM_MISC, SC_ASM_FRAG, SC_ASM_OUT,
+    SC_ASM_BAND, SC_ASM_OPS, SC_ASM_COLS, SC_ASM_MISC, SC_ASM_FRAG, SC_ASM_OUT, SC_SEED_KST,
     SC_COUNT
 };
 

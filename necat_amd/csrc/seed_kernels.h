@@ -22,8 +22,14 @@ struct SeedMeta {           // per processed read; strand 0 = FWD, 1 = REV
     u32 ht_mask[2], pool_cap[2], cs_cap[2], out_cap, out_cap0;
 };
 
+// Where the table words of read r's sampled k-mers are kept between k_seed_hits (which fetches them to size the scratch) and
+// k_seed_collect_wave (which used to fetch them again: two dependent random loads per k-mer, twice): entry 2 * i + strand of the
+// read's stretch, which starts at 2 * (g0 / z + r) - a read of L bases has at most L / z + 1 sampled k-mers, so the stretches of
+// consecutive reads never overlap and no per-read offset table is needed.  2 * (nbases / z + nreads + 1) words in all.
+NECAT_HD u64 seed_kst_base(u64 g0, u32 r, int z) { return 2 * (g0 / (u64)z + (u64)r); }
+
 __global__ void __launch_bounds__(256)
-k_seed_hits(DevVolume reads, IndexView index, int k, int z, u32 read_lo, u32 read_hi, u32* __restrict__ hits)
+k_seed_hits(DevVolume reads, IndexView index, int k, int z, u32 read_lo, u32 read_hi, u32* __restrict__ hits, u64* __restrict__ kst)
 {
     const u32 wave = (u32)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
@@ -37,8 +43,10 @@ k_seed_hits(DevVolume reads, IndexView index, int k, int z, u32 read_lo, u32 rea
         const int pos = i * z;
         const u64 xf = load32_dir(reads.bases, (i64)g0 + pos, +1, 0);
         const u64 xr = load32_dir(reads.bases, (i64)g0 + L - 1 - pos, -1, 1);
-        hf += (u32)(index.lookup(rev2(xf) >> (64 - 2 * k)) >> kOffsetBits);
-        hr += (u32)(index.lookup(rev2(xr) >> (64 - 2 * k)) >> kOffsetBits);
+        const u64 sf = index.lookup(rev2(xf) >> (64 - 2 * k)), sr = index.lookup(rev2(xr) >> (64 - 2 * k));
+        hf += (u32)(sf >> kOffsetBits);
+        hr += (u32)(sr >> kOffsetBits);
+        if (kst) { u64* dst = kst + seed_kst_base(g0, r, z) + 2 * (u64)i; dst[0] = sf; dst[1] = sr; }
     }
     for (int o = 32; o > 0; o >>= 1) { hf += __shfl_down(hf, o); hr += __shfl_down(hr, o); }
     if (lane == 0) { hits[2 * (u64)r] = hf; hits[2 * (u64)r + 1] = hr; }
@@ -95,7 +103,7 @@ k_seed_collect(DevVolume ref, DevVolume reads, IndexView index, const u64* __res
 __global__ void __launch_bounds__(64)
 k_seed_collect_wave(DevVolume ref, DevVolume reads, IndexView index, const u64* __restrict__ offset_list,
                     SeedParams P, const u32* __restrict__ order, const SeedMeta* __restrict__ meta, u32 n,
-                    SeedArenas A, i32* __restrict__ nblk_out, int* __restrict__ err_flag)
+                    SeedArenas A, i32* __restrict__ nblk_out, int* __restrict__ err_flag, const u64* __restrict__ kst)
 {
     __shared__ u32 s_pre[65];
     __shared__ u64 s_list[64];
@@ -125,10 +133,14 @@ k_seed_collect_wave(DevVolume ref, DevVolume reads, IndexView index, const u64* 
         const int kj = kbase + lane;
         u32 cnt = 0; u64 lst = 0;
         if (kj < nk) {
-            const int pos = kj * z;
-            const u64 x = strand == 0 ? load32_dir(reads.bases, (i64)q_goff + pos, +1, 0)
-                                      : load32_dir(reads.bases, (i64)q_goff + L - 1 - pos, -1, 1);
-            const u64 st = index.lookup(rev2(x) >> (64 - 2 * k));
+            u64 st;
+            if (kst) st = kst[seed_kst_base(q_goff, (u32)read_id, z) + 2 * (u64)kj + (u64)strand];      // fetched by k_seed_hits
+            else {
+                const int pos = kj * z;
+                const u64 x = strand == 0 ? load32_dir(reads.bases, (i64)q_goff + pos, +1, 0)
+                                          : load32_dir(reads.bases, (i64)q_goff + L - 1 - pos, -1, 1);
+                st = index.lookup(rev2(x) >> (64 - 2 * k));
+            }
             cnt = (u32)(st >> kOffsetBits); lst = st & kOffsetMask;
             if (cnt && soff_max != ~0ULL) {
                 u32 lo = 0, hi = cnt;
@@ -250,6 +262,18 @@ k_seed_collect_wave(DevVolume ref, DevVolume reads, IndexView index, const u64* 
         if (failed) atomicExch(err_flag, 1);
         nblk_out[t] = failed ? 0 : nblk;
     }
+}
+
+// clear_WordFindData (word_finder.c:40-52) for the whole chunk: the hash slots the strands used go back to empty, so the arena is
+// all-empty again when the call ends and the next call need not fill it (a 0xFF fill of the arena was 0.9 ms per pass)
+__global__ void __launch_bounds__(64)
+k_seed_clear(const SeedMeta* __restrict__ meta, u32 n, SeedArenas A, const i32* __restrict__ nblk_in)
+{
+    const u32 t = blockIdx.x;
+    if (t >= 2 * n) return;
+    const SeedScratch S = seed_scratch(A, meta[t >> 1], (int)(t & 1));
+    const int nb = nblk_in[t];
+    for (int b = (int)threadIdx.x; b < nb; b += 64) S.ht[S.pool[b].slot] = kHtEmpty;
 }
 
 constexpr int kLdsChain = 256;

@@ -69,7 +69,7 @@ ncclResult_t GroupEnd()
     for (size_t i = 0; i < me->pending.size(); ++i) if (me->pending[i].kind == 'R') {
         std::unique_lock<std::mutex> lk(mu);
         auto& q = box[{me->pending[i].peer, me->id}];
-        if (!cv.wait_for(lk, std::chrono::seconds(20), [&] { return !q.empty(); })) return ncclSystemError;     // a peer never sent: fail, do not hang
+        if (!cv.wait_for(lk, std::chrono::seconds(3), [&] { return !q.empty(); })) return ncclSystemError;     // a peer never sent: fail, do not hang
         if (q.front().size() != me->pending[i].bytes) return ncclInvalidArgument;
         memcpy(bufs[i].dst, q.front().data(), q.front().size());
         q.erase(q.begin());
