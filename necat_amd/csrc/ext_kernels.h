@@ -48,6 +48,11 @@ struct BlockItem {       // one scheduled block alignment
 };
 
 struct BlockResult { i32 dist, endc, err; u32 words; };
+// ext_rcwalk.h: a full block whose walk was done by k_rcwalk4 leaves its statistics here (k_traceback<WALK = 5> takes them instead of
+// walking); a block that kernel cannot take (distance too large for its 4-word window) carries kWideFlag in BlockResult::words and
+// goes through the DP + walk kernels below in `only wide` launches.
+constexpr u32 kWideFlag = 0x80000000u;
+struct WalkOut { i32 n, nmat, m, hit, acnt, qcnt, tcnt, mcnt; };
 
 struct ExtLists {
     u32* count;          // [0] = full blocks of list A (front), [1] = nB, [2] = other list-A blocks (back)
@@ -600,12 +605,22 @@ NECAT_D void myers_coop_wave(const ListView& lv, const BlockItem* __restrict__ i
     const u32 n = lv.n;
     const int sub = lane / G, b = lane % G;
     const bool filter = ((epoch >> 30) & 1u) == 0;      // bit 30 of the epoch argument switches the store filter off (A/B tests)
-    const bool fast_ok = ((epoch >> 29) & 1u) == 0;     // bit 29: never take the full-block fast path (A/B measurements)
+    // bit 25: only the blocks k_rcwalk4 left out (kWideFlag) - their band for the old walk; results stay as they are.  bit 24 (the round
+    // runs k_myers_ck + k_rcwalk4 on the full blocks, ext_rcwalk.h): that mode for the full-block part of the work index space
+    // [0, nf16), the normal one for the rest
+    // bit 26: the ragged part only - [nf16, n)
+    if (((epoch >> 26) & 1u) && wave_first < (u64)lv.nf16) { __syncthreads(); return; }
+    const bool only_wide = ((epoch >> 25) & 1u) != 0 || (((epoch >> 24) & 1u) != 0 && wave_first < (u64)lv.nf16);
+    const bool fast_ok = ((epoch >> 29) & 1u) == 0 && !only_wide;     // bit 29: never take the full-block fast path (A/B measurements)
     const bool fast_nostore = ((epoch >> 28) & 1u) != 0; // bit 28: fast path without band stores (profiling only)
     epoch &= 0x07ffffffu;
     const u64 item = wave_first + (u64)sub;
     BlockItem it0;
-    const bool valid = list_item(lv, items, item, it0);
+    bool valid = list_item(lv, items, item, it0);
+    if (only_wide) {
+        if (valid) valid = (results[item].words & kWideFlag) != 0;
+        if (!__any(valid)) { __syncthreads(); return; }
+    }
     const u64 grp = item >> 6;
     const int il = (int)(item & 63);
     int qn = 0, tn = 0;
@@ -726,7 +741,7 @@ NECAT_D void myers_coop_wave(const ListView& lv, const BlockItem* __restrict__ i
         }
         BlockResult br; br.dist = err ? -1 : best; br.endc = end0; br.err = err;
         br.words = (u32)(nblk * (tn + (!SINGLE && best >= 0 ? tn2 : 0)));
-        results[item] = br;
+        if (!only_wide) results[item] = br;
         atomicAdd(&stats[0], (unsigned long long)br.words); atomicAdd(&stats[1], (unsigned long long)(qn + tn));
     }
 }
@@ -824,7 +839,7 @@ template <int NW, int TW, int COLS, int MAXOPS, bool EXPORT, int WALK = 0, int B
 __global__ void __launch_bounds__(64)
 k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, const char* __restrict__ slabs, size_t slab_bytes,
             const BlockResult* __restrict__ results, u8* __restrict__ ops_pool, ExtTask* __restrict__ tasks, int tail_match_len,
-            i32* __restrict__ n_ops_out, int* __restrict__ err_flag, ExtLists next, u32 epoch, u32 item_base = 0)
+            i32* __restrict__ n_ops_out, int* __restrict__ err_flag, ExtLists next, u32 epoch, u32 item_base = 0, const WalkOut* __restrict__ wout = nullptr)
 {
     constexpr int FW = 2 * NW + TW;
     const ListView lv = list_view(n_host, n_dev, capA);
@@ -834,6 +849,10 @@ k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
     BlockItem it;
     if (!list_item(lv, items, item, it)) return;
     const BlockResult br = results[item];
+    // WALK == 5: the walks were done by k_rcwalk4 (the wide blocks it left out are walked by an `only wide` launch: epoch bit 25)
+    if (WALK == 5 && (item >= lv.nf || (br.words & kWideFlag))) return;
+    if (WALK != 5 && ((epoch >> 26) & 1u) && item < lv.nf16) return;
+    if (WALK != 5 && (((epoch >> 25) & 1u) || (((epoch >> 24) & 1u) && item < lv.nf16)) && !(br.words & kWideFlag)) return;
     if (br.err) atomicExch(err_flag, 10 + br.err);
     OpsWriter ow; ow.ops = ops_pool + (size_t)grp * MAXOPS * 64 + lane; ow.cap = MAXOPS; ow.overflow = 0; ow.store = true;
     ExtTask t;
@@ -845,6 +864,13 @@ k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
         ow.store = !t.found || next.task_ops != nullptr;
     }
     tail_init(ow.ts, (EXPORT || !done) ? kOcaMatCnt : tail_match_len);
+    if (WALK == 5) {
+        if (br.dist >= 0) {
+            const WalkOut o = wout[item];
+            ow.ts.n = o.n; ow.ts.nq = it.qn; ow.ts.nt = br.endc + 1; ow.ts.nmat = o.nmat; ow.ts.m = o.m; ow.ts.hit = o.hit;
+            ow.ts.acnt = o.acnt; ow.ts.qcnt = o.qcnt; ow.ts.tcnt = o.tcnt; ow.ts.mcnt = o.mcnt;
+        }
+    } else
     if (br.dist >= 0) {
         MatReader<NW> mr;
         mr.base = slab_records(const_cast<char*>(slabs) + (size_t)grp * slab_bytes); mr.lane = lane; mr.init();

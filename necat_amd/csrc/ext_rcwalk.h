@@ -1,0 +1,249 @@
+// ext_rcwalk.h - full 512 x 512 blocks WITHOUT the NW pass, the band in HBM and the lane-per-block walk: the walk recomputes the
+// cells it stands on.
+//
+// What the three-kernel chain spends on a full block (E. coli bench, a round of 220 k blocks): SHW pass 0.95 ms, NW pass 0.95 ms
+// (all 8 words of every column recomputed to store ~ 1.9 of them: 1.9 GB of band records), walk 1.1 - 1.26 ms (one dependent
+// 16-byte load per step from those records, 2.2 us per step with 228 k walks in flight).  Here:
+//   * k_myers_ck        the SHW pass of the fast path (myers_fast_full) that also keeps CHECKPOINTS: every word's (Pv, Mv) after columns
+//                       31, 63, .., 479 - 16 bytes per lane every 32 steps, 2 KB per block, 0.46 GB per round instead of 1.9 GB of records;
+//   * k_rcwalk4         4 lanes per block, 16 blocks per wave, from the end cell backwards one 32-column SEGMENT at a time: the segment's
+//                       columns are recomputed forward from the checkpoint before it on a window of 4 words that contains the block's
+//                       Ukkonen band there (cells an alignment of cost <= the block's distance can pass, |r - c| + |d - (r - c)| <= best:
+//                       the same window argument as the 4-lane NW pass of ext_fast16.h - exact where the walk looks, band boundary
+//                       carry (+1) at the window's top), the walk's decisions for the 64 rows at and above the walker are cut out of
+//                       the records into LDS (16 bytes per column), and the walk runs on them until it leaves the segment (or, rarely,
+//                       those 64 rows: the segment is then redone from the walker's new row);
+//   * k_traceback<WALK = 5>   the walk's statistics (TailScan) and ops taken from k_rcwalk4 instead of walked: trimming, counters, kept
+//                       columns, next block - unchanged code.
+// Word updates per block: 4096 (SHW) + ~ 2 200 (16 segments x 35 steps x 4 lanes) instead of 8192; no band records; every
+// memory access of the walk is an LDS read.  Blocks whose distance is too large for the 4-word window (best > kRcMaxDist: < 0.1 % at
+// 12 % error) are flagged by k_myers_ck and go through the old kernels (`only wide` launches of k_myers_coop / k_traceback).
+#pragma once
+
+namespace necat {
+
+constexpr int kRcSeg = 32;                       // columns per segment = per checkpoint
+constexpr int kRcCk = kOcaBlockSize / kRcSeg;    // checkpoint slots per block (the last one is never read)
+constexpr int kRcMaxDist = 160;                  // 63 (alignment of the window) + 31 (columns) + best <= 255 rows of a 4-word window
+
+// ---- SHW with checkpoints (fast_shw8 of ext_fast16.h + one 16-byte store per lane every 32 steps)
+template <int TW>
+NECAT_D u32 fast_shw8_ck(const int b, const u64* __restrict__ tw, const u64 nlo, const u64 nhi, ulonglong2* __restrict__ ck)
+{
+    constexpr int G = 8, N = kOcaBlockSize, kSteps = N + G - 1;
+    const u32 cm = b == G - 1 ? 0x80000000u : 0u;
+    const u32 nlo_l = (u32)nlo, nlo_h = (u32)(nlo >> 32), nhi_l = (u32)nhi, nhi_h = (u32)(nhi >> 32);
+    const u32 sk = (u32)(32 - b) & 31u;
+    const int jck = (b + 31) & 31;               // the step (mod 32) at which this lane's column is 31 mod 32
+    u32 tlo = 0, thi = 0, plo = 0, phi = 0;
+    FastWord w; w.Pv = ~0ULL; w.Mv = 0ULL; w.pubP = 0x80000000u; w.pubM = 0u;
+    u32 S = (u32)(b + 1) * 64u, key = 0xffffffffu;
+    u64 dA, dB;
+    u32 cph = 0x80000000u, cmh = 0u;
+    for (int s0 = 0; s0 < kSteps; s0 += 32) {
+        {
+            const u64 x = (s0 >> 5) < TW ? tw[s0 >> 5] : 0ULL;
+            const u32 xl = (u32)x, xh = (u32)(x >> 32);
+            tlo = b ? __builtin_amdgcn_alignbit(xl, plo, sk) : xl;
+            thi = b ? __builtin_amdgcn_alignbit(xh, phi, sk) : xh;
+            plo = xl; phi = xh;
+        }
+        const int jn = kSteps - s0 < 32 ? kSteps - s0 : 32;
+        for (int j = 0; j < jn; ++j) {
+            const int s = s0 + j;
+            cph = dpp_row_shr1(w.pubP, cph); cmh = dpp_row_shr1(w.pubM, cmh);
+            const bool edge = s < G - 1 || s >= N;
+            if (!edge || (s >= b && s - b < N)) {
+                const u32 ma = (u32)__builtin_amdgcn_sbfe((int)tlo, (u32)j, 1u), mb = (u32)__builtin_amdgcn_sbfe((int)thi, (u32)j, 1u);
+                const u32 el = bop<0x60>(nlo_l ^ ma, nhi_l, mb), eh = bop<0x60>(nlo_h ^ ma, nhi_h, mb);
+                u32 phh, mhh;
+                fast_advance<false>(w, el, eh, cph, cmh, cm, phh, mhh, dA, dB);
+                S += (phh >> 31) - (mhh >> 31);
+                const u32 k2 = (S << 10) + (u32)s;
+                key = k2 < key ? k2 : key;
+                if (j == jck) ck[(size_t)((s - b) >> 5) * G] = make_ulonglong2(w.Pv, w.Mv);      // state after column 32 m + 31 -> slot m
+            }
+        }
+    }
+    return key;
+}
+
+// the front part of list A (work indices [0, nf): full blocks; [nf, nf16): holes), 8 items per wave
+template <int NW, int TW>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, ulonglong2* __restrict__ ckpt,
+           double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, int max_dist)
+{
+    constexpr int FW = 2 * NW + TW, G = 8, N = kOcaBlockSize;
+    __shared__ u64 t_lds[8][TW];
+    const ListView lv = list_view(0u, n_dev, capA);
+    const u64 first = (u64)blockIdx.x * 8;
+    if (first >= lv.nf) return;
+    const int lane = (int)threadIdx.x, sub = lane >> 3, b = lane & 7;
+    const u64 item = first + (u64)sub;
+    const bool valid = item < lv.nf;
+    const u64 grp = item >> 6;
+    const int il = (int)(item & 63);
+    const u64* fr = frag + grp * FW * 64 + il;
+    u64 nlo = 0, nhi = 0;
+    if (valid) { nlo = fr[(u64)b * 64]; nhi = fr[(u64)(NW + b) * 64]; }
+    for (int w = b; w < TW; w += G) {
+        const u64 x = valid ? fr[(u64)(2 * NW + w) * 64] : 0ULL;
+        t_lds[sub][w] = even_bits(x) | (even_bits(x >> 1) << 32);
+    }
+    __syncthreads();
+    const u32 key = fast_shw8_ck<TW>(b, t_lds[sub], nlo, nhi, ckpt + (size_t)item * (kRcCk * G) + b);
+    const u32 bkey = (u32)__shfl((int)key, (lane & ~(G - 1)) | (G - 1));
+    int best = (int)(bkey >> 10);
+    const int end0 = (int)(bkey & 1023u) - (G - 1);
+    const int k0 = (int)((double)N * error * 1.1);                       // edlib_ex.c:751
+    if (best > k0) best = -1;
+    int err = 0;
+    if (best >= 0) { int ad = end0 + 1 - N; if (ad < 0) ad = -ad; if (best < ad) err = 1; }
+    if (b == G - 1 && valid) {
+        BlockResult br; br.dist = err ? -1 : best; br.endc = end0; br.err = err;
+        br.words = (u32)(NW * N) | ((best > max_dist && !err) ? kWideFlag : 0u);      // max_dist <= kRcMaxDist (smaller in tests: more blocks take the old path)
+        results[item] = br;
+        atomicAdd(&stats[0], (unsigned long long)(NW * N)); atomicAdd(&stats[1], (unsigned long long)(2 * N));
+    }
+}
+
+NECAT_D u32 dpp_quad_shr1(u32 v, u32 keep)      // lane i of every quad receives v of lane i - 1; lane 0 of a quad keeps `keep`
+{
+    const u32 x = (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x90 /* quad_perm:[0,0,1,2] */, 0xf, 0xf, false);
+    return (threadIdx.x & 3u) ? x : keep;
+}
+
+// 16 full blocks per wave, 4 lanes per block (see the head of the file).  ops: the walk's ops, op i of work item x at
+// ops_pool[(x / 64) * MAXOPS * 64 + i * 64 + (x % 64)] (k_traceback's layout), written while `store` (the task has not yet seen its
+// first run of 8 matches, or the caller keeps the columns).
+template <int NW, int TW, int MAXOPS>
+__global__ void __launch_bounds__(64)
+k_rcwalk4(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, const ulonglong2* __restrict__ ckpt,
+          const BlockResult* __restrict__ results, const ExtTask* __restrict__ tasks, int keep_cols, u8* __restrict__ ops_pool, WalkOut* __restrict__ wout,
+          unsigned long long* __restrict__ stats, int* __restrict__ err_flag)
+{
+    constexpr int FW = 2 * NW + TW, N = kOcaBlockSize, SEG = kRcSeg;
+    __shared__ ulonglong2 slices[16][SEG];
+    const ListView lv = list_view(0u, n_dev, capA);
+    const u64 first = (u64)blockIdx.x * 16;
+    if (first >= lv.nf) return;
+    const int lane = (int)threadIdx.x, q = lane >> 2, j = lane & 3;
+    const u64 item = first + (u64)q;
+    const bool valid = item < lv.nf;
+    const u64 grp = first >> 6;                                      // 16 consecutive work indices share a 64-item group
+    const int il = (int)(item & 63);
+    const u64* fr = frag + grp * FW * 64 + il;
+    int best = -1, endc = -1;
+    bool store = false;
+    if (valid) {
+        const BlockResult br = results[item];
+        if (!(br.words & kWideFlag)) { best = br.dist; endc = br.endc; }     // wide blocks: the old path walks them
+        if (best >= 0) store = keep_cols || !tasks[items[item].task].found;
+    }
+    // the band of r - c (ext_fast16.h): lo_x <= r - c <= hi_x
+    const int tn2 = endc + 1, d = N - tn2, ad = d < 0 ? -d : d, slack = best >= 0 ? (best - ad) >> 1 : 0;
+    const int lo_x = (d < 0 ? d : 0) - slack, hi_x = (d > 0 ? d : 0) + slack;
+    int r = N - 1, c = endc;
+    int n = 0, nmat = 0, m = 0, hit = 0, nq = 0, nt = 0, acnt = 0, qcnt = 0, tcnt = 0, mcnt = 0;
+    bool fin = best < 0;
+    u8* const ops = ops_pool + (size_t)(item >> 6) * MAXOPS * 64 + il;
+    int wcur = -1; u32 nlo_l = 0, nlo_h = 0, nhi_l = 0, nhi_h = 0;      // the query planes of the lane's current word
+    int segcur = -1; u32 tlo = 0, thi = 0;                              // the target bit-planes of the current segment's 32 columns
+    u32 words_done = 0;
+    while (!__all(fin)) {
+        const int seg = c >> 5, c0 = seg * SEG;
+        const int rb = r - 63;                                        // the walk may use rows [rb, r] of this segment's columns
+        int wtop = (c0 + lo_x) >> 6;                                  // floor: the word of the band's top row at the segment's first column
+        wtop = wtop < 0 ? 0 : (wtop > NW - 4 ? NW - 4 : wtop);
+        const int w = wtop + j;
+        if (!fin && w != wcur) {
+            const u64 a = fr[(u64)w * 64], bq = fr[(u64)(NW + w) * 64];
+            nlo_l = (u32)a; nlo_h = (u32)(a >> 32); nhi_l = (u32)bq; nhi_h = (u32)(bq >> 32); wcur = w;
+        }
+        FastWord wd; wd.Pv = ~0ULL; wd.Mv = 0ULL; wd.pubP = 0x80000000u; wd.pubM = 0u;
+        if (!fin && seg > 0) { const ulonglong2 v = ckpt[((size_t)item * kRcCk + (size_t)(seg - 1)) * 8 + (size_t)w]; wd.Pv = v.x; wd.Mv = v.y; }
+        if (!fin && seg != segcur) {
+            const u64 x = fr[(u64)(2 * NW + seg) * 64];
+            tlo = (u32)even_bits(x); thi = (u32)even_bits(x >> 1); segcur = seg;
+        }
+        const int ncol = fin ? 0 : (c - c0 + 1);                      // columns c0 .. c of the segment are needed
+        const int wa = rb >> 6, sh = rb & 63, w1 = r >> 6;            // slice rows [rb, r]: word wa from bit sh on, then word w1 = wa + 1 (sh != 0)
+        for (int s = 0; s < SEG + 3; ++s) {
+            const u32 cph = dpp_quad_shr1(wd.pubP, 0x80000000u), cmh = dpp_quad_shr1(wd.pubM, 0u);      // the window's top word: boundary carry
+            const int ci = s - j;
+            if ((u32)ci < (u32)ncol) {
+                const u32 ma = (u32)__builtin_amdgcn_sbfe((int)tlo, (u32)ci, 1u), mb = (u32)__builtin_amdgcn_sbfe((int)thi, (u32)ci, 1u);
+                const u32 el = bop<0x60>(nlo_l ^ ma, nhi_l, mb), eh = bop<0x60>(nlo_h ^ ma, nhi_h, mb);
+                u32 phh, mhh; u64 rA, rB;
+                fast_advance<true>(wd, el, eh, cph, cmh, 0u, phh, mhh, rA, rB);
+                ++words_done;
+                // the walk's 64 rows of this column: low part from word wa (written first: its lane is one step ahead), high part
+                // from word w1
+                if (w == wa) slices[q][ci] = sh ? make_ulonglong2(rA >> sh, rB >> sh) : make_ulonglong2(rA, rB);
+                else if (w == w1 && sh) {
+                    const u64 pa = rA << (64 - sh), pb = rB << (64 - sh);
+                    if (wa < wtop) slices[q][ci] = make_ulonglong2(pa, pb);       // the rows above the window are never looked at
+                    else {      // (LDS atomics without a return value: nothing to wait for)
+                        unsigned long long* dst = reinterpret_cast<unsigned long long*>(&slices[q][ci]);
+                        __hip_atomic_fetch_or(dst, pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_or(dst + 1, pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- the walk (walk_block of dp_core.h on the slices), every lane of the quad the same.  Two forms of the loop: once every
+        // block of the wave has seen its run of 8 matches and no block keeps its ops (every block but the first one or two of an
+        // extension, when only records are wanted) a step only counts columns and matches
+        const bool lean = !__any(!fin && (!hit || store));
+        bool out = false;                                             // walked out of the matrix: the block is done
+        if (!fin) {
+            if (lean) {
+                for (;;) {
+                    if (c < c0 || r < rb) break;                      // out of the segment / of the rows kept: the next segment (or this one again)
+                    const ulonglong2 v = slices[q][c - c0];
+                    const int bit = r - rb;
+                    const u32 a = (u32)(v.x >> bit) & 1u, b = (u32)(v.y >> bit) & 1u;
+                    const int drow = 1 - (int)(b & (a ^ 1u)), dcol = 1 - (int)(a & (b ^ 1u));
+                    ++n; nmat += (int)((a | b) ^ 1u);
+                    r -= drow; c -= dcol;
+                    if ((r | c) < 0) { out = true; break; }
+                }
+            } else {
+                for (;;) {
+                    if (c < c0 || r < rb) break;
+                    const ulonglong2 v = slices[q][c - c0];
+                    const int bit = r - rb;
+                    const u32 a = (u32)(v.x >> bit) & 1u, b = (u32)(v.y >> bit) & 1u;
+                    const int op = (int)(a | (b << 1));
+                    const int drow = 1 - (int)(b & (a ^ 1u)), dcol = 1 - (int)(a & (b ^ 1u));
+                    const int mt = (int)((a | b) ^ 1u);
+                    if (store && j == 0) { if (n < MAXOPS) ops[(size_t)n * 64] = (u8)op; else atomicExch(err_flag, 20); }
+                    ++n; nmat += mt;
+                    if (!hit) {
+                        nq += drow; nt += dcol;
+                        m = mt ? m + 1 : 0;
+                        if (m == kOcaMatCnt) { hit = 1; acnt = n; qcnt = nq; tcnt = nt; mcnt = nmat; }
+                    }
+                    r -= drow; c -= dcol;
+                    if ((r | c) < 0) { out = true; break; }
+                }
+            }
+        }
+        if (out) {
+            // out of the first column: the rows left are inserts; out of the first row: the columns left are deletes
+            const int kop = c < 0 ? 1 : 2, k = c < 0 ? r + 1 : c + 1;
+            if (store && j == 0) for (int i = 0; i < k; ++i) { if (n + i < MAXOPS) ops[(size_t)(n + i) * 64] = (u8)kop; else atomicExch(err_flag, 20); }
+            n += k;
+            if (!hit && k > 0) m = 0;
+            fin = true;
+            if (j == 0) { WalkOut o; o.n = n; o.nmat = nmat; o.m = m; o.hit = hit; o.acnt = acnt; o.qcnt = qcnt; o.tcnt = tcnt; o.mcnt = mcnt; wout[item] = o; }
+        }
+        __syncthreads();             // the slices are read before the next segment overwrites them
+    }
+    for (int o = 32; o > 0; o >>= 1) words_done += (u32)__shfl_xor((int)words_done, o);
+    if (lane == 0 && words_done) { atomicAdd(&stats[0], (unsigned long long)words_done); atomicAdd(&stats[2], (unsigned long long)words_done); }
+}
+
+}  // namespace necat

@@ -15,6 +15,7 @@
 #include "pcan_kernels.h"
 #include "ext_kernels.h"
 #include "ext_tail.h"
+#include "ext_rcwalk.h"
 #include "asm_kernels.h"
 #include "asm_coop.h"
 #include "cns_loop.h"
@@ -72,6 +73,8 @@ int g_fast16;          // NECAT_FAST16=1: list A's big rounds through k_myers_a1
 size_t g_band_pool;    // NECAT_BAND_POOL_MB (default 16384): cap of one band-record pool; a bigger list runs in several DP + walk launches (0 = no cap)
 int g_walk;            // NECAT_WALK=0: k_traceback runs the reference formulation of the walk (A/B measurements)
 u32 g_tail_fused;      // NECAT_TAIL_FUSED (default 512 = one workgroup per block at 2 per CU; 0 = off): lists of at most this many blocks run as ONE launch per round with the band in LDS (ext_tail.h)
+u32 g_rcwalk;          // NECAT_RCWALK (default 16384; 0 = off): list-A rounds of more than this many blocks run their full blocks through k_myers_ck + k_rcwalk4 (ext_rcwalk.h: no NW pass, no band records, the walk recomputes its cells)
+int g_rc_maxdist;      // NECAT_RC_MAXDIST (default and maximum kRcMaxDist = 160): full blocks of a larger distance take the old kernels (tests lower it)
 u32 g_walk_wave;       // NECAT_WALK_WAVE (default 12288; 0 = off): lists of at most this many blocks are walked by one WAVE per block through an LDS window (k_walk_wave, ext_tail.h)
 int g_asm_lane;        // NECAT_ASM_LANE=1: necat_asm_align_batch through the lane-per-alignment kernel (k_asm_align), the second implementation
 int g_dbg;             // NECAT_DBG: profiling-only variants of the lane-per-block DP kernel (1 = no band stores, 2 = no NW pass)
@@ -86,6 +89,8 @@ void read_knobs()
     g_tail_fused = (u32)num("NECAT_TAIL_FUSED", 512);
     g_asm_lane = (int)num("NECAT_ASM_LANE", 0);
     g_walk_wave = (u32)num("NECAT_WALK_WAVE", 12288);
+    g_rcwalk = (u32)num("NECAT_RCWALK", 16384);
+    g_rc_maxdist = (int)std::min<unsigned long long>(num("NECAT_RC_MAXDIST", kRcMaxDist), kRcMaxDist);
     g_batch_cap = (u32)std::max<unsigned long long>(64, num("NECAT_BATCH", 786432));
     g_index_lds = (int)num("NECAT_INDEX_LDS", 1);
     g_seed_wave = (int)num("NECAT_SEED_WAVE", 1);
@@ -1210,6 +1215,48 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         a_timed.push_back(0);
         if (!bound) return NECAT_OK;
         ExtLists next; next.count = c.count + 4 * nxt; next.itemsA = c.itemsA[nxt]; next.itemsB = c.itemsB[nxt]; next.task_ops = X.task_ops; next.capA = c.cap;
+        if (g_rcwalk && bound > g_rcwalk && bound <= g_coop_threshold && gchunk == gA && g_fast == 1 && g_coop_filter) {
+            // ---- a big round: the full blocks (the front of the work index space) without NW pass and band records - SHW with
+            // checkpoints, then the walk that recomputes its cells (ext_rcwalk.h); the ragged blocks and the few blocks whose band is
+            // too wide for that walk through the usual kernels, in the same launches (epoch bit 24)
+            int rc2;
+            if ((rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_CKPT], (size_t)gA * 64 * kRcCk * 8 * sizeof(ulonglong2))) ||
+                (rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_WOUT], (size_t)gA * 64 * sizeof(WalkOut)))) return rc2;
+            ulonglong2* ck = (ulonglong2*)ctx->scratch[SC_EXT_CKPT].p;
+            WalkOut* wo = (WalkOut*)ctx->scratch[SC_EXT_WOUT].p;
+            char* slabsA = (char*)ctx->scratch[SC_EXT_MAT].p;
+            // the full blocks on stream a: SHW + checkpoints, recompute walk, finish
+            hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA>), dim3((bound + 7) / 8), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, X.error, c.resA, X.stats, g_rc_maxdist);
+            NECAT_CHECK_LAUNCH(ctx, "k_myers_ck");
+            NECAT_HIP(ctx, hipEventRecord(c.a1[cur], c.sa));
+            // the ragged blocks (and, once k_myers_ck has flagged them, the wide ones) on a stream of their own: a lane-per-block walk
+            // of a tenth of the list is as long as one of the whole list (latency bound) - it runs beside the full blocks' chain
+            hipStream_t sd = ctx->stream_d;
+            const u32 fl_rag = epoch | (1u << 26), fl_wide = epoch | (1u << 25);
+            NECAT_HIP(ctx, hipStreamWaitEvent(sd, c.a0[cur], 0));            // the fragments are there
+            hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3(gA * 8), dim3(64), 0, sd, itA, bound, d_nA, c.cap,
+                               (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, fl_rag, 0u);
+            hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, 0>), dim3(gA), dim3(64), 0, sd, itA, bound, d_nA, c.cap,
+                               (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
+                               (i32*)nullptr, X.d_err, next, fl_rag, 0u);
+            NECAT_CHECK_LAUNCH(ctx, "k_myers / k_traceback<A, ragged>");
+            NECAT_HIP(ctx, hipStreamWaitEvent(sd, c.a1[cur], 0));            // k_myers_ck has flagged the wide blocks
+            hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3(gA * 8), dim3(64), 0, sd, itA, bound, d_nA, c.cap,
+                               (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, fl_wide, 0u);
+            hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, 0>), dim3(gA), dim3(64), 0, sd, itA, bound, d_nA, c.cap,
+                               (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
+                               (i32*)nullptr, X.d_err, next, fl_wide, 0u);
+            NECAT_CHECK_LAUNCH(ctx, "k_myers / k_traceback<A, wide>");
+            NECAT_HIP(ctx, hipEventRecord(ctx->ev[25], sd));
+            hipLaunchKernelGGL((k_rcwalk4<kWordsA, kTWordsA, kOpsA>), dim3((bound + 15) / 16), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, (const ulonglong2*)ck,
+                               (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, c.opsA, wo, X.stats, X.d_err);
+            NECAT_CHECK_LAUNCH(ctx, "k_rcwalk4");
+            hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, 5>), dim3(gA), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap,
+                               (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
+                               (i32*)nullptr, X.d_err, next, epoch, 0u, (const WalkOut*)wo);
+            NECAT_CHECK_LAUNCH(ctx, "k_traceback<A, rc>");
+            NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, ctx->ev[25], 0));          // the round is over when both chains are
+        } else
         for (u32 g0 = 0; g0 < gA; g0 += gchunk) {
             const u32 lo = g0 * 64, hi = std::min(gA, g0 + gchunk) * 64, cn = hi - lo;           // work indices of this chunk (the kernels know the exact list)
             char* slabsA = (char*)ctx->scratch[SC_EXT_MAT].p - (size_t)g0 * kSlabA;             // the kernels index slabs by work index / 64
@@ -1301,7 +1348,7 @@ struct RmOut { std::vector<necat_candidate> cands; std::vector<necat_m4> m4; std
 
 int ext_streams(necat_ctx* ctx)
 {
-    for (hipStream_t* st : {&ctx->stream_a, &ctx->stream_b, &ctx->stream_c, &ctx->stream_copy})
+    for (hipStream_t* st : {&ctx->stream_a, &ctx->stream_b, &ctx->stream_c, &ctx->stream_d, &ctx->stream_copy})
         if (!*st && hipStreamCreate(st) != hipSuccess) return set_err(ctx, NECAT_ERR_DEVICE, "hipStreamCreate failed");
     return NECAT_OK;
 }

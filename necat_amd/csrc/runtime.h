@@ -30,6 +30,7 @@ struct necat_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream_a = nullptr, stream_b = nullptr;   // extension rounds: list A / list B run concurrently
     hipStream_t stream_c = nullptr;                       // second list-B stream (small lists alternate)
+    hipStream_t stream_d = nullptr;                       // list A's ragged / wide blocks of a round whose full blocks run through ext_rcwalk.h
     hipStream_t stream_copy = nullptr;                    // deferred device-to-host copies (alignment columns of the consensus loop)
     bool copy_pending = false;                            // a copy on stream_copy still reads SC_EXT_COLS_OUT (ev[17] marks its end)
     char err[1024] = {0};
@@ -129,7 +130,7 @@ enum ScratchId {
     SC_SEED_META, SC_SEED_HT, SC_SEED_POOL, SC_SEED_CHAIN, SC_SEED_OUT, SC_SEED_FINAL,
     SC_EXT_TASKS, SC_EXT_LISTS, SC_EXT_FRAG, SC_EXT_MAT, SC_EXT_OPS, SC_EXT_RES, SC_EXT_CAND, SC_SMALL, SC_PART,
     SC_EXT_COLS, SC_EXT_COLS_OUT, SC_PART2, SC_SEED_ALL, SC_EXT_MATB, SC_EXT_MATB2, SC_EXT_PERM, SC_GATHER, SC_SPLIT, SC_SPLIT2,
-    SC_ASM_BAND, SC_ASM_OPS, SC_ASM_COLS, SC_ASM_MISC, SC_ASM_FRAG, SC_ASM_OUT, SC_SEED_KST,
+    SC_ASM_BAND, SC_ASM_OPS, SC_ASM_COLS, SC_ASM_MISC, SC_ASM_FRAG, SC_ASM_OUT, SC_SEED_KST, SC_EXT_CKPT, SC_EXT_WOUT,
     SC_COUNT
 };
 
