@@ -50,8 +50,8 @@ FAST = dict(kmer_size=15, scan_window=20, kmer_cnt_cutoff=500, block_size=2000, 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--genome", type=int, default=4_600_000)
     ap.add_argument("--coverage", type=float, default=40.0)
     ap.add_argument("--seed", type=int, default=7)
@@ -301,7 +301,7 @@ def new_agg():
     return dict(index_ms=0.0, seed_ms=0.0, extend_ms=0.0, myers_ms=0.0, traceback_ms=0.0, launches=0, blocks=0, words=0, bases=0, rounds=0,
                 a_ms=0.0, a_launches=0, a_blocks=0, tb_a_ms=0.0, big_ms=0.0, big_blocks=0, band_words=0,
                 ix_local_ms=0.0, ix_xchg_ms=0.0, ix_xchg_bytes=0, gather_ms=0.0, gather_bytes=0, reads_local=0,
-                fused_ms=0.0, fused_launches=0, fused_blocks=0)
+                fused_ms=0.0, fused_launches=0, fused_blocks=0, rc_ms=0.0, rc_ck_ms=0.0, rc_launches=0, rc_blocks=0, rc_words=0)
 
 
 def agg_add(agg, tm, t_index=0.0):
@@ -315,6 +315,7 @@ def agg_add(agg, tm, t_index=0.0):
         agg["big_blocks"], agg["big_ms"] = int(tm.myersA_big_blocks), float(tm.myersA_big_ms)
     agg["a_ms"] += tm.myersA_ms; agg["a_launches"] += tm.myersA_launches; agg["a_blocks"] += tm.myersA_blocks
     agg["fused_ms"] += tm.fused_ms; agg["fused_launches"] += tm.fused_launches; agg["fused_blocks"] += tm.fused_blocks
+    agg["rc_ms"] += tm.rc_ms; agg["rc_ck_ms"] += tm.rc_ck_ms; agg["rc_launches"] += tm.rc_launches; agg["rc_blocks"] += tm.rc_blocks; agg["rc_words"] += tm.rc_words
 
 
 def gather_rank_stats(dist, mine):
@@ -505,77 +506,76 @@ def pmc_builds(pmc):
     return 1
 
 
+NW_BAND_WORDS_PER_BLOCK = 1.91 * 477        # the reference's banded NW pass, words per column x columns, measured on the oracle
+SHW_BANDED_FRACTION = 6.25 / 8.0            # the reference's banded SHW pass computes 6.25 of 8 words per column
+
+
 def roofline_report(agg):
-    """roofline object of the bench line from the summed per-step timings / work counters of one rank"""
-    # ---- roofline of the dominant kernel: k_myers_coop<8,16,512,8,false>, the DP of the list-A blocks (<= 512 x 512).
-    # Integer DP: the bound is VALU issue, not HBM (SURVEY.md 8d).  Work unit = one 64-row Myers word update, priced at
-    # OPS_PER_WORD_UPDATE 32-bit lane-ops (DESIGN.md 5.3) against the chip's full-rate 32-bit VALU peak (256 CU x 4 SIMD-32
-    # x 2.4 GHz; tools/valu_microbench2.hip measures which instructions reach that rate).  `achieved` counts only the
-    # ALGORITHMIC word updates - what the reference's banded passes compute (SURVEY 8d: 6.25 of 8 words per SHW column,
-    # measured there; the NW band words are counted by the kernel itself) - `computed_frac` the updates actually executed.
-    # The HBM side is kept as a sub-field: algorithmic bytes per block alignment = its two 2-bit fragments in + one 16-byte
-    # result out; `traffic` = HBM bytes per launch from the PMC passes kept in profiles/ (the stored traceback band).
-    A_BYTES_PER_BLOCK = 2 * 512 / 4.0 + 16.0
-    SHW_BANDED_FRACTION = 6.25 / 8.0
-    a_launches = max(1, agg["a_launches"])
-    avg_launch_ms = agg["a_ms"] / a_launches
-    alg_per_launch = A_BYTES_PER_BLOCK * agg["a_blocks"] / a_launches
-    achieved_hbm = alg_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
-    words, band = float(agg["words"]), float(agg["band_words"])
-    # computed = SHW (every word of every column) + NW (every word up to the end column); algorithmic = banded SHW + NW band
-    nw_computed = words / 2.0            # the two passes cover (almost) the same columns; exact split is not needed for a fraction
-    useful_words = (words - nw_computed) * SHW_BANDED_FRACTION + band
-    word_rate = words / (agg["myers_ms"] * 1e-3) if agg["myers_ms"] > 0 else 0.0
-    useful_rate = useful_words / (agg["myers_ms"] * 1e-3) if agg["myers_ms"] > 0 else 0.0
-    # the list-A two-pass kernel alone (launches of > NECAT_SINGLE_PASS blocks): its share of the word updates ~ its share of the blocks
-    a_share = agg["a_blocks"] / max(1, agg["blocks"])
-    a_useful_rate = useful_words * a_share / (agg["a_ms"] * 1e-3) if agg["a_ms"] > 0 else 0.0
-    achieved_tops = a_useful_rate * OPS_PER_WORD_UPDATE / 1e12
+    """roofline object of the bench line from the summed per-step timings / work counters of one rank.
+
+    Integer DP: the bound is VALU issue, not HBM.  Work unit = one 64-row Myers word update, priced at
+    OPS_PER_WORD_UPDATE 32-bit lane-ops against the chip's full-rate 32-bit VALU peak (256 CU x 4 SIMD-32 x 2.4 GHz).  `achieved` counts
+    only the ALGORITHMIC word updates - what the reference's banded passes compute: 6.25 of 8 words per SHW column and 1.91 words per NW
+    column (measured there) - `computed_frac` the updates actually executed.  The dominant kernels are the two that run the
+    full 512 x 512 blocks of the big rounds (necat_amd/csrc/ext_rcwalk.h): k_myers_ck (SHW pass of every word + checkpoints) and k_rcwalk4
+    (the walk, which recomputes the cells it stands on: no NW pass, no band records in HBM); taken together, since a block needs both."""
     peak_tops = VALU_LANE_OPS_PER_S / 1e12
-    traffic = tb_traffic = None
-    pmc_file = None
-    for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+    rc_ms = agg["rc_ck_ms"] + agg["rc_ms"]
+    launches = max(1, agg["rc_launches"])
+    blocks = float(agg["rc_blocks"])
+    useful = blocks * (4096.0 * SHW_BANDED_FRACTION + NW_BAND_WORDS_PER_BLOCK)
+    computed = blocks * 4096.0 + float(agg["rc_words"])
+    useful_rate = useful / (rc_ms * 1e-3) if rc_ms > 0 else 0.0
+    computed_rate = computed / (rc_ms * 1e-3) if rc_ms > 0 else 0.0
+    achieved_tops = useful_rate * OPS_PER_WORD_UPDATE / 1e12
+    # HBM view of the same launches: algorithmic bytes per block = its two 2-bit fragments in + a 16-byte result out
+    alg_per_launch = (2 * 512 / 4.0 + 16.0) * blocks / launches
+    avg_pair_ms = rc_ms / launches
+    achieved_hbm = alg_per_launch / (avg_pair_ms * 1e-3) / 1e9 if avg_pair_ms > 0 else 0.0
+    traffic = pmc_file = None
+    for name in ("r03_pmc_hbm_traffic.json",):
         pth = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pth):
-            pmc_file = name
-            break
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))
-
-        def pmc_bytes(prefix):
-            k = next(v for n, v in pmc.items() if n.startswith(prefix))
-            # FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section)
-            return (2.0 * k["FETCH_SIZE_KB_per_launch"] + k["WRITE_SIZE_KB_per_launch"]) * 1024.0
-        traffic = pmc_bytes("void necat::k_myers_coop<8, 16, 512, 8, false>")
-        tb_traffic = pmc_bytes("void necat::k_traceback<8, 16, 512, 1024, false>")
-    except Exception:
-        pass
-    tb_avg_ms = agg["tb_a_ms"] / a_launches
-    roofline = {"bound": "valu", "kernel": "k_myers_coop<8,16,512,8,false>", "achieved": round(achieved_tops, 3), "peak": round(peak_tops, 2),
-                "unit": "T lane-op/s (32-bit VALU)", "frac": round(achieved_tops / peak_tops, 4),
-                "traffic": traffic,
-                "launches": int(agg["a_launches"]), "avg_launch_ms": round(avg_launch_ms, 4),
-                "useful_word_updates_per_s": round(a_useful_rate, 1), "ops_per_word_update": OPS_PER_WORD_UPDATE,
-                "computed_frac": round(word_rate * OPS_PER_WORD_UPDATE / VALU_LANE_OPS_PER_S, 4),
-                "useful_over_computed": round(useful_words / words, 4) if words else None,
-                "band_words_per_block": round(band / max(1, agg["blocks"]), 1),
-                "hbm": {"achieved": round(achieved_hbm, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_hbm / HBM_PEAK_GBS, 6),
-                        "algorithmic_bytes_per_launch": round(alg_per_launch, 1),
-                        "traffic_frac": round(traffic / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_launch_ms > 0 else None,
-                        "traffic_source": "profiles/%s" % pmc_file if traffic else None},
-                "traceback_kernel": {"kernel": "k_traceback<8,16,512,1024,false>", "avg_launch_ms": round(tb_avg_ms, 4), "traffic": tb_traffic,
-                                     "traffic_frac": round(tb_traffic / (tb_avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tb_traffic and tb_avg_ms > 0 else None},
-                # the launch with the most blocks (throughput regime; the small launches of the late rounds are latency bound)
-                "biggest_launch": {"blocks": agg["big_blocks"], "ms": round(agg["big_ms"], 4),
-                                   "computed_frac": round(agg["big_blocks"] * 8192.0 * OPS_PER_WORD_UPDATE / (agg["big_ms"] * 1e-3) / VALU_LANE_OPS_PER_S, 4) if agg["big_ms"] > 0 else None},
-                "all_dp_kernels": {"launches": int(agg["launches"]), "ms": round(agg["myers_ms"], 2), "blocks": int(agg["blocks"]),
-                                   "word_updates_per_s": round(word_rate, 1), "useful_word_updates_per_s": round(useful_rate, 1),
-                                   "useful_frac": round(useful_rate * OPS_PER_WORD_UPDATE / VALU_LANE_OPS_PER_S, 4)},
-                "note": "integer DP, VALU-issue bound: frac = algorithmic word updates (banded SHW 6.25/8 words per column per SURVEY 8d + the NW band words the "
-                        "kernel counts) x %d lane-ops / launch time / (256 CU x 4 SIMD-32 x 2.4 GHz); computed_frac = the same for the word updates actually "
-                        "executed (both passes compute every word). Issue-rate evidence: profiles/r02_valu_microbench2.txt, profiles/r02_sq_counters*.json. "
-                        "hbm.* = the contract's HBM view (small by construction)." % OPS_PER_WORD_UPDATE}
-    return roofline
+            try:
+                pmc = json.load(open(pth))
+                tot = 0.0
+                for kn, v in pmc.items():
+                    if "necat::k_myers_ck" in kn or "necat::k_rcwalk4" in kn:
+                        tot += (2.0 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0
+                if tot > 0:
+                    traffic, pmc_file = tot, name
+            except Exception:
+                pass
+    words, band = float(agg["words"]), float(agg["band_words"])
+    all_ms = agg["myers_ms"] + agg["rc_ms"] + agg["fused_ms"]
+    return {"bound": "valu", "kernel": "k_myers_ck<8,16> + k_rcwalk4<8,16,1024> (the full 512 x 512 blocks of the big rounds: SHW with checkpoints, then the recomputing walk)",
+            "achieved": round(achieved_tops, 3), "peak": round(peak_tops, 2), "unit": "T lane-op/s (32-bit VALU)", "frac": round(achieved_tops / peak_tops, 4),
+            "traffic": traffic,
+            "launches": int(agg["rc_launches"]), "avg_launch_ms": {"k_myers_ck": round(agg["rc_ck_ms"] / launches, 4), "k_rcwalk4": round(agg["rc_ms"] / launches, 4)},
+            # each kernel alone: the SHW pass (algorithmic = 6.25 of its 8 words per column) and the recomputing walk (algorithmic = the
+            # reference's NW band words; what it recomputes on top is the price of reading no band from HBM)
+            "k_myers_ck": {"frac": round(blocks * 4096.0 * SHW_BANDED_FRACTION * OPS_PER_WORD_UPDATE / (agg["rc_ck_ms"] * 1e-3) / VALU_LANE_OPS_PER_S, 4) if agg["rc_ck_ms"] > 0 else None,
+                           "computed_frac": round(blocks * 4096.0 * OPS_PER_WORD_UPDATE / (agg["rc_ck_ms"] * 1e-3) / VALU_LANE_OPS_PER_S, 4) if agg["rc_ck_ms"] > 0 else None},
+            "k_rcwalk4": {"frac": round(blocks * NW_BAND_WORDS_PER_BLOCK * OPS_PER_WORD_UPDATE / (agg["rc_ms"] * 1e-3) / VALU_LANE_OPS_PER_S, 4) if agg["rc_ms"] > 0 else None,
+                          "computed_frac": round(float(agg["rc_words"]) * OPS_PER_WORD_UPDATE / (agg["rc_ms"] * 1e-3) / VALU_LANE_OPS_PER_S, 4) if agg["rc_ms"] > 0 else None,
+                          "note": "also walks the alignment (520 steps per block on LDS) - the work of r02's k_traceback is inside this kernel's time"},
+            "blocks": int(blocks), "useful_word_updates_per_s": round(useful_rate, 1), "ops_per_word_update": OPS_PER_WORD_UPDATE,
+            "computed_frac": round(computed_rate * OPS_PER_WORD_UPDATE / VALU_LANE_OPS_PER_S, 4),
+            "useful_over_computed": round(useful / computed, 4) if computed else None,
+            "recomputed_words_per_block": round(agg["rc_words"] / blocks, 1) if blocks else None,
+            "issue_bound_note": "a MIXED stream of full-rate (v_xor, v_bitop3) and half-rate (v_alignbit, DPP, shifts, 64-bit add) VALU instructions issues every "
+                                "instruction at ~3.5 cycles, not 2 (profiles/r03_valu_microbench3.txt): the kernels' bound is instruction count x 3.5 cycles, "
+                                "which the SQ counters put them at ~0.9 of (profiles/r03_sq_counters*.json); `frac` is against the 2-cycle datasheet rate",
+            "hbm": {"achieved": round(achieved_hbm, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_hbm / HBM_PEAK_GBS, 6),
+                    "algorithmic_bytes_per_launch_pair": round(alg_per_launch, 1),
+                    "traffic_frac": round(traffic / (avg_pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_pair_ms > 0 else None,
+                    "traffic_source": "profiles/%s" % pmc_file if traffic else None},
+            "all_dp_and_walk_kernels": {"ms": round(all_ms + agg["traceback_ms"], 2), "dp_ms": round(agg["myers_ms"], 2), "rcwalk_ms": round(agg["rc_ms"], 2),
+                                        "walk_and_finish_ms": round(agg["traceback_ms"] - agg["rc_ms"], 2), "fused_tail_ms": round(agg["fused_ms"], 2),
+                                        "blocks": int(agg["blocks"]), "word_updates": int(words), "band_words_stored": int(band)},
+            "note": "integer DP, VALU-issue bound: frac = algorithmic word updates (SURVEY 8d: banded SHW 6.25/8 words per column + 1.91 NW words per column) x %d "
+                    "lane-ops / (k_myers_ck + k_rcwalk4 time) / (256 CU x 4 SIMD-32 x 2.4 GHz); computed_frac = the same for the word updates actually executed "
+                    "(4096 per block in the SHW pass + what the walk recomputes). hbm.* = the contract's HBM view (small by construction)." % OPS_PER_WORD_UPDATE}
 
 
 def main():
@@ -717,7 +717,7 @@ def main():
         "phases_ms_per_step": {"index": round(agg["index_ms"] / K, 2), "seed": round(agg["seed_ms"] / K, 2),
                                "extend": round(agg["extend_ms"] / K, 2), "myers_kernel": round(agg["myers_ms"] / K, 2),
                                "traceback_kernel": round(agg["traceback_ms"] / K, 2),
-                               "fused_tail_kernel": round(agg["fused_ms"] / K, 2), "fused_tail_launches": agg["fused_launches"] // K,
+                               "rcwalk_kernel": round(agg["rc_ms"] / K, 2), "fused_tail_kernel": round(agg["fused_ms"] / K, 2), "fused_tail_launches": agg["fused_launches"] // K,
                                "fused_tail_blocks": agg["fused_blocks"] // K, "rounds": agg["rounds"] // K},
         "device": ctx.device_name(),
         "roofline": roofline,

@@ -121,6 +121,12 @@ typedef struct {
      * traceback_ms */
     double   fused_ms;
     uint64_t fused_launches, fused_blocks;
+    /* the full 512 x 512 blocks of the big list-A rounds (necat_amd/csrc/ext_rcwalk.h): k_myers_ck (SHW pass + checkpoints; its time is
+     * what myersA_ms holds for those rounds) and k_rcwalk4 (the walk that recomputes its cells: rc_ms); rc_blocks of them, rc_words word
+     * updates recomputed by the walk (each block also cost 4096 in the SHW pass) */
+    double   rc_ms;
+    uint64_t rc_launches, rc_blocks, rc_words;
+    double   rc_ck_ms;          /* k_myers_ck of those rounds (beside the ragged blocks' DP kernel on another stream) */
 } necat_timings;
 
 void        necat_default_options(necat_map_options* o);            /* map_options.c:12-28 */

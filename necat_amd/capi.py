@@ -34,7 +34,9 @@ class Timings(C.Structure):
                 ("myersA_ms", C.c_double), ("myersA_launches", C.c_uint64), ("myersA_blocks", C.c_uint64),
                 ("tracebackA_ms", C.c_double), ("myersA_big_ms", C.c_double), ("myersA_big_blocks", C.c_uint64),
                 ("myers_band_words", C.c_uint64),
-                ("fused_ms", C.c_double), ("fused_launches", C.c_uint64), ("fused_blocks", C.c_uint64)]
+                ("fused_ms", C.c_double), ("fused_launches", C.c_uint64), ("fused_blocks", C.c_uint64),
+                ("rc_ms", C.c_double), ("rc_launches", C.c_uint64), ("rc_blocks", C.c_uint64), ("rc_words", C.c_uint64),
+                ("rc_ck_ms", C.c_double)]
 
 
 class ShardTimings(C.Structure):

@@ -105,6 +105,7 @@ k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u
         br.words = (u32)(NW * N) | ((best > max_dist && !err) ? kWideFlag : 0u);      // max_dist <= kRcMaxDist (smaller in tests: more blocks take the old path)
         results[item] = br;
         atomicAdd(&stats[0], (unsigned long long)(NW * N)); atomicAdd(&stats[1], (unsigned long long)(2 * N));
+        if (br.dist >= 0 && !(br.words & kWideFlag)) atomicAdd(&stats[3], 1ULL);          // blocks k_rcwalk4 will walk
     }
 }
 
@@ -243,7 +244,7 @@ k_rcwalk4(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u3
         __syncthreads();             // the slices are read before the next segment overwrites them
     }
     for (int o = 32; o > 0; o >>= 1) words_done += (u32)__shfl_xor((int)words_done, o);
-    if (lane == 0 && words_done) { atomicAdd(&stats[0], (unsigned long long)words_done); atomicAdd(&stats[2], (unsigned long long)words_done); }
+    if (lane == 0 && words_done) { atomicAdd(&stats[0], (unsigned long long)words_done); atomicAdd(&stats[4], (unsigned long long)words_done); }
 }
 
 }  // namespace necat

@@ -1023,6 +1023,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
 {
     struct Cnt { u32 nA, nB; };
     std::vector<Cnt> hist;                      // published sizes of lists[r]
+    std::vector<u32> rc_round;                  // rounds whose full blocks ran through ext_rcwalk.h (ev[26 + r % 4] marks the end of k_rcwalk4)
     std::vector<u8> a_timed;                    // A(r) ran its DP + traceback kernels (events recorded); 2 = as one fused launch (ext_tail.h)
     const unsigned long long seq0 = ctx->round_seq;
     volatile RoundPub* ring = (volatile RoundPub*)ctx->round_ring;
@@ -1060,6 +1061,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         }
         const double mA = ev_ms(c.a0[q], c.a1[q]), tA = ev_ms(c.a1[q], c.a2[q]);
         ctx->tm.myers_ms += mA; ctx->tm.traceback_ms += tA;
+        if (std::find(rc_round.begin(), rc_round.end(), r) != rc_round.end()) { ctx->tm.rc_ms += ev_ms(c.a1[q], ctx->ev[26 + (r & 3)]); ctx->tm.rc_ck_ms += mA; ctx->tm.rc_launches += 1; }
         if (nA > g_single_pass) {      // the two-pass instantiation k_myers_coop<8,16,512,8,false> (bench.py's roofline kernel)
             ctx->tm.myersA_ms += mA; ctx->tm.tracebackA_ms += tA; ctx->tm.myersA_launches += 1; ctx->tm.myersA_blocks += nA;
         }
@@ -1251,6 +1253,8 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
             hipLaunchKernelGGL((k_rcwalk4<kWordsA, kTWordsA, kOpsA>), dim3((bound + 15) / 16), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, (const ulonglong2*)ck,
                                (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, c.opsA, wo, X.stats, X.d_err);
             NECAT_CHECK_LAUNCH(ctx, "k_rcwalk4");
+            NECAT_HIP(ctx, hipEventRecord(ctx->ev[26 + (r & 3)], c.sa));       // a1 -> this: k_rcwalk4 alone (account_a)
+            rc_round.push_back(r);
             hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, 5>), dim3(gA), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap,
                                (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
                                (i32*)nullptr, X.d_err, next, epoch, 0u, (const WalkOut*)wo);
@@ -1385,6 +1389,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     ctx->tm.myersA_ms = ctx->tm.tracebackA_ms = 0; ctx->tm.myersA_launches = ctx->tm.myersA_blocks = 0;
     ctx->tm.myersA_big_ms = 0; ctx->tm.myersA_big_blocks = 0;
     ctx->tm.fused_ms = 0; ctx->tm.fused_launches = ctx->tm.fused_blocks = 0;
+    ctx->tm.rc_ms = ctx->tm.rc_ck_ms = 0; ctx->tm.rc_launches = ctx->tm.rc_blocks = ctx->tm.rc_words = 0;
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
     // batches of <= 786 432 candidates: every batch ends in ~20 latency-bound rounds, so fewer and bigger is better
     // (yeast-size: 654 -> 615 ms against 393 216); their band records need <= 103 GB for list A + a few GB for list B
@@ -1549,10 +1554,11 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     }
     tick("rounds");
     {
-        unsigned long long hs[3] = {0, 0, 0};
-        NECAT_HIP(ctx, hipMemcpyAsync(hs, X.stats, 24, hipMemcpyDeviceToHost, s));
+        unsigned long long hs[5] = {0, 0, 0, 0, 0};
+        NECAT_HIP(ctx, hipMemcpyAsync(hs, X.stats, 40, hipMemcpyDeviceToHost, s));
         NECAT_HIP(ctx, hipStreamSynchronize(s));
         ctx->tm.myers_word_updates = hs[0]; ctx->tm.myers_cells_bases = hs[1]; ctx->tm.myers_band_words = hs[2];
+        ctx->tm.rc_blocks = hs[3]; ctx->tm.rc_words = hs[4];
     }
     if (ao) {
         int herr = 0;
