@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--cpu-t1", action="store_true", help="also time the reference with -t 1 on the bench workload itself (minutes)")
     ap.add_argument("--cpu-t1-genome", type=int, default=460_000,
                     help="genome size of the reduced sample the reference's -t 1 leg runs on by default (SURVEY 8d asks for -t 1; at full size it takes minutes); 0 = no -t 1 leg")
+    ap.add_argument("--asmpm-genome", type=int, default=0,
+                    help="also time the oc2asmpm program (SURVEY 8f.2) on corrected reads (3 %% errors) of a genome of this size x 20 against the "
+                         "reference's own program on the same host cores (widened_paths.oc2asmpm); 0 = skip (5 000 000 = 100 Mbp: minutes of CPU)")
     ap.add_argument("--parallelism", choices=["single-volume", "volumes", "pairs"], default="single-volume",
                     help="N > 1: one volume on all GPUs (strong scaling, RCCL data path), one volume per GPU (weak), or the (reference, query) "
                          "volume pairs of a --volumes V project dealt to the GPUs by cost (strong)")
@@ -147,6 +150,25 @@ def host_cpu():
     return model, (len(cores) or threads), threads
 
 
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None: a box with 256 hardware threads may
+    still hand this process 16 of them - more runnable threads than that are throttled, not run"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(round(int(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, int(round(q / float(per))))
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(args, opt_kw, rs, vol_dir):
     """The reference's own oc2pmov (oracle/_ref, built from /root/reference) - or, when absent, the oracle port - on
     this host's cores, on the SAME volume the GPU steps ran on, with the thread policy of SURVEY.md 8d: -t = physical
@@ -155,8 +177,9 @@ def cpu_baseline(args, opt_kw, rs, vol_dir):
     whole process (index build = one thread walking the 8.6 GB table, ~60 s regardless of the input)."""
     from oracle import oracle_api as ora
     model, phys, threads = host_cpu()
+    quota = cpu_quota()
     chunks = (rs.nreads + 499) // 500
-    cores = max(1, min(phys, chunks))
+    cores = max(1, min(phys, chunks, quota or phys))
     kind = "reference" if ora.have_ref() else "port"
 
     def run(nthreads):
@@ -174,10 +197,10 @@ def cpu_baseline(args, opt_kw, rs, vol_dir):
         return nrec, t_map, wall
     nrec, t_map, wall = run(cores)
     res = {"value": round(nrec / max(t_map, 1e-9), 1), "unit": "overlaps/s", "cores": cores, "kind": kind,
-           "cpu_model": model, "host_physical_cores": phys, "host_threads": threads,
+           "cpu_model": model, "host_physical_cores": phys, "host_threads": threads, "cpu_quota_cores": quota,
            "sample": "the bench workload itself (%d reads, %d bp, same volume file, same options), -t %d = min(physical cores %d, "
-                     "500-read chunks %d); value = records / mapping phase %.2f s (the reference's 'pairwise mapping' timer, index "
-                     "build excluded); whole process %.1f s" % (rs.nreads, rs.nbases, cores, phys, chunks, t_map, wall),
+                     "500-read chunks %d, the container's CPU quota %s); value = records / mapping phase %.2f s (the reference's 'pairwise "
+                     "mapping' timer, index build excluded); whole process %.1f s" % (rs.nreads, rs.nbases, cores, phys, chunks, quota, t_map, wall),
            "overlaps": nrec, "mapping_s": round(t_map, 3), "whole_process_s": round(wall, 2),
            "whole_process_overlaps_per_s": round(nrec / max(wall, 1e-9), 1)}
     if args.cpu_t1:
@@ -263,6 +286,42 @@ def widened_paths(ctx, vol, capi, opt_kw):
     best[1]["templates_per_s"] = round(best[1]["templates"] / best[0], 1)
     res["cns_extension_loop"] = best[1]
     res["_partition"] = part
+    return res
+
+
+def oc2asmpm_program(genome, threads, tmp):
+    """oc2asmpm (the overlapper of corrected reads, necat.pl:573,880,1000,1152) as a program: this repo's (host vote + chained ranges, the
+    2048-bp block aligner on the device, host end extension) and the reference's own on the same host threads, same volume, same options
+    (ASM_OVLP_OPTIONS of necat.pl:36); the records must be the same"""
+    import re
+    from necat_amd import build, synth
+    from oracle import oracle_api as ora
+    build.build_cli()
+    rs = synth.simulate_reads(genome, 20.0, seed=71, err=0.03, repeat_frac=0.05)
+    wrk = os.path.join(tmp, "asm_vols")
+    nv = synth.write_volume_dir(wrk, rs)
+    args = "-n 100 -z 10 -b 2000 -e 0.5 -j 1 -u 0 -a 400".split()
+    res = {"reads": rs.nreads, "bases": rs.nbases, "volumes": nv, "host_threads": threads, "options": " ".join(args)}
+    mine = os.path.join(tmp, "asm_mine.m4")
+    t0 = time.time()
+    r = subprocess.run([build.OC2ASMPM] + args + ["-t", str(threads), wrk, "0", mine], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, NECAT_TRACE="2"))
+    res["wall_s"] = round(time.time() - t0, 2)
+    if r.returncode != 0:
+        return dict(res, error=r.stderr[-300:])
+    calls = re.findall(r"asm_align \(cooperative\): (\d+) anchors, (\d+) rounds, (\d+) blocks, DP ([0-9.]+) ms, walk ([0-9.]+) ms, whole call ([0-9.]+) ms", r.stderr)
+    res.update(records=sum(1 for _ in open(mine, "rb")), anchors=sum(int(c[0]) for c in calls), block_alignments=sum(int(c[2]) for c in calls),
+               device_ms=round(sum(float(c[5]) for c in calls), 2), device_dp_ms=round(sum(float(c[3]) for c in calls), 2), device_walk_ms=round(sum(float(c[4]) for c in calls), 2))
+    if res["device_ms"] > 0:
+        res["anchors_per_s_device"] = round(res["anchors"] / (res["device_ms"] * 1e-3), 1)
+    ref = os.path.join(os.path.dirname(ora.REF_PMOV), "oc2asmpm")
+    if os.path.exists(ref):
+        out = os.path.join(tmp, "asm_ref.m4")
+        t0 = time.time()
+        rr = subprocess.run([ref] + args + ["-t", str(threads), wrk, "0", out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        res["reference_wall_s"] = round(time.time() - t0, 2)
+        if rr.returncode == 0:
+            res["same_records"] = sorted(open(out, "rb").read().splitlines()) == sorted(open(mine, "rb").read().splitlines())
+            res["speedup_program"] = round(res["reference_wall_s"] / max(res["wall_s"], 1e-9), 2)
     return res
 
 
@@ -756,10 +815,15 @@ def main():
                     out["oc2pmov_cold_start"] = cold_start_cli(args, opt_kw, vol_dir, local)
                 except Exception as e:
                     out["oc2pmov_cold_start"] = {"error": str(e)}
+                if args.asmpm_genome:
+                    try:
+                        out.setdefault("widened_paths", {})["oc2asmpm"] = oc2asmpm_program(args.asmpm_genome, min(host_cpu()[1], cpu_quota() or 1 << 30), tmp)
+                    except Exception as e:
+                        out.setdefault("widened_paths", {})["oc2asmpm"] = {"error": str(e)}
                 # ... and the consumer of its candidates: the oc2cns program (GPU extension loop + host consensus) on the same reads
                 if cns_part is not None:
                     try:
-                        out["widened_paths"]["oc2cns_program"] = oc2cns_program(vol_dir, cns_part, host_cpu()[1])
+                        out["widened_paths"]["oc2cns_program"] = oc2cns_program(vol_dir, cns_part, min(host_cpu()[1], cpu_quota() or 1 << 30))
                     except Exception as e:
                         out["widened_paths"]["oc2cns_program"] = {"error": str(e)}
             out["cpu_baseline"] = cpu_baseline(args, opt_kw, rs_cpu, vol_dir)
