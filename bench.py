@@ -576,7 +576,7 @@ def roofline_report(agg):
     OPS_PER_WORD_UPDATE 32-bit lane-ops against the chip's full-rate 32-bit VALU peak (256 CU x 4 SIMD-32 x 2.4 GHz).  `achieved` counts
     only the ALGORITHMIC word updates - what the reference's banded passes compute: 6.25 of 8 words per SHW column and 1.91 words per NW
     column (measured there) - `computed_frac` the updates actually executed.  The dominant kernels are the two that run the
-    full 512 x 512 blocks of the big rounds (necat_amd/csrc/ext_rcwalk.h): k_myers_ck (SHW pass of every word + checkpoints) and k_rcwalk4
+    full 512 x 512 blocks of the big rounds (necat_amd/csrc/ext_rcwalk.h): k_myers_ck (SHW pass of every word + checkpoints + the words' horizontal deltas) and k_rcwalk2
     (the walk, which recomputes the cells it stands on: no NW pass, no band records in HBM); taken together, since a block needs both."""
     peak_tops = VALU_LANE_OPS_PER_S / 1e12
     rc_ms = agg["rc_ck_ms"] + agg["rc_ms"]
@@ -599,7 +599,7 @@ def roofline_report(agg):
                 pmc = json.load(open(pth))
                 tot = 0.0
                 for kn, v in pmc.items():
-                    if "necat::k_myers_ck" in kn or "necat::k_rcwalk4" in kn:
+                    if "necat::k_myers_ck" in kn or "necat::k_rcwalk" in kn:
                         tot += (2.0 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0
                 if tot > 0:
                     traffic, pmc_file = tot, name
@@ -607,15 +607,15 @@ def roofline_report(agg):
                 pass
     words, band = float(agg["words"]), float(agg["band_words"])
     all_ms = agg["myers_ms"] + agg["rc_ms"] + agg["fused_ms"]
-    return {"bound": "valu", "kernel": "k_myers_ck<8,16> + k_rcwalk4<8,16,1024> (the full 512 x 512 blocks of the big rounds: SHW with checkpoints, then the recomputing walk)",
+    return {"bound": "valu", "kernel": "k_myers_ck<8,16,true> + k_rcwalk2<8,16,1024> (the full 512 x 512 blocks of the big rounds: SHW with checkpoints and horizontal deltas, then the walk that recomputes the two words it stands on)",
             "achieved": round(achieved_tops, 3), "peak": round(peak_tops, 2), "unit": "T lane-op/s (32-bit VALU)", "frac": round(achieved_tops / peak_tops, 4),
             "traffic": traffic,
-            "launches": int(agg["rc_launches"]), "avg_launch_ms": {"k_myers_ck": round(agg["rc_ck_ms"] / launches, 4), "k_rcwalk4": round(agg["rc_ms"] / launches, 4)},
+            "launches": int(agg["rc_launches"]), "avg_launch_ms": {"k_myers_ck": round(agg["rc_ck_ms"] / launches, 4), "k_rcwalk2": round(agg["rc_ms"] / launches, 4)},
             # each kernel alone: the SHW pass (algorithmic = 6.25 of its 8 words per column) and the recomputing walk (algorithmic = the
             # reference's NW band words; what it recomputes on top is the price of reading no band from HBM)
             "k_myers_ck": {"frac": round(blocks * 4096.0 * SHW_BANDED_FRACTION * OPS_PER_WORD_UPDATE / (agg["rc_ck_ms"] * 1e-3) / VALU_LANE_OPS_PER_S, 4) if agg["rc_ck_ms"] > 0 else None,
                            "computed_frac": round(blocks * 4096.0 * OPS_PER_WORD_UPDATE / (agg["rc_ck_ms"] * 1e-3) / VALU_LANE_OPS_PER_S, 4) if agg["rc_ck_ms"] > 0 else None},
-            "k_rcwalk4": {"frac": round(blocks * NW_BAND_WORDS_PER_BLOCK * OPS_PER_WORD_UPDATE / (agg["rc_ms"] * 1e-3) / VALU_LANE_OPS_PER_S, 4) if agg["rc_ms"] > 0 else None,
+            "k_rcwalk2": {"frac": round(blocks * NW_BAND_WORDS_PER_BLOCK * OPS_PER_WORD_UPDATE / (agg["rc_ms"] * 1e-3) / VALU_LANE_OPS_PER_S, 4) if agg["rc_ms"] > 0 else None,
                           "computed_frac": round(float(agg["rc_words"]) * OPS_PER_WORD_UPDATE / (agg["rc_ms"] * 1e-3) / VALU_LANE_OPS_PER_S, 4) if agg["rc_ms"] > 0 else None,
                           "note": "also walks the alignment (520 steps per block on LDS) - the work of r02's k_traceback is inside this kernel's time"},
             "blocks": int(blocks), "useful_word_updates_per_s": round(useful_rate, 1), "ops_per_word_update": OPS_PER_WORD_UPDATE,
@@ -633,7 +633,7 @@ def roofline_report(agg):
                                         "walk_and_finish_ms": round(agg["traceback_ms"] - agg["rc_ms"], 2), "fused_tail_ms": round(agg["fused_ms"], 2),
                                         "blocks": int(agg["blocks"]), "word_updates": int(words), "band_words_stored": int(band)},
             "note": "integer DP, VALU-issue bound: frac = algorithmic word updates (SURVEY 8d: banded SHW 6.25/8 words per column + 1.91 NW words per column) x %d "
-                    "lane-ops / (k_myers_ck + k_rcwalk4 time) / (256 CU x 4 SIMD-32 x 2.4 GHz); computed_frac = the same for the word updates actually executed "
+                    "lane-ops / (k_myers_ck + k_rcwalk2 time) / (256 CU x 4 SIMD-32 x 2.4 GHz); computed_frac = the same for the word updates actually executed "
                     "(4096 per block in the SHW pass + what the walk recomputes). hbm.* = the contract's HBM view (small by construction)." % OPS_PER_WORD_UPDATE}
 
 

@@ -850,7 +850,8 @@ k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
     if (!list_item(lv, items, item, it)) return;
     const BlockResult br = results[item];
     // WALK == 5: the walks were done by k_rcwalk4 (the wide blocks it left out are walked by an `only wide` launch: epoch bit 25)
-    if (WALK == 5 && (item >= lv.nf || (br.words & kWideFlag))) return;
+    // (epoch bit 27: every block of the list, not only the full ones at the front of a two-ended list A)
+    if (WALK == 5 && ((item >= lv.nf && !((epoch >> 27) & 1u)) || (br.words & kWideFlag))) return;
     if (WALK != 5 && ((epoch >> 26) & 1u) && item < lv.nf16) return;
     if (WALK != 5 && (((epoch >> 25) & 1u) || (((epoch >> 24) & 1u) && item < lv.nf16)) && !(br.words & kWideFlag)) return;
     if (br.err) atomicExch(err_flag, 10 + br.err);

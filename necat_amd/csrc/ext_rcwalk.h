@@ -24,17 +24,23 @@ namespace necat {
 
 constexpr int kRcSeg = 32;                       // columns per segment = per checkpoint
 constexpr int kRcCk = kOcaBlockSize / kRcSeg;    // checkpoint slots per block (the last one is never read)
+constexpr int kRcCk16 = kOcaBlockSize / 16;      // .. of the CARRY variant
 constexpr int kRcMaxDist = 160;                  // 63 (alignment of the window) + 31 (columns) + best <= 255 rows of a 4-word window
 
 // ---- SHW with checkpoints (fast_shw8 of ext_fast16.h + one 16-byte store per lane every 32 steps)
-template <int TW>
-NECAT_D u32 fast_shw8_ck(const int b, const u64* __restrict__ tw, const u64 nlo, const u64 nhi, ulonglong2* __restrict__ ck)
+// CARRY (the 2-lane-window walk k_rcwalk2 below): checkpoints every 16 columns (slot m = the state after column 16 m + 15) and every word's
+// horizontal output deltas kept as well - two bits per column, 32 columns per u64 {P bits, M bits << 32}, the bit of column 32 m + x at
+// position 31 - x (one v_alignbit per plane and step) - so that ANY word can later be recomputed exactly from a checkpoint alone.
+template <int TW, bool CARRY>
+NECAT_D u32 fast_shw8_ck(const int b, const u64* __restrict__ tw, const u64 nlo, const u64 nhi, ulonglong2* __restrict__ ck, u64* __restrict__ hc)
 {
     constexpr int G = 8, N = kOcaBlockSize, kSteps = N + G - 1;
     const u32 cm = b == G - 1 ? 0x80000000u : 0u;
     const u32 nlo_l = (u32)nlo, nlo_h = (u32)(nlo >> 32), nhi_l = (u32)nhi, nhi_h = (u32)(nhi >> 32);
     const u32 sk = (u32)(32 - b) & 31u;
     const int jck = (b + 31) & 31;               // the step (mod 32) at which this lane's column is 31 mod 32
+    const int jck16 = (b + 15) & 15;             // .. (mod 16) at which it is 15 mod 16
+    u32 hp = 0, hm = 0;
     u32 tlo = 0, thi = 0, plo = 0, phi = 0;
     FastWord w; w.Pv = ~0ULL; w.Mv = 0ULL; w.pubP = 0x80000000u; w.pubM = 0u;
     u32 S = (u32)(b + 1) * 64u, key = 0xffffffffu;
@@ -61,6 +67,13 @@ NECAT_D u32 fast_shw8_ck(const int b, const u64* __restrict__ tw, const u64 nlo,
                 S += (phh >> 31) - (mhh >> 31);
                 const u32 k2 = (S << 10) + (u32)s;
                 key = k2 < key ? k2 : key;
+                if (CARRY) {
+                    hp = __builtin_amdgcn_alignbit(hp, phh, 31); hm = __builtin_amdgcn_alignbit(hm, mhh, 31);      // (h << 1) | top bit
+                    if ((j & 15) == jck16) {
+                        ck[(size_t)((s - b) >> 4) * G] = make_ulonglong2(w.Pv, w.Mv);
+                        if (j == jck) hc[(size_t)((s - b) >> 5) * G] = (u64)hp | ((u64)hm << 32);
+                    }
+                } else
                 if (j == jck) ck[(size_t)((s - b) >> 5) * G] = make_ulonglong2(w.Pv, w.Mv);      // state after column 32 m + 31 -> slot m
             }
         }
@@ -69,19 +82,21 @@ NECAT_D u32 fast_shw8_ck(const int b, const u64* __restrict__ tw, const u64 nlo,
 }
 
 // the front part of list A (work indices [0, nf): full blocks; [nf, nf16): holes), 8 items per wave
-template <int NW, int TW>
+template <int NW, int TW, bool CARRY>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, ulonglong2* __restrict__ ckpt,
-           double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, int max_dist)
+           u64* __restrict__ hcar, double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, int max_dist, u32 lo, u32 hi)
 {
+    // work items [lo, hi) of the list (multiples of 64: a big list goes through a bounded checkpoint buffer in several launches);
+    // checkpoint / delta slots are indexed by item - lo
     constexpr int FW = 2 * NW + TW, G = 8, N = kOcaBlockSize;
     __shared__ u64 t_lds[8][TW];
     const ListView lv = list_view(0u, n_dev, capA);
-    const u64 first = (u64)blockIdx.x * 8;
-    if (first >= lv.nf) return;
+    const u64 first = (u64)lo + (u64)blockIdx.x * 8, end = lv.nf < hi ? lv.nf : hi;
+    if (first >= end) return;
     const int lane = (int)threadIdx.x, sub = lane >> 3, b = lane & 7;
     const u64 item = first + (u64)sub;
-    const bool valid = item < lv.nf;
+    const bool valid = item < end;
     const u64 grp = item >> 6;
     const int il = (int)(item & 63);
     const u64* fr = frag + grp * FW * 64 + il;
@@ -92,7 +107,8 @@ k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u
         t_lds[sub][w] = even_bits(x) | (even_bits(x >> 1) << 32);
     }
     __syncthreads();
-    const u32 key = fast_shw8_ck<TW>(b, t_lds[sub], nlo, nhi, ckpt + (size_t)item * (kRcCk * G) + b);
+    const u32 key = fast_shw8_ck<TW, CARRY>(b, t_lds[sub], nlo, nhi, ckpt + (size_t)(item - lo) * ((CARRY ? kRcCk16 : kRcCk) * G) + b,
+                                            hcar + (size_t)(item - lo) * (kRcCk * G) + b);
     const u32 bkey = (u32)__shfl((int)key, (lane & ~(G - 1)) | (G - 1));
     int best = (int)(bkey >> 10);
     const int end0 = (int)(bkey & 1023u) - (G - 1);
@@ -121,26 +137,27 @@ NECAT_D u32 dpp_quad_shr1(u32 v, u32 keep)      // lane i of every quad receives
 template <int NW, int TW, int MAXOPS>
 __global__ void __launch_bounds__(64)
 k_rcwalk4(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, const ulonglong2* __restrict__ ckpt,
-          const BlockResult* __restrict__ results, const ExtTask* __restrict__ tasks, int keep_cols, u8* __restrict__ ops_pool, WalkOut* __restrict__ wout,
-          unsigned long long* __restrict__ stats, int* __restrict__ err_flag)
+          const BlockResult* __restrict__ results, const ExtTask* __restrict__ tasks, int keep_cols, int tail_match_len, u8* __restrict__ ops_pool, WalkOut* __restrict__ wout,
+          unsigned long long* __restrict__ stats, int* __restrict__ err_flag, u32 lo, u32 hi)
 {
     constexpr int FW = 2 * NW + TW, N = kOcaBlockSize, SEG = kRcSeg;
     __shared__ ulonglong2 slices[16][SEG];
     const ListView lv = list_view(0u, n_dev, capA);
-    const u64 first = (u64)blockIdx.x * 16;
-    if (first >= lv.nf) return;
+    const u64 first = (u64)lo + (u64)blockIdx.x * 16, end = lv.nf < hi ? lv.nf : hi;
+    if (first >= end) return;
     const int lane = (int)threadIdx.x, q = lane >> 2, j = lane & 3;
     const u64 item = first + (u64)q;
-    const bool valid = item < lv.nf;
+    const bool valid = item < end;
     const u64 grp = first >> 6;                                      // 16 consecutive work indices share a 64-item group
     const int il = (int)(item & 63);
     const u64* fr = frag + grp * FW * 64 + il;
     int best = -1, endc = -1;
     bool store = false;
+    int mlen = kOcaMatCnt;                                           // the run of matches the tail scan looks for (TailScan::M)
     if (valid) {
         const BlockResult br = results[item];
         if (!(br.words & kWideFlag)) { best = br.dist; endc = br.endc; }     // wide blocks: the old path walks them
-        if (best >= 0) store = keep_cols || !tasks[items[item].task].found;
+        if (best >= 0) { const ExtTask& t = tasks[items[item].task]; store = keep_cols || !t.found; if (t.last) mlen = tail_match_len; }      // (ext_block_done: an aligned block ends its extension iff it is the last one)
     }
     // the band of r - c (ext_fast16.h): lo_x <= r - c <= hi_x
     const int tn2 = endc + 1, d = N - tn2, ad = d < 0 ? -d : d, slack = best >= 0 ? (best - ad) >> 1 : 0;
@@ -163,7 +180,7 @@ k_rcwalk4(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u3
             nlo_l = (u32)a; nlo_h = (u32)(a >> 32); nhi_l = (u32)bq; nhi_h = (u32)(bq >> 32); wcur = w;
         }
         FastWord wd; wd.Pv = ~0ULL; wd.Mv = 0ULL; wd.pubP = 0x80000000u; wd.pubM = 0u;
-        if (!fin && seg > 0) { const ulonglong2 v = ckpt[((size_t)item * kRcCk + (size_t)(seg - 1)) * 8 + (size_t)w]; wd.Pv = v.x; wd.Mv = v.y; }
+        if (!fin && seg > 0) { const ulonglong2 v = ckpt[((size_t)(item - lo) * kRcCk + (size_t)(seg - 1)) * 8 + (size_t)w]; wd.Pv = v.x; wd.Mv = v.y; }
         if (!fin && seg != segcur) {
             const u64 x = fr[(u64)(2 * NW + seg) * 64];
             tlo = (u32)even_bits(x); thi = (u32)even_bits(x >> 1); segcur = seg;
@@ -225,7 +242,7 @@ k_rcwalk4(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u3
                     if (!hit) {
                         nq += drow; nt += dcol;
                         m = mt ? m + 1 : 0;
-                        if (m == kOcaMatCnt) { hit = 1; acnt = n; qcnt = nq; tcnt = nt; mcnt = nmat; }
+                        if (m == mlen) { hit = 1; acnt = n; qcnt = nq; tcnt = nt; mcnt = nmat; }
                     }
                     r -= drow; c -= dcol;
                     if ((r | c) < 0) { out = true; break; }
@@ -246,5 +263,254 @@ k_rcwalk4(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u3
     for (int o = 32; o > 0; o >>= 1) words_done += (u32)__shfl_xor((int)words_done, o);
     if (lane == 0 && words_done) { atomicAdd(&stats[0], (unsigned long long)words_done); atomicAdd(&stats[4], (unsigned long long)words_done); }
 }
+
+
+NECAT_D u32 dpp_quad_from_below(u32 v)          // lane i of every quad receives v of lane i - 1 (lane 0 of a quad: its own)
+{
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x90 /* quad_perm:[0,0,1,2] */, 0xf, 0xf, false);
+}
+
+// checkpoint / delta slots of a block of up to COLS columns
+template <int COLS> struct RcGeom { static constexpr int kCk = (COLS + 15) / 16, kSeg = (COLS + 31) / 32; };
+
+// ---- SHW pass of ANY block (ragged list-A blocks, list B, the 2048-bp geometry) with checkpoints and deltas: the SHW part of
+// myers_coop_wave (ext_kernels.h; edlib_ex.c:108-223) - G lanes per block, lane b = 64-row word b - that keeps, as fast_shw8_ck<CARRY> does,
+// every word's (Pv, Mv) after columns 15, 31, .. (slot c / 16) and its horizontal output deltas (32 columns per u64, column 32 m + x at
+// bit 31 - x of each half).  Work items [lo, hi) of the list; epoch bit 26: only the ragged part [nf16, n) of a two-ended list A.
+template <int NW, int TW, int COLS, int G>
+__global__ void __launch_bounds__(64)
+k_myers_ckg(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, ulonglong2* __restrict__ ckpt,
+            u64* __restrict__ hcar, double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, u32 epoch, u32 lo, u32 hi)
+{
+    constexpr int FW = 2 * NW + TW, BPW = 64 / G, CK = RcGeom<COLS>::kCk, SEGS = RcGeom<COLS>::kSeg;
+    __shared__ u64 t_lds[BPW][TW];
+    const ListView lv = list_view(n_host, n_dev, capA);
+    const u64 wave_first = (u64)lo + (u64)blockIdx.x * BPW, end = lv.n < hi ? lv.n : hi;
+    if (wave_first >= end) return;
+    if (((epoch >> 26) & 1u) && wave_first + BPW <= (u64)lv.nf16) return;
+    const int lane = (int)threadIdx.x, sub = lane / G, b = lane % G;
+    const u64 item = wave_first + (u64)sub;
+    BlockItem it0;
+    bool valid = item < end && list_item(lv, items, item, it0);
+    if (((epoch >> 26) & 1u) && item < (u64)lv.nf16) valid = false;
+    const u64 grp = item >> 6;
+    const int il = (int)(item & 63);
+    int qn = 0, tn = 0;
+    if (valid) { qn = it0.qn; tn = it0.tn; }
+    const int nblk = (qn + 63) >> 6, W = nblk * 64 - qn;
+    const bool have = valid && b < nblk;
+    const bool is_last = have && b == nblk - 1;
+    const u64* fr = frag + grp * FW * 64 + il;
+    u64 nlo = 0, nhi = 0;
+    if (have) { nlo = fr[(u64)b * 64]; nhi = fr[(u64)(NW + b) * 64]; }
+    const u64 pad = (is_last && W > 0) ? (~0ULL << ((64 - W) & 63)) : 0ULL;
+    if (valid) for (int w = b; w < TW; w += G) {
+        const u64 x = (w * 32 < tn) ? fr[(u64)(2 * NW + w) * 64] : 0ULL;
+        t_lds[sub][w] = even_bits(x) | (even_bits(x >> 1) << 32);
+    }
+    __syncthreads();
+    const u64* tw = t_lds[sub];
+    const u32 nlo_l = (u32)nlo, nlo_h = (u32)(nlo >> 32), nhi_l = (u32)nhi, nhi_h = (u32)(nhi >> 32);
+    const u32 pad_l = (u32)pad, pad_h = (u32)(pad >> 32);
+    u64 tcur = 0;
+    auto eq_of = [&](int c) -> u64 {
+        const u32 ma = (u32)__builtin_amdgcn_sbfe((int)(u32)tcur, (u32)c & 31u, 1u);
+        const u32 mb = (u32)__builtin_amdgcn_sbfe((int)(u32)(tcur >> 32), (u32)c & 31u, 1u);
+        const u32 el = ((nlo_l ^ ma) & (nhi_l ^ mb)) | pad_l, eh = ((nlo_h ^ ma) & (nhi_h ^ mb)) | pad_h;
+        return ((u64)eh << 32) | el;
+    };
+    int steps = valid ? tn + nblk - 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
+    ulonglong2* const ck = ckpt + ((size_t)(item - lo) * CK) * NW + b;
+    u64* const hc = hcar + ((size_t)(item - lo) * SEGS) * NW + b;
+    int k = (int)((double)(qn < tn ? qn : tn) * error * 1.1);
+    u64 P = ~0ULL, M = 0ULL;
+    int S = (b + 1) * 64, best = -1, end0 = -1, hout = 1;
+    u32 hp = 0, hm = 0;
+    for (int s = 0; s < steps; ++s) {
+        const int c = s - b;
+        int hin = lane_below<G>(hout);
+        if (b == 0) hin = 1;
+        if (have && (u32)c < (u32)tn) {
+            if ((c & 31) == 0) tcur = tw[c >> 5];
+            const u64 eq = eq_of(c);
+            u64 rA, rB;
+            hout = advance_dev<false>(P, M, eq, hin, rA, rB);
+            S += hout;
+            hp = (hp << 1) | ((u32)(hout + 1) >> 1); hm = (hm << 1) | ((u32)hout >> 31);
+            if ((c & 15) == 15) {
+                ck[(size_t)(c >> 4) * NW] = make_ulonglong2(P, M);
+                if ((c & 31) == 31) hc[(size_t)(c >> 5) * NW] = (u64)hp | ((u64)hm << 32);
+            }
+            if (c == tn - 1 && (c & 31) != 31) { const int sh = 31 - (c & 31); hc[(size_t)(c >> 5) * NW] = (u64)(hp << sh) | ((u64)(hm << sh) << 32); }
+            if (is_last && S <= k && (best == -1 || S <= best)) {
+                if (S != best) { best = S; k = best; end0 = c - W; }
+            }
+        }
+    }
+    if (is_last && W > 0) {          // edlib_ex.c:205-219
+        int score = S;
+        for (int i = 0; i < W; ++i) {
+            if (P & (kHighBit >> i)) --score;
+            if (M & (kHighBit >> i)) ++score;
+            if (score <= k && (best == -1 || score <= best)) {
+                if (score != best) { k = best = score; end0 = tn - W + i; }
+            }
+        }
+    }
+    if (is_last) {
+        const int tn2 = end0 + 1;
+        int err = 0;
+        if (best >= 0) { int ad = tn2 - qn; if (ad < 0) ad = -ad; if (best < ad) err = 1; }
+        BlockResult br; br.dist = err ? -1 : best; br.endc = end0; br.err = err;
+        br.words = (u32)(nblk * tn);
+        results[item] = br;
+        atomicAdd(&stats[0], (unsigned long long)br.words); atomicAdd(&stats[1], (unsigned long long)(qn + tn));
+        if (br.dist >= 0) atomicAdd(&stats[3], 1ULL);
+    }
+}
+
+// k_rcwalk4 with an EXACT window of two words (needs the deltas: k_myers_ck<.., CARRY = true> / k_myers_ckg): the walk only looks at rows
+// [r - 63, r] (r = its row when the segment is entered) - the words w1 = r / 64 and w1 - 1 - and a word's column is a function of its own
+// previous column, the word above's horizontal deltas and the sequences; with those deltas on record (hcar) two words are all there is to
+// compute, for any block size and any distance: no band argument, no `wide` blocks, no pad rows (a row never depends on a row below it).
+// 4 lanes per block = 2 words x 2 halves of the 32-column segment (checkpoints every 16 columns): 17 steps per segment instead of 35.
+// Work items [lo, hi) of any list (ListView); epoch bit 27: the whole list (otherwise only the full blocks [0, nf) of a two-ended list A).
+template <int NW, int TW, int COLS, int MAXOPS>
+__global__ void __launch_bounds__(64)
+k_rcwalk2(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, const ulonglong2* __restrict__ ckpt,
+          const u64* __restrict__ hcar, const BlockResult* __restrict__ results, const ExtTask* __restrict__ tasks, int keep_cols, int tail_match_len, u8* __restrict__ ops_pool,
+          WalkOut* __restrict__ wout, unsigned long long* __restrict__ stats, int* __restrict__ err_flag, u32 epoch, u32 lo, u32 hi)
+{
+    constexpr int FW = 2 * NW + TW, SEG = kRcSeg, HALF = SEG / 2, CK = RcGeom<COLS>::kCk, SEGS = RcGeom<COLS>::kSeg;
+    __shared__ ulonglong2 slices[16][SEG];
+    const ListView lv = list_view(n_host, n_dev, capA);
+    const bool all = ((epoch >> 27) & 1u) != 0;
+    const u64 first = (u64)lo + (u64)blockIdx.x * 16, lim = all ? lv.n : lv.nf, end = lim < hi ? lim : hi;
+    if (first >= end) return;
+    const int lane = (int)threadIdx.x, q = lane >> 2, j = lane & 3, k = j & 1, h = j >> 1;
+    const u64 item = first + (u64)q;
+    BlockItem it0;
+    const bool valid = item < end && list_item(lv, items, item, it0);
+    const u64 grp = first >> 6;                                      // 16 consecutive work indices share a 64-item group
+    const int il = (int)(item & 63);
+    const u64* fr = frag + grp * FW * 64 + il;
+    int best = -1, endc = -1;
+    bool store = false;
+    int mlen = kOcaMatCnt;                                           // the run of matches the tail scan looks for (TailScan::M)
+    if (valid) {
+        const BlockResult br = results[item];
+        if (!(br.words & kWideFlag)) { best = br.dist; endc = br.endc; }     // (flagged only when a test lowers NECAT_RC_MAXDIST: the old path walks them)
+        // (ext_block_done: an aligned block ends its extension iff it is the last one; no tasks: the batch hook, which keeps every op)
+        if (best >= 0 && tasks) { const ExtTask& t = tasks[it0.task]; store = keep_cols || !t.found; if (t.last) mlen = tail_match_len; }
+        else if (best >= 0) store = true;
+    }
+    int r = valid ? it0.qn - 1 : 0, c = endc;
+    int n = 0, nmat = 0, m = 0, hit = 0, nq = 0, nt = 0, acnt = 0, qcnt = 0, tcnt = 0, mcnt = 0;
+    bool fin = best < 0;
+    u8* const ops = ops_pool + (size_t)(item >> 6) * MAXOPS * 64 + il;
+    int wcur = -1; u32 nlo_l = 0, nlo_h = 0, nhi_l = 0, nhi_h = 0;      // the query planes of the lane's current word
+    int segcur = -1; u32 tlo = 0, thi = 0;                              // the target bit-planes of the current segment's 32 columns
+    u32 words_done = 0;
+    while (!__all(fin)) {
+        const int seg = c >> 5, c0 = seg * SEG;
+        const int rb = r - 63, sh = rb & 63, w1 = r >> 6;            // the walk may use rows [rb, r] of this segment's columns: word w1 - 1 from bit sh on, word w1
+        const int w = w1 - 1 + k;
+        const int nc0 = c - c0 - HALF * h + 1;                        // columns of this lane's half that are needed
+        const int nc = (fin || w < 0 || nc0 < 0) ? 0 : (nc0 > HALF ? HALF : nc0);
+        const bool live = nc > 0;
+        if (live && w != wcur) {
+            const u64 a = fr[(u64)w * 64], bq = fr[(u64)(NW + w) * 64];
+            nlo_l = (u32)a; nlo_h = (u32)(a >> 32); nhi_l = (u32)bq; nhi_h = (u32)(bq >> 32); wcur = w;
+        }
+        FastWord wd; wd.Pv = ~0ULL; wd.Mv = 0ULL; wd.pubP = 0x80000000u; wd.pubM = 0u;
+        const int slot = 2 * seg + h - 1;                             // the state before column c0 + 16 h
+        if (live && slot >= 0) { const ulonglong2 v = ckpt[((size_t)(item - lo) * CK + (size_t)slot) * NW + (size_t)w]; wd.Pv = v.x; wd.Mv = v.y; }
+        u32 hp = 0xffffffffu, hm = 0u;                                // word 0: the top row's boundary (+1 per column)
+        if (live && k == 0 && w > 0) { const u64 v = hcar[((size_t)(item - lo) * SEGS + (size_t)seg) * NW + (size_t)(w - 1)]; hp = (u32)v; hm = (u32)(v >> 32); }
+        if (!fin && seg != segcur) {
+            const u64 x = fr[(u64)(2 * NW + seg) * 64];
+            tlo = (u32)even_bits(x); thi = (u32)even_bits(x >> 1); segcur = seg;
+        }
+        hp <<= HALF * h; hm <<= HALF * h;                             // bit 31 - x = column c0 + x: this half's first column on top
+        for (int s = 0; s < HALF + 1; ++s) {
+            const u32 xp = dpp_quad_from_below(wd.pubP), xm = dpp_quad_from_below(wd.pubM);
+            const int cl = s - k;
+            if ((u32)cl < (u32)nc) {
+                const int ci = HALF * h + cl;
+                const u32 cph = k ? xp : hp << cl, cmh = k ? xm : hm << cl;
+                const u32 ma = (u32)__builtin_amdgcn_sbfe((int)tlo, (u32)ci, 1u), mb = (u32)__builtin_amdgcn_sbfe((int)thi, (u32)ci, 1u);
+                const u32 el = bop<0x60>(nlo_l ^ ma, nhi_l, mb), eh = bop<0x60>(nlo_h ^ ma, nhi_h, mb);
+                u32 phh, mhh; u64 rA, rB;
+                fast_advance<true>(wd, el, eh, cph, cmh, 0u, phh, mhh, rA, rB);
+                ++words_done;
+                // the walk's 64 rows of this column: low part from word w1 - 1 (written first: its lane is one step ahead), high part from word w1
+                if (k == 0) { if (sh) slices[q][ci] = make_ulonglong2(rA >> sh, rB >> sh); }
+                else if (!sh) slices[q][ci] = make_ulonglong2(rA, rB);
+                else {
+                    const u64 pa = rA << (64 - sh), pb = rB << (64 - sh);
+                    if (w == 0) slices[q][ci] = make_ulonglong2(pa, pb);          // rows above the matrix are never looked at
+                    else {      // (LDS atomics without a return value: nothing to wait for)
+                        unsigned long long* dst = reinterpret_cast<unsigned long long*>(&slices[q][ci]);
+                        __hip_atomic_fetch_or(dst, pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_or(dst + 1, pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- the walk (walk_block of dp_core.h on the slices), every lane of the quad the same.  Two forms of the loop: once every
+        // block of the wave has seen its run of 8 matches and no block keeps its ops (every block but the first one or two of an
+        // extension, when only records are wanted) a step only counts columns and matches
+        const bool lean = !__any(!fin && (!hit || store));
+        bool out = false;                                             // walked out of the matrix: the block is done
+        if (!fin) {
+            if (lean) {
+                for (;;) {
+                    if (c < c0 || r < rb) break;                      // out of the segment / of the rows kept: the next segment (or this one again)
+                    const ulonglong2 v = slices[q][c - c0];
+                    const int bit = r - rb;
+                    const u32 a = (u32)(v.x >> bit) & 1u, b = (u32)(v.y >> bit) & 1u;
+                    const int drow = 1 - (int)(b & (a ^ 1u)), dcol = 1 - (int)(a & (b ^ 1u));
+                    ++n; nmat += (int)((a | b) ^ 1u);
+                    r -= drow; c -= dcol;
+                    if ((r | c) < 0) { out = true; break; }
+                }
+            } else {
+                for (;;) {
+                    if (c < c0 || r < rb) break;
+                    const ulonglong2 v = slices[q][c - c0];
+                    const int bit = r - rb;
+                    const u32 a = (u32)(v.x >> bit) & 1u, b = (u32)(v.y >> bit) & 1u;
+                    const int op = (int)(a | (b << 1));
+                    const int drow = 1 - (int)(b & (a ^ 1u)), dcol = 1 - (int)(a & (b ^ 1u));
+                    const int mt = (int)((a | b) ^ 1u);
+                    if (store && j == 0) { if (n < MAXOPS) ops[(size_t)n * 64] = (u8)op; else atomicExch(err_flag, 20); }
+                    ++n; nmat += mt;
+                    if (!hit) {
+                        nq += drow; nt += dcol;
+                        m = mt ? m + 1 : 0;
+                        if (m == mlen) { hit = 1; acnt = n; qcnt = nq; tcnt = nt; mcnt = nmat; }
+                    }
+                    r -= drow; c -= dcol;
+                    if ((r | c) < 0) { out = true; break; }
+                }
+            }
+        }
+        if (out) {
+            // out of the first column: the rows left are inserts; out of the first row: the columns left are deletes
+            const int kop = c < 0 ? 1 : 2, k = c < 0 ? r + 1 : c + 1;
+            if (store && j == 0) for (int i = 0; i < k; ++i) { if (n + i < MAXOPS) ops[(size_t)(n + i) * 64] = (u8)kop; else atomicExch(err_flag, 20); }
+            n += k;
+            if (!hit && k > 0) m = 0;
+            fin = true;
+            if (j == 0) { WalkOut o; o.n = n; o.nmat = nmat; o.m = m; o.hit = hit; o.acnt = acnt; o.qcnt = qcnt; o.tcnt = tcnt; o.mcnt = mcnt; wout[item] = o; }
+        }
+        __syncthreads();             // the slices are read before the next segment overwrites them
+    }
+    for (int o = 32; o > 0; o >>= 1) words_done += (u32)__shfl_xor((int)words_done, o);
+    if (lane == 0 && words_done) { atomicAdd(&stats[0], (unsigned long long)words_done); atomicAdd(&stats[4], (unsigned long long)words_done); }
+}
+
 
 }  // namespace necat

@@ -74,6 +74,9 @@ size_t g_band_pool;    // NECAT_BAND_POOL_MB (default 16384): cap of one band-re
 int g_walk;            // NECAT_WALK=0: k_traceback runs the reference formulation of the walk (A/B measurements)
 u32 g_tail_fused;      // NECAT_TAIL_FUSED (default 512 = one workgroup per block at 2 per CU; 0 = off): lists of at most this many blocks run as ONE launch per round with the band in LDS (ext_tail.h)
 u32 g_rcwalk;          // NECAT_RCWALK (default 16384; 0 = off): list-A rounds of more than this many blocks run their full blocks through k_myers_ck + k_rcwalk4 (ext_rcwalk.h: no NW pass, no band records, the walk recomputes its cells)
+size_t g_rc_pool;      // NECAT_RC_POOL_MB (default 2048): cap of the checkpoint buffer of those rounds; a longer list goes through it in several launches
+u32 g_rc_ragged;       // NECAT_RC_RAGGED (default 1, needs NECAT_RC_CARRY): the ragged blocks of those rounds through k_myers_ckg + k_rcwalk2 as well (0: two-pass kernel + lane walk on a stream of their own)
+u32 g_rc_carry;        // NECAT_RC_CARRY (default 1): the recompute walk on an exact two-word window (k_myers_ck<CARRY> keeps the words' horizontal deltas, k_rcwalk2); 0 = the 4-word band window (k_rcwalk4)
 int g_rc_maxdist;      // NECAT_RC_MAXDIST (default and maximum kRcMaxDist = 160): full blocks of a larger distance take the old kernels (tests lower it)
 u32 g_walk_wave;       // NECAT_WALK_WAVE (default 12288; 0 = off): lists of at most this many blocks are walked by one WAVE per block through an LDS window (k_walk_wave, ext_tail.h)
 int g_asm_lane;        // NECAT_ASM_LANE=1: necat_asm_align_batch through the lane-per-alignment kernel (k_asm_align), the second implementation
@@ -90,7 +93,11 @@ void read_knobs()
     g_asm_lane = (int)num("NECAT_ASM_LANE", 0);
     g_walk_wave = (u32)num("NECAT_WALK_WAVE", 12288);
     g_rcwalk = (u32)num("NECAT_RCWALK", 16384);
-    g_rc_maxdist = (int)std::min<unsigned long long>(num("NECAT_RC_MAXDIST", kRcMaxDist), kRcMaxDist);
+    g_rc_carry = (u32)num("NECAT_RC_CARRY", 1);
+    g_rc_ragged = g_rc_carry ? (u32)num("NECAT_RC_RAGGED", 1) : 0u;
+    g_rc_pool = (size_t)std::max<unsigned long long>(1, num("NECAT_RC_POOL_MB", 2048)) << 20;
+    g_rc_maxdist = (int)num("NECAT_RC_MAXDIST", g_rc_carry ? 1 << 20 : kRcMaxDist);
+    if (!g_rc_carry) g_rc_maxdist = std::min(g_rc_maxdist, kRcMaxDist);
     g_batch_cap = (u32)std::max<unsigned long long>(64, num("NECAT_BATCH", 786432));
     g_index_lds = (int)num("NECAT_INDEX_LDS", 1);
     g_seed_wave = (int)num("NECAT_SEED_WAVE", 1);
@@ -1200,7 +1207,11 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         // dirtied) the list runs in chunks of what the pool holds, DP + walk per chunk
         u32 gchunk = gA;
         if (g_band_pool && (size_t)gA * kSlabA > g_band_pool) gchunk = (u32)std::max<size_t>(1, g_band_pool / kSlabA);
-        if ((size_t)gchunk * kSlabA > ctx->scratch[SC_EXT_MAT].cap) {
+        // a big round through ext_rcwalk.h (checkpoints + recomputing walk): no band records at all when its ragged blocks go the same way
+        const bool wide_possible = g_rc_maxdist < (int)((double)kOcaBlockSize * X.error * 1.1);       // (edlib_ex.c:751: no block has a larger distance)
+        const bool rc_band = !g_rc_ragged || wide_possible;                                            // the round still needs the band pool (whole list: slabs are indexed by work index)
+        const bool use_rc = g_rcwalk && bound > g_rcwalk && bound <= g_coop_threshold && g_fast == 1 && g_coop_filter && (!rc_band || gchunk == gA);
+        if ((!use_rc || rc_band) && (size_t)gchunk * kSlabA > ctx->scratch[SC_EXT_MAT].cap) {
             const size_t need = (size_t)gchunk * kSlabA;
             int rc = ensure_zeroed(ctx, ctx->scratch[SC_EXT_MAT], gchunk < gA ? need : need + need / 8, c.sa);
             if (rc) return rc;
@@ -1217,49 +1228,82 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         a_timed.push_back(0);
         if (!bound) return NECAT_OK;
         ExtLists next; next.count = c.count + 4 * nxt; next.itemsA = c.itemsA[nxt]; next.itemsB = c.itemsB[nxt]; next.task_ops = X.task_ops; next.capA = c.cap;
-        if (g_rcwalk && bound > g_rcwalk && bound <= g_coop_threshold && gchunk == gA && g_fast == 1 && g_coop_filter) {
+        if (use_rc) {
             // ---- a big round: the full blocks (the front of the work index space) without NW pass and band records - SHW with
             // checkpoints, then the walk that recomputes its cells (ext_rcwalk.h); the ragged blocks and the few blocks whose band is
             // too wide for that walk through the usual kernels, in the same launches (epoch bit 24)
             int rc2;
-            if ((rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_CKPT], (size_t)gA * 64 * kRcCk * 8 * sizeof(ulonglong2))) ||
+            // checkpoints (+ deltas) of at most g_rc_pool bytes: a longer list goes through the buffer in several launches, one after the other on stream a
+            const size_t per_item = (size_t)(g_rc_carry ? kRcCk16 : kRcCk) * 8 * sizeof(ulonglong2), per_item_hc = g_rc_carry ? (size_t)kRcCk * 8 * sizeof(u64) : 0;
+            const u32 rc_chunk = (u32)std::max<size_t>(64, std::min<size_t>((size_t)gA * 64, (g_rc_pool / (per_item + per_item_hc)) & ~(size_t)63));
+            const size_t ck_bytes = (size_t)rc_chunk * per_item;
+            if ((rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_CKPT], ck_bytes + (size_t)rc_chunk * per_item_hc)) ||
                 (rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_WOUT], (size_t)gA * 64 * sizeof(WalkOut)))) return rc2;
             ulonglong2* ck = (ulonglong2*)ctx->scratch[SC_EXT_CKPT].p;
+            u64* hcar = (u64*)((char*)ctx->scratch[SC_EXT_CKPT].p + ck_bytes);
             WalkOut* wo = (WalkOut*)ctx->scratch[SC_EXT_WOUT].p;
             char* slabsA = (char*)ctx->scratch[SC_EXT_MAT].p;
-            // the full blocks on stream a: SHW + checkpoints, recompute walk, finish
-            hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA>), dim3((bound + 7) / 8), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, X.error, c.resA, X.stats, g_rc_maxdist);
-            NECAT_CHECK_LAUNCH(ctx, "k_myers_ck");
-            NECAT_HIP(ctx, hipEventRecord(c.a1[cur], c.sa));
             // the ragged blocks (and, once k_myers_ck has flagged them, the wide ones) on a stream of their own: a lane-per-block walk
             // of a tenth of the list is as long as one of the whole list (latency bound) - it runs beside the full blocks' chain
             hipStream_t sd = ctx->stream_d;
-            const u32 fl_rag = epoch | (1u << 26), fl_wide = epoch | (1u << 25);
-            NECAT_HIP(ctx, hipStreamWaitEvent(sd, c.a0[cur], 0));            // the fragments are there
-            hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3(gA * 8), dim3(64), 0, sd, itA, bound, d_nA, c.cap,
-                               (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, fl_rag, 0u);
-            hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, 0>), dim3(gA), dim3(64), 0, sd, itA, bound, d_nA, c.cap,
-                               (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
-                               (i32*)nullptr, X.d_err, next, fl_rag, 0u);
-            NECAT_CHECK_LAUNCH(ctx, "k_myers / k_traceback<A, ragged>");
-            NECAT_HIP(ctx, hipStreamWaitEvent(sd, c.a1[cur], 0));            // k_myers_ck has flagged the wide blocks
-            hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3(gA * 8), dim3(64), 0, sd, itA, bound, d_nA, c.cap,
-                               (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, fl_wide, 0u);
-            hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, 0>), dim3(gA), dim3(64), 0, sd, itA, bound, d_nA, c.cap,
-                               (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
-                               (i32*)nullptr, X.d_err, next, fl_wide, 0u);
-            NECAT_CHECK_LAUNCH(ctx, "k_myers / k_traceback<A, wide>");
-            NECAT_HIP(ctx, hipEventRecord(ctx->ev[25], sd));
-            hipLaunchKernelGGL((k_rcwalk4<kWordsA, kTWordsA, kOpsA>), dim3((bound + 15) / 16), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, (const ulonglong2*)ck,
-                               (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, c.opsA, wo, X.stats, X.d_err);
-            NECAT_CHECK_LAUNCH(ctx, "k_rcwalk4");
-            NECAT_HIP(ctx, hipEventRecord(ctx->ev[26 + (r & 3)], c.sa));       // a1 -> this: k_rcwalk4 alone (account_a)
+            const u32 fl_rag = epoch | (1u << 26), fl_wide = epoch | (1u << 25), fl_all = g_rc_ragged ? epoch | (1u << 27) : epoch;
+            if (!g_rc_ragged) {
+                NECAT_HIP(ctx, hipStreamWaitEvent(sd, c.a0[cur], 0));            // the fragments are there
+                hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3(gA * 8), dim3(64), 0, sd, itA, bound, d_nA, c.cap,
+                                   (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, fl_rag, 0u);
+                hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, 0>), dim3(gA), dim3(64), 0, sd, itA, bound, d_nA, c.cap,
+                                   (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
+                                   (i32*)nullptr, X.d_err, next, fl_rag, 0u);
+                NECAT_CHECK_LAUNCH(ctx, "k_myers / k_traceback<A, ragged>");
+            }
+            // the full blocks on stream a: SHW + checkpoints, recompute walk (chunk by chunk), finish
+            const bool one_chunk = rc_chunk >= bound;
+            for (u32 lo = 0; lo < bound; lo += rc_chunk) {
+                const u32 hi = std::min<u64>((u64)lo + rc_chunk, (u64)gA * 64), cn = hi - lo;
+                const bool last = (u64)lo + rc_chunk >= bound;
+                static const bool ckg_all = getenv("NECAT_RC_CKG_ALL") != nullptr;       // debugging: every block through the general pass
+                if (ckg_all && g_rc_ragged) {}
+                else if (g_rc_carry)
+                    hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA, true>), dim3((cn + 7) / 8), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error, c.resA, X.stats, g_rc_maxdist, lo, hi);
+                else
+                    hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA, false>), dim3((cn + 7) / 8), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error, c.resA, X.stats, g_rc_maxdist, lo, hi);
+                if (g_rc_ragged) {
+                    // the ragged blocks of the chunk (the back of the work index space): the general SHW pass, same checkpoints.  A tenth of
+                    // the blocks, few waves, latency bound: beside the full blocks' pass on a stream of its own when the list is one chunk
+                    hipStream_t sr = one_chunk ? sd : c.sa;
+                    if (one_chunk) NECAT_HIP(ctx, hipStreamWaitEvent(sd, c.a0[cur], 0));            // the fragments are there
+                    hipLaunchKernelGGL((k_myers_ckg<kWordsA, kTWordsA, kColsA, 8>), dim3((cn + 7) / 8), dim3(64), 0, sr, itA, bound, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error,
+                                       c.resA, X.stats, ckg_all ? epoch : fl_rag, lo, hi);
+                    if (one_chunk) { NECAT_HIP(ctx, hipEventRecord(ctx->ev[30], sd)); }
+                }
+                NECAT_CHECK_LAUNCH(ctx, "k_myers_ck");
+                if (last) NECAT_HIP(ctx, hipEventRecord(c.a1[cur], c.sa));
+                if (g_rc_ragged && one_chunk) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, ctx->ev[30], 0));
+                if (g_rc_carry)
+                    hipLaunchKernelGGL((k_rcwalk2<kWordsA, kTWordsA, kColsA, kOpsA>), dim3((cn + 15) / 16), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap, (const u64*)c.fragA, (const ulonglong2*)ck,
+                                       (const u64*)hcar, (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsA, wo, X.stats, X.d_err, fl_all, lo, hi);
+                else
+                    hipLaunchKernelGGL((k_rcwalk4<kWordsA, kTWordsA, kOpsA>), dim3((cn + 15) / 16), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, (const ulonglong2*)ck,
+                                       (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsA, wo, X.stats, X.d_err, lo, hi);
+                NECAT_CHECK_LAUNCH(ctx, "k_rcwalk");
+            }
+            NECAT_HIP(ctx, hipEventRecord(ctx->ev[26 + (r & 3)], c.sa));       // a1 -> this: the walk kernel alone (account_a; of the last chunk, normally the only one)
+            if (wide_possible) {
+                NECAT_HIP(ctx, hipStreamWaitEvent(sd, c.a1[cur], 0));            // k_myers_ck has flagged the wide blocks
+                hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3(gA * 8), dim3(64), 0, sd, itA, bound, d_nA, c.cap,
+                                   (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, fl_wide, 0u);
+                hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, 0>), dim3(gA), dim3(64), 0, sd, itA, bound, d_nA, c.cap,
+                                   (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
+                                   (i32*)nullptr, X.d_err, next, fl_wide, 0u);
+                NECAT_CHECK_LAUNCH(ctx, "k_myers / k_traceback<A, wide>");
+            }
+            if (!g_rc_ragged || wide_possible) NECAT_HIP(ctx, hipEventRecord(ctx->ev[25], sd));
             rc_round.push_back(r);
             hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, 5>), dim3(gA), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap,
                                (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
-                               (i32*)nullptr, X.d_err, next, epoch, 0u, (const WalkOut*)wo);
+                               (i32*)nullptr, X.d_err, next, fl_all, 0u, (const WalkOut*)wo);
             NECAT_CHECK_LAUNCH(ctx, "k_traceback<A, rc>");
-            NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, ctx->ev[25], 0));          // the round is over when both chains are
+            if (!g_rc_ragged || wide_possible) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, ctx->ev[25], 0));          // the round is over when both chains are
         } else
         for (u32 g0 = 0; g0 < gA; g0 += gchunk) {
             const u32 lo = g0 * 64, hi = std::min(gA, g0 + gchunk) * 64, cn = hi - lo;           // work indices of this chunk (the kernels know the exact list)
@@ -2605,6 +2649,39 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[4], s));
             const bool coop = m <= g_coop_threshold;
             const u32 epoch = ++ctx->epoch & 0x3fffffu;
+            const bool batch_rc = getenv("NECAT_BATCH_RC") != nullptr;        // the blocks through the checkpoint pass + recomputing walk (ext_rcwalk.h) instead
+            if (batch_rc) {
+                const size_t per_ck = full ? (size_t)RcGeom<kColsA>::kCk * kWordsA * 16 : (size_t)RcGeom<kColsB>::kCk * kWordsB * 16;
+                const size_t per_hc = full ? (size_t)RcGeom<kColsA>::kSeg * kWordsA * 8 : (size_t)RcGeom<kColsB>::kSeg * kWordsB * 8;
+                if ((rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_CKPT], (size_t)g * 64 * (per_ck + per_hc))) ||
+                    (rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_WOUT], (size_t)g * 64 * sizeof(WalkOut)))) return rc2;
+                ulonglong2* ck = (ulonglong2*)ctx->scratch[SC_EXT_CKPT].p;
+                u64* hcar = (u64*)((char*)ctx->scratch[SC_EXT_CKPT].p + (size_t)g * 64 * per_ck);
+                WalkOut* wo = (WalkOut*)ctx->scratch[SC_EXT_WOUT].p;
+                const u32 fl = epoch | (1u << 27);
+                if (full) {
+                    hipLaunchKernelGGL((k_myers_ckg<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag, ck, hcar, error,
+                                       d_res, d_stats, epoch, 0u, g * 64);
+                    NECAT_HIP(ctx, hipEventRecord(ctx->ev[5], s));
+                    hipLaunchKernelGGL((k_rcwalk2<kWordsA, kTWordsA, kColsA, kOpsA>), dim3((m + 15) / 16), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag,
+                                       (const ulonglong2*)ck, (const u64*)hcar, (const BlockResult*)d_res, (const ExtTask*)nullptr, 1, 1, d_ops, wo, d_stats, d_err, fl, 0u, g * 64);
+                    hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, true, 5>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag,
+                                       (const char*)d_slabs, slab, (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), fl, 0u, (const WalkOut*)wo);
+                } else {
+                    if (atoi(getenv("NECAT_BATCH_RC")) == 64)
+                    hipLaunchKernelGGL((k_myers_ckg<kWordsB, kTWordsB, kColsB, 64>), dim3(m), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag, ck, hcar, error,
+                                       d_res, d_stats, epoch, 0u, g * 64);
+                    else
+                    hipLaunchKernelGGL((k_myers_ckg<kWordsB, kTWordsB, kColsB, 16>), dim3((m + 3) / 4), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag, ck, hcar, error,
+                                       d_res, d_stats, epoch, 0u, g * 64);
+                    NECAT_HIP(ctx, hipEventRecord(ctx->ev[5], s));
+                    hipLaunchKernelGGL((k_rcwalk2<kWordsB, kTWordsB, kColsB, kOpsB>), dim3((m + 15) / 16), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag,
+                                       (const ulonglong2*)ck, (const u64*)hcar, (const BlockResult*)d_res, (const ExtTask*)nullptr, 1, 1, d_ops, wo, d_stats, d_err, fl, 0u, g * 64);
+                    hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, true, 5>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag,
+                                       (const char*)d_slabs, slab, (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), fl, 0u, (const WalkOut*)wo);
+                }
+                NECAT_CHECK_LAUNCH(ctx, "k_myers_ckg / k_rcwalk2 / k_traceback");
+            } else {
             if (full && coop) {
                 const bool f16 = g_fast16 && g_fast >= 1 && g_coop_filter;
                 const u32 fl = epoch | (g_coop_filter ? 0u : 1u << 30) | (g_fast == 0 ? 1u << 29 : 0u) | (g_fast == 2 ? 1u << 28 : 0u);
@@ -2621,6 +2698,7 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
             if (full) { if (g_walk == 1) NECAT_TB_LAUNCH(kWordsA, kTWordsA, kColsA, kOpsA, 1); else if (g_walk == 2) NECAT_TB_LAUNCH(kWordsA, kTWordsA, kColsA, kOpsA, 2); else NECAT_TB_LAUNCH(kWordsA, kTWordsA, kColsA, kOpsA, 0); }
             else { if (g_walk == 1) NECAT_TB_LAUNCH(kWordsB, kTWordsB, kColsB, kOpsB, 1); else if (g_walk == 2) NECAT_TB_LAUNCH(kWordsB, kTWordsB, kColsB, kOpsB, 2); else NECAT_TB_LAUNCH(kWordsB, kTWordsB, kColsB, kOpsB, 0); }
 #undef NECAT_TB_LAUNCH
+            }
             NECAT_CHECK_LAUNCH(ctx, "k_traceback");
             NECAT_HIP(ctx, hipEventRecord(ctx->ev[6], s));
             std::vector<BlockResult> hres(m); std::vector<i32> hn(m); std::vector<u8> hops((size_t)g * 64 * maxops);

@@ -101,7 +101,16 @@ inline int buf_ensure(necat_ctx* ctx, DevBuf& b, size_t bytes)
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) {
         b.p = nullptr; b.cap = 0;
-        return set_err(ctx, NECAT_ERR_MEMORY, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = tot = 0;
+        char own[512]; int at = 0; size_t sum = 0;          // this context's arenas of 256 MB and more (ScratchId : MB)
+        own[0] = 0;
+        if (ctx) for (int i = 0; i < 40; ++i) {
+            sum += ctx->scratch[i].cap;
+            if (ctx->scratch[i].cap >= ((size_t)256 << 20) && at < 480) at += snprintf(own + at, sizeof own - (size_t)at, " %d:%zu", i, ctx->scratch[i].cap >> 20);
+        }
+        return set_err(ctx, NECAT_ERR_MEMORY, "hipMalloc(%zu) failed: %s (device memory: %zu MB free of %zu MB; this context's arenas: %zu MB, the big ones [id:MB]%s)", want,
+                       hipGetErrorString(e), fr >> 20, tot >> 20, sum >> 20, own);
     }
     b.cap = want;
     return NECAT_OK;

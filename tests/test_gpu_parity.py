@@ -129,9 +129,14 @@ def _random_pairs(rng, n, qlo, qhi, err):
     return np.concatenate(seqs), qo, ql, to, tl
 
 
-def test_edlib_blocks_match_oracle(ctx):
+@pytest.mark.parametrize("path", ["band", "recompute"])
+def test_edlib_blocks_match_oracle(ctx, monkeypatch, path):
     """The dominant kernel in isolation: distance, end column and the full edit path, including
-    ragged sizes (1..794), failures (too divergent) and exact 512 x 512 blocks (the FULL kernel)."""
+    ragged sizes (1..794), failures (too divergent) and exact 512 x 512 blocks (the FULL kernel).
+    band: DP passes + band records + walk; recompute: checkpoint pass + the walk that recomputes its cells (ext_rcwalk.h: k_myers_ckg,
+    k_rcwalk2) at both geometries (8 words / 13 words per block)."""
+    if path == "recompute":
+        monkeypatch.setenv("NECAT_BATCH_RC", "1")
     rng = np.random.default_rng(2024)
     seqs, qo, ql, to, tl = _random_pairs(rng, 300, 1, 794, 0.15)
     # query much longer than the target: distance >= |q| - |t| > k = 0.55 * min(|q|, |t|) -> Edlib_align fails
@@ -457,7 +462,9 @@ def test_capped_band_pool_runs_lists_in_chunks(ctx, small, tmp_path, monkeypatch
 
 @pytest.mark.parametrize("knob", ["NECAT_CHAIN_WAVE=0", "NECAT_FAST16=1", "NECAT_WALK=1", "NECAT_FAST=0", "NECAT_SEED_WAVE=0",
                                   "NECAT_TAIL_FUSED=0", "NECAT_TAIL_FUSED=100000000", "NECAT_WALK_WAVE=0", "NECAT_WALK_WAVE=100000000 NECAT_TAIL_FUSED=0", "NECAT_SEED_KST=0",
-                                  "NECAT_RCWALK=0", "NECAT_RCWALK=1 NECAT_TAIL_FUSED=0 NECAT_WALK_WAVE=0", "NECAT_RCWALK=1 NECAT_RC_MAXDIST=90 NECAT_TAIL_FUSED=0"])
+                                  "NECAT_RCWALK=0", "NECAT_RCWALK=1 NECAT_TAIL_FUSED=0 NECAT_WALK_WAVE=0", "NECAT_RCWALK=1 NECAT_RC_MAXDIST=90 NECAT_TAIL_FUSED=0",
+                                  "NECAT_RCWALK=1 NECAT_RC_CARRY=0 NECAT_TAIL_FUSED=0", "NECAT_RCWALK=1 NECAT_RC_CARRY=0 NECAT_RC_MAXDIST=90",
+                                  "NECAT_RCWALK=1 NECAT_RC_POOL_MB=1", "NECAT_RCWALK=1 NECAT_RC_RAGGED=0 NECAT_TAIL_FUSED=0"])
 def test_alternative_kernel_paths_give_the_same_records(ctx, small, monkeypatch, knob):
     """Code paths kept behind a knob (the lane-0 chain DP, the 16-block / 4-lane NW kernel, the restated walk, the general DP
     path without the full-block fast path, lane-per-strand seed collection, every round / no round through the one-launch
