@@ -75,6 +75,7 @@ int g_walk;            // NECAT_WALK=0: k_traceback runs the reference formulati
 u32 g_tail_fused;      // NECAT_TAIL_FUSED (default 512 = one workgroup per block at 2 per CU; 0 = off): lists of at most this many blocks run as ONE launch per round with the band in LDS (ext_tail.h)
 u32 g_rcwalk;          // NECAT_RCWALK (default 16384; 0 = off): list-A rounds of more than this many blocks run their full blocks through k_myers_ck + k_rcwalk4 (ext_rcwalk.h: no NW pass, no band records, the walk recomputes its cells)
 size_t g_rc_pool;      // NECAT_RC_POOL_MB (default 2048): cap of the checkpoint buffer of those rounds; a longer list goes through it in several launches
+u32 g_asm_rc;          // NECAT_ASM_RC (default 1): the 2048-bp block aligner of oc2asmpm through k_myers_ckg + k_rcwalk2 (no NW pass, no band records); 0 = two-pass kernel + band + wave walk
 u32 g_rc_ragged;       // NECAT_RC_RAGGED (default 1, needs NECAT_RC_CARRY): the ragged blocks of those rounds through k_myers_ckg + k_rcwalk2 as well (0: two-pass kernel + lane walk on a stream of their own)
 u32 g_rc_carry;        // NECAT_RC_CARRY (default 1): the recompute walk on an exact two-word window (k_myers_ck<CARRY> keeps the words' horizontal deltas, k_rcwalk2); 0 = the 4-word band window (k_rcwalk4)
 int g_rc_maxdist;      // NECAT_RC_MAXDIST (default and maximum kRcMaxDist = 160): full blocks of a larger distance take the old kernels (tests lower it)
@@ -94,6 +95,7 @@ void read_knobs()
     g_walk_wave = (u32)num("NECAT_WALK_WAVE", 12288);
     g_rcwalk = (u32)num("NECAT_RCWALK", 16384);
     g_rc_carry = (u32)num("NECAT_RC_CARRY", 1);
+    g_asm_rc = (u32)num("NECAT_ASM_RC", 1);
     g_rc_ragged = g_rc_carry ? (u32)num("NECAT_RC_RAGGED", 1) : 0u;
     g_rc_pool = (size_t)std::max<unsigned long long>(1, num("NECAT_RC_POOL_MB", 2048)) << 20;
     g_rc_maxdist = (int)num("NECAT_RC_MAXDIST", g_rc_carry ? 1 << 20 : kRcMaxDist);
@@ -1709,7 +1711,21 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
     const u32 gchunkB = (u32)std::max<size_t>(1, std::min<size_t>(groups, pool_cap / kAsmSlab));
     int rc;
     const size_t misc = n * (sizeof(AsmAnchor) + sizeof(ExtTask) + 8) + (size_t)cap * 4 * sizeof(BlockItem) + (size_t)groups * 64 * 2 * sizeof(BlockResult) + (n + 1) * 8 + 8192;
-    if ((rc = buf_ensure(ctx, ctx->scratch[SC_ASM_BAND], std::max((size_t)gchunkA * kAsmSlabA, (size_t)gchunkB * kAsmSlab))) ||
+    // checkpoint pool of the recompute path: per block 128 slots x 32 words x 16 B + 64 x 32 x 8 B of deltas = 80 KB (list A), 154 KB (list B)
+    constexpr size_t kCkA = (size_t)RcGeom<kAsmBlock>::kCk * kAsmWordsA * 16, kHcA = (size_t)RcGeom<kAsmBlock>::kSeg * kAsmWordsA * 8;
+    constexpr size_t kCkB = (size_t)RcGeom<kAsmCols>::kCk * kAsmWords * 16, kHcB = (size_t)RcGeom<kAsmCols>::kSeg * kAsmWords * 8;
+    const size_t rc_pool = std::max<size_t>(g_rc_pool, (size_t)4 << 30);
+    const u32 rc_chunkA = (u32)std::max<size_t>(64, std::min<size_t>((size_t)groups * 64, (rc_pool / (kCkA + kHcA)) & ~(size_t)63));
+    const u32 rc_chunkB = (u32)std::max<size_t>(64, std::min<size_t>((size_t)groups * 64, (rc_pool / (kCkB + kHcB)) & ~(size_t)63));
+    if (g_asm_rc) {
+        if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_CKPT], std::max((size_t)rc_chunkA * (kCkA + kHcA), (size_t)rc_chunkB * (kCkB + kHcB)))) ||
+            (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_WOUT], (size_t)groups * 64 * sizeof(WalkOut)))) return rc;
+    }
+    ulonglong2* const rc_ck = (ulonglong2*)ctx->scratch[SC_EXT_CKPT].p;
+    u64* const rc_hcA = (u64*)((char*)ctx->scratch[SC_EXT_CKPT].p + (size_t)rc_chunkA * kCkA);
+    u64* const rc_hcB = (u64*)((char*)ctx->scratch[SC_EXT_CKPT].p + (size_t)rc_chunkB * kCkB);
+    WalkOut* const d_wout = (WalkOut*)ctx->scratch[SC_EXT_WOUT].p;
+    if ((rc = g_asm_rc ? 0 : buf_ensure(ctx, ctx->scratch[SC_ASM_BAND], std::max((size_t)gchunkA * kAsmSlabA, (size_t)gchunkB * kAsmSlab))) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_OPS], (size_t)groups * 64 * std::max(kAsmMaxOps, kAsmOpsA))) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_FRAG], (size_t)groups * 64 * std::max(kAsmFragWords, kAsmFragWordsA) * 8)) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_COLS], base[n] + 64)) ||
@@ -1757,6 +1773,29 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
             hipLaunchKernelGGL((k_ext_frag<kAsmWordsA, kAsmTWordsA>), dim3(grid_for((u64)gA * 64 * (kAsmWordsA + kAsmTWordsA), 256)), dim3(256), 0, s,
                                drd, dref, (const BlockItem*)d_itemsA[cur], boundA, d_nA, cap, d_frag, ctl);
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<asm A>");
+            if (g_asm_rc) {
+                // SHW pass with checkpoints + deltas, then the walk that recomputes the two words it stands on (ext_rcwalk.h), chunk by chunk
+                // through the checkpoint buffer; then one finishing launch for the whole list
+                const u32 epoch = ++ctx->epoch & 0x3fffffu, fl = epoch | (1u << 27);
+                NECAT_HIP(ctx, hipEventRecord(ctx->ev[2], s));
+                for (u32 lo = 0; lo < boundA; lo += rc_chunkA) {
+                    const u32 hi = std::min<u64>((u64)lo + rc_chunkA, (u64)gA * 64), cn = hi - lo;
+                    hipLaunchKernelGGL((k_myers_ckg<kAsmWordsA, kAsmTWordsA, kAsmBlock, 32>), dim3((cn + 1) / 2), dim3(64), 0, s, (const BlockItem*)d_itemsA[cur], boundA, d_nA, cap,
+                                       (const u64*)d_frag, rc_ck, rc_hcA, error, d_res, d_stats, epoch, lo, hi);
+                    hipLaunchKernelGGL((k_rcwalk2<kAsmWordsA, kAsmTWordsA, kAsmBlock, kAsmOpsA>), dim3((cn + 15) / 16), dim3(64), 0, s, (const BlockItem*)d_itemsA[cur], boundA, d_nA, cap,
+                                       (const u64*)d_frag, (const ulonglong2*)rc_ck, (const u64*)rc_hcA, (const BlockResult*)d_res, (const ExtTask*)d_tasks, 1, 8, d_ops, d_wout, d_stats, d_err, fl, lo, hi);
+                    NECAT_CHECK_LAUNCH(ctx, "k_myers_ckg / k_rcwalk2<asm A>");
+                }
+                NECAT_HIP(ctx, hipEventRecord(ctx->ev[3], s));
+                hipLaunchKernelGGL((k_traceback<kAsmWordsA, kAsmTWordsA, kAsmBlock, kAsmOpsA, false, 5, kAsmBlock>), dim3(gA), dim3(64), 0, s,
+                                   (const BlockItem*)d_itemsA[cur], boundA, d_nA, cap, (const u64*)d_frag, (const char*)nullptr, (size_t)0,
+                                   (const BlockResult*)d_res, d_ops, d_tasks, 8 /* kMatchCnt2: the tail match length of hbn_align */, (i32*)nullptr, d_err, next, fl, 0u, (const WalkOut*)d_wout);
+                NECAT_CHECK_LAUNCH(ctx, "k_traceback<asm A, rc>");
+                NECAT_HIP(ctx, hipEventRecord(ctx->ev[24], s));
+                NECAT_HIP(ctx, hipStreamSynchronize(s));
+                dp += ev_ms(ctx->ev[2], ctx->ev[3]); wk += ev_ms(ctx->ev[3], ctx->ev[24]);
+                ctx->tm.myers_launches += 1;
+            } else
             for (u32 g0 = 0; g0 < gA; g0 += gchunkA) {
                 const u32 lo = g0 * 64, hi = std::min(gA, g0 + gchunkA) * 64, cn = hi - lo;
                 char* slabs = (char*)ctx->scratch[SC_ASM_BAND].p - (size_t)g0 * kAsmSlabA;         // the kernels index slabs by work index / 64
@@ -1786,6 +1825,27 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
             hipLaunchKernelGGL((k_ext_frag<kAsmWords, kAsmTWords>), dim3(grid_for((u64)gB * 64 * (kAsmWords + kAsmTWords), 256)), dim3(256), 0, s,
                                drd, dref, (const BlockItem*)d_itemsB[cur], nB, (const u32*)nullptr, 0u, d_frag, ctl);
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<asm B>");
+            if (g_asm_rc) {
+                const u32 epoch = ++ctx->epoch & 0x3fffffu, fl = epoch | (1u << 27);
+                NECAT_HIP(ctx, hipEventRecord(ctx->ev[2], s));
+                for (u32 lo = 0; lo < nB; lo += rc_chunkB) {
+                    const u32 hi = std::min<u64>((u64)lo + rc_chunkB, (u64)gB * 64), cn = std::min(hi, nB) - lo;
+                    hipLaunchKernelGGL((k_myers_ckg<kAsmWords, kAsmTWords, kAsmCols, 64>), dim3(cn), dim3(64), 0, s, (const BlockItem*)d_itemsB[cur], nB, (const u32*)nullptr, 0u,
+                                       (const u64*)d_frag, rc_ck, rc_hcB, error, d_res, d_stats, epoch, lo, hi);
+                    hipLaunchKernelGGL((k_rcwalk2<kAsmWords, kAsmTWords, kAsmCols, kAsmMaxOps>), dim3((cn + 15) / 16), dim3(64), 0, s, (const BlockItem*)d_itemsB[cur], nB, (const u32*)nullptr, 0u,
+                                       (const u64*)d_frag, (const ulonglong2*)rc_ck, (const u64*)rc_hcB, (const BlockResult*)d_res, (const ExtTask*)d_tasks, 1, 8, d_ops, d_wout, d_stats, d_err, fl, lo, hi);
+                    NECAT_CHECK_LAUNCH(ctx, "k_myers_ckg / k_rcwalk2<asm B>");
+                }
+                NECAT_HIP(ctx, hipEventRecord(ctx->ev[3], s));
+                hipLaunchKernelGGL((k_traceback<kAsmWords, kAsmTWords, kAsmCols, kAsmMaxOps, false, 5, kAsmBlock>), dim3(gB), dim3(64), 0, s,
+                                   (const BlockItem*)d_itemsB[cur], nB, (const u32*)nullptr, 0u, (const u64*)d_frag, (const char*)nullptr, (size_t)0,
+                                   (const BlockResult*)d_res, d_ops, d_tasks, 8, (i32*)nullptr, d_err, next, fl, 0u, (const WalkOut*)d_wout);
+                NECAT_CHECK_LAUNCH(ctx, "k_traceback<asm B, rc>");
+                NECAT_HIP(ctx, hipEventRecord(ctx->ev[24], s));
+                NECAT_HIP(ctx, hipStreamSynchronize(s));
+                dp += ev_ms(ctx->ev[2], ctx->ev[3]); wk += ev_ms(ctx->ev[3], ctx->ev[24]);
+                ctx->tm.myers_launches += 1;
+            } else
             for (u32 g0 = 0; g0 < gB; g0 += gchunkB) {
                 const u32 lo = g0 * 64, hi = std::min(nB, (g0 + gchunkB) * 64), cn = hi - lo;
                 char* slabs = (char*)ctx->scratch[SC_ASM_BAND].p - (size_t)g0 * kAsmSlab;

@@ -11,13 +11,14 @@ from oracle import oracle_api as ora
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("impl", ["cooperative", "lane"])
+@pytest.mark.parametrize("impl", ["cooperative", "band", "lane"])
 def test_asm_align_arbitrary_anchors(ctx, monkeypatch, impl):
-    """cooperative: the default path (asm_coop.h - the extension stage's round structure and kernels at the 2048-bp geometry);
-    lane: the lane-per-alignment kernel it replaced, kept as the second implementation (NECAT_ASM_LANE=1)"""
+    """cooperative: the default path (asm_coop.h - the extension stage's round structure at the 2048-bp geometry, blocks through the
+    checkpoint pass + recomputing walk of ext_rcwalk.h); band: the same rounds through the two-pass kernel + band records + wave walk
+    (NECAT_ASM_RC=0); lane: the lane-per-alignment kernel they replaced, kept as a further implementation (NECAT_ASM_LANE=1)"""
     own = None
-    if impl == "lane":
-        monkeypatch.setenv("NECAT_ASM_LANE", "1")
+    if impl != "cooperative":
+        monkeypatch.setenv("NECAT_ASM_LANE" if impl == "lane" else "NECAT_ASM_RC", "1" if impl == "lane" else "0")
         own = ctx = capi.Context(0)          # knobs are read when a context is created
     rng = np.random.default_rng(654)
     seqs, rows = [], []
@@ -65,7 +66,7 @@ def test_asm_align_arbitrary_anchors(ctx, monkeypatch, impl):
         ctx.asm_align_batch(vol, vol, 0, 0, bad)
     aln, ops, off = ctx.asm_align_batch(vol, vol, 0, 0, anchors[:0])
     assert aln.shape[0] == 0 and off.shape[0] == 1
-    if impl == "cooperative":
+    if impl != "lane":
         tm = ctx.timings()
         assert tm.rounds >= 1 or len(rows) == 0          # (the empty call above ran no round; the counters are the last non-empty call's only if > 0)
     vol.free()
