@@ -383,7 +383,7 @@ k_rcwalk2(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict
           WalkOut* __restrict__ wout, unsigned long long* __restrict__ stats, int* __restrict__ err_flag, u32 epoch, u32 lo, u32 hi)
 {
     constexpr int FW = 2 * NW + TW, SEG = kRcSeg, HALF = SEG / 2, CK = RcGeom<COLS>::kCk, SEGS = RcGeom<COLS>::kSeg;
-    __shared__ ulonglong2 slices[16][SEG];
+    __shared__ ulonglong2 slices[SEG][16];      // [column][block]: a block's 16 bytes of every column sit in its own 4 LDS banks - blocks never conflict, whatever column each is at
     const ListView lv = list_view(n_host, n_dev, capA);
     const bool all = ((epoch >> 27) & 1u) != 0;
     const u64 first = (u64)lo + (u64)blockIdx.x * 16, lim = all ? lv.n : lv.nf, end = lim < hi ? lim : hi;
@@ -445,13 +445,13 @@ k_rcwalk2(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict
                 fast_advance<true>(wd, el, eh, cph, cmh, 0u, phh, mhh, rA, rB);
                 ++words_done;
                 // the walk's 64 rows of this column: low part from word w1 - 1 (written first: its lane is one step ahead), high part from word w1
-                if (k == 0) { if (sh) slices[q][ci] = make_ulonglong2(rA >> sh, rB >> sh); }
-                else if (!sh) slices[q][ci] = make_ulonglong2(rA, rB);
+                if (k == 0) { if (sh) slices[ci][q] = make_ulonglong2(rA >> sh, rB >> sh); }
+                else if (!sh) slices[ci][q] = make_ulonglong2(rA, rB);
                 else {
                     const u64 pa = rA << (64 - sh), pb = rB << (64 - sh);
-                    if (w == 0) slices[q][ci] = make_ulonglong2(pa, pb);          // rows above the matrix are never looked at
+                    if (w == 0) slices[ci][q] = make_ulonglong2(pa, pb);          // rows above the matrix are never looked at
                     else {      // (LDS atomics without a return value: nothing to wait for)
-                        unsigned long long* dst = reinterpret_cast<unsigned long long*>(&slices[q][ci]);
+                        unsigned long long* dst = reinterpret_cast<unsigned long long*>(&slices[ci][q]);
                         __hip_atomic_fetch_or(dst, pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_fetch_or(dst + 1, pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
@@ -468,7 +468,7 @@ k_rcwalk2(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict
             if (lean) {
                 for (;;) {
                     if (c < c0 || r < rb) break;                      // out of the segment / of the rows kept: the next segment (or this one again)
-                    const ulonglong2 v = slices[q][c - c0];
+                    const ulonglong2 v = slices[c - c0][q];
                     const int bit = r - rb;
                     const u32 a = (u32)(v.x >> bit) & 1u, b = (u32)(v.y >> bit) & 1u;
                     const int drow = 1 - (int)(b & (a ^ 1u)), dcol = 1 - (int)(a & (b ^ 1u));
@@ -479,7 +479,7 @@ k_rcwalk2(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict
             } else {
                 for (;;) {
                     if (c < c0 || r < rb) break;
-                    const ulonglong2 v = slices[q][c - c0];
+                    const ulonglong2 v = slices[c - c0][q];
                     const int bit = r - rb;
                     const u32 a = (u32)(v.x >> bit) & 1u, b = (u32)(v.y >> bit) & 1u;
                     const int op = (int)(a | (b << 1));

@@ -174,7 +174,7 @@ void necat_ctx_destroy(necat_ctx* ctx)
     if (ctx->pin_plan) (void)hipHostFree(ctx->pin_plan);
     for (int i = 0; i < kNumEvents; ++i) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->round_ring) (void)hipHostFree(ctx->round_ring);
-    for (hipStream_t st : {ctx->stream, ctx->stream_a, ctx->stream_b, ctx->stream_c, ctx->stream_copy}) if (st) (void)hipStreamDestroy(st);
+    for (hipStream_t st : {ctx->stream, ctx->stream_a, ctx->stream_b, ctx->stream_c, ctx->stream_d, ctx->stream_copy}) if (st) (void)hipStreamDestroy(st);
     delete ctx;
 }
 
