@@ -76,6 +76,7 @@ u32 g_tail_fused;      // NECAT_TAIL_FUSED (default 512 = one workgroup per bloc
 u32 g_rcwalk;          // NECAT_RCWALK (default 16384; 0 = off): list-A rounds of more than this many blocks run their full blocks through k_myers_ck + k_rcwalk4 (ext_rcwalk.h: no NW pass, no band records, the walk recomputes its cells)
 size_t g_rc_pool;      // NECAT_RC_POOL_MB (default 2048): cap of the checkpoint buffer of those rounds; a longer list goes through it in several launches
 u32 g_asm_rc;          // NECAT_ASM_RC (default 1): the 2048-bp block aligner of oc2asmpm through k_myers_ckg + k_rcwalk2 (no NW pass, no band records); 0 = two-pass kernel + band + wave walk
+u32 g_rc_listb;        // NECAT_RC_LISTB (default 1, needs NECAT_RC_CARRY): list B (blocks up to 794 x 794) through k_myers_ckg + k_rcwalk2 too; 0 = two-pass kernel + band pool + walk
 u32 g_rc_ragged;       // NECAT_RC_RAGGED (default 1, needs NECAT_RC_CARRY): the ragged blocks of those rounds through k_myers_ckg + k_rcwalk2 as well (0: two-pass kernel + lane walk on a stream of their own)
 u32 g_rc_carry;        // NECAT_RC_CARRY (default 1): the recompute walk on an exact two-word window (k_myers_ck<CARRY> keeps the words' horizontal deltas, k_rcwalk2); 0 = the 4-word band window (k_rcwalk4)
 int g_rc_maxdist;      // NECAT_RC_MAXDIST (default and maximum kRcMaxDist = 160): full blocks of a larger distance take the old kernels (tests lower it)
@@ -96,6 +97,7 @@ void read_knobs()
     g_rcwalk = (u32)num("NECAT_RCWALK", 16384);
     g_rc_carry = (u32)num("NECAT_RC_CARRY", 1);
     g_asm_rc = (u32)num("NECAT_ASM_RC", 1);
+    g_rc_listb = g_rc_carry ? (u32)num("NECAT_RC_LISTB", 1) : 0u;
     g_rc_ragged = g_rc_carry ? (u32)num("NECAT_RC_RAGGED", 1) : 0u;
     g_rc_pool = (size_t)std::max<unsigned long long>(1, num("NECAT_RC_POOL_MB", 2048)) << 20;
     g_rc_maxdist = (int)num("NECAT_RC_MAXDIST", g_rc_carry ? 1 << 20 : kRcMaxDist);
@@ -1120,6 +1122,46 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
             NECAT_HIP(ctx, hipEventRecord(c.b1[slot], sb));
             NECAT_HIP(ctx, hipEventRecord(c.b2[slot], sb));
             b_pending[slot] = true; b_fused[slot] = true; b_blocks[slot] = nB;
+            return NECAT_OK;
+        }
+        const int cur_b = q % 4, nxt2_b = (q + 2) % 4;
+        if (g_rc_listb && g_rc_carry && nB <= g_coop_threshold) {
+            // ---- list B through the checkpoint pass + recomputing walk as well (ext_rcwalk.h at 13 words / 16 lanes per block): one DP
+            // pass instead of two, no band records, the walk on LDS
+            constexpr size_t per_ck = (size_t)RcGeom<kColsB>::kCk * kWordsB * sizeof(ulonglong2), per_hc = (size_t)RcGeom<kColsB>::kSeg * kWordsB * sizeof(u64);
+            const u32 rc_chunk = (u32)std::max<size_t>(64, std::min<size_t>((size_t)gB * 64, (g_rc_pool / (per_ck + per_hc)) & ~(size_t)63));
+            DevBuf& ckb = ctx->scratch[slot ? SC_EXT_CKPTB2 : SC_EXT_CKPTB];
+            DevBuf& wob = ctx->scratch[slot ? SC_EXT_WOUTB2 : SC_EXT_WOUTB];
+            int rc2;
+            if ((rc2 = buf_ensure(ctx, ckb, (size_t)rc_chunk * (per_ck + per_hc))) || (rc2 = buf_ensure(ctx, wob, (size_t)gB * 64 * sizeof(WalkOut)))) return rc2;
+            ulonglong2* ck = (ulonglong2*)ckb.p;
+            u64* hcar = (u64*)((char*)ckb.p + (size_t)rc_chunk * per_ck);
+            WalkOut* wo = (WalkOut*)wob.p;
+            const BlockItem* itB = c.itemsB[cur_b];
+            const u32* d_nB = c.count + 4 * cur_b + 1;
+            NECAT_HIP(ctx, hipStreamWaitEvent(sb, c.a0[cur_b], 0));     // lists[q] complete (A(q - 1) done), counters of lists[q + 2] reset
+            NECAT_HIP(ctx, hipStreamWaitEvent(sb, c.b2[slot], 0));      // B(q - 2): appended to lists[q], previous user of the slot's buffers
+            const u32 epoch = ++ctx->epoch & 0x3fffffu, fl = epoch | (1u << 27);
+            ExtLists next; next.count = c.count + 4 * nxt2_b; next.itemsA = c.itemsA[nxt2_b]; next.itemsB = c.itemsB[nxt2_b]; next.task_ops = X.task_ops; next.capA = c.cap;
+            RoundCtl ctl; ctl.zero_bins = c.bins[slot];
+            hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, sb,
+                               drd, dref, itB, nB, d_nB, 0u, c.fragB[slot], ctl);
+            NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
+            NECAT_HIP(ctx, hipEventRecord(c.b0[slot], sb));
+            for (u32 lo = 0; lo < nB; lo += rc_chunk) {
+                const u32 hi = std::min<u64>((u64)lo + rc_chunk, (u64)gB * 64), cn = std::min(hi, nB) - lo;
+                hipLaunchKernelGGL((k_myers_ckg<kWordsB, kTWordsB, kColsB, 16>), dim3((cn + 3) / 4), dim3(64), 0, sb, itB, nB, d_nB, 0u, (const u64*)c.fragB[slot], ck, hcar, X.error,
+                                   c.resB[slot], X.stats, epoch, lo, hi);
+                if (lo + rc_chunk >= nB) NECAT_HIP(ctx, hipEventRecord(c.b1[slot], sb));
+                hipLaunchKernelGGL((k_rcwalk2<kWordsB, kTWordsB, kColsB, kOpsB>), dim3((cn + 15) / 16), dim3(64), 0, sb, itB, nB, d_nB, 0u, (const u64*)c.fragB[slot], (const ulonglong2*)ck,
+                                   (const u64*)hcar, (const BlockResult*)c.resB[slot], (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsB[slot], wo, X.stats, X.d_err, fl, lo, hi);
+                NECAT_CHECK_LAUNCH(ctx, "k_myers_ckg / k_rcwalk2<B>");
+            }
+            hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false, 5>), dim3(gB), dim3(64), 0, sb, itB, nB, d_nB, 0u, (const u64*)c.fragB[slot], (const char*)nullptr, (size_t)0,
+                               (const BlockResult*)c.resB[slot], c.opsB[slot], c.tasks, X.tail_match_len, (i32*)nullptr, X.d_err, next, fl, 0u, (const WalkOut*)wo);
+            NECAT_CHECK_LAUNCH(ctx, "k_traceback<B, rc>");
+            NECAT_HIP(ctx, hipEventRecord(c.b2[slot], sb));
+            b_pending[slot] = true; b_blocks[slot] = nB;
             return NECAT_OK;
         }
         DevBuf& poolB = ctx->scratch[slot ? SC_EXT_MATB2 : SC_EXT_MATB];

@@ -41,7 +41,7 @@ struct necat_ctx {
     void* round_ring = nullptr;        // pinned, device-visible ring of RoundPub entries: list sizes published by the round kernels
     void* round_ring_dev = nullptr;    // the same memory as the device addresses it
     unsigned long long round_seq = 0;  // rounds published so far (the next round publishes round_seq + 1)
-    necat::DevBuf scratch[40];         // grow-only arenas, indexed by purpose (ScratchId)
+    necat::DevBuf scratch[48];         // grow-only arenas, indexed by purpose (ScratchId)
     void* seed_ht_ptr = nullptr;       // the seeding hash arena (SC_SEED_HT) whose first seed_ht_clean bytes are known to be all-empty (0xFF):
     size_t seed_ht_clean = 0;          // every call leaves the arena as it found it (k_seed_clear resets the slots it used), so it is filled once per allocation
     char devname[256] = {0};
@@ -105,7 +105,7 @@ inline int buf_ensure(necat_ctx* ctx, DevBuf& b, size_t bytes)
         if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = tot = 0;
         char own[512]; int at = 0; size_t sum = 0;          // this context's arenas of 256 MB and more (ScratchId : MB)
         own[0] = 0;
-        if (ctx) for (int i = 0; i < 40; ++i) {
+        if (ctx) for (int i = 0; i < 48; ++i) {
             sum += ctx->scratch[i].cap;
             if (ctx->scratch[i].cap >= ((size_t)256 << 20) && at < 480) at += snprintf(own + at, sizeof own - (size_t)at, " %d:%zu", i, ctx->scratch[i].cap >> 20);
         }
@@ -139,7 +139,7 @@ enum ScratchId {
     SC_SEED_META, SC_SEED_HT, SC_SEED_POOL, SC_SEED_CHAIN, SC_SEED_OUT, SC_SEED_FINAL,
     SC_EXT_TASKS, SC_EXT_LISTS, SC_EXT_FRAG, SC_EXT_MAT, SC_EXT_OPS, SC_EXT_RES, SC_EXT_CAND, SC_SMALL, SC_PART,
     SC_EXT_COLS, SC_EXT_COLS_OUT, SC_PART2, SC_SEED_ALL, SC_EXT_MATB, SC_EXT_MATB2, SC_EXT_PERM, SC_GATHER, SC_SPLIT, SC_SPLIT2,
-    SC_ASM_BAND, SC_ASM_OPS, SC_ASM_COLS, SC_ASM_MISC, SC_ASM_FRAG, SC_ASM_OUT, SC_SEED_KST, SC_EXT_CKPT, SC_EXT_WOUT,
+    SC_ASM_BAND, SC_ASM_OPS, SC_ASM_COLS, SC_ASM_MISC, SC_ASM_FRAG, SC_ASM_OUT, SC_SEED_KST, SC_EXT_CKPT, SC_EXT_WOUT, SC_EXT_CKPTB, SC_EXT_CKPTB2, SC_EXT_WOUTB, SC_EXT_WOUTB2,
     SC_COUNT
 };
 
