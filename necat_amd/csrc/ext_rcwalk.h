@@ -366,7 +366,6 @@ k_myers_ckg(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
         br.words = (u32)(nblk * tn);
         results[item] = br;
         atomicAdd(&stats[0], (unsigned long long)br.words); atomicAdd(&stats[1], (unsigned long long)(qn + tn));
-        if (br.dist >= 0) atomicAdd(&stats[3], 1ULL);
     }
 }
 

@@ -73,7 +73,7 @@ int g_fast16;          // NECAT_FAST16=1: list A's big rounds through k_myers_a1
 size_t g_band_pool;    // NECAT_BAND_POOL_MB (default 16384): cap of one band-record pool; a bigger list runs in several DP + walk launches (0 = no cap)
 int g_walk;            // NECAT_WALK=0: k_traceback runs the reference formulation of the walk (A/B measurements)
 u32 g_tail_fused;      // NECAT_TAIL_FUSED (default 512 = one workgroup per block at 2 per CU; 0 = off): lists of at most this many blocks run as ONE launch per round with the band in LDS (ext_tail.h)
-u32 g_rcwalk;          // NECAT_RCWALK (default 16384; 0 = off): list-A rounds of more than this many blocks run their full blocks through k_myers_ck + k_rcwalk4 (ext_rcwalk.h: no NW pass, no band records, the walk recomputes its cells)
+u32 g_rcwalk;          // NECAT_RCWALK (default 512 = every list the one-launch tail kernel does not take; 0 = off): list-A rounds of more than this many blocks run through k_myers_ck / k_myers_ckg + k_rcwalk2 (ext_rcwalk.h: no NW pass, no band records, the walk recomputes its cells)
 size_t g_rc_pool;      // NECAT_RC_POOL_MB (default 2048): cap of the checkpoint buffer of those rounds; a longer list goes through it in several launches
 u32 g_asm_rc;          // NECAT_ASM_RC (default 1): the 2048-bp block aligner of oc2asmpm through k_myers_ckg + k_rcwalk2 (no NW pass, no band records); 0 = two-pass kernel + band + wave walk
 u32 g_rc_listb;        // NECAT_RC_LISTB (default 1, needs NECAT_RC_CARRY): list B (blocks up to 794 x 794) through k_myers_ckg + k_rcwalk2 too; 0 = two-pass kernel + band pool + walk
@@ -94,7 +94,7 @@ void read_knobs()
     g_tail_fused = (u32)num("NECAT_TAIL_FUSED", 512);
     g_asm_lane = (int)num("NECAT_ASM_LANE", 0);
     g_walk_wave = (u32)num("NECAT_WALK_WAVE", 12288);
-    g_rcwalk = (u32)num("NECAT_RCWALK", 16384);
+    g_rcwalk = (u32)num("NECAT_RCWALK", 512);
     g_rc_carry = (u32)num("NECAT_RC_CARRY", 1);
     g_asm_rc = (u32)num("NECAT_ASM_RC", 1);
     g_rc_listb = g_rc_carry ? (u32)num("NECAT_RC_LISTB", 1) : 0u;

@@ -460,8 +460,9 @@ def test_capped_band_pool_runs_lists_in_chunks(ctx, small, tmp_path, monkeypatch
         c.close()
 
 
-@pytest.mark.parametrize("knob", ["NECAT_CHAIN_WAVE=0", "NECAT_FAST16=1", "NECAT_WALK=1", "NECAT_FAST=0", "NECAT_SEED_WAVE=0",
-                                  "NECAT_TAIL_FUSED=0", "NECAT_TAIL_FUSED=100000000", "NECAT_WALK_WAVE=0", "NECAT_WALK_WAVE=100000000 NECAT_TAIL_FUSED=0", "NECAT_SEED_KST=0",
+@pytest.mark.parametrize("knob", ["NECAT_CHAIN_WAVE=0", "NECAT_RCWALK=0 NECAT_FAST16=1", "NECAT_RCWALK=0 NECAT_WALK=1", "NECAT_FAST=0", "NECAT_SEED_WAVE=0",
+                                  "NECAT_TAIL_FUSED=0", "NECAT_TAIL_FUSED=100000000", "NECAT_RCWALK=0 NECAT_WALK_WAVE=0", "NECAT_RCWALK=0 NECAT_WALK_WAVE=100000000 NECAT_TAIL_FUSED=0", "NECAT_SEED_KST=0",
+                                  "NECAT_RCWALK=0 NECAT_RC_LISTB=0 NECAT_TAIL_FUSED=0",
                                   "NECAT_RCWALK=0", "NECAT_RCWALK=1 NECAT_TAIL_FUSED=0 NECAT_WALK_WAVE=0", "NECAT_RCWALK=1 NECAT_RC_MAXDIST=90 NECAT_TAIL_FUSED=0",
                                   "NECAT_RCWALK=1 NECAT_RC_CARRY=0 NECAT_TAIL_FUSED=0", "NECAT_RCWALK=1 NECAT_RC_CARRY=0 NECAT_RC_MAXDIST=90",
                                   "NECAT_RCWALK=1 NECAT_RC_POOL_MB=1", "NECAT_RCWALK=1 NECAT_RC_RAGGED=0 NECAT_TAIL_FUSED=0",
