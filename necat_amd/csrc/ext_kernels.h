@@ -905,11 +905,19 @@ k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
         } else {
             const int mine = kept.cols > 0 ? nops : 0;          // rows [nops - cols, nops) hold forward [0, cols)
             const int lo = nops - kept.cols;
-            int r = wave_max_u11(mine) - 1;
-            for (; r >= 0; --r) {
-                if (r < mine && r >= lo) {
-                    acc |= (u64)ow.ops[(size_t)r * 64] << sh; sh += 2;
-                    if (sh == 64) { reg[w++] = acc; acc = 0; sh = 0; }
+            // (32 rows per trip, loaded before any is used: the loads are independent - the loop used to be one memory round trip per row)
+            constexpr int kRows = 32;
+            for (int r = wave_max_u11(mine) - 1; r >= 0; r -= kRows) {
+                u32 b[kRows];
+#pragma unroll
+                for (int k = 0; k < kRows; ++k) { const int rr = r - k; b[k] = (rr < mine && rr >= lo) ? (u32)ow.ops[(size_t)rr * 64] : 0u; }
+#pragma unroll
+                for (int k = 0; k < kRows; ++k) {
+                    const int rr = r - k;
+                    if (rr < mine && rr >= lo) {
+                        acc |= (u64)b[k] << sh; sh += 2;
+                        if (sh == 64) { reg[w++] = acc; acc = 0; sh = 0; }
+                    }
                 }
             }
         }

@@ -1759,17 +1759,25 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
     const size_t rc_pool = std::max<size_t>(g_rc_pool, (size_t)4 << 30);
     const u32 rc_chunkA = (u32)std::max<size_t>(64, std::min<size_t>((size_t)groups * 64, (rc_pool / (kCkA + kHcA)) & ~(size_t)63));
     const u32 rc_chunkB = (u32)std::max<size_t>(64, std::min<size_t>((size_t)groups * 64, (rc_pool / (kCkB + kHcB)) & ~(size_t)63));
+    // (the recompute path runs the two lists of a round side by side on two streams: list B has buffers of its own)
     if (g_asm_rc) {
-        if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_CKPT], std::max((size_t)rc_chunkA * (kCkA + kHcA), (size_t)rc_chunkB * (kCkB + kHcB)))) ||
-            (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_WOUT], (size_t)groups * 64 * sizeof(WalkOut)))) return rc;
+        if ((rc = ext_streams(ctx)) ||
+            (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_CKPT], (size_t)rc_chunkA * (kCkA + kHcA))) ||
+            (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_CKPTB], (size_t)rc_chunkB * (kCkB + kHcB))) ||
+            (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_WOUT], (size_t)groups * 64 * sizeof(WalkOut))) ||
+            (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_WOUTB], (size_t)groups * 64 * sizeof(WalkOut)))) return rc;
     }
     ulonglong2* const rc_ck = (ulonglong2*)ctx->scratch[SC_EXT_CKPT].p;
+    ulonglong2* const rc_ckB = (ulonglong2*)ctx->scratch[SC_EXT_CKPTB].p;
     u64* const rc_hcA = (u64*)((char*)ctx->scratch[SC_EXT_CKPT].p + (size_t)rc_chunkA * kCkA);
-    u64* const rc_hcB = (u64*)((char*)ctx->scratch[SC_EXT_CKPT].p + (size_t)rc_chunkB * kCkB);
+    u64* const rc_hcB = (u64*)((char*)ctx->scratch[SC_EXT_CKPTB].p + (size_t)rc_chunkB * kCkB);
     WalkOut* const d_wout = (WalkOut*)ctx->scratch[SC_EXT_WOUT].p;
+    WalkOut* const d_woutB = (WalkOut*)ctx->scratch[SC_EXT_WOUTB].p;
+    const size_t opsA_bytes = (size_t)groups * 64 * kAsmOpsA, opsB_bytes = (size_t)groups * 64 * kAsmMaxOps;
+    const size_t fragA_bytes = (size_t)groups * 64 * kAsmFragWordsA * 8, fragB_bytes = (size_t)groups * 64 * kAsmFragWords * 8;
     if ((rc = g_asm_rc ? 0 : buf_ensure(ctx, ctx->scratch[SC_ASM_BAND], std::max((size_t)gchunkA * kAsmSlabA, (size_t)gchunkB * kAsmSlab))) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_OPS], (size_t)groups * 64 * std::max(kAsmMaxOps, kAsmOpsA))) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_FRAG], (size_t)groups * 64 * std::max(kAsmFragWords, kAsmFragWordsA) * 8)) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_OPS], g_asm_rc ? opsA_bytes + opsB_bytes : std::max(opsA_bytes, opsB_bytes))) ||
+        (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_FRAG], g_asm_rc ? fragA_bytes + fragB_bytes : std::max(fragA_bytes, fragB_bytes))) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_COLS], base[n] + 64)) ||
         (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_MISC], misc))) return rc;
     char* mb = (char*)ctx->scratch[SC_ASM_MISC].p;
@@ -1783,6 +1791,7 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
     for (int k = 0; k < 2; ++k) { d_itemsA[k] = (BlockItem*)take((size_t)cap * sizeof(BlockItem)); d_itemsB[k] = (BlockItem*)take((size_t)cap * sizeof(BlockItem)); }
     u64* d_base = (u64*)take((n + 1) * 8);
     BlockResult* d_res = (BlockResult*)take(((size_t)groups * 64) * sizeof(BlockResult));
+    BlockResult* d_resB = (BlockResult*)take(((size_t)groups * 64) * sizeof(BlockResult));
     u8* d_cols = (u8*)ctx->scratch[SC_ASM_COLS].p;
     NECAT_HIP(ctx, hipMemcpyAsync(d_anchor, h.data(), n * sizeof(AsmAnchor), hipMemcpyHostToDevice, s));
     NECAT_HIP(ctx, hipMemcpyAsync(d_base, base.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
@@ -1795,6 +1804,9 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
     NECAT_CHECK_LAUNCH(ctx, "k_asm_init");
     u64* const d_frag = (u64*)ctx->scratch[SC_ASM_FRAG].p;
     u8* const d_ops = (u8*)ctx->scratch[SC_ASM_OPS].p;
+    u64* const d_fragB = g_asm_rc ? (u64*)((char*)d_frag + fragA_bytes) : d_frag;
+    u8* const d_opsB = g_asm_rc ? d_ops + opsA_bytes : d_ops;
+    hipStream_t sB = g_asm_rc ? ctx->stream_b : s;
     for (u32 r = 0;; ++r) {
         if (r > 4096) return set_err(ctx, NECAT_ERR_INTERNAL, "asm aligner: no end of rounds");
         const int cur = (int)(r & 1), nxt = cur ^ 1;
@@ -1804,6 +1816,7 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
         const u32 nf = cnt[0], nB = cnt[1], np = cnt[2];
         if (nf + nB + np == 0) break;
         NECAT_HIP(ctx, hipMemsetAsync(d_count + 4 * nxt, 0, 16, s));
+        if (g_asm_rc) { NECAT_HIP(ctx, hipEventRecord(ctx->ev[34], s)); NECAT_HIP(ctx, hipStreamWaitEvent(sB, ctx->ev[34], 0)); }
         const ExtLists next = lists(nxt);
         RoundCtl ctl;
         double dp = 0, wk = 0;
@@ -1834,8 +1847,6 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
                                    (const BlockResult*)d_res, d_ops, d_tasks, 8 /* kMatchCnt2: the tail match length of hbn_align */, (i32*)nullptr, d_err, next, fl, 0u, (const WalkOut*)d_wout);
                 NECAT_CHECK_LAUNCH(ctx, "k_traceback<asm A, rc>");
                 NECAT_HIP(ctx, hipEventRecord(ctx->ev[24], s));
-                NECAT_HIP(ctx, hipStreamSynchronize(s));
-                dp += ev_ms(ctx->ev[2], ctx->ev[3]); wk += ev_ms(ctx->ev[3], ctx->ev[24]);
                 ctx->tm.myers_launches += 1;
             } else
             for (u32 g0 = 0; g0 < gA; g0 += gchunkA) {
@@ -1864,28 +1875,26 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
         // ---- list B: a plain list of nB items
         if (nB) {
             const u32 gB = (nB + 63) / 64;
-            hipLaunchKernelGGL((k_ext_frag<kAsmWords, kAsmTWords>), dim3(grid_for((u64)gB * 64 * (kAsmWords + kAsmTWords), 256)), dim3(256), 0, s,
-                               drd, dref, (const BlockItem*)d_itemsB[cur], nB, (const u32*)nullptr, 0u, d_frag, ctl);
+            hipLaunchKernelGGL((k_ext_frag<kAsmWords, kAsmTWords>), dim3(grid_for((u64)gB * 64 * (kAsmWords + kAsmTWords), 256)), dim3(256), 0, sB,
+                               drd, dref, (const BlockItem*)d_itemsB[cur], nB, (const u32*)nullptr, 0u, d_fragB, ctl);
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<asm B>");
             if (g_asm_rc) {
                 const u32 epoch = ++ctx->epoch & 0x3fffffu, fl = epoch | (1u << 27);
-                NECAT_HIP(ctx, hipEventRecord(ctx->ev[2], s));
+                NECAT_HIP(ctx, hipEventRecord(ctx->ev[36], sB));
                 for (u32 lo = 0; lo < nB; lo += rc_chunkB) {
                     const u32 hi = std::min<u64>((u64)lo + rc_chunkB, (u64)gB * 64), cn = std::min(hi, nB) - lo;
-                    hipLaunchKernelGGL((k_myers_ckg<kAsmWords, kAsmTWords, kAsmCols, 64>), dim3(cn), dim3(64), 0, s, (const BlockItem*)d_itemsB[cur], nB, (const u32*)nullptr, 0u,
-                                       (const u64*)d_frag, rc_ck, rc_hcB, error, d_res, d_stats, epoch, lo, hi);
-                    hipLaunchKernelGGL((k_rcwalk2<kAsmWords, kAsmTWords, kAsmCols, kAsmMaxOps>), dim3((cn + 15) / 16), dim3(64), 0, s, (const BlockItem*)d_itemsB[cur], nB, (const u32*)nullptr, 0u,
-                                       (const u64*)d_frag, (const ulonglong2*)rc_ck, (const u64*)rc_hcB, (const BlockResult*)d_res, (const ExtTask*)d_tasks, 1, 8, d_ops, d_wout, d_stats, d_err, fl, lo, hi);
+                    hipLaunchKernelGGL((k_myers_ckg<kAsmWords, kAsmTWords, kAsmCols, 64>), dim3(cn), dim3(64), 0, sB, (const BlockItem*)d_itemsB[cur], nB, (const u32*)nullptr, 0u,
+                                       (const u64*)d_fragB, rc_ckB, rc_hcB, error, d_resB, d_stats, epoch, lo, hi);
+                    hipLaunchKernelGGL((k_rcwalk2<kAsmWords, kAsmTWords, kAsmCols, kAsmMaxOps>), dim3((cn + 15) / 16), dim3(64), 0, sB, (const BlockItem*)d_itemsB[cur], nB, (const u32*)nullptr, 0u,
+                                       (const u64*)d_fragB, (const ulonglong2*)rc_ckB, (const u64*)rc_hcB, (const BlockResult*)d_resB, (const ExtTask*)d_tasks, 1, 8, d_opsB, d_woutB, d_stats, d_err, fl, lo, hi);
                     NECAT_CHECK_LAUNCH(ctx, "k_myers_ckg / k_rcwalk2<asm B>");
                 }
-                NECAT_HIP(ctx, hipEventRecord(ctx->ev[3], s));
-                hipLaunchKernelGGL((k_traceback<kAsmWords, kAsmTWords, kAsmCols, kAsmMaxOps, false, 5, kAsmBlock>), dim3(gB), dim3(64), 0, s,
-                                   (const BlockItem*)d_itemsB[cur], nB, (const u32*)nullptr, 0u, (const u64*)d_frag, (const char*)nullptr, (size_t)0,
-                                   (const BlockResult*)d_res, d_ops, d_tasks, 8, (i32*)nullptr, d_err, next, fl, 0u, (const WalkOut*)d_wout);
+                NECAT_HIP(ctx, hipEventRecord(ctx->ev[37], sB));
+                hipLaunchKernelGGL((k_traceback<kAsmWords, kAsmTWords, kAsmCols, kAsmMaxOps, false, 5, kAsmBlock>), dim3(gB), dim3(64), 0, sB,
+                                   (const BlockItem*)d_itemsB[cur], nB, (const u32*)nullptr, 0u, (const u64*)d_fragB, (const char*)nullptr, (size_t)0,
+                                   (const BlockResult*)d_resB, d_opsB, d_tasks, 8, (i32*)nullptr, d_err, next, fl, 0u, (const WalkOut*)d_woutB);
                 NECAT_CHECK_LAUNCH(ctx, "k_traceback<asm B, rc>");
-                NECAT_HIP(ctx, hipEventRecord(ctx->ev[24], s));
-                NECAT_HIP(ctx, hipStreamSynchronize(s));
-                dp += ev_ms(ctx->ev[2], ctx->ev[3]); wk += ev_ms(ctx->ev[3], ctx->ev[24]);
+                NECAT_HIP(ctx, hipEventRecord(ctx->ev[38], sB));
                 ctx->tm.myers_launches += 1;
             } else
             for (u32 g0 = 0; g0 < gB; g0 += gchunkB) {
@@ -1910,6 +1919,12 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
                 dp += ev_ms(ctx->ev[2], ctx->ev[3]); wk += ev_ms(ctx->ev[3], ctx->ev[24]);
                 ctx->tm.myers_launches += 1;
             }
+        }
+        if (g_asm_rc) {
+            if (nB) { NECAT_HIP(ctx, hipEventRecord(ctx->ev[35], sB)); NECAT_HIP(ctx, hipStreamWaitEvent(s, ctx->ev[35], 0)); }
+            NECAT_HIP(ctx, hipStreamSynchronize(s));
+            if (boundA) { dp += ev_ms(ctx->ev[2], ctx->ev[3]); wk += ev_ms(ctx->ev[3], ctx->ev[24]); }
+            if (nB) { dp += ev_ms(ctx->ev[36], ctx->ev[37]); wk += ev_ms(ctx->ev[37], ctx->ev[38]); }      // (the two chains overlap: the sums exceed the round's wall time)
         }
         ctx->tm.myers_ms += dp; ctx->tm.traceback_ms += wk;
         ctx->tm.myers_blocks += nf + np + nB; ctx->tm.rounds += 1;

@@ -22,7 +22,7 @@ struct DevBuf {
 
 }  // namespace necat
 
-constexpr int kNumEvents = 32;
+constexpr int kNumEvents = 40;
 constexpr unsigned kRoundRing = 1024;  // entries of necat_ctx::round_ring
 
 struct necat_ctx {
