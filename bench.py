@@ -311,6 +311,8 @@ def oc2asmpm_program(genome, threads, tmp):
     calls = re.findall(r"asm_align \(cooperative\): (\d+) anchors, (\d+) rounds, (\d+) blocks, DP ([0-9.]+) ms, walk ([0-9.]+) ms, whole call ([0-9.]+) ms", r.stderr)
     res.update(records=sum(1 for _ in open(mine, "rb")), anchors=sum(int(c[0]) for c in calls), block_alignments=sum(int(c[2]) for c in calls),
                device_ms=round(sum(float(c[5]) for c in calls), 2), device_dp_ms=round(sum(float(c[3]) for c in calls), 2), device_walk_ms=round(sum(float(c[4]) for c in calls), 2))
+    res["note"] = ("device_ms = the aligner calls start to end on the device clock; device_dp_ms / device_walk_ms = SHW pass + recomputing walk / finishing kernel "
+                   "summed over the two lists of every round, whose chains run side by side (the sums can exceed device_ms)")
     if res["device_ms"] > 0:
         res["anchors_per_s_device"] = round(res["anchors"] / (res["device_ms"] * 1e-3), 1)
     ref = os.path.join(os.path.dirname(ora.REF_PMOV), "oc2asmpm")

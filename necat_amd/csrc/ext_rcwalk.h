@@ -384,9 +384,10 @@ k_rcwalk2(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict
     constexpr int FW = 2 * NW + TW, SEG = kRcSeg, HALF = SEG / 2, CK = RcGeom<COLS>::kCk, SEGS = RcGeom<COLS>::kSeg;
     __shared__ ulonglong2 slices[SEG][16];      // [column][block]: a block's 16 bytes of every column sit in its own 4 LDS banks - blocks never conflict, whatever column each is at
     const ListView lv = list_view(n_host, n_dev, capA);
-    const bool all = ((epoch >> 27) & 1u) != 0;
-    const u64 first = (u64)lo + (u64)blockIdx.x * 16, lim = all ? lv.n : lv.nf, end = lim < hi ? lim : hi;
-    if (first >= end) return;
+    // epoch bit 27: the whole list; bit 26: only the ragged part [nf16, n) of a two-ended list A; neither: only its full blocks [0, nf)
+    const bool all = ((epoch >> 27) & 1u) != 0, ragged = ((epoch >> 26) & 1u) != 0;
+    const u64 first = (u64)lo + (u64)blockIdx.x * 16, lim = (all || ragged) ? lv.n : lv.nf, end = lim < hi ? lim : hi;
+    if (first >= end || (ragged && first + 16 <= (u64)lv.nf16)) return;      // (nf16 is a multiple of 16: a wave is all full blocks / holes or all ragged ones)
     const int lane = (int)threadIdx.x, q = lane >> 2, j = lane & 3, k = j & 1, h = j >> 1;
     const u64 item = first + (u64)q;
     BlockItem it0;

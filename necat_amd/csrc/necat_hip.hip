@@ -1318,14 +1318,18 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                     if (one_chunk) NECAT_HIP(ctx, hipStreamWaitEvent(sd, c.a0[cur], 0));            // the fragments are there
                     hipLaunchKernelGGL((k_myers_ckg<kWordsA, kTWordsA, kColsA, 8>), dim3((cn + 7) / 8), dim3(64), 0, sr, itA, bound, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error,
                                        c.resA, X.stats, ckg_all ? epoch : fl_rag, lo, hi);
-                    if (one_chunk) { NECAT_HIP(ctx, hipEventRecord(ctx->ev[30], sd)); }
+                    if (one_chunk) {       // .. and their walk there too: the full blocks' walk need not wait for this pass (as long as the full blocks' own)
+                        hipLaunchKernelGGL((k_rcwalk2<kWordsA, kTWordsA, kColsA, kOpsA>), dim3((cn + 15) / 16), dim3(64), 0, sd, itA, bound, d_nA, c.cap, (const u64*)c.fragA, (const ulonglong2*)ck,
+                                           (const u64*)hcar, (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsA, wo, X.stats, X.d_err, fl_rag, lo, hi);
+                        NECAT_HIP(ctx, hipEventRecord(ctx->ev[30], sd));
+                    }
                 }
                 NECAT_CHECK_LAUNCH(ctx, "k_myers_ck");
                 if (last) NECAT_HIP(ctx, hipEventRecord(c.a1[cur], c.sa));
-                if (g_rc_ragged && one_chunk) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, ctx->ev[30], 0));
                 if (g_rc_carry)
                     hipLaunchKernelGGL((k_rcwalk2<kWordsA, kTWordsA, kColsA, kOpsA>), dim3((cn + 15) / 16), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap, (const u64*)c.fragA, (const ulonglong2*)ck,
-                                       (const u64*)hcar, (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsA, wo, X.stats, X.d_err, fl_all, lo, hi);
+                                       (const u64*)hcar, (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsA, wo, X.stats, X.d_err,
+                                       (g_rc_ragged && one_chunk) ? epoch : fl_all, lo, hi);
                 else
                     hipLaunchKernelGGL((k_rcwalk4<kWordsA, kTWordsA, kOpsA>), dim3((cn + 15) / 16), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, (const ulonglong2*)ck,
                                        (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsA, wo, X.stats, X.d_err, lo, hi);
@@ -1342,6 +1346,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                 NECAT_CHECK_LAUNCH(ctx, "k_myers / k_traceback<A, wide>");
             }
             if (!g_rc_ragged || wide_possible) NECAT_HIP(ctx, hipEventRecord(ctx->ev[25], sd));
+            if (g_rc_ragged && one_chunk) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, ctx->ev[30], 0));       // the ragged blocks are walked
             rc_round.push_back(r);
             hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, 5>), dim3(gA), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap,
                                (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,

@@ -30,7 +30,7 @@ python - <<'PY'
 import json
 d=json.loads(open('gpurun_out/r03/r03_bench_final.json').read().strip().splitlines()[-1])
 for k in ('value','gbp_aligned_per_s','ms_per_step','phases_ms_per_step'): print(k, d.get(k))
-r=d['roofline']; print({k:r[k] for k in ('frac','achieved','traffic','avg_launch_ms','computed_frac','useful_over_computed','k_myers_ck','k_rcwalk4')})
+r=d['roofline']; print({k:r[k] for k in ('frac','achieved','traffic','avg_launch_ms','computed_frac','useful_over_computed','k_myers_ck','k_rcwalk2')})
 print(d.get('roofline_index'))
 print(d['widened_paths'].get('oc2asmpm'))
 print(d['widened_paths'].get('oc2cns_program'))
