@@ -23,7 +23,9 @@ for case in range(n_cases):
     if knobs:
         krng = np.random.default_rng(77 + seed0 + case)
         env = {"NECAT_BAND_POOL_MB": str(int(krng.choice([4, 16, 64, 16384]))), "NECAT_BATCH": str(int(krng.choice([192, 1024, 786432]))),
-               "NECAT_SEED_BUDGET": str(int(krng.choice([20000, 200000, 48000000]))), "NECAT_SINGLE_PASS": str(int(krng.choice([0, 64, 4096])))}
+               "NECAT_SEED_BUDGET": str(int(krng.choice([20000, 200000, 48000000]))), "NECAT_SINGLE_PASS": str(int(krng.choice([0, 64, 4096]))),
+               "NECAT_RC_POOL_MB": str(int(krng.choice([1, 8, 2048]))), "NECAT_RCWALK": str(int(krng.choice([1, 512, 4096]))), "NECAT_TAIL_FUSED": str(int(krng.choice([0, 512]))),
+               "NECAT_RC_LISTB": str(int(krng.choice([0, 1, 1]))), "NECAT_RC_RAGGED": str(int(krng.choice([0, 1, 1])))}
         os.environ.update(env)
         if ctx is not None:
             ctx.close()
