@@ -578,7 +578,7 @@ def roofline_report(agg):
     OPS_PER_WORD_UPDATE 32-bit lane-ops against the chip's full-rate 32-bit VALU peak (256 CU x 4 SIMD-32 x 2.4 GHz).  `achieved` counts
     only the ALGORITHMIC word updates - what the reference's banded passes compute: 6.25 of 8 words per SHW column and 1.91 words per NW
     column (measured there) - `computed_frac` the updates actually executed.  The dominant kernels are the two that run the
-    full 512 x 512 blocks of the big rounds (necat_amd/csrc/ext_rcwalk.h): k_myers_ck (SHW pass of every word + checkpoints + the words' horizontal deltas) and k_rcwalk2
+    full 512 x 512 blocks of every round above 512 blocks (necat_amd/csrc/ext_rcwalk.h): k_myers_ck (SHW pass of every word + checkpoints + the words' horizontal deltas) and k_rcwalk2
     (the walk, which recomputes the cells it stands on: no NW pass, no band records in HBM); taken together, since a block needs both."""
     peak_tops = VALU_LANE_OPS_PER_S / 1e12
     rc_ms = agg["rc_ck_ms"] + agg["rc_ms"]
@@ -609,7 +609,7 @@ def roofline_report(agg):
                 pass
     words, band = float(agg["words"]), float(agg["band_words"])
     all_ms = agg["myers_ms"] + agg["rc_ms"] + agg["fused_ms"]
-    return {"bound": "valu", "kernel": "k_myers_ck<8,16,true> + k_rcwalk2<8,16,1024> (the full 512 x 512 blocks of the big rounds: SHW with checkpoints and horizontal deltas, then the walk that recomputes the two words it stands on)",
+    return {"bound": "valu", "kernel": "k_myers_ck<8,16,true> + k_rcwalk2<8,16,1024> (the full 512 x 512 blocks of every round above 512 blocks - 85 % of all block alignments: SHW with checkpoints and horizontal deltas, then the walk that recomputes the two words it stands on; launch averages are over big and small rounds alike)",
             "achieved": round(achieved_tops, 3), "peak": round(peak_tops, 2), "unit": "T lane-op/s (32-bit VALU)", "frac": round(achieved_tops / peak_tops, 4),
             "traffic": traffic,
             "launches": int(agg["rc_launches"]), "avg_launch_ms": {"k_myers_ck": round(agg["rc_ck_ms"] / launches, 4), "k_rcwalk2": round(agg["rc_ms"] / launches, 4)},

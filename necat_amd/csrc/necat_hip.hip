@@ -25,6 +25,7 @@
 #include "pair_sched.h"
 
 using namespace necat;
+static_assert(SC_COUNT <= (int)(sizeof(necat_ctx::scratch) / sizeof(necat::DevBuf)), "a ScratchId without an arena");
 
 namespace {
 

@@ -41,7 +41,7 @@ struct necat_ctx {
     void* round_ring = nullptr;        // pinned, device-visible ring of RoundPub entries: list sizes published by the round kernels
     void* round_ring_dev = nullptr;    // the same memory as the device addresses it
     unsigned long long round_seq = 0;  // rounds published so far (the next round publishes round_seq + 1)
-    necat::DevBuf scratch[48];         // grow-only arenas, indexed by purpose (ScratchId)
+    necat::DevBuf scratch[48];         // grow-only arenas, indexed by purpose (ScratchId; SC_COUNT <= 48)
     void* seed_ht_ptr = nullptr;       // the seeding hash arena (SC_SEED_HT) whose first seed_ht_clean bytes are known to be all-empty (0xFF):
     size_t seed_ht_clean = 0;          // every call leaves the arena as it found it (k_seed_clear resets the slots it used), so it is filled once per allocation
     char devname[256] = {0};
@@ -105,7 +105,7 @@ inline int buf_ensure(necat_ctx* ctx, DevBuf& b, size_t bytes)
         if (hipMemGetInfo(&fr, &tot) != hipSuccess) fr = tot = 0;
         char own[512]; int at = 0; size_t sum = 0;          // this context's arenas of 256 MB and more (ScratchId : MB)
         own[0] = 0;
-        if (ctx) for (int i = 0; i < 48; ++i) {
+        if (ctx) for (int i = 0; i < (int)(sizeof ctx->scratch / sizeof ctx->scratch[0]); ++i) {
             sum += ctx->scratch[i].cap;
             if (ctx->scratch[i].cap >= ((size_t)256 << 20) && at < 480) at += snprintf(own + at, sizeof own - (size_t)at, " %d:%zu", i, ctx->scratch[i].cap >> 20);
         }
