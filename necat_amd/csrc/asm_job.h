@@ -147,6 +147,8 @@ inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const 
                 mappers[tid].plan(votes, opt.num_candidates, fwd.data(), L, subject_of, planned[r]);
             });
         }
+        const double t_plan = now_sec() - t0;
+        double t_dev = 0, t_fin = 0;
         // phases B and C over runs of reads whose anchors fit one call (the aligner keeps every anchor's columns: read + subject bytes each)
         std::vector<std::vector<necat_m4>> recs(nreads);
         std::vector<asmpm::BatchMapper> mappers((size_t)nthreads);
@@ -173,8 +175,11 @@ inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const 
                 }
             }
             necat_alignment* aln = nullptr; uint8_t* cols = nullptr; uint64_t* cols_off = nullptr;
+            const double tb = now_sec();
             if (necat_asm_align_batch(ctx, ref, reads, read_start, ref_start, anchors.data(), anchors.size(), 0.5 /* hbn_align.c:8 */, 400 /* asm_pm_common.c:354 */,
                                       &aln, &cols, &cols_off)) { status = fail("necat_asm_align_batch", necat_last_error(ctx)); }
+            const double tc = now_sec();
+            t_dev += tc - tb;
             // phase C: end extension, records
             if (!status) {
                 asm_parallel(r1 - r0, nthreads, [&](uint64_t k0, unsigned tid) {
@@ -202,6 +207,7 @@ inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const 
                     for (necat_m4& m : recs[r]) m.sid += ref_start;
                 });
             }
+            t_fin += now_sec() - tc;
             necat_free(aln); necat_free(cols); necat_free(cols_off);
             r0 = r1;
         }
@@ -225,6 +231,8 @@ inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const 
         }
         if (reads != ref) necat_volume_free(ctx, reads);
         H.reads = nullptr;
+        if (getenv("NECAT_CLI_TRACE")) fprintf(stderr, "[oc2asmpm] %s: votes + ranges %.2f s, block aligner calls %.2f s, end extension + records %.2f s (%d host threads)\n", job, t_plan,
+                                                t_dev, t_fin, nthreads);
         if (!status) log_line("[%s] INFO: '%s' takes %.2lf secs.\n", job, now_sec() - t0);
     }
     H.out = nullptr;                  // closed here: the guard only cleans up after an early return
