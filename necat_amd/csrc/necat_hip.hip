@@ -75,7 +75,7 @@ size_t g_band_pool;    // NECAT_BAND_POOL_MB (default 16384): cap of one band-re
 int g_walk;            // NECAT_WALK=0: k_traceback runs the reference formulation of the walk (A/B measurements)
 u32 g_tail_fused;      // NECAT_TAIL_FUSED (default 512 = one workgroup per block at 2 per CU; 0 = off): lists of at most this many blocks run as ONE launch per round with the band in LDS (ext_tail.h)
 u32 g_rcwalk;          // NECAT_RCWALK (default 512 = every list the one-launch tail kernel does not take; 0 = off): list-A rounds of more than this many blocks run through k_myers_ck / k_myers_ckg + k_rcwalk2 (ext_rcwalk.h: no NW pass, no band records, the walk recomputes its cells)
-size_t g_rc_pool;      // NECAT_RC_POOL_MB (default 2048): cap of the checkpoint buffer of those rounds; a longer list goes through it in several launches
+size_t g_rc_pool;      // NECAT_RC_POOL_MB (default 8192 = 1.6 M list-A blocks per launch; a 0.6 Gbp volume: 182 -> 174 ms per pass against 2048): cap of the checkpoint buffer of those rounds; a longer list goes through it in several launches
 u32 g_asm_rc;          // NECAT_ASM_RC (default 1): the 2048-bp block aligner of oc2asmpm through k_myers_ckg + k_rcwalk2 (no NW pass, no band records); 0 = two-pass kernel + band + wave walk
 u32 g_rc_listb;        // NECAT_RC_LISTB (default 1, needs NECAT_RC_CARRY): list B (blocks up to 794 x 794) through k_myers_ckg + k_rcwalk2 too; 0 = two-pass kernel + band pool + walk
 u32 g_rc_ragged;       // NECAT_RC_RAGGED (default 1, needs NECAT_RC_CARRY): the ragged blocks of those rounds through k_myers_ckg + k_rcwalk2 as well (0: two-pass kernel + lane walk on a stream of their own)
@@ -100,7 +100,7 @@ void read_knobs()
     g_asm_rc = (u32)num("NECAT_ASM_RC", 1);
     g_rc_listb = g_rc_carry ? (u32)num("NECAT_RC_LISTB", 1) : 0u;
     g_rc_ragged = g_rc_carry ? (u32)num("NECAT_RC_RAGGED", 1) : 0u;
-    g_rc_pool = (size_t)std::max<unsigned long long>(1, num("NECAT_RC_POOL_MB", 2048)) << 20;
+    g_rc_pool = (size_t)std::max<unsigned long long>(1, num("NECAT_RC_POOL_MB", 8192)) << 20;
     g_rc_maxdist = (int)num("NECAT_RC_MAXDIST", g_rc_carry ? 1 << 20 : kRcMaxDist);
     if (!g_rc_carry) g_rc_maxdist = std::min(g_rc_maxdist, kRcMaxDist);
     g_batch_cap = (u32)std::max<unsigned long long>(64, num("NECAT_BATCH", 786432));
