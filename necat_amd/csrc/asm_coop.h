@@ -48,7 +48,7 @@ k_asm_init(const AsmAnchor* __restrict__ anchors, u32 n, const u64* __restrict__
         go = ext_plan<kAsmBlock>(t);
         tasks[i] = t;
     }
-    ext_append_block<kAsmBlock, false>(t, i, go, L);
+    ext_append_block_wg<kAsmBlock, false, 4>(t, i, go, L);
 }
 
 }  // namespace necat

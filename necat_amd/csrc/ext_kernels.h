@@ -131,6 +131,39 @@ NECAT_D void ext_append_block(const ExtTask& t, u32 ti, bool go, const ExtLists&
     }
 }
 
+// The same for a workgroup of WAVES waves whose every thread calls it: ONE atomic per workgroup and list (the list counters are
+// three addresses the whole grid reserves its slots at - 3 k waves x 2 - 3 atomics in a row on them was the finishing kernel's time).
+template <int BLOCK, bool ONE_LIST, int WAVES>
+NECAT_D void ext_append_block_wg(const ExtTask& t, u32 ti, bool go, const ExtLists& L)
+{
+    __shared__ u32 wcnt[3][WAVES];
+    __shared__ u32 wbase[3];
+    const bool isA = !ONE_LIST && go && t.qblk <= BLOCK && t.tblk <= BLOCK;
+    const bool isB = go && !isA;
+    const bool isF = isA && t.qblk == BLOCK && t.tblk == BLOCK;
+    const bool isP = isA && !isF;
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    const u64 below = (1ULL << lane) - 1ULL;
+    const u64 mF = __ballot(isF), mP = __ballot(isP), mB = __ballot(isB);
+    if (lane == 0) { wcnt[0][wave] = (u32)popc64(mF); wcnt[1][wave] = (u32)popc64(mP); wcnt[2][wave] = (u32)popc64(mB); }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        u32 tot = 0;
+        for (int w = 0; w < WAVES; ++w) tot += wcnt[threadIdx.x][w];
+        wbase[threadIdx.x] = tot ? atomicAdd(&L.count[threadIdx.x == 0 ? 0 : threadIdx.x == 1 ? 2 : 1], tot) : 0u;
+    }
+    __syncthreads();
+    u32 baseF = wbase[0], baseP = wbase[1], baseB = wbase[2];
+    for (int w = 0; w < wave; ++w) { baseF += wcnt[0][w]; baseP += wcnt[1][w]; baseB += wcnt[2][w]; }
+    if (go) {
+        BlockItem it;
+        it.g = ext_frag_geom(t); it.task = (i32)ti; it.qn = (i16)t.qblk; it.tn = (i16)t.tblk;
+        if (isF) L.itemsA[baseF + (u32)popc64(mF & below)] = it;
+        else if (isP) L.itemsA[L.capA - 1u - (baseP + (u32)popc64(mP & below))] = it;
+        else L.itemsB[baseB + (u32)popc64(mB & below)] = it;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_ext_init(const necat_candidate* __restrict__ cands, u32 n, u32 cand_base, int read_start_id, int ref_start_id,
            const u64* __restrict__ reads_off, const u64* __restrict__ ref_off, ExtTask* __restrict__ tasks, ExtLists L,
@@ -154,7 +187,7 @@ k_ext_init(const necat_candidate* __restrict__ cands, u32 n, u32 cand_base, int 
         go = ext_plan(t);          // first block (or an immediately finished candidate)
         tasks[i] = t;
     }
-    ext_append_block(t, i, go, L);
+    ext_append_block_wg<kOcaBlockSize, false, 4>(t, i, go, L);      // (256 threads: one reservation per workgroup and list)
 }
 
 // ---- batch order: with several batches the candidates are dealt out by expected chain length (what is left of the two reads beyond
@@ -835,28 +868,31 @@ struct SameReader {   // query fragment element i == target fragment element i ?
 // EXPORT = false: fold the block into its ExtTask.  EXPORT = true (batch API): keep the ops.
 // WALK: 0 = traceback_block (the reference formulation, the default), 1 = walk_block, 2 = walk_block without record prefetch
 // (a template parameter, not a run-time switch: the two walks in one kernel cost the faster one its registers)
-template <int NW, int TW, int COLS, int MAXOPS, bool EXPORT, int WALK = 0, int BLOCK = kOcaBlockSize, bool ONE_LIST = false>
-__global__ void __launch_bounds__(64)
+// WAVES: waves per workgroup (1, or 4 for the finishing launches of the big lists: one reservation per workgroup and list, ext_append_block_wg)
+template <int NW, int TW, int COLS, int MAXOPS, bool EXPORT, int WALK = 0, int BLOCK = kOcaBlockSize, bool ONE_LIST = false, int WAVES = 1>
+__global__ void __launch_bounds__(64 * WAVES)
 k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, const char* __restrict__ slabs, size_t slab_bytes,
             const BlockResult* __restrict__ results, u8* __restrict__ ops_pool, ExtTask* __restrict__ tasks, int tail_match_len,
             i32* __restrict__ n_ops_out, int* __restrict__ err_flag, ExtLists next, u32 epoch, u32 item_base = 0, const WalkOut* __restrict__ wout = nullptr)
 {
     constexpr int FW = 2 * NW + TW;
     const ListView lv = list_view(n_host, n_dev, capA);
-    const u32 grp = blockIdx.x + (item_base >> 6);      // item_base: a multiple of 64 (a list handled in several launches: bounded band pool)
-    const int lane = threadIdx.x;
+    const u32 grp = blockIdx.x * WAVES + (threadIdx.x >> 6) + (item_base >> 6);      // item_base: a multiple of 64 (a list handled in several launches: bounded band pool)
+    const int lane = threadIdx.x & 63;
     const u64 item = (u64)grp * 64 + lane;
     BlockItem it;
-    if (!list_item(lv, items, item, it)) return;
+    ExtTask t;
+    // (every thread reaches the list append below: the workgroup form of it has barriers)
+    auto block_of_lane = [&]() -> bool {
+    if (!list_item(lv, items, item, it)) return false;
     const BlockResult br = results[item];
     // WALK == 5: the walks were done by k_rcwalk4 (the wide blocks it left out are walked by an `only wide` launch: epoch bit 25)
     // (epoch bit 27: every block of the list, not only the full ones at the front of a two-ended list A)
-    if (WALK == 5 && ((item >= lv.nf && !((epoch >> 27) & 1u)) || (br.words & kWideFlag))) return;
-    if (WALK != 5 && ((epoch >> 26) & 1u) && item < lv.nf16) return;
-    if (WALK != 5 && (((epoch >> 25) & 1u) || (((epoch >> 24) & 1u) && item < lv.nf16)) && !(br.words & kWideFlag)) return;
+    if (WALK == 5 && ((item >= lv.nf && !((epoch >> 27) & 1u)) || (br.words & kWideFlag))) return false;
+    if (WALK != 5 && ((epoch >> 26) & 1u) && item < lv.nf16) return false;
+    if (WALK != 5 && (((epoch >> 25) & 1u) || (((epoch >> 24) & 1u) && item < lv.nf16)) && !(br.words & kWideFlag)) return false;
     if (br.err) atomicExch(err_flag, 10 + br.err);
     OpsWriter ow; ow.ops = ops_pool + (size_t)grp * MAXOPS * 64 + lane; ow.cap = MAXOPS; ow.overflow = 0; ow.store = true;
-    ExtTask t;
     int done = 0;
     if (!EXPORT) {
         t = tasks[it.task];
@@ -885,7 +921,7 @@ k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
         }
         if (ow.overflow) atomicExch(err_flag, 20);
     }
-    if (EXPORT) { n_ops_out[item] = ow.ts.n; return; }
+    if (EXPORT) { n_ops_out[item] = ow.ts.n; return false; }
     OpsReader rd; rd.ops = ow.ops;
     SameReader<NW> same; same.fr = frag + (u64)grp * FW * 64 + lane;
     const int stream_at = t.phase == 1 ? t.s_lto : 0;     // where the block's stream starts in the task's column region
@@ -923,9 +959,14 @@ k_traceback(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
         }
         if (sh) reg[w] = acc;                                   // the bits above `sh` are zero: the next block ORs into them
     }
-    const bool go = ext_plan<BLOCK>(t);       // schedule the candidate's next block for the next round (or finish it)
+    const bool go_ = ext_plan<BLOCK>(t);      // schedule the candidate's next block for the next round (or finish it)
     tasks[it.task] = t;
-    ext_append_block<BLOCK, ONE_LIST>(t, (u32)it.task, go, next);
+    return go_;
+    };
+    const bool go = block_of_lane();
+    if (EXPORT) return;
+    if (WAVES > 1) ext_append_block_wg<BLOCK, ONE_LIST, WAVES>(t, go ? (u32)it.task : 0u, go, next);
+    else ext_append_block<BLOCK, ONE_LIST>(t, go ? (u32)it.task : 0u, go, next);
 }
 
 // ---- final records: pm_worker.c:56-80 (M4 fields), oc_aligner.c:419-450 (coordinates, identity) ----

@@ -1158,7 +1158,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                                    (const u64*)hcar, (const BlockResult*)c.resB[slot], (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsB[slot], wo, X.stats, X.d_err, fl, lo, hi);
                 NECAT_CHECK_LAUNCH(ctx, "k_myers_ckg / k_rcwalk2<B>");
             }
-            hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false, 5>), dim3(gB), dim3(64), 0, sb, itB, nB, d_nB, 0u, (const u64*)c.fragB[slot], (const char*)nullptr, (size_t)0,
+            hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, false, 5, kOcaBlockSize, false, 4>), dim3((gB + 3) / 4), dim3(256), 0, sb, itB, nB, d_nB, 0u, (const u64*)c.fragB[slot], (const char*)nullptr, (size_t)0,
                                (const BlockResult*)c.resB[slot], c.opsB[slot], c.tasks, X.tail_match_len, (i32*)nullptr, X.d_err, next, fl, 0u, (const WalkOut*)wo);
             NECAT_CHECK_LAUNCH(ctx, "k_traceback<B, rc>");
             NECAT_HIP(ctx, hipEventRecord(c.b2[slot], sb));
@@ -1349,7 +1349,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
             if (!g_rc_ragged || wide_possible) NECAT_HIP(ctx, hipEventRecord(ctx->ev[25], sd));
             if (g_rc_ragged && one_chunk) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, ctx->ev[30], 0));       // the ragged blocks are walked
             rc_round.push_back(r);
-            hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, 5>), dim3(gA), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap,
+            hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, 5, kOcaBlockSize, false, 4>), dim3((gA + 3) / 4), dim3(256), 0, c.sa, itA, bound, d_nA, c.cap,
                                (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
                                (i32*)nullptr, X.d_err, next, fl_all, 0u, (const WalkOut*)wo);
             NECAT_CHECK_LAUNCH(ctx, "k_traceback<A, rc>");
@@ -1848,7 +1848,7 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
                     NECAT_CHECK_LAUNCH(ctx, "k_myers_ckg / k_rcwalk2<asm A>");
                 }
                 NECAT_HIP(ctx, hipEventRecord(ctx->ev[3], s));
-                hipLaunchKernelGGL((k_traceback<kAsmWordsA, kAsmTWordsA, kAsmBlock, kAsmOpsA, false, 5, kAsmBlock>), dim3(gA), dim3(64), 0, s,
+                hipLaunchKernelGGL((k_traceback<kAsmWordsA, kAsmTWordsA, kAsmBlock, kAsmOpsA, false, 5, kAsmBlock, false, 4>), dim3((gA + 3) / 4), dim3(256), 0, s,
                                    (const BlockItem*)d_itemsA[cur], boundA, d_nA, cap, (const u64*)d_frag, (const char*)nullptr, (size_t)0,
                                    (const BlockResult*)d_res, d_ops, d_tasks, 8 /* kMatchCnt2: the tail match length of hbn_align */, (i32*)nullptr, d_err, next, fl, 0u, (const WalkOut*)d_wout);
                 NECAT_CHECK_LAUNCH(ctx, "k_traceback<asm A, rc>");
@@ -1896,7 +1896,7 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
                     NECAT_CHECK_LAUNCH(ctx, "k_myers_ckg / k_rcwalk2<asm B>");
                 }
                 NECAT_HIP(ctx, hipEventRecord(ctx->ev[37], sB));
-                hipLaunchKernelGGL((k_traceback<kAsmWords, kAsmTWords, kAsmCols, kAsmMaxOps, false, 5, kAsmBlock>), dim3(gB), dim3(64), 0, sB,
+                hipLaunchKernelGGL((k_traceback<kAsmWords, kAsmTWords, kAsmCols, kAsmMaxOps, false, 5, kAsmBlock, false, 4>), dim3((gB + 3) / 4), dim3(256), 0, sB,
                                    (const BlockItem*)d_itemsB[cur], nB, (const u32*)nullptr, 0u, (const u64*)d_fragB, (const char*)nullptr, (size_t)0,
                                    (const BlockResult*)d_resB, d_opsB, d_tasks, 8, (i32*)nullptr, d_err, next, fl, 0u, (const WalkOut*)d_woutB);
                 NECAT_CHECK_LAUNCH(ctx, "k_traceback<asm B, rc>");
