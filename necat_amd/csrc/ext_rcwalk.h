@@ -120,8 +120,15 @@ k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u
         BlockResult br; br.dist = err ? -1 : best; br.endc = end0; br.err = err;
         br.words = (u32)(NW * N) | ((best > max_dist && !err) ? kWideFlag : 0u);      // max_dist <= kRcMaxDist (smaller in tests: more blocks take the old path)
         results[item] = br;
-        atomicAdd(&stats[0], (unsigned long long)(NW * N)); atomicAdd(&stats[1], (unsigned long long)(2 * N));
-        if (br.dist >= 0 && !(br.words & kWideFlag)) atomicAdd(&stats[3], 1ULL);          // blocks k_rcwalk4 will walk
+    }
+    // the work counters once per wave (its 8 blocks together): they are three words of ONE cache line, and 3 atomics per block were 580 k
+    // same-line atomics per launch of a big round
+    const bool owner = b == G - 1 && valid;
+    const u64 m_all = __ballot(owner), m_walk = __ballot(owner && best >= 0 && !err && !(best > max_dist));
+    if (lane == 0 && m_all) {
+        const unsigned long long nb = (unsigned long long)popc64(m_all);
+        atomicAdd(&stats[0], nb * (unsigned long long)(NW * N)); atomicAdd(&stats[1], nb * (unsigned long long)(2 * N));
+        if (m_walk) atomicAdd(&stats[3], (unsigned long long)popc64(m_walk));           // blocks the recomputing walk will take
     }
 }
 
@@ -365,7 +372,11 @@ k_myers_ckg(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
         BlockResult br; br.dist = err ? -1 : best; br.endc = end0; br.err = err;
         br.words = (u32)(nblk * tn);
         results[item] = br;
-        atomicAdd(&stats[0], (unsigned long long)br.words); atomicAdd(&stats[1], (unsigned long long)(qn + tn));
+    }
+    {   // the work counters once per wave
+        unsigned long long w = is_last ? (unsigned long long)(nblk * tn) : 0ULL, bs = is_last ? (unsigned long long)(qn + tn) : 0ULL;
+        for (int o = 32; o > 0; o >>= 1) { w += __shfl_xor(w, o); bs += __shfl_xor(bs, o); }
+        if (lane == 0 && w) { atomicAdd(&stats[0], w); atomicAdd(&stats[1], bs); }
     }
 }
 
