@@ -17,7 +17,7 @@
 
 namespace necat {
 
-constexpr int kPosPerThread = 8;
+constexpr int kPosPerThread = 16;
 constexpr int kScanTile = 2048;     // entries per block in the table scan (256 threads x 8)
 
 NECAT_D u64 kmer_hash_at(const u64* bases, i64 g, int k)
@@ -106,7 +106,8 @@ k_part_hist(DevVolume vol, int k, int shift, u32 nb, u32 b_lo, u32 b_hi, u32* __
 // first sorted by part in LDS writes runs of consecutive records from consecutive lanes instead.  So the 12 partition bits are
 // split 6 + 6 (k_split_bases: volume -> coarse buckets; k_split_recs: coarse -> fine buckets), and k_subpart (the next 6 bits)
 // scatters through the same staging.  The order of the records inside a part is free (k_slice_emit ranks by offset).
-constexpr int kSplitTile = 2048;                  // records per tile = kPosPerThread per thread of a 256-thread block
+constexpr int kSplitTile = 4096;                  // records per tile = kPosPerThread per thread of a 256-thread block (2048: 6.2 ms for the whole build, 4096: 5.6, 8192: 5.9 -
+                                                  // a tile reserves its space with up to 64 atomics on 64 cursors the whole grid shares)
 constexpr int kSplitPer = kSplitTile / 256;
 constexpr int kCurStride = 16;                   // the 64 coarse cursors of k_split_bases sit on their own 128-byte lines: every block bumps all of them
 static_assert(kSplitPer == kPosPerThread, "a thread of k_split_bases hashes the positions of one tile slot");
