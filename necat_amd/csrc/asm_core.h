@@ -280,6 +280,46 @@ inline void find_kmer_match(const std::vector<KmerInfo>& q, const std::vector<Km
         if (qi >= qn || ti >= tn) break;
     }
 }
+// The same matches through a hash of the SECOND list's groups (built once per read: the read is the second sequence of every candidate's
+// call, asm_pm_common.c:375-383): a probe per group of the first list instead of a merge over both - the read's list has one entry per base
+// (window 1), six times the subject's.  The matches come out in another order; extend_kmer_match sorts them (mem_before is a total order).
+struct KmifIndex {
+    std::vector<uint64_t> key; std::vector<uint32_t> at;      // open addressing, linear probing: key = hash + 1 (0 = empty), at = first entry of the group
+    uint32_t mask = 0;
+    void build(const std::vector<KmerInfo>& a)
+    {
+        size_t groups = 0;
+        for (size_t i = 0; i < a.size(); i += (size_t)a[i].occ) ++groups;
+        uint32_t cap = 64;
+        while (cap < 2 * groups + 2) cap <<= 1;
+        mask = cap - 1;
+        key.assign(cap, 0); at.assign(cap, 0);
+        for (size_t i = 0; i < a.size(); i += (size_t)a[i].occ) {
+            uint32_t p = (uint32_t)((a[i].hash * 0x9E3779B97F4A7C15ULL) >> 40) & mask;
+            while (key[p]) p = (p + 1) & mask;
+            key[p] = a[i].hash + 1; at[p] = (uint32_t)i;
+        }
+    }
+    // index of the group of `hash` in the list the index was built from, or -1
+    long find(uint64_t hash) const
+    {
+        uint32_t p = (uint32_t)((hash * 0x9E3779B97F4A7C15ULL) >> 40) & mask;
+        for (;;) { const uint64_t k = key[p]; if (!k) return -1; if (k == hash + 1) return (long)at[p]; p = (p + 1) & mask; }
+    }
+};
+inline void find_kmer_match_indexed(const std::vector<KmerInfo>& q, const std::vector<KmerInfo>& t, const KmifIndex& tix, int kmer, int max_occ, std::vector<Mem>& out)
+{
+    out.clear();
+    if (q.empty() || t.empty()) return;
+    for (size_t qi = 0; qi < q.size(); qi += (size_t)q[qi].occ) {
+        if (q[qi].occ > max_occ) continue;
+        const long ti = tix.find(q[qi].hash);
+        if (ti < 0) continue;
+        const int to = t[(size_t)ti].occ;
+        if (to > max_occ || q[qi].occ * to > max_occ) continue;
+        for (int i = 0; i < q[qi].occ; ++i) for (int j = 0; j < to; ++j) out.push_back(Mem{kmer, q[qi + (size_t)i].offset, t[(size_t)ti + (size_t)j].offset});
+    }
+}
 // extend_kmer_match (:173-220)
 inline void extend_kmer_match(std::vector<Mem>& a, const uint8_t* q, int qsize, const uint8_t* t, int tsize, int min_mem)
 {
@@ -399,11 +439,12 @@ struct RangeFinder {
     std::vector<KmerInfo> first_kmif;
     std::vector<Mem> mems;
     bool go(const uint8_t* first, int first_size, const uint8_t* second, int second_size, const std::vector<KmerInfo>& second_kmif, int kmer, int window,
-            int min_mem, ChainRange* out)
+            int min_mem, ChainRange* out, const KmifIndex* second_index = nullptr)
     {
         build_kmif(first, (size_t)first_size, kmer, window, first_kmif);
         sort_kmif(first_kmif);
-        find_kmer_match(first_kmif, second_kmif, kmer, 20, mems);
+        if (second_index) find_kmer_match_indexed(first_kmif, second_kmif, *second_index, kmer, 20, mems);
+        else find_kmer_match(first_kmif, second_kmif, kmer, 20, mems);
         extend_kmer_match(mems, first, first_size, second, second_size, min_mem);
         std::sort(mems.begin(), mems.end(), mem_before);
         return chain.best(mems.data(), (int)mems.size(), out);
@@ -544,6 +585,7 @@ struct BatchMapper {
     RangeFinder range;
     Extender ext;
     std::vector<KmerInfo> read_kmif;
+    KmifIndex read_index;
     std::vector<uint8_t> subject;
 
     void plan(std::vector<VoteCandidate>& cands, int num_extended, const uint8_t* fwd_read, int read_size,
@@ -553,6 +595,7 @@ struct BatchMapper {
         std::sort(cands.begin(), cands.end(), vote_before);
         build_kmif(fwd_read, (size_t)read_size, 10, 1, read_kmif);
         sort_kmif(read_kmif);
+        read_index.build(read_kmif);
         const size_t first = out.size();
         for (size_t i = 0; i < cands.size() && (int)i < num_extended; ++i) {
             const int sid = cands[i].target_id, sdir = cands[i].chain;
@@ -563,7 +606,7 @@ struct BatchMapper {
             ChainRange r;
             Planned p;
             p.sid = sid; p.sdir = sdir; p.ssize = (int)subject.size(); p.qoff = p.soff = -1; p.score = 0;        // qoff < 0: no chain, nothing to align
-            if (range.go(subject.data(), p.ssize, fwd_read, read_size, read_kmif, 10, 6, 15, &r)) { p.qoff = r.soff; p.soff = r.qoff; p.score = r.score; }
+            if (range.go(subject.data(), p.ssize, fwd_read, read_size, read_kmif, 10, 6, 15, &r, &read_index)) { p.qoff = r.soff; p.soff = r.qoff; p.score = r.score; }
             out.push_back(p);
         }
     }
