@@ -524,4 +524,174 @@ k_rcwalk2(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict
 }
 
 
+// k_rcwalk2 with the walk taken off the quads.  In k_rcwalk2 the four lanes of a quad recompute together and then all four
+// run the SAME walk: 16 distinct walks on 64 lanes.  Here a workgroup is four waves = 64 blocks: every wave recomputes the two-word window of
+// its 16 blocks exactly as k_rcwalk2 does (quad = block, 2 words x 2 half-segments), the slices of all 64 blocks land in LDS ([column][block],
+// 32 KB: the same 512 bytes per block in flight), and ONE wave walks all 64 blocks, a lane each - the walk's instructions are issued once per 64
+// blocks instead of once per 16, and the three other waves wait at the barrier without taking issue slots.  Which wave walks is a hash of the
+// workgroup's index, so that the walkers of the workgroups resident on a CU spread over its SIMDs.  The walker hands (r, c, done, all done) of
+// every block back through the block's own column-0 slice (the quad that reads it is the only writer of that block's slices: no third barrier).
+template <int NW, int TW, int COLS, int MAXOPS>
+__global__ void __launch_bounds__(256)
+k_rcwalk2w(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, const ulonglong2* __restrict__ ckpt,
+           const u64* __restrict__ hcar, const BlockResult* __restrict__ results, const ExtTask* __restrict__ tasks, int keep_cols, int tail_match_len, u8* __restrict__ ops_pool,
+           WalkOut* __restrict__ wout, unsigned long long* __restrict__ stats, int* __restrict__ err_flag, u32 epoch, u32 lo, u32 hi)
+{
+    constexpr int FW = 2 * NW + TW, SEG = kRcSeg, HALF = SEG / 2, CK = RcGeom<COLS>::kCk, SEGS = RcGeom<COLS>::kSeg;
+    static_assert(COLS < 4096, "the hand-over word keeps r and c in 12 bits each");
+    __shared__ ulonglong2 slices[SEG][64];
+    const ListView lv = list_view(n_host, n_dev, capA);
+    const bool all = ((epoch >> 27) & 1u) != 0, ragged = ((epoch >> 26) & 1u) != 0;
+    const u64 first = (u64)lo + (u64)blockIdx.x * 64, lim = (all || ragged) ? lv.n : lv.nf, end = lim < hi ? lim : hi;
+    if (first >= end || (ragged && first + 64 <= (u64)lv.nf16)) return;
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int q = lane >> 2, j = lane & 3, k = j & 1, h = j >> 1;
+    const int rbk = 16 * wave + q;                                    // the block this lane's quad recomputes
+    const u64 grp = first >> 6;                                       // the 64 work indices of the workgroup are one 64-item group
+    const bool walker = wave == (int)((blockIdx.x * 0x9E3779B1u) >> 30);
+    auto usable = [&](u64 item, BlockItem& it) { return item < end && !(ragged && item < (u64)lv.nf16) && list_item(lv, items, item, it); };
+    // ---- the recomputing role: block rbk
+    const u64 item = first + (u64)rbk;
+    const u64* fr = frag + grp * FW * 64 + rbk;
+    int r = 0, c = -1;
+    bool fin = true;
+    {
+        BlockItem it0;
+        if (usable(item, it0)) {
+            const BlockResult br = results[item];
+            if (!(br.words & kWideFlag) && br.dist >= 0) { fin = false; r = it0.qn - 1; c = br.endc; }
+        }
+    }
+    // ---- the walking role (every wave sets it up - the loop's first test needs every block's state - only the walker's is used after that)
+    const u64 witem = first + (u64)lane;
+    int wr = 0, wc = -1;
+    bool wfin = true, store = false;
+    int mlen = kOcaMatCnt;
+    {
+        BlockItem it0;
+        if (usable(witem, it0)) {
+            const BlockResult br = results[witem];
+            if (!(br.words & kWideFlag) && br.dist >= 0) {
+                wfin = false; wr = it0.qn - 1; wc = br.endc;
+                if (tasks) { const ExtTask& t = tasks[it0.task]; store = keep_cols || !t.found; if (t.last) mlen = tail_match_len; }
+                else store = true;
+            }
+        }
+    }
+    bool all_fin = __all(wfin);
+    int n = 0, nmat = 0, m = 0, hit = 0, nq = 0, nt = 0, acnt = 0, qcnt = 0, tcnt = 0, mcnt = 0;
+    u8* const ops = ops_pool + (size_t)grp * MAXOPS * 64 + lane;
+    int wcur = -1; u32 nlo_l = 0, nlo_h = 0, nhi_l = 0, nhi_h = 0;
+    int segcur = -1; u32 tlo = 0, thi = 0;
+    u32 words_done = 0;
+    while (!all_fin) {
+        {   // ---- recompute (k_rcwalk2's, with q -> rbk in the slices)
+            const int seg = c >> 5, c0 = seg * SEG;
+            const int rb = r - 63, sh = rb & 63, w1 = r >> 6;
+            const int w = w1 - 1 + k;
+            const int nc0 = c - c0 - HALF * h + 1;
+            const int nc = (fin || w < 0 || nc0 < 0) ? 0 : (nc0 > HALF ? HALF : nc0);
+            const bool live = nc > 0;
+            if (live && w != wcur) {
+                const u64 a = fr[(u64)w * 64], bq = fr[(u64)(NW + w) * 64];
+                nlo_l = (u32)a; nlo_h = (u32)(a >> 32); nhi_l = (u32)bq; nhi_h = (u32)(bq >> 32); wcur = w;
+            }
+            FastWord wd; wd.Pv = ~0ULL; wd.Mv = 0ULL; wd.pubP = 0x80000000u; wd.pubM = 0u;
+            const int slot = 2 * seg + h - 1;
+            if (live && slot >= 0) { const ulonglong2 v = ckpt[((size_t)(item - lo) * CK + (size_t)slot) * NW + (size_t)w]; wd.Pv = v.x; wd.Mv = v.y; }
+            u32 hp = 0xffffffffu, hm = 0u;
+            if (live && k == 0 && w > 0) { const u64 v = hcar[((size_t)(item - lo) * SEGS + (size_t)seg) * NW + (size_t)(w - 1)]; hp = (u32)v; hm = (u32)(v >> 32); }
+            if (!fin && seg != segcur) {
+                const u64 x = fr[(u64)(2 * NW + seg) * 64];
+                tlo = (u32)even_bits(x); thi = (u32)even_bits(x >> 1); segcur = seg;
+            }
+            hp <<= HALF * h; hm <<= HALF * h;
+            for (int s = 0; s < HALF + 1; ++s) {
+                const u32 xp = dpp_quad_from_below(wd.pubP), xm = dpp_quad_from_below(wd.pubM);
+                const int cl = s - k;
+                if ((u32)cl < (u32)nc) {
+                    const int ci = HALF * h + cl;
+                    const u32 cph = k ? xp : hp << cl, cmh = k ? xm : hm << cl;
+                    const u32 ma = (u32)__builtin_amdgcn_sbfe((int)tlo, (u32)ci, 1u), mb = (u32)__builtin_amdgcn_sbfe((int)thi, (u32)ci, 1u);
+                    const u32 el = bop<0x60>(nlo_l ^ ma, nhi_l, mb), eh = bop<0x60>(nlo_h ^ ma, nhi_h, mb);
+                    u32 phh, mhh; u64 rA, rB;
+                    fast_advance<true>(wd, el, eh, cph, cmh, 0u, phh, mhh, rA, rB);
+                    ++words_done;
+                    if (k == 0) { if (sh) slices[ci][rbk] = make_ulonglong2(rA >> sh, rB >> sh); }
+                    else if (!sh) slices[ci][rbk] = make_ulonglong2(rA, rB);
+                    else {
+                        const u64 pa = rA << (64 - sh), pb = rB << (64 - sh);
+                        if (w == 0) slices[ci][rbk] = make_ulonglong2(pa, pb);
+                        else {
+                            unsigned long long* dst = reinterpret_cast<unsigned long long*>(&slices[ci][rbk]);
+                            __hip_atomic_fetch_or(dst, pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_fetch_or(dst + 1, pb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (walker) {
+            // ---- the walk of block `lane` (walk_block of dp_core.h on the slices): the lean form once no block of the workgroup is before its
+            // run of matches or keeps its ops
+            const int c0 = (wc >> 5) * SEG, rb = wr - 63;
+            const bool lean = !__any(!wfin && (!hit || store));
+            bool out = false;
+            if (!wfin) {
+                if (lean) {
+                    for (;;) {
+                        if (wc < c0 || wr < rb) break;
+                        const ulonglong2 v = slices[wc - c0][lane];
+                        const int bit = wr - rb;
+                        const u32 a = (u32)(v.x >> bit) & 1u, b = (u32)(v.y >> bit) & 1u;
+                        const int drow = 1 - (int)(b & (a ^ 1u)), dcol = 1 - (int)(a & (b ^ 1u));
+                        ++n; nmat += (int)((a | b) ^ 1u);
+                        wr -= drow; wc -= dcol;
+                        if ((wr | wc) < 0) { out = true; break; }
+                    }
+                } else {
+                    for (;;) {
+                        if (wc < c0 || wr < rb) break;
+                        const ulonglong2 v = slices[wc - c0][lane];
+                        const int bit = wr - rb;
+                        const u32 a = (u32)(v.x >> bit) & 1u, b = (u32)(v.y >> bit) & 1u;
+                        const int op = (int)(a | (b << 1));
+                        const int drow = 1 - (int)(b & (a ^ 1u)), dcol = 1 - (int)(a & (b ^ 1u));
+                        const int mt = (int)((a | b) ^ 1u);
+                        if (store) { if (n < MAXOPS) ops[(size_t)n * 64] = (u8)op; else atomicExch(err_flag, 20); }
+                        ++n; nmat += mt;
+                        if (!hit) {
+                            nq += drow; nt += dcol;
+                            m = mt ? m + 1 : 0;
+                            if (m == mlen) { hit = 1; acnt = n; qcnt = nq; tcnt = nt; mcnt = nmat; }
+                        }
+                        wr -= drow; wc -= dcol;
+                        if ((wr | wc) < 0) { out = true; break; }
+                    }
+                }
+            }
+            if (out) {
+                const int kop = wc < 0 ? 1 : 2, kk = wc < 0 ? wr + 1 : wc + 1;
+                if (store) for (int i = 0; i < kk; ++i) { if (n + i < MAXOPS) ops[(size_t)(n + i) * 64] = (u8)kop; else atomicExch(err_flag, 20); }
+                n += kk;
+                if (!hit && kk > 0) m = 0;
+                wfin = true;
+                WalkOut o; o.n = n; o.nmat = nmat; o.m = m; o.hit = hit; o.acnt = acnt; o.qcnt = qcnt; o.tcnt = tcnt; o.mcnt = mcnt; wout[witem] = o;
+            }
+            const u32 word = wfin ? (1u << 24) : ((u32)wr | ((u32)wc << 12));
+            reinterpret_cast<u32*>(&slices[0][lane])[0] = word | (__all(wfin) ? 1u << 25 : 0u);
+        }
+        __syncthreads();
+        {
+            const u32 word = reinterpret_cast<const u32*>(&slices[0][rbk])[0];
+            fin = (word >> 24) & 1u; all_fin = (word >> 25) & 1u;
+            r = (int)(word & 0xfffu); c = (int)((word >> 12) & 0xfffu);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) words_done += (u32)__shfl_xor((int)words_done, o);
+    if (lane == 0 && words_done) { atomicAdd(&stats[0], (unsigned long long)words_done); atomicAdd(&stats[4], (unsigned long long)words_done); }
+}
+
+
 }  // namespace necat

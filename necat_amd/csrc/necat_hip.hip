@@ -79,11 +79,20 @@ size_t g_rc_pool;      // NECAT_RC_POOL_MB (default 8192 = 1.6 M list-A blocks p
 u32 g_asm_rc;          // NECAT_ASM_RC (default 1): the 2048-bp block aligner of oc2asmpm through k_myers_ckg + k_rcwalk2 (no NW pass, no band records); 0 = two-pass kernel + band + wave walk
 u32 g_rc_listb;        // NECAT_RC_LISTB (default 1, needs NECAT_RC_CARRY): list B (blocks up to 794 x 794) through k_myers_ckg + k_rcwalk2 too; 0 = two-pass kernel + band pool + walk
 u32 g_rc_ragged;       // NECAT_RC_RAGGED (default 1, needs NECAT_RC_CARRY): the ragged blocks of those rounds through k_myers_ckg + k_rcwalk2 as well (0: two-pass kernel + lane walk on a stream of their own)
+u32 g_rc_ww;           // NECAT_RC_WW (default 1): the recompute walk as k_rcwalk2w - four waves recompute 64 blocks, ONE wave walks them, a lane each; 0 = k_rcwalk2 (every lane of a quad walks its block)
 u32 g_rc_carry;        // NECAT_RC_CARRY (default 1): the recompute walk on an exact two-word window (k_myers_ck<CARRY> keeps the words' horizontal deltas, k_rcwalk2); 0 = the 4-word band window (k_rcwalk4)
 int g_rc_maxdist;      // NECAT_RC_MAXDIST (default and maximum kRcMaxDist = 160): full blocks of a larger distance take the old kernels (tests lower it)
 u32 g_walk_wave;       // NECAT_WALK_WAVE (default 12288; 0 = off): lists of at most this many blocks are walked by one WAVE per block through an LDS window (k_walk_wave, ext_tail.h)
 int g_asm_lane;        // NECAT_ASM_LANE=1: necat_asm_align_batch through the lane-per-alignment kernel (k_asm_align), the second implementation
 int g_dbg;             // NECAT_DBG: profiling-only variants of the lane-per-block DP kernel (1 = no band stores, 2 = no NW pass)
+
+// the recompute walk of a list of `nitems` work indices: one workgroup of four waves per 64 blocks (k_rcwalk2w) or one wave per 16 (k_rcwalk2)
+template <int NW, int TW, int COLS, int MAXOPS, class... A>
+static void launch_rcwalk2(u32 nitems, hipStream_t s, A... a)
+{
+    if (g_rc_ww) hipLaunchKernelGGL((k_rcwalk2w<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(256), 0, s, a...);
+    else hipLaunchKernelGGL((k_rcwalk2<NW, TW, COLS, MAXOPS>), dim3((nitems + 15) / 16), dim3(64), 0, s, a...);
+}
 
 // Tuning / test knobs: process-wide, (re)read from the environment whenever a context is created, defaults otherwise.
 void read_knobs()
@@ -98,6 +107,7 @@ void read_knobs()
     g_rcwalk = (u32)num("NECAT_RCWALK", 512);
     g_rc_carry = (u32)num("NECAT_RC_CARRY", 1);
     g_asm_rc = (u32)num("NECAT_ASM_RC", 1);
+    g_rc_ww = (u32)num("NECAT_RC_WW", 1);
     g_rc_listb = g_rc_carry ? (u32)num("NECAT_RC_LISTB", 1) : 0u;
     g_rc_ragged = g_rc_carry ? (u32)num("NECAT_RC_RAGGED", 1) : 0u;
     g_rc_pool = (size_t)std::max<unsigned long long>(1, num("NECAT_RC_POOL_MB", 8192)) << 20;
@@ -1154,7 +1164,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                 hipLaunchKernelGGL((k_myers_ckg<kWordsB, kTWordsB, kColsB, 16>), dim3((cn + 3) / 4), dim3(64), 0, sb, itB, nB, d_nB, 0u, (const u64*)c.fragB[slot], ck, hcar, X.error,
                                    c.resB[slot], X.stats, epoch, lo, hi);
                 if (lo + rc_chunk >= nB) NECAT_HIP(ctx, hipEventRecord(c.b1[slot], sb));
-                hipLaunchKernelGGL((k_rcwalk2<kWordsB, kTWordsB, kColsB, kOpsB>), dim3((cn + 15) / 16), dim3(64), 0, sb, itB, nB, d_nB, 0u, (const u64*)c.fragB[slot], (const ulonglong2*)ck,
+                launch_rcwalk2<kWordsB, kTWordsB, kColsB, kOpsB>(cn, sb, itB, nB, d_nB, 0u, (const u64*)c.fragB[slot], (const ulonglong2*)ck,
                                    (const u64*)hcar, (const BlockResult*)c.resB[slot], (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsB[slot], wo, X.stats, X.d_err, fl, lo, hi);
                 NECAT_CHECK_LAUNCH(ctx, "k_myers_ckg / k_rcwalk2<B>");
             }
@@ -1320,7 +1330,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                     hipLaunchKernelGGL((k_myers_ckg<kWordsA, kTWordsA, kColsA, 8>), dim3((cn + 7) / 8), dim3(64), 0, sr, itA, bound, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error,
                                        c.resA, X.stats, ckg_all ? epoch : fl_rag, lo, hi);
                     if (one_chunk) {       // .. and their walk there too: the full blocks' walk need not wait for this pass (as long as the full blocks' own)
-                        hipLaunchKernelGGL((k_rcwalk2<kWordsA, kTWordsA, kColsA, kOpsA>), dim3((cn + 15) / 16), dim3(64), 0, sd, itA, bound, d_nA, c.cap, (const u64*)c.fragA, (const ulonglong2*)ck,
+                        launch_rcwalk2<kWordsA, kTWordsA, kColsA, kOpsA>(cn, sd, itA, bound, d_nA, c.cap, (const u64*)c.fragA, (const ulonglong2*)ck,
                                            (const u64*)hcar, (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsA, wo, X.stats, X.d_err, fl_rag, lo, hi);
                         NECAT_HIP(ctx, hipEventRecord(ctx->ev[30], sd));
                     }
@@ -1328,7 +1338,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                 NECAT_CHECK_LAUNCH(ctx, "k_myers_ck");
                 if (last) NECAT_HIP(ctx, hipEventRecord(c.a1[cur], c.sa));
                 if (g_rc_carry)
-                    hipLaunchKernelGGL((k_rcwalk2<kWordsA, kTWordsA, kColsA, kOpsA>), dim3((cn + 15) / 16), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap, (const u64*)c.fragA, (const ulonglong2*)ck,
+                    launch_rcwalk2<kWordsA, kTWordsA, kColsA, kOpsA>(cn, c.sa, itA, bound, d_nA, c.cap, (const u64*)c.fragA, (const ulonglong2*)ck,
                                        (const u64*)hcar, (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsA, wo, X.stats, X.d_err,
                                        (g_rc_ragged && one_chunk) ? epoch : fl_all, lo, hi);
                 else
@@ -1843,7 +1853,7 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
                     const u32 hi = std::min<u64>((u64)lo + rc_chunkA, (u64)gA * 64), cn = hi - lo;
                     hipLaunchKernelGGL((k_myers_ckg<kAsmWordsA, kAsmTWordsA, kAsmBlock, 32>), dim3((cn + 1) / 2), dim3(64), 0, s, (const BlockItem*)d_itemsA[cur], boundA, d_nA, cap,
                                        (const u64*)d_frag, rc_ck, rc_hcA, error, d_res, d_stats, epoch, lo, hi);
-                    hipLaunchKernelGGL((k_rcwalk2<kAsmWordsA, kAsmTWordsA, kAsmBlock, kAsmOpsA>), dim3((cn + 15) / 16), dim3(64), 0, s, (const BlockItem*)d_itemsA[cur], boundA, d_nA, cap,
+                    launch_rcwalk2<kAsmWordsA, kAsmTWordsA, kAsmBlock, kAsmOpsA>(cn, s, (const BlockItem*)d_itemsA[cur], boundA, d_nA, cap,
                                        (const u64*)d_frag, (const ulonglong2*)rc_ck, (const u64*)rc_hcA, (const BlockResult*)d_res, (const ExtTask*)d_tasks, 1, 8, d_ops, d_wout, d_stats, d_err, fl, lo, hi);
                     NECAT_CHECK_LAUNCH(ctx, "k_myers_ckg / k_rcwalk2<asm A>");
                 }
@@ -1891,7 +1901,7 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
                     const u32 hi = std::min<u64>((u64)lo + rc_chunkB, (u64)gB * 64), cn = std::min(hi, nB) - lo;
                     hipLaunchKernelGGL((k_myers_ckg<kAsmWords, kAsmTWords, kAsmCols, 64>), dim3(cn), dim3(64), 0, sB, (const BlockItem*)d_itemsB[cur], nB, (const u32*)nullptr, 0u,
                                        (const u64*)d_fragB, rc_ckB, rc_hcB, error, d_resB, d_stats, epoch, lo, hi);
-                    hipLaunchKernelGGL((k_rcwalk2<kAsmWords, kAsmTWords, kAsmCols, kAsmMaxOps>), dim3((cn + 15) / 16), dim3(64), 0, sB, (const BlockItem*)d_itemsB[cur], nB, (const u32*)nullptr, 0u,
+                    launch_rcwalk2<kAsmWords, kAsmTWords, kAsmCols, kAsmMaxOps>(cn, sB, (const BlockItem*)d_itemsB[cur], nB, (const u32*)nullptr, 0u,
                                        (const u64*)d_fragB, (const ulonglong2*)rc_ckB, (const u64*)rc_hcB, (const BlockResult*)d_resB, (const ExtTask*)d_tasks, 1, 8, d_opsB, d_woutB, d_stats, d_err, fl, lo, hi);
                     NECAT_CHECK_LAUNCH(ctx, "k_myers_ckg / k_rcwalk2<asm B>");
                 }
@@ -2786,7 +2796,7 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
                     hipLaunchKernelGGL((k_myers_ckg<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag, ck, hcar, error,
                                        d_res, d_stats, epoch, 0u, g * 64);
                     NECAT_HIP(ctx, hipEventRecord(ctx->ev[5], s));
-                    hipLaunchKernelGGL((k_rcwalk2<kWordsA, kTWordsA, kColsA, kOpsA>), dim3((m + 15) / 16), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag,
+                    launch_rcwalk2<kWordsA, kTWordsA, kColsA, kOpsA>(m, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag,
                                        (const ulonglong2*)ck, (const u64*)hcar, (const BlockResult*)d_res, (const ExtTask*)nullptr, 1, 1, d_ops, wo, d_stats, d_err, fl, 0u, g * 64);
                     hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, true, 5>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag,
                                        (const char*)d_slabs, slab, (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), fl, 0u, (const WalkOut*)wo);
@@ -2798,7 +2808,7 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
                     hipLaunchKernelGGL((k_myers_ckg<kWordsB, kTWordsB, kColsB, 16>), dim3((m + 3) / 4), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag, ck, hcar, error,
                                        d_res, d_stats, epoch, 0u, g * 64);
                     NECAT_HIP(ctx, hipEventRecord(ctx->ev[5], s));
-                    hipLaunchKernelGGL((k_rcwalk2<kWordsB, kTWordsB, kColsB, kOpsB>), dim3((m + 15) / 16), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag,
+                    launch_rcwalk2<kWordsB, kTWordsB, kColsB, kOpsB>(m, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag,
                                        (const ulonglong2*)ck, (const u64*)hcar, (const BlockResult*)d_res, (const ExtTask*)nullptr, 1, 1, d_ops, wo, d_stats, d_err, fl, 0u, g * 64);
                     hipLaunchKernelGGL((k_traceback<kWordsB, kTWordsB, kColsB, kOpsB, true, 5>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag,
                                        (const char*)d_slabs, slab, (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), fl, 0u, (const WalkOut*)wo);

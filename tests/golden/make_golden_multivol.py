@@ -6,7 +6,13 @@ offsets, 32-bit slot counts and the candidate batch cap matter).
 Run in the build container (needs oracle/_ref/oc2pmov = the reference compiled from /root/reference by oracle/Makefile;
 ~30 GB of RAM for the 1 Gbp volume's k = 15 table + offset list + sort buffer; about half an hour on 8 cores):
 
-    python tests/golden/make_golden_multivol.py [threads]      -> tests/golden/multivol_full_reference.json
+    python tests/golden/make_golden_multivol.py [threads]                 -> tests/golden/multivol_full_reference.json
+    python tests/golden/make_golden_multivol.py [threads] drosophila      -> tests/golden/drosophila_full_reference.json
+
+`drosophila` is BASELINE.json configs[3] at its real size: a 140 Mb genome x 40 = 5.6 Gbp cut by oc2mkdb's own rule (a volume
+is closed once it holds >= 2 000 000 000 bases, makedb/main.c:8,29) into volumes of 2.0 / 2.0 / 1.6 Gbp - six (reference,
+query) pairs; ~41 GB of RAM for a 2 Gbp volume's k = 15 table (8.6 GB) + offset list (16 GB) + sort buffer (16 GB), about
+two hours on 6 threads.
 
 The dataset is the seeded synthetic one of necat_amd/synth.py (regenerated on the GPU box by the test and fingerprinted by
 `reads_md5`), cut into three volumes of UNEQUAL size (synth.write_volume_dir_cuts).  What is committed is data only: per
@@ -30,11 +36,15 @@ sys.path.insert(0, ROOT)
 from necat_amd import synth                      # noqa: E402
 from oracle import oracle_api as ora             # noqa: E402
 
-CFG = dict(genome=37_000_000, coverage=40.0, seed=31, err=0.12, cuts=[1_050_000_000, 300_000_000],
+CFGS = {}
+CFGS["multivol"] = dict(genome=37_000_000, coverage=40.0, seed=31, err=0.12, cuts=[1_050_000_000, 300_000_000],
            flags="-k 15 -z 20 -q 500 -b 2000 -s 3 -n 500 -a 1000 -d 0.25 -e 0.5 -m 500")
+CFGS["drosophila"] = dict(genome=140_000_000, coverage=40.0, seed=41, err=0.12, cuts=[2_000_000_000, 2_000_000_000],
+                          flags="-k 15 -z 20 -q 500 -b 2000 -s 3 -n 500 -a 1000 -d 0.25 -e 0.5 -m 500")
 
 
-def main(threads: int) -> None:
+def main(threads: int, name: str = "multivol") -> None:
+    CFG = CFGS[name]
     t0 = time.time()
     rs = synth.simulate_reads(CFG["genome"], CFG["coverage"], seed=CFG["seed"], err=CFG["err"])
     print("%d reads / %d bp generated in %.0f s" % (rs.nreads, rs.nbases, time.time() - t0), flush=True)
@@ -79,11 +89,11 @@ def main(threads: int) -> None:
     out["m4_records"] = len(all_m4)
     out["m4_text_sorted_md5"] = hashlib.md5(b"".join(all_m4)).hexdigest()
     shutil.rmtree(tmp, ignore_errors=True)
-    path = os.path.join(ROOT, "tests", "golden", "multivol_full_reference.json")
+    path = os.path.join(ROOT, "tests", "golden", "%s_full_reference.json" % name)
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", path, flush=True)
 
 
 if __name__ == "__main__":
-    main(int(sys.argv[1]) if len(sys.argv) > 1 else (os.cpu_count() or 1))
+    main(int(sys.argv[1]) if len(sys.argv) > 1 else (os.cpu_count() or 1), sys.argv[2] if len(sys.argv) > 2 else "multivol")

@@ -129,14 +129,19 @@ def _random_pairs(rng, n, qlo, qhi, err):
     return np.concatenate(seqs), qo, ql, to, tl
 
 
-@pytest.mark.parametrize("path", ["band", "recompute"])
+@pytest.mark.parametrize("path", ["band", "recompute", "recompute_quad"])
 def test_edlib_blocks_match_oracle(ctx, monkeypatch, path):
     """The dominant kernel in isolation: distance, end column and the full edit path, including
     ragged sizes (1..794), failures (too divergent) and exact 512 x 512 blocks (the FULL kernel).
     band: DP passes + band records + walk; recompute: checkpoint pass + the walk that recomputes its cells (ext_rcwalk.h: k_myers_ckg,
-    k_rcwalk2) at both geometries (8 words / 13 words per block)."""
-    if path == "recompute":
+    k_rcwalk2w: four waves recompute 64 blocks, one wave walks them) at both geometries (8 words / 13 words per block); recompute_quad:
+    the same through k_rcwalk2 (every quad recomputes and walks its own block, NECAT_RC_WW=0)."""
+    if path != "band":
         monkeypatch.setenv("NECAT_BATCH_RC", "1")
+    if path == "recompute_quad":
+        from necat_amd import capi
+        monkeypatch.setenv("NECAT_RC_WW", "0")
+        capi.Context(0).close()          # knobs are process-wide and read when a context is created
     rng = np.random.default_rng(2024)
     seqs, qo, ql, to, tl = _random_pairs(rng, 300, 1, 794, 0.15)
     # query much longer than the target: distance >= |q| - |t| > k = 0.55 * min(|q|, |t|) -> Edlib_align fails
@@ -180,6 +185,10 @@ def test_edlib_blocks_match_oracle(ctx, monkeypatch, path):
     assert nfail >= 40 and nfail < len(qo) // 2
     tm = ctx.timings()
     assert tm.myers_word_updates > 0
+    if path == "recompute_quad":
+        from necat_amd import capi
+        monkeypatch.undo()
+        capi.Context(0).close()          # back to the defaults for the tests that follow
 
 
 def test_empty_and_tiny_inputs(ctx, tmp_path):
@@ -466,7 +475,8 @@ def test_capped_band_pool_runs_lists_in_chunks(ctx, small, tmp_path, monkeypatch
                                   "NECAT_RCWALK=0", "NECAT_RCWALK=1 NECAT_TAIL_FUSED=0 NECAT_WALK_WAVE=0", "NECAT_RCWALK=1 NECAT_RC_MAXDIST=90 NECAT_TAIL_FUSED=0",
                                   "NECAT_RCWALK=1 NECAT_RC_CARRY=0 NECAT_TAIL_FUSED=0", "NECAT_RCWALK=1 NECAT_RC_CARRY=0 NECAT_RC_MAXDIST=90",
                                   "NECAT_RCWALK=1 NECAT_RC_POOL_MB=1", "NECAT_RCWALK=1 NECAT_RC_RAGGED=0 NECAT_TAIL_FUSED=0",
-                                  "NECAT_RC_LISTB=0", "NECAT_RC_LISTB=1 NECAT_TAIL_FUSED=0 NECAT_RC_POOL_MB=1"])
+                                  "NECAT_RC_LISTB=0", "NECAT_RC_LISTB=1 NECAT_TAIL_FUSED=0 NECAT_RC_POOL_MB=1",
+                                  "NECAT_RC_WW=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0"])
 def test_alternative_kernel_paths_give_the_same_records(ctx, small, monkeypatch, knob):
     """Code paths kept behind a knob (the lane-0 chain DP, the 16-block / 4-lane NW kernel, the restated walk, the general DP
     path without the full-block fast path, lane-per-strand seed collection, every round / no round through the one-launch
@@ -487,6 +497,8 @@ def test_alternative_kernel_paths_give_the_same_records(ctx, small, monkeypatch,
         _, m_got = capi.pm_main(c, o1, 0, d)
     finally:
         c.close()
+        monkeypatch.undo()
+        capi.Context(0).close()          # the knobs are process-wide: back to the defaults for the tests that follow
     assert c_got.tobytes() == c_base.tobytes() and c_base.shape[0] > 500
     assert util.m4_key_rows(m_got) == util.m4_key_rows(m_base) and m_base.shape[0] > 500
 
