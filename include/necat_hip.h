@@ -234,6 +234,16 @@ int  necat_asm_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_
                            const necat_asm_anchor* anchors, uint64_t n, double error, int min_align_size,
                            necat_alignment** aln, uint8_t** ops, uint64_t** ops_off);
 
+/* oc2asmpm's candidate stage for all reads of a volume at once (asm_pm/asm_pm_common.c): the 1000-bp block vote of both strands of every read
+ * (pairwise_mapping :509-702, find_location :479-507), the per-read order and cut (AsmGappedCandidate_ScoreGT :145-153, the first -n candidates,
+ * extend_candidates :329-345) and, for every distinct (subject, strand) among those in that order, the chained range of compute_align_range_1
+ * (asm_pm/find_mem.c:222-265: 10-mer matches -> maximal exact matches -> mem_find_best_can, asm_pm/km_chain.c:322-445).  opt: kmer_size (the index's),
+ * scan_window (BC), num_candidates.  out[first[r] .. first[r + 1]): read r's entries in the walk's order; ids global; qoff (forward read) / soff (on
+ * strand sdir of the subject) = the anchor, score = the chain's score; qoff < 0: no chain of score >= 100, nothing to align.  Both arrays: necat_free. */
+typedef struct { int32_t qid, sid, sdir, qoff, soff, score, ssize; } necat_asm_plan;
+int  necat_asm_plan_batch(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, const necat_volume* reads, int read_start_id, int ref_start_id,
+                          const necat_map_options* opt, necat_asm_plan** out, uint64_t** first);
+
 /* Host helper: expand `n` packed columns into query_align / target_align (each n bytes, no terminator).
  * qseq / tseq: byte codes 0..3 of the query STRAND (reverse complement for qdir = 1) and of the subject;
  * qoff / toff: the alignment's start in them (necat_alignment.qoff / .toff).  Returns 0, or NECAT_ERR_ARG

@@ -81,7 +81,7 @@ class _CnsResult(C.Structure):
 EXPORTED_SYMBOLS = [
     "necat_default_options", "necat_ctx_create", "necat_ctx_destroy", "necat_ctx_trim", "necat_last_error", "necat_device_name",
     "necat_volume_upload", "necat_volume_pack", "necat_volume_free", "necat_index_build", "necat_index_size", "necat_index_download",
-    "necat_index_free", "necat_index_sparse_size", "necat_index_download_sparse", "necat_find_candidates", "necat_extend", "necat_map_pair", "necat_map_reference", "necat_onc_align_batch", "necat_asm_align_batch",
+    "necat_index_free", "necat_index_sparse_size", "necat_index_download_sparse", "necat_find_candidates", "necat_extend", "necat_map_pair", "necat_map_reference", "necat_onc_align_batch", "necat_asm_align_batch", "necat_asm_plan_batch",
     "necat_gapped_strings", "necat_cns_default_options", "necat_cns_load_partition", "necat_cns_extension_batch",
     "necat_cns_result_free",
     "necat_edlib_align_batch", "necat_get_timings", "necat_free", "necat_pcan_partition",
@@ -136,6 +136,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.necat_onc_align_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_uint64, C.POINTER(MapOptions), C.c_int,
                                           C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     lib.necat_asm_align_batch.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_uint64, C.c_double, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    lib.necat_asm_plan_batch.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp, C.POINTER(vp), C.POINTER(vp)]
     lib.necat_gapped_strings.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.c_uint64, vp, C.c_uint64, C.c_uint64, vp, vp]
     lib.necat_cns_default_options.argtypes = [C.POINTER(CnsOptions)]
     lib.necat_cns_default_options.restype = None

@@ -1,6 +1,7 @@
-// asm_job.h - one oc2asmpm job (asm_pm/asmpm.c:11-68): reference volume `vid` against the volumes vid .. V-1.  Per volume pair: the vote and the
-// chained range of every read on the host threads (asm_core.h; 4 % + 20 % of the reference's time), ALL anchors of the pair in one call of the
-// device's block aligner (necat_asm_align_batch; 74 %), then the end extension and the records on the host threads again.
+// asm_job.h - one oc2asmpm job (asm_pm/asmpm.c:11-68): reference volume `vid` against the volumes vid .. V-1.  Per volume pair: the block vote and the
+// chained range of every read on the device (necat_asm_plan_batch, asm_plan.h; 4 % + 20 % of the reference's time), ALL anchors of the pair in one
+// call of the device's block aligner (necat_asm_align_batch; 74 %), then DALIGNER's end extension and the records on the host threads
+// (asm_core.h Extender / BatchMapper::finish).
 #pragma once
 #include <atomic>
 #include <memory>
@@ -49,7 +50,10 @@ inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const 
     auto fail = [&](const char* what, const char* detail) { fprintf(stderr, "[%s] ERROR: %s: %s\n", tag, what, detail); return 1; };
     std::string err;
     HostVolume href;
+    const bool cli_trace = getenv("NECAT_CLI_TRACE") != nullptr;
+    const double t_job = now_sec();
     if (!load_volume(vi.names[vid].c_str(), &href, &err)) return fail("volume", err.c_str());
+    const double t_loaded = now_sec();
     // everything the job holds on the device / in files, released on every way out (the context may outlive a failed job)
     struct Held {
         necat_ctx* ctx; necat_volume* ref = nullptr; necat_volume* reads = nullptr; necat_index* ix = nullptr; FILE* out = nullptr; std::string tmp_out;
@@ -66,38 +70,10 @@ inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const 
     log_line("", "build_lookup_table");
     double t0 = now_sec();
     if (necat_index_build(ctx, ref, opt.kmer_size, opt.kmer_cnt_cutoff, &H.ix)) return fail("necat_index_build", necat_last_error(ctx));
-    // The vote reads the table on the host - in the layout the device built it in: the sparse one (k >= 11: one (bits, base) pair per 64
-    // table entries + the non-zero entries, 0.27 GB + 8 bytes per kept k-mer at k = 15) instead of the reference's dense kmer_stats
-    // (8.6 GB at k = 15, 1.7 s to download per job); the dense layout only for the small tables that are built dense.
-    uint64_t n_table = 0, n_offsets = 0, n_pairs = 0, n_compact = 0;
-    necat_index_size(H.ix, &n_table, &n_offsets);
-    necat_index_sparse_size(H.ix, &n_pairs, &n_compact);
-    // (not value-initialised: the downloads write all of them)
-    std::unique_ptr<uint64_t[]> kmer_stats, pairs, compact, offset_list(new uint64_t[n_offsets + 1]);
-    if (n_pairs) {
-        pairs.reset(new uint64_t[2 * n_pairs]); compact.reset(new uint64_t[n_compact + 1]);
-        if (necat_index_download_sparse(ctx, H.ix, pairs.get(), compact.get(), offset_list.get())) return fail("necat_index_download_sparse", necat_last_error(ctx));
-    } else {
-        kmer_stats.reset(new uint64_t[n_table + 1]);
-        if (necat_index_download(ctx, H.ix, kmer_stats.get(), offset_list.get())) return fail("necat_index_download", necat_last_error(ctx));
-    }
-    necat_index_free(ctx, H.ix); H.ix = nullptr;
     log_line("[%s] INFO: '%s' takes %.2lf secs.\n", "build_lookup_table", now_sec() - t0);
+    const double t_indexed = now_sec();
     HostCodes cref; cref.set(href);
-    std::vector<uint64_t> ref_off(href.offset.size() + 1, 0);
-    for (size_t i = 0; i < href.offset.size(); ++i) ref_off[i + 1] = href.offset[i] + href.size[i];
-    asmpm::RefView rv;
-    rv.seq_off = ref_off.data(); rv.nseq = href.offset.size();
-    rv.kmer_list = [&](uint64_t h, uint64_t* n) -> const uint64_t* {
-        uint64_t u;
-        if (pairs) {        // IndexView::lookup (dev_common.h) on the host copy
-            const uint64_t bits = pairs[2 * (h >> 6)], bit = 1ULL << (h & 63);
-            u = (bits & bit) ? compact[pairs[2 * (h >> 6) + 1] + (uint64_t)__builtin_popcountll(bits & (bit - 1))] : 0;
-        } else u = kmer_stats[h];
-        const uint64_t cnt = u >> 34, start = u & ((1ULL << 34) - 1);
-        *n = cnt;
-        return cnt ? offset_list.get() + start : nullptr;
-    };
+    if (cli_trace) fprintf(stderr, "[oc2asmpm] volume %d: read %.2f s, upload + index %.2f s, one-byte codes %.2f s\n", vid, t_loaded - t_job, t_indexed - t_loaded, now_sec() - t_indexed);
     auto subject_of = [&](int sid, int strand, std::vector<uint8_t>& s) { cref.strand((uint64_t)sid, strand, s); };
 
     H.tmp_out = std::string(output) + ".part";
@@ -128,24 +104,19 @@ inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const 
         necat_volume* const reads = H.reads;
         const int read_start = vi.read_start_id[i];
         const uint64_t nreads = hreads->offset.size();
-        // phase A: votes and ranges
+        // phase A: votes and chained ranges of every read of the volume, on the device (asm_plan.h)
         std::vector<std::vector<asmpm::Planned>> planned(nreads);
         {
-            std::vector<asmpm::Voter> voters((size_t)nthreads);
-            std::vector<asmpm::BatchMapper> mappers((size_t)nthreads);
-            std::vector<char> inited((size_t)nthreads, 0);
-            asm_parallel(nreads, nthreads, [&](uint64_t r, unsigned tid) {
-                if (!inited[tid]) { voters[tid].init(href.nbases); inited[tid] = 1; }
-                std::vector<uint8_t> fwd, rev;
-                crd->strand(r, 0, fwd); crd->strand(r, 1, rev);
-                const int L = (int)fwd.size(), gid = (int)r + read_start;
-                int64_t soff_max = INT32_MAX;
-                if (gid >= ref_start && gid < ref_start + (int)rv.nseq) soff_max = (int64_t)ref_off[(size_t)(gid - ref_start)];
-                std::vector<asmpm::VoteCandidate> votes;
-                voters[tid].strand(fwd.data(), L, 0, (int)r, gid, ref_start, rv, opt.kmer_size, opt.scan_window, soff_max, votes);
-                voters[tid].strand(rev.data(), L, 1, (int)r, gid, ref_start, rv, opt.kmer_size, opt.scan_window, soff_max, votes);
-                mappers[tid].plan(votes, opt.num_candidates, fwd.data(), L, subject_of, planned[r]);
-            });
+            necat_asm_plan* plans = nullptr; uint64_t* first = nullptr;
+            if (necat_asm_plan_batch(ctx, H.ix, ref, reads, read_start, ref_start, &opt, &plans, &first)) { status = fail("necat_asm_plan_batch", necat_last_error(ctx)); break; }
+            for (uint64_t r = 0; r < nreads; ++r) {
+                planned[r].resize((size_t)(first[r + 1] - first[r]));
+                for (uint64_t q = first[r]; q < first[r + 1]; ++q) {
+                    asmpm::Planned& p = planned[r][(size_t)(q - first[r])];
+                    p.sid = plans[q].sid - ref_start; p.sdir = plans[q].sdir; p.qoff = plans[q].qoff; p.soff = plans[q].soff; p.score = plans[q].score; p.ssize = plans[q].ssize;
+                }
+            }
+            necat_free(plans); necat_free(first);
         }
         const double t_plan = now_sec() - t0;
         double t_dev = 0, t_fin = 0;
@@ -211,6 +182,7 @@ inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const 
             necat_free(aln); necat_free(cols); necat_free(cols_off);
             r0 = r1;
         }
+        const double t_w0 = now_sec();
         if (!status) {
             std::vector<necat_m4> all;
             for (auto& v : recs) all.insert(all.end(), v.begin(), v.end());
@@ -231,8 +203,8 @@ inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const 
         }
         if (reads != ref) necat_volume_free(ctx, reads);
         H.reads = nullptr;
-        if (getenv("NECAT_CLI_TRACE")) fprintf(stderr, "[oc2asmpm] %s: votes + ranges %.2f s, block aligner calls %.2f s, end extension + records %.2f s (%d host threads)\n", job, t_plan,
-                                                t_dev, t_fin, nthreads);
+        if (cli_trace) fprintf(stderr, "[oc2asmpm] %s: votes + ranges (device) %.2f s, block aligner calls %.2f s, end extension + records %.2f s (%d host threads), output %.2f s\n", job, t_plan,
+                               t_dev, t_fin, nthreads, now_sec() - t_w0);
         if (!status) log_line("[%s] INFO: '%s' takes %.2lf secs.\n", job, now_sec() - t0);
     }
     H.out = nullptr;                  // closed here: the guard only cleans up after an early return

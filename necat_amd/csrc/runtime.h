@@ -41,7 +41,7 @@ struct necat_ctx {
     void* round_ring = nullptr;        // pinned, device-visible ring of RoundPub entries: list sizes published by the round kernels
     void* round_ring_dev = nullptr;    // the same memory as the device addresses it
     unsigned long long round_seq = 0;  // rounds published so far (the next round publishes round_seq + 1)
-    necat::DevBuf scratch[48];         // grow-only arenas, indexed by purpose (ScratchId; SC_COUNT <= 48)
+    necat::DevBuf scratch[64];         // grow-only arenas, indexed by purpose (ScratchId; SC_COUNT <= 64)
     void* seed_ht_ptr = nullptr;       // the seeding hash arena (SC_SEED_HT) whose first seed_ht_clean bytes are known to be all-empty (0xFF):
     size_t seed_ht_clean = 0;          // every call leaves the arena as it found it (k_seed_clear resets the slots it used), so it is filled once per allocation
     char devname[256] = {0};
@@ -140,6 +140,7 @@ enum ScratchId {
     SC_EXT_TASKS, SC_EXT_LISTS, SC_EXT_FRAG, SC_EXT_MAT, SC_EXT_OPS, SC_EXT_RES, SC_EXT_CAND, SC_SMALL, SC_PART,
     SC_EXT_COLS, SC_EXT_COLS_OUT, SC_PART2, SC_SEED_ALL, SC_EXT_MATB, SC_EXT_MATB2, SC_EXT_PERM, SC_GATHER, SC_SPLIT, SC_SPLIT2,
     SC_ASM_BAND, SC_ASM_OPS, SC_ASM_COLS, SC_ASM_MISC, SC_ASM_FRAG, SC_ASM_OUT, SC_SEED_KST, SC_EXT_CKPT, SC_EXT_WOUT, SC_EXT_CKPTB, SC_EXT_CKPTB2, SC_EXT_WOUTB, SC_EXT_WOUTB2,
+    SC_ASM_OCC, SC_ASM_TAB, SC_ASM_VMETA, SC_ASM_VHT, SC_ASM_VPOOL, SC_ASM_VOUT, SC_ASM_SEL, SC_ASM_RIDX, SC_ASM_RNEXT, SC_ASM_PAIRS, SC_ASM_SEEDS,
     SC_COUNT
 };
 
