@@ -64,9 +64,13 @@ def parse():
     ap.add_argument("--cpu-t1", action="store_true", help="also time the reference with -t 1 on the bench workload itself (minutes)")
     ap.add_argument("--cpu-t1-genome", type=int, default=460_000,
                     help="genome size of the reduced sample the reference's -t 1 leg runs on by default (SURVEY 8d asks for -t 1; at full size it takes minutes); 0 = no -t 1 leg")
-    ap.add_argument("--asmpm-genome", type=int, default=0,
+    ap.add_argument("--asmpm-genome", type=int, default=5_000_000,
                     help="also time the oc2asmpm program (SURVEY 8f.2) on corrected reads (3 %% errors) of a genome of this size x 20 against the "
-                         "reference's own program on the same host cores (widened_paths.oc2asmpm); 0 = skip (5 000 000 = 100 Mbp: minutes of CPU)")
+                         "reference's own program on the same host cores (widened_paths.oc2asmpm); 0 = skip (5 000 000 = 100 Mbp: ~ 25 s of the "
+                         "reference on 16 cores)")
+    ap.add_argument("--config2-genome", type=int, default=12_000_000,
+                    help="also time one step of BASELINE configs[2] (a genome of this size x 50, OVLP_SENSITIVE_OPTIONS -z 10) after the timed region "
+                         "(extra_configs.configs2_sensitive; parity at that size is tests/test_gpu_full_size.py); 0 = skip")
     ap.add_argument("--parallelism", choices=["single-volume", "volumes", "pairs"], default="single-volume",
                     help="N > 1: one volume on all GPUs (strong scaling, RCCL data path), one volume per GPU (weak), or the (reference, query) "
                          "volume pairs of a --volumes V project dealt to the GPUs by cost (strong)")
@@ -289,10 +293,45 @@ def widened_paths(ctx, vol, capi, opt_kw):
     return res
 
 
+def config2_step(ctx, capi, synth, args):
+    """BASELINE configs[2] - a 12 Mb genome x 50 (0.6 Gbp, one volume), OVLP_SENSITIVE_OPTIONS (-z 10) - as `ms_per_step` extras: the same pass as the
+    bench step (index -> candidates -> extension -> M4 on the host) on its own resident volume, 1 warm-up + 2 timed steps of -j 1 and of -j 0"""
+    rs2 = synth.simulate_reads(args.config2_genome, 50.0, seed=11)
+    vol2 = ctx.upload_volume(synth.pack_2bit(rs2.codes), rs2.nbases, rs2.offsets, rs2.sizes)
+    res = {"workload": "%.1f Mb genome x 50 synthetic ONT reads (%d reads, %d bp, 1 volume), OVLP_SENSITIVE_OPTIONS (-k %d -z 10 -q 500 -b 2000 -s 3 -n 500 -a 1000 -e 0.5)"
+                       % (args.config2_genome / 1e6, rs2.nreads, rs2.nbases, args.kmer)}
+    try:
+        for job in (1, 0):
+            o = capi.default_options(**dict(FAST, kmer_size=args.kmer, scan_window=10, job=job, num_threads=1))
+            n_rec = aligned = 0
+            t0 = 0.0
+            for it in range(3):
+                if it == 1:
+                    t0 = time.perf_counter()          # (every call returns with its records on the host: nothing in flight)
+                ix = ctx.build_index(vol2, o.kmer_size, o.kmer_cnt_cutoff)
+                if job == 1:
+                    m4, _ = ctx.map_pair(ix, vol2, vol2, 0, 0, o, True, 1)
+                    if it:
+                        n_rec += m4.shape[0]; aligned += int((m4["qend"] - m4["qoff"]).sum())
+                else:
+                    c = ctx.find_candidates(ix, vol2, vol2, 0, 0, o, True)
+                    if it:
+                        n_rec += c.shape[0]
+                ix.free()
+            dt = time.perf_counter() - t0
+            key = "m4_job1" if job == 1 else "candidates_job0"
+            res[key] = {"ms_per_step": round(1e3 * dt / 2, 2), "records_per_step": n_rec // 2, "overlaps_per_s": round(n_rec / dt, 1)}
+            if job == 1:
+                res[key]["gbp_aligned_per_s"] = round(aligned / dt / 1e9, 3)
+    finally:
+        vol2.free()
+    return res
+
+
 def oc2asmpm_program(genome, threads, tmp):
-    """oc2asmpm (the overlapper of corrected reads, necat.pl:573,880,1000,1152) as a program: this repo's (host vote + chained ranges, the
-    2048-bp block aligner on the device, host end extension) and the reference's own on the same host threads, same volume, same options
-    (ASM_OVLP_OPTIONS of necat.pl:36); the records must be the same"""
+    """oc2asmpm (the overlapper of corrected reads, necat.pl:573,880,1000,1152) as a program: this repo's (block vote + chained ranges on the
+    device, the 2048-bp block aligner on the device, DALIGNER's end extension on the host) and the reference's own on the same host threads,
+    same volume, same options (ASM_OVLP_OPTIONS of necat.pl:36); the records must be the same"""
     import re
     from necat_amd import build, synth
     from oracle import oracle_api as ora
@@ -304,10 +343,23 @@ def oc2asmpm_program(genome, threads, tmp):
     res = {"reads": rs.nreads, "bases": rs.nbases, "volumes": nv, "host_threads": threads, "options": " ".join(args)}
     mine = os.path.join(tmp, "asm_mine.m4")
     t0 = time.time()
-    r = subprocess.run([build.OC2ASMPM] + args + ["-t", str(threads), wrk, "0", mine], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, NECAT_TRACE="2"))
+    r = subprocess.run([build.OC2ASMPM] + args + ["-t", str(threads), wrk, "0", mine], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, NECAT_TRACE="2", NECAT_CLI_TRACE="1"))
     res["wall_s"] = round(time.time() - t0, 2)
     if r.returncode != 0:
         return dict(res, error=r.stderr[-300:])
+    plan = re.findall(r"asm plan: (\d+) reads, (\d+) planned pairs, (\d+) matches, ([0-9.]+) ms", r.stderr)
+    if plan:
+        res.update(planned_pairs=sum(int(p[1]) for p in plan), kmer_matches=sum(int(p[2]) for p in plan), plan_calls_ms=round(sum(float(p[3]) for p in plan), 2))
+    ph = re.findall(r"votes \+ ranges \(device\) ([0-9.]+) s, block aligner calls ([0-9.]+) s, end extension \+ records ([0-9.]+) s \((\d+) host threads\), output ([0-9.]+) s", r.stderr)
+    v0 = re.findall(r"volume \d+: read ([0-9.]+) s, upload \+ index ([0-9.]+) s, one-byte codes ([0-9.]+) s", r.stderr)
+    if ph:
+        host = sum(float(p[2]) + float(p[4]) for p in ph) + sum(float(q[0]) + float(q[2]) for q in v0)
+        res["phases_s"] = {"plan_calls": round(sum(float(p[0]) for p in ph), 2), "aligner_calls": round(sum(float(p[1]) for p in ph), 2),
+                           "end_extension_and_records_host": round(sum(float(p[2]) for p in ph), 2), "output_host": round(sum(float(p[4]) for p in ph), 2),
+                           "volume_read_and_codes_host": round(sum(float(q[0]) + float(q[2]) for q in v0), 2), "upload_and_index": round(sum(float(q[1]) for q in v0), 2)}
+        res["host_share"] = round(host / max(res["wall_s"], 1e-9), 3)
+        res["host_share_note"] = ("host phases (volume read, one-byte codes, end extension + records, output) / wall; the plan and aligner calls are device passes "
+                                  "with their host-side planning inside")
     calls = re.findall(r"asm_align \(cooperative\): (\d+) anchors, (\d+) rounds, (\d+) blocks, DP ([0-9.]+) ms, walk ([0-9.]+) ms, whole call ([0-9.]+) ms", r.stderr)
     res.update(records=sum(1 for _ in open(mine, "rb")), anchors=sum(int(c[0]) for c in calls), block_alignments=sum(int(c[2]) for c in calls),
                device_ms=round(sum(float(c[5]) for c in calls), 2), device_dp_ms=round(sum(float(c[3]) for c in calls), 2), device_walk_ms=round(sum(float(c[4]) for c in calls), 2))
@@ -534,7 +586,7 @@ def roofline_index(index_ms, nbases, k, n_offsets, n_distinct):
     alg = 2 * (N / 4) + 8 * T + 16 * N + 16 * T + 8 * N + 8 * M + 4 * 16 * M + 8 * M + 8 * float(n_distinct) + 16 * M
     achieved = alg / (index_ms * 1e-3) / 1e9 if index_ms > 0 else 0.0
     traffic = src = None
-    for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
+    for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
         pth = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(pth):
             continue
@@ -542,7 +594,7 @@ def roofline_index(index_ms, nbases, k, n_offsets, n_distinct):
             pmc = json.load(open(pth))
             tot = 0.0
             for kn, v in pmc.items():
-                if any(("necat::" + q) in kn for q in INDEX_KERNELS):
+                if isinstance(v, dict) and any(("necat::" + q) in kn for q in INDEX_KERNELS):
                     # per-launch averages x launches / builds: every build launches each kernel the same number of times
                     per_build = v.get("launches", 1) / max(1, pmc_builds(pmc))
                     tot += (2.0 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0 * per_build
@@ -551,8 +603,17 @@ def roofline_index(index_ms, nbases, k, n_offsets, n_distinct):
                 break
         except Exception:
             pass
+    # the second denominator: the bytes THIS build's passes have to move when every pass reads and writes its data exactly once:
+    # histogram N/4; three split levels N/4 + 8 N written, then 2 x (8 N read + 8 N written); slice count 8 N; slice emit 8 N read, the offset
+    # list (8 M), the non-zero table entries (8 distinct) and the sparse table words (16 B per 64 entries) written
+    D = float(n_distinct)
+    own = N / 4 + (N / 4 + 8 * N) + 2 * 16 * N + 8 * N + (8 * N + 8 * M + 8 * D + 16 * T / 64)
+    own_rate = own / (index_ms * 1e-3) / 1e9 if index_ms > 0 else 0.0
     return {"bound": "hbm", "kernels": "the index build: " + ", ".join(INDEX_KERNELS), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "algorithmic_bytes": round(alg), "ms": round(index_ms, 3),
+            "own_layout": {"bytes": round(own), "achieved": round(own_rate, 1), "frac": round(own_rate / HBM_PEAK_GBS, 4),
+                           "note": "bytes this build's own passes move at one read + one write each (sparse table, three 6-bit split levels): the fraction of the "
+                                   "HBM peak that is comparable across rounds of THIS design; `frac` above prices the reference's dense layout"},
             "traffic": traffic, "traffic_frac": round(traffic / (index_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and index_ms > 0 else None,
             "traffic_source": src,
             "note": "algorithmic bytes of the REFERENCE layout (dense 4^k table: 24 T of the bytes are table sweeps the sparse build never does), so frac can "
@@ -562,7 +623,7 @@ def roofline_index(index_ms, nbases, k, n_offsets, n_distinct):
 def pmc_builds(pmc):
     """index builds in a PMC profile = launches of k_slice_emit"""
     for kn, v in pmc.items():
-        if "k_slice_emit" in kn:
+        if isinstance(v, dict) and "k_slice_emit" in kn:
             return int(v.get("launches", 1))
     return 1
 
@@ -593,20 +654,28 @@ def roofline_report(agg):
     alg_per_launch = (2 * 512 / 4.0 + 16.0) * blocks / launches
     avg_pair_ms = rc_ms / launches
     achieved_hbm = alg_per_launch / (avg_pair_ms * 1e-3) / 1e9 if avg_pair_ms > 0 else 0.0
-    traffic = pmc_file = None
-    for name in ("r03_pmc_hbm_traffic.json",):
+    # HBM bytes per launch of the two kernels `frac` is about, each on its own: read from the newest kept rocprofv3 --pmc profile under profiles/
+    # (FETCH_SIZE counted twice per the guide's gfx950 correction + WRITE_SIZE), not measured in this run - `traffic_source` says which file and
+    # which commit's binary it was taken on
+    traffic = pmc_file = pmc_meta = None
+    for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json"):
         pth = os.path.join(ROOT, "profiles", name)
         if os.path.exists(pth):
             try:
                 pmc = json.load(open(pth))
-                tot = 0.0
+                per = {}
                 for kn, v in pmc.items():
-                    if "necat::k_myers_ck" in kn or "necat::k_rcwalk" in kn:
-                        tot += (2.0 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0
-                if tot > 0:
-                    traffic, pmc_file = tot, name
+                    if not isinstance(v, dict):
+                        continue
+                    short = "k_myers_ck" if "necat::k_myers_ck<" in kn else "k_rcwalk2" if ("necat::k_rcwalk2<8" in kn or "necat::k_rcwalk2w<8" in kn) else None
+                    if short:
+                        per[short] = per.get(short, 0.0) + (2.0 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0
+                if per:
+                    traffic, pmc_file, pmc_meta = {k: round(x, 1) for k, x in per.items()}, name, pmc.get("_meta")
+                    break
             except Exception:
                 pass
+    traffic_pair = sum(traffic.values()) if traffic else None
     words, band = float(agg["words"]), float(agg["band_words"])
     all_ms = agg["myers_ms"] + agg["rc_ms"] + agg["fused_ms"]
     return {"bound": "valu", "kernel": "k_myers_ck<8,16,true> + k_rcwalk2<8,16,1024> (the full 512 x 512 blocks of every round above 512 blocks - 85 % of all block alignments: SHW with checkpoints and horizontal deltas, then the walk that recomputes the two words it stands on; launch averages are over big and small rounds alike)",
@@ -629,8 +698,10 @@ def roofline_report(agg):
                                 "which the SQ counters put them at ~0.9 of (profiles/r03_sq_counters*.json); `frac` is against the 2-cycle datasheet rate",
             "hbm": {"achieved": round(achieved_hbm, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved_hbm / HBM_PEAK_GBS, 6),
                     "algorithmic_bytes_per_launch_pair": round(alg_per_launch, 1),
-                    "traffic_frac": round(traffic / (avg_pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_pair_ms > 0 else None,
-                    "traffic_source": "profiles/%s" % pmc_file if traffic else None},
+                    "traffic_frac": round(traffic_pair / (avg_pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_pair_ms > 0 else None,
+                    "traffic_over_algorithmic": round(traffic_pair / alg_per_launch, 1) if traffic and alg_per_launch > 0 else None,
+                    "traffic_source": {"file": "profiles/%s" % pmc_file, "taken_on": pmc_meta,
+                                       "note": "bytes per launch of each kernel (object `traffic`), read from that kept rocprofv3 --pmc profile, not measured in this run"} if traffic else None},
             "all_dp_and_walk_kernels": {"ms": round(all_ms + agg["traceback_ms"], 2), "dp_ms": round(agg["myers_ms"], 2), "rcwalk_ms": round(agg["rc_ms"], 2),
                                         "walk_and_finish_ms": round(agg["traceback_ms"] - agg["rc_ms"], 2), "fused_tail_ms": round(agg["fused_ms"], 2),
                                         "blocks": int(agg["blocks"]), "word_updates": int(words), "band_words_stored": int(band)},
@@ -800,6 +871,11 @@ def main():
             out["widened_paths"] = widened_paths(ctx, vol, capi, opt_kw)
         except Exception as e:
             out["widened_paths"] = {"error": str(e)}
+    if world == 1 and not args.no_widened and args.config2_genome:
+        try:
+            out["extra_configs"] = {"configs2_sensitive": config2_step(ctx, capi, synth, args)}
+        except Exception as e:
+            out["extra_configs"] = {"configs2_sensitive": {"error": str(e)}}
     cns_part = out.get("widened_paths", {}).pop("_partition", None) if isinstance(out.get("widened_paths"), dict) else None
     if world == 1 and not args.no_cpu_baseline:
         import shutil

@@ -387,6 +387,10 @@ int  necat_get_shard_timings(const necat_ctx* ctx, necat_shard_timings* t);
 /* Test hook: runs the RCCL transport's call path (librccl opened at run time, communicator, send/recv group on the context's
  * stream) with ONE rank sending `bytes` bytes to itself, and compares them. */
 int  necat_comm_selftest_rccl(necat_ctx* ctx, uint64_t bytes);
+/* The same between TWO devices: rank 0 on the context's device, rank 1 on another one of this process, each sends `bytes` to the other and
+ * checks what it received (one ncclSend / ncclRecv group per rank, comm.h's exchange pattern).  Returns 1 (and no error) when the box has fewer
+ * than two devices - a test skips then, with that reason. */
+int  necat_comm_selftest_rccl2(necat_ctx* ctx, uint64_t bytes);
 
 /* necat_index_build with the work split by hash range and the result all-gathered: the returned index is the
  * complete one, bit-identical to necat_index_build's, on every rank.  Collective: every rank of `comm` calls it.

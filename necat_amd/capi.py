@@ -85,7 +85,7 @@ EXPORTED_SYMBOLS = [
     "necat_gapped_strings", "necat_cns_default_options", "necat_cns_load_partition", "necat_cns_extension_batch",
     "necat_cns_result_free",
     "necat_edlib_align_batch", "necat_get_timings", "necat_free", "necat_pcan_partition",
-    "necat_comm_create", "necat_comm_destroy", "necat_comm_transport", "necat_get_shard_timings", "necat_comm_selftest_rccl",
+    "necat_comm_create", "necat_comm_destroy", "necat_comm_transport", "necat_get_shard_timings", "necat_comm_selftest_rccl", "necat_comm_selftest_rccl2",
     "necat_index_build_sharded", "necat_find_candidates_sharded", "necat_map_pair_sharded",
     "necat_pair_schedule", "necat_pair_chunk_reads", "necat_find_candidates_part", "necat_map_pair_part",
 ]
@@ -112,6 +112,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.necat_ctx_trim.restype = None
     lib.necat_pcan_partition.argtypes = [vp, vp, C.c_uint64, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int)]
     lib.necat_comm_selftest_rccl.argtypes = [vp, C.c_uint64]
+    lib.necat_comm_selftest_rccl2.argtypes = [vp, C.c_uint64]
     lib.necat_last_error.argtypes = [vp]
     lib.necat_last_error.restype = C.c_char_p
     lib.necat_device_name.argtypes = [vp, C.c_char_p, C.c_size_t]

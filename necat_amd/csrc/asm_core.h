@@ -526,6 +526,77 @@ struct Extender {
         }
         a.qoff = qbeg; a.toff = tbeg; a.qend = qend; a.tend = tend;
     }
+
+    // The same on the alignment as the device returns it - n columns, two bits each (0: a base of both, 1: a query base against a gap, 2: a subject
+    // base against a gap; necat_gapped_strings) - without writing the two strings out: hbn_map_extend only looks at the columns up to the first run of
+    // 8 matches from either end, and fix_ident_perc's count of unequal columns between them is the alignment's total (n minus its matches, which its
+    // identity 100 * matches / n gives back exactly) less those of the two ends.
+    void ends_packed(const uint8_t* query, int qsize, const uint8_t* target, int tsize, const uint8_t* ops, size_t n, BlockAlignment& a)
+    {
+        const int kMaxHang = 300, kMatchSize = 8;
+        auto op_at = [&](size_t i) { return (int)((ops[i >> 2] >> ((i & 3) * 2)) & 3); };
+        size_t from = 0, to = n;
+        int left_dist = 0, right_dist = 0;
+        bool lext = false, rext = false;
+        int qbeg = a.qoff, tbeg = a.toff, qend = a.qend, tend = a.tend;
+        {
+            const int ls = std::min(qbeg, tbeg);
+            if (ls <= kMaxHang && ls != 0) {
+                int run = 0, qi = 0, ti = 0;
+                size_t i = 0;
+                for (; run < kMatchSize && i < n; ++i) {
+                    const int op = op_at(i);
+                    const bool same = op == 0 && query[a.qoff + qi] == target[a.toff + ti];
+                    if (op != 2) ++qi;
+                    if (op != 1) ++ti;
+                    run = same ? run + 1 : 0;
+                }
+                if (run >= kMatchSize) {
+                    from = i + 1;
+                    const int qls = qbeg + qi, tls = tbeg + ti;
+                    if (local(query, qls, qls, target, tls, tls) && dal.r.aepos == qls && dal.r.bepos == tls) {
+                        qbeg = dal.r.abpos; tbeg = dal.r.bbpos; left_dist = dal.r.diffs; lext = true;
+                    }
+                }
+            }
+        }
+        {
+            const int rs = std::min(qsize - qend, tsize - tend);
+            if (rs <= kMaxHang && rs != 0) {
+                int run = 0, qi = 0, ti = 0;
+                size_t i = n;
+                while (i && run < kMatchSize) {
+                    --i;
+                    const int op = op_at(i);
+                    if (op != 2) ++qi;
+                    if (op != 1) ++ti;
+                    const bool same = op == 0 && query[a.qend - qi] == target[a.tend - ti];
+                    run = same ? run + 1 : 0;
+                }
+                if (run >= kMatchSize) {
+                    to = i;
+                    const int qrs = qend - qi, trs = tend - ti;
+                    if (local(query + qrs, 0, qsize - qrs, target + trs, 0, tsize - trs) && dal.r.abpos == 0 && dal.r.bbpos == 0) {
+                        qend = qrs + dal.r.aepos; tend = trs + dal.r.bepos; right_dist = dal.r.diffs; rext = true;
+                    }
+                }
+            }
+        }
+        if (lext || rext) {
+            int diff = left_dist + right_dist;
+            if (from < to) {
+                const long matches = llround(a.ident_perc * (double)n / 100.0);
+                long unequal = (long)n - matches;
+                int q = a.qoff, t = a.toff;
+                for (size_t i = 0; i < from; ++i) { const int op = op_at(i); if (!(op == 0 && query[q] == target[t])) --unequal; q += op != 2; t += op != 1; }
+                q = a.qend; t = a.tend;
+                for (size_t i = n; i > to; --i) { const int op = op_at(i - 1); q -= op != 2; t -= op != 1; if (!(op == 0 && query[q] == target[t])) --unequal; }
+                diff += (int)unequal;
+            }
+            a.ident_perc = 100.0 - 200.0 * diff / (qend + tend - qbeg - tbeg);
+        }
+        a.qoff = qbeg; a.toff = tbeg; a.qend = qend; a.tend = tend;
+    }
 };
 
 // ---- one read: extend_candidates (asm_pm_common.c:329-422) ------------------------------------------------------------------
@@ -608,6 +679,25 @@ struct BatchMapper {
             p.sid = sid; p.sdir = sdir; p.ssize = (int)subject.size(); p.qoff = p.soff = -1; p.score = 0;        // qoff < 0: no chain, nothing to align
             if (range.go(subject.data(), p.ssize, fwd_read, read_size, read_kmif, 10, 6, 15, &r, &read_index)) { p.qoff = r.soff; p.soff = r.qoff; p.score = r.score; }
             out.push_back(p);
+        }
+    }
+
+    // the same with the alignments' columns as the device packed them (ops[k], a[k].qaln / taln unused): Extender::ends_packed
+    void finish_packed(const Planned* planned, size_t n, const bool* ok, BlockAlignment* a, const uint8_t* const* ops, const size_t* ncols, const uint8_t* fwd_read, int read_id,
+                       int read_size, const std::function<void(int sid, int strand, std::vector<uint8_t>& out)>& subject_of, std::vector<necat_m4>& out)
+    {
+        for (size_t k = 0; k < n; ++k) {
+            const Planned& p = planned[k];
+            if (p.qoff < 0 || !ok[k] || !(a[k].ident_perc >= 65.0)) continue;
+            subject_of(p.sid, p.sdir, subject);
+            ext.ends_packed(fwd_read, read_size, subject.data(), p.ssize, ops[k], ncols[k], a[k]);
+            necat_m4 m;
+            memset(&m, 0, sizeof m);
+            m.qid = read_id; m.sid = p.sid; m.ident_perc = a[k].ident_perc; m.vscore = p.score; m.qdir = 0;
+            m.qoff = (uint64_t)a[k].qoff; m.qend = (uint64_t)a[k].qend; m.qext = (uint64_t)p.qoff; m.qsize = (uint64_t)read_size;
+            m.sdir = p.sdir; m.soff = (uint64_t)a[k].toff; m.send = (uint64_t)a[k].tend; m.sext = (uint64_t)p.soff; m.ssize = (uint64_t)p.ssize;
+            if (m.sdir == 1) { const uint64_t so = m.ssize - m.send, se = m.ssize - m.soff; m.soff = so; m.send = se; }
+            out.push_back(m);
         }
     }
 

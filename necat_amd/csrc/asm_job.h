@@ -157,10 +157,12 @@ inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const 
                     const uint64_t r = r0 + k0;
                     const size_t n = planned[r].size();
                     if (n == 0) return;
-                    std::vector<uint8_t> fwd, subj;
+                    std::vector<uint8_t> fwd;
                     crd->strand(r, 0, fwd);
                     std::vector<asmpm::BlockAlignment> ba(n);
                     std::unique_ptr<bool[]> ok(new bool[n]);
+                    std::vector<const uint8_t*> ops(n, nullptr);
+                    std::vector<size_t> ncols(n, 0);
                     for (size_t k = 0; k < n; ++k) {
                         ok[k] = false;
                         const int64_t s = slot[first[k0] + k];
@@ -169,12 +171,10 @@ inline int asm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const 
                         ok[k] = a.ok != 0;
                         if (!ok[k]) continue;
                         ba[k].qoff = a.qoff; ba[k].qend = a.qend; ba[k].toff = a.toff; ba[k].tend = a.tend; ba[k].ident_perc = a.ident_perc;
-                        ba[k].qaln.resize((size_t)a.align_size); ba[k].taln.resize((size_t)a.align_size);
-                        cref.strand((uint64_t)planned[r][k].sid, planned[r][k].sdir, subj);
-                        if (necat_gapped_strings(cols + cols_off[s], (uint64_t)a.align_size, fwd.data(), fwd.size(), (uint64_t)a.qoff, subj.data(), subj.size(), (uint64_t)a.toff,
-                                                 &ba[k].qaln[0], &ba[k].taln[0])) ok[k] = false;
+                        ops[k] = cols + cols_off[s]; ncols[k] = (size_t)a.align_size;
                     }
-                    mappers[tid].finish(planned[r].data(), n, ok.get(), ba.data(), fwd.data(), (int)r + read_start, (int)fwd.size(), subject_of, recs[r]);
+                    // (the alignment columns stay packed: only their two ends are looked at, asm_core.h Extender::ends_packed)
+                    mappers[tid].finish_packed(planned[r].data(), n, ok.get(), ba.data(), ops.data(), ncols.data(), fwd.data(), (int)r + read_start, (int)fwd.size(), subject_of, recs[r]);
                     for (necat_m4& m : recs[r]) m.sid += ref_start;
                 });
             }

@@ -63,13 +63,31 @@ NECAT_D VBlock* vb_find(const u64* ht, u32 mask, VBlock* pool, i32 block_id)
     }
 }
 
-// find_location's test (:483): quotient and "- 1" in float, fabs and the comparison in double
+// find_location's test (:483): quotient and "- 1" in float, fabs and the comparison in double.  Callers pass dloc > 0, dseed > 0.
+// Without the division, exactly: with D = dseed * len (an integer below 2^24, so the float product and both operands are exact) the quotient is the
+// correctly rounded float of dloc / D; r - 1.0f is exact near 1; |r - 1| < 0.1 (the double) holds for the floats 0x3F666667 .. 0x3F8CCCCC, i.e. for
+// dloc / D above the midpoint 0.9 + 5.96e-9 (a tie rounds to the even 0x3F666666, which fails) and up to the midpoint 1.1 - 3.58e-8 (a tie rounds to the
+// even 0x3F8CCCCC, which passes).  10 dloc and 9 D, 11 D are integers and the two offsets times 10 D stay far below 1, so that is 9 D < 10 dloc < 11 D.
 NECAT_D bool asm_ratio_ok(int dloc, int dseed, float len)
 {
+    const int li = (int)len;
+    if ((float)li == len && li > 0 && dloc < (1 << 24) && (i64)dseed * li < (1 << 24)) {
+        const i64 a = 10 * (i64)dloc, d = (i64)dseed * li;
+        return a > 9 * d && a < 11 * d;
+    }
     const float r = (float)dloc / ((float)dseed * len);
     double d = (double)(r - 1.0f);
     if (d < 0) d = -d;
     return d < 0.10;
+}
+// the top-up's test (:685, :693): fabs(x / (y * 1.0) - 1.0) < 0.10, all in double, x and y any ints.  Exactly, without the division: the quotient is the
+// correctly rounded double of x / y; the test holds for the doubles 0x3FECCCCCCCCCCCCD .. 0x3FF1999999999999, i.e. for x / y >= 0.9 - 3.3e-17 (the double
+// nearest to 0.9 passes) and < 1.1 - 2.2e-17 (the double nearest to 1.1 fails); in integers 9 |y| <= 10 |x| < 11 |y| with x, y of one sign, y != 0.
+NECAT_D bool asm_ratio_ok_f64(int x, int y)
+{
+    if (y == 0 || x == 0 || ((x < 0) != (y < 0))) return false;
+    const i64 ax = x < 0 ? -(i64)x : (i64)x, ay = y < 0 ? -(i64)y : (i64)y;
+    return 9 * ay <= 10 * ax && 10 * ax < 11 * ay;
 }
 
 // ---- collection: k_seed_collect_wave with this stage's rules
@@ -299,7 +317,6 @@ k_asm_vote_eval(DevVolume ref, DevVolume reads, VoteParams P, const u32* __restr
     const int gid = r + P.read_start_id;
     const int nblk = nblk_in[t];
     const float len = (float)P.bc;
-    const double bcd = (double)P.bc;
     int n_out = 0;
     u64 pending = 0; int pbase = -64;
     for (;;) {
@@ -327,10 +344,14 @@ k_asm_vote_eval(DevVolume ref, DevVolume reads, VoteParams P, const u32* __restr
         const int ns = np + nc;
         for (int x = lane; x < 128; x += 64) s_score[x] = 0;
         __syncthreads();
-        for (int ii = lane; ii < ns - 1; ii += 64) {
-            LdsAdder add; add.s = s_score;
-            const int own = asm_vote_row(s_loc, s_seedn, ii, ns, len, L, add);
-            if (own) atomicAdd(&s_score[ii], own);
+        // rows 0 .. ns - 2, one or two per lane; the rows beyond 63 in reverse (row i scans ns - 1 - i hits: lane l gets rows l and ns - 2 - l, ns hits in all)
+        for (int q = 0; q < 2; ++q) {
+            const int ii = q == 0 ? lane : ns - 2 - lane;
+            if (ii < ns - 1 && (q == 0 || ii >= 64)) {
+                LdsAdder add; add.s = s_score;
+                const int own = asm_vote_row(s_loc, s_seedn, ii, ns, len, L, add);
+                if (own) atomicAdd(&s_score[ii], own);
+            }
         }
         __syncthreads();
         int msid = -1;
@@ -384,12 +405,8 @@ k_asm_vote_eval(DevVolume ref, DevVolume reads, VoteParams P, const u32* __restr
                     const int u2 = sl2 < nleft ? b - 2 - sl2 : b + 1 + (sl2 - nleft);
                     const int at = u2 * kAsmZV;
                     const int hl = X->loc[e], hs = X->seedno[e];
-                    double x;
-                    if (sl2 < nleft) x = (double)(loc_list - at - hl) / ((double)((loc_seed - hs) * P.bc) * 1.0);
-                    else x = (double)(at + hl - loc_list) / ((double)((hs - loc_seed) * P.bc) * 1.0);
-                    x -= 1.0;
-                    if (x < 0) x = -x;
-                    acc = x < 0.10;
+                    if (sl2 < nleft) acc = asm_ratio_ok_f64(loc_list - at - hl, (loc_seed - hs) * P.bc);
+                    else acc = asm_ratio_ok_f64(at + hl - loc_list, (hs - loc_seed) * P.bc);
                 }
                 const u64 mask = __ballot(acc);
                 if (acc) atomicAdd(&s_rel[lo], 1);
@@ -398,7 +415,7 @@ k_asm_vote_eval(DevVolume ref, DevVolume reads, VoteParams P, const u32* __restr
             __syncthreads();
             if (nsc && (double)s_rel[lane] * 1.0 / (double)nsc > 0.4) T->score = 0;
         }
-        (void)bcd; (void)below;
+        (void)below;
         if (lane == 0) {
             VoteCand c;
             c.score = score0 + seedcount; c.chain = strand; c.target_id = readno; c.query_start = qstart;
@@ -422,10 +439,19 @@ NECAT_D bool vote_before_dev(const VoteCand& a, const VoteCand& b)
 
 // one wave per read: its candidates (forward strand's, then reverse strand's) ranked by the order above, the first num_extended of them, one plan
 // entry per (subject, strand) in that order.  sel: num_extended VoteCands of scratch per read; plan: num_extended entries per read.
+// The order as two ascending 64-bit keys (score descending = its complement ascending; the fields are non-negative ints): up to kSelLds
+// candidates are ranked on keys kept in LDS, longer lists on the records in global memory.
+constexpr int kSelLds = 1024;
+NECAT_D void vote_keys(const VoteCand& c, u64* k1, u64* k2)
+{
+    *k1 = ((u64)(0x7fffffffu - (u32)c.score) << 32) | ((u64)(u32)c.chain << 31) | (u64)(u32)c.target_id;
+    *k2 = ((u64)(u32)c.query_start << 32) | (u64)(u32)c.target_start;
+}
 __global__ void __launch_bounds__(64)
 k_asm_select(VoteParams P, const VoteMeta* __restrict__ meta, u32 n, VoteArenas A, const i32* __restrict__ n_strand, VoteCand* __restrict__ sel,
              AsmPlanDev* __restrict__ plan, i32* __restrict__ nplan)
 {
+    __shared__ ulonglong2 l_key[kSelLds];
     const u32 i = blockIdx.x;
     if (i >= n) return;
     const int lane = threadIdx.x;
@@ -436,14 +462,28 @@ k_asm_select(VoteParams P, const VoteMeta* __restrict__ meta, u32 n, VoteArenas 
     const VoteCand* c1 = A.out + m.pool_off[1];
     auto at = [&](int x) -> const VoteCand& { return x < n0 ? c0[x] : c1[x - n0]; };
     VoteCand* const top = sel + (u64)i * (u64)NE;
-    for (int a = lane; a < nn; a += 64) {
-        const VoteCand ca = at(a);
-        int rk = 0;
-        for (int b = 0; b < nn && rk < NE; ++b) {
-            const VoteCand& cb = at(b);
-            rk += (vote_before_dev(cb, ca) || (!vote_before_dev(ca, cb) && b < a)) ? 1 : 0;
+    if (nn <= kSelLds) {
+        for (int a = lane; a < nn; a += 64) { u64 k1, k2; vote_keys(at(a), &k1, &k2); l_key[a] = make_ulonglong2(k1, k2); }
+        __syncthreads();
+        for (int a = lane; a < nn; a += 64) {
+            const ulonglong2 ka = l_key[a];
+            int rk = 0;
+            for (int b = 0; b < nn; ++b) {
+                const ulonglong2 kb = l_key[b];
+                rk += (kb.x < ka.x || (kb.x == ka.x && (kb.y < ka.y || (kb.y == ka.y && b < a)))) ? 1 : 0;
+            }
+            if (rk < NE) top[rk] = at(a);
         }
-        if (rk < NE) top[rk] = ca;
+    } else {
+        for (int a = lane; a < nn; a += 64) {
+            const VoteCand ca = at(a);
+            int rk = 0;
+            for (int b = 0; b < nn && rk < NE; ++b) {
+                const VoteCand& cb = at(b);
+                rk += (vote_before_dev(cb, ca) || (!vote_before_dev(ca, cb) && b < a)) ? 1 : 0;
+            }
+            if (rk < NE) top[rk] = ca;
+        }
     }
     __syncthreads();
     const int mtop = nn < NE ? nn : NE;

@@ -188,6 +188,7 @@ void necat_ctx_destroy(necat_ctx* ctx)
     if (ctx->pin_plan) (void)hipHostFree(ctx->pin_plan);
     for (int i = 0; i < kNumEvents; ++i) (void)hipEventDestroy(ctx->ev[i]);
     if (ctx->round_ring) (void)hipHostFree(ctx->round_ring);
+    if (ctx->serial_streams) ctx->stream_a = ctx->stream_b = ctx->stream_c = ctx->stream_d = nullptr;      // aliases of ctx->stream (NECAT_SERIAL)
     for (hipStream_t st : {ctx->stream, ctx->stream_a, ctx->stream_b, ctx->stream_c, ctx->stream_d, ctx->stream_copy}) if (st) (void)hipStreamDestroy(st);
     delete ctx;
 }
@@ -1457,6 +1458,10 @@ struct RmOut { std::vector<necat_candidate> cands; std::vector<necat_m4> m4; std
 
 int ext_streams(necat_ctx* ctx)
 {
+    // NECAT_SERIAL=1 (profiling): the four streams of the extension rounds are ONE stream, so that every kernel has the chip to itself and its
+    // duration is its own work, not its wait for wave slots behind the other chains (tools/r04_profile.sh: the exclusive-time table)
+    static const bool serial = getenv("NECAT_SERIAL") && atoi(getenv("NECAT_SERIAL"));
+    if (serial && !ctx->stream_a) { ctx->stream_a = ctx->stream_b = ctx->stream_c = ctx->stream_d = ctx->stream; ctx->serial_streams = true; }
     for (hipStream_t* st : {&ctx->stream_a, &ctx->stream_b, &ctx->stream_c, &ctx->stream_d, &ctx->stream_copy})
         if (!*st && hipStreamCreate(st) != hipSuccess) return set_err(ctx, NECAT_ERR_DEVICE, "hipStreamCreate failed");
     return NECAT_OK;
@@ -2522,6 +2527,64 @@ int necat_comm_selftest_rccl(necat_ctx* ctx, uint64_t bytes)
     if (a) (void)hipFree(a);
     if (b) (void)hipFree(b);
     (void)c.p_CommDestroy(c.nccl);
+    return rc;
+}
+
+// Two ranks on two devices in ONE process: the all-pairs exchange of comm.h's RCCL branch in its smallest form - each rank sends its
+// buffer to the other and receives the other's, one ncclSend / ncclRecv group per rank, both inside one ncclGroup (as several communicators
+// of one process must be driven).  Returns 1 when the box has fewer than two devices (callers skip), 0 when both ranks received the
+// right bytes over the link.
+int necat_comm_selftest_rccl2(necat_ctx* ctx, uint64_t bytes)
+{
+    if (!ctx || !bytes) return NECAT_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 2) { (void)hipGetLastError(); set_err(ctx, NECAT_OK, "fewer than two devices: the two-rank RCCL exchange cannot run here"); return 1; }
+    necat_comm c;
+    c.rank = 0; c.nranks = 2;
+    int rc = comm::load_rccl(ctx, &c);
+    if (rc) return rc;
+    const int dev[2] = {ctx->device, ctx->device == 0 ? 1 : 0};
+    ncclUniqueId id;
+    NECAT_NCCL(ctx, &c, c.p_GetUniqueId(&id));
+    ncclComm_t cm[2] = {nullptr, nullptr};
+    hipStream_t st[2] = {nullptr, nullptr};
+    unsigned char* buf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    std::vector<unsigned char> h[2], g[2];
+    for (int r = 0; r < 2; ++r) { h[r].resize(bytes); g[r].resize(bytes); for (uint64_t i = 0; i < bytes; ++i) h[r][i] = (unsigned char)(i * 131u + 7u + 101u * (unsigned)r); }
+    auto body = [&]() -> int {
+        NECAT_NCCL(ctx, &c, c.p_GroupStart());
+        for (int r = 0; r < 2; ++r) { NECAT_HIP(ctx, hipSetDevice(dev[r])); NECAT_NCCL(ctx, &c, c.p_CommInitRank(&cm[r], 2, id, r)); }
+        NECAT_NCCL(ctx, &c, c.p_GroupEnd());
+        for (int r = 0; r < 2; ++r) {
+            NECAT_HIP(ctx, hipSetDevice(dev[r]));
+            NECAT_HIP(ctx, hipStreamCreate(&st[r]));
+            NECAT_HIP(ctx, hipMalloc((void**)&buf[r][0], bytes)); NECAT_HIP(ctx, hipMalloc((void**)&buf[r][1], bytes));
+            NECAT_HIP(ctx, hipMemcpyAsync(buf[r][0], h[r].data(), bytes, hipMemcpyHostToDevice, st[r]));
+            NECAT_HIP(ctx, hipMemsetAsync(buf[r][1], 0, bytes, st[r]));
+        }
+        NECAT_NCCL(ctx, &c, c.p_GroupStart());
+        for (int r = 0; r < 2; ++r) {
+            NECAT_HIP(ctx, hipSetDevice(dev[r]));
+            NECAT_NCCL(ctx, &c, c.p_Send(buf[r][0], bytes, ncclChar, 1 - r, cm[r], st[r]));
+            NECAT_NCCL(ctx, &c, c.p_Recv(buf[r][1], bytes, ncclChar, 1 - r, cm[r], st[r]));
+        }
+        NECAT_NCCL(ctx, &c, c.p_GroupEnd());
+        for (int r = 0; r < 2; ++r) {
+            NECAT_HIP(ctx, hipSetDevice(dev[r]));
+            NECAT_HIP(ctx, hipMemcpyAsync(g[r].data(), buf[r][1], bytes, hipMemcpyDeviceToHost, st[r]));
+            NECAT_HIP(ctx, hipStreamSynchronize(st[r]));
+        }
+        for (int r = 0; r < 2; ++r) if (memcmp(g[r].data(), h[1 - r].data(), bytes)) return set_err(ctx, NECAT_ERR_COMM, "RCCL exchange between devices %d and %d: rank %d received different bytes", dev[0], dev[1], r);
+        return NECAT_OK;
+    };
+    rc = body();
+    for (int r = 0; r < 2; ++r) {
+        (void)hipSetDevice(dev[r]);
+        for (int q = 0; q < 2; ++q) if (buf[r][q]) (void)hipFree(buf[r][q]);
+        if (st[r]) (void)hipStreamDestroy(st[r]);
+        if (cm[r]) (void)c.p_CommDestroy(cm[r]);
+    }
+    (void)hipSetDevice(ctx->device);
     return rc;
 }
 

@@ -31,6 +31,7 @@ struct necat_ctx {
     hipStream_t stream_a = nullptr, stream_b = nullptr;   // extension rounds: list A / list B run concurrently
     hipStream_t stream_c = nullptr;                       // second list-B stream (small lists alternate)
     hipStream_t stream_d = nullptr;                       // list A's ragged / wide blocks of a round whose full blocks run through ext_rcwalk.h
+    bool serial_streams = false;                          // NECAT_SERIAL=1: stream_a .. stream_d are aliases of `stream`
     hipStream_t stream_copy = nullptr;                    // deferred device-to-host copies (alignment columns of the consensus loop)
     bool copy_pending = false;                            // a copy on stream_copy still reads SC_EXT_COLS_OUT (ev[17] marks its end)
     char err[1024] = {0};

@@ -56,7 +56,8 @@ int main(int argc, char** argv)
     voter.init(ref.nbases);
     asmpm::ReadMapper mapper;
     asmpm::BatchMapper batch;
-    const bool use_batch = getenv("CHECK_ASM_BATCH") && atoi(getenv("CHECK_ASM_BATCH"));
+    const int batch_mode = getenv("CHECK_ASM_BATCH") ? atoi(getenv("CHECK_ASM_BATCH")) : 0;       // 2: the finish step on packed columns (Extender::ends_packed), as the program runs it
+    const bool use_batch = batch_mode != 0;
     uint64_t n_records = 0, n_votes = 0;
     for (int v = vid; v < vi.num_volumes; ++v) {
         ora_volume reads;
@@ -90,6 +91,21 @@ int main(int argc, char** argv)
                     subject_of(pl[k].sid, pl[k].sdir, subj);
                     ok[k] = block_align(fwd.data(), pl[k].qoff, L, subj.data(), pl[k].soff, pl[k].ssize, 400, &ba[k]);
                 }
+                if (batch_mode == 2) {
+                    // the columns two bits each, the strings dropped: what necat_asm_align_batch hands the program
+                    std::vector<std::vector<uint8_t>> packed(pl.size());
+                    std::vector<const uint8_t*> ops(pl.size(), nullptr);
+                    std::vector<size_t> ncols(pl.size(), 0);
+                    for (size_t k = 0; k < pl.size(); ++k) {
+                        if (!ok[k]) continue;
+                        const size_t n = ba[k].qaln.size();
+                        packed[k].assign((n + 3) / 4 + 1, 0);
+                        for (size_t c = 0; c < n; ++c) { const int op = ba[k].qaln[c] == '-' ? 2 : ba[k].taln[c] == '-' ? 1 : 0; packed[k][c >> 2] |= (uint8_t)(op << ((c & 3) * 2)); }
+                        ops[k] = packed[k].data(); ncols[k] = n;
+                        ba[k].qaln.clear(); ba[k].taln.clear();
+                    }
+                    batch.finish_packed(pl.data(), pl.size(), ok.get(), ba.data(), ops.data(), ncols.data(), fwd.data(), (int)i, L, subject_of, recs);
+                } else
                 batch.finish(pl.data(), pl.size(), ok.get(), ba.data(), fwd.data(), (int)i, L, subject_of, recs);
             }
             for (const necat_m4& m : recs) {        // DUMP_ASM_M4_HDR_ID (m4_record.h:99-124)

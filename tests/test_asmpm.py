@@ -59,7 +59,7 @@ def test_asmpm_matches_reference(check_asmpm, tmp_path, seed, err, repeat, indel
         want, got = os.path.join(str(tmp_path), "ref_%d.m4" % v), os.path.join(str(tmp_path), "mine_%d.m4" % v)
         subprocess.run([REF_ASMPM] + args.split() + ["-t", "1", wrk, str(v), want], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
         a = open(want, "rb").read()
-        for batch in ("0", "1"):        # candidate by candidate, and the two-phase walk of the program (all anchors planned, aligned, finished)
+        for batch in ("0", "1", "2"):   # candidate by candidate; the two-phase walk of the program (all anchors planned, aligned, finished); the same finished on packed columns
             r = subprocess.run([check_asmpm] + args.split() + [wrk, str(v), got], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                                env=dict(os.environ, CHECK_ASM_BATCH=batch))
             assert r.returncode == 0, r.stdout

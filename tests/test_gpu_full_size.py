@@ -64,22 +64,38 @@ def test_m4_identical_to_reference(ctx, ecoli):
     assert np.all((m4["ident_perc"] > 50.0) & (m4["ident_perc"] <= 100.0))
 
 
-# ---- a multi-volume project at real volume sizes (the shape of BASELINE configs[3] / [4]) through the oc2pm PROGRAM ----
-MV = json.load(open(os.path.join(util.GOLDEN, "multivol_full_reference.json")))
+# ---- multi-volume projects at real volume sizes through the oc2pm PROGRAM: "multivol" = 1.48 Gbp in three volumes of 1.05 / 0.30 / 0.13 Gbp;
+# "drosophila" = BASELINE configs[3] at its real size, a 140 Mb genome x 40 = 5.6 Gbp cut by oc2mkdb's own 2 Gbp rule into 2.0 / 2.0 / 1.6 Gbp
+# (the volume size at which 34-bit offsets, u32 slot counts and the 786 432-candidate batch cap are real; 6.9 M records per mode)
+MV_SETS = {}
+for _name in ("multivol", "drosophila"):
+    _p = os.path.join(util.GOLDEN, "%s_full_reference.json" % _name)
+    if os.path.exists(_p):
+        MV_SETS[_name] = json.load(open(_p))
 
 
-@pytest.fixture(scope="module")
-def multivol_dir(tmp_path_factory):
-    """1.48 Gbp in three volumes of 1.05 / 0.30 / 0.13 Gbp (synth.write_volume_dir_cuts): volume 0 sits where 34-bit offsets, 32-bit
-    slot counts and the 786 432-candidate batch cap matter (1.68 M candidates in its own job)"""
+@pytest.fixture(scope="module", params=sorted(MV_SETS))
+def multivol_dir(tmp_path_factory, request):
+    """the seeded read set of the golden, cut into its volumes (synth.write_volume_dir_cuts; for `drosophila` the cuts are oc2mkdb's 2 Gbp)"""
     from necat_amd import synth
+    MV = MV_SETS[request.param]
     g = MV["generator"]
+    if MV["nbases"] > 3_000_000_000:
+        try:
+            import psutil
+            if psutil.virtual_memory().available < 48 << 30:
+                pytest.skip("the 5.6 Gbp read set needs ~ 48 GB of host memory to generate")
+        except ImportError:
+            pass
     rs = synth.simulate_reads(g["genome"], g["coverage"], seed=g["seed"], err=g["err"])
     if hashlib.md5(rs.codes.tobytes()).hexdigest() != MV["reads_md5"]:
         pytest.skip("numpy generator drift: the seeded dataset differs from the one the golden was made on")
     d = os.path.join(str(tmp_path_factory.mktemp("mv")), "vols")
     assert synth.write_volume_dir_cuts(d, rs, g["cuts"]) == MV["volumes"]
-    return d
+    del rs
+    yield d, MV
+    import shutil
+    shutil.rmtree(d, ignore_errors=True)
 
 
 @pytest.mark.parametrize("mode", ["can", "m4"])
@@ -89,7 +105,7 @@ def test_multivolume_project_through_oc2pm_equals_the_reference(multivol_dir, bu
     (tests/golden/make_golden_multivol.py: sorted md5 over all volumes)"""
     import subprocess
     pmov, pm = built.build_cli()
-    d = multivol_dir
+    d, MV = multivol_dir
     for f in os.listdir(d):
         if f.startswith("pm") and f.endswith(".finished"):
             os.remove(os.path.join(d, f))
@@ -101,11 +117,13 @@ def test_multivolume_project_through_oc2pm_equals_the_reference(multivol_dir, bu
     assert r.stdout.count("unit(s) of job") >= 3          # both workers ran units, volume 0's pairs were split between them
     if mode == "can":
         raw = np.fromfile(out, dtype="<u4").reshape(-1, 7)
-        recs = sorted(bytes(x) for x in raw)
-        assert len(recs) == MV["candidate_records"]
-        assert hashlib.md5(b"".join(recs)).hexdigest() == MV["candidates_packed_sorted_md5"]
+        os.remove(out)
+        assert raw.shape[0] == MV["candidate_records"]
+        # sorted as 28-byte strings (the golden sorted bytes objects): a lexicographic sort over the records' byte columns
+        order = np.lexsort(raw.view(np.uint8).reshape(-1, 28).T[::-1])
+        assert hashlib.md5(raw[order].tobytes()).hexdigest() == MV["candidates_packed_sorted_md5"]
     else:
         lines = sorted(open(out, "rb").read().splitlines(keepends=True))
+        os.remove(out)
         assert len(lines) == MV["m4_records"]
         assert hashlib.md5(b"".join(lines)).hexdigest() == MV["m4_text_sorted_md5"]
-    os.remove(out)

@@ -93,3 +93,12 @@ def test_rccl_transport_call_path_runs(ctx):
     ncclSend / ncclRecv group on the context's stream - runs here with one rank sending to itself."""
     rc = ctx.lib.necat_comm_selftest_rccl(ctx.h, 1 << 20)
     assert rc == 0, ctx.lib.necat_last_error(ctx.h).decode()
+
+
+def test_rccl_exchange_between_two_devices(ctx):
+    """The RCCL data path between two DEVICES (what comm.h's all-pairs exchange is made of): two ranks of one process, each sends to and receives
+    from the other over the link.  Skipped - with the reason - on a box with one device; the first multi-GPU box to run the suite runs it."""
+    rc = ctx.lib.necat_comm_selftest_rccl2(ctx.h, 4 << 20)
+    if rc == 1:
+        pytest.skip("one device on this box: " + ctx.lib.necat_last_error(ctx.h).decode())
+    assert rc == 0, ctx.lib.necat_last_error(ctx.h).decode()
