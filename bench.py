@@ -342,11 +342,16 @@ def oc2asmpm_program(genome, threads, tmp):
     args = "-n 100 -z 10 -b 2000 -e 0.5 -j 1 -u 0 -a 400".split()
     res = {"reads": rs.nreads, "bases": rs.nbases, "volumes": nv, "host_threads": threads, "options": " ".join(args)}
     mine = os.path.join(tmp, "asm_mine.m4")
-    t0 = time.time()
-    r = subprocess.run([build.OC2ASMPM] + args + ["-t", str(threads), wrk, "0", mine], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, NECAT_TRACE="2", NECAT_CLI_TRACE="1"))
-    res["wall_s"] = round(time.time() - t0, 2)
-    if r.returncode != 0:
-        return dict(res, error=r.stderr[-300:])
+    # twice: a short-lived process pays for the device memory it maps, and the first process on a fresh box pays most (wall_first_run_s);
+    # wall_s and everything below are the second run's
+    walls = []
+    for _ in range(2):
+        t0 = time.time()
+        r = subprocess.run([build.OC2ASMPM] + args + ["-t", str(threads), wrk, "0", mine], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, NECAT_TRACE="2", NECAT_CLI_TRACE="1"))
+        walls.append(round(time.time() - t0, 2))
+        if r.returncode != 0:
+            return dict(res, error=r.stderr[-300:])
+    res["wall_first_run_s"], res["wall_s"] = walls[0], walls[1]
     plan = re.findall(r"asm plan: (\d+) reads, (\d+) planned pairs, (\d+) matches, ([0-9.]+) ms", r.stderr)
     if plan:
         res.update(planned_pairs=sum(int(p[1]) for p in plan), kmer_matches=sum(int(p[2]) for p in plan), plan_calls_ms=round(sum(float(p[3]) for p in plan), 2))

@@ -441,7 +441,7 @@ NECAT_D bool vote_before_dev(const VoteCand& a, const VoteCand& b)
 // entry per (subject, strand) in that order.  sel: num_extended VoteCands of scratch per read; plan: num_extended entries per read.
 // The order as two ascending 64-bit keys (score descending = its complement ascending; the fields are non-negative ints): up to kSelLds
 // candidates are ranked on keys kept in LDS, longer lists on the records in global memory.
-constexpr int kSelLds = 1024;
+constexpr int kSelLds = 4096;          // 64 KB of LDS: a read in a repeat has thousands of candidates, and ranking them in global memory made the launch's tail
 NECAT_D void vote_keys(const VoteCand& c, u64* k1, u64* k2)
 {
     *k1 = ((u64)(0x7fffffffu - (u32)c.score) << 32) | ((u64)(u32)c.chain << 31) | (u64)(u32)c.target_id;

@@ -457,7 +457,7 @@ struct FastWord {
 template <unsigned IMM> NECAT_D u32 bop(u32 a, u32 b, u32 c) { return (u32)__builtin_amdgcn_bitop3_b32(a, b, c, IMM); }
 
 template <bool REC>
-NECAT_D void fast_advance(FastWord& w, u32 el, u32 eh, u32 cph, u32 cmh, u32 cm, u32& phh_out, u32& mhh_out, u64& A, u64& B)
+NECAT_D void fast_advance(FastWord& w, u32 el, u32 eh, u32 cph, u32 cmh, u32 cm, u32& phh_out, u32& mhh_out, u64& A, u64& B, u32* phl_out = nullptr, u32* mhl_out = nullptr)
 {
     const u32 pl = (u32)w.Pv, ph = (u32)(w.Pv >> 32), ml = (u32)w.Mv, mh = (u32)(w.Mv >> 32);
     const u32 xvl = el | ml, xvh = eh | mh;                        // Xv = Eq | Mv (before the hin fix-up of Eq, edlib_ex.c:71-106)
@@ -468,6 +468,7 @@ NECAT_D void fast_advance(FastWord& w, u32 el, u32 eh, u32 cph, u32 cmh, u32 cm,
     const u32 phl = bop<0xf1>(ml, xhl, pl), phh = bop<0xf1>(mh, xhh, ph);      // Ph = Mv | ~(Xh | Pv)
     const u32 mhl = pl & xhl, mhh = ph & xhh;                                  // Mh = Pv & Xh
     phh_out = phh; mhh_out = mhh;
+    if (phl_out) { *phl_out = phl; *mhl_out = mhl; }               // (the ragged fast path tracks a row that is not the word's last)
     w.pubP = phh | cm; w.pubM = mhh & ~cm;                         // word 7 publishes the top-row boundary (+1) for the next block
     const u32 p2l = __builtin_amdgcn_alignbit(phl, cph, 31), p2h = __builtin_amdgcn_alignbit(phh, phl, 31);   // (Ph << 1) | (hin == +1)
     const u32 m2l = __builtin_amdgcn_alignbit(mhl, cmh, 31), m2h = __builtin_amdgcn_alignbit(mhh, mhl, 31);   // (Mh << 1) | (hin == -1)

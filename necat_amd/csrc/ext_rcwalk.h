@@ -81,53 +81,137 @@ NECAT_D u32 fast_shw8_ck(const int b, const u64* __restrict__ tw, const u64 nlo,
     return key;
 }
 
-// the front part of list A (work indices [0, nf): full blocks; [nf, nf16): holes), 8 items per wave
+// fast_shw8_ck<CARRY = true> for a block of ANY size up to 512 x 512 (the ragged blocks of list A: a last block of an extension, qn x tn): the
+// same 8-lane wavefront - lane = 64-row word, DPP carries, v_bitop3 logic, one 64-bit add - with what the general pass k_myers_ckg does for
+// such a block: only the words the query has (b < nblk), the rows past the query in its last word wildcards (build_peq's pad bits,
+// edlib_ex.c:46), only the columns the target has (c < tn), and the distance read where it is - at row qn - 1, a bit inside the last word,
+// for every column: the first column with the smallest value, which is what the reference's pad-row shift (:199) and its scan of the last
+// W cells (:205-219) together find (a value of a padded column c < W is at least qn, above any cutoff).  Same checkpoints, same deltas,
+// the last, partial 32-column group of deltas left-aligned as k_myers_ckg leaves it.  `steps`: the wave's longest tn + nblk - 1.
+template <int TW>
+NECAT_D u32 fast_shw8_ckr(const int b, const int qn, const int tn, const int steps, const u64* __restrict__ tw, const u64 nlo, const u64 nhi,
+                          ulonglong2* __restrict__ ck, u64* __restrict__ hc)
+{
+    constexpr int G = 8;
+    const int nblk = (qn + 63) >> 6, W = nblk * 64 - qn;
+    const bool have = b < nblk, lastw = b == nblk - 1;
+    const u64 pad = (lastw && W > 0) ? (~0ULL << ((64 - W) & 63)) : 0ULL;
+    const u32 pad_l = (u32)pad, pad_h = (u32)(pad >> 32);
+    const int pb = (qn - 1) & 63;
+    const bool row_hi = pb >= 32;
+    const u32 psh = (u32)pb & 31u;
+    const u32 cm = b == G - 1 ? 0x80000000u : 0u;
+    const u32 nlo_l = (u32)nlo, nlo_h = (u32)(nlo >> 32), nhi_l = (u32)nhi, nhi_h = (u32)(nhi >> 32);
+    const u32 sk = (u32)(32 - b) & 31u;
+    const int jck = (b + 31) & 31, jck16 = (b + 15) & 15;
+    u32 hp = 0, hm = 0;
+    u32 tlo = 0, thi = 0, plo = 0, phi = 0;
+    FastWord w; w.Pv = ~0ULL; w.Mv = 0ULL; w.pubP = 0x80000000u; w.pubM = 0u;
+    u32 S = (u32)qn, key = 0xffffffffu;
+    u64 dA, dB;
+    u32 cph = 0x80000000u, cmh = 0u;
+    for (int s0 = 0; s0 < steps; s0 += 32) {
+        {
+            const u64 x = (s0 >> 5) < TW ? tw[s0 >> 5] : 0ULL;
+            const u32 xl = (u32)x, xh = (u32)(x >> 32);
+            tlo = b ? __builtin_amdgcn_alignbit(xl, plo, sk) : xl;
+            thi = b ? __builtin_amdgcn_alignbit(xh, phi, sk) : xh;
+            plo = xl; phi = xh;
+        }
+        const int jn = steps - s0 < 32 ? steps - s0 : 32;
+        for (int j = 0; j < jn; ++j) {
+            const int s = s0 + j, c = s - b;
+            cph = dpp_row_shr1(w.pubP, cph); cmh = dpp_row_shr1(w.pubM, cmh);
+            if (have && (u32)c < (u32)tn) {
+                const u32 ma = (u32)__builtin_amdgcn_sbfe((int)tlo, (u32)j, 1u), mb = (u32)__builtin_amdgcn_sbfe((int)thi, (u32)j, 1u);
+                const u32 el = bop<0x60>(nlo_l ^ ma, nhi_l, mb) | pad_l, eh = bop<0x60>(nlo_h ^ ma, nhi_h, mb) | pad_h;
+                u32 phh, mhh, phl, mhl;
+                fast_advance<false>(w, el, eh, cph, cmh, cm, phh, mhh, dA, dB, &phl, &mhl);
+                if (lastw) {
+                    const u32 pw = row_hi ? phh : phl, mw = row_hi ? mhh : mhl;
+                    S += ((pw >> psh) & 1u) - ((mw >> psh) & 1u);
+                    const u32 k2 = (S << 10) + (u32)s;
+                    key = k2 < key ? k2 : key;
+                }
+                hp = __builtin_amdgcn_alignbit(hp, phh, 31); hm = __builtin_amdgcn_alignbit(hm, mhh, 31);
+                if ((j & 15) == jck16) {
+                    ck[(size_t)(c >> 4) * G] = make_ulonglong2(w.Pv, w.Mv);
+                    if (j == jck) hc[(size_t)(c >> 5) * G] = (u64)hp | ((u64)hm << 32);
+                }
+                if (c == tn - 1 && (c & 31) != 31) { const int sh = 31 - (c & 31); hc[(size_t)(c >> 5) * G] = (u64)(hp << sh) | ((u64)(hm << sh) << 32); }
+            }
+        }
+    }
+    return key;
+}
+
+// the front part of list A (work indices [0, nf): full blocks; [nf, nf16): holes), 8 items per wave; flags bit 27 (CARRY only): the whole
+// list - the ragged blocks at its back too, their waves (and the one wave that may hold both kinds) through fast_shw8_ckr
 template <int NW, int TW, bool CARRY>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, ulonglong2* __restrict__ ckpt,
-           u64* __restrict__ hcar, double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, int max_dist, u32 lo, u32 hi)
+           u64* __restrict__ hcar, double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, int max_dist, u32 lo, u32 hi, u32 flags)
 {
     // work items [lo, hi) of the list (multiples of 64: a big list goes through a bounded checkpoint buffer in several launches);
     // checkpoint / delta slots are indexed by item - lo
     constexpr int FW = 2 * NW + TW, G = 8, N = kOcaBlockSize;
     __shared__ u64 t_lds[8][TW];
     const ListView lv = list_view(0u, n_dev, capA);
-    const u64 first = (u64)lo + (u64)blockIdx.x * 8, end = lv.nf < hi ? lv.nf : hi;
+    const bool all = CARRY && ((flags >> 27) & 1u) != 0;
+    const u64 first = (u64)lo + (u64)blockIdx.x * 8, lim = all ? lv.n : lv.nf, end = lim < hi ? lim : hi;
     if (first >= end) return;
     const int lane = (int)threadIdx.x, sub = lane >> 3, b = lane & 7;
     const u64 item = first + (u64)sub;
-    const bool valid = item < end;
+    bool valid = item < end;
+    int qn = N, tn = N;
+    if (all && valid) {
+        BlockItem it0;
+        valid = list_item(lv, items, item, it0);
+        if (valid) { qn = it0.qn; tn = it0.tn; }
+    }
+    const bool ragged = all && __any(valid && (qn != N || tn != N));
     const u64 grp = item >> 6;
     const int il = (int)(item & 63);
     const u64* fr = frag + grp * FW * 64 + il;
+    const int nblk = (qn + 63) >> 6;
     u64 nlo = 0, nhi = 0;
-    if (valid) { nlo = fr[(u64)b * 64]; nhi = fr[(u64)(NW + b) * 64]; }
+    if (valid && b < nblk) { nlo = fr[(u64)b * 64]; nhi = fr[(u64)(NW + b) * 64]; }
     for (int w = b; w < TW; w += G) {
-        const u64 x = valid ? fr[(u64)(2 * NW + w) * 64] : 0ULL;
+        const u64 x = (valid && w * 32 < tn) ? fr[(u64)(2 * NW + w) * 64] : 0ULL;
         t_lds[sub][w] = even_bits(x) | (even_bits(x >> 1) << 32);
     }
     __syncthreads();
-    const u32 key = fast_shw8_ck<TW, CARRY>(b, t_lds[sub], nlo, nhi, ckpt + (size_t)(item - lo) * ((CARRY ? kRcCk16 : kRcCk) * G) + b,
-                                            hcar + (size_t)(item - lo) * (kRcCk * G) + b);
-    const u32 bkey = (u32)__shfl((int)key, (lane & ~(G - 1)) | (G - 1));
+    ulonglong2* const ckp = ckpt + (size_t)(item - lo) * ((CARRY ? kRcCk16 : kRcCk) * G) + b;
+    u64* const hcp = hcar + (size_t)(item - lo) * (kRcCk * G) + b;
+    u32 key;
+    if (ragged) {
+        int steps = valid ? tn + nblk - 1 : 0;
+        for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
+        key = fast_shw8_ckr<TW>(b, valid ? qn : 0, valid ? tn : 0, steps, t_lds[sub], nlo, nhi, ckp, hcp);
+    } else key = fast_shw8_ck<TW, CARRY>(b, t_lds[sub], nlo, nhi, ckp, hcp);
+    const int bl = ragged ? nblk - 1 : G - 1;                           // the word the distance was read in
+    const u32 bkey = (u32)__shfl((int)key, (lane & ~(G - 1)) | bl);
     int best = (int)(bkey >> 10);
-    const int end0 = (int)(bkey & 1023u) - (G - 1);
-    const int k0 = (int)((double)N * error * 1.1);                       // edlib_ex.c:751
+    const int end0 = (int)(bkey & 1023u) - bl;
+    const int k0 = (int)((double)(qn < tn ? qn : tn) * error * 1.1);     // edlib_ex.c:751
     if (best > k0) best = -1;
     int err = 0;
-    if (best >= 0) { int ad = end0 + 1 - N; if (ad < 0) ad = -ad; if (best < ad) err = 1; }
+    if (best >= 0) { int ad = end0 + 1 - qn; if (ad < 0) ad = -ad; if (best < ad) err = 1; }
+    const bool full = qn == N && tn == N;
     if (b == G - 1 && valid) {
         BlockResult br; br.dist = err ? -1 : best; br.endc = end0; br.err = err;
-        br.words = (u32)(NW * N) | ((best > max_dist && !err) ? kWideFlag : 0u);      // max_dist <= kRcMaxDist (smaller in tests: more blocks take the old path)
+        br.words = (u32)(nblk * tn) | ((full && best > max_dist && !err) ? kWideFlag : 0u);      // max_dist <= kRcMaxDist (smaller in tests: more blocks take the old path)
         results[item] = br;
     }
     // the work counters once per wave (its 8 blocks together): they are three words of ONE cache line, and 3 atomics per block were 580 k
     // same-line atomics per launch of a big round
     const bool owner = b == G - 1 && valid;
-    const u64 m_all = __ballot(owner), m_walk = __ballot(owner && best >= 0 && !err && !(best > max_dist));
+    const u64 m_all = __ballot(owner), m_walk = __ballot(owner && best >= 0 && !err && !(full && best > max_dist));
+    unsigned long long wsum = owner ? (unsigned long long)(nblk * tn) : 0ULL, bsum = owner ? (unsigned long long)(qn + tn) : 0ULL;
+    if (ragged) for (int o = 32; o > 0; o >>= 1) { wsum += __shfl_xor(wsum, o); bsum += __shfl_xor(bsum, o); }
+    else { wsum = (unsigned long long)popc64(m_all) * (unsigned long long)(NW * N); bsum = (unsigned long long)popc64(m_all) * (unsigned long long)(2 * N); }
     if (lane == 0 && m_all) {
-        const unsigned long long nb = (unsigned long long)popc64(m_all);
-        atomicAdd(&stats[0], nb * (unsigned long long)(NW * N)); atomicAdd(&stats[1], nb * (unsigned long long)(2 * N));
+        atomicAdd(&stats[0], wsum); atomicAdd(&stats[1], bsum);
         if (m_walk) atomicAdd(&stats[3], (unsigned long long)popc64(m_walk));           // blocks the recomputing walk will take
     }
 }

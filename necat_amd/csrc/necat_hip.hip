@@ -80,6 +80,8 @@ size_t g_rc_pool;      // NECAT_RC_POOL_MB (default 8192 = 1.6 M list-A blocks p
 u32 g_asm_rc;          // NECAT_ASM_RC (default 1): the 2048-bp block aligner of oc2asmpm through k_myers_ckg + k_rcwalk2 (no NW pass, no band records); 0 = two-pass kernel + band + wave walk
 u32 g_rc_listb;        // NECAT_RC_LISTB (default 1, needs NECAT_RC_CARRY): list B (blocks up to 794 x 794) through k_myers_ckg + k_rcwalk2 too; 0 = two-pass kernel + band pool + walk
 u32 g_rc_ragged;       // NECAT_RC_RAGGED (default 1, needs NECAT_RC_CARRY): the ragged blocks of those rounds through k_myers_ckg + k_rcwalk2 as well (0: two-pass kernel + lane walk on a stream of their own)
+u32 g_ck_lds;          // NECAT_CK_LDS (bytes, default 0): dynamic LDS claimed by every workgroup (one wave) of k_myers_ck - caps how many of its waves a CU holds (160 KB / (1 KB + this)), leaving wave slots to the chains of the other streams (A/B measurements)
+u32 g_rc_merge;        // NECAT_RC_MERGE (default 1, needs NECAT_RC_RAGGED): the ragged list-A blocks of a big round through k_myers_ck's ragged fast path and the full blocks' walk launch; 0 = k_myers_ckg + a walk launch of their own on stream d
 u32 g_rc_ww;           // NECAT_RC_WW (default 1): the recompute walk as k_rcwalk2w - four waves recompute 64 blocks, ONE wave walks them, a lane each; 0 = k_rcwalk2 (every lane of a quad walks its block)
 u32 g_rc_carry;        // NECAT_RC_CARRY (default 1): the recompute walk on an exact two-word window (k_myers_ck<CARRY> keeps the words' horizontal deltas, k_rcwalk2); 0 = the 4-word band window (k_rcwalk4)
 int g_rc_maxdist;      // NECAT_RC_MAXDIST (default and maximum kRcMaxDist = 160): full blocks of a larger distance take the old kernels (tests lower it)
@@ -109,6 +111,8 @@ void read_knobs()
     g_rc_carry = (u32)num("NECAT_RC_CARRY", 1);
     g_asm_rc = (u32)num("NECAT_ASM_RC", 1);
     g_rc_ww = (u32)num("NECAT_RC_WW", 1);
+    g_rc_merge = (u32)num("NECAT_RC_MERGE", 1);
+    g_ck_lds = (u32)num("NECAT_CK_LDS", 0);
     g_rc_listb = g_rc_carry ? (u32)num("NECAT_RC_LISTB", 1) : 0u;
     g_rc_ragged = g_rc_carry ? (u32)num("NECAT_RC_RAGGED", 1) : 0u;
     g_rc_pool = (size_t)std::max<unsigned long long>(1, num("NECAT_RC_POOL_MB", 8192)) << 20;
@@ -200,7 +204,7 @@ void necat_ctx_trim(necat_ctx* ctx)
     (void)hipDeviceSynchronize();
     for (auto& b : ctx->scratch) if (b.p) { (void)hipFree(b.p); b = DevBuf(); }
     for (auto& b : ctx->idx_cache) if (b.p) { (void)hipFree(b.p); b = DevBuf(); }
-    ctx->seed_ht_ptr = nullptr; ctx->seed_ht_clean = 0;
+    ctx->seed_ht_ptr = nullptr; ctx->seed_ht_clean = 0; ctx->seed_ht_cap = 0;
 }
 
 const char* necat_last_error(const necat_ctx* ctx) { return ctx ? ctx->err : "no context"; }
@@ -868,10 +872,14 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
         NECAT_HIP(ctx, hipMemcpyAsync(d_meta, meta, n * sizeof(SeedMeta), hipMemcpyHostToDevice, s));
         NECAT_HIP(ctx, hipMemcpyAsync(d_order, order + pos, (size_t)n * 4, hipMemcpyHostToDevice, s));
         // the hash arena is all-empty between calls (k_seed_clear below): filled only when it is new or a failed call left it dirty
-        if (ctx->seed_ht_ptr != ctx->scratch[SC_SEED_HT].p || ctx->seed_ht_clean < ht_tot * 8) {
-            NECAT_HIP(ctx, hipMemsetAsync(A.ht, 0xFF, ctx->scratch[SC_SEED_HT].cap, s));
+        // (only the stretch this chunk uses beyond what is known clean: a fresh 13 GB arena is not filled for a 0.3 GB chunk)
+        if (ctx->seed_ht_ptr != ctx->scratch[SC_SEED_HT].p || ctx->seed_ht_cap != ctx->scratch[SC_SEED_HT].cap) {      // a new allocation (also one at the old address)
+            ctx->seed_ht_ptr = ctx->scratch[SC_SEED_HT].p; ctx->seed_ht_cap = ctx->scratch[SC_SEED_HT].cap; ctx->seed_ht_clean = 0;
         }
-        ctx->seed_ht_ptr = ctx->scratch[SC_SEED_HT].p; ctx->seed_ht_clean = 0;      // in use: clean again once this chunk's kernels (k_seed_clear last) are known to have run
+        const size_t ht_clean_before = ctx->seed_ht_clean;
+        if (ht_clean_before < ht_tot * 8) NECAT_HIP(ctx, hipMemsetAsync((char*)A.ht + ht_clean_before, 0xFF, ht_tot * 8 - ht_clean_before, s));
+        const size_t ht_clean_after = std::max<size_t>(ht_clean_before, ht_tot * 8);
+        ctx->seed_ht_clean = 0;      // in use: clean again once this chunk's kernels (k_seed_clear last) are known to have run
         if (g_seed_wave)
             hipLaunchKernelGGL(k_seed_collect_wave, dim3(2 * n), dim3(64), 0, s, dref, drd, index_view(ix), (const u64*)ix->offset_list,
                                P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A, d_nblk, d_err, (const u64*)d_kst);
@@ -892,7 +900,7 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
         NECAT_HIP(ctx, hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, s));
         NECAT_HIP(ctx, hipStreamSynchronize(s));
         if (herr) { return set_err(ctx, NECAT_ERR_CAPACITY, "seeding scratch overflow (code %d)", herr); }
-        ctx->seed_ht_clean = ctx->scratch[SC_SEED_HT].cap;
+        ctx->seed_ht_clean = ht_clean_after;
 #ifdef NECAT_SEED_PROF
         {   // tools/seed_prof.sh: cycles of lane 0 per phase of k_seed_eval, summed over the waves
             unsigned long long h[32], z[32] = {0};
@@ -1319,12 +1327,16 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                 const u32 hi = std::min<u64>((u64)lo + rc_chunk, (u64)gA * 64), cn = hi - lo;
                 const bool last = (u64)lo + rc_chunk >= bound;
                 static const bool ckg_all = getenv("NECAT_RC_CKG_ALL") != nullptr;       // debugging: every block through the general pass
+                // NECAT_RC_MERGE (default): the ragged blocks ride the same two launches as the full ones (k_myers_ck's ragged fast path, the walk
+                // over the whole list) instead of a chain of their own (k_myers_ckg + walk on stream d)
+                const bool merged = g_rc_merge && g_rc_ragged && g_rc_carry && !ckg_all;
                 if (ckg_all && g_rc_ragged) {}
                 else if (g_rc_carry)
-                    hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA, true>), dim3((cn + 7) / 8), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error, c.resA, X.stats, g_rc_maxdist, lo, hi);
+                    hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA, true>), dim3((cn + 7) / 8), dim3(64), g_ck_lds, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error, c.resA, X.stats, g_rc_maxdist, lo, hi,
+                                       merged ? fl_all : epoch);
                 else
-                    hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA, false>), dim3((cn + 7) / 8), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error, c.resA, X.stats, g_rc_maxdist, lo, hi);
-                if (g_rc_ragged) {
+                    hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA, false>), dim3((cn + 7) / 8), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error, c.resA, X.stats, g_rc_maxdist, lo, hi, epoch);
+                if (g_rc_ragged && !merged) {
                     // the ragged blocks of the chunk (the back of the work index space): the general SHW pass, same checkpoints.  A tenth of
                     // the blocks, few waves, latency bound: beside the full blocks' pass on a stream of its own when the list is one chunk
                     hipStream_t sr = one_chunk ? sd : c.sa;
@@ -1342,7 +1354,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                 if (g_rc_carry)
                     launch_rcwalk2<kWordsA, kTWordsA, kColsA, kOpsA>(cn, c.sa, itA, bound, d_nA, c.cap, (const u64*)c.fragA, (const ulonglong2*)ck,
                                        (const u64*)hcar, (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsA, wo, X.stats, X.d_err,
-                                       (g_rc_ragged && one_chunk) ? epoch : fl_all, lo, hi);
+                                       (g_rc_ragged && one_chunk && !merged) ? epoch : fl_all, lo, hi);
                 else
                     hipLaunchKernelGGL((k_rcwalk4<kWordsA, kTWordsA, kOpsA>), dim3((cn + 15) / 16), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, (const ulonglong2*)ck,
                                        (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsA, wo, X.stats, X.d_err, lo, hi);
@@ -1359,7 +1371,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                 NECAT_CHECK_LAUNCH(ctx, "k_myers / k_traceback<A, wide>");
             }
             if (!g_rc_ragged || wide_possible) NECAT_HIP(ctx, hipEventRecord(ctx->ev[25], sd));
-            if (g_rc_ragged && one_chunk) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, ctx->ev[30], 0));       // the ragged blocks are walked
+            if (g_rc_ragged && one_chunk && !(g_rc_merge && g_rc_carry && !getenv("NECAT_RC_CKG_ALL"))) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, ctx->ev[30], 0));       // the ragged blocks are walked
             rc_round.push_back(r);
             hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, 5, kOcaBlockSize, false, 4>), dim3((gA + 3) / 4), dim3(256), 0, c.sa, itA, bound, d_nA, c.cap,
                                (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
@@ -2144,8 +2156,10 @@ int necat_asm_plan_batch(necat_ctx* ctx, const necat_index* ix, const necat_volu
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return std::max(hits[2 * (size_t)a], hits[2 * (size_t)a + 1]) > std::max(hits[2 * (size_t)b], hits[2 * (size_t)b + 1]); });
     // (the pool of 384-byte blocks is sized by the hit counts, an upper bound several times the blocks really touched: the budget is what keeps a
-    // chunk inside HBM - 64 M blocks = 24.6 GB by default, never more than 40 % of the memory that is free now)
-    u64 budget_blocks = getenv("NECAT_ASM_VOTE_BUDGET") ? std::max<u64>(1024, strtoull(getenv("NECAT_ASM_VOTE_BUDGET"), nullptr, 10)) : (u64)64 << 20;
+    // chunk inside HBM - 32 M blocks = 12.3 GB by default, never more than 40 % of the memory that is free now.  Fewer, larger chunks are faster -
+    // a chunk is as long as its longest read's walk: 100 Mbp of corrected reads take 0.30 s in 5 chunks of 64 M, 0.64 s in 20 of 16 M - but a
+    // short-lived process pays for the memory it maps: the first 30 GB of arenas of a process on a fresh box took 0.9 s, profiles/NOTES_r04.md)
+    u64 budget_blocks = getenv("NECAT_ASM_VOTE_BUDGET") ? std::max<u64>(1024, strtoull(getenv("NECAT_ASM_VOTE_BUDGET"), nullptr, 10)) : (u64)32 << 20;
     {
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr) budget_blocks = std::max<u64>(1 << 16, std::min<u64>(budget_blocks, (u64)(fr * 0.4) / sizeof(VBlock)));
@@ -2183,6 +2197,7 @@ int necat_asm_plan_batch(necat_ctx* ctx, const necat_index* ix, const necat_volu
             (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_RIDX], mx_tab * 4)) ||
             (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_RNEXT], mx_next * 4))) return fail(rc);
     }
+    tick("chunk plan + arenas");
     u32 pos = 0;
     for (size_t ci = 0; ci < chunk_end.size(); ++ci) {
         const u32 hi = chunk_end[ci];

@@ -75,8 +75,20 @@ int main(int argc, char** argv)
         const PairSchedule S = pair_schedule(bases.data(), V, G, kPmSlots, skip.data());
         const int pcan_batch = (opt.job == 0 && getenv("NECAT_PM_PARTITIONS")) ? atoi(getenv("NECAT_PM_PARTITIONS")) : 0;
         const int np = pcan_batch > 0 ? (vi.num_reads + pcan_batch - 1) / pcan_batch : 0;
+        // leftovers of an earlier, aborted run (another schedule, another batch size) must not be merged into this one's files: the shares
+        // pm_result_<v>.r<g>[.p<p>] of every worker and the partition files pm_result_<v>.p<p> of the volumes still to do
+        for (int v : todo) {
+            const std::string res = base + "pm_result_" + std::to_string(v);
+            for (int p = 0; p < np; ++p) remove((res + ".p" + std::to_string(p)).c_str());
+            for (int g = 0; g < std::max(G, 64); ++g) {
+                const std::string share = res + ".r" + std::to_string(g);
+                if (remove(share.c_str()) != 0 && g >= G) continue;
+                for (int p = 0; p < np; ++p) remove((share + ".p" + std::to_string(p)).c_str());
+            }
+        }
         fflush(stdout); fflush(stderr);
         std::vector<pid_t> pids;
+        std::vector<int> pid_worker;
         for (int g = 0; g < G; ++g) {
             if (S.rank_off[(size_t)g + 1] == S.rank_off[(size_t)g]) continue;          // nothing for this worker
             const pid_t pid = fork();
@@ -102,15 +114,34 @@ int main(int argc, char** argv)
                 _exit(status ? 1 : 0);
             }
             pids.push_back(pid);
+            pid_worker.push_back(g);
         }
-        for (pid_t pid : pids) {
+        std::vector<uint8_t> worker_failed((size_t)G, 0);
+        for (size_t w = 0; w < pids.size(); ++w) {
             int status = 0;
-            if (waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) failed = true;
+            if (waitpid(pids[w], &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) { failed = true; worker_failed[(size_t)pid_worker[w]] = 1; }
         }
-        // the shares of a job, in worker order, make the job's file (written under a temporary name first, like the job itself does)
-        for (size_t t = 0; t < todo.size() && !failed; ++t) {
+        // the shares of a job, in worker order, make the job's file (written under a temporary name first, like the job itself does).  A volume whose
+        // whole team succeeded is assembled and marked finished even when another worker failed (a rerun then only redoes the others, as the
+        // whole-volume mode does); the shares of a volume with a failed worker are removed
+        for (size_t t = 0; t < todo.size(); ++t) {
             const int v = todo[t];
             const std::string res = base + "pm_result_" + std::to_string(v), tmp = res + ".part";
+            bool team_ok = true;
+            for (int g = S.team_lo[(size_t)v]; g <= S.team_hi[(size_t)v]; ++g) {
+                bool has = false;
+                for (uint64_t k = S.rank_off[(size_t)g]; k < S.rank_off[(size_t)g + 1]; ++k) has = has || S.units[k].ref_vol == v;
+                // (a worker stops at its first failing job: the jobs after it were not run either)
+                if (has && worker_failed[(size_t)g]) team_ok = false;
+            }
+            if (!team_ok) {
+                for (int g = S.team_lo[(size_t)v]; g <= S.team_hi[(size_t)v]; ++g) {
+                    const std::string share = res + ".r" + std::to_string(g);
+                    remove(share.c_str());
+                    for (int p = 0; p < np; ++p) remove((share + ".p" + std::to_string(p)).c_str());
+                }
+                continue;
+            }
             FILE* out = fopen(tmp.c_str(), "w");
             bool ok = out != nullptr;
             for (int g = S.team_lo[(size_t)v]; ok && g <= S.team_hi[(size_t)v]; ++g) {
@@ -123,6 +154,9 @@ int main(int argc, char** argv)
             for (int p = 0; ok && p < np; ++p) {
                 FILE* po = nullptr;
                 for (int g = S.team_lo[(size_t)v]; ok && g <= S.team_hi[(size_t)v]; ++g) {
+                    bool has = false;
+                    for (uint64_t k = S.rank_off[(size_t)g]; k < S.rank_off[(size_t)g + 1]; ++k) has = has || S.units[k].ref_vol == v;
+                    if (!has) continue;
                     const std::string src = res + ".r" + std::to_string(g) + ".p" + std::to_string(p);
                     if (access(src.c_str(), F_OK) != 0) continue;
                     if (!po) { po = fopen((res + ".p" + std::to_string(p)).c_str(), "wb"); if (!po) { ok = false; break; } }
@@ -132,7 +166,7 @@ int main(int argc, char** argv)
                 if (po && fclose(po) != 0) ok = false;
             }
             if (ok) ok = rename(tmp.c_str(), res.c_str()) == 0;
-            if (!ok) { fprintf(stderr, "[oc2pm] ERROR: assembling %s failed\n", res.c_str()); failed = true; break; }
+            if (!ok) { fprintf(stderr, "[oc2pm] ERROR: assembling %s failed\n", res.c_str()); failed = true; continue; }
             for (int g = S.team_lo[(size_t)v]; g <= S.team_hi[(size_t)v]; ++g) remove((res + ".r" + std::to_string(g)).c_str());
             char fin[4096];
             snprintf(fin, sizeof fin, "%s/pm%d.finished", wrk_dir, v);

@@ -44,6 +44,7 @@ struct necat_ctx {
     unsigned long long round_seq = 0;  // rounds published so far (the next round publishes round_seq + 1)
     necat::DevBuf scratch[64];         // grow-only arenas, indexed by purpose (ScratchId; SC_COUNT <= 64)
     void* seed_ht_ptr = nullptr;       // the seeding hash arena (SC_SEED_HT) whose first seed_ht_clean bytes are known to be all-empty (0xFF):
+    size_t seed_ht_cap = 0;            // .. and its capacity when that was established (a reallocation at the same address is a new arena)
     size_t seed_ht_clean = 0;          // every call leaves the arena as it found it (k_seed_clear resets the slots it used), so it is filled once per allocation
     char devname[256] = {0};
     int num_cu = 0;

@@ -22,9 +22,11 @@ def torch_allgather(dist, group=None, device=None) -> Callable[[bytes], List[byt
     return allgather
 
 
-def file_allgather(directory: str, rank: int, nranks: int, timeout_s: float = 120.0) -> Callable[[bytes], List[bytes]]:
+def file_allgather(directory: str, rank: int, nranks: int, timeout_s: float = 120.0, comm_id: str = "") -> Callable[[bytes], List[bytes]]:
     """The same exchange through files of a shared directory (one sequence number per call): for ranks started by hand
-    or by the tests without a process group.  Every rank must make the same sequence of calls."""
+    or by the tests without a process group.  Every rank must make the same sequence of calls.  Two communicators alive at the same
+    time in ONE directory (the teams of a pairs schedule) must be given different `comm_id`s: the handshake files are keyed by the
+    rank inside the communicator."""
     import os
     import time
     seq = [0]
@@ -55,15 +57,20 @@ def file_allgather(directory: str, rank: int, nranks: int, timeout_s: float = 12
         returns once every rank has acknowledged the current token.  Stale files of an earlier run carry other nonces."""
         import json
         nonce = "%d_%d" % (os.getpid(), time.time_ns())
-        ann = os.path.join(directory, "run_token")
+        tag = ("c%s_" % comm_id) if comm_id else ""
+        ann = os.path.join(directory, tag + "run_token")
         t0 = time.time()
         if rank != 0:
-            put(os.path.join(directory, "hello_%d" % rank), nonce)
+            put(os.path.join(directory, tag + "hello_%d" % rank), nonce)
             while True:
                 try:
                     a = json.loads(get(ann) or "{}")
                     if a.get("nonces", {}).get(str(rank)) == nonce:
-                        put(os.path.join(directory, "ack_%s_%d" % (a["token"], rank)), nonce)
+                        put(os.path.join(directory, tag + "ack_%s_%d" % (a["token"], rank)), nonce)
+                        try:
+                            os.remove(os.path.join(directory, tag + "hello_%d" % rank))        # agreed: the next run publishes its own
+                        except OSError:
+                            pass
                         return a["token"]
                 except ValueError:
                     pass
@@ -72,12 +79,17 @@ def file_allgather(directory: str, rank: int, nranks: int, timeout_s: float = 12
                 time.sleep(0.0005)
         seen = None
         while True:
-            nonces = {str(r): get(os.path.join(directory, "hello_%d" % r)) for r in range(1, nranks)}
+            nonces = {str(r): get(os.path.join(directory, tag + "hello_%d" % r)) or (seen or {}).get(str(r)) for r in range(1, nranks)}
             if all(nonces.values()):
                 if nonces != seen:
                     put(ann, json.dumps({"token": nonce, "nonces": nonces}))
                     seen = nonces
-                if all(get(os.path.join(directory, "ack_%s_%d" % (nonce, r))) == nonces[str(r)] for r in range(1, nranks)):
+                if all(get(os.path.join(directory, tag + "ack_%s_%d" % (nonce, r))) == nonces[str(r)] for r in range(1, nranks)):
+                    for r in range(1, nranks):
+                        try:
+                            os.remove(os.path.join(directory, tag + "ack_%s_%d" % (nonce, r)))
+                        except OSError:
+                            pass
                     return nonce
             if time.time() - t0 > timeout_s:
                 raise TimeoutError("the other ranks never showed up in %s" % directory)

@@ -90,12 +90,14 @@ def multivol_dir(tmp_path_factory, request):
     rs = synth.simulate_reads(g["genome"], g["coverage"], seed=g["seed"], err=g["err"])
     if hashlib.md5(rs.codes.tobytes()).hexdigest() != MV["reads_md5"]:
         pytest.skip("numpy generator drift: the seeded dataset differs from the one the golden was made on")
-    d = os.path.join(str(tmp_path_factory.mktemp("mv")), "vols")
+    keep = os.environ.get("NECAT_TEST_KEEP_VOLS")          # tools/r04: the profile pass reuses the volumes this fixture wrote
+    d = os.path.join(keep, request.param) if keep else os.path.join(str(tmp_path_factory.mktemp("mv")), "vols")
     assert synth.write_volume_dir_cuts(d, rs, g["cuts"]) == MV["volumes"]
     del rs
     yield d, MV
-    import shutil
-    shutil.rmtree(d, ignore_errors=True)
+    if not keep:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
 
 
 @pytest.mark.parametrize("mode", ["can", "m4"])
