@@ -88,11 +88,13 @@ NECAT_D u32 fast_shw8_ck(const int b, const u64* __restrict__ tw, const u64 nlo,
 // for every column: the first column with the smallest value, which is what the reference's pad-row shift (:199) and its scan of the last
 // W cells (:205-219) together find (a value of a padded column c < W is at least qn, above any cutoff).  Same checkpoints, same deltas,
 // the last, partial 32-column group of deltas left-aligned as k_myers_ckg leaves it.  `steps`: the wave's longest tn + nblk - 1.
-template <int TW>
-NECAT_D u32 fast_shw8_ckr(const int b, const int qn, const int tn, const int steps, const u64* __restrict__ tw, const u64 nlo, const u64 nhi,
-                          ulonglong2* __restrict__ ck, u64* __restrict__ hc)
+// (G lanes per block - 8: list A, 16: list B at 13 words; NWS: words per checkpoint / delta slot of the geometry; the key keeps the step in 10 bits)
+template <int G, int NWS, int TW>
+NECAT_D u32 fast_shw_ckr(const int b, const int qn, const int tn, const int steps, const u64* __restrict__ tw, const u64 nlo, const u64 nhi,
+                         ulonglong2* __restrict__ ck, u64* __restrict__ hc)
 {
-    constexpr int G = 8;
+    static_assert(G == 8 || G == 16, "the carries run on DPP row_shr: a block is half a row or a row of 16 lanes");
+    static_assert(TW * 32 + G <= 1024, "step count in 10 bits of the key");
     const int nblk = (qn + 63) >> 6, W = nblk * 64 - qn;
     const bool have = b < nblk, lastw = b == nblk - 1;
     const u64 pad = (lastw && W > 0) ? (~0ULL << ((64 - W) & 63)) : 0ULL;
@@ -100,7 +102,7 @@ NECAT_D u32 fast_shw8_ckr(const int b, const int qn, const int tn, const int ste
     const int pb = (qn - 1) & 63;
     const bool row_hi = pb >= 32;
     const u32 psh = (u32)pb & 31u;
-    const u32 cm = b == G - 1 ? 0x80000000u : 0u;
+    const u32 cm = (G == 8 && b == G - 1) ? 0x80000000u : 0u;          // (half a row: the last word publishes the top-row boundary for the block in the other half)
     const u32 nlo_l = (u32)nlo, nlo_h = (u32)(nlo >> 32), nhi_l = (u32)nhi, nhi_h = (u32)(nhi >> 32);
     const u32 sk = (u32)(32 - b) & 31u;
     const int jck = (b + 31) & 31, jck16 = (b + 15) & 15;
@@ -135,10 +137,10 @@ NECAT_D u32 fast_shw8_ckr(const int b, const int qn, const int tn, const int ste
                 }
                 hp = __builtin_amdgcn_alignbit(hp, phh, 31); hm = __builtin_amdgcn_alignbit(hm, mhh, 31);
                 if ((j & 15) == jck16) {
-                    ck[(size_t)(c >> 4) * G] = make_ulonglong2(w.Pv, w.Mv);
-                    if (j == jck) hc[(size_t)(c >> 5) * G] = (u64)hp | ((u64)hm << 32);
+                    ck[(size_t)(c >> 4) * NWS] = make_ulonglong2(w.Pv, w.Mv);
+                    if (j == jck) hc[(size_t)(c >> 5) * NWS] = (u64)hp | ((u64)hm << 32);
                 }
-                if (c == tn - 1 && (c & 31) != 31) { const int sh = 31 - (c & 31); hc[(size_t)(c >> 5) * G] = (u64)(hp << sh) | ((u64)(hm << sh) << 32); }
+                if (c == tn - 1 && (c & 31) != 31) { const int sh = 31 - (c & 31); hc[(size_t)(c >> 5) * NWS] = (u64)(hp << sh) | ((u64)(hm << sh) << 32); }
             }
         }
     }
@@ -146,7 +148,7 @@ NECAT_D u32 fast_shw8_ckr(const int b, const int qn, const int tn, const int ste
 }
 
 // the front part of list A (work indices [0, nf): full blocks; [nf, nf16): holes), 8 items per wave; flags bit 27 (CARRY only): the whole
-// list - the ragged blocks at its back too, their waves (and the one wave that may hold both kinds) through fast_shw8_ckr
+// list - the ragged blocks at its back too, their waves (and the one wave that may hold both kinds) through fast_shw_ckr
 template <int NW, int TW, bool CARRY>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, ulonglong2* __restrict__ ckpt,
@@ -187,7 +189,7 @@ k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u
     if (ragged) {
         int steps = valid ? tn + nblk - 1 : 0;
         for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
-        key = fast_shw8_ckr<TW>(b, valid ? qn : 0, valid ? tn : 0, steps, t_lds[sub], nlo, nhi, ckp, hcp);
+        key = fast_shw_ckr<8, 8, TW>(b, valid ? qn : 0, valid ? tn : 0, steps, t_lds[sub], nlo, nhi, ckp, hcp);
     } else key = fast_shw8_ck<TW, CARRY>(b, t_lds[sub], nlo, nhi, ckp, hcp);
     const int bl = ragged ? nblk - 1 : G - 1;                           // the word the distance was read in
     const u32 bkey = (u32)__shfl((int)key, (lane & ~(G - 1)) | bl);
@@ -199,7 +201,7 @@ k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u
     if (best >= 0) { int ad = end0 + 1 - qn; if (ad < 0) ad = -ad; if (best < ad) err = 1; }
     const bool full = qn == N && tn == N;
     if (b == G - 1 && valid) {
-        BlockResult br; br.dist = err ? -1 : best; br.endc = end0; br.err = err;
+        BlockResult br; br.dist = err ? -1 : best; br.endc = (full || best >= 0) ? end0 : -1; br.err = err;      // (a ragged block without an end column: -1, as k_myers_ckg leaves it)
         br.words = (u32)(nblk * tn) | ((full && best > max_dist && !err) ? kWideFlag : 0u);      // max_dist <= kRcMaxDist (smaller in tests: more blocks take the old path)
         results[item] = br;
     }
@@ -459,6 +461,61 @@ k_myers_ckg(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
     }
     {   // the work counters once per wave
         unsigned long long w = is_last ? (unsigned long long)(nblk * tn) : 0ULL, bs = is_last ? (unsigned long long)(qn + tn) : 0ULL;
+        for (int o = 32; o > 0; o >>= 1) { w += __shfl_xor(w, o); bs += __shfl_xor(bs, o); }
+        if (lane == 0 && w) { atomicAdd(&stats[0], w); atomicAdd(&stats[1], bs); }
+    }
+}
+
+// k_myers_ckg's drop-in for blocks of at most 16 words (list B: 13 words, 16 lanes per block, four blocks per wave): the same results, checkpoints
+// and deltas through fast_shw_ckr - 32-bit halves, v_bitop3 logic, DPP carries - instead of the general pass's 64-bit steps.
+template <int NW, int TW, int COLS, int G>
+__global__ void __launch_bounds__(64)
+k_myers_ckf(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, ulonglong2* __restrict__ ckpt,
+            u64* __restrict__ hcar, double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, u32 epoch, u32 lo, u32 hi)
+{
+    constexpr int FW = 2 * NW + TW, BPW = 64 / G, CK = RcGeom<COLS>::kCk, SEGS = RcGeom<COLS>::kSeg;
+    static_assert(NW <= G, "one lane per word");
+    __shared__ u64 t_lds[BPW][TW];
+    const ListView lv = list_view(n_host, n_dev, capA);
+    const u64 wave_first = (u64)lo + (u64)blockIdx.x * BPW, end = lv.n < hi ? lv.n : hi;
+    if (wave_first >= end) return;
+    if (((epoch >> 26) & 1u) && wave_first + BPW <= (u64)lv.nf16) return;
+    const int lane = (int)threadIdx.x, sub = lane / G, b = lane % G;
+    const u64 item = wave_first + (u64)sub;
+    BlockItem it0;
+    bool valid = item < end && list_item(lv, items, item, it0);
+    if (((epoch >> 26) & 1u) && item < (u64)lv.nf16) valid = false;
+    const u64 grp = item >> 6;
+    const int il = (int)(item & 63);
+    const int qn = valid ? it0.qn : 0, tn = valid ? it0.tn : 0;
+    const int nblk = (qn + 63) >> 6;
+    const u64* fr = frag + grp * FW * 64 + il;
+    u64 nlo = 0, nhi = 0;
+    if (valid && b < nblk) { nlo = fr[(u64)b * 64]; nhi = fr[(u64)(NW + b) * 64]; }
+    if (valid) for (int w = b; w < TW; w += G) {
+        const u64 x = (w * 32 < tn) ? fr[(u64)(2 * NW + w) * 64] : 0ULL;
+        t_lds[sub][w] = even_bits(x) | (even_bits(x >> 1) << 32);
+    }
+    __syncthreads();
+    int steps = valid ? tn + nblk - 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
+    const u32 key = fast_shw_ckr<G, NW, TW>(b, qn, tn, steps, t_lds[sub], nlo, nhi, ckpt + ((size_t)(item - lo) * CK) * NW + b, hcar + ((size_t)(item - lo) * SEGS) * NW + b);
+    const int bl = nblk > 0 ? nblk - 1 : 0;
+    const u32 bkey = (u32)__shfl((int)key, (lane / G) * G + bl);
+    int best = (int)(bkey >> 10);
+    const int end0 = (int)(bkey & 1023u) - bl;
+    const int k0 = (int)((double)(qn < tn ? qn : tn) * error * 1.1);     // edlib_ex.c:751
+    if (bkey == 0xffffffffu || best > k0) best = -1;
+    int err = 0;
+    if (best >= 0) { int ad = end0 + 1 - qn; if (ad < 0) ad = -ad; if (best < ad) err = 1; }
+    const bool owner = valid && b == 0;
+    if (owner) {
+        BlockResult br; br.dist = err ? -1 : best; br.endc = best >= 0 ? end0 : -1; br.err = err;
+        br.words = (u32)(nblk * tn);
+        results[item] = br;
+    }
+    {   // the work counters once per wave
+        unsigned long long w = owner ? (unsigned long long)(nblk * tn) : 0ULL, bs = owner ? (unsigned long long)(qn + tn) : 0ULL;
         for (int o = 32; o > 0; o >>= 1) { w += __shfl_xor(w, o); bs += __shfl_xor(bs, o); }
         if (lane == 0 && w) { atomicAdd(&stats[0], w); atomicAdd(&stats[1], bs); }
     }

@@ -459,8 +459,12 @@ k_bucket_base(const u32* __restrict__ bucket_kept, u32 nb, u64* __restrict__ buc
 // The kernel is a chain of short barrier-separated phases, latency bound at full occupancy, so the common case - a slice of at
 // most 2 T records of which at most kLdsTmp are kept - keeps its records in registers from the first load on and ranks inside
 // LDS; anything bigger reloads per phase and ranks through the global tmp array.
-constexpr int kLdsTmp = 2048;
-template <int T>
+// LT: offsets of a slice that are ranked inside LDS.  2048 (with the register path above) at E. coli size, 700 records per slice; a volume at
+// oc2mkdb's 2 Gbp cut has 7 600 per slice, every slice took the reload + global tmp path and this kernel was 50 of the build's 90 ms:
+// with LT = 8000 (64 KB of LDS per workgroup in all) such a slice still reads its records three times - coalesced - but groups and ranks
+// them in LDS.
+constexpr int kLdsTmp = 2048, kLdsTmpBig = 8000;
+template <int T, int LT = kLdsTmp>
 __global__ void __launch_bounds__(T)
 k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u32 max_occ, const u64* __restrict__ bucket_base, const u32* __restrict__ kept_tot,
              const u64* __restrict__ bucket_cbase, const u32* __restrict__ pres_tot, IdxWord* __restrict__ words, u64* __restrict__ compact,
@@ -472,7 +476,7 @@ k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u
     static_assert(kSlice / T == 8, "a thread owns the 8 table entries of one byte of an IdxWord");
     __shared__ u32 cnt[kSlice];      // occurrences per table entry of the slice
     __shared__ u32 cur[kSlice];      // start of the entry's group inside the slice, then its fill cursor
-    __shared__ u32 ltmp[kLdsTmp];    // the kept offsets of the slice, grouped by entry (small slices)
+    __shared__ u32 ltmp[LT];         // the kept offsets of the slice, grouped by entry (small slices)
     __shared__ u32 wtot[T / 64], ptot[T / 64];
     __shared__ u64 s_base, s_cbase;
     const u64 s = (u64)blockIdx.x + s0;
@@ -526,7 +530,7 @@ k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u
         for (int i = 0; i < E; ++i) { cur[threadIdx.x * E + i] = at; if (c[i]) compact[q++] = ((u64)c[i] << kOffsetBits) | (base + at); at += c[i]; }
     }
     __syncthreads();
-    if (small && kept_all <= (u32)kLdsTmp) {
+    if (small && kept_all <= (u32)LT) {
         // radix_sort is stable (hash_list_bucket_sort.c:134): offsets ascend inside a k-mer
         const u32 h0 = (u32)(r0 >> kOffsetBits) & (kSlice - 1), h1 = (u32)(r1 >> kOffsetBits) & (kSlice - 1);
         const u32 k0 = r0 != ~0ULL ? filtered_count(cnt[h0], max_occ) : 0u, k1 = r1 != ~0ULL ? filtered_count(cnt[h1], max_occ) : 0u;
@@ -536,6 +540,27 @@ k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u
         __syncthreads();        // cur[h] is now the END of the group
         if (k0) { const u32 st = cur[h0] - k0; u32 rank = 0; if (k0 > 1) for (u32 j = 0; j < k0; ++j) rank += ltmp[st + j] < p0; offset_list[base + st + rank] = (u64)p0; }
         if (k1) { const u32 st = cur[h1] - k1; u32 rank = 0; if (k1 > 1) for (u32 j = 0; j < k1; ++j) rank += ltmp[st + j] < p1; offset_list[base + st + rank] = (u64)p1; }
+        return;
+    }
+    if (kept_all <= (u32)LT) {
+        // a bigger slice whose kept offsets still fit LDS: the records come from global memory again, the groups and the ranks stay in LDS
+        for (u64 e = lo + threadIdx.x; e < hi; e += T) {
+            const u64 rec = part2[e];
+            const u32 h = (u32)(rec >> kOffsetBits) & (kSlice - 1);
+            if (filtered_count(cnt[h], max_occ)) ltmp[atomicAdd(&cur[h], 1u)] = (u32)(rec & kOffsetMask);
+        }
+        __syncthreads();
+        for (u64 e = lo + threadIdx.x; e < hi; e += T) {
+            const u64 rec = part2[e];
+            const u32 h = (u32)(rec >> kOffsetBits) & (kSlice - 1);
+            const u32 k = filtered_count(cnt[h], max_occ);
+            if (!k) continue;
+            const u32 p = (u32)(rec & kOffsetMask);
+            const u32 st = cur[h] - k;
+            u32 rank = 0;
+            if (k > 1) for (u32 j = 0; j < k; ++j) rank += ltmp[st + j] < p;
+            offset_list[base + st + rank] = (u64)p;
+        }
         return;
     }
     for (u64 e = lo + threadIdx.x; e < hi; e += T) {

@@ -82,6 +82,7 @@ u32 g_rc_listb;        // NECAT_RC_LISTB (default 1, needs NECAT_RC_CARRY): list
 u32 g_rc_ragged;       // NECAT_RC_RAGGED (default 1, needs NECAT_RC_CARRY): the ragged blocks of those rounds through k_myers_ckg + k_rcwalk2 as well (0: two-pass kernel + lane walk on a stream of their own)
 u32 g_ck_lds;          // NECAT_CK_LDS (bytes, default 0): dynamic LDS claimed by every workgroup (one wave) of k_myers_ck - caps how many of its waves a CU holds (160 KB / (1 KB + this)), leaving wave slots to the chains of the other streams (A/B measurements)
 u32 g_rc_merge;        // NECAT_RC_MERGE (default 1, needs NECAT_RC_RAGGED): the ragged list-A blocks of a big round through k_myers_ck's ragged fast path and the full blocks' walk launch; 0 = k_myers_ckg + a walk launch of their own on stream d
+u32 g_rc_fastb;        // NECAT_RC_FASTB (default 1): list B's checkpoint pass through k_myers_ckf (32-bit halves, bitop3, DPP carries); 0 = the general pass k_myers_ckg
 u32 g_rc_ww;           // NECAT_RC_WW (default 1): the recompute walk as k_rcwalk2w - four waves recompute 64 blocks, ONE wave walks them, a lane each; 0 = k_rcwalk2 (every lane of a quad walks its block)
 u32 g_rc_carry;        // NECAT_RC_CARRY (default 1): the recompute walk on an exact two-word window (k_myers_ck<CARRY> keeps the words' horizontal deltas, k_rcwalk2); 0 = the 4-word band window (k_rcwalk4)
 int g_rc_maxdist;      // NECAT_RC_MAXDIST (default and maximum kRcMaxDist = 160): full blocks of a larger distance take the old kernels (tests lower it)
@@ -111,6 +112,7 @@ void read_knobs()
     g_rc_carry = (u32)num("NECAT_RC_CARRY", 1);
     g_asm_rc = (u32)num("NECAT_ASM_RC", 1);
     g_rc_ww = (u32)num("NECAT_RC_WW", 1);
+    g_rc_fastb = (u32)num("NECAT_RC_FASTB", 1);
     g_rc_merge = (u32)num("NECAT_RC_MERGE", 1);
     g_ck_lds = (u32)num("NECAT_CK_LDS", 0);
     g_rc_listb = g_rc_carry ? (u32)num("NECAT_RC_LISTB", 1) : 0u;
@@ -557,7 +559,15 @@ int index_build_body(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
         if ((rc = buf_ensure(ctx, ctx->scratch[SC_TMPLIST], (n_local + 1) * 4))) return rc;
         // 512 threads per slice: 4 workgroups (32 waves) per CU instead of 5 x 4 waves with 256 - the kernel is a chain of short
         // barrier-separated phases and needs the waves to hide their latencies (10.6 -> 9.8 ms for the whole build)
-        hipLaunchKernelGGL(k_slice_emit<512>, dim3(nsl), dim3(512), 0, s, (const u64*)d_part2, (const u64*)d_sub, (u32)max_occ, (const u64*)d_bbase, (const u32*)d_kept,
+        // (slices of more than ~ 1000 records on average - volumes above 0.27 Gbp at k = 15 - rank in a bigger LDS buffer: index_kernels.h)
+        const int emit_big = getenv("NECAT_INDEX_EMIT_BIG") ? atoi(getenv("NECAT_INDEX_EMIT_BIG")) : -1;          // (tests force either instance)
+        const bool big = emit_big >= 0 ? emit_big != 0 : (nsl && n_local / nsl > 1000);
+        if (big)
+        hipLaunchKernelGGL((k_slice_emit<512, kLdsTmpBig>), dim3(nsl), dim3(512), 0, s, (const u64*)d_part2, (const u64*)d_sub, (u32)max_occ, (const u64*)d_bbase, (const u32*)d_kept,
+                           (const u64*)d_cbase, (const u32*)d_pres, (IdxWord*)ix->words, ix->compact,
+                           (u32*)ctx->scratch[SC_TMPLIST].p - base_add, ix->offset_list, s0, base_add, cbase_add);
+        else
+        hipLaunchKernelGGL((k_slice_emit<512, kLdsTmp>), dim3(nsl), dim3(512), 0, s, (const u64*)d_part2, (const u64*)d_sub, (u32)max_occ, (const u64*)d_bbase, (const u32*)d_kept,
                            (const u64*)d_cbase, (const u32*)d_pres, (IdxWord*)ix->words, ix->compact,
                            (u32*)ctx->scratch[SC_TMPLIST].p - base_add, ix->offset_list, s0, base_add, cbase_add);
         NECAT_CHECK_LAUNCH(ctx, "k_slice_emit");
@@ -887,11 +897,14 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
             hipLaunchKernelGGL(k_seed_collect, dim3(grid_for((u64)2 * n, 64)), dim3(64), 0, s, dref, drd, index_view(ix), (const u64*)ix->offset_list,
                                P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A, d_nblk, d_err);
         NECAT_CHECK_LAUNCH(ctx, "k_seed_collect");
+        static const bool fused_clear = !getenv("NECAT_SEED_CLEAR_KERNEL");        // (A/B: the slots cleared by a launch of their own, as in round 3)
         hipLaunchKernelGGL(k_seed_eval, dim3(2 * n), dim3(64), 0, s, dref, drd, P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A,
-                           (const i32*)d_nblk, d_nstrand, d_err);
+                           (const i32*)d_nblk, d_nstrand, d_err, fused_clear && P.debug_phase != 1 ? 1 : 0);
         NECAT_CHECK_LAUNCH(ctx, "k_seed_eval");
-        hipLaunchKernelGGL(k_seed_clear, dim3(2 * n), dim3(64), 0, s, (const SeedMeta*)d_meta, n, A, (const i32*)d_nblk);
-        NECAT_CHECK_LAUNCH(ctx, "k_seed_clear");
+        if (!fused_clear || P.debug_phase == 1) {
+            hipLaunchKernelGGL(k_seed_clear, dim3(2 * n), dim3(64), 0, s, (const SeedMeta*)d_meta, n, A, (const i32*)d_nblk);
+            NECAT_CHECK_LAUNCH(ctx, "k_seed_clear");
+        }
         hipLaunchKernelGGL(k_seed_finish, dim3(grid_for(n, 64)), dim3(64), 0, s, P, (const SeedMeta*)d_meta, n, A, (const i32*)d_nstrand, d_ncand);
         NECAT_CHECK_LAUNCH(ctx, "k_seed_finish");
         std::vector<i32> nc(n);
@@ -1171,6 +1184,10 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
             NECAT_HIP(ctx, hipEventRecord(c.b0[slot], sb));
             for (u32 lo = 0; lo < nB; lo += rc_chunk) {
                 const u32 hi = std::min<u64>((u64)lo + rc_chunk, (u64)gB * 64), cn = std::min(hi, nB) - lo;
+                if (g_rc_fastb)
+                hipLaunchKernelGGL((k_myers_ckf<kWordsB, kTWordsB, kColsB, 16>), dim3((cn + 3) / 4), dim3(64), 0, sb, itB, nB, d_nB, 0u, (const u64*)c.fragB[slot], ck, hcar, X.error,
+                                   c.resB[slot], X.stats, epoch, lo, hi);
+                else
                 hipLaunchKernelGGL((k_myers_ckg<kWordsB, kTWordsB, kColsB, 16>), dim3((cn + 3) / 4), dim3(64), 0, sb, itB, nB, d_nB, 0u, (const u64*)c.fragB[slot], ck, hcar, X.error,
                                    c.resB[slot], X.stats, epoch, lo, hi);
                 if (lo + rc_chunk >= nB) NECAT_HIP(ctx, hipEventRecord(c.b1[slot], sb));
@@ -3104,7 +3121,12 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
                 u64* hcar = (u64*)((char*)ctx->scratch[SC_EXT_CKPT].p + (size_t)g * 64 * per_ck);
                 WalkOut* wo = (WalkOut*)ctx->scratch[SC_EXT_WOUT].p;
                 const u32 fl = epoch | (1u << 27);
+                const bool batch_fast = atoi(getenv("NECAT_BATCH_RC")) == 2;       // .. through the fast general pass k_myers_ckf (both geometries)
                 if (full) {
+                    if (batch_fast)
+                    hipLaunchKernelGGL((k_myers_ckf<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag, ck, hcar, error,
+                                       d_res, d_stats, epoch, 0u, g * 64);
+                    else
                     hipLaunchKernelGGL((k_myers_ckg<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag, ck, hcar, error,
                                        d_res, d_stats, epoch, 0u, g * 64);
                     NECAT_HIP(ctx, hipEventRecord(ctx->ev[5], s));
@@ -3113,7 +3135,10 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
                     hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, true, 5>), dim3(g), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag,
                                        (const char*)d_slabs, slab, (const BlockResult*)d_res, d_ops, (ExtTask*)nullptr, 1, d_nops, d_err, ExtLists(), fl, 0u, (const WalkOut*)wo);
                 } else {
-                    if (atoi(getenv("NECAT_BATCH_RC")) == 64)
+                    if (batch_fast)
+                    hipLaunchKernelGGL((k_myers_ckf<kWordsB, kTWordsB, kColsB, 16>), dim3((m + 3) / 4), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag, ck, hcar, error,
+                                       d_res, d_stats, epoch, 0u, g * 64);
+                    else if (atoi(getenv("NECAT_BATCH_RC")) == 64)
                     hipLaunchKernelGGL((k_myers_ckg<kWordsB, kTWordsB, kColsB, 64>), dim3(m), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag, ck, hcar, error,
                                        d_res, d_stats, epoch, 0u, g * 64);
                     else

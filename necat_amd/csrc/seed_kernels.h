@@ -497,7 +497,7 @@ struct LdsAdder { int* s; NECAT_D void operator()(int j) { atomicAdd(&s[j], 1); 
 #endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NECAT_SEED_WAVES, NECAT_SEED_WAVES)))
 k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict__ order, const SeedMeta* __restrict__ meta, u32 n,
-            SeedArenas A, const i32* __restrict__ nblk_in, i32* __restrict__ n_strand, int* __restrict__ err_flag)
+            SeedArenas A, const i32* __restrict__ nblk_in, i32* __restrict__ n_strand, int* __restrict__ err_flag, int clear_ht)
 {
     // LDS per wave: 6 KB, so that the CU holds as many of these latency-bound waves as their registers allow.
     // votes (phases A - C) and the gather's slot table (phase D) share one buffer
@@ -695,6 +695,14 @@ k_seed_eval(DevVolume ref, DevVolume reads, SeedParams P, const u32* __restrict_
         if (tot > 3000000) { for (int q = 0; q < 10; ++q) atomicAdd(&g_seed_prof[16 + q], pacc[q]); atomicAdd(&g_seed_prof[26], 1ULL); }     // what the long waves do
     }
 #endif
+    // clear_WordFindData (word_finder.c:40-52): the hash slots this strand used go back to empty, so the arena is all-empty again when the
+    // call ends (what k_seed_clear did as a launch of its own, 0.18 ms per pass; nothing after this point probes the table)
+    if (clear_ht) {
+        __syncthreads();
+        const SeedScratch S = seed_scratch(A, m, strand0);
+        const int nb = nblk_in[2 * (u64)i + strand0];
+        for (int b = lane; b < nb; b += 64) S.ht[S.pool[b].slot] = kHtEmpty;
+    }
     if (lane == 0) {
         if (failed) atomicExch(err_flag, 1);
         n_strand[blockIdx.x] = failed ? 0 : n_out;

@@ -26,8 +26,12 @@ def multi(tmp_path_factory):
     return d, rs, nv
 
 
-def test_index_matches_oracle(ctx, small):
-    """k = 8: direct passes; k = 11..13: bucket partition + LDS slices (16..256 buckets); cutoffs 500 / 50 / 1."""
+@pytest.mark.parametrize("emit_big", [None, "1", "0"])
+def test_index_matches_oracle(ctx, small, monkeypatch, emit_big):
+    """k = 8: direct passes; k = 11..13: bucket partition + LDS slices (16..256 buckets); cutoffs 500 / 50 / 1.  emit_big: the slice kernel's
+    instance with the big LDS ranking buffer (what a volume above 0.27 Gbp takes by itself) forced on / off."""
+    if emit_big is not None:
+        monkeypatch.setenv("NECAT_INDEX_EMIT_BIG", emit_big)
     d, rs = small
     vol = ctx.load_volume(os.path.join(d, "vol0"))
     for k, q in ((11, 50), (13, 500), (8, 500), (12, 1)):
@@ -129,7 +133,7 @@ def _random_pairs(rng, n, qlo, qhi, err):
     return np.concatenate(seqs), qo, ql, to, tl
 
 
-@pytest.mark.parametrize("path", ["band", "recompute", "recompute_quad"])
+@pytest.mark.parametrize("path", ["band", "recompute", "recompute_quad", "recompute_fast"])
 def test_edlib_blocks_match_oracle(ctx, monkeypatch, path):
     """The dominant kernel in isolation: distance, end column and the full edit path, including
     ragged sizes (1..794), failures (too divergent) and exact 512 x 512 blocks (the FULL kernel).
@@ -137,7 +141,7 @@ def test_edlib_blocks_match_oracle(ctx, monkeypatch, path):
     k_rcwalk2w: four waves recompute 64 blocks, one wave walks them) at both geometries (8 words / 13 words per block); recompute_quad:
     the same through k_rcwalk2 (every quad recomputes and walks its own block, NECAT_RC_WW=0)."""
     if path != "band":
-        monkeypatch.setenv("NECAT_BATCH_RC", "1")
+        monkeypatch.setenv("NECAT_BATCH_RC", "2" if path == "recompute_fast" else "1")          # 2: the checkpoint pass through k_myers_ckf (fast_shw_ckr at 8 and 16 lanes per block)
     if path == "recompute_quad":
         from necat_amd import capi
         monkeypatch.setenv("NECAT_RC_WW", "0")
@@ -477,7 +481,7 @@ def test_capped_band_pool_runs_lists_in_chunks(ctx, small, tmp_path, monkeypatch
                                   "NECAT_RCWALK=1 NECAT_RC_POOL_MB=1", "NECAT_RCWALK=1 NECAT_RC_RAGGED=0 NECAT_TAIL_FUSED=0",
                                   "NECAT_RC_LISTB=0", "NECAT_RC_LISTB=1 NECAT_TAIL_FUSED=0 NECAT_RC_POOL_MB=1",
                                   "NECAT_RC_WW=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_MERGE=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0",
-                                  "NECAT_RC_MERGE=1 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0 NECAT_RC_POOL_MB=1"])
+                                  "NECAT_RC_MERGE=1 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0 NECAT_RC_POOL_MB=1", "NECAT_RC_FASTB=0 NECAT_TAIL_FUSED=0"])
 def test_alternative_kernel_paths_give_the_same_records(ctx, small, monkeypatch, knob):
     """Code paths kept behind a knob (the lane-0 chain DP, the 16-block / 4-lane NW kernel, the restated walk, the general DP
     path without the full-block fast path, lane-per-strand seed collection, every round / no round through the one-launch
