@@ -676,10 +676,11 @@ template <int NW, int TW, int COLS, int MAXOPS>
 __global__ void __launch_bounds__(256)
 k_rcwalk2w(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, const ulonglong2* __restrict__ ckpt,
            const u64* __restrict__ hcar, const BlockResult* __restrict__ results, const ExtTask* __restrict__ tasks, int keep_cols, int tail_match_len, u8* __restrict__ ops_pool,
-           WalkOut* __restrict__ wout, unsigned long long* __restrict__ stats, int* __restrict__ err_flag, u32 epoch, u32 lo, u32 hi)
+           WalkOut* __restrict__ wout, unsigned long long* __restrict__ stats, int* __restrict__ err_flag, u32 epoch, u32 lo, u32 hi, u32 opts)
 {
     constexpr int FW = 2 * NW + TW, SEG = kRcSeg, HALF = SEG / 2, CK = RcGeom<COLS>::kCk, SEGS = RcGeom<COLS>::kSeg;
     static_assert(COLS < 4096, "the hand-over word keeps r and c in 12 bits each");
+    const bool pf = (opts & 1u) != 0;                                 // prefetch the next segment's inputs (NECAT_RC_PREFETCH)
     __shared__ ulonglong2 slices[SEG][64];
     const ListView lv = list_view(n_host, n_dev, capA);
     const bool all = ((epoch >> 27) & 1u) != 0, ragged = ((epoch >> 26) & 1u) != 0;
@@ -725,6 +726,13 @@ k_rcwalk2w(const BlockItem* __restrict__ items, u32 n_host, const u32* __restric
     int wcur = -1; u32 nlo_l = 0, nlo_h = 0, nhi_l = 0, nhi_h = 0;
     int segcur = -1; u32 tlo = 0, thi = 0;
     u32 words_done = 0;
+    // What the NEXT segment will need, fetched a whole segment ahead (NECAT_RC_PREFETCH, `pf`): the walk leaves a segment through its first
+    // column almost always (the next segment is seg - 1) and it moves up about as many rows as it crossed columns, so the words it will stand
+    // in are this segment's pair or the pair one word up - the checkpoints / deltas / query planes of both, and the target word of seg - 1, are
+    // loaded while this segment is recomputed and walked, and used if the guess was right (otherwise loaded then, as without the prefetch).
+    int p_seg = -2, p_w = -100000;                                   // the prefetched segment, and the word p_ck0 belongs to (p_ck1: p_w - 1)
+    u64 p_ck0x = 0, p_ck0y = 0, p_ck1x = 0, p_ck1y = 0;               // (scalars, selected: arrays indexed by `pi` / vector temporaries end up in scratch)
+    u64 p_hc0 = 0, p_hc1 = 0, p_tg = 0, p_qa = 0, p_qb = 0;           // (p_hc: deltas of the word above p_ck's; p_qa / p_qb: planes of word p_w - 1)
     while (!all_fin) {
         {   // ---- recompute (k_rcwalk2's, with q -> rbk in the slices)
             const int seg = c >> 5, c0 = seg * SEG;
@@ -733,19 +741,37 @@ k_rcwalk2w(const BlockItem* __restrict__ items, u32 n_host, const u32* __restric
             const int nc0 = c - c0 - HALF * h + 1;
             const int nc = (fin || w < 0 || nc0 < 0) ? 0 : (nc0 > HALF ? HALF : nc0);
             const bool live = nc > 0;
+            const bool hit = pf && seg == p_seg && (w == p_w || w == p_w - 1);
+            const int pi = w == p_w ? 0 : 1;
             if (live && w != wcur) {
-                const u64 a = fr[(u64)w * 64], bq = fr[(u64)(NW + w) * 64];
+                u64 a, bq;
+                if (hit && pi == 1) { a = p_qa; bq = p_qb; } else { a = fr[(u64)w * 64]; bq = fr[(u64)(NW + w) * 64]; }
                 nlo_l = (u32)a; nlo_h = (u32)(a >> 32); nhi_l = (u32)bq; nhi_h = (u32)(bq >> 32); wcur = w;
             }
             FastWord wd; wd.Pv = ~0ULL; wd.Mv = 0ULL; wd.pubP = 0x80000000u; wd.pubM = 0u;
             const int slot = 2 * seg + h - 1;
-            if (live && slot >= 0) { const ulonglong2 v = ckpt[((size_t)(item - lo) * CK + (size_t)slot) * NW + (size_t)w]; wd.Pv = v.x; wd.Mv = v.y; }
+            if (live && slot >= 0) {
+                if (hit) { wd.Pv = pi ? p_ck1x : p_ck0x; wd.Mv = pi ? p_ck1y : p_ck0y; }
+                else { const ulonglong2 v = ckpt[((size_t)(item - lo) * CK + (size_t)slot) * NW + (size_t)w]; wd.Pv = v.x; wd.Mv = v.y; }
+            }
             u32 hp = 0xffffffffu, hm = 0u;
-            if (live && k == 0 && w > 0) { const u64 v = hcar[((size_t)(item - lo) * SEGS + (size_t)seg) * NW + (size_t)(w - 1)]; hp = (u32)v; hm = (u32)(v >> 32); }
+            if (live && k == 0 && w > 0) { const u64 v = hit ? (pi ? p_hc1 : p_hc0) : hcar[((size_t)(item - lo) * SEGS + (size_t)seg) * NW + (size_t)(w - 1)]; hp = (u32)v; hm = (u32)(v >> 32); }
             if (!fin && seg != segcur) {
-                const u64 x = fr[(u64)(2 * NW + seg) * 64];
+                const u64 x = (pf && seg == p_seg) ? p_tg : fr[(u64)(2 * NW + seg) * 64];
                 tlo = (u32)even_bits(x); thi = (u32)even_bits(x >> 1); segcur = seg;
             }
+            if (pf && !fin && seg > 0) {
+                // (issued now, consumed a segment later: the loads fly under this segment's recompute, both barriers and the walk)
+                p_seg = seg - 1; p_w = w;
+                const int ns = 2 * (seg - 1) + h - 1;
+                const size_t ib = (size_t)(item - lo);
+                if (ns >= 0 && w >= 0) { const ulonglong2 v = ckpt[(ib * CK + (size_t)ns) * NW + (size_t)w]; p_ck0x = v.x; p_ck0y = v.y; }
+                if (ns >= 0 && w >= 1) { const ulonglong2 v = ckpt[(ib * CK + (size_t)ns) * NW + (size_t)(w - 1)]; p_ck1x = v.x; p_ck1y = v.y; }
+                if (k == 0 && w >= 1) p_hc0 = hcar[(ib * SEGS + (size_t)(seg - 1)) * NW + (size_t)(w - 1)];
+                if (k == 0 && w >= 2) p_hc1 = hcar[(ib * SEGS + (size_t)(seg - 1)) * NW + (size_t)(w - 2)];
+                p_tg = fr[(u64)(2 * NW + seg - 1) * 64];
+                if (w >= 1) { p_qa = fr[(u64)(w - 1) * 64]; p_qb = fr[(u64)(NW + w - 1) * 64]; }
+            } else p_seg = -2;
             hp <<= HALF * h; hm <<= HALF * h;
             for (int s = 0; s < HALF + 1; ++s) {
                 const u32 xp = dpp_quad_from_below(wd.pubP), xm = dpp_quad_from_below(wd.pubM);
