@@ -836,6 +836,13 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
+    if single and os.environ.get("NECAT_BENCH_ONE_DEVICE") != "1" and args.transport in ("auto", "rccl"):
+        # ranks on distinct devices: the line is only worth printing if the data path really was RCCL over the links and every rank received
+        # its peers' index slices - otherwise fail loudly instead of reporting a number measured on some other path
+        bad = [r for r in per_rank if r.get("transport") != "rccl" or not r.get("index_allgather_bytes")]
+        if bad:
+            raise SystemExit("bench.py: N = %d on distinct devices, but rank(s) %s did not run the RCCL data path (transport / index all-gather bytes: %s)"
+                             % (world, [r.get("rank") for r in bad], [(r.get("transport"), r.get("index_allgather_bytes")) for r in bad]))
     K = max(1, args.steps)
     roofline = roofline_report(agg)
     out = {

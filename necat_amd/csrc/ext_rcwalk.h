@@ -733,7 +733,16 @@ k_rcwalk2w(const BlockItem* __restrict__ items, u32 n_host, const u32* __restric
     int p_seg = -2, p_w = -100000;                                   // the prefetched segment, and the word p_ck0 belongs to (p_ck1: p_w - 1)
     u64 p_ck0x = 0, p_ck0y = 0, p_ck1x = 0, p_ck1y = 0;               // (scalars, selected: arrays indexed by `pi` / vector temporaries end up in scratch)
     u64 p_hc0 = 0, p_hc1 = 0, p_tg = 0, p_qa = 0, p_qb = 0;           // (p_hc: deltas of the word above p_ck's; p_qa / p_qb: planes of word p_w - 1)
+    // (opts bits 1 / 2, timing experiments only: the walk of a segment done twice - once into a sink - / the recompute of a segment done twice: what
+    // each phase costs is the difference to the plain run, profiles/NOTES_r04.md 3)
+    // Compiled in only with -DNECAT_RC_TIMING (their registers cost the kernel a wave per SIMD).
+#ifdef NECAT_RC_TIMING
+    int sink = 0;
+#endif
     while (!all_fin) {
+#ifdef NECAT_RC_TIMING
+        for (int rrep = (opts & 4u) ? 0 : 1; rrep < 2; ++rrep)
+#endif
         {   // ---- recompute (k_rcwalk2's, with q -> rbk in the slices)
             const int seg = c >> 5, c0 = seg * SEG;
             const int rb = r - 63, sh = rb & 63, w1 = r >> 6;
@@ -805,6 +814,22 @@ k_rcwalk2w(const BlockItem* __restrict__ items, u32 n_host, const u32* __restric
             const int c0 = (wc >> 5) * SEG, rb = wr - 63;
             const bool lean = !__any(!wfin && (!hit || store));
             bool out = false;
+#ifdef NECAT_RC_TIMING
+            if ((opts & 2u) && !wfin) {
+                int r2 = wr, c2 = wc, n2 = 0;
+                for (;;) {
+                    if (c2 < c0 || r2 < rb) break;
+                    const ulonglong2 v = slices[c2 - c0][lane];
+                    const int bit = r2 - rb;
+                    const u32 a = (u32)(v.x >> bit) & 1u, b = (u32)(v.y >> bit) & 1u;
+                    const int drow = 1 - (int)(b & (a ^ 1u)), dcol = 1 - (int)(a & (b ^ 1u));
+                    ++n2; sink += (int)((a | b) ^ 1u);
+                    r2 -= drow; c2 -= dcol;
+                    if ((r2 | c2) < 0) break;
+                }
+                sink += n2;
+            }
+#endif
             if (!wfin) {
                 if (lean) {
                     for (;;) {
@@ -856,6 +881,9 @@ k_rcwalk2w(const BlockItem* __restrict__ items, u32 n_host, const u32* __restric
             r = (int)(word & 0xfffu); c = (int)((word >> 12) & 0xfffu);
         }
     }
+#ifdef NECAT_RC_TIMING
+    if (sink == 0x7fffffff) atomicExch(err_flag, 21);             // (keeps the sink alive; never true)
+#endif
     for (int o = 32; o > 0; o >>= 1) words_done += (u32)__shfl_xor((int)words_done, o);
     if (lane == 0 && words_done) { atomicAdd(&stats[0], (unsigned long long)words_done); atomicAdd(&stats[4], (unsigned long long)words_done); }
 }

@@ -83,6 +83,7 @@ u32 g_rc_ragged;       // NECAT_RC_RAGGED (default 1, needs NECAT_RC_CARRY): the
 u32 g_ck_lds;          // NECAT_CK_LDS (bytes, default 0): dynamic LDS claimed by every workgroup (one wave) of k_myers_ck - caps how many of its waves a CU holds (160 KB / (1 KB + this)), leaving wave slots to the chains of the other streams (A/B measurements)
 u32 g_rc_merge;        // NECAT_RC_MERGE (default 1, needs NECAT_RC_RAGGED): the ragged list-A blocks of a big round through k_myers_ck's ragged fast path and the full blocks' walk launch; 0 = k_myers_ckg + a walk launch of their own on stream d
 u32 g_rc_fastb;        // NECAT_RC_FASTB (default 1): list B's checkpoint pass through k_myers_ckf (32-bit halves, bitop3, DPP carries); 0 = the general pass k_myers_ckg
+u32 g_rc_dbg;          // NECAT_RC_DBG (timing only): 2 = k_rcwalk2w walks every segment twice (once into a sink), 4 = recomputes every segment twice
 u32 g_rc_prefetch;     // NECAT_RC_PREFETCH (default 0: measured 0.4 ms per step SLOWER, profiles/NOTES_r04.md 3): k_rcwalk2w loads the next segment's checkpoints / deltas / planes a segment ahead
 u32 g_rc_ww;           // NECAT_RC_WW (default 1): the recompute walk as k_rcwalk2w - four waves recompute 64 blocks, ONE wave walks them, a lane each; 0 = k_rcwalk2 (every lane of a quad walks its block)
 u32 g_rc_carry;        // NECAT_RC_CARRY (default 1): the recompute walk on an exact two-word window (k_myers_ck<CARRY> keeps the words' horizontal deltas, k_rcwalk2); 0 = the 4-word band window (k_rcwalk4)
@@ -95,7 +96,7 @@ int g_dbg;             // NECAT_DBG: profiling-only variants of the lane-per-blo
 template <int NW, int TW, int COLS, int MAXOPS, class... A>
 static void launch_rcwalk2(u32 nitems, hipStream_t s, A... a)
 {
-    if (g_rc_ww) hipLaunchKernelGGL((k_rcwalk2w<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(256), 0, s, a..., g_rc_prefetch);
+    if (g_rc_ww) hipLaunchKernelGGL((k_rcwalk2w<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(256), 0, s, a..., g_rc_prefetch | g_rc_dbg);
     else hipLaunchKernelGGL((k_rcwalk2<NW, TW, COLS, MAXOPS>), dim3((nitems + 15) / 16), dim3(64), 0, s, a...);
 }
 
@@ -114,6 +115,7 @@ void read_knobs()
     g_asm_rc = (u32)num("NECAT_ASM_RC", 1);
     g_rc_ww = (u32)num("NECAT_RC_WW", 1);
     g_rc_prefetch = (u32)num("NECAT_RC_PREFETCH", 0);
+    g_rc_dbg = (u32)num("NECAT_RC_DBG", 0) & 6u;
     g_rc_fastb = (u32)num("NECAT_RC_FASTB", 1);
     g_rc_merge = (u32)num("NECAT_RC_MERGE", 1);
     g_ck_lds = (u32)num("NECAT_CK_LDS", 0);
