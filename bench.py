@@ -347,7 +347,7 @@ def oc2asmpm_program(genome, threads, tmp):
     walls = []
     for _ in range(2):
         t0 = time.time()
-        r = subprocess.run([build.OC2ASMPM] + args + ["-t", str(threads), wrk, "0", mine], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, NECAT_TRACE="2", NECAT_CLI_TRACE="1"))
+        r = subprocess.run([build.OC2ASMPM] + args + ["-t", str(threads), wrk, "0", mine], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, NECAT_TRACE="2", NECAT_CLI_TRACE="1"))      # (neither adds a synchronisation point)
         walls.append(round(time.time() - t0, 2))
         if r.returncode != 0:
             return dict(res, error=r.stderr[-300:])

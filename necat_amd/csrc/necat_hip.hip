@@ -191,6 +191,14 @@ void necat_ctx_destroy(necat_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (g_trace & 2) {        // what the context holds at its end: the arenas of 64 MB and more (ScratchId : MB)
+        size_t sum = 0; char own[1024]; int at = 0; own[0] = 0;
+        for (int i = 0; i < (int)(sizeof ctx->scratch / sizeof ctx->scratch[0]); ++i) {
+            sum += ctx->scratch[i].cap;
+            if (ctx->scratch[i].cap >= ((size_t)64 << 20) && at < 980) at += snprintf(own + at, sizeof own - (size_t)at, " %d:%zu", i, ctx->scratch[i].cap >> 20);
+        }
+        fprintf(stderr, "[necat] context arenas at destroy: %zu MB in all; [id:MB]%s\n", sum >> 20, own);
+    }
     if (ctx->stream_copy) (void)hipStreamSynchronize(ctx->stream_copy);
     for (auto& b : ctx->scratch) if (b.p) (void)hipFree(b.p);
     for (auto& b : ctx->idx_cache) if (b.p) (void)hipFree(b.p);
@@ -1495,8 +1503,16 @@ int ext_streams(necat_ctx* ctx)
     // duration is its own work, not its wait for wave slots behind the other chains (tools/r04_profile.sh: the exclusive-time table)
     static const bool serial = getenv("NECAT_SERIAL") && atoi(getenv("NECAT_SERIAL"));
     if (serial && !ctx->stream_a) { ctx->stream_a = ctx->stream_b = ctx->stream_c = ctx->stream_d = ctx->stream; ctx->serial_streams = true; }
-    for (hipStream_t* st : {&ctx->stream_a, &ctx->stream_b, &ctx->stream_c, &ctx->stream_d, &ctx->stream_copy})
-        if (!*st && hipStreamCreate(st) != hipSuccess) return set_err(ctx, NECAT_ERR_DEVICE, "hipStreamCreate failed");
+    // NECAT_STREAM_PRIO=1: the streams of list B and of the ragged / wide blocks at the device's highest priority - their kernels are small and sit
+    // behind list A's issue-bound launches (k_ext_frag<13,25>: 0.03 ms alone, 0.5 ms in the round), which delays the chain that trails list A
+    static const bool prio = getenv("NECAT_STREAM_PRIO") && atoi(getenv("NECAT_STREAM_PRIO"));
+    int least = 0, greatest = 0;
+    if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+    for (hipStream_t* st : {&ctx->stream_a, &ctx->stream_b, &ctx->stream_c, &ctx->stream_d, &ctx->stream_copy}) {
+        if (*st) continue;
+        const bool high = prio && greatest != least && (st == &ctx->stream_b || st == &ctx->stream_c || st == &ctx->stream_d);
+        if ((high ? hipStreamCreateWithPriority(st, hipStreamDefault, greatest) : hipStreamCreate(st)) != hipSuccess) return set_err(ctx, NECAT_ERR_DEVICE, "hipStreamCreate failed");
+    }
     return NECAT_OK;
 }
 
@@ -1811,9 +1827,11 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
     // checkpoint pool of the recompute path: per block 128 slots x 32 words x 16 B + 64 x 32 x 8 B of deltas = 80 KB (list A), 154 KB (list B)
     constexpr size_t kCkA = (size_t)RcGeom<kAsmBlock>::kCk * kAsmWordsA * 16, kHcA = (size_t)RcGeom<kAsmBlock>::kSeg * kAsmWordsA * 8;
     constexpr size_t kCkB = (size_t)RcGeom<kAsmCols>::kCk * kAsmWords * 16, kHcB = (size_t)RcGeom<kAsmCols>::kSeg * kAsmWords * 8;
-    const size_t rc_pool = std::max<size_t>(g_rc_pool, (size_t)4 << 30);
-    const u32 rc_chunkA = (u32)std::max<size_t>(64, std::min<size_t>((size_t)groups * 64, (rc_pool / (kCkA + kHcA)) & ~(size_t)63));
-    const u32 rc_chunkB = (u32)std::max<size_t>(64, std::min<size_t>((size_t)groups * 64, (rc_pool / (kCkB + kHcB)) & ~(size_t)63));
+    // (2 GB + 1 GB by default, NECAT_ASM_RC_POOL_MB: 26 k list-A / 6.8 k list-B blocks per launch still are 13 k / 6.8 k waves, and the 2 x 9 GB the
+    // extension stage's cap allowed were most of what this short-lived program mapped - profiles/NOTES_r04.md 4)
+    static const size_t asm_pool = (size_t)std::max<unsigned long long>(256, getenv("NECAT_ASM_RC_POOL_MB") ? strtoull(getenv("NECAT_ASM_RC_POOL_MB"), nullptr, 10) : 2048ULL) << 20;
+    const u32 rc_chunkA = (u32)std::max<size_t>(64, std::min<size_t>((size_t)groups * 64, (asm_pool / (kCkA + kHcA)) & ~(size_t)63));
+    const u32 rc_chunkB = (u32)std::max<size_t>(64, std::min<size_t>((size_t)groups * 64, ((asm_pool / 2) / (kCkB + kHcB)) & ~(size_t)63));
     // (the recompute path runs the two lists of a round side by side on two streams: list B has buffers of its own)
     if (g_asm_rc) {
         if ((rc = ext_streams(ctx)) ||
@@ -2142,9 +2160,8 @@ int necat_asm_plan_batch(necat_ctx* ctx, const necat_index* ix, const necat_volu
     int rc;
     const auto t_begin = std::chrono::steady_clock::now();
     auto t_prev = t_begin;
-    auto tick = [&](const char* what) {
-        if (!(g_trace & 2)) return;
-        (void)hipStreamSynchronize(s);
+    auto tick = [&](const char* what) {          // (host clock between the calls' own synchronisation points; NECAT_TRACE=4 - it must not add any: the chunks overlap)
+        if (!(g_trace & 4)) return;
         const auto now = std::chrono::steady_clock::now();
         fprintf(stderr, "[necat] asm plan %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
         t_prev = now;
@@ -2177,15 +2194,17 @@ int necat_asm_plan_batch(necat_ctx* ctx, const necat_index* ix, const necat_volu
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](u32 a, u32 b) { return std::max(hits[2 * (size_t)a], hits[2 * (size_t)a + 1]) > std::max(hits[2 * (size_t)b], hits[2 * (size_t)b + 1]); });
     // (the pool of 384-byte blocks is sized by the hit counts, an upper bound several times the blocks really touched: the budget is what keeps a
-    // chunk inside HBM - 32 M blocks = 12.3 GB by default, never more than 40 % of the memory that is free now.  Fewer, larger chunks are faster -
-    // a chunk is as long as its longest read's walk: 100 Mbp of corrected reads take 0.30 s in 5 chunks of 64 M, 0.64 s in 20 of 16 M - but a
-    // short-lived process pays for the memory it maps: the first 30 GB of arenas of a process on a fresh box took 0.9 s, profiles/NOTES_r04.md)
-    u64 budget_blocks = getenv("NECAT_ASM_VOTE_BUDGET") ? std::max<u64>(1024, strtoull(getenv("NECAT_ASM_VOTE_BUDGET"), nullptr, 10)) : (u64)32 << 20;
+    // chunk inside HBM.  A chunk's vote kernels are as long as the walk of its heaviest read, so the chunks run on TWO arena sets and two streams:
+    // chunk i + 1's vote kernels are in flight while chunk i's tail finishes and its range stage runs.  16 M blocks = 6 GB per set by default - a
+    // short-lived process pays for the device memory it maps (the first 30 GB of arenas of a process on a fresh box took 0.9 s,
+    // profiles/NOTES_r04.md 4) - never more than 20 % of the memory that is free now)
+    u64 budget_blocks = getenv("NECAT_ASM_VOTE_BUDGET") ? std::max<u64>(1024, strtoull(getenv("NECAT_ASM_VOTE_BUDGET"), nullptr, 10)) : (u64)16 << 20;
     {
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr) budget_blocks = std::max<u64>(1 << 16, std::min<u64>(budget_blocks, (u64)(fr * 0.4) / sizeof(VBlock)));
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr) budget_blocks = std::max<u64>(1 << 16, std::min<u64>(budget_blocks, (u64)(fr * 0.2) / sizeof(VBlock)));
     }
-    static const u64 budget_seeds = getenv("NECAT_ASM_SEED_BUDGET") ? std::max<u64>(1024, strtoull(getenv("NECAT_ASM_SEED_BUDGET"), nullptr, 10)) : (u64)96 << 20;
+    static const u64 budget_seeds = getenv("NECAT_ASM_SEED_BUDGET") ? std::max<u64>(1024, strtoull(getenv("NECAT_ASM_SEED_BUDGET"), nullptr, 10)) : (u64)32 << 20;
+    static const bool overlap = !getenv("NECAT_ASM_NO_OVERLAP");            // (A/B: one arena set, one stream, chunk after chunk)
     VoteParams P; P.k = opt->kmer_size; P.bc = opt->scan_window; P.read_start_id = read_start_id; P.ref_start_id = ref_start_id; P.num_extended = NE;
     std::vector<std::vector<necat_asm_plan>> per_read(nreads);
     u64 tot_pairs = 0, tot_seeds = 0, tot_plans = 0;
@@ -2193,6 +2212,8 @@ int necat_asm_plan_batch(necat_ctx* ctx, const necat_index* ix, const necat_volu
     // allocated again each time)
     auto both = [&](u32 r) { return (u64)hits[2 * (size_t)r] + hits[2 * (size_t)r + 1] + 2; };
     std::vector<u32> chunk_end;
+    static const ScratchId kSet[2][7] = {{SC_ASM_VMETA, SC_ASM_VHT, SC_ASM_VPOOL, SC_ASM_VOUT, SC_ASM_SEL, SC_ASM_RIDX, SC_ASM_RNEXT},
+                                         {SC_ASM_VMETA2, SC_ASM_VHT2, SC_ASM_VPOOL2, SC_ASM_VOUT2, SC_ASM_SEL2, SC_ASM_RIDX2, SC_ASM_RNEXT2}};
     {
         u64 mx_n = 0, mx_ht = 0, mx_pool = 0, mx_tab = 0, mx_next = 0;
         for (u32 p0 = 0; p0 < nreads;) {
@@ -2210,19 +2231,31 @@ int necat_asm_plan_batch(necat_ctx* ctx, const necat_index* ix, const necat_volu
             p0 = h1;
         }
         const size_t meta_bytes = (size_t)mx_n * (sizeof(VoteMeta) + sizeof(ReadIdxMeta) + 4 /* order */ + 8 /* nblk */ + 8 /* nstrand */ + 4 /* nplan */) + 512;
-        if ((rc = buf_ensure(ctx, ctx->scratch[SC_ASM_VMETA], meta_bytes)) ||
-            (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_VHT], mx_ht * 8)) ||
-            (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_VPOOL], mx_pool * sizeof(VBlock))) ||
-            (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_VOUT], mx_pool * sizeof(VoteCand))) ||
-            (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_SEL], (size_t)mx_n * NE * (sizeof(VoteCand) + sizeof(AsmPlanDev)))) ||
-            (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_RIDX], mx_tab * 4)) ||
-            (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_RNEXT], mx_next * 4))) return fail(rc);
+        for (int e = 0; e < ((overlap && chunk_end.size() > 1) ? 2 : 1); ++e)
+            if ((rc = buf_ensure(ctx, ctx->scratch[kSet[e][0]], meta_bytes)) ||
+                (rc = buf_ensure(ctx, ctx->scratch[kSet[e][1]], mx_ht * 8)) ||
+                (rc = buf_ensure(ctx, ctx->scratch[kSet[e][2]], mx_pool * sizeof(VBlock))) ||
+                (rc = buf_ensure(ctx, ctx->scratch[kSet[e][3]], mx_pool * sizeof(VoteCand))) ||
+                (rc = buf_ensure(ctx, ctx->scratch[kSet[e][4]], (size_t)mx_n * NE * (sizeof(VoteCand) + sizeof(AsmPlanDev)))) ||
+                (rc = buf_ensure(ctx, ctx->scratch[kSet[e][5]], mx_tab * 4)) ||
+                (rc = buf_ensure(ctx, ctx->scratch[kSet[e][6]], mx_next * 4))) return fail(rc);
+    }
+    hipStream_t st2[2] = {s, s};
+    if (overlap && chunk_end.size() > 1) {
+        if (!ctx->stream_b && hipStreamCreate(&ctx->stream_b) != hipSuccess) return fail(set_err(ctx, NECAT_ERR_DEVICE, "hipStreamCreate failed"));
+        st2[1] = ctx->stream_b;
     }
     tick("chunk plan + arenas");
-    u32 pos = 0;
-    for (size_t ci = 0; ci < chunk_end.size(); ++ci) {
-        const u32 hi = chunk_end[ci];
-        const u32 n = hi - pos;
+    // what a chunk leaves on the device between its two halves
+    struct Chunk { u32 pos = 0, n = 0; VoteMeta* d_meta = nullptr; ReadIdxMeta* d_rmeta = nullptr; u32* d_order = nullptr; i32 *d_nblk = nullptr, *d_nstrand = nullptr, *d_nplan = nullptr;
+                   VoteArenas A; VoteCand* d_sel = nullptr; AsmPlanDev* d_plan = nullptr; u32 *d_tabs = nullptr, *d_next = nullptr; };
+    Chunk chunks2[2];
+    // ---- first half of a chunk: vote of both strands, the per-read cut, the reads' 10-mer tables - launched, not waited for
+    auto launch_vote = [&](size_t ci, int e) -> int {
+        hipStream_t sv = st2[e];
+        Chunk& C = chunks2[e];
+        C.pos = ci ? chunk_end[ci - 1] : 0u; C.n = chunk_end[ci] - C.pos;
+        const u32 n = C.n, pos = C.pos;
         std::vector<VoteMeta> meta(n);
         std::vector<ReadIdxMeta> rmeta(n);
         u64 ht_tot = 0, pool_tot = 0, tab_tot = 0, next_tot = 0;
@@ -2239,41 +2272,48 @@ int necat_asm_plan_batch(necat_ctx* ctx, const necat_index* ix, const necat_volu
             rmeta[i].tab_off = tab_tot; rmeta[i].next_off = next_tot; rmeta[i].cap = (u32)cap; rmeta[i]._pad = 0;
             tab_tot += 2 * cap; next_tot += L + 1;
         }
-        char* mb = (char*)ctx->scratch[SC_ASM_VMETA].p;
+        char* mb = (char*)ctx->scratch[kSet[e][0]].p;
         auto carve = [&](size_t bytes) { char* q = mb; mb += (bytes + 63) & ~(size_t)63; return q; };
-        VoteMeta* d_meta = (VoteMeta*)carve(n * sizeof(VoteMeta));
-        ReadIdxMeta* d_rmeta = (ReadIdxMeta*)carve(n * sizeof(ReadIdxMeta));
-        u32* d_order = (u32*)carve((size_t)n * 4);
-        i32* d_nblk = (i32*)carve((size_t)n * 8);
-        i32* d_nstrand = (i32*)carve((size_t)n * 8);
-        i32* d_nplan = (i32*)carve((size_t)n * 4);
-        VoteArenas A; A.ht = (u64*)ctx->scratch[SC_ASM_VHT].p; A.pool = (VBlock*)ctx->scratch[SC_ASM_VPOOL].p; A.out = (VoteCand*)ctx->scratch[SC_ASM_VOUT].p;
-        VoteCand* d_sel = (VoteCand*)ctx->scratch[SC_ASM_SEL].p;
-        AsmPlanDev* d_plan = (AsmPlanDev*)((char*)ctx->scratch[SC_ASM_SEL].p + (size_t)n * NE * sizeof(VoteCand));
-        u32* d_tabs = (u32*)ctx->scratch[SC_ASM_RIDX].p; u32* d_next = (u32*)ctx->scratch[SC_ASM_RNEXT].p;
-        if (hipMemcpyAsync(d_meta, meta.data(), n * sizeof(VoteMeta), hipMemcpyHostToDevice, s) != hipSuccess ||
-            hipMemcpyAsync(d_rmeta, rmeta.data(), n * sizeof(ReadIdxMeta), hipMemcpyHostToDevice, s) != hipSuccess ||
-            hipMemcpyAsync(d_order, order.data() + pos, (size_t)n * 4, hipMemcpyHostToDevice, s) != hipSuccess ||
-            hipMemsetAsync(A.ht, 0xFF, ht_tot * 8, s) != hipSuccess ||
-            hipMemsetAsync(d_tabs, 0, tab_tot * 4, s) != hipSuccess) return fail(set_err(ctx, NECAT_ERR_DEVICE, "asm plan: chunk upload"));
-        hipLaunchKernelGGL(k_asm_vote_collect, dim3(2 * n), dim3(64), 0, s, dref, drd, index_view(ix), (const u64*)ix->offset_list, P, (const u32*)d_order, (const VoteMeta*)d_meta, n, A,
-                           d_nblk, d_err, (const u64*)d_kst);
-        hipLaunchKernelGGL(k_asm_vote_eval, dim3(2 * n), dim3(64), 0, s, dref, drd, P, (const u32*)d_order, (const VoteMeta*)d_meta, n, A, (const i32*)d_nblk, d_nstrand);
-        hipLaunchKernelGGL(k_asm_select, dim3(n), dim3(64), 0, s, P, (const VoteMeta*)d_meta, n, A, (const i32*)d_nstrand, d_sel, d_plan, d_nplan);
-        hipLaunchKernelGGL(k_asm_read_index, dim3(n), dim3(64), 0, s, drd, (const u32*)d_order, (const ReadIdxMeta*)d_rmeta, n, d_tabs, d_next);
-        if (hipGetLastError() != hipSuccess) return fail(set_err(ctx, NECAT_ERR_DEVICE, "asm plan: vote kernels launch failed"));
+        C.d_meta = (VoteMeta*)carve(n * sizeof(VoteMeta));
+        C.d_rmeta = (ReadIdxMeta*)carve(n * sizeof(ReadIdxMeta));
+        C.d_order = (u32*)carve((size_t)n * 4);
+        C.d_nblk = (i32*)carve((size_t)n * 8);
+        C.d_nstrand = (i32*)carve((size_t)n * 8);
+        C.d_nplan = (i32*)carve((size_t)n * 4);
+        C.A.ht = (u64*)ctx->scratch[kSet[e][1]].p; C.A.pool = (VBlock*)ctx->scratch[kSet[e][2]].p; C.A.out = (VoteCand*)ctx->scratch[kSet[e][3]].p;
+        C.d_sel = (VoteCand*)ctx->scratch[kSet[e][4]].p;
+        C.d_plan = (AsmPlanDev*)((char*)ctx->scratch[kSet[e][4]].p + (size_t)n * NE * sizeof(VoteCand));
+        C.d_tabs = (u32*)ctx->scratch[kSet[e][5]].p; C.d_next = (u32*)ctx->scratch[kSet[e][6]].p;
+        if (hipMemcpyAsync(C.d_meta, meta.data(), n * sizeof(VoteMeta), hipMemcpyHostToDevice, sv) != hipSuccess ||
+            hipMemcpyAsync(C.d_rmeta, rmeta.data(), n * sizeof(ReadIdxMeta), hipMemcpyHostToDevice, sv) != hipSuccess ||
+            hipMemcpyAsync(C.d_order, order.data() + pos, (size_t)n * 4, hipMemcpyHostToDevice, sv) != hipSuccess ||
+            hipMemsetAsync(C.A.ht, 0xFF, ht_tot * 8, sv) != hipSuccess ||
+            hipMemsetAsync(C.d_tabs, 0, tab_tot * 4, sv) != hipSuccess) return set_err(ctx, NECAT_ERR_DEVICE, "asm plan: chunk upload");
+        hipLaunchKernelGGL(k_asm_vote_collect, dim3(2 * n), dim3(64), 0, sv, dref, drd, index_view(ix), (const u64*)ix->offset_list, P, (const u32*)C.d_order, (const VoteMeta*)C.d_meta, n, C.A,
+                           C.d_nblk, d_err, (const u64*)d_kst);
+        hipLaunchKernelGGL(k_asm_vote_eval, dim3(2 * n), dim3(64), 0, sv, dref, drd, P, (const u32*)C.d_order, (const VoteMeta*)C.d_meta, n, C.A, (const i32*)C.d_nblk, C.d_nstrand);
+        hipLaunchKernelGGL(k_asm_select, dim3(n), dim3(64), 0, sv, P, (const VoteMeta*)C.d_meta, n, C.A, (const i32*)C.d_nstrand, C.d_sel, C.d_plan, C.d_nplan);
+        hipLaunchKernelGGL(k_asm_read_index, dim3(n), dim3(64), 0, sv, drd, (const u32*)C.d_order, (const ReadIdxMeta*)C.d_rmeta, n, C.d_tabs, C.d_next);
+        if (hipGetLastError() != hipSuccess) return set_err(ctx, NECAT_ERR_DEVICE, "asm plan: vote kernels launch failed");
+        return NECAT_OK;
+    };
+    // ---- second half: the planned pairs' match counts, matches, chains; the chunk's plan to the host
+    auto finish_chunk = [&](int e) -> int {
+        hipStream_t sv = st2[e];
+        Chunk& C = chunks2[e];
+        const u32 n = C.n, pos = C.pos;
         std::vector<i32> nplan(n);
         int herr = 0;
-        if (hipMemcpyAsync(nplan.data(), d_nplan, (size_t)n * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipStreamSynchronize(s) != hipSuccess) return fail(set_err(ctx, NECAT_ERR_DEVICE, "asm plan: vote kernels failed: %s", hipGetErrorString(hipGetLastError())));
-        if (herr) return fail(set_err(ctx, NECAT_ERR_CAPACITY, "asm plan: vote scratch overflow (code %d)", herr));
+        if (hipMemcpyAsync(nplan.data(), C.d_nplan, (size_t)n * 4, hipMemcpyDeviceToHost, sv) != hipSuccess || hipMemcpyAsync(&herr, d_err, 4, hipMemcpyDeviceToHost, sv) != hipSuccess ||
+            hipStreamSynchronize(sv) != hipSuccess) return set_err(ctx, NECAT_ERR_DEVICE, "asm plan: vote kernels failed: %s", hipGetErrorString(hipGetLastError()));
+        if (herr) return set_err(ctx, NECAT_ERR_CAPACITY, "asm plan: vote scratch overflow (code %d)", herr);
         tick("vote + select + read index");
         if (const char* dump = getenv("NECAT_ASM_DUMP_VOTES")) {
             // tests/host_core/check_asm_plan.cpp: per read {read id, candidates of both strands, kept}, then the ranked candidates (6 ints each)
             std::vector<VoteCand> hsel((size_t)n * NE);
             std::vector<i32> hns((size_t)n * 2);
-            if (hipMemcpy(hsel.data(), d_sel, hsel.size() * sizeof(VoteCand), hipMemcpyDeviceToHost) == hipSuccess &&
-                hipMemcpy(hns.data(), d_nstrand, hns.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (hipMemcpy(hsel.data(), C.d_sel, hsel.size() * sizeof(VoteCand), hipMemcpyDeviceToHost) == hipSuccess &&
+                hipMemcpy(hns.data(), C.d_nstrand, hns.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
                 if (FILE* f = fopen(dump, "ab")) {
                     for (u32 i = 0; i < n; ++i) {
                         const i32 tot = hns[2 * (size_t)i] + hns[2 * (size_t)i + 1], kept = std::min<i32>(tot, NE);
@@ -2285,30 +2325,30 @@ int necat_asm_plan_batch(necat_ctx* ctx, const necat_index* ix, const necat_volu
                 }
             }
         }
-        // ---- the planned (read, subject strand) pairs: match counts, then the matches / chains in batches bounded by the match arena
         std::vector<PairMeta> pairs;
         for (u32 i = 0; i < n; ++i) for (i32 q = 0; q < nplan[i]; ++q) { PairMeta pm; pm.read_i = i; pm.slot = (u32)q; pm.seed_off = 0; pairs.push_back(pm); }
         const u32 np = (u32)pairs.size();
         tot_pairs += np;
         std::vector<AsmPlanDev> hplan;
+        int rc2;
         if (np) {
-            if ((rc = buf_ensure(ctx, ctx->scratch[SC_ASM_PAIRS], (size_t)np * (sizeof(PairMeta) + 8) + 256))) return fail(rc);
+            if ((rc2 = buf_ensure(ctx, ctx->scratch[SC_ASM_PAIRS], (size_t)np * (sizeof(PairMeta) + 8) + 256))) return rc2;
             PairMeta* d_pairs = (PairMeta*)ctx->scratch[SC_ASM_PAIRS].p;
             u32* d_counts = (u32*)((char*)d_pairs + (((size_t)np * sizeof(PairMeta) + 63) & ~(size_t)63));
             u32* d_nmem = d_counts + np;
-            if (hipMemcpyAsync(d_pairs, pairs.data(), (size_t)np * sizeof(PairMeta), hipMemcpyHostToDevice, s) != hipSuccess) return fail(set_err(ctx, NECAT_ERR_DEVICE, "asm plan: pair upload"));
-            hipLaunchKernelGGL(k_asm_seeds<false>, dim3(np), dim3(64), 0, s, dref, drd, (const u32*)d_order, (const ReadIdxMeta*)d_rmeta, (const u32*)d_tabs, (const u32*)d_next, (const u8*)d_occ,
-                               (const AsmPlanDev*)d_plan, NE, (const PairMeta*)d_pairs, np, d_counts, (AsmSeed*)nullptr, (AsmMem*)nullptr, (AsmMem*)nullptr, (u32*)nullptr);
+            if (hipMemcpyAsync(d_pairs, pairs.data(), (size_t)np * sizeof(PairMeta), hipMemcpyHostToDevice, sv) != hipSuccess) return set_err(ctx, NECAT_ERR_DEVICE, "asm plan: pair upload");
+            hipLaunchKernelGGL(k_asm_seeds<false>, dim3(np), dim3(64), 0, sv, dref, drd, (const u32*)C.d_order, (const ReadIdxMeta*)C.d_rmeta, (const u32*)C.d_tabs, (const u32*)C.d_next, (const u8*)d_occ,
+                               (const AsmPlanDev*)C.d_plan, NE, (const PairMeta*)d_pairs, np, d_counts, (AsmSeed*)nullptr, (AsmMem*)nullptr, (AsmMem*)nullptr, (u32*)nullptr);
             std::vector<u32> counts(np);
-            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(counts.data(), d_counts, (size_t)np * 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-                return fail(set_err(ctx, NECAT_ERR_DEVICE, "k_asm_seeds<count> failed: %s", hipGetErrorString(hipGetLastError())));
+            if (hipGetLastError() != hipSuccess || hipMemcpyAsync(counts.data(), d_counts, (size_t)np * 4, hipMemcpyDeviceToHost, sv) != hipSuccess || hipStreamSynchronize(sv) != hipSuccess)
+                return set_err(ctx, NECAT_ERR_DEVICE, "k_asm_seeds<count> failed: %s", hipGetErrorString(hipGetLastError()));
             tick("match counts");
             const size_t per_seed = sizeof(AsmSeed) + 2 * sizeof(AsmMem) + 16;
             {   // the arena once per chunk, for its largest batch (+ a quarter: the next chunk's is about as large)
                 u64 mx = 0, so = 0;
                 for (u32 b = 0; b < np; ++b) { if (so && so + counts[b] > budget_seeds) { mx = std::max(mx, so); so = 0; } so += counts[b]; }
                 mx = std::max(mx, so);
-                if (std::max<u64>(1, mx) * per_seed + 256 > ctx->scratch[SC_ASM_SEEDS].cap && (rc = buf_ensure(ctx, ctx->scratch[SC_ASM_SEEDS], (std::max<u64>(1, mx) + mx / 4) * per_seed + 256))) return fail(rc);
+                if (std::max<u64>(1, mx) * per_seed + 256 > ctx->scratch[SC_ASM_SEEDS].cap && (rc2 = buf_ensure(ctx, ctx->scratch[SC_ASM_SEEDS], (std::max<u64>(1, mx) + mx / 4) * per_seed + 256))) return rc2;
             }
             for (u32 b0 = 0; b0 < np;) {
                 u64 so = 0; u32 b1 = b0;
@@ -2320,30 +2360,42 @@ int necat_asm_plan_batch(necat_ctx* ctx, const necat_index* ix, const necat_volu
                 AsmMem* d_tmp = (AsmMem*)sb; sb += ((so * sizeof(AsmMem)) + 63) & ~(size_t)63;
                 i32* d_chain = (i32*)sb;
                 const u32 nb = b1 - b0;
-                if (hipMemcpyAsync(d_pairs + b0, pairs.data() + b0, (size_t)nb * sizeof(PairMeta), hipMemcpyHostToDevice, s) != hipSuccess) return fail(set_err(ctx, NECAT_ERR_DEVICE, "asm plan: pair upload"));
-                hipLaunchKernelGGL(k_asm_seeds<true>, dim3(nb), dim3(64), 0, s, dref, drd, (const u32*)d_order, (const ReadIdxMeta*)d_rmeta, (const u32*)d_tabs, (const u32*)d_next, (const u8*)d_occ,
-                                   (const AsmPlanDev*)d_plan, NE, (const PairMeta*)(d_pairs + b0), nb, (u32*)nullptr, d_seeds, d_mems, d_tmp, d_nmem + b0);
-                hipLaunchKernelGGL(k_asm_chain, dim3(nb), dim3(64), 0, s, (const PairMeta*)(d_pairs + b0), nb, (const AsmMem*)d_mems, (const u32*)(d_nmem + b0), d_chain, d_plan, NE);
-                if (hipGetLastError() != hipSuccess) return fail(set_err(ctx, NECAT_ERR_DEVICE, "asm plan: range kernels launch failed"));
-                if (b1 < np && hipStreamSynchronize(s) != hipSuccess) return fail(set_err(ctx, NECAT_ERR_DEVICE, "asm plan: range kernels failed: %s", hipGetErrorString(hipGetLastError())));
+                if (hipMemcpyAsync(d_pairs + b0, pairs.data() + b0, (size_t)nb * sizeof(PairMeta), hipMemcpyHostToDevice, sv) != hipSuccess) return set_err(ctx, NECAT_ERR_DEVICE, "asm plan: pair upload");
+                hipLaunchKernelGGL(k_asm_seeds<true>, dim3(nb), dim3(64), 0, sv, dref, drd, (const u32*)C.d_order, (const ReadIdxMeta*)C.d_rmeta, (const u32*)C.d_tabs, (const u32*)C.d_next, (const u8*)d_occ,
+                                   (const AsmPlanDev*)C.d_plan, NE, (const PairMeta*)(d_pairs + b0), nb, (u32*)nullptr, d_seeds, d_mems, d_tmp, d_nmem + b0);
+                hipLaunchKernelGGL(k_asm_chain, dim3(nb), dim3(64), 0, sv, (const PairMeta*)(d_pairs + b0), nb, (const AsmMem*)d_mems, (const u32*)(d_nmem + b0), d_chain, C.d_plan, NE);
+                if (hipGetLastError() != hipSuccess) return set_err(ctx, NECAT_ERR_DEVICE, "asm plan: range kernels launch failed");
+                if (b1 < np && hipStreamSynchronize(sv) != hipSuccess) return set_err(ctx, NECAT_ERR_DEVICE, "asm plan: range kernels failed: %s", hipGetErrorString(hipGetLastError()));
                 b0 = b1;
             }
             hplan.resize((size_t)n * NE);
-            if (hipMemcpyAsync(hplan.data(), d_plan, (size_t)n * NE * sizeof(AsmPlanDev), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
-                return fail(set_err(ctx, NECAT_ERR_DEVICE, "asm plan: range kernels failed: %s", hipGetErrorString(hipGetLastError())));
+            if (hipMemcpyAsync(hplan.data(), C.d_plan, (size_t)n * NE * sizeof(AsmPlanDev), hipMemcpyDeviceToHost, sv) != hipSuccess || hipStreamSynchronize(sv) != hipSuccess)
+                return set_err(ctx, NECAT_ERR_DEVICE, "asm plan: range kernels failed: %s", hipGetErrorString(hipGetLastError()));
             tick("matches + chains");
         }
         for (u32 i = 0; i < n; ++i) {
             std::vector<necat_asm_plan>& dst = per_read[order[pos + i]];
             dst.resize((size_t)nplan[i]);
             for (i32 q = 0; q < nplan[i]; ++q) {
-                const AsmPlanDev& e = hplan[(size_t)i * NE + (size_t)q];
+                const AsmPlanDev& en = hplan[(size_t)i * NE + (size_t)q];
                 necat_asm_plan& o = dst[(size_t)q];
-                o.qid = (int32_t)order[pos + i] + read_start_id; o.sid = e.sid + ref_start_id; o.sdir = e.sdir; o.qoff = e.qoff; o.soff = e.soff; o.score = e.score; o.ssize = e.ssize;
+                o.qid = (int32_t)order[pos + i] + read_start_id; o.sid = en.sid + ref_start_id; o.sdir = en.sdir; o.qoff = en.qoff; o.soff = en.soff; o.score = en.score; o.ssize = en.ssize;
             }
             tot_plans += (u64)nplan[i];
         }
-        pos = hi;
+        return NECAT_OK;
+    };
+    {
+        const size_t nch = chunk_end.size();
+        const int two = (overlap && nch > 1) ? 1 : 0;
+        auto drain = [&]() { (void)hipStreamSynchronize(st2[0]); (void)hipStreamSynchronize(st2[1]); };       // nothing in flight when an error returns
+        if ((rc = launch_vote(0, 0))) { drain(); return fail(rc); }
+        for (size_t ci = 0; ci < nch; ++ci) {
+            const int e = two ? (int)(ci & 1) : 0;
+            if (two && ci + 1 < nch && (rc = launch_vote(ci + 1, e ^ 1))) { drain(); return fail(rc); }
+            if ((rc = finish_chunk(e))) { drain(); return fail(rc); }
+            if (!two && ci + 1 < nch && (rc = launch_vote(ci + 1, 0))) { drain(); return fail(rc); }
+        }
     }
     necat_asm_plan* res = (necat_asm_plan*)result_alloc(std::max<u64>(1, tot_plans) * sizeof(necat_asm_plan));
     if (!res) return fail(set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"));
