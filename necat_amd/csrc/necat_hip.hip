@@ -474,6 +474,11 @@ int index_build_body(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
     if (!lds_slices) NECAT_HIP(ctx, hipMemsetAsync(cnt32, 0, T * 4, s));
     if (partitioned) {
+        // SC_PART ends up as the index's offset list (emit_phase) and comes back through idx_cache[1] when that index is released
+        if (lds_slices && !sharded && ctx->scratch[SC_PART].cap < (ref->nbases + 1) * 8 && ctx->idx_cache[1].cap >= (ref->nbases + 1) * 8) {
+            if (ctx->scratch[SC_PART].p) (void)hipFree(ctx->scratch[SC_PART].p);
+            ctx->scratch[SC_PART] = ctx->idx_cache[1]; ctx->idx_cache[1] = DevBuf();
+        }
         if ((rc = buf_ensure(ctx, ctx->scratch[SC_SMALL], (size_t)NB * 4 + (size_t)(NB + 1) * 8 * 2 + 64)) ||
             (rc = buf_ensure(ctx, ctx->scratch[SC_PART], (ref->nbases + 1) * 8))) return rc;
         char* sb = (char*)ctx->scratch[SC_SMALL].p;
@@ -486,7 +491,7 @@ int index_build_body(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
         const int bits2 = PB > 6 ? PB - 6 : 0;
         const u32 NC = NB >> bits2;
         if ((rc = buf_ensure(ctx, ctx->scratch[SC_SPLIT], (size_t)(NC + 1) * 8 * kCurStride + (size_t)(NC + 1) * 4 + 64)) ||
-            (bits2 && (rc = buf_ensure(ctx, ctx->scratch[SC_PART2], (ref->nbases + 1) * 8 + ((u64)NB * kSubs + 1) * 16 + (u64)NB * kSubs * 4 + 256)))) return rc;
+            (bits2 && (rc = buf_ensure_lend(ctx, SC_PART2, (ref->nbases + 1) * 8 + ((u64)NB * kSubs + 1) * 16 + (u64)NB * kSubs * 4 + 256, {SC_SEED_POOL, SC_SEED_CHAIN, SC_SEED_OUT})))) return rc;
         u64* d_ccur = (u64*)ctx->scratch[SC_SPLIT].p;
         u32* d_tpre = (u32*)(d_ccur + (size_t)(NC + 1) * kCurStride);
         hipLaunchKernelGGL(k_part_hist, dim3(pgrid), dim3(kPartThreads), NB * 2, s, vol, kmer_size, pshift, NB, b_lo, b_hi, d_bcnt);
@@ -508,7 +513,7 @@ int index_build_body(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
     if (lds_slices) {
         // ---- second split + one workgroup per 4096-entry slice of the table (index_kernels.h)
         const u64 nsub = (u64)NB * kSubs;
-        if ((rc = buf_ensure(ctx, ctx->scratch[SC_PART2], (ref->nbases + 1) * 8 + (nsub + 1) * 16 + nsub * 4 + 256)) ||
+        if ((rc = buf_ensure_lend(ctx, SC_PART2, (ref->nbases + 1) * 8 + (nsub + 1) * 16 + nsub * 4 + 256, {SC_SEED_POOL, SC_SEED_CHAIN, SC_SEED_OUT})) ||
             (rc = buf_ensure(ctx, ctx->scratch[SC_SPLIT2], nsub * 4 + (size_t)(NB + 1) * 8 + (size_t)NB * 4 + 256))) return rc;
         char* pb = (char*)ctx->scratch[SC_PART2].p;
         d_part2 = (u64*)pb; pb += (ref->nbases + 1) * 8;
@@ -566,9 +571,17 @@ int index_build_body(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
         const size_t words_bytes = (size_t)(T / 64) * sizeof(IdxWord);
         if ((rc = table_alloc(ctx, ix, words_bytes + (n_comp + 1) * 8))) return rc;
         ix->words = ix->table; ix->compact = (uint64_t*)((char*)ix->table + words_bytes);
-        if (ctx->idx_cache[1].p && ctx->idx_cache[1].cap >= (n_off + 1) * 8) { ix->offset_list = (uint64_t*)ctx->idx_cache[1].p; ix->offs_cap = ctx->idx_cache[1].cap; ctx->idx_cache[1] = DevBuf(); }
+        // the offset list takes over the buffer of the fine buckets: k_subpart was their last reader, and a third array of 8 bytes per
+        // base is what the first build of a process at oc2mkdb's 2 Gbp cut waited for (16 GB more device memory to map and clear).
+        // Not in a sharded build: its offset list is published to the peers (HIP IPC), and with scratch buffers joining the pool of
+        // published allocations `hipIpcGetMemHandle` failed with "invalid argument" in the second step of the two-rank pairs bench
+        // (tests/test_gpu_pairs.py; profiles/NOTES_r04.md 6) - there the list keeps its own allocation as before.
+        if (!sharded && ctx->scratch[SC_PART].p && ctx->scratch[SC_PART].cap >= (n_off + 1) * 8 && !(getenv("NECAT_INDEX_OWN_OFFSETS") && atoi(getenv("NECAT_INDEX_OWN_OFFSETS")))) {
+            ix->offset_list = (uint64_t*)ctx->scratch[SC_PART].p; ix->offs_cap = ctx->scratch[SC_PART].cap; ctx->scratch[SC_PART] = DevBuf(); d_part = nullptr;
+        }
+        else if (ctx->idx_cache[1].p && ctx->idx_cache[1].cap >= (n_off + 1) * 8) { ix->offset_list = (uint64_t*)ctx->idx_cache[1].p; ix->offs_cap = ctx->idx_cache[1].cap; ctx->idx_cache[1] = DevBuf(); }
         else { NECAT_HIP(ctx, hipMalloc((void**)&ix->offset_list, (n_off + 1) * 8 + (n_off >> 4))); ix->offs_cap = (n_off + 1) * 8 + (n_off >> 4); }
-        if ((rc = buf_ensure(ctx, ctx->scratch[SC_TMPLIST], (n_local + 1) * 4))) return rc;
+        if ((rc = buf_ensure_lend(ctx, SC_TMPLIST, (n_local + 1) * 4, {SC_SEED_CHAIN, SC_SEED_OUT, SC_SEED_POOL}))) return rc;
         // 512 threads per slice: 4 workgroups (32 waves) per CU instead of 5 x 4 waves with 256 - the kernel is a chain of short
         // barrier-separated phases and needs the waves to hide their latencies (10.6 -> 9.8 ms for the whole build)
         // (slices of more than ~ 1000 records on average - volumes above 0.27 Gbp at k = 15 - rank in a bigger LDS buffer: index_kernels.h)
@@ -871,9 +884,10 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
         }
         if ((rc = buf_ensure(ctx, ctx->scratch[SC_SEED_META], n * sizeof(SeedMeta) + (size_t)n * (8 + 4 + 4 + 8 + 8) + 64)) ||
             (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_HT], ht_tot * 8)) ||
-            (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_POOL], pool_tot * sizeof(SBlock))) ||
-            (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_CHAIN], chain_tot * (8 + 16 + 8 + sizeof(DevCand)))) ||
-            (rc = buf_ensure(ctx, ctx->scratch[SC_SEED_OUT], out_tot * sizeof(DevCand)))) { return rc; }
+            // (the block pool and the chain scratch take over the index build's split buffers, idle until the next build: runtime.h)
+            (rc = buf_ensure_lend(ctx, SC_SEED_POOL, pool_tot * sizeof(SBlock), {SC_PART2, SC_TMPLIST})) ||
+            (rc = buf_ensure_lend(ctx, SC_SEED_CHAIN, chain_tot * (8 + 16 + 8 + sizeof(DevCand)), {SC_TMPLIST, SC_PART2})) ||
+            (rc = buf_ensure_lend(ctx, SC_SEED_OUT, out_tot * sizeof(DevCand), {SC_TMPLIST, SC_PART2}))) { return rc; }
         tick("plan + buffers");
         char* mb = (char*)ctx->scratch[SC_SEED_META].p;
         SeedMeta* d_meta = (SeedMeta*)mb; mb += n * sizeof(SeedMeta);

@@ -7,7 +7,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <initializer_list>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/necat_hip.h"
@@ -146,5 +148,21 @@ enum ScratchId {
     SC_ASM_VMETA2, SC_ASM_VHT2, SC_ASM_VPOOL2, SC_ASM_VOUT2, SC_ASM_SEL2, SC_ASM_RIDX2, SC_ASM_RNEXT2,
     SC_COUNT
 };
+
+// buf_ensure for arenas of DIFFERENT phases of a context (the index build's split buffers / the seeding arenas: never live at the same
+// time, every call that uses them has finished with them when it returns): before allocating, take the buffer of a donor that is big
+// enough and leave it this one's - the phases then hand ONE allocation back and forth instead of holding two (a 2 Gbp volume: 17 GB of
+// split records and 14 GB of seed blocks; a process waits 30 - 55 ms per GB for device memory it maps the first time).
+inline int buf_ensure_lend(necat_ctx* ctx, int id, size_t bytes, std::initializer_list<int> donors)
+{
+    DevBuf& b = ctx->scratch[id];
+    if (bytes <= b.cap) return NECAT_OK;
+    static const bool off = getenv("NECAT_NO_LEND") && atoi(getenv("NECAT_NO_LEND"));
+    if (!off) for (int d : donors) {
+        DevBuf& o = ctx->scratch[d];
+        if (d != id && o.cap >= bytes) { std::swap(b, o); return NECAT_OK; }
+    }
+    return buf_ensure(ctx, b, bytes);
+}
 
 }  // namespace necat
