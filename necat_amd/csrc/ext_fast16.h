@@ -178,7 +178,7 @@ NECAT_D void myers_fast16(const int lane, const u64* __restrict__ fr0, char* __r
     // ---- results (one lane per block) and work counters
     u32 live = kept;
     for (int o = 32; o > 0; o >>= 1) live += (u32)__shfl_xor((int)live, o);
-    if (lane == 0) { atomicAdd(&stats[2], (unsigned long long)live); atomicAdd(&stats[0], (unsigned long long)live + 16ull * NW * N); atomicAdd(&stats[1], 16ull * 2 * N); }
+    if (lane == 0) { stat_add(stats, 2, (unsigned long long)live); stat_add(stats, 0, (unsigned long long)live + 16ull * NW * N); stat_add(stats, 1, 16ull * 2 * N); }
     if (j == 0 && (narrow || !go)) {
         BlockResult br; br.dist = go ? best : -1; br.endc = end0; br.err = err;
         br.words = (u32)(NW * N) + (narrow ? (u32)((64 + hi_x - lo_x) * NW) : 0u);

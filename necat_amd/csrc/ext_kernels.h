@@ -48,6 +48,19 @@ struct BlockItem {       // one scheduled block alignment
 };
 
 struct BlockResult { i32 dist, endc, err; u32 words; };
+
+// The work counters of the extension kernels (word updates, bases, band words, walk blocks / words: necat_timings).  Every wave of every DP /
+// walk kernel adds to them, and atomics on ONE cache line are served one after the other, ~ 8 ns each on MI355X whether or not anybody waits
+// for the result: 3 per wave of k_myers_ck were 86 k per launch of a big round = 0.65 ms, more than half of that kernel's own 1.2 ms
+// (tools/ck_microbench.hip; profiles/NOTES_r04.md 10).  So the counters live in kStatSlots copies on lines of their own, a workgroup adds to
+// the copy its index hashes to, and the host sums the copies when it reads them.
+constexpr int kStatSlots = 64, kStatStride = 16;                 // copies; u64 per copy (one 128-byte line)
+constexpr size_t kStatBytes = (size_t)kStatSlots * kStatStride * 8;
+NECAT_D void stat_add(unsigned long long* stats, int idx, unsigned long long v)
+{
+    atomicAdd(&stats[(size_t)((blockIdx.x * 0x9E3779B1u) >> 26) * kStatStride + idx], v);
+}
+static_assert(kStatSlots == 64, "stat_add takes the top 6 bits of the hash");
 // ext_rcwalk.h: a full block whose walk was done by k_rcwalk4 leaves its statistics here (k_traceback<WALK = 5> takes them instead of
 // walking); a block that kernel cannot take (distance too large for its 4-word window) carries kWideFlag in BlockResult::words and
 // goes through the DP + walk kernels below in `only wide` launches.
@@ -400,8 +413,8 @@ k_myers(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict__
     u32 w = r.words, bases = (u32)(qn + tn);
     if (__popcll(__ballot(1)) == 64) {       // full wave: every lane is alive, shuffles are safe
         for (int o = 32; o > 0; o >>= 1) { w += __shfl_down(w, o); bases += __shfl_down(bases, o); }
-        if (lane == 0) { atomicAdd(&stats[0], (unsigned long long)w); atomicAdd(&stats[1], (unsigned long long)bases); }
-    } else { atomicAdd(&stats[0], (unsigned long long)w); atomicAdd(&stats[1], (unsigned long long)bases); }
+        if (lane == 0) { stat_add(stats, 0, (unsigned long long)w); stat_add(stats, 1, (unsigned long long)bases); }
+    } else { stat_add(stats, 0, (unsigned long long)w); stat_add(stats, 1, (unsigned long long)bases); }
 }
 
 // Cooperative variant for rounds with few blocks (the latency-bound tail: a candidate's blocks form a
@@ -589,7 +602,7 @@ NECAT_D void fast_nw8(const int lane, const u64* __restrict__ tw, const u64 nlo,
         }
     }
     for (int o = 32; o > 0; o >>= 1) kept += (u32)__shfl_xor((int)kept, o);
-    if (lane == 0 && kept) atomicAdd(&stats[2], (unsigned long long)kept);
+    if (lane == 0 && kept) stat_add(stats, 2, (unsigned long long)kept);
 }
 
 }  // namespace necat
@@ -620,7 +633,7 @@ NECAT_D void myers_fast_full(const int lane, const u64* __restrict__ tw, const u
         BlockResult br; br.dist = err ? -1 : best; br.endc = end0; br.err = err;
         br.words = (u32)(NW * (N + (go ? tn2 : 0)));
         *result = br;
-        atomicAdd(&stats[0], (unsigned long long)br.words); atomicAdd(&stats[1], (unsigned long long)(2 * N));
+        stat_add(stats, 0, (unsigned long long)br.words); stat_add(stats, 1, (unsigned long long)(2 * N));
     }
 }
 
@@ -765,7 +778,7 @@ NECAT_D void myers_coop_wave(const ListView& lv, const BlockItem* __restrict__ i
     }
     if (!SINGLE) {
         for (int o = 32; o > 0; o >>= 1) kept += (u32)__shfl_xor((int)kept, o);
-        if (lane == 0 && kept) atomicAdd(&stats[2], (unsigned long long)kept);
+        if (lane == 0 && kept) stat_add(stats, 2, (unsigned long long)kept);
     }
     if (is_last) {
         if (!SINGLE && best >= 0 && !err) {
@@ -776,7 +789,7 @@ NECAT_D void myers_coop_wave(const ListView& lv, const BlockItem* __restrict__ i
         BlockResult br; br.dist = err ? -1 : best; br.endc = end0; br.err = err;
         br.words = (u32)(nblk * (tn + (!SINGLE && best >= 0 ? tn2 : 0)));
         if (!only_wide) results[item] = br;
-        atomicAdd(&stats[0], (unsigned long long)br.words); atomicAdd(&stats[1], (unsigned long long)(qn + tn));
+        stat_add(stats, 0, (unsigned long long)br.words); stat_add(stats, 1, (unsigned long long)(qn + tn));
     }
 }
 

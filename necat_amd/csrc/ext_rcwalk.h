@@ -81,6 +81,154 @@ NECAT_D u32 fast_shw8_ck(const int b, const u64* __restrict__ tw, const u64 nlo,
     return key;
 }
 
+// fast_shw8_ck<TW, true> with the bottom row's minimum found AFTER the pass.  The DP kernel is bound by VALU issue (88 % of the SIMD cycles at 41
+// vector instructions per step, profiles/r04_sq_counters.json), and 8 of those 41 were not the recurrence:
+//   * the running score and its minimum (5 per step, on every lane, for a value only word 7 needs): the bottom row's deltas are the very bits
+//     word 7 writes to `hc`, so after the pass the 8 lanes of a block read them back - lane x the 64 columns [64 x, 64 x + 64) - start from 512 +
+//     the deltas of the columns before (popcounts, a prefix over the 8 lanes) and walk their 64 columns: 5 x 64 instructions instead of 5 x 519;
+//   * the per-lane test "is this my checkpoint step" (2): with the 32 steps of a window unrolled the step number is a constant, the lanes
+//     that store at it are those of ONE word, and the compare against that word is loop invariant (a scalar mask);
+//   * the copy of the new Pv over the old one (1): gone with the unrolling.
+// The first and the last window (steps 0 - 31: lanes join one by one; 512 - 518: they leave) keep the rolled, masked loop.
+// Returns, on all 8 lanes of the block, what fast_shw8_ck returns on lane 7: (smallest bottom-row value << 10) + the step of word 7 at the
+// FIRST column attaining it (= that column + 7).
+// fast_advance<false> with the -1 carry published as the NUMBER 0 / 1 (pubM) instead of in bit 31: the word below ORs it into Eq and into
+// (Mh << 1) as it comes - one shift per step less; `mw` = 1, or 0 on the lane of word 7, which publishes "no carry" for the top word of
+// the next block of its DPP row (v_bfe_u32 with a width of 0 bits)
+NECAT_D void fast_advance_m1(FastWord& w, u32 el, u32 eh, u32 cph, u32 cm1, u32 cm, u32 mw, u32& phh_out, u32& mhh_out)
+{
+    const u32 pl = (u32)w.Pv, ph = (u32)(w.Pv >> 32), ml = (u32)w.Mv, mh = (u32)(w.Mv >> 32);
+    const u32 xvl = el | ml, xvh = eh | mh;
+    const u32 e2l = el | cm1;
+#if defined(NECAT_CK_MV) && NECAT_CK_MV == 3      // (tools/ck_microbench.hip: timing variants, wrong results)
+    const u64 sum = (((u64)(eh & ph) << 32) | (e2l & pl)) ^ w.Pv;
+#else
+    const u64 sum = (((u64)(eh & ph) << 32) | (e2l & pl)) + w.Pv;
+#endif
+    const u32 sl = (u32)sum, sh = (u32)(sum >> 32);
+    const u32 xhl = bop<0xbe>(sl, pl, e2l), xhh = bop<0xbe>(sh, ph, eh);
+    const u32 phl = bop<0xf1>(ml, xhl, pl), phh = bop<0xf1>(mh, xhh, ph);
+    const u32 mhl = pl & xhl, mhh = ph & xhh;
+    phh_out = phh; mhh_out = mhh;
+    w.pubP = phh | cm; w.pubM = __builtin_amdgcn_ubfe(mhh, 31u, mw);
+    const u32 p2l = __builtin_amdgcn_alignbit(phl, cph, 31), p2h = __builtin_amdgcn_alignbit(phh, phl, 31);
+    const u32 m2l = (mhl << 1) | cm1, m2h = __builtin_amdgcn_alignbit(mhh, mhl, 31);
+    const u32 ol = bop<0xf1>(m2l, xvl, p2l), oh = bop<0xf1>(m2h, xvh, p2h);
+    const u32 nl = p2l & xvl, nh = p2h & xvh;
+    w.Pv = ((u64)oh << 32) | ol; w.Mv = ((u64)nh << 32) | nl;
+}
+
+template <int TW>
+NECAT_D u32 fast_shw8_ckp(const int b, const u64* __restrict__ tw, const u64 nlo, const u64 nhi, ulonglong2* __restrict__ ck, u64* __restrict__ hc, const u32 dbg = 0u)
+{
+    // dbg (tools/ck_microbench.hip only; 0 in the library): bit 0 = no checkpoint / delta stores
+    const bool st = !(dbg & 1u);
+    constexpr int G = 8, N = kOcaBlockSize, kSteps = N + G - 1;
+    static_assert(N == 512 && TW * 32 >= N, "16 windows of 32 columns");
+    const u32 cm = b == G - 1 ? 0x80000000u : 0u;
+    const u32 nlo_l = (u32)nlo, nlo_h = (u32)(nlo >> 32), nhi_l = (u32)nhi, nhi_h = (u32)(nhi >> 32);
+    const u32 sk = (u32)(32 - b) & 31u;
+    const int jck = (b + 31) & 31, jck16 = (b + 15) & 15;
+    u32 hp = 0, hm = 0;
+    u32 tlo = 0, thi = 0, plo = 0, phi = 0;
+    FastWord w; w.Pv = ~0ULL; w.Mv = 0ULL; w.pubP = 0x80000000u; w.pubM = 0u;
+    const u32 mw = b == G - 1 ? 0u : 1u;
+    u32 cph = 0x80000000u, cmh = 0u;           // (cmh: 0 / 1 here, fast_advance_m1)
+    auto step = [&](const int j) {          // one column of this lane's word: the target bit of step j of the window, the recurrence, the delta bits
+#if defined(NECAT_CK_MV) && NECAT_CK_MV == 4
+        const u32 el = nlo_l ^ (u32)j, eh = nlo_h;
+#else
+        const u32 ma = (u32)__builtin_amdgcn_sbfe((int)tlo, (u32)j, 1u), mb = (u32)__builtin_amdgcn_sbfe((int)thi, (u32)j, 1u);
+        const u32 el = bop<0x60>(nlo_l ^ ma, nhi_l, mb), eh = bop<0x60>(nlo_h ^ ma, nhi_h, mb);
+#endif
+        u32 phh, mhh;
+        fast_advance_m1(w, el, eh, cph, cmh, cm, mw, phh, mhh);
+#if defined(NECAT_CK_MV) && NECAT_CK_MV == 2
+        hp ^= phh; hm |= mhh;
+#else
+        hp = __builtin_amdgcn_alignbit(hp, phh, 31); hm = __builtin_amdgcn_alignbit(hm, mhh, 31);
+#endif
+    };
+    // ckr / hcr: the slots of the window's first column (two checkpoints, one delta word per window)
+    ulonglong2* ckr = ck; u64* hcr = hc;
+#if defined(NECAT_CK_MV) && (NECAT_CK_MV == 5 || NECAT_CK_MV == 7 || NECAT_CK_MV == 8 || NECAT_CK_MV == 10)
+    for (int s0 = 0; s0 < (NECAT_CK_MV == 5 ? kSteps / 2 : NECAT_CK_MV == 8 ? 32 : 0); s0 += 32, ckr += 2 * G, hcr += G) {
+#else
+    for (int s0 = 0; s0 < kSteps; s0 += 32, ckr += 2 * G, hcr += G) {
+#endif
+        {
+            const u64 x = (s0 >> 5) < TW ? tw[s0 >> 5] : 0ULL;
+            const u32 xl = (u32)x, xh = (u32)(x >> 32);
+            tlo = b ? __builtin_amdgcn_alignbit(xl, plo, sk) : xl;
+            thi = b ? __builtin_amdgcn_alignbit(xh, phi, sk) : xh;
+            plo = xl; phi = xh;
+        }
+        if (s0 != 0 && s0 + 32 <= N) {
+            // steps 32 .. 511: every lane is inside its block; the slots relative to the window's are constants
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+#if defined(NECAT_CK_MV) && NECAT_CK_MV == 1
+                cph = w.pubP; cmh = w.pubM;
+#else
+                cph = dpp_row_shr1(w.pubP, cph); cmh = dpp_row_shr1(w.pubM, cmh);
+#endif
+                step(j);
+                const int K = ((j & 15) + 1) & 15;                 // the word whose column is 15 mod 16 at this step
+                if (K < G && b == K && st) {
+                    ckr[((j - K) >> 4) * G] = make_ulonglong2(w.Pv, w.Mv);
+                    if (j == ((K + 31) & 31)) hcr[((j - K) >> 5) * G] = (u64)hp | ((u64)hm << 32);
+                }
+            }
+        } else {
+            const int jn = kSteps - s0 < 32 ? kSteps - s0 : 32;
+            for (int j = 0; j < jn; ++j) {
+                const int s = s0 + j;
+                cph = dpp_row_shr1(w.pubP, cph); cmh = dpp_row_shr1(w.pubM, cmh);
+                const bool edge = s < G - 1 || s >= N;
+                if (!edge || (s >= b && s - b < N)) {
+                    step(j);
+                    if ((j & 15) == jck16) {
+                        ckr[((j - b) >> 4) * G] = make_ulonglong2(w.Pv, w.Mv);
+                        if (j == jck) hcr[((j - b) >> 5) * G] = (u64)hp | ((u64)hm << 32);
+                    }
+                }
+            }
+        }
+    }
+    // ---- the bottom row: word 7's deltas, 64 columns per lane.  (The stores above and these loads are by lanes of ONE wave: made visible
+    // by a workgroup-scope release / acquire - no cache maintenance on gfx950, the CU's vector cache is coherent for its own wavefronts.)
+#if defined(NECAT_CK_MV) && NECAT_CK_MV == 6
+    return (u32)(w.Pv ^ w.Mv ^ hp ^ hm);
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const u64* hb = hc - b + (G - 1);                                // slot m of word 7: hb[m * G]
+    const u64 g0 = __builtin_nontemporal_load(hb + (size_t)(2 * b) * G), g1 = __builtin_nontemporal_load(hb + (size_t)(2 * b + 1) * G);
+    const u32 P0 = (u32)g0, M0 = (u32)(g0 >> 32), P1 = (u32)g1, M1 = (u32)(g1 >> 32);
+    const int d = (int)__popc(P0) + (int)__popc(P1) - (int)__popc(M0) - (int)__popc(M1);
+    int incl = d;
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) { const int v = __shfl_up(incl, o); if (b >= o) incl += v; }
+    u32 S = (u32)(N + incl - d);                                     // the bottom row's value left of this lane's first column
+    u32 key = 0xffffffffu;
+    const u32 c0 = (u32)(64 * b + G - 1);
+#pragma unroll
+    for (int x = 0; x < 32; ++x) {
+        S += ((P0 >> (31 - x)) & 1u) - ((M0 >> (31 - x)) & 1u);
+        const u32 k2 = (S << 10) + c0 + (u32)x;
+        key = k2 < key ? k2 : key;
+    }
+#pragma unroll
+    for (int x = 0; x < 32; ++x) {
+        S += ((P1 >> (31 - x)) & 1u) - ((M1 >> (31 - x)) & 1u);
+        const u32 k2 = (S << 10) + c0 + 32u + (u32)x;
+        key = k2 < key ? k2 : key;
+    }
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) { const u32 v = (u32)__shfl_xor((int)key, o); key = v < key ? v : key; }
+    return key;
+}
+
 // fast_shw8_ck<CARRY = true> for a block of ANY size up to 512 x 512 (the ragged blocks of list A: a last block of an extension, qn x tn): the
 // same 8-lane wavefront - lane = 64-row word, DPP carries, v_bitop3 logic, one 64-bit add - with what the general pass k_myers_ckg does for
 // such a block: only the words the query has (b < nblk), the rows past the query in its last word wildcards (build_peq's pad bits,
@@ -190,7 +338,13 @@ k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u
         int steps = valid ? tn + nblk - 1 : 0;
         for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
         key = fast_shw_ckr<8, 8, TW>(b, valid ? qn : 0, valid ? tn : 0, steps, t_lds[sub], nlo, nhi, ckp, hcp);
-    } else key = fast_shw8_ck<TW, CARRY>(b, t_lds[sub], nlo, nhi, ckp, hcp);
+#ifdef NECAT_CK_MICRO
+    } else if (CARRY && !((flags >> 24) & 1u)) key = fast_shw8_ckp<TW>(b, t_lds[sub], nlo, nhi, (flags >> 21) & 1u ? ckpt + (size_t)(blockIdx.x & 1023u) * 8 * (kRcCk16 * G) + (size_t)sub * (kRcCk16 * G) + b : ckp,
+                                                                       (flags >> 21) & 1u ? hcar + (size_t)(blockIdx.x & 1023u) * 8 * (kRcCk * G) + (size_t)sub * (kRcCk * G) + b : hcp, (flags >> 20) & 1u);
+#else
+    } else if (CARRY && !((flags >> 24) & 1u)) key = fast_shw8_ckp<TW>(b, t_lds[sub], nlo, nhi, ckp, hcp);        // (bit 24, NECAT_CK_POST=0: the minimum tracked inside the pass, as before)
+#endif
+    else key = fast_shw8_ck<TW, CARRY>(b, t_lds[sub], nlo, nhi, ckp, hcp);
     const int bl = ragged ? nblk - 1 : G - 1;                           // the word the distance was read in
     const u32 bkey = (u32)__shfl((int)key, (lane & ~(G - 1)) | bl);
     int best = (int)(bkey >> 10);
@@ -212,9 +366,13 @@ k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u
     unsigned long long wsum = owner ? (unsigned long long)(nblk * tn) : 0ULL, bsum = owner ? (unsigned long long)(qn + tn) : 0ULL;
     if (ragged) for (int o = 32; o > 0; o >>= 1) { wsum += __shfl_xor(wsum, o); bsum += __shfl_xor(bsum, o); }
     else { wsum = (unsigned long long)popc64(m_all) * (unsigned long long)(NW * N); bsum = (unsigned long long)popc64(m_all) * (unsigned long long)(2 * N); }
+#if defined(NECAT_CK_MV) && (NECAT_CK_MV == 9 || NECAT_CK_MV == 10)
+    if (lane == 0 && m_all && wsum == 12345) {
+#else
     if (lane == 0 && m_all) {
-        atomicAdd(&stats[0], wsum); atomicAdd(&stats[1], bsum);
-        if (m_walk) atomicAdd(&stats[3], (unsigned long long)popc64(m_walk));           // blocks the recomputing walk will take
+#endif
+        stat_add(stats, 0, wsum); stat_add(stats, 1, bsum);
+        if (m_walk) stat_add(stats, 3, (unsigned long long)popc64(m_walk));           // blocks the recomputing walk will take
     }
 }
 
@@ -354,7 +512,7 @@ k_rcwalk4(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u3
         __syncthreads();             // the slices are read before the next segment overwrites them
     }
     for (int o = 32; o > 0; o >>= 1) words_done += (u32)__shfl_xor((int)words_done, o);
-    if (lane == 0 && words_done) { atomicAdd(&stats[0], (unsigned long long)words_done); atomicAdd(&stats[4], (unsigned long long)words_done); }
+    if (lane == 0 && words_done) { stat_add(stats, 0, (unsigned long long)words_done); stat_add(stats, 4, (unsigned long long)words_done); }
 }
 
 
@@ -462,7 +620,7 @@ k_myers_ckg(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
     {   // the work counters once per wave
         unsigned long long w = is_last ? (unsigned long long)(nblk * tn) : 0ULL, bs = is_last ? (unsigned long long)(qn + tn) : 0ULL;
         for (int o = 32; o > 0; o >>= 1) { w += __shfl_xor(w, o); bs += __shfl_xor(bs, o); }
-        if (lane == 0 && w) { atomicAdd(&stats[0], w); atomicAdd(&stats[1], bs); }
+        if (lane == 0 && w) { stat_add(stats, 0, w); stat_add(stats, 1, bs); }
     }
 }
 
@@ -517,7 +675,7 @@ k_myers_ckf(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
     {   // the work counters once per wave
         unsigned long long w = owner ? (unsigned long long)(nblk * tn) : 0ULL, bs = owner ? (unsigned long long)(qn + tn) : 0ULL;
         for (int o = 32; o > 0; o >>= 1) { w += __shfl_xor(w, o); bs += __shfl_xor(bs, o); }
-        if (lane == 0 && w) { atomicAdd(&stats[0], w); atomicAdd(&stats[1], bs); }
+        if (lane == 0 && w) { stat_add(stats, 0, w); stat_add(stats, 1, bs); }
     }
 }
 
@@ -661,7 +819,7 @@ k_rcwalk2(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict
         __syncthreads();             // the slices are read before the next segment overwrites them
     }
     for (int o = 32; o > 0; o >>= 1) words_done += (u32)__shfl_xor((int)words_done, o);
-    if (lane == 0 && words_done) { atomicAdd(&stats[0], (unsigned long long)words_done); atomicAdd(&stats[4], (unsigned long long)words_done); }
+    if (lane == 0 && words_done) { stat_add(stats, 0, (unsigned long long)words_done); stat_add(stats, 4, (unsigned long long)words_done); }
 }
 
 
@@ -885,7 +1043,7 @@ k_rcwalk2w(const BlockItem* __restrict__ items, u32 n_host, const u32* __restric
     if (sink == 0x7fffffff) atomicExch(err_flag, 21);             // (keeps the sink alive; never true)
 #endif
     for (int o = 32; o > 0; o >>= 1) words_done += (u32)__shfl_xor((int)words_done, o);
-    if (lane == 0 && words_done) { atomicAdd(&stats[0], (unsigned long long)words_done); atomicAdd(&stats[4], (unsigned long long)words_done); }
+    if (lane == 0 && words_done) { stat_add(stats, 0, (unsigned long long)words_done); stat_add(stats, 4, (unsigned long long)words_done); }
 }
 
 

@@ -244,7 +244,7 @@ k_tail_fused(DevVolume reads, DevVolume ref, const BlockItem* __restrict__ items
     __syncthreads();
     // ---- walk, trimming, the candidate's counters, its kept columns, its next block
     const int dist = res[0], endc = res[1];
-    if (lane == 0) { atomicAdd(&stats[0], (unsigned long long)(nblk * tn)); atomicAdd(&stats[1], (unsigned long long)(qn + tn)); }
+    if (lane == 0) { stat_add(stats, 0, (unsigned long long)(nblk * tn)); stat_add(stats, 1, (unsigned long long)(qn + tn)); }
     LdsBand mr; mr.band = band; mr.nblk = nblk;
     LdsSame<NW> same; same.fr = fr;
     wave_after_dp<MAXOPS, kOcaBlockSize>(lane, it, dist, endc, mr, same, ops, tasks, tail_match_len, err_flag, next);

@@ -82,6 +82,7 @@ u32 g_rc_listb;        // NECAT_RC_LISTB (default 1, needs NECAT_RC_CARRY): list
 u32 g_rc_ragged;       // NECAT_RC_RAGGED (default 1, needs NECAT_RC_CARRY): the ragged blocks of those rounds through k_myers_ckg + k_rcwalk2 as well (0: two-pass kernel + lane walk on a stream of their own)
 u32 g_ck_lds;          // NECAT_CK_LDS (bytes, default 0): dynamic LDS claimed by every workgroup (one wave) of k_myers_ck - caps how many of its waves a CU holds (160 KB / (1 KB + this)), leaving wave slots to the chains of the other streams (A/B measurements)
 u32 g_rc_merge;        // NECAT_RC_MERGE (default 1, needs NECAT_RC_RAGGED): the ragged list-A blocks of a big round through k_myers_ck's ragged fast path and the full blocks' walk launch; 0 = k_myers_ckg + a walk launch of their own on stream d
+u32 g_ck_post;         // NECAT_CK_POST (default 1): k_myers_ck finds the bottom row's minimum after the pass, from word 7's deltas, and unrolls its windows (fast_shw8_ckp); 0 = tracked inside the pass
 u32 g_rc_fastb;        // NECAT_RC_FASTB (default 1): list B's checkpoint pass through k_myers_ckf (32-bit halves, bitop3, DPP carries); 0 = the general pass k_myers_ckg
 u32 g_rc_dbg;          // NECAT_RC_DBG (timing only): 2 = k_rcwalk2w walks every segment twice (once into a sink), 4 = recomputes every segment twice
 u32 g_rc_prefetch;     // NECAT_RC_PREFETCH (default 0: measured 0.4 ms per step SLOWER, profiles/NOTES_r04.md 3): k_rcwalk2w loads the next segment's checkpoints / deltas / planes a segment ahead
@@ -117,6 +118,7 @@ void read_knobs()
     g_rc_prefetch = (u32)num("NECAT_RC_PREFETCH", 0);
     g_rc_dbg = (u32)num("NECAT_RC_DBG", 0) & 6u;
     g_rc_fastb = (u32)num("NECAT_RC_FASTB", 1);
+    g_ck_post = (u32)num("NECAT_CK_POST", 1);
     g_rc_merge = (u32)num("NECAT_RC_MERGE", 1);
     g_ck_lds = (u32)num("NECAT_CK_LDS", 0);
     g_rc_listb = g_rc_carry ? (u32)num("NECAT_RC_LISTB", 1) : 0u;
@@ -1376,7 +1378,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                 if (ckg_all && g_rc_ragged) {}
                 else if (g_rc_carry)
                     hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA, true>), dim3((cn + 7) / 8), dim3(64), g_ck_lds, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error, c.resA, X.stats, g_rc_maxdist, lo, hi,
-                                       merged ? fl_all : epoch);
+                                       (merged ? fl_all : epoch) | (g_ck_post ? 0u : 1u << 24));
                 else
                     hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA, false>), dim3((cn + 7) / 8), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error, c.resA, X.stats, g_rc_maxdist, lo, hi, epoch);
                 if (g_rc_ragged && !merged) {
@@ -1637,7 +1639,9 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
         k.base = 0; k.n = 0;
     }
     ExtShared X;
-    X.d_cands = d_cands; X.d_m4 = d_m4; X.d_ok = d_ok; X.d_err = d_err; X.stats = (unsigned long long*)(d_outcnt + 18);
+    if ((rc = buf_ensure(ctx, ctx->scratch[SC_STATS], kStatBytes))) return rc;          // the work counters, kStatSlots copies (stat_add, ext_kernels.h)
+    NECAT_HIP(ctx, hipMemsetAsync(ctx->scratch[SC_STATS].p, 0, kStatBytes, s));
+    X.d_cands = d_cands; X.d_m4 = d_m4; X.d_ok = d_ok; X.d_err = d_err; X.stats = (unsigned long long*)ctx->scratch[SC_STATS].p;
     X.error = opt->error; X.tail_match_len = tail_match_len; X.min_align = opt->align_size_cutoff;
     X.read_start_id = read_start_id; X.ref_start_id = ref_start_id; X.reads_off = reads->seq_off; X.ref_off = ref->seq_off;
     std::vector<u64> goff;
@@ -1728,8 +1732,10 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     tick("rounds");
     {
         unsigned long long hs[5] = {0, 0, 0, 0, 0};
-        NECAT_HIP(ctx, hipMemcpyAsync(hs, X.stats, 40, hipMemcpyDeviceToHost, s));
+        std::vector<unsigned long long> copies((size_t)kStatSlots * kStatStride);
+        NECAT_HIP(ctx, hipMemcpyAsync(copies.data(), X.stats, kStatBytes, hipMemcpyDeviceToHost, s));
         NECAT_HIP(ctx, hipStreamSynchronize(s));
+        for (int c = 0; c < kStatSlots; ++c) for (int q = 0; q < 5; ++q) hs[q] += copies[(size_t)c * kStatStride + q];
         ctx->tm.myers_word_updates = hs[0]; ctx->tm.myers_cells_bases = hs[1]; ctx->tm.myers_band_words = hs[2];
         ctx->tm.rc_blocks = hs[3]; ctx->tm.rc_words = hs[4];
     }
@@ -1871,7 +1877,8 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
     auto take = [&](size_t bytes) { char* p = mb; mb += (bytes + 255) & ~(size_t)255; return p; };
     u32* d_count = (u32*)take(256);                    // [0..3] list buffer 0, [4..7] list buffer 1 (ExtLists counters: full A blocks, B blocks, other A blocks), [16] error flag, [32..] work counters
     int* d_err = (int*)(d_count + 16);
-    unsigned long long* d_stats = (unsigned long long*)(d_count + 32);
+    if ((rc = buf_ensure(ctx, ctx->scratch[SC_STATS], kStatBytes))) return rc;
+    unsigned long long* d_stats = (unsigned long long*)ctx->scratch[SC_STATS].p;       // (work counters nobody reads here; the kernels want their kStatSlots copies)
     AsmAnchor* d_anchor = (AsmAnchor*)take(n * sizeof(AsmAnchor));
     ExtTask* d_tasks = (ExtTask*)take(n * sizeof(ExtTask));
     BlockItem* d_itemsA[2]; BlockItem* d_itemsB[2];
@@ -3154,7 +3161,8 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
     int* d_err = nullptr;
     NECAT_HIP(ctx, hipMalloc((void**)&d_err, 4 + 4 + 24));
     NECAT_HIP(ctx, hipMemsetAsync(d_err, 0, 32, s));
-    unsigned long long* d_stats = (unsigned long long*)(d_err + 2);
+    { const int rcs = buf_ensure(ctx, ctx->scratch[SC_STATS], kStatBytes); if (rcs) { (void)hipFree(d_err); return rcs; } }
+    unsigned long long* d_stats = (unsigned long long*)ctx->scratch[SC_STATS].p;
     const u32 chunk = getenv("NECAT_BATCH_CHUNK") ? (u32)strtoul(getenv("NECAT_BATCH_CHUNK"), nullptr, 10) : 65536u;
     auto run_shape = [&](std::vector<BlockItem>& items, std::vector<u64>& ids, bool full) -> int {
         for (size_t base = 0; base < items.size(); base += chunk) {

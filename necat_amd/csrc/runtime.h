@@ -146,6 +146,7 @@ enum ScratchId {
     SC_ASM_BAND, SC_ASM_OPS, SC_ASM_COLS, SC_ASM_MISC, SC_ASM_FRAG, SC_ASM_OUT, SC_SEED_KST, SC_EXT_CKPT, SC_EXT_WOUT, SC_EXT_CKPTB, SC_EXT_CKPTB2, SC_EXT_WOUTB, SC_EXT_WOUTB2,
     SC_ASM_OCC, SC_ASM_TAB, SC_ASM_VMETA, SC_ASM_VHT, SC_ASM_VPOOL, SC_ASM_VOUT, SC_ASM_SEL, SC_ASM_RIDX, SC_ASM_RNEXT, SC_ASM_PAIRS, SC_ASM_SEEDS,
     SC_ASM_VMETA2, SC_ASM_VHT2, SC_ASM_VPOOL2, SC_ASM_VOUT2, SC_ASM_SEL2, SC_ASM_RIDX2, SC_ASM_RNEXT2,
+    SC_STATS,
     SC_COUNT
 };
 
