@@ -31,6 +31,19 @@ constexpr int kRcMaxDist = 160;                  // 63 (alignment of the window)
 // CARRY (the 2-lane-window walk k_rcwalk2 below): checkpoints every 16 columns (slot m = the state after column 16 m + 15) and every word's
 // horizontal output deltas kept as well - two bits per column, 32 columns per u64 {P bits, M bits << 32}, the bit of column 32 m + x at
 // position 31 - x (one v_alignbit per plane and step) - so that ANY word can later be recomputed exactly from a checkpoint alone.
+// ---- where a checkpoint / a delta word lives.  Slot `slot` (of `slots` per block), word w of block x (work index minus the launch's `lo`):
+// the blocks whose word-w lanes store in ONE instruction of the checkpoint pass - the 8 blocks of a list-A wave, the 4 of a list-B wave -
+// sit side by side, so that instruction writes one 128- (64-) byte line instead of 16 bytes in 8 (4) lines 4 KB apart: 5 - 7 % of the pass
+// (tools/ck_microbench.hip).  The walk reads a block's two words of a slot as two 16-byte pieces either way.
+template <int NW> struct RcLay { static constexpr int kGI = NW == 8 ? 8 : NW == 13 ? 4 : 1; };       // blocks per group (the 2048-bp geometries: one block per wave)
+template <int NW>
+NECAT_D size_t rc_at(u64 x, int slots, size_t slot, size_t w)
+{
+    constexpr u64 GI = RcLay<NW>::kGI;
+    return (size_t)((((x / GI) * (u64)slots + slot) * NW + w) * GI + x % GI);
+}
+template <int NW> constexpr int kRcStride = NW * RcLay<NW>::kGI;          // elements between two slots' same word
+
 template <int TW, bool CARRY>
 NECAT_D u32 fast_shw8_ck(const int b, const u64* __restrict__ tw, const u64 nlo, const u64 nhi, ulonglong2* __restrict__ ck, u64* __restrict__ hc)
 {
@@ -70,11 +83,11 @@ NECAT_D u32 fast_shw8_ck(const int b, const u64* __restrict__ tw, const u64 nlo,
                 if (CARRY) {
                     hp = __builtin_amdgcn_alignbit(hp, phh, 31); hm = __builtin_amdgcn_alignbit(hm, mhh, 31);      // (h << 1) | top bit
                     if ((j & 15) == jck16) {
-                        ck[(size_t)((s - b) >> 4) * G] = make_ulonglong2(w.Pv, w.Mv);
-                        if (j == jck) hc[(size_t)((s - b) >> 5) * G] = (u64)hp | ((u64)hm << 32);
+                        ck[(size_t)((s - b) >> 4) * kRcStride<G>] = make_ulonglong2(w.Pv, w.Mv);
+                        if (j == jck) hc[(size_t)((s - b) >> 5) * kRcStride<G>] = (u64)hp | ((u64)hm << 32);
                     }
                 } else
-                if (j == jck) ck[(size_t)((s - b) >> 5) * G] = make_ulonglong2(w.Pv, w.Mv);      // state after column 32 m + 31 -> slot m
+                if (j == jck) ck[(size_t)((s - b) >> 5) * kRcStride<G>] = make_ulonglong2(w.Pv, w.Mv);      // state after column 32 m + 31 -> slot m
             }
         }
     }
@@ -118,7 +131,7 @@ NECAT_D void fast_advance_m1(FastWord& w, u32 el, u32 eh, u32 cph, u32 cm1, u32 
     w.Pv = ((u64)oh << 32) | ol; w.Mv = ((u64)nh << 32) | nl;
 }
 
-template <int TW>
+template <int TW, int ST = kRcStride<8>>          // ST: distance of two slots' same word in `ck` / `hc` (elements)
 NECAT_D u32 fast_shw8_ckp(const int b, const u64* __restrict__ tw, const u64 nlo, const u64 nhi, ulonglong2* __restrict__ ck, u64* __restrict__ hc, const u32 dbg = 0u)
 {
     // dbg (tools/ck_microbench.hip only; 0 in the library): bit 0 = no checkpoint / delta stores
@@ -152,9 +165,9 @@ NECAT_D u32 fast_shw8_ckp(const int b, const u64* __restrict__ tw, const u64 nlo
     // ckr / hcr: the slots of the window's first column (two checkpoints, one delta word per window)
     ulonglong2* ckr = ck; u64* hcr = hc;
 #if defined(NECAT_CK_MV) && (NECAT_CK_MV == 5 || NECAT_CK_MV == 7 || NECAT_CK_MV == 8 || NECAT_CK_MV == 10)
-    for (int s0 = 0; s0 < (NECAT_CK_MV == 5 ? kSteps / 2 : NECAT_CK_MV == 8 ? 32 : 0); s0 += 32, ckr += 2 * G, hcr += G) {
+    for (int s0 = 0; s0 < (NECAT_CK_MV == 5 ? kSteps / 2 : NECAT_CK_MV == 8 ? 32 : 0); s0 += 32, ckr += 2 * ST, hcr += ST) {
 #else
-    for (int s0 = 0; s0 < kSteps; s0 += 32, ckr += 2 * G, hcr += G) {
+    for (int s0 = 0; s0 < kSteps; s0 += 32, ckr += 2 * ST, hcr += ST) {
 #endif
         {
             const u64 x = (s0 >> 5) < TW ? tw[s0 >> 5] : 0ULL;
@@ -175,8 +188,8 @@ NECAT_D u32 fast_shw8_ckp(const int b, const u64* __restrict__ tw, const u64 nlo
                 step(j);
                 const int K = ((j & 15) + 1) & 15;                 // the word whose column is 15 mod 16 at this step
                 if (K < G && b == K && st) {
-                    ckr[((j - K) >> 4) * G] = make_ulonglong2(w.Pv, w.Mv);
-                    if (j == ((K + 31) & 31)) hcr[((j - K) >> 5) * G] = (u64)hp | ((u64)hm << 32);
+                    ckr[((j - K) >> 4) * ST] = make_ulonglong2(w.Pv, w.Mv);
+                    if (j == ((K + 31) & 31)) hcr[((j - K) >> 5) * ST] = (u64)hp | ((u64)hm << 32);
                 }
             }
         } else {
@@ -188,8 +201,8 @@ NECAT_D u32 fast_shw8_ckp(const int b, const u64* __restrict__ tw, const u64 nlo
                 if (!edge || (s >= b && s - b < N)) {
                     step(j);
                     if ((j & 15) == jck16) {
-                        ckr[((j - b) >> 4) * G] = make_ulonglong2(w.Pv, w.Mv);
-                        if (j == jck) hcr[((j - b) >> 5) * G] = (u64)hp | ((u64)hm << 32);
+                        ckr[((j - b) >> 4) * ST] = make_ulonglong2(w.Pv, w.Mv);
+                        if (j == jck) hcr[((j - b) >> 5) * ST] = (u64)hp | ((u64)hm << 32);
                     }
                 }
             }
@@ -202,8 +215,8 @@ NECAT_D u32 fast_shw8_ckp(const int b, const u64* __restrict__ tw, const u64 nlo
 #endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    const u64* hb = hc - b + (G - 1);                                // slot m of word 7: hb[m * G]
-    const u64 g0 = __builtin_nontemporal_load(hb + (size_t)(2 * b) * G), g1 = __builtin_nontemporal_load(hb + (size_t)(2 * b + 1) * G);
+    const u64* hb = hc + (G - 1 - b) * (ST / G);                      // slot m of word 7: hb[m * ST]
+    const u64 g0 = __builtin_nontemporal_load(hb + (size_t)(2 * b) * ST), g1 = __builtin_nontemporal_load(hb + (size_t)(2 * b + 1) * ST);
     const u32 P0 = (u32)g0, M0 = (u32)(g0 >> 32), P1 = (u32)g1, M1 = (u32)(g1 >> 32);
     const int d = (int)__popc(P0) + (int)__popc(P1) - (int)__popc(M0) - (int)__popc(M1);
     int incl = d;
@@ -285,10 +298,10 @@ NECAT_D u32 fast_shw_ckr(const int b, const int qn, const int tn, const int step
                 }
                 hp = __builtin_amdgcn_alignbit(hp, phh, 31); hm = __builtin_amdgcn_alignbit(hm, mhh, 31);
                 if ((j & 15) == jck16) {
-                    ck[(size_t)(c >> 4) * NWS] = make_ulonglong2(w.Pv, w.Mv);
-                    if (j == jck) hc[(size_t)(c >> 5) * NWS] = (u64)hp | ((u64)hm << 32);
+                    ck[(size_t)(c >> 4) * kRcStride<NWS>] = make_ulonglong2(w.Pv, w.Mv);
+                    if (j == jck) hc[(size_t)(c >> 5) * kRcStride<NWS>] = (u64)hp | ((u64)hm << 32);
                 }
-                if (c == tn - 1 && (c & 31) != 31) { const int sh = 31 - (c & 31); hc[(size_t)(c >> 5) * NWS] = (u64)(hp << sh) | ((u64)(hm << sh) << 32); }
+                if (c == tn - 1 && (c & 31) != 31) { const int sh = 31 - (c & 31); hc[(size_t)(c >> 5) * kRcStride<NWS>] = (u64)(hp << sh) | ((u64)(hm << sh) << 32); }
             }
         }
     }
@@ -305,6 +318,7 @@ k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u
     // work items [lo, hi) of the list (multiples of 64: a big list goes through a bounded checkpoint buffer in several launches);
     // checkpoint / delta slots are indexed by item - lo
     constexpr int FW = 2 * NW + TW, G = 8, N = kOcaBlockSize;
+    if ((flags >> 23) & 1u) __builtin_amdgcn_s_setprio(3);          // (NECAT_RC_PRIO bit 1)
     __shared__ u64 t_lds[8][TW];
     const ListView lv = list_view(0u, n_dev, capA);
     const bool all = CARRY && ((flags >> 27) & 1u) != 0;
@@ -331,16 +345,15 @@ k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u
         t_lds[sub][w] = even_bits(x) | (even_bits(x >> 1) << 32);
     }
     __syncthreads();
-    ulonglong2* const ckp = ckpt + (size_t)(item - lo) * ((CARRY ? kRcCk16 : kRcCk) * G) + b;
-    u64* const hcp = hcar + (size_t)(item - lo) * (kRcCk * G) + b;
+    ulonglong2* const ckp = ckpt + rc_at<G>(item - lo, CARRY ? kRcCk16 : kRcCk, 0, (size_t)b);
+    u64* const hcp = hcar + rc_at<G>(item - lo, kRcCk, 0, (size_t)b);
     u32 key;
     if (ragged) {
         int steps = valid ? tn + nblk - 1 : 0;
         for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
         key = fast_shw_ckr<8, 8, TW>(b, valid ? qn : 0, valid ? tn : 0, steps, t_lds[sub], nlo, nhi, ckp, hcp);
 #ifdef NECAT_CK_MICRO
-    } else if (CARRY && !((flags >> 24) & 1u)) key = fast_shw8_ckp<TW>(b, t_lds[sub], nlo, nhi, (flags >> 21) & 1u ? ckpt + (size_t)(blockIdx.x & 1023u) * 8 * (kRcCk16 * G) + (size_t)sub * (kRcCk16 * G) + b : ckp,
-                                                                       (flags >> 21) & 1u ? hcar + (size_t)(blockIdx.x & 1023u) * 8 * (kRcCk * G) + (size_t)sub * (kRcCk * G) + b : hcp, (flags >> 20) & 1u);
+    } else if (CARRY && !((flags >> 24) & 1u)) key = fast_shw8_ckp<TW>(b, t_lds[sub], nlo, nhi, ckp, hcp, (flags >> 20) & 1u);
 #else
     } else if (CARRY && !((flags >> 24) & 1u)) key = fast_shw8_ckp<TW>(b, t_lds[sub], nlo, nhi, ckp, hcp);        // (bit 24, NECAT_CK_POST=0: the minimum tracked inside the pass, as before)
 #endif
@@ -431,7 +444,7 @@ k_rcwalk4(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u3
             nlo_l = (u32)a; nlo_h = (u32)(a >> 32); nhi_l = (u32)bq; nhi_h = (u32)(bq >> 32); wcur = w;
         }
         FastWord wd; wd.Pv = ~0ULL; wd.Mv = 0ULL; wd.pubP = 0x80000000u; wd.pubM = 0u;
-        if (!fin && seg > 0) { const ulonglong2 v = ckpt[((size_t)(item - lo) * kRcCk + (size_t)(seg - 1)) * 8 + (size_t)w]; wd.Pv = v.x; wd.Mv = v.y; }
+        if (!fin && seg > 0) { const ulonglong2 v = ckpt[rc_at<8>(item - lo, kRcCk, (size_t)(seg - 1), (size_t)w)]; wd.Pv = v.x; wd.Mv = v.y; }
         if (!fin && seg != segcur) {
             const u64 x = fr[(u64)(2 * NW + seg) * 64];
             tlo = (u32)even_bits(x); thi = (u32)even_bits(x >> 1); segcur = seg;
@@ -572,8 +585,8 @@ k_myers_ckg(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
     };
     int steps = valid ? tn + nblk - 1 : 0;
     for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
-    ulonglong2* const ck = ckpt + ((size_t)(item - lo) * CK) * NW + b;
-    u64* const hc = hcar + ((size_t)(item - lo) * SEGS) * NW + b;
+    ulonglong2* const ck = ckpt + rc_at<NW>(item - lo, CK, 0, (size_t)b);
+    u64* const hc = hcar + rc_at<NW>(item - lo, SEGS, 0, (size_t)b);
     int k = (int)((double)(qn < tn ? qn : tn) * error * 1.1);
     u64 P = ~0ULL, M = 0ULL;
     int S = (b + 1) * 64, best = -1, end0 = -1, hout = 1;
@@ -590,10 +603,10 @@ k_myers_ckg(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
             S += hout;
             hp = (hp << 1) | ((u32)(hout + 1) >> 1); hm = (hm << 1) | ((u32)hout >> 31);
             if ((c & 15) == 15) {
-                ck[(size_t)(c >> 4) * NW] = make_ulonglong2(P, M);
-                if ((c & 31) == 31) hc[(size_t)(c >> 5) * NW] = (u64)hp | ((u64)hm << 32);
+                ck[(size_t)(c >> 4) * kRcStride<NW>] = make_ulonglong2(P, M);
+                if ((c & 31) == 31) hc[(size_t)(c >> 5) * kRcStride<NW>] = (u64)hp | ((u64)hm << 32);
             }
-            if (c == tn - 1 && (c & 31) != 31) { const int sh = 31 - (c & 31); hc[(size_t)(c >> 5) * NW] = (u64)(hp << sh) | ((u64)(hm << sh) << 32); }
+            if (c == tn - 1 && (c & 31) != 31) { const int sh = 31 - (c & 31); hc[(size_t)(c >> 5) * kRcStride<NW>] = (u64)(hp << sh) | ((u64)(hm << sh) << 32); }
             if (is_last && S <= k && (best == -1 || S <= best)) {
                 if (S != best) { best = S; k = best; end0 = c - W; }
             }
@@ -657,7 +670,7 @@ k_myers_ckf(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
     __syncthreads();
     int steps = valid ? tn + nblk - 1 : 0;
     for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
-    const u32 key = fast_shw_ckr<G, NW, TW>(b, qn, tn, steps, t_lds[sub], nlo, nhi, ckpt + ((size_t)(item - lo) * CK) * NW + b, hcar + ((size_t)(item - lo) * SEGS) * NW + b);
+    const u32 key = fast_shw_ckr<G, NW, TW>(b, qn, tn, steps, t_lds[sub], nlo, nhi, ckpt + rc_at<NW>(item - lo, CK, 0, (size_t)b), hcar + rc_at<NW>(item - lo, SEGS, 0, (size_t)b));
     const int bl = nblk > 0 ? nblk - 1 : 0;
     const u32 bkey = (u32)__shfl((int)key, (lane / G) * G + bl);
     int best = (int)(bkey >> 10);
@@ -735,9 +748,9 @@ k_rcwalk2(const BlockItem* __restrict__ items, u32 n_host, const u32* __restrict
         }
         FastWord wd; wd.Pv = ~0ULL; wd.Mv = 0ULL; wd.pubP = 0x80000000u; wd.pubM = 0u;
         const int slot = 2 * seg + h - 1;                             // the state before column c0 + 16 h
-        if (live && slot >= 0) { const ulonglong2 v = ckpt[((size_t)(item - lo) * CK + (size_t)slot) * NW + (size_t)w]; wd.Pv = v.x; wd.Mv = v.y; }
+        if (live && slot >= 0) { const ulonglong2 v = ckpt[rc_at<NW>(item - lo, CK, (size_t)slot, (size_t)w)]; wd.Pv = v.x; wd.Mv = v.y; }
         u32 hp = 0xffffffffu, hm = 0u;                                // word 0: the top row's boundary (+1 per column)
-        if (live && k == 0 && w > 0) { const u64 v = hcar[((size_t)(item - lo) * SEGS + (size_t)seg) * NW + (size_t)(w - 1)]; hp = (u32)v; hm = (u32)(v >> 32); }
+        if (live && k == 0 && w > 0) { const u64 v = hcar[rc_at<NW>(item - lo, SEGS, (size_t)seg, (size_t)(w - 1))]; hp = (u32)v; hm = (u32)(v >> 32); }
         if (!fin && seg != segcur) {
             const u64 x = fr[(u64)(2 * NW + seg) * 64];
             tlo = (u32)even_bits(x); thi = (u32)even_bits(x >> 1); segcur = seg;
@@ -839,6 +852,7 @@ k_rcwalk2w(const BlockItem* __restrict__ items, u32 n_host, const u32* __restric
     constexpr int FW = 2 * NW + TW, SEG = kRcSeg, HALF = SEG / 2, CK = RcGeom<COLS>::kCk, SEGS = RcGeom<COLS>::kSeg;
     static_assert(COLS < 4096, "the hand-over word keeps r and c in 12 bits each");
     const bool pf = (opts & 1u) != 0;                                 // prefetch the next segment's inputs (NECAT_RC_PREFETCH)
+    if (opts & 8u) __builtin_amdgcn_s_setprio(3);                     // (NECAT_RC_PIPE: beside the checkpoint pass of the next piece, whose 8 waves per SIMD would otherwise take 8 of 9 issue slots)
     __shared__ ulonglong2 slices[SEG][64];
     const ListView lv = list_view(n_host, n_dev, capA);
     const bool all = ((epoch >> 27) & 1u) != 0, ragged = ((epoch >> 26) & 1u) != 0;
@@ -919,10 +933,10 @@ k_rcwalk2w(const BlockItem* __restrict__ items, u32 n_host, const u32* __restric
             const int slot = 2 * seg + h - 1;
             if (live && slot >= 0) {
                 if (hit) { wd.Pv = pi ? p_ck1x : p_ck0x; wd.Mv = pi ? p_ck1y : p_ck0y; }
-                else { const ulonglong2 v = ckpt[((size_t)(item - lo) * CK + (size_t)slot) * NW + (size_t)w]; wd.Pv = v.x; wd.Mv = v.y; }
+                else { const ulonglong2 v = ckpt[rc_at<NW>(item - lo, CK, (size_t)slot, (size_t)w)]; wd.Pv = v.x; wd.Mv = v.y; }
             }
             u32 hp = 0xffffffffu, hm = 0u;
-            if (live && k == 0 && w > 0) { const u64 v = hit ? (pi ? p_hc1 : p_hc0) : hcar[((size_t)(item - lo) * SEGS + (size_t)seg) * NW + (size_t)(w - 1)]; hp = (u32)v; hm = (u32)(v >> 32); }
+            if (live && k == 0 && w > 0) { const u64 v = hit ? (pi ? p_hc1 : p_hc0) : hcar[rc_at<NW>(item - lo, SEGS, (size_t)seg, (size_t)(w - 1))]; hp = (u32)v; hm = (u32)(v >> 32); }
             if (!fin && seg != segcur) {
                 const u64 x = (pf && seg == p_seg) ? p_tg : fr[(u64)(2 * NW + seg) * 64];
                 tlo = (u32)even_bits(x); thi = (u32)even_bits(x >> 1); segcur = seg;
@@ -932,10 +946,10 @@ k_rcwalk2w(const BlockItem* __restrict__ items, u32 n_host, const u32* __restric
                 p_seg = seg - 1; p_w = w;
                 const int ns = 2 * (seg - 1) + h - 1;
                 const size_t ib = (size_t)(item - lo);
-                if (ns >= 0 && w >= 0) { const ulonglong2 v = ckpt[(ib * CK + (size_t)ns) * NW + (size_t)w]; p_ck0x = v.x; p_ck0y = v.y; }
-                if (ns >= 0 && w >= 1) { const ulonglong2 v = ckpt[(ib * CK + (size_t)ns) * NW + (size_t)(w - 1)]; p_ck1x = v.x; p_ck1y = v.y; }
-                if (k == 0 && w >= 1) p_hc0 = hcar[(ib * SEGS + (size_t)(seg - 1)) * NW + (size_t)(w - 1)];
-                if (k == 0 && w >= 2) p_hc1 = hcar[(ib * SEGS + (size_t)(seg - 1)) * NW + (size_t)(w - 2)];
+                if (ns >= 0 && w >= 0) { const ulonglong2 v = ckpt[rc_at<NW>(ib, CK, (size_t)ns, (size_t)w)]; p_ck0x = v.x; p_ck0y = v.y; }
+                if (ns >= 0 && w >= 1) { const ulonglong2 v = ckpt[rc_at<NW>(ib, CK, (size_t)ns, (size_t)(w - 1))]; p_ck1x = v.x; p_ck1y = v.y; }
+                if (k == 0 && w >= 1) p_hc0 = hcar[rc_at<NW>(ib, SEGS, (size_t)(seg - 1), (size_t)(w - 1))];
+                if (k == 0 && w >= 2) p_hc1 = hcar[rc_at<NW>(ib, SEGS, (size_t)(seg - 1), (size_t)(w - 2))];
                 p_tg = fr[(u64)(2 * NW + seg - 1) * 64];
                 if (w >= 1) { p_qa = fr[(u64)(w - 1) * 64]; p_qb = fr[(u64)(NW + w - 1) * 64]; }
             } else p_seg = -2;

@@ -82,6 +82,8 @@ u32 g_rc_listb;        // NECAT_RC_LISTB (default 1, needs NECAT_RC_CARRY): list
 u32 g_rc_ragged;       // NECAT_RC_RAGGED (default 1, needs NECAT_RC_CARRY): the ragged blocks of those rounds through k_myers_ckg + k_rcwalk2 as well (0: two-pass kernel + lane walk on a stream of their own)
 u32 g_ck_lds;          // NECAT_CK_LDS (bytes, default 0): dynamic LDS claimed by every workgroup (one wave) of k_myers_ck - caps how many of its waves a CU holds (160 KB / (1 KB + this)), leaving wave slots to the chains of the other streams (A/B measurements)
 u32 g_rc_merge;        // NECAT_RC_MERGE (default 1, needs NECAT_RC_RAGGED): the ragged list-A blocks of a big round through k_myers_ck's ragged fast path and the full blocks' walk launch; 0 = k_myers_ckg + a walk launch of their own on stream d
+u32 g_rc_prio;         // NECAT_RC_PRIO (bits; default 1: 41.6 -> 41.0 ms per step; 2 costs 0.5 ms, 4 nothing): waves that raise their issue priority (s_setprio 3) - 1: list A's walk, 2: list A's checkpoint pass, 4: list B's walk
+u32 g_rc_pipe, g_rc_pipe_min;    // NECAT_RC_PIPE (default 1 = off: 2 - 4 pieces cost 1.8 - 2.3 ms per step, tools/r04/run28.sh, run29.sh) / NECAT_RC_PIPE_MIN (default 49152 blocks): list A of a big round in pieces, walk of piece i beside the pass of piece i + 1
 u32 g_ck_post;         // NECAT_CK_POST (default 1): k_myers_ck finds the bottom row's minimum after the pass, from word 7's deltas, and unrolls its windows (fast_shw8_ckp); 0 = tracked inside the pass
 u32 g_rc_fastb;        // NECAT_RC_FASTB (default 1): list B's checkpoint pass through k_myers_ckf (32-bit halves, bitop3, DPP carries); 0 = the general pass k_myers_ckg
 u32 g_rc_dbg;          // NECAT_RC_DBG (timing only): 2 = k_rcwalk2w walks every segment twice (once into a sink), 4 = recomputes every segment twice
@@ -97,7 +99,8 @@ int g_dbg;             // NECAT_DBG: profiling-only variants of the lane-per-blo
 template <int NW, int TW, int COLS, int MAXOPS, class... A>
 static void launch_rcwalk2(u32 nitems, hipStream_t s, A... a)
 {
-    if (g_rc_ww) hipLaunchKernelGGL((k_rcwalk2w<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(256), 0, s, a..., g_rc_prefetch | g_rc_dbg);
+    const u32 pr = (NW == kWordsA ? (g_rc_prio & 1u) : NW == kWordsB ? (g_rc_prio & 4u) : 0u) ? 8u : 0u;
+    if (g_rc_ww) hipLaunchKernelGGL((k_rcwalk2w<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(256), 0, s, a..., g_rc_prefetch | g_rc_dbg | pr);
     else hipLaunchKernelGGL((k_rcwalk2<NW, TW, COLS, MAXOPS>), dim3((nitems + 15) / 16), dim3(64), 0, s, a...);
 }
 
@@ -119,6 +122,8 @@ void read_knobs()
     g_rc_dbg = (u32)num("NECAT_RC_DBG", 0) & 6u;
     g_rc_fastb = (u32)num("NECAT_RC_FASTB", 1);
     g_ck_post = (u32)num("NECAT_CK_POST", 1);
+    g_rc_prio = (u32)num("NECAT_RC_PRIO", 1);
+    g_rc_pipe = (u32)std::min<unsigned long long>(8, std::max<unsigned long long>(1, num("NECAT_RC_PIPE", 1))); g_rc_pipe_min = (u32)num("NECAT_RC_PIPE_MIN", 49152);
     g_rc_merge = (u32)num("NECAT_RC_MERGE", 1);
     g_ck_lds = (u32)num("NECAT_CK_LDS", 0);
     g_rc_listb = g_rc_carry ? (u32)num("NECAT_RC_LISTB", 1) : 0u;
@@ -1368,19 +1373,32 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
             }
             // the full blocks on stream a: SHW + checkpoints, recompute walk (chunk by chunk), finish
             const bool one_chunk = rc_chunk >= bound;
-            for (u32 lo = 0; lo < bound; lo += rc_chunk) {
-                const u32 hi = std::min<u64>((u64)lo + rc_chunk, (u64)gA * 64), cn = hi - lo;
-                const bool last = (u64)lo + rc_chunk >= bound;
-                static const bool ckg_all = getenv("NECAT_RC_CKG_ALL") != nullptr;       // debugging: every block through the general pass
-                // NECAT_RC_MERGE (default): the ragged blocks ride the same two launches as the full ones (k_myers_ck's ragged fast path, the walk
-                // over the whole list) instead of a chain of their own (k_myers_ckg + walk on stream d)
-                const bool merged = g_rc_merge && g_rc_ragged && g_rc_carry && !ckg_all;
+            static const bool ckg_all = getenv("NECAT_RC_CKG_ALL") != nullptr;       // debugging: every block through the general pass
+            // NECAT_RC_MERGE (default): the ragged blocks ride the same two launches as the full ones (k_myers_ck's ragged fast path, the walk
+            // over the whole list) instead of a chain of their own (k_myers_ckg + walk on stream d)
+            const bool merged = g_rc_merge && g_rc_ragged && g_rc_carry && !ckg_all;
+            // NECAT_RC_PIPE (default 1 = off): a big list in that many pieces, the walk of piece i on stream d beside the checkpoint pass of piece
+            // i + 1 on stream a - the pass is bound by VALU issue, the walk by the latency of its one walker wave per 64 blocks (a third of the
+            // pass's instruction rate), and one after the other they are the critical chain of every big round.  Measured: both kernels just
+            // take longer side by side, 41.6 -> 43.4 - 43.9 ms per step with 2 - 4 pieces, with or without raised priority for the walk
+            const bool piped = g_rc_pipe > 1 && one_chunk && merged && !wide_possible && bound >= g_rc_pipe_min;
+            const u32 step_chunk = piped ? (u32)(((((u64)gA * 64 + g_rc_pipe - 1) / g_rc_pipe) + 63) & ~63ULL) : rc_chunk;
+            int ci = 0;
+            for (u32 lo = 0; lo < bound; lo += step_chunk, ++ci) {
+                const u32 hi = std::min<u64>((u64)lo + step_chunk, (u64)gA * 64), cn = hi - lo;
+                const bool last = (u64)lo + step_chunk >= bound;
+                // (a piece's checkpoints and deltas at its own place in the buffer, which holds the whole list then: the kernels index by item - lo)
+                ulonglong2* const ck_all = ck; u64* const hcar_all = hcar;
+                ulonglong2* const ck = piped ? ck_all + (size_t)lo * (per_item / sizeof(ulonglong2)) : ck_all;
+                u64* const hcar = piped ? hcar_all + (size_t)lo * (per_item_hc / sizeof(u64)) : hcar_all;
+                hipStream_t sw = piped ? sd : c.sa;
                 if (ckg_all && g_rc_ragged) {}
                 else if (g_rc_carry)
                     hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA, true>), dim3((cn + 7) / 8), dim3(64), g_ck_lds, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error, c.resA, X.stats, g_rc_maxdist, lo, hi,
-                                       (merged ? fl_all : epoch) | (g_ck_post ? 0u : 1u << 24));
+                                       (merged ? fl_all : epoch) | (g_ck_post ? 0u : 1u << 24) | (g_rc_prio & 2u ? 1u << 23 : 0u));
                 else
                     hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA, false>), dim3((cn + 7) / 8), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error, c.resA, X.stats, g_rc_maxdist, lo, hi, epoch);
+                if (piped) { NECAT_HIP(ctx, hipEventRecord(ctx->ev[40 + (ci & 7)], c.sa)); NECAT_HIP(ctx, hipStreamWaitEvent(sw, ctx->ev[40 + (ci & 7)], 0)); }
                 if (g_rc_ragged && !merged) {
                     // the ragged blocks of the chunk (the back of the work index space): the general SHW pass, same checkpoints.  A tenth of
                     // the blocks, few waves, latency bound: beside the full blocks' pass on a stream of its own when the list is one chunk
@@ -1397,7 +1415,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                 NECAT_CHECK_LAUNCH(ctx, "k_myers_ck");
                 if (last) NECAT_HIP(ctx, hipEventRecord(c.a1[cur], c.sa));
                 if (g_rc_carry)
-                    launch_rcwalk2<kWordsA, kTWordsA, kColsA, kOpsA>(cn, c.sa, itA, bound, d_nA, c.cap, (const u64*)c.fragA, (const ulonglong2*)ck,
+                    launch_rcwalk2<kWordsA, kTWordsA, kColsA, kOpsA>(cn, sw, itA, bound, d_nA, c.cap, (const u64*)c.fragA, (const ulonglong2*)ck,
                                        (const u64*)hcar, (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsA, wo, X.stats, X.d_err,
                                        (g_rc_ragged && one_chunk && !merged) ? epoch : fl_all, lo, hi);
                 else
@@ -1405,7 +1423,8 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                                        (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsA, wo, X.stats, X.d_err, lo, hi);
                 NECAT_CHECK_LAUNCH(ctx, "k_rcwalk");
             }
-            NECAT_HIP(ctx, hipEventRecord(ctx->ev[26 + (r & 3)], c.sa));       // a1 -> this: the walk kernel alone (account_a; of the last chunk, normally the only one)
+            NECAT_HIP(ctx, hipEventRecord(ctx->ev[26 + (r & 3)], piped ? sd : c.sa));       // a1 -> this: the walk kernel alone (account_a; of the last chunk, normally the only one)
+            if (piped) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, ctx->ev[26 + (r & 3)], 0));          // the finishing kernel reads what the walks left
             if (wide_possible) {
                 NECAT_HIP(ctx, hipStreamWaitEvent(sd, c.a1[cur], 0));            // k_myers_ck has flagged the wide blocks
                 hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3(gA * 8), dim3(64), 0, sd, itA, bound, d_nA, c.cap,

@@ -24,7 +24,7 @@ struct DevBuf {
 
 }  // namespace necat
 
-constexpr int kNumEvents = 40;
+constexpr int kNumEvents = 48;
 constexpr unsigned kRoundRing = 1024;  // entries of necat_ctx::round_ring
 
 struct necat_ctx {

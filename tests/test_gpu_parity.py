@@ -482,7 +482,8 @@ def test_capped_band_pool_runs_lists_in_chunks(ctx, small, tmp_path, monkeypatch
                                   "NECAT_RC_LISTB=0", "NECAT_RC_LISTB=1 NECAT_TAIL_FUSED=0 NECAT_RC_POOL_MB=1",
                                   "NECAT_RC_WW=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_MERGE=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0",
                                   "NECAT_RC_MERGE=1 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0 NECAT_RC_POOL_MB=1", "NECAT_RC_FASTB=0 NECAT_TAIL_FUSED=0", "NECAT_RC_PREFETCH=1 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0",
-                                  "NECAT_CK_POST=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0"])
+                                  "NECAT_CK_POST=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0",
+                                  "NECAT_RC_PIPE=3 NECAT_RC_PIPE_MIN=64 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_PRIO=6 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0"])
 def test_alternative_kernel_paths_give_the_same_records(ctx, small, monkeypatch, knob):
     """Code paths kept behind a knob (the lane-0 chain DP, the 16-block / 4-lane NW kernel, the restated walk, the general DP
     path without the full-block fast path, lane-per-strand seed collection, every round / no round through the one-launch
