@@ -113,11 +113,7 @@ NECAT_D void fast_advance_m1(FastWord& w, u32 el, u32 eh, u32 cph, u32 cm1, u32 
     const u32 pl = (u32)w.Pv, ph = (u32)(w.Pv >> 32), ml = (u32)w.Mv, mh = (u32)(w.Mv >> 32);
     const u32 xvl = el | ml, xvh = eh | mh;
     const u32 e2l = el | cm1;
-#if defined(NECAT_CK_MV) && NECAT_CK_MV == 3      // (tools/ck_microbench.hip: timing variants, wrong results)
-    const u64 sum = (((u64)(eh & ph) << 32) | (e2l & pl)) ^ w.Pv;
-#else
     const u64 sum = (((u64)(eh & ph) << 32) | (e2l & pl)) + w.Pv;
-#endif
     const u32 sl = (u32)sum, sh = (u32)(sum >> 32);
     const u32 xhl = bop<0xbe>(sl, pl, e2l), xhh = bop<0xbe>(sh, ph, eh);
     const u32 phl = bop<0xf1>(ml, xhl, pl), phh = bop<0xf1>(mh, xhh, ph);
@@ -148,19 +144,11 @@ NECAT_D u32 fast_shw8_ckp(const int b, const u64* __restrict__ tw, const u64 nlo
     const u32 mw = b == G - 1 ? 0u : 1u;
     u32 cph = 0x80000000u, cmh = 0u;           // (cmh: 0 / 1 here, fast_advance_m1)
     auto step = [&](const int j) {          // one column of this lane's word: the target bit of step j of the window, the recurrence, the delta bits
-#if defined(NECAT_CK_MV) && NECAT_CK_MV == 4
-        const u32 el = nlo_l ^ (u32)j, eh = nlo_h;
-#else
         const u32 ma = (u32)__builtin_amdgcn_sbfe((int)tlo, (u32)j, 1u), mb = (u32)__builtin_amdgcn_sbfe((int)thi, (u32)j, 1u);
         const u32 el = bop<0x60>(nlo_l ^ ma, nhi_l, mb), eh = bop<0x60>(nlo_h ^ ma, nhi_h, mb);
-#endif
         u32 phh, mhh;
         fast_advance_m1(w, el, eh, cph, cmh, cm, mw, phh, mhh);
-#if defined(NECAT_CK_MV) && NECAT_CK_MV == 2
-        hp ^= phh; hm |= mhh;
-#else
         hp = __builtin_amdgcn_alignbit(hp, phh, 31); hm = __builtin_amdgcn_alignbit(hm, mhh, 31);
-#endif
     };
     // ckr / hcr: the slots of the window's first column (two checkpoints, one delta word per window)
     ulonglong2* ckr = ck; u64* hcr = hc;
@@ -180,11 +168,7 @@ NECAT_D u32 fast_shw8_ckp(const int b, const u64* __restrict__ tw, const u64 nlo
             // steps 32 .. 511: every lane is inside its block; the slots relative to the window's are constants
 #pragma unroll
             for (int j = 0; j < 32; ++j) {
-#if defined(NECAT_CK_MV) && NECAT_CK_MV == 1
-                cph = w.pubP; cmh = w.pubM;
-#else
                 cph = dpp_row_shr1(w.pubP, cph); cmh = dpp_row_shr1(w.pubM, cmh);
-#endif
                 step(j);
                 const int K = ((j & 15) + 1) & 15;                 // the word whose column is 15 mod 16 at this step
                 if (K < G && b == K && st) {

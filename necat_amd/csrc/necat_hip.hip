@@ -1540,12 +1540,13 @@ int ext_streams(necat_ctx* ctx)
     if (serial && !ctx->stream_a) { ctx->stream_a = ctx->stream_b = ctx->stream_c = ctx->stream_d = ctx->stream; ctx->serial_streams = true; }
     // NECAT_STREAM_PRIO=1: the streams of list B and of the ragged / wide blocks at the device's highest priority - their kernels are small and sit
     // behind list A's issue-bound launches (k_ext_frag<13,25>: 0.03 ms alone, 0.5 ms in the round), which delays the chain that trails list A
-    static const bool prio = getenv("NECAT_STREAM_PRIO") && atoi(getenv("NECAT_STREAM_PRIO"));
+    // (= 2: list A's stream instead - its chain is the round's critical one)
+    static const int prio = getenv("NECAT_STREAM_PRIO") ? atoi(getenv("NECAT_STREAM_PRIO")) : 0;
     int least = 0, greatest = 0;
     if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
     for (hipStream_t* st : {&ctx->stream_a, &ctx->stream_b, &ctx->stream_c, &ctx->stream_d, &ctx->stream_copy}) {
         if (*st) continue;
-        const bool high = prio && greatest != least && (st == &ctx->stream_b || st == &ctx->stream_c || st == &ctx->stream_d);
+        const bool high = prio && greatest != least && (prio == 2 ? st == &ctx->stream_a : (st == &ctx->stream_b || st == &ctx->stream_c || st == &ctx->stream_d));
         if ((high ? hipStreamCreateWithPriority(st, hipStreamDefault, greatest) : hipStreamCreate(st)) != hipSuccess) return set_err(ctx, NECAT_ERR_DEVICE, "hipStreamCreate failed");
     }
     return NECAT_OK;
