@@ -53,6 +53,34 @@ NECAT_HD int ctz64(u64 x)  // x != 0
     return __builtin_ctzll(x);
 #endif
 }
+
+#if defined(__HIPCC__)
+// ---- wave-wide sums without the LDS crossbar.  __shfl_up / __shfl_down are ds_bpermute (an LDS instruction + its address arithmetic + a select
+// per step); DPP moves ride on the add itself.  Inclusive prefix sum over the 64 lanes: Kogge-Stone inside the rows of 16 (row_shr 1, 2, 4, 8:
+// lanes without a source add 0), then lane 15 of every row into the next row (rows 1 and 3), then lane 31 into rows 2 and 3.
+NECAT_D u32 wave_scan_add(u32 v)
+{
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return (u32)x;
+}
+// the wave's total from an inclusive scan (lane 63's value, on every lane: a scalar)
+NECAT_D u32 wave_last(u32 incl) { return (u32)__builtin_amdgcn_readlane((int)incl, 63); }
+// OR over each group of 8 consecutive lanes, on all 8: quad_perm [1,0,3,2], [2,3,0,1], then the mirror image inside the half row (the other quad)
+NECAT_D u32 or_lanes8(u32 v)
+{
+    int x = (int)v;
+    x |= __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false);
+    return (u32)x;
+}
+#endif
 NECAT_HD u64 brev64(u64 x)
 {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -127,8 +127,7 @@ NECAT_D void split_tile(SplitLds& L, const u64 (&r)[kSplitPer], u32 valid, Digit
     __syncthreads();
     if (tid < 64) {
         const u32 c = L.cnt[tid];
-        u32 incl = c;
-        for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o); if (tid >= o) incl += v; }
+        const u32 incl = wave_scan_add(c);
         L.lstart[tid] = incl - c;
         if (tid == 63) L.lstart[64] = incl;
         L.gbase[tid] = c ? reserve((u32)tid, c) : 0ULL;
@@ -389,8 +388,7 @@ k_subpart(const u64* __restrict__ part, const u64* __restrict__ bucket_start, u3
     __syncthreads();
     if (w == 0) {
         const u32 tot = hist[0][lane] + hist[1][lane] + hist[2][lane] + hist[3][lane];
-        u32 incl = tot;
-        for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+        const u32 incl = wave_scan_add(tot);
         run[lane] = lo + (incl - tot);
         sub_start[(u64)b * kSubs + lane] = lo + (incl - tot);
         if (b == nb - 1 && lane == 0) sub_start[(u64)nb * kSubs] = hi;
@@ -408,7 +406,11 @@ k_subpart(const u64* __restrict__ part, const u64* __restrict__ bucket_start, u3
 template <int T = 256>
 NECAT_D void slice_count(const u64* __restrict__ part2, u64 lo, u64 hi, u32* cnt)
 {
-    for (int i = threadIdx.x; i < kSlice; i += T) cnt[i] = 0;
+    {
+        uint4* z = reinterpret_cast<uint4*>(cnt) + threadIdx.x * (kSlice / T / 4);        // (cnt: 16-byte aligned)
+#pragma unroll
+        for (int i = 0; i < kSlice / T / 4; ++i) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     __syncthreads();
     for (u64 e = lo + threadIdx.x; e < hi; e += T) atomicAdd(&cnt[(u32)(part2[e] >> kOffsetBits) & (kSlice - 1)], 1u);
     __syncthreads();
@@ -421,13 +423,21 @@ __global__ void __launch_bounds__(256)
 k_slice_count(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u32 max_occ, u32* __restrict__ kept_tot, u32* __restrict__ bucket_kept,
               u32* __restrict__ pres_tot, u32* __restrict__ bucket_pres, u32 s0)
 {
-    __shared__ u32 cnt[kSlice];
+    __shared__ __attribute__((aligned(16))) u32 cnt[kSlice];
     __shared__ u32 red[4], redp[4];
     const u64 s = (u64)blockIdx.x + s0;           // s0 = first slice of this rank's hash range
     slice_count(part2, sub_start[s], sub_start[s + 1], cnt);
     u32 sum = 0, pres = 0;
-    for (int i = threadIdx.x; i < kSlice; i += 256) { const u32 c = filtered_count(cnt[i], max_occ); sum += c; pres += c ? 1u : 0u; }
-    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_down(sum, o); pres += __shfl_down(pres, o); }
+    {
+        const uint4* own = reinterpret_cast<const uint4*>(cnt) + threadIdx.x * (kSlice / 256 / 4);      // any 16 entries: only the sums matter
+#pragma unroll
+        for (int i = 0; i < kSlice / 256 / 4; ++i) {
+            const uint4 v = own[i];
+            const u32 c0 = filtered_count(v.x, max_occ), c1 = filtered_count(v.y, max_occ), c2 = filtered_count(v.z, max_occ), c3 = filtered_count(v.w, max_occ);
+            sum += c0 + c1 + c2 + c3; pres += (c0 ? 1u : 0u) + (c1 ? 1u : 0u) + (c2 ? 1u : 0u) + (c3 ? 1u : 0u);
+        }
+    }
+    sum = wave_last(wave_scan_add(sum)); pres = wave_last(wave_scan_add(pres));
     if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = sum; redp[threadIdx.x >> 6] = pres; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -463,7 +473,7 @@ k_bucket_base(const u32* __restrict__ bucket_kept, u32 nb, u64* __restrict__ buc
 // oc2mkdb's 2 Gbp cut has 7 600 per slice, every slice took the reload + global tmp path and this kernel was 50 of the build's 90 ms:
 // with LT = 8000 (64 KB of LDS per workgroup in all) such a slice still reads its records three times - coalesced - but groups and ranks
 // them in LDS.
-constexpr int kLdsTmp = 2048, kLdsTmpBig = 8000;
+constexpr int kLdsTmp = 2016, kLdsTmpBig = 8000;      // (2016, not 2048: with cnt + cur + the small arrays that is 40 912 bytes, and FOUR workgroups fit a CU's 160 KB - 2048 was 80 bytes too many for the fourth)
 template <int T, int LT = kLdsTmp>
 __global__ void __launch_bounds__(T)
 k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u32 max_occ, const u64* __restrict__ bucket_base, const u32* __restrict__ kept_tot,
@@ -474,8 +484,8 @@ k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u
     // (the starts and bases written here are final: positions in the gathered arrays; tmp and compact are addressed the same way by
     // pointers shifted back by base_add / cbase_add)
     static_assert(kSlice / T == 8, "a thread owns the 8 table entries of one byte of an IdxWord");
-    __shared__ u32 cnt[kSlice];      // occurrences per table entry of the slice
-    __shared__ u32 cur[kSlice];      // start of the entry's group inside the slice, then its fill cursor
+    __shared__ __attribute__((aligned(16))) u32 cnt[kSlice];      // occurrences per table entry of the slice
+    __shared__ __attribute__((aligned(16))) u32 cur[kSlice];      // start of the entry's group inside the slice, then its fill cursor
     __shared__ u32 ltmp[LT];         // the kept offsets of the slice, grouped by entry (small slices)
     __shared__ u32 wtot[T / 64], ptot[T / 64];
     __shared__ u64 s_base, s_cbase;
@@ -492,11 +502,15 @@ k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u
     if (wave == T / 64 - 1) {        // the slice's bases = its bucket's bases + the totals of the bucket's earlier slices
         const u32 j = (u32)s & (kSubs - 1);
         const u64 first = s & ~(u64)(kSubs - 1);
-        u64 before = (u32)lane < j ? (u64)kept_tot[first + lane] : 0ULL, pbefore = (u32)lane < j ? (u64)pres_tot[first + lane] : 0ULL;
-        for (int o = 32; o > 0; o >>= 1) { before += __shfl_down(before, o); pbefore += __shfl_down(pbefore, o); }
+        // (a bucket's kept entries are < 2^32: offsets are 32-bit positions of one volume)
+        const u32 before = wave_last(wave_scan_add((u32)lane < j ? kept_tot[first + lane] : 0u)), pbefore = wave_last(wave_scan_add((u32)lane < j ? pres_tot[first + lane] : 0u));
         if (lane == 0) { s_base = bucket_base[s >> kSubBits] + before + base_add; s_cbase = bucket_cbase[s >> kSubBits] + pbefore + cbase_add; }
     }
-    for (int i = threadIdx.x; i < kSlice; i += T) cnt[i] = 0;
+    {
+        uint4* z = reinterpret_cast<uint4*>(cnt) + threadIdx.x * (kSlice / T / 4);
+#pragma unroll
+        for (int i = 0; i < kSlice / T / 4; ++i) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     __syncthreads();
     if (small) {
         if (r0 != ~0ULL) atomicAdd(&cnt[(u32)(r0 >> kOffsetBits) & (kSlice - 1)], 1u);
@@ -509,11 +523,14 @@ k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u
     // exclusive scans of the kept counts and of the non-zero entries: thread t owns entries [8 t, 8 t + 8)
     constexpr int E = kSlice / T;
     u32 c[E], sum = 0, pres = 0, fb = 0;
+    {
+        const uint4* own = reinterpret_cast<const uint4*>(cnt) + threadIdx.x * (E / 4);
+        const uint4 v0 = own[0], v1 = own[1];
+        c[0] = v0.x; c[1] = v0.y; c[2] = v0.z; c[3] = v0.w; c[4] = v1.x; c[5] = v1.y; c[6] = v1.z; c[7] = v1.w;
+    }
 #pragma unroll
-    for (int i = 0; i < E; ++i) { c[i] = filtered_count(cnt[threadIdx.x * E + i], max_occ); sum += c[i]; if (c[i]) { ++pres; fb |= 1u << i; } }
-    u32 incl = sum, pincl = pres;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o), q = __shfl_up(pincl, o); if (lane >= o) { incl += v; pincl += q; } }
+    for (int i = 0; i < E; ++i) { c[i] = filtered_count(c[i], max_occ); sum += c[i]; if (c[i]) { ++pres; fb |= 1u << i; } }
+    const u32 incl = wave_scan_add(sum), pincl = wave_scan_add(pres);
     if (lane == 63) { wtot[wave] = incl; ptot[wave] = pincl; }
     __syncthreads();
     u32 run = incl - sum, prun = pincl - pres, kept_all = 0;
@@ -522,12 +539,18 @@ k_slice_emit(const u64* __restrict__ part2, const u64* __restrict__ sub_start, u
     // kmer_stats[h] = cnt<<34 | start for the k-mers that exist and pass the cutoff (lookup_table.c:43-51, :94-113): the non-zero
     // entries in hash order; the word of 64 entries = the flag bytes of 8 neighbouring threads
     {
-        u64 bits = (u64)fb << (8 * (lane & 7));
-        bits |= __shfl_xor(bits, 1); bits |= __shfl_xor(bits, 2); bits |= __shfl_xor(bits, 4);
-        if ((lane & 7) == 0) { IdxWord w; w.bits = bits; w.base = cbase + prun; words[s * (kSlice / 64) + (threadIdx.x >> 3)] = w; }
-        u32 at = run; u64 q = cbase + prun;
+        const u32 sh8 = 8u * ((u32)lane & 3u);
+        const u32 bl = or_lanes8((lane & 4) ? 0u : fb << sh8), bh = or_lanes8((lane & 4) ? fb << sh8 : 0u);      // lanes 0 - 3 of the 8: bytes 0 - 3, lanes 4 - 7: bytes 4 - 7
+        if ((lane & 7) == 0) { IdxWord w; w.bits = ((u64)bh << 32) | bl; w.base = cbase + prun; words[s * (kSlice / 64) + (threadIdx.x >> 3)] = w; }
+        u32 a[E];
+        { u32 at = run;
 #pragma unroll
-        for (int i = 0; i < E; ++i) { cur[threadIdx.x * E + i] = at; if (c[i]) compact[q++] = ((u64)c[i] << kOffsetBits) | (base + at); at += c[i]; }
+          for (int i = 0; i < E; ++i) { a[i] = at; at += c[i]; } }
+        uint4* own = reinterpret_cast<uint4*>(cur) + threadIdx.x * (E / 4);
+        own[0] = make_uint4(a[0], a[1], a[2], a[3]); own[1] = make_uint4(a[4], a[5], a[6], a[7]);
+        u64 q = cbase + prun;
+#pragma unroll
+        for (int i = 0; i < E; ++i) if (c[i]) compact[q++] = ((u64)c[i] << kOffsetBits) | (base + a[i]);
     }
     __syncthreads();
     if (small && kept_all <= (u32)LT) {
