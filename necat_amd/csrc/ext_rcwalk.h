@@ -835,7 +835,11 @@ k_rcwalk2w(const BlockItem* __restrict__ items, u32 n_host, const u32* __restric
 {
     constexpr int FW = 2 * NW + TW, SEG = kRcSeg, HALF = SEG / 2, CK = RcGeom<COLS>::kCk, SEGS = RcGeom<COLS>::kSeg;
     static_assert(COLS < 4096, "the hand-over word keeps r and c in 12 bits each");
+#ifdef NECAT_RC_NOPF
+    const bool pf = false;                                            // (tools/rcwalk_microbench.hip: the kernel without the prefetch's registers)
+#else
     const bool pf = (opts & 1u) != 0;                                 // prefetch the next segment's inputs (NECAT_RC_PREFETCH)
+#endif
     if (opts & 8u) __builtin_amdgcn_s_setprio(3);                     // (NECAT_RC_PIPE: beside the checkpoint pass of the next piece, whose 8 waves per SIMD would otherwise take 8 of 9 issue slots)
     __shared__ ulonglong2 slices[SEG][64];
     const ListView lv = list_view(n_host, n_dev, capA);
@@ -965,6 +969,7 @@ k_rcwalk2w(const BlockItem* __restrict__ items, u32 n_host, const u32* __restric
         }
         __syncthreads();
         if (walker) {
+            if (opts & 16u) __builtin_amdgcn_s_setprio(3);           // (microbenchmark: only the walking wave at raised priority, for the length of its walk)
             // ---- the walk of block `lane` (walk_block of dp_core.h on the slices): the lean form once no block of the workgroup is before its
             // run of matches or keeps its ops
             const int c0 = (wc >> 5) * SEG, rb = wr - 63;
@@ -1029,6 +1034,7 @@ k_rcwalk2w(const BlockItem* __restrict__ items, u32 n_host, const u32* __restric
             }
             const u32 word = wfin ? (1u << 24) : ((u32)wr | ((u32)wc << 12));
             reinterpret_cast<u32*>(&slices[0][lane])[0] = word | (__all(wfin) ? 1u << 25 : 0u);
+            if (opts & 16u) __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
         {

@@ -99,7 +99,7 @@ int g_dbg;             // NECAT_DBG: profiling-only variants of the lane-per-blo
 template <int NW, int TW, int COLS, int MAXOPS, class... A>
 static void launch_rcwalk2(u32 nitems, hipStream_t s, A... a)
 {
-    const u32 pr = (NW == kWordsA ? (g_rc_prio & 1u) : NW == kWordsB ? (g_rc_prio & 4u) : 0u) ? 8u : 0u;
+    const u32 pr = ((NW == kWordsA ? (g_rc_prio & 1u) : NW == kWordsB ? (g_rc_prio & 4u) : 0u) ? 8u : 0u) | ((NW == kWordsA ? (g_rc_prio & 8u) : NW == kWordsB ? (g_rc_prio & 16u) : 0u) ? 16u : 0u);
     if (g_rc_ww) hipLaunchKernelGGL((k_rcwalk2w<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(256), 0, s, a..., g_rc_prefetch | g_rc_dbg | pr);
     else hipLaunchKernelGGL((k_rcwalk2<NW, TW, COLS, MAXOPS>), dim3((nitems + 15) / 16), dim3(64), 0, s, a...);
 }
