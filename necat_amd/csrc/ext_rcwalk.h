@@ -294,8 +294,11 @@ NECAT_D u32 fast_shw_ckr(const int b, const int qn, const int tn, const int step
 
 // the front part of list A (work indices [0, nf): full blocks; [nf, nf16): holes), 8 items per wave; flags bit 27 (CARRY only): the whole
 // list - the ragged blocks at its back too, their waves (and the one wave that may hold both kinds) through fast_shw_ckr
+#ifndef NECAT_CK_WAVES
+#define NECAT_CK_WAVES 8          // (tools/ck_microbench.hip builds it with 7 and 6 as well: more registers, fewer waves)
+#endif
 template <int NW, int TW, bool CARRY>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NECAT_CK_WAVES, NECAT_CK_WAVES)))
 k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, ulonglong2* __restrict__ ckpt,
            u64* __restrict__ hcar, double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, int max_dist, u32 lo, u32 hi, u32 flags)
 {
