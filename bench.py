@@ -60,6 +60,11 @@ def parse():
     ap.add_argument("--job", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-widened", action="store_true", help="skip the extra measurements of the SURVEY 8f.1 rows")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that measure `traffic` in this run; "
+                                                          "the newest kept profile under profiles/ is used instead and flagged")
+    ap.add_argument("--config4-genome", type=int, default=0,
+                    help="genome size of the extra measurement at BASELINE configs[4]'s shape (extra_configs.configs4_human_subset: the first volumes of a 3 Gb x 30 read "
+                         "set; 3000000000 = the size tests/test_gpu_full_size.py[human_subset] checks against the reference; needs ~ 40 GB of host memory and minutes); 0 = skip")
     ap.add_argument("--cpu-genome", type=int, default=0, help="genome size of the CPU-baseline input (0 = the bench workload itself)")
     ap.add_argument("--cpu-t1", action="store_true", help="also time the reference with -t 1 on the bench workload itself (minutes)")
     ap.add_argument("--cpu-t1-genome", type=int, default=460_000,
@@ -328,6 +333,62 @@ def config2_step(ctx, capi, synth, args):
     return res
 
 
+def config4_step(ctx, capi, synth, args):
+    """BASELINE configs[4]'s shape as a stated SUBSET (SURVEY 8d allows one): a 3 Gb genome read at the 30x rate, of whose 45 oc2mkdb volumes the first three
+    are kept (synth draws reads one after the other, so coverage 2.0 IS the first 6 Gbp of the 90 Gbp set; volumes closed by makedb/main.c:8,29's 2 Gbp rule).
+    Per reference volume: the index build of a volume whose ~ 2 x 10^9 k-mer positions are nearly all distinct; per (reference, query) pair: one -j 0 and one
+    -j 1 pass with OVLP_FAST_OPTIONS.  Records of this data set are checked against the reference binary's by tests/test_gpu_full_size.py[human_subset]."""
+    G = args.config4_genome
+    rs = synth.simulate_reads(G, 2.0, seed=51)
+    ranges = synth.cut_ranges(rs, [2_000_000_000, 2_000_000_000] if G >= 1_000_000_000 else [int(0.67 * G)] * 2)
+    res = {"workload": "%.2f Gb genome read at the 30x rate, the first %d of its oc2mkdb volumes (%d reads, %d bp: %s Gbp per volume = 2.0x of the genome; the whole project "
+                       "would be %d volumes / %d pairs), OVLP_FAST_OPTIONS (-k %d -z 20 -q 500 -b 2000 -s 3 -n 500 -a 1000 -e 0.5)"
+                       % (G / 1e9, len(ranges), rs.nreads, rs.nbases, " / ".join("%.2f" % (float(rs.offsets[b - 1] + rs.sizes[b - 1] - rs.offsets[a]) / 1e9) for a, b in ranges),
+                          round(15 * G / 2e9 + 0.5), round(15 * G / 2e9 + 0.5) * (round(15 * G / 2e9 + 0.5) + 1) // 2, args.kmer)}
+    vols = []
+    for a, b in ranges:
+        o0, o1 = int(rs.offsets[a]), int(rs.offsets[b - 1] + rs.sizes[b - 1])
+        vols.append((ctx.upload_volume(synth.pack_2bit(rs.codes[o0:o1]), o1 - o0, rs.offsets[a:b] - o0, rs.sizes[a:b]), a))
+    del rs
+    try:
+        res["volumes"] = []
+        for v, (ref, ref_start) in enumerate(vols):
+            t = []
+            for _ in range(2):
+                t0 = time.perf_counter()
+                ix = ctx.build_index(ref, args.kmer, 500)
+                t.append(1e3 * (time.perf_counter() - t0))
+                if _ == 0:
+                    ix.free()
+            nk, noff = ix.sizes()
+            nw, nc = ix.sparse_sizes()
+            ent = {"volume": v, "index_ms_first": round(t[0], 1), "index_ms": round(t[1], 1), "offsets": int(noff), "distinct_kmers": int(nc or 0),
+                   "table_occupancy": round((nc or 0) / float(4 ** args.kmer), 3), "pairs": []}
+            for i in range(v, len(vols)):
+                q, q_start = vols[i]
+                pe = {"query_volume": i}
+                for job in (0, 1):
+                    o = capi.default_options(**dict(FAST, kmer_size=args.kmer, scan_window=20, job=job, num_threads=1))
+                    t0 = time.perf_counter()
+                    if job == 1:
+                        m4, _ = ctx.map_pair(ix, ref, q, q_start, ref_start, o, True, 1)
+                        n = int(m4.shape[0]); pe["gbp_aligned"] = round(float((m4["qend"] - m4["qoff"]).sum()) / 1e9, 3)
+                    else:
+                        n = int(ctx.find_candidates(ix, ref, q, q_start, ref_start, o, True).shape[0])
+                    dt = time.perf_counter() - t0
+                    tm = ctx.timings()
+                    pe["job%d" % job] = {"ms": round(1e3 * dt, 1), "records": n, "seed_ms": round(tm.seed_ms, 1), "kmer_lookups": int(tm.seed_lookups), "offset_entries": int(tm.seed_hits)}
+                    if job == 1:
+                        pe["job1"]["extend_ms"] = round(tm.extend_ms, 1)
+                ent["pairs"].append(pe)
+            ix.free()
+            res["volumes"].append(ent)
+    finally:
+        for v, _ in vols:
+            v.free()
+    return res
+
+
 def oc2asmpm_program(genome, threads, tmp):
     """oc2asmpm (the overlapper of corrected reads, necat.pl:573,880,1000,1152) as a program: this repo's (block vote + chained ranges on the
     device, the 2048-bp block aligner on the device, DALIGNER's end extension on the host) and the reference's own on the same host threads,
@@ -419,7 +480,8 @@ def new_agg():
     return dict(index_ms=0.0, seed_ms=0.0, extend_ms=0.0, myers_ms=0.0, traceback_ms=0.0, launches=0, blocks=0, words=0, bases=0, rounds=0,
                 a_ms=0.0, a_launches=0, a_blocks=0, tb_a_ms=0.0, big_ms=0.0, big_blocks=0, band_words=0,
                 ix_local_ms=0.0, ix_xchg_ms=0.0, ix_xchg_bytes=0, gather_ms=0.0, gather_bytes=0, reads_local=0,
-                fused_ms=0.0, fused_launches=0, fused_blocks=0, rc_ms=0.0, rc_ck_ms=0.0, rc_launches=0, rc_blocks=0, rc_words=0)
+                fused_ms=0.0, fused_launches=0, fused_blocks=0, rc_ms=0.0, rc_ck_ms=0.0, rc_launches=0, rc_blocks=0, rc_words=0,
+                seed_bases=0, seed_lookups=0, seed_hits=0, seed_cands=0)
 
 
 def agg_add(agg, tm, t_index=0.0):
@@ -434,6 +496,7 @@ def agg_add(agg, tm, t_index=0.0):
     agg["a_ms"] += tm.myersA_ms; agg["a_launches"] += tm.myersA_launches; agg["a_blocks"] += tm.myersA_blocks
     agg["fused_ms"] += tm.fused_ms; agg["fused_launches"] += tm.fused_launches; agg["fused_blocks"] += tm.fused_blocks
     agg["rc_ms"] += tm.rc_ms; agg["rc_ck_ms"] += tm.rc_ck_ms; agg["rc_launches"] += tm.rc_launches; agg["rc_blocks"] += tm.rc_blocks; agg["rc_words"] += tm.rc_words
+    agg["seed_bases"] += tm.seed_bases; agg["seed_lookups"] += tm.seed_lookups; agg["seed_hits"] += tm.seed_hits; agg["seed_cands"] += tm.seed_cands
 
 
 def gather_rank_stats(dist, mine):
@@ -581,6 +644,103 @@ def main_pairs(args, rank, world, local, dist, json_fd):
 INDEX_KERNELS = ("k_part_hist", "k_bucket_scan", "k_split_bases", "k_split_recs", "k_subpart", "k_slice_count", "k_bucket_base", "k_slice_emit")
 
 
+PMC = {"data": None, "source": None}     # per-kernel HBM counters of THIS run (pmc_live) or of the newest kept profile (flagged): set once by main()
+
+
+def src_fingerprint():
+    """sha1 over the sources libnecat_hip.so is built from: a kept PMC profile whose `_meta.src_sha1` differs was taken on other kernels"""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "necat_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "necat_amd", "csrc", "*.hip"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_live(args):
+    """HBM traffic measured in THIS run: two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass, MI355X_MICROARCH.md) over a short
+    run of this very script - same binary, same workload, same knobs - after the timed region.  Per kernel: launches and the per-launch averages of the
+    two counters in KB (the gfx950 correction - FETCH_SIZE x 2 - is applied by the readers).  Returns (dict, meta) or (None, reason)."""
+    import shutil
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import make_profiles
+    except Exception as e:
+        return None, "tools/make_profiles.py: %s" % e
+    tmp = tempfile.mkdtemp(prefix="necat_pmc_", dir="/tmp")
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-widened", "--no-pmc", "--genome", str(args.genome),
+           "--coverage", str(args.coverage), "--seed", str(args.seed), "--kmer", str(args.kmer), "--scan-window", str(args.scan_window), "--job", str(args.job)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    dirs = []
+    t0 = time.perf_counter()
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            r = subprocess.run([exe, "--pmc", ctr, "-d", d, "-o", "r", "--output-format", "csv", "--"] + cmd, cwd="/tmp", env=env,
+                               stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=900)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s: exit %d: %s" % (ctr, r.returncode, r.stderr[-300:])
+            dirs.append(d)
+        out = os.path.join(tmp, "pmc.json")
+        make_profiles.pmc(dirs, out)
+        data = json.load(open(out))
+    except Exception as e:
+        return None, "pmc pass failed: %s" % e
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    meta = {"measured": "in this run", "command": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes) -- " + " ".join(cmd[1:]), "src_sha1": src_fingerprint(),
+            "seconds": round(time.perf_counter() - t0, 1)}
+    try:        # kept for profiles/ (gpurun_out/ travels back from the GPU box)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        json.dump(dict(data, _meta=meta), open(os.path.join(ROOT, "gpurun_out", "pmc_live.json"), "w"), indent=1)
+    except Exception:
+        pass
+    return data, meta
+
+
+def pmc_select(args, world):
+    """the PMC numbers the roofline objects quote: measured now (default at N = 1), else the newest kept profile - flagged `stale` when it was taken on
+    other kernel sources than the ones this library was built from"""
+    why = "--no-pmc" if args.no_pmc else ("N > 1" if world > 1 else None)
+    if why is None:
+        data, meta = pmc_live(args)
+        if data is not None:
+            PMC["data"], PMC["source"] = data, dict(meta, stale=False)
+            return
+        why = meta
+    import glob
+    for pth in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
+        try:
+            data = json.load(open(pth))
+        except Exception:
+            continue
+        meta = data.get("_meta") or {}
+        sha = meta.get("src_sha1")
+        PMC["data"] = data
+        PMC["source"] = {"measured": "NOT in this run (%s): kept profile profiles/%s" % (why, os.path.basename(pth)), "taken_on": meta,
+                         "stale": (sha != src_fingerprint()) if sha else "unknown (the profile carries no source fingerprint)"}
+        return
+    PMC["source"] = {"measured": "no PMC numbers (%s; no kept profile)" % why, "stale": None}
+
+
+def pmc_kernel_bytes(names):
+    """sum over the kernels whose name contains one of `names` of (2 FETCH_SIZE + WRITE_SIZE) bytes per launch, and of launches: {short name: (bytes, launches)}"""
+    res = {}
+    for kn, v in (PMC["data"] or {}).items():
+        if not isinstance(v, dict) or "launches" not in v:
+            continue
+        for q in names:
+            if q in kn:
+                b, n = res.get(q, (0.0, 0))
+                # several instances of a template under one short name: weight the per-launch averages by their launches
+                res[q] = (b + (2.0 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0 * v["launches"], n + int(v["launches"]))
+                break
+    return {q: (b / max(1, n), n) for q, (b, n) in res.items()}
+
+
 def roofline_index(index_ms, nbases, k, n_offsets, n_distinct):
     """HBM roofline of the index build (SURVEY.md 8d names HBM as that stage's bound).  Algorithmic bytes = SURVEY 8d's
     reference-layout formula for one volume: 2 (N / 4) + 8 T + 16 N + 16 T + 8 N + 8 M + 4 x 16 M + 8 M + 8 distinct + 16 M with
@@ -590,39 +750,28 @@ def roofline_index(index_ms, nbases, k, n_offsets, n_distinct):
     T, N, M = float(4 ** k), float(nbases), float(n_offsets)
     alg = 2 * (N / 4) + 8 * T + 16 * N + 16 * T + 8 * N + 8 * M + 4 * 16 * M + 8 * M + 8 * float(n_distinct) + 16 * M
     achieved = alg / (index_ms * 1e-3) / 1e9 if index_ms > 0 else 0.0
-    traffic = src = None
-    for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json"):
-        pth = os.path.join(ROOT, "profiles", name)
-        if not os.path.exists(pth):
-            continue
-        try:
-            pmc = json.load(open(pth))
-            tot = 0.0
-            for kn, v in pmc.items():
-                if isinstance(v, dict) and any(("necat::" + q) in kn for q in INDEX_KERNELS):
-                    # per-launch averages x launches / builds: every build launches each kernel the same number of times
-                    per_build = v.get("launches", 1) / max(1, pmc_builds(pmc))
-                    tot += (2.0 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0 * per_build
-            if tot > 0:
-                traffic, src = tot, "profiles/" + name
-                break
-        except Exception:
-            pass
+    traffic = None
+    per = pmc_kernel_bytes(["necat::" + q for q in INDEX_KERNELS])
+    builds = max([n for q, (_, n) in per.items() if "k_slice_emit" in q] or [1])
+    if per:
+        # per-launch averages x launches per build: every build launches each kernel the same number of times
+        traffic = sum(b * n / builds for b, n in per.values())
     # the second denominator: the bytes THIS build's passes have to move when every pass reads and writes its data exactly once:
     # histogram N/4; three split levels N/4 + 8 N written, then 2 x (8 N read + 8 N written); slice count 8 N; slice emit 8 N read, the offset
     # list (8 M), the non-zero table entries (8 distinct) and the sparse table words (16 B per 64 entries) written
     D = float(n_distinct)
     own = N / 4 + (N / 4 + 8 * N) + 2 * 16 * N + 8 * N + (8 * N + 8 * M + 8 * D + 16 * T / 64)
     own_rate = own / (index_ms * 1e-3) / 1e9 if index_ms > 0 else 0.0
-    return {"bound": "hbm", "kernels": "the index build: " + ", ".join(INDEX_KERNELS), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "algorithmic_bytes": round(alg), "ms": round(index_ms, 3),
-            "own_layout": {"bytes": round(own), "achieved": round(own_rate, 1), "frac": round(own_rate / HBM_PEAK_GBS, 4),
-                           "note": "bytes this build's own passes move at one read + one write each (sparse table, three 6-bit split levels): the fraction of the "
-                                   "HBM peak that is comparable across rounds of THIS design; `frac` above prices the reference's dense layout"},
-            "traffic": traffic, "traffic_frac": round(traffic / (index_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and index_ms > 0 else None,
-            "traffic_source": src,
-            "note": "algorithmic bytes of the REFERENCE layout (dense 4^k table: 24 T of the bytes are table sweeps the sparse build never does), so frac can "
-                    "approach or pass 1 while the bytes actually moved (`traffic`, FETCH x 2 + WRITE per MI355X_MICROARCH.md) stay far below the HBM peak"}
+    return {"bound": "hbm", "kernels": "the index build: " + ", ".join(INDEX_KERNELS), "achieved": round(own_rate, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(own_rate / HBM_PEAK_GBS, 4), "algorithmic_bytes": round(own), "ms": round(index_ms, 3),
+            "layout": "own: the bytes THIS build's passes move at one read + one write each (sparse table; histogram N/4, base split N/4 + 8 N, two record splits 2 x 16 N, "
+                      "slice count 8 N, slice emit 8 N + 8 M + 8 distinct + T/4) - a fraction of the HBM peak that is <= 1 by construction and comparable across rounds",
+            "reference_layout": {"algorithmic_bytes": round(alg), "achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
+                                 "note": "SURVEY 8d's formula for build_lookup_table's dense layout (lookup_table.c:15-147): 24 T of its bytes are sweeps of the 4^k table this "
+                                         "build never makes, so this ratio can pass 1 - a comparison number, not a roofline fraction"},
+            "traffic": traffic, "traffic_over_algorithmic": round(traffic / own, 2) if traffic and own > 0 else None,
+            "traffic_frac": round(traffic / (index_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and index_ms > 0 else None,
+            "traffic_source": PMC["source"]}
 
 
 def pmc_builds(pmc):
@@ -659,41 +808,28 @@ def roofline_report(agg):
     alg_per_launch = (2 * 512 / 4.0 + 16.0) * blocks / launches
     avg_pair_ms = rc_ms / launches
     achieved_hbm = alg_per_launch / (avg_pair_ms * 1e-3) / 1e9 if avg_pair_ms > 0 else 0.0
-    # HBM bytes per launch of the two kernels `frac` is about, each on its own: read from the newest kept rocprofv3 --pmc profile under profiles/
-    # (FETCH_SIZE counted twice per the guide's gfx950 correction + WRITE_SIZE), not measured in this run - `traffic_source` says which file and
-    # which commit's binary it was taken on
-    traffic = pmc_file = pmc_meta = None
-    for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json"):
-        pth = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(pth):
-            try:
-                pmc = json.load(open(pth))
-                per = {}
-                for kn, v in pmc.items():
-                    if not isinstance(v, dict):
-                        continue
-                    short = "k_myers_ck" if "necat::k_myers_ck<" in kn else "k_rcwalk2" if ("necat::k_rcwalk2<8" in kn or "necat::k_rcwalk2w<8" in kn) else None
-                    if short:
-                        per[short] = per.get(short, 0.0) + (2.0 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0
-                if per:
-                    traffic, pmc_file, pmc_meta = {k: round(x, 1) for k, x in per.items()}, name, pmc.get("_meta")
-                    break
-            except Exception:
-                pass
+    # HBM bytes per launch of the two kernels `frac` is about, each on its own (FETCH_SIZE counted twice per the guide's gfx950 correction + WRITE_SIZE):
+    # measured by this run's own rocprofv3 --pmc passes (pmc_live) unless `traffic_source` says otherwise
+    per = pmc_kernel_bytes(["necat::k_myers_ck<8", "necat::k_rcwalk3<8", "necat::k_rcwalk2w<8", "necat::k_rcwalk2<8"])
+    traffic = {}
+    for q, (bts, n) in per.items():
+        short = "k_myers_ck" if "k_myers_ck" in q else "k_rcwalk"
+        traffic[short] = round(traffic.get(short, 0.0) + bts, 1)
+    traffic = traffic or None
     traffic_pair = sum(traffic.values()) if traffic else None
     words, band = float(agg["words"]), float(agg["band_words"])
     all_ms = agg["myers_ms"] + agg["rc_ms"] + agg["fused_ms"]
-    return {"bound": "valu", "kernel": "k_myers_ck<8,16,true> + k_rcwalk2<8,16,1024> (the full 512 x 512 blocks of every round above 512 blocks - 85 % of all block alignments: SHW with checkpoints and horizontal deltas, then the walk that recomputes the two words it stands on; launch averages are over big and small rounds alike)",
+    return {"bound": "valu", "kernel": "k_myers_ck<8,16,true> + k_rcwalk3<8,16,512,1024> (every list-A block - full 512 x 512 and ragged - of every round above 512 blocks, 92 % of all block alignments: SHW with checkpoints and horizontal deltas, then the walk that recomputes the two words it stands on into 32-diagonal records; launch averages are over big and small rounds alike)",
             "achieved": round(achieved_tops, 3), "peak": round(peak_tops, 2), "unit": "T lane-op/s (32-bit VALU)", "frac": round(achieved_tops / peak_tops, 4),
             "traffic": traffic,
-            "launches": int(agg["rc_launches"]), "avg_launch_ms": {"k_myers_ck": round(agg["rc_ck_ms"] / launches, 4), "k_rcwalk2": round(agg["rc_ms"] / launches, 4)},
+            "launches": int(agg["rc_launches"]), "avg_launch_ms": {"k_myers_ck": round(agg["rc_ck_ms"] / launches, 4), "k_rcwalk": round(agg["rc_ms"] / launches, 4)},
             # each kernel alone: the SHW pass (algorithmic = 6.25 of its 8 words per column) and the recomputing walk (algorithmic = the
             # reference's NW band words; what it recomputes on top is the price of reading no band from HBM)
             "k_myers_ck": {"frac": round(blocks * 4096.0 * SHW_BANDED_FRACTION * OPS_PER_WORD_UPDATE / (agg["rc_ck_ms"] * 1e-3) / VALU_LANE_OPS_PER_S, 4) if agg["rc_ck_ms"] > 0 else None,
                            "computed_frac": round(blocks * 4096.0 * OPS_PER_WORD_UPDATE / (agg["rc_ck_ms"] * 1e-3) / VALU_LANE_OPS_PER_S, 4) if agg["rc_ck_ms"] > 0 else None},
-            "k_rcwalk2": {"frac": round(blocks * NW_BAND_WORDS_PER_BLOCK * OPS_PER_WORD_UPDATE / (agg["rc_ms"] * 1e-3) / VALU_LANE_OPS_PER_S, 4) if agg["rc_ms"] > 0 else None,
+            "k_rcwalk": {"frac": round(blocks * NW_BAND_WORDS_PER_BLOCK * OPS_PER_WORD_UPDATE / (agg["rc_ms"] * 1e-3) / VALU_LANE_OPS_PER_S, 4) if agg["rc_ms"] > 0 else None,
                           "computed_frac": round(float(agg["rc_words"]) * OPS_PER_WORD_UPDATE / (agg["rc_ms"] * 1e-3) / VALU_LANE_OPS_PER_S, 4) if agg["rc_ms"] > 0 else None,
-                          "note": "also walks the alignment (520 steps per block on LDS) - the work of r02's k_traceback is inside this kernel's time"},
+                          "note": "also walks the alignment (520 steps per block, 32 column steps per segment on LDS records) - the work of r02's k_traceback is inside this kernel's time"},
             "blocks": int(blocks), "useful_word_updates_per_s": round(useful_rate, 1), "ops_per_word_update": OPS_PER_WORD_UPDATE,
             "computed_frac": round(computed_rate * OPS_PER_WORD_UPDATE / VALU_LANE_OPS_PER_S, 4),
             "useful_over_computed": round(useful / computed, 4) if computed else None,
@@ -705,14 +841,42 @@ def roofline_report(agg):
                     "algorithmic_bytes_per_launch_pair": round(alg_per_launch, 1),
                     "traffic_frac": round(traffic_pair / (avg_pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and avg_pair_ms > 0 else None,
                     "traffic_over_algorithmic": round(traffic_pair / alg_per_launch, 1) if traffic and alg_per_launch > 0 else None,
-                    "traffic_source": {"file": "profiles/%s" % pmc_file, "taken_on": pmc_meta,
-                                       "note": "bytes per launch of each kernel (object `traffic`), read from that kept rocprofv3 --pmc profile, not measured in this run"} if traffic else None},
+                    "traffic_source": PMC["source"]},
             "all_dp_and_walk_kernels": {"ms": round(all_ms + agg["traceback_ms"], 2), "dp_ms": round(agg["myers_ms"], 2), "rcwalk_ms": round(agg["rc_ms"], 2),
                                         "walk_and_finish_ms": round(agg["traceback_ms"] - agg["rc_ms"], 2), "fused_tail_ms": round(agg["fused_ms"], 2),
                                         "blocks": int(agg["blocks"]), "word_updates": int(words), "band_words_stored": int(band)},
             "note": "integer DP, VALU-issue bound: frac = algorithmic word updates (SURVEY 8d: banded SHW 6.25/8 words per column + 1.91 NW words per column) x %d "
-                    "lane-ops / (k_myers_ck + k_rcwalk2 time) / (256 CU x 4 SIMD-32 x 2.4 GHz); computed_frac = the same for the word updates actually executed "
+                    "lane-ops / (k_myers_ck + k_rcwalk3 time) / (256 CU x 4 SIMD-32 x 2.4 GHz); computed_frac = the same for the word updates actually executed "
                     "(4096 per block in the SHW pass + what the walk recomputes). hbm.* = the contract's HBM view (small by construction)." % OPS_PER_WORD_UPDATE}
+
+
+SEED_KERNELS = ("k_seed_hits", "k_seed_collect_wave", "k_seed_collect(", "k_seed_eval", "k_seed_clear", "k_seed_finish", "k_pack_cands", "k_move_cands")
+
+
+def roofline_seed(agg, steps):
+    """HBM roofline of the seeding stage (find_candidates, word_finder.c:364-412): algorithmic bytes per query strand of length L =
+    L / 4 (packed read) + 8 per sampled k-mer (one kmer_stats word) + 8 per hit (offset entries read) + 28 per candidate, summed by the library over the
+    call's reads (necat_timings.seed_*), against the stage's time (HIP events around the whole call: hit counts, host plan, collection, evaluation,
+    packing, D2H of the counts).  Random 8-byte gathers: far below the HBM peak by construction - the gather rate says more than the GB/s."""
+    K = max(1, steps)
+    ms = agg["seed_ms"] / K
+    bases, lookups, hits, cands = (agg[k] / K for k in ("seed_bases", "seed_lookups", "seed_hits", "seed_cands"))
+    alg = bases / 4.0 + 8.0 * lookups + 8.0 * hits + 28.0 * cands
+    rate = alg / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    per = pmc_kernel_bytes(["necat::" + q for q in SEED_KERNELS])
+    passes = max([n for q, (_, n) in per.items() if "k_seed_hits" in q] or [1])
+    traffic = sum(b * n / passes for b, n in per.values()) if per else None
+    return {"bound": "hbm", "kernels": "the seeding stage: k_seed_hits, k_seed_collect_wave, k_seed_eval, k_seed_finish, k_pack_cands", "ms": round(ms, 3),
+            "achieved": round(rate, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(rate / HBM_PEAK_GBS, 5),
+            "algorithmic_bytes": round(alg), "terms": {"query_strand_bases": int(bases), "kmer_lookups": int(lookups), "offset_entries": int(hits), "candidates": int(cands)},
+            "lookups_per_s": round(lookups / (ms * 1e-3), 1) if ms > 0 else None, "gathers_per_s": round((lookups + hits) / (ms * 1e-3), 1) if ms > 0 else None,
+            "traffic": traffic, "traffic_over_algorithmic": round(traffic / alg, 1) if traffic and alg > 0 else None,
+            "traffic_frac": round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if traffic and ms > 0 else None,
+            "traffic_by_kernel": {q.replace("necat::", "").rstrip("("): round(b * n / passes) for q, (b, n) in per.items()} if per else None,
+            "traffic_source": PMC["source"],
+            "note": "B_seed = L/4 + 8 lookups + 8 hits + 28 candidates (SURVEY 8d) per step / seeding time; `traffic` = 2 FETCH_SIZE + WRITE_SIZE of the stage's kernels per "
+                    "pass - the FETCH x 2 correction is calibrated for wide streaming reads and OVERSTATES these kernels' 8- / 16-byte gathers (raw: about half); "
+                    "most of the traffic is the per-read hash tables and block pools of the replay of find_candidates, which the formula prices at zero"}
 
 
 def main():
@@ -844,6 +1008,7 @@ def main():
             raise SystemExit("bench.py: N = %d on distinct devices, but rank(s) %s did not run the RCCL data path (transport / index all-gather bytes: %s)"
                              % (world, [r.get("rank") for r in bad], [(r.get("transport"), r.get("index_allgather_bytes")) for r in bad]))
     K = max(1, args.steps)
+    pmc_select(args, world)
     roofline = roofline_report(agg)
     out = {
         "metric": "overlaps/sec (all-vs-all, index build + seeding + banded Myers extension -> M4)",
@@ -868,6 +1033,8 @@ def main():
     }
     if ix_info:
         out["roofline_index"] = roofline_index(agg["index_ms"] / K, rs.nbases, args.kmer, ix_info["n_offsets"], ix_info["n_distinct"])
+    if agg["seed_lookups"]:
+        out["roofline_seed"] = roofline_seed(agg, K)
     out.update(extras)
     if single:
         out["multi_gpu"] = {"transport": transport, "rank0_index_local_ms": round(agg["ix_local_ms"] / K, 3),
@@ -888,6 +1055,11 @@ def main():
             out["extra_configs"] = {"configs2_sensitive": config2_step(ctx, capi, synth, args)}
         except Exception as e:
             out["extra_configs"] = {"configs2_sensitive": {"error": str(e)}}
+    if world == 1 and args.config4_genome:
+        try:
+            out.setdefault("extra_configs", {})["configs4_human_subset"] = config4_step(ctx, capi, synth, args)
+        except Exception as e:
+            out.setdefault("extra_configs", {})["configs4_human_subset"] = {"error": str(e)}
     cns_part = out.get("widened_paths", {}).pop("_partition", None) if isinstance(out.get("widened_paths"), dict) else None
     if world == 1 and not args.no_cpu_baseline:
         import shutil

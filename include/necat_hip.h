@@ -127,6 +127,11 @@ typedef struct {
     double   rc_ms;
     uint64_t rc_launches, rc_blocks, rc_words;
     double   rc_ck_ms;          /* k_myers_ck of those rounds (beside the ragged blocks' DP kernel on another stream) */
+    /* work counters of the last seeding call (necat_find_candidates* / the seeding part of necat_map_pair*), the terms of SURVEY 8d's
+     * B_seed = L / 4 + 8 lookups + 8 hits + 28 candidates: bases of the query strands walked (both strands of every read of the
+     * call), sampled k-mers looked up in the table (word_finder.c:66-83, one kmer_stats word each), offset-list entries those k-mers
+     * own (what collect_seeds reads, word_finder.c:107-139) and candidates emitted */
+    uint64_t seed_bases, seed_lookups, seed_hits, seed_cands;
 } necat_timings;
 
 void        necat_default_options(necat_map_options* o);            /* map_options.c:12-28 */

@@ -36,7 +36,8 @@ class Timings(C.Structure):
                 ("myers_band_words", C.c_uint64),
                 ("fused_ms", C.c_double), ("fused_launches", C.c_uint64), ("fused_blocks", C.c_uint64),
                 ("rc_ms", C.c_double), ("rc_launches", C.c_uint64), ("rc_blocks", C.c_uint64), ("rc_words", C.c_uint64),
-                ("rc_ck_ms", C.c_double)]
+                ("rc_ck_ms", C.c_double),
+                ("seed_bases", C.c_uint64), ("seed_lookups", C.c_uint64), ("seed_hits", C.c_uint64), ("seed_cands", C.c_uint64)]
 
 
 class ShardTimings(C.Structure):

@@ -114,7 +114,7 @@ k_asm_vote_collect(DevVolume ref, DevVolume reads, IndexView index, const u64* _
     u64 soff_max = ~0ULL;                       // :539-543
     {
         const int gid = read_id + P.read_start_id;
-        if (gid >= P.ref_start_id && gid < P.ref_start_id + (int)ref.nseq) soff_max = ref.seq_off[read_id];
+        if (gid >= P.ref_start_id && gid < P.ref_start_id + (int)ref.nseq) soff_max = ref.seq_off[gid - P.ref_start_id];      // (the host Voter's ref_off[gid - ref_start]: the read's own copy in the reference volume, whatever the two start ids)
     }
     const int k = P.k, z = P.bc;
     const int nk = L >= k ? (L - k) / z + 1 : 0;

@@ -16,6 +16,7 @@
 #include "ext_kernels.h"
 #include "ext_tail.h"
 #include "ext_rcwalk.h"
+#include "ext_rcwalk3.h"
 #include "asm_kernels.h"
 #include "asm_coop.h"
 #include "asm_plan.h"
@@ -88,19 +89,20 @@ u32 g_ck_post;         // NECAT_CK_POST (default 1): k_myers_ck finds the bottom
 u32 g_rc_fastb;        // NECAT_RC_FASTB (default 1): list B's checkpoint pass through k_myers_ckf (32-bit halves, bitop3, DPP carries); 0 = the general pass k_myers_ckg
 u32 g_rc_dbg;          // NECAT_RC_DBG (timing only): 2 = k_rcwalk2w walks every segment twice (once into a sink), 4 = recomputes every segment twice
 u32 g_rc_prefetch;     // NECAT_RC_PREFETCH (default 0: measured 0.4 ms per step SLOWER, profiles/NOTES_r04.md 3): k_rcwalk2w loads the next segment's checkpoints / deltas / planes a segment ahead
-u32 g_rc_ww;           // NECAT_RC_WW (default 1): the recompute walk as k_rcwalk2w - four waves recompute 64 blocks, ONE wave walks them, a lane each; 0 = k_rcwalk2 (every lane of a quad walks its block)
+u32 g_rc_ww;           // NECAT_RC_WW (default 2): the recompute walk as k_rcwalk3 (ext_rcwalk3.h: four waves recompute 64 blocks into 32-DIAGONAL records, one wave walks them column by column); 1 = k_rcwalk2w (64-row records, one LDS read per walk step), 0 = k_rcwalk2 (every lane of a quad walks its block)
 u32 g_rc_carry;        // NECAT_RC_CARRY (default 1): the recompute walk on an exact two-word window (k_myers_ck<CARRY> keeps the words' horizontal deltas, k_rcwalk2); 0 = the 4-word band window (k_rcwalk4)
 int g_rc_maxdist;      // NECAT_RC_MAXDIST (default and maximum kRcMaxDist = 160): full blocks of a larger distance take the old kernels (tests lower it)
 u32 g_walk_wave;       // NECAT_WALK_WAVE (default 12288; 0 = off): lists of at most this many blocks are walked by one WAVE per block through an LDS window (k_walk_wave, ext_tail.h)
 int g_asm_lane;        // NECAT_ASM_LANE=1: necat_asm_align_batch through the lane-per-alignment kernel (k_asm_align), the second implementation
 int g_dbg;             // NECAT_DBG: profiling-only variants of the lane-per-block DP kernel (1 = no band stores, 2 = no NW pass)
 
-// the recompute walk of a list of `nitems` work indices: one workgroup of four waves per 64 blocks (k_rcwalk2w) or one wave per 16 (k_rcwalk2)
+// the recompute walk of a list of `nitems` work indices: one workgroup of four waves per 64 blocks (k_rcwalk3, k_rcwalk2w) or one wave per 16 (k_rcwalk2)
 template <int NW, int TW, int COLS, int MAXOPS, class... A>
 static void launch_rcwalk2(u32 nitems, hipStream_t s, A... a)
 {
     const u32 pr = ((NW == kWordsA ? (g_rc_prio & 1u) : NW == kWordsB ? (g_rc_prio & 4u) : 0u) ? 8u : 0u) | ((NW == kWordsA ? (g_rc_prio & 8u) : NW == kWordsB ? (g_rc_prio & 16u) : 0u) ? 16u : 0u);
-    if (g_rc_ww) hipLaunchKernelGGL((k_rcwalk2w<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(256), 0, s, a..., g_rc_prefetch | g_rc_dbg | pr);
+    if (g_rc_ww >= 2) hipLaunchKernelGGL((k_rcwalk3<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(256), 0, s, a..., pr);
+    else if (g_rc_ww) hipLaunchKernelGGL((k_rcwalk2w<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(256), 0, s, a..., g_rc_prefetch | g_rc_dbg | pr);
     else hipLaunchKernelGGL((k_rcwalk2<NW, TW, COLS, MAXOPS>), dim3((nitems + 15) / 16), dim3(64), 0, s, a...);
 }
 
@@ -117,7 +119,7 @@ void read_knobs()
     g_rcwalk = (u32)num("NECAT_RCWALK", 512);
     g_rc_carry = (u32)num("NECAT_RC_CARRY", 1);
     g_asm_rc = (u32)num("NECAT_ASM_RC", 1);
-    g_rc_ww = (u32)num("NECAT_RC_WW", 1);
+    g_rc_ww = (u32)num("NECAT_RC_WW", 2);
     g_rc_prefetch = (u32)num("NECAT_RC_PREFETCH", 0);
     g_rc_dbg = (u32)num("NECAT_RC_DBG", 0) & 6u;
     g_rc_fastb = (u32)num("NECAT_RC_FASTB", 1);
@@ -849,6 +851,16 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
         for (u32 i = 0; i < nsel; ++i) order[i] = src[i];
     }
     ctx->shard_tm.reads_local = nsel;
+    {   // the terms of SURVEY 8d's B_seed for this call (bench.py: roofline_seed)
+        u64 lk = 0, ht = 0, bs = 0;
+        const bool have_off = reads->h_seq_off.size() == (size_t)nreads + 1;
+        for (u32 i = 0; i < nsel; ++i) {
+            const u32 r = order[i];
+            ht += (u64)hits[2 * (size_t)r] + hits[2 * (size_t)r + 1];
+            if (have_off) { const u64 L = reads->h_seq_off[r + 1] - reads->h_seq_off[r]; bs += L; if (L >= (u64)opt->kmer_size) lk += (L - (u64)opt->kmer_size) / (u64)opt->scan_window + 1; }
+        }
+        ctx->tm.seed_bases = 2 * bs; ctx->tm.seed_lookups = 2 * lk; ctx->tm.seed_hits = ht; ctx->tm.seed_cands = 0;
+    }
     if (nsel == 0) {
         if (dev) { dev->n = 0; dev->d = nullptr; dev->group_off.assign(2, 0); }
         else { *out = (necat_candidate*)result_alloc(sizeof(necat_candidate)); *n_out = 0; }
@@ -987,6 +999,7 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
                     if (e != hipSuccess) { necat_free(res); return set_err(ctx, NECAT_ERR_DEVICE, "seeding result copy: %s", hipGetErrorString(e)); }
             } else { NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s)); NECAT_HIP(ctx, hipStreamSynchronize(s)); }
             ctx->tm.seed_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
+            ctx->tm.seed_cands = tot;
             tick("pack + copy to host");
             if (!dev) { *out = res; *n_out = tot; }
             return NECAT_OK;
@@ -1041,6 +1054,7 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
         for (hipError_t x : e) if (x != hipSuccess) { necat_free(res); return set_err(ctx, NECAT_ERR_DEVICE, "seeding result assembly: %s", hipGetErrorString(x)); }
     } else { NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s)); NECAT_HIP(ctx, hipStreamSynchronize(s)); }
     ctx->tm.seed_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
+    ctx->tm.seed_cands = total;
     tick("assemble in read order");
     if (!dev) { *out = res; *n_out = total; }
     return NECAT_OK;
@@ -2238,11 +2252,12 @@ int necat_asm_plan_batch(necat_ctx* ctx, const necat_index* ix, const necat_volu
     // chunk inside HBM.  A chunk's vote kernels are as long as the walk of its heaviest read, so the chunks run on TWO arena sets and two streams:
     // chunk i + 1's vote kernels are in flight while chunk i's tail finishes and its range stage runs.  16 M blocks = 6 GB per set by default - a
     // short-lived process pays for the device memory it maps (the first 30 GB of arenas of a process on a fresh box took 0.9 s,
-    // profiles/NOTES_r04.md 4) - never more than 20 % of the memory that is free now)
+    // profiles/NOTES_r04.md 4) - and the two sets' pools + candidate lists (the per-block bytes below: both scale with the budget; the hash tables, the
+    // selection and read-index arenas are small beside them) together never more than 40 % of the memory that is free now)
     u64 budget_blocks = getenv("NECAT_ASM_VOTE_BUDGET") ? std::max<u64>(1024, strtoull(getenv("NECAT_ASM_VOTE_BUDGET"), nullptr, 10)) : (u64)16 << 20;
     {
         size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr) budget_blocks = std::max<u64>(1 << 16, std::min<u64>(budget_blocks, (u64)(fr * 0.2) / sizeof(VBlock)));
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr) budget_blocks = std::max<u64>(1 << 16, std::min<u64>(budget_blocks, (u64)(fr * 0.4) / (2 * (sizeof(VBlock) + sizeof(VoteCand)))));
     }
     static const u64 budget_seeds = getenv("NECAT_ASM_SEED_BUDGET") ? std::max<u64>(1024, strtoull(getenv("NECAT_ASM_SEED_BUDGET"), nullptr, 10)) : (u64)32 << 20;
     static const bool overlap = !getenv("NECAT_ASM_NO_OVERLAP");            // (A/B: one arena set, one stream, chunk after chunk)
@@ -2283,7 +2298,7 @@ int necat_asm_plan_batch(necat_ctx* ctx, const necat_index* ix, const necat_volu
     }
     hipStream_t st2[2] = {s, s};
     if (overlap && chunk_end.size() > 1) {
-        if (!ctx->stream_b && hipStreamCreate(&ctx->stream_b) != hipSuccess) return fail(set_err(ctx, NECAT_ERR_DEVICE, "hipStreamCreate failed"));
+        if (int rcs = ext_streams(ctx)) return fail(rcs);          // (the context's one place that makes streams: NECAT_SERIAL aliases and NECAT_STREAM_PRIO apply here too)
         st2[1] = ctx->stream_b;
     }
     tick("chunk plan + arenas");

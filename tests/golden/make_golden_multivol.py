@@ -8,6 +8,7 @@ Run in the build container (needs oracle/_ref/oc2pmov = the reference compiled f
 
     python tests/golden/make_golden_multivol.py [threads]                 -> tests/golden/multivol_full_reference.json
     python tests/golden/make_golden_multivol.py [threads] drosophila      -> tests/golden/drosophila_full_reference.json
+    python tests/golden/make_golden_multivol.py [threads] human_subset    -> tests/golden/human_subset_full_reference.json
 
 `drosophila` is BASELINE.json configs[3] at its real size: a 140 Mb genome x 40 = 5.6 Gbp cut by oc2mkdb's own rule (a volume
 is closed once it holds >= 2 000 000 000 bases, makedb/main.c:8,29) into volumes of 2.0 / 2.0 / 1.6 Gbp - six (reference,
@@ -41,6 +42,13 @@ CFGS["multivol"] = dict(genome=37_000_000, coverage=40.0, seed=31, err=0.12, cut
            flags="-k 15 -z 20 -q 500 -b 2000 -s 3 -n 500 -a 1000 -d 0.25 -e 0.5 -m 500")
 CFGS["drosophila"] = dict(genome=140_000_000, coverage=40.0, seed=41, err=0.12, cuts=[2_000_000_000, 2_000_000_000],
                           flags="-k 15 -z 20 -q 500 -b 2000 -s 3 -n 500 -a 1000 -d 0.25 -e 0.5 -m 500")
+# BASELINE configs[4] as a stated SUBSET (SURVEY 8d allows one): a 3 Gb genome read at the 30x RATE, of whose 45 oc2mkdb volumes
+# the first three are kept - synth.simulate_reads draws reads one after the other until the target is met, so `coverage = 2.0`
+# IS the first 6 Gbp of the 90 Gbp read set (volumes 0 and 1 closed by the 2 Gbp rule, volume 2 = what is left of the 6 Gbp).
+# The regime no smaller genome has: a 2 Gbp volume is 0.67x of the genome, so its ~2 x 10^9 k-mer positions are nearly all
+# distinct (table occupancy ~ 0.85 of 4^15, the -q cut idle) and a read has a handful of true overlaps instead of ~ 80.
+CFGS["human_subset"] = dict(genome=3_000_000_000, coverage=2.0, seed=51, err=0.12, cuts=[2_000_000_000, 2_000_000_000],
+                            flags="-k 15 -z 20 -q 500 -b 2000 -s 3 -n 500 -a 1000 -d 0.25 -e 0.5 -m 500")
 
 
 def main(threads: int, name: str = "multivol") -> None:

@@ -22,8 +22,9 @@ def ecoli(ctx, request):
     GOLD = GOLDS[request.param]
     g = GOLD["generator"]
     rs = synth.simulate_reads(g["genome"], g["coverage"], seed=g["seed"], err=g["err"])
-    if hashlib.md5(rs.codes.tobytes()).hexdigest() != GOLD["reads_md5"]:
-        pytest.skip("numpy generator drift: the seeded dataset differs from the one the golden was made on")
+    # (a FAILURE, not a skip: a numpy whose generators drifted would otherwise silently turn the strongest parity tests off)
+    assert hashlib.md5(rs.codes.tobytes()).hexdigest() == GOLD["reads_md5"], \
+        "numpy generator drift: the seeded dataset differs from the one tests/golden/%s_full_reference.json was made on - regenerate the golden (make_golden_full.py)" % request.param
     vol = ctx.upload_volume(synth.pack_2bit(rs.codes), rs.nbases, rs.offsets, rs.sizes)
     ix = ctx.build_index(vol, 15, 500)
     yield rs, vol, ix, GOLD
@@ -66,9 +67,12 @@ def test_m4_identical_to_reference(ctx, ecoli):
 
 # ---- multi-volume projects at real volume sizes through the oc2pm PROGRAM: "multivol" = 1.48 Gbp in three volumes of 1.05 / 0.30 / 0.13 Gbp;
 # "drosophila" = BASELINE configs[3] at its real size, a 140 Mb genome x 40 = 5.6 Gbp cut by oc2mkdb's own 2 Gbp rule into 2.0 / 2.0 / 1.6 Gbp
-# (the volume size at which 34-bit offsets, u32 slot counts and the 786 432-candidate batch cap are real; 6.9 M records per mode)
+# (the volume size at which 34-bit offsets, u32 slot counts and the 786 432-candidate batch cap are real; 6.9 M records per mode);
+# "human_subset" = BASELINE configs[4] as a stated subset: a 3 Gb genome read at the 30x rate, the first three of its 45 oc2mkdb volumes (2.0 / 2.0 / 2.0 Gbp =
+# 2x of the genome): ~ 2 x 10^9 k-mer positions per volume that are nearly all distinct (table occupancy ~ 0.85 of 4^15, the -q cut idle), a handful of true
+# overlaps per read instead of ~ 80 - index build and seeding at a hit density no smaller genome has (word_finder.c:121-127, lookup_table.h:12-15)
 MV_SETS = {}
-for _name in ("multivol", "drosophila"):
+for _name in ("multivol", "drosophila", "human_subset"):
     _p = os.path.join(util.GOLDEN, "%s_full_reference.json" % _name)
     if os.path.exists(_p):
         MV_SETS[_name] = json.load(open(_p))
@@ -88,8 +92,8 @@ def multivol_dir(tmp_path_factory, request):
         except ImportError:
             pass
     rs = synth.simulate_reads(g["genome"], g["coverage"], seed=g["seed"], err=g["err"])
-    if hashlib.md5(rs.codes.tobytes()).hexdigest() != MV["reads_md5"]:
-        pytest.skip("numpy generator drift: the seeded dataset differs from the one the golden was made on")
+    assert hashlib.md5(rs.codes.tobytes()).hexdigest() == MV["reads_md5"], \
+        "numpy generator drift: the seeded dataset differs from the one tests/golden/%s_full_reference.json was made on - regenerate the golden (make_golden_multivol.py)" % request.param
     keep = os.environ.get("NECAT_TEST_KEEP_VOLS")          # tools/r04: the profile pass reuses the volumes this fixture wrote
     d = os.path.join(keep, request.param) if keep else os.path.join(str(tmp_path_factory.mktemp("mv")), "vols")
     assert synth.write_volume_dir_cuts(d, rs, g["cuts"]) == MV["volumes"]

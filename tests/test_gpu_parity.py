@@ -133,18 +133,19 @@ def _random_pairs(rng, n, qlo, qhi, err):
     return np.concatenate(seqs), qo, ql, to, tl
 
 
-@pytest.mark.parametrize("path", ["band", "recompute", "recompute_quad", "recompute_fast"])
+@pytest.mark.parametrize("path", ["band", "recompute", "recompute_rows", "recompute_quad", "recompute_fast"])
 def test_edlib_blocks_match_oracle(ctx, monkeypatch, path):
     """The dominant kernel in isolation: distance, end column and the full edit path, including
     ragged sizes (1..794), failures (too divergent) and exact 512 x 512 blocks (the FULL kernel).
-    band: DP passes + band records + walk; recompute: checkpoint pass + the walk that recomputes its cells (ext_rcwalk.h: k_myers_ckg,
-    k_rcwalk2w: four waves recompute 64 blocks, one wave walks them) at both geometries (8 words / 13 words per block); recompute_quad:
-    the same through k_rcwalk2 (every quad recomputes and walks its own block, NECAT_RC_WW=0)."""
+    band: DP passes + band records + walk; recompute: checkpoint pass + the walk that recomputes its cells (k_myers_ckg, ext_rcwalk.h; k_rcwalk3,
+    ext_rcwalk3.h: four waves recompute 64 blocks into 32-diagonal records, one wave walks them column by column) at both geometries (8 words / 13 words
+    per block); recompute_rows: the same through round 4's k_rcwalk2w (64-row records, one LDS read per walk step, NECAT_RC_WW=1); recompute_quad:
+    through k_rcwalk2 (every quad recomputes and walks its own block, NECAT_RC_WW=0)."""
     if path != "band":
         monkeypatch.setenv("NECAT_BATCH_RC", "2" if path == "recompute_fast" else "1")          # 2: the checkpoint pass through k_myers_ckf (fast_shw_ckr at 8 and 16 lanes per block)
-    if path == "recompute_quad":
+    if path in ("recompute_quad", "recompute_rows"):
         from necat_amd import capi
-        monkeypatch.setenv("NECAT_RC_WW", "0")
+        monkeypatch.setenv("NECAT_RC_WW", "0" if path == "recompute_quad" else "1")
         capi.Context(0).close()          # knobs are process-wide and read when a context is created
     rng = np.random.default_rng(2024)
     seqs, qo, ql, to, tl = _random_pairs(rng, 300, 1, 794, 0.15)
@@ -189,7 +190,7 @@ def test_edlib_blocks_match_oracle(ctx, monkeypatch, path):
     assert nfail >= 40 and nfail < len(qo) // 2
     tm = ctx.timings()
     assert tm.myers_word_updates > 0
-    if path == "recompute_quad":
+    if path in ("recompute_quad", "recompute_rows"):
         from necat_amd import capi
         monkeypatch.undo()
         capi.Context(0).close()          # back to the defaults for the tests that follow
@@ -480,8 +481,8 @@ def test_capped_band_pool_runs_lists_in_chunks(ctx, small, tmp_path, monkeypatch
                                   "NECAT_RCWALK=1 NECAT_RC_CARRY=0 NECAT_TAIL_FUSED=0", "NECAT_RCWALK=1 NECAT_RC_CARRY=0 NECAT_RC_MAXDIST=90",
                                   "NECAT_RCWALK=1 NECAT_RC_POOL_MB=1", "NECAT_RCWALK=1 NECAT_RC_RAGGED=0 NECAT_TAIL_FUSED=0",
                                   "NECAT_RC_LISTB=0", "NECAT_RC_LISTB=1 NECAT_TAIL_FUSED=0 NECAT_RC_POOL_MB=1",
-                                  "NECAT_RC_WW=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_MERGE=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0",
-                                  "NECAT_RC_MERGE=1 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0 NECAT_RC_POOL_MB=1", "NECAT_RC_FASTB=0 NECAT_TAIL_FUSED=0", "NECAT_RC_PREFETCH=1 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0",
+                                  "NECAT_RC_WW=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_WW=1 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_WW=1 NECAT_RC_PREFETCH=1 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_MERGE=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0",
+                                  "NECAT_RC_MERGE=1 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0 NECAT_RC_POOL_MB=1", "NECAT_RC_FASTB=0 NECAT_TAIL_FUSED=0",
                                   "NECAT_CK_POST=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0",
                                   "NECAT_RC_PIPE=3 NECAT_RC_PIPE_MIN=64 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_PRIO=6 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0"])
 def test_alternative_kernel_paths_give_the_same_records(ctx, small, monkeypatch, knob):

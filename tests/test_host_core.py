@@ -193,3 +193,18 @@ def test_cns_loop_deep_coverage_cut_to_300(check_cns, tmp_path):
     assert r.returncode == 0, r.stdout
     assert "cns_mismatch=0 " in r.stdout and " overlaps=0 " not in r.stdout
 
+
+
+# ---- the diagonal-band walk of k_rcwalk3 (necat_amd/csrc/ext_bandwalk.h): the per-lane cores against walk_block ----
+
+@pytest.mark.parametrize("seed", [1, 20260928])
+def test_band_walk_equals_walk_block(tmp_path, seed):
+    """band_piece + band_walk_col / band_walk_col2 - what a quad of k_rcwalk3 stores per column and what its walker does with it - replayed
+    on the CPU over random blocks of every geometry (512 x 512, ragged, list B, 2048-bp blocks), error rates 0 - 35 %, long indels that force
+    the redo path, every tail-match length, ops kept or not: the same n / nmat / tail statistics / ops as walk_block on the full matrix"""
+    exe = os.path.join(str(tmp_path), "check_bandwalk")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(util.ROOT, "necat_amd", "csrc"), "-o", exe,
+                    os.path.join(util.ROOT, "tests", "host_core", "check_bandwalk.cpp")], check=True)
+    r = subprocess.run([exe, "1500", str(seed)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    assert "1500 blocks equal to walk_block" in r.stdout

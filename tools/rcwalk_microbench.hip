@@ -1,4 +1,4 @@
-// rcwalk_microbench.hip - the recomputing walk of list A (k_rcwalk2w<8, 16, 512, 1024>, ext_rcwalk.h) alone, on synthetic 512 x 512 blocks
+// rcwalk_microbench.hip - the recomputing walk of list A (k_rcwalk3<8, 16, 512, 1024>, ext_rcwalk3.h, and its predecessor k_rcwalk2w, ext_rcwalk.h) alone, on synthetic 512 x 512 blocks
 // (random query, target = the query with 12 % substitutions / insertions / deletions) whose checkpoints, deltas and results come from
 // k_myers_ck on the same fragments.  Per-launch time by list size, by workgroups per CU (dynamic LDS), with / without kept ops (the
 // `found` flag of the block's task), with raised wave priority; with -DNECAT_RC_TIMING also with the walk / the recompute of every segment
@@ -14,6 +14,7 @@
 #include "ext_kernels.h"
 #include "ext_tail.h"
 #include "ext_rcwalk.h"
+#include "ext_rcwalk3.h"
 using namespace necat;
 #define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -79,6 +80,67 @@ int main(int argc, char** argv)
     }
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     CHECK(hipFuncSetAttribute((const void*)k_rcwalk2w<NW, TW, N, MAXOPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
+    CHECK(hipFuncSetAttribute((const void*)k_rcwalk3<NW, TW, N, MAXOPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
+    WalkOut* wout2; u8* ops2;
+    CHECK(hipMalloc(&wout2, (size_t)nmax * sizeof(WalkOut)));
+    CHECK(hipMalloc(&ops2, (size_t)(nmax / 64) * MAXOPS * 64));
+    // k_rcwalk3 against k_rcwalk2w on the same blocks: every WalkOut field, and (with kept ops) every op, must be equal
+    auto same = [&](u32 n, int found) {
+        ExtTask t; memset(&t, 0, sizeof t); t.found = found;
+        CHECK(hipMemcpy(tasks, &t, sizeof t, hipMemcpyHostToDevice));
+        const u32 c2[4] = {n, 0, 0, 0};
+        CHECK(hipMemcpy(ndev, c2, 16, hipMemcpyHostToDevice));
+        CHECK(hipMemset(wout, 0xff, (size_t)n * sizeof(WalkOut))); CHECK(hipMemset(wout2, 0xee, (size_t)n * sizeof(WalkOut)));
+        CHECK(hipMemset(ops, 0x7f, (size_t)(nmax / 64) * MAXOPS * 64)); CHECK(hipMemset(ops2, 0x7f, (size_t)(nmax / 64) * MAXOPS * 64));
+        hipLaunchKernelGGL((k_rcwalk2w<NW, TW, N, MAXOPS>), dim3((n + 63) / 64), dim3(256), 0, 0, (const BlockItem*)items, n, (const u32*)ndev, n, (const u64*)frag, (const ulonglong2*)ck,
+                           (const u64*)hc, (const BlockResult*)res, (const ExtTask*)tasks, 0, 8, ops, wout, stats, errf, 1u, 0u, n, 0u);
+        hipLaunchKernelGGL((k_rcwalk3<NW, TW, N, MAXOPS>), dim3((n + 63) / 64), dim3(256), 0, 0, (const BlockItem*)items, n, (const u32*)ndev, n, (const u64*)frag, (const ulonglong2*)ck,
+                           (const u64*)hc, (const BlockResult*)res, (const ExtTask*)tasks, 0, 8, ops2, wout2, stats, errf, 1u, 0u, n, 0u);
+        CHECK(hipDeviceSynchronize());
+        std::vector<WalkOut> a(n), b(n);
+        CHECK(hipMemcpy(a.data(), wout, (size_t)n * sizeof(WalkOut), hipMemcpyDeviceToHost)); CHECK(hipMemcpy(b.data(), wout2, (size_t)n * sizeof(WalkOut), hipMemcpyDeviceToHost));
+        std::vector<u8> oa((size_t)((n + 63) / 64) * MAXOPS * 64), ob(oa.size());
+        CHECK(hipMemcpy(oa.data(), ops, oa.size(), hipMemcpyDeviceToHost)); CHECK(hipMemcpy(ob.data(), ops2, ob.size(), hipMemcpyDeviceToHost));
+        size_t bad_w = 0, bad_o = 0;
+        for (u32 x = 0; x < n; ++x) if (memcmp(&a[x], &b[x], sizeof(WalkOut))) { if (!bad_w) printf("  first WalkOut difference at block %u: n %d / %d, nmat %d / %d, hit %d / %d, acnt %d / %d\n", x, a[x].n, b[x].n, a[x].nmat, b[x].nmat, a[x].hit, b[x].hit, a[x].acnt, b[x].acnt); ++bad_w; }
+        for (size_t i = 0; i < oa.size(); ++i) if (oa[i] != ob[i]) ++bad_o;
+        int he = 0; CHECK(hipMemcpy(&he, errf, 4, hipMemcpyDeviceToHost));
+        printf("k_rcwalk3 == k_rcwalk2w on %u blocks (%s): %zu WalkOut records differ, %zu op bytes differ, err %d  %s\n", n, found ? "lean" : "ops kept", bad_w, bad_o, he, (bad_w || bad_o || he) ? "MISMATCH" : "ok");
+        return !(bad_w || bad_o || he);
+    };
+    bool ok = same(nmax, 1); ok = same(nmax, 0) && ok; ok = same(1000, 0) && ok;
+    auto run3 = [&](u32 n, int found, u32 opts, u32 lds, const char* what) {
+        ExtTask t; memset(&t, 0, sizeof t); t.found = found;
+        CHECK(hipMemcpy(tasks, &t, sizeof t, hipMemcpyHostToDevice));
+        const u32 c2[4] = {n, 0, 0, 0};
+        CHECK(hipMemcpy(ndev, c2, 16, hipMemcpyHostToDevice));
+        float best = 1e9f;
+        for (int r = 0; r < 5; ++r) {
+            CHECK(hipEventRecord(e0, 0));
+            hipLaunchKernelGGL((k_rcwalk3<NW, TW, N, MAXOPS>), dim3((n + 63) / 64), dim3(256), lds, 0, (const BlockItem*)items, n, (const u32*)ndev, n, (const u64*)frag, (const ulonglong2*)ck,
+                               (const u64*)hc, (const BlockResult*)res, (const ExtTask*)tasks, 0, 8, ops, wout, stats, errf, 1u, 0u, n, opts);
+            CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (r) best = std::min(best, ms);
+        }
+        int he = 0; CHECK(hipMemcpy(&he, errf, 4, hipMemcpyDeviceToHost));
+        WalkOut w0; CHECK(hipMemcpy(&w0, wout, sizeof w0, hipMemcpyDeviceToHost));
+        printf("k_rcwalk3  %7u blocks (%4u workgroups) | %-58s | %8.1f us | %.2f ns per block | err %d, block 0: n %d nmat %d\n", n, (n + 63) / 64, what, best * 1e3, best * 1e6 / n, he, w0.n, w0.nmat);
+    };
+    run3(nmax, 1, 0, 0, "lean");
+    run3(nmax, 0, 0, 0, "ops kept");
+    run3(nmax, 1, 8, 0, "lean, s_setprio 3");
+    run3(nmax, 1, 16, 0, "lean, only the walking wave at s_setprio 3");
+    run3(nmax, 1, 0, 0, "lean again");
+    run3(nmax, 1, 0, 4u << 10, "lean, 7 workgroups per CU (dynamic LDS)");
+    run3(nmax, 1, 0, 7u << 10, "lean, 6 workgroups per CU");
+    run3(nmax, 1, 0, 12u << 10, "lean, 5 workgroups per CU");
+    run3(nmax, 1, 0, 20u << 10, "lean, 4 workgroups per CU");
+    run3(nmax, 1, 0, 36u << 10, "lean, 3 workgroups per CU");
+    run3(110592, 1, 0, 0, "lean, half the list (the bench's typical big round)");
+    run3(81920, 1, 0, 0, "lean, 5 workgroups per CU's worth");
+    run3(16384, 1, 0, 0, "lean, one workgroup per CU");
+    run3(64, 1, 0, 0, "lean, ONE workgroup");
     auto run = [&](u32 n, int found, u32 opts, u32 lds, const char* what) {
         ExtTask t; memset(&t, 0, sizeof t); t.found = found;
         CHECK(hipMemcpy(tasks, &t, sizeof t, hipMemcpyHostToDevice));
@@ -97,6 +159,7 @@ int main(int argc, char** argv)
         WalkOut w0; CHECK(hipMemcpy(&w0, wout, sizeof w0, hipMemcpyDeviceToHost));
         printf("%7u blocks (%4u workgroups) | %-58s | %8.1f us | %.2f ns per block | err %d, block 0: n %d nmat %d\n", n, (n + 63) / 64, what, best * 1e3, best * 1e6 / n, he, w0.n, w0.nmat);
     };
+    printf("---- k_rcwalk2w (round 4)\n");
     run(nmax, 1, 0, 0, "tasks past their first run of matches (lean walk)");
     run(nmax, 0, 0, 0, "tasks before it (ops kept)");
     run(nmax, 1, 8, 0, "lean, s_setprio 3");
@@ -115,5 +178,5 @@ int main(int argc, char** argv)
     run(64, 1, 2, 0, "ONE workgroup, walk twice");
     run(64, 1, 4, 0, "ONE workgroup, recompute twice");
 #endif
-    return 0;
+    return ok ? 0 : 2;
 }
