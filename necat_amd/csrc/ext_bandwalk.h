@@ -49,6 +49,32 @@ NECAT_HD u32 band_piece(u64 plane, int rel)
     return rel >= 0 ? (u32)(plane >> rel) : ((u32)plane << (-rel));
 }
 
+// Which two words a segment entered at row r is recomputed on: the rows it can touch are [r - 47, r] (32 columns, the entry on bit 16), so the pair starts at the
+// word of row r - 47 (word 0 when r < 47: the rows above the matrix then read as zero, band_piece2's general form)
+NECAT_HD int band_word_lo(int r) { return r >= 47 ? (r - 47) >> 6 : 0; }
+
+// a column's record from the decision planes of the pair (lo: word wl, hi: word wl + 1): bits [S, S + 32) of the 128 rows that start at row 64 wl.
+// GENERAL = false: 0 <= S < 96 (every segment entered at r >= 47); true: any S in (-64, 128), rows outside the pair read as zero.
+template <bool GENERAL>
+NECAT_HD u32 band_piece2(const u32 d0, const u32 d1, const u32 d2, const u32 d3, const int S)
+{
+    const int i = S >> 5;
+    const u32 sh = (u32)S & 31u;
+    u32 x0, x1;
+    if (GENERAL) {
+        x0 = i == 0 ? d0 : (i == 1 ? d1 : (i == 2 ? d2 : (i == 3 ? d3 : 0u)));
+        x1 = i == -1 ? d0 : (i == 0 ? d1 : (i == 1 ? d2 : (i == 2 ? d3 : 0u)));
+    } else {
+        x0 = i == 0 ? d0 : (i == 1 ? d1 : d2);
+        x1 = i == 0 ? d1 : (i == 1 ? d2 : d3);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(x1, x0, sh);
+#else
+    return (u32)((((u64)x1 << 32) | x0) >> sh);
+#endif
+}
+
 // the walker's state of one block (walk_block's locals, dp_core.h)
 struct BandWalk {
     int r, c;                    // the cell the walk stands on
@@ -132,5 +158,44 @@ NECAT_HD void band_walk_col2(BandWalk& w, int& st, const bool act, const u32 A, 
     const bool out2 = go && (w.r | w.c) < 0, red2 = go && !out2 && w.p > 31;
     st = (out1 || out2) ? 2 : ((red1 || red2) ? 1 : st);
 }
+
+// band_walk_col2 with the bookkeeping cut to what a column needs (k_rcwalk3's walker is a third of the kernel's instructions): no status code per
+// column - a lane is `alive` until it leaves the band or the matrix, and which of the two it was is read off (r, c, p) after the segment (band_walk_why);
+// `here`: the lane has reached this column (x <= its entry column; always true for a lane that entered the segment at its last column).
+template <int MAXOPS, class Store>
+NECAT_HD void band_walk_col3(BandWalk& w, bool& alive, const bool here, const u32 A, const u32 B, const int mlen, const bool store, Store& st_op, int& ovf)
+{
+    const bool act = alive && here;
+    const u32 lim = (u32)w.p + 1u;
+    u32 run = (u32)clz32((~A | B) << ((31u - (u32)w.p) & 31u));           // the ups below bit p (p in [0, 31] while the lane is alive) ..
+    run = run < lim ? run : lim;                                          // .. ending at the band's bit 0
+    run = act ? run : 0u;
+    if (NECAT_ANY(run > 0 && (store || !w.hit))) {
+        if (run > 0) {
+            if (store) for (u32 i = 0; i < run; ++i) { if (w.n + (int)i < MAXOPS) st_op(w.n + (int)i, 1); else ovf = 1; }
+            if (!w.hit) {
+                if (mlen == 0) { w.hit = 1; w.acnt = w.n + 1; w.qcnt = w.nq + 1; w.tcnt = w.nt; w.mcnt = w.nmat; }
+                w.m = 0; w.nq += (int)run;
+            }
+        }
+    }
+    w.n += (int)run; w.r -= (int)run; w.p -= (int)run;
+    const bool go = act && (w.r | w.p) >= 0;
+    const u32 p2 = (u32)w.p & 31u;
+    const u32 a = (A >> p2) & 1u, b = (B >> p2) & 1u;
+    const int left = (int)(b & (a ^ 1u)), nm = (int)(a | b);
+    if (NECAT_ANY(go && store)) { if (go && store) { if (w.n < MAXOPS) st_op(w.n, (int)(a | (b << 1))); else ovf = 1; } }
+    if (NECAT_ANY(go && !w.hit)) {
+        if (go && !w.hit) {
+            w.nq += 1 - left; w.nt += 1;
+            w.m = nm ? 0 : w.m + 1;
+            if (w.m == mlen) { w.hit = 1; w.acnt = w.n + 1; w.qcnt = w.nq; w.tcnt = w.nt; w.mcnt = w.nmat + 1 - nm; }
+        }
+    }
+    if (go) { w.n += 1; w.nmat += 1 - nm; w.r -= 1 - left; w.c -= 1; w.p += left; }
+    alive = act ? (go && (w.r | w.c) >= 0 && (u32)w.p <= 31u) : alive;
+}
+// after a segment, for a lane that was walking when it began: 0 = still walking (on to the segment before), 1 = left the band (redo from (r, c)), 2 = left the matrix
+NECAT_HD int band_walk_why(const BandWalk& w, const bool alive) { return alive ? 0 : ((w.r | w.c) < 0 ? 2 : 1); }
 
 }  // namespace necat

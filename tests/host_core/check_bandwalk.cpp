@@ -90,20 +90,38 @@ int main(int argc, char** argv)
             if (seg == prev_seg) { ++redo; ++myredo; } prev_seg = seg; ++segs;
             w.p = kBandP0;
             u32 ra[32], rb_[32];
+            const int wl = band_word_lo(w.r), wh = wl + 1 < nw ? wl + 1 : nw - 1;      // the kernel's pair of words (ext_rcwalk3.h)
+            const bool general = (c0 + d0 - kBandP0 - 64 * wl) < 0;                   // some column's record starts above the pair: zero fill
             for (int x = 0; x <= xin; ++x) {
-                const int col = c0 + x, rb = col + d0 - kBandP0;
-                u32 a = 0, b = 0;
-                for (int k = 0; k < 2; ++k) {
-                    const int ww = w1 - 1 + k;
-                    if (ww < 0) continue;
-                    u64 pa, pb; fm.rec(col, ww, pa, pb);
-                    a |= band_piece(pa, rb - 64 * ww); b |= band_piece(pb, rb - 64 * ww);
+                const int col = c0 + x, rb = col + d0 - kBandP0, S = rb - 64 * wl;
+                u64 pa0, pb0, pa1, pb1; fm.rec(col, wl, pa0, pb0); fm.rec(col, wh, pa1, pb1);
+                if (wh == wl) { pa1 = rng(); pb1 = rng(); }                           // (the top word twice: its second copy is never looked at)
+                if (!general && (S < 0 || S >= 96)) { fprintf(stderr, "block %d: S = %d outside the fast form's range\n", blk, S); return 1; }
+                u32 a, b;
+                if (general) { a = band_piece2<true>((u32)pa0, (u32)(pa0 >> 32), (u32)pa1, (u32)(pa1 >> 32), S); b = band_piece2<true>((u32)pb0, (u32)(pb0 >> 32), (u32)pb1, (u32)(pb1 >> 32), S); }
+                else { a = band_piece2<false>((u32)pa0, (u32)(pa0 >> 32), (u32)pa1, (u32)(pa1 >> 32), S); b = band_piece2<false>((u32)pb0, (u32)(pb0 >> 32), (u32)pb1, (u32)(pb1 >> 32), S); }
+                if ((blk & 8) == 0) {      // and the four-lane form's pieces (band_piece per word, OR-ed): the same record where the walk can look
+                    u32 a2 = 0, b2 = 0;
+                    const int w1 = w.r >> 6;
+                    for (int k = 0; k < 2; ++k) {
+                        const int ww = w1 - 1 + k;
+                        if (ww < 0) continue;
+                        u64 qa, qb; fm.rec(col, ww, qa, qb);
+                        a2 |= band_piece(qa, rb - 64 * ww); b2 |= band_piece(qb, rb - 64 * ww);
+                    }
+                    for (int p = 0; p < 32; ++p) { const int row = rb + p; if (row <= w.r && (((a ^ a2) | (b ^ b2)) >> p & 1u)) { fprintf(stderr, "block %d: the two forms of the record differ at row %d\n", blk, row); return 1; } }
                 }
-                // rows above r of the entry column and everything outside the two words: poison (the walk must never look there)
-                for (int p = 0; p < 32; ++p) { const int row = rb + p; if (row > w.r || row > 64 * w1 + 63) { a |= (u32)(rng() & 1) << p; b |= (u32)(rng() & 1) << p; } }
+                // rows above r (the walk only moves up): poison
+                for (int p = 0; p < 32; ++p) { const int row = rb + p; if (row > w.r) { a = (a & ~(1u << p)) | ((u32)(rng() & 1) << p); b = (b & ~(1u << p)) | ((u32)(rng() & 1) << p); } }
                 ra[x] = a; rb_[x] = b;
             }
             int st = 0;
+            if ((blk & 6) == 6) {    // the lean wave form: alive flag, the reason read off the state afterwards
+                int ovf = 0; bool alive = true;
+                for (int x = 31; x >= 0; --x) band_walk_col3<1 << 20>(w, alive, x <= xin, x <= xin ? ra[x] : (u32)rng(), x <= xin ? rb_[x] : (u32)rng(), mlen, store, put, ovf);
+                if (ovf) { fprintf(stderr, "block %d: op index overflow\n", blk); return 1; }
+                st = band_walk_why(w, alive);
+            } else
             if (blk & 2) {       // the wave form (selects instead of branches): every column of the segment goes through it, active or not
                 int ovf = 0;
                 for (int x = 31; x >= 0; --x) band_walk_col2<1 << 20>(w, st, st == 0 && x <= xin, x <= xin ? ra[x] : (u32)rng(), x <= xin ? rb_[x] : (u32)rng(), mlen, store, put, ovf);

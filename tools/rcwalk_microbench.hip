@@ -23,6 +23,7 @@ int main(int argc, char** argv)
     constexpr int NW = 8, TW = 16, FW = 2 * NW + TW, G = 8, N = 512, MAXOPS = 1024;
     const u32 nmax = 221184;                       // 3456 workgroups of 64 blocks: the size of the bench's big rounds
     const double err = argc > 1 ? atof(argv[1]) : 0.12;
+    const int store_pct = argc > 2 ? atoi(argv[2]) : 0;          // per cent of the blocks whose task keeps its ops in the "mixed" runs (task 1: found = 0)
     std::vector<u64> hfrag((size_t)nmax * FW, 0);
     {
         std::mt19937_64 rng(12345);
@@ -63,7 +64,7 @@ int main(int argc, char** argv)
     CHECK(hipMalloc(&ops, (size_t)(nmax / 64) * MAXOPS * 64));
     {
         std::vector<BlockItem> hi(nmax);
-        for (u32 x = 0; x < nmax; ++x) { memset(&hi[x], 0, sizeof(BlockItem)); hi[x].task = 0; hi[x].qn = (i16)N; hi[x].tn = (i16)N; }
+        for (u32 x = 0; x < nmax; ++x) { memset(&hi[x], 0, sizeof(BlockItem)); hi[x].task = ((x * 2654435761u) >> 8) % 100u < (u32)store_pct ? 1 : 0; hi[x].qn = (i16)N; hi[x].tn = (i16)N; }
         CHECK(hipMalloc(&items, (size_t)nmax * sizeof(BlockItem))); CHECK(hipMemcpy(items, hi.data(), (size_t)nmax * sizeof(BlockItem), hipMemcpyHostToDevice));
         CHECK(hipMalloc(&tasks, 2 * sizeof(ExtTask)));
     }
@@ -86,15 +87,15 @@ int main(int argc, char** argv)
     CHECK(hipMalloc(&ops2, (size_t)(nmax / 64) * MAXOPS * 64));
     // k_rcwalk3 against k_rcwalk2w on the same blocks: every WalkOut field, and (with kept ops) every op, must be equal
     auto same = [&](u32 n, int found) {
-        ExtTask t; memset(&t, 0, sizeof t); t.found = found;
-        CHECK(hipMemcpy(tasks, &t, sizeof t, hipMemcpyHostToDevice));
+        ExtTask t[2]; memset(t, 0, sizeof t); t[0].found = found;
+        CHECK(hipMemcpy(tasks, t, sizeof t, hipMemcpyHostToDevice));
         const u32 c2[4] = {n, 0, 0, 0};
         CHECK(hipMemcpy(ndev, c2, 16, hipMemcpyHostToDevice));
         CHECK(hipMemset(wout, 0xff, (size_t)n * sizeof(WalkOut))); CHECK(hipMemset(wout2, 0xee, (size_t)n * sizeof(WalkOut)));
         CHECK(hipMemset(ops, 0x7f, (size_t)(nmax / 64) * MAXOPS * 64)); CHECK(hipMemset(ops2, 0x7f, (size_t)(nmax / 64) * MAXOPS * 64));
         hipLaunchKernelGGL((k_rcwalk2w<NW, TW, N, MAXOPS>), dim3((n + 63) / 64), dim3(256), 0, 0, (const BlockItem*)items, n, (const u32*)ndev, n, (const u64*)frag, (const ulonglong2*)ck,
                            (const u64*)hc, (const BlockResult*)res, (const ExtTask*)tasks, 0, 8, ops, wout, stats, errf, 1u, 0u, n, 0u);
-        hipLaunchKernelGGL((k_rcwalk3<NW, TW, N, MAXOPS>), dim3((n + 63) / 64), dim3(256), 0, 0, (const BlockItem*)items, n, (const u32*)ndev, n, (const u64*)frag, (const ulonglong2*)ck,
+        hipLaunchKernelGGL((k_rcwalk3<NW, TW, N, MAXOPS>), dim3((n + 63) / 64), dim3(128), 0, 0, (const BlockItem*)items, n, (const u32*)ndev, n, (const u64*)frag, (const ulonglong2*)ck,
                            (const u64*)hc, (const BlockResult*)res, (const ExtTask*)tasks, 0, 8, ops2, wout2, stats, errf, 1u, 0u, n, 0u);
         CHECK(hipDeviceSynchronize());
         std::vector<WalkOut> a(n), b(n);
@@ -110,14 +111,14 @@ int main(int argc, char** argv)
     };
     bool ok = same(nmax, 1); ok = same(nmax, 0) && ok; ok = same(1000, 0) && ok;
     auto run3 = [&](u32 n, int found, u32 opts, u32 lds, const char* what) {
-        ExtTask t; memset(&t, 0, sizeof t); t.found = found;
-        CHECK(hipMemcpy(tasks, &t, sizeof t, hipMemcpyHostToDevice));
+        ExtTask t[2]; memset(t, 0, sizeof t); t[0].found = found;
+        CHECK(hipMemcpy(tasks, t, sizeof t, hipMemcpyHostToDevice));
         const u32 c2[4] = {n, 0, 0, 0};
         CHECK(hipMemcpy(ndev, c2, 16, hipMemcpyHostToDevice));
         float best = 1e9f;
         for (int r = 0; r < 5; ++r) {
             CHECK(hipEventRecord(e0, 0));
-            hipLaunchKernelGGL((k_rcwalk3<NW, TW, N, MAXOPS>), dim3((n + 63) / 64), dim3(256), lds, 0, (const BlockItem*)items, n, (const u32*)ndev, n, (const u64*)frag, (const ulonglong2*)ck,
+            hipLaunchKernelGGL((k_rcwalk3<NW, TW, N, MAXOPS>), dim3((n + 63) / 64), dim3(128), lds, 0, (const BlockItem*)items, n, (const u32*)ndev, n, (const u64*)frag, (const ulonglong2*)ck,
                                (const u64*)hc, (const BlockResult*)res, (const ExtTask*)tasks, 0, 8, ops, wout, stats, errf, 1u, 0u, n, opts);
             CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -132,7 +133,8 @@ int main(int argc, char** argv)
     run3(nmax, 1, 8, 0, "lean, s_setprio 3");
     run3(nmax, 1, 16, 0, "lean, only the walking wave at s_setprio 3");
     run3(nmax, 1, 0, 0, "lean again");
-    run3(nmax, 1, 0, 4u << 10, "lean, 7 workgroups per CU (dynamic LDS)");
+    run3(nmax, 1, 0, 2u << 10, "lean, 8 workgroups per CU (dynamic LDS)");
+    run3(nmax, 1, 0, 4u << 10, "lean, 7 workgroups per CU");
     run3(nmax, 1, 0, 7u << 10, "lean, 6 workgroups per CU");
     run3(nmax, 1, 0, 12u << 10, "lean, 5 workgroups per CU");
     run3(nmax, 1, 0, 20u << 10, "lean, 4 workgroups per CU");
@@ -142,8 +144,8 @@ int main(int argc, char** argv)
     run3(16384, 1, 0, 0, "lean, one workgroup per CU");
     run3(64, 1, 0, 0, "lean, ONE workgroup");
     auto run = [&](u32 n, int found, u32 opts, u32 lds, const char* what) {
-        ExtTask t; memset(&t, 0, sizeof t); t.found = found;
-        CHECK(hipMemcpy(tasks, &t, sizeof t, hipMemcpyHostToDevice));
+        ExtTask t[2]; memset(t, 0, sizeof t); t[0].found = found;
+        CHECK(hipMemcpy(tasks, t, sizeof t, hipMemcpyHostToDevice));
         const u32 c2[4] = {n, 0, 0, 0};
         CHECK(hipMemcpy(ndev, c2, 16, hipMemcpyHostToDevice));
         float best = 1e9f;
