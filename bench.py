@@ -339,17 +339,27 @@ def config4_step(ctx, capi, synth, args):
     Per reference volume: the index build of a volume whose ~ 2 x 10^9 k-mer positions are nearly all distinct; per (reference, query) pair: one -j 0 and one
     -j 1 pass with OVLP_FAST_OPTIONS.  Records of this data set are checked against the reference binary's by tests/test_gpu_full_size.py[human_subset]."""
     G = args.config4_genome
-    rs = synth.simulate_reads(G, 2.0, seed=51)
-    ranges = synth.cut_ranges(rs, [2_000_000_000, 2_000_000_000] if G >= 1_000_000_000 else [int(0.67 * G)] * 2)
+    nvol_all = int(-(-30.0 * G // 2e9))          # 30x of the genome in oc2mkdb's 2 Gbp volumes
+    vols = []
+    vdir = os.environ.get("NECAT_CONFIG4_VOLS")         # volume files written earlier (tests/test_gpu_full_size.py[human_subset] with NECAT_TEST_KEEP_VOLS): no second generation
+    if vdir and os.path.exists(os.path.join(vdir, "volume_names.txt")):
+        names = [ln.rstrip("\n").split("\t") for ln in open(os.path.join(vdir, "volume_names.txt"))]
+        nreads = nbases = 0
+        sizes = []
+        for path, start, cnt in names:
+            v = ctx.load_volume(path)
+            vols.append((v, int(start))); nreads += int(cnt); nbases += v.nbases; sizes.append(v.nbases)
+    else:
+        rs = synth.simulate_reads(G, 2.0, seed=51)
+        ranges = synth.cut_ranges(rs, [2_000_000_000, 2_000_000_000] if G >= 1_000_000_000 else [int(0.67 * G)] * 2)
+        nreads, nbases, sizes = rs.nreads, rs.nbases, []
+        for a, b in ranges:
+            o0, o1 = int(rs.offsets[a]), int(rs.offsets[b - 1] + rs.sizes[b - 1])
+            vols.append((ctx.upload_volume(synth.pack_2bit(rs.codes[o0:o1]), o1 - o0, rs.offsets[a:b] - o0, rs.sizes[a:b]), a)); sizes.append(o1 - o0)
+        del rs
     res = {"workload": "%.2f Gb genome read at the 30x rate, the first %d of its oc2mkdb volumes (%d reads, %d bp: %s Gbp per volume = 2.0x of the genome; the whole project "
                        "would be %d volumes / %d pairs), OVLP_FAST_OPTIONS (-k %d -z 20 -q 500 -b 2000 -s 3 -n 500 -a 1000 -e 0.5)"
-                       % (G / 1e9, len(ranges), rs.nreads, rs.nbases, " / ".join("%.2f" % (float(rs.offsets[b - 1] + rs.sizes[b - 1] - rs.offsets[a]) / 1e9) for a, b in ranges),
-                          round(15 * G / 2e9 + 0.5), round(15 * G / 2e9 + 0.5) * (round(15 * G / 2e9 + 0.5) + 1) // 2, args.kmer)}
-    vols = []
-    for a, b in ranges:
-        o0, o1 = int(rs.offsets[a]), int(rs.offsets[b - 1] + rs.sizes[b - 1])
-        vols.append((ctx.upload_volume(synth.pack_2bit(rs.codes[o0:o1]), o1 - o0, rs.offsets[a:b] - o0, rs.sizes[a:b]), a))
-    del rs
+                       % (G / 1e9, len(vols), nreads, nbases, " / ".join("%.2f" % (x / 1e9) for x in sizes), nvol_all, nvol_all * (nvol_all + 1) // 2, args.kmer)}
     try:
         res["volumes"] = []
         for v, (ref, ref_start) in enumerate(vols):

@@ -90,6 +90,7 @@ u32 g_rc_fastb;        // NECAT_RC_FASTB (default 1): list B's checkpoint pass t
 u32 g_rc_dbg;          // NECAT_RC_DBG (timing only): 2 = k_rcwalk2w walks every segment twice (once into a sink), 4 = recomputes every segment twice
 u32 g_rc_prefetch;     // NECAT_RC_PREFETCH (default 0: measured 0.4 ms per step SLOWER, profiles/NOTES_r04.md 3): k_rcwalk2w loads the next segment's checkpoints / deltas / planes a segment ahead
 u32 g_rc_ww;           // NECAT_RC_WW (default 1; 2 until it wins in the bench and not only alone, profiles/NOTES_r05.md 1): 2 = the recompute walk as k_rcwalk3 (ext_rcwalk3.h: two waves recompute 64 blocks - two lanes per block, both words of the pair per lane - into 32-DIAGONAL records, one of them walks the blocks column by column); 1 = k_rcwalk2w (64-row records, one LDS read per walk step), 0 = k_rcwalk2 (every lane of a quad walks its block)
+u32 g_rc3_min;         // NECAT_RC3_MIN (blocks, default 160000; 4294967295 = never): with NECAT_RC_WW=1, list-A launches of at least this many blocks go through k_rcwalk3 (throughput form: fewer instructions per block, longer chain per segment) instead of k_rcwalk2w
 u32 g_rc_carry;        // NECAT_RC_CARRY (default 1): the recompute walk on an exact two-word window (k_myers_ck<CARRY> keeps the words' horizontal deltas, k_rcwalk2); 0 = the 4-word band window (k_rcwalk4)
 int g_rc_maxdist;      // NECAT_RC_MAXDIST (default and maximum kRcMaxDist = 160): full blocks of a larger distance take the old kernels (tests lower it)
 u32 g_walk_wave;       // NECAT_WALK_WAVE (default 12288; 0 = off): lists of at most this many blocks are walked by one WAVE per block through an LDS window (k_walk_wave, ext_tail.h)
@@ -101,7 +102,10 @@ template <int NW, int TW, int COLS, int MAXOPS, class... A>
 static void launch_rcwalk2(u32 nitems, hipStream_t s, A... a)
 {
     const u32 pr = ((NW == kWordsA ? (g_rc_prio & 1u) : NW == kWordsB ? (g_rc_prio & 4u) : 0u) ? 8u : 0u) | ((NW == kWordsA ? (g_rc_prio & 8u) : NW == kWordsB ? (g_rc_prio & 16u) : 0u) ? 16u : 0u);
-    if (g_rc_ww >= 2) hipLaunchKernelGGL((k_rcwalk3<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(128), 0, s, a..., pr);
+    // (k_rcwalk3's walking wave alone at raised priority where k_rcwalk2w raises every wave: 39.2 against 39.5 ms per step, tools/r05/run5.sh)
+    if (g_rc_ww == 1 && NW == kWordsA && nitems >= g_rc3_min) hipLaunchKernelGGL((k_rcwalk3<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(128), 0, s, a..., (pr & 8u) ? 16u : pr);
+    else if (g_rc_ww >= 3) hipLaunchKernelGGL((k_rcwalk3p<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(192), 0, s, a..., pr);
+    else if (g_rc_ww == 2) hipLaunchKernelGGL((k_rcwalk3<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(128), 0, s, a..., pr);
     else if (g_rc_ww) hipLaunchKernelGGL((k_rcwalk2w<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(256), 0, s, a..., g_rc_prefetch | g_rc_dbg | pr);
     else hipLaunchKernelGGL((k_rcwalk2<NW, TW, COLS, MAXOPS>), dim3((nitems + 15) / 16), dim3(64), 0, s, a...);
 }
@@ -120,6 +124,7 @@ void read_knobs()
     g_rc_carry = (u32)num("NECAT_RC_CARRY", 1);
     g_asm_rc = (u32)num("NECAT_ASM_RC", 1);
     g_rc_ww = (u32)num("NECAT_RC_WW", 1);
+    g_rc3_min = (u32)num("NECAT_RC3_MIN", 160000);
     g_rc_prefetch = (u32)num("NECAT_RC_PREFETCH", 0);
     g_rc_dbg = (u32)num("NECAT_RC_DBG", 0) & 6u;
     g_rc_fastb = (u32)num("NECAT_RC_FASTB", 1);

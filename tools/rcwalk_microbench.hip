@@ -82,6 +82,14 @@ int main(int argc, char** argv)
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     CHECK(hipFuncSetAttribute((const void*)k_rcwalk2w<NW, TW, N, MAXOPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
     CHECK(hipFuncSetAttribute((const void*)k_rcwalk3<NW, TW, N, MAXOPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
+    CHECK(hipFuncSetAttribute((const void*)k_rcwalk3p<NW, TW, N, MAXOPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
+    int kern = 4;            // 3: k_rcwalk3 (two waves per 64 blocks), 4: k_rcwalk3p (three waves, the two phases side by side)
+    auto launch3 = [&](u32 n, u32 lds, u8* o, WalkOut* w, u32 opts) {
+        if (kern == 4) hipLaunchKernelGGL((k_rcwalk3p<NW, TW, N, MAXOPS>), dim3((n + 63) / 64), dim3(192), lds, 0, (const BlockItem*)items, n, (const u32*)ndev, n, (const u64*)frag, (const ulonglong2*)ck,
+                                          (const u64*)hc, (const BlockResult*)res, (const ExtTask*)tasks, 0, 8, o, w, stats, errf, 1u, 0u, n, opts);
+        else hipLaunchKernelGGL((k_rcwalk3<NW, TW, N, MAXOPS>), dim3((n + 63) / 64), dim3(128), lds, 0, (const BlockItem*)items, n, (const u32*)ndev, n, (const u64*)frag, (const ulonglong2*)ck,
+                                (const u64*)hc, (const BlockResult*)res, (const ExtTask*)tasks, 0, 8, o, w, stats, errf, 1u, 0u, n, opts);
+    };
     WalkOut* wout2; u8* ops2;
     CHECK(hipMalloc(&wout2, (size_t)nmax * sizeof(WalkOut)));
     CHECK(hipMalloc(&ops2, (size_t)(nmax / 64) * MAXOPS * 64));
@@ -95,8 +103,7 @@ int main(int argc, char** argv)
         CHECK(hipMemset(ops, 0x7f, (size_t)(nmax / 64) * MAXOPS * 64)); CHECK(hipMemset(ops2, 0x7f, (size_t)(nmax / 64) * MAXOPS * 64));
         hipLaunchKernelGGL((k_rcwalk2w<NW, TW, N, MAXOPS>), dim3((n + 63) / 64), dim3(256), 0, 0, (const BlockItem*)items, n, (const u32*)ndev, n, (const u64*)frag, (const ulonglong2*)ck,
                            (const u64*)hc, (const BlockResult*)res, (const ExtTask*)tasks, 0, 8, ops, wout, stats, errf, 1u, 0u, n, 0u);
-        hipLaunchKernelGGL((k_rcwalk3<NW, TW, N, MAXOPS>), dim3((n + 63) / 64), dim3(128), 0, 0, (const BlockItem*)items, n, (const u32*)ndev, n, (const u64*)frag, (const ulonglong2*)ck,
-                           (const u64*)hc, (const BlockResult*)res, (const ExtTask*)tasks, 0, 8, ops2, wout2, stats, errf, 1u, 0u, n, 0u);
+        launch3(n, 0, ops2, wout2, 0u);
         CHECK(hipDeviceSynchronize());
         std::vector<WalkOut> a(n), b(n);
         CHECK(hipMemcpy(a.data(), wout, (size_t)n * sizeof(WalkOut), hipMemcpyDeviceToHost)); CHECK(hipMemcpy(b.data(), wout2, (size_t)n * sizeof(WalkOut), hipMemcpyDeviceToHost));
@@ -106,7 +113,7 @@ int main(int argc, char** argv)
         for (u32 x = 0; x < n; ++x) if (memcmp(&a[x], &b[x], sizeof(WalkOut))) { if (!bad_w) printf("  first WalkOut difference at block %u: n %d / %d, nmat %d / %d, hit %d / %d, acnt %d / %d\n", x, a[x].n, b[x].n, a[x].nmat, b[x].nmat, a[x].hit, b[x].hit, a[x].acnt, b[x].acnt); ++bad_w; }
         for (size_t i = 0; i < oa.size(); ++i) if (oa[i] != ob[i]) ++bad_o;
         int he = 0; CHECK(hipMemcpy(&he, errf, 4, hipMemcpyDeviceToHost));
-        printf("k_rcwalk3 == k_rcwalk2w on %u blocks (%s): %zu WalkOut records differ, %zu op bytes differ, err %d  %s\n", n, found ? "lean" : "ops kept", bad_w, bad_o, he, (bad_w || bad_o || he) ? "MISMATCH" : "ok");
+        printf("%s == k_rcwalk2w on %u blocks (%s): %zu WalkOut records differ, %zu op bytes differ, err %d  %s\n", kern == 4 ? "k_rcwalk3p" : "k_rcwalk3", n, found ? "lean" : "ops kept", bad_w, bad_o, he, (bad_w || bad_o || he) ? "MISMATCH" : "ok");
         return !(bad_w || bad_o || he);
     };
     bool ok = same(nmax, 1); ok = same(nmax, 0) && ok; ok = same(1000, 0) && ok;
@@ -118,16 +125,17 @@ int main(int argc, char** argv)
         float best = 1e9f;
         for (int r = 0; r < 5; ++r) {
             CHECK(hipEventRecord(e0, 0));
-            hipLaunchKernelGGL((k_rcwalk3<NW, TW, N, MAXOPS>), dim3((n + 63) / 64), dim3(128), lds, 0, (const BlockItem*)items, n, (const u32*)ndev, n, (const u64*)frag, (const ulonglong2*)ck,
-                               (const u64*)hc, (const BlockResult*)res, (const ExtTask*)tasks, 0, 8, ops, wout, stats, errf, 1u, 0u, n, opts);
+            launch3(n, lds, ops, wout, opts);
             CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
             if (r) best = std::min(best, ms);
         }
         int he = 0; CHECK(hipMemcpy(&he, errf, 4, hipMemcpyDeviceToHost));
         WalkOut w0; CHECK(hipMemcpy(&w0, wout, sizeof w0, hipMemcpyDeviceToHost));
-        printf("k_rcwalk3  %7u blocks (%4u workgroups) | %-58s | %8.1f us | %.2f ns per block | err %d, block 0: n %d nmat %d\n", n, (n + 63) / 64, what, best * 1e3, best * 1e6 / n, he, w0.n, w0.nmat);
+        printf("%-10s %7u blocks (%4u workgroups) | %-58s | %8.1f us | %.2f ns per block | err %d, block 0: n %d nmat %d\n", kern == 4 ? "k_rcwalk3p" : "k_rcwalk3", n, (n + 63) / 64, what, best * 1e3, best * 1e6 / n, he, w0.n, w0.nmat);
     };
+    for (kern = 4; kern >= 3; --kern) {
+    if (kern == 3) { ok = same(nmax, 1) && ok; ok = same(nmax, 0) && ok; }
     run3(nmax, 1, 0, 0, "lean");
     run3(nmax, 0, 0, 0, "ops kept");
     run3(nmax, 1, 8, 0, "lean, s_setprio 3");
@@ -143,6 +151,7 @@ int main(int argc, char** argv)
     run3(81920, 1, 0, 0, "lean, 5 workgroups per CU's worth");
     run3(16384, 1, 0, 0, "lean, one workgroup per CU");
     run3(64, 1, 0, 0, "lean, ONE workgroup");
+    }
     auto run = [&](u32 n, int found, u32 opts, u32 lds, const char* what) {
         ExtTask t[2]; memset(t, 0, sizeof t); t[0].found = found;
         CHECK(hipMemcpy(tasks, t, sizeof t, hipMemcpyHostToDevice));
