@@ -821,11 +821,12 @@ def roofline_report(agg):
     # HBM bytes per launch of the two kernels `frac` is about, each on its own (FETCH_SIZE counted twice per the guide's gfx950 correction + WRITE_SIZE):
     # measured by this run's own rocprofv3 --pmc passes (pmc_live) unless `traffic_source` says otherwise
     per = pmc_kernel_bytes(["necat::k_myers_ck<8", "necat::k_rcwalk3<8", "necat::k_rcwalk2w<8", "necat::k_rcwalk2<8"])
-    traffic = {}
-    for q, (bts, n) in per.items():
+    acc = {}
+    for q, (bts, n) in per.items():         # (the walk of a list-A launch is k_rcwalk3 or k_rcwalk2w by its size: one launch-weighted average over both)
         short = "k_myers_ck" if "k_myers_ck" in q else "k_rcwalk"
-        traffic[short] = round(traffic.get(short, 0.0) + bts, 1)
-    traffic = traffic or None
+        b0, n0 = acc.get(short, (0.0, 0))
+        acc[short] = (b0 + bts * n, n0 + n)
+    traffic = {k: round(b / max(1, n), 1) for k, (b, n) in acc.items()} or None
     traffic_pair = sum(traffic.values()) if traffic else None
     words, band = float(agg["words"]), float(agg["band_words"])
     all_ms = agg["myers_ms"] + agg["rc_ms"] + agg["fused_ms"]
@@ -926,6 +927,7 @@ def main():
             raise SystemExit("bench.py: ranks on distinct devices but the data path is %s, not rccl" % comm.transport())
 
     ix_info = {}
+    sh_ix_mode = [0, 0.0, 0.0]
 
     def step(job=args.job):
         o = opt if job == args.job else capi.default_options(**dict(opt_kw, job=job, num_threads=1))
@@ -933,6 +935,7 @@ def main():
             ix = ctx.build_index_sharded(comm, vol, o.kmer_size, o.kmer_cnt_cutoff)
             t_index = ctx.timings().index_ms
             sh_ix = ctx.shard_timings()
+            sh_ix_mode[:] = [sh_ix.index_sharded, sh_ix.index_plan_replicate_ms, sh_ix.index_plan_shard_ms]
             if job == 1:
                 m4, _, _ = ctx.map_pair_sharded(comm, ix, vol, vol, 0, 0, o, True, 1, args.chunk_reads, 0)
                 cands = None
@@ -975,6 +978,7 @@ def main():
         agg_add(agg, tm, t_index)
         if sh is not None:
             agg["ix_local_ms"] += sh.index_local_ms; agg["ix_xchg_ms"] += sh.index_exchange_ms; agg["ix_xchg_bytes"] += sh.index_exchange_bytes
+            agg["ix_sharded"] = int(sh_ix_mode[0]); agg["ix_plan"] = (sh_ix_mode[1], sh_ix_mode[2])
             agg["gather_ms"] += sh.gather_ms; agg["gather_bytes"] += sh.gather_bytes; agg["reads_local"] = int(sh.reads_local)
     barrier_sync(dist, local)
     elapsed = time.perf_counter() - t0
@@ -1003,7 +1007,8 @@ def main():
         "rank": rank, "transport": transport, "query_reads": agg["reads_local"], "index_local_ms": round(agg["ix_local_ms"] / K0, 3),
         "index_allgather_ms": round(agg["ix_xchg_ms"] / K0, 3), "index_allgather_bytes": int(agg["ix_xchg_bytes"] // K0),
         "record_gather_ms": round(agg["gather_ms"] / K0, 3), "record_gather_bytes": int(agg["gather_bytes"] // K0),
-        "seed_ms": round(agg["seed_ms"] / K0, 2), "extend_ms": round(agg["extend_ms"] / K0, 2)}) if single else None
+        "seed_ms": round(agg["seed_ms"] / K0, 2), "extend_ms": round(agg["extend_ms"] / K0, 2),
+        "index_sharded": int(agg.get("ix_sharded", 0))}) if single else None
     if rank != 0:
         if comm is not None:
             comm.close()
@@ -1013,10 +1018,13 @@ def main():
     if single and os.environ.get("NECAT_BENCH_ONE_DEVICE") != "1" and args.transport in ("auto", "rccl"):
         # ranks on distinct devices: the line is only worth printing if the data path really was RCCL over the links and every rank received
         # its peers' index slices - otherwise fail loudly instead of reporting a number measured on some other path
-        bad = [r for r in per_rank if r.get("transport") != "rccl" or not r.get("index_allgather_bytes")]
+        # (a replicated index build - necat_index_plan's choice for small volumes - exchanges nothing: the records' gather on rank 0 is then the evidence)
+        bad = [r for r in per_rank if r.get("transport") != "rccl" or (r.get("index_sharded") and not r.get("index_allgather_bytes"))]
+        if not bad and not per_rank[0].get("record_gather_bytes"):
+            bad = [per_rank[0]]
         if bad:
-            raise SystemExit("bench.py: N = %d on distinct devices, but rank(s) %s did not run the RCCL data path (transport / index all-gather bytes: %s)"
-                             % (world, [r.get("rank") for r in bad], [(r.get("transport"), r.get("index_allgather_bytes")) for r in bad]))
+            raise SystemExit("bench.py: N = %d on distinct devices, but rank(s) %s did not run the RCCL data path (transport / index all-gather bytes / record gather bytes: %s)"
+                             % (world, [r.get("rank") for r in bad], [(r.get("transport"), r.get("index_allgather_bytes"), r.get("record_gather_bytes")) for r in bad]))
     K = max(1, args.steps)
     pmc_select(args, world)
     roofline = roofline_report(agg)
@@ -1047,7 +1055,11 @@ def main():
         out["roofline_seed"] = roofline_seed(agg, K)
     out.update(extras)
     if single:
-        out["multi_gpu"] = {"transport": transport, "rank0_index_local_ms": round(agg["ix_local_ms"] / K, 3),
+        out["multi_gpu"] = {"transport": transport,
+                            "index_mode": "hash-range slices + all-gather" if agg.get("ix_sharded") else "replicated: every rank builds the whole table, no exchange (necat_index_plan)",
+                            "index_plan": {"replicate_ms": round(agg.get("ix_plan", (0, 0))[0], 3), "shard_ms": round(agg.get("ix_plan", (0, 0))[1], 3),
+                                           "note": "the cost model's two prices for this volume on this many ranks (include/necat_hip.h: necat_index_plan); NECAT_INDEX_SHARD=0/1 overrides"},
+                            "rank0_index_local_ms": round(agg["ix_local_ms"] / K, 3),
                             "rank0_index_allgather_ms": round(agg["ix_xchg_ms"] / K, 3),
                             "rank0_index_allgather_bytes": int(agg["ix_xchg_bytes"] // K),
                             "rank0_record_gather_ms": round(agg["gather_ms"] / K, 3), "rank0_record_gather_bytes": int(agg["gather_bytes"] // K),

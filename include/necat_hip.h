@@ -386,8 +386,29 @@ typedef struct {
     double   gather_ms;          /* gather-v of the records on the root (wall) */
     uint64_t gather_bytes;
     uint64_t reads_local;        /* query reads this rank processed */
+    /* how the last necat_index_build_sharded built its index: 1 = hash-range slices + all-gather, 0 = every rank built the whole table (no
+     * exchange), and the two costs necat_index_plan priced for it */
+    uint64_t index_sharded;
+    double   index_plan_replicate_ms, index_plan_shard_ms;
 } necat_shard_timings;
 int  necat_get_shard_timings(const necat_ctx* ctx, necat_shard_timings* t);
+
+/* The cost model behind necat_index_build_sharded's choice (no reference counterpart: build_lookup_table, lookup_table.c:149, is one thread).
+ * SURVEY 8e's sharded build was specified against a 66 s CPU build; on the device ONE rank builds an E. coli-size table in 5 ms, so slicing the build
+ * pays only when (build time saved) > (time to move the other ranks' slices over the links):
+ *     replicate_ms = (scan + work) nbases
+ *     shard_ms     = scan nbases + work nbases / nranks + 3 exchanges' latency + bytes / nranks / link rate
+ * with scan = the passes every rank makes over ALL bases (k_part_hist, k_split_bases), work = the passes that shrink with the rank's hash range
+ * (both measured on MI355X: 6.0 / 22.3 ps per base - 5.2 ms at 184 Mbp, 58 ms at 2.0 Gbp), bytes = the sparse table words + 8 per distinct k-mer +
+ * 8 per offset, every peer's slice on its own xGMI link (direct all-pairs groups).  link_gbs <= 0: NECAT_XGMI_GBS or 100 (of a link's nominal 153).
+ * NECAT_INDEX_SHARD=0 / 1 overrides the choice (tests run both); every rank computes the same plan from the same arguments. */
+typedef struct {
+    int32_t  shard;              /* 1: slices + all-gather is the cheaper plan */
+    int32_t  _pad;
+    double   replicate_ms, shard_ms, exchange_ms;
+    uint64_t exchange_bytes;     /* all ranks' slices together */
+} necat_index_plan_t;
+int  necat_index_plan(uint64_t nbases, int kmer_size, int nranks, double link_gbs, necat_index_plan_t* out);
 
 /* Test hook: runs the RCCL transport's call path (librccl opened at run time, communicator, send/recv group on the context's
  * stream) with ONE rank sending `bytes` bytes to itself, and compares them. */

@@ -43,7 +43,14 @@ class Timings(C.Structure):
 class ShardTimings(C.Structure):
     """necat_shard_timings"""
     _fields_ = [("index_local_ms", C.c_double), ("index_exchange_ms", C.c_double), ("index_exchange_bytes", C.c_uint64),
-                ("gather_ms", C.c_double), ("gather_bytes", C.c_uint64), ("reads_local", C.c_uint64)]
+                ("gather_ms", C.c_double), ("gather_bytes", C.c_uint64), ("reads_local", C.c_uint64),
+                ("index_sharded", C.c_uint64), ("index_plan_replicate_ms", C.c_double), ("index_plan_shard_ms", C.c_double)]
+
+
+class IndexPlan(C.Structure):
+    """necat_index_plan_t"""
+    _fields_ = [("shard", C.c_int32), ("_pad", C.c_int32), ("replicate_ms", C.c_double), ("shard_ms", C.c_double), ("exchange_ms", C.c_double),
+                ("exchange_bytes", C.c_uint64)]
 
 
 HOST_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -87,7 +94,7 @@ EXPORTED_SYMBOLS = [
     "necat_cns_result_free",
     "necat_edlib_align_batch", "necat_get_timings", "necat_free", "necat_pcan_partition",
     "necat_comm_create", "necat_comm_destroy", "necat_comm_transport", "necat_get_shard_timings", "necat_comm_selftest_rccl", "necat_comm_selftest_rccl2",
-    "necat_index_build_sharded", "necat_find_candidates_sharded", "necat_map_pair_sharded",
+    "necat_index_build_sharded", "necat_index_plan", "necat_find_candidates_sharded", "necat_map_pair_sharded",
     "necat_pair_schedule", "necat_pair_chunk_reads", "necat_find_candidates_part", "necat_map_pair_part",
 ]
 
@@ -156,6 +163,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.necat_comm_transport.argtypes = [vp, C.c_char_p, C.c_size_t]
     lib.necat_get_shard_timings.argtypes = [vp, C.POINTER(ShardTimings)]
     lib.necat_index_build_sharded.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.necat_index_plan.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_double, C.POINTER(IndexPlan)]
     lib.necat_find_candidates_sharded.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(MapOptions), C.c_int, C.c_int,
                                                   C.POINTER(vp), u64p, u64p]
     lib.necat_map_pair_sharded.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(MapOptions), C.c_int, C.c_int, C.c_int,
@@ -172,6 +180,15 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         getattr(lib, name)
     _lib = lib
     return lib
+
+
+def index_plan(nbases: int, k: int, nranks: int, link_gbs: float = 0.0) -> IndexPlan:
+    """necat_index_plan: what a `nranks`-rank build of a volume's index costs either way (no device needed)"""
+    p = IndexPlan()
+    rc = load_library().necat_index_plan(nbases, k, nranks, link_gbs, C.byref(p))
+    if rc:
+        raise NecatError("necat_index_plan: %d" % rc)
+    return p
 
 
 def default_options(**kw) -> MapOptions:

@@ -415,6 +415,24 @@ int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, in
     return index_build_impl(ctx, nullptr, ref, kmer_size, max_occ, out);
 }
 
+int necat_index_plan(uint64_t nbases, int kmer_size, int nranks, double link_gbs, necat_index_plan_t* out)
+{
+    if (!out || kmer_size < 1 || kmer_size > 15 || nranks < 1) return NECAT_ERR_ARG;
+    if (link_gbs <= 0) { const char* e = getenv("NECAT_XGMI_GBS"); link_gbs = e && atof(e) > 0 ? atof(e) : 100.0; }
+    const double N = (double)nbases, T = (double)(1ULL << (2 * kmer_size));
+    const double scan_ms = 5.98e-9 * N, work_ms = 22.3e-9 * N;                    // (1.1 + 4.1 ms at 184 Mbp; 58 ms at 2.0 Gbp: profiles/r04_kernel_stats.md, r05_config4_human_subset.json)
+    const double distinct = T * (1.0 - exp(-N / T));                              // non-zero table entries of N uniformly drawn k-mers (an upper bound for real reads)
+    const double bytes = T / 64.0 * 16.0 + 8.0 * distinct + 8.0 * N;
+    out->_pad = 0;
+    out->replicate_ms = scan_ms + work_ms;
+    out->exchange_bytes = (uint64_t)bytes;
+    out->exchange_ms = nranks > 1 ? 3 * 0.05 + bytes / nranks / (link_gbs * 1e6) : 0.0;
+    out->shard_ms = scan_ms + work_ms / nranks + out->exchange_ms;
+    out->shard = nranks > 1 && out->shard_ms < out->replicate_ms;
+    if (const char* e = getenv("NECAT_INDEX_SHARD")) out->shard = nranks > 1 && atoi(e) != 0;
+    return NECAT_OK;
+}
+
 int necat_index_build_sharded(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, int kmer_size, int max_occ, necat_index** out)
 {
     if (!comm) return NECAT_ERR_ARG;
@@ -460,7 +478,12 @@ int index_build_body(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
     // hash-range sharding: rank g owns buckets [g NB / G, (g + 1) NB / G) = table entries [that << pshift); small tables
     // (k < 11) and the global-atomic fallback are built whole on every rank
     const int G = comm ? comm->nranks : 1, rk = comm ? comm->rank : 0;
-    const bool sharded = G > 1 && lds_slices && NB >= (u32)G;
+    // slices + all-gather only where that is the cheaper plan (necat_index_plan): one rank builds an E. coli-size table in 5 ms, the all-gather of its
+    // 3.3 GB takes longer than that for every N <= 4 - there every rank builds the whole table and nothing is exchanged
+    necat_index_plan_t plan; plan.shard = 0; plan.replicate_ms = plan.shard_ms = 0;
+    if (G > 1) (void)necat_index_plan(ref->nbases, kmer_size, G, 0.0, &plan);
+    const bool sharded = G > 1 && lds_slices && NB >= (u32)G && plan.shard;
+    ctx->shard_tm.index_sharded = sharded ? 1 : 0; ctx->shard_tm.index_plan_replicate_ms = plan.replicate_ms; ctx->shard_tm.index_plan_shard_ms = plan.shard_ms;
     const u32 b_lo = sharded ? (u32)((u64)rk * NB / G) : 0u, b_hi = sharded ? (u32)((u64)(rk + 1) * NB / G) : NB;
     ctx->shard_tm.index_local_ms = 0; ctx->shard_tm.index_exchange_ms = 0; ctx->shard_tm.index_exchange_bytes = 0;
     // A sharded build is a sequence of collective steps.  Whatever fails on ONE rank between two of them (an allocation, a launch)

@@ -80,13 +80,19 @@ def test_bench_gpus_2_runs_two_ranks_and_the_same_records(built):
     """`python bench.py --gpus 2` with no launcher around it: the script starts its own two ranks (NECAT_BENCH_ONE_DEVICE: both on
     device 0, so the records travel by HIP IPC) and reports the record count of the 1-rank run"""
     one = _bench(SMALL + ["--gpus", "1"])
-    two = _bench(SMALL + ["--gpus", "2"], env={"NECAT_BENCH_ONE_DEVICE": "1"})
+    two = _bench(SMALL + ["--gpus", "2"], env={"NECAT_BENCH_ONE_DEVICE": "1", "NECAT_INDEX_SHARD": "1"})      # (the index in hash-range slices + all-gather, whatever the plan says for a volume this small)
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
     assert two["config"]["overlaps_per_step"] == one["config"]["overlaps_per_step"] > 500
     assert two["scaling"] == "strong" and two["multi_gpu"]["transport"] == "ipc"
     ranks = two["multi_gpu"]["ranks"]
     assert [r["rank"] for r in ranks] == [0, 1] and all(r["query_reads"] > 0 and r["index_allgather_bytes"] > 0 for r in ranks)
     assert "roofline" in two and "roofline" in one
+    assert two["multi_gpu"]["index_mode"] == "hash-range slices + all-gather"
+    # the plan's own choice for a 4.8 Mbp volume on two ranks: every rank builds the whole table, nothing is exchanged - same records
+    rep = _bench(SMALL + ["--gpus", "2"], env={"NECAT_BENCH_ONE_DEVICE": "1"})
+    assert rep["config"]["overlaps_per_step"] == one["config"]["overlaps_per_step"]
+    assert rep["multi_gpu"]["index_mode"].startswith("replicated") and all(r["index_allgather_bytes"] == 0 for r in rep["multi_gpu"]["ranks"])
+    assert rep["multi_gpu"]["index_plan"]["replicate_ms"] < rep["multi_gpu"]["index_plan"]["shard_ms"]
 
 
 @pytest.mark.parametrize("job", [1, 0])
@@ -101,7 +107,7 @@ def test_bench_pairs_mode_records_equal_the_oracle(built, tmp_path, job):
     want = _oracle_all_volumes(d, 3, kw, tmp_path, job)
     for world in (1, 2):
         pre = os.path.join(str(tmp_path), "recs_w%d" % world)
-        out = _bench(base + ["--gpus", str(world), "--dump-records", pre], env={"NECAT_BENCH_ONE_DEVICE": "1"} if world > 1 else None)
+        out = _bench(base + ["--gpus", str(world), "--dump-records", pre], env={"NECAT_BENCH_ONE_DEVICE": "1", "NECAT_INDEX_SHARD": "1"} if world > 1 else None)
         assert out["n_gpus"] == world and out["config"]["overlaps_per_step"] == len(want) > 500
         got = []
         per_rank = []

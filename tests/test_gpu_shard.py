@@ -18,11 +18,16 @@ pytestmark = pytest.mark.gpu
 WORKER = os.path.join(util.ROOT, "tests", "tools", "shard_worker.py")
 
 
-def _run_ranks(nranks, vdir, tmp, k, z, chunk=16):
-    xdir = os.path.join(str(tmp), "xchg_%d_%d" % (nranks, k))
+def _run_ranks(nranks, vdir, tmp, k, z, chunk=16, shard="1"):
+    # shard: NECAT_INDEX_SHARD - "1" hash-range slices + all-gather, "0" every rank builds the whole table (what necat_index_plan picks for a volume
+    # this small, and for E. coli / yeast at N <= 4), "" the plan's own choice
+    xdir = os.path.join(str(tmp), "xchg_%d_%d_%s" % (nranks, k, shard))
     os.makedirs(xdir)
-    prefix = os.path.join(str(tmp), "r%d_k%d" % (nranks, k))
+    prefix = os.path.join(str(tmp), "r%d_k%d_%s" % (nranks, k, shard))
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SHARD_CHUNK=str(chunk))
+    env.pop("NECAT_INDEX_SHARD", None)
+    if shard != "":
+        env["NECAT_INDEX_SHARD"] = shard
     procs = [subprocess.Popen([sys.executable, WORKER, str(r), str(nranks), "0", vdir, xdir, prefix, str(k), str(z), "auto"],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(nranks)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -37,12 +42,12 @@ def data(tmp_path_factory):
     return d, rs
 
 
-@pytest.mark.parametrize("nranks,k", [(2, 13), (3, 12)])
-def test_sharded_run_equals_single_rank(ctx, data, tmp_path, nranks, k):
+@pytest.mark.parametrize("nranks,k,shard", [(2, 13, "1"), (3, 12, "1"), (2, 13, "0"), (3, 12, "")])
+def test_sharded_run_equals_single_rank(ctx, data, tmp_path, nranks, k, shard):
     from necat_amd import capi
     d, rs = data
     kw = dict(util.FAST, kmer_size=k)
-    prefix = _run_ranks(nranks, d, tmp_path, k, kw["scan_window"])
+    prefix = _run_ranks(nranks, d, tmp_path, k, kw["scan_window"], shard=shard)
     # ---- the gathered index: complete and identical on every rank, equal to the oracle's
     ostats, ooffs = ora.build_index(os.path.join(d, "vol0"), k, kw["kmer_cnt_cutoff"])
     for r in range(nranks):
@@ -50,7 +55,10 @@ def test_sharded_run_equals_single_rank(ctx, data, tmp_path, nranks, k):
         assert np.array_equal(np.load(prefix + "_offs_%d.npy" % r), ooffs), "offset_list of rank %d" % r
     infos = [json.load(open(prefix + "_info_%d.json" % r)) for r in range(nranks)]
     assert all(i["transport"] == "ipc" for i in infos)                       # the ranks share device 0
-    assert all(i["index_exchange_bytes"] > 0 for i in infos)
+    if shard == "1":
+        assert all(i["index_exchange_bytes"] > 0 and i["index_sharded"] == 1 for i in infos)
+    else:       # replicate mode (forced, or the plan's choice for a 2.7 Mbp volume): no rank received a byte of index
+        assert all(i["index_exchange_bytes"] == 0 and i["index_sharded"] == 0 for i in infos)
     assert sum(i["reads_local"] for i in infos) == rs.nreads
     assert min(i["reads_local"] for i in infos) > 0
     # ---- records: rank 0 holds everybody's, equal to the single-rank run

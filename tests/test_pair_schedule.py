@@ -78,3 +78,26 @@ def test_bench_refuses_a_world_that_is_not_gpus():
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(util.ROOT, "bench.py"), "--gpus", "8", "--steps", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
     assert r.returncode != 0 and "--gpus 8" in r.stderr and r.stdout.strip() == ""
+
+
+def test_index_plan_replicates_small_volumes_and_shards_big_ones_on_many_ranks(built, monkeypatch):
+    """necat_index_plan (include/necat_hip.h), the cost model behind necat_index_build_sharded's choice: one rank builds an E. coli-size table in
+    5 ms while the all-gather of its 3.3 GB takes longer for every N <= 4 - there every rank builds the whole table; a volume at oc2mkdb's 2 Gbp
+    cut on 8 ranks is cheaper in hash-range slices.  Host arithmetic only: runs without a device."""
+    from necat_amd import capi
+    monkeypatch.delenv("NECAT_INDEX_SHARD", raising=False)
+    monkeypatch.delenv("NECAT_XGMI_GBS", raising=False)
+    ecoli, big = 184_010_740, 2_000_000_000
+    p1 = capi.index_plan(ecoli, 15, 1)
+    assert p1.shard == 0 and abs(p1.replicate_ms - 5.2) < 0.3 and p1.exchange_ms == 0.0
+    for n in (2, 4):
+        p = capi.index_plan(ecoli, 15, n)
+        assert p.shard == 0 and p.shard_ms > p.replicate_ms and 3.0e9 < p.exchange_bytes < 3.6e9
+    assert capi.index_plan(big, 15, 8).shard == 1 and capi.index_plan(big, 15, 2).shard == 0
+    assert abs(capi.index_plan(big, 15, 1).replicate_ms - 58.0) < 3.0          # measured: 58 ms (profiles/r05_config4_human_subset.json)
+    # a faster link moves the break-even; the environment overrides the choice
+    assert capi.index_plan(ecoli, 15, 8, 400.0).shard == 1 and capi.index_plan(ecoli, 15, 8, 50.0).shard == 0
+    monkeypatch.setenv("NECAT_INDEX_SHARD", "1")
+    assert capi.index_plan(ecoli, 15, 2).shard == 1 and capi.index_plan(ecoli, 15, 1).shard == 0
+    monkeypatch.setenv("NECAT_INDEX_SHARD", "0")
+    assert capi.index_plan(big, 15, 8).shard == 0

@@ -26,7 +26,7 @@ def main():
     ix = ctx.build_index_sharded(comm, vol, k, kw["kmer_cnt_cutoff"])
     st = ctx.shard_timings()
     info = {"transport": comm.transport(), "index_exchange_bytes": int(st.index_exchange_bytes), "index_exchange_ms": st.index_exchange_ms,
-            "index_local_ms": st.index_local_ms}
+            "index_local_ms": st.index_local_ms, "index_sharded": int(st.index_sharded)}
     if k <= 13:                              # every rank must hold the COMPLETE index
         stats, offs = ix.download()
         np.save(prefix + "_stats_%d.npy" % rank, stats)
