@@ -1,20 +1,20 @@
 // asm_coop.h - the block aligner of oc2asmpm (blockwise_edlib_align, asm_pm/blockwise_edlib.c:1205-1371 = onc_align with 2048-bp blocks, tail
 // match length 8; called by hbn_map_extend, asm_pm/hbn_align.c:282-326) through the extension stage's own machinery at a bigger geometry:
 //
-//   every (read, subject strand, anchor) triple is an ExtTask that advances one block per ROUND (ext_plan<2048>); a round is
-//   k_ext_frag<44, 88>           fragments of every scheduled block from the 2-bit volumes (the subject on either strand)
-//   k_myers_coop<44, 88, .., 64> the cooperative, register-resident DP of the 512-bp stage: lane b of the wave owns 64-row word b of ONE block
-//                                (a full 2048 x 2048 block has 32 words, the longest last block - (2048 + 99) x 1.3 = 2791 - has 44), anti-diagonal
-//                                wavefront, the carry between words by DPP wave_shr:1, target bit-planes staged in LDS, SHW pass then NW pass whose
-//                                band records are stored only for the words the walk can reach (the reference's own band tests with k = the
-//                                block's distance)
-//   k_traceback<44, 88, ..>      the walk (up > left > diagonal), the tail trimmed at the last run of 8 matches, the kept columns appended to the
-//                                task's 2-bit column stream, the next block planned and appended to the next round's list
+//   every (read, subject strand, anchor) triple is an ExtTask that advances one block per ROUND (ext_plan<2048>); a round is (necat_asm_align_batch, necat_hip.hip)
+//   k_ext_frag<32 | 44, ..>      fragments of every scheduled block from the 2-bit volumes (the subject on either strand)
+//   k_myers_ckg<32 | 44, ..>     ONE DP pass (ext_rcwalk.h): lane b of the wave owns 64-row word b of a block (32 lanes per block up to 2048 x 2048, a whole wave for
+//                                the longer last blocks - (2048 + 99) x 1.3 = 2791 bases, 44 words), anti-diagonal wavefront, carries by DPP; it keeps every word's
+//                                (Pv, Mv) after every 16th column and the words' horizontal deltas - no NW pass, no band records
+//   k_rcwalk2w<32 | 44, ..>      the walk, which recomputes the two words it stands on from those checkpoints (up > left > diagonal)
+//   k_traceback<.., WALK = 5>    the tail trimmed at the last run of 8 matches, the kept columns appended to the task's 2-bit column stream, the next block
+//                                planned and appended to the next round's list
 //   and after the last round k_ext_alignment / k_ext_strings give every anchor's coordinates, identity and alignment columns - exactly the outputs
 //   of necat_onc_align_batch.
-// Two lists per round as in the 512-bp stage (A: blocks up to 2048 x 2048 - 32 words, 32 lanes per block; B: the longer last blocks - 44 words, one
-// block per wave), rounds synchronous on the host - a corrected read is 3 - 5 blocks long, so a call is a handful of rounds.  The lane-per-alignment kernel this replaces (k_asm_align, asm_kernels.h: 512 registers + scratch per lane,
-// a 126 MB band slab per wave, one wave per SIMD) stays as the second implementation the tests compare with (NECAT_ASM_LANE=1).
+// Two lists per round as in the 512-bp stage (A: blocks up to 2048 x 2048; B: the longer last blocks), rounds synchronous on the host - a corrected read is
+// 3 - 5 blocks long, so a call is a handful of rounds.  NECAT_ASM_RC=0 runs the round-3 form instead - k_myers_coop (below: SHW pass + NW pass with band
+// records) and the band walk - and NECAT_ASM_LANE=1 the lane-per-alignment kernel of round 2 (k_asm_align, asm_kernels.h): the two older implementations
+// the tests compare with.
 #pragma once
 #include "asm_kernels.h"
 #include "ext_kernels.h"

@@ -152,11 +152,7 @@ NECAT_D u32 fast_shw8_ckp(const int b, const u64* __restrict__ tw, const u64 nlo
     };
     // ckr / hcr: the slots of the window's first column (two checkpoints, one delta word per window)
     ulonglong2* ckr = ck; u64* hcr = hc;
-#if defined(NECAT_CK_MV) && (NECAT_CK_MV == 5 || NECAT_CK_MV == 7 || NECAT_CK_MV == 8 || NECAT_CK_MV == 10)
-    for (int s0 = 0; s0 < (NECAT_CK_MV == 5 ? kSteps / 2 : NECAT_CK_MV == 8 ? 32 : 0); s0 += 32, ckr += 2 * ST, hcr += ST) {
-#else
     for (int s0 = 0; s0 < kSteps; s0 += 32, ckr += 2 * ST, hcr += ST) {
-#endif
         {
             const u64 x = (s0 >> 5) < TW ? tw[s0 >> 5] : 0ULL;
             const u32 xl = (u32)x, xh = (u32)(x >> 32);
@@ -194,9 +190,6 @@ NECAT_D u32 fast_shw8_ckp(const int b, const u64* __restrict__ tw, const u64 nlo
     }
     // ---- the bottom row: word 7's deltas, 64 columns per lane.  (The stores above and these loads are by lanes of ONE wave: made visible
     // by a workgroup-scope release / acquire - no cache maintenance on gfx950, the CU's vector cache is coherent for its own wavefronts.)
-#if defined(NECAT_CK_MV) && NECAT_CK_MV == 6
-    return (u32)(w.Pv ^ w.Mv ^ hp ^ hm);
-#endif
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const u64* hb = hc + (G - 1 - b) * (ST / G);                      // slot m of word 7: hb[m * ST]
@@ -366,11 +359,7 @@ k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u
     unsigned long long wsum = owner ? (unsigned long long)(nblk * tn) : 0ULL, bsum = owner ? (unsigned long long)(qn + tn) : 0ULL;
     if (ragged) for (int o = 32; o > 0; o >>= 1) { wsum += __shfl_xor(wsum, o); bsum += __shfl_xor(bsum, o); }
     else { wsum = (unsigned long long)popc64(m_all) * (unsigned long long)(NW * N); bsum = (unsigned long long)popc64(m_all) * (unsigned long long)(2 * N); }
-#if defined(NECAT_CK_MV) && (NECAT_CK_MV == 9 || NECAT_CK_MV == 10)
-    if (lane == 0 && m_all && wsum == 12345) {
-#else
     if (lane == 0 && m_all) {
-#endif
         stat_add(stats, 0, wsum); stat_add(stats, 1, bsum);
         if (m_walk) stat_add(stats, 3, (unsigned long long)popc64(m_walk));           // blocks the recomputing walk will take
     }
@@ -843,7 +832,7 @@ k_rcwalk2w(const BlockItem* __restrict__ items, u32 n_host, const u32* __restric
 #else
     const bool pf = (opts & 1u) != 0;                                 // prefetch the next segment's inputs (NECAT_RC_PREFETCH)
 #endif
-    if (opts & 8u) __builtin_amdgcn_s_setprio(3);                     // (NECAT_RC_PIPE: beside the checkpoint pass of the next piece, whose 8 waves per SIMD would otherwise take 8 of 9 issue slots)
+    if (opts & 8u) __builtin_amdgcn_s_setprio(3);                     // (NECAT_RC_PRIO bits 1 / 4: every wave of this launch above the other streams' kernels; bits 8 / 16 -> opts 16: the walker only, below)
     __shared__ ulonglong2 slices[SEG][64];
     const ListView lv = list_view(n_host, n_dev, capA);
     const bool all = ((epoch >> 27) & 1u) != 0, ragged = ((epoch >> 26) & 1u) != 0;

@@ -26,6 +26,25 @@ NECAT_D u64 kmer_hash_at(const u64* bases, i64 g, int k)
     return rev2(load32(bases, g)) >> (64 - 2 * k);
 }
 
+// the 16 consecutive positions a thread of the streaming passes hashes (g0 a multiple of 16, k <= 15: the last k-mer ends at base g0 + 29) share ONE
+// 32-base window: reversed once, every position's hash is two shifts of it (the passes were bound by hashing: ~ 95 instructions per position)
+NECAT_D u64 kmer_window16(const u64* bases, i64 g0) { return rev2(load32(bases, g0)); }
+NECAT_D u64 kmer_hash_win(u64 win, int i, int k) { return (win << (2 * i)) >> (64 - 2 * k); }
+
+// seq_of_offset for the threads of a block whose positions lie in [p_first, p_last]: two lanes search the whole volume once, everybody else only the
+// few reads that range spans (a thread of the streaming passes used to run its own 15-step search of dependent loads for every 16 positions it hashes)
+NECAT_D void block_read_range(const DevVolume& vol, u64 p_first, u64 p_last, u64* s_range)
+{
+    if (threadIdx.x < 2) s_range[threadIdx.x] = seq_of_offset(vol.seq_off, vol.nseq, threadIdx.x ? p_last : p_first);
+    __syncthreads();
+}
+NECAT_D u64 seq_of_offset_in(const u64* seq_off, u64 lo, u64 hi_incl, u64 g)      // seq_off[lo] <= g < seq_off[hi_incl + 1]
+{
+    u64 hi = hi_incl + 1;
+    while (hi - lo > 1) { const u64 mid = (lo + hi) >> 1; if (seq_off[mid] <= g) lo = mid; else hi = mid; }
+    return lo;
+}
+
 // MODE 0: count occurrences.  MODE 1: scatter offsets into bucket slots; cnt32[h] then holds the
 // bucket's END cursor (start + count; 0 for k-mers dropped by the occurrence cutoff), so one atomic
 // both tests the k-mer and yields its slot - no second random read of kmer_stats.
@@ -82,16 +101,20 @@ k_part_hist(DevVolume vol, int k, int shift, u32 nb, u32 b_lo, u32 b_hi, u32* __
     __syncthreads();
     const u64 p0 = (u64)blockIdx.x * kPartPosPerBlock;
     const u64 p1 = (p0 + kPartPosPerBlock < vol.nbases) ? p0 + kPartPosPerBlock : vol.nbases;
+    __shared__ u64 s_range[2];
+    block_read_range(vol, p0, p1 - 1, s_range);          // (p0 < nbases: the grid covers the volume exactly)
+    const u64 r_lo = s_range[0], r_hi = s_range[1];
     for (u64 g0 = p0 + (u64)threadIdx.x * kPosPerThread; g0 < p1; g0 += (u64)kPartThreads * kPosPerThread) {
-        u64 r = seq_of_offset(vol.seq_off, vol.nseq, g0);
+        u64 r = seq_of_offset_in(vol.seq_off, r_lo, r_hi, g0);
         u64 rend = vol.seq_off[r + 1];
+        const u64 win = kmer_window16(vol.bases, (i64)g0);
 #pragma unroll
         for (int i = 0; i < kPosPerThread; ++i) {
             const u64 p = g0 + i;
             if (p >= p1) break;
             while (p >= rend) { ++r; rend = vol.seq_off[r + 1]; }
             if (p + (u64)k <= rend) {
-                const u32 b = (u32)(kmer_hash_at(vol.bases, (i64)p, k) >> shift);
+                const u32 b = (u32)(kmer_hash_win(win, i, k) >> shift);
                 if (b < b_lo || b >= b_hi) continue;
                 atomicAdd(&hist[b >> 1], 1u << ((b & 1u) * 16));
             }
@@ -108,16 +131,18 @@ k_part_hist(DevVolume vol, int k, int shift, u32 nb, u32 b_lo, u32 b_hi, u32* __
 // scatters through the same staging.  The order of the records inside a part is free (k_slice_emit ranks by offset).
 constexpr int kSplitTile = 4096;                  // records per tile = kPosPerThread per thread of a 256-thread block (2048: 6.2 ms for the whole build, 4096: 5.6, 8192: 5.9 -
                                                   // a tile reserves its space with up to 64 atomics on 64 cursors the whole grid shares)
-constexpr int kSplitPer = kSplitTile / 256;
 constexpr int kCurStride = 16;                   // the 64 coarse cursors of k_split_bases sit on their own 128-byte lines: every block bumps all of them
-static_assert(kSplitPer == kPosPerThread, "a thread of k_split_bases hashes the positions of one tile slot");
+static_assert(kPosPerThread == 16, "kmer_window16: 16 positions + a 15-mer = 30 bases of one 32-base window");
+// T threads per tile (kSplitTile / T records each): 256 until round 5; 512 puts twice the waves behind the same 33 KB of LDS - the split kernels are chains of
+// short barrier-separated phases (count, scan, stage, copy out) and four workgroups of four waves per CU did not hide their latencies
 struct SplitLds { u64 rec[kSplitTile]; u64 gbase[64]; u32 cnt[64]; u32 lstart[65]; };
 
 // One tile: r[q] (valid if bit q of `valid`) -> part digit(rec) in [0, 64); reserve(d, c) = where the tile's c records of part
 // d go in `out` (called by lane d of wave 0 for the parts with c > 0).  All 256 threads call.
-template <class Digit, class Reserve>
-NECAT_D void split_tile(SplitLds& L, const u64 (&r)[kSplitPer], u32 valid, Digit digit, Reserve reserve, u64* __restrict__ out)
+template <int T, class Digit, class Reserve>
+NECAT_D void split_tile(SplitLds& L, const u64 (&r)[kSplitTile / T], u32 valid, Digit digit, Reserve reserve, u64* __restrict__ out)
 {
+    constexpr int kSplitPer = kSplitTile / T;
     const int tid = threadIdx.x;
     if (tid < 64) L.cnt[tid] = 0;
     __syncthreads();
@@ -137,7 +162,7 @@ NECAT_D void split_tile(SplitLds& L, const u64 (&r)[kSplitPer], u32 valid, Digit
     for (int q = 0; q < kSplitPer; ++q) if ((valid >> q) & 1u) L.rec[L.lstart[digit(r[q])] + rk[q]] = r[q];
     __syncthreads();
     const u32 total = L.lstart[64];
-    for (u32 idx = tid; idx < total; idx += 256) {
+    for (u32 idx = tid; idx < total; idx += T) {
         const u64 rec = L.rec[idx];
         const u32 d = digit(rec);
         out[L.gbase[d] + (idx - L.lstart[d])] = rec;
@@ -146,23 +171,30 @@ NECAT_D void split_tile(SplitLds& L, const u64 (&r)[kSplitPer], u32 valid, Digit
 }
 
 // volume -> records in coarse buckets (top bits1 of the bucket id); cursor[c] runs from the coarse bucket's start
-__global__ void __launch_bounds__(256)
+template <int T>
+__global__ void __launch_bounds__(T)
 k_split_bases(DevVolume vol, int k, int shift, u32 b_lo, u32 b_hi, int bits2, u64* __restrict__ cursor, int cur_stride, u64* __restrict__ out)
 {
+    constexpr int kSplitPer = kSplitTile / T;
+    static_assert(kSplitPer <= kPosPerThread, "kmer_window16 covers a thread's positions");
     __shared__ SplitLds L;
-    const u64 g0 = (u64)blockIdx.x * kSplitTile + (u64)threadIdx.x * kPosPerThread;
+    __shared__ u64 s_range[2];
+    const u64 t0 = (u64)blockIdx.x * kSplitTile, t1 = t0 + kSplitTile < vol.nbases ? t0 + kSplitTile : vol.nbases;
+    block_read_range(vol, t0, t1 - 1, s_range);
+    const u64 g0 = t0 + (u64)threadIdx.x * kSplitPer;
     u64 r[kSplitPer]; u32 valid = 0;
     if (g0 < vol.nbases) {
-        u64 sq = seq_of_offset(vol.seq_off, vol.nseq, g0);
+        u64 sq = seq_of_offset_in(vol.seq_off, s_range[0], s_range[1], g0);
         u64 rend = vol.seq_off[sq + 1];
+        const u64 win = kmer_window16(vol.bases, (i64)g0);
 #pragma unroll
-        for (int i = 0; i < kPosPerThread; ++i) {
+        for (int i = 0; i < kSplitPer; ++i) {
             const u64 p = g0 + i;
             r[i] = 0;
             if (p >= vol.nbases) continue;
             while (p >= rend) { ++sq; rend = vol.seq_off[sq + 1]; }
             if (p + (u64)k <= rend) {
-                const u64 h = kmer_hash_at(vol.bases, (i64)p, k);
+                const u64 h = kmer_hash_win(win, i, k);
                 const u32 b = (u32)(h >> shift);
                 if (b >= b_lo && b < b_hi) { r[i] = (h << kOffsetBits) | p; valid |= 1u << i; }
             }
@@ -172,16 +204,18 @@ k_split_bases(DevVolume vol, int k, int shift, u32 b_lo, u32 b_hi, int bits2, u6
         for (int i = 0; i < kSplitPer; ++i) r[i] = 0;
     }
     const int dsh = kOffsetBits + shift + bits2;
-    split_tile(L, r, valid, [=](u64 rec) { return (u32)(rec >> dsh) & 63u; },
+    split_tile<T>(L, r, valid, [=](u64 rec) { return (u32)(rec >> dsh) & 63u; },
                [=](u32 d, u32 c) { return (u64)atomicAdd(reinterpret_cast<unsigned long long*>(&cursor[(u64)d * cur_stride]), (unsigned long long)c); }, out);
 }
 
 // tiles of the coarse buckets: tile_pre[c] = tiles of the coarse buckets before c (k_bucket_scan), cstart = bucket_start
 // at stride 1 << bits2.  Records of coarse bucket c -> its fine buckets (c << bits2) + d through bucket_cursor.
-__global__ void __launch_bounds__(256)
+template <int T>
+__global__ void __launch_bounds__(T)
 k_split_recs(const u64* __restrict__ in, const u64* __restrict__ bucket_start, const u32* __restrict__ tile_pre, int nc, int shift, int bits2,
              u64* __restrict__ bucket_cursor, u64* __restrict__ out)
 {
+    constexpr int kSplitPer = kSplitTile / T;
     __shared__ SplitLds L;
     const u32 t = blockIdx.x;
     if (t >= tile_pre[nc]) return;
@@ -190,11 +224,11 @@ k_split_recs(const u64* __restrict__ in, const u64* __restrict__ bucket_start, c
     const u64 lo = bucket_start[(u64)c << bits2] + (u64)(t - tile_pre[c]) * kSplitTile, hi = bucket_start[(u64)(c + 1) << bits2];
     u64 r[kSplitPer]; u32 valid = 0;
 #pragma unroll
-    for (int q = 0; q < kSplitPer; ++q) { const u64 e = lo + (u64)q * 256 + threadIdx.x; r[q] = 0; if (e < hi) { r[q] = in[e]; valid |= 1u << q; } }
+    for (int q = 0; q < kSplitPer; ++q) { const u64 e = lo + (u64)q * T + threadIdx.x; r[q] = 0; if (e < hi) { r[q] = in[e]; valid |= 1u << q; } }
     const int dsh = kOffsetBits + shift;
     const u32 dmask = (1u << bits2) - 1u;
     u64* cur = bucket_cursor + ((u64)c << bits2);
-    split_tile(L, r, valid, [=](u64 rec) { return (u32)(rec >> dsh) & dmask; },
+    split_tile<T>(L, r, valid, [=](u64 rec) { return (u32)(rec >> dsh) & dmask; },
                [=](u32 d, u32 n) { return (u64)atomicAdd(reinterpret_cast<unsigned long long*>(&cur[d]), (unsigned long long)n); }, out);
 }
 
@@ -366,11 +400,13 @@ static_assert(kSubBits + kSliceBits == 18, "a bucket holds 2^18 table entries");
 // part -> part2: the records of bucket b regrouped by sub-bucket; sub_start[b * 64 + j] = first record
 // of slice (b, j) in part2 (absolute), sub_start[nb * 64] = number of records.  One workgroup per bucket: a histogram pass,
 // then the scatter tile by tile through LDS (split_tile) with running cursors.
-__global__ void __launch_bounds__(256)
+template <int T>
+__global__ void __launch_bounds__(T)
 k_subpart(const u64* __restrict__ part, const u64* __restrict__ bucket_start, u32 nb, u64* __restrict__ part2, u64* __restrict__ sub_start)
 {
+    constexpr int kSplitPer = kSplitTile / T;
     __shared__ SplitLds L;
-    __shared__ u32 hist[4][kSubs];
+    __shared__ u32 hist[T / 64][kSubs];
     __shared__ u64 run[kSubs];
     const u32 b = blockIdx.x;
     const u64 lo = bucket_start[b], hi = bucket_start[b + 1];
@@ -378,16 +414,18 @@ k_subpart(const u64* __restrict__ part, const u64* __restrict__ bucket_start, u3
     hist[w][lane] = 0;
     __syncthreads();
     constexpr int kSubUnroll = 4;
-    for (u64 e0 = lo + (u64)w * 64; e0 < hi; e0 += 256 * kSubUnroll) {
+    for (u64 e0 = lo + (u64)w * 64; e0 < hi; e0 += T * kSubUnroll) {
         u64 rec[kSubUnroll];
 #pragma unroll
-        for (int q = 0; q < kSubUnroll; ++q) { const u64 e = e0 + 256 * q + lane; rec[q] = e < hi ? part[e] : ~0ULL; }
+        for (int q = 0; q < kSubUnroll; ++q) { const u64 e = e0 + T * q + lane; rec[q] = e < hi ? part[e] : ~0ULL; }
 #pragma unroll
-        for (int q = 0; q < kSubUnroll; ++q) if (e0 + 256 * q + lane < hi) atomicAdd(&hist[w][(u32)(rec[q] >> (kOffsetBits + kSliceBits)) & (kSubs - 1)], 1u);
+        for (int q = 0; q < kSubUnroll; ++q) if (e0 + T * q + lane < hi) atomicAdd(&hist[w][(u32)(rec[q] >> (kOffsetBits + kSliceBits)) & (kSubs - 1)], 1u);
     }
     __syncthreads();
     if (w == 0) {
-        const u32 tot = hist[0][lane] + hist[1][lane] + hist[2][lane] + hist[3][lane];
+        u32 tot = 0;
+#pragma unroll
+        for (int ww = 0; ww < T / 64; ++ww) tot += hist[ww][lane];
         const u32 incl = wave_scan_add(tot);
         run[lane] = lo + (incl - tot);
         sub_start[(u64)b * kSubs + lane] = lo + (incl - tot);
@@ -397,8 +435,8 @@ k_subpart(const u64* __restrict__ part, const u64* __restrict__ bucket_start, u3
     for (u64 t0 = lo; t0 < hi; t0 += kSplitTile) {
         u64 r[kSplitPer]; u32 valid = 0;
 #pragma unroll
-        for (int q = 0; q < kSplitPer; ++q) { const u64 e = t0 + (u64)q * 256 + threadIdx.x; r[q] = 0; if (e < hi) { r[q] = part[e]; valid |= 1u << q; } }
-        split_tile(L, r, valid, [](u64 rec) { return (u32)(rec >> (kOffsetBits + kSliceBits)) & (u32)(kSubs - 1); },
+        for (int q = 0; q < kSplitPer; ++q) { const u64 e = t0 + (u64)q * T + threadIdx.x; r[q] = 0; if (e < hi) { r[q] = part[e]; valid |= 1u << q; } }
+        split_tile<T>(L, r, valid, [](u64 rec) { return (u32)(rec >> (kOffsetBits + kSliceBits)) & (u32)(kSubs - 1); },
                    [&](u32 d, u32 c) { const u64 at = run[d]; run[d] = at + c; return at; }, part2);
     }
 }

@@ -26,6 +26,7 @@
 #include "comm.h"
 #include "pair_sched.h"
 
+namespace necat { thread_local const Knobs* tl_knobs = nullptr; }      // knobs.h: set by KnobScope in every entry point that takes a context
 using namespace necat;
 static_assert(SC_COUNT <= (int)(sizeof(necat_ctx::scratch) / sizeof(necat::DevBuf)), "a ScratchId without an arena");
 
@@ -56,46 +57,7 @@ DevVolume dev_view(const necat_volume* v)
     return d;
 }
 
-// Lists with at most this many blocks use the cooperative DP kernel (k_myers_coop), longer ones the
-// lane-per-block kernel (k_myers).  With the band store filter the cooperative kernel is the faster one at
-// every size measured on MI355X (200 k blocks: 2.66 vs 2.80 ms; 50 k: 0.77 vs 1.38 ms), so the default is
-// "always"; NECAT_COOP_THRESHOLD=0 selects the lane-per-block kernel (tests compare the two).
-u32 g_coop_threshold;
-unsigned long long g_seed_budget;   // seeding scratch budget per chunk, in k-mer hits
-u32 g_batch_cap;       // candidates per extension batch (NECAT_BATCH)
-u32 g_single_pass;     // lists up to this many blocks use the single-pass DP kernel (NECAT_SINGLE_PASS; 0 = never)
-int g_index_lds;       // LDS-slice index passes (NECAT_INDEX_LDS=0: global-atomic bucket passes)
-int g_seed_wave;       // wave-per-strand seed collection (NECAT_SEED_WAVE=0: the lane-per-strand kernel)
-int g_seed_kst;        // NECAT_SEED_KST=0: k_seed_collect_wave looks the table up again instead of reading the words k_seed_hits kept (A/B tests)
-int g_trace;           // NECAT_TRACE: 1 = extension rounds, 2 = host stages
-int g_coop_filter;     // NECAT_COOP_FILTER=0: the cooperative kernel stores every word (A/B tests)
-int g_sort_b;          // NECAT_SORT_B=0 disables the size sort of list B
-int g_cns_spec_extra, g_cns_spec_cover;   // NECAT_CNS_SPEC_EXTRA / NECAT_CNS_SPEC: speculation width of the consensus loop
-int g_fast;            // NECAT_FAST=0: the list-A DP kernel never takes its full-block fast path (A/B measurements); 2: fast path without band stores (profiling only, results invalid)
-int g_fast16;          // NECAT_FAST16=1: list A's big rounds through k_myers_a16 (16 full blocks per workgroup: SHW 8 lanes, NW 4 lanes per block)
-size_t g_band_pool;    // NECAT_BAND_POOL_MB (default 16384): cap of one band-record pool; a bigger list runs in several DP + walk launches (0 = no cap)
-int g_walk;            // NECAT_WALK=0: k_traceback runs the reference formulation of the walk (A/B measurements)
-u32 g_tail_fused;      // NECAT_TAIL_FUSED (default 512 = one workgroup per block at 2 per CU; 0 = off): lists of at most this many blocks run as ONE launch per round with the band in LDS (ext_tail.h)
-u32 g_rcwalk;          // NECAT_RCWALK (default 512 = every list the one-launch tail kernel does not take; 0 = off): list-A rounds of more than this many blocks run through k_myers_ck / k_myers_ckg + k_rcwalk2 (ext_rcwalk.h: no NW pass, no band records, the walk recomputes its cells)
-size_t g_rc_pool;      // NECAT_RC_POOL_MB (default 8192 = 1.6 M list-A blocks per launch; a 0.6 Gbp volume: 182 -> 174 ms per pass against 2048): cap of the checkpoint buffer of those rounds; a longer list goes through it in several launches
-u32 g_asm_rc;          // NECAT_ASM_RC (default 1): the 2048-bp block aligner of oc2asmpm through k_myers_ckg + k_rcwalk2 (no NW pass, no band records); 0 = two-pass kernel + band + wave walk
-u32 g_rc_listb;        // NECAT_RC_LISTB (default 1, needs NECAT_RC_CARRY): list B (blocks up to 794 x 794) through k_myers_ckg + k_rcwalk2 too; 0 = two-pass kernel + band pool + walk
-u32 g_rc_ragged;       // NECAT_RC_RAGGED (default 1, needs NECAT_RC_CARRY): the ragged blocks of those rounds through k_myers_ckg + k_rcwalk2 as well (0: two-pass kernel + lane walk on a stream of their own)
-u32 g_ck_lds;          // NECAT_CK_LDS (bytes, default 0): dynamic LDS claimed by every workgroup (one wave) of k_myers_ck - caps how many of its waves a CU holds (160 KB / (1 KB + this)), leaving wave slots to the chains of the other streams (A/B measurements)
-u32 g_rc_merge;        // NECAT_RC_MERGE (default 1, needs NECAT_RC_RAGGED): the ragged list-A blocks of a big round through k_myers_ck's ragged fast path and the full blocks' walk launch; 0 = k_myers_ckg + a walk launch of their own on stream d
-u32 g_rc_prio;         // NECAT_RC_PRIO (bits; default 1: 41.6 -> 41.0 ms per step; 2 costs 0.5 ms, 4 nothing): waves that raise their issue priority (s_setprio 3) - 1: list A's walk, 2: list A's checkpoint pass, 4: list B's walk
-u32 g_rc_pipe, g_rc_pipe_min;    // NECAT_RC_PIPE (default 1 = off: 2 - 4 pieces cost 1.8 - 2.3 ms per step, tools/r04/run28.sh, run29.sh) / NECAT_RC_PIPE_MIN (default 49152 blocks): list A of a big round in pieces, walk of piece i beside the pass of piece i + 1
-u32 g_ck_post;         // NECAT_CK_POST (default 1): k_myers_ck finds the bottom row's minimum after the pass, from word 7's deltas, and unrolls its windows (fast_shw8_ckp); 0 = tracked inside the pass
-u32 g_rc_fastb;        // NECAT_RC_FASTB (default 1): list B's checkpoint pass through k_myers_ckf (32-bit halves, bitop3, DPP carries); 0 = the general pass k_myers_ckg
-u32 g_rc_dbg;          // NECAT_RC_DBG (timing only): 2 = k_rcwalk2w walks every segment twice (once into a sink), 4 = recomputes every segment twice
-u32 g_rc_prefetch;     // NECAT_RC_PREFETCH (default 0: measured 0.4 ms per step SLOWER, profiles/NOTES_r04.md 3): k_rcwalk2w loads the next segment's checkpoints / deltas / planes a segment ahead
-u32 g_rc_ww;           // NECAT_RC_WW (default 1; 2 until it wins in the bench and not only alone, profiles/NOTES_r05.md 1): 2 = the recompute walk as k_rcwalk3 (ext_rcwalk3.h: two waves recompute 64 blocks - two lanes per block, both words of the pair per lane - into 32-DIAGONAL records, one of them walks the blocks column by column); 1 = k_rcwalk2w (64-row records, one LDS read per walk step), 0 = k_rcwalk2 (every lane of a quad walks its block)
-u32 g_rc3_min;         // NECAT_RC3_MIN (blocks, default 160000; 4294967295 = never): with NECAT_RC_WW=1, list-A launches of at least this many blocks go through k_rcwalk3 (throughput form: fewer instructions per block, longer chain per segment) instead of k_rcwalk2w
-u32 g_rc_carry;        // NECAT_RC_CARRY (default 1): the recompute walk on an exact two-word window (k_myers_ck<CARRY> keeps the words' horizontal deltas, k_rcwalk2); 0 = the 4-word band window (k_rcwalk4)
-int g_rc_maxdist;      // NECAT_RC_MAXDIST (default and maximum kRcMaxDist = 160): full blocks of a larger distance take the old kernels (tests lower it)
-u32 g_walk_wave;       // NECAT_WALK_WAVE (default 12288; 0 = off): lists of at most this many blocks are walked by one WAVE per block through an LDS window (k_walk_wave, ext_tail.h)
-int g_asm_lane;        // NECAT_ASM_LANE=1: necat_asm_align_batch through the lane-per-alignment kernel (k_asm_align), the second implementation
-int g_dbg;             // NECAT_DBG: profiling-only variants of the lane-per-block DP kernel (1 = no band stores, 2 = no NW pass)
+// (the knobs: knobs.h - per context since round 5)
 
 // the recompute walk of a list of `nitems` work indices: one workgroup per 64 blocks (two waves: k_rcwalk3; four: k_rcwalk2w) or one wave per 16 (k_rcwalk2)
 template <int NW, int TW, int COLS, int MAXOPS, class... A>
@@ -110,48 +72,49 @@ static void launch_rcwalk2(u32 nitems, hipStream_t s, A... a)
     else hipLaunchKernelGGL((k_rcwalk2<NW, TW, COLS, MAXOPS>), dim3((nitems + 15) / 16), dim3(64), 0, s, a...);
 }
 
-// Tuning / test knobs: process-wide, (re)read from the environment whenever a context is created, defaults otherwise.
-void read_knobs()
+// Tuning / test knobs of ONE context: read from the environment when it is created (knobs.h), defaults otherwise.
+void read_knobs(necat::Knobs& K)
 {
     auto num = [](const char* name, unsigned long long dflt) { const char* e = getenv(name); return e ? strtoull(e, nullptr, 10) : dflt; };
-    g_coop_threshold = (u32)num("NECAT_COOP_THRESHOLD", 0xffffffffu);
-    g_seed_budget = num("NECAT_SEED_BUDGET", 48ULL << 20);
-    g_single_pass = (u32)num("NECAT_SINGLE_PASS", 4096);
-    g_tail_fused = (u32)num("NECAT_TAIL_FUSED", 512);
-    g_asm_lane = (int)num("NECAT_ASM_LANE", 0);
-    g_walk_wave = (u32)num("NECAT_WALK_WAVE", 12288);
-    g_rcwalk = (u32)num("NECAT_RCWALK", 512);
-    g_rc_carry = (u32)num("NECAT_RC_CARRY", 1);
-    g_asm_rc = (u32)num("NECAT_ASM_RC", 1);
-    g_rc_ww = (u32)num("NECAT_RC_WW", 1);
-    g_rc3_min = (u32)num("NECAT_RC3_MIN", 160000);
-    g_rc_prefetch = (u32)num("NECAT_RC_PREFETCH", 0);
-    g_rc_dbg = (u32)num("NECAT_RC_DBG", 0) & 6u;
-    g_rc_fastb = (u32)num("NECAT_RC_FASTB", 1);
-    g_ck_post = (u32)num("NECAT_CK_POST", 1);
-    g_rc_prio = (u32)num("NECAT_RC_PRIO", 1);
-    g_rc_pipe = (u32)std::min<unsigned long long>(8, std::max<unsigned long long>(1, num("NECAT_RC_PIPE", 1))); g_rc_pipe_min = (u32)num("NECAT_RC_PIPE_MIN", 49152);
-    g_rc_merge = (u32)num("NECAT_RC_MERGE", 1);
-    g_ck_lds = (u32)num("NECAT_CK_LDS", 0);
-    g_rc_listb = g_rc_carry ? (u32)num("NECAT_RC_LISTB", 1) : 0u;
-    g_rc_ragged = g_rc_carry ? (u32)num("NECAT_RC_RAGGED", 1) : 0u;
-    g_rc_pool = (size_t)std::max<unsigned long long>(1, num("NECAT_RC_POOL_MB", 8192)) << 20;
-    g_rc_maxdist = (int)num("NECAT_RC_MAXDIST", g_rc_carry ? 1 << 20 : kRcMaxDist);
-    if (!g_rc_carry) g_rc_maxdist = std::min(g_rc_maxdist, kRcMaxDist);
-    g_batch_cap = (u32)std::max<unsigned long long>(64, num("NECAT_BATCH", 786432));
-    g_index_lds = (int)num("NECAT_INDEX_LDS", 1);
-    g_seed_wave = (int)num("NECAT_SEED_WAVE", 1);
-    g_seed_kst = (int)num("NECAT_SEED_KST", 1);
-    g_trace = (int)num("NECAT_TRACE", 0);
-    g_coop_filter = (int)num("NECAT_COOP_FILTER", 1);
-    g_sort_b = (int)num("NECAT_SORT_B", 1);
-    g_dbg = (int)num("NECAT_DBG", 0);
-    g_fast = (int)num("NECAT_FAST", 1);
-    g_band_pool = (size_t)num("NECAT_BAND_POOL_MB", 16384) << 20;   // 16 GB = 250 k list-A blocks per launch: as efficient as the whole list, and the first call does not allocate 50 - 100 GB
-    g_fast16 = (int)num("NECAT_FAST16", 0);      // measured: no gain on the bench workload, off by default
-    g_walk = (int)num("NECAT_WALK", 0);      // 0: reference formulation (default until the restated walk wins), 1: walk_block, 2: walk_block without record prefetch
-    g_cns_spec_extra = getenv("NECAT_CNS_SPEC_EXTRA") ? atoi(getenv("NECAT_CNS_SPEC_EXTRA")) : 1;
-    g_cns_spec_cover = (int)num("NECAT_CNS_SPEC", 12);     // 0 = adaptive
+    K.coop_threshold = (u32)num("NECAT_COOP_THRESHOLD", 0xffffffffu);
+    K.seed_budget = num("NECAT_SEED_BUDGET", 48ULL << 20);
+    K.single_pass = (u32)num("NECAT_SINGLE_PASS", 4096);
+    K.tail_fused = (u32)num("NECAT_TAIL_FUSED", 512);
+    K.asm_lane = (int)num("NECAT_ASM_LANE", 0);
+    K.walk_wave = (u32)num("NECAT_WALK_WAVE", 12288);
+    K.rcwalk = (u32)num("NECAT_RCWALK", 512);
+    K.rc_carry = (u32)num("NECAT_RC_CARRY", 1);
+    K.asm_rc = (u32)num("NECAT_ASM_RC", 1);
+    K.rc_ww = (u32)num("NECAT_RC_WW", 1);
+    K.rc3_min = (u32)num("NECAT_RC3_MIN", 160000);
+    K.rc_prefetch = (u32)num("NECAT_RC_PREFETCH", 0);
+    K.rc_dbg = (u32)num("NECAT_RC_DBG", 0) & 6u;
+    K.rc_fastb = (u32)num("NECAT_RC_FASTB", 1);
+    K.ck_post = (u32)num("NECAT_CK_POST", 1);
+    K.rc_prio = (u32)num("NECAT_RC_PRIO", 1);
+    K.rc_pipe = (u32)std::min<unsigned long long>(8, std::max<unsigned long long>(1, num("NECAT_RC_PIPE", 1))); K.rc_pipe_min = (u32)num("NECAT_RC_PIPE_MIN", 49152);
+    K.rc_merge = (u32)num("NECAT_RC_MERGE", 1);
+    K.ck_lds = (u32)num("NECAT_CK_LDS", 0);
+    K.rc_listb = K.rc_carry ? (u32)num("NECAT_RC_LISTB", 1) : 0u;
+    K.rc_ragged = K.rc_carry ? (u32)num("NECAT_RC_RAGGED", 1) : 0u;
+    K.rc_pool = (size_t)std::max<unsigned long long>(1, num("NECAT_RC_POOL_MB", 8192)) << 20;
+    K.rc_maxdist = (int)num("NECAT_RC_MAXDIST", K.rc_carry ? 1 << 20 : kRcMaxDist);
+    if (!K.rc_carry) K.rc_maxdist = std::min(K.rc_maxdist, kRcMaxDist);
+    K.batch_cap = (u32)std::max<unsigned long long>(64, num("NECAT_BATCH", 786432));
+    K.index_lds = (int)num("NECAT_INDEX_LDS", 1);
+    K.split_threads = num("NECAT_SPLIT_THREADS", 512) == 256 ? 256 : 512;
+    K.seed_wave = (int)num("NECAT_SEED_WAVE", 1);
+    K.seed_kst = (int)num("NECAT_SEED_KST", 1);
+    K.trace = (int)num("NECAT_TRACE", 0);
+    K.coop_filter = (int)num("NECAT_COOP_FILTER", 1);
+    K.sort_b = (int)num("NECAT_SORT_B", 1);
+    K.dbg = (int)num("NECAT_DBG", 0);
+    K.fast = (int)num("NECAT_FAST", 1);
+    K.band_pool = (size_t)num("NECAT_BAND_POOL_MB", 16384) << 20;   // 16 GB = 250 k list-A blocks per launch: as efficient as the whole list, and the first call does not allocate 50 - 100 GB
+    K.fast16 = (int)num("NECAT_FAST16", 0);      // measured: no gain on the bench workload, off by default
+    K.walk = (int)num("NECAT_WALK", 0);      // 0: reference formulation (default until the restated walk wins), 1: walk_block, 2: walk_block without record prefetch
+    K.cns_spec_extra = getenv("NECAT_CNS_SPEC_EXTRA") ? atoi(getenv("NECAT_CNS_SPEC_EXTRA")) : 1;
+    K.cns_spec_cover = (int)num("NECAT_CNS_SPEC", 12);     // 0 = adaptive
 }
 
 double wall_ms() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
@@ -180,7 +143,7 @@ int necat_ctx_create(int device_id, necat_ctx** out)
     if (hipSetDevice(device_id) != hipSuccess) return NECAT_ERR_DEVICE;
     necat_ctx* ctx = new necat_ctx();
     ctx->device = device_id;
-    read_knobs();
+    read_knobs(ctx->knobs);
     memset(&ctx->tm, 0, sizeof ctx->tm);
     memset(&ctx->shard_tm, 0, sizeof ctx->shard_tm);
     hipDeviceProp_t prop;
@@ -202,6 +165,7 @@ int necat_ctx_create(int device_id, necat_ctx** out)
 
 void necat_ctx_destroy(necat_ctx* ctx)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -227,6 +191,7 @@ void necat_ctx_destroy(necat_ctx* ctx)
 
 void necat_ctx_trim(necat_ctx* ctx)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
@@ -239,6 +204,7 @@ const char* necat_last_error(const necat_ctx* ctx) { return ctx ? ctx->err : "no
 
 int necat_device_name(const necat_ctx* ctx, char* buf, size_t n)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !buf || !n) return NECAT_ERR_ARG;
     snprintf(buf, n, "%s", ctx->devname);
     return NECAT_OK;
@@ -246,6 +212,7 @@ int necat_device_name(const necat_ctx* ctx, char* buf, size_t n)
 
 int necat_get_timings(const necat_ctx* ctx, necat_timings* t)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !t) return NECAT_ERR_ARG;
     *t = ctx->tm;
     return NECAT_OK;
@@ -315,6 +282,7 @@ void necat_free(void* p)
 int necat_volume_upload(necat_ctx* ctx, const uint8_t* pac, uint64_t nbases, const uint64_t* seq_offset,
                         const uint64_t* seq_size, uint64_t nseq, necat_volume** out)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !out || (nbases && !pac) || (nseq && (!seq_offset || !seq_size))) return NECAT_ERR_ARG;
     *out = nullptr;
     NECAT_HIP(ctx, hipSetDevice(ctx->device));
@@ -364,6 +332,7 @@ int necat_volume_upload(necat_ctx* ctx, const uint8_t* pac, uint64_t nbases, con
 int necat_volume_pack(necat_ctx* ctx, const char* ascii, uint64_t nbases, const uint64_t* seq_offset, const uint64_t* seq_size,
                       uint64_t nseq, uint8_t* pac_out, necat_volume** out)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || (nbases && !ascii) || (!pac_out && !out)) return NECAT_ERR_ARG;
     if (out) *out = nullptr;
     NECAT_HIP(ctx, hipSetDevice(ctx->device));
@@ -398,6 +367,7 @@ int necat_volume_pack(necat_ctx* ctx, const char* ascii, uint64_t nbases, const 
 
 void necat_volume_free(necat_ctx* ctx, necat_volume* v)
 {
+    KnobScope knob_scope_(ctx);
     if (!v) return;
     if (ctx) (void)hipSetDevice(ctx->device);
     if (v->bases_alloc) (void)hipFree(v->bases_alloc);
@@ -412,6 +382,7 @@ int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
 }
 int necat_index_build(necat_ctx* ctx, const necat_volume* ref, int kmer_size, int max_occ, necat_index** out)
 {
+    KnobScope knob_scope_(ctx);
     return index_build_impl(ctx, nullptr, ref, kmer_size, max_occ, out);
 }
 
@@ -435,6 +406,7 @@ int necat_index_plan(uint64_t nbases, int kmer_size, int nranks, double link_gbs
 
 int necat_index_build_sharded(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, int kmer_size, int max_occ, necat_index** out)
 {
+    KnobScope knob_scope_(ctx);
     if (!comm) return NECAT_ERR_ARG;
     return index_build_impl(ctx, comm, ref, kmer_size, max_occ, out);
 }
@@ -460,6 +432,7 @@ int table_alloc(necat_ctx* ctx, necat_index* ix, size_t bytes)
 int index_build_body(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, int kmer_size, int max_occ, necat_index* ix)
 {
     const double w0 = wall_ms();
+    ArenaUse in_use(ctx, {SC_PART, SC_PART2, SC_SPLIT, SC_SPLIT2, SC_TMPLIST, SC_SMALL});      // (buf_ensure_lend: nobody borrows these while this build holds pointers into them)
     if (kmer_size < 1 || kmer_size > 15) return set_err(ctx, NECAT_ERR_ARG, "kmer_size %d outside 1..15 (HashBits = 30, lookup_table.h:13)", kmer_size);
     if (max_occ < 0) return set_err(ctx, NECAT_ERR_ARG, "negative kmer_cnt_cutoff");
     NECAT_HIP(ctx, hipSetDevice(ctx->device));
@@ -538,12 +511,15 @@ int index_build_body(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
         const unsigned tgrid = (unsigned)((ref->nbases + kSplitTile - 1) / kSplitTile);
         if (bits2) {
             u64* d_coarse = (u64*)ctx->scratch[SC_PART2].p;
-            hipLaunchKernelGGL(k_split_bases, dim3(tgrid), dim3(256), 0, s, vol, kmer_size, pshift, b_lo, b_hi, bits2, d_ccur, kCurStride, d_coarse);
+            if (g_split_threads == 512) hipLaunchKernelGGL(k_split_bases<512>, dim3(tgrid), dim3(512), 0, s, vol, kmer_size, pshift, b_lo, b_hi, bits2, d_ccur, kCurStride, d_coarse);
+            else hipLaunchKernelGGL(k_split_bases<256>, dim3(tgrid), dim3(256), 0, s, vol, kmer_size, pshift, b_lo, b_hi, bits2, d_ccur, kCurStride, d_coarse);
             NECAT_CHECK_LAUNCH(ctx, "k_split_bases");
-            hipLaunchKernelGGL(k_split_recs, dim3(tgrid + NC), dim3(256), 0, s, (const u64*)d_coarse, (const u64*)d_bstart, (const u32*)d_tpre, (int)NC, pshift, bits2, d_bcur, d_part);
+            if (g_split_threads == 512) hipLaunchKernelGGL(k_split_recs<512>, dim3(tgrid + NC), dim3(512), 0, s, (const u64*)d_coarse, (const u64*)d_bstart, (const u32*)d_tpre, (int)NC, pshift, bits2, d_bcur, d_part);
+            else hipLaunchKernelGGL(k_split_recs<256>, dim3(tgrid + NC), dim3(256), 0, s, (const u64*)d_coarse, (const u64*)d_bstart, (const u32*)d_tpre, (int)NC, pshift, bits2, d_bcur, d_part);
             NECAT_CHECK_LAUNCH(ctx, "k_split_recs");
         } else {
-            hipLaunchKernelGGL(k_split_bases, dim3(tgrid), dim3(256), 0, s, vol, kmer_size, pshift, b_lo, b_hi, 0, d_bcur, 1, d_part);
+            if (g_split_threads == 512) hipLaunchKernelGGL(k_split_bases<512>, dim3(tgrid), dim3(512), 0, s, vol, kmer_size, pshift, b_lo, b_hi, 0, d_bcur, 1, d_part);
+            else hipLaunchKernelGGL(k_split_bases<256>, dim3(tgrid), dim3(256), 0, s, vol, kmer_size, pshift, b_lo, b_hi, 0, d_bcur, 1, d_part);
             NECAT_CHECK_LAUNCH(ctx, "k_split_bases");
         }
     }
@@ -561,7 +537,8 @@ int index_build_body(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
         d_cbase = (u64*)qb; qb += (size_t)(NB + 1) * 8;
         d_pres = (u32*)qb; qb += nsub * 4;
         d_bpres = (u32*)qb;
-        hipLaunchKernelGGL(k_subpart, dim3(NB), dim3(256), 0, s, (const u64*)d_part, (const u64*)d_bstart, NB, d_part2, d_sub);
+        if (g_split_threads == 512) hipLaunchKernelGGL(k_subpart<512>, dim3(NB), dim3(512), 0, s, (const u64*)d_part, (const u64*)d_bstart, NB, d_part2, d_sub);
+        else hipLaunchKernelGGL(k_subpart<256>, dim3(NB), dim3(256), 0, s, (const u64*)d_part, (const u64*)d_bstart, NB, d_part2, d_sub);
         NECAT_CHECK_LAUNCH(ctx, "k_subpart");
         NECAT_HIP(ctx, hipMemsetAsync(d_bcnt, 0, (size_t)NB * 4, s));                // reused: kept entries per bucket
         NECAT_HIP(ctx, hipMemsetAsync(d_bpres, 0, (size_t)NB * 4, s));
@@ -722,6 +699,7 @@ int necat_index_size(const necat_index* ix, uint64_t* table_entries, uint64_t* n
 
 int necat_index_download(necat_ctx* ctx, const necat_index* ix, uint64_t* kmer_stats, uint64_t* offset_list)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !ix) return NECAT_ERR_ARG;
     NECAT_HIP(ctx, hipSetDevice(ctx->device));
     if (kmer_stats) {
@@ -756,6 +734,7 @@ int necat_index_sparse_size(const necat_index* ix, uint64_t* n_pairs, uint64_t* 
 
 int necat_index_download_sparse(necat_ctx* ctx, const necat_index* ix, uint64_t* pairs, uint64_t* compact, uint64_t* offset_list)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !ix) return NECAT_ERR_ARG;
     if (!ix->words || ix->kmer_stats) return set_err(ctx, NECAT_ERR_ARG, "the index holds the dense table (k = %d): use necat_index_download", ix->k);
     NECAT_HIP(ctx, hipSetDevice(ctx->device));
@@ -767,6 +746,7 @@ int necat_index_download_sparse(necat_ctx* ctx, const necat_index* ix, uint64_t*
 
 void necat_index_free(necat_ctx* ctx, necat_index* ix)
 {
+    KnobScope knob_scope_(ctx);
     if (!ix) return;
     if (ctx) (void)hipSetDevice(ctx->device);
     auto give = [&](void* p, size_t cap, DevBuf& slot) {
@@ -820,6 +800,7 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
     hipStream_t s = ctx->stream;
     const u32 nreads = (u32)reads->nseq;
     if (nreads == 0) return NECAT_OK;
+    ArenaUse in_use(ctx, {SC_SEED_POOL, SC_SEED_CHAIN, SC_SEED_OUT, SC_SEED_HT, SC_SEED_META});      // (buf_ensure_lend: held for the length of this call)
     DevVolume dref = dev_view(ref), drd = dev_view(reads);
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[0], s));
     int rc;
@@ -1093,6 +1074,7 @@ int necat_find_candidates(necat_ctx* ctx, const necat_index* ix, const necat_vol
                           int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt,
                           necat_candidate** out, uint64_t* n_out)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !ix || !ref || !reads || !opt || !out || !n_out) return NECAT_ERR_ARG;
     *out = nullptr; *n_out = 0;
     return find_impl(ctx, ix, ref, reads, read_start_id, ref_start_id, pairwise, opt, out, n_out, nullptr);
@@ -1858,6 +1840,7 @@ int necat_extend(necat_ctx* ctx, const necat_volume* ref, const necat_volume* re
                  const necat_candidate* cands, uint64_t n, const necat_map_options* opt, int tail_match_len,
                  necat_m4** out, uint64_t* n_out)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !ref || !reads || !opt || !out || !n_out || (n && !cands)) return NECAT_ERR_ARG;
     *out = nullptr; *n_out = 0;
     if (n == 0) return NECAT_OK;
@@ -1868,6 +1851,7 @@ int necat_map_pair(necat_ctx* ctx, const necat_index* ix, const necat_volume* re
                    int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt, int tail_match_len,
                    necat_m4** out, uint64_t* n_out, uint64_t* n_candidates)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !ix || !ref || !reads || !opt || !out || !n_out) return NECAT_ERR_ARG;
     *out = nullptr; *n_out = 0;
     if (n_candidates) *n_candidates = 0;
@@ -2134,6 +2118,7 @@ int necat_asm_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_v
                           const necat_asm_anchor* anchors, uint64_t n, double error, int min_align_size,
                           necat_alignment** aln, uint8_t** ops, uint64_t** ops_off)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !ref || !reads || !aln || !ops || !ops_off || (n && !anchors)) return NECAT_ERR_ARG;
     *aln = nullptr; *ops = nullptr; *ops_off = nullptr;
     if (!(error > 0.0 && error <= 1.0) || n >= (1ULL << 31)) return set_err(ctx, NECAT_ERR_ARG, "error rate / count out of range");
@@ -2226,6 +2211,7 @@ int necat_asm_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_v
 int necat_asm_plan_batch(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, const necat_volume* reads, int read_start_id, int ref_start_id,
                          const necat_map_options* opt, necat_asm_plan** out, uint64_t** first)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !ix || !ref || !reads || !opt || !out || !first) return NECAT_ERR_ARG;
     *out = nullptr; *first = nullptr;
     if (opt->kmer_size != ix->k) return set_err(ctx, NECAT_ERR_ARG, "index was built for k=%d, options say %d", ix->k, opt->kmer_size);
@@ -2498,6 +2484,7 @@ int necat_map_reference(necat_ctx* ctx, const necat_index* ix, const necat_volum
                         int read_start_id, int ref_start_id, const necat_map_options* opt,
                         necat_m4** out, uint64_t* n_out, uint64_t* n_candidates, uint64_t* n_rescued)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !ix || !ref || !reads || !opt || !out || !n_out) return NECAT_ERR_ARG;
     *out = nullptr; *n_out = 0;
     if (n_candidates) *n_candidates = 0;
@@ -2567,6 +2554,7 @@ int necat_map_reference(necat_ctx* ctx, const necat_index* ix, const necat_volum
 int necat_pcan_partition(necat_ctx* ctx, const necat_candidate* cands, uint64_t n, int batch_size, int num_reads,
                          uint32_t** records, uint64_t** part_off, int* num_parts)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || (n && !cands) || !records || !part_off || !num_parts || batch_size < 1 || num_reads < 0) return NECAT_ERR_ARG;
     *records = nullptr; *part_off = nullptr;
     const int nparts = (int)(((int64_t)num_reads + batch_size - 1) / batch_size);       // pcan.c:111
@@ -2610,6 +2598,7 @@ int necat_pcan_partition(necat_ctx* ctx, const necat_candidate* cands, uint64_t 
 
 int necat_comm_create(necat_ctx* ctx, int rank, int nranks, necat_host_allgather_fn fn, void* user, const char* transport, necat_comm** out)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !out || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn)) return NECAT_ERR_ARG;
     *out = nullptr;
     NECAT_HIP(ctx, hipSetDevice(ctx->device));
@@ -2671,6 +2660,7 @@ int necat_comm_create(necat_ctx* ctx, int rank, int nranks, necat_host_allgather
 // send/recv group to itself on the context's stream - so that it runs on hardware even where a second GPU is not available.
 int necat_comm_selftest_rccl(necat_ctx* ctx, uint64_t bytes)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !bytes) return NECAT_ERR_ARG;
     NECAT_HIP(ctx, hipSetDevice(ctx->device));
     necat_comm c;
@@ -2708,6 +2698,7 @@ int necat_comm_selftest_rccl(necat_ctx* ctx, uint64_t bytes)
 // right bytes over the link.
 int necat_comm_selftest_rccl2(necat_ctx* ctx, uint64_t bytes)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !bytes) return NECAT_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 2) { (void)hipGetLastError(); set_err(ctx, NECAT_OK, "fewer than two devices: the two-rank RCCL exchange cannot run here"); return 1; }
@@ -2776,6 +2767,7 @@ int necat_comm_transport(const necat_comm* c, char* buf, size_t n)
 
 int necat_get_shard_timings(const necat_ctx* ctx, necat_shard_timings* t)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !t) return NECAT_ERR_ARG;
     *t = ctx->shard_tm;
     return NECAT_OK;
@@ -2837,6 +2829,7 @@ int necat_find_candidates_sharded(necat_ctx* ctx, necat_comm* comm, const necat_
                                   int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt, int chunk_reads, int root,
                                   necat_candidate** out, uint64_t* n_out, uint64_t* n_local)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !comm || !ix || !ref || !reads || !opt || !out || !n_out || chunk_reads < 1 || root < 0 || root >= comm->nranks) return NECAT_ERR_ARG;
     *out = nullptr; *n_out = 0;
     if (n_local) *n_local = 0;
@@ -2854,6 +2847,7 @@ int necat_map_pair_sharded(necat_ctx* ctx, necat_comm* comm, const necat_index* 
                            int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt, int tail_match_len, int chunk_reads, int root,
                            necat_m4** out, uint64_t* n_out, uint64_t* n_local, uint64_t* n_candidates)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !comm || !ix || !ref || !reads || !opt || !out || !n_out || chunk_reads < 1 || root < 0 || root >= comm->nranks) return NECAT_ERR_ARG;
     *out = nullptr; *n_out = 0;
     if (n_local) *n_local = 0;
@@ -2879,6 +2873,7 @@ int necat_find_candidates_part(necat_ctx* ctx, const necat_index* ix, const neca
                                int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt,
                                int chunk_reads, int slot_lo, int slot_hi, int slots, necat_candidate** out, uint64_t* n_out)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !ix || !ref || !reads || !opt || !out || !n_out || chunk_reads < 1 || slots < 1 || slot_lo < 0 || slot_hi < slot_lo || slot_hi > slots) return NECAT_ERR_ARG;
     *out = nullptr; *n_out = 0;
     ReadSel sel; sel.lo = slot_lo; sel.hi = slot_hi; sel.nparts = slots; sel.chunk = chunk_reads; sel.always = true;
@@ -2889,6 +2884,7 @@ int necat_map_pair_part(necat_ctx* ctx, const necat_index* ix, const necat_volum
                         int read_start_id, int ref_start_id, int pairwise, const necat_map_options* opt, int tail_match_len,
                         int chunk_reads, int slot_lo, int slot_hi, int slots, necat_m4** out, uint64_t* n_out, uint64_t* n_candidates)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !ix || !ref || !reads || !opt || !out || !n_out || chunk_reads < 1 || slots < 1 || slot_lo < 0 || slot_hi < slot_lo || slot_hi > slots) return NECAT_ERR_ARG;
     *out = nullptr; *n_out = 0;
     if (n_candidates) *n_candidates = 0;
@@ -2926,6 +2922,7 @@ int necat_onc_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_v
                           const necat_candidate* cands, uint64_t n, const necat_map_options* opt, int tail_match_len,
                           necat_alignment** aln, uint8_t** ops, uint64_t** ops_off)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !ref || !reads || !opt || !aln || !ops || !ops_off || (n && !cands)) return NECAT_ERR_ARG;
     *aln = nullptr; *ops = nullptr; *ops_off = nullptr;
     AlignOut ao;
@@ -2979,6 +2976,7 @@ void necat_cns_default_options(necat_cns_options* o)
 int necat_cns_load_partition(necat_ctx* ctx, const necat_volume* reads, const void* packed, uint64_t n,
                              necat_candidate** cands, uint64_t** tmpl_off, uint64_t** n_all, uint64_t* n_templates)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !reads || (n && !packed) || !cands || !tmpl_off || !n_all || !n_templates) return NECAT_ERR_ARG;
     *cands = nullptr; *tmpl_off = nullptr; *n_all = nullptr; *n_templates = 0;
     std::vector<cns::Packed> recs(n);
@@ -3008,6 +3006,7 @@ void necat_cns_result_free(necat_cns_result* r)
 int necat_cns_extension_batch(necat_ctx* ctx, const necat_volume* reads, const necat_candidate* cands, const uint64_t* tmpl_off,
                               const uint64_t* n_all, uint64_t n_templates, const necat_cns_options* opt, necat_cns_result** out)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !reads || !opt || !out || (n_templates && (!tmpl_off || !cands))) return NECAT_ERR_ARG;
     *out = nullptr;
     if (opt->max_cov < 1 || opt->max_cov > 60000 || opt->min_align_size < 0 || !(opt->error > 0.0 && opt->error <= 1.0))
@@ -3192,6 +3191,7 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
                             const uint64_t* t_off, const int32_t* t_len, uint64_t n, double error,
                             int32_t* dist, int32_t* qend, int32_t* tend, uint8_t** ops, uint64_t** ops_off)
 {
+    KnobScope knob_scope_(ctx);
     if (!ctx || !seqs || !q_off || !q_len || !t_off || !t_len || !dist || !qend || !tend) return NECAT_ERR_ARG;
     if (ops) *ops = nullptr;
     if (ops_off) *ops_off = nullptr;

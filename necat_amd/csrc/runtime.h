@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "../../include/necat_hip.h"
+#include "knobs.h"
 #include "dev_common.h"
 
 namespace necat {
@@ -45,6 +46,7 @@ struct necat_ctx {
     void* round_ring_dev = nullptr;    // the same memory as the device addresses it
     unsigned long long round_seq = 0;  // rounds published so far (the next round publishes round_seq + 1)
     necat::DevBuf scratch[64];         // grow-only arenas, indexed by purpose (ScratchId; SC_COUNT <= 64)
+    uint64_t scratch_live = 0;         // bit i: a call in progress holds pointers into scratch[i] (necat::ArenaUse) - buf_ensure_lend never hands such an arena to another phase
     void* seed_ht_ptr = nullptr;       // the seeding hash arena (SC_SEED_HT) whose first seed_ht_clean bytes are known to be all-empty (0xFF):
     size_t seed_ht_cap = 0;            // .. and its capacity when that was established (a reallocation at the same address is a new arena)
     size_t seed_ht_clean = 0;          // every call leaves the arena as it found it (k_seed_clear resets the slots it used), so it is filled once per allocation
@@ -52,6 +54,7 @@ struct necat_ctx {
     int num_cu = 0;
     uint32_t epoch = 0;
     void* cns_scratch = nullptr;       // host buffers of the consensus loop kept between calls (necat::cns::Scratch)
+    necat::Knobs knobs;                // this context's tuning / test knobs (knobs.h: read from the environment in necat_ctx_create)
     necat::DevBuf idx_cache[2];        // released index arrays kept for the next build (8.6 GB hipMalloc/hipFree per step otherwise)                // launch counter stamped into the traceback band records
 };
 
@@ -78,6 +81,14 @@ struct necat_index {
 };
 
 namespace necat {
+
+// an entry point of the C ABI makes its context's knobs the current ones of this thread for the length of the call (knobs.h)
+struct KnobScope {
+    const Knobs* prev;
+    explicit KnobScope(const necat_ctx* c) : prev(tl_knobs) { if (c) tl_knobs = &c->knobs; }
+    ~KnobScope() { tl_knobs = prev; }
+    KnobScope(const KnobScope&) = delete; KnobScope& operator=(const KnobScope&) = delete;
+};
 
 inline int set_err(necat_ctx* ctx, int code, const char* fmt, ...)
 {
@@ -154,6 +165,14 @@ enum ScratchId {
 // time, every call that uses them has finished with them when it returns): before allocating, take the buffer of a donor that is big
 // enough and leave it this one's - the phases then hand ONE allocation back and forth instead of holding two (a 2 Gbp volume: 17 GB of
 // split records and 14 GB of seed blocks; a process waits 30 - 55 ms per GB for device memory it maps the first time).
+// What keeps that safe is no longer only the order of the donor lists: a phase marks the arenas it holds pointers into (ArenaUse, for the length of
+// the call) and a marked arena is never taken - an index build running beside a candidate search of the same context would allocate instead of aliasing.
+struct ArenaUse {
+    necat_ctx* ctx; uint64_t mine;
+    ArenaUse(necat_ctx* c, std::initializer_list<int> ids) : ctx(c), mine(0) { for (int i : ids) mine |= 1ULL << i; mine &= ~c->scratch_live; c->scratch_live |= mine; }
+    ~ArenaUse() { ctx->scratch_live &= ~mine; }
+    ArenaUse(const ArenaUse&) = delete; ArenaUse& operator=(const ArenaUse&) = delete;
+};
 inline int buf_ensure_lend(necat_ctx* ctx, int id, size_t bytes, std::initializer_list<int> donors)
 {
     DevBuf& b = ctx->scratch[id];
@@ -161,7 +180,7 @@ inline int buf_ensure_lend(necat_ctx* ctx, int id, size_t bytes, std::initialize
     static const bool off = getenv("NECAT_NO_LEND") && atoi(getenv("NECAT_NO_LEND"));
     if (!off) for (int d : donors) {
         DevBuf& o = ctx->scratch[d];
-        if (d != id && o.cap >= bytes) { std::swap(b, o); return NECAT_OK; }
+        if (d != id && o.cap >= bytes && !((ctx->scratch_live >> d) & 1ULL)) { std::swap(b, o); return NECAT_OK; }
     }
     return buf_ensure(ctx, b, bytes);
 }

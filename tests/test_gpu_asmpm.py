@@ -1,5 +1,6 @@
-"""GPU parity of oc2asmpm: this repo's program - vote and chained ranges on the host threads (asm_core.h), every anchor of a volume pair through
-the device's 2048-bp block aligner (necat_asm_align_batch, asm_kernels.h), end extension on the host - against the REFERENCE's own oc2asmpm -t 1
+"""GPU parity of oc2asmpm: this repo's program - block vote and chained ranges on the device (necat_asm_plan_batch, asm_plan.h), every anchor of a
+volume pair through the device's 2048-bp block aligner (necat_asm_align_batch: k_myers_ckg + k_rcwalk2w), DALIGNER's end extension on the host (rescue.h) - against
+the REFERENCE's own oc2asmpm -t 1
 (oracle/_ref/oc2asmpm, built from /root/reference; it travels to the GPU box): byte-identical text records, field-identical binary records."""
 import os
 import subprocess

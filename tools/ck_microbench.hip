@@ -1,6 +1,8 @@
 // ck_microbench.hip - the list-A checkpoint pass (k_myers_ck<8, 16, true>, ext_rcwalk.h) alone, on random full blocks: per-launch time
 // at three list sizes (one wave per SIMD, one full round of 8 waves per SIMD, the biggest round of the bench) for the variants the
 // kernel's `flags` select.  The SHW pass has no data-dependent control flow, so random words time like real ones.
+// (The structural variants of round 4 - half the windows, no post-pass, no windows, no work counters: -DNECAT_CK_MV=5 .. 10 - were cut out of the product header in
+// round 5; they are at commit 240f31f, their numbers in profiles/NOTES_r04.md 10.)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -mllvm -disable-promote-alloca-to-lds -I necat_amd/csrc -o tools/ck_microbench tools/ck_microbench.hip
 #include <algorithm>
 #include <chrono>
