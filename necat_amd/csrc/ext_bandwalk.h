@@ -49,9 +49,10 @@ NECAT_HD u32 band_piece(u64 plane, int rel)
     return rel >= 0 ? (u32)(plane >> rel) : ((u32)plane << (-rel));
 }
 
-// Which two words a segment entered at row r is recomputed on: the rows it can touch are [r - 47, r] (32 columns, the entry on bit 16), so the pair starts at the
-// word of row r - 47 (word 0 when r < 47: the rows above the matrix then read as zero, band_piece2's general form)
-NECAT_HD int band_word_lo(int r) { return r >= 47 ? (r - 47) >> 6 : 0; }
+// Which two words a segment entered at row r is recomputed on: the rows it can touch are [r - 47, r] (32 columns, 32 diagonals, the entry on bit 16), so the
+// pair starts at the word of row r - 47 (word 0 when r < 47: the rows above the matrix then read as zero, band_piece2's general form)
+// (BW diagonals, the entry on bit BW / 2: 32 columns back the band's lowest row is r - 31 - BW / 2)
+template <int BW = 32> NECAT_HD int band_word_lo(int r) { return r >= 31 + BW / 2 ? (r - 31 - BW / 2) >> 6 : 0; }
 
 // a column's record from the decision planes of the pair (lo: word wl, hi: word wl + 1): bits [S, S + 32) of the 128 rows that start at row 64 wl.
 // GENERAL = false: 0 <= S < 96 (every segment entered at r >= 47); true: any S in (-64, 128), rows outside the pair read as zero.
@@ -119,55 +120,17 @@ NECAT_HD int band_walk_col(BandWalk& w, const u32 A, const u32 B, const int mlen
     return w.p > 31 ? 1 : 0;
 }
 
-// band_walk_col written for the walker WAVE: 64 lanes on 64 different walks, so a data-dependent branch is executed by the whole wave anyway and every
-// taken branch is a bubble in the one chain the workgroup waits for.  The moves are selects; the two things only some lanes do - keeping ops, and the
-// tail scan of a walk that has not yet seen its run of matches - sit behind wave-uniform tests (NECAT_ANY).  `act`: the lane is walking and has reached
-// this column; st: 0 walking, 1 out of the band, 2 out of the matrix (left alone when the lane is not active).  ovf: an op index beyond the list.
-template <int MAXOPS, class Store>
-NECAT_HD void band_walk_col2(BandWalk& w, int& st, const bool act, const u32 A, const u32 B, const int mlen, const bool store, Store& st_op, int& ovf)
-{
-    const u32 pp = (u32)w.p & 31u;
-    int run = clz32(((~A | B) << (31u - pp)) | (0x40000000u >> pp));     // the ups below bit p; the sentinel ends the count at the band's bit 0
-    run = act ? (run < 32 ? run : 32) : 0;
-    if (NECAT_ANY(run > 0 && (store || !w.hit))) {
-        if (run > 0) {
-            if (store) for (int i = 0; i < run; ++i) { if (w.n + i < MAXOPS) st_op(w.n + i, 1); else ovf = 1; }
-            if (!w.hit) {
-                if (mlen == 0) { w.hit = 1; w.acnt = w.n + 1; w.qcnt = w.nq + 1; w.tcnt = w.nt; w.mcnt = w.nmat; }
-                w.m = 0; w.nq += run;
-            }
-        }
-    }
-    w.n += run; w.r -= run; w.p -= run;
-    const bool out1 = act && w.r < 0, red1 = act && !out1 && w.p < 0;
-    const bool go = act && !out1 && !red1;
-    const u32 p2 = (u32)w.p & 31u;
-    const u32 a = (A >> p2) & 1u, b = (B >> p2) & 1u;
-    const int left = (int)(b & (a ^ 1u)), mt = (int)((a | b) ^ 1u);
-    if (NECAT_ANY(go && (store || !w.hit))) {
-        if (go && store) { if (w.n < MAXOPS) st_op(w.n, (int)(a | (b << 1))); else ovf = 1; }
-        if (go && !w.hit) {
-            w.nq += 1 - left; w.nt += 1;
-            w.m = mt ? w.m + 1 : 0;
-            if (w.m == mlen) { w.hit = 1; w.acnt = w.n + 1; w.qcnt = w.nq; w.tcnt = w.nt; w.mcnt = w.nmat + mt; }
-        }
-    }
-    const int g = go ? 1 : 0;
-    w.n += g; w.nmat += go ? mt : 0;
-    w.r -= go ? 1 - left : 0; w.c -= g; w.p += go ? left : 0;
-    const bool out2 = go && (w.r | w.c) < 0, red2 = go && !out2 && w.p > 31;
-    st = (out1 || out2) ? 2 : ((red1 || red2) ? 1 : st);
-}
-
-// band_walk_col2 with the bookkeeping cut to what a column needs (k_rcwalk3's walker is a third of the kernel's instructions): no status code per
-// column - a lane is `alive` until it leaves the band or the matrix, and which of the two it was is read off (r, c, p) after the segment (band_walk_why);
-// `here`: the lane has reached this column (x <= its entry column; always true for a lane that entered the segment at its last column).
-template <int MAXOPS, class Store>
+// band_walk_col written for the walker WAVE: 64 lanes on 64 different walks, so a data-dependent branch is executed by the whole wave anyway and every taken
+// branch is a bubble in the one chain the workgroup waits for.  The moves are selects; the two things only some lanes do - keeping ops, and the tail scan of
+// a walk that has not yet seen its run of matches - sit behind wave-uniform tests (NECAT_ANY).  No status code per column: a lane is `alive` until it leaves
+// the band or the matrix, and which of the two it was is read off (r, c, p) after the segment (band_walk_why); `here`: the lane has reached this column
+// (x <= its entry column; always true for a lane that entered the segment at its last column).  BW: diagonals per record (bits of A and of B).
+template <int MAXOPS, int BW = 32, class Store>
 NECAT_HD void band_walk_col3(BandWalk& w, bool& alive, const bool here, const u32 A, const u32 B, const int mlen, const bool store, Store& st_op, int& ovf)
 {
     const bool act = alive && here;
     const u32 lim = (u32)w.p + 1u;
-    u32 run = (u32)clz32((~A | B) << ((31u - (u32)w.p) & 31u));           // the ups below bit p (p in [0, 31] while the lane is alive) ..
+    u32 run = (u32)clz32((~A | B) << ((31u - (u32)w.p) & 31u));           // the ups below bit p (p in [0, BW) while the lane is alive) ..
     run = run < lim ? run : lim;                                          // .. ending at the band's bit 0
     run = act ? run : 0u;
     if (NECAT_ANY(run > 0 && (store || !w.hit))) {
@@ -193,7 +156,7 @@ NECAT_HD void band_walk_col3(BandWalk& w, bool& alive, const bool here, const u3
         }
     }
     if (go) { w.n += 1; w.nmat += 1 - nm; w.r -= 1 - left; w.c -= 1; w.p += left; }
-    alive = act ? (go && (w.r | w.c) >= 0 && (u32)w.p <= 31u) : alive;
+    alive = act ? (go && (w.r | w.c) >= 0 && (u32)w.p < (u32)BW) : alive;
 }
 // after a segment, for a lane that was walking when it began: 0 = still walking (on to the segment before), 1 = left the band (redo from (r, c)), 2 = left the matrix
 NECAT_HD int band_walk_why(const BandWalk& w, const bool alive) { return alive ? 0 : ((w.r | w.c) < 0 ? 2 : 1); }

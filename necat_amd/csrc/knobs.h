@@ -45,6 +45,7 @@ struct Knobs {
     u32 rc_dbg;          // NECAT_RC_DBG (timing only): 2 = k_rcwalk2w walks every segment twice (once into a sink), 4 = recomputes every segment twice
     u32 rc_prefetch;     // NECAT_RC_PREFETCH (default 0: measured 0.4 ms per step SLOWER, profiles/NOTES_r04.md 3): k_rcwalk2w loads the next segment's checkpoints / deltas / planes a segment ahead
     u32 rc_ww;           // NECAT_RC_WW (default 1; 2 until it wins in the bench and not only alone, profiles/NOTES_r05.md 1): 2 = the recompute walk as k_rcwalk3 (ext_rcwalk3.h: two waves recompute 64 blocks - two lanes per block, both words of the pair per lane - into 32-DIAGONAL records, one of them walks the blocks column by column); 1 = k_rcwalk2w (64-row records, one LDS read per walk step), 0 = k_rcwalk2 (every lane of a quad walks its block)
+    u32 rc3_band;          // NECAT_RC3_BAND (32 or 16): diagonals per record of k_rcwalk3 (16: half the LDS per block in flight, 7 waves per SIMD instead of 4.5, a few per cent of the segments redone)
     u32 rc3_min;         // NECAT_RC3_MIN (blocks, default 160000; 4294967295 = never): with NECAT_RC_WW=1, list-A launches of at least this many blocks go through k_rcwalk3 (throughput form: fewer instructions per block, longer chain per segment) instead of k_rcwalk2w
     u32 rc_carry;        // NECAT_RC_CARRY (default 1): the recompute walk on an exact two-word window (k_myers_ck<CARRY> keeps the words' horizontal deltas, k_rcwalk2); 0 = the 4-word band window (k_rcwalk4)
     int rc_maxdist;      // NECAT_RC_MAXDIST (default and maximum kRcMaxDist = 160): full blocks of a larger distance take the old kernels (tests lower it)
@@ -91,6 +92,7 @@ extern thread_local const Knobs* tl_knobs;      // the knobs of the context whos
 #define g_rc_prefetch (necat::tl_knobs->rc_prefetch)
 #define g_rc_ww (necat::tl_knobs->rc_ww)
 #define g_rc3_min (necat::tl_knobs->rc3_min)
+#define g_rc3_band (necat::tl_knobs->rc3_band)
 #define g_rc_carry (necat::tl_knobs->rc_carry)
 #define g_rc_maxdist (necat::tl_knobs->rc_maxdist)
 #define g_walk_wave (necat::tl_knobs->walk_wave)

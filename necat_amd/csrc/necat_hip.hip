@@ -65,9 +65,12 @@ static void launch_rcwalk2(u32 nitems, hipStream_t s, A... a)
 {
     const u32 pr = ((NW == kWordsA ? (g_rc_prio & 1u) : NW == kWordsB ? (g_rc_prio & 4u) : 0u) ? 8u : 0u) | ((NW == kWordsA ? (g_rc_prio & 8u) : NW == kWordsB ? (g_rc_prio & 16u) : 0u) ? 16u : 0u);
     // (k_rcwalk3's walking wave alone at raised priority where k_rcwalk2w raises every wave: 39.2 against 39.5 ms per step, tools/r05/run5.sh)
-    if (g_rc_ww == 1 && NW == kWordsA && nitems >= g_rc3_min) hipLaunchKernelGGL((k_rcwalk3<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(128), 0, s, a..., (pr & 8u) ? 16u : pr);
-    else if (g_rc_ww >= 3) hipLaunchKernelGGL((k_rcwalk3p<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(192), 0, s, a..., pr);
-    else if (g_rc_ww == 2) hipLaunchKernelGGL((k_rcwalk3<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(128), 0, s, a..., pr);
+    if (g_rc_ww == 1 && NW == kWordsA && nitems >= g_rc3_min) {
+        if (g_rc3_band == 16) hipLaunchKernelGGL((k_rcwalk3<NW, TW, COLS, MAXOPS, 16>), dim3((nitems + 63) / 64), dim3(128), 0, s, a..., (pr & 8u) ? 16u : pr);
+        else hipLaunchKernelGGL((k_rcwalk3<NW, TW, COLS, MAXOPS, 32>), dim3((nitems + 63) / 64), dim3(128), 0, s, a..., (pr & 8u) ? 16u : pr);
+    }
+    else if (g_rc_ww >= 2 && g_rc3_band == 16) hipLaunchKernelGGL((k_rcwalk3<NW, TW, COLS, MAXOPS, 16>), dim3((nitems + 63) / 64), dim3(128), 0, s, a..., pr);
+    else if (g_rc_ww >= 2) hipLaunchKernelGGL((k_rcwalk3<NW, TW, COLS, MAXOPS, 32>), dim3((nitems + 63) / 64), dim3(128), 0, s, a..., pr);
     else if (g_rc_ww) hipLaunchKernelGGL((k_rcwalk2w<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(256), 0, s, a..., g_rc_prefetch | g_rc_dbg | pr);
     else hipLaunchKernelGGL((k_rcwalk2<NW, TW, COLS, MAXOPS>), dim3((nitems + 15) / 16), dim3(64), 0, s, a...);
 }
@@ -87,6 +90,7 @@ void read_knobs(necat::Knobs& K)
     K.asm_rc = (u32)num("NECAT_ASM_RC", 1);
     K.rc_ww = (u32)num("NECAT_RC_WW", 1);
     K.rc3_min = (u32)num("NECAT_RC3_MIN", 160000);
+    K.rc3_band = num("NECAT_RC3_BAND", 32) == 16 ? 16u : 32u;
     K.rc_prefetch = (u32)num("NECAT_RC_PREFETCH", 0);
     K.rc_dbg = (u32)num("NECAT_RC_DBG", 0) & 6u;
     K.rc_fastb = (u32)num("NECAT_RC_FASTB", 1);

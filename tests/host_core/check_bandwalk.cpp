@@ -21,6 +21,60 @@ struct FullMat {
 };
 struct VecSink { std::vector<int>* v; bool on; bool storing() const { return on; } void put(int i, int op) { if ((int)v->size() <= i) v->resize(i + 1, -1); (*v)[i] = op; } };
 
+// one block the way k_rcwalk3<.., BW> walks it: segment by segment, the pair of words band_word_lo<BW> names, every column's record cut out of the pair's
+// decision planes (band_piece2, the fast form wherever the kernel uses it), everything the walk must not look at poisoned, one band_walk_col / band_walk_col3 per column
+template <int BW, class Put, class Rng>
+int kernel_walk(int blk, const FullMat& fm, int nw, BandWalk& w, int mlen, bool store, Put& put, Rng& rng, long long& redo, long long& myredo, long long& segs)
+{
+    constexpr int P0 = BW / 2;
+    const u32 mask = BW == 32 ? 0xffffffffu : ((1u << BW) - 1u);
+    bool out = false;
+    int prev_seg = 1 << 30;
+    while (!out) {
+        const int seg = w.c >> 5, c0 = seg * 32, xin = w.c - c0, d0 = w.r - w.c;
+        if (seg == prev_seg) { ++redo; ++myredo; } prev_seg = seg; ++segs;
+        w.p = P0;
+        u32 ra[32], rb_[32];
+        const int wl = band_word_lo<BW>(w.r), wh = wl + 1 < nw ? wl + 1 : nw - 1;      // the kernel's pair of words (ext_rcwalk3.h)
+        const bool general = (c0 + d0 - P0 - 64 * wl) < 0;                            // some column's record starts above the pair: zero fill
+        for (int x = 0; x <= xin; ++x) {
+            const int col = c0 + x, rb = col + d0 - P0, S = rb - 64 * wl;
+            u64 pa0, pb0, pa1, pb1; fm.rec(col, wl, pa0, pb0); fm.rec(col, wh, pa1, pb1);
+            if (wh == wl) { pa1 = rng(); pb1 = rng(); }                               // (the top word twice: its second copy is never looked at)
+            if (!general && (S < 0 || S >= 96)) { fprintf(stderr, "block %d: S = %d outside the fast form's range\n", blk, S); return 1; }
+            u32 a, b;
+            if (general) { a = band_piece2<true>((u32)pa0, (u32)(pa0 >> 32), (u32)pa1, (u32)(pa1 >> 32), S); b = band_piece2<true>((u32)pb0, (u32)(pb0 >> 32), (u32)pb1, (u32)(pb1 >> 32), S); }
+            else { a = band_piece2<false>((u32)pa0, (u32)(pa0 >> 32), (u32)pa1, (u32)(pa1 >> 32), S); b = band_piece2<false>((u32)pb0, (u32)(pb0 >> 32), (u32)pb1, (u32)(pb1 >> 32), S); }
+            if (BW == 32 && (blk & 8) == 0) {      // and the four-lane form's pieces (band_piece per word, OR-ed): the same record where the walk can look
+                u32 a2 = 0, b2 = 0;
+                const int w1 = w.r >> 6;
+                for (int k = 0; k < 2; ++k) {
+                    const int ww = w1 - 1 + k;
+                    if (ww < 0) continue;
+                    u64 qa, qb; fm.rec(col, ww, qa, qb);
+                    a2 |= band_piece(qa, rb - 64 * ww); b2 |= band_piece(qb, rb - 64 * ww);
+                }
+                for (int p = 0; p < 32; ++p) { const int row = rb + p; if (row <= w.r && (((a ^ a2) | (b ^ b2)) >> p & 1u)) { fprintf(stderr, "block %d: the two forms of the record differ at row %d\n", blk, row); return 1; } }
+            }
+            a &= mask; b &= mask;          // a record keeps BW diagonals (the kernel packs A | B << 16 for BW = 16)
+            // rows above r (the walk only moves up): poison
+            for (int p = 0; p < BW; ++p) { const int row = rb + p; if (row > w.r) { a = (a & ~(1u << p)) | ((u32)(rng() & 1) << p); b = (b & ~(1u << p)) | ((u32)(rng() & 1) << p); } }
+            ra[x] = a; rb_[x] = b;
+        }
+        int st = 0;
+        if ((blk & 6) == 6 || BW != 32) {    // the wave form: alive flag, the reason read off the state afterwards
+            int ovf = 0; bool alive = true;
+            for (int x = 31; x >= 0; --x) band_walk_col3<1 << 20, BW>(w, alive, x <= xin, x <= xin ? ra[x] : ((u32)rng() & mask), x <= xin ? rb_[x] : ((u32)rng() & mask), mlen, store, put, ovf);
+            if (ovf) { fprintf(stderr, "block %d: op index overflow\n", blk); return 1; }
+            st = band_walk_why(w, alive);
+        } else
+        for (int x = xin; x >= 0 && st == 0; --x) st = band_walk_col(w, ra[x], rb_[x], mlen, store, put);
+        if (st == 2) out = true;
+        else if (st == 0 && w.c < 0) { fprintf(stderr, "block %d: column ran out without the walk noticing\n", blk); return 1; }
+    }
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     const int nblocks = argc > 1 ? atoi(argv[1]) : 4000;
@@ -78,59 +132,14 @@ int main(int argc, char** argv)
         std::vector<int> ops_ref, ops_new;
         TailScan ts; tail_init(ts, mlen);
         { VecSink sk{&ops_ref, store}; walk_block(qn, endc + 1, fm, sk, ts); }
-        // ---- the kernel's way
+        // ---- the kernel's way, on records of 32 diagonals (k_rcwalk3<.., 32>) or of 16 (k_rcwalk3<.., 16>: half the LDS per block in flight)
         BandWalk w; memset(&w, 0, sizeof w); w.r = qn - 1; w.c = endc;
         VecSink sk{&ops_new, store};
         auto put = [&](int i, int op) { sk.put(i, op); };
-        bool out = false;
         long long myredo = 0;
-        int prev_seg = 1 << 30;
-        while (!out) {
-            const int seg = w.c >> 5, c0 = seg * 32, xin = w.c - c0, d0 = w.r - w.c, w1 = w.r >> 6;
-            if (seg == prev_seg) { ++redo; ++myredo; } prev_seg = seg; ++segs;
-            w.p = kBandP0;
-            u32 ra[32], rb_[32];
-            const int wl = band_word_lo(w.r), wh = wl + 1 < nw ? wl + 1 : nw - 1;      // the kernel's pair of words (ext_rcwalk3.h)
-            const bool general = (c0 + d0 - kBandP0 - 64 * wl) < 0;                   // some column's record starts above the pair: zero fill
-            for (int x = 0; x <= xin; ++x) {
-                const int col = c0 + x, rb = col + d0 - kBandP0, S = rb - 64 * wl;
-                u64 pa0, pb0, pa1, pb1; fm.rec(col, wl, pa0, pb0); fm.rec(col, wh, pa1, pb1);
-                if (wh == wl) { pa1 = rng(); pb1 = rng(); }                           // (the top word twice: its second copy is never looked at)
-                if (!general && (S < 0 || S >= 96)) { fprintf(stderr, "block %d: S = %d outside the fast form's range\n", blk, S); return 1; }
-                u32 a, b;
-                if (general) { a = band_piece2<true>((u32)pa0, (u32)(pa0 >> 32), (u32)pa1, (u32)(pa1 >> 32), S); b = band_piece2<true>((u32)pb0, (u32)(pb0 >> 32), (u32)pb1, (u32)(pb1 >> 32), S); }
-                else { a = band_piece2<false>((u32)pa0, (u32)(pa0 >> 32), (u32)pa1, (u32)(pa1 >> 32), S); b = band_piece2<false>((u32)pb0, (u32)(pb0 >> 32), (u32)pb1, (u32)(pb1 >> 32), S); }
-                if ((blk & 8) == 0) {      // and the four-lane form's pieces (band_piece per word, OR-ed): the same record where the walk can look
-                    u32 a2 = 0, b2 = 0;
-                    const int w1 = w.r >> 6;
-                    for (int k = 0; k < 2; ++k) {
-                        const int ww = w1 - 1 + k;
-                        if (ww < 0) continue;
-                        u64 qa, qb; fm.rec(col, ww, qa, qb);
-                        a2 |= band_piece(qa, rb - 64 * ww); b2 |= band_piece(qb, rb - 64 * ww);
-                    }
-                    for (int p = 0; p < 32; ++p) { const int row = rb + p; if (row <= w.r && (((a ^ a2) | (b ^ b2)) >> p & 1u)) { fprintf(stderr, "block %d: the two forms of the record differ at row %d\n", blk, row); return 1; } }
-                }
-                // rows above r (the walk only moves up): poison
-                for (int p = 0; p < 32; ++p) { const int row = rb + p; if (row > w.r) { a = (a & ~(1u << p)) | ((u32)(rng() & 1) << p); b = (b & ~(1u << p)) | ((u32)(rng() & 1) << p); } }
-                ra[x] = a; rb_[x] = b;
-            }
-            int st = 0;
-            if ((blk & 6) == 6) {    // the lean wave form: alive flag, the reason read off the state afterwards
-                int ovf = 0; bool alive = true;
-                for (int x = 31; x >= 0; --x) band_walk_col3<1 << 20>(w, alive, x <= xin, x <= xin ? ra[x] : (u32)rng(), x <= xin ? rb_[x] : (u32)rng(), mlen, store, put, ovf);
-                if (ovf) { fprintf(stderr, "block %d: op index overflow\n", blk); return 1; }
-                st = band_walk_why(w, alive);
-            } else
-            if (blk & 2) {       // the wave form (selects instead of branches): every column of the segment goes through it, active or not
-                int ovf = 0;
-                for (int x = 31; x >= 0; --x) band_walk_col2<1 << 20>(w, st, st == 0 && x <= xin, x <= xin ? ra[x] : (u32)rng(), x <= xin ? rb_[x] : (u32)rng(), mlen, store, put, ovf);
-                if (ovf) { fprintf(stderr, "block %d: op index overflow\n", blk); return 1; }
-            } else
-            for (int x = xin; x >= 0 && st == 0; --x) st = band_walk_col(w, ra[x], rb_[x], mlen, store, put);
-            if (st == 2) out = true;
-            else if (st == 0 && w.c < 0) { fprintf(stderr, "block %d: column ran out without the walk noticing\n", blk); return 1; }
-        }
+        const int bw = (blk & 16) ? 16 : 32;
+        const int rcw = bw == 16 ? kernel_walk<16>(blk, fm, nw, w, mlen, store, put, rng, redo, myredo, segs) : kernel_walk<32>(blk, fm, nw, w, mlen, store, put, rng, redo, myredo, segs);
+        if (rcw) return rcw;
         if (myredo > maxredo) maxredo = myredo;
         {   // the walk's epilogue (k_rcwalk2w / walk_block): the rest of the other sequence is one run of inserts / deletes
             const int kop = w.c < 0 ? 1 : 2, k = w.c < 0 ? w.r + 1 : w.c + 1;

@@ -81,13 +81,13 @@ int main(int argc, char** argv)
     }
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     CHECK(hipFuncSetAttribute((const void*)k_rcwalk2w<NW, TW, N, MAXOPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
-    CHECK(hipFuncSetAttribute((const void*)k_rcwalk3<NW, TW, N, MAXOPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
-    CHECK(hipFuncSetAttribute((const void*)k_rcwalk3p<NW, TW, N, MAXOPS>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
-    int kern = 4;            // 3: k_rcwalk3 (two waves per 64 blocks), 4: k_rcwalk3p (three waves, the two phases side by side)
+    CHECK(hipFuncSetAttribute((const void*)k_rcwalk3<NW, TW, N, MAXOPS, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
+    CHECK(hipFuncSetAttribute((const void*)k_rcwalk3<NW, TW, N, MAXOPS, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 << 10));
+    int kern = 4;            // 3: k_rcwalk3 on 32-diagonal records, 4: on 16-diagonal records
     auto launch3 = [&](u32 n, u32 lds, u8* o, WalkOut* w, u32 opts) {
-        if (kern == 4) hipLaunchKernelGGL((k_rcwalk3p<NW, TW, N, MAXOPS>), dim3((n + 63) / 64), dim3(192), lds, 0, (const BlockItem*)items, n, (const u32*)ndev, n, (const u64*)frag, (const ulonglong2*)ck,
+        if (kern == 4) hipLaunchKernelGGL((k_rcwalk3<NW, TW, N, MAXOPS, 16>), dim3((n + 63) / 64), dim3(128), lds, 0, (const BlockItem*)items, n, (const u32*)ndev, n, (const u64*)frag, (const ulonglong2*)ck,
                                           (const u64*)hc, (const BlockResult*)res, (const ExtTask*)tasks, 0, 8, o, w, stats, errf, 1u, 0u, n, opts);
-        else hipLaunchKernelGGL((k_rcwalk3<NW, TW, N, MAXOPS>), dim3((n + 63) / 64), dim3(128), lds, 0, (const BlockItem*)items, n, (const u32*)ndev, n, (const u64*)frag, (const ulonglong2*)ck,
+        else hipLaunchKernelGGL((k_rcwalk3<NW, TW, N, MAXOPS, 32>), dim3((n + 63) / 64), dim3(128), lds, 0, (const BlockItem*)items, n, (const u32*)ndev, n, (const u64*)frag, (const ulonglong2*)ck,
                                 (const u64*)hc, (const BlockResult*)res, (const ExtTask*)tasks, 0, 8, o, w, stats, errf, 1u, 0u, n, opts);
     };
     WalkOut* wout2; u8* ops2;
@@ -113,7 +113,7 @@ int main(int argc, char** argv)
         for (u32 x = 0; x < n; ++x) if (memcmp(&a[x], &b[x], sizeof(WalkOut))) { if (!bad_w) printf("  first WalkOut difference at block %u: n %d / %d, nmat %d / %d, hit %d / %d, acnt %d / %d\n", x, a[x].n, b[x].n, a[x].nmat, b[x].nmat, a[x].hit, b[x].hit, a[x].acnt, b[x].acnt); ++bad_w; }
         for (size_t i = 0; i < oa.size(); ++i) if (oa[i] != ob[i]) ++bad_o;
         int he = 0; CHECK(hipMemcpy(&he, errf, 4, hipMemcpyDeviceToHost));
-        printf("%s == k_rcwalk2w on %u blocks (%s): %zu WalkOut records differ, %zu op bytes differ, err %d  %s\n", kern == 4 ? "k_rcwalk3p" : "k_rcwalk3", n, found ? "lean" : "ops kept", bad_w, bad_o, he, (bad_w || bad_o || he) ? "MISMATCH" : "ok");
+        printf("%s == k_rcwalk2w on %u blocks (%s): %zu WalkOut records differ, %zu op bytes differ, err %d  %s\n", kern == 4 ? "k_rcwalk3/16" : "k_rcwalk3/32", n, found ? "lean" : "ops kept", bad_w, bad_o, he, (bad_w || bad_o || he) ? "MISMATCH" : "ok");
         return !(bad_w || bad_o || he);
     };
     bool ok = same(nmax, 1); ok = same(nmax, 0) && ok; ok = same(1000, 0) && ok;
@@ -132,7 +132,7 @@ int main(int argc, char** argv)
         }
         int he = 0; CHECK(hipMemcpy(&he, errf, 4, hipMemcpyDeviceToHost));
         WalkOut w0; CHECK(hipMemcpy(&w0, wout, sizeof w0, hipMemcpyDeviceToHost));
-        printf("%-10s %7u blocks (%4u workgroups) | %-58s | %8.1f us | %.2f ns per block | err %d, block 0: n %d nmat %d\n", kern == 4 ? "k_rcwalk3p" : "k_rcwalk3", n, (n + 63) / 64, what, best * 1e3, best * 1e6 / n, he, w0.n, w0.nmat);
+        printf("%-10s %7u blocks (%4u workgroups) | %-58s | %8.1f us | %.2f ns per block | err %d, block 0: n %d nmat %d\n", kern == 4 ? "k_rcwalk3/16" : "k_rcwalk3/32", n, (n + 63) / 64, what, best * 1e3, best * 1e6 / n, he, w0.n, w0.nmat);
     };
     for (kern = 4; kern >= 3; --kern) {
     if (kern == 3) { ok = same(nmax, 1) && ok; ok = same(nmax, 0) && ok; }
@@ -141,12 +141,11 @@ int main(int argc, char** argv)
     run3(nmax, 1, 8, 0, "lean, s_setprio 3");
     run3(nmax, 1, 16, 0, "lean, only the walking wave at s_setprio 3");
     run3(nmax, 1, 0, 0, "lean again");
-    run3(nmax, 1, 0, 2u << 10, "lean, 8 workgroups per CU (dynamic LDS)");
-    run3(nmax, 1, 0, 4u << 10, "lean, 7 workgroups per CU");
-    run3(nmax, 1, 0, 7u << 10, "lean, 6 workgroups per CU");
-    run3(nmax, 1, 0, 12u << 10, "lean, 5 workgroups per CU");
-    run3(nmax, 1, 0, 20u << 10, "lean, 4 workgroups per CU");
-    run3(nmax, 1, 0, 36u << 10, "lean, 3 workgroups per CU");
+    run3(nmax, 1, 0, 2u << 10, "lean, + 2 KB of dynamic LDS per workgroup");
+    run3(nmax, 1, 0, 6u << 10, "lean, + 6 KB");
+    run3(nmax, 1, 0, 12u << 10, "lean, + 12 KB");
+    run3(nmax, 1, 0, 20u << 10, "lean, + 20 KB");
+    run3(nmax, 1, 0, 36u << 10, "lean, + 36 KB");
     run3(110592, 1, 0, 0, "lean, half the list (the bench's typical big round)");
     run3(81920, 1, 0, 0, "lean, 5 workgroups per CU's worth");
     run3(16384, 1, 0, 0, "lean, one workgroup per CU");
