@@ -1827,13 +1827,15 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
         ctx->tm.extend_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
         return NECAT_OK;
     }
+    tick("filter");
     necat_m4* res = (necat_m4*)result_alloc(std::max<size_t>(1, nout) * sizeof(necat_m4));
     if (!res) { cleanup(); return set_err(ctx, NECAT_ERR_MEMORY, "host malloc failed"); }
+    tick("result block");
     if (nout) NECAT_HIP(ctx, hipMemcpyAsync(res, d_out, (size_t)nout * sizeof(necat_m4), hipMemcpyDeviceToHost, s));
     NECAT_HIP(ctx, hipEventRecord(ctx->ev[1], s));
     NECAT_HIP(ctx, hipStreamSynchronize(s));
     ctx->tm.extend_ms = ev_ms(ctx->ev[0], ctx->ev[1]);
-    tick("filter + copy to host");
+    tick("copy to host");
     cleanup();
     *out = res; *n_out = nout;
     return NECAT_OK;

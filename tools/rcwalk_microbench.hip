@@ -23,7 +23,8 @@ int main(int argc, char** argv)
     constexpr int NW = 8, TW = 16, FW = 2 * NW + TW, G = 8, N = 512, MAXOPS = 1024;
     const u32 nmax = 221184;                       // 3456 workgroups of 64 blocks: the size of the bench's big rounds
     const double err = argc > 1 ? atof(argv[1]) : 0.12;
-    const int store_pct = argc > 2 ? atoi(argv[2]) : 0;          // per cent of the blocks whose task keeps its ops in the "mixed" runs (task 1: found = 0)
+    const int store_pct = argc > 2 ? atoi(argv[2]) : 0;
+    const bool store_sorted = argc > 3 && atoi(argv[3]);   // the blocks that keep their ops at the back of the list instead of scattered over it          // per cent of the blocks whose task keeps its ops in the "mixed" runs (task 1: found = 0)
     std::vector<u64> hfrag((size_t)nmax * FW, 0);
     {
         std::mt19937_64 rng(12345);
@@ -64,7 +65,7 @@ int main(int argc, char** argv)
     CHECK(hipMalloc(&ops, (size_t)(nmax / 64) * MAXOPS * 64));
     {
         std::vector<BlockItem> hi(nmax);
-        for (u32 x = 0; x < nmax; ++x) { memset(&hi[x], 0, sizeof(BlockItem)); hi[x].task = ((x * 2654435761u) >> 8) % 100u < (u32)store_pct ? 1 : 0; hi[x].qn = (i16)N; hi[x].tn = (i16)N; }
+        for (u32 x = 0; x < nmax; ++x) { memset(&hi[x], 0, sizeof(BlockItem)); hi[x].task = (store_sorted ? (x >= (u32)((u64)nmax * (100 - store_pct) / 100)) : (((x * 2654435761u) >> 8) % 100u < (u32)store_pct)) ? 1 : 0; hi[x].qn = (i16)N; hi[x].tn = (i16)N; }
         CHECK(hipMalloc(&items, (size_t)nmax * sizeof(BlockItem))); CHECK(hipMemcpy(items, hi.data(), (size_t)nmax * sizeof(BlockItem), hipMemcpyHostToDevice));
         CHECK(hipMalloc(&tasks, 2 * sizeof(ExtTask)));
     }
