@@ -37,6 +37,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# hardware queues the HIP runtime maps its streams onto (default 4): the library's two extension lanes are eight streams and it sets this itself when it is loaded
+# (necat_hip.hip) - here too, before anything can initialise the runtime, so that the runs under rocprofv3 and torch.distributed see the same
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz (32-bit integer lane-ops)
@@ -1143,6 +1146,49 @@ def main():
         except Exception as e:  # the baseline is a reported extra; never fail the GPU measurement on it
             out["cpu_baseline"] = {"value": None, "unit": "overlaps/s", "cores": os.cpu_count(), "kind": "unavailable", "sample": str(e)}
         shutil.rmtree(tmp, ignore_errors=True)
+    if comm is None and world == 1 and args.job == 1 and not args.no_widened:
+        # the bench step's one batch of candidates cut in two that run side by side (NECAT_EXT_OVERLAP_MIN, knobs.h): what the second lane of the extension rounds
+        # is worth at this size - a context of its own (knobs are per context), same volume bytes, 1 warm-up + 5 timed passes.  The bench's own context is closed
+        # first: two live contexts' streams share the runtime's hardware queues, and lanes whose streams share a queue run one after the other (tools/r05/run22.sh:
+        # 45 ms as a second context, 36 as the only one)
+        try:
+            vol.free(); ctx.close()
+            env2 = {"NECAT_EXT_OVERLAP_MIN": "131072", "NECAT_EXT_OVERLAP_SPLIT": "20", "NECAT_RC3_MIN": "130000"}
+            old_env = {k_: os.environ.get(k_) for k_ in env2}
+            os.environ.update(env2)
+            try:
+                ctx2 = capi.Context(local)
+            finally:
+                for k_, v_ in old_env.items():
+                    if v_ is None:
+                        os.environ.pop(k_, None)
+                    else:
+                        os.environ[k_] = v_
+            v2 = ctx2.upload_volume(pac, rs.nbases, rs.offsets, rs.sizes)
+            n2 = 0
+            ext2 = 0.0
+            held2 = None
+            for it in range(6):
+                if it == 1:
+                    t1 = time.perf_counter()
+                ix2 = ctx2.build_index(v2, opt.kmer_size, opt.kmer_cnt_cutoff)
+                m2, _ = ctx2.map_pair(ix2, v2, v2, 0, 0, opt, True, 1)
+                if it:
+                    n2 += m2.shape[0]; ext2 += ctx2.timings().extend_ms
+                else:
+                    held2 = m2          # (both pinned result blocks of the library's pool exist before the clock starts)
+                ix2.free()
+            dt = time.perf_counter() - t1
+            out["two_lanes_one_batch_cut"] = {"ms_per_step": round(1e3 * dt / 5, 2), "extend_ms": round(ext2 / 5, 2), "overlaps_per_s": round(n2 / dt, 1), "records_per_step": n2 // 5,
+                                                 "knobs": " ".join("%s=%s" % kv for kv in sorted(env2.items())),
+                                                 "note": "A/B, not the headline: the step's 228 k candidates as two batches (the 20 % longest chains first) whose rounds run side by side on the "
+                                                         "two lanes that calls of several batches use by default (yeast size: 300.7 -> 278 - 283 ms per step); same records.  At this size the gain is "
+                                                         "inside the run-to-run spread - 36.8 to 39.6 ms against 38.8 to 39.3 on one lane (tools/r05/run19, run24) - so ONE batch stays on one lane, "
+                                                         "which also keeps `roofline` (priced on its launches' event durations) free of launches that share the chip (knobs.h, NOTES_r05 6)"}
+            del held2
+            v2.free(); ctx2.close()
+        except Exception as e:
+            out["two_lanes_one_batch_cut"] = {"error": str(e)}
     sys.stdout.flush()
     os.write(json_fd, (json.dumps(out) + "\n").encode())
     if comm is not None:

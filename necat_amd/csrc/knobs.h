@@ -17,6 +17,16 @@ struct Knobs {
     u32 coop_threshold;
     unsigned long long seed_budget;   // seeding scratch budget per chunk, in k-mer hits
     u32 batch_cap;       // candidates per extension batch (NECAT_BATCH)
+    // NECAT_EXT_OVERLAP (default 1): a call of two or more batches runs them two at a time, side by side (two lanes: ExtLane, necat_hip.hip) - the other batch's
+    // kernels fill the drain / ramp-up of every round's kernels and the ~ 15 latency-bound rounds a batch ends in.  0 = one batch after the other.
+    // NECAT_EXT_OVERLAP_PCT (default 100): the next batch starts as soon as a lane is free; < 100: only when fewer than that per cent of the batch started last
+    // still have a block to align (70: 293.7 against 277.5 ms per step at yeast size).
+    // NECAT_EXT_OVERLAP_MIN (default 0 = never): a call of ONE batch of at least this many candidates is cut in two for the same effect, NECAT_EXT_OVERLAP_SPLIT per
+    // cent (default 20: the longest chains) in the first.  E. coli size: 36.8 - 39.6 ms per step against 38.8 - 39.3 on one lane, depending on which of the process's
+    // streams the runtime has put on one hardware queue (tools/r05/run19, run22, run24): not a reliable gain, so not the default - which also keeps the bench line's
+    // roofline (priced on its kernels' event durations) free of launches that share the chip.
+    u32 ext_overlap_order;       // NECAT_EXT_ORDER=0: several batches take the candidates as they come instead of longest expected chain first (A/B)
+    u32 ext_overlap, ext_overlap_min, ext_overlap_pct, ext_overlap_split;      
     u32 single_pass;     // lists up to this many blocks use the single-pass DP kernel (NECAT_SINGLE_PASS; 0 = never)
     int index_lds;       // LDS-slice index passes (NECAT_INDEX_LDS=0: global-atomic bucket passes)
     int split_threads;   // NECAT_SPLIT_THREADS (512, or 256 = until round 5): threads of a workgroup of the index build's split kernels (k_split_bases, k_split_recs, k_subpart), each on a 4096-record tile
@@ -61,6 +71,11 @@ extern thread_local const Knobs* tl_knobs;      // the knobs of the context whos
 #define g_coop_threshold (necat::tl_knobs->coop_threshold)
 #define g_seed_budget (necat::tl_knobs->seed_budget)
 #define g_batch_cap (necat::tl_knobs->batch_cap)
+#define g_ext_overlap (necat::tl_knobs->ext_overlap)
+#define g_ext_overlap_min (necat::tl_knobs->ext_overlap_min)
+#define g_ext_overlap_pct (necat::tl_knobs->ext_overlap_pct)
+#define g_ext_overlap_split (necat::tl_knobs->ext_overlap_split)
+#define g_ext_overlap_order (necat::tl_knobs->ext_overlap_order)
 #define g_single_pass (necat::tl_knobs->single_pass)
 #define g_index_lds (necat::tl_knobs->index_lds)
 #define g_split_threads (necat::tl_knobs->split_threads)

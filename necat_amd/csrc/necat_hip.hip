@@ -3,6 +3,7 @@
 // residency of whole volumes, work lists and the traceback band of 10^5 concurrent alignments.
 #include <algorithm>
 #include <chrono>
+#include <memory>
 #include <mutex>
 #include <unordered_map>
 #include <time.h>
@@ -25,6 +26,11 @@
 #include "rm_host.h"
 #include "comm.h"
 #include "pair_sched.h"
+
+// The two lanes of the extension rounds are eight streams; the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams
+// that share a queue run one after the other - with 4 queues the second lane gains 3.7 % at yeast size, with 8 it gains 7.7 % (tools/r05/run20.sh).  The variable is read
+// when the runtime initialises (the first HIP call of the process), so it is set - unless the user has - when this library is loaded.
+__attribute__((constructor)) static void necat_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 namespace necat { thread_local const Knobs* tl_knobs = nullptr; }      // knobs.h: set by KnobScope in every entry point that takes a context
 using namespace necat;
@@ -105,6 +111,11 @@ void read_knobs(necat::Knobs& K)
     K.rc_maxdist = (int)num("NECAT_RC_MAXDIST", K.rc_carry ? 1 << 20 : kRcMaxDist);
     if (!K.rc_carry) K.rc_maxdist = std::min(K.rc_maxdist, kRcMaxDist);
     K.batch_cap = (u32)std::max<unsigned long long>(64, num("NECAT_BATCH", 786432));
+    K.ext_overlap = (u32)num("NECAT_EXT_OVERLAP", 1);
+    K.ext_overlap_min = (u32)num("NECAT_EXT_OVERLAP_MIN", 0);
+    K.ext_overlap_pct = (u32)std::min<unsigned long long>(100, num("NECAT_EXT_OVERLAP_PCT", 100));
+    K.ext_overlap_order = (u32)num("NECAT_EXT_ORDER", 1);
+    K.ext_overlap_split = (u32)std::min<unsigned long long>(95, std::max<unsigned long long>(5, num("NECAT_EXT_OVERLAP_SPLIT", 20)));
     K.index_lds = (int)num("NECAT_INDEX_LDS", 1);
     K.split_threads = num("NECAT_SPLIT_THREADS", 512) == 256 ? 256 : 512;
     K.seed_wave = (int)num("NECAT_SEED_WAVE", 1);
@@ -160,9 +171,9 @@ int necat_ctx_create(int device_id, necat_ctx** out)
     if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
     for (int i = 0; i < kNumEvents; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
     // the list sizes of the extension rounds reach the host through this pinned ring (RoundPub, ext_kernels.h)
-    if (hipHostMalloc(&ctx->round_ring, kRoundRing * sizeof(RoundPub), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+    if (hipHostMalloc(&ctx->round_ring, 2 * kRoundRing * sizeof(RoundPub), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer(&ctx->round_ring_dev, ctx->round_ring, 0) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
-    memset(ctx->round_ring, 0, kRoundRing * sizeof(RoundPub));
+    memset(ctx->round_ring, 0, 2 * kRoundRing * sizeof(RoundPub));      // (lane 1's half: ExtLane1)
     *out = ctx;
     return NECAT_OK;
 }
@@ -184,6 +195,9 @@ void necat_ctx_destroy(necat_ctx* ctx)
     if (ctx->stream_copy) (void)hipStreamSynchronize(ctx->stream_copy);
     for (auto& b : ctx->scratch) if (b.p) (void)hipFree(b.p);
     for (auto& b : ctx->idx_cache) if (b.p) (void)hipFree(b.p);
+    for (auto& b : ctx->lane1.buf) if (b.p) (void)hipFree(b.p);
+    if (ctx->lane1.ready) for (int i = 0; i < kNumEvents; ++i) (void)hipEventDestroy(ctx->lane1.ev[i]);
+    for (hipStream_t st : ctx->lane1.st) if (st) (void)hipStreamDestroy(st);
     delete (cns::Scratch*)ctx->cns_scratch;
     if (ctx->pin_plan) (void)hipHostFree(ctx->pin_plan);
     for (int i = 0; i < kNumEvents; ++i) (void)hipEventDestroy(ctx->ev[i]);
@@ -201,6 +215,7 @@ void necat_ctx_trim(necat_ctx* ctx)
     (void)hipDeviceSynchronize();
     for (auto& b : ctx->scratch) if (b.p) { (void)hipFree(b.p); b = DevBuf(); }
     for (auto& b : ctx->idx_cache) if (b.p) { (void)hipFree(b.p); b = DevBuf(); }
+    for (auto& b : ctx->lane1.buf) if (b.p) { (void)hipFree(b.p); b = DevBuf(); }
     ctx->seed_ht_ptr = nullptr; ctx->seed_ht_clean = 0; ctx->seed_ht_cap = 0;
 }
 
@@ -1123,21 +1138,80 @@ struct ExtShared {
     u8* task_ops = nullptr;      // alignment columns per task (necat_onc_align_batch)
 };
 
-// all rounds of one batch (its first blocks are already in lists[0], appended by k_ext_init on stream a; every list
-// counter but lists[0]'s is zero)
-int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch& c, const ExtShared& X)
+// One lane of the extension rounds: everything run-to-run state of a batch in flight lives in - arenas, streams, events, its half of the
+// published-sizes ring.  Lane 0 is the context's own set; lane 1 (ExtLane1, runtime.h) exists so that the NEXT batch can run its first,
+// chip-filling rounds while this one is in its last, latency-bound ones (extend_impl).
+enum ExtLaneBuf { LB_TASKS = 0, LB_LISTS, LB_FRAG, LB_OPS, LB_RES, LB_MAT, LB_CKPT, LB_WOUT, LB_CKPTB, LB_CKPTB2, LB_WOUTB, LB_WOUTB2, LB_MATB, LB_MATB2, LB_COUNT };
+static_assert(LB_COUNT <= (int)(sizeof(ExtLane1::buf) / sizeof(necat::DevBuf)), "a lane-1 arena without a slot");
+struct ExtLane {
+    DevBuf *tasks, *lists, *frag, *ops, *res, *mat, *ckpt, *wout, *ckptb[2], *woutb[2], *matb[2];
+    hipStream_t sa, sb[2], sd;
+    hipEvent_t* ev;                                   // kNumEvents of them, used as necat_ctx::ev is
+    volatile RoundPub* ring; RoundPub* ring_dev;      // kRoundRing entries
+    unsigned long long* round_seq;
+};
+
+int ext_lane(necat_ctx* ctx, int id, ExtLane& L)
 {
+    if (id == 0) {
+        DevBuf* S = ctx->scratch;
+        L.tasks = S + SC_EXT_TASKS; L.lists = S + SC_EXT_LISTS; L.frag = S + SC_EXT_FRAG; L.ops = S + SC_EXT_OPS; L.res = S + SC_EXT_RES; L.mat = S + SC_EXT_MAT;
+        L.ckpt = S + SC_EXT_CKPT; L.wout = S + SC_EXT_WOUT; L.ckptb[0] = S + SC_EXT_CKPTB; L.ckptb[1] = S + SC_EXT_CKPTB2; L.woutb[0] = S + SC_EXT_WOUTB; L.woutb[1] = S + SC_EXT_WOUTB2;
+        L.matb[0] = S + SC_EXT_MATB; L.matb[1] = S + SC_EXT_MATB2;
+        L.sa = ctx->stream_a; L.sb[0] = ctx->stream_b; L.sb[1] = ctx->stream_c; L.sd = ctx->stream_d;
+        L.ev = ctx->ev;
+        L.ring = (volatile RoundPub*)ctx->round_ring; L.ring_dev = (RoundPub*)ctx->round_ring_dev; L.round_seq = &ctx->round_seq;
+        return NECAT_OK;
+    }
+    ExtLane1& Q = ctx->lane1;
+    if (!Q.ready) {
+        // Four streams of its own, at the device's LOWEST stream priority (NECAT_LANE1_PRIO: 0 = normal, 1 = lowest - the default -, 2 = highest): the runtime keeps
+        // a pool of hardware queues per priority level (GPU_MAX_HW_QUEUES each), so these streams never share a queue with lane 0's - kernels of streams that share
+        // a queue run one after the other, and which streams share is the runtime's choice (tools/r05/run22.sh: the same two-lane step took 36 or 45 ms depending on
+        // the streams another context had made before) - and lane 0, which holds the longest chains of a call, is served first where both have waves to place.
+        static const int lane_prio = getenv("NECAT_LANE1_PRIO") ? atoi(getenv("NECAT_LANE1_PRIO")) : 1;
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+        const int pr = lane_prio == 1 ? least : lane_prio == 2 ? greatest : 0;
+        for (hipStream_t& st : Q.st)
+            if (!st && (lane_prio && least != greatest ? hipStreamCreateWithPriority(&st, hipStreamDefault, pr) : hipStreamCreate(&st)) != hipSuccess)
+                return set_err(ctx, NECAT_ERR_DEVICE, "hipStreamCreate failed (second extension lane)");
+        for (int i = 0; i < kNumEvents; ++i) if (hipEventCreate(&Q.ev[i]) != hipSuccess) return set_err(ctx, NECAT_ERR_DEVICE, "hipEventCreate failed (second extension lane)");
+        Q.ready = true;
+    }
+    DevBuf* S = Q.buf;
+    L.tasks = S + LB_TASKS; L.lists = S + LB_LISTS; L.frag = S + LB_FRAG; L.ops = S + LB_OPS; L.res = S + LB_RES; L.mat = S + LB_MAT;
+    L.ckpt = S + LB_CKPT; L.wout = S + LB_WOUT; L.ckptb[0] = S + LB_CKPTB; L.ckptb[1] = S + LB_CKPTB2; L.woutb[0] = S + LB_WOUTB; L.woutb[1] = S + LB_WOUTB2;
+    L.matb[0] = S + LB_MATB; L.matb[1] = S + LB_MATB2;
+    L.sa = Q.st[0]; L.sb[0] = Q.st[1]; L.sb[1] = Q.st[2]; L.sd = Q.st[3];
+    L.ev = Q.ev;
+    L.ring = (volatile RoundPub*)ctx->round_ring + kRoundRing; L.ring_dev = (RoundPub*)ctx->round_ring_dev + kRoundRing; L.round_seq = &Q.round_seq;
+    return NECAT_OK;
+}
+
+// All rounds of one batch (its first blocks are already in lists[0], appended by k_ext_init on stream a; every list counter but lists[0]'s is
+// zero) as a resumable loop: run() is the whole of it; with two lanes (extend_impl) the scheduler calls step() on whichever batch has its next
+// sizes published.
+struct BatchRun {
+    necat_ctx* ctx; const DevVolume& dref; const DevVolume& drd; Batch& c; const ExtShared& X; const ExtLane& L;
     struct Cnt { u32 nA, nB; };
     std::vector<Cnt> hist;                      // published sizes of lists[r]
-    std::vector<u32> rc_round;                  // rounds whose full blocks ran through ext_rcwalk.h (ev[26 + r % 4] marks the end of k_rcwalk4)
+    std::vector<u32> rc_round;                  // rounds whose full blocks ran through ext_rcwalk.h (L.ev[26 + r % 4] marks the end of the walk kernel)
     std::vector<u8> a_timed;                    // A(r) ran its DP + traceback kernels (events recorded); 2 = as one fused launch (ext_tail.h)
-    const unsigned long long seq0 = ctx->round_seq;
-    volatile RoundPub* ring = (volatile RoundPub*)ctx->round_ring;
-    RoundPub* ring_dev = (RoundPub*)ctx->round_ring_dev;
+    const unsigned long long seq0;
+    volatile RoundPub* const ring;
+    RoundPub* const ring_dev;
     bool b_pending[2] = {false, false}, b_fused[2] = {false, false};
     u32 b_blocks[2] = {0, 0};
-    double last_wall = wall_ms();
-    auto wait_pub = [&](u32 r, Cnt& out) -> int {
+    double last_wall;
+    u32 rnd = 0, launched = 0;                  // the next round to launch; rounds launched
+    bool tail = false;                          // fewer than NECAT_EXT_OVERLAP_PCT per cent of the batch's candidates still have a block: the next batch may start beside this one
+    bool over = false;                          // nothing alive (or an error): finish() is next
+    BatchRun(necat_ctx* ctx_, const DevVolume& dref_, const DevVolume& drd_, Batch& c_, const ExtShared& X_, const ExtLane& L_)
+        : ctx(ctx_), dref(dref_), drd(drd_), c(c_), X(X_), L(L_), seq0(*L_.round_seq), ring(L_.ring), ring_dev(L_.ring_dev), last_wall(wall_ms()) {}
+
+    int wait_pub(u32 r, Cnt& out)
+    {
         const unsigned long long want = seq0 + r + 1;
         volatile RoundPub* e = &ring[(seq0 + r) % kRoundRing];
         const double t0 = wall_ms();
@@ -1152,8 +1226,9 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         out.nA = e->nA; out.nB = e->nB;
         return NECAT_OK;
-    };
-    auto account_a = [&](u32 r) {
+    }
+    void account_a(u32 r)
+    {
         if (r >= a_timed.size() || !a_timed[r]) return;
         const int q = r % 4;
         const u32 nA = hist[r].nA;
@@ -1167,7 +1242,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         }
         const double mA = ev_ms(c.a0[q], c.a1[q]), tA = ev_ms(c.a1[q], c.a2[q]);
         ctx->tm.myers_ms += mA; ctx->tm.traceback_ms += tA;
-        if (std::find(rc_round.begin(), rc_round.end(), r) != rc_round.end()) { ctx->tm.rc_ms += ev_ms(c.a1[q], ctx->ev[26 + (r & 3)]); ctx->tm.rc_ck_ms += mA; ctx->tm.rc_launches += 1; }
+        if (std::find(rc_round.begin(), rc_round.end(), r) != rc_round.end()) { ctx->tm.rc_ms += ev_ms(c.a1[q], L.ev[26 + (r & 3)]); ctx->tm.rc_ck_ms += mA; ctx->tm.rc_launches += 1; }
         if (nA > g_single_pass) {      // the two-pass instantiation k_myers_coop<8,16,512,8,false> (bench.py's roofline kernel)
             ctx->tm.myersA_ms += mA; ctx->tm.tracebackA_ms += tA; ctx->tm.myersA_launches += 1; ctx->tm.myersA_blocks += nA;
         }
@@ -1180,8 +1255,9 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
             last_wall = now;
         }
         a_timed[r] = 0;
-    };
-    auto account_b = [&](int slot) {
+    }
+    void account_b(int slot)
+    {
         if (!b_pending[slot]) return;
         if (b_fused[slot]) {
             const double f = ev_ms(c.b0[slot], c.b2[slot]);
@@ -1195,9 +1271,10 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         ctx->tm.myers_launches += 1; ctx->tm.myers_blocks += b_blocks[slot];
         if (g_trace & 1) fprintf(stderr, "[necat]          list B: %7u blocks  myers %.3f ms traceback %.3f ms\n", b_blocks[slot], mB, tB);
         b_pending[slot] = false;
-    };
+    }
     // ---- B(q): exact size known (published by A(q)'s first kernel)
-    auto launch_b = [&](u32 q, u32 nB) -> int {
+    int launch_b(u32 q, u32 nB)
+    {
         const int slot = q & 1;
         account_b(slot);                                        // B(q - 2), the previous user of this slot, is done (A(q + 0) started after it)
         const u32 gB = (nB + 63) / 64;
@@ -1225,8 +1302,8 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
             // pass instead of two, no band records, the walk on LDS
             constexpr size_t per_ck = (size_t)RcGeom<kColsB>::kCk * kWordsB * sizeof(ulonglong2), per_hc = (size_t)RcGeom<kColsB>::kSeg * kWordsB * sizeof(u64);
             const u32 rc_chunk = (u32)std::max<size_t>(64, std::min<size_t>((size_t)gB * 64, (g_rc_pool / (per_ck + per_hc)) & ~(size_t)63));
-            DevBuf& ckb = ctx->scratch[slot ? SC_EXT_CKPTB2 : SC_EXT_CKPTB];
-            DevBuf& wob = ctx->scratch[slot ? SC_EXT_WOUTB2 : SC_EXT_WOUTB];
+            DevBuf& ckb = *L.ckptb[slot];
+            DevBuf& wob = *L.woutb[slot];
             int rc2;
             if ((rc2 = buf_ensure(ctx, ckb, (size_t)rc_chunk * (per_ck + per_hc))) || (rc2 = buf_ensure(ctx, wob, (size_t)gB * 64 * sizeof(WalkOut)))) return rc2;
             ulonglong2* ck = (ulonglong2*)ckb.p;
@@ -1263,7 +1340,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
             b_pending[slot] = true; b_blocks[slot] = nB;
             return NECAT_OK;
         }
-        DevBuf& poolB = ctx->scratch[slot ? SC_EXT_MATB2 : SC_EXT_MATB];
+        DevBuf& poolB = *L.matb[slot];
         // a capped band pool (NECAT_BAND_POOL_MB): the list in chunks of what the pool holds, DP + walk per chunk
         u32 gchunk = gB;
         if (g_band_pool && (size_t)gB * kSlabB > g_band_pool) gchunk = (u32)std::max<size_t>(1, g_band_pool / kSlabB);
@@ -1321,9 +1398,10 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         NECAT_HIP(ctx, hipEventRecord(c.b2[slot], sb));
         b_pending[slot] = true; b_blocks[slot] = nB;
         return NECAT_OK;
-    };
+    }
     // ---- A(r): grid sized by an upper bound, the kernels read the exact size of lists[r]
-    auto launch_a = [&](u32 r, u32 bound) -> int {
+    int launch_a(u32 r, u32 bound)
+    {
         const int cur = r % 4, nxt = (r + 1) % 4, nxt2 = (r + 2) % 4;
         if (g_tail_fused && bound && bound <= g_tail_fused) {
             // a small list: one launch for the round (ext_tail.h); the round's bookkeeping first, as a launch of its own - list B's
@@ -1354,9 +1432,9 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         const bool wide_possible = g_rc_maxdist < (int)((double)kOcaBlockSize * X.error * 1.1);       // (edlib_ex.c:751: no block has a larger distance)
         const bool rc_band = !g_rc_ragged || wide_possible;                                            // the round still needs the band pool (whole list: slabs are indexed by work index)
         const bool use_rc = g_rcwalk && bound > g_rcwalk && bound <= g_coop_threshold && g_fast == 1 && g_coop_filter && (!rc_band || gchunk == gA);
-        if ((!use_rc || rc_band) && (size_t)gchunk * kSlabA > ctx->scratch[SC_EXT_MAT].cap) {
+        if ((!use_rc || rc_band) && (size_t)gchunk * kSlabA > (*L.mat).cap) {
             const size_t need = (size_t)gchunk * kSlabA;
-            int rc = ensure_zeroed(ctx, ctx->scratch[SC_EXT_MAT], gchunk < gA ? need : need + need / 8, c.sa);
+            int rc = ensure_zeroed(ctx, (*L.mat), gchunk < gA ? need : need + need / 8, c.sa);
             if (rc) return rc;
         }
         const BlockItem* itA = c.itemsA[cur];
@@ -1380,15 +1458,15 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
             const size_t per_item = (size_t)(g_rc_carry ? kRcCk16 : kRcCk) * 8 * sizeof(ulonglong2), per_item_hc = g_rc_carry ? (size_t)kRcCk * 8 * sizeof(u64) : 0;
             const u32 rc_chunk = (u32)std::max<size_t>(64, std::min<size_t>((size_t)gA * 64, (g_rc_pool / (per_item + per_item_hc)) & ~(size_t)63));
             const size_t ck_bytes = (size_t)rc_chunk * per_item;
-            if ((rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_CKPT], ck_bytes + (size_t)rc_chunk * per_item_hc)) ||
-                (rc2 = buf_ensure(ctx, ctx->scratch[SC_EXT_WOUT], (size_t)gA * 64 * sizeof(WalkOut)))) return rc2;
-            ulonglong2* ck = (ulonglong2*)ctx->scratch[SC_EXT_CKPT].p;
-            u64* hcar = (u64*)((char*)ctx->scratch[SC_EXT_CKPT].p + ck_bytes);
-            WalkOut* wo = (WalkOut*)ctx->scratch[SC_EXT_WOUT].p;
-            char* slabsA = (char*)ctx->scratch[SC_EXT_MAT].p;
+            if ((rc2 = buf_ensure(ctx, (*L.ckpt), ck_bytes + (size_t)rc_chunk * per_item_hc)) ||
+                (rc2 = buf_ensure(ctx, (*L.wout), (size_t)gA * 64 * sizeof(WalkOut)))) return rc2;
+            ulonglong2* ck = (ulonglong2*)(*L.ckpt).p;
+            u64* hcar = (u64*)((char*)(*L.ckpt).p + ck_bytes);
+            WalkOut* wo = (WalkOut*)(*L.wout).p;
+            char* slabsA = (char*)(*L.mat).p;
             // the ragged blocks (and, once k_myers_ck has flagged them, the wide ones) on a stream of their own: a lane-per-block walk
             // of a tenth of the list is as long as one of the whole list (latency bound) - it runs beside the full blocks' chain
-            hipStream_t sd = ctx->stream_d;
+            hipStream_t sd = L.sd;
             const u32 fl_rag = epoch | (1u << 26), fl_wide = epoch | (1u << 25), fl_all = g_rc_ragged ? epoch | (1u << 27) : epoch;
             if (!g_rc_ragged) {
                 NECAT_HIP(ctx, hipStreamWaitEvent(sd, c.a0[cur], 0));            // the fragments are there
@@ -1426,7 +1504,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                                        (merged ? fl_all : epoch) | (g_ck_post ? 0u : 1u << 24) | (g_rc_prio & 2u ? 1u << 23 : 0u));
                 else
                     hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA, false>), dim3((cn + 7) / 8), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error, c.resA, X.stats, g_rc_maxdist, lo, hi, epoch);
-                if (piped) { NECAT_HIP(ctx, hipEventRecord(ctx->ev[40 + (ci & 7)], c.sa)); NECAT_HIP(ctx, hipStreamWaitEvent(sw, ctx->ev[40 + (ci & 7)], 0)); }
+                if (piped) { NECAT_HIP(ctx, hipEventRecord(L.ev[40 + (ci & 7)], c.sa)); NECAT_HIP(ctx, hipStreamWaitEvent(sw, L.ev[40 + (ci & 7)], 0)); }
                 if (g_rc_ragged && !merged) {
                     // the ragged blocks of the chunk (the back of the work index space): the general SHW pass, same checkpoints.  A tenth of
                     // the blocks, few waves, latency bound: beside the full blocks' pass on a stream of its own when the list is one chunk
@@ -1437,7 +1515,7 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                     if (one_chunk) {       // .. and their walk there too: the full blocks' walk need not wait for this pass (as long as the full blocks' own)
                         launch_rcwalk2<kWordsA, kTWordsA, kColsA, kOpsA>(cn, sd, itA, bound, d_nA, c.cap, (const u64*)c.fragA, (const ulonglong2*)ck,
                                            (const u64*)hcar, (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsA, wo, X.stats, X.d_err, fl_rag, lo, hi);
-                        NECAT_HIP(ctx, hipEventRecord(ctx->ev[30], sd));
+                        NECAT_HIP(ctx, hipEventRecord(L.ev[30], sd));
                     }
                 }
                 NECAT_CHECK_LAUNCH(ctx, "k_myers_ck");
@@ -1451,8 +1529,8 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                                        (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsA, wo, X.stats, X.d_err, lo, hi);
                 NECAT_CHECK_LAUNCH(ctx, "k_rcwalk");
             }
-            NECAT_HIP(ctx, hipEventRecord(ctx->ev[26 + (r & 3)], piped ? sd : c.sa));       // a1 -> this: the walk kernel alone (account_a; of the last chunk, normally the only one)
-            if (piped) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, ctx->ev[26 + (r & 3)], 0));          // the finishing kernel reads what the walks left
+            NECAT_HIP(ctx, hipEventRecord(L.ev[26 + (r & 3)], piped ? sd : c.sa));       // a1 -> this: the walk kernel alone (account_a; of the last chunk, normally the only one)
+            if (piped) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, L.ev[26 + (r & 3)], 0));          // the finishing kernel reads what the walks left
             if (wide_possible) {
                 NECAT_HIP(ctx, hipStreamWaitEvent(sd, c.a1[cur], 0));            // k_myers_ck has flagged the wide blocks
                 hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3(gA * 8), dim3(64), 0, sd, itA, bound, d_nA, c.cap,
@@ -1462,18 +1540,18 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
                                    (i32*)nullptr, X.d_err, next, fl_wide, 0u);
                 NECAT_CHECK_LAUNCH(ctx, "k_myers / k_traceback<A, wide>");
             }
-            if (!g_rc_ragged || wide_possible) NECAT_HIP(ctx, hipEventRecord(ctx->ev[25], sd));
-            if (g_rc_ragged && one_chunk && !(g_rc_merge && g_rc_carry && !getenv("NECAT_RC_CKG_ALL"))) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, ctx->ev[30], 0));       // the ragged blocks are walked
+            if (!g_rc_ragged || wide_possible) NECAT_HIP(ctx, hipEventRecord(L.ev[25], sd));
+            if (g_rc_ragged && one_chunk && !(g_rc_merge && g_rc_carry && !getenv("NECAT_RC_CKG_ALL"))) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, L.ev[30], 0));       // the ragged blocks are walked
             rc_round.push_back(r);
             hipLaunchKernelGGL((k_traceback<kWordsA, kTWordsA, kColsA, kOpsA, false, 5, kOcaBlockSize, false, 4>), dim3((gA + 3) / 4), dim3(256), 0, c.sa, itA, bound, d_nA, c.cap,
                                (const u64*)c.fragA, (const char*)slabsA, kSlabA, (const BlockResult*)c.resA, c.opsA, c.tasks, X.tail_match_len,
                                (i32*)nullptr, X.d_err, next, fl_all, 0u, (const WalkOut*)wo);
             NECAT_CHECK_LAUNCH(ctx, "k_traceback<A, rc>");
-            if (!g_rc_ragged || wide_possible) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, ctx->ev[25], 0));          // the round is over when both chains are
+            if (!g_rc_ragged || wide_possible) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, L.ev[25], 0));          // the round is over when both chains are
         } else
         for (u32 g0 = 0; g0 < gA; g0 += gchunk) {
             const u32 lo = g0 * 64, hi = std::min(gA, g0 + gchunk) * 64, cn = hi - lo;           // work indices of this chunk (the kernels know the exact list)
-            char* slabsA = (char*)ctx->scratch[SC_EXT_MAT].p - (size_t)g0 * kSlabA;             // the kernels index slabs by work index / 64
+            char* slabsA = (char*)(*L.mat).p - (size_t)g0 * kSlabA;             // the kernels index slabs by work index / 64
             if (bound <= g_single_pass && bound <= g_coop_threshold)
                 hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8, true>), dim3(cn / 8), dim3(64), 0, c.sa, itA, bound, d_nA, c.cap,
                                    (const u64*)c.fragA, slabsA, kSlabA, X.error, c.resA, X.stats, epoch, lo);
@@ -1505,40 +1583,63 @@ int run_batch(necat_ctx* ctx, const DevVolume& dref, const DevVolume& drd, Batch
         NECAT_HIP(ctx, hipEventRecord(c.a2[cur], c.sa));
         a_timed[r] = 1;
         return NECAT_OK;
-    };
-    int rc = NECAT_OK;
-    u32 launched = 0;
-    for (u32 r = 0;; ++r) {
+    }
+    // the sizes of lists[rnd] have been published (round 0: k_ext_init filled them): step() will not wait
+    bool ready() const { return rnd == 0 || ring[(seq0 + rnd - 1) % kRoundRing].seq == seq0 + rnd; }
+    // one turn of the round loop: the published sizes of lists[rnd], list B of round rnd - 1, list A of round rnd
+    int step()
+    {
+        int rc;
         u32 bound = c.n + 16;
-        if (r > 0) {
+        if (rnd > 0) {
             Cnt prev;
-            if ((rc = wait_pub(r - 1, prev))) break;          // A(r - 1) has started: A(r - 2) and B(r - 3) are done
+            if ((rc = wait_pub(rnd - 1, prev))) { over = true; return rc; }          // A(rnd - 1) has started: A(rnd - 2) and B(rnd - 3) are done
             hist.push_back(prev);
-            if (r >= 2) account_a(r - 2);
-            const u32 nB2 = r >= 2 ? hist[r - 2].nB : 0;     // B(r - 2) may still be running: its successors join lists[r]
-            if (prev.nA + prev.nB + nB2 == 0) break;          // nothing alive
-            if (prev.nB) { if ((rc = launch_b(r - 1, prev.nB))) break; }
+            if (rnd >= 2) account_a(rnd - 2);
+            const u32 nB2 = rnd >= 2 ? hist[rnd - 2].nB : 0;     // B(rnd - 2) may still be running: its successors join lists[rnd]
+            const u64 alive = (u64)prev.nA + prev.nB + nB2;
+            if (alive * 100 < (u64)c.n * g_ext_overlap_pct) tail = true;
+            if (alive == 0) { over = tail = true; return NECAT_OK; }          // nothing alive
+            if (prev.nB) { if ((rc = launch_b(rnd - 1, prev.nB))) { over = true; return rc; } }
             bound = prev.nA + nB2 + 16;                     // work indices: the full blocks rounded up to 16, then the others
         }
-        if ((rc = launch_a(r, bound))) break;
-        launched = r + 1;
+        if ((rc = launch_a(rnd, bound))) { over = true; return rc; }
+        launched = ++rnd;
+        return NECAT_OK;
     }
-    // drain: whatever is still in flight
-    hipError_t e1 = hipStreamSynchronize(c.sa), e2 = hipStreamSynchronize(c.sb[0]), e3 = hipStreamSynchronize(c.sb[1]);
-    ctx->round_seq = seq0 + launched;
-    if (!rc) for (hipError_t e : {e1, e2, e3}) if (e != hipSuccess) rc = set_err(ctx, NECAT_ERR_DEVICE, "extension rounds: %s", hipGetErrorString(e));
-    if (rc) return rc;
-    if (launched) {
-        // the last launched round published too (its lists are empty unless the loop ended on an error)
-        Cnt last; if ((rc = wait_pub(launched - 1, last))) return rc;
-        if (hist.size() < launched) hist.push_back(last);
-        if (launched >= 2) account_a(launched - 2);
-        account_a(launched - 1);
+    // nothing of this batch is in flight any more (two lanes: the scheduler polls this instead of blocking in finish())
+    bool drained() const
+    {
+        for (hipStream_t s : {c.sa, c.sb[0], c.sb[1]}) if (hipStreamQuery(s) == hipErrorNotReady) { (void)hipGetLastError(); return false; }      // ("not ready" is no error to the next launch check)
+        return true;
     }
-    account_b(0); account_b(1);
-    for (const Cnt& h : hist) ctx->tm.rounds += (h.nA + h.nB) ? 1 : 0;
-    return NECAT_OK;
-}
+    // drain whatever is still in flight, the last rounds' accounts; rc = what step() returned
+    int finish(int rc)
+    {
+        over = tail = true;
+        hipError_t e1 = hipStreamSynchronize(c.sa), e2 = hipStreamSynchronize(c.sb[0]), e3 = hipStreamSynchronize(c.sb[1]);
+        *L.round_seq = seq0 + launched;
+        if (!rc) for (hipError_t e : {e1, e2, e3}) if (e != hipSuccess) rc = set_err(ctx, NECAT_ERR_DEVICE, "extension rounds: %s", hipGetErrorString(e));
+        if (rc) return rc;
+        if (launched) {
+            // the last launched round published too (its lists are empty unless the loop ended on an error)
+            Cnt last; if ((rc = wait_pub(launched - 1, last))) return rc;
+            if (hist.size() < launched) hist.push_back(last);
+            if (launched >= 2) account_a(launched - 2);
+            account_a(launched - 1);
+        }
+        account_b(0); account_b(1);
+        for (const Cnt& h : hist) ctx->tm.rounds += (h.nA + h.nB) ? 1 : 0;
+        return NECAT_OK;
+    }
+    // all rounds, one after the other (one lane)
+    int run()
+    {
+        int rc = NECAT_OK;
+        while (!over && !(rc = step())) {}
+        return finish(rc);
+    }
+};
 
 }  // namespace
 
@@ -1560,7 +1661,7 @@ struct DevOut { const necat_m4* d = nullptr; uint64_t n = 0; };      // records 
 // instead of the filtered records every candidate's own record + flag come back, with the candidates: the caller's loop decides
 struct RmOut { std::vector<necat_candidate> cands; std::vector<necat_m4> m4; std::vector<u8> ok; std::vector<u64> group_off; };
 
-int ext_streams(necat_ctx* ctx)
+int ext_streams(necat_ctx* ctx, bool with_copy = false)
 {
     // NECAT_SERIAL=1 (profiling): the four streams of the extension rounds are ONE stream, so that every kernel has the chip to itself and its
     // duration is its own work, not its wait for wave slots behind the other chains (tools/r04_profile.sh: the exclusive-time table)
@@ -1572,8 +1673,10 @@ int ext_streams(necat_ctx* ctx)
     static const int prio = getenv("NECAT_STREAM_PRIO") ? atoi(getenv("NECAT_STREAM_PRIO")) : 0;
     int least = 0, greatest = 0;
     if (prio && hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+    // (the copy stream - deferred column copies of the consensus loop - only for the calls that use it: every stream is a share of the runtime's hardware queues,
+    // GPU_MAX_HW_QUEUES, and kernels of streams that share a queue run one after the other; with the second lane's two streams a context has eight)
     for (hipStream_t* st : {&ctx->stream_a, &ctx->stream_b, &ctx->stream_c, &ctx->stream_d, &ctx->stream_copy}) {
-        if (*st) continue;
+        if (*st || (st == &ctx->stream_copy && !with_copy)) continue;
         const bool high = prio && greatest != least && (prio == 2 ? st == &ctx->stream_a : (st == &ctx->stream_b || st == &ctx->stream_c || st == &ctx->stream_d));
         if ((high ? hipStreamCreateWithPriority(st, hipStreamDefault, greatest) : hipStreamCreate(st)) != hipSuccess) return set_err(ctx, NECAT_ERR_DEVICE, "hipStreamCreate failed");
     }
@@ -1584,7 +1687,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
                 const necat_candidate* cands, uint64_t n, const necat_map_options* opt, int tail_match_len,
                 necat_m4** out, uint64_t* n_out, AlignOut* ao, const DevCands* dev = nullptr, DevOut* devout = nullptr, RmOut* rm = nullptr)
 {
-    if (int rc0 = ext_streams(ctx)) return rc0;
+    if (int rc0 = ext_streams(ctx, ao && ao->defer_copy)) return rc0;
     // dev != nullptr (necat_map_pair): the candidates are this library's own, still on the device
     auto t_prev = std::chrono::steady_clock::now();
     auto tick = [&](const char* what) {
@@ -1617,35 +1720,55 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     // batches of <= 786 432 candidates: every batch ends in ~20 latency-bound rounds, so fewer and bigger is better
     // (yeast-size: 654 -> 615 ms against 393 216); their band records need <= 103 GB for list A + a few GB for list B
     // of the 288 GB (NECAT_BATCH overrides)
-    const uint64_t n_batches = (n + g_batch_cap - 1) / g_batch_cap;
-    const u32 cap = (u32)((((n + n_batches - 1) / n_batches) + 63) & ~63ULL);
+    // Two lanes (NECAT_EXT_OVERLAP, default on; not in the alignment-keeping mode, whose batches hand columns to the host in between): two batches run their
+    // rounds side by side.  A round is a chain of kernels (fragments -> pass -> walk -> finish) each of which drains before the next ramps up - 0.14 + 0.21 ms of a
+    // 110 k-block round's 1.0 ms (NOTES_r05 6) - and a batch ends in ~ 15 rounds that are one block's dependent chain each whatever their size; the other lane's
+    // kernels fill both.  Yeast size (four batches): 300.7 -> 278 - 283 ms per step.  NECAT_EXT_OVERLAP_MIN > 0 cuts ONE batch of at least that many candidates in
+    // two for the same effect (E. coli size, first batch = the 20 % longest chains: 36.8 - 39.6 against 38.8 - 39.3 ms - not a reliable gain, not the default: knobs.h).
+    const bool overlap = g_ext_overlap && !ao && !ctx->serial_streams;
+    uint64_t n_batches = (n + g_batch_cap - 1) / g_batch_cap;
+    if (overlap && n_batches == 1 && g_ext_overlap_min && n >= g_ext_overlap_min) n_batches = 2;
+    // batch sizes: equal shares, or - one batch cut in two - NECAT_EXT_OVERLAP_SPLIT per cent (default 20) of the candidates in the first
+    std::vector<u32> bsize;
+    if (n) {
+        const bool cut = overlap && (n + g_batch_cap - 1) / g_batch_cap == 1 && n_batches == 2;
+        const u64 share = cut ? std::min<u64>(n, std::max<u64>(64, (n * g_ext_overlap_split / 100 + 63) & ~63ULL)) : (((n + n_batches - 1) / n_batches) + 63) & ~63ULL;
+        for (u64 at = 0; at < n;) { const u64 m = std::min<u64>(n - at, cut && at ? n - at : share); bsize.push_back((u32)m); at += m; }
+    }
+    n_batches = bsize.size();
+    const u32 cap = n ? (*std::max_element(bsize.begin(), bsize.end()) + 63) & ~63u : 64u;
+    const int nlanes = overlap && n_batches > 1 ? 2 : 1;
     const u32 groups = cap / 64 + 1;
     int rc;
     // candidate-wide arrays
     const uint64_t n_groups_max = n;
-    const size_t cand_bytes = n * sizeof(necat_candidate) + 2 * n * sizeof(necat_m4) + ((n + 63) & ~63ULL) + (n_groups_max + 1) * 8 + 512;
+    const size_t cand_bytes = n * sizeof(necat_candidate) + 2 * n * sizeof(necat_m4) + ((n + 63) & ~63ULL) + (n_groups_max + 1) * 8 + 1024;
     if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_CAND], cand_bytes))) return rc;
     char* cb = (char*)ctx->scratch[SC_EXT_CAND].p;
     necat_candidate* d_cands = (necat_candidate*)cb; cb += n * sizeof(necat_candidate);
     necat_m4* d_m4 = (necat_m4*)cb; cb += n * sizeof(necat_m4);
     necat_m4* d_out = (necat_m4*)cb; cb += n * sizeof(necat_m4);
     u64* d_goff = (u64*)cb; cb += (n_groups_max + 1) * 8;
-    u32* d_outcnt = (u32*)cb; cb += 128;          // [0..1] output counter, [2..17] list counters (4 buffers x 4), [18..23] work counters
+    u32* d_outcnt = (u32*)cb; cb += 256;          // [0..1] output counter, [2..17] list counters (4 buffers x 4) of lane 0, [34..49] of lane 1
     int* d_err = (int*)cb; cb += 64;
     u8* d_ok = (u8*)cb;
     NECAT_HIP(ctx, hipMemcpyAsync(d_cands, dev ? dev->d : cands, n * sizeof(necat_candidate), dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-    NECAT_HIP(ctx, hipMemsetAsync(d_outcnt, 0, 192, s));
+    NECAT_HIP(ctx, hipMemsetAsync(d_outcnt, 0, 320, s));
     auto cleanup = [&]() {};
-    if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_TASKS], (size_t)cap * sizeof(ExtTask) + 64)) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_LISTS], (size_t)cap * 10 * sizeof(BlockItem) + 2 * 4096 + 64)) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_FRAG], (size_t)groups * 64 * (kFragWordsA + 2 * kFragWordsB) * 8)) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_OPS], (size_t)groups * 64 * (kOpsA + 2 * kOpsB))) ||
-        (rc = buf_ensure(ctx, ctx->scratch[SC_EXT_RES], (size_t)groups * 64 * 3 * sizeof(BlockResult)))) { cleanup(); return rc; }
+    ExtLane lane[2];
+    for (int l = 0; l < nlanes; ++l) {
+        if ((rc = ext_lane(ctx, l, lane[l]))) return rc;
+        if ((rc = buf_ensure(ctx, *lane[l].tasks, (size_t)cap * sizeof(ExtTask) + 64)) ||
+            (rc = buf_ensure(ctx, *lane[l].lists, (size_t)cap * 10 * sizeof(BlockItem) + 2 * 4096 + 64)) ||
+            (rc = buf_ensure(ctx, *lane[l].frag, (size_t)groups * 64 * (kFragWordsA + 2 * kFragWordsB) * 8)) ||
+            (rc = buf_ensure(ctx, *lane[l].ops, (size_t)groups * 64 * (kOpsA + 2 * kOpsB))) ||
+            (rc = buf_ensure(ctx, *lane[l].res, (size_t)groups * 64 * 3 * sizeof(BlockResult)))) { cleanup(); return rc; }
+    }
     // Several batches: every batch runs as many rounds as its longest chain of blocks and ends in latency-bound rounds,
     // so the candidates are dealt to the batches by expected chain length (what is left of the two reads beyond the
     // anchor, in blocks), longest first: the first batch has the ~30-round chains, the last ones a handful of rounds.
     u32* d_perm = nullptr;
-    if (n_batches > 1 && !ao) {
+    if (n_batches > 1 && !ao && g_ext_overlap_order) {
         // on the device (k_len_order): the candidates may never have been on the host (necat_map_pair), and a host counting sort of
         // millions of 88-byte records costs more than a batch's first rounds
         if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_PERM], n * 4 + 2 * kLenBins * 4 + 64))) { cleanup(); return rc; }
@@ -1665,27 +1788,29 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     }
     NECAT_HIP(ctx, hipStreamSynchronize(s));        // candidates + zeroed counters are in place before the batch streams start
     tick("buffers + upload");
-    Batch k;
-    {
-        k.tasks = (ExtTask*)ctx->scratch[SC_EXT_TASKS].p;
-        BlockItem* q = (BlockItem*)ctx->scratch[SC_EXT_LISTS].p;
+    Batch kb[2];
+    for (int l = 0; l < nlanes; ++l) {
+        Batch& k = kb[l]; const ExtLane& E = lane[l];
+        k.tasks = (ExtTask*)E.tasks->p;
+        BlockItem* q = (BlockItem*)E.lists->p;
         for (int j = 0; j < 4; ++j) { k.itemsA[j] = q + (size_t)(2 * j) * cap; k.itemsB[j] = q + (size_t)(2 * j + 1) * cap; }
-        k.fragA = (u64*)ctx->scratch[SC_EXT_FRAG].p;
-        k.opsA = (u8*)ctx->scratch[SC_EXT_OPS].p;
-        k.resA = (BlockResult*)ctx->scratch[SC_EXT_RES].p;
+        k.fragA = (u64*)E.frag->p;
+        k.opsA = (u8*)E.ops->p;
+        k.resA = (BlockResult*)E.res->p;
         for (int j = 0; j < 2; ++j) {
             k.sortedB[j] = q + (size_t)(8 + j) * cap; k.bins[j] = (u32*)(q + 10 * (size_t)cap) + 1024 * j;
             k.fragB[j] = k.fragA + (size_t)groups * 64 * (kFragWordsA + j * kFragWordsB);
             k.opsB[j] = k.opsA + (size_t)groups * 64 * (kOpsA + j * kOpsB);
             k.resB[j] = k.resA + (size_t)groups * 64 * (1 + j);
         }
-        k.count = d_outcnt + 2; k.cap = cap;
-        k.sa = ctx->stream_a; k.sb[0] = ctx->stream_b; k.sb[1] = ctx->stream_c;
-        for (int j = 0; j < 4; ++j) { k.a0[j] = ctx->ev[4 + 3 * j]; k.a1[j] = ctx->ev[5 + 3 * j]; k.a2[j] = ctx->ev[6 + 3 * j]; }     // ev[4..15]
-        for (int j = 0; j < 2; ++j) { k.b0[j] = ctx->ev[18 + 3 * j]; k.b1[j] = ctx->ev[19 + 3 * j]; k.b2[j] = ctx->ev[20 + 3 * j]; } // ev[18..23]
+        k.count = d_outcnt + 2 + 32 * l; k.cap = cap;
+        k.sa = E.sa; k.sb[0] = E.sb[0]; k.sb[1] = E.sb[1];
+        for (int j = 0; j < 4; ++j) { k.a0[j] = E.ev[4 + 3 * j]; k.a1[j] = E.ev[5 + 3 * j]; k.a2[j] = E.ev[6 + 3 * j]; }     // ev[4..15]
+        for (int j = 0; j < 2; ++j) { k.b0[j] = E.ev[18 + 3 * j]; k.b1[j] = E.ev[19 + 3 * j]; k.b2[j] = E.ev[20 + 3 * j]; } // ev[18..23]
         NECAT_HIP(ctx, hipMemsetAsync(k.bins[0], 0, 2 * 4096, k.sa));     // size-sort counters of list B: reset by the kernels after every use
         k.base = 0; k.n = 0;
     }
+    Batch& k = kb[0];
     ExtShared X;
     if ((rc = buf_ensure(ctx, ctx->scratch[SC_STATS], kStatBytes))) return rc;          // the work counters, kStatSlots copies (stat_add, ext_kernels.h)
     NECAT_HIP(ctx, hipMemsetAsync(ctx->scratch[SC_STATS].p, 0, kStatBytes, s));
@@ -1693,8 +1818,73 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     X.error = opt->error; X.tail_match_len = tail_match_len; X.min_align = opt->align_size_cutoff;
     X.read_start_id = read_start_id; X.ref_start_id = ref_start_id; X.reads_off = reads->seq_off; X.ref_off = ref->seq_off;
     std::vector<u64> goff;
-    for (uint64_t next_base = 0; next_base < n;) {
-        k.base = next_base; k.n = (u32)std::min<uint64_t>(cap, n - next_base); next_base += k.n;
+    if (nlanes == 2) {
+        // ---- two lanes: batch i + 1 starts on the free lane once batch i is in its tail (BatchRun::tail); ONE host thread turns both round loops,
+        // whichever has its next list sizes published (BatchRun::ready) - the host still never waits for the device inside a loop
+        struct LaneRun { std::unique_ptr<BatchRun> run; int state = 0; int rc = NECAT_OK; };      // state: 0 free, 1 in its rounds, 2 draining
+        LaneRun lr[2];
+        uint64_t next_base = 0, done = 0; size_t started = 0;
+        int last = -1;                              // the lane of the batch started last
+        auto start = [&](int l) -> int {
+            Batch& b = kb[l];
+            b.base = next_base; b.n = bsize[started++]; next_base += b.n;
+            NECAT_HIP(ctx, hipMemsetAsync(b.count, 0, 64, b.sa));
+            ExtLists L0; L0.count = b.count; L0.itemsA = b.itemsA[0]; L0.itemsB = b.itemsB[0]; L0.capA = cap;
+            hipLaunchKernelGGL(k_ext_init, dim3(grid_for(b.n, 256)), dim3(256), 0, b.sa, (const necat_candidate*)d_cands, b.n, (u32)b.base,
+                               read_start_id, ref_start_id, X.reads_off, X.ref_off, b.tasks, L0, (const u64*)nullptr, (const u32*)d_perm, rm ? 1 : 0);
+            NECAT_CHECK_LAUNCH(ctx, "k_ext_init");
+            lr[l].run.reset(new BatchRun(ctx, dref, drd, b, X, lane[l])); lr[l].state = 1; lr[l].rc = NECAT_OK; last = l;
+            if (g_trace & 1) fprintf(stderr, "[necat] batch@%lu (%u candidates) starts on lane %d\n", (unsigned long)b.base, b.n, l);
+            return NECAT_OK;
+        };
+        int err = NECAT_OK;
+        u64 idle = 0; double t_idle = wall_ms();
+        while (done < n_batches && !err) {
+            bool progressed = false;
+            if (next_base < n && (last < 0 || lr[last].state != 1 || lr[last].run->tail || g_ext_overlap_pct >= 100)) {
+                for (int l = 0; l < 2; ++l) if (lr[l].state == 0) {
+                    if ((err = start(l))) break;
+                    progressed = true;
+                    if (goff.empty() && dev) goff = dev->group_off;
+                    if (goff.empty()) {
+                        // while the first kernels run: groups of equal qid for the containment filter (candidates arrive grouped per read: pm_worker.c:100-140)
+                        goff.push_back(0);
+                        for (uint64_t i = 1; i < n; ++i) if (cands[i].qid != cands[i - 1].qid) goff.push_back(i);
+                        goff.push_back(n);
+                    }
+                    break;
+                }
+                if (err) break;
+            }
+            for (int l = 0; l < 2 && !err; ++l) {
+                LaneRun& R = lr[l];
+                if (R.state == 1 && R.run->ready()) { R.rc = R.run->step(); progressed = true; if (R.run->over) R.state = 2; }
+                if (R.state == 2 && (R.rc || R.run->drained())) {
+                    if (!(err = R.run->finish(R.rc))) {
+                        hipLaunchKernelGGL(k_ext_result, dim3(grid_for(kb[l].n, 256)), dim3(256), 0, kb[l].sa, (const ExtTask*)kb[l].tasks, kb[l].n, (const necat_candidate*)d_cands,
+                                           opt->align_size_cutoff, d_m4, d_ok, rm ? 1 : 0);
+                        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(kb[l].sa) != hipSuccess) err = set_err(ctx, NECAT_ERR_DEVICE, "k_ext_result failed");
+                    }
+                    R.run.reset(); R.state = 0; ++done; progressed = true;
+                }
+            }
+            if (progressed) { idle = 0; t_idle = wall_ms(); continue; }
+            if ((++idle & 0xfffff) == 0) {
+                // a failed kernel never publishes: look at the streams instead of spinning forever
+                for (int l = 0; l < 2 && !err; ++l) if (lr[l].state == 1) {
+                    const hipError_t q = hipStreamQuery(kb[l].sa);
+                    if (q != hipSuccess && q != hipErrorNotReady) err = set_err(ctx, NECAT_ERR_DEVICE, "extension rounds (lane %d) failed: %s", l, hipGetErrorString(q));
+                }
+                if (!err && wall_ms() - t_idle > 120e3) err = set_err(ctx, NECAT_ERR_DEVICE, "extension rounds: no progress for 120 s");
+            }
+        }
+        if (err) {
+            for (LaneRun& R : lr) if (R.state) { (void)R.run->finish(err); R.run.reset(); }       // nothing of a lane is in flight when its buffers are handed on
+            cleanup(); return err;
+        }
+    } else
+    for (uint64_t next_base = 0, bi = 0; next_base < n; ++bi) {
+        k.base = next_base; k.n = bsize[bi]; next_base += k.n;
         NECAT_HIP(ctx, hipMemsetAsync(k.count, 0, 64, k.sa));
         ExtLists L0; L0.count = k.count; L0.itemsA = k.itemsA[0]; L0.itemsB = k.itemsB[0]; L0.capA = cap;
         const u64* d_ops_base = nullptr;
@@ -1724,7 +1914,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
             for (uint64_t i = 1; i < n; ++i) if (cands[i].qid != cands[i - 1].qid) goff.push_back(i);
             goff.push_back(n);
         }
-        if ((rc = run_batch(ctx, dref, drd, k, X))) { cleanup(); return rc; }
+        { BatchRun run(ctx, dref, drd, k, X, lane[0]); if ((rc = run.run())) { cleanup(); return rc; } }
         if (!ao) {
             hipLaunchKernelGGL(k_ext_result, dim3(grid_for(k.n, 256)), dim3(256), 0, k.sa, (const ExtTask*)k.tasks, k.n, (const necat_candidate*)d_cands,
                                opt->align_size_cutoff, d_m4, d_ok, rm ? 1 : 0);
@@ -3115,7 +3305,8 @@ int necat_cns_extension_batch(necat_ctx* ctx, const necat_volume* reads, const n
         ao.off.assign(m + 1, 0);
         const int rc = extend_impl(ctx, reads, reads, 0, 0, c, m, &mo, 4 /* ONC_TAIL_MATCH_LEN_LONG, oc_aligner.h:42 */, nullptr, nullptr, &ao);
         if (rc) {
-            (void)hipStreamSynchronize(ctx->stream_copy); ctx->copy_pending = false;
+            if (ctx->stream_copy) (void)hipStreamSynchronize(ctx->stream_copy);
+            ctx->copy_pending = false;
             necat_free(ao.aln); for (auto& pr : ao.parts) necat_free(pr.first); return rc;
         }
         device_ms += ctx->tm.extend_ms;
@@ -3144,7 +3335,7 @@ int necat_cns_extension_batch(necat_ctx* ctx, const necat_volume* reads, const n
                              st.gather_ms, st.replay_ms);
     auto drop = [&]() { for (u8* b : blocks) necat_free(b); };
     {   // the last columns may still be on their way
-        const hipError_t e = hipStreamSynchronize(ctx->stream_copy);
+        const hipError_t e = ctx->stream_copy ? hipStreamSynchronize(ctx->stream_copy) : hipSuccess;
         ctx->copy_pending = false;
         if (e != hipSuccess && !rc) { drop(); return set_err(ctx, NECAT_ERR_DEVICE, "column copy failed: %s", hipGetErrorString(e)); }
     }

@@ -26,7 +26,18 @@ struct DevBuf {
 }  // namespace necat
 
 constexpr int kNumEvents = 48;
-constexpr unsigned kRoundRing = 1024;  // entries of necat_ctx::round_ring
+constexpr unsigned kRoundRing = 1024;  // entries of necat_ctx::round_ring per lane (the ring holds two lanes' worth)
+
+// The second lane of the extension rounds (necat_hip.hip, ExtLane): while one batch of candidates is in its last, latency-bound rounds
+// the next batch runs its first, chip-filling ones beside it - on buffers, streams, events and a ring half of its own.  Lane 0 is the
+// context's own set (scratch[SC_EXT_*], stream_a .. stream_d, ev[]); this is lane 1, created the first time two batches overlap.
+struct ExtLane1 {
+    necat::DevBuf buf[16];             // by role: ExtLaneBuf in necat_hip.hip
+    hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[kNumEvents];
+    unsigned long long round_seq = 0;
+    bool ready = false;
+};
 
 struct necat_ctx {
     int device = 0;
@@ -55,7 +66,8 @@ struct necat_ctx {
     uint32_t epoch = 0;
     void* cns_scratch = nullptr;       // host buffers of the consensus loop kept between calls (necat::cns::Scratch)
     necat::Knobs knobs;                // this context's tuning / test knobs (knobs.h: read from the environment in necat_ctx_create)
-    necat::DevBuf idx_cache[2];        // released index arrays kept for the next build (8.6 GB hipMalloc/hipFree per step otherwise)                // launch counter stamped into the traceback band records
+    necat::DevBuf idx_cache[2];        // released index arrays kept for the next build (8.6 GB hipMalloc/hipFree per step otherwise)
+    ExtLane1 lane1;                    // the second lane of the extension rounds (created on first use)
 };
 
 struct necat_volume {

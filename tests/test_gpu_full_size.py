@@ -65,6 +65,27 @@ def test_m4_identical_to_reference(ctx, ecoli):
     assert np.all((m4["ident_perc"] > 50.0) & (m4["ident_perc"] <= 100.0))
 
 
+def test_m4_identical_with_the_batch_cut_in_two(ecoli, monkeypatch):
+    """the same records when the one batch of candidates (E. coli: 228 k; yeast runs its four batches on two lanes by default) is cut in two whose rounds run side
+    by side - NECAT_EXT_OVERLAP_MIN, knobs.h; a context of its own: the knobs are read when a context is created"""
+    from necat_amd import capi
+    rs, vol, ix, GOLD = ecoli
+    monkeypatch.setenv("NECAT_EXT_OVERLAP_MIN", "100000")
+    monkeypatch.setenv("NECAT_EXT_OVERLAP_SPLIT", "20" if GOLD is GOLDS["ecoli"] else "45")
+    monkeypatch.setenv("NECAT_BATCH", "3000000")           # (yeast: its 2.46 M candidates as ONE batch, cut 45 : 55)
+    c = capi.Context(0)
+    try:
+        from necat_amd import synth
+        v = c.upload_volume(synth.pack_2bit(rs.codes), rs.nbases, rs.offsets, rs.sizes)
+        x = c.build_index(v, 15, 500)
+        m4, _ = c.map_pair(x, v, v, 0, 0, _opt(1, GOLD), True, 1)
+        x.free(); v.free()
+    finally:
+        c.close()
+    assert m4.shape[0] == GOLD["m4_records"]
+    assert hashlib.md5(b"".join(sorted(capi.m4_text_lines(m4)))).hexdigest() == GOLD["m4_text_sorted_md5"]
+
+
 # ---- multi-volume projects at real volume sizes through the oc2pm PROGRAM: "multivol" = 1.48 Gbp in three volumes of 1.05 / 0.30 / 0.13 Gbp;
 # "drosophila" = BASELINE configs[3] at its real size, a 140 Mb genome x 40 = 5.6 Gbp cut by oc2mkdb's own 2 Gbp rule into 2.0 / 2.0 / 1.6 Gbp
 # (the volume size at which 34-bit offsets, u32 slot counts and the 786 432-candidate batch cap are real; 6.9 M records per mode);

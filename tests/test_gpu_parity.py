@@ -417,18 +417,25 @@ def test_map_pair_equals_find_then_extend(ctx, multi):
     assert total > 300
 
 
-def test_extension_in_several_batches(ctx, small):
+@pytest.mark.parametrize("lanes", [dict(), dict(NECAT_EXT_OVERLAP="0"), dict(NECAT_EXT_OVERLAP_PCT="100"), dict(NECAT_EXT_OVERLAP_PCT="0"),
+                                   dict(NECAT_BATCH="100000", NECAT_EXT_OVERLAP_MIN="1000", NECAT_EXT_OVERLAP_SPLIT="30")],
+                         ids=["overlap", "one_lane", "overlap_at_once", "overlap_never_early", "one_batch_cut_in_two"])
+def test_extension_in_several_batches(ctx, small, lanes):
     """Candidates go through the extension in batches (NECAT_BATCH, default 786 432); tiny batches - many batch
-    switches, lists far below the single-pass threshold - must give the same M4 records and the same alignments."""
+    switches, lists far below the single-pass threshold - must give the same M4 records and the same alignments.
+    With two lanes (the default: batch i + 1's first rounds beside batch i's last, necat_hip.hip extend_impl) and with one;
+    the next batch started as soon as a lane is free / only when the previous one has ended; one batch cut in two uneven halves."""
     from necat_amd import capi
     d, rs = small
     opt = capi.default_options(**dict(util.FAST, job=1))
     _, base = capi.pm_main(ctx, opt, 0, d)
-    os.environ["NECAT_BATCH"] = "320"
+    env = dict({"NECAT_BATCH": "320"}, **lanes)
+    os.environ.update(env)
     try:
         c = capi.Context(0)
     finally:
-        os.environ.pop("NECAT_BATCH", None)
+        for k_ in env:
+            os.environ.pop(k_, None)
     _, got = capi.pm_main(c, opt, 0, d)
     cands, _ = capi.pm_main(c, capi.default_options(**dict(util.FAST, job=0)), 0, d)
     _, _, vols = capi.load_volumes_info(d)
