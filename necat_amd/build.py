@@ -24,13 +24,13 @@ OC2CNS = os.path.join(CSRC, "oc2cns")
 OC2RM = os.path.join(CSRC, "oc2rm_worker")
 OC2ASMPM = os.path.join(CSRC, "oc2asmpm")
 
-HIP_SOURCES = ["necat_hip.hip"]
+HIP_SOURCES = ["necat_hip.hip"]          # one translation unit; its stages are the stage_*.inl files it includes
 
 
 def _hip_deps():
     """every header next to the translation unit + the public header: editing any of them rebuilds the library"""
     import glob
-    return HIP_SOURCES + sorted(os.path.basename(h) for h in glob.glob(os.path.join(CSRC, "*.h"))) + \
+    return HIP_SOURCES + sorted(os.path.basename(h) for h in glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(CSRC, "stage_*.inl"))) + \
         sorted(glob.glob(os.path.join(ROOT, "include", "*.h")))
 
 

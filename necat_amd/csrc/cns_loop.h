@@ -18,7 +18,7 @@
 // the replay sees exactly the alignments it needs, and the overlaps, their order and the per-template
 // numbers are the sequential ones.
 //
-// No HIP in this header: the alignments come from a callback (the device path in necat_hip.hip; the CPU test
+// No HIP in this header: the alignments come from a callback (the device path in stage_cns.inl; the CPU test
 // tests/host_core/check_cns.cpp plugs the oracle's aligner in to check this logic without a GPU).
 #pragma once
 #include <math.h>

@@ -3,7 +3,7 @@
 // query, is aligned again around its anchor with DALIGNER's local alignment and, if that gives an overlap, globally over exactly
 // that range with edlib's path (rescue.h); the block-wise result is kept when the pair gives nothing.
 //
-// Host code as in the reference, run after a device pass on the candidates that need it (necat_hip.hip; tests/host_core/
+// Host code as in the reference, run after a device pass on the candidates that need it (stage_cns.inl; tests/host_core/
 // check_cns.cpp plugs it behind the oracle's aligner).  No HIP in this header.
 #pragma once
 #include <stdint.h>

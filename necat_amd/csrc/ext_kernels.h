@@ -2,7 +2,7 @@
 //
 // Every candidate is a small state machine (ext_core.h) that needs one block alignment per round;
 // its scheduled block sits in list A (blocks of at most 512 x 512) or list B (bigger last blocks of an
-// extension, <= 794 x 794).  A round is three launches per list (the host loop: run_batch in necat_hip.hip):
+// extension, <= 794 x 794).  A round is three launches per list (the host loop: BatchRun in stage_extend.inl):
 //
 //   k_ext_frag      gather the two fragments of every block from the 2-bit volumes: query as two
 //                   complemented bit-planes per 64 rows, target 2-bit packed; written lane-interleaved

@@ -17,7 +17,7 @@ struct Knobs {
     u32 coop_threshold;
     unsigned long long seed_budget;   // seeding scratch budget per chunk, in k-mer hits
     u32 batch_cap;       // candidates per extension batch (NECAT_BATCH)
-    // NECAT_EXT_OVERLAP (default 1): a call of two or more batches runs them two at a time, side by side (two lanes: ExtLane, necat_hip.hip) - the other batch's
+    // NECAT_EXT_OVERLAP (default 1): a call of two or more batches runs them two at a time, side by side (two lanes: ExtLane, stage_extend.inl) - the other batch's
     // kernels fill the drain / ramp-up of every round's kernels and the ~ 15 latency-bound rounds a batch ends in.  0 = one batch after the other.
     // NECAT_EXT_OVERLAP_PCT (default 100): the next batch starts as soon as a lane is free; < 100: only when fewer than that per cent of the batch started last
     // still have a block to align (70: 293.7 against 277.5 ms per step at yeast size).

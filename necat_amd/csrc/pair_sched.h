@@ -11,7 +11,7 @@
 // Here the pairs are laid end to end on one cost line, in job order (v ascending, then i ascending), and rank g takes the stretch
 // [g C / G, (g + 1) C / G) of it.  A pair the stretch cuts through is split by query reads: a pair's query volume is dealt out in
 // chunks of `chunk_reads` reads, chunk c into slot c % slots, and a rank gets a contiguous range of slots (interleaving keeps the
-// shares of a self pair alike, see ReadSel in necat_hip.hip).  Consequences:
+// shares of a self pair alike, see ReadSel in stage_seed.inl).  Consequences:
 //   * every rank gets the same modelled cost up to one slot of one pair;
 //   * a rank's units are consecutive on the line: it needs the index of few reference volumes (usually one or two), in ascending
 //     order, and a reference volume's ranks are CONSECUTIVE ranks - its team.  A team of one builds the index alone

@@ -28,11 +28,11 @@ struct DevBuf {
 constexpr int kNumEvents = 48;
 constexpr unsigned kRoundRing = 1024;  // entries of necat_ctx::round_ring per lane (the ring holds two lanes' worth)
 
-// The second lane of the extension rounds (necat_hip.hip, ExtLane): while one batch of candidates is in its last, latency-bound rounds
+// The second lane of the extension rounds (stage_extend.inl, ExtLane): while one batch of candidates is in its last, latency-bound rounds
 // the next batch runs its first, chip-filling ones beside it - on buffers, streams, events and a ring half of its own.  Lane 0 is the
 // context's own set (scratch[SC_EXT_*], stream_a .. stream_d, ev[]); this is lane 1, created the first time two batches overlap.
 struct ExtLane1 {
-    necat::DevBuf buf[16];             // by role: ExtLaneBuf in necat_hip.hip
+    necat::DevBuf buf[16];             // by role: ExtLaneBuf in stage_extend.inl
     hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev[kNumEvents];
     unsigned long long round_seq = 0;

@@ -423,7 +423,7 @@ def test_map_pair_equals_find_then_extend(ctx, multi):
 def test_extension_in_several_batches(ctx, small, lanes):
     """Candidates go through the extension in batches (NECAT_BATCH, default 786 432); tiny batches - many batch
     switches, lists far below the single-pass threshold - must give the same M4 records and the same alignments.
-    With two lanes (the default: batch i + 1's first rounds beside batch i's last, necat_hip.hip extend_impl) and with one;
+    With two lanes (the default: batch i + 1's first rounds beside batch i's last, stage_extend.inl extend_impl) and with one;
     the next batch started as soon as a lane is free / only when the previous one has ended; one batch cut in two uneven halves."""
     from necat_amd import capi
     d, rs = small
