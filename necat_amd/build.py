@@ -16,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libnecat_hip.so")
+LIB_XCHECK = os.path.join(CSRC, "libnecat_hip_xcheck.so")      # the same sources + the retired kernel families (-DNECAT_BUILD_CROSSCHECK): what the tests' alternative-path cases load
 OC2PMOV = os.path.join(CSRC, "oc2pmov")
 OC2PM = os.path.join(CSRC, "oc2pm")
 OC2MKDB = os.path.join(CSRC, "oc2mkdb")
@@ -71,6 +72,14 @@ def build_hip(force: bool = False) -> str:
     return LIB
 
 
+def build_xcheck(force: bool = False) -> str:
+    """the cross-check build (necat_hip.hip, NECAT_BUILD_CROSSCHECK): the product's code + the kernel families its default paths replaced; test infrastructure -
+    no program links it"""
+    if force or _stale(LIB_XCHECK, _hip_deps()):
+        _run([_hipcc()] + HIPCC_FLAGS + ["-DNECAT_BUILD_CROSSCHECK", "-shared", "-o", LIB_XCHECK] + HIP_SOURCES, cwd=CSRC)
+    return LIB_XCHECK
+
+
 def build_cli(force: bool = False):
     build_hip()
     if force or _stale(OC2PMOV, ["oc2pmov_main.cpp", "pm_job.h", "host_fmt.h", "host_io.h", LIB]):
@@ -93,6 +102,7 @@ def build_cli(force: bool = False):
 
 def build_all(force: bool = False):
     build_hip(force)
+    build_xcheck(force)
     build_cli(force)
 
 

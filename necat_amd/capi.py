@@ -99,16 +99,42 @@ EXPORTED_SYMBOLS = [
 ]
 
 _lib = None
+_lib_xcheck = None
 
 
-def load_library(path: Optional[str] = None) -> C.CDLL:
-    """dlopen the in-tree library; never falls back to anything else."""
-    global _lib
-    if _lib is not None:
+def needs_xcheck(env=None) -> bool:
+    """True when the kernel-path knobs in `env` (default: os.environ) select a path of the CROSS-CHECK build - a kernel family the default paths replaced, kept as an
+    independent implementation for the parity tests (necat_hip.hip, NECAT_BUILD_CROSSCHECK; libnecat_hip_xcheck.so).  The product library refuses such a knob with
+    NECAT_ERR_ARG (never another path), so a wrong answer here fails a test loudly."""
+    env = os.environ if env is None else env
+    num = lambda k, d: int(env.get(k, d))
+    rcwalk, tail = num("NECAT_RCWALK", 512), num("NECAT_TAIL_FUSED", 512)
+    all_fused = tail >= 1 << 26                      # every list through k_tail_fused
+    if not all_fused and (rcwalk == 0 or rcwalk > max(tail, 15)):      # list sizes no default path covers (a round's bound is >= 16)
+        return True
+    if num("NECAT_RC_CARRY", 1) == 0 or num("NECAT_RC_RAGGED", 1) == 0 or num("NECAT_RC_WW", 1) == 0 or num("NECAT_FAST", 1) != 1 or num("NECAT_COOP_FILTER", 1) == 0:
+        return True
+    if (num("NECAT_RC_LISTB", 1) == 0 and not all_fused) or "NECAT_COOP_THRESHOLD" in env or num("NECAT_RC_MAXDIST", 1 << 20) < 300:
+        return True
+    return num("NECAT_SEED_WAVE", 1) == 0 or num("NECAT_ASM_LANE", 0) != 0 or num("NECAT_ASM_RC", 1) == 0
+
+
+def load_library(path: Optional[str] = None, xcheck: bool = False) -> C.CDLL:
+    """dlopen the in-tree library (xcheck: the tests' cross-check build of the same sources); never falls back to anything else."""
+    global _lib, _lib_xcheck
+    if xcheck:
+        if _lib_xcheck is not None:
+            return _lib_xcheck
+    elif _lib is not None:
         return _lib
-    p = path or os.environ.get("NECAT_HIP_LIB") or _build.LIB       # NECAT_HIP_LIB: an instrumented build of the same sources (tools/seed_prof.sh)
-    if not os.path.exists(p):
-        raise RuntimeError("libnecat_hip.so is not built (%s): run `python -m necat_amd.build`" % p)
+    if xcheck:
+        p = path or _build.LIB_XCHECK
+        if not os.path.exists(p):
+            raise RuntimeError("libnecat_hip_xcheck.so is not built (%s): run `python -m necat_amd.build` (build_xcheck)" % p)
+    else:
+        p = path or os.environ.get("NECAT_HIP_LIB") or _build.LIB       # NECAT_HIP_LIB: an instrumented build of the same sources (tools/seed_prof.sh)
+        if not os.path.exists(p):
+            raise RuntimeError("libnecat_hip.so is not built (%s): run `python -m necat_amd.build`" % p)
     lib = C.CDLL(p)
     vp, u64p, i32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)
     lib.necat_default_options.argtypes = [C.POINTER(MapOptions)]
@@ -178,7 +204,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.necat_free.restype = None
     for name in EXPORTED_SYMBOLS:
         getattr(lib, name)
-    _lib = lib
+    if xcheck:
+        _lib_xcheck = lib
+    else:
+        _lib = lib
     return lib
 
 
@@ -208,8 +237,12 @@ class NecatError(RuntimeError):
 class Context:
     """necat_ctx + RAII wrappers of volumes and indexes."""
 
-    def __init__(self, device: int = 0):
-        self.lib = load_library()
+    def __init__(self, device: int = 0, xcheck: Optional[bool] = None):
+        # xcheck None: the cross-check build exactly when the environment's knobs select one of its paths (needs_xcheck) - the product library otherwise
+        self.xcheck = needs_xcheck() if xcheck is None else bool(xcheck)
+        self.device = device
+        self._xc = None
+        self.lib = load_library(xcheck=self.xcheck)
         h = C.c_void_p()
         rc = self.lib.necat_ctx_create(device, C.byref(h))
         if rc != 0:
@@ -218,6 +251,9 @@ class Context:
         self.h = h
 
     def close(self):
+        if getattr(self, "_xc", None) is not None:
+            self._xc.close()
+            self._xc = None
         if getattr(self, "h", None):
             self.lib.necat_ctx_destroy(self.h)
             self.h = None
@@ -419,6 +455,12 @@ class Context:
         return CnsResult(self.lib, r)
 
     def edlib_align_batch(self, seqs: np.ndarray, q_off, q_len, t_off, t_len, error: float = 0.5, want_ops: bool = True):
+        """necat_edlib_align_batch, the block-by-block hook of the parity tests: it exists in the cross-check build only, so a product context hands the call to a
+        cross-check context of its own (made on first use, with the knobs of the environment at that moment)"""
+        if not self.xcheck:
+            if self._xc is None:
+                self._xc = Context(self.device, xcheck=True)
+            return self._xc.edlib_align_batch(seqs, q_off, q_len, t_off, t_len, error, want_ops)
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
         q_off = np.ascontiguousarray(q_off, dtype=np.uint64)
         t_off = np.ascontiguousarray(t_off, dtype=np.uint64)

@@ -43,6 +43,7 @@ struct AsmSame {
     }
 };
 
+#if NECAT_XCHECK          // the lane-per-alignment kernel the cooperative path replaced: cross-check build only (necat_hip.hip)
 __global__ void __launch_bounds__(64)
 k_asm_align(const AsmAnchor* __restrict__ anchors, u32 n, DevVolume reads, DevVolume ref, double error, int tail_match_len,
             char* __restrict__ band_pool, u8* __restrict__ ops_pool, u8* __restrict__ cols, const u64* __restrict__ cols_off, AsmOut* __restrict__ out)
@@ -105,5 +106,6 @@ k_asm_align(const AsmAnchor* __restrict__ anchors, u32 n, DevVolume reads, DevVo
     o.lfrom = t.s_lfrom; o.lto = t.s_lto; o.rfrom = t.s_rfrom; o.rto = t.s_rto; o.blocks = blocks; o.err = err;
     out[i] = o;
 }
+#endif
 
 }  // namespace necat

@@ -236,6 +236,7 @@ k_len_order(const necat_candidate* __restrict__ cands, u32 n, u32* __restrict__ 
 // counting-sorted by target length (longest first) before the round's kernels run.
 constexpr int kSortBins = kMaxFragLen + 1;
 
+#if NECAT_XCHECK          // the size sort of list B exists for the band-record path only: cross-check build only (necat_hip.hip)
 __global__ void __launch_bounds__(256)
 k_items_hist(const BlockItem* __restrict__ items, u32 n, u32* __restrict__ bins)
 {
@@ -267,6 +268,7 @@ k_items_scatter(const BlockItem* __restrict__ items, u32 n, u32* __restrict__ bi
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const BlockItem it = items[i]; out[atomicAdd(&bins[kMaxFragLen - it.tn], 1u)] = it; }
 }
+#endif
 
 // frag layout per 64-item group g: word w of lane l at frag[(g * FW + w) * 64 + l];
 // words [0,NW) = ~lo planes, [NW,2NW) = ~hi planes, [2NW, 2NW+TW) = target 2-bit words

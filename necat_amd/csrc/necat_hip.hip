@@ -10,6 +10,17 @@
 #include <unistd.h>
 #include <numeric>
 
+// Two builds of these sources.  libnecat_hip.so - the product - launches the kernels of the default paths only; the kernel families those paths replaced and the tests keep
+// as independent implementations of the same results (k_myers_coop / k_myers with the band-record k_traceback and k_walk_wave, k_myers_a16, k_rcwalk2, k_rcwalk4, k_myers_ck
+// without carries, the lane-per-strand seed collection, the global-atomic index passes, k_asm_align, and the batch Edlib_align hook that drives them block by block) are
+// compiled with -DNECAT_BUILD_CROSSCHECK into libnecat_hip_xcheck.so, which the tests' alternative-path cases load (necat_amd/capi.py).  A knob that selects such a path
+// in the product build fails the call with NECAT_ERR_ARG and says so - it never falls back to another path.
+#ifdef NECAT_BUILD_CROSSCHECK
+#define NECAT_XCHECK 1
+#else
+#define NECAT_XCHECK 0
+#endif
+
 #include "runtime.h"
 #include "index_kernels.h"
 #include "seed_kernels.h"
@@ -34,6 +45,9 @@ __attribute__((constructor)) static void necat_hw_queues() { setenv("GPU_MAX_HW_
 
 namespace necat { thread_local const Knobs* tl_knobs = nullptr; }      // knobs.h: set by KnobScope in every entry point that takes a context
 using namespace necat;
+
+#define NECAT_RETIRED(ctx, what) return necat::set_err(ctx, NECAT_ERR_ARG, "%s: a cross-check path this library is built without (it is in libnecat_hip_xcheck.so, -DNECAT_BUILD_CROSSCHECK)", what)
+
 static_assert(SC_COUNT <= (int)(sizeof(necat_ctx::scratch) / sizeof(necat::DevBuf)), "a ScratchId without an arena");
 
 namespace {
@@ -78,7 +92,10 @@ static void launch_rcwalk2(u32 nitems, hipStream_t s, A... a)
     else if (g_rc_ww >= 2 && g_rc3_band == 16) hipLaunchKernelGGL((k_rcwalk3<NW, TW, COLS, MAXOPS, 16>), dim3((nitems + 63) / 64), dim3(128), 0, s, a..., pr);
     else if (g_rc_ww >= 2) hipLaunchKernelGGL((k_rcwalk3<NW, TW, COLS, MAXOPS, 32>), dim3((nitems + 63) / 64), dim3(128), 0, s, a..., pr);
     else if (g_rc_ww) hipLaunchKernelGGL((k_rcwalk2w<NW, TW, COLS, MAXOPS>), dim3((nitems + 63) / 64), dim3(256), 0, s, a..., g_rc_prefetch | g_rc_dbg | pr);
+#if NECAT_XCHECK
     else hipLaunchKernelGGL((k_rcwalk2<NW, TW, COLS, MAXOPS>), dim3((nitems + 15) / 16), dim3(64), 0, s, a...);
+#endif
+    // (NECAT_RC_WW=0 in the product build: necat_ctx_create refuses it - read_knobs)
 }
 
 // Tuning / test knobs of ONE context: read from the environment when it is created (knobs.h), defaults otherwise.
@@ -159,6 +176,12 @@ int necat_ctx_create(int device_id, necat_ctx** out)
     necat_ctx* ctx = new necat_ctx();
     ctx->device = device_id;
     read_knobs(ctx->knobs);
+#if !NECAT_XCHECK
+    if (ctx->knobs.rc_ww == 0) {      // (the one retired path chosen inside a launcher that cannot fail: refused here)
+        fprintf(stderr, "[necat] NECAT_RC_WW=0 selects k_rcwalk2, a cross-check kernel this library is built without (libnecat_hip_xcheck.so has it)\n");
+        delete ctx; return NECAT_ERR_ARG;
+    }
+#endif
     memset(&ctx->tm, 0, sizeof ctx->tm);
     memset(&ctx->shard_tm, 0, sizeof ctx->shard_tm);
     hipDeviceProp_t prop;

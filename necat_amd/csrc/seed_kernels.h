@@ -72,6 +72,7 @@ NECAT_D SeedScratch seed_scratch(const SeedArenas& A, const SeedMeta& m, int str
 
 // Seed collection: one lane per (read, strand); every lane runs the same loop nest (sampled k-mers x
 // their occurrence lists), so lanes diverge only in trip counts.
+#if NECAT_XCHECK          // the lane-per-strand collection k_seed_collect_wave replaced: cross-check build only (necat_hip.hip)
 __global__ void __launch_bounds__(64)
 k_seed_collect(DevVolume ref, DevVolume reads, IndexView index, const u64* __restrict__ offset_list,
                SeedParams P, const u32* __restrict__ order, const SeedMeta* __restrict__ meta, u32 n,
@@ -86,6 +87,7 @@ k_seed_collect(DevVolume ref, DevVolume reads, IndexView index, const u64* __res
     if (nb < 0) atomicExch(err_flag, 1);
     nblk_out[t] = nb < 0 ? 0 : nb;
 }
+#endif
 
 // Seed collection, one WAVE per (read, strand).  collect_seeds (word_finder.c:107-139) is a strictly
 // ordered walk - sampled k-mers in read order, each k-mer's occurrences in ascending offset order - whose

@@ -125,7 +125,11 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
                 NECAT_CHECK_LAUNCH(ctx, "k_traceback<asm A, rc>");
                 NECAT_HIP(ctx, hipEventRecord(ctx->ev[24], s));
                 ctx->tm.myers_launches += 1;
-            } else
+            }
+#if !NECAT_XCHECK
+            else NECAT_RETIRED(ctx, "the 2048-bp blocks through k_myers_coop + band records (NECAT_ASM_RC=0)");
+#else
+            else
             for (u32 g0 = 0; g0 < gA; g0 += gchunkA) {
                 const u32 lo = g0 * 64, hi = std::min(gA, g0 + gchunkA) * 64, cn = hi - lo;
                 char* slabs = (char*)ctx->scratch[SC_ASM_BAND].p - (size_t)g0 * kAsmSlabA;         // the kernels index slabs by work index / 64
@@ -148,6 +152,7 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
                 dp += ev_ms(ctx->ev[2], ctx->ev[3]); wk += ev_ms(ctx->ev[3], ctx->ev[24]);
                 ctx->tm.myers_launches += 1;
             }
+#endif
         }
         // ---- list B: a plain list of nB items
         if (nB) {
@@ -173,7 +178,11 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
                 NECAT_CHECK_LAUNCH(ctx, "k_traceback<asm B, rc>");
                 NECAT_HIP(ctx, hipEventRecord(ctx->ev[38], sB));
                 ctx->tm.myers_launches += 1;
-            } else
+            }
+#if !NECAT_XCHECK
+            else NECAT_RETIRED(ctx, "the 2048-bp blocks through k_myers_coop + band records (NECAT_ASM_RC=0)");
+#else
+            else
             for (u32 g0 = 0; g0 < gB; g0 += gchunkB) {
                 const u32 lo = g0 * 64, hi = std::min(nB, (g0 + gchunkB) * 64), cn = hi - lo;
                 char* slabs = (char*)ctx->scratch[SC_ASM_BAND].p - (size_t)g0 * kAsmSlab;
@@ -196,6 +205,7 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
                 dp += ev_ms(ctx->ev[2], ctx->ev[3]); wk += ev_ms(ctx->ev[3], ctx->ev[24]);
                 ctx->tm.myers_launches += 1;
             }
+#endif
         }
         if (g_asm_rc) {
             if (nB) { NECAT_HIP(ctx, hipEventRecord(ctx->ev[35], sB)); NECAT_HIP(ctx, hipStreamWaitEvent(s, ctx->ev[35], 0)); }
@@ -281,6 +291,9 @@ int necat_asm_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_v
     off[0] = 0;
     auto fail = [&](int rc) { necat_free(res); necat_free(off); return rc; };
     if (n == 0) { *aln = res; *ops_off = off; *ops = (uint8_t*)result_alloc(8); return NECAT_OK; }
+#if !NECAT_XCHECK
+    return fail(necat::set_err(ctx, NECAT_ERR_ARG, "the lane-per-alignment kernel k_asm_align (NECAT_ASM_LANE=1): a cross-check path this library is built without (libnecat_hip_xcheck.so)"));
+#else
     // waves per launch: one band slab (126 MB) per wave inside the band-pool cap
     const size_t pool = g_band_pool ? std::max<size_t>(g_band_pool, kAsmBandWave) : (size_t)32 << 30;
     const u32 waves_total = (u32)((n + 63) / 64);
@@ -341,4 +354,5 @@ int necat_asm_align_batch(necat_ctx* ctx, const necat_volume* ref, const necat_v
     if (g_trace & 2) fprintf(stderr, "[necat] asm_align: %lu anchors, %u waves (%u per launch), kernels %.2f ms\n", (unsigned long)n, waves_total, waves_max, ctx->tm.extend_ms);
     *aln = res; *ops = packed; *ops_off = off;
     return NECAT_OK;
+#endif
 }

@@ -243,6 +243,9 @@ struct BatchRun {
             b_pending[slot] = true; b_blocks[slot] = nB;
             return NECAT_OK;
         }
+#if !NECAT_XCHECK
+        NECAT_RETIRED(ctx, "list B through the band-record kernels (NECAT_RC_LISTB=0 / NECAT_RC_CARRY=0 / NECAT_COOP_THRESHOLD)");
+#else
         DevBuf& poolB = *L.matb[slot];
         // a capped band pool (NECAT_BAND_POOL_MB): the list in chunks of what the pool holds, DP + walk per chunk
         u32 gchunk = gB;
@@ -301,6 +304,7 @@ struct BatchRun {
         NECAT_HIP(ctx, hipEventRecord(c.b2[slot], sb));
         b_pending[slot] = true; b_blocks[slot] = nB;
         return NECAT_OK;
+#endif
     }
     // ---- A(r): grid sized by an upper bound, the kernels read the exact size of lists[r]
     int launch_a(u32 r, u32 bound)
@@ -340,6 +344,10 @@ struct BatchRun {
             int rc = ensure_zeroed(ctx, (*L.mat), gchunk < gA ? need : need + need / 8, c.sa);
             if (rc) return rc;
         }
+#if !NECAT_XCHECK
+        if (!use_rc || !g_rc_carry || !g_rc_ragged || wide_possible)
+            NECAT_RETIRED(ctx, "list A through the band-record kernels (NECAT_RCWALK=0, NECAT_TAIL_FUSED=0 without NECAT_RCWALK=1, NECAT_RC_CARRY=0, NECAT_RC_RAGGED=0, NECAT_RC_MAXDIST, NECAT_FAST, NECAT_COOP_*)");
+#endif
         const BlockItem* itA = c.itemsA[cur];
         const u32* d_nA = c.count + 4 * cur;            // [0] full blocks (front of itemsA), [2] the others (back)
         if (r >= 2) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, c.b2[r & 1], 0));        // B(r - 2) appended to lists[r]
@@ -371,6 +379,7 @@ struct BatchRun {
             // of a tenth of the list is as long as one of the whole list (latency bound) - it runs beside the full blocks' chain
             hipStream_t sd = L.sd;
             const u32 fl_rag = epoch | (1u << 26), fl_wide = epoch | (1u << 25), fl_all = g_rc_ragged ? epoch | (1u << 27) : epoch;
+#if NECAT_XCHECK
             if (!g_rc_ragged) {
                 NECAT_HIP(ctx, hipStreamWaitEvent(sd, c.a0[cur], 0));            // the fragments are there
                 hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3(gA * 8), dim3(64), 0, sd, itA, bound, d_nA, c.cap,
@@ -380,6 +389,7 @@ struct BatchRun {
                                    (i32*)nullptr, X.d_err, next, fl_rag, 0u);
                 NECAT_CHECK_LAUNCH(ctx, "k_myers / k_traceback<A, ragged>");
             }
+#endif
             // the full blocks on stream a: SHW + checkpoints, recompute walk (chunk by chunk), finish
             const bool one_chunk = rc_chunk >= bound;
             static const bool ckg_all = getenv("NECAT_RC_CKG_ALL") != nullptr;       // debugging: every block through the general pass
@@ -406,7 +416,11 @@ struct BatchRun {
                     hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA, true>), dim3((cn + 7) / 8), dim3(64), g_ck_lds, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error, c.resA, X.stats, g_rc_maxdist, lo, hi,
                                        (merged ? fl_all : epoch) | (g_ck_post ? 0u : 1u << 24) | (g_rc_prio & 2u ? 1u << 23 : 0u));
                 else
+#if NECAT_XCHECK
                     hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA, false>), dim3((cn + 7) / 8), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error, c.resA, X.stats, g_rc_maxdist, lo, hi, epoch);
+#else
+                    {}
+#endif
                 if (piped) { NECAT_HIP(ctx, hipEventRecord(L.ev[40 + (ci & 7)], c.sa)); NECAT_HIP(ctx, hipStreamWaitEvent(sw, L.ev[40 + (ci & 7)], 0)); }
                 if (g_rc_ragged && !merged) {
                     // the ragged blocks of the chunk (the back of the work index space): the general SHW pass, same checkpoints.  A tenth of
@@ -428,12 +442,17 @@ struct BatchRun {
                                        (const u64*)hcar, (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsA, wo, X.stats, X.d_err,
                                        (g_rc_ragged && one_chunk && !merged) ? epoch : fl_all, lo, hi);
                 else
+#if NECAT_XCHECK
                     hipLaunchKernelGGL((k_rcwalk4<kWordsA, kTWordsA, kOpsA>), dim3((cn + 15) / 16), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, (const ulonglong2*)ck,
                                        (const BlockResult*)c.resA, (const ExtTask*)c.tasks, X.task_ops ? 1 : 0, X.tail_match_len, c.opsA, wo, X.stats, X.d_err, lo, hi);
+#else
+                    {}
+#endif
                 NECAT_CHECK_LAUNCH(ctx, "k_rcwalk");
             }
             NECAT_HIP(ctx, hipEventRecord(L.ev[26 + (r & 3)], piped ? sd : c.sa));       // a1 -> this: the walk kernel alone (account_a; of the last chunk, normally the only one)
             if (piped) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, L.ev[26 + (r & 3)], 0));          // the finishing kernel reads what the walks left
+#if NECAT_XCHECK
             if (wide_possible) {
                 NECAT_HIP(ctx, hipStreamWaitEvent(sd, c.a1[cur], 0));            // k_myers_ck has flagged the wide blocks
                 hipLaunchKernelGGL((k_myers_coop<kWordsA, kTWordsA, kColsA, 8>), dim3(gA * 8), dim3(64), 0, sd, itA, bound, d_nA, c.cap,
@@ -443,6 +462,7 @@ struct BatchRun {
                                    (i32*)nullptr, X.d_err, next, fl_wide, 0u);
                 NECAT_CHECK_LAUNCH(ctx, "k_myers / k_traceback<A, wide>");
             }
+#endif
             if (!g_rc_ragged || wide_possible) NECAT_HIP(ctx, hipEventRecord(L.ev[25], sd));
             if (g_rc_ragged && one_chunk && !(g_rc_merge && g_rc_carry && !getenv("NECAT_RC_CKG_ALL"))) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, L.ev[30], 0));       // the ragged blocks are walked
             rc_round.push_back(r);
@@ -451,7 +471,9 @@ struct BatchRun {
                                (i32*)nullptr, X.d_err, next, fl_all, 0u, (const WalkOut*)wo);
             NECAT_CHECK_LAUNCH(ctx, "k_traceback<A, rc>");
             if (!g_rc_ragged || wide_possible) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, L.ev[25], 0));          // the round is over when both chains are
-        } else
+        }
+#if NECAT_XCHECK
+        else
         for (u32 g0 = 0; g0 < gA; g0 += gchunk) {
             const u32 lo = g0 * 64, hi = std::min(gA, g0 + gchunk) * 64, cn = hi - lo;           // work indices of this chunk (the kernels know the exact list)
             char* slabsA = (char*)(*L.mat).p - (size_t)g0 * kSlabA;             // the kernels index slabs by work index / 64
@@ -483,6 +505,7 @@ struct BatchRun {
 #undef NECAT_TB_LAUNCH
             NECAT_CHECK_LAUNCH(ctx, "k_traceback<A>");
         }
+#endif
         NECAT_HIP(ctx, hipEventRecord(c.a2[cur], c.sa));
         a_timed[r] = 1;
         return NECAT_OK;

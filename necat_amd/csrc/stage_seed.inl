@@ -190,8 +190,12 @@ int find_impl(necat_ctx* ctx, const necat_index* ix, const necat_volume* ref, co
             hipLaunchKernelGGL(k_seed_collect_wave, dim3(2 * n), dim3(64), 0, s, dref, drd, index_view(ix), (const u64*)ix->offset_list,
                                P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A, d_nblk, d_err, (const u64*)d_kst);
         else
+#if NECAT_XCHECK
             hipLaunchKernelGGL(k_seed_collect, dim3(grid_for((u64)2 * n, 64)), dim3(64), 0, s, dref, drd, index_view(ix), (const u64*)ix->offset_list,
                                P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A, d_nblk, d_err);
+#else
+            NECAT_RETIRED(ctx, "the lane-per-strand seed collection (NECAT_SEED_WAVE=0)");
+#endif
         NECAT_CHECK_LAUNCH(ctx, "k_seed_collect");
         static const bool fused_clear = !getenv("NECAT_SEED_CLEAR_KERNEL");        // (A/B: the slots cleared by a launch of their own, as in round 3)
         hipLaunchKernelGGL(k_seed_eval, dim3(2 * n), dim3(64), 0, s, dref, drd, P, (const u32*)d_order, (const SeedMeta*)d_meta, n, A,

@@ -17,6 +17,7 @@ def built():
     """Build (or reuse) the in-tree libraries.  hipcc cross-compiles without a GPU."""
     from necat_amd import build
     build.build_hip()
+    build.build_xcheck()          # the same sources + the retired kernel families: the alternative-path cases load it (capi.needs_xcheck)
     from tests import oracle_build
     oracle_build.build_oracle()
     return build

@@ -22,6 +22,7 @@ static FakeIdx blockIdx, threadIdx;
 #define __global__
 #define __launch_bounds__(...)
 
+#define NECAT_XCHECK 1          // k_asm_align is a kernel of the cross-check build (necat_hip.hip, NECAT_BUILD_CROSSCHECK)
 #include "../../necat_amd/csrc/asm_kernels.h"
 extern "C" {
 #include "../../oracle/necat_oracle.h"

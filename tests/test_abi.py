@@ -22,10 +22,32 @@ def test_library_exports_every_declared_symbol(built):
     hdr = open(os.path.join(util.ROOT, "include", "necat_hip.h")).read()
     declared = sorted(set(re.findall(r"\b(necat_[a-z0-9_]+)\s*\(", hdr)))
     assert len(declared) >= 14
-    lib = ctypes.CDLL(built.LIB)
-    for name in declared:
-        assert hasattr(lib, name), name
+    for path in (built.LIB, built.build_xcheck()):          # the product and the tests' cross-check build of the same sources: one ABI
+        lib = ctypes.CDLL(path)
+        for name in declared:
+            assert hasattr(lib, name), (path, name)
     assert sorted(capi.EXPORTED_SYMBOLS) == declared
+
+
+def test_the_product_library_has_no_retired_kernels(built):
+    """the kernel families the default paths replaced (k_myers_coop, k_myers, k_myers_a16, the band-record k_traceback forms, k_walk_wave, k_rcwalk2 / 4,
+    the lane-per-strand seed collection, k_asm_align) exist in libnecat_hip_xcheck.so only; which library a knob set needs: capi.needs_xcheck"""
+    import subprocess
+    from necat_amd import capi
+
+    def stubs(path):
+        out = subprocess.run(["nm", "-C", path], stdout=subprocess.PIPE, text=True).stdout
+        return set(re.findall(r"__device_stub__(k_[a-z0-9_]+)", out))
+    prod, xc = stubs(built.LIB), stubs(built.build_xcheck())
+    retired = {"k_myers_coop", "k_myers", "k_myers_a16", "k_walk_wave", "k_rcwalk2", "k_rcwalk4", "k_seed_collect", "k_asm_align", "k_items_hist"}
+    assert retired <= xc and not (retired & prod) and prod < xc
+    assert {"k_myers_ck", "k_rcwalk3", "k_rcwalk2w", "k_tail_fused", "k_seed_collect_wave", "k_slice_emit"} <= prod
+    # the rule the test binding uses to pick the library
+    assert not capi.needs_xcheck({}) and not capi.needs_xcheck({"NECAT_RCWALK": "1", "NECAT_TAIL_FUSED": "0"}) and not capi.needs_xcheck({"NECAT_TAIL_FUSED": "100000000"})
+    assert not capi.needs_xcheck({"NECAT_RC_POOL_MB": "1", "NECAT_CK_POST": "0", "NECAT_RC_FASTB": "0", "NECAT_RC_MERGE": "0", "NECAT_INDEX_LDS": "0", "NECAT_CHAIN_WAVE": "0"})
+    for env in ({"NECAT_RCWALK": "0"}, {"NECAT_TAIL_FUSED": "0"}, {"NECAT_RC_CARRY": "0"}, {"NECAT_RC_RAGGED": "0"}, {"NECAT_RC_LISTB": "0"}, {"NECAT_RC_WW": "0"},
+                {"NECAT_FAST": "0"}, {"NECAT_COOP_THRESHOLD": "0"}, {"NECAT_RC_MAXDIST": "90"}, {"NECAT_SEED_WAVE": "0"}, {"NECAT_ASM_LANE": "1"}, {"NECAT_ASM_RC": "0"}):
+        assert capi.needs_xcheck(env), env
 
 
 def test_struct_layouts_match_reference_records(built):

@@ -450,6 +450,31 @@ def test_extension_in_several_batches(ctx, small, lanes):
         assert x.tobytes() == y.tobytes()
 
 
+def test_product_library_refuses_cross_check_knobs(small, monkeypatch):
+    """libnecat_hip.so is built without the kernel families its default paths replaced (necat_hip.hip, NECAT_BUILD_CROSSCHECK): a knob that selects one of them
+    fails the call and says so - no other path runs in its place; the cross-check build takes the same knob (the alternative-path tests)"""
+    from necat_amd import capi
+    d, rs = small
+    o1 = capi.default_options(**dict(util.FAST, job=1))
+    monkeypatch.setenv("NECAT_RCWALK", "0")
+    assert capi.needs_xcheck()
+    c = capi.Context(0, xcheck=False)
+    try:
+        with pytest.raises(capi.NecatError, match="cross-check"):
+            capi.pm_main(c, o1, 0, d)
+    finally:
+        c.close()
+    x = capi.Context(0)                      # (auto: the cross-check build)
+    try:
+        assert x.xcheck and capi.pm_main(x, o1, 0, d)[1].shape[0] > 500
+    finally:
+        x.close()
+    monkeypatch.setenv("NECAT_RCWALK", "512")
+    monkeypatch.setenv("NECAT_RC_WW", "0")
+    with pytest.raises(capi.NecatError):
+        capi.Context(0, xcheck=False)        # k_rcwalk2 is chosen inside a launcher that cannot fail: refused when the context is made
+
+
 def test_capped_band_pool_runs_lists_in_chunks(ctx, small, tmp_path, monkeypatch):
     """NECAT_BAND_POOL_MB (set by the command-line programs: a fresh process pays for every GB of VRAM it touches) caps the
     band-record pools; a round's list then runs as several DP + walk launches over the same pool.  An 8 MB cap = chunks of
