@@ -241,7 +241,7 @@ class Context:
         # xcheck None: the cross-check build exactly when the environment's knobs select one of its paths (needs_xcheck) - the product library otherwise
         self.xcheck = needs_xcheck() if xcheck is None else bool(xcheck)
         self.device = device
-        self._xc = None
+        self._xc, self._xc_key = None, None
         self.lib = load_library(xcheck=self.xcheck)
         h = C.c_void_p()
         rc = self.lib.necat_ctx_create(device, C.byref(h))
@@ -458,8 +458,12 @@ class Context:
         """necat_edlib_align_batch, the block-by-block hook of the parity tests: it exists in the cross-check build only, so a product context hands the call to a
         cross-check context of its own (made on first use, with the knobs of the environment at that moment)"""
         if not self.xcheck:
-            if self._xc is None:
-                self._xc = Context(self.device, xcheck=True)
+            # (a context reads its knobs when it is made: a cross-check context per knob environment, so that a test's NECAT_* settings choose the kernels they name)
+            key = tuple(sorted((k, v) for k, v in os.environ.items() if k.startswith("NECAT_")))
+            if self._xc is None or self._xc_key != key:
+                if self._xc is not None:
+                    self._xc.close()
+                self._xc, self._xc_key = Context(self.device, xcheck=True), key
             return self._xc.edlib_align_batch(seqs, q_off, q_len, t_off, t_len, error, want_ops)
         seqs = np.ascontiguousarray(seqs, dtype=np.uint8)
         q_off = np.ascontiguousarray(q_off, dtype=np.uint64)

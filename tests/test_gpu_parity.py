@@ -133,20 +133,21 @@ def _random_pairs(rng, n, qlo, qhi, err):
     return np.concatenate(seqs), qo, ql, to, tl
 
 
-@pytest.mark.parametrize("path", ["band", "recompute", "recompute_rows", "recompute_quad", "recompute_fast"])
+@pytest.mark.parametrize("path", ["band", "recompute", "recompute_16", "recompute_rows", "recompute_quad", "recompute_fast"])
 def test_edlib_blocks_match_oracle(ctx, monkeypatch, path):
     """The dominant kernel in isolation: distance, end column and the full edit path, including
     ragged sizes (1..794), failures (too divergent) and exact 512 x 512 blocks (the FULL kernel).
     band: DP passes + band records + walk; recompute: checkpoint pass + the walk that recomputes its cells (k_myers_ckg, ext_rcwalk.h; k_rcwalk3,
     ext_rcwalk3.h: four waves recompute 64 blocks into 32-diagonal records, one wave walks them column by column) at both geometries (8 words / 13 words
-    per block); recompute_rows: the same through round 4's k_rcwalk2w (64-row records, one LDS read per walk step, NECAT_RC_WW=1); recompute_quad:
+    per block; NECAT_RC_WW=2 = that kernel at every list size - the default takes it from 160 k blocks up); recompute_16: the same on 16-diagonal records
+    (NECAT_RC3_BAND=16); recompute_rows: round 4's k_rcwalk2w (64-row records, one LDS read per walk step: NECAT_RC_WW=1 at this list size); recompute_quad:
     through k_rcwalk2 (every quad recomputes and walks its own block, NECAT_RC_WW=0)."""
     if path != "band":
         monkeypatch.setenv("NECAT_BATCH_RC", "2" if path == "recompute_fast" else "1")          # 2: the checkpoint pass through k_myers_ckf (fast_shw_ckr at 8 and 16 lanes per block)
-    if path in ("recompute_quad", "recompute_rows"):
-        from necat_amd import capi
-        monkeypatch.setenv("NECAT_RC_WW", "0" if path == "recompute_quad" else "1")
-        capi.Context(0).close()          # knobs are process-wide and read when a context is created
+    # (knobs are read when a context is made: ctx.edlib_align_batch runs on a cross-check context of its own per knob environment, capi.py)
+    monkeypatch.setenv("NECAT_RC_WW", {"recompute_quad": "0", "recompute_rows": "1", "recompute": "2", "recompute_16": "2"}.get(path, "1"))
+    if path == "recompute_16":
+        monkeypatch.setenv("NECAT_RC3_BAND", "16")
     rng = np.random.default_rng(2024)
     seqs, qo, ql, to, tl = _random_pairs(rng, 300, 1, 794, 0.15)
     # query much longer than the target: distance >= |q| - |t| > k = 0.55 * min(|q|, |t|) -> Edlib_align fails
@@ -188,12 +189,9 @@ def test_edlib_blocks_match_oracle(ctx, monkeypatch, path):
         assert (dist[i], qend[i], tend[i]) == (d, qe, te), i
         assert np.array_equal(ops[ops_off[i]:ops_off[i + 1]], oops), i
     assert nfail >= 40 and nfail < len(qo) // 2
-    tm = ctx.timings()
-    assert tm.myers_word_updates > 0
-    if path in ("recompute_quad", "recompute_rows"):
-        from necat_amd import capi
-        monkeypatch.undo()
-        capi.Context(0).close()          # back to the defaults for the tests that follow
+    ran = ctx._xc if ctx._xc is not None else ctx            # the context the hook ran on
+    tm = ran.timings()
+    assert ran.xcheck and tm.myers_word_updates > 0
 
 
 def test_empty_and_tiny_inputs(ctx, tmp_path):
@@ -513,7 +511,8 @@ def test_capped_band_pool_runs_lists_in_chunks(ctx, small, tmp_path, monkeypatch
                                   "NECAT_RCWALK=1 NECAT_RC_CARRY=0 NECAT_TAIL_FUSED=0", "NECAT_RCWALK=1 NECAT_RC_CARRY=0 NECAT_RC_MAXDIST=90",
                                   "NECAT_RCWALK=1 NECAT_RC_POOL_MB=1", "NECAT_RCWALK=1 NECAT_RC_RAGGED=0 NECAT_TAIL_FUSED=0",
                                   "NECAT_RC_LISTB=0", "NECAT_RC_LISTB=1 NECAT_TAIL_FUSED=0 NECAT_RC_POOL_MB=1",
-                                  "NECAT_RC_WW=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_WW=1 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_WW=1 NECAT_RC_PREFETCH=1 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_MERGE=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0",
+                                  "NECAT_RC_WW=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_WW=1 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0",
+                                  "NECAT_RC_WW=2 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_WW=2 NECAT_RC3_BAND=16 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC3_MIN=64 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_WW=1 NECAT_RC_PREFETCH=1 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_MERGE=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0",
                                   "NECAT_RC_MERGE=1 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0 NECAT_RC_POOL_MB=1", "NECAT_RC_FASTB=0 NECAT_TAIL_FUSED=0",
                                   "NECAT_CK_POST=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0",
                                   "NECAT_RC_PIPE=3 NECAT_RC_PIPE_MIN=64 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_PRIO=6 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0"])
@@ -538,7 +537,6 @@ def test_alternative_kernel_paths_give_the_same_records(ctx, small, monkeypatch,
     finally:
         c.close()
         monkeypatch.undo()
-        capi.Context(0).close()          # the knobs are process-wide: back to the defaults for the tests that follow
     assert c_got.tobytes() == c_base.tobytes() and c_base.shape[0] > 500
     assert util.m4_key_rows(m_got) == util.m4_key_rows(m_base) and m_base.shape[0] > 500
 
