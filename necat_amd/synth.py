@@ -89,14 +89,32 @@ def make_genome(length: int, seed: int, repeat_frac: float = 0.0) -> np.ndarray:
     return g
 
 
+def make_genome_families(length: int, seed: int, families: Sequence[Sequence[int]]) -> np.ndarray:
+    """i.i.d. uniform ACGT genome with repeat FAMILIES pasted in: `families` = [(unit_len, copies), ...], every family a random
+    unit of its own, its copies at random places (later copies may overwrite earlier ones).  SURVEY 8d's stress variant at full
+    size: with R-fold coverage a family of c copies puts ~ R c (1 - err)^k exact occurrences of each of its k-mers into a
+    volume - above the -q cutoff (lookup_table.c:15-58) for many short copies, below it but far above a block's 40 seeds
+    (word_finder.c:91-92) and a read's -n candidates (pm_worker.c:139-140, :168-171) for fewer, longer ones."""
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 4, length, dtype=np.uint8)
+    for unit_len, copies in families:
+        unit = rng.integers(0, 4, int(unit_len), dtype=np.uint8)
+        for p in rng.integers(0, length - int(unit_len), int(copies)):
+            g[p:p + int(unit_len)] = unit
+    return g
+
+
 def simulate_reads(genome_len: int = 4_600_000, coverage: float = 40.0, seed: int = 7,
                    mean_len: float = 8000.0, sd_len: float = 2400.0, min_len: int = 3000,
                    err: float = 0.12, repeat_frac: float = 0.0,
-                   genome: Optional[np.ndarray] = None) -> ReadSet:
+                   genome: Optional[np.ndarray] = None, families: Optional[Sequence[Sequence[int]]] = None,
+                   lognormal: Optional[Sequence[float]] = None, max_len: Optional[int] = None) -> ReadSet:
     """SURVEY.md §8d generator: reads sampled uniformly, length ~ N(mean, sd) clipped to
-    [min_len, G], strand 50/50, 12 % errors (1:1:1), names r<idx>_<start>_<len>_<strand>."""
+    [min_len, G], strand 50/50, 12 % errors (1:1:1), names r<idx>_<start>_<len>_<strand>.
+    `families`: the genome of make_genome_families.  `lognormal` = (median, sigma): a long-tailed length model instead of the
+    normal one (ONT-like: a few reads of 100 kb and more), cut at `max_len`."""
     if genome is None:
-        genome = make_genome(genome_len, seed, repeat_frac)
+        genome = make_genome_families(genome_len, seed, families) if families else make_genome(genome_len, seed, repeat_frac)
     G = int(genome.shape[0])
     rng = np.random.default_rng(seed + 1)
     target = coverage * G
@@ -107,7 +125,9 @@ def simulate_reads(genome_len: int = 4_600_000, coverage: float = 40.0, seed: in
     i = 0
     lo = min(min_len, G)
     while total < target:
-        L = int(rng.normal(mean_len, sd_len))
+        L = int(rng.lognormal(np.log(lognormal[0]), lognormal[1])) if lognormal else int(rng.normal(mean_len, sd_len))
+        if max_len:
+            L = min(L, int(max_len))
         L = max(lo, min(L, G))
         start = int(rng.integers(0, G - L + 1))
         frag = genome[start:start + L]

@@ -6,6 +6,7 @@ oracle/Makefile; ~10 GB of RAM per run for the k = 15 table):
 
     python tests/golden/make_golden_full.py ecoli      -> tests/golden/ecoli_full_reference.json
     python tests/golden/make_golden_full.py yeast      -> tests/golden/yeast_full_reference.json
+    python tests/golden/make_golden_full.py ecoli_repeats | ecoli_err6 | ecoli_longtail   (round 6: SURVEY 8d's other data shapes)
 
 The dataset is the seeded synthetic one of necat_amd/synth.py (regenerated on the GPU box by the tests and
 fingerprinted by `reads_md5`); what is committed is data only: record counts and md5s of the SORTED records
@@ -35,19 +36,38 @@ CONFIGS = {
     # BASELINE configs[2]: S. cerevisiae-size 12 Mb x 50, OVLP_SENSITIVE_OPTIONS (-z 10)
     "yeast": dict(genome=12_000_000, coverage=50.0, seed=13, err=0.12,
                   flags="-k 15 -z 10 -q 500 -b 2000 -s 3 -n 500 -a 1000 -d 0.25 -e 0.5 -m 500"),
+    # SURVEY 8d's other data shapes at configs[1]'s size (round 6).  Repeat families (unit length, copies): 5 kb x 140 - each of its 15-mers
+    # occurs ~ 40 x 140 x 0.88^15 = 820 times in the volume, above -q 500: dropped by the cutoff (lookup_table.c:15-58) -, 20 kb x 24 and
+    # 2 kb x 60 (~ 140 / 350 occurrences: kept; blocks at their 40 seeds, word_finder.c:91-92, reads with far more than -n 500 candidates,
+    # pm_worker.c:139-140, :168-171): 29 % of the genome inside a repeat
+    "ecoli_repeats": dict(genome=4_600_000, coverage=40.0, seed=31, err=0.12, families=[[5000, 140], [20000, 24], [2000, 60]],
+                          flags="-k 15 -z 20 -q 500 -b 2000 -s 3 -n 500 -a 1000 -d 0.25 -e 0.5 -m 500"),
+    # 6 % errors: twice the exact 15-mers per overlap, candidate counts and chain lengths change by > 2 x, blocks of distance ~ 55
+    "ecoli_err6": dict(genome=4_600_000, coverage=40.0, seed=37, err=0.06,
+                       flags="-k 15 -z 20 -q 500 -b 2000 -s 3 -n 500 -a 1000 -d 0.25 -e 0.5 -m 500"),
+    # long-tailed read lengths: log-normal (median 6 kb, sigma 0.85), cut at 200 kb - a few reads of 100 - 180 kb, chains of 300 blocks
+    "ecoli_longtail": dict(genome=4_600_000, coverage=40.0, seed=29, err=0.12, lognormal=[6000, 0.85], max_len=200_000,
+                           flags="-k 15 -z 20 -q 500 -b 2000 -s 3 -n 500 -a 1000 -d 0.25 -e 0.5 -m 500"),
 }
+GEN_KEYS = ("genome", "coverage", "seed", "err", "families", "lognormal", "max_len")
+
+
+def generate(g: dict):
+    """the dataset of a golden's "generator" entry (the tests call this too)"""
+    return synth.simulate_reads(g["genome"], g["coverage"], seed=g["seed"], err=g["err"], families=g.get("families"),
+                                lognormal=g.get("lognormal"), max_len=g.get("max_len"))
 
 
 def run(name: str, threads: int) -> None:
     cfg = CONFIGS[name]
     t0 = time.time()
-    rs = synth.simulate_reads(cfg["genome"], cfg["coverage"], seed=cfg["seed"], err=cfg["err"])
+    rs = generate(cfg)
     print("%s: %d reads / %d bp generated in %.0f s" % (name, rs.nreads, rs.nbases, time.time() - t0), flush=True)
     tmp = tempfile.mkdtemp(prefix="necat_full_")
     d = os.path.join(tmp, "vols")
     nvol = synth.write_volume_dir(d, rs)
     assert nvol == 1
-    out = {"generator": {k: cfg[k] for k in ("genome", "coverage", "seed", "err")}, "options": cfg["flags"],
+    out = {"generator": {k: cfg[k] for k in GEN_KEYS if k in cfg}, "options": cfg["flags"],
            "reads_md5": hashlib.md5(rs.codes.tobytes()).hexdigest(), "nreads": rs.nreads, "nbases": rs.nbases,
            "source": "oracle/_ref/oc2pmov (the reference compiled from /root/reference), -t %d, -j 1 -u 0 -i 0 and -j 0 -u 1" % threads}
     for mode, extra in (("m4", "-j 1 -u 0 -i 0"), ("can", "-j 0 -u 1 -i 1")):

@@ -2,7 +2,11 @@
 12 Mb x 50, OVLP_SENSITIVE_OPTIONS -z 10: 2.46 M candidates, several seeding chunks and extension batches at their real
 sizes), k = 15.  The expected fingerprints were produced by the REFERENCE binary (oracle/_ref/oc2pmov, built from
 /root/reference) on the same seeded datasets by tests/golden/make_golden_full.py and are committed as
-tests/golden/{ecoli,yeast}_full_reference.json; nothing here needs /root/reference at run time."""
+tests/golden/{ecoli,yeast}_full_reference.json; nothing here needs /root/reference at run time.
+
+Round 6 - SURVEY 8d's other data shapes at configs[1]'s size, same generator script, same reference binary: "ecoli_repeats" (29 % of the genome in three repeat
+families: 15-mers above the -q 500 cutoff, lookup_table.c:15-58; blocks at their 40 seeds, word_finder.c:91-92; reads with more than -n 500 candidates,
+pm_worker.c:139-140, :168-171), "ecoli_err6" (6 % errors) and "ecoli_longtail" (log-normal read lengths up to 180 kb: chains of 300 blocks)."""
 import hashlib
 import json
 import os
@@ -13,15 +17,21 @@ import pytest
 from tests import util
 
 pytestmark = pytest.mark.gpu
-GOLDS = {n: json.load(open(os.path.join(util.GOLDEN, "%s_full_reference.json" % n))) for n in ("ecoli", "yeast")}
+SHAPES = ("ecoli", "yeast", "ecoli_repeats", "ecoli_err6", "ecoli_longtail")
+GOLDS = {n: json.load(open(os.path.join(util.GOLDEN, "%s_full_reference.json" % n))) for n in SHAPES}
 
 
-@pytest.fixture(scope="module", params=["ecoli", "yeast"])
+def _generate(g):
+    from necat_amd import synth
+    return synth.simulate_reads(g["genome"], g["coverage"], seed=g["seed"], err=g["err"], families=g.get("families"), lognormal=g.get("lognormal"), max_len=g.get("max_len"))
+
+
+@pytest.fixture(scope="module", params=list(SHAPES))
 def ecoli(ctx, request):
     from necat_amd import synth
     GOLD = GOLDS[request.param]
     g = GOLD["generator"]
-    rs = synth.simulate_reads(g["genome"], g["coverage"], seed=g["seed"], err=g["err"])
+    rs = _generate(g)
     # (a FAILURE, not a skip: a numpy whose generators drifted would otherwise silently turn the strongest parity tests off)
     assert hashlib.md5(rs.codes.tobytes()).hexdigest() == GOLD["reads_md5"], \
         "numpy generator drift: the seeded dataset differs from the one tests/golden/%s_full_reference.json was made on - regenerate the golden (make_golden_full.py)" % request.param
@@ -71,7 +81,7 @@ def test_m4_identical_with_the_batch_cut_in_two(ecoli, monkeypatch):
     from necat_amd import capi
     rs, vol, ix, GOLD = ecoli
     monkeypatch.setenv("NECAT_EXT_OVERLAP_MIN", "100000")
-    monkeypatch.setenv("NECAT_EXT_OVERLAP_SPLIT", "20" if GOLD is GOLDS["ecoli"] else "45")
+    monkeypatch.setenv("NECAT_EXT_OVERLAP_SPLIT", "45" if GOLD is GOLDS["yeast"] else "20")
     monkeypatch.setenv("NECAT_BATCH", "3000000")           # (yeast: its 2.46 M candidates as ONE batch, cut 45 : 55)
     c = capi.Context(0)
     try:
