@@ -35,6 +35,13 @@
 extern "C" {
 #endif
 
+/* ABI version of this header.  It changes whenever a struct an entry point copies into caller memory changes size or layout (round 5 grew
+ * necat_timings and necat_shard_timings, round 6 necat_timings again): a caller built against another header must not pass its smaller struct to
+ * necat_get_timings / necat_get_shard_timings.  Check necat_abi_version() == NECAT_ABI_VERSION once after loading the library, or use the
+ * *_sized getters, which copy at most the bytes the caller says its struct has (new fields are always appended). */
+#define NECAT_ABI_VERSION   6
+int  necat_abi_version(void);
+
 #define NECAT_OK            0
 #define NECAT_ERR_ARG      (-1)
 #define NECAT_ERR_DEVICE   (-2)   /* no usable GPU / HIP runtime error */
@@ -142,7 +149,7 @@ void        necat_ctx_destroy(necat_ctx* ctx);
  * demand.  For short-lived processes that build an index once: on MI355X a fresh process pays tens of ms per GB of VRAM that is
  * still being cleaned after the previous one, so a command-line program keeps its peak small.  (No reference counterpart.) */
 void        necat_ctx_trim(necat_ctx* ctx);
-const char* necat_last_error(const necat_ctx* ctx);
+const char* necat_last_error(const necat_ctx* ctx);    /* ctx == NULL: why this thread's last necat_ctx_create failed */
 int         necat_device_name(const necat_ctx* ctx, char* buf, size_t n);
 
 /* pac: NECAT 2-bit bases (first base of a byte in its top two bits, ontcns_aux.h:118-119);
@@ -392,6 +399,7 @@ typedef struct {
     double   index_plan_replicate_ms, index_plan_shard_ms;
 } necat_shard_timings;
 int  necat_get_shard_timings(const necat_ctx* ctx, necat_shard_timings* t);
+int  necat_get_shard_timings_sized(const necat_ctx* ctx, void* t, size_t bytes);
 
 /* The cost model behind necat_index_build_sharded's choice (no reference counterpart: build_lookup_table, lookup_table.c:149, is one thread).
  * SURVEY 8e's sharded build was specified against a 66 s CPU build; on the device ONE rank builds an E. coli-size table in 5 ms, so slicing the build
@@ -477,6 +485,8 @@ int  necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_
                              uint8_t** ops, uint64_t** ops_off);
 
 int  necat_get_timings(const necat_ctx* ctx, necat_timings* t);
+/* the first min(bytes, sizeof(necat_timings)) bytes of the timings: safe for a caller built against an older (smaller) struct */
+int  necat_get_timings_sized(const necat_ctx* ctx, void* t, size_t bytes);
 void necat_free(void* p);
 
 #ifdef __cplusplus

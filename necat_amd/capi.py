@@ -86,13 +86,15 @@ class _CnsResult(C.Structure):
                 ("n_aligned", C.c_uint64), ("n_used", C.c_uint64), ("n_rounds", C.c_uint32), ("device_ms", C.c_double),
                 ("host_ms", C.c_double), ("n_rescue_tried", C.c_uint64), ("n_rescued", C.c_uint64), ("rescue_ms", C.c_double)]
 
+ABI_VERSION = 6          # include/necat_hip.h: NECAT_ABI_VERSION
+
 EXPORTED_SYMBOLS = [
     "necat_default_options", "necat_ctx_create", "necat_ctx_destroy", "necat_ctx_trim", "necat_last_error", "necat_device_name",
     "necat_volume_upload", "necat_volume_pack", "necat_volume_free", "necat_index_build", "necat_index_size", "necat_index_download",
     "necat_index_free", "necat_index_sparse_size", "necat_index_download_sparse", "necat_find_candidates", "necat_extend", "necat_map_pair", "necat_map_reference", "necat_onc_align_batch", "necat_asm_align_batch", "necat_asm_plan_batch",
     "necat_gapped_strings", "necat_cns_default_options", "necat_cns_load_partition", "necat_cns_extension_batch",
     "necat_cns_result_free",
-    "necat_edlib_align_batch", "necat_get_timings", "necat_free", "necat_pcan_partition",
+    "necat_edlib_align_batch", "necat_get_timings", "necat_get_timings_sized", "necat_get_shard_timings_sized", "necat_abi_version", "necat_free", "necat_pcan_partition",
     "necat_comm_create", "necat_comm_destroy", "necat_comm_transport", "necat_get_shard_timings", "necat_comm_selftest_rccl", "necat_comm_selftest_rccl2",
     "necat_index_build_sharded", "necat_index_plan", "necat_find_candidates_sharded", "necat_map_pair_sharded",
     "necat_pair_schedule", "necat_pair_chunk_reads", "necat_find_candidates_part", "necat_map_pair_part",
@@ -135,8 +137,15 @@ def load_library(path: Optional[str] = None, xcheck: bool = False) -> C.CDLL:
         p = path or os.environ.get("NECAT_HIP_LIB") or _build.LIB       # NECAT_HIP_LIB: an instrumented build of the same sources (tools/seed_prof.sh)
         if not os.path.exists(p):
             raise RuntimeError("libnecat_hip.so is not built (%s): run `python -m necat_amd.build`" % p)
+    # (the host program's job since round 6 - the library no longer sets it when it is loaded; read by the HIP runtime at its first call)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     lib = C.CDLL(p)
+    lib.necat_abi_version.restype = C.c_int
+    if lib.necat_abi_version() != ABI_VERSION:
+        raise RuntimeError("%s has ABI version %d, this binding was written for %d (include/necat_hip.h: NECAT_ABI_VERSION)" % (p, lib.necat_abi_version(), ABI_VERSION))
     vp, u64p, i32p = C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_int32)
+    lib.necat_get_timings_sized.argtypes = [vp, vp, C.c_size_t]
+    lib.necat_get_shard_timings_sized.argtypes = [vp, vp, C.c_size_t]
     lib.necat_default_options.argtypes = [C.POINTER(MapOptions)]
     lib.necat_default_options.restype = None
     lib.necat_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]

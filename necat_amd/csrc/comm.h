@@ -100,6 +100,35 @@ struct FirstErr {
     void keep(int r) { if (r && !rc) rc = r; }
 };
 
+// First contact (round 6): the first bytes a new RCCL communicator moves are a ring of small messages - rank r sends a pattern of its own to
+// rank r + 1 and receives rank r - 1's - checked byte for byte, before any index slice or record depends on the transport.  `dbuf`: 2 x `bytes`
+// of device memory (send half, receive half).  Every rank returns the same verdict (the ranks exchange their status through the host callback):
+// NECAT_OK, or NECAT_ERR_COMM with the RCCL / HIP error text of THIS rank, or "rank %d failed".  necat_comm_create runs it when the ranks sit on
+// distinct devices: a transport that cannot move 4 KB fails (or, with transport "auto", falls back to HIP IPC) at creation, with the reason.
+inline unsigned char contact_byte(int rank, size_t i) { return (unsigned char)(i * 131u + 7u + 101u * (unsigned)rank); }
+inline int first_contact(necat_ctx* ctx, necat_comm* c, void* dbuf, size_t bytes, hipStream_t s)
+{
+    if (c->nranks < 2 || c->transport != 0) return NECAT_OK;
+    const int to = (c->rank + 1) % c->nranks, from = (c->rank - 1 + c->nranks) % c->nranks;
+    std::vector<unsigned char> h(bytes), g(bytes, 0);
+    for (size_t i = 0; i < bytes; ++i) h[i] = contact_byte(c->rank, i);
+    unsigned char* d = (unsigned char*)dbuf;
+    FirstErr fe{ctx, c};
+    fe.hip(hipMemcpyAsync(d, h.data(), bytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync");
+    fe.hip(hipMemcpyAsync(d + bytes, g.data(), bytes, hipMemcpyHostToDevice, s), "hipMemcpyAsync");
+    fe.nccl(c->p_GroupStart(), "ncclGroupStart");
+    if (!fe.rc) {
+        fe.nccl(c->p_Send(d, bytes, ncclChar, to, c->nccl, s), "ncclSend (first contact)");
+        fe.nccl(c->p_Recv(d + bytes, bytes, ncclChar, from, c->nccl, s), "ncclRecv (first contact)");
+    }
+    fe.nccl(c->p_GroupEnd(), "ncclGroupEnd");            // the group is closed whatever was queued
+    fe.hip(hipMemcpyAsync(g.data(), d + bytes, bytes, hipMemcpyDeviceToHost, s), "hipMemcpyAsync");
+    fe.hip(hipStreamSynchronize(s), "hipStreamSynchronize");
+    if (!fe.rc) for (size_t i = 0; i < bytes; ++i)
+        if (g[i] != contact_byte(from, i)) { fe.keep(set_err(ctx, NECAT_ERR_COMM, "RCCL first contact: byte %zu of rank %d's message arrived as %u, not %u", i, from, (unsigned)g[i], (unsigned)contact_byte(from, i))); break; }
+    return agree(ctx, c, fe.rc);
+}
+
 // One part of a distributed buffer: `bytes` bytes at `off` from the buffer's base on every rank.
 struct Part { size_t off, bytes; };
 

@@ -54,7 +54,7 @@ struct Knobs {
     u32 rc_fastb;        // NECAT_RC_FASTB (default 1): list B's checkpoint pass through k_myers_ckf (32-bit halves, bitop3, DPP carries); 0 = the general pass k_myers_ckg
     u32 rc_dbg;          // NECAT_RC_DBG (timing only): 2 = k_rcwalk2w walks every segment twice (once into a sink), 4 = recomputes every segment twice
     u32 rc_prefetch;     // NECAT_RC_PREFETCH (default 0: measured 0.4 ms per step SLOWER, profiles/NOTES_r04.md 3): k_rcwalk2w loads the next segment's checkpoints / deltas / planes a segment ahead
-    u32 rc_ww;           // NECAT_RC_WW (default 1; 2 until it wins in the bench and not only alone, profiles/NOTES_r05.md 1): 2 = the recompute walk as k_rcwalk3 (ext_rcwalk3.h: two waves recompute 64 blocks - two lanes per block, both words of the pair per lane - into 32-DIAGONAL records, one of them walks the blocks column by column); 1 = k_rcwalk2w (64-row records, one LDS read per walk step), 0 = k_rcwalk2 (every lane of a quad walks its block)
+    u32 rc_ww;           // NECAT_RC_WW (default 1): which recompute walk runs. 1 = k_rcwalk2w (64-row records, one LDS read per walk step), except that list-A launches of at least NECAT_RC3_MIN blocks go through k_rcwalk3; 2 = k_rcwalk3 everywhere (ext_rcwalk3.h: a workgroup of TWO waves recomputes 64 blocks - two lanes per block, both words of the pair per lane - into 32-DIAGONAL records, one of the two then walks the blocks column by column: faster alone, slower in the bench's small launches, profiles/NOTES_r05.md 1); 0 = k_rcwalk2 (every lane of a quad walks its block: cross-check build only - the product library refuses it when the context is created, necat_ctx_create prints why)
     u32 rc3_band;          // NECAT_RC3_BAND (32 or 16): diagonals per record of k_rcwalk3 (16: half the LDS per block in flight, 7 waves per SIMD instead of 4.5, a few per cent of the segments redone)
     u32 rc3_min;         // NECAT_RC3_MIN (blocks, default 160000; 4294967295 = never): with NECAT_RC_WW=1, list-A launches of at least this many blocks go through k_rcwalk3 (throughput form: fewer instructions per block, longer chain per segment) instead of k_rcwalk2w
     u32 rc_carry;        // NECAT_RC_CARRY (default 1): the recompute walk on an exact two-word window (k_myers_ck<CARRY> keeps the words' horizontal deltas, k_rcwalk2); 0 = the 4-word band window (k_rcwalk4)

@@ -40,8 +40,9 @@
 
 // The two lanes of the extension rounds are eight streams; the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and kernels of streams
 // that share a queue run one after the other - with 4 queues the second lane gains 3.7 % at yeast size, with 8 it gains 7.7 % (tools/r05/run20.sh).  The variable is read
-// when the runtime initialises (the first HIP call of the process), so it is set - unless the user has - when this library is loaded.
-__attribute__((constructor)) static void necat_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// when the runtime initialises (the first HIP call of the process): the command-line programs (necat_cli_env, pm_job.h) and bench.py set it before their first HIP
+// call; the LIBRARY does not touch its host's environment (until round 6 a load-time constructor did: a setenv behind the back of a multi-threaded host, and without
+// effect where the runtime was already up).  A context that finds fewer than 8 says so once under NECAT_TRACE.
 
 namespace necat { thread_local const Knobs* tl_knobs = nullptr; }      // knobs.h: set by KnobScope in every entry point that takes a context
 using namespace necat;
@@ -165,21 +166,25 @@ void necat_default_options(necat_map_options* o)
     o->job = 1; o->binary_output = 0; o->use_hdr_as_id = 1;
 }
 
+// why the last necat_ctx_create of this thread failed (there is no context to hold that text): necat_last_error(NULL)
+static thread_local char g_create_err[256] = "no context";
+#define NECAT_CREATE_FAIL(code, ...) do { snprintf(g_create_err, sizeof g_create_err, __VA_ARGS__); return (code); } while (0)
+
 int necat_ctx_create(int device_id, necat_ctx** out)
 {
     if (!out) return NECAT_ERR_ARG;
     *out = nullptr;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NECAT_ERR_DEVICE;
-    if (device_id < 0 || device_id >= ndev) return NECAT_ERR_ARG;
-    if (hipSetDevice(device_id) != hipSuccess) return NECAT_ERR_DEVICE;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); NECAT_CREATE_FAIL(NECAT_ERR_DEVICE, "no usable HIP device (there is no CPU fallback)"); }
+    if (device_id < 0 || device_id >= ndev) NECAT_CREATE_FAIL(NECAT_ERR_ARG, "device %d of %d", device_id, ndev);
+    if (hipSetDevice(device_id) != hipSuccess) NECAT_CREATE_FAIL(NECAT_ERR_DEVICE, "hipSetDevice(%d) failed", device_id);
     necat_ctx* ctx = new necat_ctx();
     ctx->device = device_id;
     read_knobs(ctx->knobs);
 #if !NECAT_XCHECK
     if (ctx->knobs.rc_ww == 0) {      // (the one retired path chosen inside a launcher that cannot fail: refused here)
         fprintf(stderr, "[necat] NECAT_RC_WW=0 selects k_rcwalk2, a cross-check kernel this library is built without (libnecat_hip_xcheck.so has it)\n");
-        delete ctx; return NECAT_ERR_ARG;
+        delete ctx; NECAT_CREATE_FAIL(NECAT_ERR_ARG, "NECAT_RC_WW=0 selects k_rcwalk2, a cross-check kernel this library is built without (libnecat_hip_xcheck.so has it)");
     }
 #endif
     memset(&ctx->tm, 0, sizeof ctx->tm);
@@ -219,7 +224,7 @@ void necat_ctx_destroy(necat_ctx* ctx)
     for (auto& b : ctx->scratch) if (b.p) (void)hipFree(b.p);
     for (auto& b : ctx->idx_cache) if (b.p) (void)hipFree(b.p);
     for (auto& b : ctx->lane1.buf) if (b.p) (void)hipFree(b.p);
-    if (ctx->lane1.ready) for (int i = 0; i < kNumEvents; ++i) (void)hipEventDestroy(ctx->lane1.ev[i]);
+    for (int i = 0; i < kNumEvents; ++i) if (ctx->lane1.ev[i]) (void)hipEventDestroy(ctx->lane1.ev[i]);          // (every event that exists, also those of a creation that failed half-way)
     for (hipStream_t st : ctx->lane1.st) if (st) (void)hipStreamDestroy(st);
     delete (cns::Scratch*)ctx->cns_scratch;
     if (ctx->pin_plan) (void)hipHostFree(ctx->pin_plan);
@@ -242,7 +247,7 @@ void necat_ctx_trim(necat_ctx* ctx)
     ctx->seed_ht_ptr = nullptr; ctx->seed_ht_clean = 0; ctx->seed_ht_cap = 0;
 }
 
-const char* necat_last_error(const necat_ctx* ctx) { return ctx ? ctx->err : "no context"; }
+const char* necat_last_error(const necat_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
 
 int necat_device_name(const necat_ctx* ctx, char* buf, size_t n)
 {
@@ -259,6 +264,15 @@ int necat_get_timings(const necat_ctx* ctx, necat_timings* t)
     *t = ctx->tm;
     return NECAT_OK;
 }
+
+int necat_get_timings_sized(const necat_ctx* ctx, void* t, size_t bytes)
+{
+    if (!ctx || !t) return NECAT_ERR_ARG;
+    memcpy(t, &ctx->tm, bytes < sizeof(necat_timings) ? bytes : sizeof(necat_timings));
+    return NECAT_OK;
+}
+
+int necat_abi_version(void) { return NECAT_ABI_VERSION; }
 
 // Result blocks handed to the caller.  Big ones are pinned host memory (the device copies straight into
 // them) and are recycled: necat_free() parks up to kPoolBlocks of them for the next call instead of

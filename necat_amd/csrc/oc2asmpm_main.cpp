@@ -10,6 +10,7 @@ using namespace necat_host;
 
 int main(int argc, char** argv)
 {
+    necat_host::necat_cli_env();          // (before the first HIP call: host_io.h)
     necat_map_options opt;
     necat_default_options(&opt);
     opt.num_candidates = opt.num_output = 100;           // MAXC, asmpm.c:14

@@ -85,6 +85,7 @@ struct ReadSet {
 
 int main(int argc, char** argv)
 {
+    necat_host::necat_cli_env();          // (before the first HIP call: host_io.h)
     CnsOpts opt;
     int spid = 0, nnode = 1;
     int ac = argc;

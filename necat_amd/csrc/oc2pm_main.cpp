@@ -23,6 +23,7 @@ using namespace necat_host;
 
 int main(int argc, char** argv)
 {
+    necat_host::necat_cli_env();          // (before the first HIP call: host_io.h)
     necat_map_options opt;
     // sDefaultPairwiseMapingOptions (map_options.c:12-28); oc2pm applies them (main.c:83)
     opt.kmer_size = 15; opt.scan_window = 10; opt.kmer_cnt_cutoff = 500; opt.block_size = 2000; opt.block_score_cutoff = 3;

@@ -15,6 +15,7 @@ static int fail(const char* what, const char* detail)
 
 int main(int argc, char** argv)
 {
+    necat_host::necat_cli_env();          // (before the first HIP call: host_io.h)
     const PmTrace tr;
     necat_map_options opt;
     necat_default_options(&opt);

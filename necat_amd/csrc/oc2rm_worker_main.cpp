@@ -37,6 +37,7 @@ static int usage(const char* prog)
 
 int main(int argc, char** argv)
 {
+    necat_host::necat_cli_env();          // (before the first HIP call: host_io.h)
     const PmTrace tr;
     int svid = 0, num_nodes = 1;
     if (argc >= 7 && strcmp(argv[argc - 3], "-mn") == 0) { svid = atoi(argv[argc - 2]); num_nodes = atoi(argv[argc - 1]); argc -= 3; }

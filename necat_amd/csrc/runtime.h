@@ -34,7 +34,7 @@ constexpr unsigned kRoundRing = 1024;  // entries of necat_ctx::round_ring per l
 struct ExtLane1 {
     necat::DevBuf buf[16];             // by role: ExtLaneBuf in stage_extend.inl
     hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev[kNumEvents];
+    hipEvent_t ev[kNumEvents] = {};    // (null = not created: ext_lane creates the missing ones, necat_ctx_destroy destroys the others)
     unsigned long long round_seq = 0;
     bool ready = false;
 };

@@ -79,7 +79,8 @@ int ext_lane(necat_ctx* ctx, int id, ExtLane& L)
         for (hipStream_t& st : Q.st)
             if (!st && (lane_prio && least != greatest ? hipStreamCreateWithPriority(&st, hipStreamDefault, pr) : hipStreamCreate(&st)) != hipSuccess)
                 return set_err(ctx, NECAT_ERR_DEVICE, "hipStreamCreate failed (second extension lane)");
-        for (int i = 0; i < kNumEvents; ++i) if (hipEventCreate(&Q.ev[i]) != hipSuccess) return set_err(ctx, NECAT_ERR_DEVICE, "hipEventCreate failed (second extension lane)");
+        // (events that exist are kept: a creation that failed half-way is completed by the next call, and necat_ctx_destroy destroys every non-null one)
+        for (int i = 0; i < kNumEvents; ++i) if (!Q.ev[i] && hipEventCreate(&Q.ev[i]) != hipSuccess) { Q.ev[i] = nullptr; return set_err(ctx, NECAT_ERR_DEVICE, "hipEventCreate failed (second extension lane)"); }
         Q.ready = true;
     }
     DevBuf* S = Q.buf;

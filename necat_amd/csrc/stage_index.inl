@@ -84,6 +84,17 @@ int index_build_body(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
     if (G > 1) (void)necat_index_plan(ref->nbases, kmer_size, G, 0.0, &plan);
     const bool sharded = G > 1 && lds_slices && NB >= (u32)G && plan.shard;
     ctx->shard_tm.index_sharded = sharded ? 1 : 0; ctx->shard_tm.index_plan_replicate_ms = plan.replicate_ms; ctx->shard_tm.index_plan_shard_ms = plan.shard_ms;
+    if (G > 1) {
+        // The plan is every rank's own arithmetic on its own environment (NECAT_INDEX_SHARD, NECAT_XGMI_GBS, NECAT_INDEX_LDS): ranks that decide
+        // differently would take different collective paths and wait for each other forever - they compare their decisions first and fail together
+        int mine_plan = sharded ? 1 : 0;
+        std::vector<int> all(G, 0);
+        if (const int rg = comm->gather(comm->user, &mine_plan, all.data(), sizeof(int))) return set_err(ctx, NECAT_ERR_COMM, "host all-gather callback failed (%d)", rg);
+        for (int g = 0; g < G; ++g)
+            if (all[g] != all[0])
+                return set_err(ctx, NECAT_ERR_COMM, "ranks disagree on the index build plan (rank 0: %s, rank %d: %s): NECAT_INDEX_SHARD / NECAT_XGMI_GBS / NECAT_INDEX_LDS must be the same on every rank",
+                               all[0] ? "slices" : "replicate", g, all[g] ? "slices" : "replicate");
+    }
     const u32 b_lo = sharded ? (u32)((u64)rk * NB / G) : 0u, b_hi = sharded ? (u32)((u64)(rk + 1) * NB / G) : NB;
     ctx->shard_tm.index_local_ms = 0; ctx->shard_tm.index_exchange_ms = 0; ctx->shard_tm.index_exchange_bytes = 0;
     // A sharded build is a sequence of collective steps.  Whatever fails on ONE rank between two of them (an allocation, a launch)
@@ -309,7 +320,11 @@ int index_build_impl(necat_ctx* ctx, necat_comm* comm, const necat_volume* ref, 
     if (!ctx || !ref || !out) return NECAT_ERR_ARG;
     *out = nullptr;
     necat_index* ix = new necat_index();
-    const int rc = index_build_body(ctx, comm, ref, kmer_size, max_occ, ix);
+    int rc = index_build_body(ctx, comm, ref, kmer_size, max_occ, ix);
+    // a replicated build (every rank the whole table) has no collective step of its own: the ranks report their status here, so that a rank-local
+    // failure (an allocation, a launch) fails the call on EVERY rank instead of leaving the peers waiting in the next collective (find / map_pair)
+    // for a rank that has already returned.  (A sliced build agrees before each of its exchanges; a disagreement on the plan fails on every rank.)
+    if (comm && comm->nranks > 1 && !ctx->shard_tm.index_sharded && rc != NECAT_ERR_COMM) rc = comm::agree(ctx, comm, rc);
     if (rc) { (void)hipStreamSynchronize(ctx->stream); necat_index_free(ctx, ix); return rc; }
     *out = ix;
     return NECAT_OK;

@@ -53,9 +53,20 @@ int necat_comm_create(necat_ctx* ctx, int rank, int nranks, necat_host_allgather
             if ((rc = comm::host_allgather(ctx, c, &ok, oks.data(), sizeof(int)))) { delete c; return rc; }
             all_ok = true; for (int v : oks) all_ok = all_ok && v;
         }
+        if (all_ok) {
+            // first contact: a ring of 4 KB messages over the new communicator, checked byte for byte (comm::first_contact) - the ranks sit on
+            // distinct devices here, and an exchange between two devices is exactly what no single-GPU box ever ran
+            constexpr size_t kContact = 4096;
+            void* d = nullptr;
+            int fc = hipMalloc(&d, 2 * kContact) == hipSuccess ? NECAT_OK : set_err(ctx, NECAT_ERR_MEMORY, "hipMalloc (first contact)");
+            if (fc) { (void)hipGetLastError(); fc = comm::agree(ctx, c, fc); } else fc = comm::first_contact(ctx, c, d, kContact, ctx->stream);
+            if (d) (void)hipFree(d);
+            if (fc) { all_ok = false; ok = 0; }
+            else if (g_trace && rank == 0) fprintf(stderr, "[necat] RCCL first contact among %d ranks: ok\n", nranks);
+        }
         if (!all_ok) {
             if (c->nccl && c->p_CommDestroy) { (void)c->p_CommDestroy(c->nccl); c->nccl = nullptr; }
-            if (!was_auto) { const int e = ok ? set_err(ctx, NECAT_ERR_COMM, "RCCL could not be initialised on another rank") : NECAT_ERR_COMM; delete c; return e; }
+            if (!was_auto) { const int e = ok ? set_err(ctx, NECAT_ERR_COMM, "RCCL could not be initialised on another rank") : NECAT_ERR_COMM; delete c; return e; }      // (ctx->err: this rank's RCCL / HIP error text)
             if (rank == 0) fprintf(stderr, "[necat] RCCL transport unavailable (%s): using HIP IPC copies\n", ok ? "another rank failed" : ctx->err);
             c->transport = 1;
         }
@@ -178,6 +189,13 @@ int necat_get_shard_timings(const necat_ctx* ctx, necat_shard_timings* t)
     KnobScope knob_scope_(ctx);
     if (!ctx || !t) return NECAT_ERR_ARG;
     *t = ctx->shard_tm;
+    return NECAT_OK;
+}
+
+int necat_get_shard_timings_sized(const necat_ctx* ctx, void* t, size_t bytes)
+{
+    if (!ctx || !t) return NECAT_ERR_ARG;
+    memcpy(t, &ctx->shard_tm, bytes < sizeof(necat_shard_timings) ? bytes : sizeof(necat_shard_timings));
     return NECAT_OK;
 }
 

@@ -6,7 +6,9 @@
 //   * the call pattern: one group per exchange, in step d a rank sends its own part to rank + d and receives part rank - d from rank - d, byte
 //     counts = the parts', nothing is posted for empty parts (a rank with nothing to give, a zero-length slice), root != 0 works;
 //   * a failing call on ONE rank: the group is still closed, that rank returns the error, comm::agree gives every rank a non-zero verdict and
-//     nobody blocks.
+//     nobody blocks;
+//   * comm::first_contact (the ring of small messages necat_comm_create sends over a new communicator): every rank receives its left neighbour's
+//     pattern and returns 0; with one rank's send failing - or one message corrupted on the way - EVERY rank returns non-zero.
 //
 //   check_comm   (no arguments; exit code 0 = all good)
 #include <condition_variable>
@@ -38,6 +40,7 @@ std::mutex mu;
 std::condition_variable cv;
 std::map<std::pair<int, int>, std::vector<std::vector<char>>> box;      // (from, to) -> queue of messages
 int fail_send_on_rank = -1;
+int corrupt_from_rank = -1;       // messages of this rank arrive with one byte flipped
 thread_local Rank* me = nullptr;
 struct Buf { const void* src; void* dst; };
 thread_local std::vector<Buf> bufs;
@@ -64,6 +67,7 @@ ncclResult_t GroupEnd()
     for (size_t i = 0; i < me->pending.size(); ++i) if (me->pending[i].kind == 'S') {
         std::lock_guard<std::mutex> lk(mu);
         box[{me->id, me->pending[i].peer}].emplace_back((const char*)bufs[i].src, (const char*)bufs[i].src + me->pending[i].bytes);
+        if (me->id == corrupt_from_rank && me->pending[i].bytes) box[{me->id, me->pending[i].peer}].back()[me->pending[i].bytes / 2] ^= 0x40;
         cv.notify_all();
     }
     for (size_t i = 0; i < me->pending.size(); ++i) if (me->pending[i].kind == 'R') {
@@ -183,11 +187,41 @@ static void run_world(int G, int root, int fail_rank)
     EXPECT((unsigned char)recvs[root][at] == 0xDD, "world %d: the root wrote past its records", G);
 }
 
+static void run_contact(int G, int fail_rank, int corrupt_rank)
+{
+    using namespace necat;
+    Gather gather; gather.n = G;
+    std::vector<fake::Rank> ranks(G);
+    std::vector<int> rc(G, -99);
+    fake::box.clear();
+    fake::fail_send_on_rank = fail_rank; fake::corrupt_from_rank = corrupt_rank;
+    std::vector<std::thread> th;
+    for (int r = 0; r < G; ++r) th.emplace_back([&, r]() {
+        fake::me = &ranks[r]; ranks[r].id = r;
+        necat_ctx ctx;
+        GUser u{&gather, r};
+        necat_comm c; setup(c, r, G, &u);
+        std::vector<unsigned char> dbuf(2 * 4096);
+        rc[r] = comm::first_contact(&ctx, &c, dbuf.data(), 4096, nullptr);
+    });
+    for (auto& t : th) t.join();
+    fake::fail_send_on_rank = -1; fake::corrupt_from_rank = -1;
+    for (int r = 0; r < G; ++r) {
+        if (fail_rank < 0 && corrupt_rank < 0) EXPECT(rc[r] == 0, "first contact, world %d: rank %d returned %d", G, r, rc[r]);
+        else EXPECT(rc[r] != 0, "first contact, world %d: rank %d returned 0 although rank %d %s", G, r, fail_rank >= 0 ? fail_rank : corrupt_rank, fail_rank >= 0 ? "could not send" : "sent a corrupted message");
+        int opens = 0, closes = 0;
+        for (auto& cl : ranks[r].log) { opens += cl.kind == '('; closes += cl.kind == ')'; }
+        EXPECT(opens == closes && (G == 1 || opens == 1), "first contact, world %d: rank %d: %d group starts, %d ends", G, r, opens, closes);
+    }
+}
+
 int main()
 {
+    for (int G : {1, 2, 3, 8}) run_contact(G, -1, -1);
+    for (int G : {2, 3, 8}) { run_contact(G, G / 2, -1); run_contact(G, -1, G - 1); }
     for (int G : {1, 2, 3, 8}) for (int root : {0, G - 1}) run_world(G, root, -1);
     for (int G : {2, 3, 8}) run_world(G, 0, G / 2);            // one rank's ncclSend fails
     if (failures) { fprintf(stderr, "%d check(s) failed\n", failures); return 1; }
-    printf("check_comm: all-gather-v and gather-v through the RCCL branch at world 1, 2, 3, 8 (roots 0 and last), and a failing rank: ok\n");
+    printf("check_comm: all-gather-v and gather-v through the RCCL branch at world 1, 2, 3, 8 (roots 0 and last), and a failing rank; first contact (clean, a failing send, a corrupted message): ok\n");
     return 0;
 }

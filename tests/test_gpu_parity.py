@@ -138,7 +138,7 @@ def test_edlib_blocks_match_oracle(ctx, monkeypatch, path):
     """The dominant kernel in isolation: distance, end column and the full edit path, including
     ragged sizes (1..794), failures (too divergent) and exact 512 x 512 blocks (the FULL kernel).
     band: DP passes + band records + walk; recompute: checkpoint pass + the walk that recomputes its cells (k_myers_ckg, ext_rcwalk.h; k_rcwalk3,
-    ext_rcwalk3.h: four waves recompute 64 blocks into 32-diagonal records, one wave walks them column by column) at both geometries (8 words / 13 words
+    ext_rcwalk3.h: a workgroup of two waves recomputes 64 blocks into 32-diagonal records, one of the two walks them column by column) at both geometries (8 words / 13 words
     per block; NECAT_RC_WW=2 = that kernel at every list size - the default takes it from 160 k blocks up); recompute_16: the same on 16-diagonal records
     (NECAT_RC3_BAND=16); recompute_rows: round 4's k_rcwalk2w (64-row records, one LDS read per walk step: NECAT_RC_WW=1 at this list size); recompute_quad:
     through k_rcwalk2 (every quad recomputes and walks its own block, NECAT_RC_WW=0)."""

@@ -199,7 +199,7 @@ def test_cns_loop_deep_coverage_cut_to_300(check_cns, tmp_path):
 
 @pytest.mark.parametrize("seed", [1, 20260928])
 def test_band_walk_equals_walk_block(tmp_path, seed):
-    """band_piece + band_walk_col / band_walk_col2 - what a quad of k_rcwalk3 stores per column and what its walker does with it - replayed
+    """band_piece + band_walk_col - what a quad of k_rcwalk3 stores per column and what its walker does with it - replayed
     on the CPU over random blocks of every geometry (512 x 512, ragged, list B, 2048-bp blocks), error rates 0 - 35 %, long indels that force
     the redo path, every tail-match length, ops kept or not: the same n / nmat / tail statistics / ops as walk_block on the full matrix"""
     exe = os.path.join(str(tmp_path), "check_bandwalk")
