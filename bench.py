@@ -238,7 +238,10 @@ def cpu_baseline(args, opt_kw, rs, vol_dir):
 
 def cold_start_cli(args, opt_kw, vol_dir, device):
     """wall time of the oc2pmov PROGRAM (what necat.pl launches per volume, necat.pl:197), cold: process start, HIP
-    initialisation, volume read + upload, pools, the three stages, M4 text out"""
+    initialisation, volume read + upload, pools, the three stages, M4 text out.  Per mode: the FIRST run (nothing of this program warm: no page cache
+    for its code objects) and the best of three; -t 4 = the pipeline's default THREADS (the text records are formatted by -t host threads).  Since round 6
+    main() runs this BEFORE its own process initialises the HIP runtime: a parent that holds a context and GBs of arenas on the same device costs the
+    child 0.15 - 0.25 s (0.73 against 0.49 - 0.55 s, tools/r06/run3.sh) - not what a pipeline's process sees"""
     from necat_amd import build
     pmov, _ = build.build_cli()
     res = {}
@@ -246,20 +249,22 @@ def cold_start_cli(args, opt_kw, vol_dir, device):
         out = os.path.join(vol_dir, "cli_out")
         argv = ["-k", str(opt_kw["kmer_size"]), "-z", str(opt_kw["scan_window"]), "-q", str(opt_kw["kmer_cnt_cutoff"]), "-b", str(opt_kw["block_size"]),
                 "-s", str(opt_kw["block_score_cutoff"]), "-n", str(opt_kw["num_candidates"]), "-a", str(opt_kw["align_size_cutoff"]),
-                "-d", "%f" % opt_kw["ddfs_cutoff"], "-e", "%f" % opt_kw["error"], "-m", str(opt_kw["num_output"]), "-t", "1",
+                "-d", "%f" % opt_kw["ddfs_cutoff"], "-e", "%f" % opt_kw["error"], "-m", str(opt_kw["num_output"]), "-t", "4",
                 "-j", str(job), "-u", str(binary), "-i", "0"]
         env = dict(os.environ, HIP_VISIBLE_DEVICES=str(device))
-        best = None
-        for _ in range(2):
+        walls = []
+        for _ in range(3):
             t0 = time.time()
             r = subprocess.run([pmov] + argv + [vol_dir, "0", out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env)
             dt = time.time() - t0
             if r.returncode != 0:
                 return {"error": r.stderr[-300:]}
-            best = dt if best is None else min(best, dt)
+            walls.append(dt)
+        best = min(walls)
         nrec = os.path.getsize(out) // 28 if binary else sum(1 for _ in open(out, "rb"))
         os.remove(out)
-        res["-j %d -u %d" % (job, binary)] = {"wall_s": round(best, 3), "records": nrec, "overlaps_per_s": round(nrec / best, 1)}
+        res["-j %d -u %d" % (job, binary)] = {"wall_s": round(best, 3), "first_run_wall_s": round(walls[0], 3), "runs_s": [round(w, 3) for w in walls], "records": nrec,
+                                             "overlaps_per_s": round(nrec / best, 1)}
     return res
 
 
@@ -458,30 +463,67 @@ def oc2asmpm_program(genome, threads, tmp):
     return res
 
 
-def oc2cns_program(vol_dir, part, threads):
-    """the oc2cns PROGRAM end to end on the bench partition (all templates of the volume in one partition): wall, the GPU extension
-    loop and the host consensus proper (tags, klib-order sort, backbone, best path: cns_consensus.h) as the program reports them"""
+def oc2cns_program(vol_dir, part, threads, ref_wall=True):
+    """the oc2cns PROGRAM end to end on the bench's candidates, partitioned as oc2pcan would (-p 4000 reads: several partitions, so that partition
+    p + 1's GPU extension loop runs beside partition p's host consensus - the program's two stages since round 6): wall, the GPU extension loops and
+    the host consensus proper (tags, klib-order sort, backbone, best path: cns_consensus.h) as the program reports them; the same partitions one after
+    the other (NECAT_CNS_PIPELINE=0: round 5's form); and - `reference_wall_s` - the REFERENCE's own oc2cns (oracle/_ref/oc2cns, consensus/main.c:51)
+    on the same partition files and the same host threads, its corrected reads compared with this program's (sorted records)"""
     import re
+    import numpy as np
     from necat_amd import build
     build.build_cli()
     can = os.path.join(vol_dir, "bench_cands")
-    with open(can + ".p0", "wb") as f:
-        f.write(part)
+    # oc2pcan's partitions (pcan.c:47-75, :111): the template (= subject, word 1 of a record) in batches of `batch` consecutive read ids;
+    # the number of partitions follows from the number of reads
+    rec = np.frombuffer(part, dtype="<u4").reshape(-1, 7)
+    batch = 4000
+    tmpl = rec[:, 1].astype(np.int64)
+    nreads = int(open(os.path.join(vol_dir, "reads_info.txt")).read().split()[1])
+    npart = max(1, (nreads + batch - 1) // batch)
+    files = []
+    for p in range(npart):
+        with open(can + ".p%d" % p, "wb") as f:
+            f.write(rec[(tmpl // batch) == p].tobytes())
+        files.append(can + ".p%d" % p)
     with open(can + ".partitions", "w") as f:
-        f.write("1\n")
+        f.write("%d\n" % npart)
     out_c, out_r = os.path.join(vol_dir, "cns_out.fa"), os.path.join(vol_dir, "raw_out.fa")
-    t0 = time.time()
-    r = subprocess.run([build.OC2CNS, "-t", str(threads), vol_dir, can, out_c, out_r], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-    wall = time.time() - t0
+
+    def run(env_extra, tag):
+        t0 = time.time()
+        r = subprocess.run([build.OC2CNS, "-t", str(threads), vol_dir, can, out_c + tag, out_r + tag], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                           env=dict(os.environ, **env_extra))
+        return r, time.time() - t0
+    r, wall = run({}, "")
     if r.returncode != 0:
         return {"error": r.stderr[-300:]}
-    m = re.search(r"partition 0: (\d+) templates, extension loop ([0-9.]+) s, consensus ([0-9.]+) s \((\d+) host threads\)", r.stdout)
-    res = {"wall_s": round(wall, 2), "host_threads": threads, "corrected_bytes": os.path.getsize(out_c)}
-    if m:
-        res.update(templates=int(m.group(1)), extension_loop_s=float(m.group(2)), host_consensus_s=float(m.group(3)),
-                   templates_per_s=round(int(m.group(1)) / wall, 1),
-                   host_over_device=round(float(m.group(3)) / max(float(m.group(2)), 1e-9), 2))
-    for f in (can + ".p0", can + ".partitions", out_c, out_r):
+    ms = re.findall(r"partition \d+: (\d+) templates, extension loop ([0-9.]+) s(?: \([^)]*\))?, consensus ([0-9.]+) s \((\d+) host threads\)", r.stdout)
+    res = {"wall_s": round(wall, 2), "host_threads": threads, "partitions": npart, "corrected_bytes": os.path.getsize(out_c)}
+    if ms:
+        nt = sum(int(m[0]) for m in ms); ext = sum(float(m[1]) for m in ms); host = sum(float(m[2]) for m in ms)
+        res.update(templates=nt, extension_loop_s=round(ext, 3), host_consensus_s=round(host, 2), templates_per_s=round(nt / wall, 1),
+                   host_over_device=round(host / max(ext, 1e-9), 2))
+    r2, wall2 = run({"NECAT_CNS_PIPELINE": "0"}, ".seq")
+    if r2.returncode == 0:
+        res["wall_one_partition_after_the_other_s"] = round(wall2, 2)
+        res["same_files_either_way"] = open(out_c, "rb").read() == open(out_c + ".seq", "rb").read() and open(out_r, "rb").read() == open(out_r + ".seq", "rb").read()
+    try:
+        from oracle import oracle_api as ora          # test infrastructure: only this reported comparison leg touches it, after every timed region
+        if ref_wall and os.path.exists(ora.REF_OC2CNS):
+            t0 = time.time()
+            rr = subprocess.run([ora.REF_OC2CNS, "-t", str(threads), vol_dir, can, out_c + ".ref", out_r + ".ref"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            res["reference_wall_s"] = round(time.time() - t0, 2)
+            if rr.returncode == 0:
+                recs = lambda b: sorted(b.split(b">"))
+                res["same_records_as_reference"] = recs(open(out_c, "rb").read()) == recs(open(out_c + ".ref", "rb").read()) and \
+                    recs(open(out_r, "rb").read()) == recs(open(out_r + ".ref", "rb").read())
+                res["speedup_vs_reference"] = round(res["reference_wall_s"] / max(wall, 1e-9), 2)
+            else:
+                res["reference_error"] = rr.stdout[-200:]
+    except Exception as e:
+        res["reference_error"] = str(e)
+    for f in files + [can + ".partitions"] + [o + t for o in (out_c, out_r) for t in ("", ".seq", ".ref")]:
         try:
             os.remove(f)
         except OSError:
@@ -918,6 +960,16 @@ def main():
     # ---- synthetic volume, made resident in HBM before the clock starts (single-volume mode: the SAME volume on every rank)
     rs = synth.simulate_reads(args.genome, args.coverage, seed=args.seed + (0 if single or world == 1 else 1000 * rank))
     pac = synth.pack_2bit(rs.codes)
+    # what the pipeline sees - the oc2pmov program, cold, on the same volume file - is measured FIRST, before this process initialises the HIP runtime
+    # (cold_start_cli: a parent with a context and arenas on the device slows the child's start by 0.15 - 0.25 s)
+    early_tmp, early = None, {}
+    if world == 1 and not args.no_cpu_baseline and not args.cpu_genome:
+        early_tmp = tempfile.mkdtemp(prefix="necat_bench_")
+        synth.write_volume_dir(os.path.join(early_tmp, "vols"), rs)
+        try:
+            early["oc2pmov_cold_start"] = cold_start_cli(args, opt_kw, os.path.join(early_tmp, "vols"), local)
+        except Exception as e:
+            early["oc2pmov_cold_start"] = {"error": str(e)}
     ctx = capi.Context(local)
     vol = ctx.upload_volume(pac, rs.nbases, rs.offsets, rs.sizes)
     comm = None
@@ -1086,6 +1138,12 @@ def main():
     if agg["seed_lookups"]:
         out["roofline_seed"] = roofline_seed(agg, K)
     out.update(extras)
+    # the pipeline-true mode beside the headline (necat.pl:31-32 runs -j 0 -u 1; the headline is BASELINE configs[1]'s -j 1 -> M4): also inside `config` and
+    # `roofline`, the objects the driver's record keeps whole
+    if isinstance(extras.get("candidates_job0"), dict) and "ms_per_step" in extras["candidates_job0"]:
+        j0 = {k_: extras["candidates_job0"][k_] for k_ in ("ms_per_step", "overlaps_per_s", "records_per_step")}
+        out["config"]["pipeline_mode_job0"] = dict(j0, what="-j 0 -u 1: index build + candidate search, 28-byte records (what necat.pl runs in the correction pipeline), same volume, after the timed region")
+        out["roofline"]["pipeline_mode_job0"] = j0
     if single:
         out["multi_gpu"] = {"transport": transport,
                             "index_mode": "hash-range slices + all-gather" if agg.get("ix_sharded") else "replicated: every rank builds the whole table, no exchange (necat_index_plan)",
@@ -1117,20 +1175,17 @@ def main():
     cns_part = out.get("widened_paths", {}).pop("_partition", None) if isinstance(out.get("widened_paths"), dict) else None
     if world == 1 and not args.no_cpu_baseline:
         import shutil
-        tmp = tempfile.mkdtemp(prefix="necat_bench_")
+        tmp = early_tmp or tempfile.mkdtemp(prefix="necat_bench_")
         vol_dir = os.path.join(tmp, "vols")
         try:
             if args.cpu_genome:
                 rs_cpu = synth.simulate_reads(args.cpu_genome, args.coverage, seed=args.seed)
             else:
                 rs_cpu = rs
-            synth.write_volume_dir(vol_dir, rs_cpu)
+            if not early_tmp:
+                synth.write_volume_dir(vol_dir, rs_cpu)
             if not args.cpu_genome:
-                # what the pipeline sees: the oc2pmov program, cold, on the same volume file
-                try:
-                    out["oc2pmov_cold_start"] = cold_start_cli(args, opt_kw, vol_dir, local)
-                except Exception as e:
-                    out["oc2pmov_cold_start"] = {"error": str(e)}
+                out.update(early)          # oc2pmov_cold_start, measured before this process touched the GPU
                 if args.asmpm_genome:
                     try:
                         out.setdefault("widened_paths", {})["oc2asmpm"] = oc2asmpm_program(args.asmpm_genome, min(host_cpu()[1], cpu_quota() or 1 << 30), tmp)

@@ -270,6 +270,7 @@ k_items_scatter(const BlockItem* __restrict__ items, u32 n, u32* __restrict__ bi
 }
 #endif
 
+constexpr int kFragSplit = 4;          // threads per item of k_ext_frag (each takes every kFragSplit-th channel)
 // frag layout per 64-item group g: word w of lane l at frag[(g * FW + w) * 64 + l];
 // words [0,NW) = ~lo planes, [NW,2NW) = ~hi planes, [2NW, 2NW+TW) = target 2-bit words
 template <int NW, int TW>
@@ -291,24 +292,30 @@ k_ext_frag(DevVolume reads, DevVolume ref, const BlockItem* __restrict__ items, 
             __threadfence_system();
         }
     }
+    // Round 6: a thread takes ITS item's channels kFragSplit apart (6 of the 24 of a list-A item) instead of one channel - the 40-byte item is read by 4 threads, not by
+    // 24, and a thread has 6 independent volume loads in flight where it had one: 54 -> ~ 30 us per 222 k-block round (the kernel is a chain of two dependent loads per
+    // thread - item, then bases - and what it lacked was loads in flight per wave, not waves).  The grid covers items x kFragSplit threads.
     const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 grp = gid / (64 * CH);
-    const u32 r = (u32)(gid % (64 * CH));
-    const int ch = (int)(r >> 6), lane = (int)(r & 63);
+    const u64 grp = gid / (64 * kFragSplit);
+    const u32 r = (u32)(gid % (64 * kFragSplit));
+    const int part = (int)(r >> 6), lane = (int)(r & 63);
     const u64 item = grp * 64 + lane;
     BlockItem it;
     if (!list_item(lv, items, item, it)) return;
     u64* dst = frag + grp * FW * 64 + lane;
-    if (ch < NW) {
-        if (ch * 64 < it.qn) {
-            u64 lo, hi;
-            load64_planes(reads.bases, it.g.q_base, it.g.q_dir, it.g.q_comp, ch * 64, &lo, &hi);
-            dst[(u64)ch * 64] = ~lo; dst[(u64)(NW + ch) * 64] = ~hi;
+#pragma unroll
+    for (int ch = part; ch < CH; ch += kFragSplit) {
+        if (ch < NW) {
+            if (ch * 64 < it.qn) {
+                u64 lo, hi;
+                load64_planes(reads.bases, it.g.q_base, it.g.q_dir, it.g.q_comp, ch * 64, &lo, &hi);
+                dst[(u64)ch * 64] = ~lo; dst[(u64)(NW + ch) * 64] = ~hi;
+            }
+        } else {
+            const int tw = ch - NW;
+            if (tw * 32 < it.tn)
+                dst[(u64)(2 * NW + tw) * 64] = load32_dir(ref.bases, it.g.t_base + (i64)it.g.t_dir * (tw * 32), it.g.t_dir, it.g.t_comp);
         }
-    } else {
-        const int tw = ch - NW;
-        if (tw * 32 < it.tn)
-            dst[(u64)(2 * NW + tw) * 64] = load32_dir(ref.bases, it.g.t_base + (i64)it.g.t_dir * (tw * 32), it.g.t_dir, it.g.t_comp);
     }
 }
 

@@ -4,6 +4,8 @@
 // candidate partitions `candidates.p<i>` written by oc2pcan), same two FASTA outputs: corrected reads / stretches
 // (cns_out) and the uncorrected rest (raw_out), record format DUMP_CNS_SEQ (common/cns_seq.h:24-44).
 //
+// Partitions go through two stages one partition apart: the extension loop of partition p + 1 on the GPU (a producer thread) beside the host
+// consensus of partition p (consensus_one_partition.c:110 runs them one after the other; the files come out the same).
 // Per partition: the extension loop of every template runs on the GPU (necat_cns_extension_batch: which candidates get
 // aligned, which alignments count, with what weight - consensus/consensus_one_read.c:221-372), the consensus proper
 // (tasc/) on the host threads (cns_consensus.h).  Records come out in template order (the reference's order with -t 1;
@@ -13,6 +15,9 @@
 // loaded per partition) behaves like -s 0 - the read set is resident in HBM either way.  There is no CPU fallback for the
 // block-wise alignments: without a usable GPU the program exits 1.
 #include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include <thread>
 
 #include "host_io.h"
@@ -151,31 +156,75 @@ int main(int argc, char** argv)
     co.rescue_long_indels = opt.rescue_long_indels != 0;
     const int nthreads = std::max(1, std::min(opt.num_threads, 256));       // -t: host threads of the consensus proper
 
-    for (int pid = spid; pid < num_partitions; pid += nnode) {
-        char job[128];
-        snprintf(job, sizeof job, "consensus partition %d", pid);
-        log_line("", job);
-        const double t0 = now_sec();
+    // ---- two stages, one partition apart (round 6): a producer thread reads partition p + 1 and runs its extension loop on the device
+    // (necat_cns_load_partition + necat_cns_extension_batch: the context is that thread's alone from here on) while the host threads do the
+    // consensus proper of partition p - 88 % of a partition's time is host work, the device loop of the next one hides behind it.
+    // One finished partition waits at most (the alignment columns of a partition are hundreds of MB of pinned memory).  Output order =
+    // partition order, as before.  NECAT_CNS_PIPELINE=0: one partition after the other on the main thread (the round-5 form).
+    struct PartWork {
+        int pid = -1; bool empty = false; int rc = 0; std::string what, detail;
+        necat_candidate* cands = nullptr; uint64_t* tmpl_off = nullptr; uint64_t* n_all = nullptr; uint64_t nt = 0;
+        necat_cns_result* res = nullptr; double t_gpu = 0, t0 = 0;
+    };
+    auto device_stage = [&](int pid) -> PartWork {
+        PartWork w; w.pid = pid; w.t0 = now_sec();
         std::vector<uint8_t> packed;
         {
             char suffix[32];
             snprintf(suffix, sizeof suffix, ".p%d", pid);
             FILE* in = fopen((can_path + suffix).c_str(), "rb");
-            if (!in) return fail("candidates", ("cannot open " + can_path + suffix).c_str());
+            if (!in) { w.rc = 1; w.what = "candidates"; w.detail = "cannot open " + can_path + suffix; return w; }
             fseek(in, 0, SEEK_END);
             const long bytes = ftell(in);
             fseek(in, 0, SEEK_SET);
             packed.resize((size_t)(bytes / 28) * 28);
-            if (!packed.empty() && fread(packed.data(), 1, packed.size(), in) != packed.size()) { fclose(in); return fail("candidates", "short read"); }
+            if (!packed.empty() && fread(packed.data(), 1, packed.size(), in) != packed.size()) { fclose(in); w.rc = 1; w.what = "candidates"; w.detail = "short read"; return w; }
             fclose(in);
         }
-        if (packed.empty()) { log_line("[%s] INFO: '%s' takes %.2lf secs.\n", job, now_sec() - t0); continue; }
-        necat_candidate* cands = nullptr; uint64_t* tmpl_off = nullptr; uint64_t* n_all = nullptr; uint64_t nt = 0;
-        if (necat_cns_load_partition(ctx, reads, packed.data(), packed.size() / 28, &cands, &tmpl_off, &n_all, &nt)) return fail("necat_cns_load_partition", necat_last_error(ctx));
-        necat_cns_result* res = nullptr;
-        if (necat_cns_extension_batch(ctx, reads, cands, tmpl_off, n_all, nt, &co, &res)) return fail("necat_cns_extension_batch", necat_last_error(ctx));
-        const double t_gpu = now_sec() - t0;
-
+        if (packed.empty()) { w.empty = true; return w; }
+        if (necat_cns_load_partition(ctx, reads, packed.data(), packed.size() / 28, &w.cands, &w.tmpl_off, &w.n_all, &w.nt)) { w.rc = 1; w.what = "necat_cns_load_partition"; w.detail = necat_last_error(ctx); return w; }
+        if (necat_cns_extension_batch(ctx, reads, w.cands, w.tmpl_off, w.n_all, w.nt, &co, &w.res)) { w.rc = 1; w.what = "necat_cns_extension_batch"; w.detail = necat_last_error(ctx); return w; }
+        w.t_gpu = now_sec() - w.t0;
+        return w;
+    };
+    std::vector<int> pids;
+    for (int pid = spid; pid < num_partitions; pid += nnode) pids.push_back(pid);
+    const bool pipelined = pids.size() > 1 && !(getenv("NECAT_CNS_PIPELINE") && atoi(getenv("NECAT_CNS_PIPELINE")) == 0);
+    std::mutex qmu; std::condition_variable qcv;
+    std::deque<PartWork> ready;              // finished device stages, in partition order (at most one waits)
+    bool stop = false;
+    std::thread producer;
+    if (pipelined) producer = std::thread([&]() {
+        for (int pid : pids) {
+            { std::unique_lock<std::mutex> lk(qmu); qcv.wait(lk, [&] { return ready.size() < 1 || stop; }); if (stop) return; }
+            PartWork w = device_stage(pid);
+            const bool failed = w.rc != 0;
+            { std::lock_guard<std::mutex> lk(qmu); ready.push_back(std::move(w)); }
+            qcv.notify_all();
+            if (failed) return;
+        }
+    });
+    auto stop_producer = [&]() { if (producer.joinable()) { { std::lock_guard<std::mutex> lk(qmu); stop = true; } qcv.notify_all(); producer.join(); } };
+    double t_prev_done = now_sec();
+    for (size_t pi = 0; pi < pids.size(); ++pi) {
+        const int pid = pids[pi];
+        char job[128];
+        snprintf(job, sizeof job, "consensus partition %d", pid);
+        log_line("", job);
+        PartWork W;
+        if (pipelined) {
+            std::unique_lock<std::mutex> lk(qmu);
+            qcv.wait(lk, [&] { return !ready.empty(); });
+            W = std::move(ready.front()); ready.pop_front();
+            lk.unlock(); qcv.notify_all();
+        } else W = device_stage(pid);
+        if (W.rc) { stop_producer(); return fail(W.what.c_str(), W.detail.c_str()); }
+        const double t0 = pipelined ? t_prev_done : W.t0;          // what this partition added to the wall clock
+        if (W.empty) { log_line("[%s] INFO: '%s' takes %.2lf secs.\n", job, now_sec() - t0); t_prev_done = now_sec(); continue; }
+        necat_candidate* cands = W.cands; uint64_t* tmpl_off = W.tmpl_off; uint64_t* n_all = W.n_all; const uint64_t nt = W.nt;
+        necat_cns_result* res = W.res;
+        const double t_gpu = W.t_gpu;
+        const double t_host0 = now_sec();
         // ---- consensus proper, templates in parallel on the host
         std::vector<std::string> out_cns((size_t)nt), out_raw((size_t)nt);
         std::vector<uint8_t> corrected((size_t)nt, 0);
@@ -231,13 +280,15 @@ int main(int argc, char** argv)
                 wok = wok && fwrite(rec.data(), 1, rec.size(), raw_out) == rec.size();
             }
         }
-        if (!wok) return fail("output", "write failed");
+        if (!wok) { stop_producer(); return fail("output", "write failed"); }
         necat_cns_result_free(res);
         necat_free(cands); necat_free(tmpl_off); necat_free(n_all);
-        fprintf(stdout, "[oc2cns] partition %d: %lu templates, extension loop %.2f s, consensus %.2f s (%d host threads)\n", pid, (unsigned long)nt, t_gpu,
-                now_sec() - t0 - t_gpu, nthreads);
+        fprintf(stdout, "[oc2cns] partition %d: %lu templates, extension loop %.2f s%s, consensus %.2f s (%d host threads)\n", pid, (unsigned long)nt, t_gpu,
+                pipelined && pi ? " (beside the previous partition's consensus)" : "", now_sec() - t_host0, nthreads);
         log_line("[%s] INFO: '%s' takes %.2lf secs.\n", job, now_sec() - t0);
+        t_prev_done = now_sec();
     }
+    stop_producer();
     const bool ok = fclose(cns_out) == 0;
     const bool ok2 = fclose(raw_out) == 0;
     if (!ok || !ok2) return fail("output", "write failed");

@@ -3,6 +3,7 @@
 // Same argv, same volume inputs, same candidate / M4 record files; the work runs on one MI355X
 // through libnecat_hip.so (device from NECAT_GPU, default 0).  There is no CPU fallback: without a
 // usable GPU the program exits 1, like every other fatal error of the reference (OC_ERROR).
+#include <unistd.h>
 #include "pm_job.h"
 
 using namespace necat_host;
@@ -47,6 +48,14 @@ int main(int argc, char** argv)
     if (rc) { ref_volume.wait(); return fail("GPU", "no usable gfx950 device (libnecat_hip has no CPU fallback)"); }
     tr.stage("context created");
     const int status = pm_run_volume(ctx, vi, vid, opt, output, "oc2pmov", tr, &ref_volume);
+    // The job is over: its output is closed and renamed (or removed, status 1).  A process that runs ONE job does not take its context apart piece by piece
+    // (25 - 30 ms of hipFree / hipStreamDestroy for arenas the driver reclaims with the process anyway) nor run the runtime's exit handlers: it flushes its
+    // streams and leaves (round 6; NECAT_FAST_EXIT=0: the orderly way, as oc2pm's resident workers and every library user do).  necat.pl starts one such process per volume.
+    if (!(getenv("NECAT_FAST_EXIT") && atoi(getenv("NECAT_FAST_EXIT")) == 0)) {
+        tr.stage("leaving");
+        fflush(nullptr);
+        _exit(status);
+    }
     necat_ctx_destroy(ctx);
     tr.stage("context destroyed");
     return status;

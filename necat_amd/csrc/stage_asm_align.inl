@@ -102,7 +102,7 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
         if (boundA) {
             const u32 gA = (boundA + 63) / 64;
             const u32* d_nA = d_count + 4 * cur;
-            hipLaunchKernelGGL((k_ext_frag<kAsmWordsA, kAsmTWordsA>), dim3(grid_for((u64)gA * 64 * (kAsmWordsA + kAsmTWordsA), 256)), dim3(256), 0, s,
+            hipLaunchKernelGGL((k_ext_frag<kAsmWordsA, kAsmTWordsA>), dim3(grid_for((u64)gA * 64 * kFragSplit, 256)), dim3(256), 0, s,
                                drd, dref, (const BlockItem*)d_itemsA[cur], boundA, d_nA, cap, d_frag, ctl);
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<asm A>");
             if (g_asm_rc) {
@@ -157,7 +157,7 @@ int asm_align_coop(necat_ctx* ctx, const necat_volume* ref, const necat_volume* 
         // ---- list B: a plain list of nB items
         if (nB) {
             const u32 gB = (nB + 63) / 64;
-            hipLaunchKernelGGL((k_ext_frag<kAsmWords, kAsmTWords>), dim3(grid_for((u64)gB * 64 * (kAsmWords + kAsmTWords), 256)), dim3(256), 0, sB,
+            hipLaunchKernelGGL((k_ext_frag<kAsmWords, kAsmTWords>), dim3(grid_for((u64)gB * 64 * kFragSplit, 256)), dim3(256), 0, sB,
                                drd, dref, (const BlockItem*)d_itemsB[cur], nB, (const u32*)nullptr, 0u, d_fragB, ctl);
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<asm B>");
             if (g_asm_rc) {

@@ -220,7 +220,7 @@ struct BatchRun {
             const u32 epoch = ++ctx->epoch & 0x3fffffu, fl = epoch | (1u << 27);
             ExtLists next; next.count = c.count + 4 * nxt2_b; next.itemsA = c.itemsA[nxt2_b]; next.itemsB = c.itemsB[nxt2_b]; next.task_ops = X.task_ops; next.capA = c.cap;
             RoundCtl ctl; ctl.zero_bins = c.bins[slot];
-            hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, sb,
+            hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * kFragSplit, 256)), dim3(256), 0, sb,
                                drd, dref, itB, nB, d_nB, 0u, c.fragB[slot], ctl);
             NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
             NECAT_HIP(ctx, hipEventRecord(c.b0[slot], sb));
@@ -274,7 +274,7 @@ struct BatchRun {
             itB = c.sortedB[slot];
         }
         RoundCtl ctl; ctl.zero_bins = c.bins[slot];
-        hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * (kWordsB + kTWordsB), 256)), dim3(256), 0, sb,
+        hipLaunchKernelGGL((k_ext_frag<kWordsB, kTWordsB>), dim3(grid_for((u64)gB * 64 * kFragSplit, 256)), dim3(256), 0, sb,
                            drd, dref, itB, nB, d_nB, 0u, c.fragB[slot], ctl);
         NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<B>");
         NECAT_HIP(ctx, hipEventRecord(c.b0[slot], sb));
@@ -354,7 +354,7 @@ struct BatchRun {
         if (r >= 2) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, c.b2[r & 1], 0));        // B(r - 2) appended to lists[r]
         const u32 epoch = ++ctx->epoch & 0x3fffffu;
         RoundCtl ctl; ctl.count = d_nA; ctl.zero = c.count + 4 * nxt2; ctl.seq = seq0 + r + 1; ctl.pub = ring_dev + (seq0 + r) % kRoundRing;
-        hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)std::max(gA, 1u) * 64 * (kWordsA + kTWordsA), 256)), dim3(256), 0, c.sa,
+        hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)std::max(gA, 1u) * 64 * kFragSplit, 256)), dim3(256), 0, c.sa,
                            drd, dref, itA, bound, d_nA, c.cap, c.fragA, ctl);
         NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<A>");
         NECAT_HIP(ctx, hipEventRecord(c.a0[cur], c.sa));
