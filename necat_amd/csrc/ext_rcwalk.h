@@ -293,8 +293,12 @@ NECAT_D u32 fast_shw_ckr(const int b, const int qn, const int tn, const int step
 template <int NW, int TW, bool CARRY>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NECAT_CK_WAVES, NECAT_CK_WAVES)))
 k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u32 capA, const u64* __restrict__ frag, ulonglong2* __restrict__ ckpt,
-           u64* __restrict__ hcar, double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, int max_dist, u32 lo, u32 hi, u32 flags)
+           u64* __restrict__ hcar, double error, BlockResult* __restrict__ results, unsigned long long* __restrict__ stats, int max_dist, u32 lo, u32 hi, u32 flags,
+           const u64* __restrict__ q_bases = nullptr, const u64* __restrict__ t_bases = nullptr)
 {
+    // flags bit 22 (round 6, NECAT_FRAG_FUSE; needs bit 27): the wave cuts its 8 blocks' fragments out of the 2-bit volumes itself (q_bases / t_bases) - what k_ext_frag
+    // did in a launch of its own before every pass - and leaves them in `frag` for the walk and the finishing kernel: one kernel (30 - 54 us + its ramp and drain + a
+    // launch gap) less in every round's chain.  Same words, same places, same conditions as k_ext_frag.
     // work items [lo, hi) of the list (multiples of 64: a big list goes through a bounded checkpoint buffer in several launches);
     // checkpoint / delta slots are indexed by item - lo
     constexpr int FW = 2 * NW + TW, G = 8, N = kOcaBlockSize;
@@ -308,10 +312,11 @@ k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u
     const u64 item = first + (u64)sub;
     bool valid = item < end;
     int qn = N, tn = N;
+    FragGeom geo; geo.q_base = geo.t_base = 0; geo.q_dir = geo.t_dir = 1; geo.q_comp = geo.t_comp = 0;
     if (all && valid) {
         BlockItem it0;
         valid = list_item(lv, items, item, it0);
-        if (valid) { qn = it0.qn; tn = it0.tn; }
+        if (valid) { qn = it0.qn; tn = it0.tn; geo = it0.g; }
     }
     const bool ragged = all && __any(valid && (qn != N || tn != N));
     const u64 grp = item >> 6;
@@ -319,10 +324,25 @@ k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u
     const u64* fr = frag + grp * FW * 64 + il;
     const int nblk = (qn + 63) >> 6;
     u64 nlo = 0, nhi = 0;
+    if (CARRY && ((flags >> 22) & 1u)) {
+        u64* const fw = const_cast<u64*>(fr);
+        if (valid && b < nblk) {
+            u64 plo, phi;
+            load64_planes(q_bases, geo.q_base, geo.q_dir, geo.q_comp, b * 64, &plo, &phi);
+            nlo = ~plo; nhi = ~phi;
+            fw[(u64)b * 64] = nlo; fw[(u64)(NW + b) * 64] = nhi;
+        }
+        for (int w = b; w < TW; w += G) {
+            u64 x = 0ULL;
+            if (valid && w * 32 < tn) { x = load32_dir(t_bases, geo.t_base + (i64)geo.t_dir * (w * 32), geo.t_dir, geo.t_comp); fw[(u64)(2 * NW + w) * 64] = x; }
+            t_lds[sub][w] = even_bits(x) | (even_bits(x >> 1) << 32);
+        }
+    } else {
     if (valid && b < nblk) { nlo = fr[(u64)b * 64]; nhi = fr[(u64)(NW + b) * 64]; }
     for (int w = b; w < TW; w += G) {
         const u64 x = (valid && w * 32 < tn) ? fr[(u64)(2 * NW + w) * 64] : 0ULL;
         t_lds[sub][w] = even_bits(x) | (even_bits(x >> 1) << 32);
+    }
     }
     __syncthreads();
     ulonglong2* const ckp = ckpt + rc_at<G>(item - lo, CARRY ? kRcCk16 : kRcCk, 0, (size_t)b);

@@ -47,6 +47,7 @@ struct Knobs {
     u32 rc_listb;        // NECAT_RC_LISTB (default 1, needs NECAT_RC_CARRY): list B (blocks up to 794 x 794) through k_myers_ckg + k_rcwalk2 too; 0 = two-pass kernel + band pool + walk
     u32 rc_ragged;       // NECAT_RC_RAGGED (default 1, needs NECAT_RC_CARRY): the ragged blocks of those rounds through k_myers_ckg + k_rcwalk2 as well (0: two-pass kernel + lane walk on a stream of their own)
     u32 ck_lds;          // NECAT_CK_LDS (bytes, default 0): dynamic LDS claimed by every workgroup (one wave) of k_myers_ck - caps how many of its waves a CU holds (160 KB / (1 KB + this)), leaving wave slots to the chains of the other streams (A/B measurements)
+    u32 frag_fuse;       // NECAT_FRAG_FUSE (default 1; needs the merged big-round path): list A's checkpoint pass cuts its blocks' fragments out of the volumes itself (k_myers_ck flag bit 22) and k_round_ctl does the round's bookkeeping; 0 = k_ext_frag in a launch of its own before every pass, as until round 5
     u32 rc_merge;        // NECAT_RC_MERGE (default 1, needs NECAT_RC_RAGGED): the ragged list-A blocks of a big round through k_myers_ck's ragged fast path and the full blocks' walk launch; 0 = k_myers_ckg + a walk launch of their own on stream d
     u32 rc_prio;         // NECAT_RC_PRIO (bits; default 1: 41.6 -> 41.0 ms per step; 2 costs 0.5 ms, 4 nothing): waves that raise their issue priority (s_setprio 3) - 1: list A's walk (k_rcwalk2w: every wave; k_rcwalk3: its walking wave), 2: list A's checkpoint pass, 4: list B's walk, 8 / 16: only the WALKING wave of list A's / list B's walk, for the length of its walk (kernel opts bit 16)
     u32 rc_pipe, rc_pipe_min;    // NECAT_RC_PIPE (default 1 = off: 2 - 4 pieces cost 1.8 - 2.3 ms per step, tools/r04/run28.sh, run29.sh) / NECAT_RC_PIPE_MIN (default 49152 blocks): list A of a big round in pieces, walk of piece i beside the pass of piece i + 1
@@ -98,6 +99,7 @@ extern thread_local const Knobs* tl_knobs;      // the knobs of the context whos
 #define g_rc_ragged (necat::tl_knobs->rc_ragged)
 #define g_ck_lds (necat::tl_knobs->ck_lds)
 #define g_rc_merge (necat::tl_knobs->rc_merge)
+#define g_frag_fuse (necat::tl_knobs->frag_fuse)
 #define g_rc_prio (necat::tl_knobs->rc_prio)
 #define g_rc_pipe (necat::tl_knobs->rc_pipe)
 #define g_rc_pipe_min (necat::tl_knobs->rc_pipe_min)

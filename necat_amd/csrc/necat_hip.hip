@@ -122,6 +122,7 @@ void read_knobs(necat::Knobs& K)
     K.rc_prio = (u32)num("NECAT_RC_PRIO", 1);
     K.rc_pipe = (u32)std::min<unsigned long long>(8, std::max<unsigned long long>(1, num("NECAT_RC_PIPE", 1))); K.rc_pipe_min = (u32)num("NECAT_RC_PIPE_MIN", 49152);
     K.rc_merge = (u32)num("NECAT_RC_MERGE", 1);
+    K.frag_fuse = (u32)num("NECAT_FRAG_FUSE", 1);
     K.ck_lds = (u32)num("NECAT_CK_LDS", 0);
     K.rc_listb = K.rc_carry ? (u32)num("NECAT_RC_LISTB", 1) : 0u;
     K.rc_ragged = K.rc_carry ? (u32)num("NECAT_RC_RAGGED", 1) : 0u;

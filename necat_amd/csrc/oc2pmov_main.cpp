@@ -3,7 +3,6 @@
 // Same argv, same volume inputs, same candidate / M4 record files; the work runs on one MI355X
 // through libnecat_hip.so (device from NECAT_GPU, default 0).  There is no CPU fallback: without a
 // usable GPU the program exits 1, like every other fatal error of the reference (OC_ERROR).
-#include <unistd.h>
 #include "pm_job.h"
 
 using namespace necat_host;
@@ -48,14 +47,9 @@ int main(int argc, char** argv)
     if (rc) { ref_volume.wait(); return fail("GPU", "no usable gfx950 device (libnecat_hip has no CPU fallback)"); }
     tr.stage("context created");
     const int status = pm_run_volume(ctx, vi, vid, opt, output, "oc2pmov", tr, &ref_volume);
-    // The job is over: its output is closed and renamed (or removed, status 1).  A process that runs ONE job does not take its context apart piece by piece
-    // (25 - 30 ms of hipFree / hipStreamDestroy for arenas the driver reclaims with the process anyway) nor run the runtime's exit handlers: it flushes its
-    // streams and leaves (round 6; NECAT_FAST_EXIT=0: the orderly way, as oc2pm's resident workers and every library user do).  necat.pl starts one such process per volume.
-    if (!(getenv("NECAT_FAST_EXIT") && atoi(getenv("NECAT_FAST_EXIT")) == 0)) {
-        tr.stage("leaving");
-        fflush(nullptr);
-        _exit(status);
-    }
+    // (Round 6 tried leaving with _exit() right here - the output is closed and renamed, the driver reclaims the arenas with the process - to save the 25 - 30 ms of
+    // necat_ctx_destroy: the NEXT process then waited ~ 450 ms in its first big allocation while the driver scrubbed what this one had left mapped (tools/r06/run4.sh:
+    // 0.93 - 1.0 s per run against 0.49 - 0.6 s).  Memory handed back with hipFree is clean when the next process asks for it; so the context is taken apart in order.)
     necat_ctx_destroy(ctx);
     tr.stage("context destroyed");
     return status;

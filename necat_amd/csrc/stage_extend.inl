@@ -354,9 +354,17 @@ struct BatchRun {
         if (r >= 2) NECAT_HIP(ctx, hipStreamWaitEvent(c.sa, c.b2[r & 1], 0));        // B(r - 2) appended to lists[r]
         const u32 epoch = ++ctx->epoch & 0x3fffffu;
         RoundCtl ctl; ctl.count = d_nA; ctl.zero = c.count + 4 * nxt2; ctl.seq = seq0 + r + 1; ctl.pub = ring_dev + (seq0 + r) % kRoundRing;
+        // NECAT_FRAG_FUSE (round 6): the merged big-round path cuts its fragments inside the checkpoint pass (k_myers_ck flag bit 22); the round's bookkeeping - list sizes
+        // published, the counters of the list after next reset - is then the one-wave k_round_ctl, and list B's chain of the round (which waits for a0) starts that much earlier
+        const bool fuse_frag = g_frag_fuse && use_rc && g_rc_carry && g_rc_ragged && g_rc_merge && !wide_possible && !getenv("NECAT_RC_CKG_ALL") && bound > 0;
+        if (fuse_frag) {
+            hipLaunchKernelGGL(k_round_ctl, dim3(1), dim3(64), 0, c.sa, ctl);
+            NECAT_CHECK_LAUNCH(ctx, "k_round_ctl");
+        } else {
         hipLaunchKernelGGL((k_ext_frag<kWordsA, kTWordsA>), dim3(grid_for((u64)std::max(gA, 1u) * 64 * kFragSplit, 256)), dim3(256), 0, c.sa,
                            drd, dref, itA, bound, d_nA, c.cap, c.fragA, ctl);
         NECAT_CHECK_LAUNCH(ctx, "k_ext_frag<A>");
+        }
         NECAT_HIP(ctx, hipEventRecord(c.a0[cur], c.sa));
         a_timed.push_back(0);
         if (!bound) return NECAT_OK;
@@ -415,7 +423,8 @@ struct BatchRun {
                 if (ckg_all && g_rc_ragged) {}
                 else if (g_rc_carry)
                     hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA, true>), dim3((cn + 7) / 8), dim3(64), g_ck_lds, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error, c.resA, X.stats, g_rc_maxdist, lo, hi,
-                                       (merged ? fl_all : epoch) | (g_ck_post ? 0u : 1u << 24) | (g_rc_prio & 2u ? 1u << 23 : 0u));
+                                       (merged ? fl_all : epoch) | (g_ck_post ? 0u : 1u << 24) | (g_rc_prio & 2u ? 1u << 23 : 0u) | (fuse_frag && merged ? 1u << 22 : 0u),
+                                       (const u64*)drd.bases, (const u64*)dref.bases);
                 else
 #if NECAT_XCHECK
                     hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA, false>), dim3((cn + 7) / 8), dim3(64), 0, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error, c.resA, X.stats, g_rc_maxdist, lo, hi, epoch);
