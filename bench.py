@@ -1026,14 +1026,15 @@ def main():
     agg = new_agg()
     n_over = 0
     gbp = 0.0
+    step_counts = set()
     cands, m4 = held[0], held[1]
     del held
     for _ in range(args.steps):
         cands, m4, t_index, tm, sh = step()
         if comm is None or rank == 0:        # single-volume mode: rank 0 holds the gathered records of all ranks
-            n_over += (m4.shape[0] if m4 is not None else cands.shape[0])
-            if m4 is not None:
-                gbp += float((m4["qend"] - m4["qoff"]).sum()) / 1e9
+            n_step = m4.shape[0] if m4 is not None else cands.shape[0]
+            n_over += n_step
+            step_counts.add(n_step)
         agg_add(agg, tm, t_index)
         if sh is not None:
             agg["ix_local_ms"] += sh.index_local_ms; agg["ix_xchg_ms"] += sh.index_exchange_ms; agg["ix_xchg_bytes"] += sh.index_exchange_bytes
@@ -1041,6 +1042,13 @@ def main():
             agg["gather_ms"] += sh.gather_ms; agg["gather_bytes"] += sh.gather_bytes; agg["reads_local"] = int(sh.reads_local)
     barrier_sync(dist, local)
     elapsed = time.perf_counter() - t0
+    # Gbp aligned: sum(qend - qoff) over the records.  Every step maps the same volume and returns the same records (checked: one record count), so the sum is taken
+    # ONCE, on the last step's records, after the clock has stopped - until round 5 this numpy reduction over a 22 MB structured array (0.5 - 1.4 ms of host time per
+    # step, none of it the hot path's) sat inside the timed loop
+    if (comm is None or rank == 0) and m4 is not None:
+        if len(step_counts) != 1:
+            raise SystemExit("bench.py: the steps returned different record counts (%s)" % sorted(step_counts))
+        gbp = args.steps * float((m4["qend"] - m4["qoff"]).sum()) / 1e9
     from necat_amd import shard
     elapsed, tot_over, tot_gbp = shard.reduce_step_stats(dist, elapsed, float(n_over), gbp,
                                                          device="cuda" if (dist is not None and dist.get_backend() == "nccl") else None)

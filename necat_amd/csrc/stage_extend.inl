@@ -757,7 +757,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     if (nlanes == 2) {
         // ---- two lanes: batch i + 1 starts on the free lane once batch i is in its tail (BatchRun::tail); ONE host thread turns both round loops,
         // whichever has its next list sizes published (BatchRun::ready) - the host still never waits for the device inside a loop
-        struct LaneRun { std::unique_ptr<BatchRun> run; int state = 0; int rc = NECAT_OK; };      // state: 0 free, 1 in its rounds, 2 draining
+        struct LaneRun { std::unique_ptr<BatchRun> run; int state = 0; int rc = NECAT_OK; u32 polls = 0; };      // state: 0 free, 1 in its rounds, 2 draining, 3 its result kernel in flight
         LaneRun lr[2];
         uint64_t next_base = 0, done = 0; size_t started = 0;
         int last = -1;                              // the lane of the batch started last
@@ -795,13 +795,24 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
             for (int l = 0; l < 2 && !err; ++l) {
                 LaneRun& R = lr[l];
                 if (R.state == 1 && R.run->ready()) { R.rc = R.run->step(); progressed = true; if (R.run->over) R.state = 2; }
-                if (R.state == 2 && (R.rc || R.run->drained())) {
+                // (a draining lane is looked at every 64th turn of the loop: three hipStreamQuery calls per turn would be the OTHER lane's launch latency)
+                if (R.state == 2 && (R.rc || ((++R.polls & 63u) == 0 && R.run->drained()))) {
                     if (!(err = R.run->finish(R.rc))) {
+                        // the batch's records: launched and left to an event - the host thread goes on turning the other lane's rounds instead of waiting here
                         hipLaunchKernelGGL(k_ext_result, dim3(grid_for(kb[l].n, 256)), dim3(256), 0, kb[l].sa, (const ExtTask*)kb[l].tasks, kb[l].n, (const necat_candidate*)d_cands,
                                            opt->align_size_cutoff, d_m4, d_ok, rm ? 1 : 0);
-                        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(kb[l].sa) != hipSuccess) err = set_err(ctx, NECAT_ERR_DEVICE, "k_ext_result failed");
+                        if (hipGetLastError() != hipSuccess || hipEventRecord(lane[l].ev[31], kb[l].sa) != hipSuccess) err = set_err(ctx, NECAT_ERR_DEVICE, "k_ext_result failed");
                     }
-                    R.run.reset(); R.state = 0; ++done; progressed = true;
+                    R.run.reset(); R.state = err ? 0 : 3; R.polls = 0; progressed = true;
+                    if (err) ++done;
+                }
+                if (R.state == 3 && (++R.polls & 15u) == 0) {
+                    const hipError_t q = hipEventQuery(lane[l].ev[31]);
+                    if (q == hipErrorNotReady) (void)hipGetLastError();
+                    else {
+                        if (q != hipSuccess) err = set_err(ctx, NECAT_ERR_DEVICE, "k_ext_result failed: %s", hipGetErrorString(q));
+                        R.state = 0; ++done; progressed = true;
+                    }
                 }
             }
             if (progressed) { idle = 0; t_idle = wall_ms(); continue; }
@@ -815,7 +826,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
             }
         }
         if (err) {
-            for (LaneRun& R : lr) if (R.state) { (void)R.run->finish(err); R.run.reset(); }       // nothing of a lane is in flight when its buffers are handed on
+            for (int l = 0; l < 2; ++l) { LaneRun& R = lr[l]; if (R.state == 3) (void)hipStreamSynchronize(kb[l].sa); else if (R.state) { (void)R.run->finish(err); R.run.reset(); } }       // nothing of a lane is in flight when its buffers are handed on
             cleanup(); return err;
         }
     } else
