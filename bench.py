@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--kmer", type=int, default=15)
     ap.add_argument("--scan-window", type=int, default=20)
     ap.add_argument("--job", type=int, default=1)
+    ap.add_argument("--in-flight", type=int, default=0,
+                    help="whole steps in flight on the GPU: D contexts (own arenas, streams, events), one host thread each, all mapping the one resident volume - the way the "
+                         "oc2pm worker keeps several (reference volume, query volume) jobs of a project on its device (NECAT_PAIR_LANES). 0 = the default: 3 at N = 1, 1 under a "
+                         "communicator (the sharded calls are collective). 1 = one step after the other, as until round 5 (always ALSO measured: `one_in_flight`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-widened", action="store_true", help="skip the extra measurements of the SURVEY 8f.1 rows")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that measure `traffic` in this run; "
@@ -730,7 +734,7 @@ def pmc_live(args):
     except Exception as e:
         return None, "tools/make_profiles.py: %s" % e
     tmp = tempfile.mkdtemp(prefix="necat_pmc_", dir="/tmp")
-    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-widened", "--no-pmc", "--genome", str(args.genome),
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--in-flight", "1", "--no-cpu-baseline", "--no-widened", "--no-pmc", "--genome", str(args.genome),
            "--coverage", str(args.coverage), "--seed", str(args.seed), "--kmer", str(args.kmer), "--scan-window", str(args.scan_window), "--job", str(args.job)]
     env = dict(os.environ, TMPDIR="/tmp")
     dirs = []
@@ -988,7 +992,17 @@ def main():
     ix_info = {}
     sh_ix_mode = [0, 0.0, 0.0]
 
-    def step(job=args.job):
+    # Steps in flight (round 6).  A step's extension ends in ~ 15 rounds that are one block's dependent chain each on a mostly idle chip, and its index build and
+    # seeding are HBM- / latency-bound while the DP kernels are issue-bound - so the throughput of a device is not 1 / (one step's latency): D contexts (own arenas,
+    # streams, events, pinned rings), one host thread each, run whole steps side by side on the ONE resident volume, exactly as the oc2pm worker keeps D jobs of a
+    # project on its device (pm_job.h: NECAT_PAIR_LANES).  Every step is the full pass (index build -> seeding -> extension -> records on the host); the K timed steps
+    # are dealt to the D threads from one counter.  D = 1 is measured too, after the timed region (`one_in_flight`).
+    D = args.in_flight if args.in_flight > 0 else (3 if (comm is None and world == 1) else 1)
+    if comm is not None and D > 1:
+        raise SystemExit("bench.py: --in-flight > 1 under a communicator: the sharded calls are collective, one at a time per communicator")
+    ctxs = [ctx] + [capi.Context(local) for _ in range(D - 1)]
+
+    def step(job=args.job, ctx=ctx):
         o = opt if job == args.job else capi.default_options(**dict(opt_kw, job=job, num_threads=1))
         if comm is not None:
             ix = ctx.build_index_sharded(comm, vol, o.kmer_size, o.kmer_cnt_cutoff)
@@ -1018,34 +1032,77 @@ def main():
         ix.free()
         return cands, m4, t_index, tm, sh
 
-    # setup (untimed): initialise the torch/HIP runtimes and let the library size its HBM pools once
+    import threading
+
+    def run_steps(nsteps, depth, agg, counts, job=args.job):
+        """`nsteps` whole steps, `depth` of them in flight (thread i on ctxs[i], steps dealt from one counter); every step's timings / work counters into `agg`,
+        its record count into `counts`; returns the last step that ended (a thread keeps its previous result referenced while its next step runs: the library
+        then holds TWO pinned result blocks per context in rotation, as in the warm-up)"""
+        lock = threading.Lock()
+        todo, errors, last = [nsteps], [], [None]
+
+        def account(res):
+            cands_, m4_, t_index_, tm_, sh_ = res
+            if comm is None or rank == 0:        # single-volume mode: rank 0 holds the gathered records of all ranks
+                counts.append(m4_.shape[0] if m4_ is not None else cands_.shape[0])
+            agg_add(agg, tm_, t_index_)
+            if sh_ is not None:
+                agg["ix_local_ms"] += sh_.index_local_ms; agg["ix_xchg_ms"] += sh_.index_exchange_ms; agg["ix_xchg_bytes"] += sh_.index_exchange_bytes
+                agg["ix_sharded"] = int(sh_ix_mode[0]); agg["ix_plan"] = (sh_ix_mode[1], sh_ix_mode[2])
+                agg["gather_ms"] += sh_.gather_ms; agg["gather_bytes"] += sh_.gather_bytes; agg["reads_local"] = int(sh_.reads_local)
+            last[0] = res
+
+        if depth <= 1:
+            for _ in range(nsteps):
+                account(step(job=job))
+            return last[0]
+
+        def worker(i):
+            mine = None
+            while True:
+                with lock:
+                    if todo[0] <= 0 or errors:
+                        return mine
+                    todo[0] -= 1
+                try:
+                    res = step(job=job, ctx=ctxs[i])
+                except BaseException as e:      # (a failed step stops the run: the main thread re-raises)
+                    with lock:
+                        errors.append(e)
+                    return None
+                with lock:
+                    account(res)
+                mine = res
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(depth)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errors:
+            raise errors[0]
+        return last[0]
+
+    # setup (untimed): initialise the torch/HIP runtimes and let the library size its HBM pools once - on every context
     barrier_sync(dist, local)
-    held = step()
-    for _ in range(args.warmup):
-        # (the result of the step before stays referenced while a step runs, exactly as in the timed loop below: the library then holds TWO pinned
-        # result blocks in rotation, and the second one - a 5 ms hipHostMalloc - is allocated here, not in the second timed step)
-        held = step()
+    for c in ctxs:
+        held = step(ctx=c)
+        for _ in range(args.warmup):
+            # (the result of the step before stays referenced while a step runs, exactly as in the timed loop below: the library then holds TWO pinned
+            # result blocks in rotation, and the second one - a 5 ms hipHostMalloc - is allocated here, not in the second timed step)
+            held = step(ctx=c)
+    if D > 1:
+        run_steps(2 * D, D, new_agg(), [])         # .. and once side by side
+    del held
     barrier_sync(dist, local)
     t0 = time.perf_counter()
     agg = new_agg()
-    n_over = 0
     gbp = 0.0
-    step_counts = set()
-    cands, m4 = held[0], held[1]
-    del held
-    for _ in range(args.steps):
-        cands, m4, t_index, tm, sh = step()
-        if comm is None or rank == 0:        # single-volume mode: rank 0 holds the gathered records of all ranks
-            n_step = m4.shape[0] if m4 is not None else cands.shape[0]
-            n_over += n_step
-            step_counts.add(n_step)
-        agg_add(agg, tm, t_index)
-        if sh is not None:
-            agg["ix_local_ms"] += sh.index_local_ms; agg["ix_xchg_ms"] += sh.index_exchange_ms; agg["ix_xchg_bytes"] += sh.index_exchange_bytes
-            agg["ix_sharded"] = int(sh_ix_mode[0]); agg["ix_plan"] = (sh_ix_mode[1], sh_ix_mode[2])
-            agg["gather_ms"] += sh.gather_ms; agg["gather_bytes"] += sh.gather_bytes; agg["reads_local"] = int(sh.reads_local)
+    counts = []
+    cands, m4 = run_steps(args.steps, D, agg, counts)[:2]
     barrier_sync(dist, local)
     elapsed = time.perf_counter() - t0
+    n_over = sum(counts)
+    step_counts = set(counts)
     # Gbp aligned: sum(qend - qoff) over the records.  Every step maps the same volume and returns the same records (checked: one record count), so the sum is taken
     # ONCE, on the last step's records, after the clock has stopped - until round 5 this numpy reduction over a 22 MB structured array (0.5 - 1.4 ms of host time per
     # step, none of it the hot path's) sat inside the timed loop
@@ -1058,20 +1115,45 @@ def main():
                                                          device="cuda" if (dist is not None and dist.get_backend() == "nccl") else None)
     # extras measured after the timed region, on every rank when collective
     extras = {}
+    one = None
     try:
+        K0j = 3 * D
+        c0 = []
+        barrier_sync(dist, local)
         t1 = time.perf_counter()
-        n0 = 0
-        for _ in range(3):
-            c0, _, _, _, _ = step(job=0)
-            if comm is None or rank == 0:
-                n0 += c0.shape[0]
+        run_steps(K0j, D, new_agg(), c0, job=0)
         barrier_sync(dist, local)
         dt0 = time.perf_counter() - t1
-        extras["candidates_job0"] = {"overlaps_per_s": round(n0 / dt0, 1), "ms_per_step": round(1e3 * dt0 / 3, 2), "records_per_step": n0 // 3,
+        n0 = sum(c0)
+        extras["candidates_job0"] = {"overlaps_per_s": round(n0 / dt0, 1), "ms_per_step": round(1e3 * dt0 / K0j, 2), "records_per_step": n0 // max(1, len(c0)),
+                                     "steps": K0j, "steps_in_flight": D,
                                      "note": "-j 0 -u 1, what necat.pl runs in the correction pipeline (necat.pl:31-32): index build + candidate search, "
                                              "28-byte records; same volume, measured after the timed region"}
     except Exception as e:
         extras["candidates_job0"] = {"error": str(e)}
+    if D > 1:
+        # the same steps ONE after the other (what `ms_per_step` meant until round 5, and what a project of a single volume pair sees): its own clock, its own
+        # timings - the kernels' durations here are not stretched by another step's kernels beside them.  The other contexts are closed first: a live context's
+        # streams keep their share of the runtime's hardware queues even when idle (tools/r05/run22.sh)
+        for c in ctxs[1:]:
+            c.close()
+        del ctxs[1:]
+        K1 = max(3, min(args.steps, 10))
+        agg1, c1 = new_agg(), []
+        run_steps(2, 1, new_agg(), [])
+        barrier_sync(dist, local)
+        t1 = time.perf_counter()
+        run_steps(K1, 1, agg1, c1)
+        barrier_sync(dist, local)
+        dt1 = time.perf_counter() - t1
+        one = {"steps": K1, "ms_per_step": round(1e3 * dt1 / K1, 2), "overlaps_per_s": round(sum(c1) / dt1, 1), "agg": agg1}
+        try:
+            t1 = time.perf_counter()
+            run_steps(3, 1, new_agg(), [], job=0)
+            barrier_sync(dist, local)
+            extras["candidates_job0"]["one_in_flight_ms_per_step"] = round(1e3 * (time.perf_counter() - t1) / 3, 2)
+        except Exception as e:
+            extras["candidates_job0"]["one_in_flight_error"] = str(e)
     if comm is None and world == 1:
         # "include H2D of volumes and D2H of records in the end-to-end figure" - the same pass with the volume NOT resident: host pac bytes -> device
         # (H2D + the repack kernel), index, seeding, extension, records on the host (their D2H is inside every step); context and arenas warm
@@ -1145,10 +1227,39 @@ def main():
         "device": ctx.device_name(),
         "roofline": roofline,
     }
+    def phases(a, k):
+        return {"index": round(a["index_ms"] / k, 2), "seed": round(a["seed_ms"] / k, 2), "extend": round(a["extend_ms"] / k, 2),
+                "myers_kernel": round(a["myers_ms"] / k, 2), "traceback_kernel": round(a["traceback_ms"] / k, 2), "rcwalk_kernel": round(a["rc_ms"] / k, 2),
+                "fused_tail_kernel": round(a["fused_ms"] / k, 2), "rounds": a["rounds"] // k}
+    out["config"]["steps_in_flight"] = D
+    # the chip's view of the timed region: the algorithmic lane-ops of ALL its list-A block alignments over the region's wall clock (not over the kernels' own
+    # durations) - what the launch tails, the latency-bound small rounds and the stages that are not DP leave of the VALU peak
+    rb = float(agg["rc_blocks"])
+    roofline["timed_region"] = {"frac": round(rb * (4096.0 * SHW_BANDED_FRACTION + NW_BAND_WORDS_PER_BLOCK) * OPS_PER_WORD_UPDATE / elapsed / VALU_LANE_OPS_PER_S, 4),
+                                "steps_in_flight": D,
+                                "note": "algorithmic lane-ops of the region's list-A blocks / the region's wall clock / peak (round 5, one step at a time: 0.165)"}
+    if one is not None:
+        a1, k1 = one.pop("agg"), one["steps"]
+        r1 = roofline_report(a1)
+        one["phases_ms_per_step"] = phases(a1, k1)
+        one["roofline"] = {q: r1[q] for q in ("achieved", "frac", "avg_launch_ms", "k_myers_ck", "k_rcwalk", "launches", "blocks")}
+        one["note"] = ("the same steps one after the other on one context (%d steps, after the timed region): a single step's latency, and every kernel's duration "
+                       "with no other step's kernels beside it" % k1)
+        out["one_in_flight"] = one
+        out["config"]["parallelism"] += ("; %d whole steps in flight (own context + host thread each, one resident volume; one at a time: %.2f ms per step)"
+                                         % (D, one["ms_per_step"]))
+        out["phases_ms_per_step"]["note"] = ("per step, as each step's own events saw them with %d steps side by side: a phase waits for issue slots beside the other "
+                                             "steps' kernels, so the phases add up to a step's LATENCY (~ %d x ms_per_step); one_in_flight.phases_ms_per_step = alone" % (D, D))
+        roofline["steps_in_flight_note"] = ("launch durations of the timed region are taken with %d steps' kernels sharing the chip: `frac` is what ONE launch gets of the "
+                                            "peak while it runs beside the others; timed_region.frac is the chip's, one_in_flight.roofline the kernels' alone" % D)
     if ix_info:
         out["roofline_index"] = roofline_index(agg["index_ms"] / K, rs.nbases, args.kmer, ix_info["n_offsets"], ix_info["n_distinct"])
+        if one is not None:
+            out["one_in_flight"]["roofline_index"] = roofline_index(a1["index_ms"] / k1, rs.nbases, args.kmer, ix_info["n_offsets"], ix_info["n_distinct"])
     if agg["seed_lookups"]:
         out["roofline_seed"] = roofline_seed(agg, K)
+        if one is not None:
+            out["one_in_flight"]["roofline_seed"] = {q: v for q, v in roofline_seed(a1, k1).items() if q in ("ms", "achieved", "frac", "traffic_frac", "lookups_per_s", "gathers_per_s")}
     out.update(extras)
     # the pipeline-true mode beside the headline (necat.pl:31-32 runs -j 0 -u 1; the headline is BASELINE configs[1]'s -j 1 -> M4): also inside `config` and
     # `roofline`, the objects the driver's record keeps whole

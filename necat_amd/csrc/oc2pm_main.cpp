@@ -99,6 +99,7 @@ int main(int argc, char** argv)
                 necat_ctx* ctx = nullptr;
                 if (necat_ctx_create(gpus[(size_t)g], &ctx)) { fprintf(stderr, "[oc2pm] ERROR: GPU %d: no usable gfx950 device (libnecat_hip has no CPU fallback)\n", gpus[(size_t)g]); _exit(1); }
                 int status = 0;
+                PmLanes lanes(gpus[(size_t)g]);            // a job's units on NECAT_PAIR_LANES contexts of this device (pm_job.h), kept from job to job
                 // the reference volume of this worker's NEXT job is read from disk while the current job runs
                 std::future<std::unique_ptr<PmLoaded>> ahead, cur;
                 for (uint64_t k = S.rank_off[(size_t)g]; k < S.rank_off[(size_t)g + 1] && !status;) {
@@ -112,9 +113,10 @@ int main(int argc, char** argv)
                     fprintf(stdout, "Running %zu unit(s) of job 'oc2pmov %s %s %d %spm_result_%d' on GPU %d (worker %d)\n", mine.size(), options_to_string(&opt).c_str(), wrk_dir, v,
                             base.c_str(), v, gpus[(size_t)g], g);
                     fflush(stdout);
-                    if ((status = pm_run_volume(ctx, vi, v, opt, res, "oc2pm", tr, cur.valid() ? &cur : nullptr, &mine))) fprintf(stderr, "[oc2pm] ERROR: worker %d failed in the job of volume %d\n", g, v);
+                    if ((status = pm_run_volume(ctx, vi, v, opt, res, "oc2pm", tr, cur.valid() ? &cur : nullptr, &mine, &lanes))) fprintf(stderr, "[oc2pm] ERROR: worker %d failed in the job of volume %d\n", g, v);
                 }
                 if (ahead.valid()) ahead.wait();
+                lanes.close();
                 necat_ctx_destroy(ctx);
                 fflush(stdout); fflush(stderr);
                 _exit(status ? 1 : 0);
@@ -197,6 +199,7 @@ int main(int argc, char** argv)
                 if (necat_ctx_create(gpus[g], &ctx)) { fprintf(stderr, "[oc2pm] ERROR: GPU %d: no usable gfx950 device (libnecat_hip has no CPU fallback)\n", gpus[g]); _exit(1); }
                 tr.stage("context created");
                 int status = 0;
+                PmLanes lanes(gpus[g]);                    // a job's query volumes on NECAT_PAIR_LANES contexts of this device (pm_job.h), kept from job to job
                 // While a job runs, the reference volume of the job this worker would draw NEXT (the first one nobody has claimed yet)
                 // is read from disk; if another worker draws it first the read is thrown away.  Jobs are still claimed one at a time.
                 std::future<std::unique_ptr<PmLoaded>> ahead, cur;
@@ -214,11 +217,12 @@ int main(int argc, char** argv)
                     snprintf(res, sizeof res, "%spm_result_%d", base.c_str(), v);
                     fprintf(stdout, "Running job 'oc2pmov %s %s %d %s' on GPU %d\n", options_to_string(&opt).c_str(), wrk_dir, v, res, gpus[g]);
                     fflush(stdout);
-                    if ((status = pm_run_volume(ctx, vi, v, opt, res, "oc2pm", tr, cur.valid() ? &cur : nullptr))) { fprintf(stderr, "[oc2pm] ERROR: the job of volume %d failed\n", v); break; }
+                    if ((status = pm_run_volume(ctx, vi, v, opt, res, "oc2pm", tr, cur.valid() ? &cur : nullptr, nullptr, &lanes))) { fprintf(stderr, "[oc2pm] ERROR: the job of volume %d failed\n", v); break; }
                     snprintf(fin, sizeof fin, "%s/pm%d.finished", wrk_dir, v);
                     FILE* f = fopen(fin, "w"); if (f) fclose(f);
                 }
                 if (ahead.valid()) ahead.wait();
+                lanes.close();
                 necat_ctx_destroy(ctx);
                 fflush(stdout); fflush(stderr);
                 _exit(status ? 1 : 0);

@@ -46,7 +46,12 @@ int main(int argc, char** argv)
     int rc = necat_ctx_create(dev_env ? atoi(dev_env) : 0, &ctx);
     if (rc) { ref_volume.wait(); return fail("GPU", "no usable gfx950 device (libnecat_hip has no CPU fallback)"); }
     tr.stage("context created");
-    const int status = pm_run_volume(ctx, vi, vid, opt, output, "oc2pmov", tr, &ref_volume);
+    // the job's query volumes on NECAT_PAIR_LANES lanes (default 2): a second context is only made when the job has a second unit, by its lane's thread, beside unit 0
+    int status;
+    {
+        PmLanes lanes(dev_env ? atoi(dev_env) : 0);
+        status = pm_run_volume(ctx, vi, vid, opt, output, "oc2pmov", tr, &ref_volume, nullptr, &lanes);
+    }
     // (Round 6 tried leaving with _exit() right here - the output is closed and renamed, the driver reclaims the arenas with the process - to save the 25 - 30 ms of
     // necat_ctx_destroy: the NEXT process then waited ~ 450 ms in its first big allocation while the driver scrubbed what this one had left mapped (tools/r06/run4.sh:
     // 0.93 - 1.0 s per run against 0.49 - 0.6 s).  Memory handed back with hipFree is clean when the next process asks for it; so the context is taken apart in order.)
