@@ -229,7 +229,7 @@ NECAT_D u32 fast_shw8_ckp(const int b, const u64* __restrict__ tw, const u64 nlo
 // (G lanes per block - 8: list A, 16: list B at 13 words; NWS: words per checkpoint / delta slot of the geometry; the key keeps the step in 10 bits)
 template <int G, int NWS, int TW>
 NECAT_D u32 fast_shw_ckr(const int b, const int qn, const int tn, const int steps, const u64* __restrict__ tw, const u64 nlo, const u64 nhi,
-                         ulonglong2* __restrict__ ck, u64* __restrict__ hc)
+                         ulonglong2* __restrict__ ck, u64* __restrict__ hc, const bool ckr_fast_windows = true)
 {
     static_assert(G == 8 || G == 16, "the carries run on DPP row_shr: a block is half a row or a row of 16 lanes");
     static_assert(TW * 32 + G <= 1024, "step count in 10 bits of the key");
@@ -250,6 +250,7 @@ NECAT_D u32 fast_shw_ckr(const int b, const int qn, const int tn, const int step
     u32 S = (u32)qn, key = 0xffffffffu;
     u64 dA, dB;
     u32 cph = 0x80000000u, cmh = 0u;
+    constexpr int ST = kRcStride<NWS>;
     for (int s0 = 0; s0 < steps; s0 += 32) {
         {
             const u64 x = (s0 >> 5) < TW ? tw[s0 >> 5] : 0ULL;
@@ -257,6 +258,36 @@ NECAT_D u32 fast_shw_ckr(const int b, const int qn, const int tn, const int step
             tlo = b ? __builtin_amdgcn_alignbit(xl, plo, sk) : xl;
             thi = b ? __builtin_amdgcn_alignbit(xh, phi, sk) : xh;
             plo = xl; phi = xh;
+        }
+        // Round 6: a window in which EVERY lane of the wave that has a word stays inside its block's columns - and short of its last one - for all 32 steps (the blocks
+        // of a wave are of like size: all but the first and the last two or three windows of a list-B wave) runs unrolled, without a per-step lane mask, as the
+        // full blocks' pass does (fast_shw8_ckp): the step number is a constant, the lanes that store a checkpoint at it are those of ONE word - a loop-invariant
+        // scalar mask -, the running minimum is kept by every lane on a row of its own (only the last word's is read) instead of under an exec mask.  Lanes without a
+        // word run along: they store nothing, and nobody reads what they publish (the lane below them has no word either; the last lane of a half row always
+        // publishes the boundary).  49 -> 38 vector and 18 -> 2 scalar instructions per step.
+        if (ckr_fast_windows && __all(!have || (s0 >= b && s0 + 31 - b < tn - 1))) {
+            ulonglong2* const ckr = ck + (size_t)(s0 >> 4) * ST;
+            u64* const hcr = hc + (size_t)(s0 >> 5) * ST;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                cph = dpp_row_shr1(w.pubP, cph); cmh = dpp_row_shr1(w.pubM, cmh);
+                const u32 ma = (u32)__builtin_amdgcn_sbfe((int)tlo, (u32)j, 1u), mb = (u32)__builtin_amdgcn_sbfe((int)thi, (u32)j, 1u);
+                const u32 el = bop<0x60>(nlo_l ^ ma, nhi_l, mb) | pad_l, eh = bop<0x60>(nlo_h ^ ma, nhi_h, mb) | pad_h;
+                u32 phh, mhh, phl, mhl;
+                fast_advance<false>(w, el, eh, cph, cmh, cm, phh, mhh, dA, dB, &phl, &mhl);
+                const u32 pw = row_hi ? phh : phl, mw = row_hi ? mhh : mhl;
+                S += ((pw >> psh) & 1u) - ((mw >> psh) & 1u);
+                const u32 k2 = (S << 10) + (u32)(s0 + j);
+                key = k2 < key ? k2 : key;
+                asm volatile("" : "+v"(key));                      // (the minimum is taken HERE: left to itself the scheduler sinks the 32 steps' updates below the window and keeps every step's Ph / Mh words alive for them - 188 registers)
+                hp = __builtin_amdgcn_alignbit(hp, phh, 31); hm = __builtin_amdgcn_alignbit(hm, mhh, 31);
+                const int K = ((j & 15) + 1) & 15;                 // the word whose column is 15 mod 16 at this step
+                if (K < G && b == K && have) {
+                    ckr[((j - K) >> 4) * ST] = make_ulonglong2(w.Pv, w.Mv);
+                    if (j == ((K + 31) & 31)) hcr[((j - K) >> 5) * ST] = (u64)hp | ((u64)hm << 32);
+                }
+            }
+            continue;
         }
         const int jn = steps - s0 < 32 ? steps - s0 : 32;
         for (int j = 0; j < jn; ++j) {
@@ -351,7 +382,7 @@ k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u
     if (ragged) {
         int steps = valid ? tn + nblk - 1 : 0;
         for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
-        key = fast_shw_ckr<8, 8, TW>(b, valid ? qn : 0, valid ? tn : 0, steps, t_lds[sub], nlo, nhi, ckp, hcp);
+        key = fast_shw_ckr<8, 8, TW>(b, valid ? qn : 0, valid ? tn : 0, steps, t_lds[sub], nlo, nhi, ckp, hcp, !((flags >> 28) & 1u));      // (bit 28, NECAT_CKR_FAST=0: every window rolled, as until round 5)
 #ifdef NECAT_CK_MICRO
     } else if (CARRY && !((flags >> 24) & 1u)) key = fast_shw8_ckp<TW>(b, t_lds[sub], nlo, nhi, ckp, hcp, (flags >> 20) & 1u);
 #else
@@ -666,7 +697,8 @@ k_myers_ckf(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
     __syncthreads();
     int steps = valid ? tn + nblk - 1 : 0;
     for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
-    const u32 key = fast_shw_ckr<G, NW, TW>(b, qn, tn, steps, t_lds[sub], nlo, nhi, ckpt + rc_at<NW>(item - lo, CK, 0, (size_t)b), hcar + rc_at<NW>(item - lo, SEGS, 0, (size_t)b));
+    const u32 key = fast_shw_ckr<G, NW, TW>(b, qn, tn, steps, t_lds[sub], nlo, nhi, ckpt + rc_at<NW>(item - lo, CK, 0, (size_t)b), hcar + rc_at<NW>(item - lo, SEGS, 0, (size_t)b),
+                                            !((epoch >> 28) & 1u));      // (bit 28, NECAT_CKR_FAST=0: every window rolled, as until round 5)
     const int bl = nblk > 0 ? nblk - 1 : 0;
     const u32 bkey = (u32)__shfl((int)key, (lane / G) * G + bl);
     int best = (int)(bkey >> 10);

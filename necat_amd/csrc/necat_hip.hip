@@ -119,6 +119,7 @@ void read_knobs(necat::Knobs& K)
     K.rc_dbg = (u32)num("NECAT_RC_DBG", 0) & 6u;
     K.rc_fastb = (u32)num("NECAT_RC_FASTB", 1);
     K.ck_post = (u32)num("NECAT_CK_POST", 1);
+    K.ckr_fast = (u32)num("NECAT_CKR_FAST", 1);
     K.rc_prio = (u32)num("NECAT_RC_PRIO", 1);
     K.rc_pipe = (u32)std::min<unsigned long long>(8, std::max<unsigned long long>(1, num("NECAT_RC_PIPE", 1))); K.rc_pipe_min = (u32)num("NECAT_RC_PIPE_MIN", 49152);
     K.rc_merge = (u32)num("NECAT_RC_MERGE", 1);

@@ -87,7 +87,7 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
                 if (full) {
                     if (batch_fast)
                     hipLaunchKernelGGL((k_myers_ckf<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag, ck, hcar, error,
-                                       d_res, d_stats, epoch, 0u, g * 64);
+                                       d_res, d_stats, epoch | (g_ckr_fast ? 0u : 1u << 28), 0u, g * 64);
                     else
                     hipLaunchKernelGGL((k_myers_ckg<kWordsA, kTWordsA, kColsA, 8>), dim3((m + 7) / 8), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag, ck, hcar, error,
                                        d_res, d_stats, epoch, 0u, g * 64);
@@ -99,7 +99,7 @@ int necat_edlib_align_batch(necat_ctx* ctx, const uint8_t* seqs, uint64_t seqs_l
                 } else {
                     if (batch_fast)
                     hipLaunchKernelGGL((k_myers_ckf<kWordsB, kTWordsB, kColsB, 16>), dim3((m + 3) / 4), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag, ck, hcar, error,
-                                       d_res, d_stats, epoch, 0u, g * 64);
+                                       d_res, d_stats, epoch | (g_ckr_fast ? 0u : 1u << 28), 0u, g * 64);
                     else if (atoi(getenv("NECAT_BATCH_RC")) == 64)
                     hipLaunchKernelGGL((k_myers_ckg<kWordsB, kTWordsB, kColsB, 64>), dim3(m), dim3(64), 0, s, (const BlockItem*)d_items, m, (const u32*)nullptr, 0u, (const u64*)d_frag, ck, hcar, error,
                                        d_res, d_stats, epoch, 0u, g * 64);

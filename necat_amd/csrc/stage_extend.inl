@@ -228,7 +228,7 @@ struct BatchRun {
                 const u32 hi = std::min<u64>((u64)lo + rc_chunk, (u64)gB * 64), cn = std::min(hi, nB) - lo;
                 if (g_rc_fastb)
                 hipLaunchKernelGGL((k_myers_ckf<kWordsB, kTWordsB, kColsB, 16>), dim3((cn + 3) / 4), dim3(64), 0, sb, itB, nB, d_nB, 0u, (const u64*)c.fragB[slot], ck, hcar, X.error,
-                                   c.resB[slot], X.stats, epoch, lo, hi);
+                                   c.resB[slot], X.stats, epoch | (g_ckr_fast ? 0u : 1u << 28), lo, hi);
                 else
                 hipLaunchKernelGGL((k_myers_ckg<kWordsB, kTWordsB, kColsB, 16>), dim3((cn + 3) / 4), dim3(64), 0, sb, itB, nB, d_nB, 0u, (const u64*)c.fragB[slot], ck, hcar, X.error,
                                    c.resB[slot], X.stats, epoch, lo, hi);
@@ -423,7 +423,7 @@ struct BatchRun {
                 if (ckg_all && g_rc_ragged) {}
                 else if (g_rc_carry)
                     hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA, true>), dim3((cn + 7) / 8), dim3(64), g_ck_lds, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error, c.resA, X.stats, g_rc_maxdist, lo, hi,
-                                       (merged ? fl_all : epoch) | (g_ck_post ? 0u : 1u << 24) | (g_rc_prio & 2u ? 1u << 23 : 0u) | (fuse_frag && merged ? 1u << 22 : 0u),
+                                       (merged ? fl_all : epoch) | (g_ck_post ? 0u : 1u << 24) | (g_rc_prio & 2u ? 1u << 23 : 0u) | (fuse_frag && merged ? 1u << 22 : 0u) | (g_ckr_fast ? 0u : 1u << 28),
                                        (const u64*)drd.bases, (const u64*)dref.bases);
                 else
 #if NECAT_XCHECK

@@ -133,7 +133,7 @@ def _random_pairs(rng, n, qlo, qhi, err):
     return np.concatenate(seqs), qo, ql, to, tl
 
 
-@pytest.mark.parametrize("path", ["band", "recompute", "recompute_16", "recompute_rows", "recompute_quad", "recompute_fast"])
+@pytest.mark.parametrize("path", ["band", "recompute", "recompute_16", "recompute_rows", "recompute_quad", "recompute_fast", "recompute_fast_sorted", "recompute_fast_rolled"])
 def test_edlib_blocks_match_oracle(ctx, monkeypatch, path):
     """The dominant kernel in isolation: distance, end column and the full edit path, including
     ragged sizes (1..794), failures (too divergent) and exact 512 x 512 blocks (the FULL kernel).
@@ -141,9 +141,13 @@ def test_edlib_blocks_match_oracle(ctx, monkeypatch, path):
     ext_rcwalk3.h: a workgroup of two waves recomputes 64 blocks into 32-diagonal records, one of the two walks them column by column) at both geometries (8 words / 13 words
     per block; NECAT_RC_WW=2 = that kernel at every list size - the default takes it from 160 k blocks up); recompute_16: the same on 16-diagonal records
     (NECAT_RC3_BAND=16); recompute_rows: round 4's k_rcwalk2w (64-row records, one LDS read per walk step: NECAT_RC_WW=1 at this list size); recompute_quad:
-    through k_rcwalk2 (every quad recomputes and walks its own block, NECAT_RC_WW=0)."""
+    through k_rcwalk2 (every quad recomputes and walks its own block, NECAT_RC_WW=0); recompute_fast_sorted: the pairs of a batch in order of size, as the rounds' sorted
+    list B hands them to k_myers_ckf - the blocks of a wave are then of like size and most of its 32-step windows take fast_shw_ckr's unrolled form (round 6);
+    recompute_fast_rolled: NECAT_CKR_FAST=0, every window in the rolled, lane-masked form."""
     if path != "band":
-        monkeypatch.setenv("NECAT_BATCH_RC", "2" if path == "recompute_fast" else "1")          # 2: the checkpoint pass through k_myers_ckf (fast_shw_ckr at 8 and 16 lanes per block)
+        monkeypatch.setenv("NECAT_BATCH_RC", "2" if path.startswith("recompute_fast") else "1")          # 2: the checkpoint pass through k_myers_ckf (fast_shw_ckr at 8 and 16 lanes per block)
+    if path == "recompute_fast_rolled":
+        monkeypatch.setenv("NECAT_CKR_FAST", "0")
     # (knobs are read when a context is made: ctx.edlib_align_batch runs on a cross-check context of its own per knob environment, capi.py)
     monkeypatch.setenv("NECAT_RC_WW", {"recompute_quad": "0", "recompute_rows": "1", "recompute": "2", "recompute_16": "2"}.get(path, "1"))
     if path == "recompute_16":
@@ -176,6 +180,9 @@ def test_edlib_blocks_match_oracle(ctx, monkeypatch, path):
         qo.append(pos); ql.append(512); pos += 512
         to.append(pos); tl.append(512); pos += 512
     allseq = np.concatenate(allseq)
+    if path == "recompute_fast_sorted":
+        order = sorted(range(len(qo)), key=lambda i: (tl[i], ql[i]))
+        qo, ql, to, tl = ([x[i] for i in order] for x in (qo, ql, to, tl))
     dist, qend, tend, ops, ops_off = ctx.edlib_align_batch(allseq, qo, ql, to, tl, 0.5)
     nfail = 0
     for i in range(len(qo)):
@@ -514,7 +521,7 @@ def test_capped_band_pool_runs_lists_in_chunks(ctx, small, tmp_path, monkeypatch
                                   "NECAT_RC_WW=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_WW=1 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0",
                                   "NECAT_RC_WW=2 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_WW=2 NECAT_RC3_BAND=16 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC3_MIN=64 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_WW=1 NECAT_RC_PREFETCH=1 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_MERGE=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0",
                                   "NECAT_RC_MERGE=1 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0 NECAT_RC_POOL_MB=1", "NECAT_RC_FASTB=0 NECAT_TAIL_FUSED=0",
-                                  "NECAT_CK_POST=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0",
+                                  "NECAT_CK_POST=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_CKR_FAST=0 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0",
                                   "NECAT_RC_PIPE=3 NECAT_RC_PIPE_MIN=64 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0", "NECAT_RC_PRIO=6 NECAT_RCWALK=1 NECAT_TAIL_FUSED=0"])
 def test_alternative_kernel_paths_give_the_same_records(ctx, small, monkeypatch, knob):
     """Code paths kept behind a knob (the lane-0 chain DP, the 16-block / 4-lane NW kernel, the restated walk, the general DP
