@@ -63,8 +63,9 @@ def parse():
     ap.add_argument("--job", type=int, default=1)
     ap.add_argument("--in-flight", type=int, default=0,
                     help="whole steps in flight on the GPU: D contexts (own arenas, streams, events), one host thread each, all mapping the one resident volume - the way the "
-                         "oc2pm worker keeps several (reference volume, query volume) jobs of a project on its device (NECAT_PAIR_LANES). 0 = the default: 3 at N = 1, 1 under a "
-                         "communicator (the sharded calls are collective). 1 = one step after the other, as until round 5 (always ALSO measured: `one_in_flight`)")
+                         "oc2pm worker keeps several (reference volume, query volume) jobs of a project on its device (NECAT_PAIR_LANES). 0 = the default: 3 wherever a rank maps "
+                         "volumes of its own (N = 1, --parallelism volumes), 1 under a communicator (the sharded calls are collective). 1 = one step after the other, as until "
+                         "round 5 (always ALSO measured: `one_in_flight`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-widened", action="store_true", help="skip the extra measurements of the SURVEY 8f.1 rows")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that measure `traffic` in this run; "
@@ -997,7 +998,7 @@ def main():
     # streams, events, pinned rings), one host thread each, run whole steps side by side on the ONE resident volume, exactly as the oc2pm worker keeps D jobs of a
     # project on its device (pm_job.h: NECAT_PAIR_LANES).  Every step is the full pass (index build -> seeding -> extension -> records on the host); the K timed steps
     # are dealt to the D threads from one counter.  D = 1 is measured too, after the timed region (`one_in_flight`).
-    D = args.in_flight if args.in_flight > 0 else (3 if (comm is None and world == 1) else 1)
+    D = args.in_flight if args.in_flight > 0 else (3 if comm is None else 1)
     if comm is not None and D > 1:
         raise SystemExit("bench.py: --in-flight > 1 under a communicator: the sharded calls are collective, one at a time per communicator")
     ctxs = [ctx] + [capi.Context(local) for _ in range(D - 1)]
@@ -1252,6 +1253,11 @@ def main():
                                              "steps' kernels, so the phases add up to a step's LATENCY (~ %d x ms_per_step); one_in_flight.phases_ms_per_step = alone" % (D, D))
         roofline["steps_in_flight"] = D
         roofline["frac_one_in_flight"] = r1["frac"]
+        # (the driver's record keeps `roofline` and `config` whole and only the NAMES of the other keys: the leg's numbers here too)
+        roofline["one_in_flight"] = {"ms_per_step": one["ms_per_step"], "overlaps_per_s": one["overlaps_per_s"], "steps": k1, "phases_ms_per_step": one["phases_ms_per_step"],
+                                     "achieved": r1["achieved"], "frac": r1["frac"], "avg_launch_ms": r1["avg_launch_ms"], "k_myers_ck": r1["k_myers_ck"],
+                                     "k_rcwalk": {q: r1["k_rcwalk"][q] for q in ("frac", "computed_frac")}}
+        out["config"]["one_step_at_a_time"] = {"ms_per_step": one["ms_per_step"], "overlaps_per_s": one["overlaps_per_s"]}
         roofline["steps_in_flight_note"] = ("launch durations of the timed region are taken with %d steps' kernels sharing the chip (the launches of different steps overlap: their "
                                             "durations add up to MORE than the region's wall clock): `frac` is what ONE launch gets of the peak while it runs beside the others, "
                                             "frac_one_in_flight / one_in_flight.roofline the same kernels with the chip to themselves (round 5's 0.26), timed_region.frac the chip's "

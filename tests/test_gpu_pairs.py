@@ -95,6 +95,21 @@ def test_bench_gpus_2_runs_two_ranks_and_the_same_records(built):
     assert rep["multi_gpu"]["index_plan"]["replicate_ms"] < rep["multi_gpu"]["index_plan"]["shard_ms"]
 
 
+def test_bench_steps_in_flight_report_the_same_records(built):
+    """`bench.py --in-flight D` (the default is 3 at N = 1): the K timed steps are dealt to D contexts / host threads on one resident volume - every step returns the records
+    of a step run alone, the line says how many were in flight and carries the one-at-a-time leg inside `roofline` / `config` (the objects the driver's record keeps whole)"""
+    few = ["--genome", "300000", "--coverage", "16", "--kmer", "13", "--steps", "4", "--warmup", "0", "--no-cpu-baseline", "--no-widened"]
+    one = _bench(few + ["--gpus", "1", "--in-flight", "1", "--no-pmc"])
+    three = _bench(few + ["--gpus", "1", "--no-pmc"])
+    assert one["config"]["steps_in_flight"] == 1 and "one_in_flight" not in one["roofline"]
+    assert three["config"]["steps_in_flight"] == 3 and three["steps"] == 4
+    assert three["config"]["overlaps_per_step"] == one["config"]["overlaps_per_step"] > 500
+    leg = three["roofline"]["one_in_flight"]
+    assert leg["ms_per_step"] > 0 and three["config"]["one_step_at_a_time"]["ms_per_step"] == leg["ms_per_step"]
+    assert three["roofline"]["frac_one_in_flight"] == leg["frac"] and three["roofline"]["timed_region"]["steps_in_flight"] == 3
+    assert three["candidates_job0"]["steps_in_flight"] == 3 and three["candidates_job0"]["records_per_step"] == one["candidates_job0"]["records_per_step"]
+
+
 @pytest.mark.parametrize("job", [1, 0])
 def test_bench_pairs_mode_records_equal_the_oracle(built, tmp_path, job):
     """--parallelism pairs on 1 and on 2 ranks: the union of the ranks' records = the oracle's records of all three volume jobs"""
