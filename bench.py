@@ -44,6 +44,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_LANE_OPS_PER_S = 256 * 4 * 32 * 2.4e9   # 256 CUs x 4 SIMD-32 x 2.4 GHz (32-bit integer lane-ops)
 OPS_PER_WORD_UPDATE = 45       # 32-bit VALU ops of one 64-row Myers word update
+IN_FLIGHT_DEFAULT = 4          # whole steps in flight where a rank maps volumes of its own (E. coli-size steps: 37.8 / 33.4 / 30.9 / 30.2 / 31.4 ms per step at 1 / 2 / 3 / 4 / 6; NOTES_r06 8)
 
 FAST = dict(kmer_size=15, scan_window=20, kmer_cnt_cutoff=500, block_size=2000, block_score_cutoff=3,
             num_candidates=500, align_size_cutoff=1000, ddfs_cutoff=0.25, error=0.5, num_output=500,
@@ -63,7 +64,7 @@ def parse():
     ap.add_argument("--job", type=int, default=1)
     ap.add_argument("--in-flight", type=int, default=0,
                     help="whole steps in flight on the GPU: D contexts (own arenas, streams, events), one host thread each, all mapping the one resident volume - the way the "
-                         "oc2pm worker keeps several (reference volume, query volume) jobs of a project on its device (NECAT_PAIR_LANES). 0 = the default: 3 wherever a rank maps "
+                         "oc2pm worker keeps several (reference volume, query volume) jobs of a project on its device (NECAT_PAIR_LANES). 0 = the default: 4 wherever a rank maps "
                          "volumes of its own (N = 1, --parallelism volumes), 1 under a communicator (the sharded calls are collective). 1 = one step after the other, as until "
                          "round 5 (always ALSO measured: `one_in_flight`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -998,7 +999,7 @@ def main():
     # streams, events, pinned rings), one host thread each, run whole steps side by side on the ONE resident volume, exactly as the oc2pm worker keeps D jobs of a
     # project on its device (pm_job.h: NECAT_PAIR_LANES).  Every step is the full pass (index build -> seeding -> extension -> records on the host); the K timed steps
     # are dealt to the D threads from one counter.  D = 1 is measured too, after the timed region (`one_in_flight`).
-    D = args.in_flight if args.in_flight > 0 else (3 if comm is None else 1)
+    D = args.in_flight if args.in_flight > 0 else (IN_FLIGHT_DEFAULT if comm is None else 1)
     if comm is not None and D > 1:
         raise SystemExit("bench.py: --in-flight > 1 under a communicator: the sharded calls are collective, one at a time per communicator")
     ctxs = [ctx] + [capi.Context(local) for _ in range(D - 1)]

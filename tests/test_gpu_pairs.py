@@ -96,11 +96,11 @@ def test_bench_gpus_2_runs_two_ranks_and_the_same_records(built):
 
 
 def test_bench_steps_in_flight_report_the_same_records(built):
-    """`bench.py --in-flight D` (the default is 3 at N = 1): the K timed steps are dealt to D contexts / host threads on one resident volume - every step returns the records
+    """`bench.py --in-flight D` (the default is bench.IN_FLIGHT_DEFAULT at N = 1): the K timed steps are dealt to D contexts / host threads on one resident volume - every step returns the records
     of a step run alone, the line says how many were in flight and carries the one-at-a-time leg inside `roofline` / `config` (the objects the driver's record keeps whole)"""
     few = ["--genome", "300000", "--coverage", "16", "--kmer", "13", "--steps", "4", "--warmup", "0", "--no-cpu-baseline", "--no-widened"]
     one = _bench(few + ["--gpus", "1", "--in-flight", "1", "--no-pmc"])
-    three = _bench(few + ["--gpus", "1", "--no-pmc"])
+    three = _bench(few + ["--gpus", "1", "--in-flight", "3", "--no-pmc"])
     assert one["config"]["steps_in_flight"] == 1 and "one_in_flight" not in one["roofline"]
     assert three["config"]["steps_in_flight"] == 3 and three["steps"] == 4
     assert three["config"]["overlaps_per_step"] == one["config"]["overlaps_per_step"] > 500

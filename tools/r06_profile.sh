@@ -1,13 +1,13 @@
-# round 6, profile pass: kernel stats of the default bench (3 steps in flight), of one step at a time, and with the extension's streams made one (NECAT_SERIAL=1:
+# round 6, profile pass: kernel stats of the default bench (4 steps in flight), of one step at a time, and with the extension's streams made one (NECAT_SERIAL=1:
 # every kernel alone on the chip); per-launch timeline of one step; the chip's busy fraction and kernel concurrency (tools/r06/busy.py) at 3 / 1 in flight; the 2-rank
 # one-device runs; the whole GPU suite; smoke; then the full default bench line (which measures its own HBM traffic: gpurun_out/pmc_live.json)
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/r06; mkdir -p $O
-CMD3="python bench.py --steps 9 --warmup 1 --no-cpu-baseline --no-widened --no-pmc"
+CMD3="python bench.py --steps 12 --warmup 1 --no-cpu-baseline --no-widened --no-pmc"
 CMD1="python bench.py --steps 3 --warmup 1 --in-flight 1 --no-cpu-baseline --no-widened --no-pmc"
 rm -rf $O/prof_stats; rocprofv3 --kernel-trace --stats -d $O/prof_stats -o r --output-format csv -- $CMD3 > $O/prof_stats3.log 2>&1
-python tools/make_profiles.py stats $O/prof_stats $O/r06_kernel_stats.md "rocprofv3 --kernel-trace --stats -- $CMD3 (the default: 3 steps in flight; a kernel's duration includes what it waits for beside the other steps' kernels)"
-python tools/r06/busy.py $O/prof_stats > $O/r06_busy_3_in_flight.txt 2>&1
+python tools/make_profiles.py stats $O/prof_stats $O/r06_kernel_stats.md "rocprofv3 --kernel-trace --stats -- $CMD3 (the default: 4 steps in flight; a kernel's duration includes what it waits for beside the other steps' kernels)"
+python tools/r06/busy.py $O/prof_stats > $O/r06_busy_4_in_flight.txt 2>&1
 rm -rf $O/prof_stats
 rocprofv3 --kernel-trace --stats -d $O/prof_stats -o r --output-format csv -- $CMD1 > $O/prof_stats1.log 2>&1
 python tools/make_profiles.py stats $O/prof_stats $O/r06_kernel_stats_one_in_flight.md "rocprofv3 --kernel-trace --stats -- $CMD1"
