@@ -101,3 +101,30 @@ def test_index_plan_replicates_small_volumes_and_shards_big_ones_on_many_ranks(b
     assert capi.index_plan(ecoli, 15, 2).shard == 1 and capi.index_plan(ecoli, 15, 1).shard == 0
     monkeypatch.setenv("NECAT_INDEX_SHARD", "0")
     assert capi.index_plan(big, 15, 8).shard == 0
+
+
+@pytest.mark.parametrize("tsan", [False, True])
+def test_pair_lanes_of_a_job_with_a_fake_library(tmp_path, tsan):
+    """tests/host_core/check_pm_lanes.cpp: the SOURCE of necat_amd/csrc/pm_job.h (a job's units on NECAT_PAIR_LANES lanes, one context and host thread per lane, the
+    records written in unit order) compiled with g++ against a fake C ABI whose mappings sleep - longest for the first units - and log their concurrency: same bytes at
+    1 / 2 / 3 / 5 lanes and both jobs, min(L, units) mappings really side by side with lane l on units l, l + L, ..., everything freed, a failing unit or a lane without
+    a context -> exit 1, no file, nobody left waiting.  tsan: the same under ThreadSanitizer (no report).  What the lanes do on the device is
+    tests/test_gpu_cli_golden.py::test_pair_lanes_write_the_same_file."""
+    import subprocess
+    from necat_amd import synth
+    rs = synth.simulate_reads(60_000, 12.0, seed=3)
+    d = os.path.join(str(tmp_path), "vols")
+    assert synth.write_volume_dir_cuts(d, rs, [rs.nbases // 5] * 4) == 5
+    exe = os.path.join(str(tmp_path), "check_pm_lanes")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host_core", "check_pm_lanes.cpp")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17"] + (["-fsanitize=thread"] if tsan else []) + ["-I" + os.path.join(util.ROOT, "include"), "-o", exe, src, "-lpthread"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if tsan and r.returncode != 0 and "tsan" in r.stdout.lower():
+        pytest.skip("no ThreadSanitizer runtime in this toolchain")
+    assert r.returncode == 0, r.stdout[-3000:]
+    r = subprocess.run([exe, d, os.path.join(str(tmp_path), "out")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=0 exitcode=66"))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    assert r.stdout.strip().endswith("ok")
+    assert "ThreadSanitizer" not in r.stderr
+    assert r.stderr.count("ERROR") == 2 * (3 + 1)          # the injected failures, reported once each: three lane modes with a failing unit + one lane without a context, per job
