@@ -6,6 +6,11 @@ HBM: k-mer index build -> candidate search (both strands of every read) -> block
 extension -> M4 records back on the host.  Workload at N=1 = BASELINE.json configs[1]:
 E. coli-size (4.6 Mb) 40x synthetic ONT reads, OVLP_FAST_OPTIONS with -j 1 (M4 output).
 
+The K timed steps run `--in-flight` D at a time (default 4 where a rank maps volumes of its own): D contexts with a host thread each take whole
+steps from one counter and map the one resident volume - what the oc2pm worker does with the jobs of a project (NECAT_PAIR_LANES).  `value` and
+`ms_per_step` are the K steps over the region's wall clock; the same steps one after the other are measured right after (`one_in_flight`, also
+inside `roofline` and `config`): a single step's latency, and the kernels' durations with no other step's kernels beside them.
+
 `--gpus N` with N > 1 and no RANK in the environment: the script re-launches itself under `python -m torch.distributed.run
 --nproc-per-node N` (one rank per GPU) and relays that run's JSON line; under a launcher it insists that WORLD_SIZE == --gpus.
 
