@@ -173,6 +173,8 @@ NECAT_D u32 fast_shw8_ckp(const int b, const u64* __restrict__ tw, const u64 nlo
                 }
             }
         } else {
+            // (round 6 tried steps 7 .. 31 of the first window unrolled too - 25 of the pass's 39 rolled steps: the kernel grew by a third and its launches by 1 %,
+            // tools/r06/run19.sh)
             const int jn = kSteps - s0 < 32 ? kSteps - s0 : 32;
             for (int j = 0; j < jn; ++j) {
                 const int s = s0 + j;
@@ -227,7 +229,10 @@ NECAT_D u32 fast_shw8_ckp(const int b, const u64* __restrict__ tw, const u64 nlo
 // W cells (:205-219) together find (a value of a padded column c < W is at least qn, above any cutoff).  Same checkpoints, same deltas,
 // the last, partial 32-column group of deltas left-aligned as k_myers_ckg leaves it.  `steps`: the wave's longest tn + nblk - 1.
 // (G lanes per block - 8: list A, 16: list B at 13 words; NWS: words per checkpoint / delta slot of the geometry; the key keeps the step in 10 bits)
-template <int G, int NWS, int TW>
+// FASTW: the unrolled, mask-free form of the windows in which every lane of the wave is inside its block exists in this instance (k_myers_ckf: list B).  NOT in
+// k_myers_ck's ragged waves: that kernel is held at 64 registers for its full blocks' 8 waves per SIMD, and with the unrolled windows inside it the full blocks' launches
+// were 10 % longer (0.48 -> 0.53 ms on average, spills 76 -> 112 bytes, a third more code) for a ragged path that is 12 % of its blocks (tools/r06/run19.sh).
+template <int G, int NWS, int TW, bool FASTW>
 NECAT_D u32 fast_shw_ckr(const int b, const int qn, const int tn, const int steps, const u64* __restrict__ tw, const u64 nlo, const u64 nhi,
                          ulonglong2* __restrict__ ck, u64* __restrict__ hc, const bool ckr_fast_windows = true)
 {
@@ -265,7 +270,7 @@ NECAT_D u32 fast_shw_ckr(const int b, const int qn, const int tn, const int step
         // scalar mask -, the running minimum is kept by every lane on a row of its own (only the last word's is read) instead of under an exec mask.  Lanes without a
         // word run along: they store nothing, and nobody reads what they publish (the lane below them has no word either; the last lane of a half row always
         // publishes the boundary).  49 -> 38 vector and 18 -> 2 scalar instructions per step.
-        if (ckr_fast_windows && __all(!have || (s0 >= b && s0 + 31 - b < tn - 1))) {
+        if (FASTW && ckr_fast_windows && __all(!have || (s0 >= b && s0 + 31 - b < tn - 1))) {
             ulonglong2* const ckr = ck + (size_t)(s0 >> 4) * ST;
             u64* const hcr = hc + (size_t)(s0 >> 5) * ST;
 #pragma unroll
@@ -382,7 +387,7 @@ k_myers_ck(const BlockItem* __restrict__ items, const u32* __restrict__ n_dev, u
     if (ragged) {
         int steps = valid ? tn + nblk - 1 : 0;
         for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
-        key = fast_shw_ckr<8, 8, TW>(b, valid ? qn : 0, valid ? tn : 0, steps, t_lds[sub], nlo, nhi, ckp, hcp, !((flags >> 28) & 1u));      // (bit 28, NECAT_CKR_FAST=0: every window rolled, as until round 5)
+        key = fast_shw_ckr<8, 8, TW, false>(b, valid ? qn : 0, valid ? tn : 0, steps, t_lds[sub], nlo, nhi, ckp, hcp);
 #ifdef NECAT_CK_MICRO
     } else if (CARRY && !((flags >> 24) & 1u)) key = fast_shw8_ckp<TW>(b, t_lds[sub], nlo, nhi, ckp, hcp, (flags >> 20) & 1u);
 #else
@@ -697,7 +702,7 @@ k_myers_ckf(const BlockItem* __restrict__ items, u32 n_host, const u32* __restri
     __syncthreads();
     int steps = valid ? tn + nblk - 1 : 0;
     for (int o = 32; o > 0; o >>= 1) { const int x = __shfl_xor(steps, o); steps = x > steps ? x : steps; }
-    const u32 key = fast_shw_ckr<G, NW, TW>(b, qn, tn, steps, t_lds[sub], nlo, nhi, ckpt + rc_at<NW>(item - lo, CK, 0, (size_t)b), hcar + rc_at<NW>(item - lo, SEGS, 0, (size_t)b),
+    const u32 key = fast_shw_ckr<G, NW, TW, true>(b, qn, tn, steps, t_lds[sub], nlo, nhi, ckpt + rc_at<NW>(item - lo, CK, 0, (size_t)b), hcar + rc_at<NW>(item - lo, SEGS, 0, (size_t)b),
                                             !((epoch >> 28) & 1u));      // (bit 28, NECAT_CKR_FAST=0: every window rolled, as until round 5)
     const int bl = nblk > 0 ? nblk - 1 : 0;
     const u32 bkey = (u32)__shfl((int)key, (lane / G) * G + bl);

@@ -423,7 +423,7 @@ struct BatchRun {
                 if (ckg_all && g_rc_ragged) {}
                 else if (g_rc_carry)
                     hipLaunchKernelGGL((k_myers_ck<kWordsA, kTWordsA, true>), dim3((cn + 7) / 8), dim3(64), g_ck_lds, c.sa, itA, d_nA, c.cap, (const u64*)c.fragA, ck, hcar, X.error, c.resA, X.stats, g_rc_maxdist, lo, hi,
-                                       (merged ? fl_all : epoch) | (g_ck_post ? 0u : 1u << 24) | (g_rc_prio & 2u ? 1u << 23 : 0u) | (fuse_frag && merged ? 1u << 22 : 0u) | (g_ckr_fast ? 0u : 1u << 28),
+                                       (merged ? fl_all : epoch) | (g_ck_post ? 0u : 1u << 24) | (g_rc_prio & 2u ? 1u << 23 : 0u) | (fuse_frag && merged ? 1u << 22 : 0u),
                                        (const u64*)drd.bases, (const u64*)dref.bases);
                 else
 #if NECAT_XCHECK
