@@ -40,7 +40,7 @@ constexpr int kPmSlots = 64;
 
 // Pair lanes (round 6): the contexts beside the job's own on which a job's units run side by side (pm_run_volume).  One unit's extension ends in ~ 15 rounds that are
 // one block's dependent chain each on a mostly idle chip, and its seeding is HBM- / latency-bound while the DP kernels are issue-bound - two or three SMALL units in
-// flight fill each other's gaps (E. coli-size pairs: 38.1 -> 32.0 -> 30.1 ms per pair at 1 / 2 / 3 in flight, tools/r06/run9.sh).  A pair of 2 Gbp volumes is
+// flight fill each other's gaps (E. coli-size pairs: 38.1 -> 32.0 -> 30.1 -> 29.8 ms per pair at 1 / 2 / 3 / 4 in flight, tools/r06/run9.sh).  A pair of 2 Gbp volumes is
 // several extension batches that already run on the two lanes of ONE context (stage_extend.inl) and fill the chip: there a second context only costs its arenas
 // (5.6 Gbp project in 3 volumes through one worker: 2.51 - 2.62 s at one lane, 2.71 - 2.82 at two, 2.84 - 2.94 at three: tools/r06/run11.sh).
 // NECAT_PAIR_LANES = 1 .. 8 fixes the number; unset = 2 lanes for a job whose reference volume is below kPmLaneBases bases, 1 otherwise.
