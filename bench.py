@@ -59,7 +59,7 @@ FAST = dict(kmer_size=15, scan_window=20, kmer_cnt_cutoff=500, block_size=2000, 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=12)      # (a multiple of the steps in flight: the last steps do not run on a half-empty device)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--genome", type=int, default=4_600_000)
     ap.add_argument("--coverage", type=float, default=40.0)
