@@ -141,6 +141,13 @@ typedef struct {
     uint64_t seed_bases, seed_lookups, seed_hits, seed_cands;
 } necat_timings;
 
+/* Threads.  A context is used by ONE host thread at a time (its streams, arenas, timings and last-error text are its own); DIFFERENT contexts -
+ * of one device or of several - may be called from different threads at the same moment, and nothing else in the library is shared but the pool
+ * of pinned result blocks behind necat_free (a mutex).  Volumes and indexes are plain device allocations: made through one context, they may be
+ * read by calls on any other context of that device once the call that made them has returned (necat_volume_free / necat_index_free when no call
+ * uses them any more).  That is how several pairs are kept in flight on one device - one context + host thread per pair, one shared index:
+ * INTEGRATION.md 2g, the programs' NECAT_PAIR_LANES, bench.py --in-flight (reference analogue: pm_main's thread pool on one lookup table,
+ * pm_worker.c:335-390).  necat_ctx_trim synchronises the whole DEVICE: not while another context has calls in flight. */
 void        necat_default_options(necat_map_options* o);            /* map_options.c:12-28 */
 int         necat_ctx_create(int device_id, necat_ctx** out);
 void        necat_ctx_destroy(necat_ctx* ctx);
