@@ -39,13 +39,16 @@ struct PmUnit { int query_vol, slot_lo, slot_hi; };
 constexpr int kPmSlots = 64;
 
 // Pair lanes (round 6): the contexts beside the job's own on which a job's units run side by side (pm_run_volume).  One unit's extension ends in ~ 15 rounds that are
-// one block's dependent chain each on a mostly idle chip, and its seeding is HBM- / latency-bound while the DP kernels are issue-bound - two or three SMALL units in
-// flight fill each other's gaps (E. coli-size pairs: 38.1 -> 32.0 -> 30.1 -> 29.8 ms per pair at 1 / 2 / 3 / 4 in flight, tools/r06/run9.sh).  A pair of 2 Gbp volumes is
-// several extension batches that already run on the two lanes of ONE context (stage_extend.inl) and fill the chip: there a second context only costs its arenas
-// (5.6 Gbp project in 3 volumes through one worker: 2.51 - 2.62 s at one lane, 2.71 - 2.82 at two, 2.84 - 2.94 at three: tools/r06/run11.sh).
-// NECAT_PAIR_LANES = 1 .. 8 fixes the number; unset = 2 lanes for a job whose reference volume is below kPmLaneBases bases, 1 otherwise.
+// one block's dependent chain each on a mostly idle chip, and its seeding is HBM- / latency-bound while the DP kernels are issue-bound - two or three units in
+// flight fill each other's gaps.  Warm, pairs in flight against one at a time (tools/r06/run9.sh, run23.sh, run24.sh): E. coli-size pairs 38.1 -> 32.0 -> 30.1 -> 29.8 ms
+// per pair at 1 / 2 / 3 / 4; 0.6 Gbp SENSITIVE pairs 267 -> 257 -> 246 ms at 1 / 2 / 3; a 2 Gbp volume against itself 231 -> 202 ms (-j 1), 125 -> 115 ms (-j 0) at 1 / 2.
+// What a lane costs is its context's arenas (tens of GB at 2 Gbp, mapped on first use): a 5.6 Gbp project of SIX pairs through one worker took 2.51 - 2.62 s at one lane,
+// 2.71 - 2.82 at two, 2.84 - 2.94 at three (tools/r06/run11.sh) - the second context's first touches cost more than six pairs gain.
+// NECAT_PAIR_LANES = 1 .. 8 fixes the number; unset = 2 lanes for a job whose reference volume is below kPmLaneBases bases (cheap arenas) or that has at least
+// kPmLaneUnits units (enough pairs to pay for them: volume v of a 45-volume project has 45 - v), 1 otherwise.
 // The contexts are made by their lane threads on first use (beside lane 0's first unit) and kept for the owner's next job.
 constexpr uint64_t kPmLaneBases = 400000000ull;
+constexpr size_t kPmLaneUnits = 8;
 struct PmLanes {
     int device, lanes;
     bool fixed;
@@ -59,7 +62,7 @@ struct PmLanes {
         if (lanes > 8) lanes = 8;
         extra.assign((size_t)lanes - 1, nullptr);
     }
-    int for_volume(uint64_t ref_bases) const { return fixed ? lanes : (ref_bases < kPmLaneBases ? lanes : 1); }
+    int for_job(uint64_t ref_bases, size_t units) const { return fixed ? lanes : ((ref_bases < kPmLaneBases || units >= kPmLaneUnits) ? lanes : 1); }
     void close() { for (necat_ctx*& c : extra) if (c) { necat_ctx_destroy(c); c = nullptr; } }      // (a worker that leaves through _exit calls this itself)
     ~PmLanes() { close(); }
     PmLanes(const PmLanes&) = delete; PmLanes& operator=(const PmLanes&) = delete;
@@ -115,7 +118,7 @@ inline int pm_run_volume(necat_ctx* ctx, const VolumesInfo& vi, int vid, const n
     // the records in the unit's slot.  This thread writes the slots IN UNIT ORDER - the job's file is byte for byte what one lane writes - while the lanes go on
     // (at most L + 1 finished units wait in memory).  L = 1 is the sequence of round 5 with the writing taken off the mapping thread.
     const size_t nu = units->size();
-    const int L = (int)std::max<size_t>(1, std::min<size_t>(lanes ? (size_t)lanes->for_volume(href.nbases) : 1, nu));
+    const int L = (int)std::max<size_t>(1, std::min<size_t>(lanes ? (size_t)lanes->for_job(href.nbases, nu) : 1, nu));
     struct UnitOut {
         int state = 0;                   // 0 = not yet, 1 = records ready, 2 = failed (message printed), 3 = skipped after another unit's failure
         necat_m4* m4 = nullptr; uint64_t nm4 = 0; necat_candidate* cands = nullptr; uint64_t ncand = 0;

@@ -175,11 +175,11 @@ int main(int argc, char** argv)
             CHECK(fake::live_ctx == 0);
         }
     }
-    // the default: two lanes for a job whose reference volume is small, one above kPmLaneBases
+    // the default: two lanes for a job whose reference volume is small or that has enough units to pay for a second context's arenas, one otherwise
     unsetenv("NECAT_PAIR_LANES");
-    { PmLanes lanes(0); CHECK(!lanes.fixed && lanes.for_volume(1000) == 2 && lanes.for_volume(kPmLaneBases) == 1 && lanes.for_volume(2000000000ull) == 1); }
+    { PmLanes lanes(0); CHECK(!lanes.fixed && lanes.for_job(1000, 2) == 2 && lanes.for_job(kPmLaneBases, 3) == 1 && lanes.for_job(2000000000ull, kPmLaneUnits - 1) == 1 && lanes.for_job(2000000000ull, kPmLaneUnits) == 2); }
     setenv("NECAT_PAIR_LANES", "1", 1);
-    { PmLanes lanes(0); CHECK(lanes.fixed && lanes.for_volume(1000) == 1); }
+    { PmLanes lanes(0); CHECK(lanes.fixed && lanes.for_job(1000, 100) == 1); }
     printf("ok\n");
     return 0;
 }

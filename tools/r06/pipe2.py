@@ -11,7 +11,9 @@ FAST = dict(kmer_size=15, scan_window=20, kmer_cnt_cutoff=500, block_size=2000, 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 depths = [int(x) for x in sys.argv[2:]] or [1, 2, 3, 1, 2]
 job = int(os.environ.get("PIPE_JOB", "1"))
-rs = synth.simulate_reads(4_600_000, 40.0, seed=7)
+# (PIPE_GENOME / PIPE_COV / PIPE_Z: another workload, e.g. configs[2]'s 12 Mb x 50 at -z 10)
+FAST["scan_window"] = int(os.environ.get("PIPE_Z", "20"))
+rs = synth.simulate_reads(int(os.environ.get("PIPE_GENOME", "4600000")), float(os.environ.get("PIPE_COV", "40")), seed=int(os.environ.get("PIPE_SEED", "7")))
 pac = synth.pack_2bit(rs.codes)
 opt = capi.default_options(**dict(FAST, job=job, num_threads=1))
 maxd = max(depths)
