@@ -51,6 +51,7 @@ struct Knobs {
     u32 rc_merge;        // NECAT_RC_MERGE (default 1, needs NECAT_RC_RAGGED): the ragged list-A blocks of a big round through k_myers_ck's ragged fast path and the full blocks' walk launch; 0 = k_myers_ckg + a walk launch of their own on stream d
     u32 rc_prio;         // NECAT_RC_PRIO (bits; default 1: 41.6 -> 41.0 ms per step; 2 costs 0.5 ms, 4 nothing): waves that raise their issue priority (s_setprio 3) - 1: list A's walk (k_rcwalk2w: every wave; k_rcwalk3: its walking wave), 2: list A's checkpoint pass, 4: list B's walk, 8 / 16: only the WALKING wave of list A's / list B's walk, for the length of its walk (kernel opts bit 16)
     u32 rc_pipe, rc_pipe_min;    // NECAT_RC_PIPE (default 1 = off: 2 - 4 pieces cost 1.8 - 2.3 ms per step, tools/r04/run28.sh, run29.sh) / NECAT_RC_PIPE_MIN (default 49152 blocks): list A of a big round in pieces, walk of piece i beside the pass of piece i + 1
+    u32 ext_lanes;       // NECAT_EXT_LANES (1 .. 4, default 2): lanes a call of several batches runs its batches on side by side (stage_extend.inl; 1 = NECAT_EXT_OVERLAP=0)
     u32 ckr_fast;        // NECAT_CKR_FAST (default 1): list B's checkpoint pass (fast_shw_ckr in k_myers_ckf) runs the windows in which every lane of the wave is inside its block unrolled and without a per-step lane mask; 0 = every window rolled, as until round 5
     u32 ck_post;         // NECAT_CK_POST (default 1): k_myers_ck finds the bottom row's minimum after the pass, from word 7's deltas, and unrolls its windows (fast_shw8_ckp); 0 = tracked inside the pass
     u32 rc_fastb;        // NECAT_RC_FASTB (default 1): list B's checkpoint pass through k_myers_ckf (32-bit halves, bitop3, DPP carries); 0 = the general pass k_myers_ckg
@@ -106,6 +107,7 @@ extern thread_local const Knobs* tl_knobs;      // the knobs of the context whos
 #define g_rc_pipe_min (necat::tl_knobs->rc_pipe_min)
 #define g_ck_post (necat::tl_knobs->ck_post)
 #define g_ckr_fast (necat::tl_knobs->ckr_fast)
+#define g_ext_lanes (necat::tl_knobs->ext_lanes)
 #define g_rc_fastb (necat::tl_knobs->rc_fastb)
 #define g_rc_dbg (necat::tl_knobs->rc_dbg)
 #define g_rc_prefetch (necat::tl_knobs->rc_prefetch)

@@ -120,6 +120,7 @@ void read_knobs(necat::Knobs& K)
     K.rc_fastb = (u32)num("NECAT_RC_FASTB", 1);
     K.ck_post = (u32)num("NECAT_CK_POST", 1);
     K.ckr_fast = (u32)num("NECAT_CKR_FAST", 1);
+    K.ext_lanes = (u32)std::min<unsigned long long>(kMaxExtLanes, std::max<unsigned long long>(1, num("NECAT_EXT_LANES", 2)));
     K.rc_prio = (u32)num("NECAT_RC_PRIO", 1);
     K.rc_pipe = (u32)std::min<unsigned long long>(8, std::max<unsigned long long>(1, num("NECAT_RC_PIPE", 1))); K.rc_pipe_min = (u32)num("NECAT_RC_PIPE_MIN", 49152);
     K.rc_merge = (u32)num("NECAT_RC_MERGE", 1);
@@ -201,9 +202,9 @@ int necat_ctx_create(int device_id, necat_ctx** out)
     if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
     for (int i = 0; i < kNumEvents; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
     // the list sizes of the extension rounds reach the host through this pinned ring (RoundPub, ext_kernels.h)
-    if (hipHostMalloc(&ctx->round_ring, 2 * kRoundRing * sizeof(RoundPub), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+    if (hipHostMalloc(&ctx->round_ring, kMaxExtLanes * kRoundRing * sizeof(RoundPub), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer(&ctx->round_ring_dev, ctx->round_ring, 0) != hipSuccess) { delete ctx; return NECAT_ERR_DEVICE; }
-    memset(ctx->round_ring, 0, 2 * kRoundRing * sizeof(RoundPub));      // (lane 1's half: ExtLane1)
+    memset(ctx->round_ring, 0, kMaxExtLanes * kRoundRing * sizeof(RoundPub));      // (a stretch per lane: ExtLane1)
     *out = ctx;
     return NECAT_OK;
 }
@@ -225,9 +226,11 @@ void necat_ctx_destroy(necat_ctx* ctx)
     if (ctx->stream_copy) (void)hipStreamSynchronize(ctx->stream_copy);
     for (auto& b : ctx->scratch) if (b.p) (void)hipFree(b.p);
     for (auto& b : ctx->idx_cache) if (b.p) (void)hipFree(b.p);
-    for (auto& b : ctx->lane1.buf) if (b.p) (void)hipFree(b.p);
-    for (int i = 0; i < kNumEvents; ++i) if (ctx->lane1.ev[i]) (void)hipEventDestroy(ctx->lane1.ev[i]);          // (every event that exists, also those of a creation that failed half-way)
-    for (hipStream_t st : ctx->lane1.st) if (st) (void)hipStreamDestroy(st);
+    for (auto& lx : ctx->lanex) {
+        for (auto& b : lx.buf) if (b.p) (void)hipFree(b.p);
+        for (int i = 0; i < kNumEvents; ++i) if (lx.ev[i]) (void)hipEventDestroy(lx.ev[i]);          // (every event that exists, also those of a creation that failed half-way)
+        for (hipStream_t st : lx.st) if (st) (void)hipStreamDestroy(st);
+    }
     delete (cns::Scratch*)ctx->cns_scratch;
     if (ctx->pin_plan) (void)hipHostFree(ctx->pin_plan);
     for (int i = 0; i < kNumEvents; ++i) (void)hipEventDestroy(ctx->ev[i]);
@@ -245,7 +248,7 @@ void necat_ctx_trim(necat_ctx* ctx)
     (void)hipDeviceSynchronize();
     for (auto& b : ctx->scratch) if (b.p) { (void)hipFree(b.p); b = DevBuf(); }
     for (auto& b : ctx->idx_cache) if (b.p) { (void)hipFree(b.p); b = DevBuf(); }
-    for (auto& b : ctx->lane1.buf) if (b.p) { (void)hipFree(b.p); b = DevBuf(); }
+    for (auto& lx : ctx->lanex) for (auto& b : lx.buf) if (b.p) { (void)hipFree(b.p); b = DevBuf(); }
     ctx->seed_ht_ptr = nullptr; ctx->seed_ht_clean = 0; ctx->seed_ht_cap = 0;
 }
 

@@ -26,7 +26,8 @@ struct DevBuf {
 }  // namespace necat
 
 constexpr int kNumEvents = 48;
-constexpr unsigned kRoundRing = 1024;  // entries of necat_ctx::round_ring per lane (the ring holds two lanes' worth)
+constexpr unsigned kRoundRing = 1024;  // entries of necat_ctx::round_ring per lane (the ring holds kMaxExtLanes lanes' worth)
+constexpr int kMaxExtLanes = 4;        // lanes of the extension rounds: the context's own set + up to three ExtLane1 (NECAT_EXT_LANES, default 2)
 
 // The second lane of the extension rounds (stage_extend.inl, ExtLane): while one batch of candidates is in its last, latency-bound rounds
 // the next batch runs its first, chip-filling ones beside it - on buffers, streams, events and a ring half of its own.  Lane 0 is the
@@ -67,7 +68,7 @@ struct necat_ctx {
     void* cns_scratch = nullptr;       // host buffers of the consensus loop kept between calls (necat::cns::Scratch)
     necat::Knobs knobs;                // this context's tuning / test knobs (knobs.h: read from the environment in necat_ctx_create)
     necat::DevBuf idx_cache[2];        // released index arrays kept for the next build (8.6 GB hipMalloc/hipFree per step otherwise)
-    ExtLane1 lane1;                    // the second lane of the extension rounds (created on first use)
+    ExtLane1 lanex[kMaxExtLanes - 1];  // lanes 1 .. of the extension rounds (each created on first use)
 };
 
 struct necat_volume {

@@ -66,7 +66,8 @@ int ext_lane(necat_ctx* ctx, int id, ExtLane& L)
         L.ring = (volatile RoundPub*)ctx->round_ring; L.ring_dev = (RoundPub*)ctx->round_ring_dev; L.round_seq = &ctx->round_seq;
         return NECAT_OK;
     }
-    ExtLane1& Q = ctx->lane1;
+    if (id < 1 || id >= kMaxExtLanes) return set_err(ctx, NECAT_ERR_ARG, "extension lane %d of %d", id, kMaxExtLanes);
+    ExtLane1& Q = ctx->lanex[id - 1];
     if (!Q.ready) {
         // Four streams of its own, at the device's LOWEST stream priority (NECAT_LANE1_PRIO: 0 = normal, 1 = lowest - the default -, 2 = highest): the runtime keeps
         // a pool of hardware queues per priority level (GPU_MAX_HW_QUEUES each), so these streams never share a queue with lane 0's - kernels of streams that share
@@ -89,7 +90,7 @@ int ext_lane(necat_ctx* ctx, int id, ExtLane& L)
     L.matb[0] = S + LB_MATB; L.matb[1] = S + LB_MATB2;
     L.sa = Q.st[0]; L.sb[0] = Q.st[1]; L.sb[1] = Q.st[2]; L.sd = Q.st[3];
     L.ev = Q.ev;
-    L.ring = (volatile RoundPub*)ctx->round_ring + kRoundRing; L.ring_dev = (RoundPub*)ctx->round_ring_dev + kRoundRing; L.round_seq = &Q.round_seq;
+    L.ring = (volatile RoundPub*)ctx->round_ring + (size_t)id * kRoundRing; L.ring_dev = (RoundPub*)ctx->round_ring_dev + (size_t)id * kRoundRing; L.round_seq = &Q.round_seq;
     return NECAT_OK;
 }
 
@@ -673,25 +674,26 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     }
     n_batches = bsize.size();
     const u32 cap = n ? (*std::max_element(bsize.begin(), bsize.end()) + 63) & ~63u : 64u;
-    const int nlanes = overlap && n_batches > 1 ? 2 : 1;
+    const int nlanes = overlap && n_batches > 1 && g_ext_lanes > 1 ? (int)std::min<uint64_t>(g_ext_lanes, n_batches) : 1;
     const u32 groups = cap / 64 + 1;
     int rc;
     // candidate-wide arrays
     const uint64_t n_groups_max = n;
-    const size_t cand_bytes = n * sizeof(necat_candidate) + 2 * n * sizeof(necat_m4) + ((n + 63) & ~63ULL) + (n_groups_max + 1) * 8 + 1024;
+    const size_t cand_bytes = n * sizeof(necat_candidate) + 2 * n * sizeof(necat_m4) + ((n + 63) & ~63ULL) + (n_groups_max + 1) * 8 + 2048;
     if ((rc = buf_ensure(ctx, ctx->scratch[SC_EXT_CAND], cand_bytes))) return rc;
     char* cb = (char*)ctx->scratch[SC_EXT_CAND].p;
     necat_candidate* d_cands = (necat_candidate*)cb; cb += n * sizeof(necat_candidate);
     necat_m4* d_m4 = (necat_m4*)cb; cb += n * sizeof(necat_m4);
     necat_m4* d_out = (necat_m4*)cb; cb += n * sizeof(necat_m4);
     u64* d_goff = (u64*)cb; cb += (n_groups_max + 1) * 8;
-    u32* d_outcnt = (u32*)cb; cb += 256;          // [0..1] output counter, [2..17] list counters (4 buffers x 4) of lane 0, [34..49] of lane 1
+    u32* d_outcnt = (u32*)cb; cb += 1024;         // [0..1] output counter, [2 + 32 l .. 17 + 32 l] list counters (4 buffers x 4) of lane l < kMaxExtLanes
     int* d_err = (int*)cb; cb += 64;
     u8* d_ok = (u8*)cb;
     NECAT_HIP(ctx, hipMemcpyAsync(d_cands, dev ? dev->d : cands, n * sizeof(necat_candidate), dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
-    NECAT_HIP(ctx, hipMemsetAsync(d_outcnt, 0, 320, s));
+    static_assert((2 + 32 * (kMaxExtLanes - 1) + 16) * 4 <= 1024, "the lanes' list counters");
+    NECAT_HIP(ctx, hipMemsetAsync(d_outcnt, 0, 1024 + 64, s));        // (the counters and the error flag behind them)
     auto cleanup = [&]() {};
-    ExtLane lane[2];
+    ExtLane lane[kMaxExtLanes];
     for (int l = 0; l < nlanes; ++l) {
         if ((rc = ext_lane(ctx, l, lane[l]))) return rc;
         if ((rc = buf_ensure(ctx, *lane[l].tasks, (size_t)cap * sizeof(ExtTask) + 64)) ||
@@ -724,7 +726,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     }
     NECAT_HIP(ctx, hipStreamSynchronize(s));        // candidates + zeroed counters are in place before the batch streams start
     tick("buffers + upload");
-    Batch kb[2];
+    Batch kb[kMaxExtLanes];
     for (int l = 0; l < nlanes; ++l) {
         Batch& k = kb[l]; const ExtLane& E = lane[l];
         k.tasks = (ExtTask*)E.tasks->p;
@@ -754,11 +756,11 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
     X.error = opt->error; X.tail_match_len = tail_match_len; X.min_align = opt->align_size_cutoff;
     X.read_start_id = read_start_id; X.ref_start_id = ref_start_id; X.reads_off = reads->seq_off; X.ref_off = ref->seq_off;
     std::vector<u64> goff;
-    if (nlanes == 2) {
+    if (nlanes >= 2) {
         // ---- two lanes: batch i + 1 starts on the free lane once batch i is in its tail (BatchRun::tail); ONE host thread turns both round loops,
         // whichever has its next list sizes published (BatchRun::ready) - the host still never waits for the device inside a loop
         struct LaneRun { std::unique_ptr<BatchRun> run; int state = 0; int rc = NECAT_OK; u32 polls = 0; };      // state: 0 free, 1 in its rounds, 2 draining, 3 its result kernel in flight
-        LaneRun lr[2];
+        LaneRun lr[kMaxExtLanes];
         uint64_t next_base = 0, done = 0; size_t started = 0;
         int last = -1;                              // the lane of the batch started last
         auto start = [&](int l) -> int {
@@ -778,7 +780,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
         while (done < n_batches && !err) {
             bool progressed = false;
             if (next_base < n && (last < 0 || lr[last].state != 1 || lr[last].run->tail || g_ext_overlap_pct >= 100)) {
-                for (int l = 0; l < 2; ++l) if (lr[l].state == 0) {
+                for (int l = 0; l < nlanes; ++l) if (lr[l].state == 0) {
                     if ((err = start(l))) break;
                     progressed = true;
                     if (goff.empty() && dev) goff = dev->group_off;
@@ -792,7 +794,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
                 }
                 if (err) break;
             }
-            for (int l = 0; l < 2 && !err; ++l) {
+            for (int l = 0; l < nlanes && !err; ++l) {
                 LaneRun& R = lr[l];
                 if (R.state == 1 && R.run->ready()) { R.rc = R.run->step(); progressed = true; if (R.run->over) R.state = 2; }
                 // (a draining lane is looked at every 64th turn of the loop: three hipStreamQuery calls per turn would be the OTHER lane's launch latency)
@@ -818,7 +820,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
             if (progressed) { idle = 0; t_idle = wall_ms(); continue; }
             if ((++idle & 0xfffff) == 0) {
                 // a failed kernel never publishes: look at the streams instead of spinning forever
-                for (int l = 0; l < 2 && !err; ++l) if (lr[l].state == 1) {
+                for (int l = 0; l < nlanes && !err; ++l) if (lr[l].state == 1) {
                     const hipError_t q = hipStreamQuery(kb[l].sa);
                     if (q != hipSuccess && q != hipErrorNotReady) err = set_err(ctx, NECAT_ERR_DEVICE, "extension rounds (lane %d) failed: %s", l, hipGetErrorString(q));
                 }
@@ -826,7 +828,7 @@ int extend_impl(necat_ctx* ctx, const necat_volume* ref, const necat_volume* rea
             }
         }
         if (err) {
-            for (int l = 0; l < 2; ++l) { LaneRun& R = lr[l]; if (R.state == 3) (void)hipStreamSynchronize(kb[l].sa); else if (R.state) { (void)R.run->finish(err); R.run.reset(); } }       // nothing of a lane is in flight when its buffers are handed on
+            for (int l = 0; l < nlanes; ++l) { LaneRun& R = lr[l]; if (R.state == 3) (void)hipStreamSynchronize(kb[l].sa); else if (R.state) { (void)R.run->finish(err); R.run.reset(); } }       // nothing of a lane is in flight when its buffers are handed on
             cleanup(); return err;
         }
     } else

@@ -423,12 +423,13 @@ def test_map_pair_equals_find_then_extend(ctx, multi):
 
 
 @pytest.mark.parametrize("lanes", [dict(), dict(NECAT_EXT_OVERLAP="0"), dict(NECAT_EXT_OVERLAP_PCT="100"), dict(NECAT_EXT_OVERLAP_PCT="0"),
-                                   dict(NECAT_BATCH="100000", NECAT_EXT_OVERLAP_MIN="1000", NECAT_EXT_OVERLAP_SPLIT="30")],
-                         ids=["overlap", "one_lane", "overlap_at_once", "overlap_never_early", "one_batch_cut_in_two"])
+                                   dict(NECAT_BATCH="100000", NECAT_EXT_OVERLAP_MIN="1000", NECAT_EXT_OVERLAP_SPLIT="30"),
+                                   dict(NECAT_EXT_LANES="3"), dict(NECAT_EXT_LANES="4", NECAT_EXT_OVERLAP_PCT="0"), dict(NECAT_EXT_LANES="1")],
+                         ids=["overlap", "one_lane", "overlap_at_once", "overlap_never_early", "one_batch_cut_in_two", "three_lanes", "four_lanes_never_early", "lanes_1"])
 def test_extension_in_several_batches(ctx, small, lanes):
     """Candidates go through the extension in batches (NECAT_BATCH, default 786 432); tiny batches - many batch
     switches, lists far below the single-pass threshold - must give the same M4 records and the same alignments.
-    With two lanes (the default: batch i + 1's first rounds beside batch i's last, stage_extend.inl extend_impl) and with one;
+    With two lanes (the default: batch i + 1's first rounds beside batch i's last, stage_extend.inl extend_impl), with one, with three and four (NECAT_EXT_LANES);
     the next batch started as soon as a lane is free / only when the previous one has ended; one batch cut in two uneven halves."""
     from necat_amd import capi
     d, rs = small
